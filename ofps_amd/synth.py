@@ -1,0 +1,142 @@
+"""Seeded synthetic inputs for the flow hot path (SURVEY.md 8d "Synthetic inputs").
+
+Everything is a pure function of (seed, shape) built from a counter-based integer hash, so
+the CPU baseline, the parity tests and the GPU bench see identical bytes.
+
+* `luma_sequence`: F luma frames of one endless multi-octave value-noise texture; every
+  64x64 region of every frame samples the texture at its own integer offset, and the offset
+  moves by an integer step in [-max_step, max_step]^2 per frame, so each pair (k, k+1) holds
+  planted integer block displacements; +-1 uniform noise on top.
+* `rotation_field`: MotionEntry records ((x+.5)/W, (y+.5)/H, delta) as cv-decoder emits them
+  (cv-decoder/src/lib.rs:262-269) for a planted camera rotation plus Gaussian noise.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+SEED0 = 0x0F950001
+
+
+def _hash_u32(x: np.ndarray) -> np.ndarray:
+    """lowbias32-style avalanche on uint32 arrays."""
+    x = x.astype(np.uint32, copy=True)
+    x ^= x >> np.uint32(16)
+    x *= np.uint32(0x7FEB352D)
+    x ^= x >> np.uint32(15)
+    x *= np.uint32(0x846CA68B)
+    x ^= x >> np.uint32(16)
+    return x
+
+
+def _lattice(ix: np.ndarray, iy: np.ndarray, salt: int) -> np.ndarray:
+    """float32 in [0,1) per integer lattice point."""
+    with np.errstate(over="ignore"):
+        h = _hash_u32(ix.astype(np.uint32) * np.uint32(0x9E3779B1)
+                      ^ _hash_u32(iy.astype(np.uint32) * np.uint32(0x85EBCA77) + np.uint32(salt & 0xFFFFFFFF)))
+    return (h >> np.uint32(8)).astype(np.float32) * np.float32(1.0 / (1 << 24))
+
+
+def _value_noise(xs: np.ndarray, ys: np.ndarray, period: int, salt: int) -> np.ndarray:
+    """Bilinear value noise at integer sample coordinates xs, ys (int64 arrays, same shape)."""
+    ix = np.floor_divide(xs, period); iy = np.floor_divide(ys, period)
+    fx = ((xs - ix * period).astype(np.float32) + np.float32(0.5)) / np.float32(period)
+    fy = ((ys - iy * period).astype(np.float32) + np.float32(0.5)) / np.float32(period)
+    v00 = _lattice(ix, iy, salt); v10 = _lattice(ix + 1, iy, salt)
+    v01 = _lattice(ix, iy + 1, salt); v11 = _lattice(ix + 1, iy + 1, salt)
+    top = v00 + (v10 - v00) * fx
+    bot = v01 + (v11 - v01) * fx
+    return top + (bot - top) * fy
+
+
+def _texture(xs: np.ndarray, ys: np.ndarray, seed: int) -> np.ndarray:
+    """Octaves at 64/16/4 px, weights 4:2:1 -> float32 in [0,1)."""
+    n = (np.float32(4) * _value_noise(xs, ys, 64, seed) + np.float32(2) * _value_noise(xs, ys, 16, seed + 1)
+         + _value_noise(xs, ys, 4, seed + 2)) / np.float32(7)
+    return n
+
+
+def luma_sequence(n_frames: int, width: int, height: int, max_step: int, seed: int = SEED0,
+                  region: int = 64, noise: int = 1, stride: int | None = None) -> np.ndarray:
+    """-> uint8 [n_frames, height, stride] (stride >= width, padding zero)."""
+    stride = width if stride is None else stride
+    assert stride >= width
+    rx = (width + region - 1) // region; ry = (height + region - 1) // region
+    yy, xx = np.meshgrid(np.arange(height, dtype=np.int64), np.arange(width, dtype=np.int64), indexing="ij")
+    reg_id = (yy // region) * rx + (xx // region)
+    ridx = np.arange(rx * ry, dtype=np.uint32)
+    off = np.zeros((rx * ry, 2), np.int64)
+    out = np.zeros((n_frames, height, stride), np.uint8)
+    span = 2 * max_step + 1
+    for k in range(n_frames):
+        if k > 0:
+            with np.errstate(over="ignore"):
+                hx = _hash_u32(ridx * np.uint32(2654435761) + np.uint32((seed + 101 * k) & 0xFFFFFFFF))
+                hy = _hash_u32(hx + np.uint32(0x68E31DA4))
+            off[:, 0] += (hx % np.uint32(span)).astype(np.int64) - max_step
+            off[:, 1] += (hy % np.uint32(span)).astype(np.int64) - max_step
+        xs = xx + off[reg_id, 0] + 100000
+        ys = yy + off[reg_id, 1] + 100000
+        tex = _texture(xs, ys, seed)
+        img = np.float32(16.0) + tex * np.float32(219.0)
+        if noise:
+            with np.errstate(over="ignore"):
+                hn = _hash_u32((yy * width + xx).astype(np.uint32) * np.uint32(0xC2B2AE35)
+                               + np.uint32((seed + 7777 * (k + 1)) & 0xFFFFFFFF))
+            img = img + ((hn % np.uint32(2 * noise + 1)).astype(np.float32) - np.float32(noise))
+        out[k, :, :width] = np.clip(np.rint(img), 0, 255).astype(np.uint8)
+    return out
+
+
+def random_luma(n_frames: int, width: int, height: int, seed: int = SEED0) -> np.ndarray:
+    """Unstructured uint8 noise frames (worst case for SAD ties: many near-equal costs)."""
+    idx = np.arange(n_frames * height * width, dtype=np.uint32)
+    with np.errstate(over="ignore"):
+        h = _hash_u32(idx * np.uint32(0x9E3779B1) + np.uint32(seed & 0xFFFFFFFF))
+    return (h >> np.uint32(24)).astype(np.uint8).reshape(n_frames, height, width)
+
+
+def _gauss(n: int, seed: int) -> np.ndarray:
+    idx = np.arange(n, dtype=np.uint32)
+    with np.errstate(over="ignore"):
+        u1 = (_hash_u32(idx * np.uint32(0x9E3779B1) + np.uint32(seed & 0xFFFFFFFF)) >> np.uint32(8)).astype(np.float64)
+        u2 = (_hash_u32(idx * np.uint32(0x85EBCA77) + np.uint32((seed + 1) & 0xFFFFFFFF)) >> np.uint32(8)).astype(np.float64)
+    u1 = (u1 + 1.0) / float(1 << 24); u2 = u2 / float(1 << 24)
+    return (np.sqrt(-2.0 * np.log(u1)) * np.cos(2.0 * np.pi * u2)).astype(np.float32)
+
+
+def rotation_delta(pos: np.ndarray, aspect: float, fov_y_deg: float, rot3: np.ndarray) -> np.ndarray:
+    """Screen-space displacement of normalised points under a camera rotation
+    (the model of ofps/src/camera.rs:89-117 in float64 closed form; generator only)."""
+    pos = np.asarray(pos, np.float64).reshape(-1, 2)
+    t = np.tan(np.radians(fov_y_deg) / 2.0)
+    cx = pos[:, 0] * 2 - 1; cy = pos[:, 1] * 2 - 1
+    w = np.stack([-cx * t * aspect, -np.ones_like(cx), cy * t], 1)
+    r = w @ np.asarray(rot3, np.float64).T
+    sx = (-r[:, 0]) / (-r[:, 1]) / (t * aspect)
+    sy = r[:, 2] / (-r[:, 1]) / t
+    out = np.stack([(sx + 1) * 0.5, (sy + 1) * 0.5], 1) - pos
+    return out
+
+
+def euler_rot3(roll: float, pitch: float, yaw: float) -> np.ndarray:
+    sr, cr = np.sin(roll), np.cos(roll); sp, cp = np.sin(pitch), np.cos(pitch); sy, cy = np.sin(yaw), np.cos(yaw)
+    return np.array([[cy * cp, cy * sp * sr - sy * cr, cy * sp * cr + sy * sr],
+                     [sy * cp, sy * sp * sr + cy * cr, sy * sp * cr - cy * sr],
+                     [-sp, cp * sr, cp * cr]])
+
+
+def rotation_field(width: int, height: int, aspect: float = 16.0 / 9.0, fov_y_deg: float = 39.6 * 9.0 / 16.0,
+                   euler_deg=(0.5, 0.3, -0.2), sigma: float = 2e-4, seed: int = SEED0 + 3,
+                   outlier_frac: float = 0.0) -> np.ndarray:
+    """-> float32 [width*height, 4] MotionEntry records in raster order (cfg3 input)."""
+    yy, xx = np.meshgrid(np.arange(height), np.arange(width), indexing="ij")
+    pos = np.stack([(xx.ravel() + 0.5) / width, (yy.ravel() + 0.5) / height], 1)
+    r = euler_rot3(*np.radians(euler_deg))
+    d = rotation_delta(pos, aspect, fov_y_deg, r)
+    n = pos.shape[0]
+    d[:, 0] += sigma * _gauss(n, seed); d[:, 1] += sigma * _gauss(n, seed + 17)
+    if outlier_frac > 0:                      # a deterministic subset becomes gross outliers
+        k = int(n * outlier_frac)
+        idx = np.argsort(_gauss(n, seed + 99), kind="stable")[:k]
+        d[idx] = 0.02 * np.stack([_gauss(k, seed + 5), _gauss(k, seed + 6)], 1)
+    return np.concatenate([pos, d], 1).astype(np.float32)

@@ -1,0 +1,243 @@
+"""ctypes front-end for the CPU oracle (oracle/ofps_oracle.c).
+
+TEST INFRASTRUCTURE ONLY.  Importable from tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg; the product package `ofps_amd` never imports this module.  See
+ofps_oracle.h for the parity status of each restated function.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libofps_oracle.so")
+
+
+def build(force: bool = False) -> str:
+    """Compile the oracle with gcc (see oracle/Makefile)."""
+    src = os.path.join(_HERE, "ofps_oracle.c")
+    stale = (not os.path.exists(_LIB_PATH)
+             or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src)
+             or os.path.getmtime(_LIB_PATH) < os.path.getmtime(os.path.join(_HERE, "ofps_oracle.h")))
+    if force or stale:
+        subprocess.check_call(["make", "-s", "-C", _HERE, "-B", "libofps_oracle.so"])
+    return _LIB_PATH
+
+
+class Camera(C.Structure):
+    _fields_ = [(n, C.c_float) for n in
+                ("aspect", "fov_y", "m00", "m11", "m22", "m23", "r00", "r11", "r32", "r33")]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB_PATH)
+        fp = C.POINTER(C.c_float)
+        L.orc_camera_new.argtypes = [C.POINTER(Camera), C.c_float, C.c_float]
+        L.orc_camera_delta.argtypes = [C.POINTER(Camera), fp, fp, fp]
+        L.orc_camera_unproject.argtypes = [C.POINTER(Camera), fp, fp, fp]
+        L.orc_camera_project.argtypes = [C.POINTER(Camera), fp, fp, fp]
+        L.orc_camera_point_angle.argtypes = [C.POINTER(Camera), fp, fp]
+        L.orc_mat4_from_euler.argtypes = [C.c_float, C.c_float, C.c_float, fp]
+        L.orc_mat4_look_at_rh.argtypes = [fp, fp, fp, fp]
+        L.orc_quat_from_euler.argtypes = [C.c_float, C.c_float, C.c_float, fp]
+        L.orc_quat_mul.argtypes = [fp, fp, fp]
+        L.orc_quat_to_homogeneous.argtypes = [fp, fp]
+        L.orc_quat_transform_vector.argtypes = [fp, fp, fp]
+        L.orc_quat_angle_to.argtypes = [fp, fp]
+        L.orc_quat_angle_to.restype = C.c_float
+        L.orc_lu3_solve.argtypes = [fp, fp, fp]
+        L.orc_lu3_solve.restype = C.c_int
+        L.orc_densify.argtypes = [fp, C.c_size_t, C.c_int, C.c_int, fp, C.POINTER(C.c_uint32), fp]
+        L.orc_densify_to_entries.argtypes = [fp, C.c_size_t, C.c_int, C.c_int, fp]
+        L.orc_densify_to_entries.restype = C.c_size_t
+        L.orc_densify_interpolated.argtypes = [fp, C.c_size_t, C.c_int, C.c_int, fp]
+        L.orc_block_dim.argtypes = [C.c_float, C.c_size_t]
+        L.orc_block_dim.restype = C.c_int
+        L.orc_detect_motion.argtypes = [fp, C.c_size_t, C.c_float, C.c_size_t, C.c_float,
+                                        C.POINTER(C.c_size_t), C.POINTER(C.c_int), fp]
+        L.orc_detect_motion.restype = C.c_int
+        L.orc_solve_ypr_given.argtypes = [fp, C.c_size_t, C.POINTER(Camera), fp]
+        L.orc_solve_ypr_ransac.argtypes = [fp, C.c_size_t, C.POINTER(Camera), C.c_size_t, C.c_float,
+                                           C.c_size_t, C.c_uint64, fp, C.POINTER(C.c_uint32),
+                                           C.POINTER(C.c_size_t)]
+        L.orc_sample_index.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
+        L.orc_sample_index.restype = C.c_uint32
+        L.orc_sad_flow.argtypes = [C.POINTER(C.c_uint8), C.POINTER(C.c_uint8), C.c_int, C.c_int, C.c_int,
+                                   C.c_int, C.c_int, fp, C.POINTER(C.c_int32), C.c_int]
+        L.orc_sad_flow.restype = C.c_size_t
+        L.orc_num_threads.restype = C.c_int
+        _lib = L
+    return _lib
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def camera(aspect: float, fov_y_deg: float) -> Camera:
+    c = Camera()
+    lib().orc_camera_new(C.byref(c), aspect, fov_y_deg)
+    return c
+
+
+def camera_delta(cam: Camera, pos, rot4) -> np.ndarray:
+    p = _f32(pos); r = _f32(rot4).reshape(16); o = np.zeros(2, np.float32)
+    lib().orc_camera_delta(C.byref(cam), _fp(p), _fp(r), _fp(o))
+    return o
+
+
+def camera_unproject(cam: Camera, pos, inv_view4) -> np.ndarray:
+    p = _f32(pos); v = _f32(inv_view4).reshape(16); o = np.zeros(3, np.float32)
+    lib().orc_camera_unproject(C.byref(cam), _fp(p), _fp(v), _fp(o))
+    return o
+
+
+def camera_project(cam: Camera, world, view4) -> np.ndarray:
+    w = _f32(world); v = _f32(view4).reshape(16); o = np.zeros(2, np.float32)
+    lib().orc_camera_project(C.byref(cam), _fp(w), _fp(v), _fp(o))
+    return o
+
+
+def camera_point_angle(cam: Camera, pos) -> np.ndarray:
+    p = _f32(pos); o = np.zeros(2, np.float32)
+    lib().orc_camera_point_angle(C.byref(cam), _fp(p), _fp(o))
+    return o
+
+
+def mat4_from_euler(roll, pitch, yaw) -> np.ndarray:
+    o = np.zeros(16, np.float32)
+    lib().orc_mat4_from_euler(roll, pitch, yaw, _fp(o))
+    return o.reshape(4, 4)
+
+
+def look_at_rh(eye, target, up) -> np.ndarray:
+    o = np.zeros(16, np.float32)
+    e, t, u = _f32(eye), _f32(target), _f32(up)
+    lib().orc_mat4_look_at_rh(_fp(e), _fp(t), _fp(u), _fp(o))
+    return o.reshape(4, 4)
+
+
+def quat_from_euler(roll, pitch, yaw) -> np.ndarray:
+    o = np.zeros(4, np.float32)
+    lib().orc_quat_from_euler(roll, pitch, yaw, _fp(o))
+    return o
+
+
+def quat_to_homogeneous(q) -> np.ndarray:
+    q = _f32(q); o = np.zeros(16, np.float32)
+    lib().orc_quat_to_homogeneous(_fp(q), _fp(o))
+    return o.reshape(4, 4)
+
+
+def quat_transform_vector(q, v) -> np.ndarray:
+    q = _f32(q); v = _f32(v); o = np.zeros(3, np.float32)
+    lib().orc_quat_transform_vector(_fp(q), _fp(v), _fp(o))
+    return o
+
+
+def quat_angle_to(a, b) -> float:
+    a = _f32(a); b = _f32(b)
+    return float(lib().orc_quat_angle_to(_fp(a), _fp(b)))
+
+
+def lu3_solve(a3, b3):
+    a = _f32(a3).reshape(9); b = _f32(b3); x = np.zeros(3, np.float32)
+    ok = lib().orc_lu3_solve(_fp(a), _fp(b), _fp(x))
+    return (x if ok else None)
+
+
+def densify(entries, w: int, h: int, want_cells: bool = False, want_counts: bool = False):
+    e = _f32(entries).reshape(-1, 4); n = e.shape[0]
+    field = np.zeros((h, w, 2), np.float32)
+    cells = np.zeros((max(n, 1), 2), np.uint32) if want_cells else None
+    counts = np.zeros((h, w, 2), np.float32) if want_counts else None
+    lib().orc_densify(_fp(e), n, w, h, _fp(field),
+                      cells.ctypes.data_as(C.POINTER(C.c_uint32)) if want_cells else None,
+                      _fp(counts) if want_counts else None)
+    out = [field]
+    if want_cells:
+        out.append(cells[:n])
+    if want_counts:
+        out.append(counts)
+    return out[0] if len(out) == 1 else tuple(out)
+
+
+def densify_to_entries(entries, w: int, h: int) -> np.ndarray:
+    e = _f32(entries).reshape(-1, 4); n = e.shape[0]
+    out = np.zeros((w * h, 4), np.float32)
+    k = lib().orc_densify_to_entries(_fp(e), n, w, h, _fp(out))
+    return out[:k].copy()
+
+
+def densify_interpolated(entries, w: int, h: int) -> np.ndarray:
+    e = _f32(entries).reshape(-1, 4); n = e.shape[0]
+    field = np.zeros((h, w, 2), np.float32)
+    lib().orc_densify_interpolated(_fp(e), n, w, h, _fp(field))
+    return field
+
+
+def block_dim(min_size: float, subdivide: int) -> int:
+    return int(lib().orc_block_dim(min_size, subdivide))
+
+
+def detect_motion(entries, min_size=0.05, subdivide=3, target_motion=0.003):
+    """-> None or (area, field[dim,dim,2]) exactly like Detector::detect_motion."""
+    e = _f32(entries).reshape(-1, 4); n = e.shape[0]
+    dim = block_dim(min_size, subdivide)
+    field = np.zeros((dim, dim, 2), np.float32)
+    area = C.c_size_t(0); odim = C.c_int(0)
+    some = lib().orc_detect_motion(_fp(e), n, min_size, subdivide, target_motion,
+                                   C.byref(area), C.byref(odim), _fp(field))
+    assert odim.value == dim
+    return (int(area.value), field) if some else None
+
+
+def solve_ypr_given(entries, cam: Camera) -> np.ndarray:
+    e = _f32(entries).reshape(-1, 4); q = np.zeros(4, np.float32)
+    lib().orc_solve_ypr_given(_fp(e), e.shape[0], C.byref(cam), _fp(q))
+    return q
+
+
+def solve_ypr_ransac(entries, cam: Camera, num_iters=200, inlier_deg=0.05, num_samples=1000,
+                     seed=0, want_inliers=False):
+    e = _f32(entries).reshape(-1, 4); q = np.zeros(4, np.float32)
+    inl = np.zeros(max(num_samples, 1), np.uint32); n_inl = C.c_size_t(0)
+    lib().orc_solve_ypr_ransac(_fp(e), e.shape[0], C.byref(cam), num_iters, inlier_deg, num_samples,
+                               seed, _fp(q), inl.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(n_inl))
+    return (q, inl[:n_inl.value].copy()) if want_inliers else q
+
+
+def sample_index(seed, it, stream, i, n) -> int:
+    return int(lib().orc_sample_index(seed, it, stream, i, n))
+
+
+def sad_flow(prev, cur, B: int, R: int, threads: int = 1, stride=None):
+    """-> (entries[nblk,4] f32, best[nblk,3] int32 (dx,dy,sad))"""
+    prev = np.ascontiguousarray(prev, np.uint8); cur = np.ascontiguousarray(cur, np.uint8)
+    H, Wp = prev.shape
+    W = Wp if stride is None else stride[0]
+    st = Wp
+    nb = (W // B) * (H // B)
+    ent = np.zeros((max(nb, 1), 4), np.float32); best = np.zeros((max(nb, 1), 3), np.int32)
+    u8 = C.POINTER(C.c_uint8)
+    k = lib().orc_sad_flow(prev.ctypes.data_as(u8), cur.ctypes.data_as(u8), W, H, st, B, R,
+                           _fp(ent), best.ctypes.data_as(C.POINTER(C.c_int32)), threads)
+    assert k == nb
+    return ent[:nb], best[:nb]
+
+
+def num_threads() -> int:
+    return int(lib().orc_num_threads())

@@ -1,0 +1,208 @@
+"""Second, independent float32 NumPy restatement of the reference functions (TEST INFRASTRUCTURE).
+
+Purpose: guard against a self-consistent-but-wrong C oracle (SURVEY.md 8c golden-vector plan).
+It is written differently on purpose: vectorised, closed-form camera model instead of generic
+4x4 products, scipy labelling instead of a LIFO flood fill, np.add.at-free sequential sums
+via sorting.  tests/test_oracle.py cross-checks it against oracle/ofps_oracle.c.
+
+Reference lines restated: ofps/src/motion_field.rs:133-190,297-308; ofps/src/camera.rs:26-161;
+block-motion-detector/src/lib.rs:49-118; almeida-estimator/src/lib.rs:123-200.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+F = np.float32
+EPSILON = F(1.1920929e-07)
+
+
+# ---------------------------------------------------------------- densifier
+def cell_index(entries, w, h):
+    e = np.asarray(entries, F).reshape(-1, 4)
+    px, py = e[:, 0], e[:, 1]
+    with np.errstate(invalid="ignore"):
+        gt0 = (px > 0) & (py > 0)                 # nalgebra::clamp on Point2: all-components order
+        lt1 = (px < 1) & (py < 1)
+    cx = np.where(gt0, np.where(lt1, px, F(1)), F(0)).astype(F)
+    cy = np.where(gt0, np.where(lt1, py, F(1)), F(0)).astype(F)
+
+    def rnd(v):                                   # f32::round: half away from zero
+        return np.floor(v + F(0.5)).astype(np.int64)  # v >= 0 here, exact in f32 for these ranges
+    # guard the one case floor(v+0.5) differs from round-half-away in f32: v+0.5 rounding up
+    vx = (cx * F(w - 1)).astype(F); vy = (cy * F(h - 1)).astype(F)
+    x = np.where(vx - np.floor(vx) >= F(0.5), np.floor(vx) + 1, np.floor(vx)).astype(np.int64)
+    y = np.where(vy - np.floor(vy) >= F(0.5), np.floor(vy) + 1, np.floor(vy)).astype(np.int64)
+    return x, y
+
+
+def densify(entries, w, h):
+    """-> field[h,w,2] f32, cells[n,2]; sums in input order per cell (motion_field.rs:141-147)."""
+    e = np.asarray(entries, F).reshape(-1, 4)
+    x, y = cell_index(e, w, h)
+    idx = y * w + x
+    order = np.argsort(idx, kind="stable")
+    sums = np.zeros((w * h, 2), F)
+    cnts = np.full((w * h,), EPSILON, F)
+    sidx = idx[order]
+    bounds = np.flatnonzero(np.diff(sidx)) + 1
+    starts = np.concatenate([[0], bounds]); ends = np.concatenate([bounds, [len(sidx)]])
+    for s, t in zip(starts, ends):
+        if t <= s:
+            continue
+        c = sidx[s]
+        acc = np.zeros(2, F); cn = EPSILON
+        for k in order[s:t]:
+            acc = (e[k, 2:4] * F(1.0) + acc).astype(F)
+            cn = F(cn + F(1.0))
+        sums[c] = acc; cnts[c] = cn
+    field = (sums / cnts[:, None]).astype(F)
+    return field.reshape(h, w, 2), np.stack([x, y], 1)
+
+
+# ---------------------------------------------------------------- detector
+def block_dim(min_size, subdivide):
+    bw = F(np.sqrt(F(min_size))) / F(subdivide)
+    return int(np.ceil(F(1.0) / bw))
+
+
+def detect_motion(entries, min_size=0.05, subdivide=3, target_motion=0.003):
+    from scipy import ndimage
+    dim = block_dim(min_size, subdivide)
+    mf, _ = densify(entries, dim, dim)
+    mag = np.sqrt((mf[..., 0] * mf[..., 0] + mf[..., 1] * mf[..., 1]).astype(F)).astype(F)
+    mask = mag >= F(target_motion)
+    lab, n = ndimage.label(mask, structure=np.ones((3, 3), int))     # 8-connectivity
+    if n == 0:
+        return None
+    areas = ndimage.sum(mask, lab, index=np.arange(1, n + 1)).astype(int)
+    # first island in raster order of its first cell wins ties (strict > in lib.rs:106)
+    firsts = [np.flatnonzero(lab.ravel() == k)[0] for k in range(1, n + 1)]
+    best = max(range(n), key=lambda k: (areas[k], -firsts[k]))
+    area = int(areas[best])
+    if not (F(area) / F(dim * dim) >= F(min_size)):
+        return None
+    out = np.zeros_like(mf)
+    sel = lab == (best + 1)
+    out[sel] = mf[sel]
+    sy, sx = divmod(int(firsts[best]), dim)
+    out[sy, sx] = 0                      # the seed cell is never copied (lib.rs:79-102)
+    return area, out
+
+
+# ---------------------------------------------------------------- camera (closed form)
+class Camera:
+    def __init__(self, aspect, fov_y_deg):
+        self.aspect = F(aspect); self.fov_y = F(fov_y_deg)
+        fovy = F(self.fov_y * F(np.pi / 180.0))
+        self.m11 = F(1) / F(np.tan(F(fovy / F(2))))
+        self.m00 = F(self.m11 / self.aspect)
+        zn, zf = F(0.1), F(10.0)
+        self.m22 = F((zf + zn) / (zn - zf))
+        self.m23 = F(F(zf * zn) * F(2) / (zn - zf))
+        self.r00 = F(1) / self.m00; self.r11 = F(1) / self.m11
+        self.r32 = F(1) / self.m23; self.r33 = F(self.m22 * self.r32)
+
+    def delta(self, pos, R):
+        """pos[n,2], R 3x3 (f32) -> delta[n,2].  Closed form of camera.rs:89-117: world =
+        (-r00*cx, -1, r11*cy)/n0, rotate, view-permute, perspective, divide by NDC z."""
+        pos = np.asarray(pos, F).reshape(-1, 2); R = np.asarray(R, F)[:3, :3]
+        cx = (pos[:, 0] * F(2) - F(1)).astype(F); cy = (pos[:, 1] * F(2) - F(1)).astype(F)
+        n0 = F(self.r32 + self.r33)
+        wx = ((-self.r00) * cx / n0).astype(F)
+        wy = np.full_like(wx, F(-1) / n0)
+        wz = (self.r11 * cy / n0).astype(F)
+        rx = ((R[0, 0] * wx + R[0, 1] * wy).astype(F) + R[0, 2] * wz).astype(F)
+        ry = ((R[1, 0] * wx + R[1, 1] * wy).astype(F) + R[1, 2] * wz).astype(F)
+        rz = ((R[2, 0] * wx + R[2, 1] * wy).astype(F) + R[2, 2] * wz).astype(F)
+        px, py, pz = (-rx).astype(F), rz, ry           # view: (-x, z, y)
+        inv = (F(-1) / pz).astype(F)
+        sx = (self.m00 * px * inv).astype(F); sy = (self.m11 * py * inv).astype(F)
+        sz = ((self.m22 * pz + self.m23).astype(F) * inv).astype(F)
+        ox = (((sx / sz).astype(F) + F(1)) * F(0.5)).astype(F)
+        oy = (((sy / sz).astype(F) + F(1)) * F(0.5)).astype(F)
+        return np.stack([ox - pos[:, 0], oy - pos[:, 1]], 1).astype(F)
+
+
+def rot3_from_euler(roll, pitch, yaw):
+    sr, cr = F(np.sin(F(roll))), F(np.cos(F(roll)))
+    sp, cp = F(np.sin(F(pitch))), F(np.cos(F(pitch)))
+    sy, cy = F(np.sin(F(yaw))), F(np.cos(F(yaw)))
+    return np.array([[cy * cp, cy * sp * sr - sy * cr, cy * sp * cr + sy * sr],
+                     [sy * cp, sy * sp * sr + cy * cr, sy * sp * cr - cy * sr],
+                     [-sp, cp * sr, cp * cr]], F)
+
+
+def quat_from_euler(roll, pitch, yaw):
+    sr, cr = F(np.sin(F(roll) * F(0.5))), F(np.cos(F(roll) * F(0.5)))
+    sp, cp = F(np.sin(F(pitch) * F(0.5))), F(np.cos(F(pitch) * F(0.5)))
+    sy, cy = F(np.sin(F(yaw) * F(0.5))), F(np.cos(F(yaw) * F(0.5)))
+    return np.array([cr * cp * cy + sr * sp * sy, sr * cp * cy - cr * sp * sy,
+                     cr * sp * cy + sr * cp * sy, cr * cp * sy - sr * sp * cy], F)
+
+
+def quat_mul(a, b):
+    aw, ai, aj, ak = [F(v) for v in a]; bw, bi, bj, bk = [F(v) for v in b]
+    return np.array([aw * bw - ai * bi - aj * bj - ak * bk, aw * bi + ai * bw + aj * bk - ak * bj,
+                     aw * bj - ai * bk + aj * bw + ak * bi, aw * bk + ai * bj - aj * bi + ak * bw], F)
+
+
+def quat_to_rot3(q):
+    w, i, j, k = [F(v) for v in q]
+    ww, ii, jj, kk = w * w, i * i, j * j, k * k
+    ij, wk, wj = i * j * F(2), w * k * F(2), w * j * F(2)
+    ik, jk, wi = i * k * F(2), j * k * F(2), w * i * F(2)
+    return np.array([[ww + ii - jj - kk, ij - wk, wj + ik],
+                     [wk + ij, ww - ii + jj - kk, jk - wi],
+                     [ik - wj, wi + jk, ww - ii - jj + kk]], F)
+
+
+def solve_ypr_given(entries, cam: Camera):
+    """almeida-estimator/src/lib.rs:123-200, vectorised (pairwise-summed dots, float64-free)."""
+    e = np.asarray(entries, F).reshape(-1, 4)
+    EPS = F(F(0.001) * F(np.pi) / F(180.0)); ALPHA = F(0.5)
+    limit = int(np.ceil(15.0 / 0.5))
+    pos, mot = e[:, 0:2], e[:, 2:4]
+    protos = [cam.delta(pos, rot3_from_euler(0, EPS, 0)), cam.delta(pos, rot3_from_euler(EPS, 0, 0)),
+              cam.delta(pos, rot3_from_euler(0, 0, -EPS))]
+    rot = np.array([1, 0, 0, 0], F)
+    for it in range(limit):
+        alpha = F(1.0) if it == limit - 1 else ALPHA
+        res = (mot - cam.delta(pos, quat_to_rot3(rot))).astype(F)
+        A = np.zeros((3, 3), F); b = np.zeros(3, F)
+        for r in range(3):
+            for c in range(3):
+                A[r, c] = np.sum((protos[c] * protos[r]).sum(1, dtype=F), dtype=F)
+            b[r] = np.sum((protos[r] * res).sum(1, dtype=F), dtype=F)
+        try:
+            model = np.linalg.solve(A.astype(np.float64), b.astype(np.float64)).astype(F)
+        except np.linalg.LinAlgError:
+            model = np.zeros(3, F)
+        model = (model * EPS * alpha).astype(F)
+        roll = quat_from_euler(0, model[0], 0); pitch = quat_from_euler(model[1], 0, 0)
+        yaw = quat_from_euler(0, 0, -model[2])
+        rot = quat_mul(rot, quat_mul(quat_mul(pitch, roll), yaw))
+    return np.array([rot[0], -rot[1], -rot[2], -rot[3]], F)
+
+
+# ---------------------------------------------------------------- SAD (N1, build-defined)
+def sad_flow(prev, cur, B, R):
+    prev = np.asarray(prev, np.int32); cur = np.asarray(cur, np.int32)
+    H, W = prev.shape
+    nbx, nby = W // B, H // B
+    best = np.zeros((nby * nbx, 3), np.int32)
+    for by in range(nby):
+        for bx in range(nbx):
+            x0, y0 = bx * B, by * B
+            c = cur[y0:y0 + B, x0:x0 + B]
+            bk = None
+            for dy in range(-R, R + 1):
+                if y0 + dy < 0 or y0 + dy + B > H:
+                    continue
+                for dx in range(-R, R + 1):
+                    if x0 + dx < 0 or x0 + dx + B > W:
+                        continue
+                    sad = int(np.abs(c - prev[y0 + dy:y0 + dy + B, x0 + dx:x0 + dx + B]).sum())
+                    key = (sad, dx * dx + dy * dy, dy + R, dx + R)
+                    if bk is None or key < bk:
+                        bk = key; best[by * nbx + bx] = (dx, dy, sad)
+    return best

@@ -1,0 +1,732 @@
+/*
+ * ofps_oracle.c -- CPU restatement of the OFPS flow hot path.  TEST INFRASTRUCTURE ONLY:
+ * see ofps_oracle.h for who may call this and for the parity status of every function.
+ *
+ * Build: gcc -O2 -ffp-contract=off -fno-fast-math (see oracle/Makefile).  Contraction must
+ * stay off: the Rust reference never fuses a*b+c, and neither may this file.
+ *
+ * All arithmetic is f32 and follows the operation order of the Rust source / nalgebra 0.30
+ * (nalgebra is not vendored under /root/reference; its semantics are restated from
+ * SURVEY.md Appendix A and validated through the reference's own Almeida test).
+ */
+#include "ofps_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* f32::to_radians: self * (PI / 180) with the ratio folded in f32 (Rust core). */
+static float to_radians(float deg) {
+    const float k = 3.14159265358979323846264338327950288f / 180.0f;
+    return deg * k;
+}
+static float to_degrees(float rad) {
+    const float k = 57.2957795130823208767981548141051703f;
+    return rad * k;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* nalgebra helpers                                                                     */
+/* ------------------------------------------------------------------------------------ */
+
+/* Matrix4::transform_point: v = M[0:3,0:3]*p + t, n = M[3,0:3].p + M[3,3];
+ * v/n if n != 0.  The 3x3 product is nalgebra's gemv in axpy form: column 0 first, then
+ * res += col_j * p_j. */
+void orc_mat4_transform_point(const float m[16], const float p[3], float out[3]) {
+    float n = (m[12] * p[0] + m[13] * p[1]) + m[14] * p[2];
+    n = n + m[15];
+    float v[3];
+    for (int i = 0; i < 3; ++i) {
+        float acc = m[4 * i + 0] * p[0];
+        acc = m[4 * i + 1] * p[1] + acc;
+        acc = m[4 * i + 2] * p[2] + acc;
+        v[i] = acc + m[4 * i + 3];
+    }
+    if (n != 0.0f) {
+        out[0] = v[0] / n; out[1] = v[1] / n; out[2] = v[2] / n;
+    } else {
+        out[0] = v[0]; out[1] = v[1]; out[2] = v[2];
+    }
+}
+
+/* 4x4 product, axpy order over k (column of a times b[k][j]). */
+void orc_mat4_mul(const float a[16], const float b[16], float out[16]) {
+    float r[16];
+    for (int j = 0; j < 4; ++j)
+        for (int i = 0; i < 4; ++i) {
+            float acc = a[4 * i + 0] * b[0 * 4 + j];
+            for (int k = 1; k < 4; ++k) acc = a[4 * i + k] * b[4 * k + j] + acc;
+            r[4 * i + j] = acc;
+        }
+    memcpy(out, r, sizeof(r));
+}
+
+/* Rotation3::from_euler_angles(roll,pitch,yaw).to_homogeneous(). */
+void orc_mat4_from_euler(float roll, float pitch, float yaw, float out[16]) {
+    float sr = sinf(roll), cr = cosf(roll);
+    float sp = sinf(pitch), cp = cosf(pitch);
+    float sy = sinf(yaw), cy = cosf(yaw);
+    float m[16] = {
+        cy * cp, cy * sp * sr - sy * cr, cy * sp * cr + sy * sr, 0.0f,
+        sy * cp, sy * sp * sr + cy * cr, sy * sp * cr - cy * sr, 0.0f,
+        -sp,     cp * sr,                cp * cr,                0.0f,
+        0.0f,    0.0f,                   0.0f,                   1.0f};
+    memcpy(out, m, sizeof(m));
+}
+
+static void vec3_normalize(float v[3]) {
+    float n = sqrtf((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]);
+    v[0] /= n; v[1] /= n; v[2] /= n;
+}
+static void vec3_cross(const float a[3], const float b[3], float o[3]) {
+    o[0] = a[1] * b[2] - a[2] * b[1];
+    o[1] = a[2] * b[0] - a[0] * b[2];
+    o[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+/* Matrix4::look_at_rh (tests only). */
+void orc_mat4_look_at_rh(const float eye[3], const float target[3], const float up[3], float out[16]) {
+    float f[3] = {target[0] - eye[0], target[1] - eye[1], target[2] - eye[2]};
+    vec3_normalize(f);
+    float s[3]; vec3_cross(f, up, s); vec3_normalize(s);
+    float u[3]; vec3_cross(s, f, u);
+    float r[9] = {s[0], s[1], s[2], u[0], u[1], u[2], -f[0], -f[1], -f[2]};
+    float m[16] = {0};
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) m[4 * i + j] = r[3 * i + j];
+        m[4 * i + 3] = -((r[3 * i] * eye[0] + r[3 * i + 1] * eye[1]) + r[3 * i + 2] * eye[2]);
+    }
+    m[15] = 1.0f;
+    memcpy(out, m, sizeof(m));
+}
+
+/* UnitQuaternion::from_euler_angles, half-angle form.  q = (w,i,j,k). */
+void orc_quat_from_euler(float roll, float pitch, float yaw, float q[4]) {
+    float sr = sinf(roll * 0.5f), cr = cosf(roll * 0.5f);
+    float sp = sinf(pitch * 0.5f), cp = cosf(pitch * 0.5f);
+    float sy = sinf(yaw * 0.5f), cy = cosf(yaw * 0.5f);
+    q[0] = cr * cp * cy + sr * sp * sy;
+    q[1] = sr * cp * cy - cr * sp * sy;
+    q[2] = cr * sp * cy + sr * cp * sy;
+    q[3] = cr * cp * sy - sr * sp * cy;
+}
+
+/* Hamilton product a*b, nalgebra's expression order. */
+void orc_quat_mul(const float a[4], const float b[4], float out[4]) {
+    float aw = a[0], ai = a[1], aj = a[2], ak = a[3];
+    float bw = b[0], bi = b[1], bj = b[2], bk = b[3];
+    float w = aw * bw - ai * bi - aj * bj - ak * bk;
+    float i = aw * bi + ai * bw + aj * bk - ak * bj;
+    float j = aw * bj - ai * bk + aj * bw + ak * bi;
+    float k = aw * bk + ai * bj - aj * bi + ak * bw;
+    out[0] = w; out[1] = i; out[2] = j; out[3] = k;
+}
+
+void orc_quat_to_homogeneous(const float q[4], float out[16]) {
+    float w = q[0], i = q[1], j = q[2], k = q[3];
+    float ww = w * w, ii = i * i, jj = j * j, kk = k * k;
+    float ij = i * j * 2.0f, wk = w * k * 2.0f, wj = w * j * 2.0f;
+    float ik = i * k * 2.0f, jk = j * k * 2.0f, wi = w * i * 2.0f;
+    float m[16] = {
+        ww + ii - jj - kk, ij - wk,           wj + ik,           0.0f,
+        wk + ij,           ww - ii + jj - kk, jk - wi,           0.0f,
+        ik - wj,           wi + jk,           ww - ii - jj + kk, 0.0f,
+        0.0f,              0.0f,              0.0f,              1.0f};
+    memcpy(out, m, sizeof(m));
+}
+
+void orc_quat_inverse(const float q[4], float out[4]) {
+    out[0] = q[0]; out[1] = -q[1]; out[2] = -q[2]; out[3] = -q[3];
+}
+
+/* UnitQuaternion * Vector3 (tests only): v + 2*cross(q.v, cross(q.v, v) + w*v). */
+void orc_quat_transform_vector(const float q[4], const float v[3], float out[3]) {
+    float u[3] = {q[1], q[2], q[3]};
+    float t[3]; vec3_cross(u, v, t);
+    t[0] *= 2.0f; t[1] *= 2.0f; t[2] *= 2.0f;
+    float c[3]; vec3_cross(u, t, c);
+    out[0] = (t[0] * q[0] + c[0]) + v[0];
+    out[1] = (t[1] * q[0] + c[1]) + v[1];
+    out[2] = (t[2] * q[0] + c[2]) + v[2];
+}
+
+/* angle_to(a,b) = angle of b * a^-1 (tests only). */
+float orc_quat_angle_to(const float a[4], const float b[4]) {
+    float ai[4], d[4];
+    orc_quat_inverse(a, ai);
+    orc_quat_mul(b, ai, d);
+    float w = fabsf(d[0]);
+    float n = sqrtf((d[1] * d[1] + d[2] * d[2]) + d[3] * d[3]);
+    return atan2f(n, w) * 2.0f;
+}
+
+/* Matrix3::lu().solve(b): partial pivoting, multipliers scaled by the
+ * reciprocal of the pivot, axpy updates; None when a U diagonal is exactly zero. */
+int orc_lu3_solve(const float a_in[9], const float b_in[3], float x[3]) {
+    float m[9]; memcpy(m, a_in, sizeof(m));
+    int perm_a[3], perm_b[3], nperm = 0;
+    for (int i = 0; i < 3; ++i) {
+        int piv = i; float best = fabsf(m[3 * i + i]);
+        for (int r = i + 1; r < 3; ++r) {
+            float v = fabsf(m[3 * r + i]);
+            if (v > best) { best = v; piv = r; }
+        }
+        float diag = m[3 * piv + i];
+        if (diag == 0.0f) continue;
+        if (piv != i) {
+            perm_a[nperm] = i; perm_b[nperm] = piv; ++nperm;
+            for (int c = 0; c < 3; ++c) { float t = m[3 * i + c]; m[3 * i + c] = m[3 * piv + c]; m[3 * piv + c] = t; }
+        }
+        float inv_diag = 1.0f / diag;
+        for (int r = i + 1; r < 3; ++r) m[3 * r + i] *= inv_diag;
+        for (int c = i + 1; c < 3; ++c) {
+            float neg = -m[3 * i + c];
+            for (int r = i + 1; r < 3; ++r) m[3 * r + c] = neg * m[3 * r + i] + m[3 * r + c];
+        }
+    }
+    float b[3] = {b_in[0], b_in[1], b_in[2]};
+    for (int p = 0; p < nperm; ++p) { float t = b[perm_a[p]]; b[perm_a[p]] = b[perm_b[p]]; b[perm_b[p]] = t; }
+    /* unit lower-triangular forward substitution */
+    for (int i = 0; i < 2; ++i) {
+        float coeff = b[i] / 1.0f;
+        for (int r = i + 1; r < 3; ++r) b[r] = (-coeff) * m[3 * r + i] + b[r];
+    }
+    /* upper-triangular back substitution */
+    for (int i = 2; i >= 0; --i) {
+        float diag = m[3 * i + i];
+        if (diag == 0.0f) return 0;
+        float coeff = b[i] / diag;
+        b[i] = coeff;
+        for (int r = 0; r < i; ++r) b[r] = (-coeff) * m[3 * r + i] + b[r];
+    }
+    x[0] = b[0]; x[1] = b[1]; x[2] = b[2];
+    return 1;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* StandardCamera                                                                       */
+/* ------------------------------------------------------------------------------------ */
+
+/* camera.rs:26-35: Perspective3::new(aspect, fov_y.to_radians(), 0.1, 10.0) + inverse()
+ * (set_fovy then set_aspect: m00 = m11 / aspect). */
+void orc_camera_new(orc_camera* c, float aspect, float fov_y_deg) {
+    const float zn = 0.1f, zf = 10.0f;
+    float fovy = to_radians(fov_y_deg);
+    c->aspect = aspect;
+    c->fov_y = fov_y_deg;
+    c->m11 = 1.0f / tanf(fovy / 2.0f);
+    c->m00 = c->m11 / aspect;
+    c->m22 = (zf + zn) / (zn - zf);
+    c->m23 = zf * zn * 2.0f / (zn - zf);
+    c->r00 = 1.0f / c->m00;
+    c->r11 = 1.0f / c->m11;
+    c->r32 = 1.0f / c->m23;
+    c->r33 = c->m22 * c->r32;
+}
+
+static void camera_inv_proj(const orc_camera* c, float m[16]) {
+    memset(m, 0, 16 * sizeof(float));
+    m[0] = c->r00; m[5] = c->r11; m[11] = -1.0f; m[14] = c->r32; m[15] = c->r33;
+}
+
+/* camera.rs:45-55 */
+void orc_camera_unproject(const orc_camera* c, const float p[2], const float inv_view[16], float out[3]) {
+    float cx = p[0] * 2.0f - 1.0f, cy = p[1] * 2.0f - 1.0f;
+    float ip[16], m[16];
+    camera_inv_proj(c, ip);
+    orc_mat4_mul(inv_view, ip, m);
+    float pt[3] = {cx, cy, 1.0f};
+    orc_mat4_transform_point(m, pt, out);
+}
+
+/* camera.rs:72-81: project_point then divide x,y by the NDC z (sic, :77). */
+void orc_camera_project(const orc_camera* c, const float world[3], const float view[16], float out[2]) {
+    float p[3];
+    orc_mat4_transform_point(view, world, p);
+    float inverse_denom = -1.0f / p[2];
+    float sx = c->m00 * p[0] * inverse_denom;
+    float sy = c->m11 * p[1] * inverse_denom;
+    float sz = (c->m22 * p[2] + c->m23) * inverse_denom;
+    float x = sx / sz, y = sy / sz;
+    out[0] = (x + 1.0f) * 0.5f;
+    out[1] = (y + 1.0f) * 0.5f;
+}
+
+static const float ORC_VIEW[16] = {   /* camera.rs:91-96, Z up / Y forward; view == view^T */
+    -1.0f, 0.0f, 0.0f, 0.0f,
+     0.0f, 0.0f, 1.0f, 0.0f,
+     0.0f, 1.0f, 0.0f, 0.0f,
+     0.0f, 0.0f, 0.0f, 1.0f};
+
+/* camera.rs:89-112 */
+void orc_camera_rotate(const orc_camera* c, const float p[2], const float rot[16], float out[2]) {
+    float world[3], rw[3];
+    orc_camera_unproject(c, p, ORC_VIEW /* transpose of a symmetric matrix */, world);
+    orc_mat4_transform_point(rot, world, rw);
+    orc_camera_project(c, rw, ORC_VIEW, out);
+}
+
+/* camera.rs:115-117 */
+void orc_camera_delta(const orc_camera* c, const float p[2], const float rot[16], float out[2]) {
+    float r[2];
+    orc_camera_rotate(c, p, rot, r);
+    out[0] = r[0] - p[0];
+    out[1] = r[1] - p[1];
+}
+
+/* camera.rs:120-129, 150-161 */
+void orc_camera_point_angle(const orc_camera* c, const float p[2], float out[2]) {
+    float fy = 0.5f / tanf(to_radians(c->fov_y) / 2.0f);
+    float fx = fy / c->aspect;
+    float px = p[0] - 0.5f, py = p[1] - 0.5f;
+    out[0] = atanf(px / fx);
+    out[1] = atanf(py / fy);
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* MotionFieldDensifier                                                                 */
+/* ------------------------------------------------------------------------------------ */
+
+#define ORC_F32_EPSILON 1.1920929e-07f
+
+/* `as usize` on an f32: saturating, NaN -> 0. */
+static size_t f32_as_usize(float v) {
+    if (!(v > 0.0f)) return 0;            /* negatives, -0, NaN */
+    if (v >= 18446744073709551616.0f) return (size_t)-1;
+    return (size_t)v;
+}
+
+/* motion_field.rs:164-178: nalgebra::clamp on a Point2 (all-components ordering),
+ * then round-half-away-from-zero of pos*(dim-1). */
+static void densifier_cell(float px, float py, int w, int h, size_t* ox, size_t* oy) {
+    float cx, cy;
+    if (px > 0.0f && py > 0.0f) {
+        if (px < 1.0f && py < 1.0f) { cx = px; cy = py; }
+        else { cx = 1.0f; cy = 1.0f; }
+    } else { cx = 0.0f; cy = 0.0f; }
+    *ox = f32_as_usize(roundf(cx * (float)(w - 1)));
+    *oy = f32_as_usize(roundf(cy * (float)(h - 1)));
+}
+
+typedef struct { float* sum; float* cnt; int w, h; } densifier;
+
+static void densifier_init(densifier* d, int w, int h) {            /* motion_field.rs:133-138 */
+    size_t cells = (size_t)w * (size_t)h;
+    d->w = w; d->h = h;
+    d->sum = (float*)calloc(2 * cells + 2, sizeof(float));
+    d->cnt = (float*)malloc((2 * cells + 2) * sizeof(float));
+    for (size_t i = 0; i < 2 * cells; ++i) d->cnt[i] = ORC_F32_EPSILON;
+}
+static void densifier_free(densifier* d) { free(d->sum); free(d->cnt); }
+
+static void densifier_add_idx(densifier* d, size_t idx, float mx, float my, float weight) { /* :141-147 */
+    d->cnt[2 * idx + 0] += weight;
+    d->cnt[2 * idx + 1] += weight;
+    d->sum[2 * idx + 0] = mx * weight + d->sum[2 * idx + 0];
+    d->sum[2 * idx + 1] = my * weight + d->sum[2 * idx + 1];
+}
+
+static void densifier_add_all(densifier* d, const float* entries, size_t n, uint32_t* out_cells) {
+    for (size_t i = 0; i < n; ++i) {
+        const float* e = entries + 4 * i;
+        size_t x, y;
+        densifier_cell(e[0], e[1], d->w, d->h, &x, &y);
+        densifier_add_idx(d, y * (size_t)d->w + x, e[2], e[3], 1.0f);       /* :150-153, :188-190 */
+        if (out_cells) { out_cells[2 * i] = (uint32_t)x; out_cells[2 * i + 1] = (uint32_t)y; }
+    }
+}
+
+void orc_densify(const float* entries, size_t n, int w, int h,
+                 float* out_field, uint32_t* out_cells, float* out_counts) {
+    densifier d; densifier_init(&d, w, h);
+    densifier_add_all(&d, entries, n, out_cells);
+    size_t cells = (size_t)w * (size_t)h;
+    if (out_counts) memcpy(out_counts, d.cnt, 2 * cells * sizeof(float));
+    for (size_t i = 0; i < 2 * cells; ++i) out_field[i] = d.sum[i] / d.cnt[i];   /* :297-308 */
+    densifier_free(&d);
+}
+
+size_t orc_densify_to_entries(const float* entries, size_t n, int w, int h, float* out_entries) {
+    size_t cells = (size_t)w * (size_t)h;
+    float* field = (float*)malloc((2 * cells + 2) * sizeof(float));
+    uint32_t* xy = (uint32_t*)malloc((2 * n + 2) * sizeof(uint32_t));
+    unsigned char* visited = (unsigned char*)calloc(cells + 1, 1);
+    orc_densify(entries, n, w, h, field, xy, NULL);
+    for (size_t i = 0; i < n; ++i) visited[(size_t)xy[2 * i + 1] * w + xy[2 * i]] = 1;
+    float nx = 1.0f / (float)w, ny = 1.0f / (float)h;                /* cv-decoder/src/lib.rs:281 */
+    size_t k = 0;
+    for (int x = 0; x < w; ++x)                                       /* BTreeSet<(x,y)> order */
+        for (int y = 0; y < h; ++y) {
+            size_t idx = (size_t)y * w + x;
+            if (!visited[idx]) continue;
+            out_entries[4 * k + 0] = ((float)x + 0.5f) * nx;          /* :286-288 */
+            out_entries[4 * k + 1] = ((float)y + 0.5f) * ny;
+            out_entries[4 * k + 2] = field[2 * idx];
+            out_entries[4 * k + 3] = field[2 * idx + 1];
+            ++k;
+        }
+    free(field); free(xy); free(visited);
+    return k;
+}
+
+/* motion_field.rs:193-294.  The BTreeSet<InterpCell{neighbors, idx}> is restated as two
+ * arrays (membership + key) with a linear scan for the minimum: same total order. */
+static const int ORC_INTERP_NB[6][2] = {{-1, 0}, {0, -1}, {-1, -1}, {1, 0}, {0, 1}, {1, 1}};
+
+static long interp_calc_counts(const densifier* d, size_t i) {        /* :209-228 */
+    long cnt = 0;
+    long x = (long)(i % (size_t)d->w), y = (long)(i / (size_t)d->w);
+    for (int k = 0; k < 6; ++k) {
+        long nx = x + ORC_INTERP_NB[k][0], ny = y + ORC_INTERP_NB[k][1];
+        if (nx >= 0 && nx < d->w && ny >= 0 && ny < d->h &&
+            d->cnt[2 * ((size_t)nx + (size_t)ny * d->w)] > 0.1f) ++cnt;
+    }
+    return cnt;
+}
+
+static int densifier_interpolate(densifier* d) {
+    size_t cells = (size_t)d->w * (size_t)d->h;
+    unsigned char* inq = (unsigned char*)calloc(cells + 1, 1);
+    long* key = (long*)calloc(cells + 1, sizeof(long));
+    size_t qlen = 0;
+    for (size_t i = 0; i < cells; ++i)
+        if (d->cnt[2 * i] < 0.5f) { inq[i] = 1; key[i] = -interp_calc_counts(d, i); ++qlen; }   /* :230-241 */
+    int ok = 1;
+    if (qlen == cells) goto done;                                     /* :243-246 */
+    for (;;) {
+        /* queue.iter().next(): smallest (neighbors, idx) */
+        size_t best = cells; long bk = 0;
+        for (size_t i = 0; i < cells; ++i)
+            if (inq[i] && (best == cells || key[i] < bk)) { best = i; bk = key[i]; }
+        if (best == cells) break;
+        size_t i = best;
+        inq[i] = 0;
+        long x = (long)(i % (size_t)d->w), y = (long)(i / (size_t)d->w);
+        int added = 0;
+        for (int k = 0; k < 6; ++k) {                                 /* :255-268 */
+            long ox = ORC_INTERP_NB[k][0], oy = ORC_INTERP_NB[k][1];
+            long nx = x + ox, ny = y + oy;
+            if (nx >= 0 && nx < d->w && ny >= 0 && ny < d->h) {
+                size_t idx = (size_t)nx + (size_t)ny * d->w;
+                float cnt = d->cnt[2 * idx];
+                if (cnt > 0.1f) {
+                    float scale = 1.0f - sqrtf((float)(ox * ox + oy * oy)) * 0.5f;
+                    float inv_cnt = 1.0f / cnt;
+                    float s = scale * inv_cnt;
+                    densifier_add_idx(d, i, s * d->sum[2 * idx], s * d->sum[2 * idx + 1], scale);
+                    added = 1;
+                }
+            }
+        }
+        if (!added) {
+            inq[i] = 1;                                               /* :270-271 (would spin) */
+            ok = 0; break;
+        }
+        for (int k = 0; k < 6; ++k) {                                 /* :273-289 */
+            long nx = x + ORC_INTERP_NB[k][0], ny = y + ORC_INTERP_NB[k][1];
+            if (nx >= 0 && nx < d->w && ny >= 0 && ny < d->h) {
+                size_t idx = (size_t)nx + (size_t)ny * d->w;
+                long cnt = -interp_calc_counts(d, idx) + 1;
+                if (inq[idx] && key[idx] == cnt) key[idx] = cnt - 1;
+                else if (cnt != 0 && d->cnt[2 * idx] < 0.1f) { ok = 0; goto done; }  /* unreachable!() */
+            }
+        }
+    }
+done:
+    free(inq); free(key);
+    return ok;
+}
+
+void orc_densify_interpolated(const float* entries, size_t n, int w, int h, float* out_field) {
+    densifier d; densifier_init(&d, w, h);
+    densifier_add_all(&d, entries, n, NULL);
+    densifier_interpolate(&d);
+    size_t cells = (size_t)w * (size_t)h;
+    for (size_t i = 0; i < 2 * cells; ++i) out_field[i] = d.sum[i] / d.cnt[i];
+    densifier_free(&d);
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* BlockMotionDetection                                                                 */
+/* ------------------------------------------------------------------------------------ */
+
+int orc_block_dim(float min_size, size_t subdivide) {                 /* lib.rs:53-54 */
+    float block_width = sqrtf(min_size) / (float)subdivide;
+    return (int)f32_as_usize(ceilf(1.0f / block_width));
+}
+
+int orc_detect_motion(const float* entries, size_t n, float min_size, size_t subdivide,
+                      float target_motion, size_t* out_area, int* out_dim, float* out_field) {
+    int dim = orc_block_dim(min_size, subdivide);
+    size_t cells = (size_t)dim * (size_t)dim;
+    float* mf = (float*)malloc((2 * cells + 2) * sizeof(float));
+    orc_densify(entries, n, dim, dim, mf, NULL, NULL);                /* lib.rs:57-61 */
+
+    unsigned char* map = (unsigned char*)calloc(cells + 1, 1);
+    for (size_t i = 0; i < cells; ++i) {                              /* lib.rs:63-68 */
+        float mx = mf[2 * i], my = mf[2 * i + 1];
+        float mag = sqrtf(mx * mx + my * my);
+        if (mag >= target_motion) map[i] = 1;
+    }
+
+    size_t biggest_area = 0;
+    float* biggest_mf = NULL;
+    float* mf2 = (float*)malloc((2 * cells + 2) * sizeof(float));
+    size_t* stack = (size_t*)malloc((cells + 1) * sizeof(size_t));
+    for (int y = 0; y < dim; ++y)
+        for (int x = 0; x < dim; ++x) {
+            if (!map[(size_t)y * dim + x]) continue;                  /* lib.rs:74-76 */
+            size_t area = 0;
+            memset(mf2, 0, 2 * cells * sizeof(float));
+            map[(size_t)y * dim + x] = 0;
+            size_t sp = 0;
+            stack[sp++] = (size_t)y * dim + x;
+            while (sp) {                                              /* lib.rs:83-104 */
+                size_t cur = stack[--sp];
+                long cx = (long)(cur % (size_t)dim), cy = (long)(cur / (size_t)dim);
+                ++area;
+                for (long ox = -1; ox <= 1; ++ox)                     /* x-offset outer, y inner */
+                    for (long oy = -1; oy <= 1; ++oy) {
+                        long nx = cx + ox, ny = cy + oy;
+                        if (nx < 0 || nx >= dim || ny < 0 || ny >= dim) continue;
+                        size_t ni = (size_t)ny * dim + (size_t)nx;
+                        if (map[ni]) {
+                            mf2[2 * ni] = mf[2 * ni]; mf2[2 * ni + 1] = mf[2 * ni + 1];
+                            stack[sp++] = ni;
+                            map[ni] = 0;
+                        }
+                    }
+            }
+            if (area > biggest_area) {                                /* lib.rs:106-109 */
+                biggest_area = area;
+                if (!biggest_mf) biggest_mf = (float*)malloc((2 * cells + 2) * sizeof(float));
+                memcpy(biggest_mf, mf2, 2 * cells * sizeof(float));
+            }
+        }
+
+    int some = 0;
+    if ((float)biggest_area / (float)(cells) >= min_size && biggest_mf) {   /* lib.rs:114-118 */
+        some = 1;
+        memcpy(out_field, biggest_mf, 2 * cells * sizeof(float));
+    } else {
+        memset(out_field, 0, 2 * cells * sizeof(float));
+    }
+    if (out_area) *out_area = some ? biggest_area : 0;
+    if (out_dim) *out_dim = dim;
+    free(mf); free(map); free(mf2); free(stack); free(biggest_mf);
+    return some;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* Almeida estimator                                                                    */
+/* ------------------------------------------------------------------------------------ */
+
+/* almeida-estimator/src/lib.rs:17-18 */
+static float almeida_eps(void) { return 0.001f * 3.14159265358979323846264338327950288f / 180.0f; }
+#define ORC_ALPHA 0.5f
+
+void orc_solve_ypr_given(const float* entries, size_t n, const orc_camera* cam, float q_out[4]) {
+    const float EPS = almeida_eps();
+    size_t limit = (size_t)ceilf(15.0f / ORC_ALPHA);                  /* :132 */
+    float rotation[4] = {1.0f, 0.0f, 0.0f, 0.0f};
+    float m_roll[16], m_pitch[16], m_yaw[16];
+    orc_mat4_from_euler(0.0f, EPS, 0.0f, m_roll);                     /* :30-34 */
+    orc_mat4_from_euler(EPS, 0.0f, 0.0f, m_pitch);                    /* :36-38 */
+    orc_mat4_from_euler(0.0f, 0.0f, -EPS, m_yaw);                     /* :40-42 */
+
+    float* v = (float*)malloc((8 * n + 8) * sizeof(float));           /* [motion-delta, roll, pitch, yaw] */
+    for (size_t it = 0; it < limit; ++it) {
+        float alpha = (it == limit - 1) ? 1.0f : ORC_ALPHA;           /* :138 */
+        float rotm[16];
+        orc_quat_to_homogeneous(rotation, rotm);                      /* :140 */
+        for (size_t i = 0; i < n; ++i) {                              /* :142-157 */
+            const float* e = entries + 4 * i;
+            float d[2];
+            orc_camera_delta(cam, e, rotm, d);
+            float* vi = v + 8 * i;
+            vi[0] = e[2] - d[0]; vi[1] = e[3] - d[1];
+            orc_camera_delta(cam, e, m_roll, vi + 2);
+            orc_camera_delta(cam, e, m_pitch, vi + 4);
+            orc_camera_delta(cam, e, m_yaw, vi + 6);
+        }
+        /* :159-179: each dot summed over the Vec in input order, starting from 0 */
+        float a[9], b[3];
+        for (int c = 0; c < 3; ++c)
+            for (int r = 0; r < 3; ++r) {
+                float acc = 0.0f;
+                for (size_t i = 0; i < n; ++i) {
+                    const float* p = v + 8 * i + 2 * (c + 1);
+                    const float* s = v + 8 * i + 2 * (r + 1);
+                    acc += p[0] * s[0] + p[1] * s[1];
+                }
+                a[3 * r + c] = acc;       /* from_iterator is column-major: element k -> (k%3, k/3) */
+            }
+        for (int r = 0; r < 3; ++r) {
+            float acc = 0.0f;
+            for (size_t i = 0; i < n; ++i) {
+                const float* p = v + 8 * i + 2 * (r + 1);
+                const float* s = v + 8 * i;
+                acc += p[0] * s[0] + p[1] * s[1];
+            }
+            b[r] = acc;
+        }
+        float model[3];
+        if (!orc_lu3_solve(a, b, model)) { model[0] = model[1] = model[2] = 0.0f; }   /* :181-183 */
+        model[0] = model[0] * EPS * alpha;                            /* :185 */
+        model[1] = model[1] * EPS * alpha;
+        model[2] = model[2] * EPS * alpha;
+        float roll[4], pitch[4], yaw[4], pr[4], rot[4], nr[4];
+        orc_quat_from_euler(0.0f, model[0], 0.0f, roll);              /* :189-191 */
+        orc_quat_from_euler(model[1], 0.0f, 0.0f, pitch);
+        orc_quat_from_euler(0.0f, 0.0f, -model[2], yaw);
+        orc_quat_mul(pitch, roll, pr);                                /* :193 */
+        orc_quat_mul(pr, yaw, rot);
+        orc_quat_mul(rotation, rot, nr);                              /* :195 */
+        memcpy(rotation, nr, sizeof(nr));
+    }
+    free(v);
+    orc_quat_inverse(rotation, q_out);                                /* :199 */
+}
+
+/* --- counter-based sampler standing in for rand::thread_rng + choose_multiple.
+ * A keyed 4-round Feistel permutation of [0, 2^b) with cycle walking down to [0, n):
+ * distinct indices, any index computable independently (needed by the GPU). --- */
+static uint64_t mix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+uint32_t orc_sample_index(uint64_t seed, uint32_t iter, uint32_t stream, uint32_t i, uint32_t n) {
+    if (n <= 1) return 0;
+    uint32_t bits = 2;
+    while (bits < 32 && (1ull << bits) < (uint64_t)n) bits += 2;      /* even number of bits */
+    uint32_t half = bits / 2, mask = (1u << half) - 1u;
+    uint64_t k = mix64(seed ^ mix64(((uint64_t)iter << 1) | (uint64_t)(stream & 1u)));
+    uint32_t key[4];
+    for (int r = 0; r < 4; ++r) key[r] = (uint32_t)mix64(k + (uint64_t)r);
+    uint32_t x = i;
+    do {
+        uint32_t l = x >> half, r = x & mask;
+        for (int round = 0; round < 4; ++round) {
+            uint32_t f = r * 0x9E3779B1u + key[round];
+            f ^= f >> 15; f *= 0x85EBCA77u; f ^= f >> 13;
+            uint32_t nl = r, nr = l ^ (f & mask);
+            l = nl; r = nr;
+        }
+        x = (l << half) | r;
+    } while (x >= n);
+    return x;
+}
+
+void orc_solve_ypr_ransac(const float* entries, size_t n, const orc_camera* cam,
+                          size_t num_iters, float inlier_deg, size_t num_samples, uint64_t seed,
+                          float q_out[4], uint32_t* out_inliers, size_t* out_n_inliers) {
+    float target_delta = to_radians(inlier_deg);                      /* :210 */
+    size_t ns = num_samples < n ? num_samples : n;
+    size_t n3 = n < 3 ? n : 3;
+    uint32_t* best = (uint32_t*)malloc((ns + 1) * sizeof(uint32_t));
+    uint32_t* cur = (uint32_t*)malloc((ns + 1) * sizeof(uint32_t));
+    size_t best_len = 0;
+    float thr2 = target_delta * target_delta;
+    for (size_t it = 0; it < num_iters; ++it) {                       /* :214 */
+        float samples[12];
+        for (size_t j = 0; j < n3; ++j) {                             /* :215 */
+            uint32_t idx = orc_sample_index(seed, (uint32_t)it, 0, (uint32_t)j, (uint32_t)n);
+            memcpy(samples + 4 * j, entries + 4 * (size_t)idx, 4 * sizeof(float));
+        }
+        float fit[4], inv[4], mat[16];
+        orc_solve_ypr_given(samples, n3, cam, fit);                   /* :217 */
+        orc_quat_inverse(fit, inv);
+        orc_quat_to_homogeneous(inv, mat);                            /* :224 */
+        size_t len = 0;
+        for (size_t j = 0; j < ns; ++j) {                             /* :219-241 */
+            uint32_t idx = orc_sample_index(seed, (uint32_t)it, 1, (uint32_t)j, (uint32_t)n);
+            const float* e = entries + 4 * (size_t)idx;
+            float d[2], sample[2], vec[2], ang[2];
+            orc_camera_delta(cam, e, mat, d);
+            sample[0] = e[0] + d[0]; sample[1] = e[1] + d[1];
+            vec[0] = e[2] - d[0]; vec[1] = e[3] - d[1];
+            orc_camera_point_angle(cam, sample, ang);
+            float vx = vec[0] * cosf(ang[0]), vy = vec[1] * cosf(ang[1]);
+            if (vx * vx + vy * vy <= thr2) cur[len++] = idx;
+        }
+        if (len > best_len) {                                         /* :243-245 */
+            best_len = len;
+            memcpy(best, cur, len * sizeof(uint32_t));
+        }
+    }
+    if (best_len >= 3) {                                              /* :247-251 */
+        float* sel = (float*)malloc((4 * best_len + 4) * sizeof(float));
+        for (size_t j = 0; j < best_len; ++j) memcpy(sel + 4 * j, entries + 4 * (size_t)best[j], 4 * sizeof(float));
+        orc_solve_ypr_given(sel, best_len, cam, q_out);
+        free(sel);
+    } else {
+        q_out[0] = 1.0f; q_out[1] = q_out[2] = q_out[3] = 0.0f;
+    }
+    if (out_n_inliers) *out_n_inliers = best_len;
+    if (out_inliers) memcpy(out_inliers, best, best_len * sizeof(uint32_t));
+    free(best); free(cur);
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* N1: full-search SAD block matcher (build-defined; no reference counterpart)           */
+/* ------------------------------------------------------------------------------------ */
+
+static void sad_block_row(const uint8_t* prev, const uint8_t* cur, int W, int H, int stride,
+                          int B, int R, int by, int nbx, float* out_entries, int32_t* out_best) {
+    const float nx = 1.0f / (float)W, ny = 1.0f / (float)H;          /* av-decoder/src/lib.rs:404-405 */
+    for (int bx = 0; bx < nbx; ++bx) {
+        int x0 = bx * B, y0 = by * B;
+        uint64_t best_key = ~0ull; int best_dx = 0, best_dy = 0; uint32_t best_sad = 0;
+        for (int dy = -R; dy <= R; ++dy) {
+            if (y0 + dy < 0 || y0 + dy + B > H) continue;
+            for (int dx = -R; dx <= R; ++dx) {
+                if (x0 + dx < 0 || x0 + dx + B > W) continue;
+                uint32_t sad = 0;
+                for (int y = 0; y < B; ++y) {
+                    const uint8_t* c = cur + (size_t)(y0 + y) * stride + x0;
+                    const uint8_t* p = prev + (size_t)(y0 + dy + y) * stride + x0 + dx;
+                    for (int x = 0; x < B; ++x) sad += (uint32_t)abs((int)c[x] - (int)p[x]);
+                }
+                uint64_t key = ((uint64_t)sad << 32) | ((uint64_t)(uint32_t)(dx * dx + dy * dy) << 16) |
+                               ((uint64_t)(uint32_t)(dy + R) << 8) | (uint64_t)(uint32_t)(dx + R);
+                if (key < best_key) { best_key = key; best_dx = dx; best_dy = dy; best_sad = sad; }
+            }
+        }
+        size_t k = (size_t)by * nbx + bx;
+        float cx = (float)(x0 + B / 2 + best_dx), cy = (float)(y0 + B / 2 + best_dy);
+        out_entries[4 * k + 0] = cx * nx;                             /* :409-411: src * frame_norm */
+        out_entries[4 * k + 1] = cy * ny;
+        out_entries[4 * k + 2] = ((float)best_dx / 1.0f) * (-nx);     /* :412-417 */
+        out_entries[4 * k + 3] = ((float)best_dy / 1.0f) * (-ny);
+        if (out_best) { out_best[3 * k] = best_dx; out_best[3 * k + 1] = best_dy; out_best[3 * k + 2] = (int32_t)best_sad; }
+    }
+}
+
+size_t orc_sad_flow(const uint8_t* prev, const uint8_t* cur, int W, int H, int stride,
+                    int B, int R, float* out_entries, int32_t* out_best, int threads) {
+    int nbx = W / B, nby = H / B;
+    if (R > 127) return 0;          /* key packing above holds dy+R, dx+R in 8 bits */
+    (void)threads;
+#ifdef _OPENMP
+    if (threads > 1) {
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads)
+        for (int by = 0; by < nby; ++by) sad_block_row(prev, cur, W, H, stride, B, R, by, nbx, out_entries, out_best);
+        return (size_t)nbx * (size_t)nby;
+    }
+#endif
+    for (int by = 0; by < nby; ++by) sad_block_row(prev, cur, W, H, stride, B, R, by, nbx, out_entries, out_best);
+    return (size_t)nbx * (size_t)nby;
+}
+
+int orc_num_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}

@@ -1,0 +1,116 @@
+/*
+ * ofps_oracle.h -- CPU restatement of the OFPS flow hot path (TEST INFRASTRUCTURE ONLY).
+ *
+ * This is the parity oracle for the MI355X backend.  It restates, in plain C with f32
+ * arithmetic in the same operation order, the reference functions listed below.  Only
+ * tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may link or call it;
+ * the product path (libofps_hip.so) never does.
+ *
+ * PARITY STATUS
+ *   - Almeida estimator + StandardCamera: pinned by the reference's own known-answer test
+ *     (almeida-estimator/src/lib.rs:253-373, 32 rotations, error < 10% of the rotation)
+ *     and the point_angle doctest (ofps/src/camera.rs:139-149); see tests/test_oracle.py.
+ *   - MotionFieldDensifier, BlockMotionDetection: the reference holds no test or fixture
+ *     for them -> "parity unpinned" by the reference; pinned here only by a second,
+ *     independent NumPy restatement (oracle/np_oracle.py) and committed golden vectors.
+ *   - SAD full-search block matcher: NO reference counterpart;
+ *     the spec is defined in DESIGN.md ("N1") -> "parity unpinned".
+ *   The Rust reference cannot be built here (no rustc/cargo), so no oracle/_ref exists.
+ *
+ * Matrices are row-major float[16] / float[9].  Quaternions are (w, i, j, k).
+ * A MotionEntry is 4 consecutive floats [pos.x, pos.y, motion.x, motion.y]
+ * (ofps/src/decoder.rs:40-42).
+ */
+#ifndef OFPS_ORACLE_H
+#define OFPS_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- StandardCamera (ofps/src/camera.rs:12-35) ---- */
+typedef struct {
+    float aspect;   /* camera.rs:13 */
+    float fov_y;    /* degrees, camera.rs:14 */
+    float m00, m11, m22, m23;      /* Perspective3 non-trivial entries (m32 = -1) */
+    float r00, r11, r32, r33;      /* Perspective3::inverse non-trivial entries (r23 = -1) */
+} orc_camera;
+
+void orc_camera_new(orc_camera* c, float aspect, float fov_y_deg);          /* camera.rs:26-35 */
+void orc_camera_unproject(const orc_camera* c, const float p[2], const float inv_view[16],
+                          float out[3]);                                   /* camera.rs:45-55 */
+void orc_camera_project(const orc_camera* c, const float world[3], const float view[16],
+                        float out[2]);                                     /* camera.rs:72-81 */
+void orc_camera_rotate(const orc_camera* c, const float p[2], const float rot[16],
+                       float out[2]);                                      /* camera.rs:89-112 */
+void orc_camera_delta(const orc_camera* c, const float p[2], const float rot[16],
+                      float out[2]);                                       /* camera.rs:115-117 */
+void orc_camera_point_angle(const orc_camera* c, const float p[2], float out[2]); /* :150-161 */
+
+/* ---- nalgebra helpers used on the path ---- */
+void orc_mat4_from_euler(float roll, float pitch, float yaw, float out[16]);
+void orc_mat4_mul(const float a[16], const float b[16], float out[16]);
+void orc_mat4_transform_point(const float m[16], const float p[3], float out[3]);
+void orc_mat4_look_at_rh(const float eye[3], const float target[3], const float up[3], float out[16]);
+void orc_quat_from_euler(float roll, float pitch, float yaw, float q[4]);
+void orc_quat_mul(const float a[4], const float b[4], float out[4]);
+void orc_quat_to_homogeneous(const float q[4], float out[16]);
+void orc_quat_inverse(const float q[4], float out[4]);
+void orc_quat_transform_vector(const float q[4], const float v[3], float out[3]);
+float orc_quat_angle_to(const float a[4], const float b[4]);
+int  orc_lu3_solve(const float a[9], const float b[3], float x[3]);  /* 1 = solved, 0 = singular */
+
+/* ---- MotionFieldDensifier / MotionField (ofps/src/motion_field.rs) ---- */
+/* add_vector for every entry then MotionField::from (motion_field.rs:133-190, 297-308).
+ * out_field: 2*w*h floats, cell (x,y) at [2*(y*w+x)], as MotionField::as_slice (:42-49).
+ * out_cells (optional): 2*n uint32 (x,y) = the return value of add_vector per entry.
+ * out_counts (optional): 2*w*h floats, the densifier's counts matrix before the divide. */
+void orc_densify(const float* entries, size_t n, int w, int h,
+                 float* out_field, uint32_t* out_cells, float* out_counts);
+
+/* cv-decoder's downsample-through-densifier output stage (cv-decoder/src/lib.rs:244-291):
+ * densify to (w,h), then emit one entry per visited cell in BTreeSet<(x,y)> order
+ * (x-major), pos = ((x+.5)/w, (y+.5)/h), motion = cell average.  Returns entry count. */
+size_t orc_densify_to_entries(const float* entries, size_t n, int w, int h, float* out_entries);
+
+/* MotionFieldDensifier::interpolate_empty_cells (motion_field.rs:193-294) followed by
+ * MotionField::from; same output layout as orc_densify. */
+void orc_densify_interpolated(const float* entries, size_t n, int w, int h, float* out_field);
+
+/* ---- BlockMotionDetection::detect_motion (block-motion-detector/src/lib.rs:49-118) ---- */
+int orc_block_dim(float min_size, size_t subdivide);                        /* lib.rs:53-54 */
+/* out_field must hold 2*dim*dim floats (dim <= 160*... use orc_block_dim).  Returns 1 for
+ * Some((area, field)), 0 for None.  out_field is zero-filled when None. */
+int orc_detect_motion(const float* entries, size_t n, float min_size, size_t subdivide,
+                      float target_motion, size_t* out_area, int* out_dim, float* out_field);
+
+/* ---- Almeida estimator (almeida-estimator/src/lib.rs) ---- */
+void orc_solve_ypr_given(const float* entries, size_t n, const orc_camera* cam, float q[4]); /* :123-200 */
+/* :202-251 with the build's counter-based sampler in place of rand::thread_rng (the
+ * reference is unseeded).  out_inliers (optional) receives the indices of the
+ * best inlier set (capacity num_samples), *out_n_inliers its size. */
+void orc_solve_ypr_ransac(const float* entries, size_t n, const orc_camera* cam,
+                          size_t num_iters, float inlier_deg, size_t num_samples, uint64_t seed,
+                          float q[4], uint32_t* out_inliers, size_t* out_n_inliers);
+/* The sampler itself (shared definition with the HIP kernels, DESIGN.md "RANSAC sampler"):
+ * i-th of the distinct indices drawn for (seed, iter, stream) out of [0,n). */
+uint32_t orc_sample_index(uint64_t seed, uint32_t iter, uint32_t stream, uint32_t i, uint32_t n);
+
+/* ---- N1: full-search SAD block matcher (build-defined spec) ---- */
+/* prev/cur: H rows of `stride` bytes, W valid.  Blocks: B x B lattice from (0,0), full blocks
+ * only.  Candidates (dx,dy) in [-R,R]^2 whose block lies inside the frame.  Winner = min of
+ * (SAD, dx*dx+dy*dy, dy+R, dx+R) lexicographic.  out_entries: 4 floats per block, raster
+ * order; out_best (optional): 3 int32 per block (dx, dy, sad).  Returns number of blocks.
+ * threads <= 1 -> scalar single thread; otherwise OpenMP over block rows. */
+size_t orc_sad_flow(const uint8_t* prev, const uint8_t* cur, int W, int H, int stride,
+                    int B, int R, float* out_entries, int32_t* out_best, int threads);
+
+int orc_num_threads(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
