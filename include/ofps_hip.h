@@ -1,0 +1,130 @@
+/*
+ * ofps_hip.h -- C ABI of libofps_hip.so, the MI355X (gfx950) backend for the OFPS flow hot path.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++/torch types.  A Rust cdylib
+ * shim implements the reference's plugin traits on top of these calls:
+ *
+ *   ofps_hip_sad_flow*      -> Decoder::process_frame          (ofps/src/decoder.rs:45-73); output
+ *                              record convention of av-decoder   (av-decoder/src/lib.rs:404-419)
+ *   ofps_hip_densify*       -> MotionFieldDensifier::add_vector + MotionField::from
+ *                                                               (ofps/src/motion_field.rs:133-190,297-308)
+ *   ofps_hip_densify_to_entries -> cv-decoder's downsample stage (cv-decoder/src/lib.rs:244-291)
+ *   ofps_hip_detect*        -> Detector::detect_motion          (ofps/src/detection.rs:11,
+ *                                                               block-motion-detector/src/lib.rs:49-118)
+ *   ofps_hip_almeida*       -> Estimator::estimate              (ofps/src/estimator.rs:19-24,
+ *                                                               almeida-estimator/src/lib.rs:100-251)
+ *
+ * A MotionEntry is 4 consecutive f32 [pos.x, pos.y, motion.x, motion.y] (decoder.rs:40-42), the
+ * same record the reference's .mvec files hold (motion-extract/src/main.rs:23-35).
+ *
+ * Conventions
+ *   - every call returns 0 on success or a negative OFPS_HIP_E* code; ofps_hip_last_error(ctx)
+ *     returns a human-readable message for the last failure on that context.
+ *   - one context per plugin instance; calls on one context must be serialised by the caller
+ *     (plugins are Send, not Sync: ofps/src/plugins/mod.rs:244,261,278); different contexts may
+ *     be used concurrently from different host threads.
+ *   - the library never frees or retains caller memory; all outputs are caller-allocated.
+ *   - "*_dev" entry points take device pointers (hipMalloc'd on the context's device), enqueue
+ *     on the context's stream and return without synchronising; host-pointer entry points
+ *     copy in/out and synchronise before returning.
+ *   - there is no CPU fallback: without a usable gfx950 device ofps_hip_init fails.
+ */
+#ifndef OFPS_HIP_H
+#define OFPS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OFPS_HIP_API_VERSION 1
+
+enum {
+    OFPS_HIP_OK = 0,
+    OFPS_HIP_EINVAL = -1,      /* bad argument (message says which) */
+    OFPS_HIP_EDEVICE = -2,     /* HIP runtime error / no device */
+    OFPS_HIP_EUNSUPPORTED = -3, /* parameter combination has no kernel */
+    OFPS_HIP_ENOMEM = -4
+};
+
+typedef struct ofps_hip_ctx ofps_hip_ctx;
+
+/* ---- context ---- */
+int  ofps_hip_api_version(void);
+int  ofps_hip_device_count(void);
+int  ofps_hip_init(int device, ofps_hip_ctx** out);
+void ofps_hip_destroy(ofps_hip_ctx* ctx);
+const char* ofps_hip_last_error(const ofps_hip_ctx* ctx);   /* ctx may be NULL: last init error */
+/* Run on a caller-owned hipStream_t (e.g. torch's current stream).  NULL is a valid handle: HIP's
+ * default stream.  ofps_hip_use_own_stream() goes back to the stream the context created. */
+int   ofps_hip_set_stream(ofps_hip_ctx* ctx, void* hip_stream);
+int   ofps_hip_use_own_stream(ofps_hip_ctx* ctx);
+void* ofps_hip_get_stream(ofps_hip_ctx* ctx);
+int   ofps_hip_sync(ofps_hip_ctx* ctx);
+
+/* ---- device memory plumbing for hosts without their own HIP binding ---- */
+int ofps_hip_malloc(ofps_hip_ctx* ctx, size_t bytes, void** dptr);
+int ofps_hip_free(ofps_hip_ctx* ctx, void* dptr);
+int ofps_hip_memcpy_h2d(ofps_hip_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
+int ofps_hip_memcpy_d2h(ofps_hip_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
+
+/* ---- timing helper: HIP events on the context's stream (bench.py roofline leg) ---- */
+int ofps_hip_timer_start(ofps_hip_ctx* ctx);
+int ofps_hip_timer_stop(ofps_hip_ctx* ctx, float* elapsed_ms);   /* synchronises on the stop event */
+
+/* ---- N1: full-search SAD block matcher ("hip_sad" Decoder) ----
+ * Blocks on a block x block lattice from (0,0), full blocks only; candidates (dx,dy) in
+ * [-range,range]^2 whose block lies inside the frame; winner = min of
+ * (SAD, dx*dx+dy*dy, dy+range, dx+range); entry = (pos = (centre+d)/(W,H), motion = -d/(W,H)).
+ * Supported: block in {8,16} with range in {4..64, multiple of 4} run on the packed-SAD kernel;
+ * any other block<=64, range<=64 runs on the generic kernel.  stride % 4 == 0. */
+size_t ofps_hip_sad_block_count(int W, int H, int block);
+int ofps_hip_sad_flow(ofps_hip_ctx* ctx, const uint8_t* prev, const uint8_t* cur,
+                      int W, int H, int stride, int block, int range,
+                      float* out_entries /* 4*nblk */, int32_t* out_best /* 3*nblk (dx,dy,sad) or NULL */,
+                      size_t* n_out);
+/* Batched, device-resident: n_frames luma frames at d_frames + k*frame_pitch (bytes).
+ * ref_mode 0: pairs (k, k+1); ref_mode 1: pairs (0, k+1) (shared key frame).  n_frames-1 pairs.
+ * d_out_entries: [(n_frames-1) * nblk * 4] f32; d_out_best: [(n_frames-1) * nblk * 3] i32 or NULL. */
+int ofps_hip_sad_flow_dev(ofps_hip_ctx* ctx, const void* d_frames, int n_frames,
+                          int W, int H, int stride, size_t frame_pitch, int ref_mode,
+                          int block, int range, void* d_out_entries, void* d_out_best);
+
+/* ---- A1-A4: MotionFieldDensifier ---- */
+int ofps_hip_densify(ofps_hip_ctx* ctx, const float* entries, size_t n, int w, int h,
+                     float* out_field /* 2*w*h, cell (x,y) at 2*(y*w+x) */,
+                     uint32_t* out_cells /* 2*n (x,y) per entry, or NULL */);
+/* batch items of n_per_item entries each (contiguous); outputs per item. */
+int ofps_hip_densify_dev(ofps_hip_ctx* ctx, const void* d_entries, size_t n_per_item, int batch,
+                         int w, int h, void* d_out_field, void* d_out_cells /* or NULL */);
+int ofps_hip_densify_to_entries(ofps_hip_ctx* ctx, const float* entries, size_t n, int w, int h,
+                                float* out_entries /* capacity 4*w*h */, size_t* n_out);
+
+/* ---- A5: BlockMotionDetection::detect_motion ("hip_block_motion" Detector) ---- */
+int ofps_hip_block_dim(float min_size, size_t subdivide);
+int ofps_hip_detect(ofps_hip_ctx* ctx, const float* entries, size_t n,
+                    float min_size, size_t subdivide, float target_motion,
+                    int* has_motion, size_t* area, int* dim, float* out_field /* 2*dim*dim */);
+/* per item result record: int32[4] = {has_motion, area, dim, 0}; field 2*dim*dim f32 per item. */
+int ofps_hip_detect_dev(ofps_hip_ctx* ctx, const void* d_entries, size_t n_per_item, int batch,
+                        float min_size, size_t subdivide, float target_motion,
+                        void* d_out_result, void* d_out_field);
+
+/* ---- A6-A12: Almeida estimator ("hip_almeida" Estimator) ----
+ * out_quat = (w,i,j,k) of the returned UnitQuaternion; out_tr = translation (always 0,
+ * almeida-estimator/src/lib.rs:120).  seed drives the counter-based RANSAC sampler. */
+int ofps_hip_almeida(ofps_hip_ctx* ctx, const float* entries, size_t n,
+                     float aspect, float fov_y_deg, int use_ransac, size_t num_iters,
+                     float inlier_deg, size_t num_samples, uint64_t seed,
+                     float out_quat[4], float out_tr[3]);
+int ofps_hip_almeida_dev(ofps_hip_ctx* ctx, const void* d_entries, size_t n_per_item, int batch,
+                         float aspect, float fov_y_deg, int use_ransac, size_t num_iters,
+                         float inlier_deg, size_t num_samples, uint64_t seed,
+                         void* d_out_quat /* 4 f32 per item */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,89 @@
+"""ctypes binding of libofps_hip.so (include/ofps_hip.h).  No fallback: a missing library or a
+missing GPU raises -- the product path is the HIP path or nothing."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libofps_hip.so")
+
+_u8p = C.POINTER(C.c_uint8)
+_f32p = C.POINTER(C.c_float)
+_i32p = C.POINTER(C.c_int32)
+_u32p = C.POINTER(C.c_uint32)
+_szp = C.POINTER(C.c_size_t)
+_ctx = C.c_void_p
+_vp = C.c_void_p
+
+# name -> (restype, argtypes): one row per declaration in include/ofps_hip.h
+PROTOTYPES = {
+    "ofps_hip_api_version": (C.c_int, []),
+    "ofps_hip_device_count": (C.c_int, []),
+    "ofps_hip_init": (C.c_int, [C.c_int, C.POINTER(_ctx)]),
+    "ofps_hip_destroy": (None, [_ctx]),
+    "ofps_hip_last_error": (C.c_char_p, [_ctx]),
+    "ofps_hip_set_stream": (C.c_int, [_ctx, _vp]),
+    "ofps_hip_use_own_stream": (C.c_int, [_ctx]),
+    "ofps_hip_get_stream": (_vp, [_ctx]),
+    "ofps_hip_sync": (C.c_int, [_ctx]),
+    "ofps_hip_malloc": (C.c_int, [_ctx, C.c_size_t, C.POINTER(_vp)]),
+    "ofps_hip_free": (C.c_int, [_ctx, _vp]),
+    "ofps_hip_memcpy_h2d": (C.c_int, [_ctx, _vp, _vp, C.c_size_t]),
+    "ofps_hip_memcpy_d2h": (C.c_int, [_ctx, _vp, _vp, C.c_size_t]),
+    "ofps_hip_timer_start": (C.c_int, [_ctx]),
+    "ofps_hip_timer_stop": (C.c_int, [_ctx, _f32p]),
+    "ofps_hip_sad_block_count": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "ofps_hip_sad_flow": (C.c_int, [_ctx, _u8p, _u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                    _f32p, _i32p, _szp]),
+    "ofps_hip_sad_flow_dev": (C.c_int, [_ctx, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_int,
+                                        C.c_int, C.c_int, _vp, _vp]),
+    "ofps_hip_densify": (C.c_int, [_ctx, _f32p, C.c_size_t, C.c_int, C.c_int, _f32p, _u32p]),
+    "ofps_hip_densify_dev": (C.c_int, [_ctx, _vp, C.c_size_t, C.c_int, C.c_int, C.c_int, _vp, _vp]),
+    "ofps_hip_densify_to_entries": (C.c_int, [_ctx, _f32p, C.c_size_t, C.c_int, C.c_int, _f32p, _szp]),
+    "ofps_hip_block_dim": (C.c_int, [C.c_float, C.c_size_t]),
+    "ofps_hip_detect": (C.c_int, [_ctx, _f32p, C.c_size_t, C.c_float, C.c_size_t, C.c_float,
+                                  C.POINTER(C.c_int), _szp, C.POINTER(C.c_int), _f32p]),
+    "ofps_hip_detect_dev": (C.c_int, [_ctx, _vp, C.c_size_t, C.c_int, C.c_float, C.c_size_t, C.c_float, _vp, _vp]),
+    "ofps_hip_almeida": (C.c_int, [_ctx, _f32p, C.c_size_t, C.c_float, C.c_float, C.c_int, C.c_size_t,
+                                   C.c_float, C.c_size_t, C.c_uint64, _f32p, _f32p]),
+    "ofps_hip_almeida_dev": (C.c_int, [_ctx, _vp, C.c_size_t, C.c_int, C.c_float, C.c_float, C.c_int, C.c_size_t,
+                                       C.c_float, C.c_size_t, C.c_uint64, _vp]),
+}
+
+_lib = None
+
+
+class OfpsHipError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"libofps_hip error {code}: {message}")
+        self.code = code
+
+
+def load():
+    """dlopen libofps_hip.so.  torch (when importable) is imported first so that both share one
+    libamdhip64.so.7 (torch bundles its own copy; the SONAMEs match, the first one loaded wins)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: run `python -m ofps_amd.build` "
+                          "(or __graft_entry__.build()); there is no CPU fallback")
+    try:
+        import torch  # noqa: F401  (plumbing only: shares the HIP runtime, streams, distributed)
+    except Exception:
+        pass
+    lib = C.CDLL(LIB_PATH)
+    missing = []
+    for name, (res, args) in PROTOTYPES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            missing.append(name)
+            continue
+        fn.restype = res
+        fn.argtypes = args
+    if missing:
+        raise ImportError(f"{LIB_PATH} does not export: {', '.join(missing)}")
+    _lib = lib
+    return lib

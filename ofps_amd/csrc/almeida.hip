@@ -1,0 +1,642 @@
+// almeida.hip -- A6-A12: StandardCamera::delta + the Almeida rotation estimator on gfx950
+// (ofps/src/camera.rs:26-161; almeida-estimator/src/lib.rs:100-251; trait ofps/src/estimator.rs:19-24).
+//
+// delta(): closed form of unproject -> rotate -> project.  With the fixed view matrix of
+// camera.rs:91-96 every dropped term of the generic 4x4 products is an exact 0 or +-1 factor,
+// so the closed form returns the same bits as the generic path (checked against the oracle).
+// No FMA contraction (-ffp-contract=off), IEEE divides.
+//
+// Least squares (lib.rs:123-200), 30 damped Gauss-Newton steps on N entries:
+//   * the three EPS prototypes (roll/pitch/yaw deltas, lib.rs:30-42) do not depend on the
+//     iteration; they are computed once per entry and kept in registers (small problems);
+//   * per step each thread forms its 9 products (6 unique A entries -- A is symmetric bit for bit
+//     -- and 3 b entries), a fixed-shape wave butterfly + LDS tree reduces them, thread 0 runs the
+//     partial-pivot LU (nalgebra order) and the quaternion update, and the rotation is broadcast
+//     through LDS.  The sum ORDER differs from the reference's sequential f32 sum, so results
+//     agree to rounding (<= 1e-6 on the quaternion), not bit for bit;
+//   * N <= 8192: one workgroup per problem does all 30 steps in one launch (almeida_lsq_wg_kernel);
+//     larger N: one launch per step over a grid of workgroups whose partial sums are combined
+//     in a fixed order by every workgroup at the start of the next step (almeida_lsq_step_kernel).
+// MFMA is deliberately not used: the only contraction is J^T J with J in R^{2N x 3}.
+//
+// RANSAC (lib.rs:202-251): one thread per hypothesis solves its 3-sample problem sequentially (same
+// op order as the oracle), one workgroup per hypothesis counts inliers over the drawn samples,
+// the best hypothesis' inliers are compacted in sample order and re-solved.  The reference's
+// rand::thread_rng is replaced by the counter-based sampler defined in oracle/ofps_oracle.c
+// (orc_sample_index): keyed 4-round Feistel permutation with cycle walking.
+#include "common.hpp"
+
+#include <cmath>
+
+namespace ofps {
+
+struct Camera {            // same fields as the oracle's orc_camera (camera.rs:26-35)
+    float aspect, fov_y;
+    float m00, m11, m22, m23;
+    float r00, r11, r32, r33;
+};
+
+static float to_radians_host(float deg) {
+    const float k = 3.14159265358979323846264338327950288f / 180.0f;
+    return deg * k;
+}
+
+static Camera camera_new(float aspect, float fov_y_deg) {   // Perspective3::new + inverse
+    Camera c;
+    const float zn = 0.1f, zf = 10.0f;
+    const float fovy = to_radians_host(fov_y_deg);
+    c.aspect = aspect; c.fov_y = fov_y_deg;
+    c.m11 = 1.0f / tanf(fovy / 2.0f);
+    c.m00 = c.m11 / aspect;
+    c.m22 = (zf + zn) / (zn - zf);
+    c.m23 = zf * zn * 2.0f / (zn - zf);
+    c.r00 = 1.0f / c.m00;
+    c.r11 = 1.0f / c.m11;
+    c.r32 = 1.0f / c.m23;
+    c.r33 = c.m22 * c.r32;
+    return c;
+}
+
+struct Mat3 { float m[9]; };   // row-major 3x3 rotation
+
+// camera.rs:115-117 (rotate - coords), closed form; see file header.
+__device__ __forceinline__ float2 cam_delta(const Camera& c, float px, float py, const Mat3& R) {
+    const float cx = px * 2.0f - 1.0f, cy = py * 2.0f - 1.0f;
+    const float n0 = c.r32 + c.r33;
+    const float wx = ((-c.r00) * cx) / n0;
+    const float wy = -1.0f / n0;
+    const float wz = (c.r11 * cy) / n0;
+    const float rx = (R.m[0] * wx + R.m[1] * wy) + R.m[2] * wz;
+    const float ry = (R.m[3] * wx + R.m[4] * wy) + R.m[5] * wz;
+    const float rz = (R.m[6] * wx + R.m[7] * wy) + R.m[8] * wz;
+    const float qx = -rx, qy = rz, qz = ry;                   // view: (-x, z, y)
+    const float inv = -1.0f / qz;
+    const float sx = c.m00 * qx * inv;
+    const float sy = c.m11 * qy * inv;
+    const float sz = (c.m22 * qz + c.m23) * inv;
+    const float ox = (sx / sz + 1.0f) * 0.5f;                 // camera.rs:77: divide by NDC z
+    const float oy = (sy / sz + 1.0f) * 0.5f;
+    return make_float2(ox - px, oy - py);
+}
+
+// camera.rs:150-161
+__device__ __forceinline__ float2 cam_point_angle(const Camera& c, float fx, float fy, float px, float py) {
+    return make_float2(atanf((px - 0.5f) / fx), atanf((py - 0.5f) / fy));
+}
+
+struct Quat { float w, i, j, k; };
+
+__device__ __forceinline__ Quat quat_mul(const Quat& a, const Quat& b) {         // nalgebra Hamilton product
+    Quat r;
+    r.w = a.w * b.w - a.i * b.i - a.j * b.j - a.k * b.k;
+    r.i = a.w * b.i + a.i * b.w + a.j * b.k - a.k * b.j;
+    r.j = a.w * b.j - a.i * b.k + a.j * b.w + a.k * b.i;
+    r.k = a.w * b.k + a.i * b.j - a.j * b.i + a.k * b.w;
+    return r;
+}
+
+__device__ __forceinline__ Quat quat_from_euler(float roll, float pitch, float yaw) {
+    const float sr = sinf(roll * 0.5f), cr = cosf(roll * 0.5f);
+    const float sp = sinf(pitch * 0.5f), cp = cosf(pitch * 0.5f);
+    const float sy = sinf(yaw * 0.5f), cy = cosf(yaw * 0.5f);
+    Quat q;
+    q.w = cr * cp * cy + sr * sp * sy;
+    q.i = sr * cp * cy - cr * sp * sy;
+    q.j = cr * sp * cy + sr * cp * sy;
+    q.k = cr * cp * sy - sr * sp * cy;
+    return q;
+}
+
+__device__ __forceinline__ Mat3 quat_to_mat3(const Quat& q) {                    // to_homogeneous, 3x3 part
+    const float w = q.w, i = q.i, j = q.j, k = q.k;
+    const float ww = w * w, ii = i * i, jj = j * j, kk = k * k;
+    const float ij = i * j * 2.0f, wk = w * k * 2.0f, wj = w * j * 2.0f;
+    const float ik = i * k * 2.0f, jk = j * k * 2.0f, wi = w * i * 2.0f;
+    Mat3 r;
+    r.m[0] = ww + ii - jj - kk; r.m[1] = ij - wk;           r.m[2] = wj + ik;
+    r.m[3] = wk + ij;           r.m[4] = ww - ii + jj - kk; r.m[5] = jk - wi;
+    r.m[6] = ik - wj;           r.m[7] = wi + jk;           r.m[8] = ww - ii - jj + kk;
+    return r;
+}
+
+// Matrix3::lu().solve.  a is row-major; returns false when a U diagonal is exactly 0.
+__device__ __forceinline__ bool lu3_solve(const float a_in[9], const float b_in[3], float x[3]) {
+    float m[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) m[t] = a_in[t];
+    float b[3] = {b_in[0], b_in[1], b_in[2]};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        int piv = i;
+        float best = fabsf(m[3 * i + i]);
+#pragma unroll
+        for (int r = i + 1; r < 3; ++r) {
+            const float v = fabsf(m[3 * r + i]);
+            if (v > best) { best = v; piv = r; }
+        }
+        const float diag = m[3 * piv + i];
+        if (diag == 0.0f) continue;
+        if (piv != i) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { const float t = m[3 * i + c]; m[3 * i + c] = m[3 * piv + c]; m[3 * piv + c] = t; }
+            const float t = b[i]; b[i] = b[piv]; b[piv] = t;    // row permutation applied to b on the fly
+        }
+        const float inv_diag = 1.0f / diag;
+#pragma unroll
+        for (int r = i + 1; r < 3; ++r) m[3 * r + i] *= inv_diag;
+#pragma unroll
+        for (int c = i + 1; c < 3; ++c) {
+            const float neg = -m[3 * i + c];
+#pragma unroll
+            for (int r = i + 1; r < 3; ++r) m[3 * r + c] = neg * m[3 * r + i] + m[3 * r + c];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const float coeff = b[i] / 1.0f;
+#pragma unroll
+        for (int r = i + 1; r < 3; ++r) b[r] = (-coeff) * m[3 * r + i] + b[r];
+    }
+#pragma unroll
+    for (int i = 2; i >= 0; --i) {
+        const float diag = m[3 * i + i];
+        if (diag == 0.0f) return false;
+        const float coeff = b[i] / diag;
+        b[i] = coeff;
+#pragma unroll
+        for (int r = 0; r < i; ++r) b[r] = (-coeff) * m[3 * r + i] + b[r];
+    }
+    x[0] = b[0]; x[1] = b[1]; x[2] = b[2];
+    return true;
+}
+
+// NOTE on the permutation: nalgebra permutes b by the recorded swaps before the triangular
+// solves; the forward substitution above has not started when a swap is recorded, and the swaps
+// are applied in recording order, so permuting b on the fly is the same sequence of exchanges.
+
+struct Protos { Mat3 roll, pitch, yaw; };
+
+__device__ __forceinline__ Mat3 mat3_from_euler(float roll, float pitch, float yaw) {
+    const float sr = sinf(roll), cr = cosf(roll), sp = sinf(pitch), cp = cosf(pitch), sy = sinf(yaw), cy = cosf(yaw);
+    Mat3 r;
+    r.m[0] = cy * cp; r.m[1] = cy * sp * sr - sy * cr; r.m[2] = cy * sp * cr + sy * sr;
+    r.m[3] = sy * cp; r.m[4] = sy * sp * sr + cy * cr; r.m[5] = sy * sp * cr - cy * sr;
+    r.m[6] = -sp;     r.m[7] = cp * sr;                r.m[8] = cp * cr;
+    return r;
+}
+
+// One Gauss-Newton update from the 9 sums (lib.rs:159-195).  s = {a11,a12,a13,a22,a23,a33,b1,b2,b3}
+__device__ __forceinline__ Quat almeida_update(const Quat& rotation, const float s[9], float eps, float alpha) {
+    const float a[9] = {s[0], s[1], s[2], s[1], s[3], s[4], s[2], s[4], s[5]};
+    const float b[3] = {s[6], s[7], s[8]};
+    float model[3];
+    if (!lu3_solve(a, b, model)) { model[0] = model[1] = model[2] = 0.0f; }       // :181-183
+    model[0] = model[0] * eps * alpha;                                            // :185
+    model[1] = model[1] * eps * alpha;
+    model[2] = model[2] * eps * alpha;
+    const Quat roll = quat_from_euler(0.0f, model[0], 0.0f);                      // :189-191
+    const Quat pitch = quat_from_euler(model[1], 0.0f, 0.0f);
+    const Quat yaw = quat_from_euler(0.0f, 0.0f, -model[2]);
+    const Quat rot = quat_mul(quat_mul(pitch, roll), yaw);                        // :193
+    return quat_mul(rotation, rot);                                               // :195
+}
+
+constexpr int kIters = 30;                      // ceil(15 / ALPHA), lib.rs:132
+__device__ __forceinline__ float almeida_eps() { return 0.001f * 3.14159265358979323846264338327950288f / 180.0f; }
+
+// fixed-shape sum over a 1024-thread workgroup of 9 values per thread; result valid in thread 0
+__device__ __forceinline__ void block_sum9(float v[9], float (*red)[9]) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) v[k] += __shfl_xor(v[k], m, 64);
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) red[wave][k] = v[k];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int nw = blockDim.x >> 6;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            float acc = red[0][k];
+            for (int w = 1; w < nw; ++w) acc += red[w][k];
+            v[k] = acc;
+        }
+    }
+}
+
+// ---- small problems: one workgroup per item, EPT entries per thread, all 30 steps in-kernel.
+// n_dev (optional): per-item entry count on the device (RANSAC refit); stride = entries per item.
+template <int EPT>
+__global__ __launch_bounds__(1024) void almeida_lsq_wg_kernel(const float4* __restrict__ entries, size_t stride,
+                                                              size_t n_fixed, const uint32_t* __restrict__ n_dev,
+                                                              uint32_t min_n, Camera cam, float4* __restrict__ out_quat) {
+    __shared__ float red[16][9];
+    __shared__ Quat rot_sh;
+    const size_t item = blockIdx.x;
+    const size_t n = n_dev ? (size_t)n_dev[item] : n_fixed;
+    const float eps = almeida_eps();
+    if (n < min_n) {                                   // lib.rs:247-251: fewer than 3 inliers -> identity
+        if (threadIdx.x == 0) out_quat[item] = make_float4(1.0f, 0.0f, 0.0f, 0.0f);
+        return;
+    }
+    const Mat3 mroll = mat3_from_euler(0.0f, eps, 0.0f);           // lib.rs:30-34
+    const Mat3 mpitch = mat3_from_euler(eps, 0.0f, 0.0f);          // lib.rs:36-38
+    const Mat3 myaw = mat3_from_euler(0.0f, 0.0f, -eps);           // lib.rs:40-42
+    float4 e[EPT];
+    float2 pr[EPT], pp[EPT], py[EPT];
+    bool ok[EPT];
+#pragma unroll
+    for (int t = 0; t < EPT; ++t) {
+        const size_t i = (size_t)t * 1024 + threadIdx.x;
+        ok[t] = i < n;
+        e[t] = ok[t] ? entries[item * stride + i] : make_float4(0.5f, 0.5f, 0.0f, 0.0f);
+        pr[t] = cam_delta(cam, e[t].x, e[t].y, mroll);
+        pp[t] = cam_delta(cam, e[t].x, e[t].y, mpitch);
+        py[t] = cam_delta(cam, e[t].x, e[t].y, myaw);
+    }
+    Quat rotation = {1.0f, 0.0f, 0.0f, 0.0f};
+    for (int it = 0; it < kIters; ++it) {
+        const float alpha = (it == kIters - 1) ? 1.0f : 0.5f;      // lib.rs:138
+        const Mat3 rotm = quat_to_mat3(rotation);                  // lib.rs:140
+        float s[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int t = 0; t < EPT; ++t) {
+            if (!ok[t]) continue;
+            const float2 d = cam_delta(cam, e[t].x, e[t].y, rotm);
+            const float rx = e[t].z - d.x, ry = e[t].w - d.y;      // motion - delta
+            s[0] += pr[t].x * pr[t].x + pr[t].y * pr[t].y;
+            s[1] += pr[t].x * pp[t].x + pr[t].y * pp[t].y;
+            s[2] += pr[t].x * py[t].x + pr[t].y * py[t].y;
+            s[3] += pp[t].x * pp[t].x + pp[t].y * pp[t].y;
+            s[4] += pp[t].x * py[t].x + pp[t].y * py[t].y;
+            s[5] += py[t].x * py[t].x + py[t].y * py[t].y;
+            s[6] += pr[t].x * rx + pr[t].y * ry;
+            s[7] += pp[t].x * rx + pp[t].y * ry;
+            s[8] += py[t].x * rx + py[t].y * ry;
+        }
+        block_sum9(s, red);
+        if (threadIdx.x == 0) rot_sh = almeida_update(rotation, s, eps, alpha);
+        __syncthreads();
+        rotation = rot_sh;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out_quat[item] = make_float4(rotation.w, -rotation.i, -rotation.j, -rotation.k);  // :199
+}
+
+// ---- large problems: one launch per step.  state[it & 1][item] holds the rotation entering step
+// `it` (double-buffered: late workgroups of a launch still read the previous slot);
+// partials[item][blk][9] are this step's per-workgroup sums.  Every workgroup first folds the
+// previous step's partials (fixed order) into its private copy of the rotation.
+__global__ __launch_bounds__(1024) void almeida_lsq_step_kernel(const float4* __restrict__ entries, size_t n, int it,
+                                                                Camera cam, const float* __restrict__ part_prev,
+                                                                float* __restrict__ part_out, Quat* __restrict__ state,
+                                                                int batch, float4* __restrict__ out_quat) {
+    __shared__ float red[16][9];
+    __shared__ Quat rot_sh;
+    const size_t item = blockIdx.y;
+    const int nblk = gridDim.x;
+    const float eps = almeida_eps();
+    if (threadIdx.x == 0) {
+        Quat rotation = {1.0f, 0.0f, 0.0f, 0.0f};
+        if (it > 0) {
+            rotation = state[(size_t)((it - 1) & 1) * batch + item];
+            float s[9];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                float acc = part_prev[(item * nblk) * 9 + k];
+                for (int b = 1; b < nblk; ++b) acc += part_prev[(item * nblk + b) * 9 + k];
+                s[k] = acc;
+            }
+            const float alpha = (it - 1 == kIters - 1) ? 1.0f : 0.5f;
+            rotation = almeida_update(rotation, s, eps, alpha);
+        }
+        rot_sh = rotation;
+    }
+    __syncthreads();
+    const Quat rotation = rot_sh;
+    if (it == kIters) {                                  // epilogue launch: publish the result
+        if (blockIdx.x == 0 && threadIdx.x == 0)
+            out_quat[item] = make_float4(rotation.w, -rotation.i, -rotation.j, -rotation.k);
+        return;
+    }
+    const Mat3 rotm = quat_to_mat3(rotation);
+    const Mat3 mroll = mat3_from_euler(0.0f, eps, 0.0f);
+    const Mat3 mpitch = mat3_from_euler(eps, 0.0f, 0.0f);
+    const Mat3 myaw = mat3_from_euler(0.0f, 0.0f, -eps);
+    float s[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (size_t i = (size_t)blockIdx.x * 1024 + threadIdx.x; i < n; i += (size_t)nblk * 1024) {
+        const float4 e = entries[item * n + i];
+        const float2 d = cam_delta(cam, e.x, e.y, rotm);
+        const float2 pr = cam_delta(cam, e.x, e.y, mroll);
+        const float2 pp = cam_delta(cam, e.x, e.y, mpitch);
+        const float2 py = cam_delta(cam, e.x, e.y, myaw);
+        const float rx = e.z - d.x, ry = e.w - d.y;
+        s[0] += pr.x * pr.x + pr.y * pr.y;
+        s[1] += pr.x * pp.x + pr.y * pp.y;
+        s[2] += pr.x * py.x + pr.y * py.y;
+        s[3] += pp.x * pp.x + pp.y * pp.y;
+        s[4] += pp.x * py.x + pp.y * py.y;
+        s[5] += py.x * py.x + py.y * py.y;
+        s[6] += pr.x * rx + pr.y * ry;
+        s[7] += pp.x * rx + pp.y * ry;
+        s[8] += py.x * rx + py.y * ry;
+    }
+    block_sum9(s, red);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) part_out[(item * nblk + blockIdx.x) * 9 + k] = s[k];
+        if (blockIdx.x == 0) state[(size_t)(it & 1) * batch + item] = rotation;   // same value in every workgroup
+    }
+}
+
+// ---- RANSAC sampler: must stay bit-identical to orc_sample_index (oracle/ofps_oracle.c)
+__host__ __device__ inline uint64_t mix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+struct SampleKey { uint32_t key[4]; uint32_t half, mask; };
+__device__ __forceinline__ SampleKey sample_key(uint64_t seed, uint32_t iter, uint32_t stream, uint32_t n) {
+    SampleKey k;
+    uint32_t bits = 2;
+    while (bits < 32 && (1ull << bits) < (uint64_t)n) bits += 2;
+    k.half = bits / 2; k.mask = (1u << k.half) - 1u;
+    const uint64_t kk = mix64(seed ^ mix64(((uint64_t)iter << 1) | (uint64_t)(stream & 1u)));
+#pragma unroll
+    for (int r = 0; r < 4; ++r) k.key[r] = (uint32_t)mix64(kk + (uint64_t)r);
+    return k;
+}
+__device__ __forceinline__ uint32_t sample_index(const SampleKey& k, uint32_t i, uint32_t n) {
+    if (n <= 1) return 0;
+    uint32_t x = i;
+    do {
+        uint32_t l = x >> k.half, r = x & k.mask;
+#pragma unroll
+        for (int round = 0; round < 4; ++round) {
+            uint32_t f = r * 0x9E3779B1u + k.key[round];
+            f ^= f >> 15; f *= 0x85EBCA77u; f ^= f >> 13;
+            const uint32_t nl = r, nr = l ^ (f & k.mask);
+            l = nl; r = nr;
+        }
+        x = (l << k.half) | r;
+    } while (x >= n);
+    return x;
+}
+
+// one thread per (item, hypothesis): 3-sample solve, sequential sums in sample order (lib.rs:215-217);
+// writes the homogeneous matrix of fit.inverse() (lib.rs:224)
+__global__ __launch_bounds__(64) void ransac_hyp_kernel(const float4* __restrict__ entries, uint32_t n, uint32_t iters,
+                                                        uint64_t seed, Camera cam, Mat3* __restrict__ hyp) {
+    const size_t item = blockIdx.y;
+    const uint32_t it = blockIdx.x * 64 + threadIdx.x;
+    if (it >= iters) return;
+    const float eps = almeida_eps();
+    const uint32_t n3 = n < 3 ? n : 3;
+    const SampleKey sk = sample_key(seed, it, 0, n);
+    float4 e[3];
+    float2 pr[3], pp[3], py[3];
+    const Mat3 mroll = mat3_from_euler(0.0f, eps, 0.0f), mpitch = mat3_from_euler(eps, 0.0f, 0.0f),
+               myaw = mat3_from_euler(0.0f, 0.0f, -eps);
+    for (uint32_t j = 0; j < 3; ++j) {
+        if (j < n3) {
+            e[j] = entries[item * n + sample_index(sk, j, n)];
+            pr[j] = cam_delta(cam, e[j].x, e[j].y, mroll);
+            pp[j] = cam_delta(cam, e[j].x, e[j].y, mpitch);
+            py[j] = cam_delta(cam, e[j].x, e[j].y, myaw);
+        }
+    }
+    Quat rotation = {1.0f, 0.0f, 0.0f, 0.0f};
+    for (int s_it = 0; s_it < kIters; ++s_it) {
+        const float alpha = (s_it == kIters - 1) ? 1.0f : 0.5f;
+        const Mat3 rotm = quat_to_mat3(rotation);
+        float s[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        for (uint32_t j = 0; j < n3; ++j) {
+            const float2 d = cam_delta(cam, e[j].x, e[j].y, rotm);
+            const float rx = e[j].z - d.x, ry = e[j].w - d.y;
+            s[0] += pr[j].x * pr[j].x + pr[j].y * pr[j].y;
+            s[1] += pr[j].x * pp[j].x + pr[j].y * pp[j].y;
+            s[2] += pr[j].x * py[j].x + pr[j].y * py[j].y;
+            s[3] += pp[j].x * pp[j].x + pp[j].y * pp[j].y;
+            s[4] += pp[j].x * py[j].x + pp[j].y * py[j].y;
+            s[5] += py[j].x * py[j].x + py[j].y * py[j].y;
+            s[6] += pr[j].x * rx + pr[j].y * ry;
+            s[7] += pp[j].x * rx + pp[j].y * ry;
+            s[8] += py[j].x * rx + py[j].y * ry;
+        }
+        rotation = almeida_update(rotation, s, eps, alpha);
+    }
+    // fit = rotation.inverse(); mat = fit.inverse().to_homogeneous() = to_homogeneous(rotation)
+    hyp[item * iters + it] = quat_to_mat3(rotation);
+}
+
+__device__ __forceinline__ bool ransac_is_inlier(const Camera& cam, float fx, float fy, const Mat3& mat, const float4& e,
+                                                 float thr2) {
+    const float2 d = cam_delta(cam, e.x, e.y, mat);                           // lib.rs:229-231
+    const float2 ang = cam_point_angle(cam, fx, fy, e.x + d.x, e.y + d.y);    // :234
+    const float vx = (e.z - d.x) * cosf(ang.x), vy = (e.w - d.y) * cosf(ang.y);
+    return vx * vx + vy * vy <= thr2;                                         // :236
+}
+
+// one workgroup per (hypothesis, item): inlier count over the drawn samples
+__global__ __launch_bounds__(256) void ransac_count_kernel(const float4* __restrict__ entries, uint32_t n, uint32_t ns,
+                                                           uint32_t iters, uint64_t seed, Camera cam, float fx, float fy,
+                                                           float thr2, const Mat3* __restrict__ hyp,
+                                                           uint32_t* __restrict__ counts) {
+    __shared__ uint32_t total;
+    const size_t item = blockIdx.y;
+    const uint32_t it = blockIdx.x;
+    if (threadIdx.x == 0) total = 0;
+    __syncthreads();
+    const Mat3 mat = hyp[item * iters + it];
+    const SampleKey sk = sample_key(seed, it, 1, n);
+    uint32_t c = 0;
+    for (uint32_t j = threadIdx.x; j < ns; j += 256) {
+        const float4 e = entries[item * n + sample_index(sk, j, n)];
+        c += ransac_is_inlier(cam, fx, fy, mat, e, thr2) ? 1u : 0u;
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) c += __shfl_xor(c, m, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&total, c);
+    __syncthreads();
+    if (threadIdx.x == 0) counts[item * iters + it] = total;
+}
+
+// one workgroup per item: first hypothesis with the largest count (strict > in lib.rs:243), then
+// its inliers compacted in sample order into sel[item][0..count)
+__global__ __launch_bounds__(1024) void ransac_select_kernel(const float4* __restrict__ entries, uint32_t n, uint32_t ns,
+                                                             uint32_t iters, uint64_t seed, Camera cam, float fx, float fy,
+                                                             float thr2, const Mat3* __restrict__ hyp,
+                                                             const uint32_t* __restrict__ counts,
+                                                             float4* __restrict__ sel, uint32_t* __restrict__ sel_idx,
+                                                             uint32_t* __restrict__ sel_n) {
+    __shared__ unsigned long long best;
+    __shared__ uint32_t scan[1024];
+    __shared__ uint32_t base;
+    const size_t item = blockIdx.x;
+    if (threadIdx.x == 0) { best = 0; base = 0; }
+    __syncthreads();
+    unsigned long long k = 0;
+    for (uint32_t it = threadIdx.x; it < iters; it += 1024) {
+        const unsigned long long key = ((unsigned long long)counts[item * iters + it] << 32) | (0xFFFFFFFFu - it);
+        k = key > k ? key : k;
+    }
+    atomicMax(&best, k);
+    __syncthreads();
+    const uint32_t bcount = (uint32_t)(best >> 32);
+    const uint32_t bit = 0xFFFFFFFFu - (uint32_t)(best & 0xFFFFFFFFu);
+    if (bcount == 0) {                          // best_inliers stays empty (len > 0 never true)
+        if (threadIdx.x == 0) sel_n[item] = 0;
+        return;
+    }
+    const Mat3 mat = hyp[item * iters + bit];
+    const SampleKey sk = sample_key(seed, bit, 1, n);
+    for (uint32_t j0 = 0; j0 < ns; j0 += 1024) {
+        const uint32_t j = j0 + threadIdx.x;
+        uint32_t idx = 0;
+        bool in = false;
+        float4 e = make_float4(0, 0, 0, 0);
+        if (j < ns) {
+            idx = sample_index(sk, j, n);
+            e = entries[item * n + idx];
+            in = ransac_is_inlier(cam, fx, fy, mat, e, thr2);
+        }
+        scan[threadIdx.x] = in ? 1u : 0u;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {
+            const uint32_t v = threadIdx.x >= (unsigned)off ? scan[threadIdx.x - off] : 0;
+            __syncthreads();
+            scan[threadIdx.x] += v;
+            __syncthreads();
+        }
+        if (in) {
+            const uint32_t pos = base + scan[threadIdx.x] - 1;
+            sel[item * ns + pos] = e;
+            if (sel_idx) sel_idx[item * ns + pos] = idx;
+        }
+        __syncthreads();
+        if (threadIdx.x == 1023) base += scan[1023];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) sel_n[item] = base;
+}
+
+static int lsq_device(ofps_hip_ctx* ctx, const float4* d_entries, size_t stride, size_t n_max, const uint32_t* d_n,
+                      uint32_t min_n, int batch, const Camera& cam, float4* d_quat) {
+    hipStream_t s = ctx->stream;
+    if (n_max <= 8192) {
+        const dim3 g(batch), b(1024);
+        if (n_max <= 1024) hipLaunchKernelGGL((almeida_lsq_wg_kernel<1>), g, b, 0, s, d_entries, stride, n_max, d_n, min_n, cam, d_quat);
+        else if (n_max <= 2048) hipLaunchKernelGGL((almeida_lsq_wg_kernel<2>), g, b, 0, s, d_entries, stride, n_max, d_n, min_n, cam, d_quat);
+        else if (n_max <= 4096) hipLaunchKernelGGL((almeida_lsq_wg_kernel<4>), g, b, 0, s, d_entries, stride, n_max, d_n, min_n, cam, d_quat);
+        else hipLaunchKernelGGL((almeida_lsq_wg_kernel<8>), g, b, 0, s, d_entries, stride, n_max, d_n, min_n, cam, d_quat);
+    } else {
+        OFPS_REQUIRE(ctx, d_n == nullptr && stride == n_max, "almeida: device-side counts need n <= 8192");
+        // enough workgroups to fill the chip, few enough that the fixed-order fold stays short
+        int nblk = (int)((n_max + 8 * 1024 - 1) / (8 * 1024));
+        const int cap = (2 * ctx->num_cus + batch - 1) / batch;
+        if (nblk > cap) nblk = cap < 1 ? 1 : cap;
+        auto* part = static_cast<float*>(scratch(ctx, S_WORK0, 2 * (size_t)batch * nblk * 9 * sizeof(float)));
+        auto* state = static_cast<Quat*>(scratch(ctx, S_WORK1, 2 * (size_t)batch * sizeof(Quat)));
+        if (!part || !state) return OFPS_HIP_ENOMEM;
+        float* pa = part;
+        float* pb = part + (size_t)batch * nblk * 9;
+        for (int it = 0; it <= kIters; ++it) {
+            hipLaunchKernelGGL(almeida_lsq_step_kernel, dim3(nblk, batch), dim3(1024), 0, s, d_entries, n_max, it, cam,
+                               pa, pb, state, batch, d_quat);
+            float* t = pa; pa = pb; pb = t;
+        }
+    }
+    OFPS_HIP_TRY(ctx, hipGetLastError());
+    return OFPS_HIP_OK;
+}
+
+static int almeida_device(ofps_hip_ctx* ctx, const float4* d_entries, size_t n, int batch, float aspect, float fov_y_deg,
+                          int use_ransac, size_t num_iters, float inlier_deg, size_t num_samples, uint64_t seed,
+                          float4* d_quat) {
+    OFPS_REQUIRE(ctx, batch >= 1 && batch <= 65535, "almeida: batch %d out of range", batch);
+    OFPS_REQUIRE(ctx, n < (1ull << 31), "almeida: too many entries");
+    OFPS_REQUIRE(ctx, aspect > 0.0f && fov_y_deg > 0.0f && fov_y_deg < 180.0f, "almeida: bad camera (aspect=%g fov_y=%g)",
+                 (double)aspect, (double)fov_y_deg);
+    const Camera cam = camera_new(aspect, fov_y_deg);
+    if (!use_ransac) return lsq_device(ctx, d_entries, n, n, nullptr, 0, batch, cam, d_quat);
+
+    OFPS_REQUIRE(ctx, num_iters >= 1 && num_iters <= 65535, "almeida: ransac iters %zu out of range", num_iters);
+    OFPS_REQUIRE(ctx, num_samples >= 1, "almeida: ransac samples must be >= 1");
+    const uint32_t iters = (uint32_t)num_iters;
+    const uint32_t ns = (uint32_t)(num_samples < n ? num_samples : n);
+    hipStream_t s = ctx->stream;
+    auto* hyp = static_cast<Mat3*>(scratch(ctx, S_WORK2, (size_t)batch * iters * sizeof(Mat3)));
+    auto* counts = static_cast<uint32_t*>(scratch(ctx, S_WORK3, (size_t)batch * iters * sizeof(uint32_t)));
+    auto* sel = static_cast<float4*>(scratch(ctx, S_WORK4, (size_t)batch * (ns ? ns : 1) * sizeof(float4)));
+    auto* sel_n = static_cast<uint32_t*>(scratch(ctx, S_CELLS, (size_t)batch * sizeof(uint32_t)));
+    if (!hyp || !counts || !sel || !sel_n) return OFPS_HIP_ENOMEM;
+    const float target = to_radians_host(inlier_deg);                              // lib.rs:210
+    const float thr2 = target * target;
+    const float fy = 0.5f / tanf(to_radians_host(cam.fov_y) / 2.0f);                // camera.rs:121-122
+    const float fx = fy / cam.aspect;
+    if (n == 0 || ns == 0) {
+        OFPS_HIP_TRY(ctx, hipMemsetAsync(sel_n, 0, (size_t)batch * sizeof(uint32_t), s));
+    } else {
+        hipLaunchKernelGGL(ransac_hyp_kernel, dim3((iters + 63) / 64, batch), dim3(64), 0, s, d_entries, (uint32_t)n, iters,
+                           seed, cam, hyp);
+        hipLaunchKernelGGL(ransac_count_kernel, dim3(iters, batch), dim3(256), 0, s, d_entries, (uint32_t)n, ns, iters, seed,
+                           cam, fx, fy, thr2, hyp, counts);
+        hipLaunchKernelGGL(ransac_select_kernel, dim3(batch), dim3(1024), 0, s, d_entries, (uint32_t)n, ns, iters, seed, cam,
+                           fx, fy, thr2, hyp, counts, sel, (uint32_t*)nullptr, sel_n);
+    }
+    OFPS_HIP_TRY(ctx, hipGetLastError());
+    const size_t cap = ns ? ns : 1;
+    if (cap <= 8192) return lsq_device(ctx, sel, cap, cap, sel_n, 3, batch, cam, d_quat);
+    // "Ransac samples" can reach 16000 (lib.rs:92-95): refit sets above 8192 need their size on the
+    // host to pick the multi-launch path -- one small read-back per item.
+    for (int b = 0; b < batch; ++b) {
+        uint32_t cnt = 0;
+        OFPS_HIP_TRY(ctx, hipMemcpyAsync(&cnt, sel_n + b, sizeof(cnt), hipMemcpyDeviceToHost, s));
+        OFPS_HIP_TRY(ctx, hipStreamSynchronize(s));
+        int rc;
+        if (cnt <= 8192) rc = lsq_device(ctx, sel + (size_t)b * cap, cap, cnt < 1 ? 1 : cnt, sel_n + b, 3, 1, cam, d_quat + b);
+        else rc = lsq_device(ctx, sel + (size_t)b * cap, cnt, cnt, nullptr, 0, 1, cam, d_quat + b);
+        if (rc != OFPS_HIP_OK) return rc;
+    }
+    return OFPS_HIP_OK;
+}
+
+}  // namespace ofps
+
+extern "C" {
+
+int ofps_hip_almeida_dev(ofps_hip_ctx* ctx, const void* d_entries, size_t n_per_item, int batch, float aspect,
+                         float fov_y_deg, int use_ransac, size_t num_iters, float inlier_deg, size_t num_samples,
+                         uint64_t seed, void* d_out_quat) {
+    if (!ctx) return OFPS_HIP_EINVAL;
+    OFPS_REQUIRE(ctx, d_out_quat && (d_entries || n_per_item == 0), "almeida: null device pointer");
+    OFPS_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return ofps::almeida_device(ctx, static_cast<const float4*>(d_entries), n_per_item, batch, aspect, fov_y_deg, use_ransac,
+                                num_iters, inlier_deg, num_samples, seed, static_cast<float4*>(d_out_quat));
+}
+
+int ofps_hip_almeida(ofps_hip_ctx* ctx, const float* entries, size_t n, float aspect, float fov_y_deg, int use_ransac,
+                     size_t num_iters, float inlier_deg, size_t num_samples, uint64_t seed, float out_quat[4],
+                     float out_tr[3]) {
+    if (!ctx) return OFPS_HIP_EINVAL;
+    OFPS_REQUIRE(ctx, out_quat && (entries || n == 0), "almeida: null host pointer");
+    OFPS_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    auto* d_ent = static_cast<float4*>(ofps::scratch(ctx, ofps::S_ENTRIES, n * sizeof(float4)));
+    auto* d_q = static_cast<float4*>(ofps::scratch(ctx, ofps::S_QUAT, sizeof(float4)));
+    if (!d_ent || !d_q) return OFPS_HIP_ENOMEM;
+    if (n) OFPS_HIP_TRY(ctx, hipMemcpyAsync(d_ent, entries, n * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
+    int rc = ofps::almeida_device(ctx, d_ent, n, 1, aspect, fov_y_deg, use_ransac, num_iters, inlier_deg, num_samples, seed,
+                                  d_q);
+    if (rc != OFPS_HIP_OK) return rc;
+    OFPS_HIP_TRY(ctx, hipMemcpyAsync(out_quat, d_q, 4 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    OFPS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (out_tr) { out_tr[0] = out_tr[1] = out_tr[2] = 0.0f; }                       // lib.rs:120
+    return OFPS_HIP_OK;
+}
+
+}  // extern "C"

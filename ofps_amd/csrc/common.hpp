@@ -1,0 +1,52 @@
+// common.hpp -- context object and error plumbing shared by the libofps_hip.so translation units.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "../../include/ofps_hip.h"
+
+struct ofps_hip_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;        // the stream work is enqueued on (own or caller's)
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    int num_cus = 0;
+    char err[512] = {0};
+
+    // grow-only device scratch owned by the context (staging for host-pointer entry points and
+    // kernel workspaces); never shrinks, freed in ofps_hip_destroy.
+    struct Scratch { void* p = nullptr; size_t cap = 0; };
+    static constexpr int kNumScratch = 12;
+    Scratch scratch[kNumScratch];
+};
+
+namespace ofps {
+
+enum ScratchSlot {
+    S_FRAMES = 0, S_ENTRIES, S_BEST, S_FIELD, S_CELLS, S_WORK0, S_WORK1, S_WORK2, S_WORK3, S_RESULT,
+    S_QUAT, S_WORK4
+};
+
+int set_error(ofps_hip_ctx* ctx, int code, const char* fmt, ...);
+int check_hip(ofps_hip_ctx* ctx, hipError_t e, const char* what);
+// returns nullptr (and sets the error) on failure
+void* scratch(ofps_hip_ctx* ctx, int slot, size_t bytes);
+
+#define OFPS_HIP_TRY(ctx, expr)                                          \
+    do {                                                                 \
+        hipError_t _e = (expr);                                          \
+        if (_e != hipSuccess) return ofps::check_hip((ctx), _e, #expr);  \
+    } while (0)
+
+#define OFPS_REQUIRE(ctx, cond, ...)                                              \
+    do {                                                                          \
+        if (!(cond)) return ofps::set_error((ctx), OFPS_HIP_EINVAL, __VA_ARGS__);  \
+    } while (0)
+
+}  // namespace ofps

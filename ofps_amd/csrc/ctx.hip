@@ -1,0 +1,171 @@
+// ctx.hip -- context lifetime, stream selection, device-memory plumbing and the event timer
+// behind include/ofps_hip.h.  No compute lives here.
+#include "common.hpp"
+
+static thread_local char g_init_err[512] = {0};
+
+namespace ofps {
+
+int set_error(ofps_hip_ctx* ctx, int code, const char* fmt, ...) {
+    char* dst = ctx ? ctx->err : g_init_err;
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(dst, 512, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int check_hip(ofps_hip_ctx* ctx, hipError_t e, const char* what) {
+    if (e == hipSuccess) return OFPS_HIP_OK;
+    int code = (e == hipErrorOutOfMemory) ? OFPS_HIP_ENOMEM : OFPS_HIP_EDEVICE;
+    return set_error(ctx, code, "%s failed: %s", what, hipGetErrorString(e));
+}
+
+void* scratch(ofps_hip_ctx* ctx, int slot, size_t bytes) {
+    auto& s = ctx->scratch[slot];
+    if (bytes == 0) bytes = 16;
+    if (s.cap >= bytes) return s.p;
+    if (s.p) {
+        // the old buffer may still be referenced by enqueued work
+        if (hipStreamSynchronize(ctx->stream) != hipSuccess) { /* fall through to the free */ }
+        (void)hipFree(s.p);
+        s.p = nullptr; s.cap = 0;
+    }
+    size_t cap = (bytes + 4095) & ~size_t(4095);
+    hipError_t e = hipMalloc(&s.p, cap);
+    if (e != hipSuccess) {
+        check_hip(ctx, e, "hipMalloc(scratch)");
+        s.p = nullptr;
+        return nullptr;
+    }
+    s.cap = cap;
+    return s.p;
+}
+
+}  // namespace ofps
+
+extern "C" {
+
+int ofps_hip_api_version(void) { return OFPS_HIP_API_VERSION; }
+
+int ofps_hip_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int ofps_hip_init(int device, ofps_hip_ctx** out) {
+    if (!out) return ofps::set_error(nullptr, OFPS_HIP_EINVAL, "ofps_hip_init: out is NULL");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return ofps::set_error(nullptr, OFPS_HIP_EDEVICE,
+                               "ofps_hip_init: no HIP device (%s); this backend has no CPU fallback",
+                               e == hipSuccess ? "count == 0" : hipGetErrorString(e));
+    if (device < 0 || device >= n)
+        return ofps::set_error(nullptr, OFPS_HIP_EINVAL, "ofps_hip_init: device %d out of range [0,%d)", device, n);
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, device);
+    if (e != hipSuccess) return ofps::check_hip(nullptr, e, "hipGetDeviceProperties");
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return ofps::set_error(nullptr, OFPS_HIP_EUNSUPPORTED,
+                               "ofps_hip_init: device %d is %s; this library ships gfx950 code only", device,
+                               prop.gcnArchName);
+    auto* ctx = new ofps_hip_ctx();
+    ctx->device = device;
+    ctx->num_cus = prop.multiProcessorCount;
+    if ((e = hipSetDevice(device)) != hipSuccess ||
+        (e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipEventCreate(&ctx->ev_start)) != hipSuccess || (e = hipEventCreate(&ctx->ev_stop)) != hipSuccess) {
+        int rc = ofps::check_hip(nullptr, e, "context setup");
+        delete ctx;
+        return rc;
+    }
+    ctx->stream = ctx->own_stream;
+    *out = ctx;
+    return OFPS_HIP_OK;
+}
+
+void ofps_hip_destroy(ofps_hip_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    for (auto& s : ctx->scratch)
+        if (s.p) (void)hipFree(s.p);
+    if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
+    if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+const char* ofps_hip_last_error(const ofps_hip_ctx* ctx) { return ctx ? ctx->err : g_init_err; }
+
+int ofps_hip_set_stream(ofps_hip_ctx* ctx, void* hip_stream) {
+    if (!ctx) return OFPS_HIP_EINVAL;
+    ctx->stream = reinterpret_cast<hipStream_t>(hip_stream);
+    return OFPS_HIP_OK;
+}
+
+int ofps_hip_use_own_stream(ofps_hip_ctx* ctx) {
+    if (!ctx) return OFPS_HIP_EINVAL;
+    ctx->stream = ctx->own_stream;
+    return OFPS_HIP_OK;
+}
+
+void* ofps_hip_get_stream(ofps_hip_ctx* ctx) { return ctx ? reinterpret_cast<void*>(ctx->stream) : nullptr; }
+
+int ofps_hip_sync(ofps_hip_ctx* ctx) {
+    if (!ctx) return OFPS_HIP_EINVAL;
+    OFPS_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    OFPS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return OFPS_HIP_OK;
+}
+
+int ofps_hip_malloc(ofps_hip_ctx* ctx, size_t bytes, void** dptr) {
+    if (!ctx || !dptr) return OFPS_HIP_EINVAL;
+    OFPS_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    OFPS_HIP_TRY(ctx, hipMalloc(dptr, bytes ? bytes : 16));
+    return OFPS_HIP_OK;
+}
+
+int ofps_hip_free(ofps_hip_ctx* ctx, void* dptr) {
+    if (!ctx) return OFPS_HIP_EINVAL;
+    OFPS_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    OFPS_HIP_TRY(ctx, hipFree(dptr));
+    return OFPS_HIP_OK;
+}
+
+int ofps_hip_memcpy_h2d(ofps_hip_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes) {
+    if (!ctx) return OFPS_HIP_EINVAL;
+    OFPS_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    OFPS_HIP_TRY(ctx, hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    OFPS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return OFPS_HIP_OK;
+}
+
+int ofps_hip_memcpy_d2h(ofps_hip_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes) {
+    if (!ctx) return OFPS_HIP_EINVAL;
+    OFPS_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    OFPS_HIP_TRY(ctx, hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    OFPS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return OFPS_HIP_OK;
+}
+
+int ofps_hip_timer_start(ofps_hip_ctx* ctx) {
+    if (!ctx) return OFPS_HIP_EINVAL;
+    OFPS_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    OFPS_HIP_TRY(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
+    return OFPS_HIP_OK;
+}
+
+int ofps_hip_timer_stop(ofps_hip_ctx* ctx, float* elapsed_ms) {
+    if (!ctx || !elapsed_ms) return OFPS_HIP_EINVAL;
+    OFPS_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    OFPS_HIP_TRY(ctx, hipEventRecord(ctx->ev_stop, ctx->stream));
+    OFPS_HIP_TRY(ctx, hipEventSynchronize(ctx->ev_stop));
+    OFPS_HIP_TRY(ctx, hipEventElapsedTime(elapsed_ms, ctx->ev_start, ctx->ev_stop));
+    return OFPS_HIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,340 @@
+// densify.hip -- A1-A4: MotionFieldDensifier::add_vector + MotionField::from on gfx950
+// (ofps/src/motion_field.rs:133-190, 297-308) and cv-decoder's downsample output stage
+// (cv-decoder/src/lib.rs:244-291).
+//
+// The reference adds vectors to their cell one after another in input order, in f32.  To return
+// the same bits (not just the same value to 1e-4) the GPU keeps that order:
+//   1. cell_kernel        one thread per entry: nalgebra clamp quirk + round-half-away -> cell id
+//   2. stable LSD radix sort of (cell id, entry index), 8-bit digits, 1 pass for <= 256 cells,
+//      2 for <= 65536.  Ranks inside a 1024-entry tile come from an 8-ballot "same digit" match
+//      per wave plus a 16-slot per-digit prefix in LDS; tile bases from a digit-major scan.
+//   3. bounds_kernel      first/last sorted position of every cell
+//   4. cell_sum_kernel    one wave per cell: lanes gather 64 entries at a time into LDS, lanes 0/1
+//      then add x / y sequentially in input order; counts replay eps + 1 + 1 + ...;
+//      field = sum / count (IEEE divide), exactly `component_div` (motion_field.rs:304).
+// Traffic: 16 B/entry read twice (cell pass + gather) plus 8 B/entry/pass of sort keys; the
+// kernels are launch/latency-bound at detector sizes (N ~ 1e4) and HBM-bound at per-pixel
+// sizes (N ~ 2e6).
+#include "common.hpp"
+
+namespace ofps {
+
+constexpr int kTile = 1024;       // entries per sort tile (256 threads x 4 rounds)
+constexpr float kF32Eps = 1.1920929e-07f;
+
+// motion_field.rs:164-178 -> (x, y).  `clamp` on a Point2 compares all components at once
+// (SURVEY.md A.6); f32::round is half-away-from-zero; `as usize` saturates (NaN/negatives -> 0).
+__device__ __forceinline__ void densifier_cell(float px, float py, int w, int h, uint32_t& x, uint32_t& y) {
+    float cx, cy;
+    if (px > 0.0f && py > 0.0f) {
+        if (px < 1.0f && py < 1.0f) { cx = px; cy = py; }
+        else { cx = 1.0f; cy = 1.0f; }
+    } else { cx = 0.0f; cy = 0.0f; }
+    const float fx = roundf(cx * (float)(w - 1)), fy = roundf(cy * (float)(h - 1));
+    x = fx > 0.0f ? (uint32_t)fx : 0u;
+    y = fy > 0.0f ? (uint32_t)fy : 0u;
+}
+
+__global__ __launch_bounds__(256) void cell_kernel(const float4* __restrict__ entries, size_t n, int w, int h,
+                                                   uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
+                                                   uint32_t* __restrict__ out_cells) {
+    const size_t item = blockIdx.y;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float4 e = entries[item * n + i];
+    uint32_t x, y;
+    densifier_cell(e.x, e.y, w, h, x, y);
+    keys[item * n + i] = y * (uint32_t)w + x;
+    vals[item * n + i] = (uint32_t)i;
+    if (out_cells) {
+        out_cells[2 * (item * n + i)] = x;
+        out_cells[2 * (item * n + i) + 1] = y;
+    }
+}
+
+// per-tile digit histogram -> hist[item][digit][tile]
+__global__ __launch_bounds__(256) void sort_count_kernel(const uint32_t* __restrict__ keys, size_t n, int shift,
+                                                         int ntiles, uint32_t* __restrict__ hist) {
+    __shared__ uint32_t cnt[256];
+    const size_t item = blockIdx.y;
+    const int tile = blockIdx.x;
+    cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const size_t base = (size_t)tile * kTile;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const size_t i = base + r * 256 + threadIdx.x;
+        if (i < n) atomicAdd(&cnt[(keys[item * n + i] >> shift) & 0xFF], 1u);
+    }
+    __syncthreads();
+    hist[(item * 256 + threadIdx.x) * ntiles + tile] = cnt[threadIdx.x];
+}
+
+// exclusive scan of hist[item][...] (256*ntiles values, digit-major) by one workgroup per item
+__global__ __launch_bounds__(1024) void sort_scan_kernel(uint32_t* __restrict__ hist, int ntiles) {
+    __shared__ uint32_t part[1024];
+    const size_t item = blockIdx.x;
+    uint32_t* h = hist + item * 256 * (size_t)ntiles;
+    const int total = 256 * ntiles;
+    const int per = (total + 1023) / 1024;
+    const int lo = threadIdx.x * per, hi = min(lo + per, total);
+    uint32_t s = 0;
+    for (int i = lo; i < hi; ++i) s += h[i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {         // Hillis-Steele inclusive scan
+        uint32_t v = threadIdx.x >= off ? part[threadIdx.x - off] : 0;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    uint32_t run = threadIdx.x ? part[threadIdx.x - 1] : 0;
+    for (int i = lo; i < hi; ++i) { const uint32_t v = h[i]; h[i] = run; run += v; }
+}
+
+// stable scatter of one tile
+__global__ __launch_bounds__(256) void sort_scatter_kernel(const uint32_t* __restrict__ keys_in,
+                                                           const uint32_t* __restrict__ vals_in, size_t n, int shift,
+                                                           int ntiles, const uint32_t* __restrict__ hist,
+                                                           uint32_t* __restrict__ keys_out,
+                                                           uint32_t* __restrict__ vals_out) {
+    __shared__ uint32_t slot_cnt[16][256];      // [round*4 + wave][digit]
+    const size_t item = blockIdx.y;
+    const int tile = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < 16 * 256; i += 256) (&slot_cnt[0][0])[i] = 0;
+    __syncthreads();
+    const size_t base = (size_t)tile * kTile;
+    uint32_t key[4], val[4], rank[4];
+    bool ok[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const size_t i = base + r * 256 + tid;
+        ok[r] = i < n;
+        key[r] = ok[r] ? keys_in[item * n + i] : 0xFFFFFFFFu;
+        val[r] = ok[r] ? vals_in[item * n + i] : 0u;
+        const uint32_t d = (key[r] >> shift) & 0xFF;
+        // lanes holding the same digit (inactive tail lanes are excluded through `ok`)
+        unsigned long long same = __ballot(ok[r]);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const unsigned long long bal = __ballot((d >> b) & 1u);
+            same &= ((d >> b) & 1u) ? bal : ~bal;
+        }
+        const unsigned long long below = same & ((1ull << lane) - 1ull);
+        rank[r] = (uint32_t)__popcll(below);
+        if (ok[r] && below == 0) slot_cnt[r * 4 + wave][d] = (uint32_t)__popcll(same);
+    }
+    __syncthreads();
+    {   // thread d: exclusive prefix over the 16 (round, wave) slots of digit d
+        uint32_t run = 0;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) { const uint32_t v = slot_cnt[s][tid]; slot_cnt[s][tid] = run; run += v; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        if (!ok[r]) continue;
+        const uint32_t d = (key[r] >> shift) & 0xFF;
+        const size_t pos = (size_t)hist[(item * 256 + d) * ntiles + tile] + slot_cnt[r * 4 + wave][d] + rank[r];
+        keys_out[item * n + pos] = key[r];
+        vals_out[item * n + pos] = val[r];
+    }
+}
+
+// cell_begin / cell_end from the sorted keys (arrays pre-zeroed: empty cell <=> begin == end)
+__global__ __launch_bounds__(256) void bounds_kernel(const uint32_t* __restrict__ keys, size_t n, size_t cells,
+                                                     uint32_t* __restrict__ cell_begin, uint32_t* __restrict__ cell_end) {
+    const size_t item = blockIdx.y;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t* k = keys + item * n;
+    const uint32_t c = k[i];
+    if (i == 0 || k[i - 1] != c) cell_begin[item * cells + c] = (uint32_t)i;
+    if (i == n - 1 || k[i + 1] != c) cell_end[item * cells + c] = (uint32_t)(i + 1);
+}
+
+// one wave per cell; 4 cells per workgroup
+__global__ __launch_bounds__(256) void cell_sum_kernel(const float4* __restrict__ entries, size_t n,
+                                                       const uint32_t* __restrict__ vals,
+                                                       const uint32_t* __restrict__ cell_begin,
+                                                       const uint32_t* __restrict__ cell_end, size_t cells,
+                                                       float2* __restrict__ out_field) {
+    __shared__ float2 stage[4][64];
+    const size_t item = blockIdx.y;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const size_t cell = (size_t)blockIdx.x * 4 + wave;
+    if (cell >= cells) return;                         // wave-uniform; no block barrier below
+    const uint32_t b = cell_begin[item * cells + cell], e = cell_end[item * cells + cell];
+    float sum = 0.0f, cnt = kF32Eps;                   // motion_field.rs:133-138
+    for (uint32_t k0 = b; k0 < e; k0 += 64) {
+        const uint32_t k = k0 + lane;
+        if (k < e) {
+            const float4 en = entries[item * n + vals[item * n + k]];
+            stage[wave][lane] = make_float2(en.z, en.w);
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        const int m = (int)min(64u, e - k0);
+        if (lane < 2) {
+            const float* col = reinterpret_cast<const float*>(&stage[wave][0]) + lane;
+            for (int j = 0; j < m; ++j) {
+                cnt += 1.0f;                           // :142-143
+                sum = col[2 * j] * 1.0f + sum;         // :144-146 (motion * weight + column)
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+    if (lane < 2) reinterpret_cast<float*>(out_field + item * cells + cell)[lane] = sum / cnt;   // :304
+}
+
+// cv-decoder/src/lib.rs:279-291: visited cells in BTreeSet<(x,y)> order -> entries.  One
+// workgroup per item walks the x-major cell order in 1024-cell chunks with a running offset.
+__global__ __launch_bounds__(1024) void cells_to_entries_kernel(const float2* __restrict__ field,
+                                                                const uint32_t* __restrict__ cell_begin,
+                                                                const uint32_t* __restrict__ cell_end, int w, int h,
+                                                                float4* __restrict__ out_entries,
+                                                                uint32_t* __restrict__ out_count) {
+    __shared__ uint32_t scan[1024];
+    __shared__ uint32_t base;
+    const size_t item = blockIdx.x;
+    const size_t cells = (size_t)w * h;
+    const float nx = 1.0f / (float)w, ny = 1.0f / (float)h;
+    if (threadIdx.x == 0) base = 0;
+    __syncthreads();
+    for (size_t c0 = 0; c0 < cells; c0 += 1024) {
+        const size_t o = c0 + threadIdx.x;                 // position in (x, y)-sorted order
+        const int x = (int)(o / h), y = (int)(o % h);
+        const size_t idx = (size_t)y * w + x;
+        const bool vis = o < cells && cell_end[item * cells + idx] > cell_begin[item * cells + idx];
+        scan[threadIdx.x] = vis ? 1u : 0u;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {
+            uint32_t v = threadIdx.x >= (unsigned)off ? scan[threadIdx.x - off] : 0;
+            __syncthreads();
+            scan[threadIdx.x] += v;
+            __syncthreads();
+        }
+        if (vis) {
+            const uint32_t pos = base + scan[threadIdx.x] - 1;
+            const float2 m = field[item * cells + idx];
+            out_entries[item * cells + pos] =
+                make_float4(((float)x + 0.5f) * nx, ((float)y + 0.5f) * ny, m.x, m.y);
+        }
+        __syncthreads();
+        if (threadIdx.x == 1023) base += scan[1023];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out_count[item] = base;
+}
+
+// Shared by detect.hip: densify `batch` items of n entries into (w x h) fields.  Leaves the
+// per-cell [begin,end) tables in S_WORK3 (begin) / S_WORK4 (end).
+int densify_device(ofps_hip_ctx* ctx, const float4* d_entries, size_t n, int batch, int w, int h, float2* d_field,
+                   uint32_t* d_cells, uint32_t** out_begin, uint32_t** out_end) {
+    const size_t cells = (size_t)w * (size_t)h;
+    OFPS_REQUIRE(ctx, w >= 1 && h >= 1 && cells <= 65536, "densify: grid %dx%d unsupported (1..65536 cells)", w, h);
+    OFPS_REQUIRE(ctx, batch >= 1 && batch <= 65535, "densify: batch %d out of range", batch);
+    OFPS_REQUIRE(ctx, n < (1ull << 31), "densify: too many entries");
+    hipStream_t s = ctx->stream;
+    const size_t tot = n * (size_t)batch;
+    auto* begin = static_cast<uint32_t*>(scratch(ctx, S_WORK3, cells * batch * sizeof(uint32_t)));
+    auto* end = static_cast<uint32_t*>(scratch(ctx, S_WORK4, cells * batch * sizeof(uint32_t)));
+    if (!begin || !end) return OFPS_HIP_ENOMEM;
+    OFPS_HIP_TRY(ctx, hipMemsetAsync(begin, 0, cells * batch * sizeof(uint32_t), s));
+    OFPS_HIP_TRY(ctx, hipMemsetAsync(end, 0, cells * batch * sizeof(uint32_t), s));
+    if (out_begin) *out_begin = begin;
+    if (out_end) *out_end = end;
+    uint32_t* sorted_vals = nullptr;
+    if (n > 0) {
+        const int ntiles = (int)((n + kTile - 1) / kTile);
+        auto* k0 = static_cast<uint32_t*>(scratch(ctx, S_WORK0, 2 * tot * sizeof(uint32_t)));
+        auto* k1 = static_cast<uint32_t*>(scratch(ctx, S_WORK1, 2 * tot * sizeof(uint32_t)));
+        auto* hist = static_cast<uint32_t*>(scratch(ctx, S_WORK2, (size_t)batch * 256 * ntiles * sizeof(uint32_t)));
+        if (!k0 || !k1 || !hist) return OFPS_HIP_ENOMEM;
+        uint32_t *keys_a = k0, *vals_a = k0 + tot, *keys_b = k1, *vals_b = k1 + tot;
+        const dim3 ge((unsigned)((n + 255) / 256), batch), gt(ntiles, batch);
+        hipLaunchKernelGGL(cell_kernel, ge, dim3(256), 0, s, d_entries, n, w, h, keys_a, vals_a, d_cells);
+        const int passes = cells <= 256 ? 1 : 2;
+        for (int p = 0; p < passes; ++p) {
+            const int shift = 8 * p;
+            hipLaunchKernelGGL(sort_count_kernel, gt, dim3(256), 0, s, keys_a, n, shift, ntiles, hist);
+            hipLaunchKernelGGL(sort_scan_kernel, dim3(batch), dim3(1024), 0, s, hist, ntiles);
+            hipLaunchKernelGGL(sort_scatter_kernel, gt, dim3(256), 0, s, keys_a, vals_a, n, shift, ntiles, hist, keys_b,
+                               vals_b);
+            uint32_t* t;
+            t = keys_a; keys_a = keys_b; keys_b = t;
+            t = vals_a; vals_a = vals_b; vals_b = t;
+        }
+        hipLaunchKernelGGL(bounds_kernel, ge, dim3(256), 0, s, keys_a, n, cells, begin, end);
+        sorted_vals = vals_a;
+    }
+    hipLaunchKernelGGL(cell_sum_kernel, dim3((unsigned)((cells + 3) / 4), batch), dim3(256), 0, s, d_entries, n,
+                       sorted_vals, begin, end, cells, d_field);
+    OFPS_HIP_TRY(ctx, hipGetLastError());
+    return OFPS_HIP_OK;
+}
+
+}  // namespace ofps
+
+extern "C" {
+
+int ofps_hip_densify_dev(ofps_hip_ctx* ctx, const void* d_entries, size_t n_per_item, int batch, int w, int h,
+                         void* d_out_field, void* d_out_cells) {
+    if (!ctx) return OFPS_HIP_EINVAL;
+    OFPS_REQUIRE(ctx, d_out_field && (d_entries || n_per_item == 0), "densify: null device pointer");
+    OFPS_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return ofps::densify_device(ctx, static_cast<const float4*>(d_entries), n_per_item, batch, w, h,
+                                static_cast<float2*>(d_out_field), static_cast<uint32_t*>(d_out_cells), nullptr,
+                                nullptr);
+}
+
+int ofps_hip_densify(ofps_hip_ctx* ctx, const float* entries, size_t n, int w, int h, float* out_field,
+                     uint32_t* out_cells) {
+    if (!ctx) return OFPS_HIP_EINVAL;
+    OFPS_REQUIRE(ctx, out_field && (entries || n == 0), "densify: null host pointer");
+    OFPS_REQUIRE(ctx, w >= 1 && h >= 1, "densify: bad grid %dx%d", w, h);
+    OFPS_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t cells = (size_t)w * h;
+    auto* d_ent = static_cast<float4*>(ofps::scratch(ctx, ofps::S_ENTRIES, n * sizeof(float4)));
+    auto* d_field = static_cast<float2*>(ofps::scratch(ctx, ofps::S_FIELD, cells * sizeof(float2)));
+    auto* d_cells = out_cells ? static_cast<uint32_t*>(ofps::scratch(ctx, ofps::S_CELLS, 2 * n * sizeof(uint32_t))) : nullptr;
+    if (!d_ent || !d_field || (out_cells && !d_cells)) return OFPS_HIP_ENOMEM;
+    if (n) OFPS_HIP_TRY(ctx, hipMemcpyAsync(d_ent, entries, n * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
+    int rc = ofps::densify_device(ctx, d_ent, n, 1, w, h, d_field, d_cells, nullptr, nullptr);
+    if (rc != OFPS_HIP_OK) return rc;
+    OFPS_HIP_TRY(ctx, hipMemcpyAsync(out_field, d_field, cells * sizeof(float2), hipMemcpyDeviceToHost, ctx->stream));
+    if (out_cells && n)
+        OFPS_HIP_TRY(ctx, hipMemcpyAsync(out_cells, d_cells, 2 * n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    OFPS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return OFPS_HIP_OK;
+}
+
+int ofps_hip_densify_to_entries(ofps_hip_ctx* ctx, const float* entries, size_t n, int w, int h, float* out_entries,
+                                size_t* n_out) {
+    if (!ctx) return OFPS_HIP_EINVAL;
+    OFPS_REQUIRE(ctx, out_entries && n_out && (entries || n == 0), "densify_to_entries: null host pointer");
+    OFPS_REQUIRE(ctx, w >= 1 && h >= 1, "densify_to_entries: bad grid %dx%d", w, h);
+    OFPS_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t cells = (size_t)w * h;
+    auto* d_ent = static_cast<float4*>(ofps::scratch(ctx, ofps::S_ENTRIES, n * sizeof(float4)));
+    auto* d_field = static_cast<float2*>(ofps::scratch(ctx, ofps::S_FIELD, cells * sizeof(float2)));
+    auto* d_out = static_cast<float4*>(ofps::scratch(ctx, ofps::S_BEST, cells * sizeof(float4)));
+    auto* d_cnt = static_cast<uint32_t*>(ofps::scratch(ctx, ofps::S_RESULT, 16));
+    if (!d_ent || !d_field || !d_out || !d_cnt) return OFPS_HIP_ENOMEM;
+    if (n) OFPS_HIP_TRY(ctx, hipMemcpyAsync(d_ent, entries, n * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
+    uint32_t *begin = nullptr, *end = nullptr;
+    int rc = ofps::densify_device(ctx, d_ent, n, 1, w, h, d_field, nullptr, &begin, &end);
+    if (rc != OFPS_HIP_OK) return rc;
+    hipLaunchKernelGGL(ofps::cells_to_entries_kernel, dim3(1), dim3(1024), 0, ctx->stream, d_field, begin, end, w, h,
+                       d_out, d_cnt);
+    OFPS_HIP_TRY(ctx, hipGetLastError());
+    uint32_t cnt = 0;
+    OFPS_HIP_TRY(ctx, hipMemcpyAsync(&cnt, d_cnt, sizeof(cnt), hipMemcpyDeviceToHost, ctx->stream));
+    OFPS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (cnt) OFPS_HIP_TRY(ctx, hipMemcpy(out_entries, d_out, (size_t)cnt * sizeof(float4), hipMemcpyDeviceToHost));
+    *n_out = cnt;
+    return OFPS_HIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,356 @@
+// sad.hip -- N1: full-search SAD block matcher for gfx950 (the "hip_sad" Decoder's compute).
+//
+// No reference counterpart exists; the spec is include/ofps_hip.h /
+// DESIGN.md "N1" and the output record follows av-decoder/src/lib.rs:404-419.
+//
+// Kernel shape (sad_qsad_kernel):
+//   * one workgroup = 4 waves = 4 horizontally adjacent blocks; the (4B+2R) x (B+2R) search
+//     window of the previous frame is staged once in LDS with coalesced dword row loads;
+//   * one wave = one block.  The block of the current frame is wave-uniform, so it is read
+//     through the scalar cache into SGPRs and feeds v_qsad_pk_u16_u8 as its 32-bit operand;
+//   * a lane owns a (4 consecutive dx) x (K consecutive dy) patch of the candidate grid.  It
+//     walks B+K-1 window rows once, reading B/4+1 dwords per row from LDS, and issues one
+//     v_qsad_pk_u16_u8 per (row, 4-pixel column, dy) -- 16 absolute differences per lane-op,
+//     byte alignment of the 4 dx shifts handled by the instruction; costs accumulate as
+//     packed u16 (a 16x16 block's SAD <= 65280);
+//   * the LDS row stride S is chosen so that lane l = chunk*NG + group hits bank l mod 32:
+//     K*S == NG (mod 32) makes every ds_read_b32 conflict-free;
+//   * argmin: per-lane strict-< scan over its 4K candidates on a 32-bit key (SAD<<16 | d2),
+//     then a 64-bit (key, dy+R, dx+R) butterfly min over the wave.  The key is a total order,
+//     so the result is independent of the reduction order and bit-exact vs the scalar oracle.
+#include "common.hpp"
+
+namespace {
+
+constexpr int kWavesPerWG = 4;
+
+constexpr int pick_stride(int min_s, int k, int ng) {
+    // smallest S >= min_s with K*S == NG (mod 32); K odd guarantees a solution within 32 steps
+    for (int s = min_s; s < min_s + 64; ++s)
+        if ((k * s) % 32 == ng % 32) return s;
+    return min_s | 1;
+}
+
+template <int B, int R, int K>
+struct SadCfg {
+    static_assert(B % 4 == 0 && R % 4 == 0, "tile origin must stay dword aligned");
+    static_assert(B * B * 255 <= 65535, "packed u16 SAD accumulators would overflow");
+    static constexpr int NCAND = 2 * R + 1;
+    static constexpr int NG = (NCAND + 3) / 4;              // dx groups of 4
+    static constexpr int NC = (NCAND + K - 1) / K;          // dy chunks of K
+    static constexpr int T = NG * NC;                       // lane tasks per block
+    static constexpr int PASSES = (T + 63) / 64;
+    static constexpr int BW = B / 4;                        // dwords per block row
+    static constexpr int TILE_H = B + 2 * R;                // rows that hold image data
+    static constexpr int TILE_ROWS = NC * K + B - 1;        // rows the last chunk may touch
+    static constexpr int TILE_WD = (kWavesPerWG * B + 2 * R) / 4;
+    static constexpr int MAXCOL = (kWavesPerWG - 1) * BW + (NG - 1) + BW;
+    static constexpr int MIN_S = (MAXCOL + 1 > TILE_WD) ? MAXCOL + 1 : TILE_WD;
+    static constexpr int S = pick_stride(MIN_S, K, NG);
+    static constexpr int LDS_DWORDS = TILE_ROWS * S;
+};
+
+__device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v, int mask) {
+    unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
+    lo = __shfl_xor(lo, mask, 64);
+    hi = __shfl_xor(hi, mask, 64);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+struct __attribute__((packed, aligned(4))) U64A4 { unsigned long long v; };   // 8-byte LDS window, dword aligned
+
+struct SadParams {
+    const uint8_t* frames;
+    size_t frame_pitch;
+    int ref_mode;
+    int W, H, stride;
+    int nbx, nby;
+    float nx, ny;           // 1/W, 1/H computed on the host in f32 (av-decoder/src/lib.rs:404-405)
+    float4* out_entries;
+    int* out_best;          // may be null
+};
+
+__device__ __forceinline__ void write_block_result(const SadParams& p, int pair, int bx, int by, int B, int R,
+                                                   unsigned long long key) {
+    const int sad = (int)(key >> 48);
+    const int dy = (int)((key >> 8) & 0xFF) - R;
+    const int dx = (int)(key & 0xFF) - R;
+    const size_t k = ((size_t)pair * p.nby + by) * p.nbx + bx;
+    const float cx = (float)(bx * B + B / 2 + dx), cy = (float)(by * B + B / 2 + dy);
+    float4 e;
+    e.x = cx * p.nx;
+    e.y = cy * p.ny;
+    e.z = ((float)dx / 1.0f) * (-p.nx);
+    e.w = ((float)dy / 1.0f) * (-p.ny);
+    p.out_entries[k] = e;
+    if (p.out_best) {
+        p.out_best[3 * k + 0] = dx;
+        p.out_best[3 * k + 1] = dy;
+        p.out_best[3 * k + 2] = sad;
+    }
+}
+
+template <int B, int R, int K>
+__global__ __launch_bounds__(256) void sad_qsad_kernel(const SadParams p) {
+    using C = SadCfg<B, R, K>;
+    __shared__ uint32_t tile[C::LDS_DWORDS];
+
+    const int pair = blockIdx.z;
+    const uint8_t* __restrict__ prev = p.frames + (size_t)(p.ref_mode ? 0 : pair) * p.frame_pitch;
+    const uint8_t* __restrict__ cur = p.frames + (size_t)(pair + 1) * p.frame_pitch;
+    const int by = blockIdx.y;
+    const int bx0 = blockIdx.x * kWavesPerWG;
+    const int tid = threadIdx.x;
+
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int bx = bx0 + wave;
+    const int x0 = bx * B, y0 = by * B;
+
+    // ---- current block: wave-uniform address -> scalar loads, values live in SGPRs.  Issued
+    // before the window staging so their latency hides behind it.  Waves past the last block
+    // column (they exit after the barrier) read the last valid block instead of running off the row.
+    uint32_t c[B][C::BW];
+    {
+        const int bxc = bx < p.nbx ? bx : p.nbx - 1;
+        const uint32_t* __restrict__ cp = reinterpret_cast<const uint32_t*>(cur + (size_t)y0 * p.stride + bxc * B);
+        const int sdw = p.stride >> 2;
+#pragma unroll
+        for (int y = 0; y < B; ++y)
+#pragma unroll
+            for (int q = 0; q < C::BW; ++q) c[y][q] = cp[y * sdw + q];
+    }
+
+    // ---- stage the search window: coalesced dword loads along rows, guarded at the frame edge.
+    // Cells outside the frame stay unwritten: only candidates that are masked out below read them.
+    {
+        const int tx0 = bx0 * B - R, ty0 = by * B - R;
+        for (int idx = tid; idx < C::TILE_H * C::TILE_WD; idx += 256) {
+            const int row = idx / C::TILE_WD, col = idx - row * C::TILE_WD;
+            const int gx = tx0 + 4 * col, gy = ty0 + row;
+            if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W)
+                tile[row * C::S + col] = *reinterpret_cast<const uint32_t*>(prev + (size_t)gy * p.stride + gx);
+        }
+    }
+    __syncthreads();
+    if (bx >= p.nbx) return;
+
+    unsigned long long best = ~0ull;
+#pragma unroll 1
+    for (int pass = 0; pass < C::PASSES; ++pass) {
+        const int t = pass * 64 + lane;
+        const bool active = t < C::T;
+        const int tc = active ? t : 0;
+        const int chunk = tc / C::NG, g = tc - chunk * C::NG;
+        const int dx0 = -R + 4 * g, dy0 = -R + K * chunk;
+
+        unsigned long long acc[K];
+#pragma unroll
+        for (int i = 0; i < K; ++i) acc[i] = 0;
+
+        // Window rows are walked once.  hipcc's scheduler, left alone, hoists all B+K-1 rows of
+        // ds_reads to the top (170+ VGPRs, 2 waves/SIMD); the sched_group_barrier ladder below
+        // asks for "one row of LDS reads, then one row's worth of packed SADs" instead.
+        const uint32_t* trow = tile + (K * chunk) * C::S + wave * C::BW + g;
+#pragma unroll
+        for (int rr = 0; rr < B + K - 1; ++rr) {
+            // each 8-byte window is its own ds_read2_b32 straight into an even-aligned VGPR pair: LDS has
+            // the bandwidth to spare (v_qsad issues every 16 cycles), and building the odd windows from a
+            // 5-dword row with v_mov/v_pk_mov cost ~25% extra VALU issue slots.
+            unsigned long long win[C::BW];
+#pragma unroll
+            for (int q = 0; q < C::BW; ++q) win[q] = reinterpret_cast<const U64A4*>(trow + rr * C::S + q)->v;
+#pragma unroll
+            for (int i = 0; i < K; ++i) {
+                const int y = rr - i;
+                if (y >= 0 && y < B) {
+#pragma unroll
+                    for (int q = 0; q < C::BW; ++q) acc[i] = __builtin_amdgcn_qsad_pk_u16_u8(win[q], c[y][q], acc[i]);
+                }
+            }
+        }
+        // two rows of reads in flight ahead of the VALU work that consumes them
+        __builtin_amdgcn_sched_group_barrier(0x100, C::BW, 0);
+#pragma unroll
+        for (int rr = 0; rr < B + K - 1; ++rr) {
+            __builtin_amdgcn_sched_group_barrier(0x100, C::BW, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, K * C::BW, 0);
+        }
+
+        // keep the accumulate section one straight-line region: the empty asm pins the finished
+        // sums here, so the scan's control flow below cannot pull the packed SADs out of the ladder
+#pragma unroll
+        for (int i = 0; i < K; ++i) asm volatile("" : "+v"(acc[i]));
+
+        // ---- per-lane scan in (dy, dx) order with strict <: ties on (SAD, d2) keep the smaller (dy, dx)
+        uint32_t bkey = 0xFFFFFFFFu;
+        int bci = 0;
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+            const int dy = dy0 + i;
+            const int vy = (int)active & (int)(dy <= R) & (int)(y0 + dy >= 0) & (int)(y0 + dy + B <= p.H);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int dx = dx0 + j;
+                const int v = vy & (int)(dx <= R) & (int)(x0 + dx >= 0) & (int)(x0 + dx + B <= p.W);
+                // v is 0/1: (v - 1) is all-ones for a masked candidate -> key saturates to 0xFFFFFFFF
+                const uint32_t d2inv = (uint32_t)(dx * dx + dy * dy) | (uint32_t)(v - 1);
+                const uint32_t half = (j < 2) ? (uint32_t)acc[i] : (uint32_t)(acc[i] >> 32);
+                const uint32_t key = ((j & 1) ? (half & 0xFFFF0000u) : (half << 16)) | d2inv;
+                const bool lt = key < bkey;
+                bkey = lt ? key : bkey;
+                bci = lt ? (i * 4 + j) : bci;
+            }
+        }
+        if (bkey != 0xFFFFFFFFu) {
+            const int bi = bci >> 2, bj = bci & 3;
+            const unsigned long long k64 =
+                ((unsigned long long)bkey << 32) | (uint32_t)(((dy0 + bi + R) << 8) | (dx0 + bj + R));
+            best = k64 < best ? k64 : best;
+        }
+    }
+
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const unsigned long long o = shfl_xor_u64(best, m);
+        best = o < best ? o : best;
+    }
+    if (lane == 0) write_block_result(p, pair, bx, by, B, R, best);
+}
+
+// Generic kernel for block/range pairs the packed-SAD kernel does not cover: one wave per block,
+// lanes over candidates, bytes straight from global memory (L1/L2 absorb the reuse).  Slow path.
+__global__ __launch_bounds__(64) void sad_generic_kernel(const SadParams p, int B, int R) {
+    const int pair = blockIdx.z, by = blockIdx.y, bx = blockIdx.x;
+    const uint8_t* __restrict__ prev = p.frames + (size_t)(p.ref_mode ? 0 : pair) * p.frame_pitch;
+    const uint8_t* __restrict__ cur = p.frames + (size_t)(pair + 1) * p.frame_pitch;
+    const int x0 = bx * B, y0 = by * B, n = 2 * R + 1;
+    unsigned long long best = ~0ull;
+    for (int cand = threadIdx.x; cand < n * n; cand += 64) {
+        const int dy = cand / n - R, dx = cand % n - R;
+        if (x0 + dx < 0 || x0 + dx + B > p.W || y0 + dy < 0 || y0 + dy + B > p.H) continue;
+        uint32_t sad = 0;
+        for (int y = 0; y < B; ++y) {
+            const uint8_t* cr = cur + (size_t)(y0 + y) * p.stride + x0;
+            const uint8_t* pr = prev + (size_t)(y0 + dy + y) * p.stride + x0 + dx;
+            for (int x = 0; x < B; ++x) {
+                const int d = (int)cr[x] - (int)pr[x];
+                sad += (uint32_t)(d < 0 ? -d : d);
+            }
+        }
+        // same total order as the packed kernel; SAD can exceed 16 bits here, so use a wider layout
+        const unsigned long long key = ((unsigned long long)sad << 32) | ((unsigned long long)(dx * dx + dy * dy) << 16) |
+                                       (unsigned long long)(((dy + R) << 8) | (dx + R));
+        best = key < best ? key : best;
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const unsigned long long o = shfl_xor_u64(best, m);
+        best = o < best ? o : best;
+    }
+    if (threadIdx.x == 0) {
+        const int sad = (int)(best >> 32);
+        const int dy = (int)((best >> 8) & 0xFF) - R, dx = (int)(best & 0xFF) - R;
+        const size_t k = ((size_t)pair * p.nby + by) * p.nbx + bx;
+        float4 e;
+        e.x = (float)(x0 + B / 2 + dx) * p.nx;
+        e.y = (float)(y0 + B / 2 + dy) * p.ny;
+        e.z = ((float)dx / 1.0f) * (-p.nx);
+        e.w = ((float)dy / 1.0f) * (-p.ny);
+        p.out_entries[k] = e;
+        if (p.out_best) {
+            p.out_best[3 * k + 0] = dx;
+            p.out_best[3 * k + 1] = dy;
+            p.out_best[3 * k + 2] = sad;
+        }
+    }
+}
+
+template <int B, int R, int K>
+void launch_qsad(const SadParams& p, int pairs, hipStream_t s) {
+    dim3 grid((p.nbx + kWavesPerWG - 1) / kWavesPerWG, p.nby, pairs);
+    hipLaunchKernelGGL((sad_qsad_kernel<B, R, K>), grid, dim3(256), 0, s, p);
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t ofps_hip_sad_block_count(int W, int H, int block) {
+    if (W <= 0 || H <= 0 || block <= 0) return 0;
+    return (size_t)(W / block) * (size_t)(H / block);
+}
+
+int ofps_hip_sad_flow_dev(ofps_hip_ctx* ctx, const void* d_frames, int n_frames, int W, int H, int stride,
+                          size_t frame_pitch, int ref_mode, int block, int range, void* d_out_entries,
+                          void* d_out_best) {
+    if (!ctx) return OFPS_HIP_EINVAL;
+    OFPS_REQUIRE(ctx, d_frames && d_out_entries, "sad_flow: null device pointer");
+    OFPS_REQUIRE(ctx, n_frames >= 2, "sad_flow: need at least 2 frames (got %d)", n_frames);
+    OFPS_REQUIRE(ctx, W > 0 && H > 0 && stride >= W, "sad_flow: bad geometry W=%d H=%d stride=%d", W, H, stride);
+    OFPS_REQUIRE(ctx, stride % 4 == 0 && ((uintptr_t)d_frames % 4) == 0 && frame_pitch % 4 == 0,
+                 "sad_flow: rows must be 4-byte aligned (stride=%d)", stride);
+    OFPS_REQUIRE(ctx, frame_pitch >= (size_t)stride * (size_t)H, "sad_flow: frame_pitch smaller than a frame");
+    OFPS_REQUIRE(ctx, block >= 1 && block <= 64 && range >= 0 && range <= 64,
+                 "sad_flow: block=%d range=%d outside [1,64]/[0,64]", block, range);
+    OFPS_REQUIRE(ctx, ref_mode == 0 || ref_mode == 1, "sad_flow: ref_mode must be 0 or 1");
+    SadParams p;
+    p.frames = static_cast<const uint8_t*>(d_frames);
+    p.frame_pitch = frame_pitch;
+    p.ref_mode = ref_mode;
+    p.W = W; p.H = H; p.stride = stride;
+    p.nbx = W / block; p.nby = H / block;
+    p.nx = 1.0f / (float)W; p.ny = 1.0f / (float)H;
+    p.out_entries = static_cast<float4*>(d_out_entries);
+    p.out_best = static_cast<int*>(d_out_best);
+    const int pairs = n_frames - 1;
+    if (p.nbx == 0 || p.nby == 0) return OFPS_HIP_OK;
+    OFPS_REQUIRE(ctx, pairs <= 65535 && p.nby <= 65535, "sad_flow: grid too large");
+    OFPS_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const int key = block * 1000 + range;
+    switch (key) {
+        case 16016: launch_qsad<16, 16, 5>(p, pairs, s); break;
+        case 16008: launch_qsad<16, 8, 3>(p, pairs, s); break;
+        case 16032: launch_qsad<16, 32, 5>(p, pairs, s); break;
+        case 8032: launch_qsad<8, 32, 5>(p, pairs, s); break;
+        case 8016: launch_qsad<8, 16, 5>(p, pairs, s); break;
+        case 8008: launch_qsad<8, 8, 3>(p, pairs, s); break;
+        default: {
+            dim3 grid(p.nbx, p.nby, pairs);
+            hipLaunchKernelGGL(sad_generic_kernel, grid, dim3(64), 0, s, p, block, range);
+        }
+    }
+    OFPS_HIP_TRY(ctx, hipGetLastError());
+    return OFPS_HIP_OK;
+}
+
+int ofps_hip_sad_flow(ofps_hip_ctx* ctx, const uint8_t* prev, const uint8_t* cur, int W, int H, int stride,
+                      int block, int range, float* out_entries, int32_t* out_best, size_t* n_out) {
+    if (!ctx) return OFPS_HIP_EINVAL;
+    OFPS_REQUIRE(ctx, prev && cur && out_entries, "sad_flow: null host pointer");
+    OFPS_REQUIRE(ctx, W > 0 && H > 0 && stride >= W && block >= 1, "sad_flow: bad geometry");
+    OFPS_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    // repack to a 64-byte-multiple device stride so any host stride is accepted
+    const int dstride = (W + 63) & ~63;
+    const size_t pitch = (size_t)dstride * H;
+    const size_t nblk = ofps_hip_sad_block_count(W, H, block);
+    auto* d_frames = static_cast<uint8_t*>(ofps::scratch(ctx, ofps::S_FRAMES, 2 * pitch));
+    auto* d_ent = static_cast<float*>(ofps::scratch(ctx, ofps::S_ENTRIES, nblk * 4 * sizeof(float)));
+    auto* d_best = static_cast<int32_t*>(ofps::scratch(ctx, ofps::S_BEST, nblk * 3 * sizeof(int32_t)));
+    if (!d_frames || !d_ent || !d_best) return OFPS_HIP_ENOMEM;
+    OFPS_HIP_TRY(ctx, hipMemcpy2DAsync(d_frames, dstride, prev, stride, W, H, hipMemcpyHostToDevice, ctx->stream));
+    OFPS_HIP_TRY(ctx, hipMemcpy2DAsync(d_frames + pitch, dstride, cur, stride, W, H, hipMemcpyHostToDevice, ctx->stream));
+    int rc = ofps_hip_sad_flow_dev(ctx, d_frames, 2, W, H, dstride, pitch, 0, block, range, d_ent, d_best);
+    if (rc != OFPS_HIP_OK) return rc;
+    if (nblk) {
+        OFPS_HIP_TRY(ctx, hipMemcpyAsync(out_entries, d_ent, nblk * 4 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+        if (out_best)
+            OFPS_HIP_TRY(ctx, hipMemcpyAsync(out_best, d_best, nblk * 3 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    }
+    OFPS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (n_out) *n_out = nblk;
+    return OFPS_HIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,147 @@
+"""Thin Python front-end over the C ABI (include/ofps_hip.h): context handling plus numpy and
+device-pointer call wrappers.  All compute happens in libofps_hip.so; nothing here has a CPU path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import OfpsHipError
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+class HipContext:
+    """One ofps_hip_ctx (one per plugin instance, ofps/src/plugins/mod.rs:244-278 'Send, not Sync')."""
+
+    def __init__(self, device: int = 0):
+        self._lib = _lib.load()
+        h = C.c_void_p()
+        rc = self._lib.ofps_hip_init(device, C.byref(h))
+        if rc != 0:
+            raise OfpsHipError(rc, (self._lib.ofps_hip_last_error(None) or b"").decode())
+        self._h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.ofps_hip_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int):
+        if rc != 0:
+            raise OfpsHipError(rc, (self._lib.ofps_hip_last_error(self._h) or b"").decode())
+
+    # ---- plumbing
+    def set_stream(self, stream_ptr: int):
+        """Enqueue on a caller-owned hipStream_t; 0 is HIP's default stream (torch's default)."""
+        self._check(self._lib.ofps_hip_set_stream(self._h, C.c_void_p(stream_ptr)))
+
+    def use_own_stream(self):
+        self._check(self._lib.ofps_hip_use_own_stream(self._h))
+
+    def use_torch_stream(self):
+        import torch
+        self.set_stream(torch.cuda.current_stream().cuda_stream)
+
+    def sync(self):
+        self._check(self._lib.ofps_hip_sync(self._h))
+
+    def timer_start(self):
+        self._check(self._lib.ofps_hip_timer_start(self._h))
+
+    def timer_stop(self) -> float:
+        ms = C.c_float(0)
+        self._check(self._lib.ofps_hip_timer_stop(self._h, C.byref(ms)))
+        return float(ms.value)
+
+    # ---- N1
+    def sad_flow(self, prev: np.ndarray, cur: np.ndarray, block: int, search_range: int, want_best=False):
+        prev = np.ascontiguousarray(prev, np.uint8); cur = np.ascontiguousarray(cur, np.uint8)
+        assert prev.shape == cur.shape and prev.ndim == 2
+        H, W = prev.shape
+        nb = int(self._lib.ofps_hip_sad_block_count(W, H, block))
+        ent = np.zeros((max(nb, 1), 4), np.float32)
+        best = np.zeros((max(nb, 1), 3), np.int32)
+        n_out = C.c_size_t(0)
+        u8 = C.POINTER(C.c_uint8)
+        self._check(self._lib.ofps_hip_sad_flow(self._h, prev.ctypes.data_as(u8), cur.ctypes.data_as(u8), W, H, W,
+                                                block, search_range, _fp(ent),
+                                                best.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(n_out)))
+        assert n_out.value == nb
+        return (ent[:nb], best[:nb]) if want_best else ent[:nb]
+
+    def sad_flow_dev(self, d_frames: int, n_frames: int, W: int, H: int, stride: int, frame_pitch: int, ref_mode: int,
+                     block: int, search_range: int, d_out_entries: int, d_out_best: int | None = None):
+        self._check(self._lib.ofps_hip_sad_flow_dev(self._h, C.c_void_p(d_frames), n_frames, W, H, stride, frame_pitch,
+                                                    ref_mode, block, search_range, C.c_void_p(d_out_entries),
+                                                    C.c_void_p(d_out_best or 0)))
+
+    # ---- A1-A4
+    def densify(self, entries, w: int, h: int, want_cells=False):
+        e = np.ascontiguousarray(entries, np.float32).reshape(-1, 4)
+        n = e.shape[0]
+        field = np.zeros((h, w, 2), np.float32)
+        cells = np.zeros((max(n, 1), 2), np.uint32) if want_cells else None
+        self._check(self._lib.ofps_hip_densify(self._h, _fp(e), n, w, h, _fp(field),
+                                               cells.ctypes.data_as(C.POINTER(C.c_uint32)) if want_cells else None))
+        return (field, cells[:n]) if want_cells else field
+
+    def densify_dev(self, d_entries: int, n_per_item: int, batch: int, w: int, h: int, d_out_field: int,
+                    d_out_cells: int | None = None):
+        self._check(self._lib.ofps_hip_densify_dev(self._h, C.c_void_p(d_entries), n_per_item, batch, w, h,
+                                                   C.c_void_p(d_out_field), C.c_void_p(d_out_cells or 0)))
+
+    def densify_to_entries(self, entries, w: int, h: int) -> np.ndarray:
+        e = np.ascontiguousarray(entries, np.float32).reshape(-1, 4)
+        out = np.zeros((w * h, 4), np.float32)
+        n_out = C.c_size_t(0)
+        self._check(self._lib.ofps_hip_densify_to_entries(self._h, _fp(e), e.shape[0], w, h, _fp(out), C.byref(n_out)))
+        return out[:n_out.value].copy()
+
+    # ---- A5
+    def block_dim(self, min_size: float, subdivide: int) -> int:
+        return int(self._lib.ofps_hip_block_dim(min_size, subdivide))
+
+    def detect(self, entries, min_size=0.05, subdivide=3, target_motion=0.003):
+        e = np.ascontiguousarray(entries, np.float32).reshape(-1, 4)
+        dim = self.block_dim(min_size, subdivide)
+        field = np.zeros((max(dim, 1), max(dim, 1), 2), np.float32)
+        has = C.c_int(0); area = C.c_size_t(0); odim = C.c_int(0)
+        self._check(self._lib.ofps_hip_detect(self._h, _fp(e), e.shape[0], min_size, subdivide, target_motion,
+                                              C.byref(has), C.byref(area), C.byref(odim), _fp(field)))
+        return (int(area.value), field) if has.value else None
+
+    def detect_dev(self, d_entries: int, n_per_item: int, batch: int, min_size: float, subdivide: int,
+                   target_motion: float, d_out_result: int, d_out_field: int):
+        self._check(self._lib.ofps_hip_detect_dev(self._h, C.c_void_p(d_entries), n_per_item, batch, min_size, subdivide,
+                                                  target_motion, C.c_void_p(d_out_result), C.c_void_p(d_out_field)))
+
+    # ---- A6-A12
+    def almeida(self, entries, aspect: float, fov_y_deg: float, use_ransac=False, num_iters=200, inlier_deg=0.05,
+                num_samples=1000, seed=0):
+        e = np.ascontiguousarray(entries, np.float32).reshape(-1, 4)
+        q = np.zeros(4, np.float32); tr = np.zeros(3, np.float32)
+        self._check(self._lib.ofps_hip_almeida(self._h, _fp(e), e.shape[0], aspect, fov_y_deg, int(use_ransac),
+                                               num_iters, inlier_deg, num_samples, seed, _fp(q), _fp(tr)))
+        return q, tr
+
+    def almeida_dev(self, d_entries: int, n_per_item: int, batch: int, aspect: float, fov_y_deg: float,
+                    use_ransac: bool, num_iters: int, inlier_deg: float, num_samples: int, seed: int, d_out_quat: int):
+        self._check(self._lib.ofps_hip_almeida_dev(self._h, C.c_void_p(d_entries), n_per_item, batch, aspect, fov_y_deg,
+                                                   int(use_ransac), num_iters, inlier_deg, num_samples, seed,
+                                                   C.c_void_p(d_out_quat)))
+
+
+def device_count() -> int:
+    return int(_lib.load().ofps_hip_device_count())

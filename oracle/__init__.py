@@ -74,6 +74,8 @@ def lib():
         L.orc_sad_flow.argtypes = [C.POINTER(C.c_uint8), C.POINTER(C.c_uint8), C.c_int, C.c_int, C.c_int,
                                    C.c_int, C.c_int, fp, C.POINTER(C.c_int32), C.c_int]
         L.orc_sad_flow.restype = C.c_size_t
+        L.orc_sad_flow_ex.argtypes = L.orc_sad_flow.argtypes + [C.c_int]
+        L.orc_sad_flow_ex.restype = C.c_size_t
         L.orc_num_threads.restype = C.c_int
         _lib = L
     return _lib
@@ -224,7 +226,7 @@ def sample_index(seed, it, stream, i, n) -> int:
     return int(lib().orc_sample_index(seed, it, stream, i, n))
 
 
-def sad_flow(prev, cur, B: int, R: int, threads: int = 1, stride=None):
+def sad_flow(prev, cur, B: int, R: int, threads: int = 1, stride=None, simd: bool = True):
     """-> (entries[nblk,4] f32, best[nblk,3] int32 (dx,dy,sad))"""
     prev = np.ascontiguousarray(prev, np.uint8); cur = np.ascontiguousarray(cur, np.uint8)
     H, Wp = prev.shape
@@ -233,8 +235,8 @@ def sad_flow(prev, cur, B: int, R: int, threads: int = 1, stride=None):
     nb = (W // B) * (H // B)
     ent = np.zeros((max(nb, 1), 4), np.float32); best = np.zeros((max(nb, 1), 3), np.int32)
     u8 = C.POINTER(C.c_uint8)
-    k = lib().orc_sad_flow(prev.ctypes.data_as(u8), cur.ctypes.data_as(u8), W, H, st, B, R,
-                           _fp(ent), best.ctypes.data_as(C.POINTER(C.c_int32)), threads)
+    k = lib().orc_sad_flow_ex(prev.ctypes.data_as(u8), cur.ctypes.data_as(u8), W, H, st, B, R,
+                              _fp(ent), best.ctypes.data_as(C.POINTER(C.c_int32)), threads, int(simd))
     assert k == nb
     return ent[:nb], best[:nb]
 

@@ -2,7 +2,7 @@
  * ofps_oracle.c -- CPU restatement of the OFPS flow hot path.  TEST INFRASTRUCTURE ONLY:
  * see ofps_oracle.h for who may call this and for the parity status of every function.
  *
- * Build: gcc -O2 -ffp-contract=off -fno-fast-math (see oracle/Makefile).  Contraction must
+ * Build: gcc -O3 -ffp-contract=off -fno-fast-math (see oracle/Makefile).  Contraction must
  * stay off: the Rust reference never fuses a*b+c, and neither may this file.
  *
  * All arithmetic is f32 and follows the operation order of the Rust source / nalgebra 0.30
@@ -17,15 +17,14 @@
 #ifdef _OPENMP
 #include <omp.h>
 #endif
+#if defined(__SSE2__)
+#include <emmintrin.h>
+#endif
 
 /* f32::to_radians: self * (PI / 180) with the ratio folded in f32 (Rust core). */
 static float to_radians(float deg) {
     const float k = 3.14159265358979323846264338327950288f / 180.0f;
     return deg * k;
-}
-static float to_degrees(float rad) {
-    const float k = 57.2957795130823208767981548141051703f;
-    return rad * k;
 }
 
 /* ------------------------------------------------------------------------------------ */
@@ -676,8 +675,37 @@ void orc_solve_ypr_ransac(const float* entries, size_t n, const orc_camera* cam,
 /* N1: full-search SAD block matcher (build-defined; no reference counterpart)           */
 /* ------------------------------------------------------------------------------------ */
 
+/* SAD of one candidate.  The scalar loop is the definition; the SSE2 psadbw path (B = 8 or 16) is an
+ * exact integer shortcut used to give the timed CPU baseline a fair inner loop. */
+static uint32_t sad_candidate(const uint8_t* c, const uint8_t* p, int stride, int B, int simd) {
+#if defined(__SSE2__)
+    if (simd && B == 16) {
+        __m128i acc = _mm_setzero_si128();
+        for (int y = 0; y < 16; ++y)
+            acc = _mm_add_epi64(acc, _mm_sad_epu8(_mm_loadu_si128((const __m128i*)(c + (size_t)y * stride)),
+                                                  _mm_loadu_si128((const __m128i*)(p + (size_t)y * stride))));
+        return (uint32_t)(_mm_cvtsi128_si32(acc) + _mm_cvtsi128_si32(_mm_srli_si128(acc, 8)));
+    }
+    if (simd && B == 8) {
+        __m128i acc = _mm_setzero_si128();
+        for (int y = 0; y < 8; ++y)
+            acc = _mm_add_epi64(acc, _mm_sad_epu8(_mm_loadl_epi64((const __m128i*)(c + (size_t)y * stride)),
+                                                  _mm_loadl_epi64((const __m128i*)(p + (size_t)y * stride))));
+        return (uint32_t)_mm_cvtsi128_si32(acc);
+    }
+#endif
+    (void)simd;
+    uint32_t sad = 0;
+    for (int y = 0; y < B; ++y) {
+        const uint8_t* cr = c + (size_t)y * stride;
+        const uint8_t* pr = p + (size_t)y * stride;
+        for (int x = 0; x < B; ++x) sad += (uint32_t)abs((int)cr[x] - (int)pr[x]);
+    }
+    return sad;
+}
+
 static void sad_block_row(const uint8_t* prev, const uint8_t* cur, int W, int H, int stride,
-                          int B, int R, int by, int nbx, float* out_entries, int32_t* out_best) {
+                          int B, int R, int by, int nbx, float* out_entries, int32_t* out_best, int simd) {
     const float nx = 1.0f / (float)W, ny = 1.0f / (float)H;          /* av-decoder/src/lib.rs:404-405 */
     for (int bx = 0; bx < nbx; ++bx) {
         int x0 = bx * B, y0 = by * B;
@@ -686,12 +714,8 @@ static void sad_block_row(const uint8_t* prev, const uint8_t* cur, int W, int H,
             if (y0 + dy < 0 || y0 + dy + B > H) continue;
             for (int dx = -R; dx <= R; ++dx) {
                 if (x0 + dx < 0 || x0 + dx + B > W) continue;
-                uint32_t sad = 0;
-                for (int y = 0; y < B; ++y) {
-                    const uint8_t* c = cur + (size_t)(y0 + y) * stride + x0;
-                    const uint8_t* p = prev + (size_t)(y0 + dy + y) * stride + x0 + dx;
-                    for (int x = 0; x < B; ++x) sad += (uint32_t)abs((int)c[x] - (int)p[x]);
-                }
+                uint32_t sad = sad_candidate(cur + (size_t)y0 * stride + x0,
+                                             prev + (size_t)(y0 + dy) * stride + x0 + dx, stride, B, simd);
                 uint64_t key = ((uint64_t)sad << 32) | ((uint64_t)(uint32_t)(dx * dx + dy * dy) << 16) |
                                ((uint64_t)(uint32_t)(dy + R) << 8) | (uint64_t)(uint32_t)(dx + R);
                 if (key < best_key) { best_key = key; best_dx = dx; best_dy = dy; best_sad = sad; }
@@ -709,17 +733,22 @@ static void sad_block_row(const uint8_t* prev, const uint8_t* cur, int W, int H,
 
 size_t orc_sad_flow(const uint8_t* prev, const uint8_t* cur, int W, int H, int stride,
                     int B, int R, float* out_entries, int32_t* out_best, int threads) {
+    return orc_sad_flow_ex(prev, cur, W, H, stride, B, R, out_entries, out_best, threads, 1);
+}
+
+size_t orc_sad_flow_ex(const uint8_t* prev, const uint8_t* cur, int W, int H, int stride,
+                       int B, int R, float* out_entries, int32_t* out_best, int threads, int simd) {
     int nbx = W / B, nby = H / B;
     if (R > 127) return 0;          /* key packing above holds dy+R, dx+R in 8 bits */
     (void)threads;
 #ifdef _OPENMP
     if (threads > 1) {
 #pragma omp parallel for schedule(dynamic, 1) num_threads(threads)
-        for (int by = 0; by < nby; ++by) sad_block_row(prev, cur, W, H, stride, B, R, by, nbx, out_entries, out_best);
+        for (int by = 0; by < nby; ++by) sad_block_row(prev, cur, W, H, stride, B, R, by, nbx, out_entries, out_best, simd);
         return (size_t)nbx * (size_t)nby;
     }
 #endif
-    for (int by = 0; by < nby; ++by) sad_block_row(prev, cur, W, H, stride, B, R, by, nbx, out_entries, out_best);
+    for (int by = 0; by < nby; ++by) sad_block_row(prev, cur, W, H, stride, B, R, by, nbx, out_entries, out_best, simd);
     return (size_t)nbx * (size_t)nby;
 }
 

@@ -108,6 +108,10 @@ uint32_t orc_sample_index(uint64_t seed, uint32_t iter, uint32_t stream, uint32_
 size_t orc_sad_flow(const uint8_t* prev, const uint8_t* cur, int W, int H, int stride,
                     int B, int R, float* out_entries, int32_t* out_best, int threads);
 
+/* simd = 0 forces the scalar definition loop; simd = 1 allows the exact SSE2 psadbw shortcut. */
+size_t orc_sad_flow_ex(const uint8_t* prev, const uint8_t* cur, int W, int H, int stride,
+                       int B, int R, float* out_entries, int32_t* out_best, int threads, int simd);
+
 int orc_num_threads(void);
 
 #ifdef __cplusplus

@@ -1,0 +1,303 @@
+"""-m gpu parity tests: the HIP path (through the C ABI) against the CPU oracle on the same seeded
+inputs.  Bit-exact for integer/index work; floats to the tolerance written next to each check
+(north_star: 1e-4 on float (u,v); most checks here are far tighter).
+"""
+import numpy as np
+import pytest
+
+import oracle
+from ofps_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from ofps_amd.runtime import HipContext
+    c = HipContext(0)
+    yield c
+    c.close()
+
+
+# ------------------------------------------------------------------ N1: SAD block matcher
+SAD_CASES = [
+    # (W, H, B, R, kind)
+    (640, 360, 16, 8, "seq"),      # BASELINE configs[0] geometry
+    (256, 144, 16, 16, "seq"),
+    (320, 200, 8, 16, "seq"),
+    (256, 136, 8, 32, "seq"),
+    (256, 128, 16, 32, "seq"),
+    (200, 120, 8, 8, "seq"),       # width not a multiple of 64 / of 4 blocks per workgroup
+    (100, 70, 16, 16, "seq"),      # ragged: partial blocks dropped, W % 4 == 0 but W % 16 != 0
+    (192, 96, 16, 16, "random"),   # unstructured noise: many near-ties
+    (192, 96, 16, 16, "flat"),     # constant frames: every candidate ties at SAD 0 -> key order decides
+    (96, 96, 12, 5, "seq"),        # generic kernel (block/range outside the packed-SAD table)
+    (64, 48, 32, 4, "seq"),        # generic kernel, SAD beyond 16 bits possible
+]
+
+
+def _frames(W, H, R, kind):
+    if kind == "seq":
+        return synth.luma_sequence(2, W, H, max_step=R, seed=synth.SEED0 + W + H)
+    if kind == "random":
+        return synth.random_luma(2, W, H, seed=7)
+    return np.full((2, H, W), 77, np.uint8)
+
+
+@pytest.mark.parametrize("W,H,B,R,kind", SAD_CASES)
+def test_sad_matches_oracle_bit_exact(ctx, W, H, B, R, kind):
+    fr = _frames(W, H, R, kind)
+    ent_o, best_o = oracle.sad_flow(fr[0], fr[1], B, R)
+    ent_g, best_g = ctx.sad_flow(fr[0], fr[1], B, R, want_best=True)
+    assert best_g.shape == best_o.shape
+    np.testing.assert_array_equal(best_g, best_o)           # (dx, dy, SAD): integers, exact
+    np.testing.assert_array_equal(ent_g.view(np.uint32), ent_o.view(np.uint32))   # f32 records: same bits
+
+
+def test_sad_planted_displacement_recovered(ctx):
+    """Size-independent property at full 1080p: a frame shifted by an integer vector must come back
+    as that vector for every interior block (SAD 0 there), bit-exact positions."""
+    W, H, B, R = 1920, 1080, 16, 16
+    base = synth.luma_sequence(1, W + 64, H + 64, max_step=0, noise=0, seed=99)[0]
+    dx, dy = 7, -11
+    prev = np.ascontiguousarray(base[32:32 + H, 32:32 + W])
+    cur = np.ascontiguousarray(base[32 + dy:32 + dy + H, 32 + dx:32 + dx + W])   # cur(x,y) = prev(x+dx, y+dy)
+    ent, best = ctx.sad_flow(prev, cur, B, R, want_best=True)
+    nbx, nby = W // B, H // B
+    best = best.reshape(nby, nbx, 3)
+    inner = best[1:-1, 1:-1]
+    assert (inner[..., 0] == dx).all() and (inner[..., 1] == dy).all() and (inner[..., 2] == 0).all()
+    ent = ent.reshape(nby, nbx, 4)
+    np.testing.assert_array_equal(ent[1:-1, 1:-1, 2], np.float32(dx) * -np.float32(np.float32(1.0) / np.float32(W)))
+
+
+def test_sad_identical_frames_zero_motion(ctx):
+    fr = synth.luma_sequence(1, 640, 360, max_step=0)[0]
+    _, best = ctx.sad_flow(fr, fr, 16, 16, want_best=True)
+    assert (best == 0).all()
+
+
+def test_sad_batched_device_path_matches_pairwise(ctx):
+    """Batched device entry point (what bench.py times) == per-pair host entry point."""
+    import torch
+    W, H, B, R, F = 320, 192, 16, 16, 4
+    fr = synth.luma_sequence(F, W, H, max_step=R)
+    d = torch.from_numpy(fr).cuda()
+    nb = (W // B) * (H // B)
+    ctx.use_torch_stream()
+    for ref_mode in (0, 1):
+        out = torch.zeros((F - 1, nb, 4), dtype=torch.float32, device="cuda")
+        best = torch.zeros((F - 1, nb, 3), dtype=torch.int32, device="cuda")
+        ctx.sad_flow_dev(d.data_ptr(), F, W, H, W, W * H, ref_mode, B, R, out.data_ptr(), best.data_ptr())
+        torch.cuda.synchronize()
+        for k in range(F - 1):
+            prev = fr[0] if ref_mode else fr[k]
+            _, bo = oracle.sad_flow(prev, fr[k + 1], B, R)
+            np.testing.assert_array_equal(best[k].cpu().numpy(), bo)
+    ctx.use_own_stream()
+
+
+def test_sad_rejects_bad_arguments(ctx):
+    from ofps_amd.runtime import OfpsHipError
+    fr = np.zeros((32, 32), np.uint8)
+    with pytest.raises(OfpsHipError):
+        ctx.sad_flow(fr, fr, 0, 8)
+    with pytest.raises(OfpsHipError):
+        ctx.sad_flow(fr, fr, 16, 100)
+
+
+# ------------------------------------------------------------------ A1-A4: densifier
+def _entries(n, seed, lo=0.0, hi=1.0):
+    rng = np.random.default_rng(seed)
+    e = np.empty((n, 4), np.float32)
+    e[:, :2] = rng.uniform(lo, hi, (n, 2)).astype(np.float32)
+    e[:, 2:] = rng.normal(0, 0.01, (n, 2)).astype(np.float32)
+    return e
+
+
+@pytest.mark.parametrize("n,w,h", [(1000, 14, 14), (1000, 150, 84), (8040, 14, 14), (50000, 160, 160),
+                                   (1, 3, 3), (0, 4, 4), (5000, 1, 1), (3000, 256, 1), (70000, 16, 16)])
+def test_densify_bit_exact(ctx, n, w, h):
+    e = _entries(n, 100 + n + w)
+    f_o, c_o = oracle.densify(e, w, h, want_cells=True)
+    f_g, c_g = ctx.densify(e, w, h, want_cells=True)
+    np.testing.assert_array_equal(c_g, c_o)                               # cell indices: exact
+    np.testing.assert_array_equal(f_g.view(np.uint32), f_o.view(np.uint32))   # input-order sums: same bits
+
+
+def test_densify_out_of_range_and_nan_positions(ctx):
+    """nalgebra clamp quirk (semantics unverified against the Rust build): any coordinate
+    <= 0 collapses the point to (0,0), any >= 1 to (1,1); NaN -> (0,0)."""
+    e = _entries(64, 5, -0.5, 1.5)
+    e[0, :2] = (np.nan, 0.5); e[1, :2] = (0.5, np.nan); e[2, :2] = (0.0, 0.5); e[3, :2] = (1.0, 0.2)
+    e[4, :2] = (np.inf, 0.5); e[5, :2] = (-np.inf, 0.5); e[6, :2] = (0.999999, 0.999999)
+    f_o, c_o = oracle.densify(e, 14, 9, want_cells=True)
+    f_g, c_g = ctx.densify(e, 14, 9, want_cells=True)
+    np.testing.assert_array_equal(c_g, c_o)
+    np.testing.assert_array_equal(f_g.view(np.uint32), f_o.view(np.uint32))
+
+
+def test_densify_per_pixel_entries(ctx):
+    """cv-decoder full-res shape (scaled): every pixel contributes, 150x84 grid."""
+    e = synth.rotation_field(480, 270)
+    f_o = oracle.densify(e, 150, 84)
+    f_g = ctx.densify(e, 150, 84)
+    np.testing.assert_array_equal(f_g.view(np.uint32), f_o.view(np.uint32))
+    out_o = oracle.densify_to_entries(e, 150, 84)
+    out_g = ctx.densify_to_entries(e, 150, 84)
+    np.testing.assert_array_equal(out_g.view(np.uint32), out_o.view(np.uint32))
+
+
+# ------------------------------------------------------------------ A5: detector
+def _island_entries(dim, cells_on, mag=0.01, per_cell=3, seed=0):
+    """Entries landing exactly in chosen cells of a dim x dim grid."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for (x, y) in cells_on:
+        for _ in range(per_cell):
+            px = (x + rng.uniform(-0.2, 0.2)) / (dim - 1); py = (y + rng.uniform(-0.2, 0.2)) / (dim - 1)
+            out.append((min(max(px, 1e-4), 1 - 1e-4), min(max(py, 1e-4), 1 - 1e-4), mag, 0.0))
+    # background: one still vector in every cell
+    for y in range(dim):
+        for x in range(dim):
+            out.append((min(max(x / (dim - 1), 1e-4), 1 - 1e-4), min(max(y / (dim - 1), 1e-4), 1 - 1e-4), 0.0, 0.0))
+    return np.array(out, np.float32)
+
+
+def _check_detect(ctx, e, **kw):
+    r_o = oracle.detect_motion(e, **kw)
+    r_g = ctx.detect(e, **kw)
+    if r_o is None:
+        assert r_g is None
+        return None
+    assert r_g is not None
+    assert r_g[0] == r_o[0]                                               # area: exact
+    np.testing.assert_array_equal((r_g[1] != 0).any(-1), (r_o[1] != 0).any(-1))   # membership: exact
+    np.testing.assert_array_equal(r_g[1].view(np.uint32), r_o[1].view(np.uint32))
+    return r_g
+
+
+def test_detect_default_params_random_field(ctx):
+    for seed in range(6):
+        e = _entries(8040, 300 + seed)
+        e[:, 2:] *= np.float32(30.0 if seed % 2 else 0.3)
+        _check_detect(ctx, e)
+
+
+def test_detect_seed_cell_omitted_and_tie_break(ctx):
+    dim = oracle.block_dim(0.05, 3)
+    assert dim == 14 == ctx.block_dim(0.05, 3)
+    # two islands of equal area 12: the first in raster order must win; its seed cell stays zero
+    a = [(x, 2) for x in range(1, 7)] + [(x, 3) for x in range(1, 7)]
+    b = [(x, 9) for x in range(5, 11)] + [(x, 10) for x in range(5, 11)]
+    e = _island_entries(dim, a + b, mag=0.05)
+    r = _check_detect(ctx, e)
+    assert r is not None and r[0] == 12
+    assert (r[1][2, 1] == 0).all() and (r[1][2, 2] != 0).any()           # seed (1,2) omitted
+    assert (r[1][9:11] == 0).all()                                        # second island not returned
+
+
+def test_detect_min_size_boundary(ctx):
+    dim = 14
+    # area 9 of 196 = 0.0459 < 0.05 -> None ; area 10 = 0.051 -> Some
+    nine = [(x, y) for x in range(3) for y in range(3)]
+    assert _check_detect(ctx, _island_entries(dim, nine, mag=0.05)) is None
+    ten = nine + [(3, 0)]
+    r = _check_detect(ctx, _island_entries(dim, ten, mag=0.05))
+    assert r is not None and r[0] == 10
+
+
+def test_detect_diagonal_connectivity_and_large_grid(ctx):
+    # min_size 0.01, subdivide 16 -> dim 160 (largest grid the properties allow)
+    dim = oracle.block_dim(0.01, 16)
+    assert dim == 160
+    diag = [(i, i) for i in range(10, 90)] + [(i + 1, i) for i in range(10, 90, 7)]   # stays clear of the snake
+    snake = [(x, 155) for x in range(0, 160)] + [(159, y) for y in range(100, 155)] + [(x, 100) for x in range(20, 160)]
+    e = _island_entries(dim, diag + snake, mag=0.05, per_cell=1)
+    r = _check_detect(ctx, e, min_size=0.01, subdivide=16, target_motion=0.003)
+    assert r is not None and r[0] == len(set(snake))
+
+
+def test_detect_empty_and_still_inputs(ctx):
+    assert ctx.detect(np.zeros((0, 4), np.float32)) is None
+    e = _entries(500, 1); e[:, 2:] = 0
+    assert _check_detect(ctx, e) is None
+
+
+# ------------------------------------------------------------------ A6-A12: Almeida
+def test_almeida_reference_known_answer_lsq(ctx):
+    """The reference's own test (almeida-estimator/src/lib.rs:359-364) through the HIP path, plus
+    agreement with the oracle's quaternion (tolerance 1e-5 per component; north_star allows 1e-4)."""
+    import almeida_cases as ac
+    cam = oracle.camera(1.0, 90.0)
+    for rot, ang, q, field in ac.cases():
+        est, tr = ctx.almeida(field, 1.0, 90.0, use_ransac=False)
+        err = ac.error_deg(q, est)
+        assert err < 0.1 * rot or (rot == 0 and err == 0), (rot, ang, err)
+        q_o = oracle.solve_ypr_given(field, cam)
+        np.testing.assert_allclose(est, q_o, atol=1e-5, rtol=0)
+        assert (tr == 0).all()
+
+
+def test_almeida_reference_known_answer_ransac(ctx):
+    """lib.rs:366-372 (100 iterations) through the HIP path; same seeds as the oracle."""
+    import almeida_cases as ac
+    cam = oracle.camera(1.0, 90.0)
+    for i, (rot, ang, q, field) in enumerate(ac.cases()):
+        est, _ = ctx.almeida(field, 1.0, 90.0, use_ransac=True, num_iters=100, inlier_deg=0.05, num_samples=1000,
+                             seed=1234 + i)
+        err = ac.error_deg(q, est)
+        assert err < 0.1 * rot or (rot == 0 and err == 0), (rot, ang, err)
+        q_o = oracle.solve_ypr_ransac(field, cam, 100, 0.05, 1000, seed=1234 + i)
+        np.testing.assert_allclose(est, q_o, atol=1e-4, rtol=0)
+
+
+@pytest.mark.parametrize("n_side", [(64, 36), (160, 90), (480, 270)])
+def test_almeida_noisy_field_matches_oracle(ctx, n_side):
+    """cfg3-shaped input (per-pixel entries, planted rotation + noise); covers the one-workgroup and the
+    multi-launch solver.  Tolerance 2e-6 on quaternion components (sum order differs)."""
+    w, h = n_side
+    e = synth.rotation_field(w, h)
+    cam = oracle.camera(16 / 9, 39.6 * 9 / 16)
+    q_o = oracle.solve_ypr_given(e, cam)
+    q_g, _ = ctx.almeida(e, 16 / 9, 39.6 * 9 / 16, use_ransac=False)
+    np.testing.assert_allclose(q_g, q_o, atol=2e-6, rtol=0)
+
+
+def test_almeida_ransac_with_outliers(ctx):
+    e = synth.rotation_field(120, 68, outlier_frac=0.3)
+    cam = oracle.camera(16 / 9, 39.6 * 9 / 16)
+    q_o, inl = oracle.solve_ypr_ransac(e, cam, 200, 0.05, 1000, seed=42, want_inliers=True)
+    q_g, _ = ctx.almeida(e, 16 / 9, 39.6 * 9 / 16, use_ransac=True, num_iters=200, inlier_deg=0.05, num_samples=1000, seed=42)
+    assert len(inl) >= 3
+    np.testing.assert_allclose(q_g, q_o, atol=1e-4, rtol=0)
+    # and the answer is the planted rotation, not the outliers
+    q_lsq_clean = oracle.solve_ypr_given(synth.rotation_field(120, 68), cam)
+    assert np.degrees(oracle.quat_angle_to(q_lsq_clean, q_g)) < 0.02
+
+
+def test_almeida_degenerate_inputs(ctx):
+    ident = np.array([1, 0, 0, 0], np.float32)
+    for n in (0, 1, 2):
+        e = _entries(n, 9)
+        for ransac in (False, True):
+            q, _ = ctx.almeida(e, 1.0, 90.0, use_ransac=ransac, num_iters=10, num_samples=100, seed=1)
+            cam = oracle.camera(1.0, 90.0)
+            q_o = oracle.solve_ypr_ransac(e, cam, 10, 0.05, 100, seed=1) if ransac else oracle.solve_ypr_given(e, cam)
+            np.testing.assert_allclose(np.abs(q), np.abs(q_o), atol=1e-5)
+            if n == 0:
+                np.testing.assert_allclose(np.abs(q), ident, atol=0)
+
+
+def test_almeida_batched_device_path(ctx):
+    import torch
+    e = np.stack([synth.rotation_field(64, 36, euler_deg=(0.1 * k, -0.2, 0.05 * k), seed=k) for k in range(5)])
+    d = torch.from_numpy(e).cuda()
+    out = torch.zeros((5, 4), dtype=torch.float32, device="cuda")
+    ctx.use_torch_stream()
+    ctx.almeida_dev(d.data_ptr(), e.shape[1], 5, 16 / 9, 22.275, False, 0, 0.05, 0, 0, out.data_ptr())
+    torch.cuda.synchronize()
+    ctx.use_own_stream()
+    cam = oracle.camera(16 / 9, 22.275)
+    for k in range(5):
+        np.testing.assert_allclose(out[k].cpu().numpy(), oracle.solve_ypr_given(e[k], cam), atol=2e-6, rtol=0)
