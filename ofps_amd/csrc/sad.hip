@@ -20,6 +20,9 @@
 //     so the result is independent of the reduction order and bit-exact vs the scalar oracle.
 #include "common.hpp"
 
+#include <cstdlib>
+#include <utility>
+
 namespace {
 
 constexpr int kWavesPerWG = 4;
@@ -54,6 +57,13 @@ __device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v,
     unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
     lo = __shfl_xor(lo, mask, 64);
     hi = __shfl_xor(hi, mask, 64);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+__device__ __forceinline__ unsigned long long shfl_down_u64(unsigned long long v, int delta) {
+    unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
+    lo = __shfl_down(lo, delta, 64);
+    hi = __shfl_down(hi, delta, 64);
     return ((unsigned long long)hi << 32) | lo;
 }
 
@@ -218,6 +228,202 @@ __global__ __launch_bounds__(256) void sad_qsad_kernel(const SadParams p) {
     if (lane == 0) write_block_result(p, pair, bx, by, B, R, best);
 }
 
+// ------------------------------------------------------------------------------------------------
+// sad_strip_kernel: the throughput kernel for small ranges (B16 R16 = BASELINE configs[1]).
+//
+// rocprofv3 on sad_qsad_kernel<16,16,5> (profiles/sad_r01_*): VALU 98 % busy, 724 VALU instructions
+// per block of which 320 are packed SADs -- the per-block setup, LDS addressing and argmin scan cost
+// as much issue time as a quarter of the SADs.  This kernel amortises all of that over NB blocks:
+//   * one wave owns a strip of NB = 64/NG horizontally adjacent blocks (7 for +-16); lane = (block b,
+//     dx group g) and walks ALL 2R+1 dy itself: 2(2R+1) packed-u16 accumulator VGPRs, the block of the
+//     current frame in B*B/4 VGPRs (lanes of different blocks differ, so no SGPR operand here);
+//   * the strip's (NB*B+2R) x (B+2R) window is staged once per wave with 16-byte coalesced loads;
+//     every window row is read once (B/4 ds_read2_b32 per lane) and feeds up to B*B/4 packed SADs;
+//   * lane-local argmin key = SAD<<16 | d2<<6 | dy_index: inside one dx group |dx| is distinct, so
+//     (d2, dy) identifies the candidate and the 32-bit order equals the (SAD, d2, dy, dx) order.
+//     dy_index is a compile-time constant per unrolled step, masked columns saturate through a
+//     clamped add, vertical frame clipping is a scalar branch (uniform per strip);
+//   * wave waste: 63/64 lanes, 33/36 dx -> 90 % of issued SADs are useful (85 % before);
+//   * workgroup -> strip mapping is XCD-aware: the 8 XCDs (block b runs on XCD b % 8) each take a
+//     contiguous range of strips, so vertically adjacent strips share their halo rows in one L2.
+template <int B, int R>
+struct StripCfg {
+    static_assert(B % 4 == 0 && R % 4 == 0, "tile origin must stay dword aligned");
+    static_assert(B * B * 255 <= 65535, "packed u16 SAD accumulators would overflow");
+    static constexpr int NCAND = 2 * R + 1;
+    static constexpr int NG = (NCAND + 3) / 4;
+    static constexpr int NB = 64 / NG;                       // blocks per wave
+    static constexpr int BW = B / 4;
+    static constexpr int TILE_H = B + 2 * R;
+    static constexpr int TILE_W16 = (NB * B + 2 * R + 15) / 16;   // 16-byte granules per window row
+    static constexpr int MAXCOL = (NB - 1) * BW + (NG - 1) + BW;  // highest dword a lane touches
+    static constexpr int SW = ((MAXCOL + 1 > TILE_W16 * 4 ? MAXCOL + 1 : TILE_W16 * 4) + 3) / 4 * 4;  // 16-B rows
+    static constexpr int TILE_DWORDS = TILE_H * SW;
+    static_assert(2 * R * R < 1024 && NCAND <= 64, "lane key packs d2 in 10 bits and the dy index in 6");
+    static_assert((R % 16 == 0) && (B % 16 == 0), "16-byte staging needs a 16-byte aligned window origin");
+};
+
+template <int B, int R, int RR>
+__device__ __forceinline__ void strip_row(unsigned long long (&acc)[2 * R + 1], const uint32_t (&c)[B][B / 4],
+                                          const uint32_t* trow) {
+    using C = StripCfg<B, R>;
+    unsigned long long win[C::BW];
+#pragma unroll
+    for (int q = 0; q < C::BW; ++q) win[q] = reinterpret_cast<const U64A4*>(trow + RR * C::SW + q)->v;
+#pragma unroll
+    for (int i = 0; i < C::NCAND; ++i) {
+        constexpr int kDummy = 0; (void)kDummy;
+        const int y = RR - i;
+        if (y >= 0 && y < B) {
+#pragma unroll
+            for (int q = 0; q < C::BW; ++q) acc[i] = __builtin_amdgcn_qsad_pk_u16_u8(win[q], c[y][q], acc[i]);
+        }
+    }
+}
+
+template <int B, int R, int... RR>
+__device__ __forceinline__ void strip_rows(unsigned long long (&acc)[2 * R + 1], const uint32_t (&c)[B][B / 4],
+                                           const uint32_t* trow, std::integer_sequence<int, RR...>) {
+    (strip_row<B, R, RR>(acc, c, trow), ...);
+}
+
+constexpr int kStripWaves = 4;      // independent waves (strips) per workgroup; no workgroup barrier
+
+template <int B, int R>
+__global__ __launch_bounds__(64 * kStripWaves, 2) void sad_strip_kernel(const SadParams p, int strips_per_row,
+                                                                      int total_strips) {
+    using C = StripCfg<B, R>;
+    __shared__ __attribute__((aligned(16))) uint32_t tiles[kStripWaves * C::TILE_DWORDS];
+
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    // XCD-aware remap: workgroup w lands on XCD w % 8; give each XCD a contiguous run of strips
+    // (the grid is padded to a multiple of 8 workgroups so the remap is a bijection)
+    const int per_xcd = gridDim.x / 8;
+    const int lwg = (int)(blockIdx.x % 8) * per_xcd + (int)(blockIdx.x / 8);
+    const int strip = lwg * kStripWaves + wave;
+    if (strip >= total_strips) return;
+    const int strips_per_pair = strips_per_row * p.nby;
+    const int pair = strip / strips_per_pair;
+    const int rem = strip - pair * strips_per_pair;
+    const int by = rem / strips_per_row;
+    const int bx0 = (rem - by * strips_per_row) * C::NB;
+
+    const uint8_t* __restrict__ prev = p.frames + (size_t)(p.ref_mode ? 0 : pair) * p.frame_pitch;
+    const uint8_t* __restrict__ cur = p.frames + (size_t)(pair + 1) * p.frame_pitch;
+    uint32_t* tile = tiles + wave * C::TILE_DWORDS;
+
+    const bool lane_on = lane < C::NB * C::NG;
+    const int b = lane_on ? lane / C::NG : C::NB - 1;
+    const int g = lane_on ? lane - b * C::NG : 0;
+    const int bx = bx0 + b;
+    const bool blk_on = lane_on && bx < p.nbx;
+    const int y0 = by * B;
+
+    // ---- this lane's block of the current frame -> VGPRs (lanes of one block read the same lines)
+    uint32_t c[B][C::BW];
+    {
+        const int bxc = bx < p.nbx ? bx : p.nbx - 1;
+        const uint8_t* cp = cur + (size_t)y0 * p.stride + bxc * B;
+#pragma unroll
+        for (int y = 0; y < B; ++y) {
+#pragma unroll
+            for (int q4 = 0; q4 < C::BW; q4 += 4) {
+                const uint4 v = *reinterpret_cast<const uint4*>(cp + (size_t)y * p.stride + 4 * q4);
+                c[y][q4 + 0] = v.x; c[y][q4 + 1] = v.y; c[y][q4 + 2] = v.z; c[y][q4 + 3] = v.w;
+            }
+        }
+    }
+
+    // ---- stage the strip's search window: 16-byte granules, coalesced along rows
+    {
+        const int tx0 = bx0 * B - R, ty0 = y0 - R;
+        for (int idx = lane; idx < C::TILE_H * C::TILE_W16; idx += 64) {
+            const int row = idx / C::TILE_W16, col = idx - row * C::TILE_W16;
+            const int gx = tx0 + 16 * col, gy = ty0 + row;
+            if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W)
+                *reinterpret_cast<uint4*>(tile + row * C::SW + 4 * col) =
+                    *reinterpret_cast<const uint4*>(prev + (size_t)gy * p.stride + gx);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    // ---- accumulate: every lane, all dy.  The row walk is expanded through a template pack: a plain
+    // `#pragma unroll` over TILE_H x NCAND steps exceeds hipcc's unroll budget, which leaves the row
+    // index dynamic and sends the c[][] block to scratch memory.
+    unsigned long long acc[C::NCAND];
+#pragma unroll
+    for (int i = 0; i < C::NCAND; ++i) acc[i] = 0;
+    const uint32_t* trow = tile + b * C::BW + g;
+    strip_rows<B, R>(acc, c, trow, std::make_integer_sequence<int, C::TILE_H>{});
+#pragma unroll
+    for (int i = 0; i < C::NCAND; ++i) asm volatile("" : "+v"(acc[i]));
+
+    // ---- lane-local argmin.  colk[j] = dx_j^2 << 6, or all-ones for a masked column (clamped add saturates)
+    const int dx0 = -R + 4 * g;
+    uint32_t colk[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int dx = dx0 + j;
+        const int x = bx * B + dx;
+        const bool v = blk_on && dx <= R && x >= 0 && x + B <= p.W;
+        colk[j] = v ? (uint32_t)(dx * dx) << 6 : 0xFFFFFFFFu;
+    }
+    uint32_t bkey = 0xFFFFFFFFu;
+#pragma unroll
+    for (int i = 0; i < C::NCAND; ++i) {
+        const int dy = -R + i;
+        if (y0 + dy >= 0 && y0 + dy + B <= p.H) {                 // uniform over the strip: scalar branch
+            const uint32_t rowk = ((uint32_t)(dy * dy) << 6) | (uint32_t)i;     // compile-time constant
+            const uint32_t lo = (uint32_t)acc[i], hi = (uint32_t)(acc[i] >> 32);
+            const uint32_t k0 = (lo << 16) | __builtin_elementwise_add_sat(colk[0], rowk);
+            const uint32_t k1 = (lo & 0xFFFF0000u) | __builtin_elementwise_add_sat(colk[1], rowk);
+            const uint32_t k2 = (hi << 16) | __builtin_elementwise_add_sat(colk[2], rowk);
+            const uint32_t k3 = (hi & 0xFFFF0000u) | __builtin_elementwise_add_sat(colk[3], rowk);
+            bkey = min(bkey, min(min(k0, k1), min(k2, k3)));
+        }
+    }
+    // decode (d2, dy index) -> dx; build the cross-lane key (SAD, d2, dy, dx)
+    unsigned long long best = ~0ull;
+    if (bkey != 0xFFFFFFFFu) {
+        const int i = (int)(bkey & 63u);
+        const int dy = -R + i;
+        const int d2 = (int)((bkey >> 6) & 1023u);
+        const int dxsq = d2 - dy * dy;
+        int dx = dx0;
+#pragma unroll
+        for (int j = 1; j < 4; ++j) dx = ((dx0 + j) * (dx0 + j) == dxsq) ? dx0 + j : dx;
+        best = ((unsigned long long)(bkey >> 6) << 22) | ((unsigned long long)(uint32_t)i << 16) |
+               (unsigned long long)(uint32_t)(((dy + R) << 8) | (dx + R));
+        // layout: [SAD:16 | d2:10] << 22 | i:6 << 16 | (dy+R):8 | (dx+R):8 ; i duplicates dy, harmless for the order
+    }
+    // ---- min over the NG lanes of each block (segments of NG lanes; guarded shuffles)
+#pragma unroll
+    for (int off = 1; off < C::NG; off <<= 1) {
+        const unsigned long long o = shfl_down_u64(best, off);
+        const bool same = (lane + off < 64) && ((lane + off) / C::NG == lane / C::NG);
+        if (same && o < best) best = o;
+    }
+    if (blk_on && g == 0) {
+        const int sad = (int)((best >> 32) & 0xFFFFu);
+        const int dy = (int)((best >> 8) & 0xFF) - R, dx = (int)(best & 0xFF) - R;
+        const size_t k = ((size_t)pair * p.nby + by) * p.nbx + bx;
+        float4 e;
+        e.x = (float)(bx * B + B / 2 + dx) * p.nx;
+        e.y = (float)(y0 + B / 2 + dy) * p.ny;
+        e.z = ((float)dx / 1.0f) * (-p.nx);
+        e.w = ((float)dy / 1.0f) * (-p.ny);
+        p.out_entries[k] = e;
+        if (p.out_best) {
+            p.out_best[3 * k + 0] = dx;
+            p.out_best[3 * k + 1] = dy;
+            p.out_best[3 * k + 2] = sad;
+        }
+    }
+}
+
 // Generic kernel for block/range pairs the packed-SAD kernel does not cover: one wave per block,
 // lanes over candidates, bytes straight from global memory (L1/L2 absorb the reuse).  Slow path.
 __global__ __launch_bounds__(64) void sad_generic_kernel(const SadParams p, int B, int R) {
@@ -272,6 +478,15 @@ void launch_qsad(const SadParams& p, int pairs, hipStream_t s) {
     hipLaunchKernelGGL((sad_qsad_kernel<B, R, K>), grid, dim3(256), 0, s, p);
 }
 
+template <int B, int R>
+void launch_strip(const SadParams& p, int pairs, hipStream_t s) {
+    using C = StripCfg<B, R>;
+    const int strips_per_row = (p.nbx + C::NB - 1) / C::NB;
+    const int total = strips_per_row * p.nby * pairs;
+    const int nwg = ((total + kStripWaves - 1) / kStripWaves + 7) / 8 * 8;     // multiple of 8: see the XCD remap
+    hipLaunchKernelGGL((sad_strip_kernel<B, R>), dim3(nwg), dim3(64 * kStripWaves), 0, s, p, strips_per_row, total);
+}
+
 }  // namespace
 
 extern "C" {
@@ -309,8 +524,18 @@ int ofps_hip_sad_flow_dev(ofps_hip_ctx* ctx, const void* d_frames, int n_frames,
     OFPS_HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
     const int key = block * 1000 + range;
+    const char* force = getenv("OFPS_HIP_SAD_KERNEL");
+    const bool force_block = force && strcmp(force, "block") == 0;
     switch (key) {
-        case 16016: launch_qsad<16, 16, 5>(p, pairs, s); break;
+        case 16016:
+            // strip kernel needs 16-byte aligned rows; otherwise the per-block kernel handles it.
+            // OFPS_HIP_SAD_KERNEL=block forces the per-block kernel (A/B profiling only).
+            if (!force_block && stride % 16 == 0 && ((uintptr_t)d_frames % 16) == 0 && frame_pitch % 16 == 0 &&
+                (long long)((p.nbx + 6) / 7) * p.nby * pairs < (1ll << 30))
+                launch_strip<16, 16>(p, pairs, s);
+            else
+                launch_qsad<16, 16, 5>(p, pairs, s);
+            break;
         case 16008: launch_qsad<16, 8, 3>(p, pairs, s); break;
         case 16032: launch_qsad<16, 32, 5>(p, pairs, s); break;
         case 8032: launch_qsad<8, 32, 5>(p, pairs, s); break;

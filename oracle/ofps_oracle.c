@@ -704,10 +704,11 @@ static uint32_t sad_candidate(const uint8_t* c, const uint8_t* p, int stride, in
     return sad;
 }
 
-static void sad_block_row(const uint8_t* prev, const uint8_t* cur, int W, int H, int stride,
-                          int B, int R, int by, int nbx, float* out_entries, int32_t* out_best, int simd) {
+static void sad_block_run(const uint8_t* prev, const uint8_t* cur, int W, int H, int stride,
+                          int B, int R, int by, int bx_begin, int bx_end, int nbx, float* out_entries,
+                          int32_t* out_best, int simd) {
     const float nx = 1.0f / (float)W, ny = 1.0f / (float)H;          /* av-decoder/src/lib.rs:404-405 */
-    for (int bx = 0; bx < nbx; ++bx) {
+    for (int bx = bx_begin; bx < bx_end; ++bx) {
         int x0 = bx * B, y0 = by * B;
         uint64_t best_key = ~0ull; int best_dx = 0, best_dy = 0; uint32_t best_sad = 0;
         for (int dy = -R; dy <= R; ++dy) {
@@ -743,12 +744,18 @@ size_t orc_sad_flow_ex(const uint8_t* prev, const uint8_t* cur, int W, int H, in
     (void)threads;
 #ifdef _OPENMP
     if (threads > 1) {
+        /* one task = a run of up to 8 blocks of one block row: enough tasks for 100+ threads */
+        const int runs = (nbx + 7) / 8;
 #pragma omp parallel for schedule(dynamic, 1) num_threads(threads)
-        for (int by = 0; by < nby; ++by) sad_block_row(prev, cur, W, H, stride, B, R, by, nbx, out_entries, out_best, simd);
+        for (int t = 0; t < nby * runs; ++t) {
+            const int by = t / runs, b0 = (t % runs) * 8;
+            const int b1 = b0 + 8 < nbx ? b0 + 8 : nbx;
+            sad_block_run(prev, cur, W, H, stride, B, R, by, b0, b1, nbx, out_entries, out_best, simd);
+        }
         return (size_t)nbx * (size_t)nby;
     }
 #endif
-    for (int by = 0; by < nby; ++by) sad_block_row(prev, cur, W, H, stride, B, R, by, nbx, out_entries, out_best, simd);
+    for (int by = 0; by < nby; ++by) sad_block_run(prev, cur, W, H, stride, B, R, by, 0, nbx, nbx, out_entries, out_best, simd);
     return (size_t)nbx * (size_t)nby;
 }
 
