@@ -48,5 +48,23 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
+HOST = os.path.join(HERE, "host")
+TOOL = os.path.join(HOST, "ofps_hip_tool")
+
+
+def build_host(force: bool = False, verbose: bool = False) -> str:
+    """C++ host layer + CLI (g++; links libofps_hip.so, no device code)."""
+    srcs = [os.path.join(HOST, "ofps_host.cpp"), os.path.join(HOST, "ofps_hip_tool.cpp")]
+    deps = srcs + [os.path.join(HOST, "ofps_host.hpp"), LIB]
+    if force or _stale(TOOL, deps):
+        cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-Wextra", "-o", TOOL] + srcs + \
+              ["-L" + HERE, "-lofps_hip", "-Wl,-rpath,$ORIGIN/..", "-Wl,-rpath,/opt/rocm/lib", "-Wl,-rpath-link,/opt/rocm/lib"]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+    return TOOL
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    print(build_host(force="--force" in sys.argv, verbose=True))

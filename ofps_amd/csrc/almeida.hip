@@ -194,9 +194,16 @@ __device__ __forceinline__ Quat almeida_update(const Quat& rotation, const float
     model[0] = model[0] * eps * alpha;                                            // :185
     model[1] = model[1] * eps * alpha;
     model[2] = model[2] * eps * alpha;
-    const Quat roll = quat_from_euler(0.0f, model[0], 0.0f);                      // :189-191
-    const Quat pitch = quat_from_euler(model[1], 0.0f, 0.0f);
-    const Quat yaw = quat_from_euler(0.0f, 0.0f, -model[2]);
+    // :189-191.  Each factor has a single non-zero Euler angle; with the other two half-angle sines
+    // exactly 0 and cosines exactly 1, from_euler_angles reduces bit for bit to (cos, sin on one axis),
+    // so two trig evaluations per factor instead of six (this section runs on one lane per step).
+    float s0, c0, s1, c1, s2, c2;
+    sincosf(model[0] * 0.5f, &s0, &c0);
+    sincosf(model[1] * 0.5f, &s1, &c1);
+    sincosf(-model[2] * 0.5f, &s2, &c2);
+    const Quat roll = {c0, 0.0f, s0, 0.0f};     // from_euler_angles(0, m0, 0): pitch slot -> j
+    const Quat pitch = {c1, s1, 0.0f, 0.0f};    // from_euler_angles(m1, 0, 0): roll slot  -> i
+    const Quat yaw = {c2, 0.0f, 0.0f, s2};      // from_euler_angles(0, 0, -m2): yaw slot  -> k
     const Quat rot = quat_mul(quat_mul(pitch, roll), yaw);                        // :193
     return quat_mul(rotation, rot);                                               // :195
 }
@@ -217,13 +224,15 @@ __device__ __forceinline__ void block_sum9(float v[9], float (*red)[9]) {
         for (int k = 0; k < 9; ++k) red[wave][k] = v[k];
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
+    // second level: the first 16 lanes of wave 0 hold one wave-partial each and finish with a 4-step butterfly
+    if (threadIdx.x < 64) {
         const int nw = blockDim.x >> 6;
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
-            float acc = red[0][k];
-            for (int w = 1; w < nw; ++w) acc += red[w][k];
-            v[k] = acc;
+            float x = (lane < nw) ? red[lane][k] : 0.0f;
+#pragma unroll
+            for (int m = 8; m >= 1; m >>= 1) x += __shfl_xor(x, m, 64);
+            v[k] = x;
         }
     }
 }

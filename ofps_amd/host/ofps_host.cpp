@@ -1,0 +1,286 @@
+// ofps_host.cpp -- implementation of the C++ host layer (see ofps_host.hpp).  No arithmetic on the data
+// path lives here: decode, detect and estimate are calls into libofps_hip.so.
+#include "ofps_host.hpp"
+
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+
+namespace ofps {
+
+// ------------------------------------------------------------------ Properties
+Property PropertyMut::get() const {
+    if (auto s = std::get_if<std::string*>(&ref)) return Property{**s};
+    if (auto b = std::get_if<bool*>(&ref)) return Property{**b};
+    if (auto f = std::get_if<float*>(&ref)) return Property{BoundedProp<float>{**f, fmin, fmax}};
+    return Property{BoundedProp<size_t>{*std::get<size_t*>(ref), umin, umax}};
+}
+
+void PropertyMut::set(const Property& other) {
+    if (auto s = std::get_if<std::string*>(&ref)) { if (auto o = std::get_if<std::string>(&other)) **s = *o; }
+    else if (auto b = std::get_if<bool*>(&ref)) { if (auto o = std::get_if<bool>(&other)) **b = *o; }
+    else if (auto f = std::get_if<float*>(&ref)) { if (auto o = std::get_if<BoundedProp<float>>(&other)) **f = o->val; }
+    else if (auto u = std::get_if<size_t*>(&ref)) { if (auto o = std::get_if<BoundedProp<size_t>>(&other)) **u = o->val; }
+}
+
+std::vector<std::pair<std::string, Property>> Properties::props() {
+    std::vector<std::pair<std::string, Property>> out;
+    for (auto& [n, p] : props_mut()) out.emplace_back(n, p.get());
+    return out;
+}
+
+bool Properties::set_prop(const std::string& name, const Property& value) {
+    for (auto& [n, p] : props_mut())
+        if (n == name) { p.set(value); return true; }
+    return false;
+}
+
+// ------------------------------------------------------------------ small types
+std::pair<float, float> StandardCamera::fov() const {            // camera.rs:166-170
+    const float to_rad = 3.14159265358979323846264338327950288f / 180.0f;
+    const float to_deg = 57.2957795130823208767981548141051703f;
+    const float ty = std::tan(fov_y_ * to_rad / 2.0f);
+    const float tx = aspect_ * ty;
+    return {std::atan(tx) * to_deg * 2.0f, fov_y_};
+}
+
+MotionVectors MotionField::motion_iter() const {
+    MotionVectors out;
+    const auto [w, h] = dim();
+    for (size_t y = 0; y < h; ++y)
+        for (size_t x = 0; x < w; ++x) {
+            const auto [mx, my] = get_motion(x, y);
+            out.push_back({(float)x / (float)w, (float)y / (float)h, mx, my});
+        }
+    return out;
+}
+
+UnitQuaternion UnitQuaternion::operator*(const UnitQuaternion& b) const {
+    UnitQuaternion r;
+    r.w = w * b.w - i * b.i - j * b.j - k * b.k;
+    r.i = w * b.i + i * b.w + j * b.k - k * b.j;
+    r.j = w * b.j - i * b.k + j * b.w + k * b.i;
+    r.k = w * b.k + i * b.j - j * b.i + k * b.w;
+    return r;
+}
+
+void UnitQuaternion::rotate(const float v[3], float out[3]) const {   // v + 2 q.v x (q.v x v + w v)
+    const float u[3] = {i, j, k};
+    float t[3] = {2 * (u[1] * v[2] - u[2] * v[1]), 2 * (u[2] * v[0] - u[0] * v[2]), 2 * (u[0] * v[1] - u[1] * v[0])};
+    const float c[3] = {u[1] * t[2] - u[2] * t[1], u[2] * t[0] - u[0] * t[2], u[0] * t[1] - u[1] * t[0]};
+    for (int a = 0; a < 3; ++a) out[a] = (t[a] * w + c[a]) + v[a];
+}
+
+void Estimator::motion_step(const MotionEntry* mv, size_t n, const StandardCamera& camera, std::optional<float> mag,
+                            UnitQuaternion& rot, float pos[3]) {       // estimator.rs:38-53
+    auto [r, tr] = estimate(mv, n, camera, mag);
+    const float t[3] = {tr.x, tr.y, tr.z};
+    float moved[3];
+    rot.rotate(t, moved);
+    for (int a = 0; a < 3; ++a) pos[a] += moved[a];
+    rot = r * rot;
+}
+
+// ------------------------------------------------------------------ context
+HipContext::HipContext(int device) {
+    const int rc = ofps_hip_init(device, &ctx_);
+    if (rc != OFPS_HIP_OK) throw Error(std::string("ofps_hip_init: ") + ofps_hip_last_error(nullptr));
+}
+HipContext::~HipContext() { ofps_hip_destroy(ctx_); }
+void HipContext::check(int rc) const {
+    if (rc != OFPS_HIP_OK) throw Error(std::string("libofps_hip (") + std::to_string(rc) + "): " + ofps_hip_last_error(ctx_));
+}
+
+// ------------------------------------------------------------------ hip_sad
+HipSadDecoder::HipSadDecoder(std::unique_ptr<std::istream> input, size_t width, size_t height, std::optional<double> fps,
+                             int device)
+    : ctx_(device), in_(std::move(input)), w_(width), h_(height), fps_(fps), prev_(width * height), cur_(width * height) {
+    if (!in_ || !*in_) throw Error("hip_sad: cannot open input");
+    if (w_ == 0 || h_ == 0) throw Error("hip_sad: frame size required (arg \"path?w=..&h=..\")");
+}
+
+bool HipSadDecoder::process_frame(MotionVectors& field, std::vector<RGBA>* out_frame, size_t* out_height, size_t skip) {
+    for (size_t s = 0; s <= skip; ++s) {
+        std::swap(prev_, cur_);
+        in_->read(reinterpret_cast<char*>(cur_.data()), (std::streamsize)cur_.size());
+        if ((size_t)in_->gcount() != cur_.size()) throw Error("hip_sad: end of stream");   // Err ends the caller's loop
+    }
+    if (out_frame && out_height) {
+        *out_height = h_;
+        out_frame->clear();
+        out_frame->reserve(cur_.size());
+        for (uint8_t y : cur_) out_frame->push_back(RGBA{y, y, y, 255});
+    }
+    const bool had_prev = have_prev_;
+    have_prev_ = true;
+    if (!had_prev) return false;                                      // first frame: no pair yet
+    const size_t nblk = ofps_hip_sad_block_count((int)w_, (int)h_, (int)block_);
+    out_.resize(4 * nblk);
+    size_t n_out = 0;
+    ctx_.check(ofps_hip_sad_flow(ctx_.get(), prev_.data(), cur_.data(), (int)w_, (int)h_, (int)w_, (int)block_, (int)range_,
+                                 out_.data(), nullptr, &n_out));
+    const size_t base = field.size();
+    field.resize(base + n_out);                                       // vectors are APPENDED (callers clear)
+    std::memcpy(field.data() + base, out_.data(), n_out * sizeof(MotionEntry));
+    return true;
+}
+
+std::vector<std::pair<std::string, PropertyMut>> HipSadDecoder::props_mut() {
+    return {{"Block size", PropertyMut::usize(&block_, 8, 16)}, {"Search range", PropertyMut::usize(&range_, 8, 32)}};
+}
+
+// ------------------------------------------------------------------ .mvec
+bool MvecFileDecoder::process_frame(MotionVectors& field, std::vector<RGBA>*, size_t*, size_t) {
+    uint8_t hdr[4];
+    in_->read(reinterpret_cast<char*>(hdr), 4);                       // motion-loader/src/lib.rs:52-53
+    if (in_->gcount() != 4) throw Error("mvec: end of stream");
+    const uint32_t count = (uint32_t)hdr[0] | ((uint32_t)hdr[1] << 8) | ((uint32_t)hdr[2] << 16) | ((uint32_t)hdr[3] << 24);
+    const size_t base = field.size();
+    field.resize(base + count);
+    in_->read(reinterpret_cast<char*>(field.data() + base), (std::streamsize)count * 16);    // 4 x f32 LE per vector
+    if ((size_t)in_->gcount() != (size_t)count * 16) { field.resize(base); throw Error("mvec: truncated frame"); }
+    return true;
+}
+
+void write_mvec_frame(std::ostream& out, const MotionVectors& mv) {   // motion-extract/src/main.rs:25-32
+    const uint32_t n = (uint32_t)mv.size();
+    const uint8_t hdr[4] = {(uint8_t)n, (uint8_t)(n >> 8), (uint8_t)(n >> 16), (uint8_t)(n >> 24)};
+    out.write(reinterpret_cast<const char*>(hdr), 4);
+    out.write(reinterpret_cast<const char*>(mv.data()), (std::streamsize)mv.size() * 16);   // host is little-endian
+}
+
+// ------------------------------------------------------------------ hip_block_motion
+std::optional<std::pair<size_t, MotionField>> HipBlockMotionDetection::detect_motion(const MotionEntry* mv, size_t n) {
+    const int dim = ofps_hip_block_dim(min_size, subdivide);
+    if (dim < 1) return std::nullopt;
+    MotionField mf((size_t)dim, (size_t)dim);
+    int has = 0, odim = 0;
+    size_t area = 0;
+    const int rc = ofps_hip_detect(ctx_.get(), reinterpret_cast<const float*>(mv), n, min_size, subdivide, target_motion, &has,
+                                   &area, &odim, mf.raw().data());
+    if (rc != OFPS_HIP_OK || !has) return std::nullopt;               // the trait has no error channel (detection.rs:11)
+    return std::make_pair(area, std::move(mf));
+}
+
+std::vector<std::pair<std::string, PropertyMut>> HipBlockMotionDetection::props_mut() {   // lib.rs:29-46
+    return {{"Min size", PropertyMut::float_(&min_size, 0.01f, 1.0f)},
+            {"Subdivisions", PropertyMut::usize(&subdivide, 1, 16)},
+            {"Target motion", PropertyMut::float_(&target_motion, 0.0001f, 0.1f)}};
+}
+
+// ------------------------------------------------------------------ hip_almeida
+std::pair<UnitQuaternion, Vector3> HipAlmeidaEstimator::estimate(const MotionEntry* mv, size_t n, const StandardCamera& camera,
+                                                                 std::optional<float>) {
+    float q[4], tr[3];
+    ++seed;
+    ctx_.check(ofps_hip_almeida(ctx_.get(), reinterpret_cast<const float*>(mv), n, camera.aspect_ratio(), camera.fov().second,
+                                use_ransac ? 1 : 0, num_iters, inlier_angle, ransac_samples, seed, q, tr));
+    return {UnitQuaternion{q[0], q[1], q[2], q[3]}, Vector3{tr[0], tr[1], tr[2]}};
+}
+
+std::vector<std::pair<std::string, PropertyMut>> HipAlmeidaEstimator::props_mut() {       // lib.rs:80-98
+    return {{"Use ransac", PropertyMut::boolean(&use_ransac)},
+            {"Ransac iters", PropertyMut::usize(&num_iters, 1, 500)},
+            {"Inlier threshold", PropertyMut::float_(&inlier_angle, 0.01f, 1.0f)},
+            {"Ransac samples", PropertyMut::usize(&ransac_samples, 100, 16000)}};
+}
+
+// ------------------------------------------------------------------ creation by name
+static std::unique_ptr<std::istream> open_input(const std::string& path) {
+    auto f = std::make_unique<std::ifstream>(path, std::ios::binary);
+    if (!*f) throw Error("cannot open " + path);
+    return f;
+}
+
+std::unique_ptr<Decoder> create_decoder(const std::string& name, const std::string& arg) {
+    if (name == "mvec") return std::make_unique<MvecFileDecoder>(open_input(arg));
+    if (name == "hip_sad") {                                          // "<path>?w=1920&h=1080&fps=60"
+        std::string path = arg;
+        size_t w = 0, h = 0;
+        std::optional<double> fps;
+        if (auto q = arg.find('?'); q != std::string::npos) {
+            path = arg.substr(0, q);
+            std::stringstream ss(arg.substr(q + 1));
+            std::string kv;
+            while (std::getline(ss, kv, '&')) {
+                const auto eq = kv.find('=');
+                if (eq == std::string::npos) continue;
+                const std::string k = kv.substr(0, eq), v = kv.substr(eq + 1);
+                if (k == "w") w = std::stoul(v); else if (k == "h") h = std::stoul(v); else if (k == "fps") fps = std::stod(v);
+            }
+        }
+        return std::make_unique<HipSadDecoder>(open_input(path), w, h, fps);
+    }
+    throw Error("unknown decoder plugin: " + name);
+}
+std::unique_ptr<Detector> create_detector(const std::string& name, const std::string&) {
+    if (name == "hip_block_motion") return std::make_unique<HipBlockMotionDetection>();
+    throw Error("unknown detector plugin: " + name);
+}
+std::unique_ptr<Estimator> create_estimator(const std::string& name, const std::string&) {
+    if (name == "hip_almeida") return std::make_unique<HipAlmeidaEstimator>();
+    throw Error("unknown estimator plugin: " + name);
+}
+
+// ------------------------------------------------------------------ harnesses
+static double ms_since(std::chrono::steady_clock::time_point t0) {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+}
+
+DetectionRun run_detection(Decoder& decoder, Detector& detector, size_t max_frames) {
+    DetectionRun run;
+    MotionVectors mv;
+    while (run.frames < max_frames) {
+        mv.clear();                                                   // detection.rs:97
+        auto t0 = std::chrono::steady_clock::now();
+        try { decoder.process_frame(mv, nullptr, nullptr, 0); } catch (const Error&) { break; }   // :111-123
+        run.frames += 1;
+        run.decoder_ms.push_back(ms_since(t0));
+        t0 = std::chrono::steady_clock::now();
+        const auto motion = detector.detect_motion(mv.data(), mv.size());                        // :146-148
+        run.detector_ms.push_back(ms_since(t0));
+        if (motion) {                                                 // :150-155
+            if (!run.motion_ranges.empty() && run.motion_ranges.back().second == run.frames) run.motion_ranges.back().second += 1;
+            else run.motion_ranges.emplace_back(run.frames, run.frames + 1);
+        }
+    }
+    return run;
+}
+
+std::vector<std::pair<size_t, size_t>> DetectionRun::filtered(size_t max_frame_gap, size_t min_frames) const {   // :195-212
+    std::vector<std::pair<size_t, size_t>> merged;
+    for (const auto& r : motion_ranges) {
+        if (!merged.empty() && r.first - merged.back().second <= max_frame_gap) merged.back().second = r.second;
+        else merged.push_back(r);
+    }
+    std::vector<std::pair<size_t, size_t>> out;
+    for (const auto& r : merged)
+        if (r.second - r.first >= min_frames) out.push_back(r);
+    return out;
+}
+
+TrackingRun run_tracking(Decoder& decoder, Estimator& estimator, const StandardCamera& camera, size_t max_frames) {
+    TrackingRun run;
+    MotionVectors mv;
+    UnitQuaternion rot;                                               // poses start at identity
+    while (run.frames < max_frames) {
+        mv.clear();
+        auto t0 = std::chrono::steady_clock::now();
+        bool have;
+        try { have = decoder.process_frame(mv, nullptr, nullptr, 0); } catch (const Error&) { break; }
+        run.decoder_ms.push_back(ms_since(t0));
+        run.frames += 1;
+        if (!have) { run.rotations.push_back(rot); run.estimator_ms.push_back(0.0); continue; }
+        t0 = std::chrono::steady_clock::now();
+        const auto [frot, tr] = estimator.estimate(mv.data(), mv.size(), camera, std::nullopt);   // worker.rs:361
+        run.estimator_ms.push_back(ms_since(t0));
+        (void)tr;                                                     // Almeida: translation is always 0
+        rot = frot * rot;                                             // apply_pose, worker.rs:62-69
+        run.rotations.push_back(rot);
+    }
+    return run;
+}
+
+}  // namespace ofps

@@ -1,0 +1,103 @@
+"""Golden vectors (tests/golden/*.npz, made by tests/golden/generate.py from the oracle): the CPU half
+checks that the oracle still reproduces them, the -m gpu half checks the HIP path against the same bytes."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _load(name):
+    return np.load(os.path.join(G, name))
+
+
+SAD_KEYS = [("64x48_b16_r8", 16, 8), ("640x360_b16_r8", 16, 8), ("256x144_b16_r16", 16, 16), ("160x96_b8_r32", 8, 32)]
+
+
+# ---------------------------------------------------------------- oracle vs golden (CPU)
+def test_oracle_reproduces_almeida_golden():
+    g = _load("almeida.npz")
+    cam = oracle.camera(1.0, 90.0)
+    for i in g["field_index"]:
+        f = g[f"field_{i}"]
+        np.testing.assert_array_equal(oracle.solve_ypr_given(f, cam).view(np.uint32), g["q_lsq"][i].view(np.uint32))
+        q = oracle.solve_ypr_ransac(f, cam, 100, 0.05, 1000, seed=int(g["ransac_seed0"]) + int(i))
+        np.testing.assert_array_equal(q.view(np.uint32), g["q_ransac"][i].view(np.uint32))
+    # the reference's acceptance bound on all 32 stored answers (almeida-estimator/src/lib.rs:343-348)
+    for rot, qt, ql, qr in zip(g["rot"], g["q_true"], g["q_lsq"], g["q_ransac"]):
+        for q in (ql, qr):
+            err = np.degrees(oracle.quat_angle_to(qt, q))
+            assert err < 0.1 * rot or err == 0
+
+
+def test_oracle_reproduces_densify_detect_sad_golden():
+    g = _load("densify.npz")
+    for k in ("a", "b", "c", "edge"):
+        w, h = g[f"wh_{k}"]
+        f, cells = oracle.densify(g[f"in_{k}"], int(w), int(h), want_cells=True)
+        np.testing.assert_array_equal(cells, g[f"cells_{k}"])
+        np.testing.assert_array_equal(f.view(np.uint32), g[f"field_{k}"].view(np.uint32))
+    g = _load("detect.npz")
+    for k in range(4):
+        r = oracle.detect_motion(g[f"in_{k}"])
+        assert (r is not None) == bool(g[f"some_{k}"])
+        if r:
+            assert r[0] == int(g[f"area_{k}"])
+            np.testing.assert_array_equal(r[1].view(np.uint32), g[f"field_{k}"].view(np.uint32))
+    g = _load("sad.npz")
+    for name, B, R in SAD_KEYS:
+        fr = g[f"frames_{name}"]
+        ent, best = oracle.sad_flow(fr[0], fr[1], B, R)         # SIMD inner loop vs stored scalar-loop result
+        np.testing.assert_array_equal(best, g[f"best_{name}"])
+        np.testing.assert_array_equal(ent.view(np.uint32), g[f"entries_{name}"].view(np.uint32))
+
+
+# ---------------------------------------------------------------- HIP path vs golden (GPU)
+@pytest.fixture(scope="module")
+def ctx():
+    from ofps_amd.runtime import HipContext
+    c = HipContext(0)
+    yield c
+    c.close()
+
+
+@pytest.mark.gpu
+def test_hip_sad_matches_golden(ctx):
+    g = _load("sad.npz")
+    for name, B, R in SAD_KEYS:
+        fr = g[f"frames_{name}"]
+        ent, best = ctx.sad_flow(fr[0], fr[1], B, R, want_best=True)
+        np.testing.assert_array_equal(best, g[f"best_{name}"])
+        np.testing.assert_array_equal(ent.view(np.uint32), g[f"entries_{name}"].view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_hip_densify_detect_match_golden(ctx):
+    g = _load("densify.npz")
+    for k in ("a", "b", "c", "edge"):
+        w, h = g[f"wh_{k}"]
+        f, cells = ctx.densify(g[f"in_{k}"], int(w), int(h), want_cells=True)
+        np.testing.assert_array_equal(cells, g[f"cells_{k}"])
+        np.testing.assert_array_equal(f.view(np.uint32), g[f"field_{k}"].view(np.uint32))
+    g = _load("detect.npz")
+    for k in range(4):
+        r = ctx.detect(g[f"in_{k}"])
+        assert (r is not None) == bool(g[f"some_{k}"])
+        if r:
+            assert r[0] == int(g[f"area_{k}"])
+            np.testing.assert_array_equal(r[1].view(np.uint32), g[f"field_{k}"].view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_hip_almeida_matches_golden(ctx):
+    g = _load("almeida.npz")
+    for i in g["field_index"]:
+        f = g[f"field_{i}"]
+        q, _ = ctx.almeida(f, 1.0, 90.0, use_ransac=False)
+        np.testing.assert_allclose(q, g["q_lsq"][i], atol=1e-5, rtol=0)          # north_star tolerance: 1e-4
+        q, _ = ctx.almeida(f, 1.0, 90.0, use_ransac=True, num_iters=100, inlier_deg=0.05, num_samples=1000,
+                           seed=int(g["ransac_seed0"]) + int(i))
+        np.testing.assert_allclose(q, g["q_ransac"][i], atol=1e-4, rtol=0)
