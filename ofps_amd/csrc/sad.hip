@@ -255,12 +255,14 @@ struct StripCfg {
     static constexpr int NB = 64 / NG;                       // blocks per wave
     static constexpr int BW = B / 4;
     static constexpr int TILE_H = B + 2 * R;
-    static constexpr int TILE_W16 = (NB * B + 2 * R + 15) / 16;   // 16-byte granules per window row
+    // staging granule: the window origin bx0*B - R must be a multiple of it (NB*B and R both are)
+    static constexpr int GRAN = ((NB * B) % 16 == 0 && R % 16 == 0) ? 16 : (((NB * B) % 8 == 0 && R % 8 == 0) ? 8 : 4);
+    static constexpr int GDW = GRAN / 4;                          // dwords per granule
+    static constexpr int TILE_WG = (NB * B + 2 * R + GRAN - 1) / GRAN;   // granules per window row
     static constexpr int MAXCOL = (NB - 1) * BW + (NG - 1) + BW;  // highest dword a lane touches
-    static constexpr int SW = ((MAXCOL + 1 > TILE_W16 * 4 ? MAXCOL + 1 : TILE_W16 * 4) + 3) / 4 * 4;  // 16-B rows
+    static constexpr int SW = ((MAXCOL + 1 > TILE_WG * GDW ? MAXCOL + 1 : TILE_WG * GDW) + 3) / 4 * 4;  // 16-B rows
     static constexpr int TILE_DWORDS = TILE_H * SW;
-    static_assert(2 * R * R < 1024 && NCAND <= 64, "lane key packs d2 in 10 bits and the dy index in 6");
-    static_assert((R % 16 == 0) && (B % 16 == 0), "16-byte staging needs a 16-byte aligned window origin");
+    static_assert(2 * R * R < 65536, "lane key holds d2 in 16 bits");
 };
 
 template <int B, int R, int RR>
@@ -327,23 +329,35 @@ __global__ __launch_bounds__(64 * kStripWaves, 2) void sad_strip_kernel(const Sa
         const uint8_t* cp = cur + (size_t)y0 * p.stride + bxc * B;
 #pragma unroll
         for (int y = 0; y < B; ++y) {
+            if constexpr (C::BW % 4 == 0) {
 #pragma unroll
-            for (int q4 = 0; q4 < C::BW; q4 += 4) {
-                const uint4 v = *reinterpret_cast<const uint4*>(cp + (size_t)y * p.stride + 4 * q4);
-                c[y][q4 + 0] = v.x; c[y][q4 + 1] = v.y; c[y][q4 + 2] = v.z; c[y][q4 + 3] = v.w;
+                for (int q4 = 0; q4 < C::BW; q4 += 4) {
+                    const uint4 v = *reinterpret_cast<const uint4*>(cp + (size_t)y * p.stride + 4 * q4);
+                    c[y][q4 + 0] = v.x; c[y][q4 + 1] = v.y; c[y][q4 + 2] = v.z; c[y][q4 + 3] = v.w;
+                }
+            } else {
+#pragma unroll
+                for (int q2 = 0; q2 < C::BW; q2 += 2) {
+                    const uint2 v = *reinterpret_cast<const uint2*>(cp + (size_t)y * p.stride + 4 * q2);
+                    c[y][q2 + 0] = v.x; c[y][q2 + 1] = v.y;
+                }
             }
         }
     }
 
-    // ---- stage the strip's search window: 16-byte granules, coalesced along rows
+    // ---- stage the strip's search window: GRAN-byte granules, coalesced along rows
     {
         const int tx0 = bx0 * B - R, ty0 = y0 - R;
-        for (int idx = lane; idx < C::TILE_H * C::TILE_W16; idx += 64) {
-            const int row = idx / C::TILE_W16, col = idx - row * C::TILE_W16;
-            const int gx = tx0 + 16 * col, gy = ty0 + row;
-            if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W)
-                *reinterpret_cast<uint4*>(tile + row * C::SW + 4 * col) =
-                    *reinterpret_cast<const uint4*>(prev + (size_t)gy * p.stride + gx);
+        for (int idx = lane; idx < C::TILE_H * C::TILE_WG; idx += 64) {
+            const int row = idx / C::TILE_WG, col = idx - row * C::TILE_WG;
+            const int gx = tx0 + C::GRAN * col, gy = ty0 + row;
+            if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) {
+                const uint8_t* src = prev + (size_t)gy * p.stride + gx;
+                uint32_t* dst = tile + row * C::SW + C::GDW * col;
+                if constexpr (C::GRAN == 16) *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(src);
+                else if constexpr (C::GRAN == 8) *reinterpret_cast<uint2*>(dst) = *reinterpret_cast<const uint2*>(src);
+                else *dst = *reinterpret_cast<const uint32_t*>(src);
+            }
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -361,7 +375,9 @@ __global__ __launch_bounds__(64 * kStripWaves, 2) void sad_strip_kernel(const Sa
 #pragma unroll
     for (int i = 0; i < C::NCAND; ++i) asm volatile("" : "+v"(acc[i]));
 
-    // ---- lane-local argmin.  colk[j] = dx_j^2 << 6, or all-ones for a masked column (clamped add saturates)
+    // ---- lane-local argmin.  key = SAD<<16 | d2; inside one dx group |dx| is distinct, so two candidates of a
+    // lane with equal (SAD, d2) differ in dy: walking dy upwards with a strict < keeps the spec's order.
+    // colk[j] = dx_j^2, or all-ones for a masked column (the clamped add saturates the whole key).
     const int dx0 = -R + 4 * g;
     uint32_t colk[4];
 #pragma unroll
@@ -369,35 +385,35 @@ __global__ __launch_bounds__(64 * kStripWaves, 2) void sad_strip_kernel(const Sa
         const int dx = dx0 + j;
         const int x = bx * B + dx;
         const bool v = blk_on && dx <= R && x >= 0 && x + B <= p.W;
-        colk[j] = v ? (uint32_t)(dx * dx) << 6 : 0xFFFFFFFFu;
+        colk[j] = v ? (uint32_t)(dx * dx) : 0xFFFFFFFFu;
     }
     uint32_t bkey = 0xFFFFFFFFu;
+    int bi = 0;
 #pragma unroll
     for (int i = 0; i < C::NCAND; ++i) {
         const int dy = -R + i;
         if (y0 + dy >= 0 && y0 + dy + B <= p.H) {                 // uniform over the strip: scalar branch
-            const uint32_t rowk = ((uint32_t)(dy * dy) << 6) | (uint32_t)i;     // compile-time constant
+            const uint32_t rowk = (uint32_t)(dy * dy);            // compile-time constant
             const uint32_t lo = (uint32_t)acc[i], hi = (uint32_t)(acc[i] >> 32);
             const uint32_t k0 = (lo << 16) | __builtin_elementwise_add_sat(colk[0], rowk);
             const uint32_t k1 = (lo & 0xFFFF0000u) | __builtin_elementwise_add_sat(colk[1], rowk);
             const uint32_t k2 = (hi << 16) | __builtin_elementwise_add_sat(colk[2], rowk);
             const uint32_t k3 = (hi & 0xFFFF0000u) | __builtin_elementwise_add_sat(colk[3], rowk);
-            bkey = min(bkey, min(min(k0, k1), min(k2, k3)));
+            const uint32_t m = min(min(k0, k1), min(k2, k3));
+            const bool lt = m < bkey;
+            bkey = lt ? m : bkey;
+            bi = lt ? i : bi;
         }
     }
-    // decode (d2, dy index) -> dx; build the cross-lane key (SAD, d2, dy, dx)
+    // decode (d2, dy) -> dx; build the cross-lane key (SAD, d2, dy, dx)
     unsigned long long best = ~0ull;
     if (bkey != 0xFFFFFFFFu) {
-        const int i = (int)(bkey & 63u);
-        const int dy = -R + i;
-        const int d2 = (int)((bkey >> 6) & 1023u);
-        const int dxsq = d2 - dy * dy;
+        const int dy = -R + bi;
+        const int dxsq = (int)(bkey & 0xFFFFu) - dy * dy;
         int dx = dx0;
 #pragma unroll
         for (int j = 1; j < 4; ++j) dx = ((dx0 + j) * (dx0 + j) == dxsq) ? dx0 + j : dx;
-        best = ((unsigned long long)(bkey >> 6) << 22) | ((unsigned long long)(uint32_t)i << 16) |
-               (unsigned long long)(uint32_t)(((dy + R) << 8) | (dx + R));
-        // layout: [SAD:16 | d2:10] << 22 | i:6 << 16 | (dy+R):8 | (dx+R):8 ; i duplicates dy, harmless for the order
+        best = ((unsigned long long)bkey << 32) | (unsigned long long)(uint32_t)(((dy + R) << 8) | (dx + R));
     }
     // ---- min over the NG lanes of each block (segments of NG lanes; guarded shuffles)
 #pragma unroll
@@ -407,7 +423,7 @@ __global__ __launch_bounds__(64 * kStripWaves, 2) void sad_strip_kernel(const Sa
         if (same && o < best) best = o;
     }
     if (blk_on && g == 0) {
-        const int sad = (int)((best >> 32) & 0xFFFFu);
+        const int sad = (int)(best >> 48);
         const int dy = (int)((best >> 8) & 0xFF) - R, dx = (int)(best & 0xFF) - R;
         const size_t k = ((size_t)pair * p.nby + by) * p.nbx + bx;
         float4 e;
@@ -526,20 +542,22 @@ int ofps_hip_sad_flow_dev(ofps_hip_ctx* ctx, const void* d_frames, int n_frames,
     const int key = block * 1000 + range;
     const char* force = getenv("OFPS_HIP_SAD_KERNEL");
     const bool force_block = force && strcmp(force, "block") == 0;
+    const bool strip_ok = !force_block && stride % 16 == 0 && ((uintptr_t)d_frames % 16) == 0 && frame_pitch % 16 == 0 &&
+                          (long long)p.nbx * p.nby * pairs < (1ll << 30);
     switch (key) {
+        // strip kernels need 16-byte aligned rows; otherwise (or with OFPS_HIP_SAD_KERNEL=block, A/B
+        // profiling only) the per-block kernel handles the pair.
         case 16016:
-            // strip kernel needs 16-byte aligned rows; otherwise the per-block kernel handles it.
-            // OFPS_HIP_SAD_KERNEL=block forces the per-block kernel (A/B profiling only).
-            if (!force_block && stride % 16 == 0 && ((uintptr_t)d_frames % 16) == 0 && frame_pitch % 16 == 0 &&
-                (long long)((p.nbx + 6) / 7) * p.nby * pairs < (1ll << 30))
-                launch_strip<16, 16>(p, pairs, s);
-            else
-                launch_qsad<16, 16, 5>(p, pairs, s);
+            if (strip_ok) launch_strip<16, 16>(p, pairs, s); else launch_qsad<16, 16, 5>(p, pairs, s);
             break;
         case 16008: launch_qsad<16, 8, 3>(p, pairs, s); break;
         case 16032: launch_qsad<16, 32, 5>(p, pairs, s); break;
-        case 8032: launch_qsad<8, 32, 5>(p, pairs, s); break;
-        case 8016: launch_qsad<8, 16, 5>(p, pairs, s); break;
+        case 8032:
+            if (strip_ok) launch_strip<8, 32>(p, pairs, s); else launch_qsad<8, 32, 5>(p, pairs, s);
+            break;
+        case 8016:
+            if (strip_ok) launch_strip<8, 16>(p, pairs, s); else launch_qsad<8, 16, 5>(p, pairs, s);
+            break;
         case 8008: launch_qsad<8, 8, 3>(p, pairs, s); break;
         default: {
             dim3 grid(p.nbx, p.nby, pairs);
