@@ -2,7 +2,7 @@
 """bench.py -- Mvectors/s of the flow hot path on MI355X (BASELINE.json metric).
 
 A "step" is one pass of the full-search SAD block matcher (N1, the dominant kernel of the hot path)
-over one batch of P consecutive 1080p frame pairs that are already resident in HBM: one launch of
+over one batch of P = 64 consecutive 1080p frame pairs (a 65-frame sequence) already resident in HBM: one launch of
 sad_strip_kernel<16,16> through the C ABI (ofps_hip_sad_flow_dev).  Workload = BASELINE.json
 configs[1] (1080p synthetic, 16x16 blocks, +-16 full search), one GPU's worth per rank (weak scaling:
 independent frame pairs per GPU, no data-path collective -- SURVEY.md 8e).
@@ -39,7 +39,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--pairs", type=int, default=16, help="frame pairs per step (batch resident in HBM)")
+    ap.add_argument("--pairs", type=int, default=64,
+                    help="frame pairs per step: one 65-frame 1080p sequence resident in HBM (135 MB)")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--block", type=int, default=16)

@@ -229,40 +229,49 @@ __global__ __launch_bounds__(256) void sad_qsad_kernel(const SadParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// sad_strip_kernel: the throughput kernel for small ranges (B16 R16 = BASELINE configs[1]).
+// sad_strip_kernel: the throughput kernel (B16 R16 = BASELINE configs[1], and the other table entries).
 //
-// rocprofv3 on sad_qsad_kernel<16,16,5> (profiles/sad_r01_*): VALU 98 % busy, 724 VALU instructions
-// per block of which 320 are packed SADs -- the per-block setup, LDS addressing and argmin scan cost
-// as much issue time as a quarter of the SADs.  This kernel amortises all of that over NB blocks:
-//   * one wave owns a strip of NB = 64/NG horizontally adjacent blocks (7 for +-16); lane = (block b,
-//     dx group g) and walks ALL 2R+1 dy itself: 2(2R+1) packed-u16 accumulator VGPRs, the block of the
-//     current frame in B*B/4 VGPRs (lanes of different blocks differ, so no SGPR operand here);
-//   * the strip's (NB*B+2R) x (B+2R) window is staged once per wave with 16-byte coalesced loads;
-//     every window row is read once (B/4 ds_read2_b32 per lane) and feeds up to B*B/4 packed SADs;
-//   * lane-local argmin key = SAD<<16 | d2<<6 | dy_index: inside one dx group |dx| is distinct, so
-//     (d2, dy) identifies the candidate and the 32-bit order equals the (SAD, d2, dy, dx) order.
-//     dy_index is a compile-time constant per unrolled step, masked columns saturate through a
-//     clamped add, vertical frame clipping is a scalar branch (uniform per strip);
-//   * wave waste: 63/64 lanes, 33/36 dx -> 90 % of issued SADs are useful (85 % before);
-//   * workgroup -> strip mapping is XCD-aware: the 8 XCDs (block b runs on XCD b % 8) each take a
+// rocprofv3 on sad_qsad_kernel<16,16,5> (profiles/r01/sad_block): VALU 98 % busy, 724 VALU instructions
+// per block of which 320 are packed SADs -- per-block setup, LDS addressing and the argmin scan cost as
+// much issue time as a quarter of the SADs, and 15 % of the issued SADs are masked candidates.  Here:
+//   * one wave owns a strip of NB = 64/NG horizontally adjacent blocks, NG = 2R/4 (8 blocks for +-16);
+//     lane = (block b, dx group g) covers dx in [-R, R-1] exactly (no masked dx) and walks ALL 2R+1 dy:
+//     2(2R+1) packed-u16 accumulator VGPRs, its block of the current frame in B*B/4 VGPRs;
+//   * the strip's (NB*B+2R) x (B+2R) window is staged once per wave with 16-byte coalesced loads; every
+//     window row is read once (B/4 ds_read2_b32 per lane) and feeds up to B*B/4 packed SADs;
+//   * the odd column dx = +R (2R+1 is never a multiple of 4) is a short second pass: lane = (block,
+//     chunk of KE dy) with v_sad_u8 on dword-aligned window data (R % 4 == 0) -- 4 % extra SAD-unit
+//     time instead of a ninth dx group that wastes 3 of its 4 shifts and one lane in 64;
+//   * lane-local argmin key = SAD<<16 | d2, walked in ascending dy with a strict <: inside one dx group
+//     |dx| is distinct, so equal (SAD, d2) in one lane means different dy and the walk keeps the spec's
+//     (SAD, d2, dy, dx) order; masked columns saturate through a clamped add; vertical clipping is a
+//     scalar branch (uniform per strip); a 64-bit key finishes the order across the NG lanes of a block;
+//   * workgroup -> strip mapping is XCD-aware: the 8 XCDs (workgroup w runs on XCD w % 8) each take a
 //     contiguous range of strips, so vertically adjacent strips share their halo rows in one L2.
 template <int B, int R>
 struct StripCfg {
-    static_assert(B % 4 == 0 && R % 4 == 0, "tile origin must stay dword aligned");
+    static_assert(B % 4 == 0 && R % 4 == 0, "tile origin and the dx = +R column must stay dword aligned");
     static_assert(B * B * 255 <= 65535, "packed u16 SAD accumulators would overflow");
     static constexpr int NCAND = 2 * R + 1;
-    static constexpr int NG = (NCAND + 3) / 4;
+    static constexpr int NG = (2 * R) / 4;                   // dx groups of 4 covering [-R, R-1]
+    static_assert(NG >= 1 && 64 % NG == 0 && (NG & (NG - 1)) == 0, "NG must be a power of two dividing 64");
     static constexpr int NB = 64 / NG;                       // blocks per wave
     static constexpr int BW = B / 4;
     static constexpr int TILE_H = B + 2 * R;
+    static constexpr int KE = (NCAND + NG - 1) / NG;         // dy per lane in the dx = +R pass
+    static constexpr int EDGE_COL = (2 * R) / 4;             // dword offset of the dx = +R block inside a block's window
     // staging granule: the window origin bx0*B - R must be a multiple of it (NB*B and R both are)
     static constexpr int GRAN = ((NB * B) % 16 == 0 && R % 16 == 0) ? 16 : (((NB * B) % 8 == 0 && R % 8 == 0) ? 8 : 4);
     static constexpr int GDW = GRAN / 4;                          // dwords per granule
     static constexpr int TILE_WG = (NB * B + 2 * R + GRAN - 1) / GRAN;   // granules per window row
     static constexpr int MAXCOL = (NB - 1) * BW + (NG - 1) + BW;  // highest dword a lane touches
     static constexpr int SW = ((MAXCOL + 1 > TILE_WG * GDW ? MAXCOL + 1 : TILE_WG * GDW) + 3) / 4 * 4;  // 16-B rows
+    static_assert((NB - 1) * BW + EDGE_COL + BW <= SW, "edge column must lie inside a window row");
     static constexpr int TILE_DWORDS = TILE_H * SW;
     static_assert(2 * R * R < 65536, "lane key holds d2 in 16 bits");
+    // accumulators + current block + ~40 working registers: ask for 3 waves/SIMD (<= 168 VGPRs) when that fits,
+    // otherwise hipcc spreads into all 256 registers it is allowed and occupancy drops to 2 for nothing
+    static constexpr int MIN_WAVES = (2 * NCAND + B * BW + 40 <= 168) ? 3 : 2;
 };
 
 template <int B, int R, int RR>
@@ -274,7 +283,6 @@ __device__ __forceinline__ void strip_row(unsigned long long (&acc)[2 * R + 1], 
     for (int q = 0; q < C::BW; ++q) win[q] = reinterpret_cast<const U64A4*>(trow + RR * C::SW + q)->v;
 #pragma unroll
     for (int i = 0; i < C::NCAND; ++i) {
-        constexpr int kDummy = 0; (void)kDummy;
         const int y = RR - i;
         if (y >= 0 && y < B) {
 #pragma unroll
@@ -292,7 +300,7 @@ __device__ __forceinline__ void strip_rows(unsigned long long (&acc)[2 * R + 1],
 constexpr int kStripWaves = 4;      // independent waves (strips) per workgroup; no workgroup barrier
 
 template <int B, int R>
-__global__ __launch_bounds__(64 * kStripWaves, 2) void sad_strip_kernel(const SadParams p, int strips_per_row,
+__global__ __launch_bounds__(64 * kStripWaves, (StripCfg<B, R>::MIN_WAVES)) void sad_strip_kernel(const SadParams p, int strips_per_row,
                                                                       int total_strips) {
     using C = StripCfg<B, R>;
     __shared__ __attribute__((aligned(16))) uint32_t tiles[kStripWaves * C::TILE_DWORDS];
@@ -315,17 +323,16 @@ __global__ __launch_bounds__(64 * kStripWaves, 2) void sad_strip_kernel(const Sa
     const uint8_t* __restrict__ cur = p.frames + (size_t)(pair + 1) * p.frame_pitch;
     uint32_t* tile = tiles + wave * C::TILE_DWORDS;
 
-    const bool lane_on = lane < C::NB * C::NG;
-    const int b = lane_on ? lane / C::NG : C::NB - 1;
-    const int g = lane_on ? lane - b * C::NG : 0;
+    const int b = lane / C::NG;          // block of the strip
+    const int g = lane % C::NG;          // dx group in the main pass, dy chunk in the dx = +R pass
     const int bx = bx0 + b;
-    const bool blk_on = lane_on && bx < p.nbx;
+    const bool blk_on = bx < p.nbx;
     const int y0 = by * B;
 
     // ---- this lane's block of the current frame -> VGPRs (lanes of one block read the same lines)
     uint32_t c[B][C::BW];
     {
-        const int bxc = bx < p.nbx ? bx : p.nbx - 1;
+        const int bxc = blk_on ? bx : p.nbx - 1;
         const uint8_t* cp = cur + (size_t)y0 * p.stride + bxc * B;
 #pragma unroll
         for (int y = 0; y < B; ++y) {
@@ -364,27 +371,25 @@ __global__ __launch_bounds__(64 * kStripWaves, 2) void sad_strip_kernel(const Sa
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-    // ---- accumulate: every lane, all dy.  The row walk is expanded through a template pack: a plain
-    // `#pragma unroll` over TILE_H x NCAND steps exceeds hipcc's unroll budget, which leaves the row
-    // index dynamic and sends the c[][] block to scratch memory.
+    // ---- main pass: every lane, all dy, dx = dx0 .. dx0+3.  The row walk is expanded through a template
+    // pack: a plain `#pragma unroll` over TILE_H x NCAND steps exceeds hipcc's unroll budget, which leaves
+    // the row index dynamic and sends the c[][] block to scratch memory.
     unsigned long long acc[C::NCAND];
 #pragma unroll
     for (int i = 0; i < C::NCAND; ++i) acc[i] = 0;
-    const uint32_t* trow = tile + b * C::BW + g;
-    strip_rows<B, R>(acc, c, trow, std::make_integer_sequence<int, C::TILE_H>{});
+    strip_rows<B, R>(acc, c, tile + b * C::BW + g, std::make_integer_sequence<int, C::TILE_H>{});
 #pragma unroll
     for (int i = 0; i < C::NCAND; ++i) asm volatile("" : "+v"(acc[i]));
 
-    // ---- lane-local argmin.  key = SAD<<16 | d2; inside one dx group |dx| is distinct, so two candidates of a
-    // lane with equal (SAD, d2) differ in dy: walking dy upwards with a strict < keeps the spec's order.
-    // colk[j] = dx_j^2, or all-ones for a masked column (the clamped add saturates the whole key).
+    // ---- lane-local argmin of the main pass.  colk[j] = dx_j^2, or all-ones for a column clipped by the frame
+    // (the clamped add then saturates the whole key).
     const int dx0 = -R + 4 * g;
     uint32_t colk[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int dx = dx0 + j;
         const int x = bx * B + dx;
-        const bool v = blk_on && dx <= R && x >= 0 && x + B <= p.W;
+        const bool v = blk_on && x >= 0 && x + B <= p.W;
         colk[j] = v ? (uint32_t)(dx * dx) : 0xFFFFFFFFu;
     }
     uint32_t bkey = 0xFFFFFFFFu;
@@ -415,12 +420,60 @@ __global__ __launch_bounds__(64 * kStripWaves, 2) void sad_strip_kernel(const Sa
         for (int j = 1; j < 4; ++j) dx = ((dx0 + j) * (dx0 + j) == dxsq) ? dx0 + j : dx;
         best = ((unsigned long long)bkey << 32) | (unsigned long long)(uint32_t)(((dy + R) << 8) | (dx + R));
     }
-    // ---- min over the NG lanes of each block (segments of NG lanes; guarded shuffles)
+    // ---- dx = +R pass (after the main scan, so acc[] is dead and the wave stays within 168 VGPRs):
+    // lane = (block b, dy chunk g): KE consecutive dy, one v_sad_u8 per dword
+    uint32_t eacc[C::KE];
 #pragma unroll
-    for (int off = 1; off < C::NG; off <<= 1) {
-        const unsigned long long o = shfl_down_u64(best, off);
-        const bool same = (lane + off < 64) && ((lane + off) / C::NG == lane / C::NG);
-        if (same && o < best) best = o;
+    for (int i = 0; i < C::KE; ++i) eacc[i] = 0;
+    {
+        const uint32_t* ecol = tile + b * C::BW + C::EDGE_COL;
+        const int erow0 = g * C::KE;
+        // one-row software prefetch; the empty asm with a memory clobber keeps hipcc from hoisting all
+        // B+KE-1 rows of LDS reads above the loop (80 extra live VGPRs next to acc[] and c[][])
+        uint32_t nxt[C::BW];
+#pragma unroll
+        for (int q = 0; q < C::BW; ++q) nxt[q] = ecol[min(erow0, C::TILE_H - 1) * C::SW + q];
+#pragma unroll
+        for (int rr = 0; rr < B + C::KE - 1; ++rr) {
+            uint32_t ref[C::BW];
+#pragma unroll
+            for (int q = 0; q < C::BW; ++q) ref[q] = nxt[q];
+            if (rr + 1 < B + C::KE - 1) {
+                // the last chunk overshoots the window by up to KE*NG - NCAND rows: clamp (those dy are masked)
+                const int row = min(erow0 + rr + 1, C::TILE_H - 1);
+#pragma unroll
+                for (int q = 0; q < C::BW; ++q) nxt[q] = ecol[row * C::SW + q];
+            }
+#pragma unroll
+            for (int i = 0; i < C::KE; ++i) {
+                const int y = rr - i;
+                if (y >= 0 && y < B) {
+#pragma unroll
+                    for (int q = 0; q < C::BW; ++q) eacc[i] = __builtin_amdgcn_sad_u8(ref[q], c[y][q], eacc[i]);
+                }
+            }
+            asm volatile("" : "+v"(eacc[0]) : : "memory");
+        }
+    }
+
+    // ---- candidates of the dx = +R pass (ascending dy, strict <)
+    {
+        const bool xok = blk_on && bx * B + R + B <= p.W;
+#pragma unroll
+        for (int i = 0; i < C::KE; ++i) {
+            const int dy = -R + g * C::KE + i;
+            const bool v = xok && dy <= R && y0 + dy >= 0 && y0 + dy + B <= p.H;
+            const unsigned long long k64 =
+                ((unsigned long long)((eacc[i] << 16) | (uint32_t)(R * R + dy * dy)) << 32) |
+                (unsigned long long)(uint32_t)(((dy + R) << 8) | (2 * R));
+            best = (v && k64 < best) ? k64 : best;
+        }
+    }
+    // ---- min over the NG lanes of each block (aligned power-of-two segments: xor butterfly)
+#pragma unroll
+    for (int m = 1; m < C::NG; m <<= 1) {
+        const unsigned long long o = shfl_xor_u64(best, m);
+        best = o < best ? o : best;
     }
     if (blk_on && g == 0) {
         const int sad = (int)(best >> 48);
@@ -550,8 +603,12 @@ int ofps_hip_sad_flow_dev(ofps_hip_ctx* ctx, const void* d_frames, int n_frames,
         case 16016:
             if (strip_ok) launch_strip<16, 16>(p, pairs, s); else launch_qsad<16, 16, 5>(p, pairs, s);
             break;
-        case 16008: launch_qsad<16, 8, 3>(p, pairs, s); break;
-        case 16032: launch_qsad<16, 32, 5>(p, pairs, s); break;
+        case 16008:
+            if (strip_ok) launch_strip<16, 8>(p, pairs, s); else launch_qsad<16, 8, 3>(p, pairs, s);
+            break;
+        case 16032:
+            if (strip_ok) launch_strip<16, 32>(p, pairs, s); else launch_qsad<16, 32, 5>(p, pairs, s);
+            break;
         case 8032:
             if (strip_ok) launch_strip<8, 32>(p, pairs, s); else launch_qsad<8, 32, 5>(p, pairs, s);
             break;
