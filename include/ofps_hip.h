@@ -81,6 +81,16 @@ int ofps_hip_timer_stop(ofps_hip_ctx* ctx, float* elapsed_ms);   /* synchronises
  * Supported: block in {8,16} with range in {4..64, multiple of 4} run on the packed-SAD kernel;
  * any other block<=64, range<=64 runs on the generic kernel.  stride % 4 == 0. */
 size_t ofps_hip_sad_block_count(int W, int H, int block);
+/* Search strategy of ofps_hip_sad_flow*: both return the spec's winner bit for bit.
+ * EXHAUSTIVE evaluates every candidate (content-independent run time, the default).
+ * PRUNED skips candidates whose 8x8 sub-block-sum lower bound (triangle inequality) already exceeds the
+ * best exact SAD found (successive elimination); run time depends on the content; 16x16 blocks, range 16
+ * only -- other geometries ignore the mode. */
+enum { OFPS_HIP_SAD_EXHAUSTIVE = 0, OFPS_HIP_SAD_PRUNED = 1 };
+int ofps_hip_set_sad_mode(ofps_hip_ctx* ctx, int mode);
+/* Diagnostics: how many strips of the last PRUNED call overflowed their survivor lists and were redone by the
+ * exhaustive kernel (synchronises the stream). */
+int ofps_hip_sad_pruned_overflow_strips(ofps_hip_ctx* ctx, uint32_t* count);
 int ofps_hip_sad_flow(ofps_hip_ctx* ctx, const uint8_t* prev, const uint8_t* cur,
                       int W, int H, int stride, int block, int range,
                       float* out_entries /* 4*nblk */, int32_t* out_best /* 3*nblk (dx,dy,sad) or NULL */,

@@ -34,6 +34,8 @@ PROTOTYPES = {
     "ofps_hip_timer_start": (C.c_int, [_ctx]),
     "ofps_hip_timer_stop": (C.c_int, [_ctx, _f32p]),
     "ofps_hip_sad_block_count": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "ofps_hip_set_sad_mode": (C.c_int, [_ctx, C.c_int]),
+    "ofps_hip_sad_pruned_overflow_strips": (C.c_int, [_ctx, _u32p]),
     "ofps_hip_sad_flow": (C.c_int, [_ctx, _u8p, _u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                     _f32p, _i32p, _szp]),
     "ofps_hip_sad_flow_dev": (C.c_int, [_ctx, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_int,

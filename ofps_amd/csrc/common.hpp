@@ -17,6 +17,7 @@ struct ofps_hip_ctx {
     hipStream_t stream = nullptr;        // the stream work is enqueued on (own or caller's)
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     int num_cus = 0;
+    int sad_mode = OFPS_HIP_SAD_EXHAUSTIVE;
     char err[512] = {0};
 
     // grow-only device scratch owned by the context (staging for host-pointer entry points and

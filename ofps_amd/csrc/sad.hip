@@ -301,7 +301,8 @@ constexpr int kStripWaves = 4;      // independent waves (strips) per workgroup;
 
 template <int B, int R>
 __global__ __launch_bounds__(64 * kStripWaves, (StripCfg<B, R>::MIN_WAVES)) void sad_strip_kernel(const SadParams p, int strips_per_row,
-                                                                      int total_strips) {
+                                                                      int total_strips,
+                                                                      const uint32_t* __restrict__ strip_list) {
     using C = StripCfg<B, R>;
     __shared__ __attribute__((aligned(16))) uint32_t tiles[kStripWaves * C::TILE_DWORDS];
 
@@ -311,7 +312,12 @@ __global__ __launch_bounds__(64 * kStripWaves, (StripCfg<B, R>::MIN_WAVES)) void
     // (the grid is padded to a multiple of 8 workgroups so the remap is a bijection)
     const int per_xcd = gridDim.x / 8;
     const int lwg = (int)(blockIdx.x % 8) * per_xcd + (int)(blockIdx.x / 8);
-    const int strip = lwg * kStripWaves + wave;
+    int strip = lwg * kStripWaves + wave;
+    if (strip_list) {
+        // indirect mode (overflow strips of the pruned search): strip_list[0] = count, ids follow
+        if (strip >= (int)strip_list[0]) return;
+        strip = (int)strip_list[1 + strip];
+    }
     if (strip >= total_strips) return;
     const int strips_per_pair = strips_per_row * p.nby;
     const int pair = strip / strips_per_pair;
@@ -493,6 +499,257 @@ __global__ __launch_bounds__(64 * kStripWaves, (StripCfg<B, R>::MIN_WAVES)) void
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// sad_sea_kernel: exact search with successive-elimination pruning (optional mode, B16 R16).
+//
+// Triangle inequality on sub-block sums: for any split of the block into sub-blocks,
+//   sum_k | S_cur(k) - S_ref(k) |  <=  SAD(candidate).
+// With 8x8 sub-blocks the bound costs 4 |a-b| of u16 sums per candidate instead of 256 of pixels.  The
+// kernel computes the bound for every candidate, evaluates the minimum-bound candidate exactly, and then
+// only the candidates whose bound does not exceed that SAD (plus ties).  The winner is the minimum of
+// the same total-order key as the exhaustive kernels, over a candidate set that provably contains the
+// exhaustive winner -> identical output, bit for bit, on any content.  How much is pruned depends on the
+// content; a strip whose survivor lists overflow is handed to sad_strip_kernel through strip_list.
+//
+// MEASURED (round 1): NOT a win on MI355X at +-16.  The SAD unit retires 64 |a-b| per
+// clock per SIMD, so the exhaustive strip kernel needs only ~39k SIMD-cycles per 8-block strip, while the
+// bound passes of this kernel (sliding sums, 8,712 bounds, survivor bookkeeping) already cost ~31k -- and
+// frames with motion discontinuities leave > 48 survivors in at least one block of most strips (73 % of the
+// strips of the bench sequence), which then run the exhaustive kernel as well.  Kept as an opt-in mode
+// (OFPS_HIP_SAD_PRUNED) with its parity tests; the default stays exhaustive.
+//
+// One 256-thread workgroup per strip of 8 blocks (same strips as sad_strip_kernel):
+//   A  stage the 160 x 48 byte window (16-byte loads); 8x8 sums of the current blocks
+//   B  H8: horizontal 8-sums of every window row (thread = row x 32-pixel segment, sliding sum)
+//   C  S8: vertical 8-sums in place (thread = column)
+//   D  bounds: thread = (block, dx); rows of [S8(x), S8(x+8)] pairs are reused by the candidates 8 rows
+//      apart (top row with the upper sub-blocks, bottom row with the lower ones): 2 v_sad_u16 per row
+//   E  per block: minimum bound -> exact SAD of that candidate (32 threads x 8 pixels, v_sad_u8 on
+//      byte-aligned window data)
+//   F  survivors (bound <= that SAD) -> per-block lists in LDS; overflow -> strip_list
+//   G  exact SAD of the survivors, running minimum of the 64-bit key
+struct SeaCfg {
+    static constexpr int B = 16, R = 16, NB = 8;
+    static constexpr int TW = NB * B + 2 * R;        // 160 window bytes per row
+    static constexpr int TH = B + 2 * R;             // 48 rows
+    static constexpr int RAW_DW = TW / 4;            // 40 dwords per raw row
+    static constexpr int SX = TW - 7;                // 153 S8 columns
+    static constexpr int SY = TH - 7;                // 41 S8 rows
+    static constexpr int HS = TW;                    // u16 row stride of the H8/S8 map
+    static constexpr int CAP = 48;                   // survivors kept per block
+    static constexpr int NC = 2 * R + 1;             // 33
+};
+
+__device__ __forceinline__ uint32_t sea_block_sad(const uint32_t* raw, int b, int dyi, int dxi, int j, uint2 cur8) {
+    // 32 threads of a block: thread j covers row j/2, pixels 8*(j%2) .. +7 of candidate (dyi, dxi)
+    const int row = dyi + (j >> 1);
+    const int col = b * SeaCfg::B + dxi + 8 * (j & 1);            // byte column in the window
+    const uint32_t* p = raw + row * SeaCfg::RAW_DW + (col >> 2);
+    const uint32_t d0 = p[0], d1 = p[1], d2 = p[2];
+    const int sh = col & 3;
+    const uint32_t w0 = __builtin_amdgcn_alignbyte(d1, d0, sh);
+    const uint32_t w1 = __builtin_amdgcn_alignbyte(d2, d1, sh);
+    uint32_t s = __builtin_amdgcn_sad_u8(w0, cur8.x, 0u);
+    s = __builtin_amdgcn_sad_u8(w1, cur8.y, s);
+#pragma unroll
+    for (int m = 16; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);   // stays inside the 32-lane half
+    return s;
+}
+
+__global__ __launch_bounds__(256) void sad_sea_kernel(const SadParams p, int strips_per_row, int total_strips,
+                                                      uint32_t* __restrict__ strip_list) {
+    using C = SeaCfg;
+    constexpr int B = C::B, R = C::R;
+    __shared__ __attribute__((aligned(16))) uint32_t raw[C::TH * C::RAW_DW + 4];
+    __shared__ __attribute__((aligned(16))) uint16_t s8[C::TH * C::HS];
+    __shared__ uint32_t cs8[C::NB][2];                       // [b][0] = S(0,0) | S(8,0)<<16 ; [b][1] = S(0,8) | S(8,8)<<16
+    __shared__ uint32_t cnt[C::NB];
+    __shared__ uint32_t list[C::NB][C::CAP];
+    __shared__ int overflow;
+
+    const int tid = threadIdx.x;
+    const int per_xcd = gridDim.x / 8;
+    const int strip = (int)(blockIdx.x % 8) * per_xcd + (int)(blockIdx.x / 8);      // XCD-aware, see sad_strip_kernel
+    if (strip >= total_strips) return;
+    const int strips_per_pair = strips_per_row * p.nby;
+    const int pair = strip / strips_per_pair;
+    const int rem = strip - pair * strips_per_pair;
+    const int by = rem / strips_per_row;
+    const int bx0 = (rem - by * strips_per_row) * C::NB;
+    const int y0 = by * B;
+    const uint8_t* __restrict__ prev = p.frames + (size_t)(p.ref_mode ? 0 : pair) * p.frame_pitch;
+    const uint8_t* __restrict__ cur = p.frames + (size_t)(pair + 1) * p.frame_pitch;
+
+    // ---- A: window + current-block sub-sums
+    {
+        const int tx0 = bx0 * B - R, ty0 = y0 - R;
+        for (int idx = tid; idx < C::TH * (C::TW / 16); idx += 256) {
+            const int row = idx / (C::TW / 16), col = idx - row * (C::TW / 16);
+            const int gx = tx0 + 16 * col, gy = ty0 + row;
+            if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W)
+                *reinterpret_cast<uint4*>(raw + row * C::RAW_DW + 4 * col) =
+                    *reinterpret_cast<const uint4*>(prev + (size_t)gy * p.stride + gx);
+        }
+        if (tid < C::NB) cnt[tid] = 0;
+        if (tid == 0) overflow = 0;
+    }
+    const int b = tid >> 5, j = tid & 31;                    // block of the strip, thread in block
+    const int bx = bx0 + b;
+    const bool blk_on = bx < p.nbx;
+    const int bxc = blk_on ? bx : p.nbx - 1;
+    // my 8 pixels of the current block (row j/2, half j%2): fixed for every candidate
+    const uint2 cur8 = *reinterpret_cast<const uint2*>(cur + (size_t)(y0 + (j >> 1)) * p.stride + bxc * B + 8 * (j & 1));
+    {
+        // sub-block (sx, sy) = (j%2, row/8): sum of my 8 pixels, then over the 8 rows of the sub-block
+        uint32_t s = __builtin_amdgcn_sad_u8(cur8.x, 0u, 0u);
+        s = __builtin_amdgcn_sad_u8(cur8.y, 0u, s);
+        s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 8, 64);   // rows r, r^1, r^2, r^4
+        // lanes j with (j>>1)&7 == 0 hold the sums: j in {0,1} -> sy 0, j in {16,17} -> sy 1
+        const uint32_t other = __shfl_xor(s, 1, 64);          // partner sub-block sx^1
+        if ((j & 15) == 0) cs8[b][j >> 4] = s | (other << 16);
+    }
+    __syncthreads();
+
+    // ---- B: horizontal 8-sums.  thread = (row, 32-position segment); 240 threads busy
+    if (tid < C::TH * 5) {
+        const int row = tid / 5, seg = tid - row * 5;
+        const uint32_t* rp = raw + row * C::RAW_DW + 8 * seg;
+        uint32_t d[10];
+#pragma unroll
+        for (int k = 0; k < 10; ++k) d[k] = rp[k];            // last segment reads 2 dwords past the row: unused positions
+        uint32_t s = __builtin_amdgcn_sad_u8(d[0], 0u, 0u);
+        s = __builtin_amdgcn_sad_u8(d[1], 0u, s);
+        uint32_t out[16];
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+            if (k & 1) out[k >> 1] |= s << 16; else out[k >> 1] = s;
+            const uint32_t add = (d[(k + 8) >> 2] >> (8 * ((k + 8) & 3))) & 0xFFu;
+            const uint32_t sub = (d[k >> 2] >> (8 * (k & 3))) & 0xFFu;
+            s = s + add - sub;
+        }
+        uint32_t* op = reinterpret_cast<uint32_t*>(s8 + row * C::HS + 32 * seg);
+        if (seg < 4) {
+#pragma unroll
+            for (int k = 0; k < 16; k += 4) *reinterpret_cast<uint4*>(op + k) = make_uint4(out[k], out[k + 1], out[k + 2], out[k + 3]);
+        } else {                                              // positions 128..152 (+ one pad position)
+#pragma unroll
+            for (int k = 0; k < 13; ++k) op[k] = out[k];
+        }
+    }
+    __syncthreads();
+
+    // ---- C: vertical 8-sums in place.  thread = column
+    if (tid < C::SX) {
+        uint16_t* colp = s8 + tid;
+        uint32_t s = 0;
+#pragma unroll
+        for (int y = 0; y < 8; ++y) s += colp[y * C::HS];
+#pragma unroll
+        for (int y = 0; y < C::SY; ++y) {
+            const uint32_t top = colp[y * C::HS];
+            const uint32_t bot = (y + 8 < C::TH) ? colp[(y + 8) * C::HS] : 0u;
+            colp[y * C::HS] = (uint16_t)s;
+            s = s + bot - top;
+        }
+    }
+    __syncthreads();
+
+    // ---- D: bounds.  thread (b, j): dx index j (dx = j - R) for all 33 dy; the dx = +R column: dy index j (+32 on j = 0)
+    const uint32_t cs01 = cs8[b][0], cs23 = cs8[b][1];
+    uint32_t bnd[C::NC];
+    {
+        const uint16_t* sp = s8 + b * B + j;
+        uint32_t top[C::SY];                                  // only a sliding window of 9 stays live after unrolling
+#pragma unroll
+        for (int r = 0; r < C::SY; ++r) {
+            const uint32_t pr = (uint32_t)sp[r * C::HS] | ((uint32_t)sp[r * C::HS + 8] << 16);
+            if (r < C::NC) top[r] = __builtin_amdgcn_sad_u16(pr, cs01, 0u);
+            if (r >= 8) bnd[r - 8] = __builtin_amdgcn_sad_u16(pr, cs23, top[r - 8]);
+        }
+    }
+    uint32_t ebnd0, ebnd1 = 0xFFFFu;                          // dx = +R column: dy index j, and 32 for j == 0
+    {
+        const uint16_t* sp = s8 + b * B + 2 * R;
+        auto colbound = [&](int dyi) {
+            const uint32_t pt = (uint32_t)sp[dyi * C::HS] | ((uint32_t)sp[dyi * C::HS + 8] << 16);
+            const uint32_t pb = (uint32_t)sp[(dyi + 8) * C::HS] | ((uint32_t)sp[(dyi + 8) * C::HS + 8] << 16);
+            return __builtin_amdgcn_sad_u16(pb, cs23, __builtin_amdgcn_sad_u16(pt, cs01, 0u));
+        };
+        ebnd0 = colbound(j);
+        if (j == 0) ebnd1 = colbound(32);
+    }
+    // validity (block inside the frame)
+    const int xj = bx * B + j - R;
+    const bool vx = blk_on && xj >= 0 && xj + B <= p.W;
+    const bool vxe = blk_on && bx * B + R + B <= p.W;
+    auto vy = [&](int dyi) { const int y = y0 + dyi - R; return y >= 0 && y + B <= p.H; };
+
+    // ---- E: minimum bound of the block -> its exact SAD.  key = bound<<16 | dyi<<8 | dxi
+    uint32_t mk = 0xFFFFFFFFu;
+#pragma unroll
+    for (int i = 0; i < C::NC; ++i) {
+        const uint32_t k = (bnd[i] << 16) | (uint32_t)(i << 8) | (uint32_t)j;
+        mk = (vx && vy(i) && k < mk) ? k : mk;
+    }
+    {
+        const uint32_t k0 = (ebnd0 << 16) | (uint32_t)(j << 8) | 32u;
+        mk = (vxe && vy(j) && k0 < mk) ? k0 : mk;
+        const uint32_t k1 = (ebnd1 << 16) | (32u << 8) | 32u;
+        mk = (j == 0 && vxe && vy(32) && k1 < mk) ? k1 : mk;
+    }
+#pragma unroll
+    for (int m = 16; m >= 1; m >>= 1) mk = min(mk, (uint32_t)__shfl_xor(mk, m, 64));
+    // (0,0) is always a valid candidate of a full block, so mk is a real candidate when blk_on
+    const int idy = (int)((mk >> 8) & 0xFF), idx0 = (int)(mk & 0xFF);
+    auto key64 = [&](uint32_t sad, int dyi, int dxi) {
+        const int dy = dyi - R, dx = dxi - R;
+        return ((unsigned long long)((sad << 16) | (uint32_t)(dx * dx + dy * dy)) << 32) |
+               (unsigned long long)(uint32_t)((dyi << 8) | dxi);
+    };
+    uint32_t best_sad = sea_block_sad(raw, b, blk_on ? idy : R, blk_on ? idx0 : R, j, cur8);
+    unsigned long long best = key64(best_sad, blk_on ? idy : R, blk_on ? idx0 : R);
+
+    // ---- F: survivors
+    if (blk_on) {
+#pragma unroll
+        for (int i = 0; i < C::NC; ++i) {
+            if (vx && vy(i) && bnd[i] <= best_sad && !(i == idy && j == idx0)) {
+                const uint32_t pos = atomicAdd(&cnt[b], 1u);
+                if (pos < C::CAP) list[b][pos] = (uint32_t)(i << 8) | (uint32_t)j;
+            }
+        }
+        if (vxe && vy(j) && ebnd0 <= best_sad && !(j == idy && 32 == idx0)) {
+            const uint32_t pos = atomicAdd(&cnt[b], 1u);
+            if (pos < C::CAP) list[b][pos] = (uint32_t)(j << 8) | 32u;
+        }
+        if (j == 0 && vxe && vy(32) && ebnd1 <= best_sad && !(32 == idy && 32 == idx0)) {
+            const uint32_t pos = atomicAdd(&cnt[b], 1u);
+            if (pos < C::CAP) list[b][pos] = (32u << 8) | 32u;
+        }
+    }
+    __syncthreads();
+    const uint32_t n = cnt[b];
+    if (blk_on && n > C::CAP && j == 0) overflow = 1;
+    __syncthreads();
+    if (overflow) {                                           // hand the whole strip to the exhaustive kernel
+        if (tid == 0) {
+            const uint32_t pos = atomicAdd(&strip_list[0], 1u);
+            strip_list[1 + pos] = (uint32_t)strip;
+        }
+        return;
+    }
+
+    // ---- G: exact SAD of the survivors (all 32 threads of a block on one candidate at a time)
+    for (uint32_t sidx = 0; sidx < n; ++sidx) {
+        const uint32_t cnd = list[b][sidx];
+        const int dyi = (int)(cnd >> 8), dxi = (int)(cnd & 0xFF);
+        const uint32_t sad = sea_block_sad(raw, b, dyi, dxi, j, cur8);
+        const unsigned long long k = key64(sad, dyi, dxi);
+        best = k < best ? k : best;
+    }
+    if (blk_on && j == 0) write_block_result(p, pair, bx, by, B, R, best);
+}
+
 // Generic kernel for block/range pairs the packed-SAD kernel does not cover: one wave per block,
 // lanes over candidates, bytes straight from global memory (L1/L2 absorb the reuse).  Slow path.
 __global__ __launch_bounds__(64) void sad_generic_kernel(const SadParams p, int B, int R) {
@@ -553,7 +810,25 @@ void launch_strip(const SadParams& p, int pairs, hipStream_t s) {
     const int strips_per_row = (p.nbx + C::NB - 1) / C::NB;
     const int total = strips_per_row * p.nby * pairs;
     const int nwg = ((total + kStripWaves - 1) / kStripWaves + 7) / 8 * 8;     // multiple of 8: see the XCD remap
-    hipLaunchKernelGGL((sad_strip_kernel<B, R>), dim3(nwg), dim3(64 * kStripWaves), 0, s, p, strips_per_row, total);
+    hipLaunchKernelGGL((sad_strip_kernel<B, R>), dim3(nwg), dim3(64 * kStripWaves), 0, s, p, strips_per_row, total,
+                       (const uint32_t*)nullptr);
+}
+
+// pruned search: sad_sea_kernel over every strip, then the exhaustive kernel over the overflow strips
+int launch_sea_16_16(ofps_hip_ctx* ctx, const SadParams& p, int pairs, hipStream_t s) {
+    using C = StripCfg<16, 16>;
+    static_assert(C::NB == SeaCfg::NB, "both kernels must cut the frame into the same strips");
+    const int strips_per_row = (p.nbx + C::NB - 1) / C::NB;
+    const int total = strips_per_row * p.nby * pairs;
+    auto* strip_list = static_cast<uint32_t*>(ofps::scratch(ctx, ofps::S_WORK0, (size_t)(total + 1) * sizeof(uint32_t)));
+    if (!strip_list) return OFPS_HIP_ENOMEM;
+    OFPS_HIP_TRY(ctx, hipMemsetAsync(strip_list, 0, sizeof(uint32_t), s));
+    const int nwg_sea = (total + 7) / 8 * 8;
+    hipLaunchKernelGGL(sad_sea_kernel, dim3(nwg_sea), dim3(256), 0, s, p, strips_per_row, total, strip_list);
+    const int nwg = ((total + kStripWaves - 1) / kStripWaves + 7) / 8 * 8;
+    hipLaunchKernelGGL((sad_strip_kernel<16, 16>), dim3(nwg), dim3(64 * kStripWaves), 0, s, p, strips_per_row, total,
+                       (const uint32_t*)strip_list);
+    return OFPS_HIP_OK;
 }
 
 }  // namespace
@@ -601,7 +876,11 @@ int ofps_hip_sad_flow_dev(ofps_hip_ctx* ctx, const void* d_frames, int n_frames,
         // strip kernels need 16-byte aligned rows; otherwise (or with OFPS_HIP_SAD_KERNEL=block, A/B
         // profiling only) the per-block kernel handles the pair.
         case 16016:
-            if (strip_ok) launch_strip<16, 16>(p, pairs, s); else launch_qsad<16, 16, 5>(p, pairs, s);
+            if (strip_ok && ctx->sad_mode == OFPS_HIP_SAD_PRUNED) {
+                const int rc = launch_sea_16_16(ctx, p, pairs, s);
+                if (rc != OFPS_HIP_OK) return rc;
+            } else if (strip_ok) launch_strip<16, 16>(p, pairs, s);
+            else launch_qsad<16, 16, 5>(p, pairs, s);
             break;
         case 16008:
             if (strip_ok) launch_strip<16, 8>(p, pairs, s); else launch_qsad<16, 8, 3>(p, pairs, s);
@@ -650,6 +929,24 @@ int ofps_hip_sad_flow(ofps_hip_ctx* ctx, const uint8_t* prev, const uint8_t* cur
     }
     OFPS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (n_out) *n_out = nblk;
+    return OFPS_HIP_OK;
+}
+
+int ofps_hip_sad_pruned_overflow_strips(ofps_hip_ctx* ctx, uint32_t* count) {
+    if (!ctx || !count) return OFPS_HIP_EINVAL;
+    *count = 0;
+    auto& sc = ctx->scratch[ofps::S_WORK0];
+    if (!sc.p) return OFPS_HIP_OK;
+    OFPS_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    OFPS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    OFPS_HIP_TRY(ctx, hipMemcpy(count, sc.p, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return OFPS_HIP_OK;
+}
+
+int ofps_hip_set_sad_mode(ofps_hip_ctx* ctx, int mode) {
+    if (!ctx) return OFPS_HIP_EINVAL;
+    OFPS_REQUIRE(ctx, mode == OFPS_HIP_SAD_EXHAUSTIVE || mode == OFPS_HIP_SAD_PRUNED, "set_sad_mode: unknown mode %d", mode);
+    ctx->sad_mode = mode;
     return OFPS_HIP_OK;
 }
 

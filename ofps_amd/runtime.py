@@ -66,6 +66,17 @@ class HipContext:
         return float(ms.value)
 
     # ---- N1
+    SAD_EXHAUSTIVE, SAD_PRUNED = 0, 1
+
+    def set_sad_mode(self, mode: int):
+        """0 = exhaustive (default), 1 = exact search with successive-elimination pruning."""
+        self._check(self._lib.ofps_hip_set_sad_mode(self._h, mode))
+
+    def sad_pruned_overflow_strips(self) -> int:
+        n = C.c_uint32(0)
+        self._check(self._lib.ofps_hip_sad_pruned_overflow_strips(self._h, C.byref(n)))
+        return int(n.value)
+
     def sad_flow(self, prev: np.ndarray, cur: np.ndarray, block: int, search_range: int, want_best=False):
         prev = np.ascontiguousarray(prev, np.uint8); cur = np.ascontiguousarray(cur, np.uint8)
         assert prev.shape == cur.shape and prev.ndim == 2
