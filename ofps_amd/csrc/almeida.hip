@@ -79,6 +79,32 @@ __device__ __forceinline__ float2 cam_delta(const Camera& c, float px, float py,
     return make_float2(ox - px, oy - py);
 }
 
+// The unprojected point (camera.rs:45-55) does not depend on the rotation: hoisted out of the 30-step loop.
+struct Unproj { float wx, wy, wz; };
+__device__ __forceinline__ Unproj cam_unproject(const Camera& c, float px, float py) {
+    const float cx = px * 2.0f - 1.0f, cy = py * 2.0f - 1.0f;
+    const float n0 = c.r32 + c.r33;
+    Unproj u;
+    u.wx = ((-c.r00) * cx) / n0;
+    u.wy = -1.0f / n0;
+    u.wz = (c.r11 * cy) / n0;
+    return u;
+}
+// rotate + project + subtract: same operations, same order as cam_delta after its first four lines
+__device__ __forceinline__ float2 cam_delta_w(const Camera& c, float px, float py, const Unproj& u, const Mat3& R) {
+    const float rx = (R.m[0] * u.wx + R.m[1] * u.wy) + R.m[2] * u.wz;
+    const float ry = (R.m[3] * u.wx + R.m[4] * u.wy) + R.m[5] * u.wz;
+    const float rz = (R.m[6] * u.wx + R.m[7] * u.wy) + R.m[8] * u.wz;
+    const float qx = -rx, qy = rz, qz = ry;
+    const float inv = -1.0f / qz;
+    const float sx = c.m00 * qx * inv;
+    const float sy = c.m11 * qy * inv;
+    const float sz = (c.m22 * qz + c.m23) * inv;
+    const float ox = (sx / sz + 1.0f) * 0.5f;
+    const float oy = (sy / sz + 1.0f) * 0.5f;
+    return make_float2(ox - px, oy - py);
+}
+
 // camera.rs:150-161
 __device__ __forceinline__ float2 cam_point_angle(const Camera& c, float fx, float fy, float px, float py) {
     return make_float2(atanf((px - 0.5f) / fx), atanf((py - 0.5f) / fy));
@@ -257,15 +283,17 @@ __global__ __launch_bounds__(1024) void almeida_lsq_wg_kernel(const float4* __re
     const Mat3 myaw = mat3_from_euler(0.0f, 0.0f, -eps);           // lib.rs:40-42
     float4 e[EPT];
     float2 pr[EPT], pp[EPT], py[EPT];
+    Unproj un[EPT];
     bool ok[EPT];
 #pragma unroll
     for (int t = 0; t < EPT; ++t) {
         const size_t i = (size_t)t * 1024 + threadIdx.x;
         ok[t] = i < n;
         e[t] = ok[t] ? entries[item * stride + i] : make_float4(0.5f, 0.5f, 0.0f, 0.0f);
-        pr[t] = cam_delta(cam, e[t].x, e[t].y, mroll);
-        pp[t] = cam_delta(cam, e[t].x, e[t].y, mpitch);
-        py[t] = cam_delta(cam, e[t].x, e[t].y, myaw);
+        un[t] = cam_unproject(cam, e[t].x, e[t].y);
+        pr[t] = cam_delta_w(cam, e[t].x, e[t].y, un[t], mroll);
+        pp[t] = cam_delta_w(cam, e[t].x, e[t].y, un[t], mpitch);
+        py[t] = cam_delta_w(cam, e[t].x, e[t].y, un[t], myaw);
     }
     Quat rotation = {1.0f, 0.0f, 0.0f, 0.0f};
     for (int it = 0; it < kIters; ++it) {
@@ -275,7 +303,7 @@ __global__ __launch_bounds__(1024) void almeida_lsq_wg_kernel(const float4* __re
 #pragma unroll
         for (int t = 0; t < EPT; ++t) {
             if (!ok[t]) continue;
-            const float2 d = cam_delta(cam, e[t].x, e[t].y, rotm);
+            const float2 d = cam_delta_w(cam, e[t].x, e[t].y, un[t], rotm);
             const float rx = e[t].z - d.x, ry = e[t].w - d.y;      // motion - delta
             s[0] += pr[t].x * pr[t].x + pr[t].y * pr[t].y;
             s[1] += pr[t].x * pp[t].x + pr[t].y * pp[t].y;
@@ -305,21 +333,29 @@ __global__ __launch_bounds__(1024) void almeida_lsq_step_kernel(const float4* __
                                                                 float* __restrict__ part_out, Quat* __restrict__ state,
                                                                 int batch, float4* __restrict__ out_quat) {
     __shared__ float red[16][9];
+    __shared__ float fold_sh[9];
     __shared__ Quat rot_sh;
     const size_t item = blockIdx.y;
     const int nblk = gridDim.x;
     const float eps = almeida_eps();
+    // fold the previous step's partials: wave k sums entry k over the workgroups (lane-strided, then a
+    // butterfly) -- a fixed order, identical in every workgroup, without a 9*nblk serial chain on one lane
+    if (it > 0 && threadIdx.x < 9 * 64) {
+        const int k = threadIdx.x >> 6, l = threadIdx.x & 63;
+        float acc = 0.0f;
+        for (int b = l; b < nblk; b += 64) acc += part_prev[(item * nblk + b) * 9 + k];
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m, 64);
+        if (l == 0) fold_sh[k] = acc;
+    }
+    __syncthreads();
     if (threadIdx.x == 0) {
         Quat rotation = {1.0f, 0.0f, 0.0f, 0.0f};
         if (it > 0) {
             rotation = state[(size_t)((it - 1) & 1) * batch + item];
             float s[9];
 #pragma unroll
-            for (int k = 0; k < 9; ++k) {
-                float acc = part_prev[(item * nblk) * 9 + k];
-                for (int b = 1; b < nblk; ++b) acc += part_prev[(item * nblk + b) * 9 + k];
-                s[k] = acc;
-            }
+            for (int k = 0; k < 9; ++k) s[k] = fold_sh[k];
             const float alpha = (it - 1 == kIters - 1) ? 1.0f : 0.5f;
             rotation = almeida_update(rotation, s, eps, alpha);
         }
@@ -339,10 +375,11 @@ __global__ __launch_bounds__(1024) void almeida_lsq_step_kernel(const float4* __
     float s[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (size_t i = (size_t)blockIdx.x * 1024 + threadIdx.x; i < n; i += (size_t)nblk * 1024) {
         const float4 e = entries[item * n + i];
-        const float2 d = cam_delta(cam, e.x, e.y, rotm);
-        const float2 pr = cam_delta(cam, e.x, e.y, mroll);
-        const float2 pp = cam_delta(cam, e.x, e.y, mpitch);
-        const float2 py = cam_delta(cam, e.x, e.y, myaw);
+        const Unproj un = cam_unproject(cam, e.x, e.y);
+        const float2 d = cam_delta_w(cam, e.x, e.y, un, rotm);
+        const float2 pr = cam_delta_w(cam, e.x, e.y, un, mroll);
+        const float2 pp = cam_delta_w(cam, e.x, e.y, un, mpitch);
+        const float2 py = cam_delta_w(cam, e.x, e.y, un, myaw);
         const float rx = e.z - d.x, ry = e.w - d.y;
         s[0] += pr.x * pr.x + pr.y * pr.y;
         s[1] += pr.x * pp.x + pr.y * pp.y;
@@ -537,7 +574,11 @@ __global__ __launch_bounds__(1024) void ransac_select_kernel(const float4* __res
 static int lsq_device(ofps_hip_ctx* ctx, const float4* d_entries, size_t stride, size_t n_max, const uint32_t* d_n,
                       uint32_t min_n, int batch, const Camera& cam, float4* d_quat) {
     hipStream_t s = ctx->stream;
-    if (n_max <= 8192) {
+    // One-workgroup solver: one launch, 30 steps at ~13 us each on a single CU -- best for batches (one CU
+    // per item) and mandatory when the entry count lives on the device (RANSAC refit).  A lone problem is
+    // faster spread over many CUs with one launch per step.
+    const bool wg_path = n_max <= 8192 && (d_n != nullptr || batch >= 4 || n_max <= 1024);
+    if (wg_path) {
         const dim3 g(batch), b(1024);
         if (n_max <= 1024) hipLaunchKernelGGL((almeida_lsq_wg_kernel<1>), g, b, 0, s, d_entries, stride, n_max, d_n, min_n, cam, d_quat);
         else if (n_max <= 2048) hipLaunchKernelGGL((almeida_lsq_wg_kernel<2>), g, b, 0, s, d_entries, stride, n_max, d_n, min_n, cam, d_quat);
@@ -546,7 +587,8 @@ static int lsq_device(ofps_hip_ctx* ctx, const float4* d_entries, size_t stride,
     } else {
         OFPS_REQUIRE(ctx, d_n == nullptr && stride == n_max, "almeida: device-side counts need n <= 8192");
         // enough workgroups to fill the chip, few enough that the fixed-order fold stays short
-        int nblk = (int)((n_max + 8 * 1024 - 1) / (8 * 1024));
+        const size_t per_wg = n_max > 65536 ? 8 * 1024 : 1024;
+        int nblk = (int)((n_max + per_wg - 1) / per_wg);
         const int cap = (2 * ctx->num_cus + batch - 1) / batch;
         if (nblk > cap) nblk = cap < 1 ? 1 : cap;
         auto* part = static_cast<float*>(scratch(ctx, S_WORK0, 2 * (size_t)batch * nblk * 9 * sizeof(float)));

@@ -7,7 +7,8 @@
 //   1. cell_kernel        one thread per entry: nalgebra clamp quirk + round-half-away -> cell id
 //   2. stable LSD radix sort of (cell id, entry index), 8-bit digits, 1 pass for <= 256 cells,
 //      2 for <= 65536.  Ranks inside a 1024-entry tile come from an 8-ballot "same digit" match
-//      per wave plus a 16-slot per-digit prefix in LDS; tile bases from a digit-major scan.
+//      per wave plus a 16-slot per-digit prefix in LDS; tile bases from a digit-major scan (one
+//      workgroup per digit) plus the prefix over the 256 digit totals.
 //   3. bounds_kernel      first/last sorted position of every cell
 //   4. cell_sum_kernel    one wave per cell: lanes gather 64 entries at a time into LDS, lanes 0/1
 //      then add x / y sequentially in input order; counts replay eps + 1 + 1 + ...;
@@ -70,38 +71,66 @@ __global__ __launch_bounds__(256) void sort_count_kernel(const uint32_t* __restr
     hist[(item * 256 + threadIdx.x) * ntiles + tile] = cnt[threadIdx.x];
 }
 
-// exclusive scan of hist[item][...] (256*ntiles values, digit-major) by one workgroup per item
-__global__ __launch_bounds__(1024) void sort_scan_kernel(uint32_t* __restrict__ hist, int ntiles) {
-    __shared__ uint32_t part[1024];
-    const size_t item = blockIdx.x;
-    uint32_t* h = hist + item * 256 * (size_t)ntiles;
-    const int total = 256 * ntiles;
-    const int per = (total + 1023) / 1024;
-    const int lo = threadIdx.x * per, hi = min(lo + per, total);
-    uint32_t s = 0;
-    for (int i = lo; i < hi; ++i) s += h[i];
-    part[threadIdx.x] = s;
+// Digit-major scan, one workgroup per (digit, item): exclusive prefix of that digit's counts over the tiles
+// (coalesced 256-element chunks, Hillis-Steele in LDS, running carry) + the digit's total.  The scatter
+// kernel adds the exclusive prefix over the 256 digit totals itself.
+__global__ __launch_bounds__(256) void sort_scan_kernel(uint32_t* __restrict__ hist, int ntiles,
+                                                        uint32_t* __restrict__ digit_total) {
+    __shared__ uint32_t sc[256];
+    __shared__ uint32_t carry_sh;
+    const size_t item = blockIdx.y;
+    const int digit = blockIdx.x;
+    uint32_t* h = hist + (item * 256 + digit) * (size_t)ntiles;
+    if (threadIdx.x == 0) carry_sh = 0;
     __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {         // Hillis-Steele inclusive scan
-        uint32_t v = threadIdx.x >= off ? part[threadIdx.x - off] : 0;
+    for (int c0 = 0; c0 < ntiles; c0 += 256) {
+        const int i = c0 + threadIdx.x;
+        const uint32_t v = i < ntiles ? h[i] : 0u;
+        sc[threadIdx.x] = v;
         __syncthreads();
-        part[threadIdx.x] += v;
+#pragma unroll
+        for (int off = 1; off < 256; off <<= 1) {
+            const uint32_t t = threadIdx.x >= (unsigned)off ? sc[threadIdx.x - off] : 0u;
+            __syncthreads();
+            sc[threadIdx.x] += t;
+            __syncthreads();
+        }
+        const uint32_t carry = carry_sh;
+        if (i < ntiles) h[i] = carry + sc[threadIdx.x] - v;
+        __syncthreads();
+        if (threadIdx.x == 255) carry_sh = carry + sc[255];
         __syncthreads();
     }
-    uint32_t run = threadIdx.x ? part[threadIdx.x - 1] : 0;
-    for (int i = lo; i < hi; ++i) { const uint32_t v = h[i]; h[i] = run; run += v; }
+    if (threadIdx.x == 0) digit_total[item * 256 + digit] = carry_sh;
 }
 
 // stable scatter of one tile
 __global__ __launch_bounds__(256) void sort_scatter_kernel(const uint32_t* __restrict__ keys_in,
                                                            const uint32_t* __restrict__ vals_in, size_t n, int shift,
                                                            int ntiles, const uint32_t* __restrict__ hist,
+                                                           const uint32_t* __restrict__ digit_total,
                                                            uint32_t* __restrict__ keys_out,
                                                            uint32_t* __restrict__ vals_out) {
     __shared__ uint32_t slot_cnt[16][256];      // [round*4 + wave][digit]
+    __shared__ uint32_t dbase[256];             // exclusive prefix over the digit totals of this item
     const size_t item = blockIdx.y;
     const int tile = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int i = tid; i < 16 * 256; i += 256) (&slot_cnt[0][0])[i] = 0;
+    {
+        const uint32_t mine = digit_total[item * 256 + tid];
+        dbase[tid] = mine;
+        __syncthreads();
+#pragma unroll
+        for (int off = 1; off < 256; off <<= 1) {
+            const uint32_t t = tid >= off ? dbase[tid - off] : 0u;
+            __syncthreads();
+            dbase[tid] += t;
+            __syncthreads();
+        }
+        const uint32_t incl = dbase[tid];
+        __syncthreads();
+        dbase[tid] = incl - mine;
+    }
     __syncthreads();
     const size_t base = (size_t)tile * kTile;
     uint32_t key[4], val[4], rank[4];
@@ -135,7 +164,7 @@ __global__ __launch_bounds__(256) void sort_scatter_kernel(const uint32_t* __res
     for (int r = 0; r < 4; ++r) {
         if (!ok[r]) continue;
         const uint32_t d = (key[r] >> shift) & 0xFF;
-        const size_t pos = (size_t)hist[(item * 256 + d) * ntiles + tile] + slot_cnt[r * 4 + wave][d] + rank[r];
+        const size_t pos = (size_t)dbase[d] + hist[(item * 256 + d) * ntiles + tile] + slot_cnt[r * 4 + wave][d] + rank[r];
         keys_out[item * n + pos] = key[r];
         vals_out[item * n + pos] = val[r];
     }
@@ -250,8 +279,9 @@ int densify_device(ofps_hip_ctx* ctx, const float4* d_entries, size_t n, int bat
         const int ntiles = (int)((n + kTile - 1) / kTile);
         auto* k0 = static_cast<uint32_t*>(scratch(ctx, S_WORK0, 2 * tot * sizeof(uint32_t)));
         auto* k1 = static_cast<uint32_t*>(scratch(ctx, S_WORK1, 2 * tot * sizeof(uint32_t)));
-        auto* hist = static_cast<uint32_t*>(scratch(ctx, S_WORK2, (size_t)batch * 256 * ntiles * sizeof(uint32_t)));
+        auto* hist = static_cast<uint32_t*>(scratch(ctx, S_WORK2, (size_t)batch * 256 * (ntiles + 1) * sizeof(uint32_t)));
         if (!k0 || !k1 || !hist) return OFPS_HIP_ENOMEM;
+        uint32_t* digit_total = hist + (size_t)batch * 256 * ntiles;
         uint32_t *keys_a = k0, *vals_a = k0 + tot, *keys_b = k1, *vals_b = k1 + tot;
         const dim3 ge((unsigned)((n + 255) / 256), batch), gt(ntiles, batch);
         hipLaunchKernelGGL(cell_kernel, ge, dim3(256), 0, s, d_entries, n, w, h, keys_a, vals_a, d_cells);
@@ -259,9 +289,9 @@ int densify_device(ofps_hip_ctx* ctx, const float4* d_entries, size_t n, int bat
         for (int p = 0; p < passes; ++p) {
             const int shift = 8 * p;
             hipLaunchKernelGGL(sort_count_kernel, gt, dim3(256), 0, s, keys_a, n, shift, ntiles, hist);
-            hipLaunchKernelGGL(sort_scan_kernel, dim3(batch), dim3(1024), 0, s, hist, ntiles);
-            hipLaunchKernelGGL(sort_scatter_kernel, gt, dim3(256), 0, s, keys_a, vals_a, n, shift, ntiles, hist, keys_b,
-                               vals_b);
+            hipLaunchKernelGGL(sort_scan_kernel, dim3(256, batch), dim3(256), 0, s, hist, ntiles, digit_total);
+            hipLaunchKernelGGL(sort_scatter_kernel, gt, dim3(256), 0, s, keys_a, vals_a, n, shift, ntiles, hist, digit_total,
+                               keys_b, vals_b);
             uint32_t* t;
             t = keys_a; keys_a = keys_b; keys_b = t;
             t = vals_a; vals_a = vals_b; vals_b = t;
