@@ -134,6 +134,28 @@ int ofps_hip_almeida_dev(ofps_hip_ctx* ctx, const void* d_entries, size_t n_per_
                          float inlier_deg, size_t num_samples, uint64_t seed,
                          void* d_out_quat /* 4 f32 per item */);
 
+/* ---- fused per-frame path (live streams): decoder -> detector + estimator, vectors stay on the device ----
+ * One call per arriving luma frame = one iteration of the reference's worker loops
+ * (ofps-suite/src/app/detection.rs:111-148, tracking/worker.rs:328-361).  The context keeps the previous
+ * frame on the device; the first frame after ofps_hip_init / ofps_hip_reset_frames / a geometry change
+ * yields have_vectors = 0 (Decoder::process_frame -> Ok(false)). */
+typedef struct {
+    int block, range;                                   /* hip_sad */
+    int run_detector;                                   /* hip_block_motion */
+    float min_size; size_t subdivide; float target_motion;
+    int run_estimator;                                  /* hip_almeida */
+    float aspect, fov_y_deg; int use_ransac; size_t num_iters; float inlier_deg; size_t num_samples; uint64_t seed;
+} ofps_hip_frame_params;
+typedef struct {
+    int have_vectors; size_t n_vectors;
+    int has_motion; size_t area; int dim;               /* detector: Some((area, field dim x dim)) / None */
+    float quat[4];                                      /* estimator: (w,i,j,k); identity when not run */
+} ofps_hip_frame_result;
+int ofps_hip_reset_frames(ofps_hip_ctx* ctx);
+int ofps_hip_push_frame(ofps_hip_ctx* ctx, const uint8_t* luma, int W, int H, int stride,
+                        const ofps_hip_frame_params* params, ofps_hip_frame_result* out,
+                        float* out_entries /* 4*nblk or NULL */, float* out_field /* 2*dim*dim or NULL */);
+
 #ifdef __cplusplus
 }
 #endif

@@ -53,6 +53,24 @@ PROTOTYPES = {
                                        C.c_float, C.c_size_t, C.c_uint64, _vp]),
 }
 
+
+
+class FrameParams(C.Structure):
+    _fields_ = [("block", C.c_int), ("range", C.c_int), ("run_detector", C.c_int), ("min_size", C.c_float),
+                ("subdivide", C.c_size_t), ("target_motion", C.c_float), ("run_estimator", C.c_int),
+                ("aspect", C.c_float), ("fov_y_deg", C.c_float), ("use_ransac", C.c_int), ("num_iters", C.c_size_t),
+                ("inlier_deg", C.c_float), ("num_samples", C.c_size_t), ("seed", C.c_uint64)]
+
+
+class FrameResult(C.Structure):
+    _fields_ = [("have_vectors", C.c_int), ("n_vectors", C.c_size_t), ("has_motion", C.c_int), ("area", C.c_size_t),
+                ("dim", C.c_int), ("quat", C.c_float * 4)]
+
+
+PROTOTYPES["ofps_hip_reset_frames"] = (C.c_int, [_ctx])
+PROTOTYPES["ofps_hip_push_frame"] = (C.c_int, [_ctx, _u8p, C.c_int, C.c_int, C.c_int, C.POINTER(FrameParams),
+                                               C.POINTER(FrameResult), _f32p, _f32p])
+
 _lib = None
 
 

@@ -606,7 +606,7 @@ static int lsq_device(ofps_hip_ctx* ctx, const float4* d_entries, size_t stride,
     return OFPS_HIP_OK;
 }
 
-static int almeida_device(ofps_hip_ctx* ctx, const float4* d_entries, size_t n, int batch, float aspect, float fov_y_deg,
+int almeida_device(ofps_hip_ctx* ctx, const float4* d_entries, size_t n, int batch, float aspect, float fov_y_deg,
                           int use_ransac, size_t num_iters, float inlier_deg, size_t num_samples, uint64_t seed,
                           float4* d_quat) {
     OFPS_REQUIRE(ctx, batch >= 1 && batch <= 65535, "almeida: batch %d out of range", batch);

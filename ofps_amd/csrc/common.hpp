@@ -20,10 +20,14 @@ struct ofps_hip_ctx {
     int sad_mode = OFPS_HIP_SAD_EXHAUSTIVE;
     char err[512] = {0};
 
+    // per-frame pipeline state (pipeline.hip): two device frame slots, which one holds the newest frame
+    int pipe_w = 0, pipe_h = 0, pipe_stride = 0, pipe_newest = -1;
+    void* pipe_pinned = nullptr;         // small pinned host block for the result read-back
+
     // grow-only device scratch owned by the context (staging for host-pointer entry points and
     // kernel workspaces); never shrinks, freed in ofps_hip_destroy.
     struct Scratch { void* p = nullptr; size_t cap = 0; };
-    static constexpr int kNumScratch = 12;
+    static constexpr int kNumScratch = 16;
     Scratch scratch[kNumScratch];
 };
 
@@ -31,13 +35,24 @@ namespace ofps {
 
 enum ScratchSlot {
     S_FRAMES = 0, S_ENTRIES, S_BEST, S_FIELD, S_CELLS, S_WORK0, S_WORK1, S_WORK2, S_WORK3, S_RESULT,
-    S_QUAT, S_WORK4
+    S_QUAT, S_WORK4, S_PIPE_FRAMES, S_PIPE_ENTRIES, S_PIPE_OUT
 };
 
 int set_error(ofps_hip_ctx* ctx, int code, const char* fmt, ...);
 int check_hip(ofps_hip_ctx* ctx, hipError_t e, const char* what);
 // returns nullptr (and sets the error) on failure
 void* scratch(ofps_hip_ctx* ctx, int slot, size_t bytes);
+
+// ---- device-side stage entry points shared between translation units (all enqueue on ctx->stream)
+int sad_pairs_device(ofps_hip_ctx* ctx, const uint8_t* prev_base, size_t prev_pitch, const uint8_t* cur_base,
+                     size_t cur_pitch, int pairs, int W, int H, int stride, int block, int range, void* d_out_entries,
+                     void* d_out_best);
+int densify_device(ofps_hip_ctx* ctx, const float4* d_entries, size_t n, int batch, int w, int h, float2* d_field,
+                   uint32_t* d_cells, uint32_t** out_begin, uint32_t** out_end);
+int detect_device(ofps_hip_ctx* ctx, const float4* d_entries, size_t n, int batch, float min_size, size_t subdivide,
+                  float target_motion, int* d_result, float2* d_out_field, int* out_dim);
+int almeida_device(ofps_hip_ctx* ctx, const float4* d_entries, size_t n, int batch, float aspect, float fov_y_deg,
+                   int use_ransac, size_t num_iters, float inlier_deg, size_t num_samples, uint64_t seed, float4* d_quat);
 
 #define OFPS_HIP_TRY(ctx, expr)                                          \
     do {                                                                 \

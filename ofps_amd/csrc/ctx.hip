@@ -93,6 +93,7 @@ void ofps_hip_destroy(ofps_hip_ctx* ctx) {
     (void)hipDeviceSynchronize();
     for (auto& s : ctx->scratch)
         if (s.p) (void)hipFree(s.p);
+    if (ctx->pipe_pinned) (void)hipHostFree(ctx->pipe_pinned);
     if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
     if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);

@@ -14,8 +14,6 @@
 #include "common.hpp"
 
 namespace ofps {
-int densify_device(ofps_hip_ctx* ctx, const float4* d_entries, size_t n, int batch, int w, int h, float2* d_field,
-                   uint32_t* d_cells, uint32_t** out_begin, uint32_t** out_end);
 
 // dynamic LDS: area[cells] (u32) then label[cells] (u16; every cell is owned by one thread, so
 // labels need no atomics).  160x160 cells -> 150 KiB, inside the 160 KiB of one CU.

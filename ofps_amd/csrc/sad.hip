@@ -70,9 +70,9 @@ __device__ __forceinline__ unsigned long long shfl_down_u64(unsigned long long v
 struct __attribute__((packed, aligned(4))) U64A4 { unsigned long long v; };   // 8-byte LDS window, dword aligned
 
 struct SadParams {
-    const uint8_t* frames;
-    size_t frame_pitch;
-    int ref_mode;
+    const uint8_t* prev_base;   // pair k: prev = prev_base + k*prev_pitch, cur = cur_base + k*cur_pitch
+    const uint8_t* cur_base;
+    size_t prev_pitch, cur_pitch;
     int W, H, stride;
     int nbx, nby;
     float nx, ny;           // 1/W, 1/H computed on the host in f32 (av-decoder/src/lib.rs:404-405)
@@ -106,8 +106,8 @@ __global__ __launch_bounds__(256) void sad_qsad_kernel(const SadParams p) {
     __shared__ uint32_t tile[C::LDS_DWORDS];
 
     const int pair = blockIdx.z;
-    const uint8_t* __restrict__ prev = p.frames + (size_t)(p.ref_mode ? 0 : pair) * p.frame_pitch;
-    const uint8_t* __restrict__ cur = p.frames + (size_t)(pair + 1) * p.frame_pitch;
+    const uint8_t* __restrict__ prev = p.prev_base + (size_t)pair * p.prev_pitch;
+    const uint8_t* __restrict__ cur = p.cur_base + (size_t)pair * p.cur_pitch;
     const int by = blockIdx.y;
     const int bx0 = blockIdx.x * kWavesPerWG;
     const int tid = threadIdx.x;
@@ -325,8 +325,8 @@ __global__ __launch_bounds__(64 * kStripWaves, (StripCfg<B, R>::MIN_WAVES)) void
     const int by = rem / strips_per_row;
     const int bx0 = (rem - by * strips_per_row) * C::NB;
 
-    const uint8_t* __restrict__ prev = p.frames + (size_t)(p.ref_mode ? 0 : pair) * p.frame_pitch;
-    const uint8_t* __restrict__ cur = p.frames + (size_t)(pair + 1) * p.frame_pitch;
+    const uint8_t* __restrict__ prev = p.prev_base + (size_t)pair * p.prev_pitch;
+    const uint8_t* __restrict__ cur = p.cur_base + (size_t)pair * p.cur_pitch;
     uint32_t* tile = tiles + wave * C::TILE_DWORDS;
 
     const int b = lane / C::NG;          // block of the strip
@@ -577,8 +577,8 @@ __global__ __launch_bounds__(256) void sad_sea_kernel(const SadParams p, int str
     const int by = rem / strips_per_row;
     const int bx0 = (rem - by * strips_per_row) * C::NB;
     const int y0 = by * B;
-    const uint8_t* __restrict__ prev = p.frames + (size_t)(p.ref_mode ? 0 : pair) * p.frame_pitch;
-    const uint8_t* __restrict__ cur = p.frames + (size_t)(pair + 1) * p.frame_pitch;
+    const uint8_t* __restrict__ prev = p.prev_base + (size_t)pair * p.prev_pitch;
+    const uint8_t* __restrict__ cur = p.cur_base + (size_t)pair * p.cur_pitch;
 
     // ---- A: window + current-block sub-sums
     {
@@ -754,8 +754,8 @@ __global__ __launch_bounds__(256) void sad_sea_kernel(const SadParams p, int str
 // lanes over candidates, bytes straight from global memory (L1/L2 absorb the reuse).  Slow path.
 __global__ __launch_bounds__(64) void sad_generic_kernel(const SadParams p, int B, int R) {
     const int pair = blockIdx.z, by = blockIdx.y, bx = blockIdx.x;
-    const uint8_t* __restrict__ prev = p.frames + (size_t)(p.ref_mode ? 0 : pair) * p.frame_pitch;
-    const uint8_t* __restrict__ cur = p.frames + (size_t)(pair + 1) * p.frame_pitch;
+    const uint8_t* __restrict__ prev = p.prev_base + (size_t)pair * p.prev_pitch;
+    const uint8_t* __restrict__ cur = p.cur_base + (size_t)pair * p.cur_pitch;
     const int x0 = bx * B, y0 = by * B, n = 2 * R + 1;
     unsigned long long best = ~0ull;
     for (int cand = threadIdx.x; cand < n * n; cand += 64) {
@@ -840,37 +840,37 @@ size_t ofps_hip_sad_block_count(int W, int H, int block) {
     return (size_t)(W / block) * (size_t)(H / block);
 }
 
-int ofps_hip_sad_flow_dev(ofps_hip_ctx* ctx, const void* d_frames, int n_frames, int W, int H, int stride,
-                          size_t frame_pitch, int ref_mode, int block, int range, void* d_out_entries,
-                          void* d_out_best) {
-    if (!ctx) return OFPS_HIP_EINVAL;
-    OFPS_REQUIRE(ctx, d_frames && d_out_entries, "sad_flow: null device pointer");
-    OFPS_REQUIRE(ctx, n_frames >= 2, "sad_flow: need at least 2 frames (got %d)", n_frames);
+}  // extern "C" (reopened below)
+
+namespace ofps {
+// Shared by the batched entry point and the per-frame pipeline (pipeline.hip): `pairs` searches,
+// pair k between prev_base + k*prev_pitch and cur_base + k*cur_pitch.
+int sad_pairs_device(ofps_hip_ctx* ctx, const uint8_t* prev_base, size_t prev_pitch, const uint8_t* cur_base,
+                     size_t cur_pitch, int pairs, int W, int H, int stride, int block, int range, void* d_out_entries,
+                     void* d_out_best) {
     OFPS_REQUIRE(ctx, W > 0 && H > 0 && stride >= W, "sad_flow: bad geometry W=%d H=%d stride=%d", W, H, stride);
-    OFPS_REQUIRE(ctx, stride % 4 == 0 && ((uintptr_t)d_frames % 4) == 0 && frame_pitch % 4 == 0,
+    OFPS_REQUIRE(ctx, stride % 4 == 0 && ((uintptr_t)prev_base % 4) == 0 && ((uintptr_t)cur_base % 4) == 0 &&
+                          prev_pitch % 4 == 0 && cur_pitch % 4 == 0,
                  "sad_flow: rows must be 4-byte aligned (stride=%d)", stride);
-    OFPS_REQUIRE(ctx, frame_pitch >= (size_t)stride * (size_t)H, "sad_flow: frame_pitch smaller than a frame");
     OFPS_REQUIRE(ctx, block >= 1 && block <= 64 && range >= 0 && range <= 64,
                  "sad_flow: block=%d range=%d outside [1,64]/[0,64]", block, range);
-    OFPS_REQUIRE(ctx, ref_mode == 0 || ref_mode == 1, "sad_flow: ref_mode must be 0 or 1");
     SadParams p;
-    p.frames = static_cast<const uint8_t*>(d_frames);
-    p.frame_pitch = frame_pitch;
-    p.ref_mode = ref_mode;
+    p.prev_base = prev_base; p.cur_base = cur_base;
+    p.prev_pitch = prev_pitch; p.cur_pitch = cur_pitch;
     p.W = W; p.H = H; p.stride = stride;
     p.nbx = W / block; p.nby = H / block;
     p.nx = 1.0f / (float)W; p.ny = 1.0f / (float)H;
     p.out_entries = static_cast<float4*>(d_out_entries);
     p.out_best = static_cast<int*>(d_out_best);
-    const int pairs = n_frames - 1;
-    if (p.nbx == 0 || p.nby == 0) return OFPS_HIP_OK;
+    if (p.nbx == 0 || p.nby == 0 || pairs <= 0) return OFPS_HIP_OK;
     OFPS_REQUIRE(ctx, pairs <= 65535 && p.nby <= 65535, "sad_flow: grid too large");
     OFPS_HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
     const int key = block * 1000 + range;
     const char* force = getenv("OFPS_HIP_SAD_KERNEL");
     const bool force_block = force && strcmp(force, "block") == 0;
-    const bool strip_ok = !force_block && stride % 16 == 0 && ((uintptr_t)d_frames % 16) == 0 && frame_pitch % 16 == 0 &&
+    const bool strip_ok = !force_block && stride % 16 == 0 && ((uintptr_t)prev_base % 16) == 0 &&
+                          ((uintptr_t)cur_base % 16) == 0 && prev_pitch % 16 == 0 && cur_pitch % 16 == 0 &&
                           (long long)p.nbx * p.nby * pairs < (1ll << 30);
     switch (key) {
         // strip kernels need 16-byte aligned rows; otherwise (or with OFPS_HIP_SAD_KERNEL=block, A/B
@@ -902,6 +902,22 @@ int ofps_hip_sad_flow_dev(ofps_hip_ctx* ctx, const void* d_frames, int n_frames,
     }
     OFPS_HIP_TRY(ctx, hipGetLastError());
     return OFPS_HIP_OK;
+}
+}  // namespace ofps
+
+extern "C" {
+
+int ofps_hip_sad_flow_dev(ofps_hip_ctx* ctx, const void* d_frames, int n_frames, int W, int H, int stride,
+                          size_t frame_pitch, int ref_mode, int block, int range, void* d_out_entries,
+                          void* d_out_best) {
+    if (!ctx) return OFPS_HIP_EINVAL;
+    OFPS_REQUIRE(ctx, d_frames && d_out_entries, "sad_flow: null device pointer");
+    OFPS_REQUIRE(ctx, n_frames >= 2, "sad_flow: need at least 2 frames (got %d)", n_frames);
+    OFPS_REQUIRE(ctx, frame_pitch >= (size_t)stride * (size_t)H, "sad_flow: frame_pitch smaller than a frame");
+    OFPS_REQUIRE(ctx, ref_mode == 0 || ref_mode == 1, "sad_flow: ref_mode must be 0 or 1");
+    const auto* f = static_cast<const uint8_t*>(d_frames);
+    return ofps::sad_pairs_device(ctx, f, ref_mode ? 0 : frame_pitch, f + frame_pitch, frame_pitch, n_frames - 1, W, H, stride,
+                                  block, range, d_out_entries, d_out_best);
 }
 
 int ofps_hip_sad_flow(ofps_hip_ctx* ctx, const uint8_t* prev, const uint8_t* cur, int W, int H, int stride,

@@ -154,5 +154,30 @@ class HipContext:
                                                    C.c_void_p(d_out_quat)))
 
 
+    # ---- fused per-frame path
+    def reset_frames(self):
+        self._check(self._lib.ofps_hip_reset_frames(self._h))
+
+    def push_frame(self, luma: np.ndarray, block=16, search_range=16, detector=True, min_size=0.05, subdivide=3,
+                   target_motion=0.003, estimator=True, aspect=16 / 9, fov_y_deg=39.6 * 9 / 16, use_ransac=False,
+                   num_iters=200, inlier_deg=0.05, num_samples=1000, seed=0, want_entries=False, want_field=False):
+        """-> dict(have_vectors, n_vectors, motion=None|(area, field|None), quat, entries|None)"""
+        luma = np.ascontiguousarray(luma, np.uint8)
+        H, W = luma.shape
+        prm = _lib.FrameParams(block, search_range, int(detector), min_size, subdivide, target_motion, int(estimator),
+                               aspect, fov_y_deg, int(use_ransac), num_iters, inlier_deg, num_samples, seed)
+        res = _lib.FrameResult()
+        nb = int(self._lib.ofps_hip_sad_block_count(W, H, block))
+        ent = np.zeros((max(nb, 1), 4), np.float32) if want_entries else None
+        dim = self.block_dim(min_size, subdivide)
+        fld = np.zeros((dim, dim, 2), np.float32) if want_field else None
+        self._check(self._lib.ofps_hip_push_frame(self._h, luma.ctypes.data_as(C.POINTER(C.c_uint8)), W, H, W, C.byref(prm),
+                                                  C.byref(res), _fp(ent) if want_entries else None,
+                                                  _fp(fld) if want_field else None))
+        motion = (int(res.area), fld) if res.has_motion else None
+        return {"have_vectors": bool(res.have_vectors), "n_vectors": int(res.n_vectors), "motion": motion,
+                "quat": np.array(list(res.quat), np.float32), "entries": ent[:nb] if (want_entries and res.have_vectors) else None}
+
+
 def device_count() -> int:
     return int(_lib.load().ofps_hip_device_count())

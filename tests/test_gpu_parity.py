@@ -326,3 +326,29 @@ def test_almeida_batched_device_path(ctx):
     cam = oracle.camera(16 / 9, 22.275)
     for k in range(5):
         np.testing.assert_allclose(out[k].cpu().numpy(), oracle.solve_ypr_given(e[k], cam), atol=2e-6, rtol=0)
+
+
+# ------------------------------------------------------------------ fused per-frame path (cfg5)
+def test_push_frame_matches_stagewise_oracle(ctx):
+    """ofps_hip_push_frame == decoder -> detector + estimator run stage by stage on the oracle."""
+    W, H, F = 640, 360, 5
+    fr = synth.luma_sequence(F, W, H, max_step=8)
+    cam = oracle.camera(16 / 9, 22.275)
+    ctx.reset_frames()
+    for k in range(F):
+        r = ctx.push_frame(fr[k], block=16, search_range=8, aspect=16 / 9, fov_y_deg=22.275, want_entries=True, want_field=True)
+        if k == 0:
+            assert not r["have_vectors"] and r["motion"] is None and (r["quat"] == [1, 0, 0, 0]).all()
+            continue
+        ent_o, _ = oracle.sad_flow(fr[k - 1], fr[k], 16, 8)
+        assert r["have_vectors"] and r["n_vectors"] == len(ent_o)
+        np.testing.assert_array_equal(r["entries"].view(np.uint32), ent_o.view(np.uint32))
+        det_o = oracle.detect_motion(ent_o)
+        assert (r["motion"] is None) == (det_o is None)
+        if det_o is not None:
+            assert r["motion"][0] == det_o[0]
+            np.testing.assert_array_equal(r["motion"][1].view(np.uint32), det_o[1].view(np.uint32))
+        np.testing.assert_allclose(r["quat"], oracle.solve_ypr_given(ent_o, cam), atol=2e-6, rtol=0)
+    # a geometry change restarts the stream
+    r = ctx.push_frame(fr[0][:180, :320].copy(), block=16, search_range=8)
+    assert not r["have_vectors"]
