@@ -112,6 +112,10 @@ int ofps_hip_densify_dev(ofps_hip_ctx* ctx, const void* d_entries, size_t n_per_
 int ofps_hip_densify_to_entries(ofps_hip_ctx* ctx, const float* entries, size_t n, int w, int h,
                                 float* out_entries /* capacity 4*w*h */, size_t* n_out);
 
+/* new_densifier + add_vector (all entries) + interpolate_empty_cells + from_densifier: the sequence of
+ * flow-extract/src/main.rs:74-83 (ofps/src/motion_field.rs:193-294).  Sequential by definition. */
+int ofps_hip_densify_interpolated(ofps_hip_ctx* ctx, const float* entries, size_t n, int w, int h, float* out_field);
+
 /* ---- A5: BlockMotionDetection::detect_motion ("hip_block_motion" Detector) ---- */
 int ofps_hip_block_dim(float min_size, size_t subdivide);
 int ofps_hip_detect(ofps_hip_ctx* ctx, const float* entries, size_t n,

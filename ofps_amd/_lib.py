@@ -43,6 +43,7 @@ PROTOTYPES = {
     "ofps_hip_densify": (C.c_int, [_ctx, _f32p, C.c_size_t, C.c_int, C.c_int, _f32p, _u32p]),
     "ofps_hip_densify_dev": (C.c_int, [_ctx, _vp, C.c_size_t, C.c_int, C.c_int, C.c_int, _vp, _vp]),
     "ofps_hip_densify_to_entries": (C.c_int, [_ctx, _f32p, C.c_size_t, C.c_int, C.c_int, _f32p, _szp]),
+    "ofps_hip_densify_interpolated": (C.c_int, [_ctx, _f32p, C.c_size_t, C.c_int, C.c_int, _f32p]),
     "ofps_hip_block_dim": (C.c_int, [C.c_float, C.c_size_t]),
     "ofps_hip_detect": (C.c_int, [_ctx, _f32p, C.c_size_t, C.c_float, C.c_size_t, C.c_float,
                                   C.POINTER(C.c_int), _szp, C.POINTER(C.c_int), _f32p]),

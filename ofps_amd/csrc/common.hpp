@@ -49,6 +49,8 @@ int sad_pairs_device(ofps_hip_ctx* ctx, const uint8_t* prev_base, size_t prev_pi
                      void* d_out_best);
 int densify_device(ofps_hip_ctx* ctx, const float4* d_entries, size_t n, int batch, int w, int h, float2* d_field,
                    uint32_t* d_cells, uint32_t** out_begin, uint32_t** out_end);
+int densify_device_raw(ofps_hip_ctx* ctx, const float4* d_entries, size_t n, int batch, int w, int h, float2* d_field,
+                       uint32_t* d_cells, uint32_t** out_begin, uint32_t** out_end, float2* d_sum, float* d_cnt);
 int detect_device(ofps_hip_ctx* ctx, const float4* d_entries, size_t n, int batch, float min_size, size_t subdivide,
                   float target_motion, int* d_result, float2* d_out_field, int* out_dim);
 int almeida_device(ofps_hip_ctx* ctx, const float4* d_entries, size_t n, int batch, float aspect, float fov_y_deg,

@@ -187,7 +187,8 @@ __global__ __launch_bounds__(256) void cell_sum_kernel(const float4* __restrict_
                                                        const uint32_t* __restrict__ vals,
                                                        const uint32_t* __restrict__ cell_begin,
                                                        const uint32_t* __restrict__ cell_end, size_t cells,
-                                                       float2* __restrict__ out_field) {
+                                                       float2* __restrict__ out_field, float2* __restrict__ out_sum,
+                                                       float* __restrict__ out_cnt) {
     __shared__ float2 stage[4][64];
     const size_t item = blockIdx.y;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -214,7 +215,11 @@ __global__ __launch_bounds__(256) void cell_sum_kernel(const float4* __restrict_
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
-    if (lane < 2) reinterpret_cast<float*>(out_field + item * cells + cell)[lane] = sum / cnt;   // :304
+    if (lane < 2) {
+        if (out_field) reinterpret_cast<float*>(out_field + item * cells + cell)[lane] = sum / cnt;   // :304
+        if (out_sum) reinterpret_cast<float*>(out_sum + item * cells + cell)[lane] = sum;      // densifier state before
+        if (out_cnt && lane == 0) out_cnt[item * cells + cell] = cnt;                          // the final divide
+    }
 }
 
 // cv-decoder/src/lib.rs:279-291: visited cells in BTreeSet<(x,y)> order -> entries.  One
@@ -257,10 +262,126 @@ __global__ __launch_bounds__(1024) void cells_to_entries_kernel(const float2* __
     if (threadIdx.x == 0) out_count[item] = base;
 }
 
+// MotionFieldDensifier::interpolate_empty_cells (motion_field.rs:193-294) + MotionField::from.
+// The reference pops cells from a BTreeSet ordered by (-filled_neighbours, index); every fill changes the
+// keys of its neighbours and the data later fills read, so the walk is sequential by definition.  One
+// workgroup per item: all threads find the next cell (argmin of the key over the queue), thread 0 performs
+// the reference's f32 arithmetic for that cell in the reference's neighbour order -- same operations, same
+// order, same bits.  Cost grows with the number of empty cells (an offline path: flow-extract/src/main.rs:81).
+__device__ __forceinline__ int interp_filled_neighbours(const float* cnt, int w, int h, int i) {
+    const int x = i % w, y = i / w;
+    const int ox[6] = {-1, 0, -1, 1, 0, 1}, oy[6] = {0, -1, -1, 0, 1, 1};          // motion_field.rs:207
+    int c = 0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const int nx = x + ox[k], ny = y + oy[k];
+        if (nx >= 0 && nx < w && ny >= 0 && ny < h && cnt[nx + ny * w] > 0.1f) ++c;
+    }
+    return c;
+}
+
+__global__ __launch_bounds__(256) void interpolate_kernel(float2* __restrict__ sum, float* __restrict__ cnt,
+                                                          int* __restrict__ key, int w, int h,
+                                                          float2* __restrict__ out_field) {
+    __shared__ unsigned long long red[4];
+    __shared__ int chosen;
+    const size_t item = blockIdx.x;
+    const int cells = w * h, tid = threadIdx.x;
+    sum += item * cells; cnt += item * cells; key += item * cells; out_field += item * cells;
+    const int NOT_QUEUED = 0x7FFFFFFF;
+    // queue = cells with count < 0.5, key = -filled neighbours (:230-241)
+    int queued = 0;
+    for (int i = tid; i < cells; i += 256) {
+        const bool q = cnt[i] < 0.5f;
+        key[i] = q ? -interp_filled_neighbours(cnt, w, h, i) : NOT_QUEUED;
+        queued += q;
+    }
+    queued = __syncthreads_count(queued > 0) ? 1 : 0;     // any queued cell at all?
+    {
+        // "no motion vectors at all" (:243-246): every cell queued -> nothing to interpolate from
+        int filled = 0;
+        for (int i = tid; i < cells; i += 256) filled += key[i] == NOT_QUEUED;
+        if (!__syncthreads_or(filled)) queued = 0;
+    }
+    while (queued) {
+        // smallest (key, index) over the queue
+        unsigned long long best = ~0ull;
+        for (int i = tid; i < cells; i += 256) {
+            const int k = key[i];
+            if (k != NOT_QUEUED) {
+                const unsigned long long v = ((unsigned long long)(uint32_t)(k + 16) << 32) | (uint32_t)i;
+                best = v < best ? v : best;
+            }
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            const unsigned lo = __shfl_xor((unsigned)best, m, 64), hi = __shfl_xor((unsigned)(best >> 32), m, 64);
+            const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+            best = o < best ? o : best;
+        }
+        if ((tid & 63) == 0) red[tid >> 6] = best;
+        __syncthreads();
+        if (tid == 0) {
+            unsigned long long b = red[0];
+            for (int k = 1; k < 4; ++k) b = red[k] < b ? red[k] : b;
+            chosen = (b == ~0ull) ? -1 : (int)(uint32_t)b;
+            if (chosen >= 0) {
+                const int i = chosen, x = i % w, y = i / w;
+                const int ox[6] = {-1, 0, -1, 1, 0, 1}, oy[6] = {0, -1, -1, 0, 1, 1};
+                key[i] = NOT_QUEUED;                                             // queue.take
+                float2 acc = sum[i];
+                float c = cnt[i];
+                bool added = false;
+                for (int k = 0; k < 6; ++k) {                                    // :255-268
+                    const int nx = x + ox[k], ny = y + oy[k];
+                    if (nx < 0 || nx >= w || ny < 0 || ny >= h) continue;
+                    const int idx = nx + ny * w;
+                    const float nc = cnt[idx];
+                    if (nc > 0.1f) {
+                        const float scale = 1.0f - sqrtf((float)(ox[k] * ox[k] + oy[k] * oy[k])) * 0.5f;
+                        const float inv_cnt = 1.0f / nc;
+                        const float sc = scale * inv_cnt;
+                        const float2 nv = sum[idx];
+                        c += scale;                                              // add_vector_idx (:141-147)
+                        acc.x = (sc * nv.x) * scale + acc.x;
+                        acc.y = (sc * nv.y) * scale + acc.y;
+                        added = true;
+                    }
+                }
+                if (!added) chosen = -1;           // cannot happen with a filled cell present; the reference would spin
+                sum[i] = acc;
+                cnt[i] = c;
+                __threadfence_block();
+                if (added)
+                    for (int k = 0; k < 6; ++k) {                                // :273-289
+                        const int nx = x + ox[k], ny = y + oy[k];
+                        if (nx < 0 || nx >= w || ny < 0 || ny >= h) continue;
+                        const int idx = nx + ny * w;
+                        if (key[idx] != NOT_QUEUED) key[idx] = -interp_filled_neighbours(cnt, w, h, idx);
+                    }
+            }
+        }
+        __syncthreads();
+        if (chosen < 0) break;
+        __syncthreads();
+    }
+    __syncthreads();
+    for (int i = tid; i < cells; i += 256) {                                     // MotionField::from
+        const float2 sv = sum[i];
+        const float c = cnt[i];
+        out_field[i] = make_float2(sv.x / c, sv.y / c);
+    }
+}
+
 // Shared by detect.hip: densify `batch` items of n entries into (w x h) fields.  Leaves the
 // per-cell [begin,end) tables in S_WORK3 (begin) / S_WORK4 (end).
 int densify_device(ofps_hip_ctx* ctx, const float4* d_entries, size_t n, int batch, int w, int h, float2* d_field,
                    uint32_t* d_cells, uint32_t** out_begin, uint32_t** out_end) {
+    return densify_device_raw(ctx, d_entries, n, batch, w, h, d_field, d_cells, out_begin, out_end, nullptr, nullptr);
+}
+
+int densify_device_raw(ofps_hip_ctx* ctx, const float4* d_entries, size_t n, int batch, int w, int h, float2* d_field,
+                       uint32_t* d_cells, uint32_t** out_begin, uint32_t** out_end, float2* d_sum, float* d_cnt) {
     const size_t cells = (size_t)w * (size_t)h;
     OFPS_REQUIRE(ctx, w >= 1 && h >= 1 && cells <= 65536, "densify: grid %dx%d unsupported (1..65536 cells)", w, h);
     OFPS_REQUIRE(ctx, batch >= 1 && batch <= 65535, "densify: batch %d out of range", batch);
@@ -300,7 +421,7 @@ int densify_device(ofps_hip_ctx* ctx, const float4* d_entries, size_t n, int bat
         sorted_vals = vals_a;
     }
     hipLaunchKernelGGL(cell_sum_kernel, dim3((unsigned)((cells + 3) / 4), batch), dim3(256), 0, s, d_entries, n,
-                       sorted_vals, begin, end, cells, d_field);
+                       sorted_vals, begin, end, cells, d_field, d_sum, d_cnt);
     OFPS_HIP_TRY(ctx, hipGetLastError());
     return OFPS_HIP_OK;
 }
@@ -308,6 +429,29 @@ int densify_device(ofps_hip_ctx* ctx, const float4* d_entries, size_t n, int bat
 }  // namespace ofps
 
 extern "C" {
+
+int ofps_hip_densify_interpolated(ofps_hip_ctx* ctx, const float* entries, size_t n, int w, int h, float* out_field) {
+    if (!ctx) return OFPS_HIP_EINVAL;
+    OFPS_REQUIRE(ctx, out_field && (entries || n == 0), "densify_interpolated: null host pointer");
+    OFPS_REQUIRE(ctx, w >= 1 && h >= 1 && (size_t)w * h <= 65536, "densify_interpolated: grid %dx%d unsupported", w, h);
+    OFPS_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t cells = (size_t)w * h;
+    auto* d_ent = static_cast<float4*>(ofps::scratch(ctx, ofps::S_ENTRIES, n * sizeof(float4)));
+    auto* d_field = static_cast<float2*>(ofps::scratch(ctx, ofps::S_FIELD, cells * sizeof(float2)));
+    auto* d_state = static_cast<char*>(ofps::scratch(ctx, ofps::S_BEST, cells * (sizeof(float2) + sizeof(float) + sizeof(int))));
+    if (!d_ent || !d_field || !d_state) return OFPS_HIP_ENOMEM;
+    auto* d_sum = reinterpret_cast<float2*>(d_state);
+    auto* d_cnt = reinterpret_cast<float*>(d_state + cells * sizeof(float2));
+    auto* d_key = reinterpret_cast<int*>(d_state + cells * (sizeof(float2) + sizeof(float)));
+    if (n) OFPS_HIP_TRY(ctx, hipMemcpyAsync(d_ent, entries, n * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
+    int rc = ofps::densify_device_raw(ctx, d_ent, n, 1, w, h, nullptr, nullptr, nullptr, nullptr, d_sum, d_cnt);
+    if (rc != OFPS_HIP_OK) return rc;
+    hipLaunchKernelGGL(ofps::interpolate_kernel, dim3(1), dim3(256), 0, ctx->stream, d_sum, d_cnt, d_key, w, h, d_field);
+    OFPS_HIP_TRY(ctx, hipGetLastError());
+    OFPS_HIP_TRY(ctx, hipMemcpyAsync(out_field, d_field, cells * sizeof(float2), hipMemcpyDeviceToHost, ctx->stream));
+    OFPS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return OFPS_HIP_OK;
+}
 
 int ofps_hip_densify_dev(ofps_hip_ctx* ctx, const void* d_entries, size_t n_per_item, int batch, int w, int h,
                          void* d_out_field, void* d_out_cells) {

@@ -1,0 +1,155 @@
+"""Python mirror of the reference's plugin interface for the hot path (same names, argument meaning and
+error behaviour as ofps/src/{decoder,estimator,detection}.rs and ofps/src/plugins/properties.rs), on top of the
+C ABI.  It exists so tests and scripts read like the reference's own code; every result comes from
+libofps_hip.so.  The C++ twin is ofps_amd/host/ofps_host.hpp; the Rust shim is in INTEGRATION.md.
+"""
+from __future__ import annotations
+
+import math
+from typing import BinaryIO, Iterable, Iterator, Optional
+
+import numpy as np
+
+from .runtime import HipContext
+
+
+class StandardCamera:
+    """ofps/src/camera.rs:12-35,166-177 -- parameters only; the projection math runs on the device."""
+
+    def __init__(self, aspect: float, fov_y: float):
+        self.aspect, self.fov_y = float(aspect), float(fov_y)
+
+    def aspect_ratio(self) -> float:
+        return self.aspect
+
+    def fov(self):
+        ty = math.tan(math.radians(self.fov_y) / 2.0)
+        return (math.degrees(math.atan(self.aspect * ty)) * 2.0, self.fov_y)
+
+
+class MotionField:
+    """ofps/src/motion_field.rs:7-115: fixed-size field, cell (x, y) stored at width*y + x."""
+
+    def __init__(self, data: np.ndarray):
+        self.vf = np.asarray(data, np.float32)            # [h, w, 2]
+
+    def dim(self):
+        return (self.vf.shape[1], self.vf.shape[0])
+
+    def size(self) -> int:
+        return self.vf.shape[0] * self.vf.shape[1]
+
+    def as_slice(self) -> np.ndarray:
+        return self.vf.reshape(-1)
+
+    def get_motion(self, x: int, y: int) -> np.ndarray:
+        return self.vf[y, x]
+
+    def iter(self):
+        h, w = self.vf.shape[:2]
+        return ((x, y, self.vf[y, x]) for y in range(h) for x in range(w))
+
+
+class Properties:
+    """plugins/properties.rs:6-18: props() -> [(name, kind, value, min, max)], set_prop(name, value)."""
+    _PROPS: tuple = ()
+
+    def props(self):
+        return [(name, kind, getattr(self, attr), lo, hi) for name, kind, attr, lo, hi in self._PROPS]
+
+    def set_prop(self, name: str, value) -> bool:
+        for pname, kind, attr, lo, hi in self._PROPS:
+            if pname == name:
+                setattr(self, attr, {"bool": bool, "float": float, "usize": int}[kind](value))
+                return True
+        return False
+
+
+class HipSadDecoder(Properties):
+    """Decoder (ofps/src/decoder.rs:45-73) over an iterator / raw stream of luma frames: full-search SAD
+    block vectors in av-decoder's record convention (av-decoder/src/lib.rs:404-419)."""
+    _PROPS = (("Block size", "usize", "block", 8, 16), ("Search range", "usize", "range", 8, 32))
+
+    def __init__(self, frames: Iterable[np.ndarray], framerate: Optional[float] = None, device: int = 0):
+        self.ctx = HipContext(device)
+        self._it: Iterator[np.ndarray] = iter(frames)
+        self.block, self.range = 16, 16
+        self._prev: Optional[np.ndarray] = None
+        self._cur: Optional[np.ndarray] = None
+        self._fps = framerate
+
+    @classmethod
+    def from_raw_stream(cls, f: BinaryIO, width: int, height: int, framerate: Optional[float] = None, device: int = 0):
+        def gen():
+            while True:
+                buf = f.read(width * height)
+                if len(buf) != width * height:
+                    return
+                yield np.frombuffer(buf, np.uint8).reshape(height, width)
+        return cls(gen(), framerate, device)
+
+    def process_frame(self, field: list, out_frame: Optional[list] = None, skip_frames: int = 0) -> bool:
+        """True: vectors appended to `field` (callers clear it); False: no vectors this frame; raises
+        StopIteration-derived EOFError at end of stream (the Err that ends the reference's worker loop)."""
+        for _ in range(skip_frames + 1):
+            self._prev = self._cur
+            try:
+                self._cur = np.ascontiguousarray(next(self._it), np.uint8)
+            except StopIteration:
+                raise EOFError("end of stream") from None
+        if out_frame is not None:
+            out_frame[:] = [self._cur]
+        if self._prev is None or self._prev.shape != self._cur.shape:
+            return False
+        field.extend(self.ctx.sad_flow(self._prev, self._cur, self.block, self.range))
+        return True
+
+    def get_framerate(self):
+        return self._fps
+
+    def get_aspect(self):
+        return None if self._cur is None else (self._cur.shape[1], self._cur.shape[0])
+
+
+class HipBlockMotionDetection(Properties):
+    """Detector (ofps/src/detection.rs:11; block-motion-detector/src/lib.rs:13-46)."""
+    _PROPS = (("Min size", "float", "min_size", 0.01, 1.0), ("Subdivisions", "usize", "subdivide", 1, 16),
+              ("Target motion", "float", "target_motion", 0.0001, 0.1))
+
+    def __init__(self, device: int = 0):
+        self.ctx = HipContext(device)
+        self.min_size, self.subdivide, self.target_motion = 0.05, 3, 0.003
+
+    def detect_motion(self, motion):
+        """-> None | (area, MotionField)"""
+        r = self.ctx.detect(np.asarray(motion, np.float32).reshape(-1, 4), self.min_size, self.subdivide, self.target_motion)
+        return None if r is None else (r[0], MotionField(r[1]))
+
+
+class HipAlmeidaEstimator(Properties):
+    """Estimator (ofps/src/estimator.rs:8-53; almeida-estimator/src/lib.rs:57-121)."""
+    _PROPS = (("Use ransac", "bool", "use_ransac", None, None), ("Ransac iters", "usize", "num_iters", 1, 500),
+              ("Inlier threshold", "float", "inlier_angle", 0.01, 1.0), ("Ransac samples", "usize", "ransac_samples", 100, 16000))
+
+    def __init__(self, device: int = 0):
+        self.ctx = HipContext(device)
+        self.use_ransac, self.num_iters, self.inlier_angle, self.ransac_samples = True, 200, 0.05, 1000
+        self.seed = 0
+
+    def estimate(self, motion_vectors, camera: StandardCamera, move_magnitude=None):
+        """-> (quaternion (w,i,j,k), translation (0,0,0))"""
+        self.seed += 1
+        return self.ctx.almeida(np.asarray(motion_vectors, np.float32).reshape(-1, 4), camera.aspect_ratio(), camera.fov()[1],
+                                self.use_ransac, self.num_iters, self.inlier_angle, self.ransac_samples, self.seed)
+
+    def motion_step(self, motion_vectors, camera, move_magnitude, rot, pos):
+        """estimator.rs:38-53: pos += rot * tr; rot = r * rot (tr is always zero for this estimator)."""
+        r, tr = self.estimate(motion_vectors, camera, move_magnitude)
+        return quat_mul(r, rot), np.asarray(pos, np.float32) + np.asarray(tr, np.float32)
+
+
+def quat_mul(a, b) -> np.ndarray:
+    aw, ai, aj, ak = [float(v) for v in a]
+    bw, bi, bj, bk = [float(v) for v in b]
+    return np.array([aw * bw - ai * bi - aj * bj - ak * bk, aw * bi + ai * bw + aj * bk - ak * bj,
+                     aw * bj - ai * bk + aj * bw + ak * bi, aw * bk + ai * bj - aj * bi + ak * bw], np.float32)

@@ -120,6 +120,12 @@ class HipContext:
         self._check(self._lib.ofps_hip_densify_to_entries(self._h, _fp(e), e.shape[0], w, h, _fp(out), C.byref(n_out)))
         return out[:n_out.value].copy()
 
+    def densify_interpolated(self, entries, w: int, h: int) -> np.ndarray:
+        e = np.ascontiguousarray(entries, np.float32).reshape(-1, 4)
+        field = np.zeros((h, w, 2), np.float32)
+        self._check(self._lib.ofps_hip_densify_interpolated(self._h, _fp(e), e.shape[0], w, h, _fp(field)))
+        return field
+
     # ---- A5
     def block_dim(self, min_size: float, subdivide: int) -> int:
         return int(self._lib.ofps_hip_block_dim(min_size, subdivide))

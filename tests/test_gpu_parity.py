@@ -173,6 +173,18 @@ def test_densify_per_pixel_entries(ctx):
     np.testing.assert_array_equal(out_g.view(np.uint32), out_o.view(np.uint32))
 
 
+@pytest.mark.parametrize("n,w,h,seed", [(40, 12, 9, 8), (5, 16, 16, 1), (300, 40, 23, 2), (1, 7, 5, 3), (2000, 150, 84, 4)])
+def test_interpolate_empty_cells_bit_exact(ctx, n, w, h, seed):
+    """MotionFieldDensifier::interpolate_empty_cells (motion_field.rs:193-294) through the device path."""
+    e = _entries(n, seed)
+    np.testing.assert_array_equal(ctx.densify_interpolated(e, w, h).view(np.uint32),
+                                  oracle.densify_interpolated(e, w, h).view(np.uint32))
+
+
+def test_interpolate_empty_cells_no_vectors(ctx):
+    assert (ctx.densify_interpolated(np.zeros((0, 4), np.float32), 6, 4) == 0).all()
+
+
 # ------------------------------------------------------------------ A5: detector
 def _island_entries(dim, cells_on, mag=0.01, per_cell=3, seed=0):
     """Entries landing exactly in chosen cells of a dim x dim grid."""

@@ -1,0 +1,69 @@
+"""The reference's own test (almeida-estimator/src/lib.rs:308-372), written against the Python mirror of the plugin
+interface the way the Rust test is written against the Rust types, plus the detection-loop semantics."""
+import numpy as np
+import pytest
+
+import oracle
+from ofps_amd import synth
+
+import almeida_cases as ac
+
+pytestmark = pytest.mark.gpu
+
+
+def _test_rot(estimator):
+    from ofps_amd.plugins import StandardCamera
+    camera = StandardCamera(1.0, 90.0)                                  # lib.rs:309
+    for rot, angles, q, field in ac.cases():
+        r, tr = estimator.estimate(field, camera, None)                # lib.rs:341
+        delta = ac.error_deg(q, r)                                     # q.angle_to(&r).to_degrees()
+        assert delta < 0.1 * rot or delta == 0.0, (angles, delta, 0.1 * rot)     # lib.rs:347-348
+        assert (tr == 0).all()
+
+
+def test_rotation_default():
+    from ofps_amd.plugins import HipAlmeidaEstimator
+    estimator = HipAlmeidaEstimator()
+    estimator.use_ransac = False                                       # lib.rs:361-362
+    _test_rot(estimator)
+
+
+def test_rotation_ransac():
+    from ofps_amd.plugins import HipAlmeidaEstimator
+    estimator = HipAlmeidaEstimator()
+    estimator.use_ransac = True
+    estimator.num_iters = 100                                          # lib.rs:368-370
+    _test_rot(estimator)
+
+
+def test_properties_surface_matches_reference_names():
+    from ofps_amd.plugins import HipAlmeidaEstimator, HipBlockMotionDetection
+    est, det = HipAlmeidaEstimator(), HipBlockMotionDetection()
+    assert [p[0] for p in est.props()] == ["Use ransac", "Ransac iters", "Inlier threshold", "Ransac samples"]
+    assert [(p[0], p[3], p[4]) for p in det.props()] == [("Min size", 0.01, 1.0), ("Subdivisions", 1, 16), ("Target motion", 0.0001, 0.1)]
+    assert det.set_prop("Subdivisions", 5) and det.subdivide == 5 and not det.set_prop("nope", 1)
+
+
+def test_decoder_detector_loop_semantics():
+    """process_frame appends (callers clear), first frame -> False, end of stream -> error (decoder.rs:45-60)."""
+    from ofps_amd.plugins import HipBlockMotionDetection, HipSadDecoder
+    fr = synth.luma_sequence(4, 320, 192, max_step=8)
+    dec, det = HipSadDecoder(list(fr), framerate=30.0), HipBlockMotionDetection()
+    dec.range = 8
+    field = []
+    assert dec.process_frame(field) is False and field == []
+    assert dec.get_aspect() == (320, 192) and dec.get_framerate() == 30.0
+    for k in (1, 2, 3):
+        field.clear()
+        assert dec.process_frame(field) is True
+        ent_o, _ = oracle.sad_flow(fr[k - 1], fr[k], 16, 8)
+        np.testing.assert_array_equal(np.array(field, np.float32).view(np.uint32), ent_o.view(np.uint32))
+        r, ro = det.detect_motion(field), oracle.detect_motion(ent_o)
+        assert (r is None) == (ro is None)
+        if r is not None:
+            assert r[0] == ro[0] and r[1].dim() == (14, 14)
+            np.testing.assert_array_equal(r[1].vf.view(np.uint32), ro[1].view(np.uint32))
+    n = len(field)
+    with pytest.raises(EOFError):
+        dec.process_frame(field)
+    assert len(field) == n
