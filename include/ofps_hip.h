@@ -102,6 +102,17 @@ int ofps_hip_sad_flow_dev(ofps_hip_ctx* ctx, const void* d_frames, int n_frames,
                           int W, int H, int stride, size_t frame_pitch, int ref_mode,
                           int block, int range, void* d_out_entries, void* d_out_best);
 
+/* ---- N2: dense per-pixel flow, pyramidal Lucas-Kanade ("hip_lk" Decoder) ----
+ * The reference's only per-pixel flow is OpenCV's Farneback inside cv-decoder (cv-decoder/src/lib.rs:188-199); this
+ * is a build-defined algorithm (oracle/ofps_oracle.c:orc_lk_flow) with cv-decoder's conventions: prev(x,y) ~
+ * cur(x+u,y+v); records pos = ((x+.5)/W,(y+.5)/H), motion = flow/(W,H) in raster order (:239-243,262-269).
+ * levels in [1,8] (cfg3: 3), radius in [1,15] (window (2r+1)^2), iters >= 1 Gauss-Newton steps per level.
+ * out_flow: 2*W*H f32 (u,v) or NULL; out_entries: 4*W*H f32 or NULL (at least one of them). */
+int ofps_hip_lk_flow(ofps_hip_ctx* ctx, const uint8_t* prev, const uint8_t* cur, int W, int H, int stride,
+                     int levels, int radius, int iters, float* out_flow, float* out_entries);
+int ofps_hip_lk_flow_dev(ofps_hip_ctx* ctx, const void* d_prev, const void* d_cur, int W, int H, int stride,
+                         int levels, int radius, int iters, void* d_out_flow, void* d_out_entries);
+
 /* ---- A1-A4: MotionFieldDensifier ---- */
 int ofps_hip_densify(ofps_hip_ctx* ctx, const float* entries, size_t n, int w, int h,
                      float* out_field /* 2*w*h, cell (x,y) at 2*(y*w+x) */,

@@ -1,0 +1,234 @@
+// lk.hip -- N2: dense per-pixel flow, pyramidal Lucas-Kanade ("hip_lk" Decoder).
+//
+// The reference has no per-pixel flow of its own: cv-decoder calls OpenCV's calcOpticalFlowFarneback
+// (cv-decoder/src/lib.rs:188-199) and only converts the result to MotionEntry records (:239-291).  This file
+// therefore implements a build-defined algorithm (spec: oracle/ofps_oracle.c:orc_lk_flow, DESIGN.md "N2") whose
+// OUTPUT CONVENTION is cv-decoder's: prev(x,y) ~ cur(x+u,y+v); pos = ((x+.5)/W,(y+.5)/H), motion = flow/(W,H).
+// "Parity unpinned" w.r.t. the reference; bit-exact vs the build's own CPU restatement: every thread owns one
+// pixel and runs the oracle's loops in the oracle's order (f32, no FMA contraction, IEEE divide).
+//
+// Kernels per pyramid level: u8->f32 (level 0) / separable [1 4 6 4 1]/16 downsample, central-difference
+// gradients of the previous frame, the 2x2 structure tensor G summed over the (2r+1)^2 window (once per
+// level: it does not depend on the flow), then `iters` Gauss-Newton steps (b = sum grad * (I - J(q+flow)),
+// flow += G^-1 b).  All of it is window/stencil work on f32 planes: L1/L2-resident reads, VALU-bound on the
+// bilinear sampling -- no contraction wide enough for MFMA (the normal equations are 2x2 per pixel).
+#include "common.hpp"
+
+namespace ofps {
+
+__device__ __forceinline__ int lk_clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+__global__ __launch_bounds__(256) void lk_u8_to_f32_kernel(const uint8_t* __restrict__ src, int W, int H, int stride,
+                                                           float* __restrict__ dst) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x < W && y < H) dst[(size_t)y * W + x] = (float)src[(size_t)y * stride + x];
+}
+
+// horizontal [1 4 6 4 1]/16 + decimation: in (w x h) -> tmp (w1 x h)
+__global__ __launch_bounds__(256) void lk_pyr_h_kernel(const float* __restrict__ in, int w, int h, float* __restrict__ tmp, int w1) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= w1 || y >= h) return;
+    const float* r = in + (size_t)y * w;
+    const float a = r[lk_clampi(2 * x - 2, 0, w - 1)], b = r[lk_clampi(2 * x - 1, 0, w - 1)], c = r[lk_clampi(2 * x, 0, w - 1)],
+                d = r[lk_clampi(2 * x + 1, 0, w - 1)], e = r[lk_clampi(2 * x + 2, 0, w - 1)];
+    tmp[(size_t)y * w1 + x] = ((((a + 4.0f * b) + 6.0f * c) + 4.0f * d) + e) * 0.0625f;
+}
+
+// vertical pass: tmp (w1 x h) -> out (w1 x h1)
+__global__ __launch_bounds__(256) void lk_pyr_v_kernel(const float* __restrict__ tmp, int w1, int h, float* __restrict__ out, int h1) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= w1 || y >= h1) return;
+    const float a = tmp[(size_t)lk_clampi(2 * y - 2, 0, h - 1) * w1 + x], b = tmp[(size_t)lk_clampi(2 * y - 1, 0, h - 1) * w1 + x],
+                c = tmp[(size_t)lk_clampi(2 * y, 0, h - 1) * w1 + x], d = tmp[(size_t)lk_clampi(2 * y + 1, 0, h - 1) * w1 + x],
+                e = tmp[(size_t)lk_clampi(2 * y + 2, 0, h - 1) * w1 + x];
+    out[(size_t)y * w1 + x] = ((((a + 4.0f * b) + 6.0f * c) + 4.0f * d) + e) * 0.0625f;
+}
+
+__global__ __launch_bounds__(256) void lk_grad_kernel(const float* __restrict__ I, int w, int h, float* __restrict__ gx,
+                                                      float* __restrict__ gy) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= w || y >= h) return;
+    gx[(size_t)y * w + x] = (I[(size_t)y * w + lk_clampi(x + 1, 0, w - 1)] - I[(size_t)y * w + lk_clampi(x - 1, 0, w - 1)]) * 0.5f;
+    gy[(size_t)y * w + x] = (I[(size_t)lk_clampi(y + 1, 0, h - 1) * w + x] - I[(size_t)lk_clampi(y - 1, 0, h - 1) * w + x]) * 0.5f;
+}
+
+// flow_l(x,y) = 2 * flow_{l+1}(x/2, y/2)
+__global__ __launch_bounds__(256) void lk_upsample_kernel(const float2* __restrict__ coarse, int w1, int h1, float2* __restrict__ fine,
+                                                          int w, int h) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= w || y >= h) return;
+    const float2 c = coarse[(size_t)lk_clampi(y / 2, 0, h1 - 1) * w1 + lk_clampi(x / 2, 0, w1 - 1)];
+    fine[(size_t)y * w + x] = make_float2(2.0f * c.x, 2.0f * c.y);
+}
+
+// structure tensor, window sums in the oracle's order (dy outer, dx inner, clamped coordinates)
+__global__ __launch_bounds__(256) void lk_tensor_kernel(const float* __restrict__ gx, const float* __restrict__ gy, int w, int h,
+                                                        int radius, float4* __restrict__ G) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= w || y >= h) return;
+    float gxx = 0.0f, gxy = 0.0f, gyy = 0.0f;
+    for (int dy = -radius; dy <= radius; ++dy) {
+        const size_t row = (size_t)lk_clampi(y + dy, 0, h - 1) * w;
+        for (int dx = -radius; dx <= radius; ++dx) {
+            const int qx = lk_clampi(x + dx, 0, w - 1);
+            const float ix = gx[row + qx], iy = gy[row + qx];
+            gxx += ix * ix; gxy += ix * iy; gyy += iy * iy;
+        }
+    }
+    G[(size_t)y * w + x] = make_float4(gxx, gxy, gyy, 0.0f);
+}
+
+__device__ __forceinline__ float lk_bilinear(const float* __restrict__ J, int w, int h, float fx, float fy) {
+    const float x0f = floorf(fx), y0f = floorf(fy);
+    const float ax = fx - x0f, ay = fy - y0f;
+    const float cx = x0f < -1.0f ? -1.0f : (x0f > (float)w ? (float)w : x0f);
+    const float cy = y0f < -1.0f ? -1.0f : (y0f > (float)h ? (float)h : y0f);
+    const int x0 = (int)cx, y0 = (int)cy;
+    const int xa = lk_clampi(x0, 0, w - 1), xb = lk_clampi(x0 + 1, 0, w - 1);
+    const int ya = lk_clampi(y0, 0, h - 1), yb = lk_clampi(y0 + 1, 0, h - 1);
+    const float j00 = J[(size_t)ya * w + xa], j10 = J[(size_t)ya * w + xb], j01 = J[(size_t)yb * w + xa], j11 = J[(size_t)yb * w + xb];
+    const float top = j00 + ax * (j10 - j00);
+    const float bot = j01 + ax * (j11 - j01);
+    return top + ay * (bot - top);
+}
+
+// one Gauss-Newton step for every pixel
+__global__ __launch_bounds__(256) void lk_step_kernel(const float* __restrict__ I, const float* __restrict__ J,
+                                                      const float* __restrict__ gx, const float* __restrict__ gy,
+                                                      const float4* __restrict__ G, int w, int h, int radius,
+                                                      const float2* __restrict__ flow_in, float2* __restrict__ flow_out) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= w || y >= h) return;
+    const float2 f = flow_in[(size_t)y * w + x];
+    float bx = 0.0f, by = 0.0f;
+    for (int dy = -radius; dy <= radius; ++dy) {
+        const int qy = lk_clampi(y + dy, 0, h - 1);
+        const size_t row = (size_t)qy * w;
+        for (int dx = -radius; dx <= radius; ++dx) {
+            const int qx = lk_clampi(x + dx, 0, w - 1);
+            const float d = I[row + qx] - lk_bilinear(J, w, h, (float)qx + f.x, (float)qy + f.y);
+            bx += gx[row + qx] * d;
+            by += gy[row + qx] * d;
+        }
+    }
+    const float4 g = G[(size_t)y * w + x];
+    const float det = g.x * g.z - g.y * g.y;
+    float du = 0.0f, dv = 0.0f;
+    if (det > 0.01f) {
+        du = (g.z * bx - g.y * by) / det;
+        dv = (g.x * by - g.y * bx) / det;
+    }
+    flow_out[(size_t)y * w + x] = make_float2(f.x + du, f.y + dv);
+}
+
+// cv-decoder/src/lib.rs:239-243,262-269: per-pixel records, raster order
+__global__ __launch_bounds__(256) void lk_entries_kernel(const float2* __restrict__ flow, int W, int H, float nx, float ny,
+                                                         float4* __restrict__ out) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= W || y >= H) return;
+    const float2 f = flow[(size_t)y * W + x];
+    out[(size_t)y * W + x] = make_float4(((float)x + 0.5f) * nx, ((float)y + 0.5f) * ny, f.x * nx, f.y * ny);
+}
+
+static dim3 lk_grid(int w, int h) { return dim3((w + 63) / 64, (h + 3) / 4); }
+
+// d_prev/d_cur: u8 luma on the device.  d_flow: W*H float2.  Workspace comes from the context.
+int lk_flow_device(ofps_hip_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_cur, int W, int H, int stride, int levels,
+                   int radius, int iters, float2* d_flow) {
+    OFPS_REQUIRE(ctx, W >= 1 && H >= 1 && stride >= W, "lk_flow: bad geometry W=%d H=%d stride=%d", W, H, stride);
+    OFPS_REQUIRE(ctx, levels >= 1 && levels <= 8 && radius >= 1 && radius <= 15 && iters >= 1 && iters <= 64,
+                 "lk_flow: levels=%d radius=%d iters=%d out of range", levels, radius, iters);
+    hipStream_t s = ctx->stream;
+    int ws[8], hs[8];
+    size_t off[9];
+    ws[0] = W; hs[0] = H; off[0] = 0;
+    for (int l = 1; l < levels; ++l) { ws[l] = (ws[l - 1] + 1) / 2; hs[l] = (hs[l - 1] + 1) / 2; }
+    for (int l = 0; l < levels; ++l) off[l + 1] = off[l] + (size_t)ws[l] * hs[l];
+    const size_t plane0 = (size_t)W * H, pyr = off[levels];
+    // layout: I pyramid | J pyramid | tmp | gx | gy | G (float4) | flowA (float2) | flowB (float2)
+    const size_t floats = 2 * pyr + 3 * plane0 + 4 * plane0 + 2 * plane0 + 2 * plane0;
+    auto* base = static_cast<float*>(scratch(ctx, S_WORK0, floats * sizeof(float)));
+    if (!base) return OFPS_HIP_ENOMEM;
+    float* Ip = base; float* Jp = Ip + pyr; float* tmp = Jp + pyr; float* gx = tmp + plane0; float* gy = gx + plane0;
+    float4* G = reinterpret_cast<float4*>(gy + plane0);
+    float2* fa = reinterpret_cast<float2*>(reinterpret_cast<float*>(G) + 4 * plane0);
+    float2* fb = fa + plane0;
+
+    hipLaunchKernelGGL(lk_u8_to_f32_kernel, lk_grid(W, H), dim3(256), 0, s, d_prev, W, H, stride, Ip);
+    hipLaunchKernelGGL(lk_u8_to_f32_kernel, lk_grid(W, H), dim3(256), 0, s, d_cur, W, H, stride, Jp);
+    for (int l = 1; l < levels; ++l) {
+        for (float* P : {Ip, Jp}) {
+            hipLaunchKernelGGL(lk_pyr_h_kernel, lk_grid(ws[l], hs[l - 1]), dim3(256), 0, s, P + off[l - 1], ws[l - 1], hs[l - 1], tmp, ws[l]);
+            hipLaunchKernelGGL(lk_pyr_v_kernel, lk_grid(ws[l], hs[l]), dim3(256), 0, s, tmp, ws[l], hs[l - 1], P + off[l], hs[l]);
+        }
+    }
+    float2* cur_flow = fa;
+    float2* other = fb;
+    for (int l = levels - 1; l >= 0; --l) {
+        const int w = ws[l], h = hs[l];
+        if (l == levels - 1) {
+            OFPS_HIP_TRY(ctx, hipMemsetAsync(cur_flow, 0, (size_t)w * h * sizeof(float2), s));
+        } else {
+            hipLaunchKernelGGL(lk_upsample_kernel, lk_grid(w, h), dim3(256), 0, s, cur_flow, ws[l + 1], hs[l + 1], other, w, h);
+            float2* t = cur_flow; cur_flow = other; other = t;
+        }
+        hipLaunchKernelGGL(lk_grad_kernel, lk_grid(w, h), dim3(256), 0, s, Ip + off[l], w, h, gx, gy);
+        hipLaunchKernelGGL(lk_tensor_kernel, lk_grid(w, h), dim3(256), 0, s, gx, gy, w, h, radius, G);
+        for (int it = 0; it < iters; ++it) {
+            float2* dst = (l == 0 && it == iters - 1) ? d_flow : other;
+            hipLaunchKernelGGL(lk_step_kernel, lk_grid(w, h), dim3(256), 0, s, Ip + off[l], Jp + off[l], gx, gy, G, w, h, radius,
+                               cur_flow, dst);
+            if (dst != d_flow) { float2* t = cur_flow; cur_flow = other; other = t; }
+        }
+    }
+    OFPS_HIP_TRY(ctx, hipGetLastError());
+    return OFPS_HIP_OK;
+}
+
+}  // namespace ofps
+
+extern "C" {
+
+int ofps_hip_lk_flow_dev(ofps_hip_ctx* ctx, const void* d_prev, const void* d_cur, int W, int H, int stride, int levels,
+                         int radius, int iters, void* d_out_flow, void* d_out_entries) {
+    if (!ctx) return OFPS_HIP_EINVAL;
+    OFPS_REQUIRE(ctx, d_prev && d_cur && (d_out_flow || d_out_entries), "lk_flow: null device pointer");
+    OFPS_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    auto* flow = static_cast<float2*>(d_out_flow);
+    if (!flow) {
+        flow = static_cast<float2*>(ofps::scratch(ctx, ofps::S_WORK1, (size_t)W * H * sizeof(float2)));
+        if (!flow) return OFPS_HIP_ENOMEM;
+    }
+    int rc = ofps::lk_flow_device(ctx, static_cast<const uint8_t*>(d_prev), static_cast<const uint8_t*>(d_cur), W, H, stride, levels,
+                                  radius, iters, flow);
+    if (rc != OFPS_HIP_OK) return rc;
+    if (d_out_entries) {
+        hipLaunchKernelGGL(ofps::lk_entries_kernel, ofps::lk_grid(W, H), dim3(256), 0, ctx->stream, flow, W, H, 1.0f / (float)W,
+                           1.0f / (float)H, static_cast<float4*>(d_out_entries));
+        OFPS_HIP_TRY(ctx, hipGetLastError());
+    }
+    return OFPS_HIP_OK;
+}
+
+int ofps_hip_lk_flow(ofps_hip_ctx* ctx, const uint8_t* prev, const uint8_t* cur, int W, int H, int stride, int levels,
+                     int radius, int iters, float* out_flow, float* out_entries) {
+    if (!ctx) return OFPS_HIP_EINVAL;
+    OFPS_REQUIRE(ctx, prev && cur && (out_flow || out_entries), "lk_flow: null host pointer");
+    OFPS_REQUIRE(ctx, W >= 1 && H >= 1 && stride >= W, "lk_flow: bad geometry");
+    OFPS_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t px = (size_t)W * H;
+    auto* d_frames = static_cast<uint8_t*>(ofps::scratch(ctx, ofps::S_FRAMES, 2 * px));
+    auto* d_flow = static_cast<float2*>(ofps::scratch(ctx, ofps::S_WORK1, px * sizeof(float2)));
+    auto* d_ent = out_entries ? static_cast<float4*>(ofps::scratch(ctx, ofps::S_ENTRIES, px * sizeof(float4))) : nullptr;
+    if (!d_frames || !d_flow || (out_entries && !d_ent)) return OFPS_HIP_ENOMEM;
+    OFPS_HIP_TRY(ctx, hipMemcpy2DAsync(d_frames, W, prev, stride, W, H, hipMemcpyHostToDevice, ctx->stream));
+    OFPS_HIP_TRY(ctx, hipMemcpy2DAsync(d_frames + px, W, cur, stride, W, H, hipMemcpyHostToDevice, ctx->stream));
+    int rc = ofps_hip_lk_flow_dev(ctx, d_frames, d_frames + px, W, H, W, levels, radius, iters, d_flow, d_ent);
+    if (rc != OFPS_HIP_OK) return rc;
+    if (out_flow) OFPS_HIP_TRY(ctx, hipMemcpyAsync(out_flow, d_flow, px * sizeof(float2), hipMemcpyDeviceToHost, ctx->stream));
+    if (out_entries) OFPS_HIP_TRY(ctx, hipMemcpyAsync(out_entries, d_ent, px * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
+    OFPS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return OFPS_HIP_OK;
+}
+
+}  // extern "C"

@@ -98,6 +98,22 @@ class HipContext:
                                                     ref_mode, block, search_range, C.c_void_p(d_out_entries),
                                                     C.c_void_p(d_out_best or 0)))
 
+    # ---- N2
+    def lk_flow(self, prev: np.ndarray, cur: np.ndarray, levels=3, radius=4, iters=3, want_entries=False):
+        prev = np.ascontiguousarray(prev, np.uint8); cur = np.ascontiguousarray(cur, np.uint8)
+        H, W = prev.shape
+        flow = np.zeros((H, W, 2), np.float32)
+        ent = np.zeros((H * W, 4), np.float32) if want_entries else None
+        u8 = C.POINTER(C.c_uint8)
+        self._check(self._lib.ofps_hip_lk_flow(self._h, prev.ctypes.data_as(u8), cur.ctypes.data_as(u8), W, H, W, levels, radius,
+                                               iters, _fp(flow), _fp(ent) if want_entries else None))
+        return (flow, ent) if want_entries else flow
+
+    def lk_flow_dev(self, d_prev: int, d_cur: int, W: int, H: int, stride: int, levels: int, radius: int, iters: int,
+                    d_out_flow: int | None, d_out_entries: int | None):
+        self._check(self._lib.ofps_hip_lk_flow_dev(self._h, C.c_void_p(d_prev), C.c_void_p(d_cur), W, H, stride, levels, radius,
+                                                   iters, C.c_void_p(d_out_flow or 0), C.c_void_p(d_out_entries or 0)))
+
     # ---- A1-A4
     def densify(self, entries, w: int, h: int, want_cells=False):
         e = np.ascontiguousarray(entries, np.float32).reshape(-1, 4)

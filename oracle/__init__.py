@@ -76,6 +76,10 @@ def lib():
         L.orc_sad_flow.restype = C.c_size_t
         L.orc_sad_flow_ex.argtypes = L.orc_sad_flow.argtypes + [C.c_int]
         L.orc_sad_flow_ex.restype = C.c_size_t
+        L.orc_lk_flow.argtypes = [C.POINTER(C.c_uint8), C.POINTER(C.c_uint8), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                  C.c_int, fp]
+        L.orc_lk_flow.restype = C.c_int
+        L.orc_flow_to_entries.argtypes = [fp, C.c_int, C.c_int, fp]
         L.orc_num_threads.restype = C.c_int
         _lib = L
     return _lib
@@ -239,6 +243,25 @@ def sad_flow(prev, cur, B: int, R: int, threads: int = 1, stride=None, simd: boo
                               _fp(ent), best.ctypes.data_as(C.POINTER(C.c_int32)), threads, int(simd))
     assert k == nb
     return ent[:nb], best[:nb]
+
+
+def lk_flow(prev, cur, levels: int = 3, radius: int = 4, iters: int = 3) -> np.ndarray:
+    """-> flow[H, W, 2] f32 (u, v): prev(x,y) ~ cur(x+u, y+v)"""
+    prev = np.ascontiguousarray(prev, np.uint8); cur = np.ascontiguousarray(cur, np.uint8)
+    H, W = prev.shape
+    out = np.zeros((H, W, 2), np.float32)
+    u8 = C.POINTER(C.c_uint8)
+    ok = lib().orc_lk_flow(prev.ctypes.data_as(u8), cur.ctypes.data_as(u8), W, H, W, levels, radius, iters, _fp(out))
+    if not ok:
+        raise ValueError("orc_lk_flow: bad parameters")
+    return out
+
+
+def flow_to_entries(flow) -> np.ndarray:
+    f = _f32(flow); H, W = f.shape[:2]
+    out = np.zeros((H * W, 4), np.float32)
+    lib().orc_flow_to_entries(_fp(f), W, H, _fp(out))
+    return out
 
 
 def num_threads() -> int:

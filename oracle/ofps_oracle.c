@@ -766,3 +766,144 @@ int orc_num_threads(void) {
     return 1;
 #endif
 }
+
+/* ------------------------------------------------------------------------------------ */
+/* N2: dense pyramidal Lucas-Kanade flow (build-defined; the reference only calls OpenCV) */
+/* ------------------------------------------------------------------------------------ */
+/* Spec (DESIGN.md "N2"): f32 throughout, no FMA, every loop in the order written here.
+ *   pyramid   level 0 = luma as f32; level l+1 = [1 4 6 4 1]/16 separable blur (replicated border),
+ *             every second sample; size (w+1)/2 x (h+1)/2
+ *   gradient  central differences * 0.5 on the PREVIOUS frame, replicated border
+ *   G         per pixel sums over the (2r+1)^2 window (dy outer, dx inner, clamped coordinates) of
+ *             Ix*Ix, Ix*Iy, Iy*Iy
+ *   step      b = sum_w grad(q) * (I(q) - J(q + flow(p))), J sampled bilinearly with edge clamp;
+ *             flow(p) += G^-1 b when det(G) > 0.01; `iters` steps per level
+ *   levels    coarse to fine, flow_l(x,y) = 2 * flow_{l+1}(x/2, y/2); the coarsest level starts at 0
+ * Convention: prev(x,y) ~ cur(x+u, y+v), as calcOpticalFlowFarneback's output that cv-decoder consumes
+ * (cv-decoder/src/lib.rs:188-199,262-269). */
+static int lk_clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+static void lk_pyr_down(const float* in, int w, int h, float* out, int w1, int h1, float* tmp /* w1*h */) {
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w1; ++x) {
+            const float* r = in + (size_t)y * w;
+            float a = r[lk_clampi(2 * x - 2, 0, w - 1)], b = r[lk_clampi(2 * x - 1, 0, w - 1)], c = r[lk_clampi(2 * x, 0, w - 1)],
+                  d = r[lk_clampi(2 * x + 1, 0, w - 1)], e = r[lk_clampi(2 * x + 2, 0, w - 1)];
+            tmp[(size_t)y * w1 + x] = ((((a + 4.0f * b) + 6.0f * c) + 4.0f * d) + e) * 0.0625f;
+        }
+    for (int y = 0; y < h1; ++y)
+        for (int x = 0; x < w1; ++x) {
+            float a = tmp[(size_t)lk_clampi(2 * y - 2, 0, h - 1) * w1 + x], b = tmp[(size_t)lk_clampi(2 * y - 1, 0, h - 1) * w1 + x],
+                  c = tmp[(size_t)lk_clampi(2 * y, 0, h - 1) * w1 + x], d = tmp[(size_t)lk_clampi(2 * y + 1, 0, h - 1) * w1 + x],
+                  e = tmp[(size_t)lk_clampi(2 * y + 2, 0, h - 1) * w1 + x];
+            out[(size_t)y * w1 + x] = ((((a + 4.0f * b) + 6.0f * c) + 4.0f * d) + e) * 0.0625f;
+        }
+}
+
+static float lk_bilinear(const float* J, int w, int h, float fx, float fy) {
+    float x0f = floorf(fx), y0f = floorf(fy);
+    float ax = fx - x0f, ay = fy - y0f;
+    /* clamp in float first so wild flows cannot overflow the int conversion */
+    float cx = x0f < -1.0f ? -1.0f : (x0f > (float)w ? (float)w : x0f);
+    float cy = y0f < -1.0f ? -1.0f : (y0f > (float)h ? (float)h : y0f);
+    int x0 = (int)cx, y0 = (int)cy;
+    int xa = lk_clampi(x0, 0, w - 1), xb = lk_clampi(x0 + 1, 0, w - 1);
+    int ya = lk_clampi(y0, 0, h - 1), yb = lk_clampi(y0 + 1, 0, h - 1);
+    float j00 = J[(size_t)ya * w + xa], j10 = J[(size_t)ya * w + xb], j01 = J[(size_t)yb * w + xa], j11 = J[(size_t)yb * w + xb];
+    float top = j00 + ax * (j10 - j00);
+    float bot = j01 + ax * (j11 - j01);
+    return top + ay * (bot - top);
+}
+
+int orc_lk_flow(const uint8_t* prev, const uint8_t* cur, int W, int H, int stride, int levels, int radius, int iters,
+                float* out_flow) {
+    if (levels < 1 || levels > 8 || radius < 1 || radius > 15 || iters < 1 || W < 1 || H < 1) return 0;
+    int ws[8], hs[8];
+    float *I[8], *J[8];
+    ws[0] = W; hs[0] = H;
+    for (int l = 1; l < levels; ++l) { ws[l] = (ws[l - 1] + 1) / 2; hs[l] = (hs[l - 1] + 1) / 2; }
+    for (int l = 0; l < levels; ++l) {
+        I[l] = (float*)malloc((size_t)ws[l] * hs[l] * sizeof(float));
+        J[l] = (float*)malloc((size_t)ws[l] * hs[l] * sizeof(float));
+    }
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+            I[0][(size_t)y * W + x] = (float)prev[(size_t)y * stride + x];
+            J[0][(size_t)y * W + x] = (float)cur[(size_t)y * stride + x];
+        }
+    float* tmp = (float*)malloc((size_t)W * H * sizeof(float));
+    for (int l = 1; l < levels; ++l) {
+        lk_pyr_down(I[l - 1], ws[l - 1], hs[l - 1], I[l], ws[l], hs[l], tmp);
+        lk_pyr_down(J[l - 1], ws[l - 1], hs[l - 1], J[l], ws[l], hs[l], tmp);
+    }
+    float* flow = (float*)calloc((size_t)2 * W * H, sizeof(float));
+    float* next = (float*)malloc((size_t)2 * W * H * sizeof(float));
+    float* gx = (float*)malloc((size_t)W * H * sizeof(float));
+    float* gy = (float*)malloc((size_t)W * H * sizeof(float));
+    for (int l = levels - 1; l >= 0; --l) {
+        const int w = ws[l], h = hs[l];
+        const float* Il = I[l]; const float* Jl = J[l];
+        if (l < levels - 1) {                                   /* flow of the coarser level, doubled */
+            const int w1 = ws[l + 1], h1 = hs[l + 1];
+            for (int y = 0; y < h; ++y)
+                for (int x = 0; x < w; ++x) {
+                    const int sx = lk_clampi(x / 2, 0, w1 - 1), sy = lk_clampi(y / 2, 0, h1 - 1);
+                    next[2 * ((size_t)y * w + x)] = 2.0f * flow[2 * ((size_t)sy * w1 + sx)];
+                    next[2 * ((size_t)y * w + x) + 1] = 2.0f * flow[2 * ((size_t)sy * w1 + sx) + 1];
+                }
+            memcpy(flow, next, (size_t)2 * w * h * sizeof(float));
+        } else {
+            memset(flow, 0, (size_t)2 * w * h * sizeof(float));
+        }
+        for (int y = 0; y < h; ++y)
+            for (int x = 0; x < w; ++x) {
+                gx[(size_t)y * w + x] = (Il[(size_t)y * w + lk_clampi(x + 1, 0, w - 1)] - Il[(size_t)y * w + lk_clampi(x - 1, 0, w - 1)]) * 0.5f;
+                gy[(size_t)y * w + x] = (Il[(size_t)lk_clampi(y + 1, 0, h - 1) * w + x] - Il[(size_t)lk_clampi(y - 1, 0, h - 1) * w + x]) * 0.5f;
+            }
+        for (int it = 0; it < iters; ++it) {
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
+            for (int y = 0; y < h; ++y)
+                for (int x = 0; x < w; ++x) {
+                    const float u = flow[2 * ((size_t)y * w + x)], v = flow[2 * ((size_t)y * w + x) + 1];
+                    float gxx = 0.0f, gxy = 0.0f, gyy = 0.0f, bx = 0.0f, by = 0.0f;
+                    for (int dy = -radius; dy <= radius; ++dy)
+                        for (int dx = -radius; dx <= radius; ++dx) {
+                            const int qx = lk_clampi(x + dx, 0, w - 1), qy = lk_clampi(y + dy, 0, h - 1);
+                            const float ix = gx[(size_t)qy * w + qx], iy = gy[(size_t)qy * w + qx];
+                            const float d = Il[(size_t)qy * w + qx] - lk_bilinear(Jl, w, h, (float)qx + u, (float)qy + v);
+                            gxx += ix * ix; gxy += ix * iy; gyy += iy * iy;
+                            bx += ix * d; by += iy * d;
+                        }
+                    const float det = gxx * gyy - gxy * gxy;
+                    float du = 0.0f, dv = 0.0f;
+                    if (det > 0.01f) {
+                        du = (gyy * bx - gxy * by) / det;
+                        dv = (gxx * by - gxy * bx) / det;
+                    }
+                    next[2 * ((size_t)y * w + x)] = u + du;
+                    next[2 * ((size_t)y * w + x) + 1] = v + dv;
+                }
+            memcpy(flow, next, (size_t)2 * w * h * sizeof(float));
+        }
+    }
+    memcpy(out_flow, flow, (size_t)2 * W * H * sizeof(float));
+    for (int l = 0; l < levels; ++l) { free(I[l]); free(J[l]); }
+    free(tmp); free(flow); free(next); free(gx); free(gy);
+    return 1;
+}
+
+/* cv-decoder's record convention for per-pixel flow (cv-decoder/src/lib.rs:239-243, 262-269):
+ * pos = ((x+.5), (y+.5)) * (1/W, 1/H), motion = flow * (1/W, 1/H); raster order. */
+void orc_flow_to_entries(const float* flow, int W, int H, float* out_entries) {
+    const float nx = 1.0f / (float)W, ny = 1.0f / (float)H;
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+            float* e = out_entries + 4 * ((size_t)y * W + x);
+            e[0] = ((float)x + 0.5f) * nx;
+            e[1] = ((float)y + 0.5f) * ny;
+            e[2] = flow[2 * ((size_t)y * W + x)] * nx;
+            e[3] = flow[2 * ((size_t)y * W + x) + 1] * ny;
+        }
+}

@@ -112,6 +112,14 @@ size_t orc_sad_flow(const uint8_t* prev, const uint8_t* cur, int W, int H, int s
 size_t orc_sad_flow_ex(const uint8_t* prev, const uint8_t* cur, int W, int H, int stride,
                        int B, int R, float* out_entries, int32_t* out_best, int threads, int simd);
 
+/* ---- N2: dense pyramidal Lucas-Kanade flow (build-defined spec; no reference arithmetic exists:
+ * the reference calls OpenCV's calcOpticalFlowFarneback, cv-decoder/src/lib.rs:188-199) -> "parity unpinned".
+ * out_flow: 2*W*H floats (u,v) per pixel, prev(x,y) ~ cur(x+u,y+v).  Returns 1, or 0 on bad parameters. */
+int orc_lk_flow(const uint8_t* prev, const uint8_t* cur, int W, int H, int stride, int levels, int radius, int iters,
+                float* out_flow);
+/* per-pixel MotionEntry records in cv-decoder's convention (cv-decoder/src/lib.rs:239-243,262-269) */
+void orc_flow_to_entries(const float* flow, int W, int H, float* out_entries);
+
 int orc_num_threads(void);
 
 #ifdef __cplusplus

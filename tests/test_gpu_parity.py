@@ -364,3 +364,38 @@ def test_push_frame_matches_stagewise_oracle(ctx):
     # a geometry change restarts the stream
     r = ctx.push_frame(fr[0][:180, :320].copy(), block=16, search_range=8)
     assert not r["have_vectors"]
+
+
+# ------------------------------------------------------------------ N2: dense pyramidal LK flow
+@pytest.mark.parametrize("W,H,levels,radius,iters", [(160, 96, 3, 4, 3), (97, 61, 2, 2, 2), (64, 48, 1, 6, 4), (320, 180, 3, 4, 3)])
+def test_lk_flow_bit_exact_vs_oracle(ctx, W, H, levels, radius, iters):
+    """hip_lk == the build's CPU restatement, same bits (the algorithm itself is build-defined: the reference calls
+    OpenCV's Farneback, cv-decoder/src/lib.rs:188-199 -> parity unpinned w.r.t. the reference)."""
+    fr = synth.luma_sequence(2, W, H, max_step=3, seed=synth.SEED0 + W)
+    f_o = oracle.lk_flow(fr[0], fr[1], levels, radius, iters)
+    f_g, e_g = ctx.lk_flow(fr[0], fr[1], levels, radius, iters, want_entries=True)
+    np.testing.assert_array_equal(f_g.view(np.uint32), f_o.view(np.uint32))
+    np.testing.assert_array_equal(e_g.view(np.uint32), oracle.flow_to_entries(f_o).view(np.uint32))   # cv-decoder records
+
+
+def test_lk_flow_recovers_planted_translation(ctx):
+    base = synth.luma_sequence(1, 640 + 64, 360 + 64, max_step=0, noise=0, seed=5)[0]
+    dx, dy = 5, -3
+    prev = np.ascontiguousarray(base[32:32 + 360, 32:32 + 640])
+    cur = np.ascontiguousarray(base[32 - dy:32 - dy + 360, 32 - dx:32 - dx + 640])      # cur(x+dx, y+dy) = prev(x, y)
+    f = ctx.lk_flow(prev, cur, 3, 4, 3)
+    inner = f[32:-32, 32:-32]
+    assert np.abs(inner - np.array([dx, dy], np.float32)).mean() < 1e-3
+
+
+def test_lk_to_rotation_end_to_end(ctx):
+    """cfg3 shape at reduced size: frames -> per-pixel flow -> cv-decoder records -> densify 150x84 -> Almeida LSQ;
+    every stage equals the oracle run stage by stage."""
+    fr = synth.luma_sequence(2, 480, 272, max_step=2, seed=77)
+    f_g, e_g = ctx.lk_flow(fr[0], fr[1], 3, 4, 3, want_entries=True)
+    e_o = oracle.flow_to_entries(oracle.lk_flow(fr[0], fr[1], 3, 4, 3))
+    np.testing.assert_array_equal(e_g.view(np.uint32), e_o.view(np.uint32))
+    d_g, d_o = ctx.densify_to_entries(e_g, 150, 84), oracle.densify_to_entries(e_o, 150, 84)
+    np.testing.assert_array_equal(d_g.view(np.uint32), d_o.view(np.uint32))
+    q_g, _ = ctx.almeida(d_g, 16 / 9, 22.275, use_ransac=False)
+    np.testing.assert_allclose(q_g, oracle.solve_ypr_given(d_o, oracle.camera(16 / 9, 22.275)), atol=2e-6, rtol=0)

@@ -170,3 +170,16 @@ def test_interpolate_empty_cells_fills_everything():
     assert np.isfinite(f).all()
     # no vectors at all: stays empty (motion_field.rs:243-246)
     assert (oracle.densify_interpolated(np.zeros((0, 4), np.float32), 5, 5) == 0).all()
+
+
+def test_lk_flow_oracle_recovers_translation_and_zero():
+    base = synth.luma_sequence(1, 256 + 64, 160 + 64, max_step=0, noise=0, seed=5)[0]
+    prev = np.ascontiguousarray(base[32:32 + 160, 32:32 + 256])
+    for dx, dy in [(3, -2), (0, 0)]:
+        cur = np.ascontiguousarray(base[32 - dy:32 - dy + 160, 32 - dx:32 - dx + 256])
+        f = oracle.lk_flow(prev, cur, 3, 4, 3)
+        assert np.abs(f[24:-24, 24:-24] - np.array([dx, dy], np.float32)).mean() < 1e-3
+    e = oracle.flow_to_entries(np.ones((4, 6, 2), np.float32))
+    assert e.shape == (24, 4) and e[0, 0] == np.float32(0.5) * (np.float32(1) / np.float32(6)) and e[7, 1] == np.float32(1.5) * np.float32(0.25)
+    with pytest.raises(ValueError):
+        oracle.lk_flow(prev, prev, 0, 4, 3)

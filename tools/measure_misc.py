@@ -80,6 +80,20 @@ def main():
     ms = timeit(lambda: ctx.densify_dev(e.data_ptr(), n, 1, 150, 84, f150.data_ptr()), n=5, warm=1)
     out["cfg3_densify_150x84_per_pixel"] = {"ms": round(ms, 3), "Mvectors_per_s": round(n / ms / 1e3, 1),
                                             "GBps_entry_bytes": round(16 * n / ms / 1e6, 1)}
+    # --- cfg3 from pixels: 1080p pair -> 3-level LK flow (r=4, 3 steps/level) -> per-pixel records -> densify -> Almeida
+    fr = synth.luma_sequence(2, 1920, 1080, max_step=3, seed=11)
+    dfr = torch.from_numpy(fr).cuda()
+    d_ent = torch.empty((1920 * 1080, 4), dtype=torch.float32, device="cuda")
+    f84 = torch.empty((150 * 84, 2), dtype=torch.float32, device="cuda")
+    ms_lk = timeit(lambda: ctx.lk_flow_dev(dfr[0].data_ptr(), dfr[1].data_ptr(), 1920, 1080, 1920, 3, 4, 3, None, d_ent.data_ptr()), n=5, warm=1)
+
+    def chain():
+        ctx.lk_flow_dev(dfr[0].data_ptr(), dfr[1].data_ptr(), 1920, 1080, 1920, 3, 4, 3, None, d_ent.data_ptr())
+        ctx.densify_dev(d_ent.data_ptr(), 1920 * 1080, 1, 150, 84, f84.data_ptr())
+        ctx.almeida_dev(d_ent.data_ptr(), 1920 * 1080, 1, 16 / 9, 22.275, False, 0, 0.05, 0, 0, q1.data_ptr())
+    ms_chain = timeit(chain, n=5, warm=1)
+    out["cfg3_lk_flow_1080p"] = {"ms": round(ms_lk, 3), "Mvectors_per_s": round(1920 * 1080 / ms_lk / 1e3, 1)}
+    out["cfg3_chain_lk_densify_almeida"] = {"ms": round(ms_chain, 3), "Mvectors_per_s": round(1920 * 1080 / ms_chain / 1e3, 1)}
     ctx.use_own_stream()
     print(json.dumps(out, indent=1))
 
