@@ -92,7 +92,11 @@ __device__ __forceinline__ float lk_bilinear(const float* __restrict__ J, int w,
     return top + ay * (bot - top);
 }
 
-// one Gauss-Newton step for every pixel
+// One Gauss-Newton step for every pixel.  RADIUS > 0: compile-time window; the per-sample floor/clamp of the
+// oracle's bilinear fetch depends only on the window column (x side) or row (y side), so it is hoisted into
+// 2r+1 column records and one row record -- the same operations on the same inputs, hence the same bits.
+// RADIUS == 0: run-time radius, the plain per-sample form.
+template <int RADIUS>
 __global__ __launch_bounds__(256) void lk_step_kernel(const float* __restrict__ I, const float* __restrict__ J,
                                                       const float* __restrict__ gx, const float* __restrict__ gy,
                                                       const float4* __restrict__ G, int w, int h, int radius,
@@ -101,14 +105,52 @@ __global__ __launch_bounds__(256) void lk_step_kernel(const float* __restrict__ 
     if (x >= w || y >= h) return;
     const float2 f = flow_in[(size_t)y * w + x];
     float bx = 0.0f, by = 0.0f;
-    for (int dy = -radius; dy <= radius; ++dy) {
-        const int qy = lk_clampi(y + dy, 0, h - 1);
-        const size_t row = (size_t)qy * w;
-        for (int dx = -radius; dx <= radius; ++dx) {
-            const int qx = lk_clampi(x + dx, 0, w - 1);
-            const float d = I[row + qx] - lk_bilinear(J, w, h, (float)qx + f.x, (float)qy + f.y);
-            bx += gx[row + qx] * d;
-            by += gy[row + qx] * d;
+    if constexpr (RADIUS > 0) {
+        constexpr int N = 2 * RADIUS + 1;
+        int qx[N], xa[N], xb[N];
+        float ax[N];
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            qx[k] = lk_clampi(x + k - RADIUS, 0, w - 1);
+            const float fx = (float)qx[k] + f.x;
+            const float x0f = floorf(fx);
+            ax[k] = fx - x0f;
+            const float cx = x0f < -1.0f ? -1.0f : (x0f > (float)w ? (float)w : x0f);
+            const int x0 = (int)cx;
+            xa[k] = lk_clampi(x0, 0, w - 1);
+            xb[k] = lk_clampi(x0 + 1, 0, w - 1);
+        }
+#pragma unroll 1
+        for (int dy = -RADIUS; dy <= RADIUS; ++dy) {
+            const int qy = lk_clampi(y + dy, 0, h - 1);
+            const float fy = (float)qy + f.y;
+            const float y0f = floorf(fy);
+            const float ay = fy - y0f;
+            const float cy = y0f < -1.0f ? -1.0f : (y0f > (float)h ? (float)h : y0f);
+            const int y0 = (int)cy;
+            const float* ra = J + (size_t)lk_clampi(y0, 0, h - 1) * w;
+            const float* rb = J + (size_t)lk_clampi(y0 + 1, 0, h - 1) * w;
+            const size_t row = (size_t)qy * w;
+#pragma unroll
+            for (int k = 0; k < N; ++k) {
+                const float j00 = ra[xa[k]], j10 = ra[xb[k]], j01 = rb[xa[k]], j11 = rb[xb[k]];
+                const float top = j00 + ax[k] * (j10 - j00);
+                const float bot = j01 + ax[k] * (j11 - j01);
+                const float d = I[row + qx[k]] - (top + ay * (bot - top));
+                bx += gx[row + qx[k]] * d;
+                by += gy[row + qx[k]] * d;
+            }
+        }
+    } else {
+        for (int dy = -radius; dy <= radius; ++dy) {
+            const int qy = lk_clampi(y + dy, 0, h - 1);
+            const size_t row = (size_t)qy * w;
+            for (int dx = -radius; dx <= radius; ++dx) {
+                const int qx = lk_clampi(x + dx, 0, w - 1);
+                const float d = I[row + qx] - lk_bilinear(J, w, h, (float)qx + f.x, (float)qy + f.y);
+                bx += gx[row + qx] * d;
+                by += gy[row + qx] * d;
+            }
         }
     }
     const float4 g = G[(size_t)y * w + x];
@@ -176,8 +218,12 @@ int lk_flow_device(ofps_hip_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_cu
         hipLaunchKernelGGL(lk_tensor_kernel, lk_grid(w, h), dim3(256), 0, s, gx, gy, w, h, radius, G);
         for (int it = 0; it < iters; ++it) {
             float2* dst = (l == 0 && it == iters - 1) ? d_flow : other;
-            hipLaunchKernelGGL(lk_step_kernel, lk_grid(w, h), dim3(256), 0, s, Ip + off[l], Jp + off[l], gx, gy, G, w, h, radius,
-                               cur_flow, dst);
+            switch (radius) {
+                case 2: hipLaunchKernelGGL(lk_step_kernel<2>, lk_grid(w, h), dim3(256), 0, s, Ip + off[l], Jp + off[l], gx, gy, G, w, h, radius, cur_flow, dst); break;
+                case 4: hipLaunchKernelGGL(lk_step_kernel<4>, lk_grid(w, h), dim3(256), 0, s, Ip + off[l], Jp + off[l], gx, gy, G, w, h, radius, cur_flow, dst); break;
+                case 6: hipLaunchKernelGGL(lk_step_kernel<6>, lk_grid(w, h), dim3(256), 0, s, Ip + off[l], Jp + off[l], gx, gy, G, w, h, radius, cur_flow, dst); break;
+                default: hipLaunchKernelGGL(lk_step_kernel<0>, lk_grid(w, h), dim3(256), 0, s, Ip + off[l], Jp + off[l], gx, gy, G, w, h, radius, cur_flow, dst);
+            }
             if (dst != d_flow) { float2* t = cur_flow; cur_flow = other; other = t; }
         }
     }
