@@ -399,3 +399,33 @@ def test_lk_to_rotation_end_to_end(ctx):
     np.testing.assert_array_equal(d_g.view(np.uint32), d_o.view(np.uint32))
     q_g, _ = ctx.almeida(d_g, 16 / 9, 22.275, use_ransac=False)
     np.testing.assert_allclose(q_g, oracle.solve_ypr_given(d_o, oracle.camera(16 / 9, 22.275)), atol=2e-6, rtol=0)
+
+
+# ------------------------------------------------------------------ argument validation / degenerate sizes
+def test_degenerate_geometries_and_bad_arguments(ctx):
+    from ofps_amd.runtime import OfpsHipError
+    # frame smaller than one block: zero vectors, not an error
+    tiny = np.zeros((8, 8), np.uint8)
+    assert len(ctx.sad_flow(tiny, tiny, 16, 16)) == 0
+    # a single block, search window entirely clipped except (0,0)
+    one = synth.random_luma(2, 16, 16, seed=3)
+    ent, best = ctx.sad_flow(one[0], one[1], 16, 16, want_best=True)
+    _, best_o = oracle.sad_flow(one[0], one[1], 16, 16)
+    np.testing.assert_array_equal(best, best_o)
+    assert tuple(best[0][:2]) == (0, 0)
+    # densify / detect / almeida reject nonsense loudly
+    e = _entries(10, 1)
+    with pytest.raises(OfpsHipError):
+        ctx.densify(e, 0, 4)
+    with pytest.raises(OfpsHipError):
+        ctx.densify(e, 300, 300)                      # > 65536 cells
+    with pytest.raises(OfpsHipError):
+        ctx.detect(e, min_size=1e-9, subdivide=16)    # block_dim far beyond the 160 the properties allow
+    with pytest.raises(OfpsHipError):
+        ctx.almeida(e, -1.0, 90.0)
+    with pytest.raises(OfpsHipError):
+        ctx.lk_flow(tiny, tiny, levels=0)
+    with pytest.raises(OfpsHipError):
+        ctx.set_sad_mode(7)
+    # the context stays usable after errors
+    assert ctx.densify(e, 4, 4).shape == (4, 4, 2)
