@@ -110,6 +110,13 @@ int ofps_hip_sad_flow_dev(ofps_hip_ctx* ctx, const void* d_frames, int n_frames,
  * out_flow: 2*W*H f32 (u,v) or NULL; out_entries: 4*W*H f32 or NULL (at least one of them). */
 int ofps_hip_lk_flow(ofps_hip_ctx* ctx, const uint8_t* prev, const uint8_t* cur, int W, int H, int stride,
                      int levels, int radius, int iters, float* out_flow, float* out_entries);
+/* One Decoder::process_frame of a "hip_lk" plugin in cv-decoder's full-resolution mode
+ * (cv-decoder/src/lib.rs:82-294): flow -> per-pixel records -> down-sampled through the densifier to the
+ * (max_w, max_h)-capped grid of :98-121 (defaults 150 x 150 -> 150 x 84 at 16:9) -> one record per visited cell in
+ * (x, y)-sorted order.  out_entries capacity: 4 * min(max_w,W) * min(max_h,H) floats. */
+int ofps_hip_lk_decode(ofps_hip_ctx* ctx, const uint8_t* prev, const uint8_t* cur, int W, int H, int stride,
+                       int levels, int radius, int iters, int max_w, int max_h,
+                       float* out_entries, size_t* n_out, int* out_w, int* out_h);
 int ofps_hip_lk_flow_dev(ofps_hip_ctx* ctx, const void* d_prev, const void* d_cur, int W, int H, int stride,
                          int levels, int radius, int iters, void* d_out_flow, void* d_out_entries);
 

@@ -51,6 +51,8 @@ int densify_device(ofps_hip_ctx* ctx, const float4* d_entries, size_t n, int bat
                    uint32_t* d_cells, uint32_t** out_begin, uint32_t** out_end);
 int densify_device_raw(ofps_hip_ctx* ctx, const float4* d_entries, size_t n, int batch, int w, int h, float2* d_field,
                        uint32_t* d_cells, uint32_t** out_begin, uint32_t** out_end, float2* d_sum, float* d_cnt);
+int densify_entries_device(ofps_hip_ctx* ctx, const float4* d_entries, size_t n, int w, int h, float2* d_field,
+                           float4* d_out_entries, uint32_t* d_count);
 int detect_device(ofps_hip_ctx* ctx, const float4* d_entries, size_t n, int batch, float min_size, size_t subdivide,
                   float target_motion, int* d_result, float2* d_out_field, int* out_dim);
 int almeida_device(ofps_hip_ctx* ctx, const float4* d_entries, size_t n, int batch, float aspect, float fov_y_deg,

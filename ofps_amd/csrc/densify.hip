@@ -426,6 +426,18 @@ int densify_device_raw(ofps_hip_ctx* ctx, const float4* d_entries, size_t n, int
     return OFPS_HIP_OK;
 }
 
+// densify + cv-decoder's visited-cell records (cv-decoder/src/lib.rs:279-291), all on the device
+int densify_entries_device(ofps_hip_ctx* ctx, const float4* d_entries, size_t n, int w, int h, float2* d_field,
+                           float4* d_out_entries, uint32_t* d_count) {
+    uint32_t *begin = nullptr, *end = nullptr;
+    int rc = densify_device(ctx, d_entries, n, 1, w, h, d_field, nullptr, &begin, &end);
+    if (rc != OFPS_HIP_OK) return rc;
+    hipLaunchKernelGGL(cells_to_entries_kernel, dim3(1), dim3(1024), 0, ctx->stream, d_field, begin, end, w, h, d_out_entries,
+                       d_count);
+    OFPS_HIP_TRY(ctx, hipGetLastError());
+    return OFPS_HIP_OK;
+}
+
 }  // namespace ofps
 
 extern "C" {
@@ -497,12 +509,8 @@ int ofps_hip_densify_to_entries(ofps_hip_ctx* ctx, const float* entries, size_t 
     auto* d_cnt = static_cast<uint32_t*>(ofps::scratch(ctx, ofps::S_RESULT, 16));
     if (!d_ent || !d_field || !d_out || !d_cnt) return OFPS_HIP_ENOMEM;
     if (n) OFPS_HIP_TRY(ctx, hipMemcpyAsync(d_ent, entries, n * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
-    uint32_t *begin = nullptr, *end = nullptr;
-    int rc = ofps::densify_device(ctx, d_ent, n, 1, w, h, d_field, nullptr, &begin, &end);
+    int rc = ofps::densify_entries_device(ctx, d_ent, n, w, h, d_field, d_out, d_cnt);
     if (rc != OFPS_HIP_OK) return rc;
-    hipLaunchKernelGGL(ofps::cells_to_entries_kernel, dim3(1), dim3(1024), 0, ctx->stream, d_field, begin, end, w, h,
-                       d_out, d_cnt);
-    OFPS_HIP_TRY(ctx, hipGetLastError());
     uint32_t cnt = 0;
     OFPS_HIP_TRY(ctx, hipMemcpyAsync(&cnt, d_cnt, sizeof(cnt), hipMemcpyDeviceToHost, ctx->stream));
     OFPS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

@@ -131,6 +131,43 @@ std::vector<std::pair<std::string, PropertyMut>> HipSadDecoder::props_mut() {
     return {{"Block size", PropertyMut::usize(&block_, 8, 16)}, {"Search range", PropertyMut::usize(&range_, 8, 32)}};
 }
 
+// ------------------------------------------------------------------ hip_lk
+HipLkDecoder::HipLkDecoder(std::unique_ptr<std::istream> input, size_t width, size_t height, std::optional<double> fps, int device)
+    : ctx_(device), in_(std::move(input)), w_(width), h_(height), fps_(fps), prev_(width * height), cur_(width * height) {
+    if (!in_ || !*in_) throw Error("hip_lk: cannot open input");
+    if (w_ == 0 || h_ == 0) throw Error("hip_lk: frame size required (arg \"path?w=..&h=..\")");
+}
+
+bool HipLkDecoder::process_frame(MotionVectors& field, std::vector<RGBA>* out_frame, size_t* out_height, size_t skip) {
+    for (size_t s = 0; s <= skip; ++s) {                              // cv-decoder/src/lib.rs:92-142
+        std::swap(prev_, cur_);
+        in_->read(reinterpret_cast<char*>(cur_.data()), (std::streamsize)cur_.size());
+        if ((size_t)in_->gcount() != cur_.size()) throw Error("hip_lk: failed to grab frame");
+    }
+    if (out_frame && out_height) {
+        *out_height = h_;
+        out_frame->clear();
+        for (uint8_t y : cur_) out_frame->push_back(RGBA{y, y, y, 255});
+    }
+    const bool had_prev = have_prev_;
+    have_prev_ = true;
+    if (!had_prev) return false;                                      // :156-158
+    out_.resize(4 * std::min(max_w_, w_) * std::min(max_h_, h_));
+    size_t n_out = 0;
+    ctx_.check(ofps_hip_lk_decode(ctx_.get(), prev_.data(), cur_.data(), (int)w_, (int)h_, (int)w_, (int)levels_, (int)radius_,
+                                  (int)iters_, (int)max_w_, (int)max_h_, out_.data(), &n_out, nullptr, nullptr));
+    const size_t base = field.size();
+    field.resize(base + n_out);
+    std::memcpy(field.data() + base, out_.data(), n_out * sizeof(MotionEntry));
+    return true;
+}
+
+std::vector<std::pair<std::string, PropertyMut>> HipLkDecoder::props_mut() {   // cv-decoder/src/lib.rs:35-52 + the LK knobs
+    return {{"Width", PropertyMut::usize(&max_w_, 1, 2000)}, {"Height", PropertyMut::usize(&max_h_, 1, 2000)},
+            {"Pyramid levels", PropertyMut::usize(&levels_, 1, 8)}, {"Window radius", PropertyMut::usize(&radius_, 1, 15)},
+            {"Iterations", PropertyMut::usize(&iters_, 1, 64)}};
+}
+
 // ------------------------------------------------------------------ .mvec
 bool MvecFileDecoder::process_frame(MotionVectors& field, std::vector<RGBA>*, size_t*, size_t) {
     uint8_t hdr[4];
@@ -196,7 +233,7 @@ static std::unique_ptr<std::istream> open_input(const std::string& path) {
 
 std::unique_ptr<Decoder> create_decoder(const std::string& name, const std::string& arg) {
     if (name == "mvec") return std::make_unique<MvecFileDecoder>(open_input(arg));
-    if (name == "hip_sad") {                                          // "<path>?w=1920&h=1080&fps=60"
+    if (name == "hip_sad" || name == "hip_lk") {                      // "<path>?w=1920&h=1080&fps=60"
         std::string path = arg;
         size_t w = 0, h = 0;
         std::optional<double> fps;
@@ -211,6 +248,7 @@ std::unique_ptr<Decoder> create_decoder(const std::string& name, const std::stri
                 if (k == "w") w = std::stoul(v); else if (k == "h") h = std::stoul(v); else if (k == "fps") fps = std::stod(v);
             }
         }
+        if (name == "hip_lk") return std::make_unique<HipLkDecoder>(open_input(path), w, h, fps);
         return std::make_unique<HipSadDecoder>(open_input(path), w, h, fps);
     }
     throw Error("unknown decoder plugin: " + name);

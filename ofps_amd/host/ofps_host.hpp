@@ -137,6 +137,25 @@ private:
     bool have_prev_ = false;
 };
 
+// "hip_lk": dense per-pixel flow in cv-decoder's full-resolution mode (cv-decoder/src/lib.rs:82-294): one record per
+// visited cell of the (Width, Height)-capped grid; property names as in cv-decoder (:35-52).
+class HipLkDecoder : public Decoder {
+public:
+    HipLkDecoder(std::unique_ptr<std::istream> input, size_t width, size_t height, std::optional<double> fps, int device = 0);
+    bool process_frame(MotionVectors& field, std::vector<RGBA>* out_frame, size_t* out_height, size_t skip_frames) override;
+    std::optional<double> get_framerate() const override { return fps_; }
+    std::optional<std::pair<size_t, size_t>> get_aspect() const override { return std::make_pair(w_, h_); }
+    std::vector<std::pair<std::string, PropertyMut>> props_mut() override;
+private:
+    HipContext ctx_;
+    std::unique_ptr<std::istream> in_;
+    size_t w_, h_, max_w_ = 150, max_h_ = 150, levels_ = 3, radius_ = 4, iters_ = 3;
+    std::optional<double> fps_;
+    std::vector<uint8_t> prev_, cur_;
+    std::vector<float> out_;
+    bool have_prev_ = false;
+};
+
 // MvecFile of motion-loader/src/lib.rs:31-83 (pure host I/O, no GPU)
 class MvecFileDecoder : public Decoder {
 public:
@@ -173,7 +192,7 @@ private:
 };
 
 // ---- creation by name (the part of PluginStore the hot path needs: ofps/src/plugins/mod.rs:396-453)
-std::unique_ptr<Decoder> create_decoder(const std::string& name, const std::string& arg);    // "hip_sad", "mvec"
+std::unique_ptr<Decoder> create_decoder(const std::string& name, const std::string& arg);    // "hip_sad", "hip_lk", "mvec"
 std::unique_ptr<Detector> create_detector(const std::string& name, const std::string& arg);  // "hip_block_motion"
 std::unique_ptr<Estimator> create_estimator(const std::string& name, const std::string& arg);// "hip_almeida"
 

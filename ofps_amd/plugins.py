@@ -111,6 +111,33 @@ class HipSadDecoder(Properties):
         return None if self._cur is None else (self._cur.shape[1], self._cur.shape[0])
 
 
+class HipLkDecoder(HipSadDecoder):
+    """Decoder producing dense per-pixel flow the way cv-decoder does in full-resolution mode
+    (cv-decoder/src/lib.rs:82-294): records down-sampled through the densifier to the (Width, Height)-capped grid."""
+    _PROPS = (("Width", "usize", "max_w", 1, 2000), ("Height", "usize", "max_h", 1, 2000),
+              ("Pyramid levels", "usize", "levels", 1, 8), ("Window radius", "usize", "radius", 1, 15),
+              ("Iterations", "usize", "iters", 1, 64))
+
+    def __init__(self, frames, framerate=None, device: int = 0):
+        super().__init__(frames, framerate, device)
+        self.max_w, self.max_h, self.levels, self.radius, self.iters = 150, 150, 3, 4, 3
+
+    def process_frame(self, field: list, out_frame=None, skip_frames: int = 0) -> bool:
+        for _ in range(skip_frames + 1):
+            self._prev = self._cur
+            try:
+                self._cur = np.ascontiguousarray(next(self._it), np.uint8)
+            except StopIteration:
+                raise EOFError("failed to grab frame") from None
+        if out_frame is not None:
+            out_frame[:] = [self._cur]
+        if self._prev is None or self._prev.shape != self._cur.shape:
+            return False
+        ent, _ = self.ctx.lk_decode(self._prev, self._cur, self.levels, self.radius, self.iters, self.max_w, self.max_h)
+        field.extend(ent)
+        return True
+
+
 class HipBlockMotionDetection(Properties):
     """Detector (ofps/src/detection.rs:11; block-motion-detector/src/lib.rs:13-46)."""
     _PROPS = (("Min size", "float", "min_size", 0.01, 1.0), ("Subdivisions", "usize", "subdivide", 1, 16),

@@ -109,6 +109,17 @@ class HipContext:
                                                iters, _fp(flow), _fp(ent) if want_entries else None))
         return (flow, ent) if want_entries else flow
 
+    def lk_decode(self, prev: np.ndarray, cur: np.ndarray, levels=3, radius=4, iters=3, max_w=150, max_h=150):
+        """-> (entries[n,4], (grid_w, grid_h)): what a hip_lk Decoder appends per frame (cv-decoder full-res mode)."""
+        prev = np.ascontiguousarray(prev, np.uint8); cur = np.ascontiguousarray(cur, np.uint8)
+        H, W = prev.shape
+        out = np.zeros((min(max_w, W) * min(max_h, H), 4), np.float32)
+        n = C.c_size_t(0); gw = C.c_int(0); gh = C.c_int(0)
+        u8 = C.POINTER(C.c_uint8)
+        self._check(self._lib.ofps_hip_lk_decode(self._h, prev.ctypes.data_as(u8), cur.ctypes.data_as(u8), W, H, W, levels, radius,
+                                                 iters, max_w, max_h, _fp(out), C.byref(n), C.byref(gw), C.byref(gh)))
+        return out[:n.value].copy(), (gw.value, gh.value)
+
     def lk_flow_dev(self, d_prev: int, d_cur: int, W: int, H: int, stride: int, levels: int, radius: int, iters: int,
                     d_out_flow: int | None, d_out_entries: int | None):
         self._check(self._lib.ofps_hip_lk_flow_dev(self._h, C.c_void_p(d_prev), C.c_void_p(d_cur), W, H, stride, levels, radius,

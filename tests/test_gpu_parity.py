@@ -429,3 +429,17 @@ def test_degenerate_geometries_and_bad_arguments(ctx):
         ctx.set_sad_mode(7)
     # the context stays usable after errors
     assert ctx.densify(e, 4, 4).shape == (4, 4, 2)
+
+
+def test_lk_decode_matches_cv_decoder_output_stage(ctx):
+    """hip_lk process_frame body: flow -> records -> densifier down-sampling to the capped grid (150x150 -> 150x84
+    at 16:9, cv-decoder/src/lib.rs:98-121) -> visited cells in (x,y) order; equals the oracle stage by stage."""
+    fr = synth.luma_sequence(2, 480, 270, max_step=2, seed=9)
+    ent, (gw, gh) = ctx.lk_decode(fr[0], fr[1])
+    assert (gw, gh) == (150, 84)
+    e_o = oracle.densify_to_entries(oracle.flow_to_entries(oracle.lk_flow(fr[0], fr[1], 3, 4, 3)), 150, 84)
+    np.testing.assert_array_equal(ent.view(np.uint32), e_o.view(np.uint32))
+    # small frame: the cap is the frame itself (min(w, cols), min(h, rows))
+    fr = synth.luma_sequence(2, 96, 64, max_step=1, seed=2)
+    ent, (gw, gh) = ctx.lk_decode(fr[0], fr[1])
+    assert (gw, gh) == (96, 64) and len(ent) == 96 * 64

@@ -95,3 +95,19 @@ def test_extract_detect_track_through_cpp_host(tmp_path):
             rot = qmul(oracle.solve_ypr_given(e, cam).astype(np.float64), rot)  # rot = r * rot
         got = np.array([float(x) for x in csv[k + 1].split(",")[1:5]])
         np.testing.assert_allclose(got, rot, atol=2e-5)
+
+
+@pytest.mark.gpu
+def test_hip_lk_decoder_through_cpp_host(tmp_path):
+    import oracle
+    W, H, F = 320, 180, 3
+    fr = synth.luma_sequence(F, W, H, max_step=2, seed=4)
+    raw = tmp_path / "clip.y"
+    raw.write_bytes(fr.tobytes())
+    out = tmp_path / "clip_lk.mvec"
+    info = json.loads(_tool("extract", "hip_lk", f"{raw}?w={W}&h={H}", out))
+    frames = list(mvec.read_frames(open(out, "rb")))
+    assert info["frames"] == F and len(frames[0]) == 0
+    for k in range(1, F):
+        e_o = oracle.densify_to_entries(oracle.flow_to_entries(oracle.lk_flow(fr[k - 1], fr[k], 3, 4, 3)), 150, 84)
+        np.testing.assert_array_equal(frames[k].view(np.uint32), e_o.view(np.uint32))
