@@ -12,6 +12,22 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """Build the in-tree artefacts when they are missing or stale (hipcc cross-compiles without a GPU);
+    the tests themselves still fail loudly if the HIP library cannot be loaded."""
+    try:
+        from ofps_amd import build as hip_build
+        hip_build.build()
+        hip_build.build_host()
+    except Exception as e:          # no hipcc on this machine: leave it to the tests to report what is missing
+        print(f"[conftest] HIP build skipped: {e}", file=sys.stderr)
+    try:
+        import oracle
+        oracle.build()
+    except Exception as e:
+        print(f"[conftest] oracle build skipped: {e}", file=sys.stderr)
+
+
 def _have_gpu() -> bool:
     try:
         import torch
