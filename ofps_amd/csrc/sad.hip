@@ -242,7 +242,7 @@ __global__ __launch_bounds__(256) void sad_qsad_kernel(const SadParams p) {
 //   * the odd column dx = +R (2R+1 is never a multiple of 4) is a short second pass: lane = (block,
 //     chunk of KE dy) with v_sad_u8 on dword-aligned window data (R % 4 == 0) -- 4 % extra SAD-unit
 //     time instead of a ninth dx group that wastes 3 of its 4 shifts and one lane in 64;
-//   * lane-local argmin key = SAD<<16 | d2, walked in ascending dy with a strict <: inside one dx group
+//   * lane-local argmin key = SAD<<16 | d2 (dy^2 added to the row minimum), walked in ascending dy with a strict <: inside one dx group
 //     |dx| is distinct, so equal (SAD, d2) in one lane means different dy and the walk keeps the spec's
 //     (SAD, d2, dy, dx) order; masked columns saturate through a clamped add; vertical clipping is a
 //     scalar branch (uniform per strip); a 64-bit key finishes the order across the NG lanes of a block;
@@ -271,30 +271,75 @@ struct StripCfg {
     static_assert(2 * R * R < 65536, "lane key holds d2 in 16 bits");
     // accumulators + current block + ~40 working registers: ask for 3 waves/SIMD (<= 168 VGPRs) when that fits,
     // otherwise hipcc spreads into all 256 registers it is allowed and occupancy drops to 2 for nothing
-    static constexpr int MIN_WAVES = (2 * NCAND + B * BW + 40 <= 168) ? 3 : 2;
+    // dy is walked in SPLIT passes of NP candidates so the packed accumulators never need more than ~66 VGPRs:
+    // +-32 would otherwise hold 130 of them and drop to 2 waves per SIMD.  The window rows are re-read from LDS
+    // (which has bandwidth to spare); staging, the current block and the argmin state are shared by the passes.
+    static constexpr int SPLIT = (NCAND + 32) / 33;
+    static constexpr int NP = (NCAND + SPLIT - 1) / SPLIT;
+    static constexpr int MIN_WAVES = (2 * NP + B * BW + 40 <= 168) ? 3 : 2;
 };
 
-template <int B, int R, int RR>
-__device__ __forceinline__ void strip_row(unsigned long long (&acc)[2 * R + 1], const uint32_t (&c)[B][B / 4],
+template <int B, int R, int I0, int RR>
+__device__ __forceinline__ void strip_row(unsigned long long (&acc)[StripCfg<B, R>::NP], const uint32_t (&c)[B][B / 4],
                                           const uint32_t* trow) {
     using C = StripCfg<B, R>;
     unsigned long long win[C::BW];
 #pragma unroll
-    for (int q = 0; q < C::BW; ++q) win[q] = reinterpret_cast<const U64A4*>(trow + RR * C::SW + q)->v;
+    for (int q = 0; q < C::BW; ++q) win[q] = reinterpret_cast<const U64A4*>(trow + (I0 + RR) * C::SW + q)->v;
 #pragma unroll
-    for (int i = 0; i < C::NCAND; ++i) {
-        const int y = RR - i;
-        if (y >= 0 && y < B) {
+    for (int ii = 0; ii < C::NP; ++ii) {
+        const int y = RR - ii;                                  // window row I0+RR belongs to candidate I0+ii, block row y
+        if (I0 + ii < C::NCAND && y >= 0 && y < B) {
 #pragma unroll
-            for (int q = 0; q < C::BW; ++q) acc[i] = __builtin_amdgcn_qsad_pk_u16_u8(win[q], c[y][q], acc[i]);
+            for (int q = 0; q < C::BW; ++q) acc[ii] = __builtin_amdgcn_qsad_pk_u16_u8(win[q], c[y][q], acc[ii]);
         }
     }
 }
 
-template <int B, int R, int... RR>
-__device__ __forceinline__ void strip_rows(unsigned long long (&acc)[2 * R + 1], const uint32_t (&c)[B][B / 4],
+template <int B, int R, int I0, int... RR>
+__device__ __forceinline__ void strip_rows(unsigned long long (&acc)[StripCfg<B, R>::NP], const uint32_t (&c)[B][B / 4],
                                            const uint32_t* trow, std::integer_sequence<int, RR...>) {
-    (strip_row<B, R, RR>(acc, c, trow), ...);
+    (strip_row<B, R, I0, RR>(acc, c, trow), ...);
+}
+
+// One dy pass: accumulate candidates I0 .. I0+NP-1 and fold them into the lane's running (key, dy index).
+// key = SAD<<16 | dx^2 is minimised over the 4 dx first; dy^2 (a compile-time constant per step) is added to
+// the row minimum afterwards -- adding the same constant to four keys does not change their order, and
+// dx^2 + dy^2 < 65536 cannot carry into the SAD field; a clipped column holds all-ones and the clamped add
+// keeps it saturated.
+template <int B, int R, int I0>
+__device__ __forceinline__ void strip_pass(const uint32_t (&c)[B][B / 4], const uint32_t* trow, const uint32_t (&colk)[4],
+                                           int y0, int H, uint32_t& bkey, int& bi) {
+    using C = StripCfg<B, R>;
+    unsigned long long acc[C::NP];
+#pragma unroll
+    for (int ii = 0; ii < C::NP; ++ii) acc[ii] = 0;
+    constexpr int ROWS = ((I0 + C::NP < C::NCAND ? C::NP : C::NCAND - I0) + B - 1);
+    strip_rows<B, R, I0>(acc, c, trow, std::make_integer_sequence<int, ROWS>{});
+#pragma unroll
+    for (int ii = 0; ii < C::NP; ++ii) asm volatile("" : "+v"(acc[ii]));
+#pragma unroll
+    for (int ii = 0; ii < C::NP; ++ii) {
+        const int i = I0 + ii;
+        const int dy = -R + i;
+        if (i < C::NCAND && y0 + dy >= 0 && y0 + dy + B <= H) {          // uniform over the strip: scalar branch
+            const uint32_t lo = (uint32_t)acc[ii], hi = (uint32_t)(acc[ii] >> 32);
+            const uint32_t k0 = (lo << 16) | colk[0];
+            const uint32_t k1 = (lo & 0xFFFF0000u) | colk[1];
+            const uint32_t k2 = (hi << 16) | colk[2];
+            const uint32_t k3 = (hi & 0xFFFF0000u) | colk[3];
+            const uint32_t m = __builtin_elementwise_add_sat(min(min(k0, k1), min(k2, k3)), (uint32_t)(dy * dy));
+            const bool lt = m < bkey;
+            bkey = lt ? m : bkey;
+            bi = lt ? i : bi;
+        }
+    }
+}
+
+template <int B, int R, int... S>
+__device__ __forceinline__ void strip_passes(const uint32_t (&c)[B][B / 4], const uint32_t* trow, const uint32_t (&colk)[4],
+                                             int y0, int H, uint32_t& bkey, int& bi, std::integer_sequence<int, S...>) {
+    (strip_pass<B, R, S * StripCfg<B, R>::NP>(c, trow, colk, y0, H, bkey, bi), ...);
 }
 
 constexpr int kStripWaves = 4;      // independent waves (strips) per workgroup; no workgroup barrier
@@ -377,18 +422,10 @@ __global__ __launch_bounds__(64 * kStripWaves, (StripCfg<B, R>::MIN_WAVES)) void
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-    // ---- main pass: every lane, all dy, dx = dx0 .. dx0+3.  The row walk is expanded through a template
-    // pack: a plain `#pragma unroll` over TILE_H x NCAND steps exceeds hipcc's unroll budget, which leaves
-    // the row index dynamic and sends the c[][] block to scratch memory.
-    unsigned long long acc[C::NCAND];
-#pragma unroll
-    for (int i = 0; i < C::NCAND; ++i) acc[i] = 0;
-    strip_rows<B, R>(acc, c, tile + b * C::BW + g, std::make_integer_sequence<int, C::TILE_H>{});
-#pragma unroll
-    for (int i = 0; i < C::NCAND; ++i) asm volatile("" : "+v"(acc[i]));
-
-    // ---- lane-local argmin of the main pass.  colk[j] = dx_j^2, or all-ones for a column clipped by the frame
-    // (the clamped add then saturates the whole key).
+    // ---- main pass: every lane, all dy (in SPLIT passes), dx = dx0 .. dx0+3.  The row walk is expanded through
+    // template packs: a plain `#pragma unroll` over TILE_H x NCAND steps exceeds hipcc's unroll budget, which
+    // leaves the row index dynamic and sends the c[][] block to scratch memory.
+    // colk[j] = dx_j^2, or all-ones for a column clipped by the frame.
     const int dx0 = -R + 4 * g;
     uint32_t colk[4];
 #pragma unroll
@@ -400,22 +437,7 @@ __global__ __launch_bounds__(64 * kStripWaves, (StripCfg<B, R>::MIN_WAVES)) void
     }
     uint32_t bkey = 0xFFFFFFFFu;
     int bi = 0;
-#pragma unroll
-    for (int i = 0; i < C::NCAND; ++i) {
-        const int dy = -R + i;
-        if (y0 + dy >= 0 && y0 + dy + B <= p.H) {                 // uniform over the strip: scalar branch
-            const uint32_t rowk = (uint32_t)(dy * dy);            // compile-time constant
-            const uint32_t lo = (uint32_t)acc[i], hi = (uint32_t)(acc[i] >> 32);
-            const uint32_t k0 = (lo << 16) | __builtin_elementwise_add_sat(colk[0], rowk);
-            const uint32_t k1 = (lo & 0xFFFF0000u) | __builtin_elementwise_add_sat(colk[1], rowk);
-            const uint32_t k2 = (hi << 16) | __builtin_elementwise_add_sat(colk[2], rowk);
-            const uint32_t k3 = (hi & 0xFFFF0000u) | __builtin_elementwise_add_sat(colk[3], rowk);
-            const uint32_t m = min(min(k0, k1), min(k2, k3));
-            const bool lt = m < bkey;
-            bkey = lt ? m : bkey;
-            bi = lt ? i : bi;
-        }
-    }
+    strip_passes<B, R>(c, tile + b * C::BW + g, colk, y0, p.H, bkey, bi, std::make_integer_sequence<int, C::SPLIT>{});
     // decode (d2, dy) -> dx; build the cross-lane key (SAD, d2, dy, dx)
     unsigned long long best = ~0ull;
     if (bkey != 0xFFFFFFFFu) {
