@@ -159,7 +159,8 @@ def main():
             except Exception:
                 traffic = None
         out = {
-            "metric": "Mvectors/s, 1080p 16x16 blocks +-16 full-search SAD",
+            "metric": ("Mvectors/s, 1080p 16x16 blocks +-16 full-search SAD" if (W, H, B, R) == (1920, 1080, 16, 16)
+                       else f"Mvectors/s, {W}x{H} {B}x{B} blocks +-{R} full-search SAD"),
             "value": round(vectors_per_step * args.steps / el / 1e6, 3),
             "unit": "Mvectors/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -167,8 +168,10 @@ def main():
             "ms_per_frame_pair": round(ms_per_step / P, 5),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
-            "config": {"workload": f"cfg2: {W}x{H} synthetic luma, {B}x{B} blocks, +-{R} full-search SAD "
-                                   f"(BASELINE.json configs[1])",
+            "config": {"workload": ({(1920, 1080, 16, 16): "cfg2 (BASELINE.json configs[1]): ",
+                                     (3840, 2160, 8, 32): "cfg4 (BASELINE.json configs[3]): ",
+                                     (640, 360, 16, 8): "cfg1 geometry (BASELINE.json configs[0]): "}.get((W, H, B, R), "")
+                                    + f"{W}x{H} synthetic luma, {B}x{B} blocks, +-{R} full-search SAD"),
                        "pairs_per_step": P, "vectors_per_pair": nblk, "parallelism": f"frame-pair sharding x{world}",
                        "kernel": (f"sad_strip_kernel<{B},{R}>" if args.sad_mode == "exhaustive" else "sad_sea_kernel + sad_strip_kernel<16,16> on overflow strips"),
                        "sad_mode": args.sad_mode},
