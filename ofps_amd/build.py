@@ -15,7 +15,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libofps_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
-         "-Wall", "-Wno-unused-function", "-fno-gpu-rdc"]
+         "-Wall", "-Wno-unused-function", "-fno-gpu-rdc"] + os.environ.get("OFPS_HIP_EXTRA_FLAGS", "").split()
 
 
 def sources():

@@ -277,15 +277,34 @@ struct StripCfg {
     static constexpr int SPLIT = (NCAND + 32) / 33;
     static constexpr int NP = (NCAND + SPLIT - 1) / SPLIT;
     static constexpr int MIN_WAVES = (2 * NP + B * BW + 40 <= 168) ? 3 : 2;
+    // small ranges: (d2 << 6 | dy index) fits the low 16 bits of the lane key, so the key alone identifies the
+    // candidate and the scan needs no separate index tracking
+    static constexpr bool COMPACT_KEY = ((2 * R * R) << 6) + NCAND < 65536 && NCAND <= 64;
+    static constexpr int KSHIFT = COMPACT_KEY ? 6 : 0;
+};
+
+// ds_read2_b32 reaches 255 dwords from its base register; left to itself hipcc spends one v_add per read on
+// addresses.  The walk keeps ONE running dword index into the workgroup's LDS array that advances every
+// ROWS_PER_BASE rows and is made opaque to the optimiser, so every read inside a group is base + immediate.
+// (The opaque value is an integer index, not a pointer: hiding a pointer behind inline asm loses its LDS address
+// space and turns every read into a flat load -- measured 30 % slower.)
+template <int B, int R>
+struct StripWalk {
+    static constexpr int ROWS_PER_BASE = (255 - StripCfg<B, R>::BW) / StripCfg<B, R>::SW + 1;
 };
 
 template <int B, int R, int I0, int RR>
 __device__ __forceinline__ void strip_row(unsigned long long (&acc)[StripCfg<B, R>::NP], const uint32_t (&c)[B][B / 4],
-                                          const uint32_t* trow) {
+                                          const uint32_t* lds, uint32_t& base) {
     using C = StripCfg<B, R>;
+    constexpr int G = StripWalk<B, R>::ROWS_PER_BASE;
+    if constexpr (RR > 0 && RR % G == 0) {
+        base += G * C::SW;
+        asm volatile("" : "+v"(base));
+    }
     unsigned long long win[C::BW];
 #pragma unroll
-    for (int q = 0; q < C::BW; ++q) win[q] = reinterpret_cast<const U64A4*>(trow + (I0 + RR) * C::SW + q)->v;
+    for (int q = 0; q < C::BW; ++q) win[q] = reinterpret_cast<const U64A4*>(lds + base + (RR % G) * C::SW + q)->v;
 #pragma unroll
     for (int ii = 0; ii < C::NP; ++ii) {
         const int y = RR - ii;                                  // window row I0+RR belongs to candidate I0+ii, block row y
@@ -296,10 +315,13 @@ __device__ __forceinline__ void strip_row(unsigned long long (&acc)[StripCfg<B, 
     }
 }
 
+// lds: the workgroup's LDS array; tile_off: dword index of this lane's window origin inside it
 template <int B, int R, int I0, int... RR>
 __device__ __forceinline__ void strip_rows(unsigned long long (&acc)[StripCfg<B, R>::NP], const uint32_t (&c)[B][B / 4],
-                                           const uint32_t* trow, std::integer_sequence<int, RR...>) {
-    (strip_row<B, R, I0, RR>(acc, c, trow), ...);
+                                           const uint32_t* lds, uint32_t tile_off, std::integer_sequence<int, RR...>) {
+    uint32_t base = tile_off + I0 * StripCfg<B, R>::SW;
+    asm volatile("" : "+v"(base));
+    (strip_row<B, R, I0, RR>(acc, c, lds, base), ...);
 }
 
 // One dy pass: accumulate candidates I0 .. I0+NP-1 and fold them into the lane's running (key, dy index).
@@ -308,14 +330,14 @@ __device__ __forceinline__ void strip_rows(unsigned long long (&acc)[StripCfg<B,
 // dx^2 + dy^2 < 65536 cannot carry into the SAD field; a clipped column holds all-ones and the clamped add
 // keeps it saturated.
 template <int B, int R, int I0>
-__device__ __forceinline__ void strip_pass(const uint32_t (&c)[B][B / 4], const uint32_t* trow, const uint32_t (&colk)[4],
-                                           int y0, int H, uint32_t& bkey, int& bi) {
+__device__ __forceinline__ void strip_pass(const uint32_t (&c)[B][B / 4], const uint32_t* lds, uint32_t tile_off,
+                                           const uint32_t (&colk)[4], int y0, int H, uint32_t& bkey, int& bi) {
     using C = StripCfg<B, R>;
     unsigned long long acc[C::NP];
 #pragma unroll
     for (int ii = 0; ii < C::NP; ++ii) acc[ii] = 0;
     constexpr int ROWS = ((I0 + C::NP < C::NCAND ? C::NP : C::NCAND - I0) + B - 1);
-    strip_rows<B, R, I0>(acc, c, trow, std::make_integer_sequence<int, ROWS>{});
+    strip_rows<B, R, I0>(acc, c, lds, tile_off, std::make_integer_sequence<int, ROWS>{});
 #pragma unroll
     for (int ii = 0; ii < C::NP; ++ii) asm volatile("" : "+v"(acc[ii]));
 #pragma unroll
@@ -328,18 +350,24 @@ __device__ __forceinline__ void strip_pass(const uint32_t (&c)[B][B / 4], const 
             const uint32_t k1 = (lo & 0xFFFF0000u) | colk[1];
             const uint32_t k2 = (hi << 16) | colk[2];
             const uint32_t k3 = (hi & 0xFFFF0000u) | colk[3];
-            const uint32_t m = __builtin_elementwise_add_sat(min(min(k0, k1), min(k2, k3)), (uint32_t)(dy * dy));
-            const bool lt = m < bkey;
-            bkey = lt ? m : bkey;
-            bi = lt ? i : bi;
+            if constexpr (C::COMPACT_KEY) {
+                const uint32_t m = __builtin_elementwise_add_sat(min(min(k0, k1), min(k2, k3)), (uint32_t)((dy * dy) << 6 | i));
+                bkey = min(bkey, m);            // ascending dy + the dy index inside the key: ties keep the smaller dy
+            } else {
+                const uint32_t m = __builtin_elementwise_add_sat(min(min(k0, k1), min(k2, k3)), (uint32_t)(dy * dy));
+                const bool lt = m < bkey;
+                bkey = lt ? m : bkey;
+                bi = lt ? i : bi;
+            }
         }
     }
 }
 
 template <int B, int R, int... S>
-__device__ __forceinline__ void strip_passes(const uint32_t (&c)[B][B / 4], const uint32_t* trow, const uint32_t (&colk)[4],
-                                             int y0, int H, uint32_t& bkey, int& bi, std::integer_sequence<int, S...>) {
-    (strip_pass<B, R, S * StripCfg<B, R>::NP>(c, trow, colk, y0, H, bkey, bi), ...);
+__device__ __forceinline__ void strip_passes(const uint32_t (&c)[B][B / 4], const uint32_t* lds, uint32_t tile_off,
+                                             const uint32_t (&colk)[4], int y0, int H, uint32_t& bkey, int& bi,
+                                             std::integer_sequence<int, S...>) {
+    (strip_pass<B, R, S * StripCfg<B, R>::NP>(c, lds, tile_off, colk, y0, H, bkey, bi), ...);
 }
 
 constexpr int kStripWaves = 4;      // independent waves (strips) per workgroup; no workgroup barrier
@@ -433,20 +461,24 @@ __global__ __launch_bounds__(64 * kStripWaves, (StripCfg<B, R>::MIN_WAVES)) void
         const int dx = dx0 + j;
         const int x = bx * B + dx;
         const bool v = blk_on && x >= 0 && x + B <= p.W;
-        colk[j] = v ? (uint32_t)(dx * dx) : 0xFFFFFFFFu;
+        colk[j] = v ? (uint32_t)(dx * dx) << C::KSHIFT : 0xFFFFFFFFu;
     }
     uint32_t bkey = 0xFFFFFFFFu;
     int bi = 0;
-    strip_passes<B, R>(c, tile + b * C::BW + g, colk, y0, p.H, bkey, bi, std::make_integer_sequence<int, C::SPLIT>{});
+    strip_passes<B, R>(c, tiles, (uint32_t)(wave * C::TILE_DWORDS + b * C::BW + g), colk, y0, p.H, bkey, bi,
+                       std::make_integer_sequence<int, C::SPLIT>{});
     // decode (d2, dy) -> dx; build the cross-lane key (SAD, d2, dy, dx)
     unsigned long long best = ~0ull;
     if (bkey != 0xFFFFFFFFu) {
+        if constexpr (C::COMPACT_KEY) bi = (int)(bkey & 63u);
         const int dy = -R + bi;
-        const int dxsq = (int)(bkey & 0xFFFFu) - dy * dy;
+        const uint32_t d2 = (bkey & 0xFFFFu) >> C::KSHIFT;
+        const int dxsq = (int)d2 - dy * dy;
         int dx = dx0;
 #pragma unroll
         for (int j = 1; j < 4; ++j) dx = ((dx0 + j) * (dx0 + j) == dxsq) ? dx0 + j : dx;
-        best = ((unsigned long long)bkey << 32) | (unsigned long long)(uint32_t)(((dy + R) << 8) | (dx + R));
+        // cross-lane key in the spec's layout: (SAD << 16 | d2) << 32 | (dy+R) << 8 | (dx+R)
+        best = ((unsigned long long)((bkey & 0xFFFF0000u) | d2) << 32) | (unsigned long long)(uint32_t)(((dy + R) << 8) | (dx + R));
     }
     // ---- dx = +R pass (after the main scan, so acc[] is dead and the wave stays within 168 VGPRs):
     // lane = (block b, dy chunk g): KE consecutive dy, one v_sad_u8 per dword
