@@ -110,12 +110,25 @@ int ofps_hip_sad_flow_dev(ofps_hip_ctx* ctx, const void* d_frames, int n_frames,
  * out_flow: 2*W*H f32 (u,v) or NULL; out_entries: 4*W*H f32 or NULL (at least one of them). */
 int ofps_hip_lk_flow(ofps_hip_ctx* ctx, const uint8_t* prev, const uint8_t* cur, int W, int H, int stride,
                      int levels, int radius, int iters, float* out_flow, float* out_entries);
-/* One Decoder::process_frame of a "hip_lk" plugin in cv-decoder's full-resolution mode
- * (cv-decoder/src/lib.rs:82-294): flow -> per-pixel records -> down-sampled through the densifier to the
- * (max_w, max_h)-capped grid of :98-121 (defaults 150 x 150 -> 150 x 84 at 16:9) -> one record per visited cell in
- * (x, y)-sorted order.  out_entries capacity: 4 * min(max_w,W) * min(max_h,H) floats. */
+/* cv-decoder's contrast mask (cv-decoder/src/lib.rs:203-237): Sobel(gray, CV_32F, 1, 1, ksize 5) -> threshold(> 20)
+ * -> dilate(MORPH_ELLIPSE 11x11); a pixel contributes a record only where the mask is set (:253-257).  Restated
+ * from OpenCV's published definitions (oracle/ofps_oracle.c:orc_contrast_mask; "parity unpinned": OpenCV is not
+ * vendored by the reference).  out_mask: W*H bytes, 1 = keep. */
+int ofps_hip_contrast_mask(ofps_hip_ctx* ctx, const uint8_t* gray, int W, int H, int stride, uint8_t* out_mask);
+int ofps_hip_contrast_mask_dev(ofps_hip_ctx* ctx, const void* d_gray, int W, int H, int stride, void* d_out_mask);
+
+/* ofps_hip_lk_decode flags */
+#define OFPS_HIP_LK_CONTRAST_MASK 1u /* drop records of pixels outside the contrast mask of `cur` (the reference's
+                                        Farneback path always masks, :203-237,253-257) */
+#define OFPS_HIP_LK_PER_PIXEL     2u /* "Process Fullres" = false: one record per (unmasked) pixel in raster order,
+                                        no down-sampling (:274-276); the reference resizes its frames to the capped
+                                        grid before the flow (:124-133), which is the caller's job here */
+/* One Decoder::process_frame of a "hip_lk" plugin (cv-decoder/src/lib.rs:82-294): flow -> per-pixel records
+ * [-> contrast mask] -> down-sampled through the densifier to the (max_w, max_h)-capped grid of :98-121 (defaults
+ * 150 x 150 -> 150 x 84 at 16:9) -> one record per visited cell in (x, y)-sorted order.  out_entries capacity:
+ * 4 * min(max_w,W) * min(max_h,H) floats (4 * W * H with OFPS_HIP_LK_PER_PIXEL).  out_w/out_h: the record grid. */
 int ofps_hip_lk_decode(ofps_hip_ctx* ctx, const uint8_t* prev, const uint8_t* cur, int W, int H, int stride,
-                       int levels, int radius, int iters, int max_w, int max_h,
+                       int levels, int radius, int iters, int max_w, int max_h, unsigned flags,
                        float* out_entries, size_t* n_out, int* out_w, int* out_h);
 int ofps_hip_lk_flow_dev(ofps_hip_ctx* ctx, const void* d_prev, const void* d_cur, int W, int H, int stride,
                          int levels, int radius, int iters, void* d_out_flow, void* d_out_entries);

@@ -27,7 +27,7 @@ struct ofps_hip_ctx {
     // grow-only device scratch owned by the context (staging for host-pointer entry points and
     // kernel workspaces); never shrinks, freed in ofps_hip_destroy.
     struct Scratch { void* p = nullptr; size_t cap = 0; };
-    static constexpr int kNumScratch = 16;
+    static constexpr int kNumScratch = 24;
     Scratch scratch[kNumScratch];
 };
 
@@ -35,7 +35,7 @@ namespace ofps {
 
 enum ScratchSlot {
     S_FRAMES = 0, S_ENTRIES, S_BEST, S_FIELD, S_CELLS, S_WORK0, S_WORK1, S_WORK2, S_WORK3, S_RESULT,
-    S_QUAT, S_WORK4, S_PIPE_FRAMES, S_PIPE_ENTRIES, S_PIPE_OUT
+    S_QUAT, S_WORK4, S_PIPE_FRAMES, S_PIPE_ENTRIES, S_PIPE_OUT, S_MASK, S_ENTRIES2
 };
 
 int set_error(ofps_hip_ctx* ctx, int code, const char* fmt, ...);
@@ -53,6 +53,9 @@ int densify_device_raw(ofps_hip_ctx* ctx, const float4* d_entries, size_t n, int
                        uint32_t* d_cells, uint32_t** out_begin, uint32_t** out_end, float2* d_sum, float* d_cnt);
 int densify_entries_device(ofps_hip_ctx* ctx, const float4* d_entries, size_t n, int w, int h, float2* d_field,
                            float4* d_out_entries, uint32_t* d_count);
+int contrast_mask_device(ofps_hip_ctx* ctx, const uint8_t* d_gray, int W, int H, int stride, uint8_t* d_mask);
+int compact_entries_device(ofps_hip_ctx* ctx, const float4* d_in, const uint8_t* d_mask, size_t n, float4* d_out,
+                           uint32_t* d_count);
 int detect_device(ofps_hip_ctx* ctx, const float4* d_entries, size_t n, int batch, float min_size, size_t subdivide,
                   float target_motion, int* d_result, float2* d_out_field, int* out_dim);
 int almeida_device(ofps_hip_ctx* ctx, const float4* d_entries, size_t n, int batch, float aspect, float fov_y_deg,

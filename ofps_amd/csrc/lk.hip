@@ -384,23 +384,28 @@ int ofps_hip_lk_flow_dev(ofps_hip_ctx* ctx, const void* d_prev, const void* d_cu
     return OFPS_HIP_OK;
 }
 
-// The body of a "hip_lk" Decoder::process_frame in cv-decoder's full-resolution mode (cv-decoder/src/lib.rs:82-294
-// with process_fullres = true): dense flow, per-pixel records, down-sampling through the densifier to the
-// (max_w, max_h)-capped grid of :98-121, one record per visited cell in BTreeSet<(x,y)> order.  Only the
-// down-sampled records leave the device.
+// The body of a "hip_lk" Decoder::process_frame (cv-decoder/src/lib.rs:82-294): dense flow, per-pixel records,
+// optionally filtered by the contrast mask of :203-237 (OFPS_HIP_LK_CONTRAST_MASK, computed on `cur` like the
+// reference's `self.gray`), then either down-sampled through the densifier to the (max_w, max_h)-capped grid of
+// :98-121 with one record per visited cell in BTreeSet<(x,y)> order ("Process Fullres" = true, the default), or
+// returned per pixel in raster order (OFPS_HIP_LK_PER_PIXEL: the `mf.push` branch; the reference resizes its
+// frames to the capped grid first, which is the caller's job here).  Only the final records leave the device.
 int ofps_hip_lk_decode(ofps_hip_ctx* ctx, const uint8_t* prev, const uint8_t* cur, int W, int H, int stride, int levels,
-                       int radius, int iters, int max_w, int max_h, float* out_entries, size_t* n_out, int* out_w,
-                       int* out_h) {
+                       int radius, int iters, int max_w, int max_h, unsigned flags, float* out_entries, size_t* n_out,
+                       int* out_w, int* out_h) {
     if (!ctx) return OFPS_HIP_EINVAL;
     OFPS_REQUIRE(ctx, prev && cur && out_entries && n_out, "lk_decode: null host pointer");
     OFPS_REQUIRE(ctx, W >= 1 && H >= 1 && stride >= W && max_w >= 1 && max_h >= 1, "lk_decode: bad geometry");
+    OFPS_REQUIRE(ctx, (flags & ~(unsigned)(OFPS_HIP_LK_CONTRAST_MASK | OFPS_HIP_LK_PER_PIXEL)) == 0, "lk_decode: unknown flags 0x%x", flags);
     OFPS_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const bool use_mask = flags & OFPS_HIP_LK_CONTRAST_MASK, per_pixel = flags & OFPS_HIP_LK_PER_PIXEL;
     // cv-decoder/src/lib.rs:98-121 with aspect_ratio_scale = (1, 1): usize arithmetic
     const size_t cw = (size_t)(max_w < W ? max_w : W), ch = (size_t)(max_h < H ? max_h : H);
     const size_t wb0 = cw, wb1 = cw * (size_t)H / (size_t)W, hb0 = ch * (size_t)W / (size_t)H, hb1 = ch;
     const int gw = (int)(wb0 < hb0 ? wb0 : hb0), gh = (int)(wb0 < hb0 ? wb1 : hb1);
-    OFPS_REQUIRE(ctx, gw >= 1 && gh >= 1 && (size_t)gw * gh <= 65536, "lk_decode: field %dx%d unsupported", gw, gh);
-    const size_t px = (size_t)W * H, cells = (size_t)gw * gh;
+    if (!per_pixel)
+        OFPS_REQUIRE(ctx, gw >= 1 && gh >= 1 && (size_t)gw * gh <= 65536, "lk_decode: field %dx%d unsupported", gw, gh);
+    const size_t px = (size_t)W * H, cells = per_pixel ? 1 : (size_t)gw * gh;
     auto* d_frames = static_cast<uint8_t*>(ofps::scratch(ctx, ofps::S_FRAMES, 2 * px));
     auto* d_ent = static_cast<float4*>(ofps::scratch(ctx, ofps::S_ENTRIES, px * sizeof(float4)));
     auto* d_field = static_cast<float2*>(ofps::scratch(ctx, ofps::S_FIELD, cells * sizeof(float2)));
@@ -411,15 +416,37 @@ int ofps_hip_lk_decode(ofps_hip_ctx* ctx, const uint8_t* prev, const uint8_t* cu
     OFPS_HIP_TRY(ctx, hipMemcpy2DAsync(d_frames + px, W, cur, stride, W, H, hipMemcpyHostToDevice, ctx->stream));
     int rc = ofps_hip_lk_flow_dev(ctx, d_frames, d_frames + px, W, H, W, levels, radius, iters, nullptr, d_ent);
     if (rc != OFPS_HIP_OK) return rc;
-    rc = ofps::densify_entries_device(ctx, d_ent, px, gw, gh, d_field, d_out, d_cnt);
+    size_t n_rec = px;
+    const float4* d_rec = d_ent;
+    if (use_mask) {
+        auto* d_mask = static_cast<uint8_t*>(ofps::scratch(ctx, ofps::S_MASK, px));
+        auto* d_ent2 = static_cast<float4*>(ofps::scratch(ctx, ofps::S_ENTRIES2, px * sizeof(float4)));
+        if (!d_mask || !d_ent2) return OFPS_HIP_ENOMEM;
+        rc = ofps::contrast_mask_device(ctx, d_frames + px, W, H, W, d_mask);
+        if (rc != OFPS_HIP_OK) return rc;
+        rc = ofps::compact_entries_device(ctx, d_ent, d_mask, px, d_ent2, d_cnt + 1);
+        if (rc != OFPS_HIP_OK) return rc;
+        uint32_t kept = 0;
+        OFPS_HIP_TRY(ctx, hipMemcpyAsync(&kept, d_cnt + 1, sizeof(kept), hipMemcpyDeviceToHost, ctx->stream));
+        OFPS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        n_rec = kept;
+        d_rec = d_ent2;
+    }
+    if (out_w) *out_w = per_pixel ? W : gw;
+    if (out_h) *out_h = per_pixel ? H : gh;
+    if (per_pixel) {
+        if (n_rec) OFPS_HIP_TRY(ctx, hipMemcpyAsync(out_entries, d_rec, n_rec * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
+        OFPS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        *n_out = n_rec;
+        return OFPS_HIP_OK;
+    }
+    rc = ofps::densify_entries_device(ctx, d_rec, n_rec, gw, gh, d_field, d_out, d_cnt);
     if (rc != OFPS_HIP_OK) return rc;
     uint32_t cnt = 0;
     OFPS_HIP_TRY(ctx, hipMemcpyAsync(&cnt, d_cnt, sizeof(cnt), hipMemcpyDeviceToHost, ctx->stream));
     OFPS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (cnt) OFPS_HIP_TRY(ctx, hipMemcpy(out_entries, d_out, (size_t)cnt * sizeof(float4), hipMemcpyDeviceToHost));
     *n_out = cnt;
-    if (out_w) *out_w = gw;
-    if (out_h) *out_h = gh;
     return OFPS_HIP_OK;
 }
 

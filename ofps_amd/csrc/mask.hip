@@ -1,0 +1,204 @@
+// mask.hip -- cv-decoder's contrast mask and the masked per-pixel record loop on gfx950
+// (cv-decoder/src/lib.rs:203-237 mask, :251-276 loop).
+//
+//   Sobel(gray, CV_32F, dx=1, dy=1, ksize 5, BORDER_DEFAULT) -> threshold(> 20) -> dilate(MORPH_ELLIPSE 11x11)
+//
+// The reference gets these from OpenCV (absent here: "parity unpinned"); the definitions restated in
+// oracle/ofps_oracle.c (orc_contrast_mask) are what this kernel reproduces, bit for bit -- every intermediate is
+// a small integer (|Sobel| <= 36*255), so int32 arithmetic equals OpenCV's f32 accumulation exactly.
+//
+// One fused kernel: a workgroup owns a 64x16 tile of mask pixels; it stages the 78x30 luma window (halo 7 =
+// 2 Sobel + 5 dilation) in LDS, runs the separable derivative ([-1,-2,0,2,1] along x, then along y), keeps the
+// thresholded 74x26 window as bytes in LDS and ORs the 89 taps of the ellipse.  HBM traffic: 1.27 B read per
+// pixel (halo) + 1 B written; the kernel is latency-bound at 1080p (2 M pixels, ~20 us).
+//
+// compact_*: order-preserving stream compaction of the per-pixel records by the mask (the reference's raster
+// loop `continue`s on masked pixels, so the surviving records keep raster order -- which is also the order
+// the densifier's f32 sums depend on).  Tile counts -> single-workgroup scan -> scatter with wave ballots.
+#include "common.hpp"
+
+namespace ofps {
+
+constexpr int MT_W = 64, MT_H = 16;            // mask tile
+constexpr int MG_W = MT_W + 14, MG_H = MT_H + 14;   // luma window (halo 7)
+constexpr int MS_W = MT_W + 10, MS_H = MT_H + 10;   // thresholded window (halo 5)
+
+__device__ __forceinline__ int reflect101(int p, int len) {
+    if (len == 1) return 0;
+    while ((unsigned)p >= (unsigned)len) p = p < 0 ? -p : 2 * len - p - 2;
+    return p;
+}
+
+__global__ __launch_bounds__(256) void contrast_mask_kernel(const uint8_t* __restrict__ gray, int W, int H, int stride,
+                                                            uint8_t* __restrict__ mask) {
+    __shared__ uint8_t g[MG_H][MG_W + 2];
+    __shared__ short hx[MG_H][MS_W + 2];
+    __shared__ uint8_t thr[MS_H][MS_W + 2];
+    const int tid = threadIdx.x;
+    const int x0 = blockIdx.x * MT_W, y0 = blockIdx.y * MT_H;
+    // luma window; coordinates outside the image follow BORDER_REFLECT_101 (only consumed by Sobel taps of
+    // in-image pixels: out-of-image thresholded pixels are forced to 0 below)
+    for (int i = tid; i < MG_H * MG_W; i += 256) {
+        const int r = i / MG_W, c = i - r * MG_W;
+        const int yy = reflect101(y0 - 7 + r, H), xx = reflect101(x0 - 7 + c, W);
+        g[r][c] = gray[(size_t)yy * stride + xx];
+    }
+    __syncthreads();
+    // d/dx: hx(r, c) for the thresholded window's columns (window col c <-> luma col c + 2)
+    for (int i = tid; i < MG_H * MS_W; i += 256) {
+        const int r = i / MS_W, c = i - r * MS_W;
+        hx[r][c] = (short)(-(int)g[r][c] - 2 * (int)g[r][c + 1] + 2 * (int)g[r][c + 3] + (int)g[r][c + 4]);
+    }
+    __syncthreads();
+    // d/dy + threshold; pixels outside the image never win the dilation's max
+    for (int i = tid; i < MS_H * MS_W; i += 256) {
+        const int r = i / MS_W, c = i - r * MS_W;
+        const int s = -(int)hx[r][c] - 2 * (int)hx[r + 1][c] + 2 * (int)hx[r + 3][c] + (int)hx[r + 4][c];
+        const int yy = y0 - 5 + r, xx = x0 - 5 + c;
+        thr[r][c] = (s > 20 && yy >= 0 && yy < H && xx >= 0 && xx < W) ? 1 : 0;
+    }
+    __syncthreads();
+    // ellipse rows: half-width cvRound(5*sqrt(1 - dy^2/25)) for dy = -5..5
+    constexpr int HW[11] = {0, 3, 4, 5, 5, 5, 5, 5, 4, 3, 0};
+    const int lx = tid & 63;
+#pragma unroll
+    for (int k = 0; k < MT_H / 4; ++k) {
+        const int ly = (tid >> 6) + 4 * k;
+        unsigned m = 0;
+#pragma unroll
+        for (int i = 0; i < 11; ++i)
+#pragma unroll
+            for (int d = -HW[i]; d <= HW[i]; ++d) m |= thr[ly + i][lx + 5 + d];
+        const int x = x0 + lx, y = y0 + ly;
+        if (x < W && y < H) mask[(size_t)y * W + x] = (uint8_t)m;
+    }
+}
+
+// ---- ordered compaction of 16-byte records by a byte mask ------------------------------------------------
+constexpr int CT = 1024;          // records per tile (256 threads x 4 consecutive records)
+
+__global__ __launch_bounds__(256) void compact_count_kernel(const uint8_t* __restrict__ mask, size_t n,
+                                                            uint32_t* __restrict__ tile_cnt) {
+    __shared__ uint32_t wsum[4];
+    const size_t base = (size_t)blockIdx.x * CT + (size_t)threadIdx.x * 4;
+    uint32_t c = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) c += (base + k < n && mask[base + k]) ? 1u : 0u;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) c += __shfl_xor(c, m, 64);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) tile_cnt[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+// exclusive scan of the tile counts in place; total -> *out_count
+__global__ __launch_bounds__(1024) void compact_scan_kernel(uint32_t* __restrict__ tile_cnt, int ntiles,
+                                                            uint32_t* __restrict__ out_count) {
+    __shared__ uint32_t wtot[16];
+    __shared__ uint32_t carry;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (int t0 = 0; t0 < ntiles; t0 += 1024) {
+        const int t = t0 + tid;
+        const uint32_t v = t < ntiles ? tile_cnt[t] : 0u;
+        uint32_t inc = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = __shfl_up(inc, d, 64);
+            if (lane >= d) inc += o;
+        }
+        if (lane == 63) wtot[wave] = inc;
+        __syncthreads();
+        uint32_t woff = 0;
+        for (int k = 0; k < wave; ++k) woff += wtot[k];
+        const uint32_t c0 = carry;
+        if (t < ntiles) tile_cnt[t] = c0 + woff + inc - v;
+        __syncthreads();
+        if (tid == 1023) carry = c0 + woff + inc;
+        __syncthreads();
+    }
+    if (tid == 0) *out_count = carry;
+}
+
+__global__ __launch_bounds__(256) void compact_scatter_kernel(const float4* __restrict__ in, const uint8_t* __restrict__ mask,
+                                                              size_t n, const uint32_t* __restrict__ tile_off,
+                                                              float4* __restrict__ out) {
+    __shared__ uint32_t wsum[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const size_t base = (size_t)blockIdx.x * CT + (size_t)tid * 4;
+    bool keep[4];
+    uint32_t c = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { keep[k] = base + k < n && mask[base + k]; c += keep[k] ? 1u : 0u; }
+    uint32_t inc = c;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += o;
+    }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    uint32_t pos = tile_off[blockIdx.x] + inc - c;
+    for (int k = 0; k < wave; ++k) pos += wsum[k];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (keep[k]) out[pos++] = in[base + k];
+}
+
+int contrast_mask_device(ofps_hip_ctx* ctx, const uint8_t* d_gray, int W, int H, int stride, uint8_t* d_mask) {
+    OFPS_REQUIRE(ctx, W >= 1 && H >= 1 && stride >= W, "contrast_mask: bad geometry W=%d H=%d stride=%d", W, H, stride);
+    hipLaunchKernelGGL(contrast_mask_kernel, dim3((W + MT_W - 1) / MT_W, (H + MT_H - 1) / MT_H), dim3(256), 0, ctx->stream,
+                       d_gray, W, H, stride, d_mask);
+    OFPS_HIP_TRY(ctx, hipGetLastError());
+    return OFPS_HIP_OK;
+}
+
+// d_out may not alias d_in.  d_count: one uint32 on the device.  Uses S_WORK0 for the tile table.
+int compact_entries_device(ofps_hip_ctx* ctx, const float4* d_in, const uint8_t* d_mask, size_t n, float4* d_out,
+                           uint32_t* d_count) {
+    OFPS_REQUIRE(ctx, n < (1ull << 31), "compact: too many records");
+    hipStream_t s = ctx->stream;
+    if (n == 0) {
+        OFPS_HIP_TRY(ctx, hipMemsetAsync(d_count, 0, sizeof(uint32_t), s));
+        return OFPS_HIP_OK;
+    }
+    const int ntiles = (int)((n + CT - 1) / CT);
+    auto* tiles = static_cast<uint32_t*>(scratch(ctx, S_WORK0, (size_t)ntiles * sizeof(uint32_t)));
+    if (!tiles) return OFPS_HIP_ENOMEM;
+    hipLaunchKernelGGL(compact_count_kernel, dim3(ntiles), dim3(256), 0, s, d_mask, n, tiles);
+    hipLaunchKernelGGL(compact_scan_kernel, dim3(1), dim3(1024), 0, s, tiles, ntiles, d_count);
+    hipLaunchKernelGGL(compact_scatter_kernel, dim3(ntiles), dim3(256), 0, s, d_in, d_mask, n, tiles, d_out);
+    OFPS_HIP_TRY(ctx, hipGetLastError());
+    return OFPS_HIP_OK;
+}
+
+}  // namespace ofps
+
+extern "C" {
+
+int ofps_hip_contrast_mask_dev(ofps_hip_ctx* ctx, const void* d_gray, int W, int H, int stride, void* d_out_mask) {
+    if (!ctx) return OFPS_HIP_EINVAL;
+    OFPS_REQUIRE(ctx, d_gray && d_out_mask, "contrast_mask_dev: null device pointer");
+    OFPS_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return ofps::contrast_mask_device(ctx, static_cast<const uint8_t*>(d_gray), W, H, stride, static_cast<uint8_t*>(d_out_mask));
+}
+
+int ofps_hip_contrast_mask(ofps_hip_ctx* ctx, const uint8_t* gray, int W, int H, int stride, uint8_t* out_mask) {
+    if (!ctx) return OFPS_HIP_EINVAL;
+    OFPS_REQUIRE(ctx, gray && out_mask, "contrast_mask: null host pointer");
+    OFPS_REQUIRE(ctx, W >= 1 && H >= 1 && stride >= W, "contrast_mask: bad geometry W=%d H=%d stride=%d", W, H, stride);
+    OFPS_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t px = (size_t)W * H;
+    auto* d_gray = static_cast<uint8_t*>(ofps::scratch(ctx, ofps::S_FRAMES, px));
+    auto* d_mask = static_cast<uint8_t*>(ofps::scratch(ctx, ofps::S_MASK, px));
+    if (!d_gray || !d_mask) return OFPS_HIP_ENOMEM;
+    OFPS_HIP_TRY(ctx, hipMemcpy2DAsync(d_gray, W, gray, stride, W, H, hipMemcpyHostToDevice, ctx->stream));
+    int rc = ofps::contrast_mask_device(ctx, d_gray, W, H, W, d_mask);
+    if (rc != OFPS_HIP_OK) return rc;
+    OFPS_HIP_TRY(ctx, hipMemcpyAsync(out_mask, d_mask, px, hipMemcpyDeviceToHost, ctx->stream));
+    OFPS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return OFPS_HIP_OK;
+}
+
+}  // extern "C"

@@ -152,10 +152,11 @@ bool HipLkDecoder::process_frame(MotionVectors& field, std::vector<RGBA>* out_fr
     const bool had_prev = have_prev_;
     have_prev_ = true;
     if (!had_prev) return false;                                      // :156-158
-    out_.resize(4 * std::min(max_w_, w_) * std::min(max_h_, h_));
+    out_.resize(process_fullres_ ? 4 * std::min(max_w_, w_) * std::min(max_h_, h_) : 4 * w_ * h_);
     size_t n_out = 0;
+    const unsigned flags = (contrast_mask_ ? OFPS_HIP_LK_CONTRAST_MASK : 0u) | (process_fullres_ ? 0u : OFPS_HIP_LK_PER_PIXEL);
     ctx_.check(ofps_hip_lk_decode(ctx_.get(), prev_.data(), cur_.data(), (int)w_, (int)h_, (int)w_, (int)levels_, (int)radius_,
-                                  (int)iters_, (int)max_w_, (int)max_h_, out_.data(), &n_out, nullptr, nullptr));
+                                  (int)iters_, (int)max_w_, (int)max_h_, flags, out_.data(), &n_out, nullptr, nullptr));
     const size_t base = field.size();
     field.resize(base + n_out);
     std::memcpy(field.data() + base, out_.data(), n_out * sizeof(MotionEntry));
@@ -165,7 +166,8 @@ bool HipLkDecoder::process_frame(MotionVectors& field, std::vector<RGBA>* out_fr
 std::vector<std::pair<std::string, PropertyMut>> HipLkDecoder::props_mut() {   // cv-decoder/src/lib.rs:35-52 + the LK knobs
     return {{"Width", PropertyMut::usize(&max_w_, 1, 2000)}, {"Height", PropertyMut::usize(&max_h_, 1, 2000)},
             {"Pyramid levels", PropertyMut::usize(&levels_, 1, 8)}, {"Window radius", PropertyMut::usize(&radius_, 1, 15)},
-            {"Iterations", PropertyMut::usize(&iters_, 1, 64)}};
+            {"Iterations", PropertyMut::usize(&iters_, 1, 64)}, {"Contrast mask", PropertyMut::boolean(&contrast_mask_)},
+            {"Process Fullres", PropertyMut::boolean(&process_fullres_)}};
 }
 
 // ------------------------------------------------------------------ .mvec

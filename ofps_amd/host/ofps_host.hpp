@@ -150,6 +150,7 @@ private:
     HipContext ctx_;
     std::unique_ptr<std::istream> in_;
     size_t w_, h_, max_w_ = 150, max_h_ = 150, levels_ = 3, radius_ = 4, iters_ = 3;
+    bool contrast_mask_ = true, process_fullres_ = true;            // cv-decoder: the Farneback path always masks (:203-237)
     std::optional<double> fps_;
     std::vector<uint8_t> prev_, cur_;
     std::vector<float> out_;

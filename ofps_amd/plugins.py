@@ -116,11 +116,13 @@ class HipLkDecoder(HipSadDecoder):
     (cv-decoder/src/lib.rs:82-294): records down-sampled through the densifier to the (Width, Height)-capped grid."""
     _PROPS = (("Width", "usize", "max_w", 1, 2000), ("Height", "usize", "max_h", 1, 2000),
               ("Pyramid levels", "usize", "levels", 1, 8), ("Window radius", "usize", "radius", 1, 15),
-              ("Iterations", "usize", "iters", 1, 64))
+              ("Iterations", "usize", "iters", 1, 64), ("Contrast mask", "bool", "contrast_mask", None, None),
+              ("Process Fullres", "bool", "process_fullres", None, None))
 
     def __init__(self, frames, framerate=None, device: int = 0):
         super().__init__(frames, framerate, device)
         self.max_w, self.max_h, self.levels, self.radius, self.iters = 150, 150, 3, 4, 3
+        self.contrast_mask, self.process_fullres = True, True          # cv-decoder's Farneback path always masks
 
     def process_frame(self, field: list, out_frame=None, skip_frames: int = 0) -> bool:
         for _ in range(skip_frames + 1):
@@ -133,7 +135,8 @@ class HipLkDecoder(HipSadDecoder):
             out_frame[:] = [self._cur]
         if self._prev is None or self._prev.shape != self._cur.shape:
             return False
-        ent, _ = self.ctx.lk_decode(self._prev, self._cur, self.levels, self.radius, self.iters, self.max_w, self.max_h)
+        ent, _ = self.ctx.lk_decode(self._prev, self._cur, self.levels, self.radius, self.iters, self.max_w, self.max_h,
+                                    contrast_mask=self.contrast_mask, per_pixel=not self.process_fullres)
         field.extend(ent)
         return True
 

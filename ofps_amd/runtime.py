@@ -109,16 +109,32 @@ class HipContext:
                                                iters, _fp(flow), _fp(ent) if want_entries else None))
         return (flow, ent) if want_entries else flow
 
-    def lk_decode(self, prev: np.ndarray, cur: np.ndarray, levels=3, radius=4, iters=3, max_w=150, max_h=150):
-        """-> (entries[n,4], (grid_w, grid_h)): what a hip_lk Decoder appends per frame (cv-decoder full-res mode)."""
+    LK_CONTRAST_MASK, LK_PER_PIXEL = 1, 2
+
+    def lk_decode(self, prev: np.ndarray, cur: np.ndarray, levels=3, radius=4, iters=3, max_w=150, max_h=150,
+                  contrast_mask=False, per_pixel=False):
+        """-> (entries[n,4], (grid_w, grid_h)): what a hip_lk Decoder appends per frame (cv-decoder/src/lib.rs:82-294)."""
         prev = np.ascontiguousarray(prev, np.uint8); cur = np.ascontiguousarray(cur, np.uint8)
         H, W = prev.shape
-        out = np.zeros((min(max_w, W) * min(max_h, H), 4), np.float32)
+        out = np.zeros((W * H if per_pixel else min(max_w, W) * min(max_h, H), 4), np.float32)
         n = C.c_size_t(0); gw = C.c_int(0); gh = C.c_int(0)
         u8 = C.POINTER(C.c_uint8)
+        flags = (self.LK_CONTRAST_MASK if contrast_mask else 0) | (self.LK_PER_PIXEL if per_pixel else 0)
         self._check(self._lib.ofps_hip_lk_decode(self._h, prev.ctypes.data_as(u8), cur.ctypes.data_as(u8), W, H, W, levels, radius,
-                                                 iters, max_w, max_h, _fp(out), C.byref(n), C.byref(gw), C.byref(gh)))
+                                                 iters, max_w, max_h, flags, _fp(out), C.byref(n), C.byref(gw), C.byref(gh)))
         return out[:n.value].copy(), (gw.value, gh.value)
+
+    def contrast_mask(self, gray: np.ndarray) -> np.ndarray:
+        """cv-decoder's Sobel/threshold/dilate mask (cv-decoder/src/lib.rs:203-237) -> u8[H, W], 1 = keep."""
+        g = np.ascontiguousarray(gray, np.uint8)
+        H, W = g.shape
+        out = np.zeros((H, W), np.uint8)
+        u8 = C.POINTER(C.c_uint8)
+        self._check(self._lib.ofps_hip_contrast_mask(self._h, g.ctypes.data_as(u8), W, H, W, out.ctypes.data_as(u8)))
+        return out
+
+    def contrast_mask_dev(self, d_gray: int, W: int, H: int, stride: int, d_out_mask: int):
+        self._check(self._lib.ofps_hip_contrast_mask_dev(self._h, C.c_void_p(d_gray), W, H, stride, C.c_void_p(d_out_mask)))
 
     def lk_flow_dev(self, d_prev: int, d_cur: int, W: int, H: int, stride: int, levels: int, radius: int, iters: int,
                     d_out_flow: int | None, d_out_entries: int | None):

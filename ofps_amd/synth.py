@@ -87,6 +87,19 @@ def luma_sequence(n_frames: int, width: int, height: int, max_step: int, seed: i
     return out
 
 
+def flatten_regions(frames: np.ndarray, region: int = 40, seed: int = SEED0, keep: int = 2) -> np.ndarray:
+    """Copy of `frames` with about (keep-1)/keep of the region x region squares painted a flat grey: low-contrast
+    areas for cv-decoder's Sobel mask (cv-decoder/src/lib.rs:203-237) to reject."""
+    out = np.array(frames, np.uint8, copy=True)
+    h, w = out.shape[-2:]
+    yy, xx = np.meshgrid(np.arange(h, dtype=np.uint32), np.arange(w, dtype=np.uint32), indexing="ij")
+    with np.errstate(over="ignore"):
+        hid = _hash_u32((yy // np.uint32(region)) * np.uint32(7919) + (xx // np.uint32(region)) + np.uint32(seed & 0xFFFFFFFF))
+    flat = (hid % np.uint32(keep)) != 0
+    out[..., flat] = 128
+    return out
+
+
 def random_luma(n_frames: int, width: int, height: int, seed: int = SEED0) -> np.ndarray:
     """Unstructured uint8 noise frames (worst case for SAD ties: many near-equal costs)."""
     idx = np.arange(n_frames * height * width, dtype=np.uint32)

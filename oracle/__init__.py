@@ -80,6 +80,9 @@ def lib():
                                   C.c_int, fp]
         L.orc_lk_flow.restype = C.c_int
         L.orc_flow_to_entries.argtypes = [fp, C.c_int, C.c_int, fp]
+        L.orc_contrast_mask.argtypes = [C.POINTER(C.c_uint8), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint8)]
+        L.orc_masked_flow_to_entries.argtypes = [fp, C.POINTER(C.c_uint8), C.c_int, C.c_int, fp]
+        L.orc_masked_flow_to_entries.restype = C.c_size_t
         L.orc_num_threads.restype = C.c_int
         _lib = L
     return _lib
@@ -262,6 +265,23 @@ def flow_to_entries(flow) -> np.ndarray:
     out = np.zeros((H * W, 4), np.float32)
     lib().orc_flow_to_entries(_fp(f), W, H, _fp(out))
     return out
+
+
+def contrast_mask(gray) -> np.ndarray:
+    """cv-decoder's Sobel/threshold/dilate mask (cv-decoder/src/lib.rs:203-237) -> u8[H, W], 1 = keep"""
+    g = np.ascontiguousarray(gray, np.uint8); H, W = g.shape
+    out = np.zeros((H, W), np.uint8)
+    u8 = C.POINTER(C.c_uint8)
+    lib().orc_contrast_mask(g.ctypes.data_as(u8), W, H, W, out.ctypes.data_as(u8))
+    return out
+
+
+def masked_flow_to_entries(flow, mask=None) -> np.ndarray:
+    f = _f32(flow); H, W = f.shape[:2]
+    out = np.zeros((H * W, 4), np.float32)
+    m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+    n = lib().orc_masked_flow_to_entries(_fp(f), None if m is None else m.ctypes.data_as(C.POINTER(C.c_uint8)), W, H, _fp(out))
+    return out[:n].copy()
 
 
 def num_threads() -> int:

@@ -206,3 +206,32 @@ def sad_flow(prev, cur, B, R):
                     if bk is None or key < bk:
                         bk = key; best[by * nbx + bx] = (dx, dy, sad)
     return best
+
+
+def contrast_mask(gray):
+    """Second restatement of cv-decoder's contrast mask (cv-decoder/src/lib.rs:203-237) from OpenCV's published
+    definitions: Sobel(dx=1, dy=1, ksize 5) = separable [-1,-2,0,2,1] x [-1,-2,0,2,1] with BORDER_REFLECT_101,
+    `> 20`, dilation by the 11x11 MORPH_ELLIPSE element (row half-widths cvRound(5*sqrt(1 - dy^2/25)))."""
+    g = np.asarray(gray, np.uint8).astype(np.int64)
+    H, W = g.shape
+    k = np.array([-1, -2, 0, 2, 1], np.int64)
+    # reflect101 with repeated reflection for tiny images
+    def idx(n, lo, hi):
+        i = np.arange(lo, hi)
+        if n == 1:
+            return np.zeros_like(i)
+        period = 2 * n - 2
+        i = np.mod(i, period)
+        return np.where(i >= n, period - i, i)
+    gp = g[idx(H, -2, H + 2)][:, idx(W, -2, W + 2)]
+    hx = sum(k[j] * gp[:, j:j + W] for j in range(5))
+    s = sum(k[i] * hx[i:i + H, :] for i in range(5))
+    thr = (s > 20)
+    hw = [int(np.rint(5.0 * np.sqrt((25.0 - dy * dy) / 25.0))) for dy in range(-5, 6)]
+    tp = np.zeros((H + 10, W + 10), bool)
+    tp[5:5 + H, 5:5 + W] = thr
+    out = np.zeros((H, W), bool)
+    for i, dy in enumerate(range(-5, 6)):
+        for dx in range(-hw[i], hw[i] + 1):
+            out |= tp[5 + dy:5 + dy + H, 5 + dx:5 + dx + W]
+    return out.astype(np.uint8)

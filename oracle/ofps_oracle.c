@@ -759,6 +759,70 @@ size_t orc_sad_flow_ex(const uint8_t* prev, const uint8_t* cur, int W, int H, in
     return (size_t)nbx * (size_t)nby;
 }
 
+/* ---- cv-decoder's contrast mask (cv-decoder/src/lib.rs:203-237) --------------------------------------------
+ * Sobel(gray, CV_32F, dx=1, dy=1, ksize=5, scale 1, delta 0, BORDER_DEFAULT) -> threshold(> 20 -> 255, else 0)
+ * -> dilate(getStructuringElement(MORPH_ELLIPSE, 11x11, anchor (5,5)), 1 iteration, default border value).
+ * OpenCV itself is not under /root/reference and not installed ("parity unpinned"); this restates its
+ * published definitions: getDerivKernels(ksize 5): order-1 taps [-1,-2,0,2,1] on both axes for dx=dy=1,
+ * applied as a correlation; BORDER_DEFAULT = BORDER_REFLECT_101 (gfedcb|abcdefgh|gfedcba); the ellipse rows
+ * are j in [c-dx, c+dx] with dx = cvRound(c*sqrt((r*r-dy*dy)/(r*r))), r = c = 5; dilation's default border value
+ * makes out-of-image taps never win the max.  All sums are integers < 2^24, exact in f32, so the mask is
+ * integer-exact by definition.  out_mask: W bytes per row (1 = keep the pixel: `mask >= 0.1`, lib.rs:253-257). */
+static int orc_reflect101(int p, int len) {
+    if (len == 1) return 0;
+    while ((unsigned)p >= (unsigned)len) p = p < 0 ? -p : 2 * len - p - 2;
+    return p;
+}
+
+void orc_contrast_mask(const uint8_t* gray, int W, int H, int stride, uint8_t* out_mask) {
+    static const int K[5] = {-1, -2, 0, 2, 1};
+    int hw[11];
+    for (int i = 0; i < 11; ++i) {
+        int dy = i - 5;
+        hw[i] = (int)lrint(5.0 * sqrt((25.0 - (double)(dy * dy)) * (1.0 / 25.0)));
+    }
+    uint8_t* thr = (uint8_t*)malloc((size_t)W * H + 1);
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+            float acc = 0.0f;                                        /* CV_32F accumulation; exact integers */
+            for (int i = 0; i < 5; ++i) {
+                const uint8_t* row = gray + (size_t)orc_reflect101(y + i - 2, H) * stride;
+                for (int j = 0; j < 5; ++j)
+                    acc += (float)(K[i] * K[j]) * (float)row[orc_reflect101(x + j - 2, W)];
+            }
+            thr[(size_t)y * W + x] = acc > 20.0f ? 255 : 0;          /* THRESH_BINARY */
+        }
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+            int m = 0;
+            for (int i = 0; i < 11 && !m; ++i) {
+                int yy = y + i - 5;
+                if (yy < 0 || yy >= H) continue;
+                for (int xx = x - hw[i]; xx <= x + hw[i]; ++xx)
+                    if (xx >= 0 && xx < W && thr[(size_t)yy * W + xx]) { m = 1; break; }
+            }
+            out_mask[(size_t)y * W + x] = (uint8_t)m;
+        }
+    free(thr);
+}
+
+/* the masked per-pixel loop of cv-decoder/src/lib.rs:251-276 in the non-"Process Fullres" form: records of
+ * the unmasked pixels in raster order.  Returns the record count. */
+size_t orc_masked_flow_to_entries(const float* flow, const uint8_t* mask, int W, int H, float* out_entries) {
+    const float nx = 1.0f / (float)W, ny = 1.0f / (float)H;
+    size_t k = 0;
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+            if (mask && !mask[(size_t)y * W + x]) continue;
+            float* e = out_entries + 4 * k++;
+            e[0] = ((float)x + 0.5f) * nx;
+            e[1] = ((float)y + 0.5f) * ny;
+            e[2] = flow[2 * ((size_t)y * W + x)] * nx;
+            e[3] = flow[2 * ((size_t)y * W + x) + 1] * ny;
+        }
+    return k;
+}
+
 int orc_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

@@ -120,6 +120,12 @@ int orc_lk_flow(const uint8_t* prev, const uint8_t* cur, int W, int H, int strid
 /* per-pixel MotionEntry records in cv-decoder's convention (cv-decoder/src/lib.rs:239-243,262-269) */
 void orc_flow_to_entries(const float* flow, int W, int H, float* out_entries);
 
+/* cv-decoder's Sobel(1,1,k5) > 20 -> dilate(ellipse 11x11) contrast mask (cv-decoder/src/lib.rs:203-237), restated
+ * from OpenCV's published definitions ("parity unpinned").  out_mask: W*H bytes, 1 = pixel contributes a record. */
+void orc_contrast_mask(const uint8_t* gray, int W, int H, int stride, uint8_t* out_mask);
+/* records of the unmasked pixels in raster order (mask may be NULL = all); returns the count */
+size_t orc_masked_flow_to_entries(const float* flow, const uint8_t* mask, int W, int H, float* out_entries);
+
 int orc_num_threads(void);
 
 #ifdef __cplusplus

@@ -77,6 +77,13 @@ def main():
         ent, best = oracle.sad_flow(fr[0], fr[1], B, R, simd=False)
         s[f"frames_{name}"], s[f"best_{name}"], s[f"entries_{name}"] = fr, best, ent
     np.savez_compressed(os.path.join(HERE, "sad.npz"), **s)
+    # ---- dense flow decoder (N2 + cv-decoder's mask / output stage): 160x96 pair with flat regions
+    fr = synth.flatten_regions(synth.luma_sequence(2, 160, 96, max_step=2, seed=synth.SEED0 + 5), region=32, seed=4)
+    flow = oracle.lk_flow(fr[0], fr[1], 3, 4, 3)
+    mask = oracle.contrast_mask(fr[1])
+    rec = oracle.masked_flow_to_entries(flow, mask)
+    np.savez_compressed(os.path.join(HERE, "flow.npz"), frames=fr, flow=flow, mask=mask, records=rec,
+                        cells_60x36=oracle.densify_to_entries(rec, 60, 36))
     for f in sorted(os.listdir(HERE)):
         print(f, os.path.getsize(os.path.join(HERE, f)))
 

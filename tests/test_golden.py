@@ -55,6 +55,19 @@ def test_oracle_reproduces_densify_detect_sad_golden():
         np.testing.assert_array_equal(ent.view(np.uint32), g[f"entries_{name}"].view(np.uint32))
 
 
+def test_oracle_reproduces_flow_golden():
+    from oracle import np_oracle
+    g = _load("flow.npz")
+    fr = g["frames"]
+    np.testing.assert_array_equal(oracle.lk_flow(fr[0], fr[1], 3, 4, 3).view(np.uint32), g["flow"].view(np.uint32))
+    np.testing.assert_array_equal(oracle.contrast_mask(fr[1]), g["mask"])
+    np.testing.assert_array_equal(np_oracle.contrast_mask(fr[1]), g["mask"])
+    assert 0.1 < g["mask"].mean() < 0.9
+    rec = oracle.masked_flow_to_entries(g["flow"], g["mask"])
+    np.testing.assert_array_equal(rec.view(np.uint32), g["records"].view(np.uint32))
+    np.testing.assert_array_equal(oracle.densify_to_entries(rec, 60, 36).view(np.uint32), g["cells_60x36"].view(np.uint32))
+
+
 # ---------------------------------------------------------------- HIP path vs golden (GPU)
 @pytest.fixture(scope="module")
 def ctx():
@@ -101,3 +114,16 @@ def test_hip_almeida_matches_golden(ctx):
         q, _ = ctx.almeida(f, 1.0, 90.0, use_ransac=True, num_iters=100, inlier_deg=0.05, num_samples=1000,
                            seed=int(g["ransac_seed0"]) + int(i))
         np.testing.assert_allclose(q, g["q_ransac"][i], atol=1e-4, rtol=0)
+
+
+@pytest.mark.gpu
+def test_hip_flow_decoder_matches_golden(ctx):
+    g = _load("flow.npz")
+    fr = g["frames"]
+    np.testing.assert_array_equal(ctx.lk_flow(fr[0], fr[1], 3, 4, 3).view(np.uint32), g["flow"].view(np.uint32))
+    np.testing.assert_array_equal(ctx.contrast_mask(fr[1]), g["mask"])
+    rec, _ = ctx.lk_decode(fr[0], fr[1], contrast_mask=True, per_pixel=True)
+    np.testing.assert_array_equal(rec.view(np.uint32), g["records"].view(np.uint32))
+    ent, (gw, gh) = ctx.lk_decode(fr[0], fr[1], max_w=60, max_h=60, contrast_mask=True)
+    assert (gw, gh) == (60, 36)
+    np.testing.assert_array_equal(ent.view(np.uint32), g["cells_60x36"].view(np.uint32))

@@ -443,3 +443,57 @@ def test_lk_decode_matches_cv_decoder_output_stage(ctx):
     fr = synth.luma_sequence(2, 96, 64, max_step=1, seed=2)
     ent, (gw, gh) = ctx.lk_decode(fr[0], fr[1])
     assert (gw, gh) == (96, 64) and len(ent) == 96 * 64
+
+
+# ------------------------------------------------------------------ cv-decoder contrast mask (rank-4 "next" row)
+@pytest.mark.parametrize("W,H", [(1, 1), (3, 2), (7, 5), (64, 16), (65, 17), (333, 77), (640, 360)])
+def test_contrast_mask_is_bit_exact(ctx, W, H):
+    """Sobel(1,1,k5) > 20 -> dilate(ellipse 11x11) (cv-decoder/src/lib.rs:203-237): integer-exact vs both restatements,
+    tile seams, frames smaller than the halo, reflect-101 borders."""
+    from oracle import np_oracle
+    g = synth.flatten_regions(synth.luma_sequence(1, W, H, max_step=0, seed=W * 31 + H), region=24, seed=W + H)[0]
+    m = ctx.contrast_mask(g)
+    np.testing.assert_array_equal(m, oracle.contrast_mask(g))
+    np.testing.assert_array_equal(m, np_oracle.contrast_mask(g))
+    if W >= 64 and H >= 16:
+        assert 0 < m.mean() < 1
+    r = synth.random_luma(1, W, H, seed=5)[0]
+    np.testing.assert_array_equal(ctx.contrast_mask(r), oracle.contrast_mask(r))
+    z = np.full((H, W), 200, np.uint8)
+    assert not ctx.contrast_mask(z).any()
+
+
+def test_contrast_mask_device_resident_1080p(ctx):
+    import torch
+    g = synth.flatten_regions(synth.luma_sequence(1, 1920, 1080, max_step=0, seed=77), region=96, seed=3)[0]
+    d_g = torch.from_numpy(g).cuda()
+    d_m = torch.zeros((1080, 1920), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    ctx.contrast_mask_dev(d_g.data_ptr(), 1920, 1080, 1920, d_m.data_ptr())
+    ctx.sync()
+    np.testing.assert_array_equal(d_m.cpu().numpy(), oracle.contrast_mask(g))
+
+
+def test_lk_decode_with_contrast_mask(ctx):
+    """The masked record loop (cv-decoder/src/lib.rs:251-291): masked pixels contribute nothing, survivors keep raster
+    order (which fixes the densifier's f32 summation order) -- bit-exact per stage, in both output modes."""
+    fr = synth.flatten_regions(synth.luma_sequence(2, 480, 270, max_step=2, seed=12), region=40, seed=8)
+    flow = oracle.lk_flow(fr[0], fr[1], 3, 4, 3)
+    mask = oracle.contrast_mask(fr[1])
+    assert 0.1 < mask.mean() < 0.95
+    rec_o = oracle.masked_flow_to_entries(flow, mask)
+    ent, (gw, gh) = ctx.lk_decode(fr[0], fr[1], contrast_mask=True, per_pixel=True)
+    assert (gw, gh) == (480, 270)
+    np.testing.assert_array_equal(ent.view(np.uint32), rec_o.view(np.uint32))
+    ent, (gw, gh) = ctx.lk_decode(fr[0], fr[1], contrast_mask=True)
+    assert (gw, gh) == (150, 84)
+    e_o = oracle.densify_to_entries(rec_o, 150, 84)
+    assert len(e_o) < 150 * 84                         # some cells are never visited
+    np.testing.assert_array_equal(ent.view(np.uint32), e_o.view(np.uint32))
+    # per-pixel without the mask = every pixel
+    ent, _ = ctx.lk_decode(fr[0], fr[1], per_pixel=True)
+    np.testing.assert_array_equal(ent.view(np.uint32), oracle.flow_to_entries(flow).view(np.uint32))
+    # nothing survives a flat frame: zero records, not an error
+    flat = np.full((2, 64, 96), 90, np.uint8)
+    ent, _ = ctx.lk_decode(flat[0], flat[1], contrast_mask=True)
+    assert len(ent) == 0

@@ -101,7 +101,7 @@ def test_extract_detect_track_through_cpp_host(tmp_path):
 def test_hip_lk_decoder_through_cpp_host(tmp_path):
     import oracle
     W, H, F = 320, 180, 3
-    fr = synth.luma_sequence(F, W, H, max_step=2, seed=4)
+    fr = synth.flatten_regions(synth.luma_sequence(F, W, H, max_step=2, seed=4), region=40, seed=1)
     raw = tmp_path / "clip.y"
     raw.write_bytes(fr.tobytes())
     out = tmp_path / "clip_lk.mvec"
@@ -109,5 +109,7 @@ def test_hip_lk_decoder_through_cpp_host(tmp_path):
     frames = list(mvec.read_frames(open(out, "rb")))
     assert info["frames"] == F and len(frames[0]) == 0
     for k in range(1, F):
-        e_o = oracle.densify_to_entries(oracle.flow_to_entries(oracle.lk_flow(fr[k - 1], fr[k], 3, 4, 3)), 150, 84)
+        rec = oracle.masked_flow_to_entries(oracle.lk_flow(fr[k - 1], fr[k], 3, 4, 3), oracle.contrast_mask(fr[k]))
+        e_o = oracle.densify_to_entries(rec, 150, 84)             # the plugin masks by default, like cv-decoder
+        assert 0 < len(e_o) < 150 * 84
         np.testing.assert_array_equal(frames[k].view(np.uint32), e_o.view(np.uint32))

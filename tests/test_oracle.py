@@ -183,3 +183,44 @@ def test_lk_flow_oracle_recovers_translation_and_zero():
     assert e.shape == (24, 4) and e[0, 0] == np.float32(0.5) * (np.float32(1) / np.float32(6)) and e[7, 1] == np.float32(1.5) * np.float32(0.25)
     with pytest.raises(ValueError):
         oracle.lk_flow(prev, prev, 0, 4, 3)
+
+
+def test_contrast_mask_known_answers():
+    """cv-decoder/src/lib.rs:203-237.  An impulse of 6 on black gives Sobel(1,1,k5) = 6*K[i]*K[j] with K = [-1,-2,0,2,1]:
+    only the two +4 taps exceed 20, at (y0+1, x0+1) and (y0-1, x0-1); the mask is the union of two copies of
+    OpenCV's 11x11 MORPH_ELLIPSE element (the matrix getStructuringElement documents) centred there."""
+    ell = np.array([[0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0],
+                    [0, 0, 1, 1, 1, 1, 1, 1, 1, 0, 0],
+                    [0, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0],
+                    [1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1],
+                    [1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1],
+                    [1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1],
+                    [1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1],
+                    [1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1],
+                    [0, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0],
+                    [0, 0, 1, 1, 1, 1, 1, 1, 1, 0, 0],
+                    [0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0]], np.uint8)
+    g = np.zeros((40, 50), np.uint8)
+    g[20, 25] = 6
+    want = np.zeros_like(g)
+    for cy, cx in ((21, 26), (19, 24)):
+        want[cy - 5:cy + 6, cx - 5:cx + 6] |= ell
+    np.testing.assert_array_equal(oracle.contrast_mask(g), want)
+    np.testing.assert_array_equal(npo.contrast_mask(g), want)
+    g[20, 25] = 5                                           # 5*4 = 20 is not > 20
+    assert not oracle.contrast_mask(g).any()
+    # negative mixed derivative never passes (THRESH_BINARY on the signed response)
+    g[:] = 0; g[20, 25] = 255
+    m = oracle.contrast_mask(g)
+    assert m[20 + 1, 25 + 1] and m[20 - 1, 25 - 1]
+    # an image corner: out-of-image taps of the dilation are ignored, Sobel reflects (101) at the border
+    r = np.random.default_rng(3).integers(0, 256, (9, 12), dtype=np.uint8)
+    np.testing.assert_array_equal(oracle.contrast_mask(r), npo.contrast_mask(r))
+
+
+def test_masked_records_keep_raster_order():
+    flow = np.random.default_rng(1).normal(0, 1, (6, 8, 2)).astype(np.float32)
+    mask = (np.random.default_rng(2).random((6, 8)) < 0.5).astype(np.uint8)
+    full = oracle.flow_to_entries(flow)
+    np.testing.assert_array_equal(oracle.masked_flow_to_entries(flow, mask), full[mask.reshape(-1) != 0])
+    np.testing.assert_array_equal(oracle.masked_flow_to_entries(flow, None), full)

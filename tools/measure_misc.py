@@ -94,7 +94,17 @@ def main():
     ms_chain = timeit(chain, n=5, warm=1)
     out["cfg3_lk_flow_1080p"] = {"ms": round(ms_lk, 3), "Mvectors_per_s": round(1920 * 1080 / ms_lk / 1e3, 1)}
     out["cfg3_chain_lk_densify_almeida"] = {"ms": round(ms_chain, 3), "Mvectors_per_s": round(1920 * 1080 / ms_chain / 1e3, 1)}
+    # --- cv-decoder's contrast mask at 1080p (device resident) and the whole hip_lk process_frame through the host API
+    g = torch.from_numpy(synth.flatten_regions(fr[1:2], region=96, seed=3)[0]).cuda()
+    d_mask = torch.empty((1080, 1920), dtype=torch.uint8, device="cuda")
+    ms = timeit(lambda: ctx.contrast_mask_dev(g.data_ptr(), 1920, 1080, 1920, d_mask.data_ptr()), n=20)
+    out["contrast_mask_1080p"] = {"ms": round(ms, 4), "GBps_algorithmic_2B_per_px": round(2 * 1920 * 1080 / ms / 1e6, 1)}
     ctx.use_own_stream()
+    frm = synth.flatten_regions(fr, region=96, seed=3)
+    ms = timeit(lambda: ctx.lk_decode(frm[0], frm[1], contrast_mask=True), n=5, warm=1)
+    out["hip_lk_process_frame_1080p_host_api_masked_ms"] = round(ms, 3)
+    ms = timeit(lambda: ctx.lk_decode(frm[0], frm[1]), n=5, warm=1)
+    out["hip_lk_process_frame_1080p_host_api_unmasked_ms"] = round(ms, 3)
     print(json.dumps(out, indent=1))
 
 
