@@ -91,7 +91,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    # under torchrun (RANK/MASTER_PORT set) the process group is always created, also at world size 1, so the
+    # RCCL init / barrier / max-reduce path of an N-GPU run can be exercised on a 1-GPU box
+    use_dist = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     if not torch.cuda.is_available():
@@ -118,7 +121,7 @@ def main():
         ctx.sad_flow_dev(d_frames.data_ptr(), P + 1, W, H, stride, stride * H, 0, B, R, d_out.data_ptr(), None)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
 
     for _ in range(args.warmup):
@@ -129,7 +132,7 @@ def main():
         step()
     torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
     el = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([el], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
@@ -216,7 +219,7 @@ def main():
     if rank == 0:
         print(json.dumps(out), flush=True)
     ctx.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
