@@ -67,6 +67,9 @@ int   ofps_hip_sync(ofps_hip_ctx* ctx);
 /* ---- device memory plumbing for hosts without their own HIP binding ---- */
 int ofps_hip_malloc(ofps_hip_ctx* ctx, size_t bytes, void** dptr);
 int ofps_hip_free(ofps_hip_ctx* ctx, void* dptr);
+/* page-locked host memory for frame buffers (H2D by DMA, no staging copy); plain malloc'ed buffers work everywhere too */
+int ofps_hip_host_alloc(ofps_hip_ctx* ctx, size_t bytes, void** hptr);
+int ofps_hip_host_free(ofps_hip_ctx* ctx, void* hptr);
 int ofps_hip_memcpy_h2d(ofps_hip_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
 int ofps_hip_memcpy_d2h(ofps_hip_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
 
@@ -187,6 +190,8 @@ typedef struct {
     float quat[4];                                      /* estimator: (w,i,j,k); identity when not run */
 } ofps_hip_frame_result;
 int ofps_hip_reset_frames(ofps_hip_ctx* ctx);
+/* upload a frame as the stream's newest frame without computing anything (frames a Decoder skips: `skip_frames`) */
+int ofps_hip_stage_frame(ofps_hip_ctx* ctx, const uint8_t* luma, int W, int H, int stride);
 int ofps_hip_push_frame(ofps_hip_ctx* ctx, const uint8_t* luma, int W, int H, int stride,
                         const ofps_hip_frame_params* params, ofps_hip_frame_result* out,
                         float* out_entries /* 4*nblk or NULL */, float* out_field /* 2*dim*dim or NULL */);

@@ -75,6 +75,9 @@ class FrameResult(C.Structure):
 
 
 PROTOTYPES["ofps_hip_reset_frames"] = (C.c_int, [_ctx])
+PROTOTYPES["ofps_hip_stage_frame"] = (C.c_int, [_ctx, _u8p, C.c_int, C.c_int, C.c_int])
+PROTOTYPES["ofps_hip_host_alloc"] = (C.c_int, [_ctx, C.c_size_t, C.POINTER(C.c_void_p)])
+PROTOTYPES["ofps_hip_host_free"] = (C.c_int, [_ctx, C.c_void_p])
 PROTOTYPES["ofps_hip_push_frame"] = (C.c_int, [_ctx, _u8p, C.c_int, C.c_int, C.c_int, C.POINTER(FrameParams),
                                                C.POINTER(FrameResult), _f32p, _f32p])
 

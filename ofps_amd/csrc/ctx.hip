@@ -137,6 +137,21 @@ int ofps_hip_free(ofps_hip_ctx* ctx, void* dptr) {
     return OFPS_HIP_OK;
 }
 
+// pinned (page-locked) host memory: frames a decoder reads straight into it cross PCIe by DMA without a staging copy
+int ofps_hip_host_alloc(ofps_hip_ctx* ctx, size_t bytes, void** hptr) {
+    if (!ctx || !hptr) return OFPS_HIP_EINVAL;
+    OFPS_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    OFPS_HIP_TRY(ctx, hipHostMalloc(hptr, bytes ? bytes : 16, hipHostMallocDefault));
+    return OFPS_HIP_OK;
+}
+
+int ofps_hip_host_free(ofps_hip_ctx* ctx, void* hptr) {
+    if (!ctx) return OFPS_HIP_EINVAL;
+    OFPS_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    OFPS_HIP_TRY(ctx, hipHostFree(hptr));
+    return OFPS_HIP_OK;
+}
+
 int ofps_hip_memcpy_h2d(ofps_hip_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes) {
     if (!ctx) return OFPS_HIP_EINVAL;
     OFPS_HIP_TRY(ctx, hipSetDevice(ctx->device));

@@ -23,6 +23,36 @@ int ofps_hip_reset_frames(ofps_hip_ctx* ctx) {
     return OFPS_HIP_OK;
 }
 
+// H2D of one luma frame into the device slot that does not hold the newest frame; slots/pitch/prev/cur are outputs
+static int upload_frame(ofps_hip_ctx* ctx, const uint8_t* luma, int W, int H, int stride, uint8_t** slots_out, size_t* pitch_out,
+                        int* dstride_out, int* prev_slot_out, int* cur_slot_out) {
+    const int dstride = (W + 63) & ~63;
+    const size_t pitch = (size_t)dstride * H;
+    if (W != ctx->pipe_w || H != ctx->pipe_h) {            // geometry change restarts the stream (decoder.rs:66-72)
+        ctx->pipe_w = W; ctx->pipe_h = H; ctx->pipe_stride = dstride; ctx->pipe_newest = -1;
+    }
+    auto* slots = static_cast<uint8_t*>(ofps::scratch(ctx, ofps::S_PIPE_FRAMES, 2 * pitch));
+    if (!slots) return OFPS_HIP_ENOMEM;
+    const int prev_slot = ctx->pipe_newest, cur_slot = ctx->pipe_newest < 0 ? 0 : 1 - ctx->pipe_newest;
+    OFPS_HIP_TRY(ctx, hipMemcpy2DAsync(slots + (size_t)cur_slot * pitch, dstride, luma, stride, W, H, hipMemcpyHostToDevice,
+                                       ctx->stream));
+    ctx->pipe_newest = cur_slot;
+    *slots_out = slots; *pitch_out = pitch; *dstride_out = dstride; *prev_slot_out = prev_slot; *cur_slot_out = cur_slot;
+    return OFPS_HIP_OK;
+}
+
+int ofps_hip_stage_frame(ofps_hip_ctx* ctx, const uint8_t* luma, int W, int H, int stride) {
+    if (!ctx) return OFPS_HIP_EINVAL;
+    OFPS_REQUIRE(ctx, luma, "stage_frame: null pointer");
+    OFPS_REQUIRE(ctx, W > 0 && H > 0 && stride >= W, "stage_frame: bad geometry W=%d H=%d stride=%d", W, H, stride);
+    OFPS_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    uint8_t* slots; size_t pitch; int dstride, prev_slot, cur_slot;
+    int rc = upload_frame(ctx, luma, W, H, stride, &slots, &pitch, &dstride, &prev_slot, &cur_slot);
+    if (rc != OFPS_HIP_OK) return rc;
+    OFPS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // the caller may reuse `luma` right away
+    return OFPS_HIP_OK;
+}
+
 int ofps_hip_push_frame(ofps_hip_ctx* ctx, const uint8_t* luma, int W, int H, int stride,
                         const ofps_hip_frame_params* prm, ofps_hip_frame_result* out, float* out_entries,
                         float* out_field) {
@@ -31,17 +61,12 @@ int ofps_hip_push_frame(ofps_hip_ctx* ctx, const uint8_t* luma, int W, int H, in
     OFPS_REQUIRE(ctx, W > 0 && H > 0 && stride >= W, "push_frame: bad geometry W=%d H=%d stride=%d", W, H, stride);
     OFPS_HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
-    const int dstride = (W + 63) & ~63;
-    const size_t pitch = (size_t)dstride * H;
-    if (W != ctx->pipe_w || H != ctx->pipe_h) {            // geometry change restarts the stream (decoder.rs:66-72)
-        ctx->pipe_w = W; ctx->pipe_h = H; ctx->pipe_stride = dstride; ctx->pipe_newest = -1;
-    }
-    auto* slots = static_cast<uint8_t*>(ofps::scratch(ctx, ofps::S_PIPE_FRAMES, 2 * pitch));
-    if (!slots) return OFPS_HIP_ENOMEM;
     if (!ctx->pipe_pinned) OFPS_HIP_TRY(ctx, hipHostMalloc(&ctx->pipe_pinned, sizeof(PipeOut), hipHostMallocDefault));
-    const int prev_slot = ctx->pipe_newest, cur_slot = ctx->pipe_newest < 0 ? 0 : 1 - ctx->pipe_newest;
-    OFPS_HIP_TRY(ctx, hipMemcpy2DAsync(slots + (size_t)cur_slot * pitch, dstride, luma, stride, W, H, hipMemcpyHostToDevice, s));
-    ctx->pipe_newest = cur_slot;
+    uint8_t* slots; size_t pitch; int dstride, prev_slot, cur_slot;
+    {
+        int rc = upload_frame(ctx, luma, W, H, stride, &slots, &pitch, &dstride, &prev_slot, &cur_slot);
+        if (rc != OFPS_HIP_OK) return rc;
+    }
 
     memset(out, 0, sizeof(*out));
     out->quat[0] = 1.0f;

@@ -96,34 +96,44 @@ void HipContext::check(int rc) const {
 // ------------------------------------------------------------------ hip_sad
 HipSadDecoder::HipSadDecoder(std::unique_ptr<std::istream> input, size_t width, size_t height, std::optional<double> fps,
                              int device)
-    : ctx_(device), in_(std::move(input)), w_(width), h_(height), fps_(fps), prev_(width * height), cur_(width * height) {
+    : ctx_(device), in_(std::move(input)), w_(width), h_(height), fps_(fps) {
     if (!in_ || !*in_) throw Error("hip_sad: cannot open input");
     if (w_ == 0 || h_ == 0) throw Error("hip_sad: frame size required (arg \"path?w=..&h=..\")");
+    void* p = nullptr;
+    ctx_.check(ofps_hip_host_alloc(ctx_.get(), w_ * h_, &p));         // page-locked: the frame is DMA'd, not staged
+    frame_ = static_cast<uint8_t*>(p);
 }
 
+HipSadDecoder::~HipSadDecoder() {
+    if (frame_) ofps_hip_host_free(ctx_.get(), frame_);
+}
+
+// The vectors relate the last two frames read from the stream.  Only newly read frames cross PCIe: the previous
+// frame stays on the device (ofps_hip_stage_frame / ofps_hip_push_frame keep a two-slot ring in the context).
 bool HipSadDecoder::process_frame(MotionVectors& field, std::vector<RGBA>* out_frame, size_t* out_height, size_t skip) {
+    const size_t bytes = w_ * h_;
     for (size_t s = 0; s <= skip; ++s) {
-        std::swap(prev_, cur_);
-        in_->read(reinterpret_cast<char*>(cur_.data()), (std::streamsize)cur_.size());
-        if ((size_t)in_->gcount() != cur_.size()) throw Error("hip_sad: end of stream");   // Err ends the caller's loop
+        in_->read(reinterpret_cast<char*>(frame_), (std::streamsize)bytes);
+        if ((size_t)in_->gcount() != bytes) throw Error("hip_sad: end of stream");   // Err ends the caller's loop
+        if (s + 1 == skip) ctx_.check(ofps_hip_stage_frame(ctx_.get(), frame_, (int)w_, (int)h_, (int)w_));
     }
     if (out_frame && out_height) {
         *out_height = h_;
         out_frame->clear();
-        out_frame->reserve(cur_.size());
-        for (uint8_t y : cur_) out_frame->push_back(RGBA{y, y, y, 255});
+        out_frame->reserve(bytes);
+        for (size_t i = 0; i < bytes; ++i) out_frame->push_back(RGBA{frame_[i], frame_[i], frame_[i], 255});
     }
-    const bool had_prev = have_prev_;
-    have_prev_ = true;
-    if (!had_prev) return false;                                      // first frame: no pair yet
     const size_t nblk = ofps_hip_sad_block_count((int)w_, (int)h_, (int)block_);
     out_.resize(4 * nblk);
-    size_t n_out = 0;
-    ctx_.check(ofps_hip_sad_flow(ctx_.get(), prev_.data(), cur_.data(), (int)w_, (int)h_, (int)w_, (int)block_, (int)range_,
-                                 out_.data(), nullptr, &n_out));
+    ofps_hip_frame_params prm{};
+    prm.block = (int)block_;
+    prm.range = (int)range_;
+    ofps_hip_frame_result res{};
+    ctx_.check(ofps_hip_push_frame(ctx_.get(), frame_, (int)w_, (int)h_, (int)w_, &prm, &res, out_.data(), nullptr));
+    if (!res.have_vectors) return false;                              // first frame: no pair yet
     const size_t base = field.size();
-    field.resize(base + n_out);                                       // vectors are APPENDED (callers clear)
-    std::memcpy(field.data() + base, out_.data(), n_out * sizeof(MotionEntry));
+    field.resize(base + res.n_vectors);                               // vectors are APPENDED (callers clear)
+    std::memcpy(field.data() + base, out_.data(), res.n_vectors * sizeof(MotionEntry));
     return true;
 }
 

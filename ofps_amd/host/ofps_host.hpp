@@ -123,6 +123,7 @@ private:
 class HipSadDecoder : public Decoder {
 public:
     HipSadDecoder(std::unique_ptr<std::istream> input, size_t width, size_t height, std::optional<double> fps, int device = 0);
+    ~HipSadDecoder() override;
     bool process_frame(MotionVectors& field, std::vector<RGBA>* out_frame, size_t* out_height, size_t skip_frames) override;
     std::optional<double> get_framerate() const override { return fps_; }
     std::optional<std::pair<size_t, size_t>> get_aspect() const override { return std::make_pair(w_, h_); }
@@ -132,9 +133,8 @@ private:
     std::unique_ptr<std::istream> in_;
     size_t w_, h_, block_ = 16, range_ = 16;
     std::optional<double> fps_;
-    std::vector<uint8_t> prev_, cur_;
+    uint8_t* frame_ = nullptr;             // page-locked staging buffer for the frame being read
     std::vector<float> out_;
-    bool have_prev_ = false;
 };
 
 // "hip_lk": dense per-pixel flow in cv-decoder's full-resolution mode (cv-decoder/src/lib.rs:82-294): one record per

@@ -90,18 +90,27 @@ class HipSadDecoder(Properties):
 
     def process_frame(self, field: list, out_frame: Optional[list] = None, skip_frames: int = 0) -> bool:
         """True: vectors appended to `field` (callers clear it); False: no vectors this frame; raises
-        StopIteration-derived EOFError at end of stream (the Err that ends the reference's worker loop)."""
-        for _ in range(skip_frames + 1):
-            self._prev = self._cur
+        StopIteration-derived EOFError at end of stream (the Err that ends the reference's worker loop).
+        The vectors relate the last two frames read.  Only newly read frames cross PCIe, from a page-locked
+        buffer: the previous frame stays on the device (ofps_hip_stage_frame / ofps_hip_push_frame)."""
+        for k in range(skip_frames + 1):
             try:
-                self._cur = np.ascontiguousarray(next(self._it), np.uint8)
+                frame = np.asarray(next(self._it), np.uint8)
             except StopIteration:
                 raise EOFError("end of stream") from None
+            if k < skip_frames - 1:
+                continue                                   # consumed and dropped
+            if self._cur is None or self._cur.shape != frame.shape:
+                self._cur = self.ctx.pinned_frame(*frame.shape)
+            np.copyto(self._cur, frame)
+            if k == skip_frames - 1:
+                self.ctx.stage_frame(self._cur)            # becomes the frame the vectors are relative to
         if out_frame is not None:
-            out_frame[:] = [self._cur]
-        if self._prev is None or self._prev.shape != self._cur.shape:
+            out_frame[:] = [self._cur.copy()]
+        r = self.ctx.push_frame(self._cur, self.block, self.range, detector=False, estimator=False, want_entries=True)
+        if not r["have_vectors"]:                          # first frame of the stream / geometry change
             return False
-        field.extend(self.ctx.sad_flow(self._prev, self._cur, self.block, self.range))
+        field.extend(r["entries"])
         return True
 
     def get_framerate(self):

@@ -26,9 +26,13 @@ class HipContext:
             raise OfpsHipError(rc, (self._lib.ofps_hip_last_error(None) or b"").decode())
         self._h = h
         self.device = device
+        self._pinned = []
 
     def close(self):
         if getattr(self, "_h", None):
+            for p in getattr(self, "_pinned", []):
+                self._lib.ofps_hip_host_free(self._h, C.c_void_p(p))
+            self._pinned = []
             self._lib.ofps_hip_destroy(self._h)
             self._h = None
 
@@ -206,6 +210,20 @@ class HipContext:
     # ---- fused per-frame path
     def reset_frames(self):
         self._check(self._lib.ofps_hip_reset_frames(self._h))
+
+    def stage_frame(self, luma: np.ndarray):
+        """Upload a frame as the stream's newest frame without computing anything (a Decoder's skipped frames)."""
+        luma = np.ascontiguousarray(luma, np.uint8)
+        H, W = luma.shape
+        self._check(self._lib.ofps_hip_stage_frame(self._h, luma.ctypes.data_as(C.POINTER(C.c_uint8)), W, H, W))
+
+    def pinned_frame(self, height: int, width: int) -> np.ndarray:
+        """uint8[height, width] in page-locked host memory (freed with the context): frames written into it cross
+        PCIe by DMA without a staging copy."""
+        p = C.c_void_p(0)
+        self._check(self._lib.ofps_hip_host_alloc(self._h, height * width, C.byref(p)))
+        self._pinned.append(p.value)
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(height, width))
 
     def push_frame(self, luma: np.ndarray, block=16, search_range=16, detector=True, min_size=0.05, subdivide=3,
                    target_motion=0.003, estimator=True, aspect=16 / 9, fov_y_deg=39.6 * 9 / 16, use_ransac=False,

@@ -67,3 +67,32 @@ def test_decoder_detector_loop_semantics():
     with pytest.raises(EOFError):
         dec.process_frame(field)
     assert len(field) == n
+
+
+def test_decoder_skip_frames_and_geometry_change():
+    """skip_frames = n reads n+1 frames; the vectors relate the last two read (decoder.rs:47-60).  Only the new frame
+    is uploaded per call (pinned buffer + device-side previous frame), which must not change any result."""
+    from ofps_amd.plugins import HipSadDecoder
+    fr = synth.luma_sequence(8, 256, 144, max_step=4, seed=21)
+    small = synth.luma_sequence(2, 128, 96, max_step=4, seed=22)
+    dec = HipSadDecoder(list(fr) + list(small))
+    dec.range = 8
+    field = []
+    assert dec.process_frame(field, skip_frames=2) is True             # reads 0,1,2 -> pair (1,2)
+    np.testing.assert_array_equal(np.array(field, np.float32).view(np.uint32), oracle.sad_flow(fr[1], fr[2], 16, 8)[0].view(np.uint32))
+    field.clear()
+    out = []
+    assert dec.process_frame(field, out_frame=out, skip_frames=1) is True   # reads 3,4 -> pair (3,4)
+    np.testing.assert_array_equal(out[0], fr[4])
+    np.testing.assert_array_equal(np.array(field, np.float32).view(np.uint32), oracle.sad_flow(fr[3], fr[4], 16, 8)[0].view(np.uint32))
+    field.clear()
+    assert dec.process_frame(field) is True                             # reads 5 -> pair (4,5)
+    np.testing.assert_array_equal(np.array(field, np.float32).view(np.uint32), oracle.sad_flow(fr[4], fr[5], 16, 8)[0].view(np.uint32))
+    field.clear()
+    assert dec.process_frame(field, skip_frames=1) is True              # reads 6,7 -> pair (6,7)
+    np.testing.assert_array_equal(np.array(field, np.float32).view(np.uint32), oracle.sad_flow(fr[6], fr[7], 16, 8)[0].view(np.uint32))
+    field.clear()
+    assert dec.process_frame(field) is False and field == []            # geometry change restarts the stream
+    assert dec.get_aspect() == (128, 96)
+    assert dec.process_frame(field) is True
+    np.testing.assert_array_equal(np.array(field, np.float32).view(np.uint32), oracle.sad_flow(small[0], small[1], 16, 8)[0].view(np.uint32))

@@ -35,7 +35,28 @@ def main():
     out["cfg2_host_api_ms_per_pair"] = round(ms, 4)
     out["cfg2_host_api_Mvectors_per_s"] = round(8040 / ms / 1e3, 2)
 
+    # --- the Decoder::process_frame shape: only the new frame is uploaded (page-locked buffer), previous frame on device
+    pin = ctx.pinned_frame(1080, 1920)
+    seq = synth.luma_sequence(4, 1920, 1080, 16)
+    k = [0]
+
+    def push():
+        np.copyto(pin, seq[k[0] % 4]); k[0] += 1
+        ctx.push_frame(pin, 16, 16, detector=False, estimator=False, want_entries=True)
+    ms = timeit(push, n=40)
+    np.copyto(pin, seq[0])
+    ms_nocopy = timeit(lambda: ctx.push_frame(pin, 16, 16, detector=False, estimator=False, want_entries=True), n=40)
+    out["cfg2_decoder_process_frame"] = {"ms_per_frame_incl_host_copy_into_pinned": round(ms, 4), "ms_per_frame": round(ms_nocopy, 4),
+                                         "Mvectors_per_s": round(8040 / ms_nocopy / 1e3, 2),
+                                         "note": "2.07 MB H2D from page-locked memory + single-pair search + 129 KB D2H, synchronous"}
+    pag = seq[1].copy()
+    ms_pageable = timeit(lambda: ctx.push_frame(pag, 16, 16, detector=False, estimator=False, want_entries=True), n=40)
+    out["cfg2_decoder_process_frame"]["ms_per_frame_pageable_source"] = round(ms_pageable, 4)
+    # single-pair kernel alone (device resident)
+    d2 = torch.from_numpy(seq[:2]).cuda()
+    o1 = torch.empty((8040, 4), dtype=torch.float32, device="cuda")
     ctx.use_torch_stream()
+    out["cfg2_single_pair_kernel_ms"] = round(timeit(lambda: ctx.sad_flow_dev(d2.data_ptr(), 2, 1920, 1080, 1920, 1920 * 1080, 0, 16, 16, o1.data_ptr(), None), n=50), 4)
     # --- device-resident SAD at the other geometries (batched)
     for name, (W, H, B, R, P) in {"cfg1_640x360_b16_r8": (640, 360, 16, 8, 16),
                                   "cfg2_1080p_b16_r16": (1920, 1080, 16, 16, 16),
