@@ -79,29 +79,43 @@ __device__ __forceinline__ float2 cam_delta(const Camera& c, float px, float py,
     return make_float2(ox - px, oy - py);
 }
 
+// a / b.  EXACT = IEEE division (what the reference computes; ~12 VALU instructions on gfx950).  The dense-field
+// solver (n > 65536, the per-pixel regime of cfg3) uses v_rcp_f32 * a instead (<= 1 ulp per quotient, 2 instructions):
+// its 15 divisions per entry per step are 2/3 of that kernel's instruction stream, and with >= 65k entries per sum
+// the extra half-ulp of per-quotient rounding noise averages out far below the 2e-6 the parity tests allow
+// (north_star tolerance: 1e-4).  Everything pinned to the oracle's exact operation order -- the one-workgroup
+// solver, RANSAC hypotheses and inlier tests, block-vector sized problems -- keeps IEEE division.
+template <bool FAST>
+__device__ __forceinline__ float fdiv(float a, float b) {
+    if constexpr (FAST) return a * __builtin_amdgcn_rcpf(b);
+    else return a / b;
+}
+
 // The unprojected point (camera.rs:45-55) does not depend on the rotation: hoisted out of the 30-step loop.
 struct Unproj { float wx, wy, wz; };
+template <bool FAST = false>
 __device__ __forceinline__ Unproj cam_unproject(const Camera& c, float px, float py) {
     const float cx = px * 2.0f - 1.0f, cy = py * 2.0f - 1.0f;
     const float n0 = c.r32 + c.r33;
     Unproj u;
-    u.wx = ((-c.r00) * cx) / n0;
-    u.wy = -1.0f / n0;
-    u.wz = (c.r11 * cy) / n0;
+    u.wx = fdiv<FAST>((-c.r00) * cx, n0);
+    u.wy = fdiv<FAST>(-1.0f, n0);
+    u.wz = fdiv<FAST>(c.r11 * cy, n0);
     return u;
 }
 // rotate + project + subtract: same operations, same order as cam_delta after its first four lines
+template <bool FAST = false>
 __device__ __forceinline__ float2 cam_delta_w(const Camera& c, float px, float py, const Unproj& u, const Mat3& R) {
     const float rx = (R.m[0] * u.wx + R.m[1] * u.wy) + R.m[2] * u.wz;
     const float ry = (R.m[3] * u.wx + R.m[4] * u.wy) + R.m[5] * u.wz;
     const float rz = (R.m[6] * u.wx + R.m[7] * u.wy) + R.m[8] * u.wz;
     const float qx = -rx, qy = rz, qz = ry;
-    const float inv = -1.0f / qz;
+    const float inv = fdiv<FAST>(-1.0f, qz);
     const float sx = c.m00 * qx * inv;
     const float sy = c.m11 * qy * inv;
     const float sz = (c.m22 * qz + c.m23) * inv;
-    const float ox = (sx / sz + 1.0f) * 0.5f;
-    const float oy = (sy / sz + 1.0f) * 0.5f;
+    const float ox = (fdiv<FAST>(sx, sz) + 1.0f) * 0.5f;
+    const float oy = (fdiv<FAST>(sy, sz) + 1.0f) * 0.5f;
     return make_float2(ox - px, oy - py);
 }
 
@@ -328,6 +342,7 @@ __global__ __launch_bounds__(1024) void almeida_lsq_wg_kernel(const float4* __re
 // `it` (double-buffered: late workgroups of a launch still read the previous slot);
 // partials[item][blk][9] are this step's per-workgroup sums.  Every workgroup first folds the
 // previous step's partials (fixed order) into its private copy of the rotation.
+template <bool FAST>
 __global__ __launch_bounds__(1024) void almeida_lsq_step_kernel(const float4* __restrict__ entries, size_t n, int it,
                                                                 Camera cam, const float* __restrict__ part_prev,
                                                                 float* __restrict__ part_out, Quat* __restrict__ state,
@@ -375,11 +390,11 @@ __global__ __launch_bounds__(1024) void almeida_lsq_step_kernel(const float4* __
     float s[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (size_t i = (size_t)blockIdx.x * 1024 + threadIdx.x; i < n; i += (size_t)nblk * 1024) {
         const float4 e = entries[item * n + i];
-        const Unproj un = cam_unproject(cam, e.x, e.y);
-        const float2 d = cam_delta_w(cam, e.x, e.y, un, rotm);
-        const float2 pr = cam_delta_w(cam, e.x, e.y, un, mroll);
-        const float2 pp = cam_delta_w(cam, e.x, e.y, un, mpitch);
-        const float2 py = cam_delta_w(cam, e.x, e.y, un, myaw);
+        const Unproj un = cam_unproject<FAST>(cam, e.x, e.y);
+        const float2 d = cam_delta_w<FAST>(cam, e.x, e.y, un, rotm);
+        const float2 pr = cam_delta_w<FAST>(cam, e.x, e.y, un, mroll);
+        const float2 pp = cam_delta_w<FAST>(cam, e.x, e.y, un, mpitch);
+        const float2 py = cam_delta_w<FAST>(cam, e.x, e.y, un, myaw);
         const float rx = e.z - d.x, ry = e.w - d.y;
         s[0] += pr.x * pr.x + pr.y * pr.y;
         s[1] += pr.x * pp.x + pr.y * pp.y;
@@ -596,9 +611,14 @@ static int lsq_device(ofps_hip_ctx* ctx, const float4* d_entries, size_t stride,
         if (!part || !state) return OFPS_HIP_ENOMEM;
         float* pa = part;
         float* pb = part + (size_t)batch * nblk * 9;
+        const bool dense = n_max > 65536;          // per-pixel regime: reciprocal-multiply quotients, see fdiv
         for (int it = 0; it <= kIters; ++it) {
-            hipLaunchKernelGGL(almeida_lsq_step_kernel, dim3(nblk, batch), dim3(1024), 0, s, d_entries, n_max, it, cam,
-                               pa, pb, state, batch, d_quat);
+            if (dense)
+                hipLaunchKernelGGL(almeida_lsq_step_kernel<true>, dim3(nblk, batch), dim3(1024), 0, s, d_entries, n_max, it, cam,
+                                   pa, pb, state, batch, d_quat);
+            else
+                hipLaunchKernelGGL(almeida_lsq_step_kernel<false>, dim3(nblk, batch), dim3(1024), 0, s, d_entries, n_max, it, cam,
+                                   pa, pb, state, batch, d_quat);
             float* t = pa; pa = pb; pb = t;
         }
     }

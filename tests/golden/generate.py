@@ -84,6 +84,10 @@ def main():
     rec = oracle.masked_flow_to_entries(flow, mask)
     np.savez_compressed(os.path.join(HERE, "flow.npz"), frames=fr, flow=flow, mask=mask, records=rec,
                         cells_60x36=oracle.densify_to_entries(rec, 60, 36))
+    # ---- cfg3-sized Almeida LSQ: 1920x1080 per-pixel records (inputs are regenerated from synth; 18 s of oracle time)
+    e = synth.rotation_field(1920, 1080)
+    np.savez_compressed(os.path.join(HERE, "almeida_dense.npz"), q_lsq=oracle.solve_ypr_given(e, oracle.camera(16 / 9, 22.275)),
+                        checksum=np.float64(e.astype(np.float64).sum()), first=e[:4], last=e[-4:])
     for f in sorted(os.listdir(HERE)):
         print(f, os.path.getsize(os.path.join(HERE, f)))
 

@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 
 import oracle
+from ofps_amd import synth
 
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
@@ -127,3 +128,14 @@ def test_hip_flow_decoder_matches_golden(ctx):
     ent, (gw, gh) = ctx.lk_decode(fr[0], fr[1], max_w=60, max_h=60, contrast_mask=True)
     assert (gw, gh) == (60, 36)
     np.testing.assert_array_equal(ent.view(np.uint32), g["cells_60x36"].view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_hip_almeida_dense_1080p_matches_golden(ctx):
+    """cfg3 at full size: 2,073,600 per-pixel records through the multi-launch LSQ (dense regime: reciprocal-multiply
+    quotients, ofps_amd/csrc/almeida.hip:fdiv) vs the oracle's exact-division answer stored in the fixture."""
+    g = _load("almeida_dense.npz")
+    e = synth.rotation_field(1920, 1080)
+    np.testing.assert_array_equal(e[:4], g["first"]); np.testing.assert_array_equal(e[-4:], g["last"])
+    q, _ = ctx.almeida(e, 16 / 9, 22.275, use_ransac=False)
+    np.testing.assert_allclose(q, g["q_lsq"], atol=2e-6, rtol=0)

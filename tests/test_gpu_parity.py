@@ -289,7 +289,7 @@ def test_almeida_reference_known_answer_ransac(ctx):
         np.testing.assert_allclose(est, q_o, atol=1e-4, rtol=0)
 
 
-@pytest.mark.parametrize("n_side", [(64, 36), (160, 90), (480, 270)])
+@pytest.mark.parametrize("n_side", [(64, 36), (160, 90), (480, 270), (960, 540)])
 def test_almeida_noisy_field_matches_oracle(ctx, n_side):
     """cfg3-shaped input (per-pixel entries, planted rotation + noise); covers the one-workgroup and the
     multi-launch solver.  Tolerance 2e-6 on quaternion components (sum order differs)."""
