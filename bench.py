@@ -49,6 +49,9 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--sad-mode", choices=["exhaustive", "pruned"], default="exhaustive",
                     help="search strategy of the SAD kernel (both return the same bits; pruned is content-dependent)")
+    ap.add_argument("--ref-mode", choices=["pairs", "key"], default="pairs",
+                    help="pairs: frame k vs k+1 (default, no collective).  key: every frame vs one shared key frame that rank 0 "
+                         "broadcasts to all ranks over RCCL inside the timed step (SURVEY.md 8e, north_star's shared-reference case)")
     ap.add_argument("--pipeline", action="store_true",
                     help="also time the fused tail (detect + Almeida LSQ) per step; reported under 'pipeline'")
     return ap.parse_args()
@@ -117,8 +120,14 @@ def main():
     ctx.use_torch_stream()            # launches go to torch's current stream: torch events see them
     ctx.set_sad_mode(ctx.SAD_PRUNED if args.sad_mode == "pruned" else ctx.SAD_EXHAUSTIVE)
 
+    key_mode = args.ref_mode == "key"
+
     def step():
-        ctx.sad_flow_dev(d_frames.data_ptr(), P + 1, W, H, stride, stride * H, 0, B, R, d_out.data_ptr(), None)
+        if key_mode and use_dist:
+            # the shared reference frame travels rank 0 -> all ranks (RCCL broadcast, on torch's current stream like the
+            # search that follows it); its slot is frame 0 of every rank's resident sequence
+            dist.broadcast(d_frames[0], src=0)
+        ctx.sad_flow_dev(d_frames.data_ptr(), P + 1, W, H, stride, stride * H, 1 if key_mode else 0, B, R, d_out.data_ptr(), None)
 
     def barrier():
         if use_dist:
@@ -175,7 +184,8 @@ def main():
                                      (3840, 2160, 8, 32): "cfg4 (BASELINE.json configs[3]): ",
                                      (640, 360, 16, 8): "cfg1 geometry (BASELINE.json configs[0]): "}.get((W, H, B, R), "")
                                     + f"{W}x{H} synthetic luma, {B}x{B} blocks, +-{R} full-search SAD"),
-                       "pairs_per_step": P, "vectors_per_pair": nblk, "parallelism": f"frame-pair sharding x{world}",
+                       "pairs_per_step": P, "vectors_per_pair": nblk, "parallelism": (f"frame-pair sharding x{world}" + (", key frame broadcast from rank 0 per step (RCCL)" if key_mode and use_dist else "")),
+                       "ref_mode": args.ref_mode,
                        "kernel": (f"sad_strip_kernel<{B},{R}>" if args.sad_mode == "exhaustive" else "sad_sea_kernel + sad_strip_kernel<16,16> on overflow strips"),
                        "sad_mode": args.sad_mode},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
