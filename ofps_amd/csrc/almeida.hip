@@ -8,9 +8,10 @@
 //
 // Least squares (lib.rs:123-200), 30 damped Gauss-Newton steps on N entries:
 //   * the three EPS prototypes (roll/pitch/yaw deltas, lib.rs:30-42) do not depend on the
-//     iteration; they are computed once per entry and kept in registers (small problems);
-//   * per step each thread forms its 9 products (6 unique A entries -- A is symmetric bit for bit
-//     -- and 3 b entries), a fixed-shape wave butterfly + LDS tree reduces them, thread 0 runs the
+//     iteration; they are computed once per entry and kept on chip (registers; LDS for 8 entries
+//     per thread), and so is A = J^T J, which is built from the prototypes alone (small problems);
+//   * per step each thread forms its products (6 unique A entries -- A is symmetric bit for bit
+//     -- once, 3 b entries per step), a fixed-shape wave butterfly + LDS tree reduces them, thread 0 runs the
 //     partial-pivot LU (nalgebra order) and the quaternion update, and the rotation is broadcast
 //     through LDS.  The sum ORDER differs from the reference's sequential f32 sum, so results
 //     agree to rounding (<= 1e-6 on the quaternion), not bit for bit;
@@ -251,24 +252,26 @@ __device__ __forceinline__ Quat almeida_update(const Quat& rotation, const float
 constexpr int kIters = 30;                      // ceil(15 / ALPHA), lib.rs:132
 __device__ __forceinline__ float almeida_eps() { return 0.001f * 3.14159265358979323846264338327950288f / 180.0f; }
 
-// fixed-shape sum over a 1024-thread workgroup of 9 values per thread; result valid in thread 0
-__device__ __forceinline__ void block_sum9(float v[9], float (*red)[9]) {
+// fixed-shape sum over a 1024-thread workgroup of the values v[K0..K1) of every thread; result valid in thread 0.
+// (Each component is reduced independently, so reducing a sub-range gives the same bits as reducing all nine.)
+template <int K0, int K1>
+__device__ __forceinline__ void block_sum(float v[9], float (*red)[9]) {
 #pragma unroll
-    for (int k = 0; k < 9; ++k) {
+    for (int k = K0; k < K1; ++k) {
 #pragma unroll
         for (int m = 32; m >= 1; m >>= 1) v[k] += __shfl_xor(v[k], m, 64);
     }
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (lane == 0) {
 #pragma unroll
-        for (int k = 0; k < 9; ++k) red[wave][k] = v[k];
+        for (int k = K0; k < K1; ++k) red[wave][k] = v[k];
     }
     __syncthreads();
     // second level: the first 16 lanes of wave 0 hold one wave-partial each and finish with a 4-step butterfly
     if (threadIdx.x < 64) {
         const int nw = blockDim.x >> 6;
 #pragma unroll
-        for (int k = 0; k < 9; ++k) {
+        for (int k = K0; k < K1; ++k) {
             float x = (lane < nw) ? red[lane][k] : 0.0f;
 #pragma unroll
             for (int m = 8; m >= 1; m >>= 1) x += __shfl_xor(x, m, 64);
@@ -276,15 +279,22 @@ __device__ __forceinline__ void block_sum9(float v[9], float (*red)[9]) {
         }
     }
 }
+__device__ __forceinline__ void block_sum9(float v[9], float (*red)[9]) { block_sum<0, 9>(v, red); }
 
 // ---- small problems: one workgroup per item, EPT entries per thread, all 30 steps in-kernel.
 // n_dev (optional): per-item entry count on the device (RANSAC refit); stride = entries per item.
+// The normal matrix A = J^T J is built from the three epsilon-prototypes only (lib.rs:159-173), which do not depend
+// on the rotation being refined: the reference recomputes it in every step and gets the same numbers every time, so
+// it is summed once here.  EPT = 8 keeps two of the three prototype pairs in LDS (128 KB) instead of registers:
+// 13 floats x 8 entries per thread do not fit the 128 VGPRs a 1024-thread workgroup leaves (117 spilled before).
 template <int EPT>
 __global__ __launch_bounds__(1024) void almeida_lsq_wg_kernel(const float4* __restrict__ entries, size_t stride,
                                                               size_t n_fixed, const uint32_t* __restrict__ n_dev,
                                                               uint32_t min_n, Camera cam, float4* __restrict__ out_quat) {
+    constexpr bool P_LDS = EPT >= 8;
     __shared__ float red[16][9];
     __shared__ Quat rot_sh;
+    __shared__ float4 plds[P_LDS ? EPT * 1024 : 1];     // (roll.x, roll.y, pitch.x, pitch.y) per entry
     const size_t item = blockIdx.x;
     const size_t n = n_dev ? (size_t)n_dev[item] : n_fixed;
     const float eps = almeida_eps();
@@ -296,41 +306,61 @@ __global__ __launch_bounds__(1024) void almeida_lsq_wg_kernel(const float4* __re
     const Mat3 mpitch = mat3_from_euler(eps, 0.0f, 0.0f);          // lib.rs:36-38
     const Mat3 myaw = mat3_from_euler(0.0f, 0.0f, -eps);           // lib.rs:40-42
     float4 e[EPT];
-    float2 pr[EPT], pp[EPT], py[EPT];
-    Unproj un[EPT];
+    float2 pr[P_LDS ? 1 : EPT], pp[P_LDS ? 1 : EPT], py[EPT];
+    float uwx[EPT], uwz[EPT];                                       // Unproj::wy = -1/n0 is the same for every entry
+    float uwy = 0.0f;
     bool ok[EPT];
+    float s[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
     for (int t = 0; t < EPT; ++t) {
         const size_t i = (size_t)t * 1024 + threadIdx.x;
         ok[t] = i < n;
         e[t] = ok[t] ? entries[item * stride + i] : make_float4(0.5f, 0.5f, 0.0f, 0.0f);
-        un[t] = cam_unproject(cam, e[t].x, e[t].y);
-        pr[t] = cam_delta_w(cam, e[t].x, e[t].y, un[t], mroll);
-        pp[t] = cam_delta_w(cam, e[t].x, e[t].y, un[t], mpitch);
-        py[t] = cam_delta_w(cam, e[t].x, e[t].y, un[t], myaw);
+        const Unproj un = cam_unproject(cam, e[t].x, e[t].y);
+        uwx[t] = un.wx; uwz[t] = un.wz; uwy = un.wy;
+        const float2 r = cam_delta_w(cam, e[t].x, e[t].y, un, mroll);
+        const float2 p = cam_delta_w(cam, e[t].x, e[t].y, un, mpitch);
+        py[t] = cam_delta_w(cam, e[t].x, e[t].y, un, myaw);
+        if constexpr (P_LDS) plds[t * 1024 + threadIdx.x] = make_float4(r.x, r.y, p.x, p.y);
+        else { pr[t] = r; pp[t] = p; }
+        if (ok[t]) {
+            s[0] += r.x * r.x + r.y * r.y;
+            s[1] += r.x * p.x + r.y * p.y;
+            s[2] += r.x * py[t].x + r.y * py[t].y;
+            s[3] += p.x * p.x + p.y * p.y;
+            s[4] += p.x * py[t].x + p.y * py[t].y;
+            s[5] += py[t].x * py[t].x + py[t].y * py[t].y;
+        }
     }
+    block_sum<0, 6>(s, red);
+    float a[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) a[k] = s[k];                       // valid in thread 0, which is the only reader
+    __syncthreads();
     Quat rotation = {1.0f, 0.0f, 0.0f, 0.0f};
     for (int it = 0; it < kIters; ++it) {
         const float alpha = (it == kIters - 1) ? 1.0f : 0.5f;      // lib.rs:138
         const Mat3 rotm = quat_to_mat3(rotation);                  // lib.rs:140
-        float s[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        s[6] = 0.0f; s[7] = 0.0f; s[8] = 0.0f;
 #pragma unroll
         for (int t = 0; t < EPT; ++t) {
             if (!ok[t]) continue;
-            const float2 d = cam_delta_w(cam, e[t].x, e[t].y, un[t], rotm);
+            const Unproj un = {uwx[t], uwy, uwz[t]};
+            const float2 d = cam_delta_w(cam, e[t].x, e[t].y, un, rotm);
             const float rx = e[t].z - d.x, ry = e[t].w - d.y;      // motion - delta
-            s[0] += pr[t].x * pr[t].x + pr[t].y * pr[t].y;
-            s[1] += pr[t].x * pp[t].x + pr[t].y * pp[t].y;
-            s[2] += pr[t].x * py[t].x + pr[t].y * py[t].y;
-            s[3] += pp[t].x * pp[t].x + pp[t].y * pp[t].y;
-            s[4] += pp[t].x * py[t].x + pp[t].y * py[t].y;
-            s[5] += py[t].x * py[t].x + py[t].y * py[t].y;
-            s[6] += pr[t].x * rx + pr[t].y * ry;
-            s[7] += pp[t].x * rx + pp[t].y * ry;
+            float2 r, p;
+            if constexpr (P_LDS) { const float4 v = plds[t * 1024 + threadIdx.x]; r = make_float2(v.x, v.y); p = make_float2(v.z, v.w); }
+            else { r = pr[t]; p = pp[t]; }
+            s[6] += r.x * rx + r.y * ry;
+            s[7] += p.x * rx + p.y * ry;
             s[8] += py[t].x * rx + py[t].y * ry;
         }
-        block_sum9(s, red);
-        if (threadIdx.x == 0) rot_sh = almeida_update(rotation, s, eps, alpha);
+        block_sum<6, 9>(s, red);
+        if (threadIdx.x == 0) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) s[k] = a[k];
+            rot_sh = almeida_update(rotation, s, eps, alpha);
+        }
         __syncthreads();
         rotation = rot_sh;
         __syncthreads();
@@ -589,10 +619,13 @@ __global__ __launch_bounds__(1024) void ransac_select_kernel(const float4* __res
 static int lsq_device(ofps_hip_ctx* ctx, const float4* d_entries, size_t stride, size_t n_max, const uint32_t* d_n,
                       uint32_t min_n, int batch, const Camera& cam, float4* d_quat) {
     hipStream_t s = ctx->stream;
-    // One-workgroup solver: one launch, 30 steps at ~13 us each on a single CU -- best for batches (one CU
-    // per item) and mandatory when the entry count lives on the device (RANSAC refit).  A lone problem is
-    // faster spread over many CUs with one launch per step.
-    const bool wg_path = n_max <= 8192 && (d_n != nullptr || batch >= 4 || n_max <= 1024);
+    // One-workgroup solver: one launch, 30 steps at 2.5-6 us each on a single CU (tools/almeida_paths.py: 0.076 ms at
+    // N = 576, 0.185 ms at N = 8,040, flat up to 256 items) -- faster than one launch per step (>= 0.24 ms) for every
+    // N it can hold, and mandatory when the entry count lives on the device (RANSAC refit).
+    bool wg_path = n_max <= 8192;
+    if (const char* force = getenv("OFPS_HIP_ALMEIDA_PATH")) {          // A/B experiments only
+        if (!strcmp(force, "step") && d_n == nullptr) wg_path = false;
+    }
     if (wg_path) {
         const dim3 g(batch), b(1024);
         if (n_max <= 1024) hipLaunchKernelGGL((almeida_lsq_wg_kernel<1>), g, b, 0, s, d_entries, stride, n_max, d_n, min_n, cam, d_quat);
