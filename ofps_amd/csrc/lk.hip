@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256) void lk_tensor_tiled_kernel(const float* __res
 }
 
 template <int RADIUS>
-__global__ __launch_bounds__(256) void lk_step_tiled_kernel(const float* __restrict__ I, const float* __restrict__ J,
+__global__ __launch_bounds__(256, (RADIUS <= 4 ? 4 : 2)) void lk_step_tiled_kernel(const float* __restrict__ I, const float* __restrict__ J,
                                                             const float* __restrict__ gx, const float* __restrict__ gy,
                                                             const float4* __restrict__ G, int w, int h,
                                                             const float2* __restrict__ flow_in, float2* __restrict__ flow_out) {
