@@ -64,19 +64,32 @@ def luma_sequence(n_frames: int, width: int, height: int, max_step: int, seed: i
     yy, xx = np.meshgrid(np.arange(height, dtype=np.int64), np.arange(width, dtype=np.int64), indexing="ij")
     reg_id = (yy // region) * rx + (xx // region)
     ridx = np.arange(rx * ry, dtype=np.uint32)
-    off = np.zeros((rx * ry, 2), np.int64)
     out = np.zeros((n_frames, height, stride), np.uint8)
     span = 2 * max_step + 1
+    # per-frame region offsets first, then ONE evaluation of the texture over the bounding box of every coordinate
+    # any frame samples (the texture is a pure function of integer coordinates, so gathering from that canvas gives
+    # the same bytes as evaluating it per frame, at a fraction of the cost)
+    offs = np.zeros((n_frames, rx * ry, 2), np.int64)
+    for k in range(1, n_frames):
+        with np.errstate(over="ignore"):
+            hx = _hash_u32(ridx * np.uint32(2654435761) + np.uint32((seed + 101 * k) & 0xFFFFFFFF))
+            hy = _hash_u32(hx + np.uint32(0x68E31DA4))
+        offs[k, :, 0] = offs[k - 1, :, 0] + (hx % np.uint32(span)).astype(np.int64) - max_step
+        offs[k, :, 1] = offs[k - 1, :, 1] + (hy % np.uint32(span)).astype(np.int64) - max_step
+    lo_x, hi_x = int(offs[..., 0].min()), int(offs[..., 0].max())
+    lo_y, hi_y = int(offs[..., 1].min()), int(offs[..., 1].max())
+    cw, ch = width + hi_x - lo_x, height + hi_y - lo_y
+    if cw * ch <= 64 * 1024 * 1024:
+        cyy, cxx = np.meshgrid(np.arange(ch, dtype=np.int64) + lo_y + 100000, np.arange(cw, dtype=np.int64) + lo_x + 100000, indexing="ij")
+        canvas = _texture(cxx, cyy, seed)
+    else:
+        canvas = None                                     # very long sequences: fall back to per-frame evaluation
     for k in range(n_frames):
-        if k > 0:
-            with np.errstate(over="ignore"):
-                hx = _hash_u32(ridx * np.uint32(2654435761) + np.uint32((seed + 101 * k) & 0xFFFFFFFF))
-                hy = _hash_u32(hx + np.uint32(0x68E31DA4))
-            off[:, 0] += (hx % np.uint32(span)).astype(np.int64) - max_step
-            off[:, 1] += (hy % np.uint32(span)).astype(np.int64) - max_step
-        xs = xx + off[reg_id, 0] + 100000
-        ys = yy + off[reg_id, 1] + 100000
-        tex = _texture(xs, ys, seed)
+        off = offs[k]
+        if canvas is not None:
+            tex = canvas[yy + off[reg_id, 1] - lo_y, xx + off[reg_id, 0] - lo_x]
+        else:
+            tex = _texture(xx + off[reg_id, 0] + 100000, yy + off[reg_id, 1] + 100000, seed)
         img = np.float32(16.0) + tex * np.float32(219.0)
         if noise:
             with np.errstate(over="ignore"):
