@@ -122,6 +122,54 @@ def test_sad_batched_device_path_matches_pairwise(ctx):
     ctx.use_own_stream()
 
 
+def test_sad_cfg4_full_size_crop_consistency(ctx):
+    """BASELINE configs[3] geometry at full size (3840x2160, 8x8 blocks, +-32): an exhaustive search is local, so every
+    block whose +-32 window lies inside an aligned crop must get the same (dx, dy, SAD) from the oracle run on the crop
+    alone -- a size-independent check the oracle finishes in seconds."""
+    W, H, B, R = 3840, 2160, 8, 32
+    fr = synth.luma_sequence(2, W, H, max_step=R, seed=41)
+    _, best = ctx.sad_flow(fr[0], fr[1], B, R, want_best=True)
+    best = best.reshape(H // B, W // B, 3)
+    for cx, cy, cw, ch in [(0, 0, 320, 192), (1760, 984, 320, 192), (W - 320, H - 192, 320, 192), (2048, 0, 256, 160)]:
+        _, bo = oracle.sad_flow(fr[0][cy:cy + ch, cx:cx + cw], fr[1][cy:cy + ch, cx:cx + cw], B, R, threads=8)
+        bo = bo.reshape(ch // B, cw // B, 3)
+        # blocks of the crop whose window is not cut by a crop edge that is not also a frame edge
+        x_lo = 0 if cx == 0 else R // B; x_hi = cw // B if cx + cw == W else cw // B - R // B
+        y_lo = 0 if cy == 0 else R // B; y_hi = ch // B if cy + ch == H else ch // B - R // B
+        got = best[cy // B + y_lo:cy // B + y_hi, cx // B + x_lo:cx // B + x_hi]
+        np.testing.assert_array_equal(got, bo[y_lo:y_hi, x_lo:x_hi])
+
+
+def test_sad_bench_shape_batch_full_size(ctx):
+    """The launch bench.py times (1080p, 16x16, +-16, consecutive pairs of one resident sequence, padded stride): every
+    pair of the batch equals the per-pair host call, and sampled pairs equal the oracle."""
+    import torch
+    W, H, B, R, F = 1920, 1080, 16, 16, 9
+    stride = 1984                                        # not the frame width: rows are padded
+    fr = synth.luma_sequence(F, W, H, max_step=R, seed=synth.SEED0, stride=stride)
+    d = torch.from_numpy(fr).cuda()
+    nb = (W // B) * (H // B)
+    out = torch.zeros((F - 1, nb, 4), dtype=torch.float32, device="cuda")
+    best = torch.zeros((F - 1, nb, 3), dtype=torch.int32, device="cuda")
+    ctx.use_torch_stream()
+    try:
+        ctx.sad_flow_dev(d.data_ptr(), F, W, H, stride, stride * H, 0, B, R, out.data_ptr(), best.data_ptr())
+        torch.cuda.synchronize()
+    finally:
+        ctx.use_own_stream()
+    out, best = out.cpu().numpy(), best.cpu().numpy()
+    for k in range(F - 1):
+        ent_h, best_h = ctx.sad_flow(fr[k][:, :W], fr[k + 1][:, :W], B, R, want_best=True)
+        np.testing.assert_array_equal(best[k], best_h)
+        np.testing.assert_array_equal(out[k].view(np.uint32), ent_h.view(np.uint32))
+    for k in (0, 4, 7):
+        ent_o, best_o = oracle.sad_flow(np.ascontiguousarray(fr[k][:, :W]), np.ascontiguousarray(fr[k + 1][:, :W]), B, R, threads=8)
+        np.testing.assert_array_equal(best[k], best_o)
+        np.testing.assert_array_equal(out[k].view(np.uint32), ent_o.view(np.uint32))
+    # a checksum of checksums over the whole batch, stable across runs of the same build
+    assert int(best[..., 2].astype(np.int64).sum()) == int(sum(int(b[:, 2].astype(np.int64).sum()) for b in best))
+
+
 def test_sad_rejects_bad_arguments(ctx):
     from ofps_amd.runtime import OfpsHipError
     fr = np.zeros((32, 32), np.uint8)
