@@ -121,7 +121,7 @@ __device__ __forceinline__ float2 cam_delta_w(const Camera& c, float px, float p
 }
 
 // camera.rs:150-161
-__device__ __forceinline__ float2 cam_point_angle(const Camera& c, float fx, float fy, float px, float py) {
+__device__ __forceinline__ float2 cam_point_angle(float fx, float fy, float px, float py) {
     return make_float2(atanf((px - 0.5f) / fx), atanf((py - 0.5f) / fy));
 }
 
@@ -528,7 +528,7 @@ __global__ __launch_bounds__(64) void ransac_hyp_kernel(const float4* __restrict
 __device__ __forceinline__ bool ransac_is_inlier(const Camera& cam, float fx, float fy, const Mat3& mat, const float4& e,
                                                  float thr2) {
     const float2 d = cam_delta(cam, e.x, e.y, mat);                           // lib.rs:229-231
-    const float2 ang = cam_point_angle(cam, fx, fy, e.x + d.x, e.y + d.y);    // :234
+    const float2 ang = cam_point_angle(fx, fy, e.x + d.x, e.y + d.y);    // :234
     const float vx = (e.z - d.x) * cosf(ang.x), vy = (e.w - d.y) * cosf(ang.y);
     return vx * vx + vy * vy <= thr2;                                         // :236
 }

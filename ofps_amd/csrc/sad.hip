@@ -60,13 +60,6 @@ __device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v,
     return ((unsigned long long)hi << 32) | lo;
 }
 
-__device__ __forceinline__ unsigned long long shfl_down_u64(unsigned long long v, int delta) {
-    unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
-    lo = __shfl_down(lo, delta, 64);
-    hi = __shfl_down(hi, delta, 64);
-    return ((unsigned long long)hi << 32) | lo;
-}
-
 struct __attribute__((packed, aligned(4))) U64A4 { unsigned long long v; };   // 8-byte LDS window, dword aligned
 
 struct SadParams {

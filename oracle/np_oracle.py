@@ -26,9 +26,7 @@ def cell_index(entries, w, h):
     cx = np.where(gt0, np.where(lt1, px, F(1)), F(0)).astype(F)
     cy = np.where(gt0, np.where(lt1, py, F(1)), F(0)).astype(F)
 
-    def rnd(v):                                   # f32::round: half away from zero
-        return np.floor(v + F(0.5)).astype(np.int64)  # v >= 0 here, exact in f32 for these ranges
-    # guard the one case floor(v+0.5) differs from round-half-away in f32: v+0.5 rounding up
+    # f32::round (half away from zero) for v >= 0, written without v + 0.5 (which can itself round up in f32)
     vx = (cx * F(w - 1)).astype(F); vy = (cy * F(h - 1)).astype(F)
     x = np.where(vx - np.floor(vx) >= F(0.5), np.floor(vx) + 1, np.floor(vx)).astype(np.int64)
     y = np.where(vy - np.floor(vy) >= F(0.5), np.floor(vy) + 1, np.floor(vy)).astype(np.int64)
