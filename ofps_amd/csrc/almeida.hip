@@ -161,53 +161,69 @@ __device__ __forceinline__ Mat3 quat_to_mat3(const Quat& q) {                   
 }
 
 // Matrix3::lu().solve.  a is row-major; returns false when a U diagonal is exactly 0.
+// Rows live in named registers and the pivot exchange is a chain of compile-time-indexed conditional swaps: a
+// run-time row index (m[3 * piv + c]) sends the whole matrix to scratch memory.
+__device__ __forceinline__ void lu3_swap_rows(bool doit, float (&ra)[3], float (&rb)[3], float& ba, float& bb) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { const float t = ra[c]; ra[c] = doit ? rb[c] : ra[c]; rb[c] = doit ? t : rb[c]; }
+    const float t = ba; ba = doit ? bb : ba; bb = doit ? t : bb;
+}
+
 __device__ __forceinline__ bool lu3_solve(const float a_in[9], const float b_in[3], float x[3]) {
-    float m[9];
+    float r0[3] = {a_in[0], a_in[1], a_in[2]}, r1[3] = {a_in[3], a_in[4], a_in[5]}, r2[3] = {a_in[6], a_in[7], a_in[8]};
+    float b0 = b_in[0], b1 = b_in[1], b2 = b_in[2];
+    // ---- column 0: pivot = first row of maximal |.| (strict >), rows 0..2
+    {
+        int piv = 0;
+        float best = fabsf(r0[0]);
+        if (fabsf(r1[0]) > best) { best = fabsf(r1[0]); piv = 1; }
+        if (fabsf(r2[0]) > best) { piv = 2; }
+        const float diag = piv == 0 ? r0[0] : (piv == 1 ? r1[0] : r2[0]);
+        if (diag != 0.0f) {
+            lu3_swap_rows(piv == 1, r0, r1, b0, b1);
+            lu3_swap_rows(piv == 2, r0, r2, b0, b2);
+            const float inv_diag = 1.0f / diag;
+            r1[0] *= inv_diag; r2[0] *= inv_diag;
 #pragma unroll
-    for (int t = 0; t < 9; ++t) m[t] = a_in[t];
-    float b[3] = {b_in[0], b_in[1], b_in[2]};
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        int piv = i;
-        float best = fabsf(m[3 * i + i]);
-#pragma unroll
-        for (int r = i + 1; r < 3; ++r) {
-            const float v = fabsf(m[3 * r + i]);
-            if (v > best) { best = v; piv = r; }
-        }
-        const float diag = m[3 * piv + i];
-        if (diag == 0.0f) continue;
-        if (piv != i) {
-#pragma unroll
-            for (int c = 0; c < 3; ++c) { const float t = m[3 * i + c]; m[3 * i + c] = m[3 * piv + c]; m[3 * piv + c] = t; }
-            const float t = b[i]; b[i] = b[piv]; b[piv] = t;    // row permutation applied to b on the fly
-        }
-        const float inv_diag = 1.0f / diag;
-#pragma unroll
-        for (int r = i + 1; r < 3; ++r) m[3 * r + i] *= inv_diag;
-#pragma unroll
-        for (int c = i + 1; c < 3; ++c) {
-            const float neg = -m[3 * i + c];
-#pragma unroll
-            for (int r = i + 1; r < 3; ++r) m[3 * r + c] = neg * m[3 * r + i] + m[3 * r + c];
+            for (int c = 1; c < 3; ++c) {
+                const float neg = -r0[c];
+                r1[c] = neg * r1[0] + r1[c];
+                r2[c] = neg * r2[0] + r2[c];
+            }
         }
     }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const float coeff = b[i] / 1.0f;
-#pragma unroll
-        for (int r = i + 1; r < 3; ++r) b[r] = (-coeff) * m[3 * r + i] + b[r];
+    // ---- column 1: rows 1..2
+    {
+        const bool p2 = fabsf(r2[1]) > fabsf(r1[1]);
+        const float diag = p2 ? r2[1] : r1[1];
+        if (diag != 0.0f) {
+            lu3_swap_rows(p2, r1, r2, b1, b2);
+            const float inv_diag = 1.0f / diag;
+            r2[1] *= inv_diag;
+            const float neg = -r1[2];
+            r2[2] = neg * r2[1] + r2[2];
+        }
     }
-#pragma unroll
-    for (int i = 2; i >= 0; --i) {
-        const float diag = m[3 * i + i];
-        if (diag == 0.0f) return false;
-        const float coeff = b[i] / diag;
-        b[i] = coeff;
-#pragma unroll
-        for (int r = 0; r < i; ++r) b[r] = (-coeff) * m[3 * r + i] + b[r];
+    // ---- column 2: nothing below the diagonal; a zero diagonal is caught by the back substitution
+    // forward substitution with the unit-lower factor (nalgebra divides by the unit diagonal: b / 1)
+    {
+        const float c0 = b0 / 1.0f;
+        b1 = (-c0) * r1[0] + b1;
+        b2 = (-c0) * r2[0] + b2;
+        const float c1 = b1 / 1.0f;
+        b2 = (-c1) * r2[1] + b2;
     }
-    x[0] = b[0]; x[1] = b[1]; x[2] = b[2];
+    // back substitution with U
+    if (r2[2] == 0.0f) return false;
+    const float x2 = b2 / r2[2];
+    b0 = (-x2) * r0[2] + b0;
+    b1 = (-x2) * r1[2] + b1;
+    if (r1[1] == 0.0f) return false;
+    const float x1 = b1 / r1[1];
+    b0 = (-x1) * r0[1] + b0;
+    if (r0[0] == 0.0f) return false;
+    const float x0 = b0 / r0[0];
+    x[0] = x0; x[1] = x1; x[2] = x2;
     return true;
 }
 
@@ -293,7 +309,7 @@ __global__ __launch_bounds__(1024) void almeida_lsq_wg_kernel(const float4* __re
                                                               uint32_t min_n, Camera cam, float4* __restrict__ out_quat) {
     constexpr bool P_LDS = EPT >= 8;
     __shared__ float red[16][9];
-    __shared__ Quat rot_sh;
+    __shared__ Quat rot_sh[2];
     __shared__ float4 plds[P_LDS ? EPT * 1024 : 1];     // (roll.x, roll.y, pitch.x, pitch.y) per entry
     const size_t item = blockIdx.x;
     const size_t n = n_dev ? (size_t)n_dev[item] : n_fixed;
@@ -359,11 +375,13 @@ __global__ __launch_bounds__(1024) void almeida_lsq_wg_kernel(const float4* __re
         if (threadIdx.x == 0) {
 #pragma unroll
             for (int k = 0; k < 6; ++k) s[k] = a[k];
-            rot_sh = almeida_update(rotation, s, eps, alpha);
+            rot_sh[it & 1] = almeida_update(rotation, s, eps, alpha);
         }
         __syncthreads();
-        rotation = rot_sh;
-        __syncthreads();
+        // one barrier per step: the slot alternates, so thread 0 cannot overwrite a rotation that a slow wave has yet
+        // to read (it gets back to this slot only after everybody passed the next step's barrier), and `red` is not
+        // written again before this barrier, which wave 0 reaches only after its second-level read
+        rotation = rot_sh[it & 1];
     }
     if (threadIdx.x == 0) out_quat[item] = make_float4(rotation.w, -rotation.i, -rotation.j, -rotation.k);  // :199
 }
@@ -493,6 +511,7 @@ __global__ __launch_bounds__(64) void ransac_hyp_kernel(const float4* __restrict
     float2 pr[3], pp[3], py[3];
     const Mat3 mroll = mat3_from_euler(0.0f, eps, 0.0f), mpitch = mat3_from_euler(eps, 0.0f, 0.0f),
                myaw = mat3_from_euler(0.0f, 0.0f, -eps);
+#pragma unroll
     for (uint32_t j = 0; j < 3; ++j) {
         if (j < n3) {
             e[j] = entries[item * n + sample_index(sk, j, n)];
@@ -501,20 +520,29 @@ __global__ __launch_bounds__(64) void ransac_hyp_kernel(const float4* __restrict
             py[j] = cam_delta(cam, e[j].x, e[j].y, myaw);
         }
     }
+    // A = J^T J depends on the prototypes only: summed once, in sample order (the reference re-adds the same
+    // numbers in every step, lib.rs:159-173)
+    float a[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (uint32_t j = 0; j < 3; ++j) {
+        if (j >= n3) break;
+        a[0] += pr[j].x * pr[j].x + pr[j].y * pr[j].y;
+        a[1] += pr[j].x * pp[j].x + pr[j].y * pp[j].y;
+        a[2] += pr[j].x * py[j].x + pr[j].y * py[j].y;
+        a[3] += pp[j].x * pp[j].x + pp[j].y * pp[j].y;
+        a[4] += pp[j].x * py[j].x + pp[j].y * py[j].y;
+        a[5] += py[j].x * py[j].x + py[j].y * py[j].y;
+    }
     Quat rotation = {1.0f, 0.0f, 0.0f, 0.0f};
     for (int s_it = 0; s_it < kIters; ++s_it) {
         const float alpha = (s_it == kIters - 1) ? 1.0f : 0.5f;
         const Mat3 rotm = quat_to_mat3(rotation);
-        float s[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-        for (uint32_t j = 0; j < n3; ++j) {
+        float s[9] = {a[0], a[1], a[2], a[3], a[4], a[5], 0, 0, 0};
+#pragma unroll
+        for (uint32_t j = 0; j < 3; ++j) {              // compile-time indices keep e/pr/pp/py in registers
+            if (j >= n3) break;
             const float2 d = cam_delta(cam, e[j].x, e[j].y, rotm);
             const float rx = e[j].z - d.x, ry = e[j].w - d.y;
-            s[0] += pr[j].x * pr[j].x + pr[j].y * pr[j].y;
-            s[1] += pr[j].x * pp[j].x + pr[j].y * pp[j].y;
-            s[2] += pr[j].x * py[j].x + pr[j].y * py[j].y;
-            s[3] += pp[j].x * pp[j].x + pp[j].y * pp[j].y;
-            s[4] += pp[j].x * py[j].x + pp[j].y * py[j].y;
-            s[5] += py[j].x * py[j].x + py[j].y * py[j].y;
             s[6] += pr[j].x * rx + pr[j].y * ry;
             s[7] += pp[j].x * rx + pp[j].y * ry;
             s[8] += py[j].x * rx + py[j].y * ry;
