@@ -233,3 +233,72 @@ def contrast_mask(gray):
         for dx in range(-hw[i], hw[i] + 1):
             out |= tp[5 + dy:5 + dy + H, 5 + dx:5 + dx + W]
     return out.astype(np.uint8)
+
+
+def _lk_pyr_down(img):
+    """[1 4 6 4 1]/16 separable blur with replicated border, every second sample (orc lk_pyr_down)."""
+    h, w = img.shape
+    w1, h1 = (w + 1) // 2, (h + 1) // 2
+    xs = np.arange(w1) * 2
+    def tap(a, idx, n, axis):
+        return np.take(a, np.clip(idx, 0, n - 1), axis=axis)
+    t = ((((tap(img, xs - 2, w, 1) + F(4) * tap(img, xs - 1, w, 1)) + F(6) * tap(img, xs, w, 1))
+          + F(4) * tap(img, xs + 1, w, 1)) + tap(img, xs + 2, w, 1)) * F(0.0625)
+    ys = np.arange(h1) * 2
+    o = ((((tap(t, ys - 2, h, 0) + F(4) * tap(t, ys - 1, h, 0)) + F(6) * tap(t, ys, h, 0))
+          + F(4) * tap(t, ys + 1, h, 0)) + tap(t, ys + 2, h, 0)) * F(0.0625)
+    return o.astype(F)
+
+
+def _lk_bilinear(J, fx, fy):
+    h, w = J.shape
+    x0f, y0f = np.floor(fx), np.floor(fy)
+    ax, ay = (fx - x0f).astype(F), (fy - y0f).astype(F)
+    x0 = np.clip(x0f, -1.0, float(w)).astype(np.int64)
+    y0 = np.clip(y0f, -1.0, float(h)).astype(np.int64)
+    xa, xb = np.clip(x0, 0, w - 1), np.clip(x0 + 1, 0, w - 1)
+    ya, yb = np.clip(y0, 0, h - 1), np.clip(y0 + 1, 0, h - 1)
+    j00, j10, j01, j11 = J[ya, xa], J[ya, xb], J[yb, xa], J[yb, xb]
+    top = (j00 + ax * (j10 - j00)).astype(F)
+    bot = (j01 + ax * (j11 - j01)).astype(F)
+    return (top + ay * (bot - top)).astype(F)
+
+
+def lk_flow(prev, cur, levels=3, radius=4, iters=3):
+    """Second restatement of the build-defined pyramidal LK (oracle/ofps_oracle.c:orc_lk_flow): same f32 operations in the
+    same order, vectorised over pixels with explicit loops over the window taps -> the same bits."""
+    I = [np.asarray(prev, np.uint8).astype(F)]
+    J = [np.asarray(cur, np.uint8).astype(F)]
+    for _ in range(1, levels):
+        I.append(_lk_pyr_down(I[-1])); J.append(_lk_pyr_down(J[-1]))
+    flow = None
+    for l in range(levels - 1, -1, -1):
+        Il, Jl = I[l], J[l]
+        h, w = Il.shape
+        yy, xx = np.meshgrid(np.arange(h), np.arange(w), indexing="ij")
+        if flow is None:
+            u = np.zeros((h, w), F); v = np.zeros((h, w), F)
+        else:
+            h1, w1 = flow[0].shape
+            sy, sx = np.clip(yy // 2, 0, h1 - 1), np.clip(xx // 2, 0, w1 - 1)
+            u = (F(2) * flow[0][sy, sx]).astype(F); v = (F(2) * flow[1][sy, sx]).astype(F)
+        gx = ((Il[yy, np.clip(xx + 1, 0, w - 1)] - Il[yy, np.clip(xx - 1, 0, w - 1)]) * F(0.5)).astype(F)
+        gy = ((Il[np.clip(yy + 1, 0, h - 1), xx] - Il[np.clip(yy - 1, 0, h - 1), xx]) * F(0.5)).astype(F)
+        for _ in range(iters):
+            gxx = np.zeros((h, w), F); gxy = np.zeros((h, w), F); gyy = np.zeros((h, w), F)
+            bx = np.zeros((h, w), F); by = np.zeros((h, w), F)
+            for dy in range(-radius, radius + 1):
+                for dx in range(-radius, radius + 1):
+                    qx, qy = np.clip(xx + dx, 0, w - 1), np.clip(yy + dy, 0, h - 1)
+                    ix, iy = gx[qy, qx], gy[qy, qx]
+                    d = (Il[qy, qx] - _lk_bilinear(Jl, (qx.astype(F) + u).astype(F), (qy.astype(F) + v).astype(F))).astype(F)
+                    gxx = (gxx + ix * ix).astype(F); gxy = (gxy + ix * iy).astype(F); gyy = (gyy + iy * iy).astype(F)
+                    bx = (bx + ix * d).astype(F); by = (by + iy * d).astype(F)
+            det = (gxx * gyy - gxy * gxy).astype(F)
+            ok = det > F(0.01)
+            with np.errstate(divide="ignore", invalid="ignore"):
+                du = np.where(ok, ((gyy * bx - gxy * by).astype(F) / det).astype(F), F(0)).astype(F)
+                dv = np.where(ok, ((gxx * by - gxy * bx).astype(F) / det).astype(F), F(0)).astype(F)
+            u = (u + du).astype(F); v = (v + dv).astype(F)
+        flow = (u, v)
+    return np.stack(flow, axis=-1).astype(F)

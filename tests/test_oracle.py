@@ -224,3 +224,13 @@ def test_masked_records_keep_raster_order():
     full = oracle.flow_to_entries(flow)
     np.testing.assert_array_equal(oracle.masked_flow_to_entries(flow, mask), full[mask.reshape(-1) != 0])
     np.testing.assert_array_equal(oracle.masked_flow_to_entries(flow, None), full)
+
+
+@pytest.mark.parametrize("W,H,levels,radius,iters", [(64, 48, 3, 4, 3), (97, 61, 2, 2, 2), (40, 30, 1, 6, 2), (33, 17, 3, 1, 4)])
+def test_lk_flow_c_vs_numpy_bit_exact(W, H, levels, radius, iters):
+    """N2 is build-defined (the reference calls OpenCV): two independent restatements of the spec must agree bit for bit,
+    so a self-consistent-but-wrong C oracle cannot hide behind the GPU parity tests."""
+    fr = synth.luma_sequence(2, W, H, max_step=2, seed=W + H)
+    a = npo.lk_flow(fr[0], fr[1], levels, radius, iters)
+    b = oracle.lk_flow(fr[0], fr[1], levels, radius, iters)
+    np.testing.assert_array_equal(a.view(np.uint32), b.view(np.uint32))
