@@ -246,8 +246,13 @@ struct StripCfg {
     static_assert(B % 4 == 0 && R % 4 == 0, "tile origin and the dx = +R column must stay dword aligned");
     static_assert(B * B * 255 <= 65535, "packed u16 SAD accumulators would overflow");
     static constexpr int NCAND = 2 * R + 1;
-    static constexpr int NG = (2 * R) / 4;                   // dx groups of 4 covering [-R, R-1]
-    static_assert(NG >= 1 && 64 % NG == 0 && (NG & (NG - 1)) == 0, "NG must be a power of two dividing 64");
+    static constexpr int NGA = (2 * R) / 4;                  // active dx groups of 4 covering [-R, R-1]
+    static constexpr int pow2_ceil(int v) { int p = 1; while (p < v) p <<= 1; return p; }
+    // lanes per block: the next power of two, so the cross-lane argmin stays an aligned xor butterfly; for ranges
+    // whose group count is not a power of two (+-12, 20, 24, 28) the lanes g >= NGA idle in the main pass (12-37 %)
+    // -- still 20x the generic kernel
+    static constexpr int NG = pow2_ceil(NGA);
+    static_assert(NGA >= 1 && NG <= 64, "search range too wide for one wave per strip");
     static constexpr int NB = 64 / NG;                       // blocks per wave
     static constexpr int BW = B / 4;
     static constexpr int TILE_H = B + 2 * R;
@@ -453,7 +458,7 @@ __global__ __launch_bounds__(64 * kStripWaves, (StripCfg<B, R>::MIN_WAVES)) void
     for (int j = 0; j < 4; ++j) {
         const int dx = dx0 + j;
         const int x = bx * B + dx;
-        const bool v = blk_on && x >= 0 && x + B <= p.W;
+        const bool v = blk_on && g < C::NGA && x >= 0 && x + B <= p.W;
         colk[j] = v ? (uint32_t)(dx * dx) << C::KSHIFT : 0xFFFFFFFFu;
     }
     uint32_t bkey = 0xFFFFFFFFu;
@@ -942,6 +947,15 @@ int sad_pairs_device(ofps_hip_ctx* ctx, const uint8_t* prev_base, size_t prev_pi
             if (strip_ok) launch_strip<8, 16>(p, pairs, s); else launch_qsad<8, 16, 5>(p, pairs, s);
             break;
         case 8008: launch_qsad<8, 8, 3>(p, pairs, s); break;
+        // the other multiples of 4 inside the plugins' "Search range" property (8..32): strip kernel with idle lanes;
+        // unaligned rows fall through to the generic kernel
+#define OFPS_STRIP_CASE(BB, RR)                                         \
+        case BB * 1000 + RR:                                            \
+            if (strip_ok) { launch_strip<BB, RR>(p, pairs, s); break; } \
+            [[fallthrough]];
+        OFPS_STRIP_CASE(16, 12) OFPS_STRIP_CASE(16, 20) OFPS_STRIP_CASE(16, 24) OFPS_STRIP_CASE(16, 28)
+        OFPS_STRIP_CASE(8, 12) OFPS_STRIP_CASE(8, 20) OFPS_STRIP_CASE(8, 24) OFPS_STRIP_CASE(8, 28)
+#undef OFPS_STRIP_CASE
         default: {
             dim3 grid(p.nbx, p.nby, pairs);
             hipLaunchKernelGGL(sad_generic_kernel, grid, dim3(64), 0, s, p, block, range);

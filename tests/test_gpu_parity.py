@@ -31,6 +31,16 @@ SAD_CASES = [
     (100, 70, 16, 16, "seq"),      # ragged: partial blocks dropped, W % 4 == 0 but W % 16 != 0
     (192, 96, 16, 16, "random"),   # unstructured noise: many near-ties
     (192, 96, 16, 16, "flat"),     # constant frames: every candidate ties at SAD 0 -> key order decides
+    (256, 144, 16, 12, "seq"),     # ranges whose dx-group count is not a power of two: strip kernel with idle lanes
+    (320, 208, 16, 20, "seq"),
+    (256, 160, 16, 24, "seq"),
+    (384, 192, 16, 28, "seq"),
+    (200, 120, 8, 12, "seq"),
+    (256, 136, 8, 20, "seq"),
+    (256, 136, 8, 24, "random"),
+    (320, 200, 8, 28, "seq"),
+    (192, 96, 16, 24, "flat"),
+    (192, 112, 16, 10, "seq"),     # range not a multiple of 4: generic kernel
     (96, 96, 12, 5, "seq"),        # generic kernel (block/range outside the packed-SAD table)
     (64, 48, 32, 4, "seq"),        # generic kernel, SAD beyond 16 bits possible
 ]
