@@ -946,7 +946,9 @@ int sad_pairs_device(ofps_hip_ctx* ctx, const uint8_t* prev_base, size_t prev_pi
         case 8016:
             if (strip_ok) launch_strip<8, 16>(p, pairs, s); else launch_qsad<8, 16, 5>(p, pairs, s);
             break;
-        case 8008: launch_qsad<8, 8, 3>(p, pairs, s); break;
+        case 8008:
+            if (strip_ok) launch_strip<8, 8>(p, pairs, s); else launch_qsad<8, 8, 3>(p, pairs, s);
+            break;
         // the other multiples of 4 inside the plugins' "Search range" property (8..32): strip kernel with idle lanes;
         // unaligned rows fall through to the generic kernel
 #define OFPS_STRIP_CASE(BB, RR)                                         \
