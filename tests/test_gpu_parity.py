@@ -180,6 +180,29 @@ def test_sad_bench_shape_batch_full_size(ctx):
     assert int(best[..., 2].astype(np.int64).sum()) == int(sum(int(b[:, 2].astype(np.int64).sum()) for b in best))
 
 
+@pytest.mark.parametrize("B,R", [(16, 16), (16, 8), (8, 32), (8, 8), (16, 24)])
+def test_sad_device_path_with_rows_not_16_byte_aligned(ctx, B, R):
+    """Device-resident frames whose row stride is only 4-byte aligned cannot use the 16-byte staging of the strip kernel:
+    the per-block kernel (table geometries) or the generic kernel (others) must return the same bits."""
+    import torch
+    W, H, stride = 324, 200, 332
+    fr = synth.luma_sequence(3, W, H, max_step=min(R, 16), seed=B * 100 + R, stride=stride)
+    d = torch.from_numpy(fr).cuda()
+    nb = (W // B) * (H // B)
+    best = torch.zeros((2, nb, 3), dtype=torch.int32, device="cuda")
+    out = torch.zeros((2, nb, 4), dtype=torch.float32, device="cuda")
+    ctx.use_torch_stream()
+    try:
+        ctx.sad_flow_dev(d.data_ptr(), 3, W, H, stride, stride * H, 0, B, R, out.data_ptr(), best.data_ptr())
+        torch.cuda.synchronize()
+    finally:
+        ctx.use_own_stream()
+    for k in range(2):
+        ent_o, best_o = oracle.sad_flow(np.ascontiguousarray(fr[k][:, :W]), np.ascontiguousarray(fr[k + 1][:, :W]), B, R)
+        np.testing.assert_array_equal(best[k].cpu().numpy(), best_o)
+        np.testing.assert_array_equal(out[k].cpu().numpy().view(np.uint32), ent_o.view(np.uint32))
+
+
 def test_sad_rejects_bad_arguments(ctx):
     from ofps_amd.runtime import OfpsHipError
     fr = np.zeros((32, 32), np.uint8)
