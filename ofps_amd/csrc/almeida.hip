@@ -395,32 +395,81 @@ __global__ __launch_bounds__(1024) void almeida_lsq_step_kernel(const float4* __
                                                                 Camera cam, const float* __restrict__ part_prev,
                                                                 float* __restrict__ part_out, Quat* __restrict__ state,
                                                                 int batch, float4* __restrict__ out_quat) {
+    // dense variant: the first PRE entries of every thread are loaded, and everything about them that does not need the
+    // new rotation (unprojection, the three prototypes, the A sums) is computed, BEFORE the workgroup waits for the
+    // fold + update of the previous step -- that prologue is a chain of dependent global loads and ~400 serial
+    // instructions on one lane and used to cost 4 of the 16 us of a step with every other wave idle.  Two of the three
+    // prototype pairs wait in LDS (128 KB), the third and the entry in registers.
+    constexpr int PRE = FAST ? 8 : 0;
     __shared__ float red[16][9];
     __shared__ float fold_sh[9];
     __shared__ Quat rot_sh;
+    __shared__ float4 plds[FAST ? PRE * 1024 : 1];
     const size_t item = blockIdx.y;
     const int nblk = gridDim.x;
     const float eps = almeida_eps();
-    // fold the previous step's partials: wave k sums entry k over the workgroups (lane-strided, then a
+    const Mat3 mroll = mat3_from_euler(0.0f, eps, 0.0f);
+    const Mat3 mpitch = mat3_from_euler(eps, 0.0f, 0.0f);
+    const Mat3 myaw = mat3_from_euler(0.0f, 0.0f, -eps);
+    const size_t i0 = (size_t)blockIdx.x * 1024 + threadIdx.x, istride = (size_t)nblk * 1024;
+    // ---- fold the previous step's partials, part 1: wave k sums entry k over the workgroups (lane-strided, then a
     // butterfly) -- a fixed order, identical in every workgroup, without a 9*nblk serial chain on one lane
-    if (it > 0 && threadIdx.x < 9 * 64) {
+    float facc = 0.0f;
+    const bool folder = it > 0 && threadIdx.x < 9 * 64;
+    if (folder) {
         const int k = threadIdx.x >> 6, l = threadIdx.x & 63;
-        float acc = 0.0f;
-        for (int b = l; b < nblk; b += 64) acc += part_prev[(item * nblk + b) * 9 + k];
+        for (int b = l; b < nblk; b += 64) facc += part_prev[(item * nblk + b) * 9 + k];
+    }
+    Quat prev_rot = {1.0f, 0.0f, 0.0f, 0.0f};
+    if (threadIdx.x == 0 && it > 0) prev_rot = state[(size_t)((it - 1) & 1) * batch + item];
+    float s[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    float4 pre[PRE > 0 ? PRE : 1];
+    float2 ppy[PRE > 0 ? PRE : 1];
+    float uwx[PRE > 0 ? PRE : 1], uwz[PRE > 0 ? PRE : 1];
+    float uwy = 0.0f;
+    if constexpr (FAST) {
+        if (it < kIters) {
 #pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m, 64);
-        if (l == 0) fold_sh[k] = acc;
+            for (int k = 0; k < PRE; ++k) {
+                const size_t i = i0 + (size_t)k * istride;
+                pre[k] = i < n ? entries[item * n + i] : make_float4(0.5f, 0.5f, 0.0f, 0.0f);
+            }
+#pragma unroll
+            for (int k = 0; k < PRE; ++k) {
+                const float4 e = pre[k];
+                const Unproj un = cam_unproject<FAST>(cam, e.x, e.y);
+                uwx[k] = un.wx; uwz[k] = un.wz; uwy = un.wy;
+                const float2 pr = cam_delta_w<FAST>(cam, e.x, e.y, un, mroll);
+                const float2 pp = cam_delta_w<FAST>(cam, e.x, e.y, un, mpitch);
+                const float2 py = cam_delta_w<FAST>(cam, e.x, e.y, un, myaw);
+                ppy[k] = py;
+                plds[k * 1024 + threadIdx.x] = make_float4(pr.x, pr.y, pp.x, pp.y);
+                if (i0 + (size_t)k * istride < n) {
+                    s[0] += pr.x * pr.x + pr.y * pr.y;
+                    s[1] += pr.x * pp.x + pr.y * pp.y;
+                    s[2] += pr.x * py.x + pr.y * py.y;
+                    s[3] += pp.x * pp.x + pp.y * pp.y;
+                    s[4] += pp.x * py.x + pp.y * py.y;
+                    s[5] += py.x * py.x + py.y * py.y;
+                }
+            }
+        }
+    }
+    // ---- fold, part 2 + the update on one lane
+    if (folder) {
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) facc += __shfl_xor(facc, m, 64);
+        if ((threadIdx.x & 63) == 0) fold_sh[threadIdx.x >> 6] = facc;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        Quat rotation = {1.0f, 0.0f, 0.0f, 0.0f};
+        Quat rotation = prev_rot;
         if (it > 0) {
-            rotation = state[(size_t)((it - 1) & 1) * batch + item];
-            float s[9];
+            float f[9];
 #pragma unroll
-            for (int k = 0; k < 9; ++k) s[k] = fold_sh[k];
+            for (int k = 0; k < 9; ++k) f[k] = fold_sh[k];
             const float alpha = (it - 1 == kIters - 1) ? 1.0f : 0.5f;
-            rotation = almeida_update(rotation, s, eps, alpha);
+            rotation = almeida_update(rotation, f, eps, alpha);
         }
         rot_sh = rotation;
     }
@@ -432,11 +481,21 @@ __global__ __launch_bounds__(1024) void almeida_lsq_step_kernel(const float4* __
         return;
     }
     const Mat3 rotm = quat_to_mat3(rotation);
-    const Mat3 mroll = mat3_from_euler(0.0f, eps, 0.0f);
-    const Mat3 mpitch = mat3_from_euler(eps, 0.0f, 0.0f);
-    const Mat3 myaw = mat3_from_euler(0.0f, 0.0f, -eps);
-    float s[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    for (size_t i = (size_t)blockIdx.x * 1024 + threadIdx.x; i < n; i += (size_t)nblk * 1024) {
+    if constexpr (FAST) {
+#pragma unroll
+        for (int k = 0; k < PRE; ++k) {
+            if (i0 + (size_t)k * istride >= n) continue;
+            const float4 e = pre[k];
+            const Unproj un = {uwx[k], uwy, uwz[k]};
+            const float2 d = cam_delta_w<FAST>(cam, e.x, e.y, un, rotm);
+            const float rx = e.z - d.x, ry = e.w - d.y;
+            const float4 v = plds[k * 1024 + threadIdx.x];
+            s[6] += v.x * rx + v.y * ry;
+            s[7] += v.z * rx + v.w * ry;
+            s[8] += ppy[k].x * rx + ppy[k].y * ry;
+        }
+    }
+    for (size_t i = i0 + (size_t)PRE * istride; i < n; i += istride) {
         const float4 e = entries[item * n + i];
         const Unproj un = cam_unproject<FAST>(cam, e.x, e.y);
         const float2 d = cam_delta_w<FAST>(cam, e.x, e.y, un, rotm);
