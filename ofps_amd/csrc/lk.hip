@@ -210,6 +210,12 @@ __global__ __launch_bounds__(256) void lk_tensor_tiled_kernel(const float* __res
     G[(size_t)y * w + x] = make_float4(gxx, gxy, gyy, 0.0f);
 }
 
+// Current-frame window in LDS.  The bilinear fetches J(q + flow(p)) of a workgroup land in the rectangle
+// [tile + window] shifted by the flows of its pixels; when those flows differ by at most LkTile::SPREAD pixels (smooth
+// flow: almost every tile) the rectangle fits jl[][] and is staged once, coordinates clamped at staging time exactly like
+// the oracle clamps xa/xb/ya/yb -- the inner loop then has no global loads at all (it was latency-bound on 10 dependent
+// gathers per window row).  Tiles with wilder flows keep the register-reuse global path below.  Same values, same
+// operation order either way, hence the same bits.
 template <int RADIUS>
 __global__ __launch_bounds__(256, (RADIUS <= 4 ? 4 : 2)) void lk_step_tiled_kernel(const float* __restrict__ I, const float* __restrict__ J,
                                                             const float* __restrict__ gx, const float* __restrict__ gy,
@@ -217,65 +223,133 @@ __global__ __launch_bounds__(256, (RADIUS <= 4 ? 4 : 2)) void lk_step_tiled_kern
                                                             const float2* __restrict__ flow_in, float2* __restrict__ flow_out) {
     using T = LkTile<RADIUS>;
     constexpr int N = T::N;
+    constexpr int SPREAD = 6, LW = T::TW + 1 + SPREAD, LH = T::TH + 1 + SPREAD;
     __shared__ float tile[3][T::TH][T::TW];
+    __shared__ float jl[LH][LW + 1];
+    __shared__ int box[4][4];                     // per wave: min x0, max x0+1, min y0, max y0+1
     const int x0 = blockIdx.x * 64, y0 = blockIdx.y * 4;
     const float* const src[3] = {I, gx, gy};
     lk_stage<RADIUS, 3>(src, tile, w, h, x0, y0);
-    __syncthreads();
     const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6, x = x0 + lx, y = y0 + ly;
-    if (x >= w || y >= h) return;
-    const float2 f = flow_in[(size_t)y * w + x];
-    int xa[N], xb[N];
+    const bool active = x < w && y < h;
+    const float2 f = active ? flow_in[(size_t)y * w + x] : make_float2(0.0f, 0.0f);
+    // integer sample origin of a window column / row: the oracle's floor + float clamp to [-1, w] (or h)
+    auto origin = [](int q, float fl, int lim, float& frac) {
+        const float fq = (float)q + fl;
+        const float q0f = floorf(fq);
+        frac = fq - q0f;
+        const float c = q0f < -1.0f ? -1.0f : (q0f > (float)lim ? (float)lim : q0f);
+        return (int)c;
+    };
+    int xi[N];
     float ax[N];
 #pragma unroll
-    for (int k = 0; k < N; ++k) {
-        const int qx = lk_clampi(x + k - RADIUS, 0, w - 1);
-        const float fx = (float)qx + f.x;
-        const float x0f = floorf(fx);
-        ax[k] = fx - x0f;
-        const float cx = x0f < -1.0f ? -1.0f : (x0f > (float)w ? (float)w : x0f);
-        const int xi = (int)cx;
-        xa[k] = lk_clampi(xi, 0, w - 1);
-        xb[k] = lk_clampi(xi + 1, 0, w - 1);
+    for (int k = 0; k < N; ++k) xi[k] = origin(lk_clampi(x + k - RADIUS, 0, w - 1), f.x, w, ax[k]);
+    float dummy;
+    const int yt = origin(lk_clampi(y - RADIUS, 0, h - 1), f.y, h, dummy);
+    const int yb_ = origin(lk_clampi(y + RADIUS, 0, h - 1), f.y, h, dummy);
+    {
+        int bx0 = active ? xi[0] : 0x7FFFFFFF, bx1 = active ? xi[N - 1] + 1 : -0x7FFFFFFF;
+        int by0 = active ? yt : 0x7FFFFFFF, by1 = active ? yb_ + 1 : -0x7FFFFFFF;
+        // window columns / rows are monotone in k / r, so the extremes are the first and the last
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            bx0 = min(bx0, __shfl_xor(bx0, m, 64)); bx1 = max(bx1, __shfl_xor(bx1, m, 64));
+            by0 = min(by0, __shfl_xor(by0, m, 64)); by1 = max(by1, __shfl_xor(by1, m, 64));
+        }
+        if (lx == 0) { box[ly][0] = bx0; box[ly][1] = bx1; box[ly][2] = by0; box[ly][3] = by1; }
     }
+    __syncthreads();
+    const int xmin = min(min(box[0][0], box[1][0]), min(box[2][0], box[3][0]));
+    const int xmax = max(max(box[0][1], box[1][1]), max(box[2][1], box[3][1]));
+    const int ymin = min(min(box[0][2], box[1][2]), min(box[2][2], box[3][2]));
+    const int ymax = max(max(box[0][3], box[1][3]), max(box[2][3], box[3][3]));
+    // the LDS path also wants every lane's window columns to sample consecutive texels (x0[k+1] == x0[k] + 1: true
+    // away from the left/right image border), so one row of N+1 texels serves all N columns
+    bool consecutive = true;
+#pragma unroll
+    for (int k = 0; k + 1 < N; ++k) consecutive = consecutive && (xi[k + 1] == xi[k] + 1);
+    const int fits = xmax >= xmin && xmax - xmin < LW && ymax - ymin < LH;
+    const bool in_lds = __syncthreads_and(fits && (consecutive || !active));       // uniform over the workgroup
     float bx = 0.0f, by = 0.0f;
-    float jt[N + 1], jb[N + 1];          // rows ya / yb of the current frame at columns xa[0..N-1], xb[N-1]
-    int prev_yb = -1;
-#pragma unroll 1
-    for (int r = 0; r < N; ++r) {
-        const int qy = lk_clampi(y + r - RADIUS, 0, h - 1);
-        const float fy = (float)qy + f.y;
-        const float y0f = floorf(fy);
-        const float ay = fy - y0f;
-        const float cy = y0f < -1.0f ? -1.0f : (y0f > (float)h ? (float)h : y0f);
-        const int yi = (int)cy;
-        const int ya = lk_clampi(yi, 0, h - 1), yb = lk_clampi(yi + 1, 0, h - 1);
-        const float* ra = J + (size_t)ya * w;
-        const float* rb = J + (size_t)yb * w;
-        if (ya == prev_yb) {
-#pragma unroll
-            for (int k = 0; k <= N; ++k) jt[k] = jb[k];
-        } else {
-#pragma unroll
-            for (int k = 0; k < N; ++k) jt[k] = ra[xa[k]];
-            jt[N] = ra[xb[N - 1]];
+    if (in_lds) {
+        for (int idx = threadIdx.x; idx < LH * LW; idx += 256) {
+            const int cy = idx / LW, cx = idx - cy * LW;
+            jl[cy][cx] = J[(size_t)lk_clampi(ymin + cy, 0, h - 1) * w + lk_clampi(xmin + cx, 0, w - 1)];
         }
+        __syncthreads();
+        const int xo = active ? xi[0] - xmin : 0;
+        float jt[N + 1], jb[N + 1];          // texels x0 .. x0+N of the upper / lower sample row
+        int prev_yi = -0x7FFFFFFF;
+#pragma unroll 1
+        for (int r = 0; r < N; ++r) {
+            float ay;
+            const int yi = active ? origin(lk_clampi(y + r - RADIUS, 0, h - 1), f.y, h, ay) - ymin : 0;
+            // the lower row of the previous window row is this row's upper row whenever the sample row advanced by
+            // exactly one (away from the top/bottom border: always); decided per wave so the branch is uniform, and
+            // reloading is always correct
+            const bool reuse = __all(!active || yi == prev_yi + 1);
+            prev_yi = yi;
+            const float* rb = &jl[yi + 1][xo];
+            if (reuse) {
 #pragma unroll
-        for (int k = 0; k < N; ++k) jb[k] = rb[xa[k]];
-        jb[N] = rb[xb[N - 1]];
-        prev_yb = yb;
+                for (int k = 0; k <= N; ++k) jt[k] = jb[k];
+            } else {
+                const float* ra = &jl[yi][xo];
 #pragma unroll
-        for (int k = 0; k < N; ++k) {
-            float j10 = jt[k + 1], j11 = jb[k + 1];
-            if (k < N - 1 && xb[k] != xa[k + 1]) { j10 = ra[xb[k]]; j11 = rb[xb[k]]; }     // clamped border / rounding: rare
-            const float j00 = jt[k], j01 = jb[k];
-            const float top = j00 + ax[k] * (j10 - j00);
-            const float bot = j01 + ax[k] * (j11 - j01);
-            const float d = tile[0][ly + r][lx + k] - (top + ay * (bot - top));
-            bx += tile[1][ly + r][lx + k] * d;
-            by += tile[2][ly + r][lx + k] * d;
+                for (int k = 0; k <= N; ++k) jt[k] = ra[k];
+            }
+#pragma unroll
+            for (int k = 0; k <= N; ++k) jb[k] = rb[k];
+#pragma unroll
+            for (int k = 0; k < N; ++k) {
+                const float j00 = jt[k], j10 = jt[k + 1], j01 = jb[k], j11 = jb[k + 1];
+                const float top = j00 + ax[k] * (j10 - j00);
+                const float bot = j01 + ax[k] * (j11 - j01);
+                const float d = tile[0][ly + r][lx + k] - (top + ay * (bot - top));
+                bx += tile[1][ly + r][lx + k] * d;
+                by += tile[2][ly + r][lx + k] * d;
+            }
+        }
+    } else if (active) {
+        int xa[N], xb[N];
+#pragma unroll
+        for (int k = 0; k < N; ++k) { xa[k] = lk_clampi(xi[k], 0, w - 1); xb[k] = lk_clampi(xi[k] + 1, 0, w - 1); }
+        float jt[N + 1], jb[N + 1];          // rows ya / yb of the current frame at columns xa[0..N-1], xb[N-1]
+        int prev_yb = -1;
+#pragma unroll 1
+        for (int r = 0; r < N; ++r) {
+            float ay;
+            const int yi = origin(lk_clampi(y + r - RADIUS, 0, h - 1), f.y, h, ay);
+            const int ya = lk_clampi(yi, 0, h - 1), yb = lk_clampi(yi + 1, 0, h - 1);
+            const float* ra = J + (size_t)ya * w;
+            const float* rb = J + (size_t)yb * w;
+            if (ya == prev_yb) {
+#pragma unroll
+                for (int k = 0; k <= N; ++k) jt[k] = jb[k];
+            } else {
+#pragma unroll
+                for (int k = 0; k < N; ++k) jt[k] = ra[xa[k]];
+                jt[N] = ra[xb[N - 1]];
+            }
+#pragma unroll
+            for (int k = 0; k < N; ++k) jb[k] = rb[xa[k]];
+            jb[N] = rb[xb[N - 1]];
+            prev_yb = yb;
+#pragma unroll
+            for (int k = 0; k < N; ++k) {
+                float j10 = jt[k + 1], j11 = jb[k + 1];
+                if (k < N - 1 && xb[k] != xa[k + 1]) { j10 = ra[xb[k]]; j11 = rb[xb[k]]; }     // clamped border / rounding: rare
+                const float j00 = jt[k], j01 = jb[k];
+                const float top = j00 + ax[k] * (j10 - j00);
+                const float bot = j01 + ax[k] * (j11 - j01);
+                const float d = tile[0][ly + r][lx + k] - (top + ay * (bot - top));
+                bx += tile[1][ly + r][lx + k] * d;
+                by += tile[2][ly + r][lx + k] * d;
+            }
         }
     }
+    if (!active) return;
     const float4 g = G[(size_t)y * w + x];
     const float det = g.x * g.z - g.y * g.y;
     float du = 0.0f, dv = 0.0f;
