@@ -61,6 +61,13 @@ int detect_device(ofps_hip_ctx* ctx, const float4* d_entries, size_t n, int batc
 int almeida_device(ofps_hip_ctx* ctx, const float4* d_entries, size_t n, int batch, float aspect, float fov_y_deg,
                    int use_ransac, size_t num_iters, float inlier_deg, size_t num_samples, uint64_t seed, float4* d_quat);
 
+// rows of `width` bytes, host -> device; one linear copy when both sides are dense (the 2-D path is slower)
+inline hipError_t upload_rows(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t height,
+                              hipStream_t stream) {
+    if (dpitch == width && spitch == width) return hipMemcpyAsync(dst, src, width * height, hipMemcpyHostToDevice, stream);
+    return hipMemcpy2DAsync(dst, dpitch, src, spitch, width, height, hipMemcpyHostToDevice, stream);
+}
+
 #define OFPS_HIP_TRY(ctx, expr)                                          \
     do {                                                                 \
         hipError_t _e = (expr);                                          \

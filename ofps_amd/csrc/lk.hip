@@ -486,8 +486,8 @@ int ofps_hip_lk_decode(ofps_hip_ctx* ctx, const uint8_t* prev, const uint8_t* cu
     auto* d_out = static_cast<float4*>(ofps::scratch(ctx, ofps::S_BEST, cells * sizeof(float4)));
     auto* d_cnt = static_cast<uint32_t*>(ofps::scratch(ctx, ofps::S_RESULT, 16));
     if (!d_frames || !d_ent || !d_field || !d_out || !d_cnt) return OFPS_HIP_ENOMEM;
-    OFPS_HIP_TRY(ctx, hipMemcpy2DAsync(d_frames, W, prev, stride, W, H, hipMemcpyHostToDevice, ctx->stream));
-    OFPS_HIP_TRY(ctx, hipMemcpy2DAsync(d_frames + px, W, cur, stride, W, H, hipMemcpyHostToDevice, ctx->stream));
+    OFPS_HIP_TRY(ctx, ofps::upload_rows(d_frames, W, prev, stride, W, H, ctx->stream));
+    OFPS_HIP_TRY(ctx, ofps::upload_rows(d_frames + px, W, cur, stride, W, H, ctx->stream));
     int rc = ofps_hip_lk_flow_dev(ctx, d_frames, d_frames + px, W, H, W, levels, radius, iters, nullptr, d_ent);
     if (rc != OFPS_HIP_OK) return rc;
     size_t n_rec = px;
@@ -535,8 +535,8 @@ int ofps_hip_lk_flow(ofps_hip_ctx* ctx, const uint8_t* prev, const uint8_t* cur,
     auto* d_flow = static_cast<float2*>(ofps::scratch(ctx, ofps::S_WORK1, px * sizeof(float2)));
     auto* d_ent = out_entries ? static_cast<float4*>(ofps::scratch(ctx, ofps::S_ENTRIES, px * sizeof(float4))) : nullptr;
     if (!d_frames || !d_flow || (out_entries && !d_ent)) return OFPS_HIP_ENOMEM;
-    OFPS_HIP_TRY(ctx, hipMemcpy2DAsync(d_frames, W, prev, stride, W, H, hipMemcpyHostToDevice, ctx->stream));
-    OFPS_HIP_TRY(ctx, hipMemcpy2DAsync(d_frames + px, W, cur, stride, W, H, hipMemcpyHostToDevice, ctx->stream));
+    OFPS_HIP_TRY(ctx, ofps::upload_rows(d_frames, W, prev, stride, W, H, ctx->stream));
+    OFPS_HIP_TRY(ctx, ofps::upload_rows(d_frames + px, W, cur, stride, W, H, ctx->stream));
     int rc = ofps_hip_lk_flow_dev(ctx, d_frames, d_frames + px, W, H, W, levels, radius, iters, d_flow, d_ent);
     if (rc != OFPS_HIP_OK) return rc;
     if (out_flow) OFPS_HIP_TRY(ctx, hipMemcpyAsync(out_flow, d_flow, px * sizeof(float2), hipMemcpyDeviceToHost, ctx->stream));

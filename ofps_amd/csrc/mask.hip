@@ -193,7 +193,7 @@ int ofps_hip_contrast_mask(ofps_hip_ctx* ctx, const uint8_t* gray, int W, int H,
     auto* d_gray = static_cast<uint8_t*>(ofps::scratch(ctx, ofps::S_FRAMES, px));
     auto* d_mask = static_cast<uint8_t*>(ofps::scratch(ctx, ofps::S_MASK, px));
     if (!d_gray || !d_mask) return OFPS_HIP_ENOMEM;
-    OFPS_HIP_TRY(ctx, hipMemcpy2DAsync(d_gray, W, gray, stride, W, H, hipMemcpyHostToDevice, ctx->stream));
+    OFPS_HIP_TRY(ctx, ofps::upload_rows(d_gray, W, gray, stride, W, H, ctx->stream));
     int rc = ofps::contrast_mask_device(ctx, d_gray, W, H, W, d_mask);
     if (rc != OFPS_HIP_OK) return rc;
     OFPS_HIP_TRY(ctx, hipMemcpyAsync(out_mask, d_mask, px, hipMemcpyDeviceToHost, ctx->stream));

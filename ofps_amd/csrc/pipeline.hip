@@ -34,8 +34,7 @@ static int upload_frame(ofps_hip_ctx* ctx, const uint8_t* luma, int W, int H, in
     auto* slots = static_cast<uint8_t*>(ofps::scratch(ctx, ofps::S_PIPE_FRAMES, 2 * pitch));
     if (!slots) return OFPS_HIP_ENOMEM;
     const int prev_slot = ctx->pipe_newest, cur_slot = ctx->pipe_newest < 0 ? 0 : 1 - ctx->pipe_newest;
-    OFPS_HIP_TRY(ctx, hipMemcpy2DAsync(slots + (size_t)cur_slot * pitch, dstride, luma, stride, W, H, hipMemcpyHostToDevice,
-                                       ctx->stream));
+    OFPS_HIP_TRY(ctx, ofps::upload_rows(slots + (size_t)cur_slot * pitch, dstride, luma, stride, W, H, ctx->stream));
     ctx->pipe_newest = cur_slot;
     *slots_out = slots; *pitch_out = pitch; *dstride_out = dstride; *prev_slot_out = prev_slot; *cur_slot_out = cur_slot;
     return OFPS_HIP_OK;

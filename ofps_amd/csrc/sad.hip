@@ -997,8 +997,8 @@ int ofps_hip_sad_flow(ofps_hip_ctx* ctx, const uint8_t* prev, const uint8_t* cur
     auto* d_ent = static_cast<float*>(ofps::scratch(ctx, ofps::S_ENTRIES, nblk * 4 * sizeof(float)));
     auto* d_best = static_cast<int32_t*>(ofps::scratch(ctx, ofps::S_BEST, nblk * 3 * sizeof(int32_t)));
     if (!d_frames || !d_ent || !d_best) return OFPS_HIP_ENOMEM;
-    OFPS_HIP_TRY(ctx, hipMemcpy2DAsync(d_frames, dstride, prev, stride, W, H, hipMemcpyHostToDevice, ctx->stream));
-    OFPS_HIP_TRY(ctx, hipMemcpy2DAsync(d_frames + pitch, dstride, cur, stride, W, H, hipMemcpyHostToDevice, ctx->stream));
+    OFPS_HIP_TRY(ctx, ofps::upload_rows(d_frames, dstride, prev, stride, W, H, ctx->stream));
+    OFPS_HIP_TRY(ctx, ofps::upload_rows(d_frames + pitch, dstride, cur, stride, W, H, ctx->stream));
     int rc = ofps_hip_sad_flow_dev(ctx, d_frames, 2, W, H, dstride, pitch, 0, block, range, d_ent, d_best);
     if (rc != OFPS_HIP_OK) return rc;
     if (nblk) {
