@@ -203,6 +203,34 @@ def test_sad_device_path_with_rows_not_16_byte_aligned(ctx, B, R):
         np.testing.assert_array_equal(out[k].cpu().numpy().view(np.uint32), ent_o.view(np.uint32))
 
 
+def test_sad_odd_frame_sizes_full_oracle(ctx):
+    """Frame sizes that are not multiples of anything (1917 x 1079): the host entry point repacks rows, partial blocks are
+    dropped, the right/bottom search windows are clipped by the true frame edge."""
+    W, H = 1917, 1079
+    fr = synth.luma_sequence(2, W, H, max_step=16, seed=5)
+    for B, R in ((16, 16), (8, 16)):
+        ent_o, best_o = oracle.sad_flow(fr[0], fr[1], B, R, threads=8)
+        ent_g, best_g = ctx.sad_flow(fr[0], fr[1], B, R, want_best=True)
+        np.testing.assert_array_equal(best_g, best_o)
+        np.testing.assert_array_equal(ent_g.view(np.uint32), ent_o.view(np.uint32))
+
+
+def test_sad_8k_frame_crop_consistency(ctx):
+    """7680 x 4320 (the largest frame a 16-bit grid dimension still allows with room to spare): crop consistency against
+    the oracle at the four corners and the centre."""
+    W, H, B, R = 7680, 4320, 16, 16
+    fr = synth.luma_sequence(2, W, H, max_step=R, seed=8, region=128)
+    _, best = ctx.sad_flow(fr[0], fr[1], B, R, want_best=True)
+    best = best.reshape(H // B, W // B, 3)
+    cw, ch = 256, 160
+    for cx, cy in [(0, 0), (W - cw, 0), (0, H - ch), (W - cw, H - ch), (3712, 2080)]:
+        _, bo = oracle.sad_flow(fr[0][cy:cy + ch, cx:cx + cw], fr[1][cy:cy + ch, cx:cx + cw], B, R, threads=8)
+        bo = bo.reshape(ch // B, cw // B, 3)
+        x_lo = 0 if cx == 0 else R // B; x_hi = cw // B if cx + cw == W else cw // B - R // B
+        y_lo = 0 if cy == 0 else R // B; y_hi = ch // B if cy + ch == H else ch // B - R // B
+        np.testing.assert_array_equal(best[cy // B + y_lo:cy // B + y_hi, cx // B + x_lo:cx // B + x_hi], bo[y_lo:y_hi, x_lo:x_hi])
+
+
 def test_sad_rejects_bad_arguments(ctx):
     from ofps_amd.runtime import OfpsHipError
     fr = np.zeros((32, 32), np.uint8)
