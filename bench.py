@@ -2,7 +2,7 @@
 """bench.py -- Mvectors/s of the flow hot path on MI355X (BASELINE.json metric).
 
 A "step" is one pass of the full-search SAD block matcher (N1, the dominant kernel of the hot path)
-over one batch of P = 64 consecutive 1080p frame pairs (a 65-frame sequence) already resident in HBM: one launch of
+over one batch of P = 256 consecutive 1080p frame pairs (a 257-frame sequence) already resident in HBM: one launch of
 sad_strip_kernel<16,16> through the C ABI (ofps_hip_sad_flow_dev).  Workload = BASELINE.json
 configs[1] (1080p synthetic, 16x16 blocks, +-16 full search), one GPU's worth per rank (weak scaling:
 independent frame pairs per GPU, no data-path collective -- SURVEY.md 8e).
@@ -39,8 +39,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--pairs", type=int, default=64,
-                    help="frame pairs per step: one 65-frame 1080p sequence resident in HBM (135 MB)")
+    ap.add_argument("--pairs", type=int, default=256,
+                    help="frame pairs per step = per launch: a 257-frame 1080p sequence resident in HBM (0.53 GB), made of "
+                         "--gen-pairs generated pairs traversed forward and backward")
+    ap.add_argument("--gen-pairs", type=int, default=64, help="distinct frame pairs generated on the host (65 frames)")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--block", type=int, default=16)
@@ -110,8 +112,13 @@ def main():
     W, H, B, R, P = args.width, args.height, args.block, args.search_range, args.pairs
     stride = (W + 63) // 64 * 64
     # independent sequence per rank (weak scaling): same generator, different seed
-    frames = synth.luma_sequence(P + 1, W, H, max_step=R, seed=synth.SEED0 + 1000 * rank, stride=stride)
-    d_frames = torch.from_numpy(frames).cuda(non_blocking=False)
+    # G generated pairs (G+1 frames); the resident sequence of P+1 frames walks them forward and backward (every
+    # consecutive pair of it is a generated pair), so a step is long enough for the GPU to sit at its sustained clock
+    # -- a 64-pair step (1 ms) left the first steps of a short run ~10 % slow -- without 150 s of host-side generation
+    G = max(1, min(P, args.gen_pairs))
+    frames = synth.luma_sequence(G + 1, W, H, max_step=R, seed=synth.SEED0 + 1000 * rank, stride=stride)
+    walk = np.abs(((np.arange(P + 1) + G) % (2 * G)) - G) if G > 1 else np.arange(P + 1) % 2
+    d_frames = torch.from_numpy(frames).cuda(non_blocking=False)[torch.from_numpy(walk).cuda()].contiguous()
     nbx, nby = W // B, H // B
     nblk = nbx * nby
     d_out = torch.empty((P, nblk, 4), dtype=torch.float32, device="cuda")
@@ -184,7 +191,7 @@ def main():
                                      (3840, 2160, 8, 32): "cfg4 (BASELINE.json configs[3]): ",
                                      (640, 360, 16, 8): "cfg1 geometry (BASELINE.json configs[0]): "}.get((W, H, B, R), "")
                                     + f"{W}x{H} synthetic luma, {B}x{B} blocks, +-{R} full-search SAD"),
-                       "pairs_per_step": P, "vectors_per_pair": nblk, "parallelism": (f"frame-pair sharding x{world}" + (", key frame broadcast from rank 0 per step (RCCL)" if key_mode and use_dist else "")),
+                       "pairs_per_step": P, "generated_pairs": G, "vectors_per_pair": nblk, "parallelism": (f"frame-pair sharding x{world}" + (", key frame broadcast from rank 0 per step (RCCL)" if key_mode and use_dist else "")),
                        "ref_mode": args.ref_mode,
                        "kernel": (f"sad_strip_kernel<{B},{R}>" if args.sad_mode == "exhaustive" else "sad_sea_kernel + sad_strip_kernel<16,16> on overflow strips"),
                        "sad_mode": args.sad_mode},
