@@ -61,6 +61,26 @@ class HipContext:
     def sync(self):
         self._check(self._lib.ofps_hip_sync(self._h))
 
+    # device memory for hosts without a HIP binding of their own (what the Rust shim uses for resident chains)
+    def malloc(self, nbytes: int) -> int:
+        p = C.c_void_p(0)
+        self._check(self._lib.ofps_hip_malloc(self._h, nbytes, C.byref(p)))
+        return int(p.value)
+
+    def free(self, dptr: int):
+        self._check(self._lib.ofps_hip_free(self._h, C.c_void_p(dptr)))
+
+    def memcpy_h2d(self, dptr: int, host: np.ndarray):
+        a = np.ascontiguousarray(host)
+        self._check(self._lib.ofps_hip_memcpy_h2d(self._h, C.c_void_p(dptr), a.ctypes.data_as(C.c_void_p), a.nbytes))
+
+    def memcpy_d2h(self, host: np.ndarray, dptr: int):
+        assert host.flags["C_CONTIGUOUS"]
+        self._check(self._lib.ofps_hip_memcpy_d2h(self._h, host.ctypes.data_as(C.c_void_p), C.c_void_p(dptr), host.nbytes))
+
+    def get_stream(self) -> int:
+        return int(self._lib.ofps_hip_get_stream(self._h) or 0)
+
     def timer_start(self):
         self._check(self._lib.ofps_hip_timer_start(self._h))
 

@@ -606,3 +606,43 @@ def test_lk_decode_with_contrast_mask(ctx):
     flat = np.full((2, 64, 96), 90, np.uint8)
     ent, _ = ctx.lk_decode(flat[0], flat[1], contrast_mask=True)
     assert len(ent) == 0
+
+
+# ------------------------------------------------------------------ a host without its own HIP binding (the Rust shim's view)
+def test_resident_chain_through_the_c_abi_memory_plumbing():
+    """ofps_hip_malloc / memcpy_h2d / *_dev / memcpy_d2h / timer on the context's own stream, no torch anywhere: frames
+    go up once, SAD -> detect -> Almeida run on device-resident vectors, only the small results come back."""
+    from ofps_amd.runtime import HipContext
+    c = HipContext(0)
+    try:
+        W, H, B, R, F = 640, 368, 16, 16, 3
+        fr = synth.luma_sequence(F, W, H, max_step=8, seed=33)
+        nb = (W // B) * (H // B)
+        dim = c.block_dim(0.05, 3)
+        d_fr, d_ent = c.malloc(fr.nbytes), c.malloc((F - 1) * nb * 16)
+        d_res, d_fld, d_q = c.malloc((F - 1) * 16), c.malloc((F - 1) * dim * dim * 8), c.malloc((F - 1) * 16)
+        assert c.get_stream() != 0
+        c.memcpy_h2d(d_fr, fr)
+        c.timer_start()
+        c.sad_flow_dev(d_fr, F, W, H, W, W * H, 0, B, R, d_ent, None)
+        c.detect_dev(d_ent, nb, F - 1, 0.05, 3, 0.003, d_res, d_fld)
+        c.almeida_dev(d_ent, nb, F - 1, 16 / 9, 22.275, False, 0, 0.05, 0, 0, d_q)
+        ms = c.timer_stop()
+        assert 0.0 < ms < 1000.0
+        ent = np.zeros((F - 1, nb, 4), np.float32); res = np.zeros((F - 1, 4), np.int32)
+        fld = np.zeros((F - 1, dim, dim, 2), np.float32); q = np.zeros((F - 1, 4), np.float32)
+        c.memcpy_d2h(ent, d_ent); c.memcpy_d2h(res, d_res); c.memcpy_d2h(fld, d_fld); c.memcpy_d2h(q, d_q)
+        cam = oracle.camera(16 / 9, 22.275)
+        for k in range(F - 1):
+            eo, _ = oracle.sad_flow(fr[k], fr[k + 1], B, R)
+            np.testing.assert_array_equal(ent[k].view(np.uint32), eo.view(np.uint32))
+            ro = oracle.detect_motion(eo)
+            assert bool(res[k, 0]) == (ro is not None)
+            if ro is not None:
+                assert res[k, 1] == ro[0] and res[k, 2] == dim
+                np.testing.assert_array_equal(fld[k].view(np.uint32), ro[1].view(np.uint32))
+            np.testing.assert_allclose(q[k], oracle.solve_ypr_given(eo, cam), atol=2e-6, rtol=0)
+        for p in (d_fr, d_ent, d_res, d_fld, d_q):
+            c.free(p)
+    finally:
+        c.close()
