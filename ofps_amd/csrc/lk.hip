@@ -175,13 +175,19 @@ struct LkTile {
     static constexpr int R = RADIUS, N = 2 * RADIUS + 1, TW = 64 + 2 * RADIUS, TH = 4 + 2 * RADIUS;
 };
 
+// Staging without per-element divisions: thread t owns window column t % TW (a compile-time modulus done once) and
+// walks rows t / TW, t / TW + ROWS_PER_PASS, ...; per element that is a clamp, a multiply-add and the loads.
 template <int RADIUS, int PLANES>
 __device__ __forceinline__ void lk_stage(const float* const (&src)[PLANES], float (*tile)[LkTile<RADIUS>::TH][LkTile<RADIUS>::TW],
                                          int w, int h, int x0, int y0) {
     using T = LkTile<RADIUS>;
-    for (int idx = threadIdx.x; idx < T::TH * T::TW; idx += 256) {
-        const int ty = idx / T::TW, tx = idx - ty * T::TW;
-        const size_t g = (size_t)lk_clampi(y0 - T::R + ty, 0, h - 1) * w + lk_clampi(x0 - T::R + tx, 0, w - 1);
+    constexpr int ROWS_PER_PASS = 256 / T::TW;                       // 3 for TW = 72
+    const int tx = threadIdx.x % T::TW, ty0 = threadIdx.x / T::TW;
+    if (ty0 >= ROWS_PER_PASS) return;                                // 256 - 3*72 = 40 threads sit the staging out
+    const int gx = lk_clampi(x0 - T::R + tx, 0, w - 1);
+#pragma unroll
+    for (int ty = ty0; ty < T::TH; ty += ROWS_PER_PASS) {
+        const size_t g = (size_t)lk_clampi(y0 - T::R + ty, 0, h - 1) * w + gx;
 #pragma unroll
         for (int p = 0; p < PLANES; ++p) tile[p][ty][tx] = src[p][g];
     }
@@ -273,9 +279,14 @@ __global__ __launch_bounds__(256, (RADIUS <= 4 ? 4 : 2)) void lk_step_tiled_kern
     const bool in_lds = __syncthreads_and(fits && (consecutive || !active));       // uniform over the workgroup
     float bx = 0.0f, by = 0.0f;
     if (in_lds) {
-        for (int idx = threadIdx.x; idx < LH * LW; idx += 256) {
-            const int cy = idx / LW, cx = idx - cy * LW;
-            jl[cy][cx] = J[(size_t)lk_clampi(ymin + cy, 0, h - 1) * w + lk_clampi(xmin + cx, 0, w - 1)];
+        {
+            constexpr int RPP = 256 / LW;                            // rows per pass (3 for LW = 79)
+            const int cx = threadIdx.x % LW, cy0 = threadIdx.x / LW;
+            if (cy0 < RPP) {
+                const int gx = lk_clampi(xmin + cx, 0, w - 1);
+#pragma unroll
+                for (int cy = cy0; cy < LH; cy += RPP) jl[cy][cx] = J[(size_t)lk_clampi(ymin + cy, 0, h - 1) * w + gx];
+            }
         }
         __syncthreads();
         const int xo = active ? xi[0] - xmin : 0;
