@@ -38,9 +38,12 @@ __device__ __forceinline__ void densifier_cell(float px, float py, int w, int h,
 
 __global__ __launch_bounds__(256) void cell_kernel(const float4* __restrict__ entries, size_t n, int w, int h,
                                                    uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
-                                                   uint32_t* __restrict__ out_cells) {
+                                                   uint32_t* __restrict__ out_cells, uint32_t* __restrict__ begin,
+                                                   uint32_t* __restrict__ end, size_t cells) {
     const size_t item = blockIdx.y;
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    // clear the per-cell [begin, end) tables bounds_kernel fills later on this stream (saves two memset launches)
+    for (size_t c = i; c < cells; c += (size_t)gridDim.x * 256) { begin[item * cells + c] = 0; end[item * cells + c] = 0; }
     if (i >= n) return;
     const float4 e = entries[item * n + i];
     uint32_t x, y;
@@ -391,8 +394,10 @@ int densify_device_raw(ofps_hip_ctx* ctx, const float4* d_entries, size_t n, int
     auto* begin = static_cast<uint32_t*>(scratch(ctx, S_WORK3, cells * batch * sizeof(uint32_t)));
     auto* end = static_cast<uint32_t*>(scratch(ctx, S_WORK4, cells * batch * sizeof(uint32_t)));
     if (!begin || !end) return OFPS_HIP_ENOMEM;
-    OFPS_HIP_TRY(ctx, hipMemsetAsync(begin, 0, cells * batch * sizeof(uint32_t), s));
-    OFPS_HIP_TRY(ctx, hipMemsetAsync(end, 0, cells * batch * sizeof(uint32_t), s));
+    if (n == 0) {                                   // otherwise cell_kernel clears them
+        OFPS_HIP_TRY(ctx, hipMemsetAsync(begin, 0, cells * batch * sizeof(uint32_t), s));
+        OFPS_HIP_TRY(ctx, hipMemsetAsync(end, 0, cells * batch * sizeof(uint32_t), s));
+    }
     if (out_begin) *out_begin = begin;
     if (out_end) *out_end = end;
     uint32_t* sorted_vals = nullptr;
@@ -405,7 +410,7 @@ int densify_device_raw(ofps_hip_ctx* ctx, const float4* d_entries, size_t n, int
         uint32_t* digit_total = hist + (size_t)batch * 256 * ntiles;
         uint32_t *keys_a = k0, *vals_a = k0 + tot, *keys_b = k1, *vals_b = k1 + tot;
         const dim3 ge((unsigned)((n + 255) / 256), batch), gt(ntiles, batch);
-        hipLaunchKernelGGL(cell_kernel, ge, dim3(256), 0, s, d_entries, n, w, h, keys_a, vals_a, d_cells);
+        hipLaunchKernelGGL(cell_kernel, ge, dim3(256), 0, s, d_entries, n, w, h, keys_a, vals_a, d_cells, begin, end, cells);
         const int passes = cells <= 256 ? 1 : 2;
         for (int p = 0; p < passes; ++p) {
             const int shift = 8 * p;
