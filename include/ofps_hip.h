@@ -190,7 +190,8 @@ typedef struct {
     float quat[4];                                      /* estimator: (w,i,j,k); identity when not run */
 } ofps_hip_frame_result;
 int ofps_hip_reset_frames(ofps_hip_ctx* ctx);
-/* upload a frame as the stream's newest frame without computing anything (frames a Decoder skips: `skip_frames`) */
+/* upload a frame as the stream's newest frame without computing anything: the frames `Decoder::process_frame` reads
+ * past when called with `skip_frames > 0` (ofps/src/decoder.rs:47-60; cv-decoder/src/lib.rs:92-142 loops `cnt <= skip`) */
 int ofps_hip_stage_frame(ofps_hip_ctx* ctx, const uint8_t* luma, int W, int H, int stride);
 int ofps_hip_push_frame(ofps_hip_ctx* ctx, const uint8_t* luma, int W, int H, int stride,
                         const ofps_hip_frame_params* params, ofps_hip_frame_result* out,
