@@ -193,7 +193,7 @@ def main():
                                     + f"{W}x{H} synthetic luma, {B}x{B} blocks, +-{R} full-search SAD"),
                        "pairs_per_step": P, "generated_pairs": G, "vectors_per_pair": nblk, "parallelism": (f"frame-pair sharding x{world}" + (", key frame broadcast from rank 0 per step (RCCL)" if key_mode and use_dist else "")),
                        "ref_mode": args.ref_mode,
-                       "kernel": (f"sad_strip_kernel<{B},{R}>" if args.sad_mode == "exhaustive" else "sad_sea_kernel + sad_strip_kernel<16,16> on overflow strips"),
+                       "kernel": (f"sad_strip_kernel<{B},{R}>" if args.sad_mode == "exhaustive" else "sad_pde_kernel + sad_strip_kernel<16,16> on overflow strips"),
                        "sad_mode": args.sad_mode},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,

@@ -86,9 +86,10 @@ int ofps_hip_timer_stop(ofps_hip_ctx* ctx, float* elapsed_ms);   /* synchronises
 size_t ofps_hip_sad_block_count(int W, int H, int block);
 /* Search strategy of ofps_hip_sad_flow*: both return the spec's winner bit for bit.
  * EXHAUSTIVE evaluates every candidate (content-independent run time, the default).
- * PRUNED skips candidates whose 8x8 sub-block-sum lower bound (triangle inequality) already exceeds the
- * best exact SAD found (successive elimination); run time depends on the content; 16x16 blocks, range 16
- * only -- other geometries ignore the mode. */
+ * PRUNED (partial-distortion elimination) computes the SAD over 4 of the 16 block rows for every candidate -- a lower
+ * bound of the full SAD -- and evaluates in full only the candidates whose bound does not exceed the exact SAD of the
+ * minimum-bound candidate; run time depends on the content (faster on smooth camera motion with little noise, slower
+ * where there is nothing to prune); 16x16 blocks, range 16 only -- other geometries ignore the mode. */
 enum { OFPS_HIP_SAD_EXHAUSTIVE = 0, OFPS_HIP_SAD_PRUNED = 1 };
 int ofps_hip_set_sad_mode(ofps_hip_ctx* ctx, int mode);
 /* Diagnostics: how many strips of the last PRUNED call overflowed their survivor lists and were redone by the

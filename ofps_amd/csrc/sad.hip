@@ -381,8 +381,10 @@ __global__ __launch_bounds__(64 * kStripWaves, (StripCfg<B, R>::MIN_WAVES)) void
     const int lane = threadIdx.x & 63;
     // XCD-aware remap: workgroup w lands on XCD w % 8; give each XCD a contiguous run of strips
     // (the grid is padded to a multiple of 8 workgroups so the remap is a bijection)
+    // (indirect mode keeps the hardware order: the list is short and packed at the front, and the remap would put
+    // all of it on one XCD)
     const int per_xcd = gridDim.x / 8;
-    const int lwg = (int)(blockIdx.x % 8) * per_xcd + (int)(blockIdx.x / 8);
+    const int lwg = strip_list ? (int)blockIdx.x : (int)(blockIdx.x % 8) * per_xcd + (int)(blockIdx.x / 8);
     int strip = lwg * kStripWaves + wave;
     if (strip_list) {
         // indirect mode (overflow strips of the pruned search): strip_list[0] = count, ids follow
@@ -552,254 +554,276 @@ __global__ __launch_bounds__(64 * kStripWaves, (StripCfg<B, R>::MIN_WAVES)) void
 }
 
 // ------------------------------------------------------------------------------------------------
-// sad_sea_kernel: exact search with successive-elimination pruning (optional mode, B16 R16).
+// sad_pde_kernel: exact search with partial-distortion elimination (opt-in mode OFPS_HIP_SAD_PRUNED, B16 R16).
 //
-// Triangle inequality on sub-block sums: for any split of the block into sub-blocks,
-//   sum_k | S_cur(k) - S_ref(k) |  <=  SAD(candidate).
-// With 8x8 sub-blocks the bound costs 4 |a-b| of u16 sums per candidate instead of 256 of pixels.  The
-// kernel computes the bound for every candidate, evaluates the minimum-bound candidate exactly, and then
-// only the candidates whose bound does not exceed that SAD (plus ties).  The winner is the minimum of
-// the same total-order key as the exhaustive kernels, over a candidate set that provably contains the
-// exhaustive winner -> identical output, bit for bit, on any content.  How much is pruned depends on the
-// content; a strip whose survivor lists overflow is handed to sad_strip_kernel through strip_list.
-//
-// MEASURED (round 1): NOT a win on MI355X at +-16.  The SAD unit retires 64 |a-b| per
-// clock per SIMD, so the exhaustive strip kernel needs only ~39k SIMD-cycles per 8-block strip, while the
-// bound passes of this kernel (sliding sums, 8,712 bounds, survivor bookkeeping) already cost ~31k -- and
-// frames with motion discontinuities leave > 48 survivors in at least one block of most strips (73 % of the
-// strips of the bench sequence), which then run the exhaustive kernel as well.  Kept as an opt-in mode
-// (OFPS_HIP_SAD_PRUNED) with its parity tests; the default stays exhaustive.
-//
-// One 256-thread workgroup per strip of 8 blocks (same strips as sad_strip_kernel):
-//   A  stage the 160 x 48 byte window (16-byte loads); 8x8 sums of the current blocks
-//   B  H8: horizontal 8-sums of every window row (thread = row x 32-pixel segment, sliding sum)
-//   C  S8: vertical 8-sums in place (thread = column)
-//   D  bounds: thread = (block, dx); rows of [S8(x), S8(x+8)] pairs are reused by the candidates 8 rows
-//      apart (top row with the upper sub-blocks, bottom row with the lower ones): 2 v_sad_u16 per row
-//   E  per block: minimum bound -> exact SAD of that candidate (32 threads x 8 pixels, v_sad_u8 on
-//      byte-aligned window data)
-//   F  survivors (bound <= that SAD) -> per-block lists in LDS; overflow -> strip_list
-//   G  exact SAD of the survivors, running minimum of the 64-bit key
-struct SeaCfg {
-    static constexpr int B = 16, R = 16, NB = 8;
-    static constexpr int TW = NB * B + 2 * R;        // 160 window bytes per row
-    static constexpr int TH = B + 2 * R;             // 48 rows
-    static constexpr int RAW_DW = TW / 4;            // 40 dwords per raw row
-    static constexpr int SX = TW - 7;                // 153 S8 columns
-    static constexpr int SY = TH - 7;                // 41 S8 rows
-    static constexpr int HS = TW;                    // u16 row stride of the H8/S8 map
-    static constexpr int CAP = 48;                   // survivors kept per block
-    static constexpr int NC = 2 * R + 1;             // 33
+// The SAD over a subset of the block's rows is a lower bound of the SAD over all of them.  The kernel
+//   1. walks the strip exactly like sad_strip_kernel but with block rows 0, 4, 8, 12 only: the partial SAD of EVERY
+//      candidate for a quarter of the SAD-unit time (the 33 x 4 packed accumulators stay in registers);
+//   2. takes each block's minimum-partial candidate c0 and evaluates its full SAD U (8 lanes x 2 rows, v_sad_u8 on
+//      byte-aligned window data);
+//   3. lists the candidates whose partial SAD does not exceed U -- every other candidate has SAD >= partial > U and
+//      cannot win -- in a per-wave LDS list, and evaluates them exactly, 8 per wave step, folding the 64-bit key
+//      (SAD, d2, dy, dx) into the block's minimum with an LDS atomic;
+//   4. a strip whose list overflows (content with nothing to prune: noise, flat frames, blocks that straddle a motion
+//      discontinuity) is handed to sad_strip_kernel through strip_list.
+// The winner is the minimum of the same total-order key over a candidate set that provably contains the exhaustive
+// winner: identical output, bit for bit, on any content; only the run time depends on the content (DESIGN.md
+// section 3).  It replaces the successive-elimination kernel of the first version, whose bound (sub-block sums) was
+// both weaker and costlier than a quarter of the SADs themselves.
+struct PdeCfg {
+    static constexpr int B = 16, R = 16, STEP = 4, PR = B / STEP;
+    using C = StripCfg<B, R>;
+    static constexpr int CUR_DW = B * C::NB * C::BW;          // the strip of the current frame: 16 rows x 32 dwords
+    static constexpr int CAP = 512;                           // survivors per strip before falling back
+    static constexpr int WAVE_DW = C::TILE_DWORDS + 4 + CUR_DW + CAP + 2 * C::NB;       // +4: the dx=+R read of the last row
+    static constexpr int OFF_CUR = C::TILE_DWORDS + 4, OFF_LIST = OFF_CUR + CUR_DW, OFF_BEST = OFF_LIST + CAP;
+    static_assert(OFF_BEST % 2 == 0, "64-bit keys must be 8-byte aligned");
 };
 
-__device__ __forceinline__ uint32_t sea_block_sad(const uint32_t* raw, int b, int dyi, int dxi, int j, uint2 cur8) {
-    // 32 threads of a block: thread j covers row j/2, pixels 8*(j%2) .. +7 of candidate (dyi, dxi)
-    const int row = dyi + (j >> 1);
-    const int col = b * SeaCfg::B + dxi + 8 * (j & 1);            // byte column in the window
-    const uint32_t* p = raw + row * SeaCfg::RAW_DW + (col >> 2);
-    const uint32_t d0 = p[0], d1 = p[1], d2 = p[2];
-    const int sh = col & 3;
-    const uint32_t w0 = __builtin_amdgcn_alignbyte(d1, d0, sh);
-    const uint32_t w1 = __builtin_amdgcn_alignbyte(d2, d1, sh);
-    uint32_t s = __builtin_amdgcn_sad_u8(w0, cur8.x, 0u);
-    s = __builtin_amdgcn_sad_u8(w1, cur8.y, s);
+template <int RR>
+__device__ __forceinline__ void pde_row(unsigned long long (&acc)[PdeCfg::C::NP], const uint32_t (&c)[PdeCfg::PR][PdeCfg::C::BW],
+                                        const uint32_t* lds, uint32_t& base) {
+    using C = PdeCfg::C;
+    constexpr int B = PdeCfg::B, R = PdeCfg::R, STEP = PdeCfg::STEP;
+    constexpr int G = StripWalk<B, R>::ROWS_PER_BASE;
+    if constexpr (RR > 0 && RR % G == 0) {
+        base += G * C::SW;
+        asm volatile("" : "+v"(base));
+    }
+    unsigned long long win[C::BW];
 #pragma unroll
-    for (int m = 16; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);   // stays inside the 32-lane half
+    for (int q = 0; q < C::BW; ++q) win[q] = reinterpret_cast<const U64A4*>(lds + base + (RR % G) * C::SW + q)->v;
+#pragma unroll
+    for (int ii = 0; ii < C::NP; ++ii) {
+        const int y = RR - ii;                                  // window row RR belongs to candidate ii, block row y
+        if (ii < C::NCAND && y >= 0 && y < B && y % STEP == 0) {
+#pragma unroll
+            for (int q = 0; q < C::BW; ++q) acc[ii] = __builtin_amdgcn_qsad_pk_u16_u8(win[q], c[y / STEP][q], acc[ii]);
+        }
+    }
+}
+template <int... RR>
+__device__ __forceinline__ void pde_rows(unsigned long long (&acc)[PdeCfg::C::NP], const uint32_t (&c)[PdeCfg::PR][PdeCfg::C::BW],
+                                         const uint32_t* lds, uint32_t tile_off, std::integer_sequence<int, RR...>) {
+    uint32_t base = tile_off;
+    asm volatile("" : "+v"(base));
+    (pde_row<RR>(acc, c, lds, base), ...);
+}
+
+// rows 2*r8 and 2*r8+1 of candidate (dyi, dxi) of block bb: 8 lanes cover a block
+__device__ __forceinline__ uint32_t pde_two_rows(const uint32_t* tile, const uint32_t* curl, int bb, int dyi, int dxi, int r8) {
+    using C = PdeCfg::C;
+    const int sh = dxi & 3;
+    uint32_t s = 0;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int y = 2 * r8 + k;
+        const uint32_t* rp = tile + (dyi + y) * C::SW + bb * C::BW + (dxi >> 2);
+        const uint32_t* cp = curl + y * (C::NB * C::BW) + bb * C::BW;
+        uint32_t d[C::BW + 1];
+#pragma unroll
+        for (int q = 0; q <= C::BW; ++q) d[q] = rp[q];
+#pragma unroll
+        for (int q = 0; q < C::BW; ++q) s = __builtin_amdgcn_sad_u8(__builtin_amdgcn_alignbyte(d[q + 1], d[q], sh), cp[q], s);
+    }
     return s;
 }
 
-__global__ __launch_bounds__(256) void sad_sea_kernel(const SadParams p, int strips_per_row, int total_strips,
-                                                      uint32_t* __restrict__ strip_list) {
-    using C = SeaCfg;
-    constexpr int B = C::B, R = C::R;
-    __shared__ __attribute__((aligned(16))) uint32_t raw[C::TH * C::RAW_DW + 4];
-    __shared__ __attribute__((aligned(16))) uint16_t s8[C::TH * C::HS];
-    __shared__ uint32_t cs8[C::NB][2];                       // [b][0] = S(0,0) | S(8,0)<<16 ; [b][1] = S(0,8) | S(8,8)<<16
-    __shared__ uint32_t cnt[C::NB];
-    __shared__ uint32_t list[C::NB][C::CAP];
-    __shared__ int overflow;
+__global__ __launch_bounds__(64 * kStripWaves, 3) void sad_pde_kernel(const SadParams p, int strips_per_row, int total_strips,
+                                                                       uint32_t* __restrict__ strip_list) {
+    using P = PdeCfg;
+    using C = P::C;
+    constexpr int B = P::B, R = P::R;
+    __shared__ __attribute__((aligned(16))) uint32_t lds[kStripWaves * P::WAVE_DW];
 
-    const int tid = threadIdx.x;
-    const int per_xcd = gridDim.x / 8;
-    const int strip = (int)(blockIdx.x % 8) * per_xcd + (int)(blockIdx.x / 8);      // XCD-aware, see sad_strip_kernel
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int per_xcd = gridDim.x / 8;                        // XCD-aware remap, see sad_strip_kernel
+    const int lwg = (int)(blockIdx.x % 8) * per_xcd + (int)(blockIdx.x / 8);
+    const int strip = lwg * kStripWaves + wave;
     if (strip >= total_strips) return;
     const int strips_per_pair = strips_per_row * p.nby;
     const int pair = strip / strips_per_pair;
     const int rem = strip - pair * strips_per_pair;
     const int by = rem / strips_per_row;
     const int bx0 = (rem - by * strips_per_row) * C::NB;
-    const int y0 = by * B;
     const uint8_t* __restrict__ prev = p.prev_base + (size_t)pair * p.prev_pitch;
     const uint8_t* __restrict__ cur = p.cur_base + (size_t)pair * p.cur_pitch;
+    uint32_t* tile = lds + wave * P::WAVE_DW;
+    uint32_t* curl = tile + P::OFF_CUR;
+    uint32_t* list = tile + P::OFF_LIST;
+    unsigned long long* bestk = reinterpret_cast<unsigned long long*>(tile + P::OFF_BEST);
 
-    // ---- A: window + current-block sub-sums
-    {
-        const int tx0 = bx0 * B - R, ty0 = y0 - R;
-        for (int idx = tid; idx < C::TH * (C::TW / 16); idx += 256) {
-            const int row = idx / (C::TW / 16), col = idx - row * (C::TW / 16);
-            const int gx = tx0 + 16 * col, gy = ty0 + row;
-            if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W)
-                *reinterpret_cast<uint4*>(raw + row * C::RAW_DW + 4 * col) =
-                    *reinterpret_cast<const uint4*>(prev + (size_t)gy * p.stride + gx);
-        }
-        if (tid < C::NB) cnt[tid] = 0;
-        if (tid == 0) overflow = 0;
-    }
-    const int b = tid >> 5, j = tid & 31;                    // block of the strip, thread in block
+    const int b = lane / C::NG, g = lane % C::NG;
     const int bx = bx0 + b;
     const bool blk_on = bx < p.nbx;
-    const int bxc = blk_on ? bx : p.nbx - 1;
-    // my 8 pixels of the current block (row j/2, half j%2): fixed for every candidate
-    const uint2 cur8 = *reinterpret_cast<const uint2*>(cur + (size_t)(y0 + (j >> 1)) * p.stride + bxc * B + 8 * (j & 1));
-    {
-        // sub-block (sx, sy) = (j%2, row/8): sum of my 8 pixels, then over the 8 rows of the sub-block
-        uint32_t s = __builtin_amdgcn_sad_u8(cur8.x, 0u, 0u);
-        s = __builtin_amdgcn_sad_u8(cur8.y, 0u, s);
-        s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 8, 64);   // rows r, r^1, r^2, r^4
-        // lanes j with (j>>1)&7 == 0 hold the sums: j in {0,1} -> sy 0, j in {16,17} -> sy 1
-        const uint32_t other = __shfl_xor(s, 1, 64);          // partner sub-block sx^1
-        if ((j & 15) == 0) cs8[b][j >> 4] = s | (other << 16);
-    }
-    __syncthreads();
+    const int y0 = by * B;
 
-    // ---- B: horizontal 8-sums.  thread = (row, 32-position segment); 240 threads busy
-    if (tid < C::TH * 5) {
-        const int row = tid / 5, seg = tid - row * 5;
-        const uint32_t* rp = raw + row * C::RAW_DW + 8 * seg;
-        uint32_t d[10];
-#pragma unroll
-        for (int k = 0; k < 10; ++k) d[k] = rp[k];            // last segment reads 2 dwords past the row: unused positions
-        uint32_t s = __builtin_amdgcn_sad_u8(d[0], 0u, 0u);
-        s = __builtin_amdgcn_sad_u8(d[1], 0u, s);
-        uint32_t out[16];
-#pragma unroll
-        for (int k = 0; k < 32; ++k) {
-            if (k & 1) out[k >> 1] |= s << 16; else out[k >> 1] = s;
-            const uint32_t add = (d[(k + 8) >> 2] >> (8 * ((k + 8) & 3))) & 0xFFu;
-            const uint32_t sub = (d[k >> 2] >> (8 * (k & 3))) & 0xFFu;
-            s = s + add - sub;
+    // ---- stage the search window (16-byte granules) and the strip of the current frame
+    {
+        const int tx0 = bx0 * B - R, ty0 = y0 - R;
+        for (int idx = lane; idx < C::TILE_H * C::TILE_WG; idx += 64) {
+            const int row = idx / C::TILE_WG, col = idx - row * C::TILE_WG;
+            const int gx = tx0 + 16 * col, gy = ty0 + row;
+            if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W)
+                *reinterpret_cast<uint4*>(tile + row * C::SW + 4 * col) = *reinterpret_cast<const uint4*>(prev + (size_t)gy * p.stride + gx);
         }
-        uint32_t* op = reinterpret_cast<uint32_t*>(s8 + row * C::HS + 32 * seg);
-        if (seg < 4) {
 #pragma unroll
-            for (int k = 0; k < 16; k += 4) *reinterpret_cast<uint4*>(op + k) = make_uint4(out[k], out[k + 1], out[k + 2], out[k + 3]);
-        } else {                                              // positions 128..152 (+ one pad position)
-#pragma unroll
-            for (int k = 0; k < 13; ++k) op[k] = out[k];
+        for (int k = 0; k < 2; ++k) {
+            const int idx = lane + 64 * k, row = idx / C::NB, blk = idx % C::NB;
+            const int bxc = min(bx0 + blk, p.nbx - 1);
+            *reinterpret_cast<uint4*>(curl + row * (C::NB * C::BW) + blk * C::BW) =
+                *reinterpret_cast<const uint4*>(cur + (size_t)(y0 + row) * p.stride + bxc * B);
         }
     }
-    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-    // ---- C: vertical 8-sums in place.  thread = column
-    if (tid < C::SX) {
-        uint16_t* colp = s8 + tid;
-        uint32_t s = 0;
+    // ---- 1. partial SADs (rows 0, 4, 8, 12) of every candidate of the main pass
+    uint32_t c4[P::PR][C::BW];
 #pragma unroll
-        for (int y = 0; y < 8; ++y) s += colp[y * C::HS];
+    for (int r = 0; r < P::PR; ++r)
 #pragma unroll
-        for (int y = 0; y < C::SY; ++y) {
-            const uint32_t top = colp[y * C::HS];
-            const uint32_t bot = (y + 8 < C::TH) ? colp[(y + 8) * C::HS] : 0u;
-            colp[y * C::HS] = (uint16_t)s;
-            s = s + bot - top;
+        for (int q = 0; q < C::BW; ++q) c4[r][q] = curl[(P::STEP * r) * (C::NB * C::BW) + b * C::BW + q];
+    unsigned long long acc[C::NP];
+#pragma unroll
+    for (int ii = 0; ii < C::NP; ++ii) acc[ii] = 0;
+    pde_rows(acc, c4, lds, (uint32_t)(wave * P::WAVE_DW + b * C::BW + g), std::make_integer_sequence<int, C::NCAND + B - 1>{});
+#pragma unroll
+    for (int ii = 0; ii < C::NP; ++ii) asm volatile("" : "+v"(acc[ii]));
+
+    const int dx0 = -R + 4 * g;
+    bool colv[4];
+    uint32_t colk[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int x = bx * B + dx0 + j;
+        colv[j] = blk_on && x >= 0 && x + B <= p.W;
+        colk[j] = colv[j] ? (uint32_t)((dx0 + j) * (dx0 + j)) << C::KSHIFT : 0xFFFFFFFFu;
+    }
+    static_assert(C::COMPACT_KEY && C::SPLIT == 1, "written for the +-16 geometry");
+    uint32_t bkey = 0xFFFFFFFFu;
+#pragma unroll
+    for (int i = 0; i < C::NCAND; ++i) {
+        const int dy = -R + i;
+        if (y0 + dy >= 0 && y0 + dy + B <= p.H) {                 // uniform over the strip
+            const uint32_t lo = (uint32_t)acc[i], hi = (uint32_t)(acc[i] >> 32);
+            const uint32_t k0 = (lo << 16) | colk[0], k1 = (lo & 0xFFFF0000u) | colk[1];
+            const uint32_t k2 = (hi << 16) | colk[2], k3 = (hi & 0xFFFF0000u) | colk[3];
+            bkey = min(bkey, __builtin_elementwise_add_sat(min(min(k0, k1), min(k2, k3)), (uint32_t)((dy * dy) << 6 | i)));
         }
     }
-    __syncthreads();
-
-    // ---- D: bounds.  thread (b, j): dx index j (dx = j - R) for all 33 dy; the dx = +R column: dy index j (+32 on j = 0)
-    const uint32_t cs01 = cs8[b][0], cs23 = cs8[b][1];
-    uint32_t bnd[C::NC];
-    {
-        const uint16_t* sp = s8 + b * B + j;
-        uint32_t top[C::SY];                                  // only a sliding window of 9 stays live after unrolling
+    unsigned long long pbest = ~0ull;                             // (partial, d2, dy, dx): only used to pick c0
+    if (bkey != 0xFFFFFFFFu) {
+        const int bi = (int)(bkey & 63u), dy = -R + bi;
+        const uint32_t d2 = (bkey & 0xFFFFu) >> C::KSHIFT;
+        const int dxsq = (int)d2 - dy * dy;
+        int dx = dx0;
 #pragma unroll
-        for (int r = 0; r < C::SY; ++r) {
-            const uint32_t pr = (uint32_t)sp[r * C::HS] | ((uint32_t)sp[r * C::HS + 8] << 16);
-            if (r < C::NC) top[r] = __builtin_amdgcn_sad_u16(pr, cs01, 0u);
-            if (r >= 8) bnd[r - 8] = __builtin_amdgcn_sad_u16(pr, cs23, top[r - 8]);
+        for (int j = 1; j < 4; ++j) dx = ((dx0 + j) * (dx0 + j) == dxsq) ? dx0 + j : dx;
+        pbest = ((unsigned long long)((bkey & 0xFFFF0000u) | d2) << 32) | (unsigned long long)(uint32_t)(((dy + R) << 8) | (dx + R));
+    }
+    // ---- the dx = +R column: lane = (block, chunk of KE dy), partial rows only
+    uint32_t eacc[C::KE];
+    const bool xok = blk_on && bx * B + R + B <= p.W;
+    {
+        const uint32_t* ecol = tile + b * C::BW + C::EDGE_COL;
+#pragma unroll
+        for (int i = 0; i < C::KE; ++i) {
+            const int dyi = min(g * C::KE + i, C::NCAND - 1);
+            uint32_t sacc = 0;
+#pragma unroll
+            for (int r = 0; r < P::PR; ++r)
+#pragma unroll
+                for (int q = 0; q < C::BW; ++q) sacc = __builtin_amdgcn_sad_u8(ecol[(dyi + P::STEP * r) * C::SW + q], c4[r][q], sacc);
+            eacc[i] = sacc;
+            const int dy = -R + g * C::KE + i;
+            const bool v = xok && dy <= R && y0 + dy >= 0 && y0 + dy + B <= p.H;
+            const unsigned long long k64 = ((unsigned long long)((sacc << 16) | (uint32_t)(R * R + dy * dy)) << 32) |
+                                           (unsigned long long)(uint32_t)(((dy + R) << 8) | (2 * R));
+            pbest = (v && k64 < pbest) ? k64 : pbest;
         }
     }
-    uint32_t ebnd0, ebnd1 = 0xFFFFu;                          // dx = +R column: dy index j, and 32 for j == 0
-    {
-        const uint16_t* sp = s8 + b * B + 2 * R;
-        auto colbound = [&](int dyi) {
-            const uint32_t pt = (uint32_t)sp[dyi * C::HS] | ((uint32_t)sp[dyi * C::HS + 8] << 16);
-            const uint32_t pb = (uint32_t)sp[(dyi + 8) * C::HS] | ((uint32_t)sp[(dyi + 8) * C::HS + 8] << 16);
-            return __builtin_amdgcn_sad_u16(pb, cs23, __builtin_amdgcn_sad_u16(pt, cs01, 0u));
-        };
-        ebnd0 = colbound(j);
-        if (j == 0) ebnd1 = colbound(32);
-    }
-    // validity (block inside the frame)
-    const int xj = bx * B + j - R;
-    const bool vx = blk_on && xj >= 0 && xj + B <= p.W;
-    const bool vxe = blk_on && bx * B + R + B <= p.W;
-    auto vy = [&](int dyi) { const int y = y0 + dyi - R; return y >= 0 && y + B <= p.H; };
-
-    // ---- E: minimum bound of the block -> its exact SAD.  key = bound<<16 | dyi<<8 | dxi
-    uint32_t mk = 0xFFFFFFFFu;
 #pragma unroll
-    for (int i = 0; i < C::NC; ++i) {
-        const uint32_t k = (bnd[i] << 16) | (uint32_t)(i << 8) | (uint32_t)j;
-        mk = (vx && vy(i) && k < mk) ? k : mk;
+    for (int m = 1; m < C::NG; m <<= 1) {
+        const unsigned long long o = shfl_xor_u64(pbest, m);
+        pbest = o < pbest ? o : pbest;
     }
-    {
-        const uint32_t k0 = (ebnd0 << 16) | (uint32_t)(j << 8) | 32u;
-        mk = (vxe && vy(j) && k0 < mk) ? k0 : mk;
-        const uint32_t k1 = (ebnd1 << 16) | (32u << 8) | 32u;
-        mk = (j == 0 && vxe && vy(32) && k1 < mk) ? k1 : mk;
-    }
-#pragma unroll
-    for (int m = 16; m >= 1; m >>= 1) mk = min(mk, (uint32_t)__shfl_xor(mk, m, 64));
-    // (0,0) is always a valid candidate of a full block, so mk is a real candidate when blk_on
-    const int idy = (int)((mk >> 8) & 0xFF), idx0 = (int)(mk & 0xFF);
+    // ---- 2. c0 = the block's minimum-partial candidate ((0,0) is always valid for a full block) and its exact SAD
+    const int dy0i = blk_on ? (int)((pbest >> 8) & 0xFF) : R, dx0i = blk_on ? (int)(pbest & 0xFF) : R;
     auto key64 = [&](uint32_t sad, int dyi, int dxi) {
         const int dy = dyi - R, dx = dxi - R;
-        return ((unsigned long long)((sad << 16) | (uint32_t)(dx * dx + dy * dy)) << 32) |
-               (unsigned long long)(uint32_t)((dyi << 8) | dxi);
+        return ((unsigned long long)((sad << 16) | (uint32_t)(dx * dx + dy * dy)) << 32) | (unsigned long long)(uint32_t)((dyi << 8) | dxi);
     };
-    uint32_t best_sad = sea_block_sad(raw, b, blk_on ? idy : R, blk_on ? idx0 : R, j, cur8);
-    unsigned long long best = key64(best_sad, blk_on ? idy : R, blk_on ? idx0 : R);
-
-    // ---- F: survivors
-    if (blk_on) {
+    uint32_t U = pde_two_rows(tile, curl, b, dy0i, dx0i, g);
 #pragma unroll
-        for (int i = 0; i < C::NC; ++i) {
-            if (vx && vy(i) && bnd[i] <= best_sad && !(i == idy && j == idx0)) {
-                const uint32_t pos = atomicAdd(&cnt[b], 1u);
-                if (pos < C::CAP) list[b][pos] = (uint32_t)(i << 8) | (uint32_t)j;
+    for (int m = 1; m < C::NG; m <<= 1) U += __shfl_xor(U, m, 64);
+    if (g == 0) bestk[b] = blk_on ? key64(U, dy0i, dx0i) : ~0ull;
+    // ---- 3. survivors: partial <= U.  One wave-wide ballot per (dy, column): no hit (the common case) costs a compare
+    // and a uniform branch; hits are appended at ballot-prefix positions, so the list needs no atomics.  c0 itself
+    // qualifies (its partial cannot exceed its SAD) and is simply evaluated a second time.
+    int nlist = 0;                                                // wave-uniform
+    {
+        int uj[4];                                                // per-column threshold; -1 rejects a clipped column
+#pragma unroll
+        for (int j = 0; j < 4; ++j) uj[j] = colv[j] ? (int)U : -1;
+        const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+        for (int i = 0; i < C::NCAND; ++i) {
+            const int dy = -R + i;
+            if (y0 + dy >= 0 && y0 + dy + B <= p.H) {
+                const uint32_t lo = (uint32_t)acc[i], hi = (uint32_t)(acc[i] >> 32);
+                const int s4[4] = {(int)(lo & 0xFFFFu), (int)(lo >> 16), (int)(hi & 0xFFFFu), (int)(hi >> 16)};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const bool hit = s4[j] <= uj[j];
+                    const unsigned long long mask = __ballot(hit);
+                    if (mask) {
+                        const int pos = nlist + __popcll(mask & below);
+                        if (hit && pos < P::CAP) list[pos] = ((uint32_t)b << 16) | ((uint32_t)i << 8) | (uint32_t)(4 * g + j);
+                        nlist += __popcll(mask);
+                    }
+                }
             }
         }
-        if (vxe && vy(j) && ebnd0 <= best_sad && !(j == idy && 32 == idx0)) {
-            const uint32_t pos = atomicAdd(&cnt[b], 1u);
-            if (pos < C::CAP) list[b][pos] = (uint32_t)(j << 8) | 32u;
-        }
-        if (j == 0 && vxe && vy(32) && ebnd1 <= best_sad && !(32 == idy && 32 == idx0)) {
-            const uint32_t pos = atomicAdd(&cnt[b], 1u);
-            if (pos < C::CAP) list[b][pos] = (32u << 8) | 32u;
+#pragma unroll
+        for (int i = 0; i < C::KE; ++i) {
+            const int dyi = g * C::KE + i, dy = dyi - R;
+            const bool hit = xok && dy <= R && y0 + dy >= 0 && y0 + dy + B <= p.H && eacc[i] <= U;
+            const unsigned long long mask = __ballot(hit);
+            if (mask) {
+                const int pos = nlist + __popcll(mask & below);
+                if (hit && pos < P::CAP) list[pos] = ((uint32_t)b << 16) | ((uint32_t)dyi << 8) | (uint32_t)(2 * R);
+                nlist += __popcll(mask);
+            }
         }
     }
-    __syncthreads();
-    const uint32_t n = cnt[b];
-    if (blk_on && n > C::CAP && j == 0) overflow = 1;
-    __syncthreads();
-    if (overflow) {                                           // hand the whole strip to the exhaustive kernel
-        if (tid == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int n = nlist;
+    if (n > P::CAP) {                                             // nothing to prune here: the exhaustive kernel takes the strip
+        if (lane == 0) {
             const uint32_t pos = atomicAdd(&strip_list[0], 1u);
             strip_list[1 + pos] = (uint32_t)strip;
         }
         return;
     }
-
-    // ---- G: exact SAD of the survivors (all 32 threads of a block on one candidate at a time)
-    for (uint32_t sidx = 0; sidx < n; ++sidx) {
-        const uint32_t cnd = list[b][sidx];
-        const int dyi = (int)(cnd >> 8), dxi = (int)(cnd & 0xFF);
-        const uint32_t sad = sea_block_sad(raw, b, dyi, dxi, j, cur8);
-        const unsigned long long k = key64(sad, dyi, dxi);
-        best = k < best ? k : best;
+    // ---- 4. exact SAD of the survivors, 8 per step (8 lanes x 2 rows each)
+    for (int base = 0; base < n; base += 64 / C::NG) {
+        const int idx = base + lane / C::NG;
+        const uint32_t e = list[min(idx, n - 1)];
+        const int bb = (int)(e >> 16), dyi = (int)((e >> 8) & 0xFF), dxi = (int)(e & 0xFF);
+        uint32_t sfull = pde_two_rows(tile, curl, bb, dyi, dxi, g);
+#pragma unroll
+        for (int m = 1; m < C::NG; m <<= 1) sfull += __shfl_xor(sfull, m, 64);
+        if (g == 0 && idx < n) atomicMin(&bestk[bb], key64(sfull, dyi, dxi));
     }
-    if (blk_on && j == 0) write_block_result(p, pair, bx, by, B, R, best);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (blk_on && g == 0) write_block_result(p, pair, bx, by, B, R, bestk[b]);
 }
 
 // Generic kernel for block/range pairs the packed-SAD kernel does not cover: one wave per block,
@@ -866,18 +890,16 @@ void launch_strip(const SadParams& p, int pairs, hipStream_t s) {
                        (const uint32_t*)nullptr);
 }
 
-// pruned search: sad_sea_kernel over every strip, then the exhaustive kernel over the overflow strips
-int launch_sea_16_16(ofps_hip_ctx* ctx, const SadParams& p, int pairs, hipStream_t s) {
+// pruned search: sad_pde_kernel over every strip, then the exhaustive kernel over the overflow strips
+int launch_pde_16_16(ofps_hip_ctx* ctx, const SadParams& p, int pairs, hipStream_t s) {
     using C = StripCfg<16, 16>;
-    static_assert(C::NB == SeaCfg::NB, "both kernels must cut the frame into the same strips");
     const int strips_per_row = (p.nbx + C::NB - 1) / C::NB;
     const int total = strips_per_row * p.nby * pairs;
     auto* strip_list = static_cast<uint32_t*>(ofps::scratch(ctx, ofps::S_WORK0, (size_t)(total + 1) * sizeof(uint32_t)));
     if (!strip_list) return OFPS_HIP_ENOMEM;
     OFPS_HIP_TRY(ctx, hipMemsetAsync(strip_list, 0, sizeof(uint32_t), s));
-    const int nwg_sea = (total + 7) / 8 * 8;
-    hipLaunchKernelGGL(sad_sea_kernel, dim3(nwg_sea), dim3(256), 0, s, p, strips_per_row, total, strip_list);
-    const int nwg = ((total + kStripWaves - 1) / kStripWaves + 7) / 8 * 8;
+    const int nwg = ((total + kStripWaves - 1) / kStripWaves + 7) / 8 * 8;     // multiple of 8: see the XCD remap
+    hipLaunchKernelGGL(sad_pde_kernel, dim3(nwg), dim3(64 * kStripWaves), 0, s, p, strips_per_row, total, strip_list);
     hipLaunchKernelGGL((sad_strip_kernel<16, 16>), dim3(nwg), dim3(64 * kStripWaves), 0, s, p, strips_per_row, total,
                        (const uint32_t*)strip_list);
     return OFPS_HIP_OK;
@@ -929,7 +951,7 @@ int sad_pairs_device(ofps_hip_ctx* ctx, const uint8_t* prev_base, size_t prev_pi
         // profiling only) the per-block kernel handles the pair.
         case 16016:
             if (strip_ok && ctx->sad_mode == OFPS_HIP_SAD_PRUNED) {
-                const int rc = launch_sea_16_16(ctx, p, pairs, s);
+                const int rc = launch_pde_16_16(ctx, p, pairs, s);
                 if (rc != OFPS_HIP_OK) return rc;
             } else if (strip_ok) launch_strip<16, 16>(p, pairs, s);
             else launch_qsad<16, 16, 5>(p, pairs, s);

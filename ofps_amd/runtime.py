@@ -93,7 +93,7 @@ class HipContext:
     SAD_EXHAUSTIVE, SAD_PRUNED = 0, 1
 
     def set_sad_mode(self, mode: int):
-        """0 = exhaustive (default), 1 = exact search with successive-elimination pruning."""
+        """0 = exhaustive (default), 1 = exact search with partial-distortion elimination (content-dependent run time)."""
         self._check(self._lib.ofps_hip_set_sad_mode(self._h, mode))
 
     def sad_pruned_overflow_strips(self) -> int:

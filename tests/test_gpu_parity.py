@@ -64,26 +64,33 @@ def test_sad_matches_oracle_bit_exact(ctx, W, H, B, R, kind):
     np.testing.assert_array_equal(ent_g.view(np.uint32), ent_o.view(np.uint32))   # f32 records: same bits
 
 
-PRUNED_CASES = [(256, 144, "seq"), (100, 70, "seq"), (192, 96, "random"), (192, 96, "flat"), (640, 368, "seq"),
+PRUNED_CASES = [(256, 144, "seq"), (100, 70, "seq"), (192, 96, "random"), (192, 96, "flat"), (640, 368, "seq"), (1280, 720, "pan"),
                 (272, 160, "gradient"), (1920, 1080, "seq")]
 
 
 @pytest.mark.parametrize("W,H,kind", PRUNED_CASES)
 def test_sad_pruned_mode_is_bit_identical_to_exhaustive_spec(ctx, W, H, kind):
-    """Successive-elimination mode (include/ofps_hip.h OFPS_HIP_SAD_PRUNED) must return the exhaustive winner on
+    """Partial-distortion-elimination mode (include/ofps_hip.h OFPS_HIP_SAD_PRUNED) must return the exhaustive winner on
     any content: structured frames (few survivors), noise (survivor lists overflow -> strips fall back to the
-    exhaustive kernel), constant frames (every bound ties at 0), smooth gradients (weak bounds)."""
+    exhaustive kernel), constant frames (every bound ties at 0), smooth gradients (weak bounds), a camera pan."""
     if kind == "gradient":
         yy, xx = np.mgrid[0:H, 0:W]
         a = ((xx * 3 + yy * 2) % 256).astype(np.uint8)
         fr = np.stack([a, np.roll(a, (3, -5), (0, 1))])
+    elif kind == "pan":                               # one global translation + sensor noise: almost nothing overflows
+        fr = synth.luma_sequence(2, W, H, max_step=12, seed=3, region=4096, noise=1)
     else:
         fr = _frames(W, H, 16, kind)
     ctx.set_sad_mode(ctx.SAD_PRUNED)
     try:
         ent_g, best_g = ctx.sad_flow(fr[0], fr[1], 16, 16, want_best=True)
+        overflow = ctx.sad_pruned_overflow_strips()
     finally:
         ctx.set_sad_mode(ctx.SAD_EXHAUSTIVE)
+    if kind == "pan":
+        assert overflow < 0.2 * ((W // 16 + 7) // 8) * (H // 16)          # the pruned kernel did the work, not the fallback
+    if kind in ("random", "flat"):
+        assert overflow > 0                                                # nothing to prune: the fallback is exercised
     ent_o, best_o = oracle.sad_flow(fr[0], fr[1], 16, 16, threads=8)
     np.testing.assert_array_equal(best_g, best_o)
     np.testing.assert_array_equal(ent_g.view(np.uint32), ent_o.view(np.uint32))
