@@ -370,28 +370,10 @@ __device__ __forceinline__ void strip_passes(const uint32_t (&c)[B][B / 4], cons
 
 constexpr int kStripWaves = 4;      // independent waves (strips) per workgroup; no workgroup barrier
 
+// one strip: staged window -> main pass -> dx = +R pass -> argmin -> records
 template <int B, int R>
-__global__ __launch_bounds__(64 * kStripWaves, (StripCfg<B, R>::MIN_WAVES)) void sad_strip_kernel(const SadParams p, int strips_per_row,
-                                                                      int total_strips,
-                                                                      const uint32_t* __restrict__ strip_list) {
+__device__ __forceinline__ void strip_body(const SadParams& p, int strips_per_row, int strip, uint32_t* tiles, int wave, int lane) {
     using C = StripCfg<B, R>;
-    __shared__ __attribute__((aligned(16))) uint32_t tiles[kStripWaves * C::TILE_DWORDS];
-
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    // XCD-aware remap: workgroup w lands on XCD w % 8; give each XCD a contiguous run of strips
-    // (the grid is padded to a multiple of 8 workgroups so the remap is a bijection)
-    // (indirect mode keeps the hardware order: the list is short and packed at the front, and the remap would put
-    // all of it on one XCD)
-    const int per_xcd = gridDim.x / 8;
-    const int lwg = strip_list ? (int)blockIdx.x : (int)(blockIdx.x % 8) * per_xcd + (int)(blockIdx.x / 8);
-    int strip = lwg * kStripWaves + wave;
-    if (strip_list) {
-        // indirect mode (overflow strips of the pruned search): strip_list[0] = count, ids follow
-        if (strip >= (int)strip_list[0]) return;
-        strip = (int)strip_list[1 + strip];
-    }
-    if (strip >= total_strips) return;
     const int strips_per_pair = strips_per_row * p.nby;
     const int pair = strip / strips_per_pair;
     const int rem = strip - pair * strips_per_pair;
@@ -551,6 +533,38 @@ __global__ __launch_bounds__(64 * kStripWaves, (StripCfg<B, R>::MIN_WAVES)) void
             p.out_best[3 * k + 2] = sad;
         }
     }
+}
+
+template <int B, int R>
+__global__ __launch_bounds__(64 * kStripWaves, (StripCfg<B, R>::MIN_WAVES)) void sad_strip_kernel(const SadParams p, int strips_per_row,
+                                                                      int total_strips) {
+    using C = StripCfg<B, R>;
+    __shared__ __attribute__((aligned(16))) uint32_t tiles[kStripWaves * C::TILE_DWORDS];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    // XCD-aware remap: workgroup w lands on XCD w % 8; give each XCD a contiguous run of strips
+    // (the grid is padded to a multiple of 8 workgroups so the remap is a bijection)
+    const int per_xcd = gridDim.x / 8;
+    const int lwg = (int)(blockIdx.x % 8) * per_xcd + (int)(blockIdx.x / 8);
+    const int strip = lwg * kStripWaves + wave;
+    if (strip >= total_strips) return;
+    strip_body<B, R>(p, strips_per_row, strip, tiles, wave, lane);
+}
+
+// The same search over an indirect list (overflow strips of the pruned mode): strip_list[0] = count, ids follow.  A short
+// grid walks the list with a stride (the count is only known on the device, and a full grid of workgroups that find
+// nothing to do costs ~3 us per thousand); hardware order, so consecutive entries spread over the XCDs.
+template <int B, int R>
+__global__ __launch_bounds__(64 * kStripWaves, (StripCfg<B, R>::MIN_WAVES)) void sad_strip_list_kernel(const SadParams p, int strips_per_row,
+                                                                           const uint32_t* __restrict__ strip_list) {
+    using C = StripCfg<B, R>;
+    __shared__ __attribute__((aligned(16))) uint32_t tiles[kStripWaves * C::TILE_DWORDS];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int count = (int)strip_list[0];
+#pragma unroll 1
+    for (int k = (int)blockIdx.x * kStripWaves + wave; k < count; k += (int)gridDim.x * kStripWaves)
+        strip_body<B, R>(p, strips_per_row, (int)strip_list[1 + k], tiles, wave, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -886,8 +900,7 @@ void launch_strip(const SadParams& p, int pairs, hipStream_t s) {
     const int strips_per_row = (p.nbx + C::NB - 1) / C::NB;
     const int total = strips_per_row * p.nby * pairs;
     const int nwg = ((total + kStripWaves - 1) / kStripWaves + 7) / 8 * 8;     // multiple of 8: see the XCD remap
-    hipLaunchKernelGGL((sad_strip_kernel<B, R>), dim3(nwg), dim3(64 * kStripWaves), 0, s, p, strips_per_row, total,
-                       (const uint32_t*)nullptr);
+    hipLaunchKernelGGL((sad_strip_kernel<B, R>), dim3(nwg), dim3(64 * kStripWaves), 0, s, p, strips_per_row, total);
 }
 
 // pruned search: sad_pde_kernel over every strip, then the exhaustive kernel over the overflow strips
@@ -900,7 +913,8 @@ int launch_pde_16_16(ofps_hip_ctx* ctx, const SadParams& p, int pairs, hipStream
     OFPS_HIP_TRY(ctx, hipMemsetAsync(strip_list, 0, sizeof(uint32_t), s));
     const int nwg = ((total + kStripWaves - 1) / kStripWaves + 7) / 8 * 8;     // multiple of 8: see the XCD remap
     hipLaunchKernelGGL(sad_pde_kernel, dim3(nwg), dim3(64 * kStripWaves), 0, s, p, strips_per_row, total, strip_list);
-    hipLaunchKernelGGL((sad_strip_kernel<16, 16>), dim3(nwg), dim3(64 * kStripWaves), 0, s, p, strips_per_row, total,
+    const int nwg_ind = nwg < 8 * ctx->num_cus ? nwg : 8 * ctx->num_cus;      // grid-stride walk of the overflow list
+    hipLaunchKernelGGL((sad_strip_list_kernel<16, 16>), dim3(nwg_ind), dim3(64 * kStripWaves), 0, s, p, strips_per_row,
                        (const uint32_t*)strip_list);
     return OFPS_HIP_OK;
 }
