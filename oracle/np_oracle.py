@@ -302,3 +302,61 @@ def lk_flow(prev, cur, levels=3, radius=4, iters=3):
             u = (u + du).astype(F); v = (v + dv).astype(F)
         flow = (u, v)
     return np.stack(flow, axis=-1).astype(F)
+
+
+def densify_interpolated(entries, w, h):
+    """Second restatement of new_densifier + add_vector (all entries) + interpolate_empty_cells + MotionField::from
+    (ofps/src/motion_field.rs:133-147, 164-178, 193-308), written from the reference's text with an ordered set for its
+    BTreeSet<InterpCell{neighbors, idx}>; f32 arithmetic through NumPy scalars in the reference's operation order."""
+    from sortedcontainers import SortedSet
+    e = np.asarray(entries, F).reshape(-1, 4)
+    cells = w * h
+    summ = np.zeros((cells, 2), F)
+    cnt = np.full(cells, np.finfo(F).eps, F)              # Matrix2xX::repeat(.., EPSILON): both rows stay equal
+    xs, ys = cell_index(e, w, h)
+    one = F(1.0)
+    for k in range(e.shape[0]):                           # add_vector: weight 1
+        i = int(ys[k]) * w + int(xs[k])
+        cnt[i] = F(cnt[i] + one)
+        summ[i, 0] = F(F(e[k, 2] * one) + summ[i, 0])
+        summ[i, 1] = F(F(e[k, 3] * one) + summ[i, 1])
+    nbrs = [(-1, 0), (0, -1), (-1, -1), (1, 0), (0, 1), (1, 1)]
+
+    def calc_counts(i):
+        x, y = i % w, i // w
+        return sum(1 for ox, oy in nbrs if 0 <= x + ox < w and 0 <= y + oy < h and cnt[(x + ox) + (y + oy) * w] > F(0.1))
+
+    queue = SortedSet((-calc_counts(i), i) for i in range(cells) if cnt[i] < F(0.5))
+    if len(queue) != cells:                               # "no motion vectors at all": nothing to interpolate from
+        while queue:
+            cell = queue.pop(0)
+            i = cell[1]
+            x, y = i % w, i // w
+            added = False
+            for ox, oy in nbrs:
+                nx, ny = x + ox, y + oy
+                if 0 <= nx < w and 0 <= ny < h:
+                    idx = nx + ny * w
+                    c = cnt[idx]
+                    if c > F(0.1):
+                        scale = F(one - F(np.sqrt(F(ox * ox + oy * oy)) * F(0.5)))
+                        inv_cnt = F(one / c)
+                        s = F(scale * inv_cnt)
+                        mx, my = F(s * summ[idx, 0]), F(s * summ[idx, 1])
+                        cnt[i] = F(cnt[i] + scale)
+                        summ[i, 0] = F(F(mx * scale) + summ[i, 0])
+                        summ[i, 1] = F(F(my * scale) + summ[i, 1])
+                        added = True
+            if not added:                                 # the reference re-inserts the cell and would spin; cannot happen
+                raise RuntimeError("interpolate_empty_cells: isolated queue")
+            for ox, oy in nbrs:
+                nx, ny = x + ox, y + oy
+                if 0 <= nx < w and 0 <= ny < h:
+                    idx = nx + ny * w
+                    key = -calc_counts(idx) + 1
+                    if (key, idx) in queue:
+                        queue.remove((key, idx)); queue.add((key - 1, idx))
+                    elif key != 0 and cnt[idx] < F(0.1):
+                        raise AssertionError("unreachable!() of motion_field.rs:288")
+    with np.errstate(divide="ignore", invalid="ignore"):
+        return (summ / cnt[:, None]).astype(F).reshape(h, w, 2)

@@ -234,3 +234,13 @@ def test_lk_flow_c_vs_numpy_bit_exact(W, H, levels, radius, iters):
     a = npo.lk_flow(fr[0], fr[1], levels, radius, iters)
     b = oracle.lk_flow(fr[0], fr[1], levels, radius, iters)
     np.testing.assert_array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+@pytest.mark.parametrize("n,w,h,seed", [(40, 12, 9, 8), (5, 16, 16, 1), (300, 40, 23, 2), (1, 7, 5, 3), (0, 5, 5, 4), (60, 14, 14, 5)])
+def test_interpolate_empty_cells_c_vs_python_bit_exact(n, w, h, seed):
+    """interpolate_empty_cells (ofps/src/motion_field.rs:193-294) has no test in the reference: the C oracle and a second
+    restatement written from the reference's text (ordered set = its BTreeSet) must agree bit for bit."""
+    e = _entries(n, seed)
+    a = npo.densify_interpolated(e, w, h)
+    b = oracle.densify_interpolated(e, w, h)
+    np.testing.assert_array_equal(a.view(np.uint32), b.view(np.uint32))
