@@ -187,7 +187,7 @@ def test_sad_bench_shape_batch_full_size(ctx):
     assert int(best[..., 2].astype(np.int64).sum()) == int(sum(int(b[:, 2].astype(np.int64).sum()) for b in best))
 
 
-@pytest.mark.parametrize("B,R", [(16, 16), (16, 8), (8, 32), (8, 8), (16, 24)])
+@pytest.mark.parametrize("B,R", [(16, 16), (16, 8), (16, 32), (8, 32), (8, 16), (8, 8), (16, 24)])
 def test_sad_device_path_with_rows_not_16_byte_aligned(ctx, B, R):
     """Device-resident frames whose row stride is only 4-byte aligned cannot use the 16-byte staging of the strip kernel:
     the per-block kernel (table geometries) or the generic kernel (others) must return the same bits."""
@@ -405,7 +405,7 @@ def test_almeida_reference_known_answer_ransac(ctx):
         np.testing.assert_allclose(est, q_o, atol=1e-4, rtol=0)
 
 
-@pytest.mark.parametrize("n_side", [(64, 36), (160, 90), (480, 270), (960, 540)])
+@pytest.mark.parametrize("n_side", [(30, 20), (40, 40), (64, 36), (120, 67), (160, 90), (480, 270), (960, 540)])   # wg<1,2,4,8>, step, dense
 def test_almeida_noisy_field_matches_oracle(ctx, n_side):
     """cfg3-shaped input (per-pixel entries, planted rotation + noise); covers the one-workgroup and the
     multi-launch solver.  Tolerance 2e-6 on quaternion components (sum order differs)."""
