@@ -654,3 +654,13 @@ def test_resident_chain_through_the_c_abi_memory_plumbing():
             c.free(p)
     finally:
         c.close()
+
+
+def test_almeida_ransac_large_sample_count(ctx):
+    """"Ransac samples" goes up to 16000 (almeida-estimator/src/lib.rs:92-95): a refit set above 8192 inliers cannot use
+    the one-workgroup solver and takes the multi-launch path after one small read-back of the inlier count."""
+    e = synth.rotation_field(200, 100, outlier_frac=0.1, seed=4)
+    cam = oracle.camera(16 / 9, 39.6 * 9 / 16)
+    q_g, _ = ctx.almeida(e, 16 / 9, 39.6 * 9 / 16, use_ransac=True, num_iters=50, inlier_deg=0.05, num_samples=12000, seed=9)
+    q_o = oracle.solve_ypr_ransac(e, cam, 50, 0.05, 12000, seed=9)
+    np.testing.assert_allclose(q_g, q_o, atol=1e-4, rtol=0)
