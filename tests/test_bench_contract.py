@@ -26,6 +26,7 @@ def test_committed_bench_line_follows_the_contract():
     c = d["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == d["unit"] and c["sample"]
     assert d["value"] / c["value"] >= 30.0                          # north_star target: >= 30x the CPU path of the same box
+    assert d["parity_check"]["ok"] is True                           # the searched batch was checked against the oracle
 
 
 def test_bench_defaults_match_baseline_config():
