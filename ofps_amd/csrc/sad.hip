@@ -783,11 +783,20 @@ __global__ __launch_bounds__(64 * kStripWaves, 3) void sad_pde_kernel(const SadP
 #pragma unroll
         for (int j = 0; j < 4; ++j) uj[j] = colv[j] ? (int)U : -1;
         const unsigned long long below = (1ull << lane) - 1ull;
+        // fast reject of a whole dy (4 columns, all 64 lanes) with packed-u16 minima: a half survives min(., U+1)
+        // unchanged-from-U+1 exactly when it exceeds U
+        typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+        const uint32_t u1 = min(U + 1u, 0xFFFFu) * 0x10001u;
+        auto any_le = [&](uint32_t v) {
+            const us2 m = __builtin_elementwise_min(__builtin_bit_cast(us2, v), __builtin_bit_cast(us2, u1));
+            return __builtin_bit_cast(uint32_t, m) ^ u1;
+        };
 #pragma unroll
         for (int i = 0; i < C::NCAND; ++i) {
             const int dy = -R + i;
             if (y0 + dy >= 0 && y0 + dy + B <= p.H) {
                 const uint32_t lo = (uint32_t)acc[i], hi = (uint32_t)(acc[i] >> 32);
+                if (!__ballot((any_le(lo) | any_le(hi)) != 0u)) continue;
                 const int s4[4] = {(int)(lo & 0xFFFFu), (int)(lo >> 16), (int)(hi & 0xFFFFu), (int)(hi >> 16)};
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -824,15 +833,20 @@ __global__ __launch_bounds__(64 * kStripWaves, 3) void sad_pde_kernel(const SadP
         }
         return;
     }
-    // ---- 4. exact SAD of the survivors, 8 per step (8 lanes x 2 rows each)
-    for (int base = 0; base < n; base += 64 / C::NG) {
-        const int idx = base + lane / C::NG;
-        const uint32_t e = list[min(idx, n - 1)];
-        const int bb = (int)(e >> 16), dyi = (int)((e >> 8) & 0xFF), dxi = (int)(e & 0xFF);
-        uint32_t sfull = pde_two_rows(tile, curl, bb, dyi, dxi, g);
+    // ---- 4. exact SAD of the survivors: 8 lanes x 2 rows per candidate, two independent candidates per lane group and
+    // step (the chain list -> window rows -> SAD -> 3 cross-lane adds -> LDS atomic is latency-bound on its own)
+    constexpr int PER_STEP = 2 * (64 / C::NG);
+    for (int base = 0; base < n; base += PER_STEP) {
+        const int idx0 = base + lane / C::NG, idx1 = idx0 + 64 / C::NG;
+        const uint32_t e0 = list[min(idx0, n - 1)], e1 = list[min(idx1, n - 1)];
+        const int bb0 = (int)(e0 >> 16), dyi0 = (int)((e0 >> 8) & 0xFF), dxi0 = (int)(e0 & 0xFF);
+        const int bb1 = (int)(e1 >> 16), dyi1 = (int)((e1 >> 8) & 0xFF), dxi1 = (int)(e1 & 0xFF);
+        uint32_t s0 = pde_two_rows(tile, curl, bb0, dyi0, dxi0, g);
+        uint32_t s1 = pde_two_rows(tile, curl, bb1, dyi1, dxi1, g);
 #pragma unroll
-        for (int m = 1; m < C::NG; m <<= 1) sfull += __shfl_xor(sfull, m, 64);
-        if (g == 0 && idx < n) atomicMin(&bestk[bb], key64(sfull, dyi, dxi));
+        for (int m = 1; m < C::NG; m <<= 1) { s0 += __shfl_xor(s0, m, 64); s1 += __shfl_xor(s1, m, 64); }
+        if (g == 0 && idx0 < n) atomicMin(&bestk[bb0], key64(s0, dyi0, dxi0));
+        if (g == 0 && idx1 < n) atomicMin(&bestk[bb1], key64(s1, dyi1, dxi1));
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
