@@ -51,6 +51,10 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--sad-mode", choices=["exhaustive", "pruned"], default="exhaustive",
                     help="search strategy of the SAD kernel (both return the same bits; pruned is content-dependent)")
+    ap.add_argument("--content", choices=["regions", "camera"], default="regions",
+                    help="regions (default, SURVEY.md 8d): an independent integer displacement per 64x64 region and frame.  "
+                         "camera: one global translation per frame + sensor noise +-1 (smooth camera motion, the decoder's "
+                         "real input) -- the content the opt-in pruned mode is for")
     ap.add_argument("--ref-mode", choices=["pairs", "key"], default="pairs",
                     help="pairs: frame k vs k+1 (default, no collective).  key: every frame vs one shared key frame that rank 0 "
                          "broadcasts to all ranks over RCCL inside the timed step (SURVEY.md 8e, north_star's shared-reference case)")
@@ -116,7 +120,8 @@ def main():
     # consecutive pair of it is a generated pair), so a step is long enough for the GPU to sit at its sustained clock
     # -- a 64-pair step (1 ms) left the first steps of a short run ~10 % slow -- without 150 s of host-side generation
     G = max(1, min(P, args.gen_pairs))
-    frames = synth.luma_sequence(G + 1, W, H, max_step=R, seed=synth.SEED0 + 1000 * rank, stride=stride)
+    gen = dict(max_step=R) if args.content == "regions" else dict(max_step=min(R, 12), region=1 << 14, noise=1)
+    frames = synth.luma_sequence(G + 1, W, H, seed=synth.SEED0 + 1000 * rank, stride=stride, **gen)
     walk = np.abs(((np.arange(P + 1) + G) % (2 * G)) - G) if G > 1 else np.arange(P + 1) % 2
     d_frames = torch.from_numpy(frames).cuda(non_blocking=False)[torch.from_numpy(walk).cuda()].contiguous()
     nbx, nby = W // B, H // B
@@ -195,7 +200,7 @@ def main():
                                      (3840, 2160, 8, 32): "cfg4 (BASELINE.json configs[3]): ",
                                      (640, 360, 16, 8): "cfg1 geometry (BASELINE.json configs[0]): "}.get((W, H, B, R), "")
                                     + f"{W}x{H} synthetic luma, {B}x{B} blocks, +-{R} full-search SAD"),
-                       "pairs_per_step": P, "generated_pairs": G, "vectors_per_pair": nblk, "parallelism": (f"frame-pair sharding x{world}" + (", key frame broadcast from rank 0 per step (RCCL)" if key_mode and use_dist else "")),
+                       "pairs_per_step": P, "generated_pairs": G, "content": args.content, "vectors_per_pair": nblk, "parallelism": (f"frame-pair sharding x{world}" + (", key frame broadcast from rank 0 per step (RCCL)" if key_mode and use_dist else "")),
                        "ref_mode": args.ref_mode,
                        "kernel": (f"sad_strip_kernel<{B},{R}>" if args.sad_mode == "exhaustive" else "sad_pde_kernel + sad_strip_kernel<16,16> on overflow strips"),
                        "sad_mode": args.sad_mode},
@@ -209,6 +214,10 @@ def main():
                                   "frac": round(abs_diffs / (launch_ms * 1e-3) / valu_peak, 4),
                                   "peak_basis": "SAD unit: 64 |a-b| per clock per SIMD (v_qsad_pk_u16_u8 16 cyc, measured)"}},
         }
+        if args.sad_mode == "pruned":
+            out["roofline"]["valu"]["note"] = ("exhaustive-equivalent rate: the pruned search returns the same winners but "
+                                               "evaluates fewer |a-b|, so this fraction can exceed 1")
+            out["roofline"]["traffic"] = None             # the committed PMC traffic figure belongs to the exhaustive kernel
 
     if args.pipeline:
         d_res = torch.empty((P, 4), dtype=torch.int32, device="cuda")
