@@ -129,6 +129,7 @@ bool HipSadDecoder::process_frame(MotionVectors& field, std::vector<RGBA>* out_f
     prm.block = (int)block_;
     prm.range = (int)range_;
     ofps_hip_frame_result res{};
+    ctx_.check(ofps_hip_set_sad_mode(ctx_.get(), pruned_ ? OFPS_HIP_SAD_PRUNED : OFPS_HIP_SAD_EXHAUSTIVE));
     ctx_.check(ofps_hip_push_frame(ctx_.get(), frame_, (int)w_, (int)h_, (int)w_, &prm, &res, out_.data(), nullptr));
     if (!res.have_vectors) return false;                              // first frame: no pair yet
     const size_t base = field.size();
@@ -138,7 +139,8 @@ bool HipSadDecoder::process_frame(MotionVectors& field, std::vector<RGBA>* out_f
 }
 
 std::vector<std::pair<std::string, PropertyMut>> HipSadDecoder::props_mut() {
-    return {{"Block size", PropertyMut::usize(&block_, 8, 16)}, {"Search range", PropertyMut::usize(&range_, 8, 32)}};
+    return {{"Block size", PropertyMut::usize(&block_, 8, 16)}, {"Search range", PropertyMut::usize(&range_, 8, 32)},
+            {"Exact pruning", PropertyMut::boolean(&pruned_)}};       // same vectors; faster on smooth camera motion
 }
 
 // ------------------------------------------------------------------ hip_lk

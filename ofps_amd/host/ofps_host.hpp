@@ -132,6 +132,7 @@ private:
     HipContext ctx_;
     std::unique_ptr<std::istream> in_;
     size_t w_, h_, block_ = 16, range_ = 16;
+    bool pruned_ = false;                  // OFPS_HIP_SAD_PRUNED: identical vectors, content-dependent run time
     std::optional<double> fps_;
     uint8_t* frame_ = nullptr;             // page-locked staging buffer for the frame being read
     std::vector<float> out_;

@@ -68,12 +68,14 @@ class Properties:
 class HipSadDecoder(Properties):
     """Decoder (ofps/src/decoder.rs:45-73) over an iterator / raw stream of luma frames: full-search SAD
     block vectors in av-decoder's record convention (av-decoder/src/lib.rs:404-419)."""
-    _PROPS = (("Block size", "usize", "block", 8, 16), ("Search range", "usize", "range", 8, 32))
+    _PROPS = (("Block size", "usize", "block", 8, 16), ("Search range", "usize", "range", 8, 32),
+              ("Exact pruning", "bool", "pruned", None, None))      # same vectors; faster on smooth camera motion (16x16, +-16)
 
     def __init__(self, frames: Iterable[np.ndarray], framerate: Optional[float] = None, device: int = 0):
         self.ctx = HipContext(device)
         self._it: Iterator[np.ndarray] = iter(frames)
         self.block, self.range = 16, 16
+        self.pruned = False
         self._prev: Optional[np.ndarray] = None
         self._cur: Optional[np.ndarray] = None
         self._fps = framerate
@@ -107,6 +109,7 @@ class HipSadDecoder(Properties):
                 self.ctx.stage_frame(self._cur)            # becomes the frame the vectors are relative to
         if out_frame is not None:
             out_frame[:] = [self._cur.copy()]
+        self.ctx.set_sad_mode(self.ctx.SAD_PRUNED if self.pruned else self.ctx.SAD_EXHAUSTIVE)
         r = self.ctx.push_frame(self._cur, self.block, self.range, detector=False, estimator=False, want_entries=True)
         if not r["have_vectors"]:                          # first frame of the stream / geometry change
             return False

@@ -96,3 +96,17 @@ def test_decoder_skip_frames_and_geometry_change():
     assert dec.get_aspect() == (128, 96)
     assert dec.process_frame(field) is True
     np.testing.assert_array_equal(np.array(field, np.float32).view(np.uint32), oracle.sad_flow(small[0], small[1], 16, 8)[0].view(np.uint32))
+
+
+def test_decoder_exact_pruning_property_returns_the_same_vectors():
+    from ofps_amd.plugins import HipSadDecoder
+    fr = synth.luma_sequence(4, 640, 368, max_step=10, seed=5, region=4096, noise=1)      # a camera pan
+    a, b = HipSadDecoder(list(fr)), HipSadDecoder(list(fr))
+    assert b.set_prop("Exact pruning", True) and b.pruned is True
+    for k in range(4):
+        fa, fb = [], []
+        assert a.process_frame(fa) == b.process_frame(fb)
+        assert len(fa) == len(fb)
+        if fa:
+            np.testing.assert_array_equal(np.array(fa, np.float32).view(np.uint32), np.array(fb, np.float32).view(np.uint32))
+            np.testing.assert_array_equal(np.array(fb, np.float32).view(np.uint32), oracle.sad_flow(fr[k - 1], fr[k], 16, 16)[0].view(np.uint32))
