@@ -664,3 +664,31 @@ def test_almeida_ransac_large_sample_count(ctx):
     q_g, _ = ctx.almeida(e, 16 / 9, 39.6 * 9 / 16, use_ransac=True, num_iters=50, inlier_deg=0.05, num_samples=12000, seed=9)
     q_o = oracle.solve_ypr_ransac(e, cam, 50, 0.05, 12000, seed=9)
     np.testing.assert_allclose(q_g, q_o, atol=1e-4, rtol=0)
+
+
+def test_sad_pruned_equals_exhaustive_on_random_geometries_and_content(ctx):
+    """30 seeded random cases (frame size, content, noise, motion): the pruned search must return exactly what the
+    exhaustive kernel returns -- GPU vs GPU, so large counts are cheap; the exhaustive kernel itself is pinned by the
+    oracle cases above."""
+    rng = np.random.default_rng(2024)
+    for case in range(30):
+        W = int(rng.integers(3, 45)) * 16 + int(rng.integers(0, 16))
+        H = int(rng.integers(2, 30)) * 16 + int(rng.integers(0, 16))
+        kind = int(rng.integers(0, 5))
+        if kind == 0:
+            fr = synth.luma_sequence(2, W, H, max_step=int(rng.integers(0, 17)), seed=case, region=1 << 14, noise=int(rng.integers(0, 4)))
+        elif kind == 1:
+            fr = synth.luma_sequence(2, W, H, max_step=16, seed=case, region=int(rng.choice([32, 64, 128])))
+        elif kind == 2:
+            fr = synth.random_luma(2, W, H, seed=case)
+        elif kind == 3:
+            fr = synth.flatten_regions(synth.luma_sequence(2, W, H, max_step=8, seed=case), region=48, seed=case)
+        else:                                              # saturated / two-level content: many exact ties
+            fr = (synth.random_luma(2, W, H, seed=case) > 200).astype(np.uint8) * 255
+        _, b0 = ctx.sad_flow(fr[0], fr[1], 16, 16, want_best=True)
+        ctx.set_sad_mode(ctx.SAD_PRUNED)
+        try:
+            _, b1 = ctx.sad_flow(fr[0], fr[1], 16, 16, want_best=True)
+        finally:
+            ctx.set_sad_mode(ctx.SAD_EXHAUSTIVE)
+        np.testing.assert_array_equal(b1, b0, err_msg=f"case {case}: {W}x{H} kind {kind}")
