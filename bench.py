@@ -89,7 +89,20 @@ def cpu_baseline(frames: np.ndarray, block: int, rng: int, budget_s: float):
         el = time.perf_counter() - t0
         if el >= budget_s:
             break
-    return {"value": round(done * nblk / el / 1e6, 4), "unit": "Mvectors/s", "cores": threads, "kind": "port",
+    # the tail of the path on the vectors of one pair, the way the reference runs it: one thread per plugin call
+    ent, _ = oracle.sad_flow(frames[0], frames[1], block, rng, threads=threads)
+    cam = oracle.camera(16 / 9, 22.275)
+
+    def ms(fn, reps=3):
+        t = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        return round((time.perf_counter() - t) / reps * 1e3, 3)
+    tail = {"n_vectors": int(len(ent)),
+            "almeida_lsq_ms": ms(lambda: oracle.solve_ypr_given(ent, cam)),
+            "almeida_ransac_ms": ms(lambda: oracle.solve_ypr_ransac(ent, cam, 200, 0.05, 1000, seed=1)),
+            "block_motion_detect_ms": ms(lambda: oracle.detect_motion(ent)), "threads": 1}
+    return {"value": round(done * nblk / el / 1e6, 4), "unit": "Mvectors/s", "cores": threads, "kind": "port", "tail_single_thread": tail,
             "sample": f"{done} frame-pair searches cycling over the bench sequence, {frames.shape[2]}x{frames.shape[1]}, "
                       f"{block}x{block} blocks, +-{rng}, {el:.1f} s wall",
             "ms_per_pair": round(el / done * 1e3, 2),
