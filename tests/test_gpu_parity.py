@@ -692,3 +692,44 @@ def test_sad_pruned_equals_exhaustive_on_random_geometries_and_content(ctx):
         finally:
             ctx.set_sad_mode(ctx.SAD_EXHAUSTIVE)
         np.testing.assert_array_equal(b1, b0, err_msg=f"case {case}: {W}x{H} kind {kind}")
+
+
+def test_contexts_are_independent_across_host_threads():
+    """Plugins are `Send`, not `Sync` (ofps/src/plugins/mod.rs:244,261,278): one context per plugin object, used by one
+    thread at a time, different contexts concurrently from different threads (the tracking worker runs its estimators
+    on a rayon pool, tracking/worker.rs:347-361).  Four threads, four contexts, interleaved calls: every result exact."""
+    import threading
+    from ofps_amd.runtime import HipContext
+    results, errors = {}, []
+
+    def work(tag):
+        try:
+            c = HipContext(0)
+            fr = synth.luma_sequence(3, 320, 192, max_step=8, seed=100 + tag)
+            outs = []
+            for k in (1, 2):
+                for _ in range(10):
+                    ent = c.sad_flow(fr[k - 1], fr[k], 16, 8)
+                    q, _ = c.almeida(ent, 16 / 9, 22.275, use_ransac=bool(tag & 1), num_iters=50, seed=7)
+                    det = c.detect(ent)
+                outs.append((ent, q, det))
+            results[tag] = (fr, outs)
+            c.close()
+        except Exception as e:                  # surfaced below: an exception in a thread would otherwise be lost
+            errors.append((tag, repr(e)))
+
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(4)]
+    [t.start() for t in threads]
+    [t.join() for t in threads]
+    assert not errors, errors
+    cam = oracle.camera(16 / 9, 22.275)
+    for tag, (fr, outs) in results.items():
+        for k, (ent, q, det) in zip((1, 2), outs):
+            eo, _ = oracle.sad_flow(fr[k - 1], fr[k], 16, 8)
+            np.testing.assert_array_equal(ent.view(np.uint32), eo.view(np.uint32))
+            qo = oracle.solve_ypr_ransac(eo, cam, 50, 0.05, 1000, seed=7) if tag & 1 else oracle.solve_ypr_given(eo, cam)
+            np.testing.assert_allclose(q, qo, atol=1e-4 if tag & 1 else 2e-6, rtol=0)
+            do = oracle.detect_motion(eo)
+            assert (det is None) == (do is None)
+            if det is not None:
+                assert det[0] == do[0]
