@@ -9,8 +9,8 @@
 //
 // One fused kernel: a workgroup owns a 64x16 tile of mask pixels; it stages the 78x30 luma window (halo 7 =
 // 2 Sobel + 5 dilation) in LDS, runs the separable derivative ([-1,-2,0,2,1] along x, then along y), keeps the
-// thresholded 74x26 window as bytes in LDS and ORs the 89 taps of the ellipse.  HBM traffic: 1.27 B read per
-// pixel (halo) + 1 B written; the kernel is latency-bound at 1080p (2 M pixels, ~20 us).
+// thresholded 74x26 window as ballot-packed row masks in LDS and resolves the ellipse with four 128-bit window
+// extractions per pixel (rows of equal half-width OR-ed first).  HBM traffic: 1.27 B read per pixel (halo) + 1 B written.
 //
 // compact_*: order-preserving stream compaction of the per-pixel records by the mask (the reference's raster
 // loop `continue`s on masked pixels, so the surviving records keep raster order -- which is also the order
@@ -29,48 +29,72 @@ __device__ __forceinline__ int reflect101(int p, int len) {
     return p;
 }
 
+// extract bits [s, s + n) of the 128-bit row mask (lo = columns 0..63, hi = columns 64..)
+__device__ __forceinline__ bool mask_any(unsigned long long lo, unsigned long long hi, int s, int n) {
+    const unsigned long long v = s >= 64 ? hi >> (s - 64) : (s ? (lo >> s) | (hi << (64 - s)) : lo);
+    return (v & ((1ull << n) - 1ull)) != 0ull;
+}
+
 __global__ __launch_bounds__(256) void contrast_mask_kernel(const uint8_t* __restrict__ gray, int W, int H, int stride,
                                                             uint8_t* __restrict__ mask) {
     __shared__ uint8_t g[MG_H][MG_W + 2];
     __shared__ short hx[MG_H][MS_W + 2];
-    __shared__ uint8_t thr[MS_H][MS_W + 2];
-    const int tid = threadIdx.x;
+    __shared__ unsigned long long rowbits[MS_H][2];          // thresholded window, one bit per column
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int x0 = blockIdx.x * MT_W, y0 = blockIdx.y * MT_H;
-    // luma window; coordinates outside the image follow BORDER_REFLECT_101 (only consumed by Sobel taps of
-    // in-image pixels: out-of-image thresholded pixels are forced to 0 below)
-    for (int i = tid; i < MG_H * MG_W; i += 256) {
-        const int r = i / MG_W, c = i - r * MG_W;
-        const int yy = reflect101(y0 - 7 + r, H), xx = reflect101(x0 - 7 + c, W);
-        g[r][c] = gray[(size_t)yy * stride + xx];
+    // luma window; coordinates outside the image follow BORDER_REFLECT_101 (only consumed by Sobel taps of in-image
+    // pixels: out-of-image thresholded pixels are forced to 0 below).  One column per thread, rows strided: no
+    // per-element division.
+    {
+        constexpr int RPP = 256 / MG_W;                       // 3 rows per pass
+        const int c = tid % MG_W, r0 = tid / MG_W;
+        if (r0 < RPP) {
+            const int xx = reflect101(x0 - 7 + c, W);
+            for (int r = r0; r < MG_H; r += RPP) g[r][c] = gray[(size_t)reflect101(y0 - 7 + r, H) * stride + xx];
+        }
     }
     __syncthreads();
     // d/dx: hx(r, c) for the thresholded window's columns (window col c <-> luma col c + 2)
-    for (int i = tid; i < MG_H * MS_W; i += 256) {
-        const int r = i / MS_W, c = i - r * MS_W;
-        hx[r][c] = (short)(-(int)g[r][c] - 2 * (int)g[r][c + 1] + 2 * (int)g[r][c + 3] + (int)g[r][c + 4]);
+    {
+        constexpr int RPP = 256 / MS_W;                       // 3
+        const int c = tid % MS_W, r0 = tid / MS_W;
+        if (r0 < RPP) {
+            for (int r = r0; r < MG_H; r += RPP)
+                hx[r][c] = (short)(-(int)g[r][c] - 2 * (int)g[r][c + 1] + 2 * (int)g[r][c + 3] + (int)g[r][c + 4]);
+        }
     }
     __syncthreads();
-    // d/dy + threshold; pixels outside the image never win the dilation's max
-    for (int i = tid; i < MS_H * MS_W; i += 256) {
-        const int r = i / MS_W, c = i - r * MS_W;
-        const int s = -(int)hx[r][c] - 2 * (int)hx[r + 1][c] + 2 * (int)hx[r + 3][c] + (int)hx[r + 4][c];
-        const int yy = y0 - 5 + r, xx = x0 - 5 + c;
-        thr[r][c] = (s > 20 && yy >= 0 && yy < H && xx >= 0 && xx < W) ? 1 : 0;
+    // d/dy + threshold, packed by ballots: wave w owns rows w, w+4, ...; lanes = columns 0..63, then 64..73.
+    // Pixels outside the image never win the dilation's max.
+    for (int r = wave; r < MS_H; r += 4) {
+        const int yy = y0 - 5 + r;
+        const bool row_in = yy >= 0 && yy < H;
+        auto thr_at = [&](int c) {
+            const int s = -(int)hx[r][c] - 2 * (int)hx[r + 1][c] + 2 * (int)hx[r + 3][c] + (int)hx[r + 4][c];
+            const int xx = x0 - 5 + c;
+            return s > 20 && row_in && xx >= 0 && xx < W;
+        };
+        const unsigned long long lo = __ballot(thr_at(lane));
+        const unsigned long long hi = __ballot(lane < MS_W - 64 && thr_at(64 + lane));
+        if (lane == 0) { rowbits[r][0] = lo; rowbits[r][1] = hi; }
     }
     __syncthreads();
-    // ellipse rows: half-width cvRound(5*sqrt(1 - dy^2/25)) for dy = -5..5
-    constexpr int HW[11] = {0, 3, 4, 5, 5, 5, 5, 5, 4, 3, 0};
-    const int lx = tid & 63;
+    // dilation by the 11x11 ellipse, row half-widths cvRound(5*sqrt(1 - dy^2/25)) = {0,3,4,5,5,5,5,5,4,3,0}: rows that
+    // share a half-width are OR-ed first (wave-uniform), then one window extraction per half-width and lane
+    const int lx = lane;
 #pragma unroll
     for (int k = 0; k < MT_H / 4; ++k) {
-        const int ly = (tid >> 6) + 4 * k;
-        unsigned m = 0;
+        const int ly = wave + 4 * k;
+        unsigned long long m0l = rowbits[ly][0] | rowbits[ly + 10][0], m0h = rowbits[ly][1] | rowbits[ly + 10][1];
+        unsigned long long m3l = rowbits[ly + 1][0] | rowbits[ly + 9][0], m3h = rowbits[ly + 1][1] | rowbits[ly + 9][1];
+        unsigned long long m4l = rowbits[ly + 2][0] | rowbits[ly + 8][0], m4h = rowbits[ly + 2][1] | rowbits[ly + 8][1];
+        unsigned long long m5l = 0, m5h = 0;
 #pragma unroll
-        for (int i = 0; i < 11; ++i)
-#pragma unroll
-            for (int d = -HW[i]; d <= HW[i]; ++d) m |= thr[ly + i][lx + 5 + d];
+        for (int i = 3; i <= 7; ++i) { m5l |= rowbits[ly + i][0]; m5h |= rowbits[ly + i][1]; }
+        const bool m = mask_any(m0l, m0h, lx + 5, 1) || mask_any(m3l, m3h, lx + 2, 7) || mask_any(m4l, m4h, lx + 1, 9) ||
+                       mask_any(m5l, m5h, lx, 11);
         const int x = x0 + lx, y = y0 + ly;
-        if (x < W && y < H) mask[(size_t)y * W + x] = (uint8_t)m;
+        if (x < W && y < H) mask[(size_t)y * W + x] = m ? 1 : 0;
     }
 }
 
