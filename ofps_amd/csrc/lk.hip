@@ -7,7 +7,7 @@
 // "Parity unpinned" w.r.t. the reference; bit-exact vs the build's own CPU restatement: every thread owns one
 // pixel and runs the oracle's loops in the oracle's order (f32, no FMA contraction, IEEE divide).
 //
-// Kernels per pyramid level: u8->f32 (level 0) / separable [1 4 6 4 1]/16 downsample, central-difference
+// Kernels per pyramid level: u8->f32 (level 0) / [1 4 6 4 1]/16 x [1 4 6 4 1]/16 downsample (both passes fused), central-difference
 // gradients of the previous frame, the 2x2 structure tensor G summed over the (2r+1)^2 window (once per
 // level: it does not depend on the flow), then `iters` Gauss-Newton steps (b = sum grad * (I - J(q+flow)),
 // flow += G^-1 b).  All of it is window/stencil work on f32 planes: L1/L2-resident reads, VALU-bound on the
@@ -18,30 +18,34 @@ namespace ofps {
 
 __device__ __forceinline__ int lk_clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
-__global__ __launch_bounds__(256) void lk_u8_to_f32_kernel(const uint8_t* __restrict__ src, int W, int H, int stride,
-                                                           float* __restrict__ dst) {
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x < W && y < H) dst[(size_t)y * W + x] = (float)src[(size_t)y * stride + x];
-}
-
-// horizontal [1 4 6 4 1]/16 + decimation: in (w x h) -> tmp (w1 x h)
-__global__ __launch_bounds__(256) void lk_pyr_h_kernel(const float* __restrict__ in, int w, int h, float* __restrict__ tmp, int w1) {
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= w1 || y >= h) return;
-    const float* r = in + (size_t)y * w;
-    const float a = r[lk_clampi(2 * x - 2, 0, w - 1)], b = r[lk_clampi(2 * x - 1, 0, w - 1)], c = r[lk_clampi(2 * x, 0, w - 1)],
-                d = r[lk_clampi(2 * x + 1, 0, w - 1)], e = r[lk_clampi(2 * x + 2, 0, w - 1)];
-    tmp[(size_t)y * w1 + x] = ((((a + 4.0f * b) + 6.0f * c) + 4.0f * d) + e) * 0.0625f;
-}
-
-// vertical pass: tmp (w1 x h) -> out (w1 x h1)
-__global__ __launch_bounds__(256) void lk_pyr_v_kernel(const float* __restrict__ tmp, int w1, int h, float* __restrict__ out, int h1) {
+// Both pyramid passes in one launch, for both frames (blockIdx.z): each thread forms the five horizontally filtered
+// values its output needs and filters them vertically: the oracle's two separable passes (lk_pyr_down, horizontal
+// then vertical, each ((((a + 4b) + 6c) + 4d) + e) / 16) -- the same bits without the intermediate plane and with a
+// quarter of the launches.
+__global__ __launch_bounds__(256) void lk_pyr_down_kernel(const float* __restrict__ in0, const float* __restrict__ in1, int w, int h,
+                                                          float* __restrict__ out0, float* __restrict__ out1, int w1, int h1) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= w1 || y >= h1) return;
-    const float a = tmp[(size_t)lk_clampi(2 * y - 2, 0, h - 1) * w1 + x], b = tmp[(size_t)lk_clampi(2 * y - 1, 0, h - 1) * w1 + x],
-                c = tmp[(size_t)lk_clampi(2 * y, 0, h - 1) * w1 + x], d = tmp[(size_t)lk_clampi(2 * y + 1, 0, h - 1) * w1 + x],
-                e = tmp[(size_t)lk_clampi(2 * y + 2, 0, h - 1) * w1 + x];
-    out[(size_t)y * w1 + x] = ((((a + 4.0f * b) + 6.0f * c) + 4.0f * d) + e) * 0.0625f;
+    const float* in = blockIdx.z ? in1 : in0;
+    float* out = blockIdx.z ? out1 : out0;
+    const int xa = lk_clampi(2 * x - 2, 0, w - 1), xb = lk_clampi(2 * x - 1, 0, w - 1), xc = lk_clampi(2 * x, 0, w - 1),
+              xd = lk_clampi(2 * x + 1, 0, w - 1), xe = lk_clampi(2 * x + 2, 0, w - 1);
+    float t[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        const float* r = in + (size_t)lk_clampi(2 * y - 2 + k, 0, h - 1) * w;
+        t[k] = ((((r[xa] + 4.0f * r[xb]) + 6.0f * r[xc]) + 4.0f * r[xd]) + r[xe]) * 0.0625f;
+    }
+    out[(size_t)y * w1 + x] = ((((t[0] + 4.0f * t[1]) + 6.0f * t[2]) + 4.0f * t[3]) + t[4]) * 0.0625f;
+}
+
+__global__ __launch_bounds__(256) void lk_u8_to_f32_pair_kernel(const uint8_t* __restrict__ s0, const uint8_t* __restrict__ s1, int W, int H,
+                                                                int stride, float* __restrict__ d0, float* __restrict__ d1) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= W || y >= H) return;
+    const uint8_t* src = blockIdx.z ? s1 : s0;
+    float* dst = blockIdx.z ? d1 : d0;
+    dst[(size_t)y * W + x] = (float)src[(size_t)y * stride + x];
 }
 
 __global__ __launch_bounds__(256) void lk_grad_kernel(const float* __restrict__ I, int w, int h, float* __restrict__ gx,
@@ -395,22 +399,23 @@ int lk_flow_device(ofps_hip_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_cu
     for (int l = 1; l < levels; ++l) { ws[l] = (ws[l - 1] + 1) / 2; hs[l] = (hs[l - 1] + 1) / 2; }
     for (int l = 0; l < levels; ++l) off[l + 1] = off[l] + (size_t)ws[l] * hs[l];
     const size_t plane0 = (size_t)W * H, pyr = off[levels];
-    // layout: I pyramid | J pyramid | tmp | gx | gy | G (float4) | flowA (float2) | flowB (float2)
-    const size_t floats = 2 * pyr + 3 * plane0 + 4 * plane0 + 2 * plane0 + 2 * plane0;
+    // layout: I pyramid | J pyramid | gx | gy | G (float4) | flowA (float2) | flowB (float2)
+    const size_t floats = 2 * pyr + 2 * plane0 + 4 * plane0 + 2 * plane0 + 2 * plane0;
     auto* base = static_cast<float*>(scratch(ctx, S_WORK0, floats * sizeof(float)));
     if (!base) return OFPS_HIP_ENOMEM;
-    float* Ip = base; float* Jp = Ip + pyr; float* tmp = Jp + pyr; float* gx = tmp + plane0; float* gy = gx + plane0;
+    float* Ip = base; float* Jp = Ip + pyr; float* gx = Jp + pyr; float* gy = gx + plane0;
     float4* G = reinterpret_cast<float4*>(gy + plane0);
     float2* fa = reinterpret_cast<float2*>(reinterpret_cast<float*>(G) + 4 * plane0);
     float2* fb = fa + plane0;
 
-    hipLaunchKernelGGL(lk_u8_to_f32_kernel, lk_grid(W, H), dim3(256), 0, s, d_prev, W, H, stride, Ip);
-    hipLaunchKernelGGL(lk_u8_to_f32_kernel, lk_grid(W, H), dim3(256), 0, s, d_cur, W, H, stride, Jp);
+    {
+        dim3 g2 = lk_grid(W, H); g2.z = 2;
+        hipLaunchKernelGGL(lk_u8_to_f32_pair_kernel, g2, dim3(256), 0, s, d_prev, d_cur, W, H, stride, Ip, Jp);
+    }
     for (int l = 1; l < levels; ++l) {
-        for (float* P : {Ip, Jp}) {
-            hipLaunchKernelGGL(lk_pyr_h_kernel, lk_grid(ws[l], hs[l - 1]), dim3(256), 0, s, P + off[l - 1], ws[l - 1], hs[l - 1], tmp, ws[l]);
-            hipLaunchKernelGGL(lk_pyr_v_kernel, lk_grid(ws[l], hs[l]), dim3(256), 0, s, tmp, ws[l], hs[l - 1], P + off[l], hs[l]);
-        }
+        dim3 g2 = lk_grid(ws[l], hs[l]); g2.z = 2;
+        hipLaunchKernelGGL(lk_pyr_down_kernel, g2, dim3(256), 0, s, Ip + off[l - 1], Jp + off[l - 1], ws[l - 1], hs[l - 1],
+                           Ip + off[l], Jp + off[l], ws[l], hs[l]);
     }
     float2* cur_flow = fa;
     float2* other = fb;
