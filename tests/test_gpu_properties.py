@@ -38,3 +38,25 @@ def test_hip_detect_matches_oracle_on_adversarial_inputs(ctx, e, geom, target):
     if a is not None:
         assert a[0] == b[0]
         np.testing.assert_array_equal(a[1].view(np.uint32), b[1].view(np.uint32))
+
+
+@settings(max_examples=60, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture])
+@given(w=st.integers(1, 150), h=st.integers(1, 100), b=st.sampled_from([8, 16, 12]), r=st.sampled_from([0, 3, 4, 8, 12, 16, 20, 32]),
+       seed=st.integers(0, 2**31 - 1), kind=st.sampled_from(["noise", "binary", "coarse", "flat"]))
+def test_hip_sad_matches_oracle_on_random_geometry(ctx, w, h, b, r, seed, kind):
+    rng = np.random.default_rng(seed)
+    if kind == "noise":
+        fr = rng.integers(0, 256, (2, h, w), dtype=np.uint8)
+    elif kind == "binary":                                   # saturated two-level content: exact ties everywhere
+        fr = (rng.integers(0, 2, (2, h, w), dtype=np.uint8) * 255).astype(np.uint8)
+    elif kind == "coarse":                                   # 4-level content shifted by a random vector
+        base = (rng.integers(0, 4, (h + 64, w + 64), dtype=np.uint8) * 64).astype(np.uint8)
+        dx, dy = int(rng.integers(-r, r + 1)), int(rng.integers(-r, r + 1))
+        fr = np.stack([base[32:32 + h, 32:32 + w], base[32 + dy:32 + dy + h, 32 + dx:32 + dx + w]])
+    else:
+        fr = np.full((2, h, w), int(rng.integers(0, 256)), np.uint8)
+    fr = np.ascontiguousarray(fr)
+    ent_g, best_g = ctx.sad_flow(fr[0], fr[1], b, r, want_best=True)
+    ent_o, best_o = oracle.sad_flow(fr[0], fr[1], b, r)
+    np.testing.assert_array_equal(best_g, best_o)
+    np.testing.assert_array_equal(ent_g.view(np.uint32), ent_o.view(np.uint32))
