@@ -18,7 +18,7 @@ def ctx():
     c.close()
 
 
-@settings(max_examples=80, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture])
+@settings(max_examples=80, deadline=None, derandomize=True, suppress_health_check=[HealthCheck.function_scoped_fixture])
 @given(e=entries(max_n=200), w=st.integers(1, 40), h=st.integers(1, 40))
 def test_hip_densify_matches_oracle_on_adversarial_inputs(ctx, e, w, h):
     f_g, cells_g = ctx.densify(e, w, h, want_cells=True)
@@ -27,7 +27,7 @@ def test_hip_densify_matches_oracle_on_adversarial_inputs(ctx, e, w, h):
     np.testing.assert_array_equal(f_g.view(np.uint32), f_o.view(np.uint32))        # NaN payloads included
 
 
-@settings(max_examples=40, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture])
+@settings(max_examples=40, deadline=None, derandomize=True, suppress_health_check=[HealthCheck.function_scoped_fixture])
 @given(e=entries(max_n=300), geom=st.sampled_from([(0.05, 3), (0.2, 2), (0.5, 1), (0.01, 4)]), target=st.sampled_from([0.0001, 0.003, 0.05]))
 def test_hip_detect_matches_oracle_on_adversarial_inputs(ctx, e, geom, target):
     e = np.nan_to_num(e, nan=0.25, posinf=2.0, neginf=-1.0)
@@ -40,7 +40,7 @@ def test_hip_detect_matches_oracle_on_adversarial_inputs(ctx, e, geom, target):
         np.testing.assert_array_equal(a[1].view(np.uint32), b[1].view(np.uint32))
 
 
-@settings(max_examples=60, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture])
+@settings(max_examples=60, deadline=None, derandomize=True, suppress_health_check=[HealthCheck.function_scoped_fixture])
 @given(w=st.integers(1, 150), h=st.integers(1, 100), b=st.sampled_from([8, 16, 12]), r=st.sampled_from([0, 3, 4, 8, 12, 16, 20, 32]),
        seed=st.integers(0, 2**31 - 1), kind=st.sampled_from(["noise", "binary", "coarse", "flat"]))
 def test_hip_sad_matches_oracle_on_random_geometry(ctx, w, h, b, r, seed, kind):

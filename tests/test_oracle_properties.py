@@ -22,7 +22,7 @@ def entries(draw, max_n=60):
     return e
 
 
-@settings(max_examples=120, deadline=None)
+@settings(max_examples=120, deadline=None, derandomize=True)
 @given(entries(), st.integers(1, 20), st.integers(1, 20))
 def test_densify_cells_and_sums_agree_on_adversarial_inputs(e, w, h):
     with np.errstate(all="ignore"):
@@ -35,7 +35,7 @@ def test_densify_cells_and_sums_agree_on_adversarial_inputs(e, w, h):
         np.testing.assert_array_equal(f_c.view(np.uint32), np.asarray(f_n, np.float32).view(np.uint32))
 
 
-@settings(max_examples=60, deadline=None)
+@settings(max_examples=60, deadline=None, derandomize=True)
 @given(entries(max_n=120), st.sampled_from([(0.05, 3), (0.2, 2), (0.5, 1), (0.01, 4)]), st.sampled_from([0.0001, 0.003, 0.05, 0.1]))
 def test_detect_motion_agrees_on_adversarial_inputs(e, geom, target):
     e = np.nan_to_num(e, nan=0.25, posinf=2.0, neginf=-1.0)          # the detector's sqrt(x^2+y^2) >= t on NaN is its own topic
