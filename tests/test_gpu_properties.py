@@ -60,3 +60,37 @@ def test_hip_sad_matches_oracle_on_random_geometry(ctx, w, h, b, r, seed, kind):
     ent_o, best_o = oracle.sad_flow(fr[0], fr[1], b, r)
     np.testing.assert_array_equal(best_g, best_o)
     np.testing.assert_array_equal(ent_g.view(np.uint32), ent_o.view(np.uint32))
+
+
+@settings(max_examples=25, deadline=None, derandomize=True, suppress_health_check=[HealthCheck.function_scoped_fixture])
+@given(w=st.integers(2, 90), h=st.integers(2, 70), levels=st.integers(1, 4), radius=st.integers(1, 7), iters=st.integers(1, 3),
+       seed=st.integers(0, 2**31 - 1), kind=st.sampled_from(["texture", "noise", "flat"]))
+def test_hip_lk_flow_matches_oracle_on_random_geometry(ctx, w, h, levels, radius, iters, seed, kind):
+    """Dense LK, every kernel variant (tiled radius 2/4/6 with the LDS-staged current frame, run-time radius otherwise),
+    frames down to 2x2 with 4 pyramid levels, flows wild enough (noise) to force the global-memory fallback: bit-exact."""
+    rng = np.random.default_rng(seed)
+    if kind == "texture":
+        fr = synth_pair(w, h, seed)
+    elif kind == "noise":
+        fr = rng.integers(0, 256, (2, h, w), dtype=np.uint8)
+    else:
+        fr = np.full((2, h, w), 99, np.uint8)
+    f_g = ctx.lk_flow(fr[0], fr[1], levels, radius, iters)
+    f_o = oracle.lk_flow(fr[0], fr[1], levels, radius, iters)
+    np.testing.assert_array_equal(f_g.view(np.uint32), f_o.view(np.uint32))
+
+
+def synth_pair(w, h, seed):
+    from ofps_amd import synth
+    return synth.luma_sequence(2, w, h, max_step=2, seed=seed % 100000)
+
+
+@settings(max_examples=25, deadline=None, derandomize=True, suppress_health_check=[HealthCheck.function_scoped_fixture])
+@given(nx=st.integers(2, 70), ny=st.integers(2, 50), rx=st.floats(-1.5, 1.5), ry=st.floats(-1.5, 1.5), rz=st.floats(-1.5, 1.5),
+       fov=st.sampled_from([20.0, 39.6, 60.0, 90.0]), aspect=st.sampled_from([1.0, 4 / 3, 16 / 9]), seed=st.integers(0, 1000))
+def test_hip_almeida_lsq_matches_oracle_on_random_rotations(ctx, nx, ny, rx, ry, rz, fov, aspect, seed):
+    from ofps_amd import synth
+    e = synth.rotation_field(nx, ny, euler_deg=(rx, ry, rz), aspect=aspect, fov_y_deg=fov, seed=seed)
+    q_g, _ = ctx.almeida(e, aspect, fov, use_ransac=False)
+    q_o = oracle.solve_ypr_given(e, oracle.camera(aspect, fov))
+    np.testing.assert_allclose(q_g, q_o, atol=3e-6, rtol=0)
