@@ -101,6 +101,12 @@ def main():
     ms = timeit(lambda: ctx.densify_dev(e.data_ptr(), n, 1, 150, 84, f150.data_ptr()), n=5, warm=1)
     out["cfg3_densify_150x84_per_pixel"] = {"ms": round(ms, 3), "Mvectors_per_s": round(n / ms / 1e3, 1),
                                             "GBps_entry_bytes": round(16 * n / ms / 1e6, 1)}
+    # --- the estimator input cv-decoder really produces in full-resolution mode: <= 150 x 84 down-sampled records
+    e84 = torch.from_numpy(synth.rotation_field(150, 84)).cuda()
+    ms = timeit(lambda: ctx.almeida_dev(e84.data_ptr(), 150 * 84, 1, 16 / 9, 22.275, False, 0, 0.05, 0, 0, q1.data_ptr()), n=10, warm=2)
+    out["almeida_lsq_12600_downsampled_records"] = {"ms": round(ms, 4), "note": "N > 8192: one launch per step, IEEE division"}
+    ms = timeit(lambda: ctx.almeida_dev(e84.data_ptr(), 150 * 84, 1, 16 / 9, 22.275, True, 200, 0.05, 1000, 3, q1.data_ptr()), n=10, warm=2)
+    out["almeida_ransac_12600_downsampled_records"] = {"ms": round(ms, 4)}
     # --- cfg3 from pixels: 1080p pair -> 3-level LK flow (r=4, 3 steps/level) -> per-pixel records -> densify -> Almeida
     fr = synth.luma_sequence(2, 1920, 1080, max_step=3, seed=11)
     dfr = torch.from_numpy(fr).cuda()
