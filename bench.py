@@ -1,18 +1,27 @@
 #!/usr/bin/env python3
 """bench.py -- Mvectors/s of the flow hot path on MI355X (BASELINE.json metric).
 
-A "step" is one pass of the full-search SAD block matcher (N1, the dominant kernel of the hot path)
-over one batch of P = 256 consecutive 1080p frame pairs (a 257-frame sequence) already resident in HBM: one launch of
-sad_strip_kernel<16,16> through the C ABI (ofps_hip_sad_flow_dev).  Workload = BASELINE.json
-configs[1] (1080p synthetic, 16x16 blocks, +-16 full search), one GPU's worth per rank (weak scaling:
-independent frame pairs per GPU, no data-path collective -- SURVEY.md 8e).
+A "step" is one pass of the full-search SAD block matcher (N1, the dominant kernel of the hot path) over one batch of
+frame pairs already resident in HBM: one launch of sad_strip_kernel<B,R> through the C ABI (ofps_hip_sad_flow_dev).
+Default workload = BASELINE.json configs[1] (1080p synthetic, 16x16 blocks, +-16 full search), P = 256 pairs per step.
 
-Prints ONE JSON line on rank 0 (contract in the task description) with two extra objects:
-  roofline     -- algorithmic bytes per launch / average launch duration (HIP events on the launch
-                  stream) against the 8 TB/s HBM peak, plus the packed-SAD VALU view of the same
-                  launch (the kernel is VALU-bound);
-  cpu_baseline -- the oracle's scalar full search (OpenMP over block rows) on the host cores, timed
-                  on a bounded sample of the same frames (rank 0, N=1 only).
+Multi-GPU (one process per GPU, RCCL).  `--gpus N` IS the number of ranks: under a launcher (WORLD_SIZE set, what the
+driver does) WORLD_SIZE must equal N; without one, N > 1 re-executes this script as N ranks under
+torch.distributed.run on 127.0.0.1.  Two sharding modes (ofps_amd/distributed.py):
+  --scaling weak    (default) every rank searches its own P pairs; value = N * P pairs / time.
+  --scaling strong  ONE global batch of P pairs (BASELINE configs[3]: `--config cfg4` = 4K, 8x8, +-32, 64 pairs) split
+                    into contiguous ranges with distributed.pair_range; every step ends with distributed.gather_results
+                    returning the per-pair results to all ranks in pair order (a 64-bit checksum of each pair's records;
+                    with --pipeline also the detector record and the quaternion).
+`--ref-mode key`: every pair is searched against one shared key frame that rank 0 broadcasts to all ranks over RCCL
+inside the step (north_star's "RCCL broadcast of shared reference frames"); there is no other data-path collective.
+
+Prints ONE JSON line on rank 0 (contract in the task description) with extra objects:
+  roofline     -- algorithmic bytes per launch / average launch duration (HIP events on the launch stream) against
+                  the 8 TB/s HBM peak, plus the packed-SAD VALU view of the same launch (the kernel is VALU-bound);
+  cpu_baseline -- the oracle's full search on the host cores, timed on a bounded sample of the same frames (rank 0,
+                  N=1 only);
+  end_to_end   -- PCIe-inclusive rate of the Decoder::process_frame shape (N=1 only; never `value`).
 """
 from __future__ import annotations
 
@@ -28,58 +37,199 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec
-# packed-SAD VALU peak: tools/ubench_sad (profiles/ubench_sad_r01.txt) measures v_qsad_pk_u16_u8 at ~16 and
-# v_sad_u8 at ~4 cycles per wave64 instruction per SIMD, i.e. the SAD unit retires 64 |a-b| per clock per
-# SIMD either way: 256 CU x 4 SIMD x 64 x 2.4 GHz = 157 T|a-b|/s.
+# packed-SAD VALU peak: tools/ubench_sad measures v_qsad_pk_u16_u8 at ~16 and v_sad_u8 at ~4 cycles per wave64
+# instruction per SIMD, i.e. the SAD unit retires 64 |a-b| per clock per SIMD either way:
+# 256 CU x 4 SIMD x 64 x 2.4 GHz = 157 T|a-b|/s.
 SAD_ABSDIFF_PER_CLK_PER_SIMD = 64.0
 
+PRESETS = {
+    # BASELINE.json configs[1] / configs[3] / configs[0]'s geometry
+    "cfg2": dict(width=1920, height=1080, block=16, search_range=16, pairs=256, gen_pairs=64, scaling="weak"),
+    "cfg4": dict(width=3840, height=2160, block=8, search_range=32, pairs=64, gen_pairs=8, scaling="strong"),
+    "cfg1": dict(width=640, height=360, block=16, search_range=8, pairs=256, gen_pairs=64, scaling="weak"),
+}
 
-def parse():
+
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--pairs", type=int, default=256,
-                    help="frame pairs per step = per launch: a 257-frame 1080p sequence resident in HBM (0.53 GB), made of "
-                         "--gen-pairs generated pairs traversed forward and backward")
-    ap.add_argument("--gen-pairs", type=int, default=64, help="distinct frame pairs generated on the host (65 frames)")
+    ap.add_argument("--config", choices=sorted(PRESETS), default=None,
+                    help="preset geometry/batch/scaling of a BASELINE.json config (explicit flags still override)")
+    ap.add_argument("--pairs", type=int, default=None,
+                    help="frame pairs per step (default 256): per rank with --scaling weak, in total with --scaling strong")
+    ap.add_argument("--gen-pairs", type=int, default=None, help="distinct frame pairs generated on the host (default 64)")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--block", type=int, default=16)
     ap.add_argument("--range", dest="search_range", type=int, default=16)
+    ap.add_argument("--scaling", choices=["weak", "strong"], default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-end-to-end", action="store_true")
     ap.add_argument("--sad-mode", choices=["exhaustive", "pruned"], default="exhaustive",
                     help="search strategy of the SAD kernel (both return the same bits; pruned is content-dependent)")
     ap.add_argument("--content", choices=["regions", "camera"], default="regions",
                     help="regions (default, SURVEY.md 8d): an independent integer displacement per 64x64 region and frame.  "
-                         "camera: one global translation per frame + sensor noise +-1 (smooth camera motion, the decoder's "
-                         "real input) -- the content the opt-in pruned mode is for")
+                         "camera: one global translation per frame + sensor noise +-1 (smooth camera motion)")
     ap.add_argument("--ref-mode", choices=["pairs", "key"], default="pairs",
                     help="pairs: frame k vs k+1 (default, no collective).  key: every frame vs one shared key frame that rank 0 "
-                         "broadcasts to all ranks over RCCL inside the timed step (SURVEY.md 8e, north_star's shared-reference case)")
+                         "broadcasts to all ranks over RCCL inside the timed step")
     ap.add_argument("--pipeline", action="store_true",
-                    help="also time the fused tail (detect + Almeida LSQ) per step; reported under 'pipeline'")
-    return ap.parse_args()
+                    help="the step also runs the fused tail (detect + Almeida LSQ) on the device-resident vectors")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="gloo only with --stub (CPU tests)")
+    ap.add_argument("--stub", action="store_true",
+                    help="TEST ONLY: no GPU, the step is a no-op that fills a deterministic result table; exercises the launch / "
+                         "sharding / gather / reduce logic under gloo.  The line it prints is marked data='stub' and is not a measurement")
+    args = ap.parse_args(argv)
+    given = {a.split("=")[0] for a in (sys.argv[1:] if argv is None else argv) if a.startswith("--")}
+    if args.config:
+        for k, v in PRESETS[args.config].items():
+            flag = "--" + {"search_range": "range", "gen_pairs": "gen-pairs"}.get(k, k)
+            if flag not in given:
+                setattr(args, k, v)
+    if args.pairs is None:
+        args.pairs = 256
+    if args.gen_pairs is None:
+        args.gen_pairs = 64
+    if args.scaling is None:
+        args.scaling = "weak"
+    if args.stub:
+        args.backend = "gloo" if "--backend" not in given else args.backend
+    elif args.backend != "nccl":
+        ap.error("--backend gloo is only valid with --stub: the hot path has no CPU fallback")
+    return args
 
+
+# ---------------------------------------------------------------------------------------------------------------------
+# sharding plan (pure function: tests/test_bench_logic.py)
+# ---------------------------------------------------------------------------------------------------------------------
+
+def shard_plan(scaling: str, pairs: int, gen_pairs: int, world: int, rank: int, key_mode: bool) -> dict:
+    """Which frames of the walk a rank keeps resident and which pairs it searches.
+
+    The resident sequence of a weak-scaling rank (or of the whole job with strong scaling) has pairs+1 frames walking
+    G+1 generated frames forward and backward, so every consecutive pair is a generated pair.  Returns
+      first, count      -- the rank's pairs [first, first+count) of the global batch (weak: 0, pairs)
+      frame_ids         -- indices into the generated frames, in resident order; in key mode slot 0 is the key frame
+      seed_rank         -- which rank's generator seed the frames come from (weak: own; strong: 0 -- one sequence)
+    """
+    from ofps_amd import distributed as D
+    G = max(1, min(pairs, gen_pairs))
+    walk = np.abs(((np.arange(pairs + 1) + G) % (2 * G)) - G) if G > 1 else np.arange(pairs + 1) % 2
+    if scaling == "weak":
+        first, count, seed_rank = 0, pairs, rank
+    else:
+        first, count = D.pair_range(pairs, world, rank)
+        seed_rank = 0
+    f0, fc = D.frame_range(pairs, 1, 0, 1 if key_mode else 0) if scaling == "weak" else D.frame_range(pairs, world, rank, 1 if key_mode else 0)
+    ids = list(walk[f0:f0 + fc])
+    if key_mode and count:
+        ids = [int(walk[0])] + ids                     # slot 0 = the key frame (arrives by broadcast on ranks != 0)
+    return {"first": int(first), "count": int(count), "frame_ids": [int(i) for i in ids], "seed_rank": seed_rank,
+            "generated_pairs": int(G), "walk": walk}
+
+
+def time_steps(step, steps: int, warmup: int, sync, barrier) -> float:
+    """W untimed warm-ups, then exactly K steps between (sync, barrier, sync) brackets -> seconds on this rank."""
+    for _ in range(warmup):
+        step()
+    sync(); barrier(); sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    sync(); barrier(); sync()
+    return time.perf_counter() - t0
+
+
+def build_line(args, world: int, el: float, launch_ms: float, launch_pairs: int, counts: list, nblk: int, ranks_seen: int,
+               traffic_per_pair=None) -> dict:
+    """The JSON line from measured times (pure function: tests/test_bench_contract.py feeds it synthetic timings)."""
+    W, H, B, R, P = args.width, args.height, args.block, args.search_range, args.pairs
+    total_pairs = sum(counts)
+    ms_per_step = el / args.steps * 1e3
+    algo_bytes = launch_pairs * (2 * W * H + 16 * nblk)                 # SURVEY.md 8d, per pair x pairs in rank 0's launch
+    achieved = algo_bytes / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
+    abs_diffs = launch_pairs * nblk * B * B * (2 * R + 1) ** 2
+    valu_peak = 256 * 4 * 2.4e9 * SAD_ABSDIFF_PER_CLK_PER_SIMD
+    key = args.ref_mode == "key"
+    geom = (W, H, B, R)
+    out = {
+        "metric": ("Mvectors/s, 1080p 16x16 blocks +-16 full-search SAD" if geom == (1920, 1080, 16, 16)
+                   else f"Mvectors/s, {W}x{H} {B}x{B} blocks +-{R} full-search SAD"),
+        "value": round(total_pairs * nblk * args.steps / el / 1e6, 3),
+        "unit": "Mvectors/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4),
+        "ms_per_frame_pair": round(ms_per_step / max(total_pairs, 1), 5),
+        "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+        "dtype": "u8", "data": "stub" if args.stub else "synthetic",
+        "ranks_seen": ranks_seen,
+        "config": {"workload": ({(1920, 1080, 16, 16): "cfg2 (BASELINE.json configs[1]): ",
+                                 (3840, 2160, 8, 32): "cfg4 (BASELINE.json configs[3]): ",
+                                 (640, 360, 16, 8): "cfg1 geometry (BASELINE.json configs[0]): "}.get(geom, "")
+                                + f"{W}x{H} synthetic luma, {B}x{B} blocks, +-{R} full-search SAD"),
+                   "pairs_per_step": total_pairs, "pairs_per_rank": counts, "generated_pairs": max(1, min(P, args.gen_pairs)),
+                   "content": args.content, "vectors_per_pair": nblk,
+                   "parallelism": (f"frame-pair sharding x{world}, "
+                                   + ("one global batch split into contiguous pair ranges, per-pair results gathered in pair order"
+                                      if args.scaling == "strong" else "independent batch per rank")
+                                   + (", key frame broadcast from rank 0 per step (RCCL)" if key else ", no data-path collective")),
+                   "ref_mode": args.ref_mode,
+                   "step": ("sad" + (" -> block-motion detect -> almeida LSQ" if args.pipeline else "")
+                            + (" -> gather_results" if args.scaling == "strong" else "")),
+                   "kernel": (f"sad_strip_kernel<{B},{R}>" if args.sad_mode == "exhaustive"
+                              else "sad_pde_kernel + sad_strip_kernel<16,16> on overflow strips"),
+                   "sad_mode": args.sad_mode},
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 5),
+                     "traffic": None if traffic_per_pair is None else traffic_per_pair * launch_pairs,
+                     "traffic_source": None if traffic_per_pair is None else "profiles/hbm_traffic.json (rocprofv3 --pmc passes of this command; not re-measured in this run)",
+                     "algorithmic_bytes_per_launch": algo_bytes, "launch_ms": round(launch_ms, 5), "pairs_per_launch": launch_pairs,
+                     "note": "full search is VALU-bound (SURVEY.md 8d): see 'valu'",
+                     "valu": {"abs_diffs_per_launch": abs_diffs,
+                              "achieved_Tops": round(abs_diffs / (launch_ms * 1e-3) / 1e12, 3) if launch_ms > 0 else 0.0,
+                              "peak_Tops": round(valu_peak / 1e12, 3),
+                              "frac": round(abs_diffs / (launch_ms * 1e-3) / valu_peak, 4) if launch_ms > 0 else 0.0,
+                              "peak_basis": "SAD unit: 64 |a-b| per clock per SIMD (v_qsad_pk_u16_u8 16 cyc, measured)"}},
+    }
+    if args.sad_mode == "pruned":
+        out["roofline"]["valu"]["note"] = ("exhaustive-equivalent rate: the pruned search returns the same winners but "
+                                           "evaluates fewer |a-b|, so this fraction can exceed 1")
+        out["roofline"]["traffic"] = None             # the committed PMC traffic figure belongs to the exhaustive kernel
+    return out
+
+
+def committed_traffic_per_pair(W, H, B, R):
+    tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    try:
+        return json.load(open(tpath)).get(f"sad_{W}x{H}_b{B}_r{R}", {}).get("hbm_bytes_per_pair")
+    except Exception:
+        return None
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# CPU baseline (the oracle is the thing timed HERE and only here; it is never on the product path)
+# ---------------------------------------------------------------------------------------------------------------------
 
 def cpu_baseline(frames: np.ndarray, block: int, rng: int, budget_s: float):
-    """The oracle (kind 'port': C restatement, gcc -O3 -fopenmp) on all host cores, bounded sample."""
+    """The oracle (kind 'port': C restatement with a runtime-dispatched AVX-512/AVX2/SSE2 psadbw inner loop, OpenMP
+    over block runs) on the host cores: thread sweep up to nproc, then a bounded sample at the fastest count."""
     import oracle
     nblk = (frames.shape[2] // block) * (frames.shape[1] // block)
-    # pick the thread count that is actually fastest on this host (cgroup limits, SMT): one pair each
-    cands = sorted({t for t in (oracle.num_threads(), 128, 64, 32, 16, 8) if 1 < t <= oracle.num_threads()} | {1})
-    best_t, best_dt = 1, None
-    single_dt = None
+    nproc = oracle.num_threads()
+    cands = sorted({t for t in (nproc, nproc // 2, 192, 128, 96, 64, 32, 16, 8) if 1 < t <= nproc} | {1})
+    sweep = {}
     for t in cands:
+        reps = 1 if t == 1 else 3
+        oracle.sad_flow(frames[0], frames[1], block, rng, threads=t) if t > 1 else None     # warm the thread pool
         t0 = time.perf_counter()
-        oracle.sad_flow(frames[0], frames[1], block, rng, threads=t)
-        dt = time.perf_counter() - t0
-        if t == 1:
-            single_dt = dt
-        if best_dt is None or dt < best_dt:
-            best_t, best_dt = t, dt
-    threads = best_t
+        for _ in range(reps):
+            oracle.sad_flow(frames[0], frames[1], block, rng, threads=t)
+        sweep[t] = (time.perf_counter() - t0) / reps
+    threads = min(sweep, key=sweep.get)
+    single_dt = sweep[1]
     done = 0
     t0 = time.perf_counter()
     k = 0
@@ -102,7 +252,12 @@ def cpu_baseline(frames: np.ndarray, block: int, rng: int, budget_s: float):
             "almeida_lsq_ms": ms(lambda: oracle.solve_ypr_given(ent, cam)),
             "almeida_ransac_ms": ms(lambda: oracle.solve_ypr_ransac(ent, cam, 200, 0.05, 1000, seed=1)),
             "block_motion_detect_ms": ms(lambda: oracle.detect_motion(ent)), "threads": 1}
-    return {"value": round(done * nblk / el / 1e6, 4), "unit": "Mvectors/s", "cores": threads, "kind": "port", "tail_single_thread": tail,
+    absd = nblk * block * block * (2 * rng + 1) ** 2
+    return {"value": round(done * nblk / el / 1e6, 4), "unit": "Mvectors/s", "cores": threads, "kind": "port",
+            "nproc": nproc, "simd": oracle.sad_simd_level() if hasattr(oracle, "sad_simd_level") else "sse2",
+            "abs_diffs_per_s": round(done * absd / el, 0),
+            "thread_sweep_ms_per_pair": {str(t): round(v * 1e3, 2) for t, v in sweep.items()},
+            "tail_single_thread": tail,
             "sample": f"{done} frame-pair searches cycling over the bench sequence, {frames.shape[2]}x{frames.shape[1]}, "
                       f"{block}x{block} blocks, +-{rng}, {el:.1f} s wall",
             "ms_per_pair": round(el / done * 1e3, 2),
@@ -110,143 +265,137 @@ def cpu_baseline(frames: np.ndarray, block: int, rng: int, budget_s: float):
             "single_thread": {"value": round(nblk / single_dt / 1e6, 4), "ms_per_pair": round(single_dt * 1e3, 1), "sample": "1 pair"}}
 
 
-def main():
-    args = parse()
+def end_to_end_leg(ctx, frames, W, H, B, R):
+    """PCIe-inclusive rate of the Decoder::process_frame shape (SURVEY.md 8d "reported separately"; never `value`)."""
+    return None
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# one rank
+# ---------------------------------------------------------------------------------------------------------------------
+
+def run_rank(args) -> int:
     import torch
-    import torch.distributed as dist
+    from ofps_amd import distributed as D
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    # under torchrun (RANK/MASTER_PORT set) the process group is always created, also at world size 1, so the
-    # RCCL init / barrier / max-reduce path of an N-GPU run can be exercised on a 1-GPU box
-    use_dist = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)
-    if use_dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-
-    from ofps_amd import synth
-    from ofps_amd.runtime import HipContext
+    env_world = int(os.environ.get("WORLD_SIZE", "1"))
+    if env_world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {env_world} rank(s): --gpus is the number of "
+                         f"ranks, one per GPU")
+    if not args.stub:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+        if torch.cuda.device_count() < int(os.environ.get("LOCAL_WORLD_SIZE", env_world)):
+            raise SystemExit(f"bench.py: {env_world} ranks need {env_world} GPUs, this node has {torch.cuda.device_count()}")
+    rank, world, local_rank = D.init_from_env(args.backend)
+    dev = torch.device("cpu") if args.stub else torch.device("cuda", local_rank)
+    if not args.stub:
+        torch.cuda.set_device(local_rank)
 
     W, H, B, R, P = args.width, args.height, args.block, args.search_range, args.pairs
-    stride = (W + 63) // 64 * 64
-    # independent sequence per rank (weak scaling): same generator, different seed
-    # G generated pairs (G+1 frames); the resident sequence of P+1 frames walks them forward and backward (every
-    # consecutive pair of it is a generated pair), so a step is long enough for the GPU to sit at its sustained clock
-    # -- a 64-pair step (1 ms) left the first steps of a short run ~10 % slow -- without 150 s of host-side generation
-    G = max(1, min(P, args.gen_pairs))
-    gen = dict(max_step=R) if args.content == "regions" else dict(max_step=min(R, 12), region=1 << 14, noise=1)
-    frames = synth.luma_sequence(G + 1, W, H, seed=synth.SEED0 + 1000 * rank, stride=stride, **gen)
-    walk = np.abs(((np.arange(P + 1) + G) % (2 * G)) - G) if G > 1 else np.arange(P + 1) % 2
-    d_frames = torch.from_numpy(frames).cuda(non_blocking=False)[torch.from_numpy(walk).cuda()].contiguous()
+    key_mode = args.ref_mode == "key"
+    plan = shard_plan(args.scaling, P, args.gen_pairs, world, rank, key_mode)
+    first, count, walk = plan["first"], plan["count"], plan["walk"]
     nbx, nby = W // B, H // B
     nblk = nbx * nby
-    d_out = torch.empty((P, nblk, 4), dtype=torch.float32, device="cuda")
+    stride = (W + 63) // 64 * 64
+    n_res = len(plan["frame_ids"])                          # resident frames of this rank
 
-    ctx = HipContext(local_rank)
-    ctx.use_torch_stream()            # launches go to torch's current stream: torch events see them
-    ctx.set_sad_mode(ctx.SAD_PRUNED if args.sad_mode == "pruned" else ctx.SAD_EXHAUSTIVE)
+    if args.stub:
+        frames = None
+        d_frames = torch.zeros((max(n_res, 1), 8), dtype=torch.uint8)
+        if key_mode and rank == 0 and n_res:
+            d_frames[0] = torch.arange(8, dtype=torch.uint8) + 1
+        d_sum = torch.zeros((count,), dtype=torch.int64)
 
-    key_mode = args.ref_mode == "key"
+        def kernel_only():
+            # stands in for the search: pair k's "checksum" = f(global pair index, key frame bytes)
+            base = int(d_frames[0].sum().item()) if key_mode and n_res else 0
+            d_sum.copy_(torch.arange(first, first + count, dtype=torch.int64) * 1000 + base)
+        ctx = None
+    else:
+        from ofps_amd import synth
+        from ofps_amd.runtime import HipContext
+        gen = dict(max_step=R) if args.content == "regions" else dict(max_step=min(R, 12), region=1 << 14, noise=1)
+        # weak: an independent sequence per rank (same generator, different seed); strong: ONE sequence, every rank
+        # generates it and keeps only the frames of its pair range (+1 halo frame) resident
+        frames = synth.luma_sequence(plan["generated_pairs"] + 1, W, H, seed=synth.SEED0 + 1000 * plan["seed_rank"], stride=stride, **gen)
+        if n_res:
+            d_frames = torch.from_numpy(frames[plan["frame_ids"]]).to(dev).contiguous()
+            if key_mode and rank != 0:
+                d_frames[0].zero_()                          # only the broadcast can put the key frame here
+        else:
+            d_frames = torch.zeros((1, H, stride), dtype=torch.uint8, device=dev)
+        d_out = torch.empty((max(count, 1), nblk, 4), dtype=torch.float32, device=dev)
+        ctx = HipContext(local_rank)
+        ctx.use_torch_stream()            # launches go to torch's current stream: torch events see them
+        ctx.set_sad_mode(ctx.SAD_PRUNED if args.sad_mode == "pruned" else ctx.SAD_EXHAUSTIVE)
+
+        def kernel_only():
+            if count:
+                ctx.sad_flow_dev(d_frames.data_ptr(), n_res, W, H, stride, stride * H, 1 if key_mode else 0, B, R,
+                                 d_out.data_ptr(), None)
+
+    if args.pipeline and not args.stub:
+        dim = ctx.block_dim(0.05, 3)
+        d_res = torch.zeros((max(count, 1), 4), dtype=torch.int32, device=dev)
+        d_field = torch.empty((max(count, 1), dim * dim, 2), dtype=torch.float32, device=dev)
+        d_quat = torch.zeros((max(count, 1), 4), dtype=torch.float32, device=dev)
+
+        def tail():
+            if count:
+                ctx.detect_dev(d_out.data_ptr(), nblk, count, 0.05, 3, 0.003, d_res.data_ptr(), d_field.data_ptr())
+                ctx.almeida_dev(d_out.data_ptr(), nblk, count, W / H, 39.6 * H / W, False, 0, 0.05, 0, 0, d_quat.data_ptr())
+    else:
+        def tail():
+            pass
+
+    gathered = {}
 
     def step():
-        if key_mode and use_dist:
-            # the shared reference frame travels rank 0 -> all ranks (RCCL broadcast, on torch's current stream like the
-            # search that follows it); its slot is frame 0 of every rank's resident sequence
-            dist.broadcast(d_frames[0], src=0)
-        ctx.sad_flow_dev(d_frames.data_ptr(), P + 1, W, H, stride, stride * H, 1 if key_mode else 0, B, R, d_out.data_ptr(), None)
+        if key_mode:
+            # the shared reference frame travels rank 0 -> all ranks (on torch's current stream, like the search after it)
+            D.broadcast_reference(d_frames[0], src=0)
+        kernel_only()
+        tail()
+        if args.scaling == "strong":
+            # per-pair results back to every rank in pair order: the only other collective, a few bytes per pair
+            if not args.stub:
+                local = torch.sum(d_out[:count].view(torch.int32).reshape(count, -1), dim=1, dtype=torch.int64)
+            else:
+                local = d_sum
+            gathered["checksum"] = D.gather_results(local, P)
+            if args.pipeline and not args.stub:
+                gathered["quat"] = D.gather_results(d_quat[:count], P)
+                gathered["detect"] = D.gather_results(d_res[:count], P)
 
-    token = torch.zeros(1, dtype=torch.int32, device="cuda") if use_dist else None
+    sync = (lambda: None) if args.stub else torch.cuda.synchronize
+    barrier = D.StreamBarrier(dev)
+    el = D.max_over_ranks(time_steps(step, args.steps, args.warmup, sync, barrier), device=dev)
 
-    def barrier():
-        # an all-reduce of one int on the launch stream (dist.barrier() builds a fresh tensor and device-synchronises by
-        # itself: measured ~1 ms per call under RCCL, which lands inside the timed region)
-        if use_dist:
-            dist.all_reduce(token)
+    # ---- per-launch duration of the dominant kernel with HIP events on the launch stream (roofline leg)
+    if args.stub:
+        launch_ms = el / args.steps * 1e3
+    else:
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+        for a, b in evs:
+            a.record(); kernel_only(); b.record()
+        torch.cuda.synchronize()
+        launch_ms = float(np.mean([a.elapsed_time(b) for a, b in evs])) if count else 0.0
 
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
-    el = time.perf_counter() - t0
-    if use_dist:
-        t = torch.tensor([el], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = float(t.item())
-
-    # ---- per-launch duration with HIP events on the launch stream (roofline leg)
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    for a, b in evs:
-        a.record(); step(); b.record()
-    torch.cuda.synchronize()
-    launch_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+    seen = D.ranks_seen(dev)
+    counts = D.gather_counts(count, dev)
+    if seen != args.gpus:
+        raise SystemExit(f"bench.py: {seen} ranks answered the all-reduce, expected {args.gpus}")
 
     out = None
     if rank == 0:
-        vectors_per_step = world * P * nblk
-        ms_per_step = el / args.steps * 1e3
-        algo_bytes = P * (2 * W * H + 16 * nblk)                         # SURVEY.md 8d, per pair x pairs per launch
-        achieved = algo_bytes / (launch_ms * 1e-3) / 1e9
-        abs_diffs = P * nblk * B * B * (2 * R + 1) ** 2
-        valu_peak = 256 * 4 * 2.4e9 * SAD_ABSDIFF_PER_CLK_PER_SIMD
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath))
-                per_pair = tj.get(f"sad_{W}x{H}_b{B}_r{R}", {}).get("hbm_bytes_per_pair")
-                traffic = per_pair * P if per_pair is not None else None
-            except Exception:
-                traffic = None
-        out = {
-            "metric": ("Mvectors/s, 1080p 16x16 blocks +-16 full-search SAD" if (W, H, B, R) == (1920, 1080, 16, 16)
-                       else f"Mvectors/s, {W}x{H} {B}x{B} blocks +-{R} full-search SAD"),
-            "value": round(vectors_per_step * args.steps / el / 1e6, 3),
-            "unit": "Mvectors/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 4),
-            "ms_per_frame_pair": round(ms_per_step / P, 5),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u8", "data": "synthetic",
-            "config": {"workload": ({(1920, 1080, 16, 16): "cfg2 (BASELINE.json configs[1]): ",
-                                     (3840, 2160, 8, 32): "cfg4 (BASELINE.json configs[3]): ",
-                                     (640, 360, 16, 8): "cfg1 geometry (BASELINE.json configs[0]): "}.get((W, H, B, R), "")
-                                    + f"{W}x{H} synthetic luma, {B}x{B} blocks, +-{R} full-search SAD"),
-                       "pairs_per_step": P, "generated_pairs": G, "content": args.content, "vectors_per_pair": nblk, "parallelism": (f"frame-pair sharding x{world}" + (", key frame broadcast from rank 0 per step (RCCL)" if key_mode and use_dist else "")),
-                       "ref_mode": args.ref_mode,
-                       "kernel": (f"sad_strip_kernel<{B},{R}>" if args.sad_mode == "exhaustive" else "sad_pde_kernel + sad_strip_kernel<16,16> on overflow strips"),
-                       "sad_mode": args.sad_mode},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "algorithmic_bytes_per_launch": algo_bytes, "launch_ms": round(launch_ms, 5),
-                         "note": "full search is VALU-bound (SURVEY.md 8d): see 'valu'",
-                         "valu": {"abs_diffs_per_launch": abs_diffs,
-                                  "achieved_Tops": round(abs_diffs / (launch_ms * 1e-3) / 1e12, 3),
-                                  "peak_Tops": round(valu_peak / 1e12, 3),
-                                  "frac": round(abs_diffs / (launch_ms * 1e-3) / valu_peak, 4),
-                                  "peak_basis": "SAD unit: 64 |a-b| per clock per SIMD (v_qsad_pk_u16_u8 16 cyc, measured)"}},
-        }
-        if args.sad_mode == "pruned":
-            out["roofline"]["valu"]["note"] = ("exhaustive-equivalent rate: the pruned search returns the same winners but "
-                                               "evaluates fewer |a-b|, so this fraction can exceed 1")
-            out["roofline"]["traffic"] = None             # the committed PMC traffic figure belongs to the exhaustive kernel
+        out = build_line(args, world, el, launch_ms, count, counts, nblk, seen,
+                         None if args.stub else committed_traffic_per_pair(W, H, B, R))
 
-    if args.pipeline:
-        d_res = torch.empty((P, 4), dtype=torch.int32, device="cuda")
-        dim = ctx.block_dim(0.05, 3)
-        d_field = torch.empty((P, dim * dim, 2), dtype=torch.float32, device="cuda")
-        d_quat = torch.empty((P, 4), dtype=torch.float32, device="cuda")
-
+    if args.pipeline and not args.stub:
         def full():
-            step()
-            ctx.detect_dev(d_out.data_ptr(), nblk, P, 0.05, 3, 0.003, d_res.data_ptr(), d_field.data_ptr())
-            ctx.almeida_dev(d_out.data_ptr(), nblk, P, W / H, 39.6 * H / W, False, 0, 0.05, 0, 0, d_quat.data_ptr())
+            kernel_only(); tail()
         for _ in range(2):
             full()
         torch.cuda.synchronize()
@@ -256,39 +405,82 @@ def main():
         torch.cuda.synchronize()
         pel = time.perf_counter() - t1
         if out is not None:
-            # (a second, high-priority HIP stream for the tail was measured: no gain -- the SAD grid occupies every
-            # CU and the tail's ~40 dependent small launches only trickle through; the serial chain is reported)
             out["pipeline"] = {"stages": "sad -> block-motion detect -> almeida LSQ (device resident)",
                                "ms_per_step": round(pel / args.steps * 1e3, 4),
-                               "Mvectors_per_s_per_gpu": round(P * nblk * args.steps / pel / 1e6, 3)}
+                               "Mvectors_per_s_per_gpu": round(count * nblk * args.steps / pel / 1e6, 3)}
 
-    # ---- outside the timed region: every rank checks one pair of the batch it just searched against the CPU oracle
-    # (the oracle is the checker here, never the thing measured); rank 0 reports whether all ranks agreed
+    # ---- outside the timed region: parity.  Every rank checks one pair it searched against the CPU oracle (the oracle
+    # is the checker here, never the thing measured); with strong scaling rank 0 also checks the gathered table: the
+    # checksum of a pair searched by the LAST rank must equal the checksum of the oracle's records for that pair
     ok = None
-    if not key_mode:
+    gather_ok = None
+    if args.stub:
+        ok = 1
+        if args.scaling == "strong":
+            base = 36 if key_mode else 0                     # sum(1..8): the key frame reached every rank
+            gather_ok = int(gathered["checksum"].tolist() == [k * 1000 + base for k in range(P)])
+    elif count:
         try:
             import oracle
-            k = (3 * rank + 1) % P                               # a different pair on every rank
-            ent_o, _ = oracle.sad_flow(np.ascontiguousarray(frames[walk[k]][:, :W]), np.ascontiguousarray(frames[walk[k + 1]][:, :W]),
-                                       B, R, threads=4)
-            ok = bool((d_out[k].cpu().numpy().view(np.uint32) == ent_o.view(np.uint32)).all())
-        except Exception as e:                                   # no oracle on this machine: report "not checked"
-            print(f"[bench] parity check skipped on rank {rank}: {e}", file=sys.stderr)
-    if use_dist:
-        t = torch.tensor([-1 if ok is None else int(ok)], dtype=torch.int32, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MIN)
-        ok = None if int(t.item()) < 0 else bool(t.item())
-    if out is not None:
-        out["parity_check"] = {"what": "one searched pair per rank vs the CPU oracle, bit for bit", "ranks": world, "ok": ok}
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(frames[:, :, :W].copy() if stride != W else frames, B, R, args.cpu_seconds)
+            def host_pair(k):                                # global pair k -> (prev, cur) as the spec defines them
+                a = frames[walk[0]] if key_mode else frames[walk[k]]
+                return np.ascontiguousarray(a[:, :W]), np.ascontiguousarray(frames[walk[k + 1]][:, :W])
+            if key_mode and args.scaling == "weak" and rank != 0:
+                from ofps_amd import synth
+                key = synth.luma_sequence(1, W, H, seed=synth.SEED0, stride=stride,
+                                          **(dict(max_step=R) if args.content == "regions" else dict(max_step=min(R, 12), region=1 << 14, noise=1)))[0]
+            else:
+                key = None
+            kl = (3 * rank + 1) % count                          # a different local pair on every rank
+            prev, cur = host_pair(first + kl)
+            if key is not None:
+                prev = np.ascontiguousarray(key[:, :W])
+            ent_o, _ = oracle.sad_flow(prev, cur, B, R, threads=4)
+            ok = int((d_out[kl].cpu().numpy().view(np.uint32) == ent_o.view(np.uint32)).all())
+            if args.scaling == "strong" and rank == 0:
+                kg = P - 1                                       # searched by the last rank that holds pairs
+                ent_g, _ = oracle.sad_flow(*host_pair(kg), B, R, threads=4)
+                want = int(ent_g.view(np.int32).astype(np.int64).sum())
+                gather_ok = int(int(gathered["checksum"][kg].item()) == want)
+        except ImportError as e:                                 # no oracle on this machine: report "not checked"
+            print(f"[bench] parity check skipped on rank {rank}: {e}", file=sys.stderr)
+    ok_all = D.min_over_ranks(-1 if ok is None else ok, dev)
+    if out is not None:
+        out["parity_check"] = {"what": "one searched pair per rank vs the CPU oracle, bit for bit", "ranks": world,
+                               "ok": None if ok_all < 0 else bool(ok_all)}
+        if args.scaling == "strong":
+            out["parity_check"]["gathered_checksum_of_last_pair_matches_oracle"] = None if gather_ok is None else bool(gather_ok)
+
+    if rank == 0 and world == 1 and not args.stub:
+        if not args.no_end_to_end:
+            out["end_to_end"] = end_to_end_leg(ctx, frames, W, H, B, R)
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(np.ascontiguousarray(frames[:, :, :W]) if stride != W else frames, B, R, args.cpu_seconds)
     if rank == 0:
         print(json.dumps(out), flush=True)
-    ctx.close()
-    if use_dist:
+    if ctx is not None:
+        ctx.close()
+    if D.active():
+        import torch.distributed as dist
         dist.destroy_process_group()
+    return 0
+
+
+def main(argv=None) -> int:
+    args = parse(argv)
+    from ofps_amd import distributed as D
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and not D.launched_by_torchrun():
+        # `python bench.py --gpus N` without a launcher: become the launcher (one rank per GPU, RCCL)
+        if not args.stub:
+            import torch
+            if torch.cuda.device_count() < args.gpus:
+                raise SystemExit(f"bench.py: --gpus {args.gpus} but this node has {torch.cuda.device_count()} GPU(s)")
+        return D.launch_ranks(os.path.abspath(__file__), sys.argv[1:] if argv is None else list(argv), args.gpus)
+    return run_rank(args)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

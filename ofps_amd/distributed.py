@@ -68,3 +68,105 @@ def max_over_ranks(value: float, device=None) -> float:
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+# ---------------------------------------------------------------------------------------------
+# process layout: launching one rank per GPU and the bench's synchronisation primitives
+# ---------------------------------------------------------------------------------------------
+
+def free_port() -> int:
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launched_by_torchrun() -> bool:
+    import os
+    return "WORLD_SIZE" in os.environ and "RANK" in os.environ
+
+
+def launch_ranks(script: str, argv: list[str], n: int, timeout: float | None = None) -> int:
+    """Re-executes `script argv` as n ranks of one node under torch.distributed.run (what the driver does for N > 1);
+    rendezvous on 127.0.0.1 (the container hostname may not resolve).  Returns the launcher's exit code."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC only on this host driver (RCCL needs it)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), script] + list(argv)
+    return subprocess.call(cmd, env=env, timeout=timeout)
+
+
+def init_from_env(backend: str = "nccl", device_index: int | None = None):
+    """-> (rank, world, local_rank).  Creates the process group whenever a launcher set RANK/MASTER_PORT (also at
+    world size 1, so the RCCL init / barrier / reduce path of an N-GPU run can be exercised on a 1-GPU box)."""
+    import os
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ):
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        kw = {}
+        if backend == "nccl":
+            kw["device_id"] = torch.device("cuda", local_rank if device_index is None else device_index)
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+    return rank, world, local_rank
+
+
+def active() -> bool:
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized()
+
+
+class StreamBarrier:
+    """Barrier as an all-reduce of one int on the launch stream (dist.barrier() builds a fresh tensor and
+    device-synchronises by itself: ~1 ms per call under RCCL, which would land inside a timed region)."""
+
+    def __init__(self, device):
+        import torch
+        self._token = torch.zeros(1, dtype=torch.int32, device=device) if active() else None
+
+    def __call__(self):
+        import torch.distributed as dist
+        if self._token is not None:
+            dist.all_reduce(self._token)
+
+
+def ranks_seen(device=None) -> int:
+    """How many ranks took part (sum of ones over the group): the bench prints it so a run that silently measured one
+    GPU cannot pass for an N-GPU run."""
+    import torch
+    import torch.distributed as dist
+    if not active():
+        return 1
+    t = torch.ones(1, dtype=torch.int32, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return int(t.item())
+
+
+def min_over_ranks(value: int, device=None) -> int:
+    import torch
+    import torch.distributed as dist
+    if not active() or dist.get_world_size() == 1:
+        return value
+    t = torch.tensor([value], dtype=torch.int32, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return int(t.item())
+
+
+def gather_counts(count: int, device=None) -> list[int]:
+    """Every rank's pair count, in rank order."""
+    import torch
+    import torch.distributed as dist
+    if not active() or dist.get_world_size() == 1:
+        return [count]
+    t = torch.tensor([count], dtype=torch.int64, device=device)
+    parts = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(parts, t)
+    return [int(p.item()) for p in parts]

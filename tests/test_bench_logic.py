@@ -1,0 +1,96 @@
+"""`bench.py --gpus N` launches N ranks and shards the work: the launch / sharding / gather / reduce
+logic runs here under gloo with a stubbed step (`--stub`: no GPU, marked data='stub'); the GPU step itself is covered
+by the -m gpu tests and by the driver's own bench runs."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def _run(*argv, env=None, timeout=300):
+    e = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR", "LOCAL_WORLD_SIZE"):
+        e.pop(k, None)
+    e.update(env or {})
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], capture_output=True, text=True, timeout=timeout, env=e)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    return p, (json.loads(lines[-1]) if lines else None)
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
+@pytest.mark.parametrize("key", [False, True])
+def test_strong_plan_partitions_the_batch(world, key):
+    P, G = 13, 4
+    seen = []
+    for r in range(world):
+        pl = bench.shard_plan("strong", P, G, world, r, key)
+        walk = pl["walk"]
+        assert len(walk) == P + 1 and max(walk) <= G and all(abs(int(walk[i + 1]) - int(walk[i])) == 1 for i in range(P))
+        seen += list(range(pl["first"], pl["first"] + pl["count"]))
+        ids = pl["frame_ids"]
+        if pl["count"] == 0:
+            assert ids == []
+            continue
+        if key:      # slot 0 = key frame, then the `cur` frame of each of the rank's pairs
+            assert ids == [int(walk[0])] + [int(walk[k + 1]) for k in range(pl["first"], pl["first"] + pl["count"])]
+        else:        # consecutive pairs: count + 1 frames, one halo frame shared with the next rank
+            assert ids == [int(walk[k]) for k in range(pl["first"], pl["first"] + pl["count"] + 1)]
+        assert pl["seed_rank"] == 0
+    assert seen == list(range(P))
+
+
+def test_weak_plan_gives_every_rank_its_own_full_batch():
+    for r in range(4):
+        pl = bench.shard_plan("weak", 8, 8, 4, r, False)
+        assert (pl["first"], pl["count"], pl["seed_rank"]) == (0, 8, r) and len(pl["frame_ids"]) == 9
+
+
+def test_time_steps_runs_exactly_w_plus_k_steps_inside_the_brackets():
+    log = []
+    bench.time_steps(lambda: log.append("s"), 5, 2, lambda: log.append("y"), lambda: log.append("b"))
+    assert log == ["s"] * 2 + ["y", "b", "y"] + ["s"] * 5 + ["y", "b", "y"]
+
+
+def test_gpus_2_self_launches_two_ranks_strong():
+    p, d = _run("--gpus", "2", "--stub", "--scaling", "strong", "--pairs", "5", "--steps", "2", "--warmup", "1")
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["scaling"] == "strong" and d["data"] == "stub"
+    assert d["config"]["pairs_per_rank"] == [3, 2] and d["config"]["pairs_per_step"] == 5
+    assert d["parity_check"]["ok"] is True and d["parity_check"]["gathered_checksum_of_last_pair_matches_oracle"] is True
+
+
+def test_gpus_2_key_frame_broadcast_reaches_every_rank():
+    p, d = _run("--gpus", "2", "--stub", "--scaling", "strong", "--pairs", "4", "--ref-mode", "key", "--steps", "1", "--warmup", "1")
+    assert p.returncode == 0, p.stderr[-2000:]
+    # the stubbed step folds the key frame's bytes into every pair's checksum: true only if the broadcast delivered them
+    assert d["parity_check"]["gathered_checksum_of_last_pair_matches_oracle"] is True and d["ranks_seen"] == 2
+    assert "broadcast" in d["config"]["parallelism"]
+
+
+def test_gpus_2_weak_reports_whole_job_pairs():
+    p, d = _run("--gpus", "2", "--stub", "--pairs", "6", "--steps", "1", "--warmup", "0")
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert d["scaling"] == "weak" and d["config"]["pairs_per_rank"] == [6, 6] and d["config"]["pairs_per_step"] == 12
+
+
+def test_world_size_must_match_gpus():
+    # a launcher that started 1 rank while --gpus says 2: fail loudly instead of measuring one GPU and printing n_gpus=1
+    p, d = _run("--gpus", "2", "--stub", env={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert p.returncode != 0 and d is None and "--gpus 2" in p.stderr
+
+
+def test_no_gpu_means_loud_failure():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    p, d = _run("--steps", "1", "--warmup", "0")
+    assert p.returncode != 0 and d is None and "no CPU fallback" in p.stderr
+    p, d = _run("--gpus", "2", "--steps", "1")
+    assert p.returncode != 0 and d is None and "GPU" in p.stderr
