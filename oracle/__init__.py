@@ -66,6 +66,9 @@ def lib():
                                         C.POINTER(C.c_size_t), C.POINTER(C.c_int), fp]
         L.orc_detect_motion.restype = C.c_int
         L.orc_solve_ypr_given.argtypes = [fp, C.c_size_t, C.POINTER(Camera), fp]
+        L.orc_solve_ypr_given_ex.argtypes = [fp, C.c_size_t, C.POINTER(Camera), C.c_float, C.c_size_t, C.c_int, fp, fp]
+        L.orc_quat_inverse.argtypes = [fp, fp]
+        L.orc_almeida_model.argtypes = [fp, C.c_size_t, C.POINTER(Camera), fp, fp]
         L.orc_solve_ypr_ransac.argtypes = [fp, C.c_size_t, C.POINTER(Camera), C.c_size_t, C.c_float,
                                            C.c_size_t, C.c_uint64, fp, C.POINTER(C.c_uint32),
                                            C.POINTER(C.c_size_t)]
@@ -218,6 +221,28 @@ def solve_ypr_given(entries, cam: Camera) -> np.ndarray:
     e = _f32(entries).reshape(-1, 4); q = np.zeros(4, np.float32)
     lib().orc_solve_ypr_given(_fp(e), e.shape[0], C.byref(cam), _fp(q))
     return q
+
+
+def solve_ypr_given_ex(entries, cam: Camera, alpha: float, limit: int, order: int = 0):
+    """-> (q, steps[limit, 4]): the solver with ALPHA / step count / composition order as arguments (ofps_oracle.h);
+    steps[i] = cumulative point rotation after step i (not inverted)."""
+    e = _f32(entries).reshape(-1, 4); q = np.zeros(4, np.float32)
+    steps = np.zeros((max(limit, 1), 4), np.float32)
+    lib().orc_solve_ypr_given_ex(_fp(e), e.shape[0], C.byref(cam), alpha, limit, order, _fp(steps), _fp(q))
+    return q, steps[:limit]
+
+
+def almeida_model(entries, cam: Camera, rotation=(1.0, 0.0, 0.0, 0.0)) -> np.ndarray:
+    """One pass of the solver's loop body (almeida-estimator/src/lib.rs:140-183): the raw LU solution, units of EPS."""
+    e = _f32(entries).reshape(-1, 4); r = _f32(rotation); m = np.zeros(3, np.float32)
+    lib().orc_almeida_model(_fp(e), e.shape[0], C.byref(cam), _fp(r), _fp(m))
+    return m
+
+
+def quat_mul(a, b) -> np.ndarray:
+    a = _f32(a); b = _f32(b); o = np.zeros(4, np.float32)
+    lib().orc_quat_mul(_fp(a), _fp(b), _fp(o))
+    return o
 
 
 def solve_ypr_ransac(entries, cam: Camera, num_iters=200, inlier_deg=0.05, num_samples=1000,

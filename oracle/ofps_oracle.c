@@ -527,53 +527,63 @@ int orc_detect_motion(const float* entries, size_t n, float min_size, size_t sub
 static float almeida_eps(void) { return 0.001f * 3.14159265358979323846264338327950288f / 180.0f; }
 #define ORC_ALPHA 0.5f
 
-void orc_solve_ypr_given(const float* entries, size_t n, const orc_camera* cam, float q_out[4]) {
+/* One pass of the loop body, :140-183: residual and the three prototypes per vector, A and b as sequential f32 sums in
+ * input order, partial-pivot LU; `model` is the raw solution (in units of EPS; zero when LU fails, :183). */
+void orc_almeida_model(const float* entries, size_t n, const orc_camera* cam, const float rotation[4], float model[3]) {
     const float EPS = almeida_eps();
-    size_t limit = (size_t)ceilf(15.0f / ORC_ALPHA);                  /* :132 */
-    float rotation[4] = {1.0f, 0.0f, 0.0f, 0.0f};
-    float m_roll[16], m_pitch[16], m_yaw[16];
+    float m_roll[16], m_pitch[16], m_yaw[16], rotm[16];
     orc_mat4_from_euler(0.0f, EPS, 0.0f, m_roll);                     /* :30-34 */
     orc_mat4_from_euler(EPS, 0.0f, 0.0f, m_pitch);                    /* :36-38 */
     orc_mat4_from_euler(0.0f, 0.0f, -EPS, m_yaw);                     /* :40-42 */
-
+    orc_quat_to_homogeneous(rotation, rotm);                          /* :140 */
     float* v = (float*)malloc((8 * n + 8) * sizeof(float));           /* [motion-delta, roll, pitch, yaw] */
-    for (size_t it = 0; it < limit; ++it) {
-        float alpha = (it == limit - 1) ? 1.0f : ORC_ALPHA;           /* :138 */
-        float rotm[16];
-        orc_quat_to_homogeneous(rotation, rotm);                      /* :140 */
-        for (size_t i = 0; i < n; ++i) {                              /* :142-157 */
-            const float* e = entries + 4 * i;
-            float d[2];
-            orc_camera_delta(cam, e, rotm, d);
-            float* vi = v + 8 * i;
-            vi[0] = e[2] - d[0]; vi[1] = e[3] - d[1];
-            orc_camera_delta(cam, e, m_roll, vi + 2);
-            orc_camera_delta(cam, e, m_pitch, vi + 4);
-            orc_camera_delta(cam, e, m_yaw, vi + 6);
-        }
-        /* :159-179: each dot summed over the Vec in input order, starting from 0 */
-        float a[9], b[3];
-        for (int c = 0; c < 3; ++c)
-            for (int r = 0; r < 3; ++r) {
-                float acc = 0.0f;
-                for (size_t i = 0; i < n; ++i) {
-                    const float* p = v + 8 * i + 2 * (c + 1);
-                    const float* s = v + 8 * i + 2 * (r + 1);
-                    acc += p[0] * s[0] + p[1] * s[1];
-                }
-                a[3 * r + c] = acc;       /* from_iterator is column-major: element k -> (k%3, k/3) */
-            }
+    for (size_t i = 0; i < n; ++i) {                                  /* :142-157 */
+        const float* e = entries + 4 * i;
+        float d[2];
+        orc_camera_delta(cam, e, rotm, d);
+        float* vi = v + 8 * i;
+        vi[0] = e[2] - d[0]; vi[1] = e[3] - d[1];
+        orc_camera_delta(cam, e, m_roll, vi + 2);
+        orc_camera_delta(cam, e, m_pitch, vi + 4);
+        orc_camera_delta(cam, e, m_yaw, vi + 6);
+    }
+    /* :159-179: each dot summed over the Vec in input order, starting from 0 */
+    float a[9], b[3];
+    for (int c = 0; c < 3; ++c)
         for (int r = 0; r < 3; ++r) {
             float acc = 0.0f;
             for (size_t i = 0; i < n; ++i) {
-                const float* p = v + 8 * i + 2 * (r + 1);
-                const float* s = v + 8 * i;
+                const float* p = v + 8 * i + 2 * (c + 1);
+                const float* s = v + 8 * i + 2 * (r + 1);
                 acc += p[0] * s[0] + p[1] * s[1];
             }
-            b[r] = acc;
+            a[3 * r + c] = acc;       /* from_iterator is column-major: element k -> (k%3, k/3) */
         }
+    for (int r = 0; r < 3; ++r) {
+        float acc = 0.0f;
+        for (size_t i = 0; i < n; ++i) {
+            const float* p = v + 8 * i + 2 * (r + 1);
+            const float* s = v + 8 * i;
+            acc += p[0] * s[0] + p[1] * s[1];
+        }
+        b[r] = acc;
+    }
+    free(v);
+    if (!orc_lu3_solve(a, b, model)) { model[0] = model[1] = model[2] = 0.0f; }   /* :181-183 */
+}
+
+/* The solver with its two constants and the composition order of the per-step rotation exposed.  The reference
+ * today is (ALPHA 0.5, limit ceil(15/ALPHA) = 30, order 0 = pitch*roll*yaw, :18,:132,:193); order 1 = yaw*pitch*roll
+ * is what the build that drew docs/report/mfield used (tests/test_reference_vectors.py).  q_steps (optional): the
+ * cumulative `rotation` after every step, 4 floats each -- NOT inverted. */
+void orc_solve_ypr_given_ex(const float* entries, size_t n, const orc_camera* cam, float alpha_c, size_t limit,
+                            int order, float* q_steps, float q_out[4]) {
+    const float EPS = almeida_eps();
+    float rotation[4] = {1.0f, 0.0f, 0.0f, 0.0f};
+    for (size_t it = 0; it < limit; ++it) {
+        float alpha = (it == limit - 1) ? 1.0f : alpha_c;             /* :138 */
         float model[3];
-        if (!orc_lu3_solve(a, b, model)) { model[0] = model[1] = model[2] = 0.0f; }   /* :181-183 */
+        orc_almeida_model(entries, n, cam, rotation, model);
         model[0] = model[0] * EPS * alpha;                            /* :185 */
         model[1] = model[1] * EPS * alpha;
         model[2] = model[2] * EPS * alpha;
@@ -581,13 +591,22 @@ void orc_solve_ypr_given(const float* entries, size_t n, const orc_camera* cam, 
         orc_quat_from_euler(0.0f, model[0], 0.0f, roll);              /* :189-191 */
         orc_quat_from_euler(model[1], 0.0f, 0.0f, pitch);
         orc_quat_from_euler(0.0f, 0.0f, -model[2], yaw);
-        orc_quat_mul(pitch, roll, pr);                                /* :193 */
-        orc_quat_mul(pr, yaw, rot);
+        if (order == 0) {
+            orc_quat_mul(pitch, roll, pr);                            /* :193 */
+            orc_quat_mul(pr, yaw, rot);
+        } else {
+            orc_quat_mul(yaw, pitch, pr);
+            orc_quat_mul(pr, roll, rot);
+        }
         orc_quat_mul(rotation, rot, nr);                              /* :195 */
         memcpy(rotation, nr, sizeof(nr));
+        if (q_steps) memcpy(q_steps + 4 * it, rotation, sizeof(nr));
     }
-    free(v);
     orc_quat_inverse(rotation, q_out);                                /* :199 */
+}
+
+void orc_solve_ypr_given(const float* entries, size_t n, const orc_camera* cam, float q_out[4]) {
+    orc_solve_ypr_given_ex(entries, n, cam, ORC_ALPHA, (size_t)ceilf(15.0f / ORC_ALPHA) /* :132 */, 0, NULL, q_out);
 }
 
 /* --- counter-based sampler standing in for rand::thread_rng + choose_multiple.

@@ -89,6 +89,12 @@ int orc_detect_motion(const float* entries, size_t n, float min_size, size_t sub
 
 /* ---- Almeida estimator (almeida-estimator/src/lib.rs) ---- */
 void orc_solve_ypr_given(const float* entries, size_t n, const orc_camera* cam, float q[4]); /* :123-200 */
+/* the same loop with ALPHA, the step count and the composition order (0 = pitch*roll*yaw, today's :193; 1 =
+ * yaw*pitch*roll, the build behind docs/report/mfield) as arguments; q_steps (optional) = rotation after each step */
+/* one pass of the loop body (:140-183): raw LU solution in units of EPS, zero when the LU fails */
+void orc_almeida_model(const float* entries, size_t n, const orc_camera* cam, const float rotation[4], float model[3]);
+void orc_solve_ypr_given_ex(const float* entries, size_t n, const orc_camera* cam, float alpha, size_t limit,
+                            int order, float* q_steps, float q[4]);
 /* :202-251 with the build's counter-based sampler in place of rand::thread_rng (the
  * reference is unseeded).  out_inliers (optional) receives the indices of the
  * best inlier set (capacity num_samples), *out_n_inliers its size. */

@@ -183,8 +183,6 @@ def test_sad_bench_shape_batch_full_size(ctx):
         ent_o, best_o = oracle.sad_flow(np.ascontiguousarray(fr[k][:, :W]), np.ascontiguousarray(fr[k + 1][:, :W]), B, R, threads=8)
         np.testing.assert_array_equal(best[k], best_o)
         np.testing.assert_array_equal(out[k].view(np.uint32), ent_o.view(np.uint32))
-    # a checksum of checksums over the whole batch, stable across runs of the same build
-    assert int(best[..., 2].astype(np.int64).sum()) == int(sum(int(b[:, 2].astype(np.int64).sum()) for b in best))
 
 
 @pytest.mark.parametrize("B,R", [(16, 16), (16, 8), (16, 32), (8, 32), (8, 16), (8, 8), (16, 24)])
@@ -733,3 +731,4 @@ def test_contexts_are_independent_across_host_threads():
             assert (det is None) == (do is None)
             if det is not None:
                 assert det[0] == do[0]
+                np.testing.assert_array_equal(det[1].view(np.uint32), do[1].view(np.uint32))      # the whole field, bit for bit

@@ -1,0 +1,138 @@
+"""-m gpu: the HIP path against pins that do not come from the oracle (tests/test_reference_vectors.py explains each),
+the dense Almeida regime at the reference test's own camera, and BASELINE configs[2] / configs[4] at full size."""
+import numpy as np
+import pytest
+
+import oracle
+from ofps_amd import synth
+import indep_model as im
+import almeida_cases as ac
+import test_reference_vectors as rv
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from ofps_amd.runtime import HipContext
+    c = HipContext(0)
+    yield c
+    c.close()
+
+
+# ---- hand-derived literals through the C ABI ------------------------------------------------------------------------
+def test_hip_densifier_hand_derived_case(ctx):
+    field, cells = ctx.densify(rv.DENSIFY_ENTRIES, 3, 3, want_cells=True)
+    assert [tuple(int(v) for v in c) for c in cells] == rv.DENSIFY_CELLS
+    np.testing.assert_array_equal(field.view(np.uint32), rv.densify_expected_field())
+
+
+@pytest.mark.parametrize("name", sorted(rv.DETECT_CASES))
+def test_hip_detector_hand_derived_cases(ctx, name):
+    ent, want = rv.DETECT_CASES[name]
+    got = ctx.detect(ent)
+    if want is None:
+        assert got is None
+        return
+    assert got is not None and got[0] == want[0]
+    np.testing.assert_array_equal(got[1].view(np.uint32), want[1])
+
+
+# ---- reference-held input: docs/report/mfield/base.csv --------------------------------------------------------------
+@pytest.mark.parametrize("ransac", [False, True])
+def test_hip_almeida_on_the_reference_table(ctx, ransac):
+    base = rv.load("base").astype(np.float32)
+    q, _ = ctx.almeida(base, *rv.CAM, use_ransac=ransac, num_iters=100, inlier_deg=0.05, num_samples=1000, seed=5)
+    want = im.quat_wijk(rv._model_quat(np.radians([0.0, -20.0, 2.0]), "pry").inv()).astype(np.float32)
+    assert np.degrees(oracle.quat_angle_to(want, q)) < 0.01          # planted rotation of the table, 0.05 % of 20 degrees
+    cam = oracle.camera(*rv.CAM)
+    q_o = oracle.solve_ypr_ransac(base, cam, 100, 0.05, 1000, seed=5) if ransac else oracle.solve_ypr_given(base, cam)
+    np.testing.assert_allclose(q, q_o, atol=1e-4 if ransac else 2e-6, rtol=0)
+
+
+# ---- the reference's known-answer test on fields built by the independent model ------------------------------------
+def test_hip_almeida_known_answer_on_independent_fields(ctx):
+    cam = oracle.camera(1.0, 90.0)
+    for rot in ac.ROTS:
+        for (r, p, y) in ac.angle_combos(rot):
+            q_i, ent, keep = im.almeida_test_field(r, p, y)
+            e = ent[keep].astype(np.float32)
+            est, _ = ctx.almeida(e, 1.0, 90.0, use_ransac=False)
+            err = np.degrees(oracle.quat_angle_to(im.quat_wijk(q_i).astype(np.float32), est))
+            assert err < 0.1 * rot or err < 1e-4, (rot, (r, p, y), err)              # almeida-estimator/src/lib.rs:343-348
+            np.testing.assert_allclose(est, oracle.solve_ypr_given(e, cam), atol=1e-5, rtol=0)
+
+
+# ---- dense regime (N > 65,536: reciprocal-multiply quotients) at the reference test's camera and rotations ----------
+@pytest.mark.parametrize("rot", [0.1, 1.0, 10.0])
+def test_hip_almeida_dense_regime_reference_camera(ctx, rot):
+    """get_grid up-sampled to 300x300 (almeida-estimator/src/lib.rs:308-348 uses 50x50): ~70,000 kept vectors."""
+    cam = oracle.camera(1.0, 90.0)
+    for (r, p, y) in ac.angle_combos(rot)[1:]:
+        q_i, ent, keep = im.almeida_test_field(r, p, y, n=300)
+        e = ent[keep].astype(np.float32)
+        assert len(e) > 65536
+        est, _ = ctx.almeida(e, 1.0, 90.0, use_ransac=False)
+        err = np.degrees(oracle.quat_angle_to(im.quat_wijk(q_i).astype(np.float32), est))
+        assert err < 0.1 * rot, (rot, (r, p, y), err)
+        np.testing.assert_allclose(est, oracle.solve_ypr_given(e, cam), atol=2e-6, rtol=0)
+
+
+@pytest.mark.parametrize("cam_rot", [((1.0, 90.0), (10.0, 10.0, 10.0)), ((16 / 9, 39.6 * 9 / 16), (0.5, 0.3, -0.2))])
+def test_hip_almeida_threshold_65536_vs_65537(ctx, cam_rot):
+    """The same field one record either side of the switch from IEEE division to reciprocal multiplication
+    (almeida.hip): both answers within 2e-6 of the oracle's and of each other."""
+    (aspect, fov), eul = cam_rot
+    n = 257
+    xs, ys = np.meshgrid(np.arange(n), np.arange(n), indexing="ij")
+    pos = np.stack([(xs.ravel() + 0.5) / n, (ys.ravel() + 0.5) / n], 1)
+    d = im.delta(pos, aspect, fov, im.euler_rot3(*np.radians(eul)))
+    e = np.concatenate([pos, d], 1).astype(np.float32)
+    cam = oracle.camera(aspect, fov)
+    qs = []
+    for m in (65536, 65537):
+        q, _ = ctx.almeida(e[:m], aspect, fov, use_ransac=False)
+        np.testing.assert_allclose(q, oracle.solve_ypr_given(e[:m], cam), atol=2e-6, rtol=0)
+        qs.append(q)
+    np.testing.assert_allclose(qs[0], qs[1], atol=2e-6, rtol=0)
+
+
+# ---- BASELINE configs[2] at full size: 1080p dense flow, every pixel vs the oracle -----------------------------------
+def test_hip_lk_flow_1080p_bit_exact(ctx):
+    fr = synth.luma_sequence(2, 1920, 1080, max_step=6, seed=synth.SEED0 + 77)
+    f_o = oracle.lk_flow(fr[0], fr[1], 3, 4, 3)
+    f_g = ctx.lk_flow(fr[0], fr[1], 3, 4, 3)
+    np.testing.assert_array_equal(f_g.view(np.uint32), f_o.view(np.uint32))
+
+
+def test_hip_lk_flow_1080p_large_motion_and_flat_areas(ctx):
+    """Tiles whose flows disagree by more than the staged rectangle allows (region jumps of +-16) and flat regions
+    (singular structure tensors) take the non-staged path of the step kernel: same bits."""
+    fr = synth.flatten_regions(synth.luma_sequence(2, 1920, 1080, max_step=16, seed=synth.SEED0 + 78), region=96)
+    f_o = oracle.lk_flow(fr[0], fr[1], 3, 4, 3)
+    f_g = ctx.lk_flow(fr[0], fr[1], 3, 4, 3)
+    np.testing.assert_array_equal(f_g.view(np.uint32), f_o.view(np.uint32))
+
+
+# ---- BASELINE configs[4] at full size: the fused per-frame path on 1080p frames ---------------------------------------
+def test_hip_push_frame_1080p_matches_stagewise_oracle(ctx):
+    W, H, F = 1920, 1080, 4
+    fr = synth.luma_sequence(F, W, H, max_step=16, seed=synth.SEED0 + 79)
+    cam = oracle.camera(16 / 9, 22.275)
+    ctx.reset_frames()
+    for k in range(F):
+        r = ctx.push_frame(fr[k], block=16, search_range=16, aspect=16 / 9, fov_y_deg=22.275, want_entries=True, want_field=True,
+                           use_ransac=bool(k & 1), num_iters=60, seed=100 + k)
+        if k == 0:
+            assert not r["have_vectors"]
+            continue
+        ent_o, _ = oracle.sad_flow(fr[k - 1], fr[k], 16, 16, threads=8)
+        assert r["n_vectors"] == 8040
+        np.testing.assert_array_equal(r["entries"].view(np.uint32), ent_o.view(np.uint32))
+        det_o = oracle.detect_motion(ent_o)
+        assert (r["motion"] is None) == (det_o is None)
+        if det_o is not None:
+            assert r["motion"][0] == det_o[0]
+            np.testing.assert_array_equal(r["motion"][1].view(np.uint32), det_o[1].view(np.uint32))
+        q_o = oracle.solve_ypr_ransac(ent_o, cam, 60, 0.05, 1000, seed=100 + k) if k & 1 else oracle.solve_ypr_given(ent_o, cam)
+        np.testing.assert_allclose(r["quat"], q_o, atol=1e-4 if k & 1 else 2e-6, rtol=0)
