@@ -28,6 +28,7 @@
 #include "common.hpp"
 
 #include <cmath>
+#include <mutex>
 
 namespace ofps {
 
@@ -521,6 +522,156 @@ __global__ __launch_bounds__(1024) void almeida_lsq_step_kernel(const float4* __
     }
 }
 
+// ---- cluster solver: ONE launch, all 30 steps, a problem spread over nblk co-resident workgroups (one per CU).
+// Every thread keeps its EPT records, their hoisted unprojection and the three prototypes on chip for the whole solve
+// (registers; two prototype pairs in LDS for EPT = 8), so the records cross HBM exactly once (33 MB at 1080p per-pixel
+// instead of 30 x 33 MB re-streamed from the Infinity Cache by the launch-per-step kernel).  Per step the workgroups
+// exchange their three right-hand-side partial sums (nine in step 0: A = J^T J is rotation-independent and summed
+// once) as 8-byte {tag, f32} granules -- one write-through agent-scope store per value, the data is its own flag, no
+// fence, no separate barrier (MI355X_MICROARCH.md "allgather", cdna_hip_programming.md G16 form R2) -- and EVERY
+// workgroup folds all partials in the same fixed order and runs the same LU + quaternion update, so all of them hold
+// bit-identical rotations without a broadcast.  Slots alternate with the step parity: a fast workgroup can be at most
+// one step ahead of the slowest, so it never overwrites a granule somebody still has to read.  Tags = tag_base + step
+// + 1 with a per-call tag_base (the buffer is zeroed when allocated, never between calls).  Every spin is bounded: on
+// a timeout (the workgroups were not co-resident, e.g. another process holds CUs with a persistent kernel of its
+// own) the kernel writes a NaN quaternion and returns; the host-pointer entry point then re-solves with the
+// launch-per-step kernel.
+__device__ __forceinline__ void gran_store(unsigned long long* p, uint32_t tag, float v) {
+    __hip_atomic_store(p, ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+}
+
+constexpr unsigned kSpinLimit = 1u << 18;            // ~0.3 s of polling before giving up
+
+// wave-wide: sum of the nblk (<= 256) granules of one component once all carry `tag`; fixed order (lane-strided, then
+// a butterfly), identical in every workgroup.  false = timed out.
+__device__ __forceinline__ bool gran_sweep_sum(const unsigned long long* g, int nblk, uint32_t tag, float& total) {
+    const int lane = threadIdx.x & 63;
+    float v[4];
+    for (unsigned spins = 0;; ++spins) {
+        bool ok = true;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int b = lane + 64 * j;
+            v[j] = 0.0f;
+            if (b < nblk) {
+                const unsigned long long x = __hip_atomic_load(g + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                v[j] = __uint_as_float((uint32_t)x);
+                ok = ok && (uint32_t)(x >> 32) == tag;
+            }
+        }
+        if (__all(ok)) break;
+        if (spins >= kSpinLimit) return false;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    float acc = ((v[0] + v[1]) + v[2]) + v[3];
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m, 64);
+    total = acc;
+    return true;
+}
+
+template <bool FAST, int EPT>
+__global__ __launch_bounds__(1024) void almeida_lsq_cluster_kernel(const float4* __restrict__ entries, size_t n, Camera cam,
+                                                                   unsigned long long* gran, uint32_t tag_base,
+                                                                   float4* __restrict__ out_quat) {
+    constexpr bool P_LDS = EPT >= 8;
+    __shared__ float red[16][9];
+    __shared__ float fold_sh[9];
+    __shared__ Quat rot_sh[2];
+    __shared__ int fail_sh;
+    __shared__ float4 plds[P_LDS ? EPT * 1024 : 1];     // (roll.x, roll.y, pitch.x, pitch.y) per record
+    const int nblk = gridDim.x, blk = blockIdx.x;
+    const size_t item = blockIdx.y;
+    unsigned long long* g = gran + item * (size_t)(2 * 9) * nblk;     // [parity][component][workgroup]
+    const float eps = almeida_eps();
+    const Mat3 mroll = mat3_from_euler(0.0f, eps, 0.0f);           // lib.rs:30-34
+    const Mat3 mpitch = mat3_from_euler(eps, 0.0f, 0.0f);          // lib.rs:36-38
+    const Mat3 myaw = mat3_from_euler(0.0f, 0.0f, -eps);           // lib.rs:40-42
+    float4 e[EPT];
+    float2 pr[P_LDS ? 1 : EPT], pp[P_LDS ? 1 : EPT], py[EPT];
+    float uwx[EPT], uwz[EPT];
+    float uwy = 0.0f;
+    bool ok[EPT];
+    float s[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (threadIdx.x == 0) fail_sh = 0;
+#pragma unroll
+    for (int t = 0; t < EPT; ++t) {
+        const size_t i = ((size_t)blk * EPT + t) * 1024 + threadIdx.x;
+        ok[t] = i < n;
+        e[t] = ok[t] ? entries[item * n + i] : make_float4(0.5f, 0.5f, 0.0f, 0.0f);
+    }
+#pragma unroll
+    for (int t = 0; t < EPT; ++t) {
+        const Unproj un = cam_unproject<FAST>(cam, e[t].x, e[t].y);
+        uwx[t] = un.wx; uwz[t] = un.wz; uwy = un.wy;
+        const float2 r = cam_delta_w<FAST>(cam, e[t].x, e[t].y, un, mroll);
+        const float2 p = cam_delta_w<FAST>(cam, e[t].x, e[t].y, un, mpitch);
+        py[t] = cam_delta_w<FAST>(cam, e[t].x, e[t].y, un, myaw);
+        if constexpr (P_LDS) plds[t * 1024 + threadIdx.x] = make_float4(r.x, r.y, p.x, p.y);
+        else { pr[t] = r; pp[t] = p; }
+        if (ok[t]) {
+            s[0] += r.x * r.x + r.y * r.y;
+            s[1] += r.x * p.x + r.y * p.y;
+            s[2] += r.x * py[t].x + r.y * py[t].y;
+            s[3] += p.x * p.x + p.y * p.y;
+            s[4] += p.x * py[t].x + p.y * py[t].y;
+            s[5] += py[t].x * py[t].x + py[t].y * py[t].y;
+        }
+    }
+    float a[6] = {0, 0, 0, 0, 0, 0};                               // folded A, thread 0 only
+    Quat rotation = {1.0f, 0.0f, 0.0f, 0.0f};
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int it = 0; it < kIters; ++it) {
+        const float alpha = (it == kIters - 1) ? 1.0f : 0.5f;      // lib.rs:138
+        const Mat3 rotm = quat_to_mat3(rotation);                  // lib.rs:140
+        s[6] = 0.0f; s[7] = 0.0f; s[8] = 0.0f;
+#pragma unroll
+        for (int t = 0; t < EPT; ++t) {
+            if (!ok[t]) continue;
+            const Unproj un = {uwx[t], uwy, uwz[t]};
+            const float2 d = cam_delta_w<FAST>(cam, e[t].x, e[t].y, un, rotm);
+            const float rx = e[t].z - d.x, ry = e[t].w - d.y;      // motion - delta
+            float2 r, p;
+            if constexpr (P_LDS) { const float4 v = plds[t * 1024 + threadIdx.x]; r = make_float2(v.x, v.y); p = make_float2(v.z, v.w); }
+            else { r = pr[t]; p = pp[t]; }
+            s[6] += r.x * rx + r.y * ry;
+            s[7] += p.x * rx + p.y * ry;
+            s[8] += py[t].x * rx + py[t].y * ry;
+        }
+        const int k0 = it == 0 ? 0 : 6;
+        if (it == 0) block_sum<0, 9>(s, red); else block_sum<6, 9>(s, red);
+        const uint32_t tag = tag_base + (uint32_t)it + 1u;
+        unsigned long long* gp = g + (size_t)(it & 1) * 9 * nblk;
+        if (threadIdx.x == 0) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k)
+                if (k >= k0) gran_store(gp + (size_t)k * nblk + blk, tag, s[k]);
+        }
+        if (wave >= k0 && wave < 9) {                              // wave k gathers component k
+            float tot = 0.0f;
+            const bool got = gran_sweep_sum(gp + (size_t)wave * nblk, nblk, tag, tot);
+            if (lane == 0) { if (got) fold_sh[wave] = tot; else fail_sh = 1; }
+        }
+        __syncthreads();
+        if (fail_sh) {
+            if (threadIdx.x == 0) out_quat[item] = make_float4(__builtin_nanf(""), 0.0f, 0.0f, 0.0f);
+            return;
+        }
+        if (threadIdx.x == 0) {
+            if (it == 0) {
+#pragma unroll
+                for (int k = 0; k < 6; ++k) a[k] = fold_sh[k];
+            }
+            const float f[9] = {a[0], a[1], a[2], a[3], a[4], a[5], fold_sh[6], fold_sh[7], fold_sh[8]};
+            rot_sh[it & 1] = almeida_update(rotation, f, eps, alpha);
+        }
+        __syncthreads();
+        rotation = rot_sh[it & 1];
+    }
+    if (blk == 0 && threadIdx.x == 0) out_quat[item] = make_float4(rotation.w, -rotation.i, -rotation.j, -rotation.k);  // :199
+}
+
 // ---- RANSAC sampler: must stay bit-identical to orc_sample_index (oracle/ofps_oracle.c)
 __host__ __device__ inline uint64_t mix64(uint64_t x) {
     x += 0x9E3779B97F4A7C15ull;
@@ -703,15 +854,108 @@ __global__ __launch_bounds__(1024) void ransac_select_kernel(const float4* __res
     if (threadIdx.x == 0) sel_n[item] = base;
 }
 
-static int lsq_device(ofps_hip_ctx* ctx, const float4* d_entries, size_t stride, size_t n_max, const uint32_t* d_n,
-                      uint32_t min_n, int batch, const Camera& cam, float4* d_quat) {
+// Persistent (spin-waiting) launches of different contexts must not interleave on one device: two clusters that each
+// hold part of the CUs would wait for each other's missing workgroups.  Within a process they are chained on the GPU
+// through one event per device (no host blocking); across processes the in-kernel timeout is the safety net.
+struct ClusterGate {
+    std::mutex m;
+    hipEvent_t ev[64] = {};
+};
+static ClusterGate g_cluster_gate;
+
+template <bool FAST, int EPT>
+static void launch_cluster(hipStream_t s, int nblk, int items, const float4* d_entries, size_t n, const Camera& cam,
+                           unsigned long long* gran, uint32_t tag_base, float4* d_quat) {
+    hipLaunchKernelGGL((almeida_lsq_cluster_kernel<FAST, EPT>), dim3(nblk, items), dim3(1024), 0, s, d_entries, n, cam, gran,
+                       tag_base, d_quat);
+}
+
+// -> 1 launched, 0 not applicable (caller falls back to the launch-per-step kernel), < 0 error
+static int lsq_cluster(ofps_hip_ctx* ctx, const float4* d_entries, size_t n, int batch, const Camera& cam, float4* d_quat) {
+    int ept = n > 4096 ? 8 : (n > 2048 ? 4 : (n > 1024 ? 2 : 1));
+    if (const char* f = getenv("OFPS_HIP_ALMEIDA_EPT")) { const int v = atoi(f); if (v == 1 || v == 2 || v == 4 || v == 8) ept = v; }
+    const size_t per_wg = (size_t)ept * 1024;
+    const size_t nblk_sz = (n + per_wg - 1) / per_wg;
+    if (nblk_sz < 1 || nblk_sz > 256 || nblk_sz > (size_t)ctx->num_cus) return 0;
+    const int nblk = (int)nblk_sz;
+    const int per_launch = ctx->num_cus / nblk;              // items whose workgroups are all co-resident (1 per CU)
+    const bool dense = n > 65536;                            // per-pixel regime: reciprocal-multiply quotients, see fdiv
+    const size_t gran_bytes = (size_t)per_launch * 2 * 9 * nblk * sizeof(unsigned long long);
+    auto* gran = static_cast<unsigned long long*>(scratch(ctx, S_GRAN, gran_bytes));
+    if (!gran) return OFPS_HIP_ENOMEM;
     hipStream_t s = ctx->stream;
-    // One-workgroup solver: one launch, 30 steps at 2.5-6 us each on a single CU (tools/almeida_paths.py: 0.076 ms at
-    // N = 576, 0.185 ms at N = 8,040, flat up to 256 items) -- faster than one launch per step (>= 0.24 ms) for every
-    // N it can hold, and mandatory when the entry count lives on the device (RANSAC refit).
+    const size_t cap = ctx->scratch[S_GRAN].cap;
+    for (int b0 = 0; b0 < batch; b0 += per_launch) {
+        const int items = batch - b0 < per_launch ? batch - b0 : per_launch;
+        if (ctx->gran_zeroed != gran || ctx->gran_tag_base > 0xFFFFFF00u) {
+            OFPS_HIP_TRY(ctx, hipMemsetAsync(gran, 0, cap, s));
+            ctx->gran_zeroed = gran; ctx->gran_tag_base = 0;
+        }
+        const uint32_t tag_base = ctx->gran_tag_base;
+        ctx->gran_tag_base += 32;
+        const float4* ent = d_entries + (size_t)b0 * n;
+        float4* q = d_quat + b0;
+        std::lock_guard<std::mutex> lk(g_cluster_gate.m);
+        hipEvent_t& ev = g_cluster_gate.ev[ctx->device & 63];
+        if (!ev) OFPS_HIP_TRY(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        else OFPS_HIP_TRY(ctx, hipStreamWaitEvent(s, ev, 0));
+        if (dense) launch_cluster<true, 8>(s, nblk, items, ent, n, cam, gran, tag_base, q);
+        else if (ept == 8) launch_cluster<false, 8>(s, nblk, items, ent, n, cam, gran, tag_base, q);
+        else if (ept == 4) launch_cluster<false, 4>(s, nblk, items, ent, n, cam, gran, tag_base, q);
+        else if (ept == 2) launch_cluster<false, 2>(s, nblk, items, ent, n, cam, gran, tag_base, q);
+        else launch_cluster<false, 1>(s, nblk, items, ent, n, cam, gran, tag_base, q);
+        OFPS_HIP_TRY(ctx, hipGetLastError());
+        OFPS_HIP_TRY(ctx, hipEventRecord(ev, s));
+    }
+    return 1;
+}
+
+static int lsq_stepped(ofps_hip_ctx* ctx, const float4* d_entries, size_t n_max, int batch, const Camera& cam, float4* d_quat) {
+    hipStream_t s = ctx->stream;
+    // enough workgroups to fill the chip, few enough that the fixed-order fold stays short
+    const size_t per_wg = n_max > 65536 ? 8 * 1024 : 1024;
+    int nblk = (int)((n_max + per_wg - 1) / per_wg);
+    const int cap = (2 * ctx->num_cus + batch - 1) / batch;
+    if (nblk > cap) nblk = cap < 1 ? 1 : cap;
+    auto* part = static_cast<float*>(scratch(ctx, S_WORK0, 2 * (size_t)batch * nblk * 9 * sizeof(float)));
+    auto* state = static_cast<Quat*>(scratch(ctx, S_WORK1, 2 * (size_t)batch * sizeof(Quat)));
+    if (!part || !state) return OFPS_HIP_ENOMEM;
+    float* pa = part;
+    float* pb = part + (size_t)batch * nblk * 9;
+    const bool dense = n_max > 65536;          // per-pixel regime: reciprocal-multiply quotients, see fdiv
+    for (int it = 0; it <= kIters; ++it) {
+        if (dense)
+            hipLaunchKernelGGL(almeida_lsq_step_kernel<true>, dim3(nblk, batch), dim3(1024), 0, s, d_entries, n_max, it, cam,
+                               pa, pb, state, batch, d_quat);
+        else
+            hipLaunchKernelGGL(almeida_lsq_step_kernel<false>, dim3(nblk, batch), dim3(1024), 0, s, d_entries, n_max, it, cam,
+                               pa, pb, state, batch, d_quat);
+        float* t = pa; pa = pb; pb = t;
+    }
+    OFPS_HIP_TRY(ctx, hipGetLastError());
+    return OFPS_HIP_OK;
+}
+
+// allow_cluster = false: the caller is re-solving after a cluster launch timed out
+static int lsq_device(ofps_hip_ctx* ctx, const float4* d_entries, size_t stride, size_t n_max, const uint32_t* d_n,
+                      uint32_t min_n, int batch, const Camera& cam, float4* d_quat, bool allow_cluster = true) {
+    hipStream_t s = ctx->stream;
+    // One-workgroup solver: one launch, 30 steps at 2.5-6 us each on a single CU (0.076 ms at N = 576, 0.185 ms at
+    // N = 8,040, flat up to 256 items) -- the path for batches of block-vector sized problems and mandatory when the
+    // entry count lives on the device (RANSAC refit).  Larger problems, and lone problems above `cluster_min`, go to
+    // the cluster solver (one launch, granule exchange between co-resident workgroups); what it cannot hold
+    // (N > 256 x 8192) or a forced A/B run takes one launch per step.
     bool wg_path = n_max <= 8192;
+    bool cluster = allow_cluster && d_n == nullptr && stride == n_max;
+    size_t cluster_min = 8192;                                           // lone problems above this size use the cluster
     if (const char* force = getenv("OFPS_HIP_ALMEIDA_PATH")) {          // A/B experiments only
-        if (!strcmp(force, "step") && d_n == nullptr) wg_path = false;
+        if (!strcmp(force, "step") && d_n == nullptr) { wg_path = false; cluster = false; }
+        if (!strcmp(force, "wg")) cluster = false;
+        if (!strcmp(force, "cluster")) cluster_min = 0;
+    }
+    if (cluster && n_max > cluster_min && n_max > 0) {
+        const int rc = lsq_cluster(ctx, d_entries, n_max, batch, cam, d_quat);
+        if (rc != 0) return rc < 0 ? rc : OFPS_HIP_OK;
     }
     if (wg_path) {
         const dim3 g(batch), b(1024);
@@ -719,42 +963,22 @@ static int lsq_device(ofps_hip_ctx* ctx, const float4* d_entries, size_t stride,
         else if (n_max <= 2048) hipLaunchKernelGGL((almeida_lsq_wg_kernel<2>), g, b, 0, s, d_entries, stride, n_max, d_n, min_n, cam, d_quat);
         else if (n_max <= 4096) hipLaunchKernelGGL((almeida_lsq_wg_kernel<4>), g, b, 0, s, d_entries, stride, n_max, d_n, min_n, cam, d_quat);
         else hipLaunchKernelGGL((almeida_lsq_wg_kernel<8>), g, b, 0, s, d_entries, stride, n_max, d_n, min_n, cam, d_quat);
-    } else {
-        OFPS_REQUIRE(ctx, d_n == nullptr && stride == n_max, "almeida: device-side counts need n <= 8192");
-        // enough workgroups to fill the chip, few enough that the fixed-order fold stays short
-        const size_t per_wg = n_max > 65536 ? 8 * 1024 : 1024;
-        int nblk = (int)((n_max + per_wg - 1) / per_wg);
-        const int cap = (2 * ctx->num_cus + batch - 1) / batch;
-        if (nblk > cap) nblk = cap < 1 ? 1 : cap;
-        auto* part = static_cast<float*>(scratch(ctx, S_WORK0, 2 * (size_t)batch * nblk * 9 * sizeof(float)));
-        auto* state = static_cast<Quat*>(scratch(ctx, S_WORK1, 2 * (size_t)batch * sizeof(Quat)));
-        if (!part || !state) return OFPS_HIP_ENOMEM;
-        float* pa = part;
-        float* pb = part + (size_t)batch * nblk * 9;
-        const bool dense = n_max > 65536;          // per-pixel regime: reciprocal-multiply quotients, see fdiv
-        for (int it = 0; it <= kIters; ++it) {
-            if (dense)
-                hipLaunchKernelGGL(almeida_lsq_step_kernel<true>, dim3(nblk, batch), dim3(1024), 0, s, d_entries, n_max, it, cam,
-                                   pa, pb, state, batch, d_quat);
-            else
-                hipLaunchKernelGGL(almeida_lsq_step_kernel<false>, dim3(nblk, batch), dim3(1024), 0, s, d_entries, n_max, it, cam,
-                                   pa, pb, state, batch, d_quat);
-            float* t = pa; pa = pb; pb = t;
-        }
+        OFPS_HIP_TRY(ctx, hipGetLastError());
+        return OFPS_HIP_OK;
     }
-    OFPS_HIP_TRY(ctx, hipGetLastError());
-    return OFPS_HIP_OK;
+    OFPS_REQUIRE(ctx, d_n == nullptr && stride == n_max, "almeida: device-side counts need n <= 8192");
+    return lsq_stepped(ctx, d_entries, n_max, batch, cam, d_quat);
 }
 
 int almeida_device(ofps_hip_ctx* ctx, const float4* d_entries, size_t n, int batch, float aspect, float fov_y_deg,
                           int use_ransac, size_t num_iters, float inlier_deg, size_t num_samples, uint64_t seed,
-                          float4* d_quat) {
+                          float4* d_quat, bool allow_cluster) {
     OFPS_REQUIRE(ctx, batch >= 1 && batch <= 65535, "almeida: batch %d out of range", batch);
     OFPS_REQUIRE(ctx, n < (1ull << 31), "almeida: too many entries");
     OFPS_REQUIRE(ctx, aspect > 0.0f && fov_y_deg > 0.0f && fov_y_deg < 180.0f, "almeida: bad camera (aspect=%g fov_y=%g)",
                  (double)aspect, (double)fov_y_deg);
     const Camera cam = camera_new(aspect, fov_y_deg);
-    if (!use_ransac) return lsq_device(ctx, d_entries, n, n, nullptr, 0, batch, cam, d_quat);
+    if (!use_ransac) return lsq_device(ctx, d_entries, n, n, nullptr, 0, batch, cam, d_quat, allow_cluster);
 
     OFPS_REQUIRE(ctx, num_iters >= 1 && num_iters <= 65535, "almeida: ransac iters %zu out of range", num_iters);
     OFPS_REQUIRE(ctx, num_samples >= 1, "almeida: ransac samples must be >= 1");
@@ -791,7 +1015,7 @@ int almeida_device(ofps_hip_ctx* ctx, const float4* d_entries, size_t n, int bat
         OFPS_HIP_TRY(ctx, hipStreamSynchronize(s));
         int rc;
         if (cnt <= 8192) rc = lsq_device(ctx, sel + (size_t)b * cap, cap, cnt < 1 ? 1 : cnt, sel_n + b, 3, 1, cam, d_quat + b);
-        else rc = lsq_device(ctx, sel + (size_t)b * cap, cnt, cnt, nullptr, 0, 1, cam, d_quat + b);
+        else rc = lsq_device(ctx, sel + (size_t)b * cap, cnt, cnt, nullptr, 0, 1, cam, d_quat + b, allow_cluster);
         if (rc != OFPS_HIP_OK) return rc;
     }
     return OFPS_HIP_OK;
@@ -826,6 +1050,15 @@ int ofps_hip_almeida(ofps_hip_ctx* ctx, const float* entries, size_t n, float as
     if (rc != OFPS_HIP_OK) return rc;
     OFPS_HIP_TRY(ctx, hipMemcpyAsync(out_quat, d_q, 4 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     OFPS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (out_quat[0] != out_quat[0]) {
+        // NaN: a cluster launch gave up waiting for workgroups that were not co-resident (see almeida_lsq_cluster_kernel);
+        // solve again with one launch per step -- still the HIP path, no spin-waits
+        rc = ofps::almeida_device(ctx, d_ent, n, 1, aspect, fov_y_deg, use_ransac, num_iters, inlier_deg, num_samples, seed, d_q,
+                                  /*allow_cluster=*/false);
+        if (rc != OFPS_HIP_OK) return rc;
+        OFPS_HIP_TRY(ctx, hipMemcpyAsync(out_quat, d_q, 4 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+        OFPS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
     if (out_tr) { out_tr[0] = out_tr[1] = out_tr[2] = 0.0f; }                       // lib.rs:120
     return OFPS_HIP_OK;
 }

@@ -24,6 +24,11 @@ struct ofps_hip_ctx {
     int pipe_w = 0, pipe_h = 0, pipe_stride = 0, pipe_newest = -1;
     void* pipe_pinned = nullptr;         // small pinned host block for the result read-back
 
+    // cluster Almeida solver (almeida.hip): granule exchange buffer state.  Tags are unique per call (tag base advances
+    // by 32 per launch), so the buffer is zeroed only when (re)allocated or when the 32-bit tag space wraps.
+    uint32_t gran_tag_base = 0;
+    void* gran_zeroed = nullptr;         // the allocation the zeroing was done for
+
     // grow-only device scratch owned by the context (staging for host-pointer entry points and
     // kernel workspaces); never shrinks, freed in ofps_hip_destroy.
     struct Scratch { void* p = nullptr; size_t cap = 0; };
@@ -35,7 +40,7 @@ namespace ofps {
 
 enum ScratchSlot {
     S_FRAMES = 0, S_ENTRIES, S_BEST, S_FIELD, S_CELLS, S_WORK0, S_WORK1, S_WORK2, S_WORK3, S_RESULT,
-    S_QUAT, S_WORK4, S_PIPE_FRAMES, S_PIPE_ENTRIES, S_PIPE_OUT, S_MASK, S_ENTRIES2
+    S_QUAT, S_WORK4, S_PIPE_FRAMES, S_PIPE_ENTRIES, S_PIPE_OUT, S_MASK, S_ENTRIES2, S_GRAN, S_SAD_LIST
 };
 
 int set_error(ofps_hip_ctx* ctx, int code, const char* fmt, ...);
@@ -59,7 +64,8 @@ int compact_entries_device(ofps_hip_ctx* ctx, const float4* d_in, const uint8_t*
 int detect_device(ofps_hip_ctx* ctx, const float4* d_entries, size_t n, int batch, float min_size, size_t subdivide,
                   float target_motion, int* d_result, float2* d_out_field, int* out_dim);
 int almeida_device(ofps_hip_ctx* ctx, const float4* d_entries, size_t n, int batch, float aspect, float fov_y_deg,
-                   int use_ransac, size_t num_iters, float inlier_deg, size_t num_samples, uint64_t seed, float4* d_quat);
+                   int use_ransac, size_t num_iters, float inlier_deg, size_t num_samples, uint64_t seed, float4* d_quat,
+                   bool allow_cluster = true);
 
 // rows of `width` bytes, host -> device; one linear copy when both sides are dense (the 2-D path is slower)
 inline hipError_t upload_rows(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t height,
