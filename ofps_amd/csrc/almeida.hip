@@ -29,6 +29,7 @@
 
 #include <cmath>
 #include <mutex>
+#include <vector>
 
 namespace ofps {
 
@@ -161,6 +162,15 @@ __device__ __forceinline__ Mat3 quat_to_mat3(const Quat& q) {                   
     return r;
 }
 
+// A wave-uniform matrix moved to scalar registers (v_readfirstlane): nine VGPRs less per matrix in kernels whose
+// per-record state fills the register file; VALU instructions read the element as their scalar operand.
+__device__ __forceinline__ Mat3 mat3_uniform(const Mat3& a) {
+    Mat3 r;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) r.m[k] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(a.m[k])));
+    return r;
+}
+
 // Matrix3::lu().solve.  a is row-major; returns false when a U diagonal is exactly 0.
 // Rows live in named registers and the pivot exchange is a chain of compile-time-indexed conditional swaps: a
 // run-time row index (m[3 * piv + c]) sends the whole matrix to scratch memory.
@@ -269,31 +279,46 @@ __device__ __forceinline__ Quat almeida_update(const Quat& rotation, const float
 constexpr int kIters = 30;                      // ceil(15 / ALPHA), lib.rs:132
 __device__ __forceinline__ float almeida_eps() { return 0.001f * 3.14159265358979323846264338327950288f / 180.0f; }
 
-// fixed-shape sum over a 1024-thread workgroup of the values v[K0..K1) of every thread; result valid in thread 0.
-// (Each component is reduced independently, so reducing a sub-range gives the same bits as reducing all nine.)
+// Wave-wide f32 sum on the DPP data path (cross-lane operands of ordinary VALU adds: no LDS round trip -- the
+// __shfl_xor butterfly compiles to six dependent ds_bpermute_b32, ~700 cycles per value).  Fixed order: quad, quad pair,
+// half row, row (every lane of a 16-lane row then holds its row's sum), row 0 -> row 1 and row 2 -> row 3 (row_bcast15),
+// rows 0+1 -> rows 2,3 (row_bcast31); lane 63 holds the total.
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ float dpp_add(float x) {
+    const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, ROW_MASK, 0xF, false);
+    return x + __int_as_float(moved);
+}
+__device__ __forceinline__ float row_sum16(float x) {        // every lane of a row <- sum over its 16-lane row
+    x = dpp_add<0xB1>(x);                                     // quad_perm [1,0,3,2]
+    x = dpp_add<0x4E>(x);                                     // quad_perm [2,3,0,1]
+    x = dpp_add<0x141>(x);                                    // row_half_mirror
+    x = dpp_add<0x140>(x);                                    // row_mirror
+    return x;
+}
+__device__ __forceinline__ float wave_sum(float x) {         // -> total, uniform (read from lane 63)
+    x = row_sum16(x);
+    x = dpp_add<0x142, 0xA>(x);                               // row_bcast15 into rows 1 and 3
+    x = dpp_add<0x143, 0xC>(x);                               // row_bcast31 into rows 2 and 3
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63));
+}
+
+// fixed-shape sum over a 1024-thread workgroup of the values v[K0..K1) of every thread; result valid in thread 0
+// (in lanes 0..15 of wave 0).  Each component is reduced independently, so reducing a sub-range gives the same bits as
+// reducing all nine.
 template <int K0, int K1>
 __device__ __forceinline__ void block_sum(float v[9], float (*red)[9]) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
     for (int k = K0; k < K1; ++k) {
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) v[k] += __shfl_xor(v[k], m, 64);
-    }
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (lane == 0) {
-#pragma unroll
-        for (int k = K0; k < K1; ++k) red[wave][k] = v[k];
+        const float t = wave_sum(v[k]);
+        if (lane == 0) red[wave][k] = t;
     }
     __syncthreads();
-    // second level: the first 16 lanes of wave 0 hold one wave-partial each and finish with a 4-step butterfly
+    // second level: the first 16 lanes of wave 0 hold one wave-partial each and finish with a row sum
     if (threadIdx.x < 64) {
         const int nw = blockDim.x >> 6;
 #pragma unroll
-        for (int k = K0; k < K1; ++k) {
-            float x = (lane < nw) ? red[lane][k] : 0.0f;
-#pragma unroll
-            for (int m = 8; m >= 1; m >>= 1) x += __shfl_xor(x, m, 64);
-            v[k] = x;
-        }
+        for (int k = K0; k < K1; ++k) v[k] = row_sum16((lane < nw) ? red[lane][k] : 0.0f);
     }
 }
 __device__ __forceinline__ void block_sum9(float v[9], float (*red)[9]) { block_sum<0, 9>(v, red); }
@@ -458,8 +483,7 @@ __global__ __launch_bounds__(1024) void almeida_lsq_step_kernel(const float4* __
     }
     // ---- fold, part 2 + the update on one lane
     if (folder) {
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) facc += __shfl_xor(facc, m, 64);
+        facc = wave_sum(facc);
         if ((threadIdx.x & 63) == 0) fold_sh[threadIdx.x >> 6] = facc;
     }
     __syncthreads();
@@ -536,65 +560,105 @@ __global__ __launch_bounds__(1024) void almeida_lsq_step_kernel(const float4* __
 // a timeout (the workgroups were not co-resident, e.g. another process holds CUs with a persistent kernel of its
 // own) the kernel writes a NaN quaternion and returns; the host-pointer entry point then re-solves with the
 // launch-per-step kernel.
-__device__ __forceinline__ void gran_store(unsigned long long* p, uint32_t tag, float v) {
-    __hip_atomic_store(p, ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v), __ATOMIC_RELAXED,
-                       __HIP_MEMORY_SCOPE_AGENT);
+// A granule = ONE naturally aligned 16-byte write-through (sc0 sc1) store of three f32 sums.  Each 8-byte half carries
+// the step's 16-bit tag, so a reader accepts a granule only when both halves belong to the step it waits for -- correct
+// even if the two halves of the store became visible separately (not observed on gfx950, not an architectural promise
+// either):   x = a,  y = tag << 16 | b[31:16],  z = c,  w = tag << 16 | b[15:0].
+typedef unsigned int gran_u4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void gran_store3(gran_u4* p, uint32_t tag16, float a, float b, float c) {
+    const uint32_t bb = __float_as_uint(b);
+    gran_u4 v;
+    v.x = __float_as_uint(a); v.y = (tag16 << 16) | (bb >> 16); v.z = __float_as_uint(c); v.w = (tag16 << 16) | (bb & 0xFFFFu);
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(p), "v"(v) : "memory");
+}
+// J granule loads in flight, ONE wait (hipcc does not count the memory operations inside an asm statement, so the wait
+// is part of it; outputs are early-clobber because the first load lands before the last address is consumed)
+__device__ __forceinline__ void gran_load3x1(const gran_u4* p0, gran_u4 (&x)[4]) {
+    asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(x[0]) : "v"(p0) : "memory");
+}
+__device__ __forceinline__ void gran_load3x2(const gran_u4* p0, const gran_u4* p1, gran_u4 (&x)[4]) {
+    asm volatile("global_load_dwordx4 %0, %2, off sc0 sc1\n\tglobal_load_dwordx4 %1, %3, off sc0 sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(x[0]), "=&v"(x[1]) : "v"(p0), "v"(p1) : "memory");
+}
+__device__ __forceinline__ void gran_load3x4(const gran_u4* p0, const gran_u4* p1, const gran_u4* p2, const gran_u4* p3,
+                                             gran_u4 (&x)[4]) {
+    asm volatile("global_load_dwordx4 %0, %4, off sc0 sc1\n\tglobal_load_dwordx4 %1, %5, off sc0 sc1\n\t"
+                 "global_load_dwordx4 %2, %6, off sc0 sc1\n\tglobal_load_dwordx4 %3, %7, off sc0 sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(x[0]), "=&v"(x[1]), "=&v"(x[2]), "=&v"(x[3]) : "v"(p0), "v"(p1), "v"(p2), "v"(p3) : "memory");
 }
 
 constexpr unsigned kSpinLimit = 1u << 18;            // ~0.3 s of polling before giving up
 
-// wave-wide: sum of the nblk (<= 256) granules of one component once all carry `tag`; fixed order (lane-strided, then
-// a butterfly), identical in every workgroup.  false = timed out.
-__device__ __forceinline__ bool gran_sweep_sum(const unsigned long long* g, int nblk, uint32_t tag, float& total) {
+// wave-wide: component sums over the nblk (<= 256) granules of one triple once all carry `tag16`; fixed order
+// (lane-strided, then the DPP tree), identical in every workgroup.  false = timed out.
+__device__ __forceinline__ bool gran_sweep_sum3(const gran_u4* g, int nblk, uint32_t tag16, float& ta, float& tb, float& tc) {
     const int lane = threadIdx.x & 63;
-    float v[4];
+    const int last = nblk - 1;
+    const gran_u4* p[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) p[j] = g + (lane + 64 * j <= last ? lane + 64 * j : last);   // out-of-range lanes re-read a valid one
+    gran_u4 x[4];
     for (unsigned spins = 0;; ++spins) {
+        if (nblk <= 64) gran_load3x1(p[0], x);
+        else if (nblk <= 128) gran_load3x2(p[0], p[1], x);
+        else gran_load3x4(p[0], p[1], p[2], p[3], x);
         bool ok = true;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int b = lane + 64 * j;
-            v[j] = 0.0f;
-            if (b < nblk) {
-                const unsigned long long x = __hip_atomic_load(g + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                v[j] = __uint_as_float((uint32_t)x);
-                ok = ok && (uint32_t)(x >> 32) == tag;
-            }
-        }
+        for (int j = 0; j < 4; ++j)
+            if (64 * j < nblk) ok = ok && (x[j].y >> 16) == tag16 && (x[j].w >> 16) == tag16;
         if (__all(ok)) break;
         if (spins >= kSpinLimit) return false;
         __builtin_amdgcn_s_sleep(1);
     }
-    float acc = ((v[0] + v[1]) + v[2]) + v[3];
+    float va[4], vb[4], vc[4];
 #pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m, 64);
-    total = acc;
+    for (int j = 0; j < 4; ++j) {
+        const bool in = lane + 64 * j < nblk;
+        va[j] = in ? __uint_as_float(x[j].x) : 0.0f;
+        vb[j] = in ? __uint_as_float((x[j].y << 16) | (x[j].w & 0xFFFFu)) : 0.0f;
+        vc[j] = in ? __uint_as_float(x[j].z) : 0.0f;
+    }
+    ta = wave_sum(((va[0] + va[1]) + va[2]) + va[3]);
+    tb = wave_sum(((vb[0] + vb[1]) + vb[2]) + vb[3]);
+    tc = wave_sum(((vc[0] + vc[1]) + vc[2]) + vc[3]);
     return true;
 }
 
 template <bool FAST, int EPT>
 __global__ __launch_bounds__(1024) void almeida_lsq_cluster_kernel(const float4* __restrict__ entries, size_t n, Camera cam,
-                                                                   unsigned long long* gran, uint32_t tag_base,
-                                                                   float4* __restrict__ out_quat) {
+                                                                   gran_u4* gran, uint32_t tag_base,
+                                                                   float4* __restrict__ out_quat,
+                                                                   unsigned long long* __restrict__ prof, uint32_t fault) {
+    // fault (tests only, normally 0): workgroup fault-1 withholds its step-3 granule, which is what a workgroup that
+    // never became resident looks like to the others -- exercises the timeout and the host's re-solve
+    // prof (diagnostics, normally null): thread 0 of every workgroup stamps s_memtime at the phase boundaries of each step
+#define OFPS_STAMP(slot) do { if (prof && threadIdx.x == 0) prof[(((size_t)blockIdx.y * gridDim.x + blockIdx.x) * kIters + it) * 5 + (slot)] = __builtin_readcyclecounter(); } while (0)
     constexpr bool P_LDS = EPT >= 8;
     __shared__ float red[16][9];
     __shared__ float fold_sh[9];
+    __shared__ float apart_sh[6];                       // this workgroup's partial of A = J^T J, published in step 0
+    __shared__ float a_sh[6];                           // A folded over all workgroups (rotation-independent)
     __shared__ Quat rot_sh[2];
     __shared__ int fail_sh;
     __shared__ float4 plds[P_LDS ? EPT * 1024 : 1];     // (roll.x, roll.y, pitch.x, pitch.y) per record
     const int nblk = gridDim.x, blk = blockIdx.x;
     const size_t item = blockIdx.y;
-    unsigned long long* g = gran + item * (size_t)(2 * 9) * nblk;     // [parity][component][workgroup]
+    gran_u4* g = gran + item * (size_t)(2 * 3) * nblk;                 // [parity][triple: A0-2, A3-5, b][workgroup]
     const float eps = almeida_eps();
-    const Mat3 mroll = mat3_from_euler(0.0f, eps, 0.0f);           // lib.rs:30-34
-    const Mat3 mpitch = mat3_from_euler(eps, 0.0f, 0.0f);          // lib.rs:36-38
-    const Mat3 myaw = mat3_from_euler(0.0f, 0.0f, -eps);           // lib.rs:40-42
+    const Mat3 mroll = mat3_uniform(mat3_from_euler(0.0f, eps, 0.0f));     // lib.rs:30-34
+    const Mat3 mpitch = mat3_uniform(mat3_from_euler(eps, 0.0f, 0.0f));    // lib.rs:36-38
+    const Mat3 myaw = mat3_uniform(mat3_from_euler(0.0f, 0.0f, -eps));     // lib.rs:40-42
     float4 e[EPT];
     float2 pr[P_LDS ? 1 : EPT], pp[P_LDS ? 1 : EPT], py[EPT];
-    float uwx[EPT], uwz[EPT];
+    // the hoisted unprojection costs two registers per record; with reciprocal-multiply quotients it is four VALU
+    // instructions per component to recompute (same function, same bits), which is cheaper than spilling at EPT = 8
+    constexpr bool RECOMPUTE_UNPROJ = FAST && EPT >= 8;
+    float uwx[RECOMPUTE_UNPROJ ? 1 : EPT], uwz[RECOMPUTE_UNPROJ ? 1 : EPT];
     float uwy = 0.0f;
     bool ok[EPT];
     float s[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    if (threadIdx.x == 0) fail_sh = 0;
+    if (threadIdx.x == 0) { fail_sh = 0; rot_sh[1] = Quat{1.0f, 0.0f, 0.0f, 0.0f}; }   // slot 1 = rotation entering step 0
 #pragma unroll
     for (int t = 0; t < EPT; ++t) {
         const size_t i = ((size_t)blk * EPT + t) * 1024 + threadIdx.x;
@@ -604,32 +668,49 @@ __global__ __launch_bounds__(1024) void almeida_lsq_cluster_kernel(const float4*
 #pragma unroll
     for (int t = 0; t < EPT; ++t) {
         const Unproj un = cam_unproject<FAST>(cam, e[t].x, e[t].y);
-        uwx[t] = un.wx; uwz[t] = un.wz; uwy = un.wy;
-        const float2 r = cam_delta_w<FAST>(cam, e[t].x, e[t].y, un, mroll);
-        const float2 p = cam_delta_w<FAST>(cam, e[t].x, e[t].y, un, mpitch);
-        py[t] = cam_delta_w<FAST>(cam, e[t].x, e[t].y, un, myaw);
+        if constexpr (!RECOMPUTE_UNPROJ) { uwx[t] = un.wx; uwz[t] = un.wz; }
+        uwy = un.wy;
+        // a slot past the end of the field holds a finite dummy record with ALL-ZERO prototypes: every product it
+        // contributes below is an exact +0, so the 30-step loop needs no per-record validity branch
+        const float2 zero2 = make_float2(0.0f, 0.0f);
+        const float2 r = ok[t] ? cam_delta_w<FAST>(cam, e[t].x, e[t].y, un, mroll) : zero2;
+        const float2 p = ok[t] ? cam_delta_w<FAST>(cam, e[t].x, e[t].y, un, mpitch) : zero2;
+        py[t] = ok[t] ? cam_delta_w<FAST>(cam, e[t].x, e[t].y, un, myaw) : zero2;
         if constexpr (P_LDS) plds[t * 1024 + threadIdx.x] = make_float4(r.x, r.y, p.x, p.y);
         else { pr[t] = r; pp[t] = p; }
-        if (ok[t]) {
-            s[0] += r.x * r.x + r.y * r.y;
-            s[1] += r.x * p.x + r.y * p.y;
-            s[2] += r.x * py[t].x + r.y * py[t].y;
-            s[3] += p.x * p.x + p.y * p.y;
-            s[4] += p.x * py[t].x + p.y * py[t].y;
-            s[5] += py[t].x * py[t].x + py[t].y * py[t].y;
-        }
+        s[0] += r.x * r.x + r.y * r.y;
+        s[1] += r.x * p.x + r.y * p.y;
+        s[2] += r.x * py[t].x + r.y * py[t].y;
+        s[3] += p.x * p.x + p.y * p.y;
+        s[4] += p.x * py[t].x + p.y * py[t].y;
+        s[5] += py[t].x * py[t].x + py[t].y * py[t].y;
+        if constexpr (EPT >= 8) __builtin_amdgcn_sched_barrier(0);  // one record at a time: see the step loop
     }
-    float a[6] = {0, 0, 0, 0, 0, 0};                               // folded A, thread 0 only
-    Quat rotation = {1.0f, 0.0f, 0.0f, 0.0f};
+    // the six A partials leave the registers before the step loop (they would stay live through all 30 steps otherwise)
+    block_sum<0, 6>(s, red);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) apart_sh[k] = s[k];
+    }
+    __syncthreads();
+    // the rotation lives in LDS between steps (rot_sh[(it + 1) & 1] enters step it): nothing but the per-record state
+    // stays in vector registers across the step loop
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     for (int it = 0; it < kIters; ++it) {
         const float alpha = (it == kIters - 1) ? 1.0f : 0.5f;      // lib.rs:138
-        const Mat3 rotm = quat_to_mat3(rotation);                  // lib.rs:140
+        OFPS_STAMP(0);
+        const Mat3 rotm = mat3_uniform(quat_to_mat3(rot_sh[(it + 1) & 1]));    // lib.rs:140
         s[6] = 0.0f; s[7] = 0.0f; s[8] = 0.0f;
 #pragma unroll
         for (int t = 0; t < EPT; ++t) {
-            if (!ok[t]) continue;
-            const Unproj un = {uwx[t], uwy, uwz[t]};
+            Unproj un;
+            if constexpr (RECOMPUTE_UNPROJ) {
+                float ex = e[t].x, ey = e[t].y;
+                asm volatile("" : "+v"(ex), "+v"(ey));             // opaque to loop-invariant code motion: recompute, do not hoist
+                un = cam_unproject<FAST>(cam, ex, ey);
+            } else {
+                un = Unproj{uwx[t], uwy, uwz[t]};
+            }
             const float2 d = cam_delta_w<FAST>(cam, e[t].x, e[t].y, un, rotm);
             const float rx = e[t].z - d.x, ry = e[t].w - d.y;      // motion - delta
             float2 r, p;
@@ -638,22 +719,32 @@ __global__ __launch_bounds__(1024) void almeida_lsq_cluster_kernel(const float4*
             s[6] += r.x * rx + r.y * ry;
             s[7] += p.x * rx + p.y * ry;
             s[8] += py[t].x * rx + py[t].y * ry;
+            // 8 records x ~15 temporaries interleaved do not fit beside the 64 resident registers: keep the scheduler
+            // from overlapping more than two records (4 waves per SIMD hide the latency instead)
+            if constexpr (EPT >= 8) __builtin_amdgcn_sched_barrier(0);
         }
-        const int k0 = it == 0 ? 0 : 6;
-        if (it == 0) block_sum<0, 9>(s, red); else block_sum<6, 9>(s, red);
-        const uint32_t tag = tag_base + (uint32_t)it + 1u;
-        unsigned long long* gp = g + (size_t)(it & 1) * 9 * nblk;
+        OFPS_STAMP(1);
+        block_sum<6, 9>(s, red);
+        OFPS_STAMP(2);
+        const uint32_t tag = (tag_base + (uint32_t)it + 1u) & 0xFFFFu;
+        gran_u4* gp = g + (size_t)(it & 1) * 3 * nblk;
         if (threadIdx.x == 0) {
-#pragma unroll
-            for (int k = 0; k < 9; ++k)
-                if (k >= k0) gran_store(gp + (size_t)k * nblk + blk, tag, s[k]);
+            if (it == 0) {
+                gran_store3(gp + blk, tag, apart_sh[0], apart_sh[1], apart_sh[2]);
+                gran_store3(gp + nblk + blk, tag, apart_sh[3], apart_sh[4], apart_sh[5]);
+            }
+            if (!(fault && it == 3 && (uint32_t)blk == fault - 1u)) gran_store3(gp + 2 * (size_t)nblk + blk, tag, s[6], s[7], s[8]);
         }
-        if (wave >= k0 && wave < 9) {                              // wave k gathers component k
-            float tot = 0.0f;
-            const bool got = gran_sweep_sum(gp + (size_t)wave * nblk, nblk, tag, tot);
-            if (lane == 0) { if (got) fold_sh[wave] = tot; else fail_sh = 1; }
+        if (wave < 3 && (wave == 2 || it == 0)) {                  // wave k gathers triple k (the A triples in step 0 only)
+            float ta = 0.0f, tb = 0.0f, tc = 0.0f;
+            const bool got = gran_sweep_sum3(gp + (size_t)wave * nblk, nblk, tag, ta, tb, tc);
+            if (lane == 0) {
+                if (got) { fold_sh[3 * wave] = ta; fold_sh[3 * wave + 1] = tb; fold_sh[3 * wave + 2] = tc; }
+                else fail_sh = 1;
+            }
         }
         __syncthreads();
+        OFPS_STAMP(3);
         if (fail_sh) {
             if (threadIdx.x == 0) out_quat[item] = make_float4(__builtin_nanf(""), 0.0f, 0.0f, 0.0f);
             return;
@@ -661,14 +752,16 @@ __global__ __launch_bounds__(1024) void almeida_lsq_cluster_kernel(const float4*
         if (threadIdx.x == 0) {
             if (it == 0) {
 #pragma unroll
-                for (int k = 0; k < 6; ++k) a[k] = fold_sh[k];
+                for (int k = 0; k < 6; ++k) a_sh[k] = fold_sh[k];
             }
-            const float f[9] = {a[0], a[1], a[2], a[3], a[4], a[5], fold_sh[6], fold_sh[7], fold_sh[8]};
-            rot_sh[it & 1] = almeida_update(rotation, f, eps, alpha);
+            const float f[9] = {a_sh[0], a_sh[1], a_sh[2], a_sh[3], a_sh[4], a_sh[5], fold_sh[6], fold_sh[7], fold_sh[8]};
+            rot_sh[it & 1] = almeida_update(rot_sh[(it + 1) & 1], f, eps, alpha);
         }
         __syncthreads();
-        rotation = rot_sh[it & 1];
+        OFPS_STAMP(4);
     }
+    const Quat rotation = rot_sh[(kIters - 1) & 1];
+#undef OFPS_STAMP
     if (blk == 0 && threadIdx.x == 0) out_quat[item] = make_float4(rotation.w, -rotation.i, -rotation.j, -rotation.k);  // :199
 }
 
@@ -865,14 +958,19 @@ static ClusterGate g_cluster_gate;
 
 template <bool FAST, int EPT>
 static void launch_cluster(hipStream_t s, int nblk, int items, const float4* d_entries, size_t n, const Camera& cam,
-                           unsigned long long* gran, uint32_t tag_base, float4* d_quat) {
+                           gran_u4* gran, uint32_t tag_base, float4* d_quat, unsigned long long* prof) {
+    uint32_t fault = 0;
+    if (const char* f = getenv("OFPS_HIP_ALMEIDA_TEST_FAULT")) fault = (uint32_t)atoi(f);     // tests only
     hipLaunchKernelGGL((almeida_lsq_cluster_kernel<FAST, EPT>), dim3(nblk, items), dim3(1024), 0, s, d_entries, n, cam, gran,
-                       tag_base, d_quat);
+                       tag_base, d_quat, prof, fault);
 }
 
 // -> 1 launched, 0 not applicable (caller falls back to the launch-per-step kernel), < 0 error
 static int lsq_cluster(ofps_hip_ctx* ctx, const float4* d_entries, size_t n, int batch, const Camera& cam, float4* d_quat) {
-    int ept = n > 4096 ? 8 : (n > 2048 ? 4 : (n > 1024 ? 2 : 1));
+    // records per thread: fewer = less arithmetic per step on the critical path, more = fewer workgroups to gather from.
+    // With 16-byte granules the gather is cheap (1.5 us at 254 workgroups), so the smallest count that keeps the
+    // problem within one workgroup per CU wins at every size (tools/almeida_prof.py)
+    int ept = n > 1024 * 1024 ? 8 : (n > 512 * 1024 ? 4 : (n > 254 * 1024 ? 2 : 1));
     if (const char* f = getenv("OFPS_HIP_ALMEIDA_EPT")) { const int v = atoi(f); if (v == 1 || v == 2 || v == 4 || v == 8) ept = v; }
     const size_t per_wg = (size_t)ept * 1024;
     const size_t nblk_sz = (n + per_wg - 1) / per_wg;
@@ -880,14 +978,19 @@ static int lsq_cluster(ofps_hip_ctx* ctx, const float4* d_entries, size_t n, int
     const int nblk = (int)nblk_sz;
     const int per_launch = ctx->num_cus / nblk;              // items whose workgroups are all co-resident (1 per CU)
     const bool dense = n > 65536;                            // per-pixel regime: reciprocal-multiply quotients, see fdiv
-    const size_t gran_bytes = (size_t)per_launch * 2 * 9 * nblk * sizeof(unsigned long long);
-    auto* gran = static_cast<unsigned long long*>(scratch(ctx, S_GRAN, gran_bytes));
+    const size_t gran_bytes = (size_t)per_launch * 2 * 3 * nblk * sizeof(gran_u4);
+    auto* gran = static_cast<gran_u4*>(scratch(ctx, S_GRAN, gran_bytes));
     if (!gran) return OFPS_HIP_ENOMEM;
     hipStream_t s = ctx->stream;
+    unsigned long long* prof = nullptr;
+    if (getenv("OFPS_HIP_ALMEIDA_PROF")) {
+        prof = static_cast<unsigned long long*>(scratch(ctx, S_WORK2, (size_t)per_launch * nblk * kIters * 5 * sizeof(unsigned long long)));
+        if (!prof) return OFPS_HIP_ENOMEM;
+    }
     const size_t cap = ctx->scratch[S_GRAN].cap;
     for (int b0 = 0; b0 < batch; b0 += per_launch) {
         const int items = batch - b0 < per_launch ? batch - b0 : per_launch;
-        if (ctx->gran_zeroed != gran || ctx->gran_tag_base > 0xFFFFFF00u) {
+        if (ctx->gran_zeroed != gran || ctx->gran_tag_base > 0xFF00u) {        // 16-bit tags: re-zero before they wrap
             OFPS_HIP_TRY(ctx, hipMemsetAsync(gran, 0, cap, s));
             ctx->gran_zeroed = gran; ctx->gran_tag_base = 0;
         }
@@ -899,13 +1002,34 @@ static int lsq_cluster(ofps_hip_ctx* ctx, const float4* d_entries, size_t n, int
         hipEvent_t& ev = g_cluster_gate.ev[ctx->device & 63];
         if (!ev) OFPS_HIP_TRY(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
         else OFPS_HIP_TRY(ctx, hipStreamWaitEvent(s, ev, 0));
-        if (dense) launch_cluster<true, 8>(s, nblk, items, ent, n, cam, gran, tag_base, q);
-        else if (ept == 8) launch_cluster<false, 8>(s, nblk, items, ent, n, cam, gran, tag_base, q);
-        else if (ept == 4) launch_cluster<false, 4>(s, nblk, items, ent, n, cam, gran, tag_base, q);
-        else if (ept == 2) launch_cluster<false, 2>(s, nblk, items, ent, n, cam, gran, tag_base, q);
-        else launch_cluster<false, 1>(s, nblk, items, ent, n, cam, gran, tag_base, q);
+        if (dense && ept == 8) launch_cluster<true, 8>(s, nblk, items, ent, n, cam, gran, tag_base, q, prof);
+        else if (dense && ept == 4) launch_cluster<true, 4>(s, nblk, items, ent, n, cam, gran, tag_base, q, prof);
+        else if (dense && ept == 2) launch_cluster<true, 2>(s, nblk, items, ent, n, cam, gran, tag_base, q, prof);
+        else if (dense) launch_cluster<true, 1>(s, nblk, items, ent, n, cam, gran, tag_base, q, prof);
+        else if (ept == 8) launch_cluster<false, 8>(s, nblk, items, ent, n, cam, gran, tag_base, q, prof);
+        else if (ept == 4) launch_cluster<false, 4>(s, nblk, items, ent, n, cam, gran, tag_base, q, prof);
+        else if (ept == 2) launch_cluster<false, 2>(s, nblk, items, ent, n, cam, gran, tag_base, q, prof);
+        else launch_cluster<false, 1>(s, nblk, items, ent, n, cam, gran, tag_base, q, prof);
         OFPS_HIP_TRY(ctx, hipGetLastError());
         OFPS_HIP_TRY(ctx, hipEventRecord(ev, s));
+    }
+    if (prof) {                                              // diagnostics: phase table of the last launch to stderr
+        const size_t cnt = (size_t)nblk * kIters * 5;
+        std::vector<unsigned long long> h(cnt);
+        OFPS_HIP_TRY(ctx, hipMemcpyAsync(h.data(), prof, cnt * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+        OFPS_HIP_TRY(ctx, hipStreamSynchronize(s));
+        double ph[5] = {0, 0, 0, 0, 0};
+        for (int b = 0; b < nblk; ++b)
+            for (int it = 0; it < kIters; ++it) {
+                const unsigned long long* r = h.data() + ((size_t)b * kIters + it) * 5;
+                for (int k = 0; k < 4; ++k) ph[k] += (double)(r[k + 1] - r[k]);
+                if (it + 1 < kIters) ph[4] += (double)(r[5] - r[4]);
+            }
+        const double den = (double)nblk * kIters;
+        fprintf(stderr, "[almeida cluster prof] n=%zu nblk=%d ept=%d  cycles/step (100 MHz ticks if constant clock): compute %.0f  "
+                        "block_sum %.0f  publish+sweep %.0f  update %.0f  loop-back %.0f   wg0 total %.0f\n",
+                n, nblk, ept, ph[0] / den, ph[1] / den, ph[2] / den, ph[3] / den, ph[4] / den,
+                (double)(h[(size_t)(kIters - 1) * 5 + 4] - h[0]));
     }
     return 1;
 }
@@ -947,7 +1071,7 @@ static int lsq_device(ofps_hip_ctx* ctx, const float4* d_entries, size_t stride,
     // (N > 256 x 8192) or a forced A/B run takes one launch per step.
     bool wg_path = n_max <= 8192;
     bool cluster = allow_cluster && d_n == nullptr && stride == n_max;
-    size_t cluster_min = 8192;                                           // lone problems above this size use the cluster
+    size_t cluster_min = batch == 1 ? 4096 : 8192;                       // lone problems above this size use the cluster
     if (const char* force = getenv("OFPS_HIP_ALMEIDA_PATH")) {          // A/B experiments only
         if (!strcmp(force, "step") && d_n == nullptr) { wg_path = false; cluster = false; }
         if (!strcmp(force, "wg")) cluster = false;

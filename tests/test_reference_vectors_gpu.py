@@ -136,3 +136,23 @@ def test_hip_push_frame_1080p_matches_stagewise_oracle(ctx):
             np.testing.assert_array_equal(r["motion"][1].view(np.uint32), det_o[1].view(np.uint32))
         q_o = oracle.solve_ypr_ransac(ent_o, cam, 60, 0.05, 1000, seed=100 + k) if k & 1 else oracle.solve_ypr_given(ent_o, cam)
         np.testing.assert_allclose(r["quat"], q_o, atol=1e-4 if k & 1 else 2e-6, rtol=0)
+
+
+# ---- cluster solver: what happens when its workgroups are not all there ------------------------------------------------
+def test_hip_almeida_cluster_timeout_falls_back_to_the_stepped_solver(ctx, monkeypatch):
+    """One workgroup withholds a granule (test hook): the others give up after their bounded spin, the kernel returns
+    NaN, and the host-pointer entry point re-solves with one launch per step -- same answer, no hang."""
+    import time
+    e = synth.rotation_field(480, 270)                       # 129,600 records -> 127 workgroups
+    cam = oracle.camera(16 / 9, 22.275)
+    q_ok, _ = ctx.almeida(e, 16 / 9, 22.275, use_ransac=False)
+    monkeypatch.setenv("OFPS_HIP_ALMEIDA_TEST_FAULT", "2")
+    t0 = time.perf_counter()
+    q_fb, _ = ctx.almeida(e, 16 / 9, 22.275, use_ransac=False)
+    dt = time.perf_counter() - t0
+    monkeypatch.delenv("OFPS_HIP_ALMEIDA_TEST_FAULT")
+    assert np.isfinite(q_fb).all() and dt < 20.0
+    np.testing.assert_allclose(q_fb, oracle.solve_ypr_given(e, cam), atol=2e-6, rtol=0)
+    np.testing.assert_allclose(q_fb, q_ok, atol=2e-6, rtol=0)
+    q_again, _ = ctx.almeida(e, 16 / 9, 22.275, use_ransac=False)          # and the cluster path works again afterwards
+    np.testing.assert_allclose(q_again, q_ok, atol=0, rtol=0)
