@@ -14,7 +14,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libofps_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
+# -fno-slp-vectorize: hipcc's SLP pass packs adjacent scalar f32 adds/muls into v_pk_add_f32 / v_pk_mul_f32, which issue
+# at half the rate of the scalar forms on gfx950 (profiles/ubench_valu_r02.txt: 4.8 vs 2.5 cycles per wave64
+# instruction) -- no flops gained -- and need their operands in aligned register pairs: 31 extra v_mov per window row in
+# the LK step kernel.  Per-lane results are identical either way (IEEE f32).
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-slp-vectorize",
          "-Wall", "-Wno-unused-function", "-fno-gpu-rdc"] + os.environ.get("OFPS_HIP_EXTRA_FLAGS", "").split()
 
 
