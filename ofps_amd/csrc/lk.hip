@@ -215,6 +215,14 @@ __device__ __forceinline__ void lk_stage(const float* const (&src)[PLANES], floa
     }
 }
 
+// One whole 16-byte LDS read (ds_read_b128: 4 LDS cycles per wave).  Left to itself the compiler narrows a float4 read
+// whose .w is unused to ds_read_b96, which takes 8.
+typedef float lk_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ lk_f4 lk_lds_read4(const float4* p) {        // p must point into __shared__ memory
+    typedef const volatile __attribute__((address_space(3))) lk_f4* lds_ptr;
+    return *(lds_ptr)(p);
+}
+
 // The step kernel's three window planes interleaved: one 16-byte LDS read per tap instead of three 4-byte ones
 // (ds_read_b128 moves 256 B per LDS clock, ds_read_b32 128).
 template <int RADIUS>
@@ -256,120 +264,214 @@ __global__ __launch_bounds__(256) void lk_tensor_tiled_kernel(const float* __res
 }
 
 // Current-frame window in LDS.  The bilinear fetches J(q + flow(p)) of a workgroup land in the rectangle
-// [tile + window] shifted by the flows of its pixels; when those flows differ by at most LkTile::SPREAD pixels (smooth
-// flow: almost every tile) the rectangle fits jl[][] and is staged once, coordinates clamped at staging time exactly like
-// the oracle clamps xa/xb/ya/yb -- the inner loop then has no global loads at all (it was latency-bound on 10 dependent
-// gathers per window row).  Tiles with wilder flows keep the register-reuse global path below.  Same values, same
-// operation order either way, hence the same bits.
+// [tile + window] shifted by the flows of its pixels; when those flows differ by at most SPREAD pixels (almost every
+// tile) the rectangle fits jl[][] and is staged once, coordinates clamped at staging time exactly like the oracle
+// clamps xa/xb/ya/yb -- the inner loop then has no global loads at all.  Tiles with wilder flows, and tiles whose window
+// columns do not sample consecutive texels (left/right image border), need per-lane gathers with twice the registers;
+// they are NOT handled here: the main kernel (GENERAL = false, 57 VGPRs -> 6 waves per SIMD instead of 4) appends them
+// to a list and a small second launch (GENERAL = true) walks that list with the register-reuse global path.  Same
+// values, same operation order either way, hence the same bits.
 template <int RADIUS>
-__global__ __launch_bounds__(256, (RADIUS <= 4 ? 4 : 2)) void lk_step_tiled_kernel(const float* __restrict__ I, const float* __restrict__ J,
-                                                            const float* __restrict__ gx, const float* __restrict__ gy,
-                                                            const float4* __restrict__ G, int w, int h,
-                                                            const float2* __restrict__ flow_in, float2* __restrict__ flow_out) {
+struct LkStepShared {
     using T = LkTile<RADIUS>;
+    // capacity of the current-frame rectangle: flows inside a tile may differ by up to SPREAD pixels; only the rectangle
+    // a tile really needs is staged, so the capacity costs LDS space, not time
+    static constexpr int SPREAD = 20, LW = T::TW + 1 + SPREAD, LH = T::TH + 1 + SPREAD;
+    float4 tile[T::TH][T::TW];         // (I, gx, gy, -) of the previous frame's window
+    float jl[LH][LW + 1];
+    int box[4][4];                     // per wave: min x0, max x0+1, min y0, max y0+1
+};
+
+// integer sample origin of a window column / row: the oracle's floor + float clamp to [-1, lim]
+__device__ __forceinline__ int lk_origin(int q, float fl, int lim, float& frac) {
+    const float fq = (float)q + fl;
+    const float q0f = floorf(fq);
+    frac = fq - q0f;
+    const float c = q0f < -1.0f ? -1.0f : (q0f > (float)lim ? (float)lim : q0f);
+    return (int)c;
+}
+
+__device__ __forceinline__ void lk_solve_store(const float4* __restrict__ G, const float2 f, float bx, float by, size_t idx,
+                                               float2* __restrict__ flow_out) {
+    const float4 g = G[idx];
+    const float det = g.x * g.z - g.y * g.y;
+    float du = 0.0f, dv = 0.0f;
+    if (det > 0.01f) {
+        du = (g.z * bx - g.y * by) / det;
+        dv = (g.x * by - g.y * bx) / det;
+    }
+    flow_out[idx] = make_float2(f.x + du, f.y + dv);
+}
+
+// main kernel: one workgroup per 64 x 4 tile; tiles it cannot serve from LDS are appended to fb_tiles (count in *fb_count)
+template <int RADIUS>
+__global__ __launch_bounds__(256) void lk_step_lds_kernel(const float* __restrict__ I, const float* __restrict__ J,
+                                                          const float* __restrict__ gx, const float* __restrict__ gy,
+                                                          const float4* __restrict__ G, int w, int h,
+                                                          const float2* __restrict__ flow_in, float2* __restrict__ flow_out,
+                                                          uint32_t* __restrict__ fb_count, uint32_t* __restrict__ fb_tiles) {
+    using T = LkTile<RADIUS>;
+    using S = LkStepShared<RADIUS>;
     constexpr int N = T::N;
-    constexpr int SPREAD = 6, LW = T::TW + 1 + SPREAD, LH = T::TH + 1 + SPREAD;
-    __shared__ float4 tile[T::TH][T::TW];         // (I, gx, gy, -) of the previous frame's window
-    __shared__ float jl[LH][LW + 1];
-    __shared__ int box[4][4];                     // per wave: min x0, max x0+1, min y0, max y0+1
+    __shared__ S sh;
     const int x0 = blockIdx.x * 64, y0 = blockIdx.y * 4;
-    lk_stage3<RADIUS>(I, gx, gy, tile, w, h, x0, y0);
+    lk_stage3<RADIUS>(I, gx, gy, sh.tile, w, h, x0, y0);
     const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6, x = x0 + lx, y = y0 + ly;
     const bool active = x < w && y < h;
     const float2 f = active ? flow_in[(size_t)y * w + x] : make_float2(0.0f, 0.0f);
-    // integer sample origin of a window column / row: the oracle's floor + float clamp to [-1, w] (or h)
-    auto origin = [](int q, float fl, int lim, float& frac) {
-        const float fq = (float)q + fl;
-        const float q0f = floorf(fq);
-        frac = fq - q0f;
-        const float c = q0f < -1.0f ? -1.0f : (q0f > (float)lim ? (float)lim : q0f);
-        return (int)c;
-    };
-    int xi[N];
     float ax[N];
-#pragma unroll
-    for (int k = 0; k < N; ++k) xi[k] = origin(lk_clampi(x + k - RADIUS, 0, w - 1), f.x, w, ax[k]);
-    float dummy;
-    const int yt = origin(lk_clampi(y - RADIUS, 0, h - 1), f.y, h, dummy);
-    const int yb_ = origin(lk_clampi(y + RADIUS, 0, h - 1), f.y, h, dummy);
-    {
-        int bx0 = active ? xi[0] : 0x7FFFFFFF, bx1 = active ? xi[N - 1] + 1 : -0x7FFFFFFF;
-        int by0 = active ? yt : 0x7FFFFFFF, by1 = active ? yb_ + 1 : -0x7FFFFFFF;
-        // window columns / rows are monotone in k / r, so the extremes are the first and the last
-        bx0 = lk_wave_minmax<false>(bx0); bx1 = lk_wave_minmax<true>(bx1);
-        by0 = lk_wave_minmax<false>(by0); by1 = lk_wave_minmax<true>(by1);
-        if (lx == 0) { box[ly][0] = bx0; box[ly][1] = bx1; box[ly][2] = by0; box[ly][3] = by1; }
-    }
-    __syncthreads();
-    const int xmin = min(min(box[0][0], box[1][0]), min(box[2][0], box[3][0]));
-    const int xmax = max(max(box[0][1], box[1][1]), max(box[2][1], box[3][1]));
-    const int ymin = min(min(box[0][2], box[1][2]), min(box[2][2], box[3][2]));
-    const int ymax = max(max(box[0][3], box[1][3]), max(box[2][3], box[3][3]));
-    // the LDS path also wants every lane's window columns to sample consecutive texels (x0[k+1] == x0[k] + 1: true
-    // away from the left/right image border), so one row of N+1 texels serves all N columns
+    int xi[N];
     bool consecutive = true;
 #pragma unroll
-    for (int k = 0; k + 1 < N; ++k) consecutive = consecutive && (xi[k + 1] == xi[k] + 1);
-    const int fits = xmax >= xmin && xmax - xmin < LW && ymax - ymin < LH;
-    const bool in_lds = __syncthreads_and(fits && (consecutive || !active));       // uniform over the workgroup
-    float bx = 0.0f, by = 0.0f;
-    if (in_lds) {
-        {
-            constexpr int RPP = 256 / LW;                            // rows per pass (3 for LW = 79)
-            const int cx = threadIdx.x % LW, cy0 = threadIdx.x / LW;
-            if (cy0 < RPP) {
-                const int gx = lk_clampi(xmin + cx, 0, w - 1);
-#pragma unroll
-                for (int cy = cy0; cy < LH; cy += RPP) jl[cy][cx] = J[(size_t)lk_clampi(ymin + cy, 0, h - 1) * w + gx];
-            }
+    for (int k = 0; k < N; ++k) {
+        xi[k] = lk_origin(lk_clampi(x + k - RADIUS, 0, w - 1), f.x, w, ax[k]);
+        if (k > 0) consecutive = consecutive && (xi[k] == xi[k - 1] + 1);
+    }
+    float dummy;
+    const int yt = lk_origin(lk_clampi(y - RADIUS, 0, h - 1), f.y, h, dummy);
+    const int yb_ = lk_origin(lk_clampi(y + RADIUS, 0, h - 1), f.y, h, dummy);
+    {
+        // window columns / rows are monotone in k / r, so the extremes are the first and the last
+        int bx0 = active ? xi[0] : 0x7FFFFFFF, bx1 = active ? xi[N - 1] + 1 : -0x7FFFFFFF;
+        int by0 = active ? yt : 0x7FFFFFFF, by1 = active ? yb_ + 1 : -0x7FFFFFFF;
+        bx0 = lk_wave_minmax<false>(bx0); bx1 = lk_wave_minmax<true>(bx1);
+        by0 = lk_wave_minmax<false>(by0); by1 = lk_wave_minmax<true>(by1);
+        if (lx == 0) { sh.box[ly][0] = bx0; sh.box[ly][1] = bx1; sh.box[ly][2] = by0; sh.box[ly][3] = by1; }
+    }
+    __syncthreads();
+    const int xmin = min(min(sh.box[0][0], sh.box[1][0]), min(sh.box[2][0], sh.box[3][0]));
+    const int xmax = max(max(sh.box[0][1], sh.box[1][1]), max(sh.box[2][1], sh.box[3][1]));
+    const int ymin = min(min(sh.box[0][2], sh.box[1][2]), min(sh.box[2][2], sh.box[3][2]));
+    const int ymax = max(max(sh.box[0][3], sh.box[1][3]), max(sh.box[2][3], sh.box[3][3]));
+    const int fits = xmax >= xmin && xmax - xmin < S::LW && ymax - ymin < S::LH;
+    if (!fits) {                                                     // uniform: box[] is the same for every thread
+        if (threadIdx.x == 0) fb_tiles[atomicAdd(fb_count, 1u)] = (uint32_t)blockIdx.x | ((uint32_t)blockIdx.y << 16);
+        return;
+    }
+    // window columns that sample consecutive texels (x0[k+1] == x0[k] + 1: everywhere but at the left/right image
+    // border, where the clamped window columns repeat) share one row of N+1 texels; otherwise every column reads its
+    // own pair.  Uniform over the workgroup.
+    const bool all_consecutive = __syncthreads_and(consecutive || !active);
+    {
+        // rows [ymin, ymax] x columns [xmin, xmax] of the current frame; 128 threads per row, two rows per pass
+        const int cw = xmax - xmin + 1, chh = ymax - ymin + 1;
+        const int cx = threadIdx.x & 127, cy0 = threadIdx.x >> 7;
+        if (cx < cw) {
+            const int gxc = lk_clampi(xmin + cx, 0, w - 1);
+            for (int cy = cy0; cy < chh; cy += 2) sh.jl[cy][cx] = J[(size_t)lk_clampi(ymin + cy, 0, h - 1) * w + gxc];
         }
-        __syncthreads();
-        const int xo = active ? xi[0] - xmin : 0;
-        // hup[k] = horizontal interpolation of the UPPER sample row at column k.  The lower row of one window row is the
-        // upper row of the next whenever the sample row advanced by exactly one (always, away from the top/bottom
-        // border), and its interpolation j01 + ax[k] * (j11 - j01) is then the very expression the next row evaluates
-        // as j00 + ax[k] * (j10 - j00) on the same texels: carried over instead of recomputed -- same operations on the
-        // same inputs, 11 instead of 14 VALU operations per tap.  Decided per wave so the branch is uniform; recomputing
-        // is always correct.
-        float hup[N], jb[N + 1];
-        int prev_yi = -0x7FFFFFFF;
+    }
+    __syncthreads();
+    if (!active) return;
+    // hup[k] = horizontal interpolation of the UPPER sample row at column k.  The lower row of one window row is the
+    // upper row of the next whenever the sample row advanced by exactly one (always, away from the top/bottom
+    // border), and its interpolation j01 + ax[k] * (j11 - j01) is then the very expression the next row evaluates
+    // as j00 + ax[k] * (j10 - j00) on the same texels: carried over instead of recomputed -- same operations on the
+    // same inputs, 11 instead of 14 VALU operations per tap.  Decided per wave so the branch is uniform; recomputing
+    // is always correct.
+    float bx = 0.0f, by = 0.0f;
+    float hup[N];
+    int prev_yi = -0x7FFFFFFF;
+    if (all_consecutive) {
+        const int xo = xi[0] - xmin;
+        float jb[N + 1];
+        // (measured and rejected: unrolling the row loop, fully or by two with ping-pong hup arrays -- hipcc then hoists
+        // the next row's LDS reads, 104+ VGPRs, 4 waves per SIMD, 0.53 vs 0.50 ms)
 #pragma unroll 1
         for (int r = 0; r < N; ++r) {
             float ay;
-            const int yi = active ? origin(lk_clampi(y + r - RADIUS, 0, h - 1), f.y, h, ay) - ymin : 0;
-            const bool reuse = __all(!active || yi == prev_yi + 1);
+            const int yi = lk_origin(lk_clampi(y + r - RADIUS, 0, h - 1), f.y, h, ay) - ymin;
+            const bool reuse = __all(yi == prev_yi + 1);
             prev_yi = yi;
             if (!reuse) {
-                const float* ra = &jl[yi][xo];
+                const float* ra = &sh.jl[yi][xo];
 #pragma unroll
                 for (int k = 0; k <= N; ++k) jb[k] = ra[k];
 #pragma unroll
                 for (int k = 0; k < N; ++k) hup[k] = jb[k] + ax[k] * (jb[k + 1] - jb[k]);
             }
-            const float* rb = &jl[yi + 1][xo];
+            const float* rb = &sh.jl[yi + 1][xo];
 #pragma unroll
             for (int k = 0; k <= N; ++k) jb[k] = rb[k];
 #pragma unroll
             for (int k = 0; k < N; ++k) {
                 const float top = hup[k];
                 const float bot = jb[k] + ax[k] * (jb[k + 1] - jb[k]);
-                const float4 t = tile[ly + r][lx + k];
+                const lk_f4 t = lk_lds_read4(&sh.tile[ly + r][lx + k]);
                 const float d = t.x - (top + ay * (bot - top));
                 bx += t.y * d;
                 by += t.z * d;
                 hup[k] = bot;
             }
         }
-    } else if (active) {
-        int xa[N], xb[N];
+    } else {
 #pragma unroll
-        for (int k = 0; k < N; ++k) { xa[k] = lk_clampi(xi[k], 0, w - 1); xb[k] = lk_clampi(xi[k] + 1, 0, w - 1); }
+        for (int k = 0; k < N; ++k) xi[k] -= xmin;
+#pragma unroll 1
+        for (int r = 0; r < N; ++r) {
+            float ay;
+            const int yi = lk_origin(lk_clampi(y + r - RADIUS, 0, h - 1), f.y, h, ay) - ymin;
+            const bool reuse = __all(yi == prev_yi + 1);
+            prev_yi = yi;
+            if (!reuse) {
+                const float* ra = &sh.jl[yi][0];
+#pragma unroll
+                for (int k = 0; k < N; ++k) { const float j0 = ra[xi[k]], j1 = ra[xi[k] + 1]; hup[k] = j0 + ax[k] * (j1 - j0); }
+            }
+            const float* rb = &sh.jl[yi + 1][0];
+#pragma unroll
+            for (int k = 0; k < N; ++k) {
+                const float j0 = rb[xi[k]], j1 = rb[xi[k] + 1];
+                const float top = hup[k];
+                const float bot = j0 + ax[k] * (j1 - j0);
+                const lk_f4 t = lk_lds_read4(&sh.tile[ly + r][lx + k]);
+                const float d = t.x - (top + ay * (bot - top));
+                bx += t.y * d;
+                by += t.z * d;
+                hup[k] = bot;
+            }
+        }
+    }
+    lk_solve_store(G, f, bx, by, (size_t)y * w + x, flow_out);
+}
+
+// second launch: the listed tiles, per-lane gathers from global memory with register reuse (inside a window row j10 of
+// column k is j00 of column k+1 whenever xb[k] == xa[k+1], and the bottom row of one window row is the top row of the
+// next whenever yb == next ya -- both almost always true; the rare exceptions reload)
+template <int RADIUS>
+__global__ __launch_bounds__(256) void lk_step_general_kernel(const float* __restrict__ I, const float* __restrict__ J,
+                                                              const float* __restrict__ gx, const float* __restrict__ gy,
+                                                              const float4* __restrict__ G, int w, int h,
+                                                              const float2* __restrict__ flow_in, float2* __restrict__ flow_out,
+                                                              const uint32_t* __restrict__ fb_count,
+                                                              const uint32_t* __restrict__ fb_tiles) {
+    using T = LkTile<RADIUS>;
+    constexpr int N = T::N;
+    __shared__ float4 tile[T::TH][T::TW];
+    const uint32_t count = *fb_count;
+    for (uint32_t li = blockIdx.x; li < count; li += gridDim.x) {
+        const uint32_t id = fb_tiles[li];
+        const int x0 = (int)(id & 0xFFFFu) * 64, y0 = (int)(id >> 16) * 4;
+        __syncthreads();                                   // the previous tile's readers are done with `tile`
+        lk_stage3<RADIUS>(I, gx, gy, tile, w, h, x0, y0);
+        __syncthreads();
+        const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6, x = x0 + lx, y = y0 + ly;
+        if (x >= w || y >= h) continue;
+        const float2 f = flow_in[(size_t)y * w + x];
+        int xa[N], xb[N];
+        float ax[N];
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            const int xi = lk_origin(lk_clampi(x + k - RADIUS, 0, w - 1), f.x, w, ax[k]);
+            xa[k] = lk_clampi(xi, 0, w - 1); xb[k] = lk_clampi(xi + 1, 0, w - 1);
+        }
+        float bx = 0.0f, by = 0.0f;
         float jt[N + 1], jb[N + 1];          // rows ya / yb of the current frame at columns xa[0..N-1], xb[N-1]
         int prev_yb = -1;
 #pragma unroll 1
         for (int r = 0; r < N; ++r) {
             float ay;
-            const int yi = origin(lk_clampi(y + r - RADIUS, 0, h - 1), f.y, h, ay);
+            const int yi = lk_origin(lk_clampi(y + r - RADIUS, 0, h - 1), f.y, h, ay);
             const int ya = lk_clampi(yi, 0, h - 1), yb = lk_clampi(yi + 1, 0, h - 1);
             const float* ra = J + (size_t)ya * w;
             const float* rb = J + (size_t)yb * w;
@@ -398,16 +500,8 @@ __global__ __launch_bounds__(256, (RADIUS <= 4 ? 4 : 2)) void lk_step_tiled_kern
                 by += t.z * d;
             }
         }
+        lk_solve_store(G, f, bx, by, (size_t)y * w + x, flow_out);
     }
-    if (!active) return;
-    const float4 g = G[(size_t)y * w + x];
-    const float det = g.x * g.z - g.y * g.y;
-    float du = 0.0f, dv = 0.0f;
-    if (det > 0.01f) {
-        du = (g.z * bx - g.y * by) / det;
-        dv = (g.x * by - g.y * bx) / det;
-    }
-    flow_out[(size_t)y * w + x] = make_float2(f.x + du, f.y + dv);
 }
 
 // cv-decoder/src/lib.rs:239-243,262-269: per-pixel records, raster order
@@ -452,6 +546,13 @@ int lk_flow_device(ofps_hip_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_cu
         hipLaunchKernelGGL(lk_pyr_down_kernel, g2, dim3(256), 0, s, Ip + off[l - 1], Jp + off[l - 1], ws[l - 1], hs[l - 1],
                            Ip + off[l], Jp + off[l], ws[l], hs[l]);
     }
+    // per Gauss-Newton step: the tiles the LDS kernel hands to the general kernel (count + tile ids)
+    const dim3 g0 = lk_grid(W, H);
+    const size_t tiles0 = (size_t)g0.x * g0.y, n_steps = (size_t)levels * iters;
+    auto* fb_count = static_cast<uint32_t*>(scratch(ctx, S_WORK3, (n_steps + n_steps * tiles0) * sizeof(uint32_t)));
+    if (!fb_count) return OFPS_HIP_ENOMEM;
+    uint32_t* fb_tiles = fb_count + n_steps;
+    OFPS_HIP_TRY(ctx, hipMemsetAsync(fb_count, 0, n_steps * sizeof(uint32_t), s));
     float2* cur_flow = fa;
     float2* other = fb;
     for (int l = levels - 1; l >= 0; --l) {
@@ -471,12 +572,21 @@ int lk_flow_device(ofps_hip_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_cu
         }
         for (int it = 0; it < iters; ++it) {
             float2* dst = (l == 0 && it == iters - 1) ? d_flow : other;
+            uint32_t* cnt = fb_count + (size_t)l * iters + it;
+            uint32_t* tiles = fb_tiles + ((size_t)l * iters + it) * tiles0;
+            const dim3 g = lk_grid(w, h);
+            const unsigned ntiles = g.x * g.y;
+            const dim3 gg(ntiles < (unsigned)(8 * ctx->num_cus) ? ntiles : (unsigned)(8 * ctx->num_cus));
+#define OFPS_LK_STEP(R)                                                                                                           \
+    hipLaunchKernelGGL(lk_step_lds_kernel<R>, g, dim3(256), 0, s, Ip + off[l], Jp + off[l], gx, gy, G, w, h, cur_flow, dst, cnt, tiles); \
+    hipLaunchKernelGGL(lk_step_general_kernel<R>, gg, dim3(256), 0, s, Ip + off[l], Jp + off[l], gx, gy, G, w, h, cur_flow, dst, cnt, tiles)
             switch (radius) {
-                case 2: hipLaunchKernelGGL(lk_step_tiled_kernel<2>, lk_grid(w, h), dim3(256), 0, s, Ip + off[l], Jp + off[l], gx, gy, G, w, h, cur_flow, dst); break;
-                case 4: hipLaunchKernelGGL(lk_step_tiled_kernel<4>, lk_grid(w, h), dim3(256), 0, s, Ip + off[l], Jp + off[l], gx, gy, G, w, h, cur_flow, dst); break;
-                case 6: hipLaunchKernelGGL(lk_step_tiled_kernel<6>, lk_grid(w, h), dim3(256), 0, s, Ip + off[l], Jp + off[l], gx, gy, G, w, h, cur_flow, dst); break;
-                default: hipLaunchKernelGGL(lk_step_kernel<0>, lk_grid(w, h), dim3(256), 0, s, Ip + off[l], Jp + off[l], gx, gy, G, w, h, radius, cur_flow, dst);
+                case 2: OFPS_LK_STEP(2); break;
+                case 4: OFPS_LK_STEP(4); break;
+                case 6: OFPS_LK_STEP(6); break;
+                default: hipLaunchKernelGGL(lk_step_kernel<0>, g, dim3(256), 0, s, Ip + off[l], Jp + off[l], gx, gy, G, w, h, radius, cur_flow, dst);
             }
+#undef OFPS_LK_STEP
             if (dst != d_flow) { float2* t = cur_flow; cur_flow = other; other = t; }
         }
     }
