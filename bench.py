@@ -265,9 +265,60 @@ def cpu_baseline(frames: np.ndarray, block: int, rng: int, budget_s: float):
             "single_thread": {"value": round(nblk / single_dt / 1e6, 4), "ms_per_pair": round(single_dt * 1e3, 1), "sample": "1 pair"}}
 
 
-def end_to_end_leg(ctx, frames, W, H, B, R):
-    """PCIe-inclusive rate of the Decoder::process_frame shape (SURVEY.md 8d "reported separately"; never `value`)."""
-    return None
+def end_to_end_leg(frames, W, H, B, R, device, n_frames=300):
+    """PCIe-inclusive rate of the Decoder::process_frame shape (SURVEY.md 8d "reported separately"; never `value`): every
+    frame crosses PCIe from a page-locked buffer (2.07 MB at 1080p), the previous frame stays on the device, the vectors
+    come back to page-locked host memory (16 B each).  Forms: the synchronous call; the read-ahead form
+    (ofps_hip_push_frame_async, the previous ticket collected after the next push, so the H2D of frame k+1 overlaps the
+    search of pair k-1, k) with the frames already in page-locked memory (a decoder that writes there directly); and
+    the same with the host filling the next page-locked buffer while the GPU works (a decoder whose output must be
+    copied)."""
+    from ofps_amd.runtime import HipContext
+    ctx = HipContext(device)                   # its own context / stream, like a decoder plugin instance
+    nblk = (W // B) * (H // B)
+    src = [np.ascontiguousarray(f[:, :W]).copy() for f in frames[:4]]
+    pins = [ctx.pinned_frame(H, W) for _ in range(3)]
+    ents = [ctx.pinned_array((nblk, 4)) for _ in range(2)]
+    kw = dict(block=B, search_range=R, detector=False, estimator=False)
+    for k in range(3):
+        np.copyto(pins[k], src[k])
+
+    def run_sync(n):
+        ctx.reset_frames()
+        for k in range(n):
+            ctx.frame_wait(ctx.push_frame_async(pins[k % 3], out_entries=ents[0], **kw))
+
+    def run_read_ahead(n, fill):
+        ctx.reset_frames()
+        prev = None
+        for k in range(n):
+            t = ctx.push_frame_async(pins[k % 3], out_entries=ents[k % 2], **kw)
+            if fill:
+                np.copyto(pins[(k + 1) % 3], src[(k + 1) % 4])        # the decoder produces frame k+1 while the GPU works
+            if prev is not None:
+                ctx.frame_wait(prev)
+            prev = t
+        ctx.frame_wait(prev)
+
+    def timed(fn, *a):
+        fn(20, *a)
+        t0 = time.perf_counter()
+        fn(n_frames, *a)
+        return (time.perf_counter() - t0) / n_frames
+
+    def row(sec, **extra):
+        return dict({"ms_per_frame": round(sec * 1e3, 4), "Mvectors_per_s": round(nblk / sec / 1e6, 2)}, **extra)
+    s = timed(run_sync)
+    a = timed(run_read_ahead, False)
+    c = timed(run_read_ahead, True)
+    out = {"what": "Decoder::process_frame shape: one luma frame H2D from page-locked memory per call, previous frame resident, "
+                   "vectors D2H to page-locked memory",
+           "frames": n_frames, "bytes_h2d_per_frame": W * H, "bytes_d2h_per_frame": 16 * nblk,
+           "sync": row(s, entry_points="ofps_hip_push_frame"),
+           "read_ahead": row(a, entry_points="ofps_hip_push_frame_async + ofps_hip_frame_wait, 2 tickets in flight"),
+           "read_ahead_with_host_copy": row(c, includes="a host memcpy of every frame into the next page-locked buffer while the GPU works")}
+    ctx.close()
+    return out
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -454,7 +505,7 @@ def run_rank(args) -> int:
 
     if rank == 0 and world == 1 and not args.stub:
         if not args.no_end_to_end:
-            out["end_to_end"] = end_to_end_leg(ctx, frames, W, H, B, R)
+            out["end_to_end"] = end_to_end_leg(frames, W, H, B, R, local_rank)
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(np.ascontiguousarray(frames[:, :, :W]) if stride != W else frames, B, R, args.cpu_seconds)
     if rank == 0:

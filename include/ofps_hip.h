@@ -176,7 +176,7 @@ int ofps_hip_almeida_dev(ofps_hip_ctx* ctx, const void* d_entries, size_t n_per_
 /* ---- fused per-frame path (live streams): decoder -> detector + estimator, vectors stay on the device ----
  * One call per arriving luma frame = one iteration of the reference's worker loops
  * (ofps-suite/src/app/detection.rs:111-148, tracking/worker.rs:328-361).  The context keeps the previous
- * frame on the device; the first frame after ofps_hip_init / ofps_hip_reset_frames / a geometry change
+ * frames on the device (a ring of three slots); the first frame after ofps_hip_init / ofps_hip_reset_frames / a geometry change
  * yields have_vectors = 0 (Decoder::process_frame -> Ok(false)). */
 typedef struct {
     int block, range;                                   /* hip_sad */
@@ -197,6 +197,17 @@ int ofps_hip_stage_frame(ofps_hip_ctx* ctx, const uint8_t* luma, int W, int H, i
 int ofps_hip_push_frame(ofps_hip_ctx* ctx, const uint8_t* luma, int W, int H, int stride,
                         const ofps_hip_frame_params* params, ofps_hip_frame_result* out,
                         float* out_entries /* 4*nblk or NULL */, float* out_field /* 2*dim*dim or NULL */);
+/* The same iteration split in two for read-ahead callers (the reference decodes on its own thread into a double
+ * buffer, ofps-suite/src/app/tracking/worker.rs:165-226): push_frame_async returns once the frame's H2D copy (on a
+ * copy stream), its search and its tail are enqueued; ofps_hip_frame_wait(ticket) blocks until that frame's results
+ * are on the host and fills `out`.  Up to 2 tickets may be in flight, so the upload of frame k+1 overlaps the search of
+ * pair (k-1, k); tickets must be collected in order before a third push.  `luma`, `out_entries` and `out_field` must
+ * stay valid until the wait returns; use ofps_hip_host_alloc'ed (page-locked) buffers -- pageable memory turns the
+ * copies synchronous.  ofps_hip_push_frame == push_frame_async + frame_wait, bit for bit. */
+int ofps_hip_push_frame_async(ofps_hip_ctx* ctx, const uint8_t* luma, int W, int H, int stride,
+                              const ofps_hip_frame_params* params, float* out_entries /* 4*nblk or NULL */,
+                              float* out_field /* 2*dim*dim or NULL */, int* ticket);
+int ofps_hip_frame_wait(ofps_hip_ctx* ctx, int ticket, ofps_hip_frame_result* out);
 
 #ifdef __cplusplus
 }

@@ -81,6 +81,10 @@ PROTOTYPES["ofps_hip_host_free"] = (C.c_int, [_ctx, C.c_void_p])
 PROTOTYPES["ofps_hip_push_frame"] = (C.c_int, [_ctx, _u8p, C.c_int, C.c_int, C.c_int, C.POINTER(FrameParams),
                                                C.POINTER(FrameResult), _f32p, _f32p])
 
+PROTOTYPES["ofps_hip_push_frame_async"] = (C.c_int, [_ctx, _u8p, C.c_int, C.c_int, C.c_int, C.POINTER(FrameParams), _f32p, _f32p,
+                                                     C.POINTER(C.c_int)])
+PROTOTYPES["ofps_hip_frame_wait"] = (C.c_int, [_ctx, C.c_int, C.POINTER(FrameResult)])
+
 _lib = None
 
 

@@ -20,9 +20,24 @@ struct ofps_hip_ctx {
     int sad_mode = OFPS_HIP_SAD_EXHAUSTIVE;
     char err[512] = {0};
 
-    // per-frame pipeline state (pipeline.hip): two device frame slots, which one holds the newest frame
-    int pipe_w = 0, pipe_h = 0, pipe_stride = 0, pipe_newest = -1;
-    void* pipe_pinned = nullptr;         // small pinned host block for the result read-back
+    // per-frame pipeline state (pipeline.hip): a ring of three device frame slots (the new frame is uploaded on the copy
+    // stream while the previous pair is still being searched), two tickets in flight
+    static constexpr int kPipeSlots = 3, kPipeTickets = 2;
+    int pipe_w = 0, pipe_h = 0, pipe_stride = 0;
+    long pipe_frames = 0;                // frames pushed since the last reset; frame k lives in slot k % 3
+    hipStream_t pipe_copy_stream = nullptr;
+    hipEvent_t pipe_uploaded[kPipeSlots] = {};   // H2D of the frame in this slot finished (recorded on the copy stream)
+    hipEvent_t pipe_slot_read[kPipeSlots] = {};  // last search that reads this slot finished (recorded on the compute stream)
+    bool pipe_slot_read_valid[kPipeSlots] = {};
+    bool pipe_uploaded_on_compute[kPipeSlots] = {};   // the upload was enqueued on the compute stream (ordered by it)
+    struct PipeTicket {
+        bool pending = false;            // pushed, not yet collected by ofps_hip_frame_wait
+        hipEvent_t done = nullptr;       // everything of this ticket, read-backs included
+        void* pinned = nullptr;          // page-locked PipeOut block for the result read-back
+        int have_vectors = 0, run_detector = 0, run_estimator = 0;
+        size_t n_vectors = 0;
+    } pipe_ticket[kPipeTickets];
+    long pipe_next_ticket = 0;
 
     // cluster Almeida solver (almeida.hip): granule exchange buffer state.  Tags are unique per call (tag base advances
     // by 32 per launch), so the buffer is zeroed only when (re)allocated or when the 32-bit tag space wraps.

@@ -93,7 +93,15 @@ void ofps_hip_destroy(ofps_hip_ctx* ctx) {
     (void)hipDeviceSynchronize();
     for (auto& s : ctx->scratch)
         if (s.p) (void)hipFree(s.p);
-    if (ctx->pipe_pinned) (void)hipHostFree(ctx->pipe_pinned);
+    for (auto& t : ctx->pipe_ticket) {
+        if (t.pinned) (void)hipHostFree(t.pinned);
+        if (t.done) (void)hipEventDestroy(t.done);
+    }
+    for (int k = 0; k < ofps_hip_ctx::kPipeSlots; ++k) {
+        if (ctx->pipe_uploaded[k]) (void)hipEventDestroy(ctx->pipe_uploaded[k]);
+        if (ctx->pipe_slot_read[k]) (void)hipEventDestroy(ctx->pipe_slot_read[k]);
+    }
+    if (ctx->pipe_copy_stream) (void)hipStreamDestroy(ctx->pipe_copy_stream);
     if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
     if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -102,16 +110,26 @@ void ofps_hip_destroy(ofps_hip_ctx* ctx) {
 
 const char* ofps_hip_last_error(const ofps_hip_ctx* ctx) { return ctx ? ctx->err : g_init_err; }
 
+// Work enqueued on the old stream (and the frame uploads of the per-frame pipeline that are ordered by it) is finished
+// before the context moves to another stream: nothing in the library then depends on cross-stream ordering it did not
+// set up itself.
+static int switch_stream(ofps_hip_ctx* ctx, hipStream_t next) {
+    if (next == ctx->stream) return OFPS_HIP_OK;
+    OFPS_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    OFPS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->pipe_copy_stream) OFPS_HIP_TRY(ctx, hipStreamSynchronize(ctx->pipe_copy_stream));
+    ctx->stream = next;
+    return OFPS_HIP_OK;
+}
+
 int ofps_hip_set_stream(ofps_hip_ctx* ctx, void* hip_stream) {
     if (!ctx) return OFPS_HIP_EINVAL;
-    ctx->stream = reinterpret_cast<hipStream_t>(hip_stream);
-    return OFPS_HIP_OK;
+    return switch_stream(ctx, reinterpret_cast<hipStream_t>(hip_stream));
 }
 
 int ofps_hip_use_own_stream(ofps_hip_ctx* ctx) {
     if (!ctx) return OFPS_HIP_EINVAL;
-    ctx->stream = ctx->own_stream;
-    return OFPS_HIP_OK;
+    return switch_stream(ctx, ctx->own_stream);
 }
 
 void* ofps_hip_get_stream(ofps_hip_ctx* ctx) { return ctx ? reinterpret_cast<void*>(ctx->stream) : nullptr; }

@@ -1,11 +1,15 @@
 // pipeline.hip -- the fused per-frame path (BASELINE configs[4]: live stream, SAD decoder + block-motion
-// detector + Almeida estimator per frame).  One call per arriving frame reproduces one iteration of the
+// detector + Almeida estimator per frame).  One ticket per arriving frame reproduces one iteration of the
 // reference's worker loops -- decoder.process_frame -> detector.detect_motion
 // (ofps-suite/src/app/detection.rs:111-148) and -> estimator.estimate
 // (ofps-suite/src/app/tracking/worker.rs:328-361) -- without the motion vectors leaving the device:
-//   H2D of the new luma frame into one of two device slots (the other holds the previous frame)
-//   -> SAD search between the slots -> detect + estimate on the device-resident vectors
+//   H2D of the new luma frame into the free slot of a three-slot device ring, on a COPY stream
+//   -> (compute stream, after the copy's event) SAD search between the two newest slots
+//   -> detect + estimate on the device-resident vectors
 //   -> one small D2H (result record, quaternion; vectors / field only when the caller asks for them).
+// ofps_hip_push_frame_async returns once that is enqueued; ofps_hip_frame_wait collects a ticket.  With two tickets in
+// flight the upload of frame k+1 overlaps the search of pair (k-1, k) -- what the reference's read-ahead decoder thread
+// does on the host (ofps-suite/src/app/tracking/worker.rs:165-226).  ofps_hip_push_frame = push_async + wait.
 #include "common.hpp"
 
 namespace {
@@ -13,31 +17,69 @@ struct PipeOut {                 // layout of the pinned read-back block
     int result[4];               // has_motion, area, dim, 0
     float quat[4];
 };
+
+int pipe_setup(ofps_hip_ctx* ctx) {
+    if (ctx->pipe_copy_stream) return OFPS_HIP_OK;
+    OFPS_HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->pipe_copy_stream, hipStreamNonBlocking));
+    for (int k = 0; k < ofps_hip_ctx::kPipeSlots; ++k) {
+        OFPS_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->pipe_uploaded[k], hipEventDisableTiming));
+        OFPS_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->pipe_slot_read[k], hipEventDisableTiming));
+    }
+    for (auto& t : ctx->pipe_ticket) {
+        OFPS_HIP_TRY(ctx, hipEventCreateWithFlags(&t.done, hipEventDisableTiming));
+        OFPS_HIP_TRY(ctx, hipHostMalloc(&t.pinned, sizeof(PipeOut), hipHostMallocDefault));
+    }
+    return OFPS_HIP_OK;
+}
+
+// Waits for every ticket still in flight and forgets the stream position (geometry change / reset).
+int pipe_drain(ofps_hip_ctx* ctx) {
+    for (auto& t : ctx->pipe_ticket) {
+        if (t.pending && t.done) OFPS_HIP_TRY(ctx, hipEventSynchronize(t.done));
+        t.pending = false;
+    }
+    if (ctx->pipe_copy_stream) OFPS_HIP_TRY(ctx, hipStreamSynchronize(ctx->pipe_copy_stream));
+    ctx->pipe_frames = 0;
+    for (bool& v : ctx->pipe_slot_read_valid) v = false;
+    return OFPS_HIP_OK;
+}
+
+// Enqueues the H2D of one luma frame as frame number ctx->pipe_frames (slot = number % 3).  With another ticket in
+// flight the copy goes to the copy stream, so that it overlaps that ticket's search; a lone frame is copied on the
+// compute stream itself (no cross-stream events on the latency path of the synchronous call: 0.10 vs 0.17 ms per
+// 1080p frame).
+int pipe_upload(ofps_hip_ctx* ctx, const uint8_t* luma, int W, int H, int stride, bool overlap, uint8_t** slots_out,
+                size_t* pitch_out, int* dstride_out) {
+    int rc = pipe_setup(ctx);
+    if (rc != OFPS_HIP_OK) return rc;
+    const int dstride = (W + 63) & ~63;
+    const size_t pitch = (size_t)dstride * H;
+    if (W != ctx->pipe_w || H != ctx->pipe_h) {            // geometry change restarts the stream (decoder.rs:66-72)
+        rc = pipe_drain(ctx);
+        if (rc != OFPS_HIP_OK) return rc;
+        ctx->pipe_w = W; ctx->pipe_h = H; ctx->pipe_stride = dstride;
+    }
+    auto* slots = static_cast<uint8_t*>(ofps::scratch(ctx, ofps::S_PIPE_FRAMES, ofps_hip_ctx::kPipeSlots * pitch));
+    if (!slots) return OFPS_HIP_ENOMEM;
+    const int slot = (int)(ctx->pipe_frames % ofps_hip_ctx::kPipeSlots);
+    hipStream_t up = overlap ? ctx->pipe_copy_stream : ctx->stream;
+    // the slot's previous tenant (frame number - 3) may still be read by the search of ticket number - 2
+    if (overlap && ctx->pipe_slot_read_valid[slot]) OFPS_HIP_TRY(ctx, hipStreamWaitEvent(up, ctx->pipe_slot_read[slot], 0));
+    OFPS_HIP_TRY(ctx, ofps::upload_rows(slots + (size_t)slot * pitch, dstride, luma, stride, W, H, up));
+    OFPS_HIP_TRY(ctx, hipEventRecord(ctx->pipe_uploaded[slot], up));
+    ctx->pipe_uploaded_on_compute[slot] = !overlap;
+    ctx->pipe_frames += 1;
+    *slots_out = slots; *pitch_out = pitch; *dstride_out = dstride;
+    return OFPS_HIP_OK;
+}
 }  // namespace
 
 extern "C" {
 
 int ofps_hip_reset_frames(ofps_hip_ctx* ctx) {
     if (!ctx) return OFPS_HIP_EINVAL;
-    ctx->pipe_newest = -1;
-    return OFPS_HIP_OK;
-}
-
-// H2D of one luma frame into the device slot that does not hold the newest frame; slots/pitch/prev/cur are outputs
-static int upload_frame(ofps_hip_ctx* ctx, const uint8_t* luma, int W, int H, int stride, uint8_t** slots_out, size_t* pitch_out,
-                        int* dstride_out, int* prev_slot_out, int* cur_slot_out) {
-    const int dstride = (W + 63) & ~63;
-    const size_t pitch = (size_t)dstride * H;
-    if (W != ctx->pipe_w || H != ctx->pipe_h) {            // geometry change restarts the stream (decoder.rs:66-72)
-        ctx->pipe_w = W; ctx->pipe_h = H; ctx->pipe_stride = dstride; ctx->pipe_newest = -1;
-    }
-    auto* slots = static_cast<uint8_t*>(ofps::scratch(ctx, ofps::S_PIPE_FRAMES, 2 * pitch));
-    if (!slots) return OFPS_HIP_ENOMEM;
-    const int prev_slot = ctx->pipe_newest, cur_slot = ctx->pipe_newest < 0 ? 0 : 1 - ctx->pipe_newest;
-    OFPS_HIP_TRY(ctx, ofps::upload_rows(slots + (size_t)cur_slot * pitch, dstride, luma, stride, W, H, ctx->stream));
-    ctx->pipe_newest = cur_slot;
-    *slots_out = slots; *pitch_out = pitch; *dstride_out = dstride; *prev_slot_out = prev_slot; *cur_slot_out = cur_slot;
-    return OFPS_HIP_OK;
+    OFPS_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return pipe_drain(ctx);
 }
 
 int ofps_hip_stage_frame(ofps_hip_ctx* ctx, const uint8_t* luma, int W, int H, int stride) {
@@ -45,50 +87,68 @@ int ofps_hip_stage_frame(ofps_hip_ctx* ctx, const uint8_t* luma, int W, int H, i
     OFPS_REQUIRE(ctx, luma, "stage_frame: null pointer");
     OFPS_REQUIRE(ctx, W > 0 && H > 0 && stride >= W, "stage_frame: bad geometry W=%d H=%d stride=%d", W, H, stride);
     OFPS_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    uint8_t* slots; size_t pitch; int dstride, prev_slot, cur_slot;
-    int rc = upload_frame(ctx, luma, W, H, stride, &slots, &pitch, &dstride, &prev_slot, &cur_slot);
+    uint8_t* slots; size_t pitch; int dstride;
+    int rc = pipe_upload(ctx, luma, W, H, stride, /*overlap=*/false, &slots, &pitch, &dstride);
     if (rc != OFPS_HIP_OK) return rc;
-    OFPS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // the caller may reuse `luma` right away
+    OFPS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));             // the caller may reuse `luma` right away
     return OFPS_HIP_OK;
 }
 
-int ofps_hip_push_frame(ofps_hip_ctx* ctx, const uint8_t* luma, int W, int H, int stride,
-                        const ofps_hip_frame_params* prm, ofps_hip_frame_result* out, float* out_entries,
-                        float* out_field) {
+int ofps_hip_push_frame_async(ofps_hip_ctx* ctx, const uint8_t* luma, int W, int H, int stride,
+                              const ofps_hip_frame_params* prm, float* out_entries, float* out_field, int* ticket) {
     if (!ctx) return OFPS_HIP_EINVAL;
-    OFPS_REQUIRE(ctx, luma && prm && out, "push_frame: null pointer");
-    OFPS_REQUIRE(ctx, W > 0 && H > 0 && stride >= W, "push_frame: bad geometry W=%d H=%d stride=%d", W, H, stride);
+    OFPS_REQUIRE(ctx, luma && prm && ticket, "push_frame_async: null pointer");
+    OFPS_REQUIRE(ctx, W > 0 && H > 0 && stride >= W, "push_frame_async: bad geometry W=%d H=%d stride=%d", W, H, stride);
     OFPS_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc = pipe_setup(ctx);
+    if (rc != OFPS_HIP_OK) return rc;
+    const long tno = ctx->pipe_next_ticket;
+    auto& t = ctx->pipe_ticket[tno % ofps_hip_ctx::kPipeTickets];
+    OFPS_REQUIRE(ctx, !t.pending, "push_frame_async: ticket %ld has not been collected (at most %d frames in flight)",
+                 tno - ofps_hip_ctx::kPipeTickets, ofps_hip_ctx::kPipeTickets);
     hipStream_t s = ctx->stream;
-    if (!ctx->pipe_pinned) OFPS_HIP_TRY(ctx, hipHostMalloc(&ctx->pipe_pinned, sizeof(PipeOut), hipHostMallocDefault));
-    uint8_t* slots; size_t pitch; int dstride, prev_slot, cur_slot;
-    {
-        int rc = upload_frame(ctx, luma, W, H, stride, &slots, &pitch, &dstride, &prev_slot, &cur_slot);
-        if (rc != OFPS_HIP_OK) return rc;
-    }
-
-    memset(out, 0, sizeof(*out));
-    out->quat[0] = 1.0f;
+    uint8_t* slots; size_t pitch; int dstride;
+    const bool overlap = ctx->pipe_ticket[(tno + 1) % ofps_hip_ctx::kPipeTickets].pending;      // the other ticket is in flight
+    rc = pipe_upload(ctx, luma, W, H, stride, overlap, &slots, &pitch, &dstride);
+    if (rc != OFPS_HIP_OK) return rc;
+    const long frame_no = ctx->pipe_frames - 1;                       // the frame just enqueued
+    const int cur_slot = (int)(frame_no % ofps_hip_ctx::kPipeSlots);
+    t.have_vectors = 0; t.n_vectors = 0; t.run_detector = prm->run_detector; t.run_estimator = prm->run_estimator;
     const size_t nblk = ofps_hip_sad_block_count(W, H, prm->block);
-    if (prev_slot < 0) {                                    // first frame of a stream: Ok(false), no vectors yet
-        OFPS_HIP_TRY(ctx, hipStreamSynchronize(s));
+    if (frame_no == 0) {                                             // first frame of a stream: Ok(false), no vectors yet
+        if (!ctx->pipe_uploaded_on_compute[cur_slot]) OFPS_HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->pipe_uploaded[cur_slot], 0));
+        OFPS_HIP_TRY(ctx, hipEventRecord(t.done, s));
+        t.pending = true;
+        *ticket = (int)(tno & 0x7FFFFFFF);
+        ctx->pipe_next_ticket = tno + 1;
         return OFPS_HIP_OK;
     }
-    auto* d_ent = static_cast<float4*>(ofps::scratch(ctx, ofps::S_PIPE_ENTRIES, nblk * sizeof(float4)));
-    if (!d_ent) return OFPS_HIP_ENOMEM;
-    int rc = ofps::sad_pairs_device(ctx, slots + (size_t)prev_slot * pitch, 0, slots + (size_t)cur_slot * pitch, 0, 1, W, H, dstride,
-                                    prm->block, prm->range, d_ent, nullptr);
+    const int prev_slot = (int)((frame_no - 1) % ofps_hip_ctx::kPipeSlots);
+    const int tix = (int)(tno % ofps_hip_ctx::kPipeTickets);
+    auto* d_ent_all = static_cast<float4*>(ofps::scratch(ctx, ofps::S_PIPE_ENTRIES, ofps_hip_ctx::kPipeTickets * nblk * sizeof(float4)));
+    constexpr size_t kOutBytes = 4096 + (size_t)160 * 160 * sizeof(float2);
+    auto* d_out_all = static_cast<char*>(ofps::scratch(ctx, ofps::S_PIPE_OUT, ofps_hip_ctx::kPipeTickets * kOutBytes));
+    if (!d_ent_all || !d_out_all) return OFPS_HIP_ENOMEM;
+    float4* d_ent = d_ent_all + (size_t)tix * nblk;
+    char* d_out = d_out_all + (size_t)tix * kOutBytes;
+    // the search needs both frames on the device: the previous frame's upload was waited for by the previous ticket
+    // (or by the stage_frame that made it), this frame's by the event
+    // (uploads made on the compute stream itself are ordered by the stream)
+    if (!ctx->pipe_uploaded_on_compute[prev_slot]) OFPS_HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->pipe_uploaded[prev_slot], 0));
+    if (!ctx->pipe_uploaded_on_compute[cur_slot]) OFPS_HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->pipe_uploaded[cur_slot], 0));
+    rc = ofps::sad_pairs_device(ctx, slots + (size_t)prev_slot * pitch, 0, slots + (size_t)cur_slot * pitch, 0, 1, W, H, dstride,
+                                prm->block, prm->range, d_ent, nullptr);
     if (rc != OFPS_HIP_OK) return rc;
-    out->have_vectors = 1;
-    out->n_vectors = nblk;
+    // the older slot may be overwritten once this search is through
+    OFPS_HIP_TRY(ctx, hipEventRecord(ctx->pipe_slot_read[prev_slot], s));
+    ctx->pipe_slot_read_valid[prev_slot] = true;
+    t.have_vectors = 1;
+    t.n_vectors = nblk;
 
     int dim = 0;
-    float2* d_field = nullptr;
-    auto* d_out = static_cast<char*>(ofps::scratch(ctx, ofps::S_PIPE_OUT, 4096 + (size_t)160 * 160 * sizeof(float2)));
-    if (!d_out) return OFPS_HIP_ENOMEM;
     int* d_res = reinterpret_cast<int*>(d_out);
     float4* d_quat = reinterpret_cast<float4*>(d_out + 16);
-    d_field = reinterpret_cast<float2*>(d_out + 4096);
+    float2* d_field = reinterpret_cast<float2*>(d_out + 4096);
     if (prm->run_detector) {
         rc = ofps::detect_device(ctx, d_ent, nblk, 1, prm->min_size, prm->subdivide, prm->target_motion, d_res, d_field, &dim);
         if (rc != OFPS_HIP_OK) return rc;
@@ -98,21 +158,57 @@ int ofps_hip_push_frame(ofps_hip_ctx* ctx, const uint8_t* luma, int W, int H, in
                                   prm->inlier_deg, prm->num_samples, prm->seed, d_quat);
         if (rc != OFPS_HIP_OK) return rc;
     }
-    auto* host = static_cast<PipeOut*>(ctx->pipe_pinned);
     if (prm->run_detector || prm->run_estimator)
-        OFPS_HIP_TRY(ctx, hipMemcpyAsync(host, d_out, sizeof(PipeOut), hipMemcpyDeviceToHost, s));
+        OFPS_HIP_TRY(ctx, hipMemcpyAsync(t.pinned, d_out, sizeof(PipeOut), hipMemcpyDeviceToHost, s));
     if (out_entries && nblk)
         OFPS_HIP_TRY(ctx, hipMemcpyAsync(out_entries, d_ent, nblk * sizeof(float4), hipMemcpyDeviceToHost, s));
     if (out_field && prm->run_detector)
         OFPS_HIP_TRY(ctx, hipMemcpyAsync(out_field, d_field, (size_t)dim * dim * sizeof(float2), hipMemcpyDeviceToHost, s));
-    OFPS_HIP_TRY(ctx, hipStreamSynchronize(s));
-    if (prm->run_detector) {
-        out->has_motion = host->result[0];
-        out->area = (size_t)host->result[1];
-        out->dim = host->result[2];
-    }
-    if (prm->run_estimator) memcpy(out->quat, host->quat, sizeof(out->quat));
+    OFPS_HIP_TRY(ctx, hipEventRecord(t.done, s));
+    t.pending = true;
+    *ticket = (int)(tno & 0x7FFFFFFF);
+    ctx->pipe_next_ticket = tno + 1;
     return OFPS_HIP_OK;
+}
+
+int ofps_hip_frame_wait(ofps_hip_ctx* ctx, int ticket, ofps_hip_frame_result* out) {
+    if (!ctx) return OFPS_HIP_EINVAL;
+    OFPS_REQUIRE(ctx, out, "frame_wait: null pointer");
+    OFPS_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const long newest = ctx->pipe_next_ticket - 1;
+    long tno = -1;
+    for (long k = newest; k >= 0 && k > newest - ofps_hip_ctx::kPipeTickets; --k)
+        if ((int)(k & 0x7FFFFFFF) == ticket) { tno = k; break; }
+    OFPS_REQUIRE(ctx, tno >= 0, "frame_wait: ticket %d is not in flight", ticket);
+    auto& t = ctx->pipe_ticket[tno % ofps_hip_ctx::kPipeTickets];
+    OFPS_REQUIRE(ctx, t.pending, "frame_wait: ticket %d was already collected", ticket);
+    OFPS_HIP_TRY(ctx, hipEventSynchronize(t.done));
+    t.pending = false;
+    memset(out, 0, sizeof(*out));
+    out->quat[0] = 1.0f;
+    out->have_vectors = t.have_vectors;
+    out->n_vectors = t.n_vectors;
+    if (t.have_vectors) {
+        const auto* host = static_cast<const PipeOut*>(t.pinned);
+        if (t.run_detector) {
+            out->has_motion = host->result[0];
+            out->area = (size_t)host->result[1];
+            out->dim = host->result[2];
+        }
+        if (t.run_estimator) memcpy(out->quat, host->quat, sizeof(out->quat));
+    }
+    return OFPS_HIP_OK;
+}
+
+int ofps_hip_push_frame(ofps_hip_ctx* ctx, const uint8_t* luma, int W, int H, int stride,
+                        const ofps_hip_frame_params* prm, ofps_hip_frame_result* out, float* out_entries,
+                        float* out_field) {
+    if (!ctx) return OFPS_HIP_EINVAL;
+    OFPS_REQUIRE(ctx, luma && prm && out, "push_frame: null pointer");
+    int ticket = 0;
+    int rc = ofps_hip_push_frame_async(ctx, luma, W, H, stride, prm, out_entries, out_field, &ticket);
+    if (rc != OFPS_HIP_OK) return rc;
+    return ofps_hip_frame_wait(ctx, ticket, out);
 }
 
 }  // extern "C"

@@ -103,6 +103,8 @@ class HipSadDecoder(Properties):
             if k < skip_frames - 1:
                 continue                                   # consumed and dropped
             if self._cur is None or self._cur.shape != frame.shape:
+                if self._cur is not None:
+                    self.ctx.free_pinned(self._cur)        # a geometry change must not leak the old page-locked buffer
                 self._cur = self.ctx.pinned_frame(*frame.shape)
             np.copyto(self._cur, frame)
             if k == skip_frames - 1:

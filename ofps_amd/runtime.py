@@ -245,6 +245,48 @@ class HipContext:
         self._pinned.append(p.value)
         return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(height, width))
 
+    def free_pinned(self, buf: np.ndarray):
+        """Releases a buffer returned by pinned_frame / pinned_array before the context is closed."""
+        p = buf.ctypes.data
+        if p in self._pinned:
+            self._pinned.remove(p)
+            self._check(self._lib.ofps_hip_host_free(self._h, C.c_void_p(p)))
+
+    def pinned_array(self, shape, dtype=np.float32) -> np.ndarray:
+        """Page-locked host array (results of push_frame_async land in it by DMA)."""
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        p = C.c_void_p(0)
+        self._check(self._lib.ofps_hip_host_alloc(self._h, max(n, 16), C.byref(p)))
+        self._pinned.append(p.value)
+        return np.frombuffer((C.c_uint8 * max(n, 16)).from_address(p.value), dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+    def _frame_params(self, block, search_range, detector, min_size, subdivide, target_motion, estimator, aspect, fov_y_deg,
+                      use_ransac, num_iters, inlier_deg, num_samples, seed):
+        return _lib.FrameParams(block, search_range, int(detector), min_size, subdivide, target_motion, int(estimator),
+                                aspect, fov_y_deg, int(use_ransac), num_iters, inlier_deg, num_samples, seed)
+
+    def push_frame_async(self, luma: np.ndarray, block=16, search_range=16, detector=True, min_size=0.05, subdivide=3,
+                         target_motion=0.003, estimator=True, aspect=16 / 9, fov_y_deg=39.6 * 9 / 16, use_ransac=False,
+                         num_iters=200, inlier_deg=0.05, num_samples=1000, seed=0, out_entries: np.ndarray | None = None,
+                         out_field: np.ndarray | None = None) -> int:
+        """Enqueues one frame (ofps_hip_push_frame_async) -> ticket.  `luma`, `out_entries` and `out_field` must stay alive
+        and untouched until frame_wait(ticket) returns; at most two tickets in flight."""
+        assert luma.dtype == np.uint8 and luma.ndim == 2 and luma.flags["C_CONTIGUOUS"]
+        H, W = luma.shape
+        prm = self._frame_params(block, search_range, detector, min_size, subdivide, target_motion, estimator, aspect, fov_y_deg,
+                                 use_ransac, num_iters, inlier_deg, num_samples, seed)
+        t = C.c_int(0)
+        self._check(self._lib.ofps_hip_push_frame_async(self._h, luma.ctypes.data_as(C.POINTER(C.c_uint8)), W, H, W, C.byref(prm),
+                                                        _fp(out_entries) if out_entries is not None else None,
+                                                        _fp(out_field) if out_field is not None else None, C.byref(t)))
+        return int(t.value)
+
+    def frame_wait(self, ticket: int) -> dict:
+        res = _lib.FrameResult()
+        self._check(self._lib.ofps_hip_frame_wait(self._h, ticket, C.byref(res)))
+        return {"have_vectors": bool(res.have_vectors), "n_vectors": int(res.n_vectors),
+                "motion": (int(res.area), int(res.dim)) if res.has_motion else None, "quat": np.array(list(res.quat), np.float32)}
+
     def push_frame(self, luma: np.ndarray, block=16, search_range=16, detector=True, min_size=0.05, subdivide=3,
                    target_motion=0.003, estimator=True, aspect=16 / 9, fov_y_deg=39.6 * 9 / 16, use_ransac=False,
                    num_iters=200, inlier_deg=0.05, num_samples=1000, seed=0, want_entries=False, want_field=False):

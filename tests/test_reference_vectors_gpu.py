@@ -156,3 +156,63 @@ def test_hip_almeida_cluster_timeout_falls_back_to_the_stepped_solver(ctx, monke
     np.testing.assert_allclose(q_fb, q_ok, atol=2e-6, rtol=0)
     q_again, _ = ctx.almeida(e, 16 / 9, 22.275, use_ransac=False)          # and the cluster path works again afterwards
     np.testing.assert_allclose(q_again, q_ok, atol=0, rtol=0)
+
+
+# ---- read-ahead form of the per-frame path: same bits as the synchronous call, two tickets in flight -------------------
+def test_hip_push_frame_async_matches_sync_and_oracle(ctx):
+    W, H, F = 1920, 1080, 6
+    fr = synth.luma_sequence(F, W, H, max_step=16, seed=synth.SEED0 + 80)
+    cam = oracle.camera(16 / 9, 22.275)
+    kw = dict(block=16, search_range=16, aspect=16 / 9, fov_y_deg=22.275)
+    # synchronous reference run
+    ctx.reset_frames()
+    sync = [ctx.push_frame(fr[k], want_entries=True, want_field=True, **kw) for k in range(F)]
+    # asynchronous: frames staged in three page-locked buffers, results into page-locked arrays, tickets collected one late
+    ctx.reset_frames()
+    pins = [ctx.pinned_frame(H, W) for _ in range(3)]
+    ents = [ctx.pinned_array((8040, 4)) for _ in range(2)]
+    flds = [ctx.pinned_array((14, 14, 2)) for _ in range(2)]
+    got, pending = [], None
+    for k in range(F):
+        np.copyto(pins[k % 3], fr[k])
+        t = ctx.push_frame_async(pins[k % 3], out_entries=ents[k % 2], out_field=flds[k % 2], **kw)
+        if pending is not None:
+            r = ctx.frame_wait(pending[0]); r["entries"] = ents[pending[1] % 2].copy(); r["field"] = flds[pending[1] % 2].copy(); got.append(r)
+        pending = (t, k)
+    r = ctx.frame_wait(pending[0]); r["entries"] = ents[pending[1] % 2].copy(); r["field"] = flds[pending[1] % 2].copy(); got.append(r)
+    with pytest.raises(Exception):
+        ctx.frame_wait(pending[0])                                   # a ticket can be collected once
+    assert not got[0]["have_vectors"] and not sync[0]["have_vectors"]
+    for k in range(1, F):
+        a, s = got[k], sync[k]
+        assert a["have_vectors"] and a["n_vectors"] == 8040
+        np.testing.assert_array_equal(a["entries"].view(np.uint32), s["entries"].view(np.uint32))
+        np.testing.assert_array_equal(a["quat"].view(np.uint32), s["quat"].view(np.uint32))
+        assert (a["motion"] is None) == (s["motion"] is None)
+        if s["motion"] is not None:
+            assert a["motion"][0] == s["motion"][0]
+            np.testing.assert_array_equal(a["field"].view(np.uint32), s["motion"][1].view(np.uint32))
+        ent_o, _ = oracle.sad_flow(fr[k - 1], fr[k], 16, 16, threads=8)
+        np.testing.assert_array_equal(a["entries"].view(np.uint32), ent_o.view(np.uint32))
+        np.testing.assert_allclose(a["quat"], oracle.solve_ypr_given(ent_o, cam), atol=2e-6, rtol=0)
+    for b in pins + ents + flds:
+        ctx.free_pinned(b)
+
+
+def test_hip_push_frame_async_refuses_a_third_frame_in_flight(ctx):
+    fr = synth.luma_sequence(3, 320, 192, max_step=8)
+    ctx.reset_frames()
+    pins = [ctx.pinned_frame(192, 320) for _ in range(3)]
+    for k in range(3):
+        np.copyto(pins[k], fr[k])
+    t0 = ctx.push_frame_async(pins[0], search_range=8)
+    t1 = ctx.push_frame_async(pins[1], search_range=8)
+    with pytest.raises(Exception, match="collected"):
+        ctx.push_frame_async(pins[2], search_range=8)
+    assert not ctx.frame_wait(t0)["have_vectors"]
+    assert ctx.frame_wait(t1)["have_vectors"]
+    t2 = ctx.push_frame_async(pins[2], search_range=8)
+    assert ctx.frame_wait(t2)["n_vectors"] == 20 * 12
+    ctx.reset_frames()
+    for b in pins:
+        ctx.free_pinned(b)
