@@ -81,8 +81,9 @@ int ofps_hip_timer_stop(ofps_hip_ctx* ctx, float* elapsed_ms);   /* synchronises
  * Blocks on a block x block lattice from (0,0), full blocks only; candidates (dx,dy) in
  * [-range,range]^2 whose block lies inside the frame; winner = min of
  * (SAD, dx*dx+dy*dy, dy+range, dx+range); entry = (pos = (centre+d)/(W,H), motion = -d/(W,H)).
- * Supported: block in {8,16} with range in {4..64, multiple of 4} run on the packed-SAD kernel;
- * any other block<=64, range<=64 runs on the generic kernel.  stride % 4 == 0. */
+ * Supported: block in {8,16} with range in {8,12,16,20,24,28,32} and 16-byte aligned rows run on the packed-SAD strip
+ * kernel (the same geometries with rows only 4-byte aligned: the per-block packed kernel); any other block <= 64,
+ * range <= 64 runs on the generic kernel (correctness path, ~30x slower).  stride % 4 == 0. */
 size_t ofps_hip_sad_block_count(int W, int H, int block);
 /* Search strategy of ofps_hip_sad_flow*: both return the spec's winner bit for bit.
  * EXHAUSTIVE evaluates every candidate (content-independent run time, the default).
@@ -141,6 +142,10 @@ int ofps_hip_lk_flow_dev(ofps_hip_ctx* ctx, const void* d_prev, const void* d_cu
 int ofps_hip_densify(ofps_hip_ctx* ctx, const float* entries, size_t n, int w, int h,
                      float* out_field /* 2*w*h, cell (x,y) at 2*(y*w+x) */,
                      uint32_t* out_cells /* 2*n (x,y) per entry, or NULL */);
+/* add_vector_weighted (ofps/src/motion_field.rs:164-178): entry i is inserted with weights[i]: counts += w,
+ * sum = motion * w + sum, in input order; ofps_hip_densify is the weights == 1 case (add_vector, :188-190). */
+int ofps_hip_densify_weighted(ofps_hip_ctx* ctx, const float* entries, const float* weights, size_t n, int w, int h,
+                              float* out_field /* 2*w*h */, uint32_t* out_cells /* 2*n or NULL */);
 /* batch items of n_per_item entries each (contiguous); outputs per item. */
 int ofps_hip_densify_dev(ofps_hip_ctx* ctx, const void* d_entries, size_t n_per_item, int batch,
                          int w, int h, void* d_out_field, void* d_out_cells /* or NULL */);
@@ -163,7 +168,12 @@ int ofps_hip_detect_dev(ofps_hip_ctx* ctx, const void* d_entries, size_t n_per_i
 
 /* ---- A6-A12: Almeida estimator ("hip_almeida" Estimator) ----
  * out_quat = (w,i,j,k) of the returned UnitQuaternion; out_tr = translation (always 0,
- * almeida-estimator/src/lib.rs:120).  seed drives the counter-based RANSAC sampler. */
+ * almeida-estimator/src/lib.rs:120).  seed drives the counter-based RANSAC sampler (the reference draws from
+ * thread_rng): callers should advance it per call -- a constant seed samples the same positions every frame -- and
+ * in a batched call item b uses seed + b.  Fields of more than 65,536 vectors (per-pixel records) are solved with
+ * reciprocal-multiply quotients instead of IEEE division (<= 1 ulp per quotient; quaternion within 2e-6 of the
+ * exact path).  A quaternion whose w is NaN (device-pointer entry points only) means a cluster launch gave up waiting
+ * for workgroups that never became resident; the host-pointer entry point re-solves by itself. */
 int ofps_hip_almeida(ofps_hip_ctx* ctx, const float* entries, size_t n,
                      float aspect, float fov_y_deg, int use_ransac, size_t num_iters,
                      float inlier_deg, size_t num_samples, uint64_t seed,

@@ -809,7 +809,7 @@ __global__ __launch_bounds__(64) void ransac_hyp_kernel(const float4* __restrict
     if (it >= iters) return;
     const float eps = almeida_eps();
     const uint32_t n3 = n < 3 ? n : 3;
-    const SampleKey sk = sample_key(seed, it, 0, n);
+    const SampleKey sk = sample_key(seed + item, it, 0, n);        // every item of a batch draws its own samples
     float4 e[3];
     float2 pr[3], pp[3], py[3];
     const Mat3 mroll = mat3_from_euler(0.0f, eps, 0.0f), mpitch = mat3_from_euler(eps, 0.0f, 0.0f),
@@ -875,7 +875,7 @@ __global__ __launch_bounds__(256) void ransac_count_kernel(const float4* __restr
     if (threadIdx.x == 0) total = 0;
     __syncthreads();
     const Mat3 mat = hyp[item * iters + it];
-    const SampleKey sk = sample_key(seed, it, 1, n);
+    const SampleKey sk = sample_key(seed + item, it, 1, n);
     uint32_t c = 0;
     for (uint32_t j = threadIdx.x; j < ns; j += 256) {
         const float4 e = entries[item * n + sample_index(sk, j, n)];
@@ -916,7 +916,7 @@ __global__ __launch_bounds__(1024) void ransac_select_kernel(const float4* __res
         return;
     }
     const Mat3 mat = hyp[item * iters + bit];
-    const SampleKey sk = sample_key(seed, bit, 1, n);
+    const SampleKey sk = sample_key(seed + item, bit, 1, n);
     for (uint32_t j0 = 0; j0 < ns; j0 += 1024) {
         const uint32_t j = j0 + threadIdx.x;
         uint32_t idx = 0;

@@ -70,7 +70,8 @@ int sad_pairs_device(ofps_hip_ctx* ctx, const uint8_t* prev_base, size_t prev_pi
 int densify_device(ofps_hip_ctx* ctx, const float4* d_entries, size_t n, int batch, int w, int h, float2* d_field,
                    uint32_t* d_cells, uint32_t** out_begin, uint32_t** out_end);
 int densify_device_raw(ofps_hip_ctx* ctx, const float4* d_entries, size_t n, int batch, int w, int h, float2* d_field,
-                       uint32_t* d_cells, uint32_t** out_begin, uint32_t** out_end, float2* d_sum, float* d_cnt);
+                       uint32_t* d_cells, uint32_t** out_begin, uint32_t** out_end, float2* d_sum, float* d_cnt,
+                       const float* d_weights);
 int densify_entries_device(ofps_hip_ctx* ctx, const float4* d_entries, size_t n, int w, int h, float2* d_field,
                            float4* d_out_entries, uint32_t* d_count);
 int contrast_mask_device(ofps_hip_ctx* ctx, const uint8_t* d_gray, int W, int H, int stride, uint8_t* d_mask);

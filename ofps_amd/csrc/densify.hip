@@ -191,8 +191,10 @@ __global__ __launch_bounds__(256) void cell_sum_kernel(const float4* __restrict_
                                                        const uint32_t* __restrict__ cell_begin,
                                                        const uint32_t* __restrict__ cell_end, size_t cells,
                                                        float2* __restrict__ out_field, float2* __restrict__ out_sum,
-                                                       float* __restrict__ out_cnt) {
+                                                       float* __restrict__ out_cnt, const float* __restrict__ weights) {
+    // weights (optional, one per entry): add_vector_weighted (motion_field.rs:164-178); absent = add_vector's 1.0
     __shared__ float2 stage[4][64];
+    __shared__ float wstage[4][64];
     const size_t item = blockIdx.y;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const size_t cell = (size_t)blockIdx.x * 4 + wave;
@@ -202,8 +204,10 @@ __global__ __launch_bounds__(256) void cell_sum_kernel(const float4* __restrict_
     for (uint32_t k0 = b; k0 < e; k0 += 64) {
         const uint32_t k = k0 + lane;
         if (k < e) {
-            const float4 en = entries[item * n + vals[item * n + k]];
+            const uint32_t src = vals[item * n + k];
+            const float4 en = entries[item * n + src];
             stage[wave][lane] = make_float2(en.z, en.w);
+            wstage[wave][lane] = weights ? weights[item * n + src] : 1.0f;
         }
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -211,8 +215,9 @@ __global__ __launch_bounds__(256) void cell_sum_kernel(const float4* __restrict_
         if (lane < 2) {
             const float* col = reinterpret_cast<const float*>(&stage[wave][0]) + lane;
             for (int j = 0; j < m; ++j) {
-                cnt += 1.0f;                           // :142-143
-                sum = col[2 * j] * 1.0f + sum;         // :144-146 (motion * weight + column)
+                const float wgt = wstage[wave][j];
+                cnt += wgt;                            // :142-143
+                sum = col[2 * j] * wgt + sum;          // :144-146 (motion * weight + column)
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -380,11 +385,12 @@ __global__ __launch_bounds__(256) void interpolate_kernel(float2* __restrict__ s
 // per-cell [begin,end) tables in S_WORK3 (begin) / S_WORK4 (end).
 int densify_device(ofps_hip_ctx* ctx, const float4* d_entries, size_t n, int batch, int w, int h, float2* d_field,
                    uint32_t* d_cells, uint32_t** out_begin, uint32_t** out_end) {
-    return densify_device_raw(ctx, d_entries, n, batch, w, h, d_field, d_cells, out_begin, out_end, nullptr, nullptr);
+    return densify_device_raw(ctx, d_entries, n, batch, w, h, d_field, d_cells, out_begin, out_end, nullptr, nullptr, nullptr);
 }
 
 int densify_device_raw(ofps_hip_ctx* ctx, const float4* d_entries, size_t n, int batch, int w, int h, float2* d_field,
-                       uint32_t* d_cells, uint32_t** out_begin, uint32_t** out_end, float2* d_sum, float* d_cnt) {
+                       uint32_t* d_cells, uint32_t** out_begin, uint32_t** out_end, float2* d_sum, float* d_cnt,
+                       const float* d_weights) {
     const size_t cells = (size_t)w * (size_t)h;
     OFPS_REQUIRE(ctx, w >= 1 && h >= 1 && cells <= 65536, "densify: grid %dx%d unsupported (1..65536 cells)", w, h);
     OFPS_REQUIRE(ctx, batch >= 1 && batch <= 65535, "densify: batch %d out of range", batch);
@@ -426,7 +432,7 @@ int densify_device_raw(ofps_hip_ctx* ctx, const float4* d_entries, size_t n, int
         sorted_vals = vals_a;
     }
     hipLaunchKernelGGL(cell_sum_kernel, dim3((unsigned)((cells + 3) / 4), batch), dim3(256), 0, s, d_entries, n,
-                       sorted_vals, begin, end, cells, d_field, d_sum, d_cnt);
+                       sorted_vals, begin, end, cells, d_field, d_sum, d_cnt, d_weights);
     OFPS_HIP_TRY(ctx, hipGetLastError());
     return OFPS_HIP_OK;
 }
@@ -461,7 +467,7 @@ int ofps_hip_densify_interpolated(ofps_hip_ctx* ctx, const float* entries, size_
     auto* d_cnt = reinterpret_cast<float*>(d_state + cells * sizeof(float2));
     auto* d_key = reinterpret_cast<int*>(d_state + cells * (sizeof(float2) + sizeof(float)));
     if (n) OFPS_HIP_TRY(ctx, hipMemcpyAsync(d_ent, entries, n * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
-    int rc = ofps::densify_device_raw(ctx, d_ent, n, 1, w, h, nullptr, nullptr, nullptr, nullptr, d_sum, d_cnt);
+    int rc = ofps::densify_device_raw(ctx, d_ent, n, 1, w, h, nullptr, nullptr, nullptr, nullptr, d_sum, d_cnt, nullptr);
     if (rc != OFPS_HIP_OK) return rc;
     hipLaunchKernelGGL(ofps::interpolate_kernel, dim3(1), dim3(256), 0, ctx->stream, d_sum, d_cnt, d_key, w, h, d_field);
     OFPS_HIP_TRY(ctx, hipGetLastError());
@@ -493,6 +499,31 @@ int ofps_hip_densify(ofps_hip_ctx* ctx, const float* entries, size_t n, int w, i
     if (!d_ent || !d_field || (out_cells && !d_cells)) return OFPS_HIP_ENOMEM;
     if (n) OFPS_HIP_TRY(ctx, hipMemcpyAsync(d_ent, entries, n * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
     int rc = ofps::densify_device(ctx, d_ent, n, 1, w, h, d_field, d_cells, nullptr, nullptr);
+    if (rc != OFPS_HIP_OK) return rc;
+    OFPS_HIP_TRY(ctx, hipMemcpyAsync(out_field, d_field, cells * sizeof(float2), hipMemcpyDeviceToHost, ctx->stream));
+    if (out_cells && n)
+        OFPS_HIP_TRY(ctx, hipMemcpyAsync(out_cells, d_cells, 2 * n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    OFPS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return OFPS_HIP_OK;
+}
+
+int ofps_hip_densify_weighted(ofps_hip_ctx* ctx, const float* entries, const float* weights, size_t n, int w, int h,
+                              float* out_field, uint32_t* out_cells) {
+    if (!ctx) return OFPS_HIP_EINVAL;
+    OFPS_REQUIRE(ctx, out_field && ((entries && weights) || n == 0), "densify_weighted: null host pointer");
+    OFPS_REQUIRE(ctx, w >= 1 && h >= 1, "densify_weighted: bad grid %dx%d", w, h);
+    OFPS_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t cells = (size_t)w * h;
+    auto* d_ent = static_cast<float4*>(ofps::scratch(ctx, ofps::S_ENTRIES, n * sizeof(float4)));
+    auto* d_wgt = static_cast<float*>(ofps::scratch(ctx, ofps::S_ENTRIES2, n * sizeof(float)));
+    auto* d_field = static_cast<float2*>(ofps::scratch(ctx, ofps::S_FIELD, cells * sizeof(float2)));
+    auto* d_cells = out_cells ? static_cast<uint32_t*>(ofps::scratch(ctx, ofps::S_CELLS, 2 * n * sizeof(uint32_t))) : nullptr;
+    if (!d_ent || !d_wgt || !d_field || (out_cells && !d_cells)) return OFPS_HIP_ENOMEM;
+    if (n) {
+        OFPS_HIP_TRY(ctx, hipMemcpyAsync(d_ent, entries, n * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
+        OFPS_HIP_TRY(ctx, hipMemcpyAsync(d_wgt, weights, n * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    }
+    int rc = ofps::densify_device_raw(ctx, d_ent, n, 1, w, h, d_field, d_cells, nullptr, nullptr, nullptr, nullptr, d_wgt);
     if (rc != OFPS_HIP_OK) return rc;
     OFPS_HIP_TRY(ctx, hipMemcpyAsync(out_field, d_field, cells * sizeof(float2), hipMemcpyDeviceToHost, ctx->stream));
     if (out_cells && n)

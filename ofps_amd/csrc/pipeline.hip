@@ -66,8 +66,8 @@ int pipe_upload(ofps_hip_ctx* ctx, const uint8_t* luma, int W, int H, int stride
     // the slot's previous tenant (frame number - 3) may still be read by the search of ticket number - 2
     if (overlap && ctx->pipe_slot_read_valid[slot]) OFPS_HIP_TRY(ctx, hipStreamWaitEvent(up, ctx->pipe_slot_read[slot], 0));
     OFPS_HIP_TRY(ctx, ofps::upload_rows(slots + (size_t)slot * pitch, dstride, luma, stride, W, H, up));
-    OFPS_HIP_TRY(ctx, hipEventRecord(ctx->pipe_uploaded[slot], up));
-    ctx->pipe_uploaded_on_compute[slot] = !overlap;
+    if (overlap) OFPS_HIP_TRY(ctx, hipEventRecord(ctx->pipe_uploaded[slot], up));
+    ctx->pipe_uploaded_on_compute[slot] = !overlap;       // ... in which case the compute stream never has to wait for it
     ctx->pipe_frames += 1;
     *slots_out = slots; *pitch_out = pitch; *dstride_out = dstride;
     return OFPS_HIP_OK;
@@ -116,7 +116,10 @@ int ofps_hip_push_frame_async(ofps_hip_ctx* ctx, const uint8_t* luma, int W, int
     t.have_vectors = 0; t.n_vectors = 0; t.run_detector = prm->run_detector; t.run_estimator = prm->run_estimator;
     const size_t nblk = ofps_hip_sad_block_count(W, H, prm->block);
     if (frame_no == 0) {                                             // first frame of a stream: Ok(false), no vectors yet
-        if (!ctx->pipe_uploaded_on_compute[cur_slot]) OFPS_HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->pipe_uploaded[cur_slot], 0));
+        if (!ctx->pipe_uploaded_on_compute[cur_slot]) {
+            OFPS_HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->pipe_uploaded[cur_slot], 0));
+            ctx->pipe_uploaded_on_compute[cur_slot] = true;
+        }
         OFPS_HIP_TRY(ctx, hipEventRecord(t.done, s));
         t.pending = true;
         *ticket = (int)(tno & 0x7FFFFFFF);
@@ -133,9 +136,13 @@ int ofps_hip_push_frame_async(ofps_hip_ctx* ctx, const uint8_t* luma, int W, int
     char* d_out = d_out_all + (size_t)tix * kOutBytes;
     // the search needs both frames on the device: the previous frame's upload was waited for by the previous ticket
     // (or by the stage_frame that made it), this frame's by the event
-    // (uploads made on the compute stream itself are ordered by the stream)
-    if (!ctx->pipe_uploaded_on_compute[prev_slot]) OFPS_HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->pipe_uploaded[prev_slot], 0));
-    if (!ctx->pipe_uploaded_on_compute[cur_slot]) OFPS_HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->pipe_uploaded[cur_slot], 0));
+    // (uploads made on the compute stream itself are ordered by the stream; one wait per upload is enough)
+    for (int slot : {prev_slot, cur_slot}) {
+        if (!ctx->pipe_uploaded_on_compute[slot]) {
+            OFPS_HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->pipe_uploaded[slot], 0));
+            ctx->pipe_uploaded_on_compute[slot] = true;
+        }
+    }
     rc = ofps::sad_pairs_device(ctx, slots + (size_t)prev_slot * pitch, 0, slots + (size_t)cur_slot * pitch, 0, 1, W, H, dstride,
                                 prm->block, prm->range, d_ent, nullptr);
     if (rc != OFPS_HIP_OK) return rc;

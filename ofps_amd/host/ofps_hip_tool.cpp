@@ -1,13 +1,22 @@
 // ofps_hip_tool -- small CLI over the C++ host layer; the counterparts of the reference's non-GUI callers:
 //   extract <decoder> <arg> <out.mvec> [max_frames]     motion-extract/src/main.rs:7-38 (decode -> .mvec)
 //   detect  <decoder> <arg> [max_frames]                detection loop, ofps-suite/src/app/detection.rs:92-168
+//   detect  --config <saved.json> [--perf-csv <dir>] [max_frames]
+//                                                       the same loop from a saved MotionDetectionConfig (detection.rs:45-50):
+//                                                       plugins, their saved properties, max_frame_gap / min_frames
+//   parse-config <saved.json>                           prints what a saved configuration says (no GPU)
+//   stream-bench <w> <h> <frames> [sync|ahead]          PCIe-inclusive per-frame time of the hip_sad process_frame shape
 //   track   <decoder> <arg> [aspect fov_y] [lsq|ransac] tracking loop, ofps-suite/src/app/tracking/worker.rs:305-412
 //   mvec-copy <in.mvec> <out.mvec>                      CPU-only .mvec round trip (reader + writer)
-// decoder = hip_sad ("<raw luma file>?w=..&h=..&fps=..") or mvec ("<file.mvec>").
+// decoder = hip_sad / hip_lk ("<input>?w=..&h=..&fps=..") or mvec ("<input>"); <input> is a file path, "tcp://host:port"
+// (connect) or "tcp://@:port" (listen, accept one connection) as in ofps/src/utils.rs:92-118.
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <fstream>
 #include <iostream>
+#include <sstream>
 
 #include "ofps_host.hpp"
 
@@ -51,6 +60,107 @@ int main(int argc, char** argv) {
             std::printf("{\"frames\": %zu, \"vectors\": %zu}\n", frames, total);
             return 0;
         }
+        if (cmd == "detect" && argc >= 4 && std::string(argv[2]) == "--config") {
+            std::ifstream f(argv[3]);
+            if (!f) throw Error(std::string("cannot open ") + argv[3]);
+            std::stringstream ss; ss << f.rdbuf();
+            const MotionDetectionConfig cfg = MotionDetectionConfig::from_json(ss.str());
+            std::string perf_dir;
+            size_t max_frames = SIZE_MAX;
+            for (int a = 4; a < argc; ++a) {
+                if (std::string(argv[a]) == "--perf-csv" && a + 1 < argc) perf_dir = argv[++a];
+                else max_frames = std::strtoull(argv[a], nullptr, 10);
+            }
+            auto dec = create_decoder(cfg.decoder.selected_plugin, cfg.decoder.arg);
+            auto det = create_detector(cfg.detector.selected_plugin, cfg.detector.arg);
+            transfer_props(cfg.decoder_properties, *dec);             // detection.rs:100-109
+            transfer_props(cfg.detector_properties, *det);
+            const DetectionRun run = run_detection(*dec, *det, max_frames);
+            if (!perf_dir.empty())
+                export_perf_csv(perf_dir, cfg.decoder.selected_plugin, {{"decoder", &run.decoder_ms}, {cfg.detector.selected_plugin, &run.detector_ms}});
+            std::printf("{\"frames\": %zu, \"decoder_ms_mean\": %.4f, \"detector_ms_mean\": %.4f, \"max_frame_gap\": %zu, \"min_frames\": %zu, "
+                        "\"detector_properties\": {", run.frames, mean(run.decoder_ms), mean(run.detector_ms), cfg.max_frame_gap, cfg.min_frames);
+            bool first = true;
+            for (auto& [n, p] : det->props()) {
+                std::printf("%s\"%s\": ", first ? "" : ", ", n.c_str());
+                if (auto fl = std::get_if<BoundedProp<float>>(&p)) std::printf("%.9g", (double)fl->val);
+                else if (auto u = std::get_if<BoundedProp<size_t>>(&p)) std::printf("%zu", u->val);
+                else if (auto b = std::get_if<bool>(&p)) std::printf("%s", *b ? "true" : "false");
+                else std::printf("\"%s\"", std::get<std::string>(p).c_str());
+                first = false;
+            }
+            std::printf("}, \"motion_ranges\": [");
+            first = true;
+            for (auto [s, e] : run.filtered(cfg.max_frame_gap, cfg.min_frames)) {
+                std::printf("%s[%zu, %zu]", first ? "" : ", ", s, e);
+                first = false;
+            }
+            std::printf("]}\n");
+            return 0;
+        }
+        if (cmd == "parse-config" && argc >= 3) {                     // no GPU: what a saved configuration says
+            std::ifstream f(argv[2]);
+            if (!f) throw Error(std::string("cannot open ") + argv[2]);
+            std::stringstream ss; ss << f.rdbuf();
+            const MotionDetectionConfig cfg = MotionDetectionConfig::from_json(ss.str());
+            auto dump = [](const std::vector<std::pair<std::string, Property>>& props) {
+                bool first = true;
+                for (const auto& [n, p] : props) {
+                    std::printf("%s\"%s\": ", first ? "" : ", ", n.c_str());
+                    if (auto fl = std::get_if<BoundedProp<float>>(&p)) std::printf("[\"Float\", %.9g, %.9g, %.9g]", (double)fl->val, (double)fl->min, (double)fl->max);
+                    else if (auto u = std::get_if<BoundedProp<size_t>>(&p)) std::printf("[\"Usize\", %zu, %zu, %zu]", u->val, u->min, u->max);
+                    else if (auto b = std::get_if<bool>(&p)) std::printf("[\"Bool\", %s]", *b ? "true" : "false");
+                    else std::printf("[\"String\", \"%s\"]", std::get<std::string>(p).c_str());
+                    first = false;
+                }
+            };
+            std::printf("{\"decoder\": [\"%s\", \"%s\", %s], \"detector\": [\"%s\", \"%s\", %s], \"max_frame_gap\": %zu, \"min_frames\": %zu, "
+                        "\"overlay_mf\": %s, \"realtime_processing\": %s, \"decoder_properties\": {",
+                        cfg.decoder.selected_plugin.c_str(), cfg.decoder.arg.c_str(), cfg.decoder_open ? "true" : "false",
+                        cfg.detector.selected_plugin.c_str(), cfg.detector.arg.c_str(), cfg.detector_open ? "true" : "false",
+                        cfg.max_frame_gap, cfg.min_frames, cfg.overlay_mf ? "true" : "false", cfg.realtime_processing ? "true" : "false");
+            dump(cfg.decoder_properties);
+            std::printf("}, \"detector_properties\": {");
+            dump(cfg.detector_properties);
+            std::printf("}}\n");
+            return 0;
+        }
+        if (cmd == "stream-bench" && argc >= 5) {
+            // the Decoder::process_frame shape without Python in the loop: frames are already in page-locked buffers (a
+            // decoder that writes there), one H2D + search + 16 B/vector D2H per frame
+            const int W = std::atoi(argv[2]), H = std::atoi(argv[3]);
+            const int frames = std::atoi(argv[4]);
+            const bool ahead = !(argc > 5 && std::string(argv[5]) == "sync");
+            HipContext ctx;
+            uint8_t* pin[3]; float* ent[2];
+            const size_t nblk = ofps_hip_sad_block_count(W, H, 16);
+            for (auto& p : pin) { void* q; ctx.check(ofps_hip_host_alloc(ctx.get(), (size_t)W * H, &q)); p = static_cast<uint8_t*>(q); }
+            for (auto& p : ent) { void* q; ctx.check(ofps_hip_host_alloc(ctx.get(), nblk * 16, &q)); p = static_cast<float*>(q); }
+            uint32_t st = 12345;
+            for (auto& p : pin) for (size_t i = 0; i < (size_t)W * H; ++i) { st = st * 1664525u + 1013904223u; p[i] = (uint8_t)(st >> 24); }
+            ofps_hip_frame_params prm{}; prm.block = 16; prm.range = 16;
+            ofps_hip_frame_result res{};
+            auto run = [&](int n) {
+                ctx.check(ofps_hip_reset_frames(ctx.get()));
+                int prev = -1, t = 0;
+                for (int k = 0; k < n; ++k) {
+                    ctx.check(ofps_hip_push_frame_async(ctx.get(), pin[k % 3], W, H, W, &prm, ent[k % 2], nullptr, &t));
+                    if (!ahead) { ctx.check(ofps_hip_frame_wait(ctx.get(), t, &res)); continue; }
+                    if (prev >= 0) ctx.check(ofps_hip_frame_wait(ctx.get(), prev, &res));
+                    prev = t;
+                }
+                if (ahead && prev >= 0) ctx.check(ofps_hip_frame_wait(ctx.get(), prev, &res));
+            };
+            run(20);
+            const auto t0 = std::chrono::steady_clock::now();
+            run(frames);
+            const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / frames;
+            std::printf("{\"mode\": \"%s\", \"frames\": %d, \"ms_per_frame\": %.4f, \"Mvectors_per_s\": %.2f}\n", ahead ? "read_ahead" : "sync",
+                        frames, ms, (double)nblk / ms / 1e3);
+            for (auto p : pin) ofps_hip_host_free(ctx.get(), p);
+            for (auto p : ent) ofps_hip_host_free(ctx.get(), p);
+            return 0;
+        }
         if (cmd == "detect" && argc >= 4) {
             auto dec = create_decoder(argv[2], argv[3]);
             auto det = create_detector("hip_block_motion", "");
@@ -80,7 +190,7 @@ int main(int argc, char** argv) {
                             run.rotations[f].k, run.decoder_ms[f], run.estimator_ms[f]);
             return 0;
         }
-        std::fprintf(stderr, "usage: ofps_hip_tool extract|detect|track|mvec-copy ... (see source header)\n");
+        std::fprintf(stderr, "usage: ofps_hip_tool extract|detect|track|mvec-copy|stream-bench ... (see source header)\n");
         return 2;
     } catch (const std::exception& e) {
         std::fprintf(stderr, "error: %s\n", e.what());

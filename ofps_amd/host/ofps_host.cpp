@@ -2,11 +2,20 @@
 // path lives here: decode, detect and estimate are calls into libofps_hip.so.
 #include "ofps_host.hpp"
 
+#include <arpa/inet.h>
+#include <netdb.h>
+#include <netinet/in.h>
+#include <netinet/tcp.h>
+#include <sys/socket.h>
+#include <unistd.h>
+
 #include <chrono>
 #include <cmath>
 #include <cstring>
 #include <fstream>
+#include <iostream>
 #include <sstream>
+#include <streambuf>
 
 namespace ofps {
 
@@ -161,9 +170,10 @@ bool HipLkDecoder::process_frame(MotionVectors& field, std::vector<RGBA>* out_fr
         out_frame->clear();
         for (uint8_t y : cur_) out_frame->push_back(RGBA{y, y, y, 255});
     }
-    const bool had_prev = have_prev_;
-    have_prev_ = true;
-    if (!had_prev) return false;                                      // :156-158
+    // :156-158 compares the sizes of gray and old_gray: flow is computed as soon as TWO frames have been read, also when
+    // both were read by this very call (skip >= 1 on the first call)
+    frames_read_ += skip + 1;
+    if (frames_read_ < 2) return false;
     out_.resize(process_fullres_ ? 4 * std::min(max_w_, w_) * std::min(max_h_, h_) : 4 * w_ * h_);
     size_t n_out = 0;
     const unsigned flags = (contrast_mask_ ? OFPS_HIP_LK_CONTRAST_MASK : 0u) | (process_fullres_ ? 0u : OFPS_HIP_LK_PER_PIXEL);
@@ -238,12 +248,229 @@ std::vector<std::pair<std::string, PropertyMut>> HipAlmeidaEstimator::props_mut(
             {"Ransac samples", PropertyMut::usize(&ransac_samples, 100, 16000)}};
 }
 
-// ------------------------------------------------------------------ creation by name
-static std::unique_ptr<std::istream> open_input(const std::string& path) {
-    auto f = std::make_unique<std::ifstream>(path, std::ios::binary);
-    if (!*f) throw Error("cannot open " + path);
-    return f;
+// ------------------------------------------------------------------ input streams (ofps/src/utils.rs:92-118)
+namespace {
+class FdStreamBuf : public std::streambuf {                           // read side of a connected socket
+public:
+    explicit FdStreamBuf(int fd) : fd_(fd), buf_(1 << 16) {}
+    ~FdStreamBuf() override { if (fd_ >= 0) ::close(fd_); }
+protected:
+    int_type underflow() override {
+        if (gptr() < egptr()) return traits_type::to_int_type(*gptr());
+        ssize_t n;
+        do { n = ::recv(fd_, buf_.data(), buf_.size(), 0); } while (n < 0 && errno == EINTR);
+        if (n <= 0) return traits_type::eof();
+        setg(buf_.data(), buf_.data(), buf_.data() + n);
+        return traits_type::to_int_type(*gptr());
+    }
+    std::streamsize xsgetn(char* s, std::streamsize count) override {  // large frame reads go straight to the caller's buffer
+        std::streamsize got = 0;
+        while (got < count) {
+            if (gptr() < egptr()) {
+                const std::streamsize k = std::min<std::streamsize>(count - got, egptr() - gptr());
+                std::memcpy(s + got, gptr(), (size_t)k);
+                gbump((int)k); got += k;
+                continue;
+            }
+            ssize_t n;
+            do { n = ::recv(fd_, s + got, (size_t)(count - got), 0); } while (n < 0 && errno == EINTR);
+            if (n <= 0) break;
+            got += n;
+        }
+        return got;
+    }
+private:
+    int fd_;
+    std::vector<char> buf_;
+};
+class FdIStream : public std::istream {
+public:
+    explicit FdIStream(int fd) : std::istream(nullptr), sb_(fd) { rdbuf(&sb_); }
+private:
+    FdStreamBuf sb_;
+};
+}  // namespace
+
+std::unique_ptr<std::istream> open_file(const std::string& input) {
+    const std::string prefix = "tcp://";
+    if (input.rfind(prefix, 0) != 0) {                                // std::fs::File::open
+        auto f = std::make_unique<std::ifstream>(input, std::ios::binary);
+        if (!*f) throw Error("cannot open " + input);
+        return f;
+    }
+    const std::string rest = input.substr(prefix.size());
+    const auto colon = rest.find(':');                                // split_once(':')
+    if (colon == std::string::npos) throw Error("Invalid format");
+    const std::string addr = rest.substr(0, colon), port_s = rest.substr(colon + 1);
+    char* end = nullptr;
+    const unsigned long port = std::strtoul(port_s.c_str(), &end, 10);
+    if (port_s.empty() || *end != 0 || port > 65535) throw Error("invalid port: " + port_s);
+    int fd = -1;
+    if (addr == "@") {                                                // TcpListener::bind("0.0.0.0:port") + accept
+        const int ls = ::socket(AF_INET, SOCK_STREAM, 0);
+        if (ls < 0) throw Error("socket() failed");
+        int one = 1;
+        ::setsockopt(ls, SOL_SOCKET, SO_REUSEADDR, &one, sizeof(one));
+        sockaddr_in sa{};
+        sa.sin_family = AF_INET; sa.sin_addr.s_addr = htonl(INADDR_ANY); sa.sin_port = htons((uint16_t)port);
+        if (::bind(ls, reinterpret_cast<sockaddr*>(&sa), sizeof(sa)) != 0 || ::listen(ls, 1) != 0) {
+            ::close(ls);
+            throw Error("cannot listen on port " + port_s);
+        }
+        sockaddr_in peer{};
+        socklen_t pl = sizeof(peer);
+        fd = ::accept(ls, reinterpret_cast<sockaddr*>(&peer), &pl);
+        ::close(ls);
+        if (fd < 0) throw Error("accept() failed");
+        char ip[64] = {0};
+        ::inet_ntop(AF_INET, &peer.sin_addr, ip, sizeof(ip));
+        std::cout << "Accept " << ip << ":" << ntohs(peer.sin_port) << std::endl;
+    } else {                                                          // TcpStream::connect(host:port)
+        std::cout << "Connecting to " << rest << std::endl;
+        addrinfo hints{}, *res = nullptr;
+        hints.ai_family = AF_UNSPEC; hints.ai_socktype = SOCK_STREAM;
+        if (::getaddrinfo(addr.c_str(), port_s.c_str(), &hints, &res) != 0 || !res) throw Error("cannot resolve " + addr);
+        for (addrinfo* a = res; a && fd < 0; a = a->ai_next) {
+            fd = ::socket(a->ai_family, a->ai_socktype, a->ai_protocol);
+            if (fd >= 0 && ::connect(fd, a->ai_addr, a->ai_addrlen) != 0) { ::close(fd); fd = -1; }
+        }
+        ::freeaddrinfo(res);
+        if (fd < 0) throw Error("cannot connect to " + rest);
+    }
+    std::cout << "Got stream!" << std::endl;
+    return std::make_unique<FdIStream>(fd);
 }
+
+// ------------------------------------------------------------------ JSON + saved configuration
+namespace {
+struct JsonParser {
+    const std::string& s;
+    size_t p = 0;
+    [[noreturn]] void fail(const char* what) const { throw Error(std::string("json: ") + what + " at offset " + std::to_string(p)); }
+    void ws() { while (p < s.size() && (s[p] == ' ' || s[p] == '\n' || s[p] == '\t' || s[p] == '\r')) ++p; }
+    bool eat(char c) { ws(); if (p < s.size() && s[p] == c) { ++p; return true; } return false; }
+    void lit(const char* w) { for (const char* q = w; *q; ++q) { if (p >= s.size() || s[p] != *q) fail("bad literal"); ++p; } }
+    std::string string_() {
+        std::string out;
+        if (!eat('"')) fail("expected string");
+        while (true) {
+            if (p >= s.size()) fail("unterminated string");
+            const char c = s[p++];
+            if (c == '"') return out;
+            if (c != '\\') { out.push_back(c); continue; }
+            if (p >= s.size()) fail("bad escape");
+            const char e = s[p++];
+            switch (e) {
+                case 'n': out.push_back('\n'); break; case 't': out.push_back('\t'); break; case 'r': out.push_back('\r'); break;
+                case 'b': out.push_back('\b'); break; case 'f': out.push_back('\f'); break;
+                case 'u': {
+                    if (p + 4 > s.size()) fail("bad \\u escape");
+                    const unsigned cp = (unsigned)std::stoul(s.substr(p, 4), nullptr, 16); p += 4;
+                    if (cp < 0x80) out.push_back((char)cp);
+                    else if (cp < 0x800) { out.push_back((char)(0xC0 | (cp >> 6))); out.push_back((char)(0x80 | (cp & 0x3F))); }
+                    else { out.push_back((char)(0xE0 | (cp >> 12))); out.push_back((char)(0x80 | ((cp >> 6) & 0x3F))); out.push_back((char)(0x80 | (cp & 0x3F))); }
+                    break;
+                }
+                default: out.push_back(e);                            // \" \\ \/
+            }
+        }
+    }
+    Json value() {
+        ws();
+        if (p >= s.size()) fail("unexpected end");
+        Json j;
+        const char c = s[p];
+        if (c == '{') {
+            ++p; j.kind = Json::Object;
+            if (eat('}')) return j;
+            do { std::string k = string_(); if (!eat(':')) fail("expected ':'"); j.obj.emplace_back(std::move(k), value()); } while (eat(','));
+            if (!eat('}')) fail("expected '}'");
+        } else if (c == '[') {
+            ++p; j.kind = Json::Array;
+            if (eat(']')) return j;
+            do { j.arr.push_back(value()); } while (eat(','));
+            if (!eat(']')) fail("expected ']'");
+        } else if (c == '"') { j.kind = Json::String; j.str = string_(); }
+        else if (c == 't') { lit("true"); j.kind = Json::Bool; j.b = true; }
+        else if (c == 'f') { lit("false"); j.kind = Json::Bool; j.b = false; }
+        else if (c == 'n') { lit("null"); }
+        else {
+            size_t used = 0;
+            try { j.num = std::stod(s.substr(p), &used); } catch (...) { fail("bad number"); }
+            j.kind = Json::Number; p += used;
+        }
+        return j;
+    }
+};
+
+Property property_from_json(const Json& j) {                         // externally tagged: {"Float": {"val":..,"min":..,"max":..}}
+    if (j.kind != Json::Object || j.obj.size() != 1) throw Error("config: a Property must be an object with one variant key");
+    const auto& [tag, v] = j.obj[0];
+    auto num = [&](const char* k) { const Json* m = v.get(k); if (!m || m->kind != Json::Number) throw Error(std::string("config: Property field ") + k); return m->num; };
+    if (tag == "String" && v.kind == Json::String) return Property{v.str};
+    if (tag == "Bool" && v.kind == Json::Bool) return Property{v.b};
+    if (tag == "Float") return Property{BoundedProp<float>{(float)num("val"), (float)num("min"), (float)num("max")}};
+    if (tag == "Usize") return Property{BoundedProp<size_t>{(size_t)num("val"), (size_t)num("min"), (size_t)num("max")}};
+    throw Error("config: unknown Property variant " + tag);
+}
+
+std::vector<std::pair<std::string, Property>> property_map(const Json* j) {
+    std::vector<std::pair<std::string, Property>> out;
+    if (!j || j->kind == Json::Null) return out;                       // #[serde(default)]
+    if (j->kind != Json::Object) throw Error("config: properties must be an object");
+    for (const auto& [k, v] : j->obj) out.emplace_back(k, property_from_json(v));
+    return out;
+}
+
+void plugin_tuple(const Json* j, const char* what, CreatePluginConfig& cfg, bool& flag) {
+    if (!j || j->kind != Json::Array || j->arr.size() != 2 || j->arr[0].kind != Json::Object || j->arr[1].kind != Json::Bool)
+        throw Error(std::string("config: ") + what + " must be [ {selected_plugin, arg, extra}, bool ]");
+    const Json* sp = j->arr[0].get("selected_plugin");
+    const Json* arg = j->arr[0].get("arg");
+    if (!sp || sp->kind != Json::String || !arg || arg->kind != Json::String) throw Error(std::string("config: ") + what + ".selected_plugin / arg");
+    cfg.selected_plugin = sp->str; cfg.arg = arg->str; flag = j->arr[1].b;
+}
+}  // namespace
+
+const Json* Json::get(const std::string& key) const {
+    for (const auto& kv : obj) if (kv.first == key) return &kv.second;
+    return nullptr;
+}
+
+Json Json::parse(const std::string& text) {
+    JsonParser ps{text};
+    Json j = ps.value();
+    ps.ws();
+    if (ps.p != text.size()) ps.fail("trailing characters");
+    return j;
+}
+
+MotionDetectionConfig MotionDetectionConfig::from_json(const std::string& text) {
+    const Json root = Json::parse(text);
+    if (root.kind != Json::Object) throw Error("config: expected an object");
+    MotionDetectionConfig c;
+    plugin_tuple(root.get("decoder"), "decoder", c.decoder, c.decoder_open);
+    plugin_tuple(root.get("detector"), "detector", c.detector, c.detector_open);
+    const Json* st = root.get("settings");
+    if (!st || st->kind != Json::Object) throw Error("config: settings missing");
+    const Json* worker = st->get("worker");
+    if (!worker || worker->kind != Json::Object) throw Error("config: settings.worker missing");
+    c.decoder_properties = property_map(worker->get("decoder_properties"));
+    c.detector_properties = property_map(worker->get("detector_properties"));
+    if (const Json* r = worker->get("realtime_processing"); r && r->kind == Json::Bool) c.realtime_processing = r->b;
+    auto need_usize = [&](const char* k) { const Json* m = st->get(k); if (!m || m->kind != Json::Number) throw Error(std::string("config: settings.") + k); return (size_t)m->num; };
+    if (const Json* o = st->get("overlay_mf"); o && o->kind == Json::Bool) c.overlay_mf = o->b; else throw Error("config: settings.overlay_mf");
+    c.max_frame_gap = need_usize("max_frame_gap");
+    c.min_frames = need_usize("min_frames");
+    return c;
+}
+
+void transfer_props(const std::vector<std::pair<std::string, Property>>& saved, Properties& plugin) {
+    for (const auto& [name, value] : saved) plugin.set_prop(name, value);   // unknown names are skipped, mismatched kinds ignored
+}
+
+// ------------------------------------------------------------------ creation by name
+static std::unique_ptr<std::istream> open_input(const std::string& path) { return open_file(path); }
 
 std::unique_ptr<Decoder> create_decoder(const std::string& name, const std::string& arg) {
     if (name == "mvec") return std::make_unique<MvecFileDecoder>(open_input(arg));
@@ -311,6 +538,15 @@ std::vector<std::pair<size_t, size_t>> DetectionRun::filtered(size_t max_frame_g
     for (const auto& r : merged)
         if (r.second - r.first >= min_frames) out.push_back(r);
     return out;
+}
+
+void export_perf_csv(const std::string& dir, const std::string& decoder_name,
+                     const std::vector<std::pair<std::string, const std::vector<double>*>>& stages) {   // perf_stats.rs:86-121
+    for (const auto& [name, times] : stages) {
+        std::ofstream f(dir + "/perf_" + name + "_" + decoder_name + ".csv");
+        if (!f) throw Error("cannot write perf csv in " + dir);
+        for (double ms : *times) f << (float)ms << "\n";
+    }
 }
 
 TrackingRun run_tracking(Decoder& decoder, Estimator& estimator, const StandardCamera& camera, size_t max_frames) {

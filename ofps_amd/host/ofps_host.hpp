@@ -155,7 +155,7 @@ private:
     std::optional<double> fps_;
     std::vector<uint8_t> prev_, cur_;
     std::vector<float> out_;
-    bool have_prev_ = false;
+    size_t frames_read_ = 0;
 };
 
 // MvecFile of motion-loader/src/lib.rs:31-83 (pure host I/O, no GPU)
@@ -193,6 +193,36 @@ private:
     HipContext ctx_;
 };
 
+// ---- input streams: ofps::utils::open_file (ofps/src/utils.rs:92-118).  "tcp://host:port" connects, "tcp://@:port"
+// listens on 0.0.0.0:port and accepts one connection, anything else is a file path.
+std::unique_ptr<std::istream> open_file(const std::string& input);
+
+// ---- minimal JSON value (objects, arrays, strings, numbers, booleans, null) for the saved configurations
+struct Json {
+    enum Kind { Null, Bool, Number, String, Array, Object } kind = Null;
+    bool b = false;
+    double num = 0;
+    std::string str;
+    std::vector<Json> arr;
+    std::vector<std::pair<std::string, Json>> obj;
+    const Json* get(const std::string& key) const;                   // object member or nullptr
+    static Json parse(const std::string& text);                      // throws Error on malformed input
+};
+
+// ---- the saved detection configuration (ofps-suite/src/app/detection.rs:23-50,171-179; widgets.rs:273-278;
+// Property is the externally tagged enum of ofps/src/plugins/properties.rs:63-68)
+struct CreatePluginConfig { std::string selected_plugin, arg; };
+struct MotionDetectionConfig {
+    CreatePluginConfig decoder, detector;
+    bool decoder_open = false, detector_open = false;               // second element of the (config, bool) tuples
+    std::vector<std::pair<std::string, Property>> decoder_properties, detector_properties;
+    bool realtime_processing = false, overlay_mf = false;
+    size_t max_frame_gap = 2, min_frames = 2;                        // Default (:33-43)
+    static MotionDetectionConfig from_json(const std::string& text);
+};
+// transfer_props (ofps/src/plugins/properties.rs:120-135): every saved property whose name the plugin has is applied
+void transfer_props(const std::vector<std::pair<std::string, Property>>& saved, Properties& plugin);
+
 // ---- creation by name (the part of PluginStore the hot path needs: ofps/src/plugins/mod.rs:396-453)
 std::unique_ptr<Decoder> create_decoder(const std::string& name, const std::string& arg);    // "hip_sad", "hip_lk", "mvec"
 std::unique_ptr<Detector> create_detector(const std::string& name, const std::string& arg);  // "hip_block_motion"
@@ -206,6 +236,10 @@ struct DetectionRun {
     std::vector<double> decoder_ms, detector_ms;
     std::vector<std::pair<size_t, size_t>> filtered(size_t max_frame_gap, size_t min_frames) const;
 };
+// "Export all stats" (ofps-suite/src/app/utils/perf_stats.rs:86-121): one perf_<name>_<decoder>.csv per timed stage in
+// `dir`, one millisecond value per line (csv::Writer::serialize of an f32: no header).
+void export_perf_csv(const std::string& dir, const std::string& decoder_name,
+                     const std::vector<std::pair<std::string, const std::vector<double>*>>& stages);
 DetectionRun run_detection(Decoder& decoder, Detector& detector, size_t max_frames = SIZE_MAX);
 // Tracking loop of ofps-suite/src/app/tracking/worker.rs:62-69,305-412 (one estimator).
 struct TrackingRun {

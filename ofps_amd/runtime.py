@@ -175,6 +175,17 @@ class HipContext:
                                                cells.ctypes.data_as(C.POINTER(C.c_uint32)) if want_cells else None))
         return (field, cells[:n]) if want_cells else field
 
+    def densify_weighted(self, entries, weights, w: int, h: int, want_cells=False):
+        """add_vector_weighted for every entry (motion_field.rs:164-178)."""
+        e = np.ascontiguousarray(entries, np.float32).reshape(-1, 4)
+        wg = np.ascontiguousarray(weights, np.float32).reshape(-1)
+        assert wg.shape[0] == e.shape[0]
+        field = np.zeros((h, w, 2), np.float32)
+        cells = np.zeros((max(e.shape[0], 1), 2), np.uint32) if want_cells else None
+        self._check(self._lib.ofps_hip_densify_weighted(self._h, _fp(e), _fp(wg), e.shape[0], w, h, _fp(field),
+                                                        cells.ctypes.data_as(C.POINTER(C.c_uint32)) if want_cells else None))
+        return (field, cells[:e.shape[0]]) if want_cells else field
+
     def densify_dev(self, d_entries: int, n_per_item: int, batch: int, w: int, h: int, d_out_field: int,
                     d_out_cells: int | None = None):
         self._check(self._lib.ofps_hip_densify_dev(self._h, C.c_void_p(d_entries), n_per_item, batch, w, h,

@@ -57,6 +57,7 @@ def lib():
         L.orc_lu3_solve.argtypes = [fp, fp, fp]
         L.orc_lu3_solve.restype = C.c_int
         L.orc_densify.argtypes = [fp, C.c_size_t, C.c_int, C.c_int, fp, C.POINTER(C.c_uint32), fp]
+        L.orc_densify_weighted.argtypes = [fp, fp, C.c_size_t, C.c_int, C.c_int, fp, C.POINTER(C.c_uint32)]
         L.orc_densify_to_entries.argtypes = [fp, C.c_size_t, C.c_int, C.c_int, fp]
         L.orc_densify_to_entries.restype = C.c_size_t
         L.orc_densify_interpolated.argtypes = [fp, C.c_size_t, C.c_int, C.c_int, fp]
@@ -185,6 +186,13 @@ def densify(entries, w: int, h: int, want_cells: bool = False, want_counts: bool
     if want_counts:
         out.append(counts)
     return out[0] if len(out) == 1 else tuple(out)
+
+
+def densify_weighted(entries, weights, w: int, h: int) -> np.ndarray:
+    e = _f32(entries).reshape(-1, 4); wg = _f32(weights).reshape(-1)
+    field = np.zeros((h, w, 2), np.float32)
+    lib().orc_densify_weighted(_fp(e), _fp(wg), e.shape[0], w, h, _fp(field), None)
+    return field
 
 
 def densify_to_entries(entries, w: int, h: int) -> np.ndarray:

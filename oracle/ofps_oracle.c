@@ -348,6 +348,22 @@ void orc_densify(const float* entries, size_t n, int w, int h,
     densifier_free(&d);
 }
 
+/* add_vector_weighted for every entry (:164-178) */
+void orc_densify_weighted(const float* entries, const float* weights, size_t n, int w, int h, float* out_field,
+                          uint32_t* out_cells) {
+    densifier d; densifier_init(&d, w, h);
+    for (size_t i = 0; i < n; ++i) {
+        const float* e = entries + 4 * i;
+        size_t x, y;
+        densifier_cell(e[0], e[1], d.w, d.h, &x, &y);
+        densifier_add_idx(&d, y * (size_t)d.w + x, e[2], e[3], weights[i]);
+        if (out_cells) { out_cells[2 * i] = (uint32_t)x; out_cells[2 * i + 1] = (uint32_t)y; }
+    }
+    size_t cells = (size_t)w * (size_t)h;
+    for (size_t i = 0; i < 2 * cells; ++i) out_field[i] = d.sum[i] / d.cnt[i];
+    densifier_free(&d);
+}
+
 size_t orc_densify_to_entries(const float* entries, size_t n, int w, int h, float* out_entries) {
     size_t cells = (size_t)w * (size_t)h;
     float* field = (float*)malloc((2 * cells + 2) * sizeof(float));

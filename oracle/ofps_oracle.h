@@ -74,6 +74,8 @@ void orc_densify(const float* entries, size_t n, int w, int h,
 /* cv-decoder's downsample-through-densifier output stage (cv-decoder/src/lib.rs:244-291):
  * densify to (w,h), then emit one entry per visited cell in BTreeSet<(x,y)> order
  * (x-major), pos = ((x+.5)/w, (y+.5)/h), motion = cell average.  Returns entry count. */
+void orc_densify_weighted(const float* entries, const float* weights, size_t n, int w, int h, float* out_field,
+                          uint32_t* out_cells);                                     /* motion_field.rs:164-178 */
 size_t orc_densify_to_entries(const float* entries, size_t n, int w, int h, float* out_entries);
 
 /* MotionFieldDensifier::interpolate_empty_cells (motion_field.rs:193-294) followed by

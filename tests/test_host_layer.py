@@ -113,3 +113,154 @@ def test_hip_lk_decoder_through_cpp_host(tmp_path):
         e_o = oracle.densify_to_entries(rec, 150, 84)             # the plugin masks by default, like cv-decoder
         assert 0 < len(e_o) < 150 * 84
         np.testing.assert_array_equal(frames[k].view(np.uint32), e_o.view(np.uint32))
+
+
+# ---- (f)2 surface added in round 2: tcp:// inputs, saved configurations, perf CSV export ------------------------------
+def _free_port():
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _mvec_bytes(frames):
+    buf = io.BytesIO()
+    for fr in frames:
+        mvec.write_frame(buf, fr)
+    return buf.getvalue()
+
+
+def test_open_file_tcp_connect(tmp_path):
+    """create_decoder("mvec", "tcp://host:port"): the tool connects to a listening peer (ofps/src/utils.rs:107-110)."""
+    import socket, threading
+    rng = np.random.default_rng(2)
+    payload = _mvec_bytes([rng.normal(size=(n, 4)).astype(np.float32) for n in (7, 0, 8040, 33)])
+    srv = socket.socket(); srv.bind(("127.0.0.1", 0)); srv.listen(1)
+    port = srv.getsockname()[1]
+
+    def feed():
+        c, _ = srv.accept()
+        c.sendall(payload); c.close(); srv.close()
+    th = threading.Thread(target=feed); th.start()
+    dst = tmp_path / "out.mvec"
+    out = _tool("extract", "mvec", f"tcp://127.0.0.1:{port}", dst)
+    th.join()
+    assert "Connecting to 127.0.0.1" in out and "Got stream!" in out
+    assert json.loads(out.strip().splitlines()[-1]) == {"frames": 4, "vectors": 7 + 8040 + 33}
+    assert dst.read_bytes() == payload
+
+
+def test_open_file_tcp_listen(tmp_path):
+    """"tcp://@:port": the tool listens on 0.0.0.0:port and accepts one connection (utils.rs:100-106)."""
+    import socket, time
+    rng = np.random.default_rng(3)
+    payload = _mvec_bytes([rng.normal(size=(n, 4)).astype(np.float32) for n in (880, 880)])
+    port = _free_port()
+    dst = tmp_path / "out.mvec"
+    if not os.path.exists(TOOL):
+        hip_build.build_host()
+    proc = subprocess.Popen([TOOL, "extract", "mvec", f"tcp://@:{port}", str(dst)], stdout=subprocess.PIPE, text=True)
+    for _ in range(100):
+        try:
+            c = socket.create_connection(("127.0.0.1", port), timeout=1.0)
+            break
+        except OSError:
+            time.sleep(0.05)
+    else:
+        proc.kill(); pytest.fail("the tool never listened")
+    c.sendall(payload); c.close()
+    out, _ = proc.communicate(timeout=30)
+    assert proc.returncode == 0 and "Accept 127.0.0.1" in out
+    assert dst.read_bytes() == payload
+
+
+def test_open_file_bad_tcp_spec_fails_loudly(tmp_path):
+    p = subprocess.run([TOOL, "extract", "mvec", "tcp://nocolon", str(tmp_path / "x")], capture_output=True, text=True)
+    assert p.returncode != 0 and "Invalid format" in p.stderr
+
+
+SAVED_CONFIG = {     # SURVEY.md Appendix B: MotionDetectionConfig as serde writes it (tuples = arrays, () = null)
+    "decoder": [{"selected_plugin": "mvec", "arg": "@ARG@", "extra": False}, True],
+    "detector": [{"selected_plugin": "hip_block_motion", "arg": "", "extra": None}, True],
+    "settings": {"worker": {"decoder_properties": {}, "realtime_processing": False,
+                            "detector_properties": {"Min size": {"Float": {"val": 0.02, "min": 0.01, "max": 1.0}},
+                                                    "Subdivisions": {"Usize": {"val": 4, "min": 1, "max": 16}},
+                                                    "Target motion": {"Float": {"val": 0.004, "min": 0.0001, "max": 0.1}},
+                                                    "Not a property of this plugin": {"Bool": True}}},
+                 "overlay_mf": False, "max_frame_gap": 3, "min_frames": 1,
+                 "draw_perf_stats": {"summary_window": False, "graph_window": False}},
+}
+
+
+def test_saved_config_is_parsed_like_serde_would(tmp_path):
+    cfg = tmp_path / "basic_detect.json"
+    cfg.write_text(json.dumps(SAVED_CONFIG, indent=2).replace("@ARG@", "clip with \\\"quotes\\\".mvec"))
+    got = json.loads(_tool("parse-config", cfg).replace('with "quotes"', "with 'quotes'"))
+    assert got["decoder"] == ["mvec", "clip with 'quotes'.mvec", True] and got["detector"] == ["hip_block_motion", "", True]
+    assert (got["max_frame_gap"], got["min_frames"], got["overlay_mf"], got["realtime_processing"]) == (3, 1, False, False)
+    dp = got["detector_properties"]
+    assert dp["Subdivisions"] == ["Usize", 4, 1, 16] and dp["Not a property of this plugin"] == ["Bool", True]
+    assert dp["Min size"][0] == "Float" and abs(dp["Min size"][1] - 0.02) < 1e-7
+    # malformed input is an error, not a default
+    bad = tmp_path / "bad.json"
+    bad.write_text('{"decoder": [{"selected_plugin": "mvec"}, true]}')
+    p = subprocess.run([TOOL, "parse-config", str(bad)], capture_output=True, text=True)
+    assert p.returncode != 0 and "config" in p.stderr
+
+
+@pytest.mark.gpu
+def test_detect_from_saved_config_with_perf_csv(tmp_path):
+    """detect --config: plugins by name, saved properties transferred (detection.rs:100-109), ranges filtered with the
+    saved max_frame_gap / min_frames, per-frame times exported as perf_<name>_<decoder>.csv (perf_stats.rs:86-121)."""
+    import oracle
+    W, H, B, R, F = 320, 192, 16, 16, 6
+    fr = synth.luma_sequence(F, W, H, max_step=R)
+    frames = [np.zeros((0, 4), np.float32)] + [oracle.sad_flow(fr[k - 1], fr[k], B, R)[0] for k in range(1, F)]
+    clip = tmp_path / "clip.mvec"
+    clip.write_bytes(_mvec_bytes(frames))
+    cfg = tmp_path / "cfg.json"
+    cfg.write_text(json.dumps(SAVED_CONFIG).replace("@ARG@", str(clip)))
+    perf = tmp_path / "perf"; perf.mkdir()
+    det = json.loads(_tool("detect", "--config", cfg, "--perf-csv", perf).strip().splitlines()[-1])
+    assert det["frames"] == F and det["detector_properties"]["Subdivisions"] == 4
+    assert abs(det["detector_properties"]["Min size"] - 0.02) < 1e-7 and abs(det["detector_properties"]["Target motion"] - 0.004) < 1e-7
+    ranges = []
+    for k, e in enumerate(frames, start=1):
+        if oracle.detect_motion(e, 0.02, 4, 0.004) is not None:
+            if ranges and ranges[-1][1] == k:
+                ranges[-1][1] += 1
+            else:
+                ranges.append([k, k + 1])
+    merged = []
+    for s, e in ranges:
+        if merged and s - merged[-1][1] <= 3:
+            merged[-1][1] = e
+        else:
+            merged.append([s, e])
+    assert det["motion_ranges"] == [r for r in merged if r[1] - r[0] >= 1]
+    for name in ("perf_decoder_mvec.csv", "perf_hip_block_motion_mvec.csv"):
+        rows = (perf / name).read_text().strip().splitlines()
+        assert len(rows) == F and all(float(r) >= 0 for r in rows)
+
+
+@pytest.mark.gpu
+def test_hip_sad_decoder_over_tcp_and_native_stream_bench(tmp_path):
+    """cfg5's input shape through the C++ host: raw luma frames over a socket into create_decoder("hip_sad", "tcp://...")."""
+    import socket, threading
+    import oracle
+    W, H, B, R, F = 320, 192, 16, 16, 4
+    fr = synth.luma_sequence(F, W, H, max_step=R)
+    srv = socket.socket(); srv.bind(("127.0.0.1", 0)); srv.listen(1)
+    port = srv.getsockname()[1]
+
+    def feed():
+        c, _ = srv.accept()
+        c.sendall(fr.tobytes()); c.close(); srv.close()
+    th = threading.Thread(target=feed); th.start()
+    out = tmp_path / "tcp.mvec"
+    info = json.loads(_tool("extract", "hip_sad", f"tcp://127.0.0.1:{port}?w={W}&h={H}&fps=60", out).strip().splitlines()[-1])
+    th.join()
+    assert info["frames"] == F
+    frames = list(mvec.read_frames(open(out, "rb")))
+    for k in range(1, F):
+        np.testing.assert_array_equal(frames[k].view(np.uint32), oracle.sad_flow(fr[k - 1], fr[k], B, R)[0].view(np.uint32))
+    r = json.loads(_tool("stream-bench", 640, 360, 50, "ahead"))
+    assert r["mode"] == "read_ahead" and r["ms_per_frame"] > 0

@@ -216,3 +216,38 @@ def test_hip_push_frame_async_refuses_a_third_frame_in_flight(ctx):
     ctx.reset_frames()
     for b in pins:
         ctx.free_pinned(b)
+
+
+# ---- add_vector_weighted through the C ABI (motion_field.rs:164-178) ---------------------------------------------------
+def test_hip_densify_weighted_matches_oracle_and_hand_value(ctx):
+    e = np.array([[0.5, 0.5, 0.25, -0.5], [0.5, 0.5, 1.0, 2.0]], np.float32)
+    f = ctx.densify_weighted(e, [0.5, 0.25], 3, 3)
+    # counts: eps + .5 + .25 = 0.75000012; sums: .25*.5 = .125, then 1*.25 + .125 = .375 -> .375 / .75000012
+    assert f[1, 1, 0] == np.float32(0.375) / np.float32(0.75000012) and f[1, 1, 1] == np.float32(0.25) / np.float32(0.75000012)
+    rng = np.random.default_rng(3)
+    ent = np.concatenate([rng.uniform(0, 1, (5000, 2)), rng.normal(0, 0.01, (5000, 2))], 1).astype(np.float32)
+    wgt = rng.uniform(0.0, 2.0, 5000).astype(np.float32)
+    got, cells = ctx.densify_weighted(ent, wgt, 14, 14, want_cells=True)
+    np.testing.assert_array_equal(got.view(np.uint32), oracle.densify_weighted(ent, wgt, 14, 14).view(np.uint32))
+    # weights of exactly 1 are add_vector
+    np.testing.assert_array_equal(ctx.densify_weighted(ent, np.ones(5000, np.float32), 14, 14).view(np.uint32),
+                                  ctx.densify(ent, 14, 14).view(np.uint32))
+
+
+def test_hip_ransac_batch_items_draw_different_samples(ctx):
+    """Every item of a batched RANSAC call uses seed + item (the reference draws from thread_rng per call)."""
+    import torch
+    e = synth.rotation_field(120, 68, outlier_frac=0.3)
+    d = torch.from_numpy(np.stack([e, e, e])).cuda()
+    q = torch.empty((3, 4), dtype=torch.float32, device="cuda")
+    ctx.use_torch_stream()
+    try:
+        ctx.almeida_dev(d.data_ptr(), e.shape[0], 3, 16 / 9, 22.275, True, 200, 0.05, 1000, 42, q.data_ptr())
+        torch.cuda.synchronize()
+    finally:
+        ctx.use_own_stream()
+    q = q.cpu().numpy()
+    cam = oracle.camera(16 / 9, 22.275)
+    for b in range(3):                                   # item b == a single call with seed 42 + b, which the oracle reproduces
+        np.testing.assert_allclose(q[b], oracle.solve_ypr_ransac(e, cam, 200, 0.05, 1000, seed=42 + b), atol=1e-4, rtol=0)
+    assert not (np.array_equal(q[0], q[1]) and np.array_equal(q[1], q[2]))
