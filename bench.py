@@ -318,6 +318,19 @@ def end_to_end_leg(frames, W, H, B, R, device, n_frames=300):
            "read_ahead": row(a, entry_points="ofps_hip_push_frame_async + ofps_hip_frame_wait, 2 tickets in flight"),
            "read_ahead_with_host_copy": row(c, includes="a host memcpy of every frame into the next page-locked buffer while the GPU works")}
     ctx.close()
+    # the same two loops in the C++ host layer (ofps_amd/host/ofps_hip_tool stream-bench): no interpreter between the calls
+    try:
+        import subprocess
+        from ofps_amd.build import TOOL
+        if (W, H, B, R) == (1920, 1080, 16, 16) and os.path.exists(TOOL):
+            env = dict(os.environ, HIP_VISIBLE_DEVICES=os.environ.get("HIP_VISIBLE_DEVICES", str(device)))
+            for mode, key in (("sync", "sync_native_host"), ("ahead", "read_ahead_native_host")):
+                r = json.loads(subprocess.run([TOOL, "stream-bench", str(W), str(H), "1000", mode], capture_output=True, text=True,
+                                              timeout=120, env=env, check=True).stdout.strip().splitlines()[-1])
+                out[key] = {"ms_per_frame": r["ms_per_frame"], "Mvectors_per_s": r["Mvectors_per_s"],
+                            "entry_points": "C++ host layer, frames already in page-locked memory"}
+    except Exception as e:                                    # the tool is optional evidence, never the bench line
+        out["native_host_error"] = repr(e)[:200]
     return out
 
 

@@ -18,6 +18,37 @@ struct PipeOut {                 // layout of the pinned read-back block
     float quat[4];
 };
 
+// Device -> page-locked host memory by a kernel (the destination is device-addressable) instead of hipMemcpyAsync: a
+// D2H copy sits in the same in-order DMA queue as the NEXT frame's H2D and -- because it has to wait for this frame's
+// search -- held that upload back until the search was over (rocprofv3 memory-copy trace, ROCm 7.2 runtime): no overlap
+// at all.  The copy kernel runs on the compute stream, where it belongs.
+__global__ __launch_bounds__(256) void pipe_copy_out_kernel(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, size_t n_words) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n_words; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
+
+bool device_can_write(const void* host_ptr, void** dev_ptr) {
+    hipPointerAttribute_t a{};
+    if (hipPointerGetAttributes(&a, host_ptr) != hipSuccess) { (void)hipGetLastError(); return false; }   // pageable memory
+    if (a.type != hipMemoryTypeHost || !a.devicePointer) return false;
+    *dev_ptr = a.devicePointer;
+    return true;
+}
+
+// bytes % 4 == 0.  Page-locked destination: copy kernel; anything else: the DMA engine.
+int pipe_read_back(ofps_hip_ctx* ctx, void* host_dst, const void* dev_src, size_t bytes, hipStream_t s) {
+    void* mapped = nullptr;
+    if (device_can_write(host_dst, &mapped)) {
+        const size_t words = bytes / 4;
+        const unsigned blocks = (unsigned)((words + 255) / 256 < 64 ? (words + 255) / 256 : 64);
+        hipLaunchKernelGGL(pipe_copy_out_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, s, static_cast<const uint32_t*>(dev_src),
+                           static_cast<uint32_t*>(mapped), words);
+        OFPS_HIP_TRY(ctx, hipGetLastError());
+        return OFPS_HIP_OK;
+    }
+    OFPS_HIP_TRY(ctx, hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, s));
+    return OFPS_HIP_OK;
+}
+
 int pipe_setup(ofps_hip_ctx* ctx) {
     if (ctx->pipe_copy_stream) return OFPS_HIP_OK;
     OFPS_HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->pipe_copy_stream, hipStreamNonBlocking));
@@ -165,12 +196,18 @@ int ofps_hip_push_frame_async(ofps_hip_ctx* ctx, const uint8_t* luma, int W, int
                                   prm->inlier_deg, prm->num_samples, prm->seed, d_quat);
         if (rc != OFPS_HIP_OK) return rc;
     }
-    if (prm->run_detector || prm->run_estimator)
-        OFPS_HIP_TRY(ctx, hipMemcpyAsync(t.pinned, d_out, sizeof(PipeOut), hipMemcpyDeviceToHost, s));
-    if (out_entries && nblk)
-        OFPS_HIP_TRY(ctx, hipMemcpyAsync(out_entries, d_ent, nblk * sizeof(float4), hipMemcpyDeviceToHost, s));
-    if (out_field && prm->run_detector)
-        OFPS_HIP_TRY(ctx, hipMemcpyAsync(out_field, d_field, (size_t)dim * dim * sizeof(float2), hipMemcpyDeviceToHost, s));
+    if (prm->run_detector || prm->run_estimator) {
+        rc = pipe_read_back(ctx, t.pinned, d_out, sizeof(PipeOut), s);
+        if (rc != OFPS_HIP_OK) return rc;
+    }
+    if (out_entries && nblk) {
+        rc = pipe_read_back(ctx, out_entries, d_ent, nblk * sizeof(float4), s);
+        if (rc != OFPS_HIP_OK) return rc;
+    }
+    if (out_field && prm->run_detector) {
+        rc = pipe_read_back(ctx, out_field, d_field, (size_t)dim * dim * sizeof(float2), s);
+        if (rc != OFPS_HIP_OK) return rc;
+    }
     OFPS_HIP_TRY(ctx, hipEventRecord(t.done, s));
     t.pending = true;
     *ticket = (int)(tno & 0x7FFFFFFF);
