@@ -88,6 +88,7 @@ def lib():
         L.orc_masked_flow_to_entries.argtypes = [fp, C.POINTER(C.c_uint8), C.c_int, C.c_int, fp]
         L.orc_masked_flow_to_entries.restype = C.c_size_t
         L.orc_num_threads.restype = C.c_int
+        L.orc_sad_simd_level.restype = C.c_int
         _lib = L
     return _lib
 
@@ -315,6 +316,11 @@ def masked_flow_to_entries(flow, mask=None) -> np.ndarray:
     m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
     n = lib().orc_masked_flow_to_entries(_fp(f), None if m is None else m.ctypes.data_as(C.POINTER(C.c_uint8)), W, H, _fp(out))
     return out[:n].copy()
+
+
+def sad_simd_level() -> str:
+    """Inner loop the timed CPU baseline uses on this host (run-time dispatch)."""
+    return {2: "avx2 vmpsadbw (8 candidates per instruction)", 1: "sse2 psadbw", 0: "scalar"}[int(lib().orc_sad_simd_level())]
 
 
 def num_threads() -> int:

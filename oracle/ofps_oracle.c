@@ -19,6 +19,7 @@
 #endif
 #if defined(__SSE2__)
 #include <emmintrin.h>
+#include <immintrin.h>
 #endif
 
 /* f32::to_radians: self * (PI / 180) with the ratio folded in f32 (Rust core). */
@@ -739,17 +740,87 @@ static uint32_t sad_candidate(const uint8_t* c, const uint8_t* p, int stride, in
     return sad;
 }
 
+/* ---- AVX2 inner loop for the timed CPU baseline (16x16 blocks): vmpsadbw evaluates EIGHT consecutive dx candidates
+ * of a 4-byte column group per instruction -- the instruction x264-class encoders build their full search on -- with
+ * two block rows per 256-bit register.  Exact integer arithmetic (16x16 SAD <= 65,280 fits the u16 accumulators), so
+ * it returns the spec's numbers; selected at run time (__builtin_cpu_supports), SSE2 psadbw otherwise.
+ * out[i] = SAD of the block at `cur` against the block at prev + i, i = 0..7; reads prev[0 .. 23] of every row. */
+#if defined(__x86_64__)
+__attribute__((target("avx2")))
+static void sad16_dx8_avx2(const __m256i crow[8], const uint8_t* prev, int stride, uint16_t out[8]) {
+    __m256i acc = _mm256_setzero_si256();
+    for (int y = 0; y < 8; ++y) {                                       /* row pair 2y, 2y+1 */
+        const uint8_t* p0 = prev + (size_t)(2 * y) * stride;
+        const uint8_t* p1 = p0 + stride;
+        const __m256i b0 = _mm256_inserti128_si256(_mm256_castsi128_si256(_mm_loadu_si128((const __m128i*)p0)),
+                                                   _mm_loadu_si128((const __m128i*)p1), 1);           /* bytes 0..15 */
+        const __m256i b1 = _mm256_inserti128_si256(_mm256_castsi128_si256(_mm_loadu_si128((const __m128i*)(p0 + 8))),
+                                                   _mm_loadu_si128((const __m128i*)(p1 + 8)), 1);     /* bytes 8..23 */
+        /* imm per lane: bit 2 = window offset 4 in the first operand, bits 1:0 = 4-byte group of the second */
+        acc = _mm256_add_epi16(acc, _mm256_mpsadbw_epu8(b0, crow[y], 0x00));      /* columns  0.. 3 */
+        acc = _mm256_add_epi16(acc, _mm256_mpsadbw_epu8(b0, crow[y], 0x2D));      /* columns  4.. 7 */
+        acc = _mm256_add_epi16(acc, _mm256_mpsadbw_epu8(b1, crow[y], 0x12));      /* columns  8..11 */
+        acc = _mm256_add_epi16(acc, _mm256_mpsadbw_epu8(b1, crow[y], 0x3F));      /* columns 12..15 */
+    }
+    const __m128i s = _mm_add_epi16(_mm256_castsi256_si128(acc), _mm256_extracti128_si256(acc, 1));
+    _mm_storeu_si128((__m128i*)out, s);
+}
+__attribute__((target("avx2")))
+static void load_cur16_avx2(const uint8_t* c, int stride, __m256i crow[8]) {
+    for (int y = 0; y < 8; ++y)
+        crow[y] = _mm256_inserti128_si256(_mm256_castsi128_si256(_mm_loadu_si128((const __m128i*)(c + (size_t)(2 * y) * stride))),
+                                          _mm_loadu_si128((const __m128i*)(c + (size_t)(2 * y + 1) * stride)), 1);
+}
+static int sad_have_avx2(void) {
+    static int have = -1;
+    if (have < 0) have = __builtin_cpu_supports("avx2") ? 1 : 0;
+    return have;
+}
+#else
+static int sad_have_avx2(void) { return 0; }
+#endif
+
+/* what the timed baseline runs on this host: 2 = AVX2 vmpsadbw, 1 = SSE2 psadbw, 0 = scalar */
+int orc_sad_simd_level(void) {
+#if defined(__SSE2__)
+    return sad_have_avx2() ? 2 : 1;
+#else
+    return 0;
+#endif
+}
+
 static void sad_block_run(const uint8_t* prev, const uint8_t* cur, int W, int H, int stride,
                           int B, int R, int by, int bx_begin, int bx_end, int nbx, float* out_entries,
                           int32_t* out_best, int simd) {
     const float nx = 1.0f / (float)W, ny = 1.0f / (float)H;          /* av-decoder/src/lib.rs:404-405 */
+    const int wide = simd && B == 16 && sad_have_avx2();
     for (int bx = bx_begin; bx < bx_end; ++bx) {
         int x0 = bx * B, y0 = by * B;
         uint64_t best_key = ~0ull; int best_dx = 0, best_dy = 0; uint32_t best_sad = 0;
+#if defined(__x86_64__)
+        __m256i crow[8];
+        if (wide) load_cur16_avx2(cur + (size_t)y0 * stride + x0, stride, crow);
+#endif
         for (int dy = -R; dy <= R; ++dy) {
             if (y0 + dy < 0 || y0 + dy + B > H) continue;
             for (int dx = -R; dx <= R; ++dx) {
                 if (x0 + dx < 0 || x0 + dx + B > W) continue;
+#if defined(__x86_64__)
+                /* eight candidates dx .. dx+7 at once when all of them are valid and the 24-byte row reads stay inside
+                 * the frame row; the argmin key is a total order, so the evaluation order does not matter */
+                if (wide && dx + 7 <= R && x0 + dx + 7 + B <= W && x0 + dx + 24 <= W) {
+                    uint16_t s8[8];
+                    sad16_dx8_avx2(crow, prev + (size_t)(y0 + dy) * stride + x0 + dx, stride, s8);
+                    for (int i = 0; i < 8; ++i) {
+                        const int d = dx + i;
+                        const uint64_t key = ((uint64_t)s8[i] << 32) | ((uint64_t)(uint32_t)(d * d + dy * dy) << 16) |
+                                             ((uint64_t)(uint32_t)(dy + R) << 8) | (uint64_t)(uint32_t)(d + R);
+                        if (key < best_key) { best_key = key; best_dx = d; best_dy = dy; best_sad = s8[i]; }
+                    }
+                    dx += 7;
+                    continue;
+                }
+#endif
                 uint32_t sad = sad_candidate(cur + (size_t)y0 * stride + x0,
                                              prev + (size_t)(y0 + dy) * stride + x0 + dx, stride, B, simd);
                 uint64_t key = ((uint64_t)sad << 32) | ((uint64_t)(uint32_t)(dx * dx + dy * dy) << 16) |

@@ -113,6 +113,7 @@ uint32_t orc_sample_index(uint64_t seed, uint32_t iter, uint32_t stream, uint32_
  * (SAD, dx*dx+dy*dy, dy+R, dx+R) lexicographic.  out_entries: 4 floats per block, raster
  * order; out_best (optional): 3 int32 per block (dx, dy, sad).  Returns number of blocks.
  * threads <= 1 -> scalar single thread; otherwise OpenMP over block rows. */
+int orc_sad_simd_level(void);   /* inner loop of the timed baseline on this host: 2 = AVX2 vmpsadbw, 1 = SSE2 psadbw, 0 = scalar */
 size_t orc_sad_flow(const uint8_t* prev, const uint8_t* cur, int W, int H, int stride,
                     int B, int R, float* out_entries, int32_t* out_best, int threads);
 
