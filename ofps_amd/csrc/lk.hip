@@ -527,7 +527,9 @@ int lk_flow_device(ofps_hip_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_cu
     ws[0] = W; hs[0] = H; off[0] = 0;
     for (int l = 1; l < levels; ++l) { ws[l] = (ws[l - 1] + 1) / 2; hs[l] = (hs[l - 1] + 1) / 2; }
     for (int l = 0; l < levels; ++l) off[l + 1] = off[l] + (size_t)ws[l] * hs[l];
-    const size_t plane0 = (size_t)W * H, pyr = off[levels];
+    // every segment is rounded up to a multiple of 4 floats so that G (float4) and the flow planes (float2) stay
+    // naturally aligned inside the workspace whatever the frame size
+    const size_t plane0 = ((size_t)W * H + 3) & ~size_t(3), pyr = (off[levels] + 3) & ~size_t(3);
     // layout: I pyramid | J pyramid | gx | gy | G (float4) | flowA (float2) | flowB (float2)
     const size_t floats = 2 * pyr + 2 * plane0 + 4 * plane0 + 2 * plane0 + 2 * plane0;
     auto* base = static_cast<float*>(scratch(ctx, S_WORK0, floats * sizeof(float)));

@@ -922,7 +922,7 @@ int launch_pde_16_16(ofps_hip_ctx* ctx, const SadParams& p, int pairs, hipStream
     using C = StripCfg<16, 16>;
     const int strips_per_row = (p.nbx + C::NB - 1) / C::NB;
     const int total = strips_per_row * p.nby * pairs;
-    auto* strip_list = static_cast<uint32_t*>(ofps::scratch(ctx, ofps::S_WORK0, (size_t)(total + 1) * sizeof(uint32_t)));
+    auto* strip_list = static_cast<uint32_t*>(ofps::scratch(ctx, ofps::S_SAD_LIST, (size_t)(total + 1) * sizeof(uint32_t)));
     if (!strip_list) return OFPS_HIP_ENOMEM;
     OFPS_HIP_TRY(ctx, hipMemsetAsync(strip_list, 0, sizeof(uint32_t), s));
     const int nwg = ((total + kStripWaves - 1) / kStripWaves + 7) / 8 * 8;     // multiple of 8: see the XCD remap
@@ -1064,7 +1064,7 @@ int ofps_hip_sad_flow(ofps_hip_ctx* ctx, const uint8_t* prev, const uint8_t* cur
 int ofps_hip_sad_pruned_overflow_strips(ofps_hip_ctx* ctx, uint32_t* count) {
     if (!ctx || !count) return OFPS_HIP_EINVAL;
     *count = 0;
-    auto& sc = ctx->scratch[ofps::S_WORK0];
+    auto& sc = ctx->scratch[ofps::S_SAD_LIST];            // its own slot: no other stage writes here between the search and this read
     if (!sc.p) return OFPS_HIP_OK;
     OFPS_HIP_TRY(ctx, hipSetDevice(ctx->device));
     OFPS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

@@ -482,7 +482,8 @@ def test_push_frame_matches_stagewise_oracle(ctx):
 
 # ------------------------------------------------------------------ N2: dense pyramidal LK flow
 @pytest.mark.parametrize("W,H,levels,radius,iters", [(160, 96, 3, 4, 3), (97, 61, 2, 2, 2), (64, 48, 1, 6, 4), (320, 180, 3, 4, 3),
-                                                   (80, 60, 2, 3, 2), (50, 40, 1, 5, 1), (70, 50, 2, 9, 1)])   # odd radii: run-time-radius kernels
+                                                   (80, 60, 2, 3, 2), (50, 40, 1, 5, 1), (70, 50, 2, 9, 1),
+                                                   (101, 101, 3, 4, 2)])   # pyramid + plane sizes odd: workspace segments need padding to stay 16-byte aligned   # odd radii: run-time-radius kernels
 def test_lk_flow_bit_exact_vs_oracle(ctx, W, H, levels, radius, iters):
     """hip_lk == the build's CPU restatement, same bits (the algorithm itself is build-defined: the reference calls
     OpenCV's Farneback, cv-decoder/src/lib.rs:188-199 -> parity unpinned w.r.t. the reference)."""
