@@ -344,9 +344,9 @@ __global__ __launch_bounds__(1024) void almeida_lsq_wg_kernel(const float4* __re
         if (threadIdx.x == 0) out_quat[item] = make_float4(1.0f, 0.0f, 0.0f, 0.0f);
         return;
     }
-    const Mat3 mroll = mat3_from_euler(0.0f, eps, 0.0f);           // lib.rs:30-34
-    const Mat3 mpitch = mat3_from_euler(eps, 0.0f, 0.0f);          // lib.rs:36-38
-    const Mat3 myaw = mat3_from_euler(0.0f, 0.0f, -eps);           // lib.rs:40-42
+    const Mat3 mroll = mat3_uniform(mat3_from_euler(0.0f, eps, 0.0f));     // lib.rs:30-34 (wave-uniform: scalar registers)
+    const Mat3 mpitch = mat3_uniform(mat3_from_euler(eps, 0.0f, 0.0f));    // lib.rs:36-38
+    const Mat3 myaw = mat3_uniform(mat3_from_euler(0.0f, 0.0f, -eps));     // lib.rs:40-42
     float4 e[EPT];
     float2 pr[P_LDS ? 1 : EPT], pp[P_LDS ? 1 : EPT], py[EPT];
     float uwx[EPT], uwz[EPT];                                       // Unproj::wy = -1/n0 is the same for every entry
@@ -375,14 +375,16 @@ __global__ __launch_bounds__(1024) void almeida_lsq_wg_kernel(const float4* __re
         }
     }
     block_sum<0, 6>(s, red);
-    float a[6];
+    __shared__ float a_sh[6];                                      // A leaves the registers: it would stay live through all 30 steps
+    if (threadIdx.x == 0) {
 #pragma unroll
-    for (int k = 0; k < 6; ++k) a[k] = s[k];                       // valid in thread 0, which is the only reader
+        for (int k = 0; k < 6; ++k) a_sh[k] = s[k];
+    }
     __syncthreads();
     Quat rotation = {1.0f, 0.0f, 0.0f, 0.0f};
     for (int it = 0; it < kIters; ++it) {
         const float alpha = (it == kIters - 1) ? 1.0f : 0.5f;      // lib.rs:138
-        const Mat3 rotm = quat_to_mat3(rotation);                  // lib.rs:140
+        const Mat3 rotm = mat3_uniform(quat_to_mat3(rotation));    // lib.rs:140
         s[6] = 0.0f; s[7] = 0.0f; s[8] = 0.0f;
 #pragma unroll
         for (int t = 0; t < EPT; ++t) {
@@ -399,9 +401,8 @@ __global__ __launch_bounds__(1024) void almeida_lsq_wg_kernel(const float4* __re
         }
         block_sum<6, 9>(s, red);
         if (threadIdx.x == 0) {
-#pragma unroll
-            for (int k = 0; k < 6; ++k) s[k] = a[k];
-            rot_sh[it & 1] = almeida_update(rotation, s, eps, alpha);
+            const float f[9] = {a_sh[0], a_sh[1], a_sh[2], a_sh[3], a_sh[4], a_sh[5], s[6], s[7], s[8]};
+            rot_sh[it & 1] = almeida_update(rotation, f, eps, alpha);
         }
         __syncthreads();
         // one barrier per step: the slot alternates, so thread 0 cannot overwrite a rotation that a slow wave has yet

@@ -25,7 +25,7 @@ def main():
         if t.startswith("Function Name:"):
             name = t.split(":", 1)[1].strip()
             dem = subprocess.run(["c++filt", name], capture_output=True, text=True).stdout.strip()
-            cur = {"name": re.sub(r"\(.*", "", dem).replace("void ofps::", "")}
+            cur = {"name": re.sub(r"\((?!anonymous).*", "", dem.replace("(anonymous namespace)::", "")).replace("void ", "").replace("ofps::", "")}
             rows.append(cur)
         elif cur is not None and ":" in t:
             k, v = t.split(":", 1)
