@@ -14,6 +14,8 @@
 // bilinear sampling -- no contraction wide enough for MFMA (the normal equations are 2x2 per pixel).
 #include "common.hpp"
 
+#include <vector>
+
 namespace ofps {
 
 __device__ __forceinline__ int lk_clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
@@ -309,9 +311,13 @@ __global__ __launch_bounds__(256) void lk_step_lds_kernel(const float* __restric
                                                           const float* __restrict__ gx, const float* __restrict__ gy,
                                                           const float4* __restrict__ G, int w, int h,
                                                           const float2* __restrict__ flow_in, float2* __restrict__ flow_out,
-                                                          uint32_t* __restrict__ fb_count, uint32_t* __restrict__ fb_tiles) {
+                                                          uint32_t* __restrict__ fb_count, uint32_t* __restrict__ fb_tiles,
+                                                          unsigned long long* __restrict__ prof) {
+    // prof (diagnostics, normally null): per-workgroup s_memtime stamps at the phase boundaries
+#define OFPS_LK_STAMP(slot) do { if (prof && threadIdx.x == 0) prof[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 6 + (slot)] = __builtin_readcyclecounter(); } while (0)
     using T = LkTile<RADIUS>;
     using S = LkStepShared<RADIUS>;
+    OFPS_LK_STAMP(0);
     constexpr int N = T::N;
     __shared__ S sh;
     const int x0 = blockIdx.x * 64, y0 = blockIdx.y * 4;
@@ -338,7 +344,9 @@ __global__ __launch_bounds__(256) void lk_step_lds_kernel(const float* __restric
         by0 = lk_wave_minmax<false>(by0); by1 = lk_wave_minmax<true>(by1);
         if (lx == 0) { sh.box[ly][0] = bx0; sh.box[ly][1] = bx1; sh.box[ly][2] = by0; sh.box[ly][3] = by1; }
     }
+    OFPS_LK_STAMP(1);
     __syncthreads();
+    OFPS_LK_STAMP(2);
     const int xmin = min(min(sh.box[0][0], sh.box[1][0]), min(sh.box[2][0], sh.box[3][0]));
     const int xmax = max(max(sh.box[0][1], sh.box[1][1]), max(sh.box[2][1], sh.box[3][1]));
     const int ymin = min(min(sh.box[0][2], sh.box[1][2]), min(sh.box[2][2], sh.box[3][2]));
@@ -362,6 +370,7 @@ __global__ __launch_bounds__(256) void lk_step_lds_kernel(const float* __restric
         }
     }
     __syncthreads();
+    OFPS_LK_STAMP(3);
     if (!active) return;
     // hup[k] = horizontal interpolation of the UPPER sample row at column k.  The lower row of one window row is the
     // upper row of the next whenever the sample row advanced by exactly one (always, away from the top/bottom
@@ -432,7 +441,10 @@ __global__ __launch_bounds__(256) void lk_step_lds_kernel(const float* __restric
             }
         }
     }
+    OFPS_LK_STAMP(4);
     lk_solve_store(G, f, bx, by, (size_t)y * w + x, flow_out);
+    OFPS_LK_STAMP(5);
+#undef OFPS_LK_STAMP
 }
 
 // second launch: the listed tiles, per-lane gathers from global memory with register reuse (inside a window row j10 of
@@ -555,6 +567,11 @@ int lk_flow_device(ofps_hip_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_cu
     if (!fb_count) return OFPS_HIP_ENOMEM;
     uint32_t* fb_tiles = fb_count + n_steps;
     OFPS_HIP_TRY(ctx, hipMemsetAsync(fb_count, 0, n_steps * sizeof(uint32_t), s));
+    unsigned long long* prof = nullptr;                           // OFPS_HIP_LK_PROF=1: phase table of the first level-0 step
+    if (getenv("OFPS_HIP_LK_PROF")) {
+        prof = static_cast<unsigned long long*>(scratch(ctx, S_WORK2, tiles0 * 6 * sizeof(unsigned long long)));
+        if (!prof) return OFPS_HIP_ENOMEM;
+    }
     float2* cur_flow = fa;
     float2* other = fb;
     for (int l = levels - 1; l >= 0; --l) {
@@ -580,7 +597,8 @@ int lk_flow_device(ofps_hip_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_cu
             const unsigned ntiles = g.x * g.y;
             const dim3 gg(ntiles < (unsigned)(8 * ctx->num_cus) ? ntiles : (unsigned)(8 * ctx->num_cus));
 #define OFPS_LK_STEP(R)                                                                                                           \
-    hipLaunchKernelGGL(lk_step_lds_kernel<R>, g, dim3(256), 0, s, Ip + off[l], Jp + off[l], gx, gy, G, w, h, cur_flow, dst, cnt, tiles); \
+    hipLaunchKernelGGL(lk_step_lds_kernel<R>, g, dim3(256), 0, s, Ip + off[l], Jp + off[l], gx, gy, G, w, h, cur_flow, dst, cnt, tiles, \
+                       (l == 0 && it == 0) ? prof : nullptr); \
     hipLaunchKernelGGL(lk_step_general_kernel<R>, gg, dim3(256), 0, s, Ip + off[l], Jp + off[l], gx, gy, G, w, h, cur_flow, dst, cnt, tiles)
             switch (radius) {
                 case 2: OFPS_LK_STEP(2); break;
@@ -593,6 +611,21 @@ int lk_flow_device(ofps_hip_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_cu
         }
     }
     OFPS_HIP_TRY(ctx, hipGetLastError());
+    if (prof) {
+        std::vector<unsigned long long> hst(tiles0 * 6);
+        OFPS_HIP_TRY(ctx, hipMemcpyAsync(hst.data(), prof, hst.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+        OFPS_HIP_TRY(ctx, hipStreamSynchronize(s));
+        double ph[5] = {0, 0, 0, 0, 0};
+        unsigned long long t_min = ~0ull, t_max = 0;
+        for (size_t b = 0; b < tiles0; ++b) {
+            const unsigned long long* r = hst.data() + b * 6;
+            for (int k = 0; k < 5; ++k) ph[k] += (double)(r[k + 1] - r[k]);
+            t_min = r[0] < t_min ? r[0] : t_min; t_max = r[5] > t_max ? r[5] : t_max;
+        }
+        fprintf(stderr, "[lk prof] level-0 step, %zu tiles: cycles per workgroup  stage-tile+origins %.0f  barrier %.0f  stage-J %.0f  "
+                        "rows %.0f  solve+store %.0f   kernel span %.0f cycles\n", tiles0, ph[0] / tiles0, ph[1] / tiles0, ph[2] / tiles0,
+                ph[3] / tiles0, ph[4] / tiles0, (double)(t_max - t_min));
+    }
     return OFPS_HIP_OK;
 }
 
