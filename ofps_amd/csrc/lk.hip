@@ -231,6 +231,27 @@ template <int RADIUS>
 __device__ __forceinline__ void lk_stage3(const float* __restrict__ p0, const float* __restrict__ p1, const float* __restrict__ p2,
                                           float4 (*tile)[LkTile<RADIUS>::TW], int w, int h, int x0, int y0) {
     using T = LkTile<RADIUS>;
+    // interior tiles of 16-byte aligned planes: 16-byte loads (a quarter of the memory requests -- the staging phases
+    // are queueing-latency bound: 8k + 5.7k of the 29k cycles a workgroup lives, OFPS_HIP_LK_PROF).  Uniform branch.
+    if constexpr (T::TW % 4 == 0 && T::R % 4 == 0) {
+        const bool vec = x0 - T::R >= 0 && x0 - T::R + T::TW <= w && (w & 3) == 0 &&
+                         ((reinterpret_cast<uintptr_t>(p0) | reinterpret_cast<uintptr_t>(p1) | reinterpret_cast<uintptr_t>(p2)) & 15) == 0;
+        if (vec) {
+            constexpr int Q = T::TW / 4;                              // float4 per window row
+            for (int t = threadIdx.x; t < Q * T::TH; t += 256) {
+                const int row = t / Q, c4 = t - row * Q;
+                const size_t g = (size_t)lk_clampi(y0 - T::R + row, 0, h - 1) * w + (x0 - T::R + 4 * c4);
+                const float4 a = *reinterpret_cast<const float4*>(p0 + g);
+                const float4 b = *reinterpret_cast<const float4*>(p1 + g);
+                const float4 c = *reinterpret_cast<const float4*>(p2 + g);
+                tile[row][4 * c4 + 0] = make_float4(a.x, b.x, c.x, 0.0f);
+                tile[row][4 * c4 + 1] = make_float4(a.y, b.y, c.y, 0.0f);
+                tile[row][4 * c4 + 2] = make_float4(a.z, b.z, c.z, 0.0f);
+                tile[row][4 * c4 + 3] = make_float4(a.w, b.w, c.w, 0.0f);
+            }
+            return;
+        }
+    }
     constexpr int ROWS_PER_PASS = 256 / T::TW;
     const int tx = threadIdx.x % T::TW, ty0 = threadIdx.x / T::TW;
     if (ty0 >= ROWS_PER_PASS) return;
@@ -280,7 +301,8 @@ struct LkStepShared {
     // a tile really needs is staged, so the capacity costs LDS space, not time
     static constexpr int SPREAD = 20, LW = T::TW + 1 + SPREAD, LH = T::TH + 1 + SPREAD;
     float4 tile[T::TH][T::TW];         // (I, gx, gy, -) of the previous frame's window
-    float jl[LH][LW + 1];
+    static constexpr int JS = (LW + 4) / 4 * 4;     // row stride in floats: a multiple of 4, so rows start 16-byte aligned
+    alignas(16) float jl[LH][JS];
     int box[4][4];                     // per wave: min x0, max x0+1, min y0, max y0+1
 };
 
@@ -360,13 +382,28 @@ __global__ __launch_bounds__(256) void lk_step_lds_kernel(const float* __restric
     // border, where the clamped window columns repeat) share one row of N+1 texels; otherwise every column reads its
     // own pair.  Uniform over the workgroup.
     const bool all_consecutive = __syncthreads_and(consecutive || !active);
+    // rows [ymin, ymax] x columns [xs, xmax] of the current frame, xs = xmin rounded down to a multiple of 4 when the
+    // padded rectangle lies inside the frame and the plane is 16-byte aligned (16-byte loads), xmin otherwise
+    int xs = xmin;
     {
-        // rows [ymin, ymax] x columns [xmin, xmax] of the current frame; 128 threads per row, two rows per pass
-        const int cw = xmax - xmin + 1, chh = ymax - ymin + 1;
-        const int cx = threadIdx.x & 127, cy0 = threadIdx.x >> 7;
-        if (cx < cw) {
-            const int gxc = lk_clampi(xmin + cx, 0, w - 1);
-            for (int cy = cy0; cy < chh; cy += 2) sh.jl[cy][cx] = J[(size_t)lk_clampi(ymin + cy, 0, h - 1) * w + gxc];
+        const int chh = ymax - ymin + 1;
+        const int xa4 = xmin & ~3, cw4 = (xmax - xa4 + 4) >> 2;                      // float4 per row after padding
+        const bool vec = xmin >= 0 && xa4 + 4 * cw4 <= w && 4 * cw4 <= S::JS && (w & 3) == 0 &&
+                         (reinterpret_cast<uintptr_t>(J) & 15) == 0;
+        if (vec) {                                                   // uniform
+            xs = xa4;
+            for (int t = threadIdx.x; t < cw4 * chh; t += 256) {
+                const int cy = t / cw4, c4 = t - cy * cw4;
+                *reinterpret_cast<float4*>(&sh.jl[cy][4 * c4]) =
+                    *reinterpret_cast<const float4*>(J + (size_t)lk_clampi(ymin + cy, 0, h - 1) * w + xa4 + 4 * c4);
+            }
+        } else {
+            const int cw = xmax - xmin + 1;
+            const int cx = threadIdx.x & 127, cy0 = threadIdx.x >> 7;            // 128 threads per row, two rows per pass
+            if (cx < cw) {
+                const int gxc = lk_clampi(xmin + cx, 0, w - 1);
+                for (int cy = cy0; cy < chh; cy += 2) sh.jl[cy][cx] = J[(size_t)lk_clampi(ymin + cy, 0, h - 1) * w + gxc];
+            }
         }
     }
     __syncthreads();
@@ -382,7 +419,7 @@ __global__ __launch_bounds__(256) void lk_step_lds_kernel(const float* __restric
     float hup[N];
     int prev_yi = -0x7FFFFFFF;
     if (all_consecutive) {
-        const int xo = xi[0] - xmin;
+        const int xo = xi[0] - xs;
         float jb[N + 1];
         // (measured and rejected: unrolling the row loop, fully or by two with ping-pong hup arrays -- hipcc then hoists
         // the next row's LDS reads, 104+ VGPRs, 4 waves per SIMD, 0.53 vs 0.50 ms)
@@ -415,7 +452,7 @@ __global__ __launch_bounds__(256) void lk_step_lds_kernel(const float* __restric
         }
     } else {
 #pragma unroll
-        for (int k = 0; k < N; ++k) xi[k] -= xmin;
+        for (int k = 0; k < N; ++k) xi[k] -= xs;
 #pragma unroll 1
         for (int r = 0; r < N; ++r) {
             float ay;
