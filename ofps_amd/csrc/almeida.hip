@@ -968,11 +968,22 @@ static void launch_cluster(hipStream_t s, int nblk, int items, const float4* d_e
 
 // -> 1 launched, 0 not applicable (caller falls back to the launch-per-step kernel), < 0 error
 static int lsq_cluster(ofps_hip_ctx* ctx, const float4* d_entries, size_t n, int batch, const Camera& cam, float4* d_quat) {
-    // records per thread: fewer = less arithmetic per step on the critical path, more = fewer workgroups to gather from.
-    // With 16-byte granules the gather is cheap (1.5 us at 254 workgroups), so the smallest count that keeps the
-    // problem within one workgroup per CU wins at every size (tools/almeida_prof.py)
-    int ept = n > 1024 * 1024 ? 8 : (n > 512 * 1024 ? 4 : (n > 254 * 1024 ? 2 : 1));
-    if (const char* f = getenv("OFPS_HIP_ALMEIDA_EPT")) { const int v = atoi(f); if (v == 1 || v == 2 || v == 4 || v == 8) ept = v; }
+    // records per thread: fewer = less arithmetic per step on the critical path, more = fewer workgroups to gather from
+    // and -- for batches -- more items whose workgroups are co-resident in one launch.  Cost model fitted to
+    // tools/almeida_prof.py (ms per launch ~ 0.11 + 0.0085 * ept + 0.00022 * workgroups per item); the count that
+    // minimises launches x cost wins (lone problems: the smallest that fits; 64 x 129,600 vectors: 8 -> 4 launches).
+    int ept = 8;
+    {
+        double best = 1e30;
+        for (int e : {1, 2, 4, 8}) {
+            const size_t nb = (n + (size_t)e * 1024 - 1) / ((size_t)e * 1024);
+            if (nb < 1 || nb > 256 || nb > (size_t)ctx->num_cus) continue;
+            const int per = ctx->num_cus / (int)nb;
+            const double cost = (double)((batch + per - 1) / per) * (0.11 + 0.0085 * e + 0.00022 * (double)nb);
+            if (cost < best) { best = cost; ept = e; }
+        }
+    }
+    if (const char* f = getenv("OFPS_HIP_ALMEIDA_EPT")) { const int v = atoi(f); if (v == 1 || v == 2 || v == 4 || v == 8) ept = v; }   // A/B
     const size_t per_wg = (size_t)ept * 1024;
     const size_t nblk_sz = (n + per_wg - 1) / per_wg;
     if (nblk_sz < 1 || nblk_sz > 256 || nblk_sz > (size_t)ctx->num_cus) return 0;

@@ -104,7 +104,7 @@ def main():
     # --- the estimator input cv-decoder really produces in full-resolution mode: <= 150 x 84 down-sampled records
     e84 = torch.from_numpy(synth.rotation_field(150, 84)).cuda()
     ms = timeit(lambda: ctx.almeida_dev(e84.data_ptr(), 150 * 84, 1, 16 / 9, 22.275, False, 0, 0.05, 0, 0, q1.data_ptr()), n=10, warm=2)
-    out["almeida_lsq_12600_downsampled_records"] = {"ms": round(ms, 4), "note": "N > 8192: one launch per step, IEEE division"}
+    out["almeida_lsq_12600_downsampled_records"] = {"ms": round(ms, 4), "note": "cluster solver (13 workgroups, granule exchange), IEEE division"}
     ms = timeit(lambda: ctx.almeida_dev(e84.data_ptr(), 150 * 84, 1, 16 / 9, 22.275, True, 200, 0.05, 1000, 3, q1.data_ptr()), n=10, warm=2)
     out["almeida_ransac_12600_downsampled_records"] = {"ms": round(ms, 4)}
     # --- cfg3 from pixels: 1080p pair -> 3-level LK flow (r=4, 3 steps/level) -> per-pixel records -> densify -> Almeida
