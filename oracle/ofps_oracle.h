@@ -6,15 +6,21 @@
  * tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may link or call it;
  * the product path (libofps_hip.so) never does.
  *
- * PARITY STATUS
- *   - Almeida estimator + StandardCamera: pinned by the reference's own known-answer test
- *     (almeida-estimator/src/lib.rs:253-373, 32 rotations, error < 10% of the rotation)
- *     and the point_angle doctest (ofps/src/camera.rs:139-149); see tests/test_oracle.py.
- *   - MotionFieldDensifier, BlockMotionDetection: the reference holds no test or fixture
- *     for them -> "parity unpinned" by the reference; pinned here only by a second,
- *     independent NumPy restatement (oracle/np_oracle.py) and committed golden vectors.
- *   - SAD full-search block matcher: NO reference counterpart;
- *     the spec is defined in DESIGN.md ("N1") -> "parity unpinned".
+ * PARITY STATUS (tests/test_reference_vectors.py, tests/test_oracle.py)
+ *   - StandardCamera::delta (A6-A8): pinned by REFERENCE-HELD vectors -- the seven 144-row tables of
+ *     docs/report/mfield/*.csv are reproduced to 1.5e-6 (camera 16/9, 99 deg; the divide by NDC z of
+ *     camera.rs:77 included) -- plus the point_angle doctest (ofps/src/camera.rs:139-149).
+ *   - Almeida estimator (A9-A12): the reference's own known-answer test (almeida-estimator/src/lib.rs:253-373,
+ *     32 rotations, error < 10 % of the rotation) on fields built by the oracle AND by an independent float64 model;
+ *     the planted rotation of the reference-held base.csv recovered to 0.01 deg; the report-time iteration
+ *     (este.csv, 0..4.csv: alpha 0.3, 5 steps, order yaw*pitch*roll) reproduced to the f32 noise of the
+ *     eps-prototypes (4e-4) through orc_almeida_model.  Not bit-pinned: no Rust toolchain, and the reference's
+ *     RANSAC is unseeded.
+ *   - MotionFieldDensifier, BlockMotionDetection (A1-A5): the reference holds no test or fixture for them ->
+ *     "parity unpinned" by the reference; pinned by hand-derived literals (cells + f32 bit patterns written from the
+ *     Rust text), a second, independent NumPy restatement (oracle/np_oracle.py) and committed golden vectors.
+ *   - SAD full-search block matcher, pyramidal LK: NO reference counterpart;
+ *     the specs are defined in DESIGN.md ("N1", "N2") -> "parity unpinned".
  *   The Rust reference cannot be built here (no rustc/cargo), so no oracle/_ref exists.
  *
  * Matrices are row-major float[16] / float[9].  Quaternions are (w, i, j, k).
