@@ -218,11 +218,15 @@ __device__ __forceinline__ void lk_stage(const float* const (&src)[PLANES], floa
 }
 
 // One whole 16-byte LDS read (ds_read_b128: 4 LDS cycles per wave).  Left to itself the compiler narrows a float4 read
-// whose .w is unused to ds_read_b96, which takes 8.
+// whose .w is unused to ds_read_b96, which takes 8; an empty asm statement that "uses" .w keeps the read whole without
+// making it volatile (a volatile read is issued right before its use and waited for on the spot: nine exposed LDS
+// latencies per window row).
 typedef float lk_f4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ lk_f4 lk_lds_read4(const float4* p) {        // p must point into __shared__ memory
-    typedef const volatile __attribute__((address_space(3))) lk_f4* lds_ptr;
-    return *(lds_ptr)(p);
+__device__ __forceinline__ lk_f4 lk_lds_read4(const float4* p) {
+    const float4 v = *p;
+    asm volatile("" :: "v"(v.w));
+    lk_f4 r = {v.x, v.y, v.z, v.w};
+    return r;
 }
 
 // The step kernel's three window planes interleaved: one 16-byte LDS read per tap instead of three 4-byte ones
