@@ -37,7 +37,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec
-# packed-SAD VALU peak: tools/ubench_sad measures v_qsad_pk_u16_u8 at ~16 and v_sad_u8 at ~4 cycles per wave64
+# packed-SAD VALU peak: tools/ubench_valu (profiles/ubench_valu_r02.txt) measures v_qsad_pk_u16_u8 at ~16.5 and v_sad_u8 at ~4.25 cycles per wave64
 # instruction per SIMD, i.e. the SAD unit retires 64 |a-b| per clock per SIMD either way:
 # 256 CU x 4 SIMD x 64 x 2.4 GHz = 157 T|a-b|/s.
 SAD_ABSDIFF_PER_CLK_PER_SIMD = 64.0
