@@ -996,7 +996,7 @@ static int lsq_cluster(ofps_hip_ctx* ctx, const float4* d_entries, size_t n, int
     hipStream_t s = ctx->stream;
     unsigned long long* prof = nullptr;
     if (getenv("OFPS_HIP_ALMEIDA_PROF")) {
-        prof = static_cast<unsigned long long*>(scratch(ctx, S_WORK2, (size_t)per_launch * nblk * kIters * 5 * sizeof(unsigned long long)));
+        prof = static_cast<unsigned long long*>(scratch(ctx, S_ALM_PROF, (size_t)per_launch * nblk * kIters * 5 * sizeof(unsigned long long)));
         if (!prof) return OFPS_HIP_ENOMEM;
     }
     const size_t cap = ctx->scratch[S_GRAN].cap;
@@ -1053,8 +1053,8 @@ static int lsq_stepped(ofps_hip_ctx* ctx, const float4* d_entries, size_t n_max,
     int nblk = (int)((n_max + per_wg - 1) / per_wg);
     const int cap = (2 * ctx->num_cus + batch - 1) / batch;
     if (nblk > cap) nblk = cap < 1 ? 1 : cap;
-    auto* part = static_cast<float*>(scratch(ctx, S_WORK0, 2 * (size_t)batch * nblk * 9 * sizeof(float)));
-    auto* state = static_cast<Quat*>(scratch(ctx, S_WORK1, 2 * (size_t)batch * sizeof(Quat)));
+    auto* part = static_cast<float*>(scratch(ctx, S_ALM_PART, 2 * (size_t)batch * nblk * 9 * sizeof(float)));
+    auto* state = static_cast<Quat*>(scratch(ctx, S_ALM_STATE, 2 * (size_t)batch * sizeof(Quat)));
     if (!part || !state) return OFPS_HIP_ENOMEM;
     float* pa = part;
     float* pb = part + (size_t)batch * nblk * 9;
@@ -1121,10 +1121,10 @@ int almeida_device(ofps_hip_ctx* ctx, const float4* d_entries, size_t n, int bat
     const uint32_t iters = (uint32_t)num_iters;
     const uint32_t ns = (uint32_t)(num_samples < n ? num_samples : n);
     hipStream_t s = ctx->stream;
-    auto* hyp = static_cast<Mat3*>(scratch(ctx, S_WORK2, (size_t)batch * iters * sizeof(Mat3)));
-    auto* counts = static_cast<uint32_t*>(scratch(ctx, S_WORK3, (size_t)batch * iters * sizeof(uint32_t)));
-    auto* sel = static_cast<float4*>(scratch(ctx, S_WORK4, (size_t)batch * (ns ? ns : 1) * sizeof(float4)));
-    auto* sel_n = static_cast<uint32_t*>(scratch(ctx, S_CELLS, (size_t)batch * sizeof(uint32_t)));
+    auto* hyp = static_cast<Mat3*>(scratch(ctx, S_ALM_HYP, (size_t)batch * iters * sizeof(Mat3)));
+    auto* counts = static_cast<uint32_t*>(scratch(ctx, S_ALM_COUNTS, (size_t)batch * iters * sizeof(uint32_t)));
+    auto* sel = static_cast<float4*>(scratch(ctx, S_ALM_SEL, (size_t)batch * (ns ? ns : 1) * sizeof(float4)));
+    auto* sel_n = static_cast<uint32_t*>(scratch(ctx, S_ALM_SELN, (size_t)batch * sizeof(uint32_t)));
     if (!hyp || !counts || !sel || !sel_n) return OFPS_HIP_ENOMEM;
     const float target = to_radians_host(inlier_deg);                              // lib.rs:210
     const float thr2 = target * target;

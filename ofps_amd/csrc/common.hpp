@@ -26,6 +26,8 @@ struct ofps_hip_ctx {
     int pipe_w = 0, pipe_h = 0, pipe_stride = 0;
     long pipe_frames = 0;                // frames pushed since the last reset; frame k lives in slot k % 3
     hipStream_t pipe_copy_stream = nullptr;
+    hipStream_t pipe_aux_stream = nullptr;       // the detector runs here beside the estimator (both read the same vectors)
+    hipEvent_t pipe_fork = nullptr, pipe_join = nullptr;
     hipEvent_t pipe_uploaded[kPipeSlots] = {};   // H2D of the frame in this slot finished (recorded on the copy stream)
     hipEvent_t pipe_slot_read[kPipeSlots] = {};  // last search that reads this slot finished (recorded on the compute stream)
     bool pipe_slot_read_valid[kPipeSlots] = {};
@@ -47,7 +49,7 @@ struct ofps_hip_ctx {
     // grow-only device scratch owned by the context (staging for host-pointer entry points and
     // kernel workspaces); never shrinks, freed in ofps_hip_destroy.
     struct Scratch { void* p = nullptr; size_t cap = 0; };
-    static constexpr int kNumScratch = 24;
+    static constexpr int kNumScratch = 32;
     Scratch scratch[kNumScratch];
 };
 
@@ -55,7 +57,9 @@ namespace ofps {
 
 enum ScratchSlot {
     S_FRAMES = 0, S_ENTRIES, S_BEST, S_FIELD, S_CELLS, S_WORK0, S_WORK1, S_WORK2, S_WORK3, S_RESULT,
-    S_QUAT, S_WORK4, S_PIPE_FRAMES, S_PIPE_ENTRIES, S_PIPE_OUT, S_MASK, S_ENTRIES2, S_GRAN, S_SAD_LIST
+    S_QUAT, S_WORK4, S_PIPE_FRAMES, S_PIPE_ENTRIES, S_PIPE_OUT, S_MASK, S_ENTRIES2, S_GRAN, S_SAD_LIST,
+    // the estimator's own workspaces: it may run beside the detector (pipeline.hip), so the two share no slot
+    S_ALM_PART, S_ALM_STATE, S_ALM_HYP, S_ALM_COUNTS, S_ALM_SEL, S_ALM_SELN, S_ALM_PROF
 };
 
 int set_error(ofps_hip_ctx* ctx, int code, const char* fmt, ...);

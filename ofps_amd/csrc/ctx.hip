@@ -102,6 +102,9 @@ void ofps_hip_destroy(ofps_hip_ctx* ctx) {
         if (ctx->pipe_slot_read[k]) (void)hipEventDestroy(ctx->pipe_slot_read[k]);
     }
     if (ctx->pipe_copy_stream) (void)hipStreamDestroy(ctx->pipe_copy_stream);
+    if (ctx->pipe_aux_stream) (void)hipStreamDestroy(ctx->pipe_aux_stream);
+    if (ctx->pipe_fork) (void)hipEventDestroy(ctx->pipe_fork);
+    if (ctx->pipe_join) (void)hipEventDestroy(ctx->pipe_join);
     if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
     if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -118,6 +121,7 @@ static int switch_stream(ofps_hip_ctx* ctx, hipStream_t next) {
     OFPS_HIP_TRY(ctx, hipSetDevice(ctx->device));
     OFPS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->pipe_copy_stream) OFPS_HIP_TRY(ctx, hipStreamSynchronize(ctx->pipe_copy_stream));
+    if (ctx->pipe_aux_stream) OFPS_HIP_TRY(ctx, hipStreamSynchronize(ctx->pipe_aux_stream));
     ctx->stream = next;
     return OFPS_HIP_OK;
 }

@@ -54,6 +54,9 @@ int pipe_read_back(ofps_hip_ctx* ctx, void* host_dst, const void* dev_src, size_
 int pipe_setup(ofps_hip_ctx* ctx) {
     if (ctx->pipe_copy_stream) return OFPS_HIP_OK;
     OFPS_HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->pipe_copy_stream, hipStreamNonBlocking));
+    OFPS_HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->pipe_aux_stream, hipStreamNonBlocking));
+    OFPS_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->pipe_fork, hipEventDisableTiming));
+    OFPS_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->pipe_join, hipEventDisableTiming));
     for (int k = 0; k < ofps_hip_ctx::kPipeSlots; ++k) {
         OFPS_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->pipe_uploaded[k], hipEventDisableTiming));
         OFPS_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->pipe_slot_read[k], hipEventDisableTiming));
@@ -189,8 +192,21 @@ int ofps_hip_push_frame_async(ofps_hip_ctx* ctx, const uint8_t* luma, int W, int
     int* d_res = reinterpret_cast<int*>(d_out);
     float4* d_quat = reinterpret_cast<float4*>(d_out + 16);
     float2* d_field = reinterpret_cast<float2*>(d_out + 4096);
+    // detector and estimator read the same device-resident vectors and share no workspace: with both enabled the
+    // detector's chain of small launches runs on an auxiliary stream beside the estimator (fork after the search, join
+    // before the read-back) instead of in front of it
+    const bool fork = prm->run_detector && prm->run_estimator;
+    if (fork) {
+        OFPS_HIP_TRY(ctx, hipEventRecord(ctx->pipe_fork, s));
+        OFPS_HIP_TRY(ctx, hipStreamWaitEvent(ctx->pipe_aux_stream, ctx->pipe_fork, 0));
+    }
     if (prm->run_detector) {
+        if (fork) ctx->stream = ctx->pipe_aux_stream;           // the stage entry points enqueue on ctx->stream
         rc = ofps::detect_device(ctx, d_ent, nblk, 1, prm->min_size, prm->subdivide, prm->target_motion, d_res, d_field, &dim);
+        if (fork) {
+            ctx->stream = s;
+            if (rc == OFPS_HIP_OK) OFPS_HIP_TRY(ctx, hipEventRecord(ctx->pipe_join, ctx->pipe_aux_stream));
+        }
         if (rc != OFPS_HIP_OK) return rc;
     }
     if (prm->run_estimator) {
@@ -198,6 +214,7 @@ int ofps_hip_push_frame_async(ofps_hip_ctx* ctx, const uint8_t* luma, int W, int
                                   prm->inlier_deg, prm->num_samples, prm->seed, d_quat);
         if (rc != OFPS_HIP_OK) return rc;
     }
+    if (fork) OFPS_HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->pipe_join, 0));
     if (prm->run_detector || prm->run_estimator) {
         rc = pipe_read_back(ctx, t.pinned, d_out, sizeof(PipeOut), s);
         if (rc != OFPS_HIP_OK) return rc;

@@ -57,7 +57,10 @@ def main():
     th = threading.Thread(target=feeder, daemon=True); th.start()
     sock = socket.create_connection(("127.0.0.1", port))
     ctx = HipContext(0)
-    buf = bytearray(W * H)
+    # the receive buffer IS the page-locked staging buffer (recv_into writes the frame where the DMA engine reads it):
+    # no host copy, no pageable-memory staging inside hipMemcpy
+    pinned = ctx.pinned_frame(H, W)
+    buf = memoryview(pinned).cast("B")
     lat, proc = [], []
     islands = 0
     for k in range(args.frames):
@@ -65,7 +68,7 @@ def main():
         w, h = struct.unpack("<II", hdr)
         recv_exact(sock, w * h, buf)
         t_arr = time.perf_counter()
-        frame = np.frombuffer(buf, np.uint8).reshape(h, w)
+        frame = pinned
         r = ctx.push_frame(frame, block=16, search_range=16, use_ransac=args.ransac, seed=k)
         t_done = time.perf_counter()
         if k >= 10:                                               # steady state
