@@ -8,7 +8,7 @@
  *
  * PARITY STATUS (tests/test_reference_vectors.py, tests/test_oracle.py)
  *   - StandardCamera::delta (A6-A8): pinned by REFERENCE-HELD vectors -- the seven 144-row tables of
- *     docs/report/mfield/*.csv are reproduced to 1.5e-6 (camera 16/9, 99 deg; the divide by NDC z of
+ *     docs/report/mfield (base, este, 0..4 .csv) are reproduced to 1.5e-6 (camera 16/9, 99 deg; the divide by NDC z of
  *     camera.rs:77 included) -- plus the point_angle doctest (ofps/src/camera.rs:139-149).
  *   - Almeida estimator (A9-A12): the reference's own known-answer test (almeida-estimator/src/lib.rs:253-373,
  *     32 rotations, error < 10 % of the rotation) on fields built by the oracle AND by an independent float64 model;

@@ -251,3 +251,24 @@ def test_hip_ransac_batch_items_draw_different_samples(ctx):
     for b in range(3):                                   # item b == a single call with seed 42 + b, which the oracle reproduces
         np.testing.assert_allclose(q[b], oracle.solve_ypr_ransac(e, cam, 200, 0.05, 1000, seed=42 + b), atol=1e-4, rtol=0)
     assert not (np.array_equal(q[0], q[1]) and np.array_equal(q[1], q[2]))
+
+
+def test_hip_new_entry_points_reject_nonsense_loudly(ctx):
+    from ofps_amd.runtime import OfpsHipError
+    with pytest.raises(OfpsHipError, match="not in flight"):
+        ctx.frame_wait(12345)
+    e = np.zeros((4, 4), np.float32)
+    with pytest.raises(AssertionError):
+        ctx.densify_weighted(e, np.ones(3, np.float32), 4, 4)                       # one weight per entry
+    with pytest.raises(OfpsHipError, match="bad grid"):
+        ctx.densify_weighted(e, np.ones(4, np.float32), 0, 4)
+    # a geometry change while a ticket is in flight drains the stream position instead of mixing frame sizes
+    ctx.reset_frames()
+    a = ctx.pinned_frame(192, 320); b = ctx.pinned_frame(96, 160)
+    a[:] = 7; b[:] = 9
+    t0 = ctx.push_frame_async(a, search_range=8)
+    t1 = ctx.push_frame_async(b, search_range=8)                                     # restarts: first frame of a new stream
+    r1 = ctx.frame_wait(t1)
+    assert not r1["have_vectors"]
+    ctx.reset_frames()
+    ctx.free_pinned(a); ctx.free_pinned(b)
