@@ -319,8 +319,30 @@ __device__ __forceinline__ int lk_origin(int q, float fl, int lim, float& frac) 
     return (int)c;
 }
 
-__device__ __forceinline__ void lk_solve_store(const float4* __restrict__ G, const float2 f, float bx, float by, size_t idx,
-                                               float2* __restrict__ flow_out) {
+// Where a step kernel takes a pixel's flow from and where it puts the result.  Two small kernels per level are folded in:
+//   * first step of a level: flow_in = 2 * coarse(x/2, y/2) (lk_upsample_kernel's expression, evaluated on the fly);
+//   * last step of level 0: the per-pixel records cv-decoder emits (lk_entries_kernel's expressions) are written
+//     directly; the flow plane itself only if somebody asked for it.
+struct LkFlowIO {
+    const float2* flow_in;      // used when coarse == nullptr
+    const float2* coarse;       // flow of the next coarser level (w1 x h1), or nullptr
+    int w1, h1;
+    float2* flow_out;           // or nullptr
+    float4* out_entries;        // or nullptr
+    float nx, ny;               // 1/W, 1/H for the records
+};
+
+__device__ __forceinline__ float2 lk_flow_read(const LkFlowIO& io, int x, int y, int w) {
+    if (io.coarse) {                                                   // uniform
+        const float2 c = io.coarse[(size_t)lk_clampi(y / 2, 0, io.h1 - 1) * io.w1 + lk_clampi(x / 2, 0, io.w1 - 1)];
+        return make_float2(2.0f * c.x, 2.0f * c.y);
+    }
+    return io.flow_in[(size_t)y * w + x];
+}
+
+__device__ __forceinline__ void lk_solve_store(const float4* __restrict__ G, const float2 f, float bx, float by, int x, int y, int w,
+                                               const LkFlowIO& io) {
+    const size_t idx = (size_t)y * w + x;
     const float4 g = G[idx];
     const float det = g.x * g.z - g.y * g.y;
     float du = 0.0f, dv = 0.0f;
@@ -328,15 +350,16 @@ __device__ __forceinline__ void lk_solve_store(const float4* __restrict__ G, con
         du = (g.z * bx - g.y * by) / det;
         dv = (g.x * by - g.y * bx) / det;
     }
-    flow_out[idx] = make_float2(f.x + du, f.y + dv);
+    const float2 out = make_float2(f.x + du, f.y + dv);
+    if (io.flow_out) io.flow_out[idx] = out;
+    if (io.out_entries) io.out_entries[idx] = make_float4(((float)x + 0.5f) * io.nx, ((float)y + 0.5f) * io.ny, out.x * io.nx, out.y * io.ny);
 }
 
 // main kernel: one workgroup per 64 x 4 tile; tiles it cannot serve from LDS are appended to fb_tiles (count in *fb_count)
 template <int RADIUS>
 __global__ __launch_bounds__(256) void lk_step_lds_kernel(const float* __restrict__ I, const float* __restrict__ J,
                                                           const float* __restrict__ gx, const float* __restrict__ gy,
-                                                          const float4* __restrict__ G, int w, int h,
-                                                          const float2* __restrict__ flow_in, float2* __restrict__ flow_out,
+                                                          const float4* __restrict__ G, int w, int h, const LkFlowIO io,
                                                           uint32_t* __restrict__ fb_count, uint32_t* __restrict__ fb_tiles,
                                                           unsigned long long* __restrict__ prof) {
     // prof (diagnostics, normally null): per-workgroup s_memtime stamps at the phase boundaries
@@ -350,7 +373,7 @@ __global__ __launch_bounds__(256) void lk_step_lds_kernel(const float* __restric
     lk_stage3<RADIUS>(I, gx, gy, sh.tile, w, h, x0, y0);
     const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6, x = x0 + lx, y = y0 + ly;
     const bool active = x < w && y < h;
-    const float2 f = active ? flow_in[(size_t)y * w + x] : make_float2(0.0f, 0.0f);
+    const float2 f = active ? lk_flow_read(io, x, y, w) : make_float2(0.0f, 0.0f);
     float ax[N];
     int xi[N];
     bool consecutive = true;
@@ -483,7 +506,7 @@ __global__ __launch_bounds__(256) void lk_step_lds_kernel(const float* __restric
         }
     }
     OFPS_LK_STAMP(4);
-    lk_solve_store(G, f, bx, by, (size_t)y * w + x, flow_out);
+    lk_solve_store(G, f, bx, by, x, y, w, io);
     OFPS_LK_STAMP(5);
 #undef OFPS_LK_STAMP
 }
@@ -494,8 +517,7 @@ __global__ __launch_bounds__(256) void lk_step_lds_kernel(const float* __restric
 template <int RADIUS>
 __global__ __launch_bounds__(256) void lk_step_general_kernel(const float* __restrict__ I, const float* __restrict__ J,
                                                               const float* __restrict__ gx, const float* __restrict__ gy,
-                                                              const float4* __restrict__ G, int w, int h,
-                                                              const float2* __restrict__ flow_in, float2* __restrict__ flow_out,
+                                                              const float4* __restrict__ G, int w, int h, const LkFlowIO io,
                                                               const uint32_t* __restrict__ fb_count,
                                                               const uint32_t* __restrict__ fb_tiles) {
     using T = LkTile<RADIUS>;
@@ -510,7 +532,7 @@ __global__ __launch_bounds__(256) void lk_step_general_kernel(const float* __res
         __syncthreads();
         const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6, x = x0 + lx, y = y0 + ly;
         if (x >= w || y >= h) continue;
-        const float2 f = flow_in[(size_t)y * w + x];
+        const float2 f = lk_flow_read(io, x, y, w);
         int xa[N], xb[N];
         float ax[N];
 #pragma unroll
@@ -553,7 +575,7 @@ __global__ __launch_bounds__(256) void lk_step_general_kernel(const float* __res
                 by += t.z * d;
             }
         }
-        lk_solve_store(G, f, bx, by, (size_t)y * w + x, flow_out);
+        lk_solve_store(G, f, bx, by, x, y, w, io);
     }
 }
 
@@ -569,8 +591,9 @@ __global__ __launch_bounds__(256) void lk_entries_kernel(const float2* __restric
 static dim3 lk_grid(int w, int h) { return dim3((w + 63) / 64, (h + 3) / 4); }
 
 // d_prev/d_cur: u8 luma on the device.  d_flow: W*H float2.  Workspace comes from the context.
+// d_flow (W*H float2) and/or d_entries (W*H float4 records) receive the result; at least one of them.
 int lk_flow_device(ofps_hip_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_cur, int W, int H, int stride, int levels,
-                   int radius, int iters, float2* d_flow) {
+                   int radius, int iters, float2* d_flow, float4* d_entries) {
     OFPS_REQUIRE(ctx, W >= 1 && H >= 1 && stride >= W, "lk_flow: bad geometry W=%d H=%d stride=%d", W, H, stride);
     OFPS_REQUIRE(ctx, levels >= 1 && levels <= 8 && radius >= 1 && radius <= 15 && iters >= 1 && iters <= 64,
                  "lk_flow: levels=%d radius=%d iters=%d out of range", levels, radius, iters);
@@ -615,10 +638,19 @@ int lk_flow_device(ofps_hip_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_cu
     }
     float2* cur_flow = fa;
     float2* other = fb;
+    const bool tiled = radius == 2 || radius == 4 || radius == 6;      // kernels that fold the upsample / record passes in
+    float2* plain_flow = d_flow;                                       // the untiled path always produces a flow plane
+    if (!tiled && !plain_flow) {
+        plain_flow = static_cast<float2*>(scratch(ctx, S_WORK1, plane0 * sizeof(float2)));
+        if (!plain_flow) return OFPS_HIP_ENOMEM;
+    }
     for (int l = levels - 1; l >= 0; --l) {
         const int w = ws[l], h = hs[l];
+        const float2* coarse = nullptr;                                // set: the first step reads 2 * coarse(x/2, y/2)
         if (l == levels - 1) {
             OFPS_HIP_TRY(ctx, hipMemsetAsync(cur_flow, 0, (size_t)w * h * sizeof(float2), s));
+        } else if (tiled) {
+            coarse = cur_flow;
         } else {
             hipLaunchKernelGGL(lk_upsample_kernel, lk_grid(w, h), dim3(256), 0, s, cur_flow, ws[l + 1], hs[l + 1], other, w, h);
             float2* t = cur_flow; cur_flow = other; other = t;
@@ -631,26 +663,37 @@ int lk_flow_device(ofps_hip_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_cu
             default: hipLaunchKernelGGL(lk_tensor_kernel, lk_grid(w, h), dim3(256), 0, s, gx, gy, w, h, radius, G);
         }
         for (int it = 0; it < iters; ++it) {
-            float2* dst = (l == 0 && it == iters - 1) ? d_flow : other;
+            const bool last = l == 0 && it == iters - 1;
             uint32_t* cnt = fb_count + (size_t)l * iters + it;
             uint32_t* tiles = fb_tiles + ((size_t)l * iters + it) * tiles0;
             const dim3 g = lk_grid(w, h);
             const unsigned ntiles = g.x * g.y;
             const dim3 gg(ntiles < (unsigned)(8 * ctx->num_cus) ? ntiles : (unsigned)(8 * ctx->num_cus));
-#define OFPS_LK_STEP(R)                                                                                                           \
-    hipLaunchKernelGGL(lk_step_lds_kernel<R>, g, dim3(256), 0, s, Ip + off[l], Jp + off[l], gx, gy, G, w, h, cur_flow, dst, cnt, tiles, \
-                       (l == 0 && it == 0) ? prof : nullptr); \
-    hipLaunchKernelGGL(lk_step_general_kernel<R>, gg, dim3(256), 0, s, Ip + off[l], Jp + off[l], gx, gy, G, w, h, cur_flow, dst, cnt, tiles)
+            LkFlowIO io{};
+            io.flow_in = cur_flow;
+            io.coarse = (it == 0) ? coarse : nullptr;
+            io.w1 = l + 1 < levels ? ws[l + 1] : 0; io.h1 = l + 1 < levels ? hs[l + 1] : 0;
+            io.flow_out = last ? d_flow : other;                       // the last step skips the flow plane nobody asked for
+            io.out_entries = last ? d_entries : nullptr;
+            io.nx = 1.0f / (float)W; io.ny = 1.0f / (float)H;
+#define OFPS_LK_STEP(R)                                                                                                      \
+    hipLaunchKernelGGL(lk_step_lds_kernel<R>, g, dim3(256), 0, s, Ip + off[l], Jp + off[l], gx, gy, G, w, h, io, cnt, tiles,       \
+                       (l == 0 && it == 0) ? prof : nullptr);                                                                \
+    hipLaunchKernelGGL(lk_step_general_kernel<R>, gg, dim3(256), 0, s, Ip + off[l], Jp + off[l], gx, gy, G, w, h, io, cnt, tiles)
             switch (radius) {
                 case 2: OFPS_LK_STEP(2); break;
                 case 4: OFPS_LK_STEP(4); break;
                 case 6: OFPS_LK_STEP(6); break;
-                default: hipLaunchKernelGGL(lk_step_kernel<0>, g, dim3(256), 0, s, Ip + off[l], Jp + off[l], gx, gy, G, w, h, radius, cur_flow, dst);
+                default:
+                    hipLaunchKernelGGL(lk_step_kernel<0>, g, dim3(256), 0, s, Ip + off[l], Jp + off[l], gx, gy, G, w, h, radius, cur_flow,
+                                       last ? plain_flow : other);
             }
 #undef OFPS_LK_STEP
-            if (dst != d_flow) { float2* t = cur_flow; cur_flow = other; other = t; }
+            if (!last) { float2* t = cur_flow; cur_flow = other; other = t; }
         }
     }
+    if (!tiled && d_entries)
+        hipLaunchKernelGGL(lk_entries_kernel, lk_grid(W, H), dim3(256), 0, s, plain_flow, W, H, 1.0f / (float)W, 1.0f / (float)H, d_entries);
     OFPS_HIP_TRY(ctx, hipGetLastError());
     if (prof) {
         std::vector<unsigned long long> hst(tiles0 * 6);
@@ -679,20 +722,8 @@ int ofps_hip_lk_flow_dev(ofps_hip_ctx* ctx, const void* d_prev, const void* d_cu
     if (!ctx) return OFPS_HIP_EINVAL;
     OFPS_REQUIRE(ctx, d_prev && d_cur && (d_out_flow || d_out_entries), "lk_flow: null device pointer");
     OFPS_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    auto* flow = static_cast<float2*>(d_out_flow);
-    if (!flow) {
-        flow = static_cast<float2*>(ofps::scratch(ctx, ofps::S_WORK1, (size_t)W * H * sizeof(float2)));
-        if (!flow) return OFPS_HIP_ENOMEM;
-    }
-    int rc = ofps::lk_flow_device(ctx, static_cast<const uint8_t*>(d_prev), static_cast<const uint8_t*>(d_cur), W, H, stride, levels,
-                                  radius, iters, flow);
-    if (rc != OFPS_HIP_OK) return rc;
-    if (d_out_entries) {
-        hipLaunchKernelGGL(ofps::lk_entries_kernel, ofps::lk_grid(W, H), dim3(256), 0, ctx->stream, flow, W, H, 1.0f / (float)W,
-                           1.0f / (float)H, static_cast<float4*>(d_out_entries));
-        OFPS_HIP_TRY(ctx, hipGetLastError());
-    }
-    return OFPS_HIP_OK;
+    return ofps::lk_flow_device(ctx, static_cast<const uint8_t*>(d_prev), static_cast<const uint8_t*>(d_cur), W, H, stride, levels,
+                                radius, iters, static_cast<float2*>(d_out_flow), static_cast<float4*>(d_out_entries));
 }
 
 // The body of a "hip_lk" Decoder::process_frame (cv-decoder/src/lib.rs:82-294): dense flow, per-pixel records,
