@@ -9,9 +9,10 @@
 //
 // Kernels per pyramid level: u8->f32 (level 0) / [1 4 6 4 1]/16 x [1 4 6 4 1]/16 downsample (both passes fused), central-difference
 // gradients of the previous frame, the 2x2 structure tensor G summed over the (2r+1)^2 window (once per
-// level: it does not depend on the flow), then `iters` Gauss-Newton steps (b = sum grad * (I - J(q+flow)),
-// flow += G^-1 b).  All of it is window/stencil work on f32 planes: L1/L2-resident reads, VALU-bound on the
-// bilinear sampling -- no contraction wide enough for MFMA (the normal equations are 2x2 per pixel).
+// level: it does not depend on the flow), then ONE launch that runs all `iters` Gauss-Newton steps of the level
+// (b = sum grad * (I - J(q+flow)), flow += G^-1 b) with the previous frame's window and the flow kept on chip.
+// All of it is window/stencil work on f32 planes: L1/L2-resident reads, VALU-bound on the bilinear sampling -- no
+// contraction wide enough for MFMA (the normal equations are 2x2 per pixel).
 #include "common.hpp"
 
 #include <vector>
@@ -308,6 +309,8 @@ struct LkStepShared {
     static constexpr int JS = (LW + 4) / 4 * 4;     // row stride in floats: a multiple of 4, so rows start 16-byte aligned
     alignas(16) float jl[LH][JS];
     int box[4][4];                     // per wave: min x0, max x0+1, min y0, max y0+1
+    // what the LDS footprint allows (160 KB per CU, 4 waves per workgroup): the register budget hipcc is held to
+    static constexpr int WAVES_PER_SIMD = RADIUS <= 2 ? 8 : RADIUS <= 4 ? 6 : 4;
 };
 
 // integer sample origin of a window column / row: the oracle's floor + float clamp to [-1, lim]
@@ -319,50 +322,56 @@ __device__ __forceinline__ int lk_origin(int q, float fl, int lim, float& frac) 
     return (int)c;
 }
 
-// Where a step kernel takes a pixel's flow from and where it puts the result.  Two small kernels per level are folded in:
-//   * first step of a level: flow_in = 2 * coarse(x/2, y/2) (lk_upsample_kernel's expression, evaluated on the fly);
-//   * last step of level 0: the per-pixel records cv-decoder emits (lk_entries_kernel's expressions) are written
-//     directly; the flow plane itself only if somebody asked for it.
+// Where a level kernel takes a pixel's flow from and where it puts the result.  Two small kernels per level are folded in:
+//   * start of a level: flow_in = 2 * coarse(x/2, y/2) (lk_upsample_kernel's expression, evaluated on the fly), or zero
+//     at the coarsest level;
+//   * end of level 0: the per-pixel records cv-decoder emits (lk_entries_kernel's expressions) are written directly; the
+//     flow plane itself only if somebody asked for it.
 struct LkFlowIO {
-    const float2* flow_in;      // used when coarse == nullptr
-    const float2* coarse;       // flow of the next coarser level (w1 x h1), or nullptr
+    const float2* coarse;       // flow of the next coarser level (w1 x h1), or nullptr: the level starts from zero flow
     int w1, h1;
     float2* flow_out;           // or nullptr
     float4* out_entries;        // or nullptr
     float nx, ny;               // 1/W, 1/H for the records
 };
 
-__device__ __forceinline__ float2 lk_flow_read(const LkFlowIO& io, int x, int y, int w) {
+__device__ __forceinline__ float2 lk_flow_read(const LkFlowIO& io, int x, int y) {
     if (io.coarse) {                                                   // uniform
         const float2 c = io.coarse[(size_t)lk_clampi(y / 2, 0, io.h1 - 1) * io.w1 + lk_clampi(x / 2, 0, io.w1 - 1)];
         return make_float2(2.0f * c.x, 2.0f * c.y);
     }
-    return io.flow_in[(size_t)y * w + x];
+    return make_float2(0.0f, 0.0f);
 }
 
-__device__ __forceinline__ void lk_solve_store(const float4* __restrict__ G, const float2 f, float bx, float by, int x, int y, int w,
-                                               const LkFlowIO& io) {
-    const size_t idx = (size_t)y * w + x;
-    const float4 g = G[idx];
+// the Gauss-Newton update of one pixel: G^-1 b added to the flow (zero step when det <= 0.01)
+__device__ __forceinline__ float2 lk_solve(const float4 g, const float2 f, float bx, float by) {
     const float det = g.x * g.z - g.y * g.y;
     float du = 0.0f, dv = 0.0f;
     if (det > 0.01f) {
         du = (g.z * bx - g.y * by) / det;
         dv = (g.x * by - g.y * bx) / det;
     }
-    const float2 out = make_float2(f.x + du, f.y + dv);
+    return make_float2(f.x + du, f.y + dv);
+}
+
+__device__ __forceinline__ void lk_store(const float2 out, int x, int y, int w, const LkFlowIO& io) {
+    const size_t idx = (size_t)y * w + x;
     if (io.flow_out) io.flow_out[idx] = out;
     if (io.out_entries) io.out_entries[idx] = make_float4(((float)x + 0.5f) * io.nx, ((float)y + 0.5f) * io.ny, out.x * io.nx, out.y * io.ny);
 }
 
-// main kernel: one workgroup per 64 x 4 tile; tiles it cannot serve from LDS are appended to fb_tiles (count in *fb_count)
+// main kernel: one workgroup per 64 x 4 tile runs ALL `iters` Gauss-Newton steps of a pyramid level -- a step of a pixel
+// depends on nothing but that pixel's own flow, so the previous frame's window (I, gx, gy), the tensor G and the flow
+// stay on chip between steps; only the current frame's rectangle is restaged (it moves with the flow).  A tile whose
+// rectangle does not fit at step `it` parks its flow in fb_flow, appends (tile, it) to fb_tiles (count in *fb_count)
+// and leaves the remaining steps to lk_level_general_kernel.
 template <int RADIUS>
-__global__ __launch_bounds__(256) void lk_step_lds_kernel(const float* __restrict__ I, const float* __restrict__ J,
-                                                          const float* __restrict__ gx, const float* __restrict__ gy,
-                                                          const float4* __restrict__ G, int w, int h, const LkFlowIO io,
-                                                          uint32_t* __restrict__ fb_count, uint32_t* __restrict__ fb_tiles,
-                                                          unsigned long long* __restrict__ prof) {
-    // prof (diagnostics, normally null): per-workgroup s_memtime stamps at the phase boundaries
+__global__ __launch_bounds__(256, LkStepShared<RADIUS>::WAVES_PER_SIMD) void lk_level_lds_kernel(const float* __restrict__ I, const float* __restrict__ J,
+                                                           const float* __restrict__ gx, const float* __restrict__ gy,
+                                                           const float4* __restrict__ G, int w, int h, int iters, const LkFlowIO io,
+                                                           uint32_t* __restrict__ fb_count, uint2* __restrict__ fb_tiles,
+                                                           float2* fb_flow, unsigned long long* __restrict__ prof) {
+    // prof (diagnostics, normally null): per-workgroup s_memtime stamps at the phase boundaries of the first step
 #define OFPS_LK_STAMP(slot) do { if (prof && threadIdx.x == 0) prof[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 6 + (slot)] = __builtin_readcyclecounter(); } while (0)
     using T = LkTile<RADIUS>;
     using S = LkStepShared<RADIUS>;
@@ -371,211 +380,228 @@ __global__ __launch_bounds__(256) void lk_step_lds_kernel(const float* __restric
     __shared__ S sh;
     const int x0 = blockIdx.x * 64, y0 = blockIdx.y * 4;
     lk_stage3<RADIUS>(I, gx, gy, sh.tile, w, h, x0, y0);
-    const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6, x = x0 + lx, y = y0 + ly;
-    const bool active = x < w && y < h;
-    const float2 f = active ? lk_flow_read(io, x, y, w) : make_float2(0.0f, 0.0f);
-    float ax[N];
-    int xi[N];
-    bool consecutive = true;
-#pragma unroll
-    for (int k = 0; k < N; ++k) {
-        xi[k] = lk_origin(lk_clampi(x + k - RADIUS, 0, w - 1), f.x, w, ax[k]);
-        if (k > 0) consecutive = consecutive && (xi[k] == xi[k - 1] + 1);
-    }
-    float dummy;
-    const int yt = lk_origin(lk_clampi(y - RADIUS, 0, h - 1), f.y, h, dummy);
-    const int yb_ = lk_origin(lk_clampi(y + RADIUS, 0, h - 1), f.y, h, dummy);
-    {
-        // window columns / rows are monotone in k / r, so the extremes are the first and the last
-        int bx0 = active ? xi[0] : 0x7FFFFFFF, bx1 = active ? xi[N - 1] + 1 : -0x7FFFFFFF;
-        int by0 = active ? yt : 0x7FFFFFFF, by1 = active ? yb_ + 1 : -0x7FFFFFFF;
-        bx0 = lk_wave_minmax<false>(bx0); bx1 = lk_wave_minmax<true>(bx1);
-        by0 = lk_wave_minmax<false>(by0); by1 = lk_wave_minmax<true>(by1);
-        if (lx == 0) { sh.box[ly][0] = bx0; sh.box[ly][1] = bx1; sh.box[ly][2] = by0; sh.box[ly][3] = by1; }
-    }
-    OFPS_LK_STAMP(1);
-    __syncthreads();
-    OFPS_LK_STAMP(2);
-    const int xmin = min(min(sh.box[0][0], sh.box[1][0]), min(sh.box[2][0], sh.box[3][0]));
-    const int xmax = max(max(sh.box[0][1], sh.box[1][1]), max(sh.box[2][1], sh.box[3][1]));
-    const int ymin = min(min(sh.box[0][2], sh.box[1][2]), min(sh.box[2][2], sh.box[3][2]));
-    const int ymax = max(max(sh.box[0][3], sh.box[1][3]), max(sh.box[2][3], sh.box[3][3]));
-    const int fits = xmax >= xmin && xmax - xmin < S::LW && ymax - ymin < S::LH;
-    if (!fits) {                                                     // uniform: box[] is the same for every thread
-        if (threadIdx.x == 0) fb_tiles[atomicAdd(fb_count, 1u)] = (uint32_t)blockIdx.x | ((uint32_t)blockIdx.y << 16);
-        return;
-    }
-    // window columns that sample consecutive texels (x0[k+1] == x0[k] + 1: everywhere but at the left/right image
-    // border, where the clamped window columns repeat) share one row of N+1 texels; otherwise every column reads its
-    // own pair.  Uniform over the workgroup.
-    const bool all_consecutive = __syncthreads_and(consecutive || !active);
-    // rows [ymin, ymax] x columns [xs, xmax] of the current frame, xs = xmin rounded down to a multiple of 4 when the
-    // padded rectangle lies inside the frame and the plane is 16-byte aligned (16-byte loads), xmin otherwise
-    int xs = xmin;
-    {
-        const int chh = ymax - ymin + 1;
-        const int xa4 = xmin & ~3, cw4 = (xmax - xa4 + 4) >> 2;                      // float4 per row after padding
-        const bool vec = xmin >= 0 && xa4 + 4 * cw4 <= w && 4 * cw4 <= S::JS && (w & 3) == 0 &&
-                         (reinterpret_cast<uintptr_t>(J) & 15) == 0;
-        if (vec) {                                                   // uniform
-            xs = xa4;
-            for (int t = threadIdx.x; t < cw4 * chh; t += 256) {
-                const int cy = t / cw4, c4 = t - cy * cw4;
-                *reinterpret_cast<float4*>(&sh.jl[cy][4 * c4]) =
-                    *reinterpret_cast<const float4*>(J + (size_t)lk_clampi(ymin + cy, 0, h - 1) * w + xa4 + 4 * c4);
-            }
-        } else {
-            const int cw = xmax - xmin + 1;
-            const int cx = threadIdx.x & 127, cy0 = threadIdx.x >> 7;            // 128 threads per row, two rows per pass
-            if (cx < cw) {
-                const int gxc = lk_clampi(xmin + cx, 0, w - 1);
-                for (int cy = cy0; cy < chh; cy += 2) sh.jl[cy][cx] = J[(size_t)lk_clampi(ymin + cy, 0, h - 1) * w + gxc];
-            }
-        }
-    }
-    __syncthreads();
-    OFPS_LK_STAMP(3);
-    if (!active) return;
-    // hup[k] = horizontal interpolation of the UPPER sample row at column k.  The lower row of one window row is the
-    // upper row of the next whenever the sample row advanced by exactly one (always, away from the top/bottom
-    // border), and its interpolation j01 + ax[k] * (j11 - j01) is then the very expression the next row evaluates
-    // as j00 + ax[k] * (j10 - j00) on the same texels: carried over instead of recomputed -- same operations on the
-    // same inputs, 11 instead of 14 VALU operations per tap.  Decided per wave so the branch is uniform; recomputing
-    // is always correct.
-    float bx = 0.0f, by = 0.0f;
-    float hup[N];
-    int prev_yi = -0x7FFFFFFF;
-    if (all_consecutive) {
-        const int xo = xi[0] - xs;
-        float jb[N + 1];
-        // (measured and rejected: unrolling the row loop, fully or by two with ping-pong hup arrays -- hipcc then hoists
-        // the next row's LDS reads, 104+ VGPRs, 4 waves per SIMD, 0.53 vs 0.50 ms)
+    const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6, px = x0 + lx, py = y0 + ly;
+    const bool active = px < w && py < h;
+    float2 f = active ? lk_flow_read(io, px, py) : make_float2(0.0f, 0.0f);
 #pragma unroll 1
-        for (int r = 0; r < N; ++r) {
-            float ay;
-            const int yi = lk_origin(lk_clampi(y + r - RADIUS, 0, h - 1), f.y, h, ay) - ymin;
-            const bool reuse = __all(yi == prev_yi + 1);
-            prev_yi = yi;
-            if (!reuse) {
-                const float* ra = &sh.jl[yi][xo];
+    for (int it = 0; it < iters; ++it) {
+        // the pixel coordinates pass through an empty asm so that the compiler does not hoist the clamped window
+        // coordinates (2N integers + their float conversions) out of the step loop: that costs 40 VGPRs and two waves
+        // per SIMD for a handful of integer operations per step
+        int x = px, y = py;
+        asm volatile("" : "+v"(x), "+v"(y));
+        float ax[N];
+        int xi[N];
+        bool consecutive = true;
 #pragma unroll
-                for (int k = 0; k <= N; ++k) jb[k] = ra[k];
-#pragma unroll
-                for (int k = 0; k < N; ++k) hup[k] = jb[k] + ax[k] * (jb[k + 1] - jb[k]);
-            }
-            const float* rb = &sh.jl[yi + 1][xo];
-#pragma unroll
-            for (int k = 0; k <= N; ++k) jb[k] = rb[k];
-#pragma unroll
-            for (int k = 0; k < N; ++k) {
-                const float top = hup[k];
-                const float bot = jb[k] + ax[k] * (jb[k + 1] - jb[k]);
-                const lk_f4 t = lk_lds_read4(&sh.tile[ly + r][lx + k]);
-                const float d = t.x - (top + ay * (bot - top));
-                bx += t.y * d;
-                by += t.z * d;
-                hup[k] = bot;
+        for (int k = 0; k < N; ++k) {
+            xi[k] = lk_origin(lk_clampi(x + k - RADIUS, 0, w - 1), f.x, w, ax[k]);
+            if (k > 0) consecutive = consecutive && (xi[k] == xi[k - 1] + 1);
+        }
+        float dummy;
+        const int yt = lk_origin(lk_clampi(y - RADIUS, 0, h - 1), f.y, h, dummy);
+        const int yb_ = lk_origin(lk_clampi(y + RADIUS, 0, h - 1), f.y, h, dummy);
+        {
+            // window columns / rows are monotone in k / r, so the extremes are the first and the last
+            int bx0 = active ? xi[0] : 0x7FFFFFFF, bx1 = active ? xi[N - 1] + 1 : -0x7FFFFFFF;
+            int by0 = active ? yt : 0x7FFFFFFF, by1 = active ? yb_ + 1 : -0x7FFFFFFF;
+            bx0 = lk_wave_minmax<false>(bx0); bx1 = lk_wave_minmax<true>(bx1);
+            by0 = lk_wave_minmax<false>(by0); by1 = lk_wave_minmax<true>(by1);
+            // (the previous step's readers of box[] are all past that step's later barriers)
+            if (lx == 0) { sh.box[ly][0] = bx0; sh.box[ly][1] = bx1; sh.box[ly][2] = by0; sh.box[ly][3] = by1; }
+        }
+        if (it == 0) OFPS_LK_STAMP(1);
+        __syncthreads();                                                 // also: everybody is done reading jl[] of the previous step
+        if (it == 0) OFPS_LK_STAMP(2);
+        const int xmin = min(min(sh.box[0][0], sh.box[1][0]), min(sh.box[2][0], sh.box[3][0]));
+        const int xmax = max(max(sh.box[0][1], sh.box[1][1]), max(sh.box[2][1], sh.box[3][1]));
+        const int ymin = min(min(sh.box[0][2], sh.box[1][2]), min(sh.box[2][2], sh.box[3][2]));
+        const int ymax = max(max(sh.box[0][3], sh.box[1][3]), max(sh.box[2][3], sh.box[3][3]));
+        const int fits = xmax >= xmin && xmax - xmin < S::LW && ymax - ymin < S::LH;
+        if (!fits) {                                                     // uniform: box[] is the same for every thread
+            if (threadIdx.x == 0) fb_tiles[atomicAdd(fb_count, 1u)] = make_uint2((uint32_t)blockIdx.x | ((uint32_t)blockIdx.y << 16), (uint32_t)it);
+            if (active) fb_flow[(size_t)y * w + x] = f;
+            return;
+        }
+        // window columns that sample consecutive texels (x0[k+1] == x0[k] + 1: everywhere but at the left/right image
+        // border, where the clamped window columns repeat) share one row of N+1 texels; otherwise every column reads its
+        // own pair.  Uniform over the workgroup.
+        const bool all_consecutive = __syncthreads_and(consecutive || !active);
+        // rows [ymin, ymax] x columns [xs, xmax] of the current frame, xs = xmin rounded down to a multiple of 4 when the
+        // padded rectangle lies inside the frame and the plane is 16-byte aligned (16-byte loads), xmin otherwise
+        int xs = xmin;
+        {
+            const int chh = ymax - ymin + 1;
+            const int xa4 = xmin & ~3, cw4 = (xmax - xa4 + 4) >> 2;                      // float4 per row after padding
+            const bool vec = xmin >= 0 && xa4 + 4 * cw4 <= w && 4 * cw4 <= S::JS && (w & 3) == 0 &&
+                             (reinterpret_cast<uintptr_t>(J) & 15) == 0;
+            if (vec) {                                                   // uniform
+                xs = xa4;
+                for (int t = threadIdx.x; t < cw4 * chh; t += 256) {
+                    const int cy = t / cw4, c4 = t - cy * cw4;
+                    *reinterpret_cast<float4*>(&sh.jl[cy][4 * c4]) =
+                        *reinterpret_cast<const float4*>(J + (size_t)lk_clampi(ymin + cy, 0, h - 1) * w + xa4 + 4 * c4);
+                }
+            } else {
+                const int cw = xmax - xmin + 1;
+                const int cx = threadIdx.x & 127, cy0 = threadIdx.x >> 7;            // 128 threads per row, two rows per pass
+                if (cx < cw) {
+                    const int gxc = lk_clampi(xmin + cx, 0, w - 1);
+                    for (int cy = cy0; cy < chh; cy += 2) sh.jl[cy][cx] = J[(size_t)lk_clampi(ymin + cy, 0, h - 1) * w + gxc];
+                }
             }
         }
-    } else {
-#pragma unroll
-        for (int k = 0; k < N; ++k) xi[k] -= xs;
+        __syncthreads();
+        if (it == 0) OFPS_LK_STAMP(3);
+        if (active) {
+            // hup[k] = horizontal interpolation of the UPPER sample row at column k.  The lower row of one window row is the
+            // upper row of the next whenever the sample row advanced by exactly one (always, away from the top/bottom
+            // border), and its interpolation j01 + ax[k] * (j11 - j01) is then the very expression the next row evaluates
+            // as j00 + ax[k] * (j10 - j00) on the same texels: carried over instead of recomputed -- same operations on the
+            // same inputs, 11 instead of 14 VALU operations per tap.  Decided per wave so the branch is uniform; recomputing
+            // is always correct.
+            float bx = 0.0f, by = 0.0f;
+            float hup[N];
+            int prev_yi = -0x7FFFFFFF;
+            if (all_consecutive) {
+                const int xo = xi[0] - xs;
+                float jb[N + 1];
+                // (measured and rejected: unrolling the row loop, fully or by two/three with ping-pong hup arrays -- hipcc
+                // then hoists the next row's LDS reads, 104+ VGPRs, 4 waves per SIMD, 0.53 vs 0.50 ms)
 #pragma unroll 1
-        for (int r = 0; r < N; ++r) {
-            float ay;
-            const int yi = lk_origin(lk_clampi(y + r - RADIUS, 0, h - 1), f.y, h, ay) - ymin;
-            const bool reuse = __all(yi == prev_yi + 1);
-            prev_yi = yi;
-            if (!reuse) {
-                const float* ra = &sh.jl[yi][0];
+                for (int r = 0; r < N; ++r) {
+                    float ay;
+                    const int yi = lk_origin(lk_clampi(y + r - RADIUS, 0, h - 1), f.y, h, ay) - ymin;
+                    const bool reuse = __all(yi == prev_yi + 1);
+                    prev_yi = yi;
+                    if (!reuse) {
+                        const float* ra = &sh.jl[yi][xo];
 #pragma unroll
-                for (int k = 0; k < N; ++k) { const float j0 = ra[xi[k]], j1 = ra[xi[k] + 1]; hup[k] = j0 + ax[k] * (j1 - j0); }
-            }
-            const float* rb = &sh.jl[yi + 1][0];
+                        for (int k = 0; k <= N; ++k) jb[k] = ra[k];
 #pragma unroll
-            for (int k = 0; k < N; ++k) {
-                const float j0 = rb[xi[k]], j1 = rb[xi[k] + 1];
-                const float top = hup[k];
-                const float bot = j0 + ax[k] * (j1 - j0);
-                const lk_f4 t = lk_lds_read4(&sh.tile[ly + r][lx + k]);
-                const float d = t.x - (top + ay * (bot - top));
-                bx += t.y * d;
-                by += t.z * d;
-                hup[k] = bot;
+                        for (int k = 0; k < N; ++k) hup[k] = jb[k] + ax[k] * (jb[k + 1] - jb[k]);
+                    }
+                    const float* rb = &sh.jl[yi + 1][xo];
+#pragma unroll
+                    for (int k = 0; k <= N; ++k) jb[k] = rb[k];
+#pragma unroll
+                    for (int k = 0; k < N; ++k) {
+                        const float top = hup[k];
+                        const float bot = jb[k] + ax[k] * (jb[k + 1] - jb[k]);
+                        const lk_f4 t = lk_lds_read4(&sh.tile[ly + r][lx + k]);
+                        const float d = t.x - (top + ay * (bot - top));
+                        bx += t.y * d;
+                        by += t.z * d;
+                        hup[k] = bot;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < N; ++k) xi[k] -= xs;
+#pragma unroll 1
+                for (int r = 0; r < N; ++r) {
+                    float ay;
+                    const int yi = lk_origin(lk_clampi(y + r - RADIUS, 0, h - 1), f.y, h, ay) - ymin;
+                    const bool reuse = __all(yi == prev_yi + 1);
+                    prev_yi = yi;
+                    if (!reuse) {
+                        const float* ra = &sh.jl[yi][0];
+#pragma unroll
+                        for (int k = 0; k < N; ++k) { const float j0 = ra[xi[k]], j1 = ra[xi[k] + 1]; hup[k] = j0 + ax[k] * (j1 - j0); }
+                    }
+                    const float* rb = &sh.jl[yi + 1][0];
+#pragma unroll
+                    for (int k = 0; k < N; ++k) {
+                        const float j0 = rb[xi[k]], j1 = rb[xi[k] + 1];
+                        const float top = hup[k];
+                        const float bot = j0 + ax[k] * (j1 - j0);
+                        const lk_f4 t = lk_lds_read4(&sh.tile[ly + r][lx + k]);
+                        const float d = t.x - (top + ay * (bot - top));
+                        bx += t.y * d;
+                        by += t.z * d;
+                        hup[k] = bot;
+                    }
+                }
             }
+            f = lk_solve(G[(size_t)y * w + x], f, bx, by);       // re-read per step (L2): four registers less across the row loop
         }
+        if (it == 0) OFPS_LK_STAMP(4);
     }
-    OFPS_LK_STAMP(4);
-    lk_solve_store(G, f, bx, by, x, y, w, io);
+    if (active) lk_store(f, px, py, w, io);
     OFPS_LK_STAMP(5);
 #undef OFPS_LK_STAMP
 }
 
-// second launch: the listed tiles, per-lane gathers from global memory with register reuse (inside a window row j10 of
-// column k is j00 of column k+1 whenever xb[k] == xa[k+1], and the bottom row of one window row is the top row of the
-// next whenever yb == next ya -- both almost always true; the rare exceptions reload)
+// second launch: the listed (tile, first step) pairs, per-lane gathers from global memory with register reuse (inside a
+// window row j10 of column k is j00 of column k+1 whenever xb[k] == xa[k+1], and the bottom row of one window row is
+// the top row of the next whenever yb == next ya -- both almost always true; the rare exceptions reload)
 template <int RADIUS>
-__global__ __launch_bounds__(256) void lk_step_general_kernel(const float* __restrict__ I, const float* __restrict__ J,
-                                                              const float* __restrict__ gx, const float* __restrict__ gy,
-                                                              const float4* __restrict__ G, int w, int h, const LkFlowIO io,
-                                                              const uint32_t* __restrict__ fb_count,
-                                                              const uint32_t* __restrict__ fb_tiles) {
+__global__ __launch_bounds__(256) void lk_level_general_kernel(const float* __restrict__ I, const float* __restrict__ J,
+                                                               const float* __restrict__ gx, const float* __restrict__ gy,
+                                                               const float4* __restrict__ G, int w, int h, int iters, const LkFlowIO io,
+                                                               const uint32_t* __restrict__ fb_count,
+                                                               const uint2* __restrict__ fb_tiles,
+                                                               const float2* fb_flow) {
     using T = LkTile<RADIUS>;
     constexpr int N = T::N;
     __shared__ float4 tile[T::TH][T::TW];
     const uint32_t count = *fb_count;
     for (uint32_t li = blockIdx.x; li < count; li += gridDim.x) {
-        const uint32_t id = fb_tiles[li];
-        const int x0 = (int)(id & 0xFFFFu) * 64, y0 = (int)(id >> 16) * 4;
+        const uint2 id = fb_tiles[li];
+        const int x0 = (int)(id.x & 0xFFFFu) * 64, y0 = (int)(id.x >> 16) * 4;
         __syncthreads();                                   // the previous tile's readers are done with `tile`
         lk_stage3<RADIUS>(I, gx, gy, tile, w, h, x0, y0);
         __syncthreads();
         const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6, x = x0 + lx, y = y0 + ly;
         if (x >= w || y >= h) continue;
-        const float2 f = lk_flow_read(io, x, y, w);
-        int xa[N], xb[N];
-        float ax[N];
-#pragma unroll
-        for (int k = 0; k < N; ++k) {
-            const int xi = lk_origin(lk_clampi(x + k - RADIUS, 0, w - 1), f.x, w, ax[k]);
-            xa[k] = lk_clampi(xi, 0, w - 1); xb[k] = lk_clampi(xi + 1, 0, w - 1);
-        }
-        float bx = 0.0f, by = 0.0f;
-        float jt[N + 1], jb[N + 1];          // rows ya / yb of the current frame at columns xa[0..N-1], xb[N-1]
-        int prev_yb = -1;
-#pragma unroll 1
-        for (int r = 0; r < N; ++r) {
-            float ay;
-            const int yi = lk_origin(lk_clampi(y + r - RADIUS, 0, h - 1), f.y, h, ay);
-            const int ya = lk_clampi(yi, 0, h - 1), yb = lk_clampi(yi + 1, 0, h - 1);
-            const float* ra = J + (size_t)ya * w;
-            const float* rb = J + (size_t)yb * w;
-            if (ya == prev_yb) {
-#pragma unroll
-                for (int k = 0; k <= N; ++k) jt[k] = jb[k];
-            } else {
-#pragma unroll
-                for (int k = 0; k < N; ++k) jt[k] = ra[xa[k]];
-                jt[N] = ra[xb[N - 1]];
-            }
-#pragma unroll
-            for (int k = 0; k < N; ++k) jb[k] = rb[xa[k]];
-            jb[N] = rb[xb[N - 1]];
-            prev_yb = yb;
+        float2 f = fb_flow[(size_t)y * w + x];
+        const float4 g = G[(size_t)y * w + x];
+        for (int it = (int)id.y; it < iters; ++it) {
+            int xa[N], xb[N];
+            float ax[N];
 #pragma unroll
             for (int k = 0; k < N; ++k) {
-                float j10 = jt[k + 1], j11 = jb[k + 1];
-                if (k < N - 1 && xb[k] != xa[k + 1]) { j10 = ra[xb[k]]; j11 = rb[xb[k]]; }     // clamped border / rounding: rare
-                const float j00 = jt[k], j01 = jb[k];
-                const float top = j00 + ax[k] * (j10 - j00);
-                const float bot = j01 + ax[k] * (j11 - j01);
-                const float4 t = tile[ly + r][lx + k];
-                const float d = t.x - (top + ay * (bot - top));
-                bx += t.y * d;
-                by += t.z * d;
+                const int xi = lk_origin(lk_clampi(x + k - RADIUS, 0, w - 1), f.x, w, ax[k]);
+                xa[k] = lk_clampi(xi, 0, w - 1); xb[k] = lk_clampi(xi + 1, 0, w - 1);
             }
+            float bx = 0.0f, by = 0.0f;
+            float jt[N + 1], jb[N + 1];          // rows ya / yb of the current frame at columns xa[0..N-1], xb[N-1]
+            int prev_yb = -1;
+#pragma unroll 1
+            for (int r = 0; r < N; ++r) {
+                float ay;
+                const int yi = lk_origin(lk_clampi(y + r - RADIUS, 0, h - 1), f.y, h, ay);
+                const int ya = lk_clampi(yi, 0, h - 1), yb = lk_clampi(yi + 1, 0, h - 1);
+                const float* ra = J + (size_t)ya * w;
+                const float* rb = J + (size_t)yb * w;
+                if (ya == prev_yb) {
+#pragma unroll
+                    for (int k = 0; k <= N; ++k) jt[k] = jb[k];
+                } else {
+#pragma unroll
+                    for (int k = 0; k < N; ++k) jt[k] = ra[xa[k]];
+                    jt[N] = ra[xb[N - 1]];
+                }
+#pragma unroll
+                for (int k = 0; k < N; ++k) jb[k] = rb[xa[k]];
+                jb[N] = rb[xb[N - 1]];
+                prev_yb = yb;
+#pragma unroll
+                for (int k = 0; k < N; ++k) {
+                    float j10 = jt[k + 1], j11 = jb[k + 1];
+                    if (k < N - 1 && xb[k] != xa[k + 1]) { j10 = ra[xb[k]]; j11 = rb[xb[k]]; }     // clamped border / rounding: rare
+                    const float j00 = jt[k], j01 = jb[k];
+                    const float top = j00 + ax[k] * (j10 - j00);
+                    const float bot = j01 + ax[k] * (j11 - j01);
+                    const float4 t = tile[ly + r][lx + k];
+                    const float d = t.x - (top + ay * (bot - top));
+                    bx += t.y * d;
+                    by += t.z * d;
+                }
+            }
+            f = lk_solve(g, f, bx, by);
         }
-        lk_solve_store(G, f, bx, by, x, y, w, io);
+        lk_store(f, x, y, w, io);
     }
 }
 
@@ -624,21 +650,26 @@ int lk_flow_device(ofps_hip_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_cu
         hipLaunchKernelGGL(lk_pyr_down_kernel, g2, dim3(256), 0, s, Ip + off[l - 1], Jp + off[l - 1], ws[l - 1], hs[l - 1],
                            Ip + off[l], Jp + off[l], ws[l], hs[l]);
     }
-    // per Gauss-Newton step: the tiles the LDS kernel hands to the general kernel (count + tile ids)
+    // per level: the (tile, first step) pairs the LDS kernel hands to the general kernel, and where their flows are parked
     const dim3 g0 = lk_grid(W, H);
-    const size_t tiles0 = (size_t)g0.x * g0.y, n_steps = (size_t)levels * iters;
-    auto* fb_count = static_cast<uint32_t*>(scratch(ctx, S_WORK3, (n_steps + n_steps * tiles0) * sizeof(uint32_t)));
-    if (!fb_count) return OFPS_HIP_ENOMEM;
-    uint32_t* fb_tiles = fb_count + n_steps;
-    OFPS_HIP_TRY(ctx, hipMemsetAsync(fb_count, 0, n_steps * sizeof(uint32_t), s));
-    unsigned long long* prof = nullptr;                           // OFPS_HIP_LK_PROF=1: phase table of the first level-0 step
-    if (getenv("OFPS_HIP_LK_PROF")) {
-        prof = static_cast<unsigned long long*>(scratch(ctx, S_WORK2, tiles0 * 6 * sizeof(unsigned long long)));
-        if (!prof) return OFPS_HIP_ENOMEM;
+    const size_t tiles0 = (size_t)g0.x * g0.y;
+    const bool tiled = radius == 2 || radius == 4 || radius == 6;      // kernels that run a whole level and fold the upsample / record passes in
+    uint32_t* fb_count = nullptr;
+    uint2* fb_tiles = nullptr;
+    unsigned long long* prof = nullptr;                           // OFPS_HIP_LK_PROF=1: phase table of level 0
+    if (tiled) {
+        const size_t head = ((size_t)levels + 1) & ~size_t(1);     // keeps the uint2 list 8-byte aligned
+        fb_count = static_cast<uint32_t*>(scratch(ctx, S_WORK3, (head + 2 * (size_t)levels * tiles0) * sizeof(uint32_t)));
+        if (!fb_count) return OFPS_HIP_ENOMEM;
+        fb_tiles = reinterpret_cast<uint2*>(fb_count + head);
+        OFPS_HIP_TRY(ctx, hipMemsetAsync(fb_count, 0, (size_t)levels * sizeof(uint32_t), s));
+        if (getenv("OFPS_HIP_LK_PROF")) {
+            prof = static_cast<unsigned long long*>(scratch(ctx, S_WORK2, tiles0 * 6 * sizeof(unsigned long long)));
+            if (!prof) return OFPS_HIP_ENOMEM;
+        }
     }
     float2* cur_flow = fa;
     float2* other = fb;
-    const bool tiled = radius == 2 || radius == 4 || radius == 6;      // kernels that fold the upsample / record passes in
     float2* plain_flow = d_flow;                                       // the untiled path always produces a flow plane
     if (!tiled && !plain_flow) {
         plain_flow = static_cast<float2*>(scratch(ctx, S_WORK1, plane0 * sizeof(float2)));
@@ -646,49 +677,58 @@ int lk_flow_device(ofps_hip_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_cu
     }
     for (int l = levels - 1; l >= 0; --l) {
         const int w = ws[l], h = hs[l];
-        const float2* coarse = nullptr;                                // set: the first step reads 2 * coarse(x/2, y/2)
-        if (l == levels - 1) {
-            OFPS_HIP_TRY(ctx, hipMemsetAsync(cur_flow, 0, (size_t)w * h * sizeof(float2), s));
-        } else if (tiled) {
-            coarse = cur_flow;
-        } else {
-            hipLaunchKernelGGL(lk_upsample_kernel, lk_grid(w, h), dim3(256), 0, s, cur_flow, ws[l + 1], hs[l + 1], other, w, h);
-            float2* t = cur_flow; cur_flow = other; other = t;
-        }
         hipLaunchKernelGGL(lk_grad_kernel, lk_grid(w, h), dim3(256), 0, s, Ip + off[l], w, h, gx, gy);
-        switch (radius) {
-            case 2: hipLaunchKernelGGL(lk_tensor_tiled_kernel<2>, lk_grid(w, h), dim3(256), 0, s, gx, gy, w, h, G); break;
-            case 4: hipLaunchKernelGGL(lk_tensor_tiled_kernel<4>, lk_grid(w, h), dim3(256), 0, s, gx, gy, w, h, G); break;
-            case 6: hipLaunchKernelGGL(lk_tensor_tiled_kernel<6>, lk_grid(w, h), dim3(256), 0, s, gx, gy, w, h, G); break;
-            default: hipLaunchKernelGGL(lk_tensor_kernel, lk_grid(w, h), dim3(256), 0, s, gx, gy, w, h, radius, G);
-        }
-        for (int it = 0; it < iters; ++it) {
-            const bool last = l == 0 && it == iters - 1;
-            uint32_t* cnt = fb_count + (size_t)l * iters + it;
-            uint32_t* tiles = fb_tiles + ((size_t)l * iters + it) * tiles0;
+        if (tiled) {
+            // (measured and rejected: forming the gradients while staging -- five loads per window record instead of three,
+            // 0.53 ms -- and summing G inside the level kernel -- 0.50 ms: that kernel is held to 80 VGPRs and lives at the
+            // VALU limit, the tensor kernel runs at twice its occupancy)
+            switch (radius) {
+                case 2: hipLaunchKernelGGL(lk_tensor_tiled_kernel<2>, lk_grid(w, h), dim3(256), 0, s, gx, gy, w, h, G); break;
+                case 4: hipLaunchKernelGGL(lk_tensor_tiled_kernel<4>, lk_grid(w, h), dim3(256), 0, s, gx, gy, w, h, G); break;
+                default: hipLaunchKernelGGL(lk_tensor_tiled_kernel<6>, lk_grid(w, h), dim3(256), 0, s, gx, gy, w, h, G); break;
+            }
+            // one launch runs all `iters` steps of the level: in = the coarser level's flow (cur_flow), out = `other`
+            const bool last = l == 0;
+            uint32_t* cnt = fb_count + l;
+            uint2* tiles = fb_tiles + (size_t)l * tiles0;
             const dim3 g = lk_grid(w, h);
             const unsigned ntiles = g.x * g.y;
             const dim3 gg(ntiles < (unsigned)(8 * ctx->num_cus) ? ntiles : (unsigned)(8 * ctx->num_cus));
             LkFlowIO io{};
-            io.flow_in = cur_flow;
-            io.coarse = (it == 0) ? coarse : nullptr;
+            io.coarse = l == levels - 1 ? nullptr : cur_flow;
             io.w1 = l + 1 < levels ? ws[l + 1] : 0; io.h1 = l + 1 < levels ? hs[l + 1] : 0;
-            io.flow_out = last ? d_flow : other;                       // the last step skips the flow plane nobody asked for
+            io.flow_out = last ? d_flow : other;                       // the last level skips the flow plane nobody asked for
             io.out_entries = last ? d_entries : nullptr;
             io.nx = 1.0f / (float)W; io.ny = 1.0f / (float)H;
-#define OFPS_LK_STEP(R)                                                                                                      \
-    hipLaunchKernelGGL(lk_step_lds_kernel<R>, g, dim3(256), 0, s, Ip + off[l], Jp + off[l], gx, gy, G, w, h, io, cnt, tiles,       \
-                       (l == 0 && it == 0) ? prof : nullptr);                                                                \
-    hipLaunchKernelGGL(lk_step_general_kernel<R>, gg, dim3(256), 0, s, Ip + off[l], Jp + off[l], gx, gy, G, w, h, io, cnt, tiles)
+            // fallen tiles park their flow in `other`: never the level's input (neighbouring tiles still read `coarse`);
+            // at the last level `other` is free, elsewhere it is the level's output plane, where a pixel's parked flow
+            // is read back by the very thread that later overwrites it with the result
+            float2* park = other;
+#define OFPS_LK_LEVEL(R)                                                                                                     \
+    hipLaunchKernelGGL(lk_level_lds_kernel<R>, g, dim3(256), 0, s, Ip + off[l], Jp + off[l], gx, gy, G, w, h, iters, io, cnt,      \
+                       tiles, park, last ? prof : nullptr);                                                                 \
+    hipLaunchKernelGGL(lk_level_general_kernel<R>, gg, dim3(256), 0, s, Ip + off[l], Jp + off[l], gx, gy, G, w, h, iters, io, cnt, \
+                       tiles, park)
             switch (radius) {
-                case 2: OFPS_LK_STEP(2); break;
-                case 4: OFPS_LK_STEP(4); break;
-                case 6: OFPS_LK_STEP(6); break;
-                default:
-                    hipLaunchKernelGGL(lk_step_kernel<0>, g, dim3(256), 0, s, Ip + off[l], Jp + off[l], gx, gy, G, w, h, radius, cur_flow,
-                                       last ? plain_flow : other);
+                case 2: OFPS_LK_LEVEL(2); break;
+                case 4: OFPS_LK_LEVEL(4); break;
+                default: OFPS_LK_LEVEL(6); break;
             }
-#undef OFPS_LK_STEP
+#undef OFPS_LK_LEVEL
+            if (!last) { float2* t = cur_flow; cur_flow = other; other = t; }
+            continue;
+        }
+        hipLaunchKernelGGL(lk_tensor_kernel, lk_grid(w, h), dim3(256), 0, s, gx, gy, w, h, radius, G);
+        if (l == levels - 1) {
+            OFPS_HIP_TRY(ctx, hipMemsetAsync(cur_flow, 0, (size_t)w * h * sizeof(float2), s));
+        } else {
+            hipLaunchKernelGGL(lk_upsample_kernel, lk_grid(w, h), dim3(256), 0, s, cur_flow, ws[l + 1], hs[l + 1], other, w, h);
+            float2* t = cur_flow; cur_flow = other; other = t;
+        }
+        for (int it = 0; it < iters; ++it) {
+            const bool last = l == 0 && it == iters - 1;
+            hipLaunchKernelGGL(lk_step_kernel<0>, lk_grid(w, h), dim3(256), 0, s, Ip + off[l], Jp + off[l], gx, gy, G, w, h, radius,
+                               cur_flow, last ? plain_flow : other);
             if (!last) { float2* t = cur_flow; cur_flow = other; other = t; }
         }
     }
@@ -706,8 +746,8 @@ int lk_flow_device(ofps_hip_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_cu
             for (int k = 0; k < 5; ++k) ph[k] += (double)(r[k + 1] - r[k]);
             t_min = r[0] < t_min ? r[0] : t_min; t_max = r[5] > t_max ? r[5] : t_max;
         }
-        fprintf(stderr, "[lk prof] level-0 step, %zu tiles: cycles per workgroup  stage-tile+origins %.0f  barrier %.0f  stage-J %.0f  "
-                        "rows %.0f  solve+store %.0f   kernel span %.0f cycles\n", tiles0, ph[0] / tiles0, ph[1] / tiles0, ph[2] / tiles0,
+        fprintf(stderr, "[lk prof] level 0, %zu tiles: cycles per workgroup  stage-tile+origins %.0f  barrier %.0f  stage-J %.0f  "
+                        "rows+solve %.0f  (first step)   later steps+store %.0f   kernel span %.0f cycles\n", tiles0, ph[0] / tiles0, ph[1] / tiles0, ph[2] / tiles0,
                 ph[3] / tiles0, ph[4] / tiles0, (double)(t_max - t_min));
     }
     return OFPS_HIP_OK;
