@@ -276,7 +276,33 @@ __device__ __forceinline__ Quat almeida_update(const Quat& rotation, const float
     return quat_mul(rotation, rot);                                               // :195
 }
 
+// The same update run by a whole wave: the three half-angle sincos evaluations -- two thirds of this serial section's
+// latency -- go to lanes 0..2 in parallel and come back through v_readlane; everything else is wave-uniform.  Same
+// functions on the same arguments as almeida_update, hence the same bits.
+__device__ __forceinline__ Quat almeida_update_wave(const Quat& rotation, const float s[9], float eps, float alpha) {
+    const float a[9] = {s[0], s[1], s[2], s[1], s[3], s[4], s[2], s[4], s[5]};
+    const float b[3] = {s[6], s[7], s[8]};
+    float model[3];
+    if (!lu3_solve(a, b, model)) { model[0] = model[1] = model[2] = 0.0f; }       // :181-183
+    model[0] = model[0] * eps * alpha;                                            // :185
+    model[1] = model[1] * eps * alpha;
+    model[2] = model[2] * eps * alpha;
+    const int lane = threadIdx.x & 63;
+    const float half = lane == 0 ? model[0] * 0.5f : (lane == 1 ? model[1] * 0.5f : -model[2] * 0.5f);
+    float sn, cs;
+    sincosf(half, &sn, &cs);
+    const float s0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sn), 0)), c0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cs), 0));
+    const float s1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sn), 1)), c1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cs), 1));
+    const float s2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sn), 2)), c2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cs), 2));
+    const Quat roll = {c0, 0.0f, s0, 0.0f};
+    const Quat pitch = {c1, s1, 0.0f, 0.0f};
+    const Quat yaw = {c2, 0.0f, 0.0f, s2};
+    const Quat rot = quat_mul(quat_mul(pitch, roll), yaw);                        // :193
+    return quat_mul(rotation, rot);                                               // :195
+}
+
 constexpr int kIters = 30;                      // ceil(15 / ALPHA), lib.rs:132
+constexpr int kProfSlots = 7;                   // OFPS_HIP_ALMEIDA_PROF: stamps per step (5 by thread 0, 2 by wave 2)
 __device__ __forceinline__ float almeida_eps() { return 0.001f * 3.14159265358979323846264338327950288f / 180.0f; }
 
 // Wave-wide f32 sum on the DPP data path (cross-lane operands of ordinary VALU adds: no LDS round trip -- the
@@ -400,9 +426,13 @@ __global__ __launch_bounds__(1024) void almeida_lsq_wg_kernel(const float4* __re
             s[8] += py[t].x * rx + py[t].y * ry;
         }
         block_sum<6, 9>(s, red);
-        if (threadIdx.x == 0) {
-            const float f[9] = {a_sh[0], a_sh[1], a_sh[2], a_sh[3], a_sh[4], a_sh[5], s[6], s[7], s[8]};
-            rot_sh[it & 1] = almeida_update(rotation, f, eps, alpha);
+        if (threadIdx.x < 64) {                                    // wave 0, all lanes: see almeida_update_wave
+            const float f[9] = {a_sh[0], a_sh[1], a_sh[2], a_sh[3], a_sh[4], a_sh[5],
+                                __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(s[6]))),
+                                __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(s[7]))),
+                                __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(s[8])))};
+            const Quat q = almeida_update_wave(rotation, f, eps, alpha);
+            if (threadIdx.x == 0) rot_sh[it & 1] = q;
         }
         __syncthreads();
         // one barrier per step: the slot alternates, so thread 0 cannot overwrite a rotation that a slow wave has yet
@@ -626,23 +656,23 @@ __device__ __forceinline__ bool gran_sweep_sum3(const gran_u4* g, int nblk, uint
     return true;
 }
 
-template <bool FAST, int EPT>
-__global__ __launch_bounds__(1024) void almeida_lsq_cluster_kernel(const float4* __restrict__ entries, size_t n, Camera cam,
+template <bool FAST, int EPT, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void almeida_lsq_cluster_kernel(const float4* __restrict__ entries, size_t n, Camera cam,
                                                                    gran_u4* gran, uint32_t tag_base,
                                                                    float4* __restrict__ out_quat,
                                                                    unsigned long long* __restrict__ prof, uint32_t fault) {
     // fault (tests only, normally 0): workgroup fault-1 withholds its step-3 granule, which is what a workgroup that
     // never became resident looks like to the others -- exercises the timeout and the host's re-solve
     // prof (diagnostics, normally null): thread 0 of every workgroup stamps s_memtime at the phase boundaries of each step
-#define OFPS_STAMP(slot) do { if (prof && threadIdx.x == 0) prof[(((size_t)blockIdx.y * gridDim.x + blockIdx.x) * kIters + it) * 5 + (slot)] = __builtin_readcyclecounter(); } while (0)
+#define OFPS_STAMP(slot) do { if (prof && threadIdx.x == 0) prof[(((size_t)blockIdx.y * gridDim.x + blockIdx.x) * kIters + it) * kProfSlots + (slot)] = __builtin_readcyclecounter(); } while (0)
+#define OFPS_STAMP_W2(slot) do { if (prof && threadIdx.x == 128) prof[(((size_t)blockIdx.y * gridDim.x + blockIdx.x) * kIters + it) * kProfSlots + (slot)] = __builtin_readcyclecounter(); } while (0)
     constexpr bool P_LDS = EPT >= 8;
-    __shared__ float red[16][9];
-    __shared__ float fold_sh[9];
+    __shared__ float red[BLOCK / 64][9];
     __shared__ float apart_sh[6];                       // this workgroup's partial of A = J^T J, published in step 0
     __shared__ float a_sh[6];                           // A folded over all workgroups (rotation-independent)
     __shared__ Quat rot_sh[2];
     __shared__ int fail_sh;
-    __shared__ float4 plds[P_LDS ? EPT * 1024 : 1];     // (roll.x, roll.y, pitch.x, pitch.y) per record
+    __shared__ float4 plds[P_LDS ? EPT * BLOCK : 1];     // (roll.x, roll.y, pitch.x, pitch.y) per record
     const int nblk = gridDim.x, blk = blockIdx.x;
     const size_t item = blockIdx.y;
     gran_u4* g = gran + item * (size_t)(2 * 3) * nblk;                 // [parity][triple: A0-2, A3-5, b][workgroup]
@@ -662,7 +692,7 @@ __global__ __launch_bounds__(1024) void almeida_lsq_cluster_kernel(const float4*
     if (threadIdx.x == 0) { fail_sh = 0; rot_sh[1] = Quat{1.0f, 0.0f, 0.0f, 0.0f}; }   // slot 1 = rotation entering step 0
 #pragma unroll
     for (int t = 0; t < EPT; ++t) {
-        const size_t i = ((size_t)blk * EPT + t) * 1024 + threadIdx.x;
+        const size_t i = ((size_t)blk * EPT + t) * BLOCK + threadIdx.x;
         ok[t] = i < n;
         e[t] = ok[t] ? entries[item * n + i] : make_float4(0.5f, 0.5f, 0.0f, 0.0f);
     }
@@ -677,7 +707,7 @@ __global__ __launch_bounds__(1024) void almeida_lsq_cluster_kernel(const float4*
         const float2 r = ok[t] ? cam_delta_w<FAST>(cam, e[t].x, e[t].y, un, mroll) : zero2;
         const float2 p = ok[t] ? cam_delta_w<FAST>(cam, e[t].x, e[t].y, un, mpitch) : zero2;
         py[t] = ok[t] ? cam_delta_w<FAST>(cam, e[t].x, e[t].y, un, myaw) : zero2;
-        if constexpr (P_LDS) plds[t * 1024 + threadIdx.x] = make_float4(r.x, r.y, p.x, p.y);
+        if constexpr (P_LDS) plds[t * BLOCK + threadIdx.x] = make_float4(r.x, r.y, p.x, p.y);
         else { pr[t] = r; pp[t] = p; }
         s[0] += r.x * r.x + r.y * r.y;
         s[1] += r.x * p.x + r.y * p.y;
@@ -715,7 +745,7 @@ __global__ __launch_bounds__(1024) void almeida_lsq_cluster_kernel(const float4*
             const float2 d = cam_delta_w<FAST>(cam, e[t].x, e[t].y, un, rotm);
             const float rx = e[t].z - d.x, ry = e[t].w - d.y;      // motion - delta
             float2 r, p;
-            if constexpr (P_LDS) { const float4 v = plds[t * 1024 + threadIdx.x]; r = make_float2(v.x, v.y); p = make_float2(v.z, v.w); }
+            if constexpr (P_LDS) { const float4 v = plds[t * BLOCK + threadIdx.x]; r = make_float2(v.x, v.y); p = make_float2(v.z, v.w); }
             else { r = pr[t]; p = pp[t]; }
             s[6] += r.x * rx + r.y * ry;
             s[7] += p.x * rx + p.y * ry;
@@ -736,33 +766,40 @@ __global__ __launch_bounds__(1024) void almeida_lsq_cluster_kernel(const float4*
             }
             if (!(fault && it == 3 && (uint32_t)blk == fault - 1u)) gran_store3(gp + 2 * (size_t)nblk + blk, tag, s[6], s[7], s[8]);
         }
-        if (wave < 3 && (wave == 2 || it == 0)) {                  // wave k gathers triple k (the A triples in step 0 only)
-            float ta = 0.0f, tb = 0.0f, tc = 0.0f;
-            const bool got = gran_sweep_sum3(gp + (size_t)wave * nblk, nblk, tag, ta, tb, tc);
-            if (lane == 0) {
-                if (got) { fold_sh[3 * wave] = ta; fold_sh[3 * wave + 1] = tb; fold_sh[3 * wave + 2] = tc; }
+        // wave k gathers triple k (the A triples in step 0 only); wave 2, which gathers the right-hand side, goes straight
+        // on to the LU + quaternion update -- no barrier and no LDS round trip between the gather and the update
+        float ta = 0.0f, tb = 0.0f, tc = 0.0f;
+        bool got = true;
+        if (wave < 3 && (wave == 2 || it == 0)) got = gran_sweep_sum3(gp + (size_t)wave * nblk, nblk, tag, ta, tb, tc);
+        if (it == 0) {
+            if (wave < 2 && lane == 0) {
+                if (got) { a_sh[3 * wave] = ta; a_sh[3 * wave + 1] = tb; a_sh[3 * wave + 2] = tc; }
                 else fail_sh = 1;
+            }
+            __syncthreads();
+        }
+        OFPS_STAMP(3);
+        if (wave == 2) {
+            OFPS_STAMP_W2(5);
+            if (got) {
+                const float f[9] = {a_sh[0], a_sh[1], a_sh[2], a_sh[3], a_sh[4], a_sh[5], ta, tb, tc};
+                const Quat q = almeida_update_wave(rot_sh[(it + 1) & 1], f, eps, alpha);
+                if (lane == 0) rot_sh[it & 1] = q;
+                OFPS_STAMP_W2(6);
+            } else if (lane == 0) {
+                fail_sh = 1;
             }
         }
         __syncthreads();
-        OFPS_STAMP(3);
         if (fail_sh) {
             if (threadIdx.x == 0) out_quat[item] = make_float4(__builtin_nanf(""), 0.0f, 0.0f, 0.0f);
             return;
         }
-        if (threadIdx.x == 0) {
-            if (it == 0) {
-#pragma unroll
-                for (int k = 0; k < 6; ++k) a_sh[k] = fold_sh[k];
-            }
-            const float f[9] = {a_sh[0], a_sh[1], a_sh[2], a_sh[3], a_sh[4], a_sh[5], fold_sh[6], fold_sh[7], fold_sh[8]};
-            rot_sh[it & 1] = almeida_update(rot_sh[(it + 1) & 1], f, eps, alpha);
-        }
-        __syncthreads();
         OFPS_STAMP(4);
     }
     const Quat rotation = rot_sh[(kIters - 1) & 1];
 #undef OFPS_STAMP
+#undef OFPS_STAMP_W2
     if (blk == 0 && threadIdx.x == 0) out_quat[item] = make_float4(rotation.w, -rotation.i, -rotation.j, -rotation.k);  // :199
 }
 
@@ -957,12 +994,12 @@ struct ClusterGate {
 };
 static ClusterGate g_cluster_gate;
 
-template <bool FAST, int EPT>
+template <bool FAST, int EPT, int BLOCK = 1024>
 static void launch_cluster(hipStream_t s, int nblk, int items, const float4* d_entries, size_t n, const Camera& cam,
                            gran_u4* gran, uint32_t tag_base, float4* d_quat, unsigned long long* prof) {
     uint32_t fault = 0;
     if (const char* f = getenv("OFPS_HIP_ALMEIDA_TEST_FAULT")) fault = (uint32_t)atoi(f);     // tests only
-    hipLaunchKernelGGL((almeida_lsq_cluster_kernel<FAST, EPT>), dim3(nblk, items), dim3(1024), 0, s, d_entries, n, cam, gran,
+    hipLaunchKernelGGL((almeida_lsq_cluster_kernel<FAST, EPT, BLOCK>), dim3(nblk, items), dim3(BLOCK), 0, s, d_entries, n, cam, gran,
                        tag_base, d_quat, prof, fault);
 }
 
@@ -983,8 +1020,14 @@ static int lsq_cluster(ofps_hip_ctx* ctx, const float4* d_entries, size_t n, int
             if (cost < best) { best = cost; ept = e; }
         }
     }
+    // (measured and rejected: 256-thread workgroups for block-vector sized problems -- the block reduction drops from 2.4k
+    // to 1.3k cycles per step but the gather waits that much longer: a step ends one cross-XCD exchange after the LAST
+    // workgroup published, 0.104 vs 0.105 ms at 8,040 vectors; OFPS_HIP_ALMEIDA_BLOCK=256 keeps the variant for A/B runs)
+    int block = 1024;
     if (const char* f = getenv("OFPS_HIP_ALMEIDA_EPT")) { const int v = atoi(f); if (v == 1 || v == 2 || v == 4 || v == 8) ept = v; }   // A/B
-    const size_t per_wg = (size_t)ept * 1024;
+    if (const char* f = getenv("OFPS_HIP_ALMEIDA_BLOCK")) { const int v = atoi(f); if (v == 256 || v == 1024) block = v; }              // A/B
+    if (block == 256 && ept > 2) ept = 2;
+    const size_t per_wg = (size_t)ept * block;
     const size_t nblk_sz = (n + per_wg - 1) / per_wg;
     if (nblk_sz < 1 || nblk_sz > 256 || nblk_sz > (size_t)ctx->num_cus) return 0;
     const int nblk = (int)nblk_sz;
@@ -996,7 +1039,7 @@ static int lsq_cluster(ofps_hip_ctx* ctx, const float4* d_entries, size_t n, int
     hipStream_t s = ctx->stream;
     unsigned long long* prof = nullptr;
     if (getenv("OFPS_HIP_ALMEIDA_PROF")) {
-        prof = static_cast<unsigned long long*>(scratch(ctx, S_ALM_PROF, (size_t)per_launch * nblk * kIters * 5 * sizeof(unsigned long long)));
+        prof = static_cast<unsigned long long*>(scratch(ctx, S_ALM_PROF, (size_t)per_launch * nblk * kIters * kProfSlots * sizeof(unsigned long long)));
         if (!prof) return OFPS_HIP_ENOMEM;
     }
     const size_t cap = ctx->scratch[S_GRAN].cap;
@@ -1014,7 +1057,9 @@ static int lsq_cluster(ofps_hip_ctx* ctx, const float4* d_entries, size_t n, int
         hipEvent_t& ev = g_cluster_gate.ev[ctx->device & 63];
         if (!ev) OFPS_HIP_TRY(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
         else OFPS_HIP_TRY(ctx, hipStreamWaitEvent(s, ev, 0));
-        if (dense && ept == 8) launch_cluster<true, 8>(s, nblk, items, ent, n, cam, gran, tag_base, q, prof);
+        if (block == 256 && ept == 2) launch_cluster<false, 2, 256>(s, nblk, items, ent, n, cam, gran, tag_base, q, prof);
+        else if (block == 256) launch_cluster<false, 1, 256>(s, nblk, items, ent, n, cam, gran, tag_base, q, prof);
+        else if (dense && ept == 8) launch_cluster<true, 8>(s, nblk, items, ent, n, cam, gran, tag_base, q, prof);
         else if (dense && ept == 4) launch_cluster<true, 4>(s, nblk, items, ent, n, cam, gran, tag_base, q, prof);
         else if (dense && ept == 2) launch_cluster<true, 2>(s, nblk, items, ent, n, cam, gran, tag_base, q, prof);
         else if (dense) launch_cluster<true, 1>(s, nblk, items, ent, n, cam, gran, tag_base, q, prof);
@@ -1026,22 +1071,24 @@ static int lsq_cluster(ofps_hip_ctx* ctx, const float4* d_entries, size_t n, int
         OFPS_HIP_TRY(ctx, hipEventRecord(ev, s));
     }
     if (prof) {                                              // diagnostics: phase table of the last launch to stderr
-        const size_t cnt = (size_t)nblk * kIters * 5;
+        const size_t cnt = (size_t)nblk * kIters * kProfSlots;
         std::vector<unsigned long long> h(cnt);
         OFPS_HIP_TRY(ctx, hipMemcpyAsync(h.data(), prof, cnt * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
         OFPS_HIP_TRY(ctx, hipStreamSynchronize(s));
-        double ph[5] = {0, 0, 0, 0, 0};
+        // thread 0: 0 step start, 1 records done, 2 block sum done, 3 granule published (+ A gathered in step 0), 4 step end;
+        // wave 2: 5 right-hand side gathered, 6 rotation updated
+        double ph[6] = {0, 0, 0, 0, 0, 0};
         for (int b = 0; b < nblk; ++b)
             for (int it = 0; it < kIters; ++it) {
-                const unsigned long long* r = h.data() + ((size_t)b * kIters + it) * 5;
-                for (int k = 0; k < 4; ++k) ph[k] += (double)(r[k + 1] - r[k]);
-                if (it + 1 < kIters) ph[4] += (double)(r[5] - r[4]);
+                const unsigned long long* r = h.data() + ((size_t)b * kIters + it) * kProfSlots;
+                ph[0] += (double)(r[1] - r[0]); ph[1] += (double)(r[2] - r[1]); ph[2] += (double)(r[3] - r[2]);
+                ph[3] += (double)(r[5] - r[3]); ph[4] += (double)(r[6] - r[5]); ph[5] += (double)(r[4] - r[6]);
             }
         const double den = (double)nblk * kIters;
-        fprintf(stderr, "[almeida cluster prof] n=%zu nblk=%d ept=%d  cycles/step (100 MHz ticks if constant clock): compute %.0f  "
-                        "block_sum %.0f  publish+sweep %.0f  update %.0f  loop-back %.0f   wg0 total %.0f\n",
-                n, nblk, ept, ph[0] / den, ph[1] / den, ph[2] / den, ph[3] / den, ph[4] / den,
-                (double)(h[(size_t)(kIters - 1) * 5 + 4] - h[0]));
+        fprintf(stderr, "[almeida cluster prof] n=%zu nblk=%d ept=%d block=%d  cycles/step: records %.0f  block_sum %.0f  publish %.0f  "
+                        "gather (wave 2) %.0f  update (wave 2) %.0f  barrier %.0f   wg0 total %.0f\n",
+                n, nblk, ept, block, ph[0] / den, ph[1] / den, ph[2] / den, ph[3] / den, ph[4] / den, ph[5] / den,
+                (double)(h[(size_t)(kIters - 1) * kProfSlots + 4] - h[0]));
     }
     return 1;
 }
