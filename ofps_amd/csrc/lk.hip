@@ -370,7 +370,9 @@ __global__ __launch_bounds__(256, LkStepShared<RADIUS>::WAVES_PER_SIMD) void lk_
                                                            const float* __restrict__ gx, const float* __restrict__ gy,
                                                            const float4* __restrict__ G, int w, int h, int iters, const LkFlowIO io,
                                                            uint32_t* __restrict__ fb_count, uint2* __restrict__ fb_tiles,
-                                                           float2* fb_flow, unsigned long long* __restrict__ prof) {
+                                                           float2* fb_flow, unsigned long long* __restrict__ prof, int force_fall) {
+    // force_fall (tests only, normally -1): every other tile is treated as not fitting at that step, so that the hand-over
+    // to lk_level_general_kernel in the middle of a level is exercised on inputs that would never trigger it
     // prof (diagnostics, normally null): per-workgroup s_memtime stamps at the phase boundaries of the first step
 #define OFPS_LK_STAMP(slot) do { if (prof && threadIdx.x == 0) prof[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 6 + (slot)] = __builtin_readcyclecounter(); } while (0)
     using T = LkTile<RADIUS>;
@@ -417,7 +419,8 @@ __global__ __launch_bounds__(256, LkStepShared<RADIUS>::WAVES_PER_SIMD) void lk_
         const int xmax = max(max(sh.box[0][1], sh.box[1][1]), max(sh.box[2][1], sh.box[3][1]));
         const int ymin = min(min(sh.box[0][2], sh.box[1][2]), min(sh.box[2][2], sh.box[3][2]));
         const int ymax = max(max(sh.box[0][3], sh.box[1][3]), max(sh.box[2][3], sh.box[3][3]));
-        const int fits = xmax >= xmin && xmax - xmin < S::LW && ymax - ymin < S::LH;
+        const int fits = xmax >= xmin && xmax - xmin < S::LW && ymax - ymin < S::LH &&
+                         !(it == force_fall && ((blockIdx.x + blockIdx.y) & 1));
         if (!fits) {                                                     // uniform: box[] is the same for every thread
             if (threadIdx.x == 0) fb_tiles[atomicAdd(fb_count, 1u)] = make_uint2((uint32_t)blockIdx.x | ((uint32_t)blockIdx.y << 16), (uint32_t)it);
             if (active) fb_flow[(size_t)y * w + x] = f;
@@ -675,6 +678,8 @@ int lk_flow_device(ofps_hip_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_cu
         plain_flow = static_cast<float2*>(scratch(ctx, S_WORK1, plane0 * sizeof(float2)));
         if (!plain_flow) return OFPS_HIP_ENOMEM;
     }
+    int force_fall = -1;
+    if (const char* f = getenv("OFPS_HIP_LK_TEST_FALL")) force_fall = atoi(f);                 // tests only
     for (int l = levels - 1; l >= 0; --l) {
         const int w = ws[l], h = hs[l];
         hipLaunchKernelGGL(lk_grad_kernel, lk_grid(w, h), dim3(256), 0, s, Ip + off[l], w, h, gx, gy);
@@ -706,7 +711,7 @@ int lk_flow_device(ofps_hip_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_cu
             float2* park = other;
 #define OFPS_LK_LEVEL(R)                                                                                                     \
     hipLaunchKernelGGL(lk_level_lds_kernel<R>, g, dim3(256), 0, s, Ip + off[l], Jp + off[l], gx, gy, G, w, h, iters, io, cnt,      \
-                       tiles, park, last ? prof : nullptr);                                                                 \
+                       tiles, park, last ? prof : nullptr, force_fall);                                                     \
     hipLaunchKernelGGL(lk_level_general_kernel<R>, gg, dim3(256), 0, s, Ip + off[l], Jp + off[l], gx, gy, G, w, h, iters, io, cnt, \
                        tiles, park)
             switch (radius) {

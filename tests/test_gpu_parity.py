@@ -494,6 +494,35 @@ def test_lk_flow_bit_exact_vs_oracle(ctx, W, H, levels, radius, iters):
     np.testing.assert_array_equal(e_g.view(np.uint32), oracle.flow_to_entries(f_o).view(np.uint32))   # cv-decoder records
 
 
+@pytest.mark.parametrize("fall_step", [0, 1, 2])
+@pytest.mark.parametrize("radius", [2, 4, 6])
+def test_lk_flow_hand_over_in_the_middle_of_a_level(ctx, monkeypatch, fall_step, radius):
+    """The level kernel keeps a tile's flow on chip across the Gauss-Newton steps of a level; a tile whose current-frame
+    rectangle stops fitting LDS at step k parks its flow and the general kernel finishes steps k.. of the level.  The
+    test hook makes every other tile fall at step k (0 = the whole level, 1 / 2 = mid-level), with and without the
+    records output: same bits as the oracle either way."""
+    monkeypatch.setenv("OFPS_HIP_LK_TEST_FALL", str(fall_step))
+    W, H, levels, iters = 320, 180, 3, 3
+    fr = synth.luma_sequence(2, W, H, max_step=3, seed=77 + radius)
+    f_o = oracle.lk_flow(fr[0], fr[1], levels, radius, iters)
+    f_g, e_g = ctx.lk_flow(fr[0], fr[1], levels, radius, iters, want_entries=True)
+    np.testing.assert_array_equal(f_g.view(np.uint32), f_o.view(np.uint32))
+    np.testing.assert_array_equal(e_g.view(np.uint32), oracle.flow_to_entries(f_o).view(np.uint32))
+    f_only = ctx.lk_flow(fr[0], fr[1], levels, radius, iters, want_entries=False)
+    np.testing.assert_array_equal(f_only.view(np.uint32), f_o.view(np.uint32))
+    # records only (no flow plane requested: the device-pointer entry point, what hip_lk's decode path calls)
+    import torch
+    dfr = torch.from_numpy(fr).cuda()
+    d_ent = torch.zeros((W * H, 4), dtype=torch.float32, device="cuda")
+    ctx.use_torch_stream()
+    try:
+        ctx.lk_flow_dev(dfr[0].data_ptr(), dfr[1].data_ptr(), W, H, W, levels, radius, iters, None, d_ent.data_ptr())
+        torch.cuda.synchronize()
+    finally:
+        ctx.use_own_stream()
+    np.testing.assert_array_equal(d_ent.cpu().numpy().view(np.uint32), oracle.flow_to_entries(f_o).view(np.uint32))
+
+
 def test_lk_flow_recovers_planted_translation(ctx):
     base = synth.luma_sequence(1, 640 + 64, 360 + 64, max_step=0, noise=0, seed=5)[0]
     dx, dy = 5, -3
