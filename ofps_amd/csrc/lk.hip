@@ -19,7 +19,7 @@
 
 namespace ofps {
 
-__device__ __forceinline__ int lk_clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+__device__ __forceinline__ int lk_clampi(int v, int lo, int hi) { return max(lo, min(v, hi)); }   // lo <= hi everywhere: v_max_i32 + v_min_i32 (or one v_med3_i32)
 
 // wave-wide integer min / max on the DPP data path (cross-lane operands of ordinary VALU instructions; __shfl_xor is
 // six dependent ds_bpermute_b32 per value).  Result is wave-uniform (read from lane 63).
@@ -305,9 +305,11 @@ struct LkStepShared {
     // capacity of the current-frame rectangle: flows inside a tile may differ by up to SPREAD pixels; only the rectangle
     // a tile really needs is staged, so the capacity costs LDS space, not time
     static constexpr int SPREAD = 20, LW = T::TW + 1 + SPREAD, LH = T::TH + 1 + SPREAD;
-    float4 tile[T::TH][T::TW];         // (I, gx, gy, -) of the previous frame's window
     static constexpr int JS = (LW + 4) / 4 * 4;     // row stride in floats: a multiple of 4, so rows start 16-byte aligned
+    // jl first: its reads are ds_read2_b32, whose two offsets are 8 bits of dwords -- at LDS offset 0 the N+1 texels of a
+    // row are reachable from one address register, behind the tile each pair costs a v_add_u32
     alignas(16) float jl[LH][JS];
+    float4 tile[T::TH][T::TW];         // (I, gx, gy, -) of the previous frame's window
     int box[4][4];                     // per wave: min x0, max x0+1, min y0, max y0+1
     // what the LDS footprint allows (160 KB per CU, 4 waves per workgroup): the register budget hipcc is held to
     static constexpr int WAVES_PER_SIMD = RADIUS <= 2 ? 8 : RADIUS <= 4 ? 6 : 4;
@@ -318,7 +320,9 @@ __device__ __forceinline__ int lk_origin(int q, float fl, int lim, float& frac) 
     const float fq = (float)q + fl;
     const float q0f = floorf(fq);
     frac = fq - q0f;
-    const float c = q0f < -1.0f ? -1.0f : (q0f > (float)lim ? (float)lim : q0f);
+    // the oracle's two-sided clamp of the floor; one v_med3_f32 (flows are finite: they come from u8 frames through
+    // guarded 2x2 solves, so the NaN cases in which a median and a compare chain differ do not arise)
+    const float c = __builtin_amdgcn_fmed3f(q0f, -1.0f, (float)lim);
     return (int)c;
 }
 
@@ -440,10 +444,13 @@ __global__ __launch_bounds__(256, LkStepShared<RADIUS>::WAVES_PER_SIMD) void lk_
                              (reinterpret_cast<uintptr_t>(J) & 15) == 0;
             if (vec) {                                                   // uniform
                 xs = xa4;
-                for (int t = threadIdx.x; t < cw4 * chh; t += 256) {
-                    const int cy = t / cw4, c4 = t - cy * cw4;
-                    *reinterpret_cast<float4*>(&sh.jl[cy][4 * c4]) =
-                        *reinterpret_cast<const float4*>(J + (size_t)lk_clampi(ymin + cy, 0, h - 1) * w + xa4 + 4 * c4);
+                // 32 lanes per rectangle row (cw4 <= JS / 4 <= 32), 8 rows per pass: no division by the run-time width
+                static_assert(S::JS / 4 <= 32, "J staging assumes at most 32 float4 per rectangle row");
+                const int c4 = threadIdx.x & 31;
+                if (c4 < cw4) {
+                    for (int cy = threadIdx.x >> 5; cy < chh; cy += 8)
+                        *reinterpret_cast<float4*>(&sh.jl[cy][4 * c4]) =
+                            *reinterpret_cast<const float4*>(J + (size_t)lk_clampi(ymin + cy, 0, h - 1) * w + xa4 + 4 * c4);
                 }
             } else {
                 const int cw = xmax - xmin + 1;
