@@ -840,58 +840,85 @@ __device__ __forceinline__ uint32_t sample_index(const SampleKey& k, uint32_t i,
 
 // one thread per (item, hypothesis): 3-sample solve, sequential sums in sample order (lib.rs:215-217);
 // writes the homogeneous matrix of fit.inverse() (lib.rs:224)
+// One hypothesis per QUAD of lanes (16 per wave): lane q < 3 of a quad owns sample q -- its record, prototypes and, per
+// step, its `delta` -- and the three per-sample terms of every sum are added in sample order through quad_perm
+// broadcasts (DPP operands, no LDS), so every lane of the quad holds the sums the one-lane walk produced, bit for bit.
+// The update runs in all four lanes with the three half-angle sincos spread over lanes 0..2 (almeida_update_wave's
+// trick at quad width).  A hypothesis is a chain of 30 dependent steps on a handful of lanes either way -- latency,
+// not throughput -- and the quad form shortens the chain: three `delta` and three sincos side by side instead of in a row.
+template <int J>
+__device__ __forceinline__ float quad_bcast(float x) {            // value of lane J of the caller's quad
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), J * 0x55, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float quad_sum3(float init, float t, uint32_t n3) {   // ((init + t[0]) + t[1]) + t[2], first n3 terms
+    float s = init;
+    const float t0 = quad_bcast<0>(t), t1 = quad_bcast<1>(t), t2 = quad_bcast<2>(t);
+    if (n3 > 0) s += t0;
+    if (n3 > 1) s += t1;
+    if (n3 > 2) s += t2;
+    return s;
+}
+__device__ __forceinline__ Quat almeida_update_quad(const Quat& rotation, const float s[9], float eps, float alpha, int q) {
+    const float a[9] = {s[0], s[1], s[2], s[1], s[3], s[4], s[2], s[4], s[5]};
+    const float b[3] = {s[6], s[7], s[8]};
+    float model[3];
+    if (!lu3_solve(a, b, model)) { model[0] = model[1] = model[2] = 0.0f; }       // :181-183
+    model[0] = model[0] * eps * alpha;                                            // :185
+    model[1] = model[1] * eps * alpha;
+    model[2] = model[2] * eps * alpha;
+    const float half = q == 0 ? model[0] * 0.5f : (q == 1 ? model[1] * 0.5f : -model[2] * 0.5f);
+    float sn, cs;
+    sincosf(half, &sn, &cs);
+    const Quat roll = {quad_bcast<0>(cs), 0.0f, quad_bcast<0>(sn), 0.0f};
+    const Quat pitch = {quad_bcast<1>(cs), quad_bcast<1>(sn), 0.0f, 0.0f};
+    const Quat yaw = {quad_bcast<2>(cs), 0.0f, 0.0f, quad_bcast<2>(sn)};
+    const Quat rot = quat_mul(quat_mul(pitch, roll), yaw);                        // :193
+    return quat_mul(rotation, rot);                                               // :195
+}
+
+constexpr int kHypPerWave = 16;
+
 __global__ __launch_bounds__(64) void ransac_hyp_kernel(const float4* __restrict__ entries, uint32_t n, uint32_t iters,
                                                         uint64_t seed, Camera cam, Mat3* __restrict__ hyp) {
     const size_t item = blockIdx.y;
-    const uint32_t it = blockIdx.x * 64 + threadIdx.x;
-    if (it >= iters) return;
+    const int q = threadIdx.x & 3;
+    const uint32_t it_raw = blockIdx.x * kHypPerWave + (threadIdx.x >> 2);
+    const bool live = it_raw < iters;
+    const uint32_t it = live ? it_raw : iters - 1;                // tail quads repeat the last hypothesis (all lanes stay active for the DPP reads)
     const float eps = almeida_eps();
     const uint32_t n3 = n < 3 ? n : 3;
     const SampleKey sk = sample_key(seed + item, it, 0, n);        // every item of a batch draws its own samples
-    float4 e[3];
-    float2 pr[3], pp[3], py[3];
     const Mat3 mroll = mat3_from_euler(0.0f, eps, 0.0f), mpitch = mat3_from_euler(eps, 0.0f, 0.0f),
                myaw = mat3_from_euler(0.0f, 0.0f, -eps);
-#pragma unroll
-    for (uint32_t j = 0; j < 3; ++j) {
-        if (j < n3) {
-            e[j] = entries[item * n + sample_index(sk, j, n)];
-            pr[j] = cam_delta(cam, e[j].x, e[j].y, mroll);
-            pp[j] = cam_delta(cam, e[j].x, e[j].y, mpitch);
-            py[j] = cam_delta(cam, e[j].x, e[j].y, myaw);
-        }
-    }
+    // this lane's sample (lane 3 of a quad, and lanes past n3, carry a harmless copy of sample 0: their terms are never added)
+    const uint32_t j = (uint32_t)q < n3 ? (uint32_t)q : 0u;
+    const float4 e = entries[item * n + sample_index(sk, j, n)];
+    const float2 pr = cam_delta(cam, e.x, e.y, mroll);
+    const float2 pp = cam_delta(cam, e.x, e.y, mpitch);
+    const float2 py = cam_delta(cam, e.x, e.y, myaw);
     // A = J^T J depends on the prototypes only: summed once, in sample order (the reference re-adds the same
     // numbers in every step, lib.rs:159-173)
-    float a[6] = {0, 0, 0, 0, 0, 0};
-#pragma unroll
-    for (uint32_t j = 0; j < 3; ++j) {
-        if (j >= n3) break;
-        a[0] += pr[j].x * pr[j].x + pr[j].y * pr[j].y;
-        a[1] += pr[j].x * pp[j].x + pr[j].y * pp[j].y;
-        a[2] += pr[j].x * py[j].x + pr[j].y * py[j].y;
-        a[3] += pp[j].x * pp[j].x + pp[j].y * pp[j].y;
-        a[4] += pp[j].x * py[j].x + pp[j].y * py[j].y;
-        a[5] += py[j].x * py[j].x + py[j].y * py[j].y;
-    }
+    float a[6];
+    a[0] = quad_sum3(0.0f, pr.x * pr.x + pr.y * pr.y, n3);
+    a[1] = quad_sum3(0.0f, pr.x * pp.x + pr.y * pp.y, n3);
+    a[2] = quad_sum3(0.0f, pr.x * py.x + pr.y * py.y, n3);
+    a[3] = quad_sum3(0.0f, pp.x * pp.x + pp.y * pp.y, n3);
+    a[4] = quad_sum3(0.0f, pp.x * py.x + pp.y * py.y, n3);
+    a[5] = quad_sum3(0.0f, py.x * py.x + py.y * py.y, n3);
     Quat rotation = {1.0f, 0.0f, 0.0f, 0.0f};
     for (int s_it = 0; s_it < kIters; ++s_it) {
         const float alpha = (s_it == kIters - 1) ? 1.0f : 0.5f;
         const Mat3 rotm = quat_to_mat3(rotation);
+        const float2 d = cam_delta(cam, e.x, e.y, rotm);
+        const float rx = e.z - d.x, ry = e.w - d.y;
         float s[9] = {a[0], a[1], a[2], a[3], a[4], a[5], 0, 0, 0};
-#pragma unroll
-        for (uint32_t j = 0; j < 3; ++j) {              // compile-time indices keep e/pr/pp/py in registers
-            if (j >= n3) break;
-            const float2 d = cam_delta(cam, e[j].x, e[j].y, rotm);
-            const float rx = e[j].z - d.x, ry = e[j].w - d.y;
-            s[6] += pr[j].x * rx + pr[j].y * ry;
-            s[7] += pp[j].x * rx + pp[j].y * ry;
-            s[8] += py[j].x * rx + py[j].y * ry;
-        }
-        rotation = almeida_update(rotation, s, eps, alpha);
+        s[6] = quad_sum3(0.0f, pr.x * rx + pr.y * ry, n3);
+        s[7] = quad_sum3(0.0f, pp.x * rx + pp.y * ry, n3);
+        s[8] = quad_sum3(0.0f, py.x * rx + py.y * ry, n3);
+        rotation = almeida_update_quad(rotation, s, eps, alpha, q);
     }
     // fit = rotation.inverse(); mat = fit.inverse().to_homogeneous() = to_homogeneous(rotation)
-    hyp[item * iters + it] = quat_to_mat3(rotation);
+    if (live && q == 0) hyp[item * iters + it] = quat_to_mat3(rotation);
 }
 
 __device__ __forceinline__ bool ransac_is_inlier(const Camera& cam, float fx, float fy, const Mat3& mat, const float4& e,
@@ -1180,7 +1207,7 @@ int almeida_device(ofps_hip_ctx* ctx, const float4* d_entries, size_t n, int bat
     if (n == 0 || ns == 0) {
         OFPS_HIP_TRY(ctx, hipMemsetAsync(sel_n, 0, (size_t)batch * sizeof(uint32_t), s));
     } else {
-        hipLaunchKernelGGL(ransac_hyp_kernel, dim3((iters + 63) / 64, batch), dim3(64), 0, s, d_entries, (uint32_t)n, iters,
+        hipLaunchKernelGGL(ransac_hyp_kernel, dim3((iters + kHypPerWave - 1) / kHypPerWave, batch), dim3(64), 0, s, d_entries, (uint32_t)n, iters,
                            seed, cam, hyp);
         hipLaunchKernelGGL(ransac_count_kernel, dim3(iters, batch), dim3(256), 0, s, d_entries, (uint32_t)n, ns, iters, seed,
                            cam, fx, fy, thr2, hyp, counts);
