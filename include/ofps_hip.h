@@ -149,6 +149,15 @@ int ofps_hip_densify_weighted(ofps_hip_ctx* ctx, const float* entries, const flo
 /* batch items of n_per_item entries each (contiguous); outputs per item. */
 int ofps_hip_densify_dev(ofps_hip_ctx* ctx, const void* d_entries, size_t n_per_item, int batch,
                          int w, int h, void* d_out_field, void* d_out_cells /* or NULL */);
+/* The same fields for a PER-PIXEL producer (cv-decoder/src/lib.rs:239-291): d_entries holds W*H records in raster order
+ * whose positions are ((x+.5)/W, (y+.5)/H) -- what ofps_hip_lk_flow_dev writes -- and d_mask (W*H bytes, or NULL) selects
+ * the records that are inserted (cv-decoder's contrast mask, :251-276).  A cell's records are then a rectangle of pixels
+ * in raster order, which is their input order: one launch, no sort, the same bits as ofps_hip_densify_dev on the
+ * (compacted) records.  verify != 0 checks the precondition on the device first (blocking) and fails with
+ * OFPS_HIP_EINVAL when a record is not where the lattice puts it; without it a violated precondition gives an
+ * unspecified field. */
+int ofps_hip_densify_raster_dev(ofps_hip_ctx* ctx, const void* d_entries, const void* d_mask /* or NULL */, int W, int H,
+                                int w, int h, void* d_out_field /* 2*w*h floats */, int verify);
 int ofps_hip_densify_to_entries(ofps_hip_ctx* ctx, const float* entries, size_t n, int w, int h,
                                 float* out_entries /* capacity 4*w*h */, size_t* n_out);
 

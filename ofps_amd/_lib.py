@@ -47,6 +47,7 @@ PROTOTYPES = {
                                      C.c_uint, _f32p, _szp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "ofps_hip_lk_flow_dev": (C.c_int, [_ctx, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp]),
     "ofps_hip_densify": (C.c_int, [_ctx, _f32p, C.c_size_t, C.c_int, C.c_int, _f32p, _u32p]),
+    "ofps_hip_densify_raster_dev": (C.c_int, [_ctx, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_int]),
     "ofps_hip_densify_weighted": (C.c_int, [_ctx, _f32p, _f32p, C.c_size_t, C.c_int, C.c_int, _f32p, _u32p]),
     "ofps_hip_densify_dev": (C.c_int, [_ctx, _vp, C.c_size_t, C.c_int, C.c_int, C.c_int, _vp, _vp]),
     "ofps_hip_densify_to_entries": (C.c_int, [_ctx, _f32p, C.c_size_t, C.c_int, C.c_int, _f32p, _szp]),

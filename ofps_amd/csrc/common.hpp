@@ -78,6 +78,10 @@ int densify_device_raw(ofps_hip_ctx* ctx, const float4* d_entries, size_t n, int
                        const float* d_weights);
 int densify_entries_device(ofps_hip_ctx* ctx, const float4* d_entries, size_t n, int w, int h, float2* d_field,
                            float4* d_out_entries, uint32_t* d_count);
+int densify_raster_device(ofps_hip_ctx* ctx, const float4* d_entries, const uint8_t* d_mask, int W, int H, int w, int h,
+                          float2* d_field, uint32_t** out_begin, uint32_t** out_end);
+int densify_raster_entries_device(ofps_hip_ctx* ctx, const float4* d_entries, const uint8_t* d_mask, int W, int H, int w, int h,
+                                  float2* d_field, float4* d_out_entries, uint32_t* d_count);
 int contrast_mask_device(ofps_hip_ctx* ctx, const uint8_t* d_gray, int W, int H, int stride, uint8_t* d_mask);
 int compact_entries_device(ofps_hip_ctx* ctx, const float4* d_in, const uint8_t* d_mask, size_t n, float4* d_out,
                            uint32_t* d_count);

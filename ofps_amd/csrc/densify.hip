@@ -230,6 +230,88 @@ __global__ __launch_bounds__(256) void cell_sum_kernel(const float4* __restrict_
     }
 }
 
+// ---- per-pixel producers (cv-decoder/src/lib.rs:239-291: one record per pixel in raster order, position
+// ((x+.5)/W, (y+.5)/H), optionally only where a mask is set).  For such input the cell of a record depends on its column
+// only (x index) and on its row only (y index), monotonically, so the records of one cell are a RECTANGLE of pixels and
+// their input order is the raster order of that rectangle: no sort is needed to add them in the reference's order.  One
+// wave per cell finds its rectangle by bisection on the densifier's own cell function, gathers 64 records at a time
+// (mask-compacted in order through a ballot) and adds them exactly like cell_sum_kernel -- same operations in the same
+// order, same bits, one launch instead of nine and the records read once instead of twice.
+__device__ __forceinline__ int raster_cell_of(int i, float inv_n, int cells_1d) {   // cell index of pixel column/row i
+    uint32_t cx, cy;
+    const float p = ((float)i + 0.5f) * inv_n;              // the producer's position expression (lk.hip lk_store)
+    densifier_cell(p, p, cells_1d, cells_1d, cx, cy);        // 0 < p < 1: the all-component clamp acts per component
+    return (int)cx;
+}
+__device__ __forceinline__ int raster_first_at_least(int c, int n, float inv_n, int cells_1d) {   // min i with cell(i) >= c, or n
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (raster_cell_of(mid, inv_n, cells_1d) >= c) hi = mid; else lo = mid + 1;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(256) void raster_cell_sum_kernel(const float4* __restrict__ entries, const uint8_t* __restrict__ mask,
+                                                              int W, int H, int w, int h, float2* __restrict__ out_field,
+                                                              uint32_t* __restrict__ cell_begin, uint32_t* __restrict__ cell_end) {
+    __shared__ float2 stage[4][64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int cell = blockIdx.x * 4 + wave;
+    if (cell >= w * h) return;                         // wave-uniform; no block barrier below
+    const int cx = cell % w, cy = cell / w;
+    const float nx = 1.0f / (float)W, ny = 1.0f / (float)H;
+    const int x0 = raster_first_at_least(cx, W, nx, w), x1 = raster_first_at_least(cx + 1, W, nx, w);
+    const int y0 = raster_first_at_least(cy, H, ny, h), y1 = raster_first_at_least(cy + 1, H, ny, h);
+    const int cw = x1 - x0, total = cw * (y1 - y0);
+    float sum = 0.0f, cnt = kF32Eps;                   // motion_field.rs:133-138
+    uint32_t kept = 0;
+    for (int k0 = 0; k0 < total; k0 += 64) {
+        const int k = k0 + lane;
+        bool on = k < total;
+        float2 mv = make_float2(0.0f, 0.0f);
+        if (on) {
+            const int ry = k / cw;
+            const size_t idx = (size_t)(y0 + ry) * W + (x0 + (k - ry * cw));
+            on = !mask || mask[idx];
+            if (on) { const float4 en = entries[idx]; mv = make_float2(en.z, en.w); }
+        }
+        const unsigned long long bal = __ballot(on);
+        if (on) stage[wave][__popcll(bal & ((1ull << lane) - 1ull))] = mv;
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        const int m = __popcll(bal);
+        kept += (uint32_t)m;
+        if (lane < 2) {
+            const float* col = reinterpret_cast<const float*>(&stage[wave][0]) + lane;
+            for (int j = 0; j < m; ++j) {
+                const float wgt = 1.0f;
+                cnt += wgt;                            // :142-143
+                sum = col[2 * j] * wgt + sum;          // :144-146 (motion * weight + column)
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+    if (lane < 2) reinterpret_cast<float*>(out_field + cell)[lane] = sum / cnt;   // :304
+    if (lane == 0) { cell_begin[cell] = 0; cell_end[cell] = kept; }                // visited <=> end > begin
+}
+
+// test aid: does every record sit where the rectangle walk assumes?  flag[0] counts records whose stored position maps
+// to another cell than (cell(x), cell(y)) or whose stored position is not the producer's expression
+__global__ __launch_bounds__(256) void raster_check_kernel(const float4* __restrict__ entries, int W, int H, int w, int h,
+                                                           uint32_t* __restrict__ flag) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= W || y >= H) return;
+    const float4 e = entries[(size_t)y * W + x];
+    uint32_t cx, cy;
+    densifier_cell(e.x, e.y, w, h, cx, cy);
+    const float nx = 1.0f / (float)W, ny = 1.0f / (float)H;
+    const bool ok = (int)cx == raster_cell_of(x, nx, w) && (int)cy == raster_cell_of(y, ny, h) &&
+                    e.x == ((float)x + 0.5f) * nx && e.y == ((float)y + 0.5f) * ny;
+    if (!ok) atomicAdd(flag, 1u);
+}
+
 // cv-decoder/src/lib.rs:279-291: visited cells in BTreeSet<(x,y)> order -> entries.  One
 // workgroup per item walks the x-major cell order in 1024-cell chunks with a running offset.
 __global__ __launch_bounds__(1024) void cells_to_entries_kernel(const float2* __restrict__ field,
@@ -449,6 +531,35 @@ int densify_entries_device(ofps_hip_ctx* ctx, const float4* d_entries, size_t n,
     return OFPS_HIP_OK;
 }
 
+// densify for per-pixel raster producers (see raster_cell_sum_kernel).  d_mask: W*H bytes or nullptr.  Leaves visited
+// tables in S_WORK3 / S_WORK4 like densify_device.
+int densify_raster_device(ofps_hip_ctx* ctx, const float4* d_entries, const uint8_t* d_mask, int W, int H, int w, int h,
+                          float2* d_field, uint32_t** out_begin, uint32_t** out_end) {
+    const size_t cells = (size_t)w * (size_t)h;
+    OFPS_REQUIRE(ctx, W >= 1 && H >= 1 && (size_t)W * H < (1ull << 31), "densify_raster: bad frame %dx%d", W, H);
+    OFPS_REQUIRE(ctx, w >= 1 && h >= 1 && cells <= 65536, "densify_raster: grid %dx%d unsupported (1..65536 cells)", w, h);
+    auto* begin = static_cast<uint32_t*>(scratch(ctx, S_WORK3, cells * sizeof(uint32_t)));
+    auto* end = static_cast<uint32_t*>(scratch(ctx, S_WORK4, cells * sizeof(uint32_t)));
+    if (!begin || !end) return OFPS_HIP_ENOMEM;
+    if (out_begin) *out_begin = begin;
+    if (out_end) *out_end = end;
+    hipLaunchKernelGGL(raster_cell_sum_kernel, dim3((unsigned)((cells + 3) / 4)), dim3(256), 0, ctx->stream, d_entries, d_mask, W, H,
+                       w, h, d_field, begin, end);
+    OFPS_HIP_TRY(ctx, hipGetLastError());
+    return OFPS_HIP_OK;
+}
+
+int densify_raster_entries_device(ofps_hip_ctx* ctx, const float4* d_entries, const uint8_t* d_mask, int W, int H, int w, int h,
+                                  float2* d_field, float4* d_out_entries, uint32_t* d_count) {
+    uint32_t *begin = nullptr, *end = nullptr;
+    int rc = densify_raster_device(ctx, d_entries, d_mask, W, H, w, h, d_field, &begin, &end);
+    if (rc != OFPS_HIP_OK) return rc;
+    hipLaunchKernelGGL(cells_to_entries_kernel, dim3(1), dim3(1024), 0, ctx->stream, d_field, begin, end, w, h, d_out_entries,
+                       d_count);
+    OFPS_HIP_TRY(ctx, hipGetLastError());
+    return OFPS_HIP_OK;
+}
+
 }  // namespace ofps
 
 extern "C" {
@@ -553,6 +664,27 @@ int ofps_hip_densify_to_entries(ofps_hip_ctx* ctx, const float* entries, size_t 
     if (cnt) OFPS_HIP_TRY(ctx, hipMemcpy(out_entries, d_out, (size_t)cnt * sizeof(float4), hipMemcpyDeviceToHost));
     *n_out = cnt;
     return OFPS_HIP_OK;
+}
+
+int ofps_hip_densify_raster_dev(ofps_hip_ctx* ctx, const void* d_entries, const void* d_mask, int W, int H, int w, int h,
+                                void* d_out_field, int verify) {
+    if (!ctx) return OFPS_HIP_EINVAL;
+    OFPS_REQUIRE(ctx, d_entries && d_out_field, "densify_raster: null device pointer");
+    OFPS_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (verify) {                                       // blocking; for tests and for hosts that do not own the producer
+        OFPS_REQUIRE(ctx, W >= 1 && H >= 1 && w >= 1 && h >= 1, "densify_raster: bad geometry");
+        auto* flag = static_cast<uint32_t*>(ofps::scratch(ctx, ofps::S_RESULT, 16));
+        if (!flag) return OFPS_HIP_ENOMEM;
+        OFPS_HIP_TRY(ctx, hipMemsetAsync(flag, 0, sizeof(uint32_t), ctx->stream));
+        hipLaunchKernelGGL(ofps::raster_check_kernel, dim3((W + 63) / 64, (H + 3) / 4), dim3(256), 0, ctx->stream,
+                           static_cast<const float4*>(d_entries), W, H, w, h, flag);
+        uint32_t bad = 0;
+        OFPS_HIP_TRY(ctx, hipMemcpyAsync(&bad, flag, sizeof(bad), hipMemcpyDeviceToHost, ctx->stream));
+        OFPS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        OFPS_REQUIRE(ctx, bad == 0, "densify_raster: %u records are not the per-pixel lattice of a %dx%d frame", bad, W, H);
+    }
+    return ofps::densify_raster_device(ctx, static_cast<const float4*>(d_entries), static_cast<const uint8_t*>(d_mask), W, H, w, h,
+                                       static_cast<float2*>(d_out_field), nullptr, nullptr);
 }
 
 }  // extern "C"

@@ -810,31 +810,38 @@ int ofps_hip_lk_decode(ofps_hip_ctx* ctx, const uint8_t* prev, const uint8_t* cu
     OFPS_HIP_TRY(ctx, ofps::upload_rows(d_frames + px, W, cur, stride, W, H, ctx->stream));
     int rc = ofps_hip_lk_flow_dev(ctx, d_frames, d_frames + px, W, H, W, levels, radius, iters, nullptr, d_ent);
     if (rc != OFPS_HIP_OK) return rc;
-    size_t n_rec = px;
-    const float4* d_rec = d_ent;
+    const uint8_t* d_mask = nullptr;
     if (use_mask) {
-        auto* d_mask = static_cast<uint8_t*>(ofps::scratch(ctx, ofps::S_MASK, px));
-        auto* d_ent2 = static_cast<float4*>(ofps::scratch(ctx, ofps::S_ENTRIES2, px * sizeof(float4)));
-        if (!d_mask || !d_ent2) return OFPS_HIP_ENOMEM;
-        rc = ofps::contrast_mask_device(ctx, d_frames + px, W, H, W, d_mask);
+        auto* m = static_cast<uint8_t*>(ofps::scratch(ctx, ofps::S_MASK, px));
+        if (!m) return OFPS_HIP_ENOMEM;
+        rc = ofps::contrast_mask_device(ctx, d_frames + px, W, H, W, m);
         if (rc != OFPS_HIP_OK) return rc;
-        rc = ofps::compact_entries_device(ctx, d_ent, d_mask, px, d_ent2, d_cnt + 1);
-        if (rc != OFPS_HIP_OK) return rc;
-        uint32_t kept = 0;
-        OFPS_HIP_TRY(ctx, hipMemcpyAsync(&kept, d_cnt + 1, sizeof(kept), hipMemcpyDeviceToHost, ctx->stream));
-        OFPS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        n_rec = kept;
-        d_rec = d_ent2;
+        d_mask = m;
     }
     if (out_w) *out_w = per_pixel ? W : gw;
     if (out_h) *out_h = per_pixel ? H : gh;
     if (per_pixel) {
+        size_t n_rec = px;
+        const float4* d_rec = d_ent;
+        if (use_mask) {                                  // the masked records themselves: order-preserving compaction
+            auto* d_ent2 = static_cast<float4*>(ofps::scratch(ctx, ofps::S_ENTRIES2, px * sizeof(float4)));
+            if (!d_ent2) return OFPS_HIP_ENOMEM;
+            rc = ofps::compact_entries_device(ctx, d_ent, d_mask, px, d_ent2, d_cnt + 1);
+            if (rc != OFPS_HIP_OK) return rc;
+            uint32_t kept = 0;
+            OFPS_HIP_TRY(ctx, hipMemcpyAsync(&kept, d_cnt + 1, sizeof(kept), hipMemcpyDeviceToHost, ctx->stream));
+            OFPS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            n_rec = kept;
+            d_rec = d_ent2;
+        }
         if (n_rec) OFPS_HIP_TRY(ctx, hipMemcpyAsync(out_entries, d_rec, n_rec * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
         OFPS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         *n_out = n_rec;
         return OFPS_HIP_OK;
     }
-    rc = ofps::densify_entries_device(ctx, d_rec, n_rec, gw, gh, d_field, d_out, d_cnt);
+    // down-sampled output (cv-decoder/src/lib.rs:244-291): the records are this call's own per-pixel lattice, so the
+    // densifier walks each cell's rectangle of pixels (masked ones skipped in place) instead of sorting 2 M records
+    rc = ofps::densify_raster_entries_device(ctx, d_ent, d_mask, W, H, gw, gh, d_field, d_out, d_cnt);
     if (rc != OFPS_HIP_OK) return rc;
     uint32_t cnt = 0;
     OFPS_HIP_TRY(ctx, hipMemcpyAsync(&cnt, d_cnt, sizeof(cnt), hipMemcpyDeviceToHost, ctx->stream));

@@ -191,6 +191,13 @@ class HipContext:
         self._check(self._lib.ofps_hip_densify_dev(self._h, C.c_void_p(d_entries), n_per_item, batch, w, h,
                                                    C.c_void_p(d_out_field), C.c_void_p(d_out_cells or 0)))
 
+
+    def densify_raster_dev(self, d_entries: int, d_mask: int | None, W: int, H: int, w: int, h: int, d_out_field: int,
+                           verify: bool = False):
+        """Densify of a per-pixel raster producer's records (cv-decoder/src/lib.rs:239-291): one launch, no sort."""
+        self._check(self._lib.ofps_hip_densify_raster_dev(self._h, C.c_void_p(d_entries), C.c_void_p(d_mask or 0), W, H, w, h,
+                                                          C.c_void_p(d_out_field), 1 if verify else 0))
+
     def densify_to_entries(self, entries, w: int, h: int) -> np.ndarray:
         e = np.ascontiguousarray(entries, np.float32).reshape(-1, 4)
         out = np.zeros((w * h, 4), np.float32)

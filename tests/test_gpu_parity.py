@@ -644,6 +644,60 @@ def test_lk_decode_with_contrast_mask(ctx):
     assert len(ent) == 0
 
 
+@pytest.mark.parametrize("W,H,gw,gh", [(480, 270, 150, 84), (321, 123, 150, 57), (97, 61, 14, 14), (64, 48, 64, 48), (40, 30, 150, 84),
+                                       (1920, 1080, 150, 84)])
+@pytest.mark.parametrize("masked", [False, True])
+def test_densify_raster_matches_generic_densify_and_oracle(ctx, W, H, gw, gh, masked):
+    """ofps_hip_densify_raster_dev walks each cell's rectangle of pixels instead of sorting the records; on a per-pixel
+    producer's records (with or without cv-decoder's mask) it must return the bits of the generic densifier and of the
+    oracle's add_vector loop on the (compacted) records.  Grids finer than the frame (40x30 -> 150x84) leave cells
+    empty; odd sizes put the cell boundaries at irregular pixel columns."""
+    import torch
+    rng = np.random.default_rng(W * 7 + H)
+    flow = (rng.standard_normal((H, W, 2)) * 3).astype(np.float32)
+    ent = oracle.flow_to_entries(flow)                                        # the producer's record expression
+    mask = (rng.random((H, W)) < 0.6).astype(np.uint8) if masked else None
+    rec = ent[mask.reshape(-1) != 0] if masked else ent
+    f_o = oracle.densify(rec, gw, gh)
+    d_ent = torch.from_numpy(ent).cuda()
+    d_mask = torch.from_numpy(mask).cuda() if masked else None
+    d_f = torch.full((gh, gw, 2), -7.0, dtype=torch.float32, device="cuda")
+    ctx.use_torch_stream()
+    try:
+        ctx.densify_raster_dev(d_ent.data_ptr(), d_mask.data_ptr() if masked else None, W, H, gw, gh, d_f.data_ptr(), verify=True)
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(d_f.cpu().numpy().view(np.uint32), f_o.view(np.uint32))
+        d_rec = torch.from_numpy(np.ascontiguousarray(rec)).cuda()
+        d_g = torch.empty_like(d_f)
+        ctx.densify_dev(d_rec.data_ptr(), len(rec), 1, gw, gh, d_g.data_ptr())
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(d_f.cpu().numpy().view(np.uint32), d_g.cpu().numpy().view(np.uint32))
+    finally:
+        ctx.use_own_stream()
+
+
+def test_densify_raster_verify_rejects_records_that_are_not_the_lattice(ctx):
+    import torch
+    from ofps_amd.runtime import OfpsHipError as HipError
+    W, H = 64, 48
+    ent = oracle.flow_to_entries(np.zeros((H, W, 2), np.float32))
+    bad = ent.copy(); bad[100, 0] += 0.25                                     # one record somewhere else
+    swapped = ent.copy(); swapped[[5, 6]] = swapped[[6, 5]]                    # same cells, not the raster order
+    d_f = torch.zeros((14, 14, 2), dtype=torch.float32, device="cuda")
+    ctx.use_torch_stream()
+    try:
+        for arr in (bad, swapped):
+            d = torch.from_numpy(arr).cuda()
+            with pytest.raises(HipError):
+                ctx.densify_raster_dev(d.data_ptr(), None, W, H, 14, 14, d_f.data_ptr(), verify=True)
+        d = torch.from_numpy(ent).cuda()
+        ctx.densify_raster_dev(d.data_ptr(), None, W, H, 14, 14, d_f.data_ptr(), verify=True)
+        with pytest.raises(HipError):
+            ctx.densify_raster_dev(d.data_ptr(), None, W, H, 300, 300, d_f.data_ptr())      # > 65536 cells
+    finally:
+        ctx.use_own_stream()
+
+
 # ------------------------------------------------------------------ a host without its own HIP binding (the Rust shim's view)
 def test_resident_chain_through_the_c_abi_memory_plumbing():
     """ofps_hip_malloc / memcpy_h2d / *_dev / memcpy_d2h / timer on the context's own stream, no torch anywhere: frames

@@ -24,10 +24,11 @@ for name, step in (("small_motion_pm3", 3), ("bench_motion_pm16", 16)):
     f84 = torch.empty((150 * 84, 2), dtype=torch.float32, device="cuda")
     q1 = torch.empty((1, 4), dtype=torch.float32, device="cuda")
     lk = lambda: ctx.lk_flow_dev(dfr[0].data_ptr(), dfr[1].data_ptr(), 1920, 1080, 1920, 3, 4, 3, None, d_ent.data_ptr())
-    den = lambda: ctx.densify_dev(d_ent.data_ptr(), 1920 * 1080, 1, 150, 84, f84.data_ptr())
+    den = lambda: ctx.densify_raster_dev(d_ent.data_ptr(), None, 1920, 1080, 150, 84, f84.data_ptr())     # per-pixel producer: rectangle walk
+    den_generic = lambda: ctx.densify_dev(d_ent.data_ptr(), 1920 * 1080, 1, 150, 84, f84.data_ptr())     # any records: stable sort
     alm = lambda: ctx.almeida_dev(d_ent.data_ptr(), 1920 * 1080, 1, 16 / 9, 22.275, False, 0, 0.05, 0, 0, q1.data_ptr())
     def chain(): lk(); den(); alm()
-    out[name] = {"lk_flow_ms": timeit(lk), "densify_150x84_ms": timeit(den), "almeida_lsq_2p07M_ms": timeit(alm), "chain_ms": timeit(chain),
+    out[name] = {"lk_flow_ms": timeit(lk), "densify_150x84_ms": timeit(den), "densify_150x84_generic_sort_ms": timeit(den_generic), "almeida_lsq_2p07M_ms": timeit(alm), "chain_ms": timeit(chain),
                  "Mvectors_per_s_chain": None}
     out[name]["Mvectors_per_s_chain"] = round(1920 * 1080 / out[name]["chain_ms"] / 1e3, 1)
 print(json.dumps(out, indent=1))

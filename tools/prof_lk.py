@@ -22,7 +22,7 @@ def main():
     q1 = torch.empty((1, 4), dtype=torch.float32, device="cuda")
     for _ in range(n):
         ctx.lk_flow_dev(dfr[0].data_ptr(), dfr[1].data_ptr(), 1920, 1080, 1920, 3, 4, 3, None, d_ent.data_ptr())
-        ctx.densify_dev(d_ent.data_ptr(), 1920 * 1080, 1, 150, 84, f84.data_ptr())
+        ctx.densify_raster_dev(d_ent.data_ptr(), None, 1920, 1080, 150, 84, f84.data_ptr())
         ctx.almeida_dev(d_ent.data_ptr(), 1920 * 1080, 1, 16 / 9, 22.275, False, 0, 0.05, 0, 0, q1.data_ptr())
     torch.cuda.synchronize()
     ctx.use_own_stream()
