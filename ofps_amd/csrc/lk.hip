@@ -61,7 +61,10 @@ __global__ __launch_bounds__(256) void lk_pyr_down_kernel(const float* __restric
 }
 
 __global__ __launch_bounds__(256) void lk_u8_to_f32_pair_kernel(const uint8_t* __restrict__ s0, const uint8_t* __restrict__ s1, int W, int H,
-                                                                int stride, float* __restrict__ d0, float* __restrict__ d1) {
+                                                                int stride, float* __restrict__ d0, float* __restrict__ d1,
+                                                                uint32_t* __restrict__ zero, int n_zero) {
+    // the first launch of a flow computation also clears the per-level hand-over counters (one memset launch less)
+    if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && (int)threadIdx.x < n_zero) zero[threadIdx.x] = 0;
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= W || y >= H) return;
     const uint8_t* src = blockIdx.z ? s1 : s0;
@@ -651,15 +654,6 @@ int lk_flow_device(ofps_hip_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_cu
     float2* fa = reinterpret_cast<float2*>(reinterpret_cast<float*>(G) + 4 * plane0);
     float2* fb = fa + plane0;
 
-    {
-        dim3 g2 = lk_grid(W, H); g2.z = 2;
-        hipLaunchKernelGGL(lk_u8_to_f32_pair_kernel, g2, dim3(256), 0, s, d_prev, d_cur, W, H, stride, Ip, Jp);
-    }
-    for (int l = 1; l < levels; ++l) {
-        dim3 g2 = lk_grid(ws[l], hs[l]); g2.z = 2;
-        hipLaunchKernelGGL(lk_pyr_down_kernel, g2, dim3(256), 0, s, Ip + off[l - 1], Jp + off[l - 1], ws[l - 1], hs[l - 1],
-                           Ip + off[l], Jp + off[l], ws[l], hs[l]);
-    }
     // per level: the (tile, first step) pairs the LDS kernel hands to the general kernel, and where their flows are parked
     const dim3 g0 = lk_grid(W, H);
     const size_t tiles0 = (size_t)g0.x * g0.y;
@@ -672,11 +666,20 @@ int lk_flow_device(ofps_hip_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_cu
         fb_count = static_cast<uint32_t*>(scratch(ctx, S_WORK3, (head + 2 * (size_t)levels * tiles0) * sizeof(uint32_t)));
         if (!fb_count) return OFPS_HIP_ENOMEM;
         fb_tiles = reinterpret_cast<uint2*>(fb_count + head);
-        OFPS_HIP_TRY(ctx, hipMemsetAsync(fb_count, 0, (size_t)levels * sizeof(uint32_t), s));
         if (getenv("OFPS_HIP_LK_PROF")) {
             prof = static_cast<unsigned long long*>(scratch(ctx, S_WORK2, tiles0 * 6 * sizeof(unsigned long long)));
             if (!prof) return OFPS_HIP_ENOMEM;
         }
+    }
+    {
+        dim3 g2 = lk_grid(W, H); g2.z = 2;
+        hipLaunchKernelGGL(lk_u8_to_f32_pair_kernel, g2, dim3(256), 0, s, d_prev, d_cur, W, H, stride, Ip, Jp, fb_count,
+                           fb_count ? levels : 0);
+    }
+    for (int l = 1; l < levels; ++l) {
+        dim3 g2 = lk_grid(ws[l], hs[l]); g2.z = 2;
+        hipLaunchKernelGGL(lk_pyr_down_kernel, g2, dim3(256), 0, s, Ip + off[l - 1], Jp + off[l - 1], ws[l - 1], hs[l - 1],
+                           Ip + off[l], Jp + off[l], ws[l], hs[l]);
     }
     float2* cur_flow = fa;
     float2* other = fb;
