@@ -39,13 +39,26 @@ __device__ __forceinline__ int lk_wave_minmax(int x) {
     return __builtin_amdgcn_readlane(x, 63);
 }
 
+// XCD-aware workgroup -> tile mapping for the tiled kernels: a launch is a 1-D grid padded to a multiple of 8 workgroups;
+// workgroup b runs on XCD b % 8 (round-robin dispatch), and each XCD takes a contiguous run of tiles in raster order, so
+// vertically adjacent tiles -- which share 2R of their 4 + 2R window rows -- meet in one L2 instead of eight.
+__device__ __forceinline__ bool lk_tile_of_block(int tiles_x, int ntiles, int& tx, int& ty) {
+    const int per_xcd = (int)gridDim.x / 8;
+    const int t = (int)(blockIdx.x % 8) * per_xcd + (int)(blockIdx.x / 8);
+    if (t >= ntiles) return false;
+    ty = t / tiles_x; tx = t - ty * tiles_x;
+    return true;
+}
+
 // Both pyramid passes in one launch, for both frames (blockIdx.z): each thread forms the five horizontally filtered
 // values its output needs and filters them vertically: the oracle's two separable passes (lk_pyr_down, horizontal
 // then vertical, each ((((a + 4b) + 6c) + 4d) + e) / 16) -- the same bits without the intermediate plane and with a
 // quarter of the launches.
 __global__ __launch_bounds__(256) void lk_pyr_down_kernel(const float* __restrict__ in0, const float* __restrict__ in1, int w, int h,
                                                           float* __restrict__ out0, float* __restrict__ out1, int w1, int h1) {
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    int tx, ty;
+    if (!lk_tile_of_block((w1 + 63) / 64, ((w1 + 63) / 64) * ((h1 + 3) / 4), tx, ty)) return;
+    const int x = tx * 64 + (threadIdx.x & 63), y = ty * 4 + (threadIdx.x >> 6);
     if (x >= w1 || y >= h1) return;
     const float* in = blockIdx.z ? in1 : in0;
     float* out = blockIdx.z ? out1 : out0;
@@ -276,7 +289,9 @@ __global__ __launch_bounds__(256) void lk_tensor_tiled_kernel(const float* __res
                                                               float4* __restrict__ G) {
     using T = LkTile<RADIUS>;
     __shared__ float tile[2][T::TH][T::TW];
-    const int x0 = blockIdx.x * 64, y0 = blockIdx.y * 4;
+    int tx, ty;
+    if (!lk_tile_of_block((w + 63) / 64, ((w + 63) / 64) * ((h + 3) / 4), tx, ty)) return;
+    const int x0 = tx * 64, y0 = ty * 4;
     const float* const src[2] = {gx, gy};
     lk_stage<RADIUS, 2>(src, tile, w, h, x0, y0);
     __syncthreads();
@@ -381,13 +396,16 @@ __global__ __launch_bounds__(256, LkStepShared<RADIUS>::WAVES_PER_SIMD) void lk_
     // force_fall (tests only, normally -1): every other tile is treated as not fitting at that step, so that the hand-over
     // to lk_level_general_kernel in the middle of a level is exercised on inputs that would never trigger it
     // prof (diagnostics, normally null): per-workgroup s_memtime stamps at the phase boundaries of the first step
-#define OFPS_LK_STAMP(slot) do { if (prof && threadIdx.x == 0) prof[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 6 + (slot)] = __builtin_readcyclecounter(); } while (0)
+#define OFPS_LK_STAMP(slot) do { if (prof && threadIdx.x == 0) prof[((size_t)tile_y * tiles_x + tile_x) * 6 + (slot)] = __builtin_readcyclecounter(); } while (0)
     using T = LkTile<RADIUS>;
     using S = LkStepShared<RADIUS>;
+    const int tiles_x = (w + 63) / 64;
+    int tile_x, tile_y;
+    if (!lk_tile_of_block(tiles_x, tiles_x * ((h + 3) / 4), tile_x, tile_y)) return;
     OFPS_LK_STAMP(0);
     constexpr int N = T::N;
     __shared__ S sh;
-    const int x0 = blockIdx.x * 64, y0 = blockIdx.y * 4;
+    const int x0 = tile_x * 64, y0 = tile_y * 4;
     lk_stage3<RADIUS>(I, gx, gy, sh.tile, w, h, x0, y0);
     const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6, px = x0 + lx, py = y0 + ly;
     const bool active = px < w && py < h;
@@ -427,9 +445,9 @@ __global__ __launch_bounds__(256, LkStepShared<RADIUS>::WAVES_PER_SIMD) void lk_
         const int ymin = min(min(sh.box[0][2], sh.box[1][2]), min(sh.box[2][2], sh.box[3][2]));
         const int ymax = max(max(sh.box[0][3], sh.box[1][3]), max(sh.box[2][3], sh.box[3][3]));
         const int fits = xmax >= xmin && xmax - xmin < S::LW && ymax - ymin < S::LH &&
-                         !(it == force_fall && ((blockIdx.x + blockIdx.y) & 1));
+                         !(it == force_fall && ((tile_x + tile_y) & 1));
         if (!fits) {                                                     // uniform: box[] is the same for every thread
-            if (threadIdx.x == 0) fb_tiles[atomicAdd(fb_count, 1u)] = make_uint2((uint32_t)blockIdx.x | ((uint32_t)blockIdx.y << 16), (uint32_t)it);
+            if (threadIdx.x == 0) fb_tiles[atomicAdd(fb_count, 1u)] = make_uint2((uint32_t)tile_x | ((uint32_t)tile_y << 16), (uint32_t)it);
             if (active) fb_flow[(size_t)y * w + x] = f;
             return;
         }
@@ -628,6 +646,8 @@ __global__ __launch_bounds__(256) void lk_entries_kernel(const float2* __restric
 }
 
 static dim3 lk_grid(int w, int h) { return dim3((w + 63) / 64, (h + 3) / 4); }
+// 1-D grid of the XCD-mapped kernels (lk_tile_of_block): the tile count rounded up to a multiple of 8
+static dim3 lk_grid_xcd(int w, int h) { const unsigned n = (unsigned)((w + 63) / 64) * (unsigned)((h + 3) / 4); return dim3((n + 7) / 8 * 8); }
 
 // d_prev/d_cur: u8 luma on the device.  d_flow: W*H float2.  Workspace comes from the context.
 // d_flow (W*H float2) and/or d_entries (W*H float4 records) receive the result; at least one of them.
@@ -677,7 +697,7 @@ int lk_flow_device(ofps_hip_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_cu
                            fb_count ? levels : 0);
     }
     for (int l = 1; l < levels; ++l) {
-        dim3 g2 = lk_grid(ws[l], hs[l]); g2.z = 2;
+        dim3 g2 = lk_grid_xcd(ws[l], hs[l]); g2.z = 2;
         hipLaunchKernelGGL(lk_pyr_down_kernel, g2, dim3(256), 0, s, Ip + off[l - 1], Jp + off[l - 1], ws[l - 1], hs[l - 1],
                            Ip + off[l], Jp + off[l], ws[l], hs[l]);
     }
@@ -698,9 +718,9 @@ int lk_flow_device(ofps_hip_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_cu
             // 0.53 ms -- and summing G inside the level kernel -- 0.50 ms: that kernel is held to 80 VGPRs and lives at the
             // VALU limit, the tensor kernel runs at twice its occupancy)
             switch (radius) {
-                case 2: hipLaunchKernelGGL(lk_tensor_tiled_kernel<2>, lk_grid(w, h), dim3(256), 0, s, gx, gy, w, h, G); break;
-                case 4: hipLaunchKernelGGL(lk_tensor_tiled_kernel<4>, lk_grid(w, h), dim3(256), 0, s, gx, gy, w, h, G); break;
-                default: hipLaunchKernelGGL(lk_tensor_tiled_kernel<6>, lk_grid(w, h), dim3(256), 0, s, gx, gy, w, h, G); break;
+                case 2: hipLaunchKernelGGL(lk_tensor_tiled_kernel<2>, lk_grid_xcd(w, h), dim3(256), 0, s, gx, gy, w, h, G); break;
+                case 4: hipLaunchKernelGGL(lk_tensor_tiled_kernel<4>, lk_grid_xcd(w, h), dim3(256), 0, s, gx, gy, w, h, G); break;
+                default: hipLaunchKernelGGL(lk_tensor_tiled_kernel<6>, lk_grid_xcd(w, h), dim3(256), 0, s, gx, gy, w, h, G); break;
             }
             // one launch runs all `iters` steps of the level: in = the coarser level's flow (cur_flow), out = `other`
             const bool last = l == 0;
@@ -720,7 +740,7 @@ int lk_flow_device(ofps_hip_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_cu
             // is read back by the very thread that later overwrites it with the result
             float2* park = other;
 #define OFPS_LK_LEVEL(R)                                                                                                     \
-    hipLaunchKernelGGL(lk_level_lds_kernel<R>, g, dim3(256), 0, s, Ip + off[l], Jp + off[l], gx, gy, G, w, h, iters, io, cnt,      \
+    hipLaunchKernelGGL(lk_level_lds_kernel<R>, lk_grid_xcd(w, h), dim3(256), 0, s, Ip + off[l], Jp + off[l], gx, gy, G, w, h, iters, io, cnt,      \
                        tiles, park, last ? prof : nullptr, force_fall);                                                     \
     hipLaunchKernelGGL(lk_level_general_kernel<R>, gg, dim3(256), 0, s, Ip + off[l], Jp + off[l], gx, gy, G, w, h, iters, io, cnt, \
                        tiles, park)
