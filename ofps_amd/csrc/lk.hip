@@ -204,16 +204,23 @@ __global__ __launch_bounds__(256) void lk_step_kernel(const float* __restrict__ 
     flow_out[(size_t)y * w + x] = make_float2(f.x + du, f.y + dv);
 }
 
-// ---- tiled variants (compile-time radius).  A workgroup owns 64 x 4 pixels; the window planes (previous
+// ---- tiled variants (compile-time radius).  A workgroup owns kTX x kTY = 32 x 8 pixels; the window planes (previous
 // frame and its gradients) are staged once in LDS with the oracle's coordinate clamping applied at staging
 // time, so tile[ly+dy+R][lx+dx+R] is exactly plane[clamp(y+dy)][clamp(x+dx)].  The bilinear fetches of the
 // current frame keep their per-lane indices (they depend on the flow) but reuse registers: inside a window row
 // j10 of column k is j00 of column k+1 whenever xb[k] == xa[k+1], and the bottom row of one window row is the
 // top row of the next whenever yb == next ya -- both almost always true; the rare exceptions reload.  Same
 // values, same operation order as the untiled kernels, hence the same bits; ~5x fewer L1 requests.
+
+// pixels per workgroup of the tiled kernels (kTX * kTY = 256 threads; a wave covers 64 / kTX tile rows).  Measured at
+// 1080p, radius 4: 64 x 4 0.385 ms (0.58 on +-16 px region jumps), 32 x 8 0.38 (0.535), 16 x 16 0.43 (0.55): the squarer
+// tile stages fewer window elements per pixel (2.5 vs 3.4) and its rectangle tolerates wilder flows; 16 lanes per row
+// lose on the 16-byte staging rows.
+constexpr int kTX = 32, kTY = 8;
+
 template <int RADIUS>
 struct LkTile {
-    static constexpr int R = RADIUS, N = 2 * RADIUS + 1, TW = 64 + 2 * RADIUS, TH = 4 + 2 * RADIUS;
+    static constexpr int R = RADIUS, N = 2 * RADIUS + 1, TW = kTX + 2 * RADIUS, TH = kTY + 2 * RADIUS;
 };
 
 // Staging without per-element divisions: thread t owns window column t % TW (a compile-time modulus done once) and
@@ -290,12 +297,12 @@ __global__ __launch_bounds__(256) void lk_tensor_tiled_kernel(const float* __res
     using T = LkTile<RADIUS>;
     __shared__ float tile[2][T::TH][T::TW];
     int tx, ty;
-    if (!lk_tile_of_block((w + 63) / 64, ((w + 63) / 64) * ((h + 3) / 4), tx, ty)) return;
-    const int x0 = tx * 64, y0 = ty * 4;
+    if (!lk_tile_of_block((w + kTX - 1) / kTX, ((w + kTX - 1) / kTX) * ((h + kTY - 1) / kTY), tx, ty)) return;
+    const int x0 = tx * kTX, y0 = ty * kTY;
     const float* const src[2] = {gx, gy};
     lk_stage<RADIUS, 2>(src, tile, w, h, x0, y0);
     __syncthreads();
-    const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6, x = x0 + lx, y = y0 + ly;
+    const int lx = threadIdx.x % kTX, ly = threadIdx.x / kTX, x = x0 + lx, y = y0 + ly;
     if (x >= w || y >= h) return;
     float gxx = 0.0f, gxy = 0.0f, gyy = 0.0f;
 #pragma unroll 1
@@ -382,7 +389,7 @@ __device__ __forceinline__ void lk_store(const float2 out, int x, int y, int w, 
     if (io.out_entries) io.out_entries[idx] = make_float4(((float)x + 0.5f) * io.nx, ((float)y + 0.5f) * io.ny, out.x * io.nx, out.y * io.ny);
 }
 
-// main kernel: one workgroup per 64 x 4 tile runs ALL `iters` Gauss-Newton steps of a pyramid level -- a step of a pixel
+// main kernel: one workgroup per kTX x kTY tile runs ALL `iters` Gauss-Newton steps of a pyramid level -- a step of a pixel
 // depends on nothing but that pixel's own flow, so the previous frame's window (I, gx, gy), the tensor G and the flow
 // stay on chip between steps; only the current frame's rectangle is restaged (it moves with the flow).  A tile whose
 // rectangle does not fit at step `it` parks its flow in fb_flow, appends (tile, it) to fb_tiles (count in *fb_count)
@@ -399,15 +406,16 @@ __global__ __launch_bounds__(256, LkStepShared<RADIUS>::WAVES_PER_SIMD) void lk_
 #define OFPS_LK_STAMP(slot) do { if (prof && threadIdx.x == 0) prof[((size_t)tile_y * tiles_x + tile_x) * 6 + (slot)] = __builtin_readcyclecounter(); } while (0)
     using T = LkTile<RADIUS>;
     using S = LkStepShared<RADIUS>;
-    const int tiles_x = (w + 63) / 64;
+    const int tiles_x = (w + kTX - 1) / kTX;
     int tile_x, tile_y;
-    if (!lk_tile_of_block(tiles_x, tiles_x * ((h + 3) / 4), tile_x, tile_y)) return;
+    if (!lk_tile_of_block(tiles_x, tiles_x * ((h + kTY - 1) / kTY), tile_x, tile_y)) return;
     OFPS_LK_STAMP(0);
     constexpr int N = T::N;
     __shared__ S sh;
-    const int x0 = tile_x * 64, y0 = tile_y * 4;
+    const int x0 = tile_x * kTX, y0 = tile_y * kTY;
     lk_stage3<RADIUS>(I, gx, gy, sh.tile, w, h, x0, y0);
-    const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6, px = x0 + lx, py = y0 + ly;
+    const int lx = threadIdx.x % kTX, ly = threadIdx.x / kTX, px = x0 + lx, py = y0 + ly;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const bool active = px < w && py < h;
     float2 f = active ? lk_flow_read(io, px, py) : make_float2(0.0f, 0.0f);
 #pragma unroll 1
@@ -435,7 +443,7 @@ __global__ __launch_bounds__(256, LkStepShared<RADIUS>::WAVES_PER_SIMD) void lk_
             bx0 = lk_wave_minmax<false>(bx0); bx1 = lk_wave_minmax<true>(bx1);
             by0 = lk_wave_minmax<false>(by0); by1 = lk_wave_minmax<true>(by1);
             // (the previous step's readers of box[] are all past that step's later barriers)
-            if (lx == 0) { sh.box[ly][0] = bx0; sh.box[ly][1] = bx1; sh.box[ly][2] = by0; sh.box[ly][3] = by1; }
+            if (lane == 0) { sh.box[wave][0] = bx0; sh.box[wave][1] = bx1; sh.box[wave][2] = by0; sh.box[wave][3] = by1; }
         }
         if (it == 0) OFPS_LK_STAMP(1);
         __syncthreads();                                                 // also: everybody is done reading jl[] of the previous step
@@ -579,11 +587,11 @@ __global__ __launch_bounds__(256) void lk_level_general_kernel(const float* __re
     const uint32_t count = *fb_count;
     for (uint32_t li = blockIdx.x; li < count; li += gridDim.x) {
         const uint2 id = fb_tiles[li];
-        const int x0 = (int)(id.x & 0xFFFFu) * 64, y0 = (int)(id.x >> 16) * 4;
+        const int x0 = (int)(id.x & 0xFFFFu) * kTX, y0 = (int)(id.x >> 16) * kTY;
         __syncthreads();                                   // the previous tile's readers are done with `tile`
         lk_stage3<RADIUS>(I, gx, gy, tile, w, h, x0, y0);
         __syncthreads();
-        const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6, x = x0 + lx, y = y0 + ly;
+        const int lx = threadIdx.x % kTX, ly = threadIdx.x / kTX, x = x0 + lx, y = y0 + ly;
         if (x >= w || y >= h) continue;
         float2 f = fb_flow[(size_t)y * w + x];
         const float4 g = G[(size_t)y * w + x];
@@ -647,7 +655,10 @@ __global__ __launch_bounds__(256) void lk_entries_kernel(const float2* __restric
 
 static dim3 lk_grid(int w, int h) { return dim3((w + 63) / 64, (h + 3) / 4); }
 // 1-D grid of the XCD-mapped kernels (lk_tile_of_block): the tile count rounded up to a multiple of 8
-static dim3 lk_grid_xcd(int w, int h) { const unsigned n = (unsigned)((w + 63) / 64) * (unsigned)((h + 3) / 4); return dim3((n + 7) / 8 * 8); }
+static dim3 lk_grid_xcd(int w, int h, int tx = 64, int ty = 4) {
+    const unsigned n = (unsigned)((w + tx - 1) / tx) * (unsigned)((h + ty - 1) / ty);
+    return dim3((n + 7) / 8 * 8);
+}
 
 // d_prev/d_cur: u8 luma on the device.  d_flow: W*H float2.  Workspace comes from the context.
 // d_flow (W*H float2) and/or d_entries (W*H float4 records) receive the result; at least one of them.
@@ -675,8 +686,7 @@ int lk_flow_device(ofps_hip_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_cu
     float2* fb = fa + plane0;
 
     // per level: the (tile, first step) pairs the LDS kernel hands to the general kernel, and where their flows are parked
-    const dim3 g0 = lk_grid(W, H);
-    const size_t tiles0 = (size_t)g0.x * g0.y;
+    const size_t tiles0 = (size_t)((W + kTX - 1) / kTX) * (size_t)((H + kTY - 1) / kTY);     // tiles of the tiled kernels at level 0
     const bool tiled = radius == 2 || radius == 4 || radius == 6;      // kernels that run a whole level and fold the upsample / record passes in
     uint32_t* fb_count = nullptr;
     uint2* fb_tiles = nullptr;
@@ -718,16 +728,15 @@ int lk_flow_device(ofps_hip_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_cu
             // 0.53 ms -- and summing G inside the level kernel -- 0.50 ms: that kernel is held to 80 VGPRs and lives at the
             // VALU limit, the tensor kernel runs at twice its occupancy)
             switch (radius) {
-                case 2: hipLaunchKernelGGL(lk_tensor_tiled_kernel<2>, lk_grid_xcd(w, h), dim3(256), 0, s, gx, gy, w, h, G); break;
-                case 4: hipLaunchKernelGGL(lk_tensor_tiled_kernel<4>, lk_grid_xcd(w, h), dim3(256), 0, s, gx, gy, w, h, G); break;
-                default: hipLaunchKernelGGL(lk_tensor_tiled_kernel<6>, lk_grid_xcd(w, h), dim3(256), 0, s, gx, gy, w, h, G); break;
+                case 2: hipLaunchKernelGGL(lk_tensor_tiled_kernel<2>, lk_grid_xcd(w, h, kTX, kTY), dim3(256), 0, s, gx, gy, w, h, G); break;
+                case 4: hipLaunchKernelGGL(lk_tensor_tiled_kernel<4>, lk_grid_xcd(w, h, kTX, kTY), dim3(256), 0, s, gx, gy, w, h, G); break;
+                default: hipLaunchKernelGGL(lk_tensor_tiled_kernel<6>, lk_grid_xcd(w, h, kTX, kTY), dim3(256), 0, s, gx, gy, w, h, G); break;
             }
             // one launch runs all `iters` steps of the level: in = the coarser level's flow (cur_flow), out = `other`
             const bool last = l == 0;
             uint32_t* cnt = fb_count + l;
             uint2* tiles = fb_tiles + (size_t)l * tiles0;
-            const dim3 g = lk_grid(w, h);
-            const unsigned ntiles = g.x * g.y;
+            const unsigned ntiles = (unsigned)((w + kTX - 1) / kTX) * (unsigned)((h + kTY - 1) / kTY);
             const dim3 gg(ntiles < (unsigned)(8 * ctx->num_cus) ? ntiles : (unsigned)(8 * ctx->num_cus));
             LkFlowIO io{};
             io.coarse = l == levels - 1 ? nullptr : cur_flow;
@@ -740,7 +749,7 @@ int lk_flow_device(ofps_hip_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_cu
             // is read back by the very thread that later overwrites it with the result
             float2* park = other;
 #define OFPS_LK_LEVEL(R)                                                                                                     \
-    hipLaunchKernelGGL(lk_level_lds_kernel<R>, lk_grid_xcd(w, h), dim3(256), 0, s, Ip + off[l], Jp + off[l], gx, gy, G, w, h, iters, io, cnt,      \
+    hipLaunchKernelGGL(lk_level_lds_kernel<R>, lk_grid_xcd(w, h, kTX, kTY), dim3(256), 0, s, Ip + off[l], Jp + off[l], gx, gy, G, w, h, iters, io, cnt,      \
                        tiles, park, last ? prof : nullptr, force_fall);                                                     \
     hipLaunchKernelGGL(lk_level_general_kernel<R>, gg, dim3(256), 0, s, Ip + off[l], Jp + off[l], gx, gy, G, w, h, iters, io, cnt, \
                        tiles, park)
