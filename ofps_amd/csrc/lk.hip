@@ -337,6 +337,8 @@ struct LkStepShared {
     float4 tile[T::TH][T::TW];         // (I, gx, gy, -) of the previous frame's window
     int box[4][4];                     // per wave: min x0, max x0+1, min y0, max y0+1
     // what the LDS footprint allows (160 KB per CU, 4 waves per workgroup): the register budget hipcc is held to
+    // (radius 4 measured at 5 / 6 / 7 waves per SIMD: 0.396 / 0.380 / 0.411 ms -- 94 registers without spills, 80 with 3
+    // spilled outside the row loop, 72 with 11)
     static constexpr int WAVES_PER_SIMD = RADIUS <= 2 ? 8 : RADIUS <= 4 ? 6 : 4;
 };
 
