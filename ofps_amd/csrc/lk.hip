@@ -317,7 +317,7 @@ __global__ __launch_bounds__(256) void lk_tensor_tiled_kernel(const float* __res
 }
 
 // Current-frame window in LDS.  The bilinear fetches J(q + flow(p)) of a workgroup land in the rectangle
-// [tile + window] shifted by the flows of its pixels; when those flows differ by at most SPREAD pixels (almost every
+// [tile + window] shifted by the flows of its pixels; when those flows differ by at most SPREAD_X / SPREAD_Y pixels (almost every
 // tile) the rectangle fits jl[][] and is staged once, coordinates clamped at staging time exactly like the oracle
 // clamps xa/xb/ya/yb -- the inner loop then has no global loads at all.  Tiles with wilder flows, and tiles whose window
 // columns do not sample consecutive texels (left/right image border), need per-lane gathers with twice the registers;
@@ -327,9 +327,11 @@ __global__ __launch_bounds__(256) void lk_tensor_tiled_kernel(const float* __res
 template <int RADIUS>
 struct LkStepShared {
     using T = LkTile<RADIUS>;
-    // capacity of the current-frame rectangle: flows inside a tile may differ by up to SPREAD pixels; only the rectangle
-    // a tile really needs is staged, so the capacity costs LDS space, not time
-    static constexpr int SPREAD = 20, LW = T::TW + 1 + SPREAD, LH = T::TH + 1 + SPREAD;
+    // capacity of the current-frame rectangle: flows inside a tile may differ by up to SPREAD_X / SPREAD_Y pixels; only the
+    // rectangle a tile really needs is staged, so the capacity costs LDS space, not time.  Horizontally the capacity stops
+    // where the row stride reaches 64 floats at radius 4 (a wider stride, e.g. 76 for +-32, costs 5 % on ordinary content:
+    // measured 0.399 vs 0.380 ms); vertically it is only rows (+-16 px region jumps: 0.535 -> 0.475 ms)
+    static constexpr int SPREAD_X = 22, SPREAD_Y = 32, LW = T::TW + 1 + SPREAD_X, LH = T::TH + 1 + SPREAD_Y;
     static constexpr int JS = (LW + 4) / 4 * 4;     // row stride in floats: a multiple of 4, so rows start 16-byte aligned
     // jl first: its reads are ds_read2_b32, whose two offsets are 8 bits of dwords -- at LDS offset 0 the N+1 texels of a
     // row are reachable from one address register, behind the tile each pair costs a v_add_u32
