@@ -86,7 +86,8 @@ __device__ __forceinline__ float2 cam_delta(const Camera& c, float px, float py,
 // solver (n > 65536, the per-pixel regime of cfg3) uses v_rcp_f32 * a instead (<= 1 ulp per quotient, 2 instructions):
 // its 15 divisions per entry per step are 2/3 of that kernel's instruction stream, and with >= 65k entries per sum
 // the extra half-ulp of per-quotient rounding noise averages out far below the 2e-6 the parity tests allow
-// (north_star tolerance: 1e-4).  Everything pinned to the oracle's exact operation order -- the one-workgroup
+// (north_star tolerance: 1e-4); the same regime fuses its multiply-adds (cam_delta_w<true>, the right-hand-side sums).
+// Everything pinned to the oracle's exact operation order -- the one-workgroup
 // solver, RANSAC hypotheses and inlier tests, block-vector sized problems -- keeps IEEE division.
 template <bool FAST>
 __device__ __forceinline__ float fdiv(float a, float b) {
@@ -98,7 +99,7 @@ __device__ __forceinline__ float fdiv(float a, float b) {
 struct Unproj { float wx, wy, wz; };
 template <bool FAST = false>
 __device__ __forceinline__ Unproj cam_unproject(const Camera& c, float px, float py) {
-    const float cx = px * 2.0f - 1.0f, cy = py * 2.0f - 1.0f;
+    const float cx = FAST ? __builtin_fmaf(px, 2.0f, -1.0f) : px * 2.0f - 1.0f, cy = FAST ? __builtin_fmaf(py, 2.0f, -1.0f) : py * 2.0f - 1.0f;
     const float n0 = c.r32 + c.r33;
     Unproj u;
     u.wx = fdiv<FAST>((-c.r00) * cx, n0);
@@ -109,6 +110,21 @@ __device__ __forceinline__ Unproj cam_unproject(const Camera& c, float px, float
 // rotate + project + subtract: same operations, same order as cam_delta after its first four lines
 template <bool FAST = false>
 __device__ __forceinline__ float2 cam_delta_w(const Camera& c, float px, float py, const Unproj& u, const Mat3& R) {
+    if constexpr (FAST) {
+        // dense regime: fused multiply-adds on top of the reciprocal quotients (fdiv) -- 15 instead of 24 instructions for
+        // the rotation + projection, each result rounded once instead of twice; inside the same 2e-6 parity bound
+        const float rx = __builtin_fmaf(R.m[2], u.wz, __builtin_fmaf(R.m[1], u.wy, R.m[0] * u.wx));
+        const float ry = __builtin_fmaf(R.m[5], u.wz, __builtin_fmaf(R.m[4], u.wy, R.m[3] * u.wx));
+        const float rz = __builtin_fmaf(R.m[8], u.wz, __builtin_fmaf(R.m[7], u.wy, R.m[6] * u.wx));
+        const float inv = -__builtin_amdgcn_rcpf(ry);
+        const float sx = c.m00 * -rx * inv;
+        const float sy = c.m11 * rz * inv;
+        const float sz = __builtin_fmaf(c.m22, ry, c.m23) * inv;
+        const float isz = __builtin_amdgcn_rcpf(sz);
+        const float ox = __builtin_fmaf(sx * isz, 0.5f, 0.5f);
+        const float oy = __builtin_fmaf(sy * isz, 0.5f, 0.5f);
+        return make_float2(ox - px, oy - py);
+    }
     const float rx = (R.m[0] * u.wx + R.m[1] * u.wy) + R.m[2] * u.wz;
     const float ry = (R.m[3] * u.wx + R.m[4] * u.wy) + R.m[5] * u.wz;
     const float rz = (R.m[6] * u.wx + R.m[7] * u.wy) + R.m[8] * u.wz;
@@ -747,9 +763,15 @@ __global__ __launch_bounds__(BLOCK) void almeida_lsq_cluster_kernel(const float4
             float2 r, p;
             if constexpr (P_LDS) { const float4 v = plds[t * BLOCK + threadIdx.x]; r = make_float2(v.x, v.y); p = make_float2(v.z, v.w); }
             else { r = pr[t]; p = pp[t]; }
-            s[6] += r.x * rx + r.y * ry;
-            s[7] += p.x * rx + p.y * ry;
-            s[8] += py[t].x * rx + py[t].y * ry;
+            if constexpr (FAST) {
+                s[6] = __builtin_fmaf(r.y, ry, __builtin_fmaf(r.x, rx, s[6]));
+                s[7] = __builtin_fmaf(p.y, ry, __builtin_fmaf(p.x, rx, s[7]));
+                s[8] = __builtin_fmaf(py[t].y, ry, __builtin_fmaf(py[t].x, rx, s[8]));
+            } else {
+                s[6] += r.x * rx + r.y * ry;
+                s[7] += p.x * rx + p.y * ry;
+                s[8] += py[t].x * rx + py[t].y * ry;
+            }
             // 8 records x ~15 temporaries interleaved do not fit beside the 64 resident registers: keep the scheduler
             // from overlapping more than two records (4 waves per SIMD hide the latency instead)
             if constexpr (EPT >= 8) __builtin_amdgcn_sched_barrier(0);
