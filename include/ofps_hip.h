@@ -180,8 +180,8 @@ int ofps_hip_detect_dev(ofps_hip_ctx* ctx, const void* d_entries, size_t n_per_i
  * almeida-estimator/src/lib.rs:120).  seed drives the counter-based RANSAC sampler (the reference draws from
  * thread_rng): callers should advance it per call -- a constant seed samples the same positions every frame -- and
  * in a batched call item b uses seed + b.  Fields of more than 65,536 vectors (per-pixel records) are solved with
- * reciprocal-multiply quotients instead of IEEE division (<= 1 ulp per quotient; quaternion within 2e-6 of the
- * exact path).  A quaternion whose w is NaN (device-pointer entry points only) means a cluster launch gave up waiting
+ * reciprocal-multiply quotients instead of IEEE division and fused multiply-adds (<= 1 ulp per operation; quaternion
+ * within 2e-6 of the exact path).  A quaternion whose w is NaN (device-pointer entry points only) means a cluster launch gave up waiting
  * for workgroups that never became resident; the host-pointer entry point re-solves by itself. */
 int ofps_hip_almeida(ofps_hip_ctx* ctx, const float* entries, size_t n,
                      float aspect, float fov_y_deg, int use_ransac, size_t num_iters,
