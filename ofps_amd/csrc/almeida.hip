@@ -1040,6 +1040,7 @@ __global__ __launch_bounds__(1024) void ransac_select_kernel(const float4* __res
 struct ClusterGate {
     std::mutex m;
     hipEvent_t ev[64] = {};
+    hipStream_t last[64] = {};      // the stream of the device's latest cluster launch: stream order already chains launches on it
 };
 static ClusterGate g_cluster_gate;
 
@@ -1104,8 +1105,10 @@ static int lsq_cluster(ofps_hip_ctx* ctx, const float4* d_entries, size_t n, int
         float4* q = d_quat + b0;
         std::lock_guard<std::mutex> lk(g_cluster_gate.m);
         hipEvent_t& ev = g_cluster_gate.ev[ctx->device & 63];
+        hipStream_t& last = g_cluster_gate.last[ctx->device & 63];
         if (!ev) OFPS_HIP_TRY(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-        else OFPS_HIP_TRY(ctx, hipStreamWaitEvent(s, ev, 0));
+        else if (last != s) OFPS_HIP_TRY(ctx, hipStreamWaitEvent(s, ev, 0));      // (a barrier packet costs ~4 us in front of the kernel)
+        last = s;
         if (block == 256 && ept == 2) launch_cluster<false, 2, 256>(s, nblk, items, ent, n, cam, gran, tag_base, q, prof);
         else if (block == 256) launch_cluster<false, 1, 256>(s, nblk, items, ent, n, cam, gran, tag_base, q, prof);
         else if (dense && ept == 8) launch_cluster<true, 8>(s, nblk, items, ent, n, cam, gran, tag_base, q, prof);

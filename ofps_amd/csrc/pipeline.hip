@@ -182,7 +182,8 @@ int ofps_hip_push_frame_async(ofps_hip_ctx* ctx, const uint8_t* luma, int W, int
     rc = ofps::sad_pairs_device(ctx, slots + (size_t)prev_slot * pitch, 0, slots + (size_t)cur_slot * pitch, 0, 1, W, H, dstride,
                                 prm->block, prm->range, d_ent, nullptr);
     if (rc != OFPS_HIP_OK) return rc;
-    // the older slot may be overwritten once this search is through
+    // the older slot may be overwritten once this search is through; the same event forks the detector's stream below
+    // (one barrier packet between the search and the estimator instead of two)
     OFPS_HIP_TRY(ctx, hipEventRecord(ctx->pipe_slot_read[prev_slot], s));
     ctx->pipe_slot_read_valid[prev_slot] = true;
     t.have_vectors = 1;
@@ -196,9 +197,13 @@ int ofps_hip_push_frame_async(ofps_hip_ctx* ctx, const uint8_t* luma, int W, int
     // detector's chain of small launches runs on an auxiliary stream beside the estimator (fork after the search, join
     // before the read-back) instead of in front of it
     const bool fork = prm->run_detector && prm->run_estimator;
-    if (fork) {
-        OFPS_HIP_TRY(ctx, hipEventRecord(ctx->pipe_fork, s));
-        OFPS_HIP_TRY(ctx, hipStreamWaitEvent(ctx->pipe_aux_stream, ctx->pipe_fork, 0));
+    if (fork) OFPS_HIP_TRY(ctx, hipStreamWaitEvent(ctx->pipe_aux_stream, ctx->pipe_slot_read[prev_slot], 0));
+    // the estimator is enqueued first: it is the long pole (0.1 ms of dependent steps against the detector's seven small
+    // launches), and whatever is enqueued second starts a host-enqueue time later
+    if (prm->run_estimator) {
+        rc = ofps::almeida_device(ctx, d_ent, nblk, 1, prm->aspect, prm->fov_y_deg, prm->use_ransac, prm->num_iters,
+                                  prm->inlier_deg, prm->num_samples, prm->seed, d_quat);
+        if (rc != OFPS_HIP_OK) return rc;
     }
     if (prm->run_detector) {
         if (fork) ctx->stream = ctx->pipe_aux_stream;           // the stage entry points enqueue on ctx->stream
@@ -207,11 +212,6 @@ int ofps_hip_push_frame_async(ofps_hip_ctx* ctx, const uint8_t* luma, int W, int
             ctx->stream = s;
             if (rc == OFPS_HIP_OK) OFPS_HIP_TRY(ctx, hipEventRecord(ctx->pipe_join, ctx->pipe_aux_stream));
         }
-        if (rc != OFPS_HIP_OK) return rc;
-    }
-    if (prm->run_estimator) {
-        rc = ofps::almeida_device(ctx, d_ent, nblk, 1, prm->aspect, prm->fov_y_deg, prm->use_ransac, prm->num_iters,
-                                  prm->inlier_deg, prm->num_samples, prm->seed, d_quat);
         if (rc != OFPS_HIP_OK) return rc;
     }
     if (fork) OFPS_HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->pipe_join, 0));
