@@ -116,13 +116,11 @@ __device__ __forceinline__ float2 cam_delta_w(const Camera& c, float px, float p
         const float rx = __builtin_fmaf(R.m[2], u.wz, __builtin_fmaf(R.m[1], u.wy, R.m[0] * u.wx));
         const float ry = __builtin_fmaf(R.m[5], u.wz, __builtin_fmaf(R.m[4], u.wy, R.m[3] * u.wx));
         const float rz = __builtin_fmaf(R.m[8], u.wz, __builtin_fmaf(R.m[7], u.wy, R.m[6] * u.wx));
-        const float inv = -__builtin_amdgcn_rcpf(ry);
-        const float sx = c.m00 * -rx * inv;
-        const float sy = c.m11 * rz * inv;
-        const float sz = __builtin_fmaf(c.m22, ry, c.m23) * inv;
-        const float isz = __builtin_amdgcn_rcpf(sz);
-        const float ox = __builtin_fmaf(sx * isz, 0.5f, 0.5f);
-        const float oy = __builtin_fmaf(sy * isz, 0.5f, 0.5f);
+        // project_point scales x, y and z by the same -1/qz and camera.rs:77 divides x and y by that z: the factor cancels,
+        // (m00 * qx) / (m22 * qz + m23) -- one reciprocal instead of two and three multiplies less, fewer roundings
+        const float isz = __builtin_amdgcn_rcpf(__builtin_fmaf(c.m22, ry, c.m23));
+        const float ox = __builtin_fmaf((c.m00 * -rx) * isz, 0.5f, 0.5f);
+        const float oy = __builtin_fmaf((c.m11 * rz) * isz, 0.5f, 0.5f);
         return make_float2(ox - px, oy - py);
     }
     const float rx = (R.m[0] * u.wx + R.m[1] * u.wy) + R.m[2] * u.wz;
