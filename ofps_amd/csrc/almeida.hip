@@ -136,6 +136,52 @@ __device__ __forceinline__ float2 cam_delta_w(const Camera& c, float px, float p
     return make_float2(ox - px, oy - py);
 }
 
+// Dense regime only.  For a fixed rotation, `delta` is a projective map of the record's position: with c = 2p - 1 the
+// unprojected ray is (kx * c.x, wy, kz * c.y) (kx = -r00 / n0, kz = r11 / n0, wy = -1 / n0), each rotated component is
+// affine in p, and the projection divides two of them by a third.  The nine coefficients below fold camera and rotation
+// (the camera's factors in f64 on the host, one f32 product with the step's rotation matrix per coefficient), so
+// a record costs three 2-term fused affine forms, one reciprocal and two fused scale-and-offsets:
+//     X = -1/2 m00 (R row 0 . ray),  Y = 1/2 m11 (R row 2 . ray),  D = m22 (R row 1 . ray) + m23,
+//     delta = (X / D + 1/2 - px,  Y / D + 1/2 - py)
+// -- 11 instructions instead of ~24 for unproject + rotate + project, every operand rounded fewer times.  Worst
+// deviation of the solve from the oracle's: tools/almeida_dense_margin.py.
+struct DeltaAffine { float xa, xb, xc, ya, yb, yc, da, db, dc; };
+// the camera's share of the nine coefficients: products of camera constants, formed in f64 on the host and rounded once
+struct DeltaConsts { float x0, x1, x2, y0, y1, y2, d0, d1, d2, doff; };
+static DeltaConsts delta_consts(const Camera& c) {
+    const double n0 = (double)(c.r32 + c.r33);                     // the oracle's f32 sum
+    const double kx = -(double)c.r00 / n0, kz = (double)c.r11 / n0, wy = -1.0 / n0;
+    const double sx = -0.5 * (double)c.m00, sy = 0.5 * (double)c.m11, sd = (double)c.m22;
+    DeltaConsts k;
+    k.x0 = (float)(2.0 * sx * kx); k.x1 = (float)(sx * wy); k.x2 = (float)(2.0 * sx * kz);
+    k.y0 = (float)(2.0 * sy * kx); k.y1 = (float)(sy * wy); k.y2 = (float)(2.0 * sy * kz);
+    k.d0 = (float)(2.0 * sd * kx); k.d1 = (float)(sd * wy); k.d2 = (float)(2.0 * sd * kz);
+    k.doff = c.m23;
+    return k;
+}
+// rotated ray component j, scaled: (k0 R[j][0]) px + (k2 R[j][2]) py + (k1 R[j][1] - (k0 R[j][0] + k2 R[j][2]) / 2) [+ offset]
+__device__ __forceinline__ DeltaAffine delta_affine(const DeltaConsts& k, const Mat3& R) {
+    DeltaAffine A;
+    A.xa = k.x0 * R.m[0]; A.xb = k.x2 * R.m[2]; A.xc = __builtin_fmaf(k.x1, R.m[1], -0.5f * (A.xa + A.xb));               // view x = -(row 0)
+    A.ya = k.y0 * R.m[6]; A.yb = k.y2 * R.m[8]; A.yc = __builtin_fmaf(k.y1, R.m[7], -0.5f * (A.ya + A.yb));               // view y = row 2
+    A.da = k.d0 * R.m[3]; A.db = k.d2 * R.m[5]; A.dc = __builtin_fmaf(k.d1, R.m[4], -0.5f * (A.da + A.db)) + k.doff;      // view z = row 1
+    return A;
+}
+__device__ __forceinline__ float2 cam_delta_affine(const DeltaAffine& A, float px, float py) {
+    const float X = __builtin_fmaf(A.xa, px, __builtin_fmaf(A.xb, py, A.xc));
+    const float Y = __builtin_fmaf(A.ya, px, __builtin_fmaf(A.yb, py, A.yc));
+    const float D = __builtin_fmaf(A.da, px, __builtin_fmaf(A.db, py, A.dc));
+    const float inv = __builtin_amdgcn_rcpf(D);
+    return make_float2(__builtin_fmaf(X, inv, 0.5f) - px, __builtin_fmaf(Y, inv, 0.5f) - py);
+}
+__device__ __forceinline__ DeltaAffine delta_affine_uniform(const DeltaAffine& a) {   // wave-uniform -> scalar registers
+    DeltaAffine r;
+    const float* s = &a.xa; float* d = &r.xa;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) d[k] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(s[k])));
+    return r;
+}
+
 // camera.rs:150-161
 __device__ __forceinline__ float2 cam_point_angle(float fx, float fy, float px, float py) {
     return make_float2(atanf((px - 0.5f) / fx), atanf((py - 0.5f) / fy));
@@ -672,7 +718,7 @@ __device__ __forceinline__ bool gran_sweep_sum3(const gran_u4* g, int nblk, uint
 
 template <bool FAST, int EPT, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void almeida_lsq_cluster_kernel(const float4* __restrict__ entries, size_t n, Camera cam,
-                                                                   gran_u4* gran, uint32_t tag_base,
+                                                                   const DeltaConsts dk, gran_u4* gran, uint32_t tag_base,
                                                                    float4* __restrict__ out_quat,
                                                                    unsigned long long* __restrict__ prof, uint32_t fault) {
     // fault (tests only, normally 0): workgroup fault-1 withholds its step-3 granule, which is what a workgroup that
@@ -685,6 +731,7 @@ __global__ __launch_bounds__(BLOCK) void almeida_lsq_cluster_kernel(const float4
     __shared__ float apart_sh[6];                       // this workgroup's partial of A = J^T J, published in step 0
     __shared__ float a_sh[6];                           // A folded over all workgroups (rotation-independent)
     __shared__ Quat rot_sh[2];
+    __shared__ DeltaAffine aff_sh[2];                   // dense regime: the folded camera + rotation of rot_sh[], same slots
     __shared__ int fail_sh;
     __shared__ float4 plds[P_LDS ? EPT * BLOCK : 1];     // (roll.x, roll.y, pitch.x, pitch.y) per record
     const int nblk = gridDim.x, blk = blockIdx.x;
@@ -698,12 +745,15 @@ __global__ __launch_bounds__(BLOCK) void almeida_lsq_cluster_kernel(const float4
     float2 pr[P_LDS ? 1 : EPT], pp[P_LDS ? 1 : EPT], py[EPT];
     // the hoisted unprojection costs two registers per record; with reciprocal-multiply quotients it is four VALU
     // instructions per component to recompute (same function, same bits), which is cheaper than spilling at EPT = 8
-    constexpr bool RECOMPUTE_UNPROJ = FAST && EPT >= 8;
+    constexpr bool RECOMPUTE_UNPROJ = FAST;             // the dense regime's step loop does not use the unprojection (delta_affine)
     float uwx[RECOMPUTE_UNPROJ ? 1 : EPT], uwz[RECOMPUTE_UNPROJ ? 1 : EPT];
     float uwy = 0.0f;
     bool ok[EPT];
     float s[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    if (threadIdx.x == 0) { fail_sh = 0; rot_sh[1] = Quat{1.0f, 0.0f, 0.0f, 0.0f}; }   // slot 1 = rotation entering step 0
+    if (threadIdx.x == 0) {                              // slot 1 = rotation entering step 0
+        fail_sh = 0; rot_sh[1] = Quat{1.0f, 0.0f, 0.0f, 0.0f};
+        if constexpr (FAST) aff_sh[1] = delta_affine(dk, quat_to_mat3(rot_sh[1]));
+    }
 #pragma unroll
     for (int t = 0; t < EPT; ++t) {
         const size_t i = ((size_t)blk * EPT + t) * BLOCK + threadIdx.x;
@@ -744,19 +794,20 @@ __global__ __launch_bounds__(BLOCK) void almeida_lsq_cluster_kernel(const float4
     for (int it = 0; it < kIters; ++it) {
         const float alpha = (it == kIters - 1) ? 1.0f : 0.5f;      // lib.rs:138
         OFPS_STAMP(0);
-        const Mat3 rotm = mat3_uniform(quat_to_mat3(rot_sh[(it + 1) & 1]));    // lib.rs:140
+        Mat3 rotm;
+        DeltaAffine aff;
+        if constexpr (FAST) aff = delta_affine_uniform(aff_sh[(it + 1) & 1]);                                   // lib.rs:140, folded by the updating wave
+        else rotm = mat3_uniform(quat_to_mat3(rot_sh[(it + 1) & 1]));                                          // lib.rs:140
         s[6] = 0.0f; s[7] = 0.0f; s[8] = 0.0f;
 #pragma unroll
         for (int t = 0; t < EPT; ++t) {
-            Unproj un;
-            if constexpr (RECOMPUTE_UNPROJ) {
-                float ex = e[t].x, ey = e[t].y;
-                asm volatile("" : "+v"(ex), "+v"(ey));             // opaque to loop-invariant code motion: recompute, do not hoist
-                un = cam_unproject<FAST>(cam, ex, ey);
+            float2 d;
+            if constexpr (FAST) {
+                d = cam_delta_affine(aff, e[t].x, e[t].y);
             } else {
-                un = Unproj{uwx[t], uwy, uwz[t]};
+                const Unproj un = Unproj{uwx[t], uwy, uwz[t]};
+                d = cam_delta_w<false>(cam, e[t].x, e[t].y, un, rotm);
             }
-            const float2 d = cam_delta_w<FAST>(cam, e[t].x, e[t].y, un, rotm);
             const float rx = e[t].z - d.x, ry = e[t].w - d.y;      // motion - delta
             float2 r, p;
             if constexpr (P_LDS) { const float4 v = plds[t * BLOCK + threadIdx.x]; r = make_float2(v.x, v.y); p = make_float2(v.z, v.w); }
@@ -804,6 +855,10 @@ __global__ __launch_bounds__(BLOCK) void almeida_lsq_cluster_kernel(const float4
             if (got) {
                 const float f[9] = {a_sh[0], a_sh[1], a_sh[2], a_sh[3], a_sh[4], a_sh[5], ta, tb, tc};
                 const Quat q = almeida_update_wave(rot_sh[(it + 1) & 1], f, eps, alpha);
+                if constexpr (FAST) {                   // fold camera and new rotation once, here, for every wave's next step
+                    const DeltaAffine A = delta_affine(dk, quat_to_mat3(q));
+                    if (lane == 0) aff_sh[it & 1] = A;
+                }
                 if (lane == 0) rot_sh[it & 1] = q;
                 OFPS_STAMP_W2(6);
             } else if (lane == 0) {
@@ -1047,7 +1102,8 @@ static void launch_cluster(hipStream_t s, int nblk, int items, const float4* d_e
                            gran_u4* gran, uint32_t tag_base, float4* d_quat, unsigned long long* prof) {
     uint32_t fault = 0;
     if (const char* f = getenv("OFPS_HIP_ALMEIDA_TEST_FAULT")) fault = (uint32_t)atoi(f);     // tests only
-    hipLaunchKernelGGL((almeida_lsq_cluster_kernel<FAST, EPT, BLOCK>), dim3(nblk, items), dim3(BLOCK), 0, s, d_entries, n, cam, gran,
+    hipLaunchKernelGGL((almeida_lsq_cluster_kernel<FAST, EPT, BLOCK>), dim3(nblk, items), dim3(BLOCK), 0, s, d_entries, n, cam,
+                       delta_consts(cam), gran,
                        tag_base, d_quat, prof, fault);
 }
 
