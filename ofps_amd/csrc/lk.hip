@@ -15,6 +15,7 @@
 // contraction wide enough for MFMA (the normal equations are 2x2 per pixel).
 #include "common.hpp"
 
+#include <type_traits>
 #include <vector>
 
 namespace ofps {
@@ -223,24 +224,6 @@ struct LkTile {
     static constexpr int R = RADIUS, N = 2 * RADIUS + 1, TW = kTX + 2 * RADIUS, TH = kTY + 2 * RADIUS;
 };
 
-// Staging without per-element divisions: thread t owns window column t % TW (a compile-time modulus done once) and
-// walks rows t / TW, t / TW + ROWS_PER_PASS, ...; per element that is a clamp, a multiply-add and the loads.
-template <int RADIUS, int PLANES>
-__device__ __forceinline__ void lk_stage(const float* const (&src)[PLANES], float (*tile)[LkTile<RADIUS>::TH][LkTile<RADIUS>::TW],
-                                         int w, int h, int x0, int y0) {
-    using T = LkTile<RADIUS>;
-    constexpr int ROWS_PER_PASS = 256 / T::TW;                       // 3 for TW = 72
-    const int tx = threadIdx.x % T::TW, ty0 = threadIdx.x / T::TW;
-    if (ty0 >= ROWS_PER_PASS) return;                                // 256 - 3*72 = 40 threads sit the staging out
-    const int gx = lk_clampi(x0 - T::R + tx, 0, w - 1);
-#pragma unroll
-    for (int ty = ty0; ty < T::TH; ty += ROWS_PER_PASS) {
-        const size_t g = (size_t)lk_clampi(y0 - T::R + ty, 0, h - 1) * w + gx;
-#pragma unroll
-        for (int p = 0; p < PLANES; ++p) tile[p][ty][tx] = src[p][g];
-    }
-}
-
 // One whole 16-byte LDS read (ds_read_b128: 4 LDS cycles per wave).  Left to itself the compiler narrows a float4 read
 // whose .w is unused to ds_read_b96, which takes 8; an empty asm statement that "uses" .w keeps the read whole without
 // making it volatile (a volatile read is issued right before its use and waited for on the spot: nine exposed LDS
@@ -291,29 +274,64 @@ __device__ __forceinline__ void lk_stage3(const float* __restrict__ p0, const fl
     }
 }
 
+// Structure tensor, tiled.  Two savings over the plain kernel, neither of which touches a bit of the result:
+//   * the three products of a window element (ix*ix, ix*iy, iy*iy) are the same numbers for every pixel whose window
+//     holds it: they are formed once per staged element and the 81-tap loop only ADDS them, in the oracle's order;
+//   * a thread owns kTP vertically adjacent pixels: one LDS read of a product record feeds up to kTP running sums (each
+//     pixel still meets its taps row by row, left to right), so the loop makes (kTP + 2R) * N reads for kTP pixels instead
+//     of kTP * N * N -- the kernel was LDS-bound (one 16-byte read per tap).
+constexpr int kTP = 4;                       // pixels per thread (vertical)
+constexpr int kTTX = 32, kTTY = 8 * kTP;     // pixels per workgroup: 32 x 32
 template <int RADIUS>
 __global__ __launch_bounds__(256) void lk_tensor_tiled_kernel(const float* __restrict__ gx, const float* __restrict__ gy, int w, int h,
                                                               float4* __restrict__ G) {
-    using T = LkTile<RADIUS>;
-    __shared__ float tile[2][T::TH][T::TW];
+    constexpr int R = RADIUS, N = 2 * RADIUS + 1, TW = kTTX + 2 * RADIUS, TH = kTTY + 2 * RADIUS;
+    __shared__ float4 prod[TH][TW];
     int tx, ty;
-    if (!lk_tile_of_block((w + kTX - 1) / kTX, ((w + kTX - 1) / kTX) * ((h + kTY - 1) / kTY), tx, ty)) return;
-    const int x0 = tx * kTX, y0 = ty * kTY;
-    const float* const src[2] = {gx, gy};
-    lk_stage<RADIUS, 2>(src, tile, w, h, x0, y0);
-    __syncthreads();
-    const int lx = threadIdx.x % kTX, ly = threadIdx.x / kTX, x = x0 + lx, y = y0 + ly;
-    if (x >= w || y >= h) return;
-    float gxx = 0.0f, gxy = 0.0f, gyy = 0.0f;
-#pragma unroll 1
-    for (int r = 0; r < T::N; ++r) {
+    if (!lk_tile_of_block((w + kTTX - 1) / kTTX, ((w + kTTX - 1) / kTTX) * ((h + kTTY - 1) / kTTY), tx, ty)) return;
+    const int x0 = tx * kTTX, y0 = ty * kTTY;
+    {
+        constexpr int ROWS_PER_PASS = 256 / TW;
+        const int sx = threadIdx.x % TW, sy0 = threadIdx.x / TW;
+        if (sy0 < ROWS_PER_PASS) {
+            const int cx = lk_clampi(x0 - R + sx, 0, w - 1);
 #pragma unroll
-        for (int k = 0; k < T::N; ++k) {
-            const float ix = tile[0][ly + r][lx + k], iy = tile[1][ly + r][lx + k];
-            gxx += ix * ix; gxy += ix * iy; gyy += iy * iy;
+            for (int sy = sy0; sy < TH; sy += ROWS_PER_PASS) {
+                const size_t g = (size_t)lk_clampi(y0 - R + sy, 0, h - 1) * w + cx;
+                const float ix = gx[g], iy = gy[g];
+                prod[sy][sx] = make_float4(ix * ix, ix * iy, iy * iy, 0.0f);
+            }
         }
     }
-    G[(size_t)y * w + x] = make_float4(gxx, gxy, gyy, 0.0f);
+    __syncthreads();
+    const int lx = threadIdx.x % kTTX, ly = (threadIdx.x / kTTX) * kTP, x = x0 + lx;
+    if (x >= w || y0 + ly >= h) return;
+    float gxx[kTP], gxy[kTP], gyy[kTP];
+#pragma unroll
+    for (int q = 0; q < kTP; ++q) { gxx[q] = 0.0f; gxy[q] = 0.0f; gyy[q] = 0.0f; }
+    // window row rr of the thread's kTP-pixel column is row rr - q of pixel q.  Rows kTP-1 .. N-1 belong to every pixel
+    // (the hot loop, no predicates); the kTP-1 rows above and below belong to some (uniform branches).  The row loops are
+    // real loops: fully unrolled, hipcc hoists all (kTP + 2R) * N reads at once and spills hundreds of registers.
+    auto row = [&](int rr, auto all) {
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            const lk_f4 p = lk_lds_read4(&prod[ly + rr][lx + k]);
+#pragma unroll
+            for (int q = 0; q < kTP; ++q) {
+                if (decltype(all)::value || (rr - q >= 0 && rr - q < N)) { gxx[q] += p.x; gxy[q] += p.y; gyy[q] += p.z; }
+            }
+        }
+    };
+    static_assert(N >= kTP, "the all-pixels row range assumes a window at least kTP rows tall");
+#pragma unroll 1
+    for (int rr = 0; rr < kTP - 1; ++rr) row(rr, std::false_type{});
+#pragma unroll 1
+    for (int rr = kTP - 1; rr < N; ++rr) row(rr, std::true_type{});
+#pragma unroll 1
+    for (int rr = N; rr < kTP + 2 * R; ++rr) row(rr, std::false_type{});
+#pragma unroll
+    for (int q = 0; q < kTP; ++q)
+        if (y0 + ly + q < h) G[(size_t)(y0 + ly + q) * w + x] = make_float4(gxx[q], gxy[q], gyy[q], 0.0f);
 }
 
 // Current-frame window in LDS.  The bilinear fetches J(q + flow(p)) of a workgroup land in the rectangle
@@ -732,9 +750,9 @@ int lk_flow_device(ofps_hip_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_cu
             // 0.53 ms -- and summing G inside the level kernel -- 0.50 ms: that kernel is held to 80 VGPRs and lives at the
             // VALU limit, the tensor kernel runs at twice its occupancy)
             switch (radius) {
-                case 2: hipLaunchKernelGGL(lk_tensor_tiled_kernel<2>, lk_grid_xcd(w, h, kTX, kTY), dim3(256), 0, s, gx, gy, w, h, G); break;
-                case 4: hipLaunchKernelGGL(lk_tensor_tiled_kernel<4>, lk_grid_xcd(w, h, kTX, kTY), dim3(256), 0, s, gx, gy, w, h, G); break;
-                default: hipLaunchKernelGGL(lk_tensor_tiled_kernel<6>, lk_grid_xcd(w, h, kTX, kTY), dim3(256), 0, s, gx, gy, w, h, G); break;
+                case 2: hipLaunchKernelGGL(lk_tensor_tiled_kernel<2>, lk_grid_xcd(w, h, kTTX, kTTY), dim3(256), 0, s, gx, gy, w, h, G); break;
+                case 4: hipLaunchKernelGGL(lk_tensor_tiled_kernel<4>, lk_grid_xcd(w, h, kTTX, kTTY), dim3(256), 0, s, gx, gy, w, h, G); break;
+                default: hipLaunchKernelGGL(lk_tensor_tiled_kernel<6>, lk_grid_xcd(w, h, kTTX, kTTY), dim3(256), 0, s, gx, gy, w, h, G); break;
             }
             // one launch runs all `iters` steps of the level: in = the coarser level's flow (cur_flow), out = `other`
             const bool last = l == 0;
