@@ -295,7 +295,6 @@ __global__ __launch_bounds__(256) void lk_tensor_tiled_kernel(const float* __res
         const int sx = threadIdx.x % TW, sy0 = threadIdx.x / TW;
         if (sy0 < ROWS_PER_PASS) {
             const int cx = lk_clampi(x0 - R + sx, 0, w - 1);
-#pragma unroll
             for (int sy = sy0; sy < TH; sy += ROWS_PER_PASS) {
                 const size_t g = (size_t)lk_clampi(y0 - R + sy, 0, h - 1) * w + cx;
                 const float ix = gx[g], iy = gy[g];
