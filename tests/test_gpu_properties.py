@@ -94,3 +94,29 @@ def test_hip_almeida_lsq_matches_oracle_on_random_rotations(ctx, nx, ny, rx, ry,
     q_g, _ = ctx.almeida(e, aspect, fov, use_ransac=False)
     q_o = oracle.solve_ypr_given(e, oracle.camera(aspect, fov))
     np.testing.assert_allclose(q_g, q_o, atol=3e-6, rtol=0)
+
+
+@settings(max_examples=60, deadline=None, derandomize=True, suppress_health_check=[HealthCheck.function_scoped_fixture])
+@given(W=st.integers(1, 200), H=st.integers(1, 120), gw=st.integers(1, 160), gh=st.integers(1, 160), density=st.sampled_from([None, 0.0, 0.05, 0.5, 1.0]),
+       seed=st.integers(0, 2**31 - 1), scale=st.sampled_from([1e-3, 1.0, 1e6]))
+def test_hip_densify_raster_matches_oracle_on_random_geometry(ctx, W, H, gw, gh, density, seed, scale):
+    """The rectangle walk of a per-pixel producer's records (ofps_hip_densify_raster_dev) == the oracle's add_vector loop on
+    the (masked) records: frames from 1x1 to 200x120, grids coarser and finer than the frame, masks from empty to full,
+    motions spanning nine orders of magnitude (the summation order shows in the low bits)."""
+    import torch
+    rng = np.random.default_rng(seed)
+    flow = (rng.standard_normal((H, W, 2)) * scale).astype(np.float32)
+    ent = oracle.flow_to_entries(flow)
+    mask = None if density is None else (rng.random((H, W)) < density).astype(np.uint8)
+    rec = ent if mask is None else ent[mask.reshape(-1) != 0]
+    f_o = oracle.densify(rec, gw, gh) if len(rec) else np.zeros((gh, gw, 2), np.float32)
+    d_ent = torch.from_numpy(ent).cuda()
+    d_mask = None if mask is None else torch.from_numpy(mask).cuda()
+    d_f = torch.full((gh, gw, 2), 3.0, dtype=torch.float32, device="cuda")
+    ctx.use_torch_stream()
+    try:
+        ctx.densify_raster_dev(d_ent.data_ptr(), None if mask is None else d_mask.data_ptr(), W, H, gw, gh, d_f.data_ptr(), verify=True)
+        torch.cuda.synchronize()
+    finally:
+        ctx.use_own_stream()
+    np.testing.assert_array_equal(d_f.cpu().numpy().view(np.uint32), f_o.view(np.uint32))
