@@ -230,6 +230,111 @@ __global__ __launch_bounds__(256) void cell_sum_kernel(const float4* __restrict_
     }
 }
 
+// ---- block-vector sized problems (n <= 8,192 entries, <= 256 cells: the detector's 14 x 14 grid over one frame pair's
+// vectors): the whole densifier in ONE workgroup per item -- the same stable counting sort and the same per-cell
+// sequential sums as the six-kernel path, with workgroup barriers where that path has launch boundaries (each costs
+// ~5 us against a microsecond of work at this size).  Entries keep their input order through (slot = 64 consecutive
+// entries, lane); keys are cell ids (one 8-bit digit); the motions wait in LDS for the per-cell walk.
+constexpr int kSmallMaxN = 8192, kSmallMaxCells = 256, kSmallSlots = kSmallMaxN / 64;
+constexpr size_t kSmallLds = (size_t)kSmallMaxN * sizeof(float2) + (size_t)kSmallMaxN * sizeof(uint16_t) +
+                             (size_t)kSmallSlots * 256 * sizeof(uint16_t) + (4 * 256 + 256 + 256) * sizeof(uint32_t);
+
+__global__ __launch_bounds__(1024) void densify_small_kernel(const float4* __restrict__ entries, uint32_t n, int w, int h,
+                                                             float2* __restrict__ out_field, uint32_t* __restrict__ cell_begin,
+                                                             uint32_t* __restrict__ cell_end) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t small_lds[];
+    float2* mot = reinterpret_cast<float2*>(small_lds);                          // [kSmallMaxN] motion of entry i
+    uint16_t* sorted = reinterpret_cast<uint16_t*>(mot + kSmallMaxN);            // [kSmallMaxN] entry index by (cell, input order)
+    uint16_t* slot = sorted + kSmallMaxN;                                        // [kSmallSlots][256] entries of cell c in slot s
+    uint32_t* partsum = reinterpret_cast<uint32_t*>(slot + kSmallSlots * 256);   // [4][256] slot-quarter totals -> their prefix
+    uint32_t* total = partsum + 4 * 256;                                         // [256] entries per cell
+    uint32_t* dbase = total + 256;                                               // [256] first sorted position of a cell
+    const size_t item = blockIdx.x;
+    const int cells = w * h;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    for (int i = tid; i < kSmallSlots * 256 / 8; i += 1024) reinterpret_cast<uint4*>(slot)[i] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    // ---- cell ids, motions to LDS, rank inside the 64-entry slot (8-ballot same-cell match)
+    constexpr int ROUNDS = kSmallSlots / 16;                                     // slots per wave
+    uint32_t key[ROUNDS], rank[ROUNDS];
+    bool ok[ROUNDS];
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+        const int s = wave * ROUNDS + r;
+        const uint32_t i = (uint32_t)s * 64u + (uint32_t)lane;
+        ok[r] = i < n;
+        uint32_t k = 0;
+        if (ok[r]) {
+            const float4 e = entries[item * n + i];
+            uint32_t x, y;
+            densifier_cell(e.x, e.y, w, h, x, y);
+            k = y * (uint32_t)w + x;
+            mot[i] = make_float2(e.z, e.w);
+        }
+        key[r] = k;
+        unsigned long long same = __ballot(ok[r]);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const unsigned long long bal = __ballot((k >> b) & 1u);
+            same &= ((k >> b) & 1u) ? bal : ~bal;
+        }
+        const unsigned long long below = same & ((1ull << lane) - 1ull);
+        rank[r] = (uint32_t)__popcll(below);
+        if (ok[r] && below == 0) slot[s * 256 + k] = (uint16_t)__popcll(same);
+    }
+    __syncthreads();
+    // ---- per cell: exclusive prefix of its counts over the slots (four threads per cell, a quarter of the slots each)
+    {
+        const int d = tid & 255, part = tid >> 8;
+        constexpr int PER = kSmallSlots / 4;
+        uint32_t run = 0;
+        for (int s = part * PER; s < (part + 1) * PER; ++s) { const uint32_t v = slot[s * 256 + d]; slot[s * 256 + d] = (uint16_t)run; run += v; }
+        partsum[part * 256 + d] = run;
+    }
+    __syncthreads();
+    if (tid < 256) {
+        const uint32_t t0 = partsum[tid], t1 = partsum[256 + tid], t2 = partsum[512 + tid], t3 = partsum[768 + tid];
+        partsum[tid] = 0; partsum[256 + tid] = t0; partsum[512 + tid] = t0 + t1; partsum[768 + tid] = t0 + t1 + t2;
+        total[tid] = t0 + t1 + t2 + t3;
+    }
+    __syncthreads();
+    if (tid < 64) {                                                              // exclusive prefix over the 256 cell totals
+        const uint32_t a0 = total[4 * tid], a1 = total[4 * tid + 1], a2 = total[4 * tid + 2], a3 = total[4 * tid + 3];
+        uint32_t incl = a0 + a1 + a2 + a3;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t t = __shfl_up(incl, off);
+            if (lane >= off) incl += t;
+        }
+        const uint32_t base = incl - (a0 + a1 + a2 + a3);
+        dbase[4 * tid] = base; dbase[4 * tid + 1] = base + a0; dbase[4 * tid + 2] = base + a0 + a1; dbase[4 * tid + 3] = base + a0 + a1 + a2;
+    }
+    __syncthreads();
+    if (tid < cells) { cell_begin[item * cells + tid] = dbase[tid]; cell_end[item * cells + tid] = dbase[tid] + total[tid]; }
+    // ---- stable scatter of the entry indices
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+        if (!ok[r]) continue;
+        const int s = wave * ROUNDS + r;
+        const uint32_t pos = dbase[key[r]] + partsum[(s / (kSmallSlots / 4)) * 256 + key[r]] + slot[s * 256 + key[r]] + rank[r];
+        sorted[pos] = (uint16_t)(s * 64 + lane);
+    }
+    __syncthreads();
+    // ---- per cell and component: the reference's sequential sum in input order, then sum / count
+    if (tid < 2 * cells) {
+        const int c = tid >> 1, comp = tid & 1;
+        const uint32_t b = dbase[c], e = b + total[c];
+        const float* m = reinterpret_cast<const float*>(mot) + comp;
+        float sum = 0.0f, cnt = kF32Eps;                   // motion_field.rs:133-138
+        for (uint32_t k = b; k < e; ++k) {
+            const float wgt = 1.0f;
+            cnt += wgt;                                    // :142-143
+            sum = m[2 * sorted[k]] * wgt + sum;            // :144-146
+        }
+        reinterpret_cast<float*>(out_field + item * cells + c)[comp] = sum / cnt;      // :304
+    }
+}
+
 // ---- per-pixel producers (cv-decoder/src/lib.rs:239-291: one record per pixel in raster order, position
 // ((x+.5)/W, (y+.5)/H), optionally only where a mask is set).  For such input the cell of a record depends on its column
 // only (x index) and on its row only (y index), monotonically, so the records of one cell are a RECTANGLE of pixels and
@@ -488,6 +593,18 @@ int densify_device_raw(ofps_hip_ctx* ctx, const float4* d_entries, size_t n, int
     }
     if (out_begin) *out_begin = begin;
     if (out_end) *out_end = end;
+    if (n > 0 && n <= (size_t)kSmallMaxN && cells <= (size_t)kSmallMaxCells && !d_cells && !d_sum && !d_cnt && !d_weights && d_field &&
+        !getenv("OFPS_HIP_DENSIFY_NO_SMALL")) {                              // (the variable: A/B runs and tests of the general path)
+        static bool attr_set[64] = {};
+        if (!attr_set[ctx->device & 63]) {
+            OFPS_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(densify_small_kernel),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSmallLds));
+            attr_set[ctx->device & 63] = true;
+        }
+        hipLaunchKernelGGL(densify_small_kernel, dim3(batch), dim3(1024), kSmallLds, s, d_entries, (uint32_t)n, w, h, d_field, begin, end);
+        OFPS_HIP_TRY(ctx, hipGetLastError());
+        return OFPS_HIP_OK;
+    }
     uint32_t* sorted_vals = nullptr;
     if (n > 0) {
         const int ntiles = (int)((n + kTile - 1) / kTile);

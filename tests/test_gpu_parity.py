@@ -264,6 +264,26 @@ def test_densify_bit_exact(ctx, n, w, h):
     np.testing.assert_array_equal(f_g.view(np.uint32), f_o.view(np.uint32))   # input-order sums: same bits
 
 
+@pytest.mark.parametrize("n,w,h", [(1, 1, 1), (63, 14, 14), (64, 14, 14), (65, 16, 16), (880, 14, 14), (8040, 14, 14), (8192, 16, 16),
+                                   (8192, 256, 1), (5000, 1, 1), (4097, 3, 85), (8193, 14, 14)])
+@pytest.mark.parametrize("spread", ["uniform", "one_cell", "out_of_range"])
+def test_densify_one_workgroup_path_matches_the_general_path_and_the_oracle(ctx, monkeypatch, n, w, h, spread):
+    """Up to 8,192 entries on up to 256 cells the densifier is one workgroup per item (densify_small_kernel); above that,
+    or with OFPS_HIP_DENSIFY_NO_SMALL, the six-kernel stable sort.  Same bits either way, and the oracle's: slot edges
+    (63 / 64 / 65 entries), the size limits on both sides, every entry in one cell, positions the clamp collapses."""
+    e = _entries(n, 7 * n + w)
+    if spread == "one_cell":
+        e[:, :2] = (0.37, 0.61)
+    elif spread == "out_of_range":
+        e[::3, 0] = -0.2; e[1::5, 1] = 1.4; e[2::7, 0] = np.nan
+    f_o = oracle.densify(e, w, h)
+    f_small = ctx.densify(e, w, h)
+    np.testing.assert_array_equal(f_small.view(np.uint32), f_o.view(np.uint32))
+    monkeypatch.setenv("OFPS_HIP_DENSIFY_NO_SMALL", "1")
+    f_gen = ctx.densify(e, w, h)
+    np.testing.assert_array_equal(f_gen.view(np.uint32), f_o.view(np.uint32))
+
+
 def test_densify_out_of_range_and_nan_positions(ctx):
     """nalgebra clamp quirk (semantics unverified against the Rust build): any coordinate
     <= 0 collapses the point to (0,0), any >= 1 to (1,1); NaN -> (0,0)."""
