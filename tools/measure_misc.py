@@ -99,6 +99,9 @@ def main():
     out["cfg3_almeida_lsq_1080p_per_pixel"] = {"ms": round(ms, 3), "Mvectors_per_s": round(n / ms / 1e3, 1),
                                                "GBps_single_pass_bytes": round(16 * n / ms / 1e6, 1)}
     ms = timeit(lambda: ctx.densify_dev(e.data_ptr(), n, 1, 150, 84, f150.data_ptr()), n=5, warm=1)
+    ms_r = timeit(lambda: ctx.densify_raster_dev(e.data_ptr(), None, 1920, 1080, 150, 84, f150.data_ptr()), n=5, warm=1)
+    out["cfg3_densify_150x84_per_pixel_rectangle_walk"] = {"ms": round(ms_r, 3), "Mvectors_per_s": round(n / ms_r / 1e3, 1),
+                                                            "GBps_entry_bytes": round(16 * n / ms_r / 1e6, 1)}
     out["cfg3_densify_150x84_per_pixel"] = {"ms": round(ms, 3), "Mvectors_per_s": round(n / ms / 1e3, 1),
                                             "GBps_entry_bytes": round(16 * n / ms / 1e6, 1)}
     # --- the estimator input cv-decoder really produces in full-resolution mode: <= 150 x 84 down-sampled records
@@ -116,7 +119,7 @@ def main():
 
     def chain():
         ctx.lk_flow_dev(dfr[0].data_ptr(), dfr[1].data_ptr(), 1920, 1080, 1920, 3, 4, 3, None, d_ent.data_ptr())
-        ctx.densify_dev(d_ent.data_ptr(), 1920 * 1080, 1, 150, 84, f84.data_ptr())
+        ctx.densify_raster_dev(d_ent.data_ptr(), None, 1920, 1080, 150, 84, f84.data_ptr())
         ctx.almeida_dev(d_ent.data_ptr(), 1920 * 1080, 1, 16 / 9, 22.275, False, 0, 0.05, 0, 0, q1.data_ptr())
     ms_chain = timeit(chain, n=5, warm=1)
     out["cfg3_lk_flow_1080p"] = {"ms": round(ms_lk, 3), "Mvectors_per_s": round(1920 * 1080 / ms_lk / 1e3, 1)}
