@@ -258,6 +258,12 @@ __global__ __launch_bounds__(1024) void densify_small_kernel(const float4* __res
     constexpr int ROUNDS = kSmallSlots / 16;                                     // slots per wave
     uint32_t key[ROUNDS], rank[ROUNDS];
     bool ok[ROUNDS];
+    float4 ent[ROUNDS];
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {                                           // all of a thread's entries requested at once: the
+        const uint32_t i = (uint32_t)(wave * ROUNDS + r) * 64u + (uint32_t)lane;  // ballots below would expose one round trip per round
+        ent[r] = entries[item * n + (i < n ? i : n - 1)];
+    }
 #pragma unroll
     for (int r = 0; r < ROUNDS; ++r) {
         const int s = wave * ROUNDS + r;
@@ -265,7 +271,7 @@ __global__ __launch_bounds__(1024) void densify_small_kernel(const float4* __res
         ok[r] = i < n;
         uint32_t k = 0;
         if (ok[r]) {
-            const float4 e = entries[item * n + i];
+            const float4 e = ent[r];
             uint32_t x, y;
             densifier_cell(e.x, e.y, w, h, x, y);
             k = y * (uint32_t)w + x;
@@ -326,8 +332,16 @@ __global__ __launch_bounds__(1024) void densify_small_kernel(const float4* __res
         const uint32_t b = dbase[c], e = b + total[c];
         const float* m = reinterpret_cast<const float*>(mot) + comp;
         float sum = 0.0f, cnt = kF32Eps;                   // motion_field.rs:133-138
-        for (uint32_t k = b; k < e; ++k) {
-            const float wgt = 1.0f;
+        const float wgt = 1.0f;
+        uint32_t k = b;
+        for (; k + 4 <= e; k += 4) {                       // four independent index -> motion fetches, then the dependent adds in order
+            const float v0 = m[2 * sorted[k]], v1 = m[2 * sorted[k + 1]], v2 = m[2 * sorted[k + 2]], v3 = m[2 * sorted[k + 3]];
+            cnt += wgt; sum = v0 * wgt + sum;              // :142-146
+            cnt += wgt; sum = v1 * wgt + sum;
+            cnt += wgt; sum = v2 * wgt + sum;
+            cnt += wgt; sum = v3 * wgt + sum;
+        }
+        for (; k < e; ++k) {
             cnt += wgt;                                    // :142-143
             sum = m[2 * sorted[k]] * wgt + sum;            // :144-146
         }
