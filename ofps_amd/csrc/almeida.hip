@@ -1136,7 +1136,8 @@ static int lsq_cluster(ofps_hip_ctx* ctx, const float4* d_entries, size_t n, int
     if (nblk_sz < 1 || nblk_sz > 256 || nblk_sz > (size_t)ctx->num_cus) return 0;
     const int nblk = (int)nblk_sz;
     const int per_launch = ctx->num_cus / nblk;              // items whose workgroups are all co-resident (1 per CU)
-    const bool dense = n > 65536;                            // per-pixel regime: reciprocal-multiply quotients, see fdiv
+    bool dense = n > 65536;                                  // per-pixel regime: reciprocal-multiply quotients, see fdiv
+    if (const char* f = getenv("OFPS_HIP_ALMEIDA_FAST")) dense = atoi(f) != 0;                  // A/B
     const size_t gran_bytes = (size_t)per_launch * 2 * 3 * nblk * sizeof(gran_u4);
     auto* gran = static_cast<gran_u4*>(scratch(ctx, S_GRAN, gran_bytes));
     if (!gran) return OFPS_HIP_ENOMEM;
