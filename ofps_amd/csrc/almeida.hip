@@ -679,7 +679,58 @@ __device__ __forceinline__ void gran_load3x4(const gran_u4* p0, const gran_u4* p
                  : "=&v"(x[0]), "=&v"(x[1]), "=&v"(x[2]), "=&v"(x[3]) : "v"(p0), "v"(p1), "v"(p2), "v"(p3) : "memory");
 }
 
+// The same granule for readers on the WRITER'S XCD only: a plain store stays in that XCD's L2, where an `sc1` load (L1
+// bypass) of a workgroup on the same XCD finds it -- 540 instead of 950 cycles per hand-off (tools/ubench_exchange); a
+// reader on another XCD would never see it.
+__device__ __forceinline__ void gran_store3_local(gran_u4* p, uint32_t tag16, float a, float b, float c) {
+    const uint32_t bb = __float_as_uint(b);
+    gran_u4 v;
+    v.x = __float_as_uint(a); v.y = (tag16 << 16) | (bb >> 16); v.z = __float_as_uint(c); v.w = (tag16 << 16) | (bb & 0xFFFFu);
+    asm volatile("global_store_dwordx4 %0, %1, off" :: "v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void gran_load3_local(const gran_u4* p0, gran_u4& x) {
+    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(x) : "v"(p0) : "memory");
+}
+
 constexpr unsigned kSpinLimit = 1u << 18;            // ~0.3 s of polling before giving up
+
+// same-XCD form of gran_sweep_sum3 for at most 64 granules
+__device__ __forceinline__ bool gran_sweep_sum3_local(const gran_u4* g, int count, uint32_t tag16, float& ta, float& tb, float& tc) {
+    const int lane = threadIdx.x & 63;
+    const gran_u4* p = g + (lane < count ? lane : count - 1);
+    gran_u4 x;
+    for (unsigned spins = 0;; ++spins) {
+        gran_load3_local(p, x);
+        const bool ok = (x.y >> 16) == tag16 && (x.w >> 16) == tag16;
+        if (__all(ok)) break;
+        if (spins >= kSpinLimit) return false;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    const bool in = lane < count;
+    ta = wave_sum(in ? __uint_as_float(x.x) : 0.0f);
+    tb = wave_sum(in ? __uint_as_float((x.y << 16) | (x.w & 0xFFFFu)) : 0.0f);
+    tc = wave_sum(in ? __uint_as_float(x.z) : 0.0f);
+    return true;
+}
+// every workgroup's XCC_ID, published once per launch: all workgroups read all of them and reach the same verdict on
+// whether workgroup b runs on XCD b % 8 (round-robin dispatch), the premise of the two-level gather.  false = timed out.
+__device__ __forceinline__ bool xcc_sweep_check(const uint32_t* xccs, int nblk, uint32_t tag16, bool& round_robin) {
+    const int lane = threadIdx.x & 63;
+    bool rr = true;
+    for (int j0 = 0; j0 < nblk; j0 += 64) {
+        const int idx = j0 + lane < nblk ? j0 + lane : nblk - 1;
+        uint32_t v;
+        for (unsigned spins = 0;; ++spins) {
+            asm volatile("global_load_dword %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(xccs + idx) : "memory");
+            if (__all((v >> 16) == tag16)) break;
+            if (spins >= kSpinLimit) return false;
+            __builtin_amdgcn_s_sleep(1);
+        }
+        rr = rr && ((int)(v & 0xFFu) == (idx & 7));
+    }
+    round_robin = __all(rr);
+    return true;
+}
 
 // wave-wide: component sums over the nblk (<= 256) granules of one triple once all carry `tag16`; fixed order
 // (lane-strided, then the DPP tree), identical in every workgroup.  false = timed out.
@@ -716,11 +767,16 @@ __device__ __forceinline__ bool gran_sweep_sum3(const gran_u4* g, int nblk, uint
     return true;
 }
 
+constexpr int kXcdSlots = 32;                 // workgroups per XCD at most (256 / 8)
+constexpr int kHierMinBlocks = 32;            // below this the flat gather is as fast
+// granules per item: the flat exchange, the per-XCD partials and sums, the XCC_ID table (256 dwords = 64 granules)
+__host__ __device__ inline size_t cluster_gran_per_item(int nblk) { return 6 * (size_t)nblk + 2 * 8 * kXcdSlots + 2 * 8 + 64; }
+
 template <bool FAST, int EPT, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void almeida_lsq_cluster_kernel(const float4* __restrict__ entries, size_t n, Camera cam,
                                                                    const DeltaConsts dk, gran_u4* gran, uint32_t tag_base,
                                                                    float4* __restrict__ out_quat,
-                                                                   unsigned long long* __restrict__ prof, uint32_t fault) {
+                                                                   unsigned long long* __restrict__ prof, uint32_t fault, int hier_mode) {
     // fault (tests only, normally 0): workgroup fault-1 withholds its step-3 granule, which is what a workgroup that
     // never became resident looks like to the others -- exercises the timeout and the host's re-solve
     // prof (diagnostics, normally null): thread 0 of every workgroup stamps s_memtime at the phase boundaries of each step
@@ -733,10 +789,16 @@ __global__ __launch_bounds__(BLOCK) void almeida_lsq_cluster_kernel(const float4
     __shared__ Quat rot_sh[2];
     __shared__ DeltaAffine aff_sh[2];                   // dense regime: the folded camera + rotation of rot_sh[], same slots
     __shared__ int fail_sh;
+    __shared__ int hier_sh;                             // steps >= 1 gather in two levels (per XCD through its L2, then across)
     __shared__ float4 plds[P_LDS ? EPT * BLOCK : 1];     // (roll.x, roll.y, pitch.x, pitch.y) per record
     const int nblk = gridDim.x, blk = blockIdx.x;
     const size_t item = blockIdx.y;
-    gran_u4* g = gran + item * (size_t)(2 * 3) * nblk;                 // [parity][triple: A0-2, A3-5, b][workgroup]
+    gran_u4* g = gran + item * cluster_gran_per_item(nblk);            // [parity][triple: A0-2, A3-5, b][workgroup], then:
+    gran_u4* xl = g + 6 * (size_t)nblk;                                // [parity][XCD][rank in XCD]: per-XCD partials (same-XCD readers)
+    gran_u4* xg = xl + 2 * 8 * kXcdSlots;                              // [parity][XCD]: per-XCD sums (every reader)
+    uint32_t* xccs = reinterpret_cast<uint32_t*>(xg + 2 * 8);          // [workgroup]: tag << 16 | XCC_ID
+    const int xcd = blk & 7, xrank = blk >> 3;                         // where round-robin dispatch puts this workgroup
+    const int xmembers = (nblk - xcd + 7) / 8, nxcd = nblk < 8 ? nblk : 8;
     const float eps = almeida_eps();
     const Mat3 mroll = mat3_uniform(mat3_from_euler(0.0f, eps, 0.0f));     // lib.rs:30-34
     const Mat3 mpitch = mat3_uniform(mat3_from_euler(eps, 0.0f, 0.0f));    // lib.rs:36-38
@@ -751,7 +813,11 @@ __global__ __launch_bounds__(BLOCK) void almeida_lsq_cluster_kernel(const float4
     bool ok[EPT];
     float s[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (threadIdx.x == 0) {                              // slot 1 = rotation entering step 0
-        fail_sh = 0; rot_sh[1] = Quat{1.0f, 0.0f, 0.0f, 0.0f};
+        fail_sh = 0; hier_sh = 0; rot_sh[1] = Quat{1.0f, 0.0f, 0.0f, 0.0f};
+        if (hier_mode) {
+            const uint32_t me = (((tag_base + 1u) & 0xFFFFu) << 16) | ((uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xFFu);   // HW_REG_XCC_ID
+            asm volatile("global_store_dword %0, %1, off sc0 sc1" :: "v"(xccs + blk), "v"(me) : "memory");
+        }
         if constexpr (FAST) aff_sh[1] = delta_affine(dk, quat_to_mat3(rot_sh[1]));
     }
 #pragma unroll
@@ -830,22 +896,50 @@ __global__ __launch_bounds__(BLOCK) void almeida_lsq_cluster_kernel(const float4
         OFPS_STAMP(2);
         const uint32_t tag = (tag_base + (uint32_t)it + 1u) & 0xFFFFu;
         gran_u4* gp = g + (size_t)(it & 1) * 3 * nblk;
+        const bool hier = it > 0 && hier_sh != 0;        // uniform: written before the barrier that ended step 0
         if (threadIdx.x == 0) {
             if (it == 0) {
                 gran_store3(gp + blk, tag, apart_sh[0], apart_sh[1], apart_sh[2]);
                 gran_store3(gp + nblk + blk, tag, apart_sh[3], apart_sh[4], apart_sh[5]);
             }
-            if (!(fault && it == 3 && (uint32_t)blk == fault - 1u)) gran_store3(gp + 2 * (size_t)nblk + blk, tag, s[6], s[7], s[8]);
+            if (!(fault && it == 3 && (uint32_t)blk == fault - 1u)) {
+                if (hier) gran_store3_local(xl + ((size_t)(it & 1) * 8 + xcd) * kXcdSlots + xrank, tag, s[6], s[7], s[8]);
+                else gran_store3(gp + 2 * (size_t)nblk + blk, tag, s[6], s[7], s[8]);
+            }
         }
         // wave k gathers triple k (the A triples in step 0 only); wave 2, which gathers the right-hand side, goes straight
-        // on to the LU + quaternion update -- no barrier and no LDS round trip between the gather and the update
+        // on to the LU + quaternion update -- no barrier and no LDS round trip between the gather and the update.
+        // Two-level form (steps >= 1 of launches with many workgroups, round-robin dispatch verified in step 0): wave 3 of
+        // each XCD's first workgroup sums that XCD's partials -- plain stores found in the shared L2 by `sc1` loads -- and
+        // publishes the XCD's sum write-through; wave 2 of EVERY workgroup then gathers the <= 8 XCD sums instead of up to
+        // 256 partials.  All workgroups add the same numbers in the same order, so the rotations stay bit-identical.
         float ta = 0.0f, tb = 0.0f, tc = 0.0f;
         bool got = true;
-        if (wave < 3 && (wave == 2 || it == 0)) got = gran_sweep_sum3(gp + (size_t)wave * nblk, nblk, tag, ta, tb, tc);
+        if (hier) {
+            if (xrank == 0 && wave == 3) {
+                float la = 0.0f, lb = 0.0f, lc = 0.0f;
+                const bool lgot = gran_sweep_sum3_local(xl + ((size_t)(it & 1) * 8 + xcd) * kXcdSlots, xmembers, tag, la, lb, lc);
+                if (lane == 0) {
+                    if (lgot) gran_store3(xg + (size_t)(it & 1) * 8 + xcd, tag, la, lb, lc);
+                    else fail_sh = 1;
+                }
+            }
+            if (wave == 2) got = gran_sweep_sum3(xg + (size_t)(it & 1) * 8, nxcd, tag, ta, tb, tc);
+        } else if (wave < 3 && (wave == 2 || it == 0)) {
+            got = gran_sweep_sum3(gp + (size_t)wave * nblk, nblk, tag, ta, tb, tc);
+        }
         if (it == 0) {
             if (wave < 2 && lane == 0) {
                 if (got) { a_sh[3 * wave] = ta; a_sh[3 * wave + 1] = tb; a_sh[3 * wave + 2] = tc; }
                 else fail_sh = 1;
+            }
+            if (wave == 3 && hier_mode) {               // does workgroup b sit on XCD b % 8?  every workgroup reaches the same verdict
+                bool rr = false;
+                const bool xgot = xcc_sweep_check(xccs, nblk, tag, rr);
+                if (lane == 0) {
+                    if (!xgot) fail_sh = 1;
+                    else hier_sh = rr ? 1 : 0;
+                }
             }
             __syncthreads();
         }
@@ -1102,9 +1196,12 @@ static void launch_cluster(hipStream_t s, int nblk, int items, const float4* d_e
                            gran_u4* gran, uint32_t tag_base, float4* d_quat, unsigned long long* prof) {
     uint32_t fault = 0;
     if (const char* f = getenv("OFPS_HIP_ALMEIDA_TEST_FAULT")) fault = (uint32_t)atoi(f);     // tests only
+    int hier_mode = 1;                                        // 0 never, 1 when it pays (>= kHierMinBlocks workgroups), 2 always (A/B, tests)
+    if (const char* f = getenv("OFPS_HIP_ALMEIDA_HIER")) hier_mode = atoi(f);
+    if (hier_mode == 1 && nblk < kHierMinBlocks) hier_mode = 0;     // few workgroups: the flat gather is as fast and needs no XCC_ID round
     hipLaunchKernelGGL((almeida_lsq_cluster_kernel<FAST, EPT, BLOCK>), dim3(nblk, items), dim3(BLOCK), 0, s, d_entries, n, cam,
                        delta_consts(cam), gran,
-                       tag_base, d_quat, prof, fault);
+                       tag_base, d_quat, prof, fault, hier_mode);
 }
 
 // -> 1 launched, 0 not applicable (caller falls back to the launch-per-step kernel), < 0 error
@@ -1138,7 +1235,7 @@ static int lsq_cluster(ofps_hip_ctx* ctx, const float4* d_entries, size_t n, int
     const int per_launch = ctx->num_cus / nblk;              // items whose workgroups are all co-resident (1 per CU)
     bool dense = n > 65536;                                  // per-pixel regime: reciprocal-multiply quotients, see fdiv
     if (const char* f = getenv("OFPS_HIP_ALMEIDA_FAST")) dense = atoi(f) != 0;                  // A/B
-    const size_t gran_bytes = (size_t)per_launch * 2 * 3 * nblk * sizeof(gran_u4);
+    const size_t gran_bytes = (size_t)per_launch * cluster_gran_per_item(nblk) * sizeof(gran_u4);
     auto* gran = static_cast<gran_u4*>(scratch(ctx, S_GRAN, gran_bytes));
     if (!gran) return OFPS_HIP_ENOMEM;
     hipStream_t s = ctx->stream;

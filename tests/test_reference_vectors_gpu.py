@@ -158,6 +158,27 @@ def test_hip_almeida_cluster_timeout_falls_back_to_the_stepped_solver(ctx, monke
     np.testing.assert_allclose(q_again, q_ok, atol=0, rtol=0)
 
 
+@pytest.mark.parametrize("shape", [(120, 67), (480, 270), (960, 540)])
+def test_hip_almeida_cluster_two_level_gather_matches_the_flat_gather(ctx, monkeypatch, shape):
+    """Steps >= 1 of launches with >= 32 workgroups gather per XCD first (plain stores found in the XCD's L2), then across
+    the XCDs; OFPS_HIP_ALMEIDA_HIER=0 forces the flat all-to-all gather, =2 the two-level one at any size.  Both are fixed
+    summation orders of the same partials: each within 2e-6 of the oracle and of the other; a withheld granule times
+    out in the two-level form as well."""
+    e = synth.rotation_field(*shape)
+    cam = oracle.camera(16 / 9, 22.275)
+    q_o = oracle.solve_ypr_given(e, cam)
+    qs = {}
+    for mode in ("0", "2"):
+        monkeypatch.setenv("OFPS_HIP_ALMEIDA_HIER", mode)
+        qs[mode], _ = ctx.almeida(e, 16 / 9, 22.275, use_ransac=False)
+        np.testing.assert_allclose(qs[mode], q_o, atol=2e-6, rtol=0)
+    np.testing.assert_allclose(qs["0"], qs["2"], atol=2e-6, rtol=0)
+    monkeypatch.setenv("OFPS_HIP_ALMEIDA_TEST_FAULT", "2")
+    q_fb, _ = ctx.almeida(e, 16 / 9, 22.275, use_ransac=False)
+    monkeypatch.delenv("OFPS_HIP_ALMEIDA_TEST_FAULT")
+    np.testing.assert_allclose(q_fb, q_o, atol=2e-6, rtol=0)
+
+
 # ---- read-ahead form of the per-frame path: same bits as the synchronous call, two tickets in flight -------------------
 def test_hip_push_frame_async_matches_sync_and_oracle(ctx):
     W, H, F = 1920, 1080, 6
