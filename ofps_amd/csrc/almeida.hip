@@ -1208,7 +1208,8 @@ static void launch_cluster(hipStream_t s, int nblk, int items, const float4* d_e
 static int lsq_cluster(ofps_hip_ctx* ctx, const float4* d_entries, size_t n, int batch, const Camera& cam, float4* d_quat) {
     // records per thread: fewer = less arithmetic per step on the critical path, more = fewer workgroups to gather from
     // and -- for batches -- more items whose workgroups are co-resident in one launch.  Cost model fitted to
-    // tools/almeida_prof.py (ms per launch ~ 0.11 + 0.0085 * ept + 0.00022 * workgroups per item); the count that
+    // tools/almeida_prof.py (ms per launch ~ 0.11 + 0.004 * ept + 0.00001 * workgroups per item -- with the two-level gather
+    // a workgroup more costs next to nothing, a record more per thread is arithmetic on the critical path); the count that
     // minimises launches x cost wins (lone problems: the smallest that fits; 64 x 129,600 vectors: 8 -> 4 launches).
     int ept = 8;
     {
@@ -1217,7 +1218,7 @@ static int lsq_cluster(ofps_hip_ctx* ctx, const float4* d_entries, size_t n, int
             const size_t nb = (n + (size_t)e * 1024 - 1) / ((size_t)e * 1024);
             if (nb < 1 || nb > 256 || nb > (size_t)ctx->num_cus) continue;
             const int per = ctx->num_cus / (int)nb;
-            const double cost = (double)((batch + per - 1) / per) * (0.11 + 0.0085 * e + 0.00022 * (double)nb);
+            const double cost = (double)((batch + per - 1) / per) * (0.11 + 0.004 * e + 0.00001 * (double)nb);
             if (cost < best) { best = cost; ept = e; }
         }
     }
