@@ -135,6 +135,14 @@ int ofps_hip_contrast_mask_dev(ofps_hip_ctx* ctx, const void* d_gray, int W, int
 int ofps_hip_lk_decode(ofps_hip_ctx* ctx, const uint8_t* prev, const uint8_t* cur, int W, int H, int stride,
                        int levels, int radius, int iters, int max_w, int max_h, unsigned flags,
                        float* out_entries, size_t* n_out, int* out_w, int* out_h);
+/* The same for a STREAM of frames (cv-decoder keeps its previous gray frame and starts emitting with the second one,
+ * cv-decoder/src/lib.rs:142-158): `frame` is uploaded once and is the next call's previous frame.  *have_vectors = 0 for
+ * the first frame of a stream -- after ofps_hip_init, ofps_hip_lk_reset, a change of W/H, or an interleaved
+ * ofps_hip_lk_decode, which uses the same two device slots. */
+int ofps_hip_lk_push_frame(ofps_hip_ctx* ctx, const uint8_t* frame, int W, int H, int stride,
+                           int levels, int radius, int iters, int max_w, int max_h, unsigned flags,
+                           float* out_entries, size_t* n_out, int* out_w, int* out_h, int* have_vectors);
+int ofps_hip_lk_reset(ofps_hip_ctx* ctx);
 int ofps_hip_lk_flow_dev(ofps_hip_ctx* ctx, const void* d_prev, const void* d_cur, int W, int H, int stride,
                          int levels, int radius, int iters, void* d_out_flow, void* d_out_entries);
 

@@ -20,6 +20,10 @@ struct ofps_hip_ctx {
     int sad_mode = OFPS_HIP_SAD_EXHAUSTIVE;
     char err[512] = {0};
 
+    // hip_lk stream state (lk.hip: ofps_hip_lk_push_frame): frame k of the stream lives in slot k % 2 of S_FRAMES
+    int lk_w = 0, lk_h = 0;
+    long lk_frames = 0;
+
     // per-frame pipeline state (pipeline.hip): a ring of three device frame slots (the new frame is uploaded on the copy
     // stream while the previous pair is still being searched), two tickets in flight
     static constexpr int kPipeSlots = 3, kPipeTickets = 2;

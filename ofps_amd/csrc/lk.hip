@@ -837,14 +837,11 @@ int ofps_hip_lk_flow_dev(ofps_hip_ctx* ctx, const void* d_prev, const void* d_cu
 // :98-121 with one record per visited cell in BTreeSet<(x,y)> order ("Process Fullres" = true, the default), or
 // returned per pixel in raster order (OFPS_HIP_LK_PER_PIXEL: the `mf.push` branch; the reference resizes its
 // frames to the capped grid first, which is the caller's job here).  Only the final records leave the device.
-int ofps_hip_lk_decode(ofps_hip_ctx* ctx, const uint8_t* prev, const uint8_t* cur, int W, int H, int stride, int levels,
-                       int radius, int iters, int max_w, int max_h, unsigned flags, float* out_entries, size_t* n_out,
-                       int* out_w, int* out_h) {
-    if (!ctx) return OFPS_HIP_EINVAL;
-    OFPS_REQUIRE(ctx, prev && cur && out_entries && n_out, "lk_decode: null host pointer");
-    OFPS_REQUIRE(ctx, W >= 1 && H >= 1 && stride >= W && max_w >= 1 && max_h >= 1, "lk_decode: bad geometry");
-    OFPS_REQUIRE(ctx, (flags & ~(unsigned)(OFPS_HIP_LK_CONTRAST_MASK | OFPS_HIP_LK_PER_PIXEL)) == 0, "lk_decode: unknown flags 0x%x", flags);
-    OFPS_HIP_TRY(ctx, hipSetDevice(ctx->device));
+// the part of a hip_lk process_frame that follows the uploads: d_frames holds two W-pitched frames, slot_prev / slot_cur
+// say which is which
+static int lk_decode_resident(ofps_hip_ctx* ctx, uint8_t* d_frames, int slot_prev, int slot_cur, int W, int H, int levels, int radius,
+                              int iters, int max_w, int max_h, unsigned flags, float* out_entries, size_t* n_out, int* out_w,
+                              int* out_h) {
     const bool use_mask = flags & OFPS_HIP_LK_CONTRAST_MASK, per_pixel = flags & OFPS_HIP_LK_PER_PIXEL;
     // cv-decoder/src/lib.rs:98-121 with aspect_ratio_scale = (1, 1): usize arithmetic
     const size_t cw = (size_t)(max_w < W ? max_w : W), ch = (size_t)(max_h < H ? max_h : H);
@@ -853,21 +850,20 @@ int ofps_hip_lk_decode(ofps_hip_ctx* ctx, const uint8_t* prev, const uint8_t* cu
     if (!per_pixel)
         OFPS_REQUIRE(ctx, gw >= 1 && gh >= 1 && (size_t)gw * gh <= 65536, "lk_decode: field %dx%d unsupported", gw, gh);
     const size_t px = (size_t)W * H, cells = per_pixel ? 1 : (size_t)gw * gh;
-    auto* d_frames = static_cast<uint8_t*>(ofps::scratch(ctx, ofps::S_FRAMES, 2 * px));
     auto* d_ent = static_cast<float4*>(ofps::scratch(ctx, ofps::S_ENTRIES, px * sizeof(float4)));
     auto* d_field = static_cast<float2*>(ofps::scratch(ctx, ofps::S_FIELD, cells * sizeof(float2)));
     auto* d_out = static_cast<float4*>(ofps::scratch(ctx, ofps::S_BEST, cells * sizeof(float4)));
     auto* d_cnt = static_cast<uint32_t*>(ofps::scratch(ctx, ofps::S_RESULT, 16));
-    if (!d_frames || !d_ent || !d_field || !d_out || !d_cnt) return OFPS_HIP_ENOMEM;
-    OFPS_HIP_TRY(ctx, ofps::upload_rows(d_frames, W, prev, stride, W, H, ctx->stream));
-    OFPS_HIP_TRY(ctx, ofps::upload_rows(d_frames + px, W, cur, stride, W, H, ctx->stream));
-    int rc = ofps_hip_lk_flow_dev(ctx, d_frames, d_frames + px, W, H, W, levels, radius, iters, nullptr, d_ent);
+    if (!d_ent || !d_field || !d_out || !d_cnt) return OFPS_HIP_ENOMEM;
+    const uint8_t* d_prev = d_frames + (size_t)slot_prev * px;
+    const uint8_t* d_cur = d_frames + (size_t)slot_cur * px;
+    int rc = ofps_hip_lk_flow_dev(ctx, d_prev, d_cur, W, H, W, levels, radius, iters, nullptr, d_ent);
     if (rc != OFPS_HIP_OK) return rc;
     const uint8_t* d_mask = nullptr;
     if (use_mask) {
         auto* m = static_cast<uint8_t*>(ofps::scratch(ctx, ofps::S_MASK, px));
         if (!m) return OFPS_HIP_ENOMEM;
-        rc = ofps::contrast_mask_device(ctx, d_frames + px, W, H, W, m);
+        rc = ofps::contrast_mask_device(ctx, d_cur, W, H, W, m);
         if (rc != OFPS_HIP_OK) return rc;
         d_mask = m;
     }
@@ -901,6 +897,55 @@ int ofps_hip_lk_decode(ofps_hip_ctx* ctx, const uint8_t* prev, const uint8_t* cu
     OFPS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (cnt) OFPS_HIP_TRY(ctx, hipMemcpy(out_entries, d_out, (size_t)cnt * sizeof(float4), hipMemcpyDeviceToHost));
     *n_out = cnt;
+    return OFPS_HIP_OK;
+}
+
+int ofps_hip_lk_decode(ofps_hip_ctx* ctx, const uint8_t* prev, const uint8_t* cur, int W, int H, int stride, int levels,
+                       int radius, int iters, int max_w, int max_h, unsigned flags, float* out_entries, size_t* n_out,
+                       int* out_w, int* out_h) {
+    if (!ctx) return OFPS_HIP_EINVAL;
+    OFPS_REQUIRE(ctx, prev && cur && out_entries && n_out, "lk_decode: null host pointer");
+    OFPS_REQUIRE(ctx, W >= 1 && H >= 1 && stride >= W && max_w >= 1 && max_h >= 1, "lk_decode: bad geometry");
+    OFPS_REQUIRE(ctx, (flags & ~(unsigned)(OFPS_HIP_LK_CONTRAST_MASK | OFPS_HIP_LK_PER_PIXEL)) == 0, "lk_decode: unknown flags 0x%x", flags);
+    OFPS_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t px = (size_t)W * H;
+    auto* d_frames = static_cast<uint8_t*>(ofps::scratch(ctx, ofps::S_FRAMES, 2 * px));
+    if (!d_frames) return OFPS_HIP_ENOMEM;
+    ctx->lk_frames = 0;                                             // the stateless call overwrites the stream's frames
+    OFPS_HIP_TRY(ctx, ofps::upload_rows(d_frames, W, prev, stride, W, H, ctx->stream));
+    OFPS_HIP_TRY(ctx, ofps::upload_rows(d_frames + px, W, cur, stride, W, H, ctx->stream));
+    return lk_decode_resident(ctx, d_frames, 0, 1, W, H, levels, radius, iters, max_w, max_h, flags, out_entries, n_out, out_w, out_h);
+}
+
+int ofps_hip_lk_push_frame(ofps_hip_ctx* ctx, const uint8_t* frame, int W, int H, int stride, int levels, int radius, int iters,
+                           int max_w, int max_h, unsigned flags, float* out_entries, size_t* n_out, int* out_w, int* out_h,
+                           int* have_vectors) {
+    if (!ctx) return OFPS_HIP_EINVAL;
+    OFPS_REQUIRE(ctx, frame && out_entries && n_out && have_vectors, "lk_push_frame: null host pointer");
+    OFPS_REQUIRE(ctx, W >= 1 && H >= 1 && stride >= W && max_w >= 1 && max_h >= 1, "lk_push_frame: bad geometry");
+    OFPS_REQUIRE(ctx, (flags & ~(unsigned)(OFPS_HIP_LK_CONTRAST_MASK | OFPS_HIP_LK_PER_PIXEL)) == 0, "lk_push_frame: unknown flags 0x%x", flags);
+    OFPS_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (ctx->lk_w != W || ctx->lk_h != H) { ctx->lk_w = W; ctx->lk_h = H; ctx->lk_frames = 0; }    // a new geometry restarts the stream
+    const size_t px = (size_t)W * H;
+    auto* d_frames = static_cast<uint8_t*>(ofps::scratch(ctx, ofps::S_FRAMES, 2 * px));
+    if (!d_frames) return OFPS_HIP_ENOMEM;
+    const int slot = (int)(ctx->lk_frames & 1);
+    OFPS_HIP_TRY(ctx, ofps::upload_rows(d_frames + (size_t)slot * px, W, frame, stride, W, H, ctx->stream));
+    ctx->lk_frames += 1;
+    *n_out = 0;
+    if (ctx->lk_frames < 2) {                                       // cv-decoder/src/lib.rs:156-158: flow needs two frames
+        *have_vectors = 0;
+        OFPS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));       // the caller may reuse `frame` right away
+        return OFPS_HIP_OK;
+    }
+    *have_vectors = 1;
+    return lk_decode_resident(ctx, d_frames, slot ^ 1, slot, W, H, levels, radius, iters, max_w, max_h, flags, out_entries, n_out, out_w,
+                              out_h);
+}
+
+int ofps_hip_lk_reset(ofps_hip_ctx* ctx) {
+    if (!ctx) return OFPS_HIP_EINVAL;
+    ctx->lk_frames = 0;
     return OFPS_HIP_OK;
 }
 

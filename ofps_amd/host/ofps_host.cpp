@@ -177,8 +177,18 @@ bool HipLkDecoder::process_frame(MotionVectors& field, std::vector<RGBA>* out_fr
     out_.resize(process_fullres_ ? 4 * std::min(max_w_, w_) * std::min(max_h_, h_) : 4 * w_ * h_);
     size_t n_out = 0;
     const unsigned flags = (contrast_mask_ ? OFPS_HIP_LK_CONTRAST_MASK : 0u) | (process_fullres_ ? 0u : OFPS_HIP_LK_PER_PIXEL);
-    ctx_.check(ofps_hip_lk_decode(ctx_.get(), prev_.data(), cur_.data(), (int)w_, (int)h_, (int)w_, (int)levels_, (int)radius_,
-                                  (int)iters_, (int)max_w_, (int)max_h_, flags, out_.data(), &n_out, nullptr, nullptr));
+    // the frame uploaded by the previous call is this call's previous frame unless frames were skipped in between:
+    // then (and for the first pair) the previous frame goes up first
+    int have = 0;
+    if (!(skip == 0 && on_device_)) {
+        ctx_.check(ofps_hip_lk_reset(ctx_.get()));
+        ctx_.check(ofps_hip_lk_push_frame(ctx_.get(), prev_.data(), (int)w_, (int)h_, (int)w_, (int)levels_, (int)radius_, (int)iters_,
+                                          (int)max_w_, (int)max_h_, flags, out_.data(), &n_out, nullptr, nullptr, &have));
+    }
+    ctx_.check(ofps_hip_lk_push_frame(ctx_.get(), cur_.data(), (int)w_, (int)h_, (int)w_, (int)levels_, (int)radius_, (int)iters_,
+                                      (int)max_w_, (int)max_h_, flags, out_.data(), &n_out, nullptr, nullptr, &have));
+    on_device_ = true;
+    if (!have) throw Error("hip_lk: no vectors for the second frame of a pair");
     const size_t base = field.size();
     field.resize(base + n_out);
     std::memcpy(field.data() + base, out_.data(), n_out * sizeof(MotionEntry));

@@ -156,6 +156,7 @@ private:
     std::vector<uint8_t> prev_, cur_;
     std::vector<float> out_;
     size_t frames_read_ = 0;
+    bool on_device_ = false;           // the last frame of the previous call is on the device (ofps_hip_lk_push_frame's state)
 };
 
 // MvecFile of motion-loader/src/lib.rs:31-83 (pure host I/O, no GPU)

@@ -148,9 +148,16 @@ class HipLkDecoder(HipSadDecoder):
         if out_frame is not None:
             out_frame[:] = [self._cur]
         if self._prev is None or self._prev.shape != self._cur.shape:
+            self._on_device = None
             return False
-        ent, _ = self.ctx.lk_decode(self._prev, self._cur, self.levels, self.radius, self.iters, self.max_w, self.max_h,
-                                    contrast_mask=self.contrast_mask, per_pixel=not self.process_fullres)
+        kw = dict(contrast_mask=self.contrast_mask, per_pixel=not self.process_fullres)
+        # the frame that is on the device from the last call is this call's previous frame unless frames were skipped:
+        # then (and on the first pair) the previous frame goes up first
+        if getattr(self, "_on_device", None) is not self._prev:
+            self.ctx.lk_reset()
+            self.ctx.lk_push_frame(self._prev, self.levels, self.radius, self.iters, self.max_w, self.max_h, **kw)
+        ent, _ = self.ctx.lk_push_frame(self._cur, self.levels, self.radius, self.iters, self.max_w, self.max_h, **kw)
+        self._on_device = self._cur
         field.extend(ent)
         return True
 

@@ -148,6 +148,26 @@ class HipContext:
                                                  iters, max_w, max_h, flags, _fp(out), C.byref(n), C.byref(gw), C.byref(gh)))
         return out[:n.value].copy(), (gw.value, gh.value)
 
+
+    def lk_push_frame(self, frame: np.ndarray, levels=3, radius=4, iters=3, max_w=150, max_h=150, contrast_mask=False,
+                      per_pixel=False):
+        """Stream form of lk_decode: the frame is uploaded once and is the next call's previous frame.
+        -> None for the first frame of a stream, else (entries[n,4], (grid_w, grid_h))."""
+        frame = np.ascontiguousarray(frame, np.uint8)
+        H, W = frame.shape
+        out = np.zeros((W * H if per_pixel else min(max_w, W) * min(max_h, H), 4), np.float32)
+        n = C.c_size_t(0); gw = C.c_int(0); gh = C.c_int(0); have = C.c_int(0)
+        flags = (self.LK_CONTRAST_MASK if contrast_mask else 0) | (self.LK_PER_PIXEL if per_pixel else 0)
+        self._check(self._lib.ofps_hip_lk_push_frame(self._h, frame.ctypes.data_as(C.POINTER(C.c_uint8)), W, H, W, levels, radius,
+                                                     iters, max_w, max_h, flags, _fp(out), C.byref(n), C.byref(gw), C.byref(gh),
+                                                     C.byref(have)))
+        if not have.value:
+            return None
+        return out[:n.value].copy(), (gw.value, gh.value)
+
+    def lk_reset(self):
+        self._check(self._lib.ofps_hip_lk_reset(self._h))
+
     def contrast_mask(self, gray: np.ndarray) -> np.ndarray:
         """cv-decoder's Sobel/threshold/dilate mask (cv-decoder/src/lib.rs:203-237) -> u8[H, W], 1 = keep."""
         g = np.ascontiguousarray(gray, np.uint8)

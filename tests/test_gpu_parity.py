@@ -664,6 +664,28 @@ def test_lk_decode_with_contrast_mask(ctx):
     assert len(ent) == 0
 
 
+def test_lk_push_frame_stream_matches_pairwise_decode(ctx):
+    """ofps_hip_lk_push_frame keeps the previous frame on the device: over a sequence it must return what the stateless
+    ofps_hip_lk_decode returns for each consecutive pair (masked and unmasked, down-sampled and per pixel), nothing for
+    the first frame, and start over after a reset, a geometry change or an interleaved stateless call."""
+    fr = synth.flatten_regions(synth.luma_sequence(5, 320, 180, max_step=2, seed=21), region=40, seed=3)
+    for kw in (dict(), dict(contrast_mask=True), dict(per_pixel=True), dict(contrast_mask=True, per_pixel=True)):
+        ctx.lk_reset()
+        assert ctx.lk_push_frame(fr[0], **kw) is None
+        for k in range(1, 5):
+            ent, grid = ctx.lk_push_frame(fr[k], **kw)
+            ent_o, grid_o = ctx.lk_decode(fr[k - 1], fr[k], **kw)            # clobbers the stream's slots ...
+            assert grid == grid_o
+            np.testing.assert_array_equal(ent.view(np.uint32), ent_o.view(np.uint32))
+            assert ctx.lk_push_frame(fr[k]) is None                          # ... so the stream starts over
+    ctx.lk_reset()
+    assert ctx.lk_push_frame(fr[0]) is None
+    assert ctx.lk_push_frame(fr[1]) is not None
+    assert ctx.lk_push_frame(fr[0][:90, :160].copy()) is None                # geometry change
+    ctx.lk_reset()
+    assert ctx.lk_push_frame(fr[2]) is None
+
+
 @pytest.mark.parametrize("W,H,gw,gh", [(480, 270, 150, 84), (321, 123, 150, 57), (97, 61, 14, 14), (64, 48, 64, 48), (40, 30, 150, 84),
                                        (1920, 1080, 150, 84)])
 @pytest.mark.parametrize("masked", [False, True])
