@@ -77,34 +77,38 @@ __global__ __launch_bounds__(256) void sort_count_kernel(const uint32_t* __restr
 // Digit-major scan, one workgroup per (digit, item): exclusive prefix of that digit's counts over the tiles
 // (coalesced 256-element chunks, Hillis-Steele in LDS, running carry) + the digit's total.  The scatter
 // kernel adds the exclusive prefix over the 256 digit totals itself.
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int lane) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t t = __shfl_up(v, off);
+        if (lane >= off) v += t;
+    }
+    return v;
+}
+
 __global__ __launch_bounds__(256) void sort_scan_kernel(uint32_t* __restrict__ hist, int ntiles,
                                                         uint32_t* __restrict__ digit_total) {
-    __shared__ uint32_t sc[256];
-    __shared__ uint32_t carry_sh;
+    // 256 tiles per round: inclusive scan inside each wave (shuffles), the four wave totals through LDS -- one barrier
+    // per round (the slots alternate) instead of the 16 of a workgroup-wide Hillis-Steele scan
+    __shared__ uint32_t wtot[2][4];
     const size_t item = blockIdx.y;
     const int digit = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t* h = hist + (item * 256 + digit) * (size_t)ntiles;
-    if (threadIdx.x == 0) carry_sh = 0;
-    __syncthreads();
-    for (int c0 = 0; c0 < ntiles; c0 += 256) {
+    uint32_t carry = 0;                                    // the same value in every thread
+    int par = 0;
+    for (int c0 = 0; c0 < ntiles; c0 += 256, par ^= 1) {
         const int i = c0 + threadIdx.x;
         const uint32_t v = i < ntiles ? h[i] : 0u;
-        sc[threadIdx.x] = v;
+        const uint32_t incl = wave_incl_scan_u32(v, lane);
+        if (lane == 63) wtot[par][wave] = incl;
         __syncthreads();
-#pragma unroll
-        for (int off = 1; off < 256; off <<= 1) {
-            const uint32_t t = threadIdx.x >= (unsigned)off ? sc[threadIdx.x - off] : 0u;
-            __syncthreads();
-            sc[threadIdx.x] += t;
-            __syncthreads();
-        }
-        const uint32_t carry = carry_sh;
-        if (i < ntiles) h[i] = carry + sc[threadIdx.x] - v;
-        __syncthreads();
-        if (threadIdx.x == 255) carry_sh = carry + sc[255];
-        __syncthreads();
+        const uint32_t w0 = wtot[par][0], w1 = wtot[par][1], w2 = wtot[par][2], w3 = wtot[par][3];
+        const uint32_t before = (wave > 0 ? w0 : 0u) + (wave > 1 ? w1 : 0u) + (wave > 2 ? w2 : 0u);
+        if (i < ntiles) h[i] = carry + before + incl - v;
+        carry += w0 + w1 + w2 + w3;
     }
-    if (threadIdx.x == 0) digit_total[item * 256 + digit] = carry_sh;
+    if (threadIdx.x == 0) digit_total[item * 256 + digit] = carry;
 }
 
 // stable scatter of one tile
@@ -119,20 +123,14 @@ __global__ __launch_bounds__(256) void sort_scatter_kernel(const uint32_t* __res
     const size_t item = blockIdx.y;
     const int tile = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int i = tid; i < 16 * 256; i += 256) (&slot_cnt[0][0])[i] = 0;
-    {
+    {   // exclusive prefix over the 256 digit totals: wave scans + the four wave totals (one barrier)
+        __shared__ uint32_t dtot[4];
         const uint32_t mine = digit_total[item * 256 + tid];
-        dbase[tid] = mine;
+        const uint32_t incl = wave_incl_scan_u32(mine, lane);
+        if (lane == 63) dtot[wave] = incl;
         __syncthreads();
-#pragma unroll
-        for (int off = 1; off < 256; off <<= 1) {
-            const uint32_t t = tid >= off ? dbase[tid - off] : 0u;
-            __syncthreads();
-            dbase[tid] += t;
-            __syncthreads();
-        }
-        const uint32_t incl = dbase[tid];
-        __syncthreads();
-        dbase[tid] = incl - mine;
+        const uint32_t before = (wave > 0 ? dtot[0] : 0u) + (wave > 1 ? dtot[1] : 0u) + (wave > 2 ? dtot[2] : 0u);
+        dbase[tid] = before + incl - mine;
     }
     __syncthreads();
     const size_t base = (size_t)tile * kTile;
