@@ -1131,7 +1131,6 @@ __global__ __launch_bounds__(1024) void ransac_select_kernel(const float4* __res
                                                              float4* __restrict__ sel, uint32_t* __restrict__ sel_idx,
                                                              uint32_t* __restrict__ sel_n) {
     __shared__ unsigned long long best;
-    __shared__ uint32_t scan[1024];
     __shared__ uint32_t base;
     const size_t item = blockIdx.x;
     if (threadIdx.x == 0) { best = 0; base = 0; }
@@ -1151,7 +1150,13 @@ __global__ __launch_bounds__(1024) void ransac_select_kernel(const float4* __res
     }
     const Mat3 mat = hyp[item * iters + bit];
     const SampleKey sk = sample_key(seed + item, bit, 1, n);
-    for (uint32_t j0 = 0; j0 < ns; j0 += 1024) {
+    // ordered compaction, 1024 samples per round: rank inside the wave from a ballot, the 16 wave totals through LDS (one
+    // barrier per round: the slots alternate), the running offset kept in every thread
+    __shared__ uint32_t wave_cnt[2][16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t run = 0;
+    int par = 0;
+    for (uint32_t j0 = 0; j0 < ns; j0 += 1024, par ^= 1) {
         const uint32_t j = j0 + threadIdx.x;
         uint32_t idx = 0;
         bool in = false;
@@ -1161,23 +1166,21 @@ __global__ __launch_bounds__(1024) void ransac_select_kernel(const float4* __res
             e = entries[item * n + idx];
             in = ransac_is_inlier(cam, fx, fy, mat, e, thr2);
         }
-        scan[threadIdx.x] = in ? 1u : 0u;
+        const unsigned long long bal = __ballot(in);
+        if (lane == 0) wave_cnt[par][wave] = (uint32_t)__popcll(bal);
         __syncthreads();
-        for (int off = 1; off < 1024; off <<= 1) {
-            const uint32_t v = threadIdx.x >= (unsigned)off ? scan[threadIdx.x - off] : 0;
-            __syncthreads();
-            scan[threadIdx.x] += v;
-            __syncthreads();
-        }
+        uint32_t before = 0, total = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { const uint32_t v = wave_cnt[par][k]; total += v; before += k < wave ? v : 0u; }
         if (in) {
-            const uint32_t pos = base + scan[threadIdx.x] - 1;
+            const uint32_t pos = run + before + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
             sel[item * ns + pos] = e;
             if (sel_idx) sel_idx[item * ns + pos] = idx;
         }
-        __syncthreads();
-        if (threadIdx.x == 1023) base += scan[1023];
-        __syncthreads();
+        run += total;
     }
+    if (threadIdx.x == 0) base = run;
+    __syncthreads();
     if (threadIdx.x == 0) sel_n[item] = base;
 }
 
