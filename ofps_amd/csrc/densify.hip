@@ -360,13 +360,19 @@ __device__ __forceinline__ int raster_cell_of(int i, float inv_n, int cells_1d) 
     densifier_cell(p, p, cells_1d, cells_1d, cx, cy);        // 0 < p < 1: the all-component clamp acts per component
     return (int)cx;
 }
-__device__ __forceinline__ int raster_first_at_least(int c, int n, float inv_n, int cells_1d) {   // min i with cell(i) >= c, or n
-    int lo = 0, hi = n;
-    while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if (raster_cell_of(mid, inv_n, cells_1d) >= c) hi = mid; else lo = mid + 1;
-    }
-    return lo;
+// min i in [0, n] with cell(i) >= c (n when there is none).  The cell function is monotone, so any starting guess walks to
+// the boundary; the guess inverts round(p * (cells - 1)) and is off by at most a pixel or two -- ~3 evaluations of the
+// exact function instead of the 11 of a bisection over 1920 columns (which, run redundantly by every lane of every
+// cell's wave, was most of this kernel's time).
+__device__ __forceinline__ int raster_first_at_least(int c, int n, float inv_n, int cells_1d) {
+    if (c <= 0) return 0;
+    if (c >= cells_1d) return n;
+    const float est = ((float)c - 0.5f) * (float)n / (float)(cells_1d - 1) - 0.5f;
+    int i = (int)ceilf(est);
+    i = i < 0 ? 0 : (i > n ? n : i);
+    while (i > 0 && raster_cell_of(i - 1, inv_n, cells_1d) >= c) --i;
+    while (i < n && raster_cell_of(i, inv_n, cells_1d) < c) ++i;
+    return i;
 }
 
 __global__ __launch_bounds__(256) void raster_cell_sum_kernel(const float4* __restrict__ entries, const uint8_t* __restrict__ mask,
@@ -378,37 +384,60 @@ __global__ __launch_bounds__(256) void raster_cell_sum_kernel(const float4* __re
     if (cell >= w * h) return;                         // wave-uniform; no block barrier below
     const int cx = cell % w, cy = cell / w;
     const float nx = 1.0f / (float)W, ny = 1.0f / (float)H;
-    const int x0 = raster_first_at_least(cx, W, nx, w), x1 = raster_first_at_least(cx + 1, W, nx, w);
-    const int y0 = raster_first_at_least(cy, H, ny, h), y1 = raster_first_at_least(cy + 1, H, ny, h);
+    // the four boundaries on four lanes at once
+    const bool is_y = (lane & 2) != 0;
+    const int bnd = raster_first_at_least((is_y ? cy : cx) + (lane & 1), is_y ? H : W, is_y ? ny : nx, is_y ? h : w);
+    const int x0 = __builtin_amdgcn_readlane(bnd, 0), x1 = __builtin_amdgcn_readlane(bnd, 1);
+    const int y0 = __builtin_amdgcn_readlane(bnd, 2), y1 = __builtin_amdgcn_readlane(bnd, 3);
     const int cw = x1 - x0, total = cw * (y1 - y0);
     float sum = 0.0f, cnt = kF32Eps;                   // motion_field.rs:133-138
     uint32_t kept = 0;
-    for (int k0 = 0; k0 < total; k0 += 64) {
-        const int k = k0 + lane;
-        bool on = k < total;
-        float2 mv = make_float2(0.0f, 0.0f);
-        if (on) {
-            const int ry = k / cw;
-            const size_t idx = (size_t)(y0 + ry) * W + (x0 + (k - ry * cw));
-            on = !mask || mask[idx];
-            if (on) { const float4 en = entries[idx]; mv = make_float2(en.z, en.w); }
-        }
-        const unsigned long long bal = __ballot(on);
-        if (on) stage[wave][__popcll(bal & ((1ull << lane) - 1ull))] = mv;
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        const int m = __popcll(bal);
-        kept += (uint32_t)m;
-        if (lane < 2) {
-            const float* col = reinterpret_cast<const float*>(&stage[wave][0]) + lane;
-            for (int j = 0; j < m; ++j) {
-                const float wgt = 1.0f;
-                cnt += wgt;                            // :142-143
-                sum = col[2 * j] * wgt + sum;          // :144-146 (motion * weight + column)
+    // four 64-record rounds are requested together (a 1080p -> 150 x 84 cell holds ~170 records: one memory round trip
+    // instead of three), then staged and added round by round
+    constexpr int AHEAD = 4;
+    for (int k00 = 0; k00 < total; k00 += 64 * AHEAD) {
+        bool on[AHEAD];
+        float2 mv[AHEAD];
+#pragma unroll
+        for (int a = 0; a < AHEAD; ++a) {
+            const int k = k00 + 64 * a + lane;
+            on[a] = k < total;
+            mv[a] = make_float2(0.0f, 0.0f);
+            if (on[a]) {
+                const int ry = k / cw;
+                const size_t idx = (size_t)(y0 + ry) * W + (x0 + (k - ry * cw));
+                on[a] = !mask || mask[idx];
+                if (on[a]) { const float4 en = entries[idx]; mv[a] = make_float2(en.z, en.w); }
             }
         }
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+        for (int a = 0; a < AHEAD; ++a) {
+            if (k00 + 64 * a >= total) break;          // uniform
+            const unsigned long long bal = __ballot(on[a]);
+            if (on[a]) stage[wave][__popcll(bal & ((1ull << lane) - 1ull))] = mv[a];
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            const int m = __popcll(bal);
+            kept += (uint32_t)m;
+            if (lane < 2) {
+                const float* col = reinterpret_cast<const float*>(&stage[wave][0]) + lane;
+                const float wgt = 1.0f;
+                int j = 0;
+                for (; j + 8 <= m; j += 8) {               // eight staged values fetched together, then the dependent adds in order
+                    float v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) v[u] = col[2 * (j + u)];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) { cnt += wgt; sum = v[u] * wgt + sum; }      // :142-146
+                }
+                for (; j < m; ++j) {
+                    cnt += wgt;                            // :142-143
+                    sum = col[2 * j] * wgt + sum;          // :144-146 (motion * weight + column)
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        }
     }
     if (lane < 2) reinterpret_cast<float*>(out_field + cell)[lane] = sum / cnt;   // :304
     if (lane == 0) { cell_begin[cell] = 0; cell_end[cell] = kept; }                // visited <=> end > begin
