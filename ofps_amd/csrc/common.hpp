@@ -23,6 +23,8 @@ struct ofps_hip_ctx {
     // hip_lk stream state (lk.hip: ofps_hip_lk_push_frame): frame k of the stream lives in slot k % 2 of S_FRAMES
     int lk_w = 0, lk_h = 0;
     long lk_frames = 0;
+    void* lk_pinned = nullptr;           // page-locked staging for a frame's records + their count (one D2H, one wait)
+    size_t lk_pinned_cap = 0;
 
     // per-frame pipeline state (pipeline.hip): a ring of three device frame slots (the new frame is uploaded on the copy
     // stream while the previous pair is still being searched), two tickets in flight

@@ -101,6 +101,7 @@ void ofps_hip_destroy(ofps_hip_ctx* ctx) {
         if (ctx->pipe_uploaded[k]) (void)hipEventDestroy(ctx->pipe_uploaded[k]);
         if (ctx->pipe_slot_read[k]) (void)hipEventDestroy(ctx->pipe_slot_read[k]);
     }
+    if (ctx->lk_pinned) (void)hipHostFree(ctx->lk_pinned);
     if (ctx->pipe_copy_stream) (void)hipStreamDestroy(ctx->pipe_copy_stream);
     if (ctx->pipe_aux_stream) (void)hipStreamDestroy(ctx->pipe_aux_stream);
     if (ctx->pipe_fork) (void)hipEventDestroy(ctx->pipe_fork);

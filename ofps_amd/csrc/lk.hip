@@ -15,6 +15,7 @@
 // contraction wide enough for MFMA (the normal equations are 2x2 per pixel).
 #include "common.hpp"
 
+#include <cstring>
 #include <type_traits>
 #include <vector>
 
@@ -892,10 +893,22 @@ static int lk_decode_resident(ofps_hip_ctx* ctx, uint8_t* d_frames, int slot_pre
     // densifier walks each cell's rectangle of pixels (masked ones skipped in place) instead of sorting 2 M records
     rc = ofps::densify_raster_entries_device(ctx, d_ent, d_mask, W, H, gw, gh, d_field, d_out, d_cnt);
     if (rc != OFPS_HIP_OK) return rc;
-    uint32_t cnt = 0;
-    OFPS_HIP_TRY(ctx, hipMemcpyAsync(&cnt, d_cnt, sizeof(cnt), hipMemcpyDeviceToHost, ctx->stream));
+    // the count and all candidate records come back in ONE transfer to page-locked memory and one wait (the count first and
+    // the records after it was known cost a second round trip); only the visited cells' records reach the caller's buffer
+    const size_t need = 16 + cells * sizeof(float4);
+    if (ctx->lk_pinned_cap < need) {
+        if (ctx->lk_pinned) { OFPS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); OFPS_HIP_TRY(ctx, hipHostFree(ctx->lk_pinned)); ctx->lk_pinned = nullptr; ctx->lk_pinned_cap = 0; }
+        OFPS_HIP_TRY(ctx, hipHostMalloc(&ctx->lk_pinned, need, hipHostMallocDefault));
+        ctx->lk_pinned_cap = need;
+    }
+    auto* pin = static_cast<char*>(ctx->lk_pinned);
+    OFPS_HIP_TRY(ctx, hipMemcpyAsync(pin, d_cnt, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    OFPS_HIP_TRY(ctx, hipMemcpyAsync(pin + 16, d_out, cells * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
     OFPS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    if (cnt) OFPS_HIP_TRY(ctx, hipMemcpy(out_entries, d_out, (size_t)cnt * sizeof(float4), hipMemcpyDeviceToHost));
+    uint32_t cnt = 0;
+    memcpy(&cnt, pin, sizeof(cnt));
+    if (cnt > cells) cnt = (uint32_t)cells;
+    if (cnt) memcpy(out_entries, pin + 16, (size_t)cnt * sizeof(float4));
     *n_out = cnt;
     return OFPS_HIP_OK;
 }
