@@ -1307,7 +1307,8 @@ static int lsq_stepped(ofps_hip_ctx* ctx, const float4* d_entries, size_t n_max,
     const size_t per_wg = n_max > 65536 ? 8 * 1024 : 1024;
     int nblk = (int)((n_max + per_wg - 1) / per_wg);
     const int cap = (2 * ctx->num_cus + batch - 1) / batch;
-    if (nblk > cap) nblk = cap < 1 ? 1 : cap;
+    if (nblk > cap) nblk = cap;
+    if (nblk < 1) nblk = 1;                                  // empty fields (forced A/B path): one workgroup that sums nothing
     auto* part = static_cast<float*>(scratch(ctx, S_ALM_PART, 2 * (size_t)batch * nblk * 9 * sizeof(float)));
     auto* state = static_cast<Quat*>(scratch(ctx, S_ALM_STATE, 2 * (size_t)batch * sizeof(Quat)));
     if (!part || !state) return OFPS_HIP_ENOMEM;
