@@ -302,6 +302,73 @@ __device__ __forceinline__ bool lu3_solve(const float a_in[9], const float b_in[
 // solves; the forward substitution above has not started when a swap is recorded, and the swaps
 // are applied in recording order, so permuting b on the fly is the same sequence of exchanges.
 
+// The normal matrix A does not change from step to step, so neither does its factorisation: lu3_factor is lu3_solve's
+// elimination (the same operations on the same numbers), lu3_apply its row exchanges of b, forward and back substitution.
+struct Lu3 { float r0[3], r1[3], r2[3]; int piv0, p2; };            // L multipliers below the diagonal, U on and above it
+__device__ __forceinline__ Lu3 lu3_factor(const float a_in[9]) {
+    Lu3 f;
+    float r0[3] = {a_in[0], a_in[1], a_in[2]}, r1[3] = {a_in[3], a_in[4], a_in[5]}, r2[3] = {a_in[6], a_in[7], a_in[8]};
+    float d0 = 0.0f, d1 = 0.0f, d2 = 0.0f;                          // stand-ins for b in the shared row exchange helper
+    f.piv0 = 0; f.p2 = 0;
+    {
+        int piv = 0;
+        float best = fabsf(r0[0]);
+        if (fabsf(r1[0]) > best) { best = fabsf(r1[0]); piv = 1; }
+        if (fabsf(r2[0]) > best) { piv = 2; }
+        const float diag = piv == 0 ? r0[0] : (piv == 1 ? r1[0] : r2[0]);
+        if (diag != 0.0f) {
+            f.piv0 = piv;
+            lu3_swap_rows(piv == 1, r0, r1, d0, d1);
+            lu3_swap_rows(piv == 2, r0, r2, d0, d2);
+            const float inv_diag = 1.0f / diag;
+            r1[0] *= inv_diag; r2[0] *= inv_diag;
+#pragma unroll
+            for (int c = 1; c < 3; ++c) {
+                const float neg = -r0[c];
+                r1[c] = neg * r1[0] + r1[c];
+                r2[c] = neg * r2[0] + r2[c];
+            }
+        }
+    }
+    {
+        const bool p2 = fabsf(r2[1]) > fabsf(r1[1]);
+        const float diag = p2 ? r2[1] : r1[1];
+        if (diag != 0.0f) {
+            f.p2 = p2 ? 1 : 0;
+            lu3_swap_rows(p2, r1, r2, d1, d2);
+            const float inv_diag = 1.0f / diag;
+            r2[1] *= inv_diag;
+            const float neg = -r1[2];
+            r2[2] = neg * r2[1] + r2[2];
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { f.r0[c] = r0[c]; f.r1[c] = r1[c]; f.r2[c] = r2[c]; }
+    return f;
+}
+__device__ __forceinline__ bool lu3_apply(const Lu3& f, const float b_in[3], float x[3]) {
+    float b0 = b_in[0], b1 = b_in[1], b2 = b_in[2];
+    { float t; if (f.piv0 == 1) { t = b0; b0 = b1; b1 = t; } if (f.piv0 == 2) { t = b0; b0 = b2; b2 = t; } if (f.p2) { t = b1; b1 = b2; b2 = t; } }
+    {
+        const float c0 = b0 / 1.0f;
+        b1 = (-c0) * f.r1[0] + b1;
+        b2 = (-c0) * f.r2[0] + b2;
+        const float c1 = b1 / 1.0f;
+        b2 = (-c1) * f.r2[1] + b2;
+    }
+    if (f.r2[2] == 0.0f) return false;
+    const float x2 = b2 / f.r2[2];
+    b0 = (-x2) * f.r0[2] + b0;
+    b1 = (-x2) * f.r1[2] + b1;
+    if (f.r1[1] == 0.0f) return false;
+    const float x1 = b1 / f.r1[1];
+    b0 = (-x1) * f.r0[1] + b0;
+    if (f.r0[0] == 0.0f) return false;
+    const float x0 = b0 / f.r0[0];
+    x[0] = x0; x[1] = x1; x[2] = x2;
+    return true;
+}
+
 struct Protos { Mat3 roll, pitch, yaw; };
 
 __device__ __forceinline__ Mat3 mat3_from_euler(float roll, float pitch, float yaw) {
@@ -336,21 +403,35 @@ __device__ __forceinline__ Quat almeida_update(const Quat& rotation, const float
     return quat_mul(rotation, rot);                                               // :195
 }
 
-// The same update run by a whole wave: the three half-angle sincos evaluations -- two thirds of this serial section's
-// latency -- go to lanes 0..2 in parallel and come back through v_readlane; everything else is wave-uniform.  Same
-// functions on the same arguments as almeida_update, hence the same bits.
-__device__ __forceinline__ Quat almeida_update_wave(const Quat& rotation, const float s[9], float eps, float alpha) {
-    const float a[9] = {s[0], s[1], s[2], s[1], s[3], s[4], s[2], s[4], s[5]};
-    const float b[3] = {s[6], s[7], s[8]};
+// sin and cos of a half-angle of one Gauss-Newton step.  These angles are tiny (a whole 10 degree rotation is 0.087 rad as
+// a half-angle): below 0.25 rad the Taylor polynomials to x^7 / x^8 are exact to less than half an ulp of truncation error
+// (next terms 1e-11 and 3e-13 relative) and cost ten fused operations instead of the library routine's argument
+// reduction; anything larger takes the library routine.  The branch is wave-uniform.
+__device__ __forceinline__ void sincos_small(float x, float& sn, float& cs) {
+    if (__all(fabsf(x) < 0.25f)) {
+        const float x2 = x * x;
+        const float ps = __builtin_fmaf(x2, __builtin_fmaf(x2, __builtin_fmaf(x2, -1.0f / 5040.0f, 1.0f / 120.0f), -1.0f / 6.0f), 1.0f);
+        sn = x * ps;
+        cs = __builtin_fmaf(x2, __builtin_fmaf(x2, __builtin_fmaf(x2, __builtin_fmaf(x2, 1.0f / 40320.0f, -1.0f / 720.0f), 1.0f / 24.0f), -0.5f), 1.0f);
+    } else {
+        sincosf(x, &sn, &cs);
+    }
+}
+// The Gauss-Newton update run by a whole wave on a factorisation made once per solve (A is the same in every step): the
+// three half-angle sincos evaluations go to lanes 0..2 in parallel and come back through v_readlane; everything else is
+// wave-uniform.
+__device__ __forceinline__ Quat almeida_update_wave_lu(const Quat& rotation, const Lu3& f, float b0, float b1, float b2, float eps,
+                                                       float alpha) {
+    const float b[3] = {b0, b1, b2};
     float model[3];
-    if (!lu3_solve(a, b, model)) { model[0] = model[1] = model[2] = 0.0f; }       // :181-183
+    if (!lu3_apply(f, b, model)) { model[0] = model[1] = model[2] = 0.0f; }       // :181-183
     model[0] = model[0] * eps * alpha;                                            // :185
     model[1] = model[1] * eps * alpha;
     model[2] = model[2] * eps * alpha;
     const int lane = threadIdx.x & 63;
     const float half = lane == 0 ? model[0] * 0.5f : (lane == 1 ? model[1] * 0.5f : -model[2] * 0.5f);
     float sn, cs;
-    sincosf(half, &sn, &cs);
+    sincos_small(half, sn, cs);
     const float s0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sn), 0)), c0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cs), 0));
     const float s1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sn), 1)), c1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cs), 1));
     const float s2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sn), 2)), c2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cs), 2));
@@ -467,6 +548,12 @@ __global__ __launch_bounds__(1024) void almeida_lsq_wg_kernel(const float4* __re
         for (int k = 0; k < 6; ++k) a_sh[k] = s[k];
     }
     __syncthreads();
+    __shared__ Lu3 lu_sh;                                          // A is the same in every step: factorised once (wave 0)
+    if (threadIdx.x < 64) {
+        const float am[9] = {a_sh[0], a_sh[1], a_sh[2], a_sh[1], a_sh[3], a_sh[4], a_sh[2], a_sh[4], a_sh[5]};
+        const Lu3 lu = lu3_factor(am);
+        if (threadIdx.x == 0) lu_sh = lu;
+    }
     Quat rotation = {1.0f, 0.0f, 0.0f, 0.0f};
     for (int it = 0; it < kIters; ++it) {
         const float alpha = (it == kIters - 1) ? 1.0f : 0.5f;      // lib.rs:138
@@ -486,12 +573,12 @@ __global__ __launch_bounds__(1024) void almeida_lsq_wg_kernel(const float4* __re
             s[8] += py[t].x * rx + py[t].y * ry;
         }
         block_sum<6, 9>(s, red);
-        if (threadIdx.x < 64) {                                    // wave 0, all lanes: see almeida_update_wave
-            const float f[9] = {a_sh[0], a_sh[1], a_sh[2], a_sh[3], a_sh[4], a_sh[5],
-                                __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(s[6]))),
-                                __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(s[7]))),
-                                __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(s[8])))};
-            const Quat q = almeida_update_wave(rotation, f, eps, alpha);
+        if (threadIdx.x < 64) {                                    // wave 0, all lanes: see almeida_update_wave_lu
+            const Lu3 lu = lu_sh;                                  // (written by this very wave before the loop)
+            const Quat q = almeida_update_wave_lu(rotation, lu,
+                                                  __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(s[6]))),
+                                                  __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(s[7]))),
+                                                  __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(s[8]))), eps, alpha);
             if (threadIdx.x == 0) rot_sh[it & 1] = q;
         }
         __syncthreads();
@@ -790,6 +877,7 @@ __global__ __launch_bounds__(BLOCK) void almeida_lsq_cluster_kernel(const float4
     __shared__ DeltaAffine aff_sh[2];                   // dense regime: the folded camera + rotation of rot_sh[], same slots
     __shared__ int fail_sh;
     __shared__ int hier_sh;                             // steps >= 1 gather in two levels (per XCD through its L2, then across)
+    __shared__ Lu3 lu_sh;                               // factorisation of the folded A, made in step 0 by the updating wave
     __shared__ float4 plds[P_LDS ? EPT * BLOCK : 1];     // (roll.x, roll.y, pitch.x, pitch.y) per record
     const int nblk = gridDim.x, blk = blockIdx.x;
     const size_t item = blockIdx.y;
@@ -947,8 +1035,15 @@ __global__ __launch_bounds__(BLOCK) void almeida_lsq_cluster_kernel(const float4
         if (wave == 2) {
             OFPS_STAMP_W2(5);
             if (got) {
-                const float f[9] = {a_sh[0], a_sh[1], a_sh[2], a_sh[3], a_sh[4], a_sh[5], ta, tb, tc};
-                const Quat q = almeida_update_wave(rot_sh[(it + 1) & 1], f, eps, alpha);
+                Lu3 lu;
+                if (it == 0) {
+                    const float am[9] = {a_sh[0], a_sh[1], a_sh[2], a_sh[1], a_sh[3], a_sh[4], a_sh[2], a_sh[4], a_sh[5]};
+                    lu = lu3_factor(am);
+                    if (lane == 0) lu_sh = lu;
+                } else {
+                    lu = lu_sh;
+                }
+                const Quat q = almeida_update_wave_lu(rot_sh[(it + 1) & 1], lu, ta, tb, tc, eps, alpha);
                 if constexpr (FAST) {                   // fold camera and new rotation once, here, for every wave's next step
                     const DeltaAffine A = delta_affine(dk, quat_to_mat3(q));
                     if (lane == 0) aff_sh[it & 1] = A;
@@ -1012,7 +1107,7 @@ __device__ __forceinline__ uint32_t sample_index(const SampleKey& k, uint32_t i,
 // One hypothesis per QUAD of lanes (16 per wave): lane q < 3 of a quad owns sample q -- its record, prototypes and, per
 // step, its `delta` -- and the three per-sample terms of every sum are added in sample order through quad_perm
 // broadcasts (DPP operands, no LDS), so every lane of the quad holds the sums the one-lane walk produced, bit for bit.
-// The update runs in all four lanes with the three half-angle sincos spread over lanes 0..2 (almeida_update_wave's
+// The update runs in all four lanes with the three half-angle sincos spread over lanes 0..2 (almeida_update_wave_lu's
 // trick at quad width).  A hypothesis is a chain of 30 dependent steps on a handful of lanes either way -- latency,
 // not throughput -- and the quad form shortens the chain: three `delta` and three sincos side by side instead of in a row.
 template <int J>
