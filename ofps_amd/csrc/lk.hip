@@ -52,6 +52,28 @@ __device__ __forceinline__ bool lk_tile_of_block(int tiles_x, int ntiles, int& t
     return true;
 }
 
+// One launch over ALL pyramid levels (gradients, structure tensors: they depend on the previous frame only, not on the
+// flow): level l owns blocks [start[l], start[l + 1]), each range a multiple of 8 blocks so that a block's XCD (block % 8)
+// is the same seen from the launch and from its level, and lk_tile_of_block's mapping applies inside the range.
+struct LkPyr {
+    int levels;
+    int w[8], h[8];
+    unsigned off[8];          // level's offset inside a pyramid buffer, in pixels
+    unsigned start[9];
+};
+__device__ __forceinline__ bool lk_level_tile_of_block(const LkPyr& P, int tile_w, int tile_h, int& l, int& tx, int& ty) {
+    const unsigned b = blockIdx.x;
+    l = 0;
+#pragma unroll
+    for (int k = 1; k < 8; ++k) l += (k < P.levels && b >= P.start[k]) ? 1 : 0;
+    const unsigned local = b - P.start[l], nloc = P.start[l + 1] - P.start[l];
+    const int t = (int)((local % 8u) * (nloc / 8u) + local / 8u);
+    const int tiles_x = (P.w[l] + tile_w - 1) / tile_w, ntiles = tiles_x * ((P.h[l] + tile_h - 1) / tile_h);
+    if (t >= ntiles) return false;
+    ty = t / tiles_x; tx = t - ty * tiles_x;
+    return true;
+}
+
 // Both pyramid passes in one launch, for both frames (blockIdx.z): each thread forms the five horizontally filtered
 // values its output needs and filters them vertically: the oracle's two separable passes (lk_pyr_down, horizontal
 // then vertical, each ((((a + 4b) + 6c) + 4d) + e) / 16) -- the same bits without the intermediate plane and with a
@@ -87,10 +109,17 @@ __global__ __launch_bounds__(256) void lk_u8_to_f32_pair_kernel(const uint8_t* _
     dst[(size_t)y * W + x] = (float)src[(size_t)y * stride + x];
 }
 
-__global__ __launch_bounds__(256) void lk_grad_kernel(const float* __restrict__ I, int w, int h, float* __restrict__ gx,
-                                                      float* __restrict__ gy) {
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+// central-difference gradients of the previous frame, every level of the pyramid in one launch (64 x 4 pixels per block)
+__global__ __launch_bounds__(256) void lk_grad_all_kernel(const float* __restrict__ Ip, const LkPyr P, float* __restrict__ gxp,
+                                                          float* __restrict__ gyp) {
+    int l, tx, ty;
+    if (!lk_level_tile_of_block(P, 64, 4, l, tx, ty)) return;
+    const int w = P.w[l], h = P.h[l];
+    const int x = tx * 64 + (threadIdx.x & 63), y = ty * 4 + (threadIdx.x >> 6);
     if (x >= w || y >= h) return;
+    const float* I = Ip + P.off[l];
+    float* gx = gxp + P.off[l];
+    float* gy = gyp + P.off[l];
     gx[(size_t)y * w + x] = (I[(size_t)y * w + lk_clampi(x + 1, 0, w - 1)] - I[(size_t)y * w + lk_clampi(x - 1, 0, w - 1)]) * 0.5f;
     gy[(size_t)y * w + x] = (I[(size_t)lk_clampi(y + 1, 0, h - 1) * w + x] - I[(size_t)lk_clampi(y - 1, 0, h - 1) * w + x]) * 0.5f;
 }
@@ -284,12 +313,16 @@ __device__ __forceinline__ void lk_stage3(const float* __restrict__ p0, const fl
 constexpr int kTP = 4;                       // pixels per thread (vertical)
 constexpr int kTTX = 32, kTTY = 8 * kTP;     // pixels per workgroup: 32 x 32
 template <int RADIUS>
-__global__ __launch_bounds__(256) void lk_tensor_tiled_kernel(const float* __restrict__ gx, const float* __restrict__ gy, int w, int h,
-                                                              float4* __restrict__ G) {
+__global__ __launch_bounds__(256) void lk_tensor_tiled_kernel(const float* __restrict__ gxp, const float* __restrict__ gyp, const LkPyr P,
+                                                              float4* __restrict__ Gp) {
     constexpr int R = RADIUS, N = 2 * RADIUS + 1, TW = kTTX + 2 * RADIUS, TH = kTTY + 2 * RADIUS;
     __shared__ float4 prod[TH][TW];
-    int tx, ty;
-    if (!lk_tile_of_block((w + kTTX - 1) / kTTX, ((w + kTTX - 1) / kTTX) * ((h + kTTY - 1) / kTTY), tx, ty)) return;
+    int l, tx, ty;
+    if (!lk_level_tile_of_block(P, kTTX, kTTY, l, tx, ty)) return;     // every level of the pyramid in one launch
+    const int w = P.w[l], h = P.h[l];
+    const float* gx = gxp + P.off[l];
+    const float* gy = gyp + P.off[l];
+    float4* G = Gp + P.off[l];
     const int x0 = tx * kTTX, y0 = ty * kTTY;
     {
         constexpr int ROWS_PER_PASS = 256 / TW;
@@ -698,13 +731,14 @@ int lk_flow_device(ofps_hip_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_cu
     // every segment is rounded up to a multiple of 4 floats so that G (float4) and the flow planes (float2) stay
     // naturally aligned inside the workspace whatever the frame size
     const size_t plane0 = ((size_t)W * H + 3) & ~size_t(3), pyr = (off[levels] + 3) & ~size_t(3);
-    // layout: I pyramid | J pyramid | gx | gy | G (float4) | flowA (float2) | flowB (float2)
-    const size_t floats = 2 * pyr + 2 * plane0 + 4 * plane0 + 2 * plane0 + 2 * plane0;
+    // layout: I pyramid | J pyramid | gx pyramid | gy pyramid | G pyramid (float4) | flowA (float2) | flowB (float2): the
+    // gradients and tensors of all levels are formed up front (they do not depend on the flow), one launch each
+    const size_t floats = 2 * pyr + 2 * pyr + 4 * pyr + 2 * plane0 + 2 * plane0;
     auto* base = static_cast<float*>(scratch(ctx, S_WORK0, floats * sizeof(float)));
     if (!base) return OFPS_HIP_ENOMEM;
-    float* Ip = base; float* Jp = Ip + pyr; float* gx = Jp + pyr; float* gy = gx + plane0;
-    float4* G = reinterpret_cast<float4*>(gy + plane0);
-    float2* fa = reinterpret_cast<float2*>(reinterpret_cast<float*>(G) + 4 * plane0);
+    float* Ip = base; float* Jp = Ip + pyr; float* gxp = Jp + pyr; float* gyp = gxp + pyr;
+    float4* Gp = reinterpret_cast<float4*>(gyp + pyr);
+    float2* fa = reinterpret_cast<float2*>(reinterpret_cast<float*>(Gp) + 4 * pyr);
     float2* fb = fa + plane0;
 
     // per level: the (tile, first step) pairs the LDS kernel hands to the general kernel, and where their flows are parked
@@ -742,18 +776,36 @@ int lk_flow_device(ofps_hip_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_cu
     }
     int force_fall = -1;
     if (const char* f = getenv("OFPS_HIP_LK_TEST_FALL")) force_fall = atoi(f);                 // tests only
-    for (int l = levels - 1; l >= 0; --l) {
-        const int w = ws[l], h = hs[l];
-        hipLaunchKernelGGL(lk_grad_kernel, lk_grid(w, h), dim3(256), 0, s, Ip + off[l], w, h, gx, gy);
+    {   // gradients of every level: one launch (64 x 4 pixels per block, per-level block ranges padded to multiples of 8)
+        LkPyr P{};
+        P.levels = levels;
+        unsigned nb = 0;
+        for (int l = 0; l < levels; ++l) {
+            P.w[l] = ws[l]; P.h[l] = hs[l]; P.off[l] = (unsigned)off[l]; P.start[l] = nb;
+            nb += lk_grid_xcd(ws[l], hs[l], 64, 4).x;
+        }
+        P.start[levels] = nb;
+        hipLaunchKernelGGL(lk_grad_all_kernel, dim3(nb), dim3(256), 0, s, Ip, P, gxp, gyp);
         if (tiled) {
+            // structure tensors of every level: one launch (32 x 32 pixels per block).
             // (measured and rejected: forming the gradients while staging -- five loads per window record instead of three,
             // 0.53 ms -- and summing G inside the level kernel -- 0.50 ms: that kernel is held to 80 VGPRs and lives at the
             // VALU limit, the tensor kernel runs at twice its occupancy)
+            nb = 0;
+            for (int l = 0; l < levels; ++l) { P.start[l] = nb; nb += lk_grid_xcd(ws[l], hs[l], kTTX, kTTY).x; }
+            P.start[levels] = nb;
             switch (radius) {
-                case 2: hipLaunchKernelGGL(lk_tensor_tiled_kernel<2>, lk_grid_xcd(w, h, kTTX, kTTY), dim3(256), 0, s, gx, gy, w, h, G); break;
-                case 4: hipLaunchKernelGGL(lk_tensor_tiled_kernel<4>, lk_grid_xcd(w, h, kTTX, kTTY), dim3(256), 0, s, gx, gy, w, h, G); break;
-                default: hipLaunchKernelGGL(lk_tensor_tiled_kernel<6>, lk_grid_xcd(w, h, kTTX, kTTY), dim3(256), 0, s, gx, gy, w, h, G); break;
+                case 2: hipLaunchKernelGGL(lk_tensor_tiled_kernel<2>, dim3(nb), dim3(256), 0, s, gxp, gyp, P, Gp); break;
+                case 4: hipLaunchKernelGGL(lk_tensor_tiled_kernel<4>, dim3(nb), dim3(256), 0, s, gxp, gyp, P, Gp); break;
+                default: hipLaunchKernelGGL(lk_tensor_tiled_kernel<6>, dim3(nb), dim3(256), 0, s, gxp, gyp, P, Gp); break;
             }
+        }
+    }
+    for (int l = levels - 1; l >= 0; --l) {
+        const int w = ws[l], h = hs[l];
+        float* gx = gxp + off[l]; float* gy = gyp + off[l];
+        float4* G = Gp + off[l];
+        if (tiled) {
             // one launch runs all `iters` steps of the level: in = the coarser level's flow (cur_flow), out = `other`
             const bool last = l == 0;
             uint32_t* cnt = fb_count + l;
