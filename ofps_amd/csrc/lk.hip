@@ -97,6 +97,47 @@ __global__ __launch_bounds__(256) void lk_pyr_down_kernel(const float* __restric
     out[(size_t)y * w1 + x] = ((((t[0] + 4.0f * t[1]) + 6.0f * t[2]) + 4.0f * t[3]) + t[4]) * 0.0625f;
 }
 
+// The first pyramid step straight from the u8 frames, tiled: a workgroup produces 32 x 8 level-1 pixels of one frame from the
+// 68 x 20 level-0 window it stages in LDS (coordinates clamped per element, which is what clamping every tap of
+// lk_pyr_down_kernel amounts to), filters rows then columns in the oracle's operation order, and writes the 64 x 16
+// level-0 pixels at the window's centre to the f32 plane on the way: the u8 -> f32 launch and its 17 MB read-back go.
+constexpr int kP0X = 32, kP0Y = 8;
+__global__ __launch_bounds__(256) void lk_pyr0_kernel(const uint8_t* __restrict__ s0, const uint8_t* __restrict__ s1, int W, int H, int stride,
+                                                      float* __restrict__ f0, float* __restrict__ f1, float* __restrict__ o0,
+                                                      float* __restrict__ o1, int w1, int h1, uint32_t* __restrict__ zero, int n_zero) {
+    constexpr int RW = 2 * kP0X + 4, RH = 2 * kP0Y + 4;           // level-0 window
+    __shared__ float win[RH][RW + 1];
+    __shared__ float hor[RH][kP0X + 1];
+    if (zero && blockIdx.x == 0 && blockIdx.z == 0 && (int)threadIdx.x < n_zero) zero[threadIdx.x] = 0;   // hand-over counters
+    int tx, ty;
+    if (!lk_tile_of_block((w1 + kP0X - 1) / kP0X, ((w1 + kP0X - 1) / kP0X) * ((h1 + kP0Y - 1) / kP0Y), tx, ty)) return;
+    const uint8_t* src = blockIdx.z ? s1 : s0;
+    float* f = blockIdx.z ? f1 : f0;
+    float* out = blockIdx.z ? o1 : o0;
+    const int x0 = tx * kP0X, y0 = ty * kP0Y;                    // level-1 tile origin
+    const int gx0 = 2 * x0 - 2, gy0 = 2 * y0 - 2;                // level-0 window origin
+    for (int t = threadIdx.x; t < RW * RH; t += 256) {
+        const int r = t / RW, c = t - r * RW;
+        const int gx = gx0 + c, gy = gy0 + r;
+        const float v = (float)src[(size_t)lk_clampi(gy, 0, H - 1) * stride + lk_clampi(gx, 0, W - 1)];
+        win[r][c] = v;
+        // the window's centre is this tile's share of the level-0 plane (windows overlap only in their 2-pixel rims)
+        if (c >= 2 && c < RW - 2 && r >= 2 && r < RH - 2 && gx < W && gy < H) f[(size_t)gy * W + gx] = v;
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < kP0X * RH; t += 256) {
+        const int r = t / kP0X, x = t - r * kP0X;
+        const float* p = &win[r][2 * x];
+        hor[r][x] = ((((p[0] + 4.0f * p[1]) + 6.0f * p[2]) + 4.0f * p[3]) + p[4]) * 0.0625f;
+    }
+    __syncthreads();
+    const int lx = threadIdx.x % kP0X, ly = threadIdx.x / kP0X;
+    const int x = x0 + lx, y = y0 + ly;
+    if (x < w1 && y < h1)
+        out[(size_t)y * w1 + x] = ((((hor[2 * ly][lx] + 4.0f * hor[2 * ly + 1][lx]) + 6.0f * hor[2 * ly + 2][lx]) + 4.0f * hor[2 * ly + 3][lx]) +
+                                   hor[2 * ly + 4][lx]) * 0.0625f;
+}
+
 __global__ __launch_bounds__(256) void lk_u8_to_f32_pair_kernel(const uint8_t* __restrict__ s0, const uint8_t* __restrict__ s1, int W, int H,
                                                                 int stride, float* __restrict__ d0, float* __restrict__ d1,
                                                                 uint32_t* __restrict__ zero, int n_zero) {
@@ -757,12 +798,16 @@ int lk_flow_device(ofps_hip_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_cu
             if (!prof) return OFPS_HIP_ENOMEM;
         }
     }
-    {
+    if (levels >= 2) {                                            // level 1 from the u8 frames, level-0 f32 planes on the way
+        dim3 g2 = lk_grid_xcd(ws[1], hs[1], kP0X, kP0Y); g2.z = 2;
+        hipLaunchKernelGGL(lk_pyr0_kernel, g2, dim3(256), 0, s, d_prev, d_cur, W, H, stride, Ip, Jp, Ip + off[1], Jp + off[1], ws[1], hs[1],
+                           fb_count, fb_count ? levels : 0);
+    } else {
         dim3 g2 = lk_grid(W, H); g2.z = 2;
         hipLaunchKernelGGL(lk_u8_to_f32_pair_kernel, g2, dim3(256), 0, s, d_prev, d_cur, W, H, stride, Ip, Jp, fb_count,
                            fb_count ? levels : 0);
     }
-    for (int l = 1; l < levels; ++l) {
+    for (int l = 2; l < levels; ++l) {
         dim3 g2 = lk_grid_xcd(ws[l], hs[l]); g2.z = 2;
         hipLaunchKernelGGL(lk_pyr_down_kernel, g2, dim3(256), 0, s, Ip + off[l - 1], Jp + off[l - 1], ws[l - 1], hs[l - 1],
                            Ip + off[l], Jp + off[l], ws[l], hs[l]);
