@@ -104,7 +104,8 @@ __global__ __launch_bounds__(256) void lk_pyr_down_kernel(const float* __restric
 constexpr int kP0X = 32, kP0Y = 8;
 __global__ __launch_bounds__(256) void lk_pyr0_kernel(const uint8_t* __restrict__ s0, const uint8_t* __restrict__ s1, int W, int H, int stride,
                                                       float* __restrict__ f0, float* __restrict__ f1, float* __restrict__ o0,
-                                                      float* __restrict__ o1, int w1, int h1, uint32_t* __restrict__ zero, int n_zero) {
+                                                      float* __restrict__ o1, int w1, int h1, float* __restrict__ gx0p,
+                                                      float* __restrict__ gy0p, uint32_t* __restrict__ zero, int n_zero) {
     constexpr int RW = 2 * kP0X + 4, RH = 2 * kP0Y + 4;           // level-0 window
     __shared__ float win[RH][RW + 1];
     __shared__ float hor[RH][kP0X + 1];
@@ -125,6 +126,18 @@ __global__ __launch_bounds__(256) void lk_pyr0_kernel(const uint8_t* __restrict_
         if (c >= 2 && c < RW - 2 && r >= 2 && r < RH - 2 && gx < W && gy < H) f[(size_t)gy * W + gx] = v;
     }
     __syncthreads();
+    // the previous frame's level-0 gradients from the same window (an element holds I at its clamped coordinates, so its
+    // neighbours are lk_grad's clamped taps): the gradient launch then only has the coarser levels left
+    if (blockIdx.z == 0) {
+        for (int t = threadIdx.x; t < 2 * kP0X * 2 * kP0Y; t += 256) {
+            const int r = 2 + t / (2 * kP0X), c = 2 + t % (2 * kP0X);
+            const int gx = gx0 + c, gy = gy0 + r;
+            if (gx < W && gy < H) {
+                gx0p[(size_t)gy * W + gx] = (win[r][c + 1] - win[r][c - 1]) * 0.5f;
+                gy0p[(size_t)gy * W + gx] = (win[r + 1][c] - win[r - 1][c]) * 0.5f;
+            }
+        }
+    }
     for (int t = threadIdx.x; t < kP0X * RH; t += 256) {
         const int r = t / kP0X, x = t - r * kP0X;
         const float* p = &win[r][2 * x];
@@ -801,7 +814,7 @@ int lk_flow_device(ofps_hip_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_cu
     if (levels >= 2) {                                            // level 1 from the u8 frames, level-0 f32 planes on the way
         dim3 g2 = lk_grid_xcd(ws[1], hs[1], kP0X, kP0Y); g2.z = 2;
         hipLaunchKernelGGL(lk_pyr0_kernel, g2, dim3(256), 0, s, d_prev, d_cur, W, H, stride, Ip, Jp, Ip + off[1], Jp + off[1], ws[1], hs[1],
-                           fb_count, fb_count ? levels : 0);
+                           gxp, gyp, fb_count, fb_count ? levels : 0);
     } else {
         dim3 g2 = lk_grid(W, H); g2.z = 2;
         hipLaunchKernelGGL(lk_u8_to_f32_pair_kernel, g2, dim3(256), 0, s, d_prev, d_cur, W, H, stride, Ip, Jp, fb_count,
@@ -827,10 +840,10 @@ int lk_flow_device(ofps_hip_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_cu
         unsigned nb = 0;
         for (int l = 0; l < levels; ++l) {
             P.w[l] = ws[l]; P.h[l] = hs[l]; P.off[l] = (unsigned)off[l]; P.start[l] = nb;
-            nb += lk_grid_xcd(ws[l], hs[l], 64, 4).x;
+            if (l > 0 || levels < 2) nb += lk_grid_xcd(ws[l], hs[l], 64, 4).x;       // level 0: lk_pyr0_kernel wrote them
         }
         P.start[levels] = nb;
-        hipLaunchKernelGGL(lk_grad_all_kernel, dim3(nb), dim3(256), 0, s, Ip, P, gxp, gyp);
+        if (nb) hipLaunchKernelGGL(lk_grad_all_kernel, dim3(nb), dim3(256), 0, s, Ip, P, gxp, gyp);
         if (tiled) {
             // structure tensors of every level: one launch (32 x 32 pixels per block).
             // (measured and rejected: forming the gradients while staging -- five loads per window record instead of three,
