@@ -74,35 +74,15 @@ __device__ __forceinline__ bool lk_level_tile_of_block(const LkPyr& P, int tile_
     return true;
 }
 
-// Both pyramid passes in one launch, for both frames (blockIdx.z): each thread forms the five horizontally filtered
-// values its output needs and filters them vertically: the oracle's two separable passes (lk_pyr_down, horizontal
-// then vertical, each ((((a + 4b) + 6c) + 4d) + e) / 16) -- the same bits without the intermediate plane and with a
-// quarter of the launches.
-__global__ __launch_bounds__(256) void lk_pyr_down_kernel(const float* __restrict__ in0, const float* __restrict__ in1, int w, int h,
-                                                          float* __restrict__ out0, float* __restrict__ out1, int w1, int h1) {
-    int tx, ty;
-    if (!lk_tile_of_block((w1 + 63) / 64, ((w1 + 63) / 64) * ((h1 + 3) / 4), tx, ty)) return;
-    const int x = tx * 64 + (threadIdx.x & 63), y = ty * 4 + (threadIdx.x >> 6);
-    if (x >= w1 || y >= h1) return;
-    const float* in = blockIdx.z ? in1 : in0;
-    float* out = blockIdx.z ? out1 : out0;
-    const int xa = lk_clampi(2 * x - 2, 0, w - 1), xb = lk_clampi(2 * x - 1, 0, w - 1), xc = lk_clampi(2 * x, 0, w - 1),
-              xd = lk_clampi(2 * x + 1, 0, w - 1), xe = lk_clampi(2 * x + 2, 0, w - 1);
-    float t[5];
-#pragma unroll
-    for (int k = 0; k < 5; ++k) {
-        const float* r = in + (size_t)lk_clampi(2 * y - 2 + k, 0, h - 1) * w;
-        t[k] = ((((r[xa] + 4.0f * r[xb]) + 6.0f * r[xc]) + 4.0f * r[xd]) + r[xe]) * 0.0625f;
-    }
-    out[(size_t)y * w1 + x] = ((((t[0] + 4.0f * t[1]) + 6.0f * t[2]) + 4.0f * t[3]) + t[4]) * 0.0625f;
-}
-
-// The first pyramid step straight from the u8 frames, tiled: a workgroup produces 32 x 8 level-1 pixels of one frame from the
-// 68 x 20 level-0 window it stages in LDS (coordinates clamped per element, which is what clamping every tap of
-// lk_pyr_down_kernel amounts to), filters rows then columns in the oracle's operation order, and writes the 64 x 16
-// level-0 pixels at the window's centre to the f32 plane on the way: the u8 -> f32 launch and its 17 MB read-back go.
+// One pyramid step, both frames (blockIdx.z), tiled: a workgroup produces 32 x 8 pixels of level l+1 from the 68 x 20
+// level-l window it stages in LDS (coordinates clamped per element, which is what the oracle's per-tap clamping amounts
+// to) with the oracle's two separable passes (lk_pyr_down: rows, then columns, each ((((a + 4b) + 6c) + 4d) + e) / 16,
+// same operation order, same bits).  The first step reads the u8 frames directly and writes the 64 x 16 level-0 pixels at
+// the window's centre to the f32 planes on the way: the u8 -> f32 launch and its 17 MB read-back go.
+// TIn = uint8_t: the frames (f0 / f1 receive the f32 planes); TIn = float: a pyramid level (f0 = f1 = nullptr, stride = W).
 constexpr int kP0X = 32, kP0Y = 8;
-__global__ __launch_bounds__(256) void lk_pyr0_kernel(const uint8_t* __restrict__ s0, const uint8_t* __restrict__ s1, int W, int H, int stride,
+template <typename TIn>
+__global__ __launch_bounds__(256) void lk_pyr0_kernel(const TIn* __restrict__ s0, const TIn* __restrict__ s1, int W, int H, int stride,
                                                       float* __restrict__ f0, float* __restrict__ f1, float* __restrict__ o0,
                                                       float* __restrict__ o1, int w1, int h1, float* __restrict__ gx0p,
                                                       float* __restrict__ gy0p, uint32_t* __restrict__ zero, int n_zero) {
@@ -112,7 +92,7 @@ __global__ __launch_bounds__(256) void lk_pyr0_kernel(const uint8_t* __restrict_
     if (zero && blockIdx.x == 0 && blockIdx.z == 0 && (int)threadIdx.x < n_zero) zero[threadIdx.x] = 0;   // hand-over counters
     int tx, ty;
     if (!lk_tile_of_block((w1 + kP0X - 1) / kP0X, ((w1 + kP0X - 1) / kP0X) * ((h1 + kP0Y - 1) / kP0Y), tx, ty)) return;
-    const uint8_t* src = blockIdx.z ? s1 : s0;
+    const TIn* src = blockIdx.z ? s1 : s0;
     float* f = blockIdx.z ? f1 : f0;
     float* out = blockIdx.z ? o1 : o0;
     const int x0 = tx * kP0X, y0 = ty * kP0Y;                    // level-1 tile origin
@@ -123,7 +103,7 @@ __global__ __launch_bounds__(256) void lk_pyr0_kernel(const uint8_t* __restrict_
         const float v = (float)src[(size_t)lk_clampi(gy, 0, H - 1) * stride + lk_clampi(gx, 0, W - 1)];
         win[r][c] = v;
         // the window's centre is this tile's share of the level-0 plane (windows overlap only in their 2-pixel rims)
-        if (c >= 2 && c < RW - 2 && r >= 2 && r < RH - 2 && gx < W && gy < H) f[(size_t)gy * W + gx] = v;
+        if (f && c >= 2 && c < RW - 2 && r >= 2 && r < RH - 2 && gx < W && gy < H) f[(size_t)gy * W + gx] = v;
     }
     __syncthreads();
     // the previous frame's level-0 gradients from the same window (an element holds I at its clamped coordinates, so its
@@ -813,17 +793,18 @@ int lk_flow_device(ofps_hip_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_cu
     }
     if (levels >= 2) {                                            // level 1 from the u8 frames, level-0 f32 planes on the way
         dim3 g2 = lk_grid_xcd(ws[1], hs[1], kP0X, kP0Y); g2.z = 2;
-        hipLaunchKernelGGL(lk_pyr0_kernel, g2, dim3(256), 0, s, d_prev, d_cur, W, H, stride, Ip, Jp, Ip + off[1], Jp + off[1], ws[1], hs[1],
-                           gxp, gyp, fb_count, fb_count ? levels : 0);
+        hipLaunchKernelGGL(lk_pyr0_kernel<uint8_t>, g2, dim3(256), 0, s, d_prev, d_cur, W, H, stride, Ip, Jp, Ip + off[1], Jp + off[1], ws[1],
+                           hs[1], gxp, gyp, fb_count, fb_count ? levels : 0);
     } else {
         dim3 g2 = lk_grid(W, H); g2.z = 2;
         hipLaunchKernelGGL(lk_u8_to_f32_pair_kernel, g2, dim3(256), 0, s, d_prev, d_cur, W, H, stride, Ip, Jp, fb_count,
                            fb_count ? levels : 0);
     }
-    for (int l = 2; l < levels; ++l) {
-        dim3 g2 = lk_grid_xcd(ws[l], hs[l]); g2.z = 2;
-        hipLaunchKernelGGL(lk_pyr_down_kernel, g2, dim3(256), 0, s, Ip + off[l - 1], Jp + off[l - 1], ws[l - 1], hs[l - 1],
-                           Ip + off[l], Jp + off[l], ws[l], hs[l]);
+    for (int l = 2; l < levels; ++l) {                            // level l from level l-1, whose gradients come out of the same window
+        dim3 g2 = lk_grid_xcd(ws[l], hs[l], kP0X, kP0Y); g2.z = 2;
+        hipLaunchKernelGGL(lk_pyr0_kernel<float>, g2, dim3(256), 0, s, (const float*)(Ip + off[l - 1]), (const float*)(Jp + off[l - 1]),
+                           ws[l - 1], hs[l - 1], ws[l - 1], (float*)nullptr, (float*)nullptr, Ip + off[l], Jp + off[l], ws[l], hs[l],
+                           gxp + off[l - 1], gyp + off[l - 1], (uint32_t*)nullptr, 0);
     }
     float2* cur_flow = fa;
     float2* other = fb;
@@ -840,7 +821,7 @@ int lk_flow_device(ofps_hip_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_cu
         unsigned nb = 0;
         for (int l = 0; l < levels; ++l) {
             P.w[l] = ws[l]; P.h[l] = hs[l]; P.off[l] = (unsigned)off[l]; P.start[l] = nb;
-            if (l > 0 || levels < 2) nb += lk_grid_xcd(ws[l], hs[l], 64, 4).x;       // level 0: lk_pyr0_kernel wrote them
+            if (l == levels - 1) nb += lk_grid_xcd(ws[l], hs[l], 64, 4).x;           // the finer levels: the pyramid kernels wrote them
         }
         P.start[levels] = nb;
         if (nb) hipLaunchKernelGGL(lk_grad_all_kernel, dim3(nb), dim3(256), 0, s, Ip, P, gxp, gyp);
