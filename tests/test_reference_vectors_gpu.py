@@ -179,6 +179,18 @@ def test_hip_almeida_cluster_two_level_gather_matches_the_flat_gather(ctx, monke
     np.testing.assert_allclose(q_fb, q_o, atol=2e-6, rtol=0)
 
 
+@pytest.mark.parametrize("fast", ["0", "1"])
+def test_hip_almeida_arithmetic_switch_stays_inside_the_parity_bound(ctx, monkeypatch, fast):
+    """OFPS_HIP_ALMEIDA_FAST forces the exact (IEEE division, unfused) or the folded arithmetic of the cluster solver at any
+    field size (A/B runs): either way the quaternion stays within 2e-6 of the oracle's, below and above the 65,536 switch."""
+    monkeypatch.setenv("OFPS_HIP_ALMEIDA_FAST", fast)
+    cam = oracle.camera(16 / 9, 22.275)
+    for shape in ((120, 67), (480, 270)):
+        e = synth.rotation_field(*shape)
+        q, _ = ctx.almeida(e, 16 / 9, 22.275, use_ransac=False)
+        np.testing.assert_allclose(q, oracle.solve_ypr_given(e, cam), atol=2e-6, rtol=0)
+
+
 # ---- read-ahead form of the per-frame path: same bits as the synchronous call, two tickets in flight -------------------
 def test_hip_push_frame_async_matches_sync_and_oracle(ctx):
     W, H, F = 1920, 1080, 6
