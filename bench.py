@@ -68,6 +68,8 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-end-to-end", action="store_true")
+    ap.add_argument("--no-legs", action="store_true",
+                    help="skip the bounded cfg3 / cfg4 / cfg5 legs (bench_legs.py) that a default N=1 run adds beside the line")
     ap.add_argument("--end-to-end-only", action="store_true",
                     help="internal: print only the end_to_end object (the main run starts this in a fresh process, whose HIP runtime "
                          "state is a decoder plugin's, not a training framework's)")
@@ -85,6 +87,8 @@ def parse(argv=None):
     ap.add_argument("--stub", action="store_true",
                     help="TEST ONLY: no GPU, the step is a no-op that fills a deterministic result table; exercises the launch / "
                          "sharding / gather / reduce logic under gloo.  The line it prints is marked data='stub' and is not a measurement")
+    ap.add_argument("--stub-parity", default=None,
+                    help="TEST ONLY (with --stub): comma-separated per-rank parity verdicts 1|0|skip standing in for the oracle check")
     args = ap.parse_args(argv)
     given = {a.split("=")[0] for a in (sys.argv[1:] if argv is None else argv) if a.startswith("--")}
     if args.config:
@@ -271,12 +275,22 @@ def cpu_baseline(frames: np.ndarray, block: int, rng: int, budget_s: float):
             "almeida_lsq_ms": ms(lambda: oracle.solve_ypr_given(ent, cam)),
             "almeida_ransac_ms": ms(lambda: oracle.solve_ypr_ransac(ent, cam, 200, 0.05, 1000, seed=1)),
             "block_motion_detect_ms": ms(lambda: oracle.detect_motion(ent)), "threads": 1}
+    # the same estimates on all the cores this process may use (OpenMP over the per-vector loop and
+    # the twelve dot products / over the RANSAC hypotheses; same bits as one thread), and the per-pixel solve of
+    # BASELINE configs[2] (2,073,600 records), which one thread takes ~20 s for
+    tail_all = {"n_vectors": int(len(ent)), "threads": threads,
+                "almeida_lsq_ms": ms(lambda: oracle.solve_ypr_given(ent, cam, threads=threads), reps=5),
+                "almeida_ransac_ms": ms(lambda: oracle.solve_ypr_ransac(ent, cam, 200, 0.05, 1000, seed=1, threads=threads), reps=5),
+                "how": "OpenMP: per-vector delta loop + the 12 sequential dot sums side by side (LSQ); hypotheses (RANSAC); same bits as 1 thread"}
+    from ofps_amd import synth as _synth
+    dense = _synth.rotation_field(1920, 1080)
+    tail_all["almeida_lsq_2073600_records_ms"] = ms(lambda: oracle.solve_ypr_given(dense, cam, threads=threads), reps=1)
     absd = nblk * block * block * (2 * rng + 1) ** 2
     return {"value": round(done * nblk / el / 1e6, 4), "unit": "Mvectors/s", "cores": threads, "kind": "port",
             "nproc": nproc, "cpu_quota_cores": quota, "simd": oracle.sad_simd_level(),
             "abs_diffs_per_s": round(done * absd / el, 0),
             "thread_sweep_ms_per_pair_sustained": {str(t): round(v * 1e3, 2) for t, v in sweep.items()},
-            "tail_single_thread": tail,
+            "tail_single_thread": tail, "tail_all_cores": tail_all,
             "sample": f"{done} frame-pair searches cycling over the bench sequence, {frames.shape[2]}x{frames.shape[1]}, "
                       f"{block}x{block} blocks, +-{rng}, {el:.1f} s wall",
             "ms_per_pair": round(el / done * 1e3, 2),
@@ -499,6 +513,9 @@ def run_rank(args) -> int:
     gather_ok = None
     if args.stub:
         ok = 1
+        if args.stub_parity:
+            v = args.stub_parity.split(",")[rank]
+            ok = None if v == "skip" else int(v)
         if args.scaling == "strong":
             base = 36 if key_mode else 0                     # sum(1..8): the key frame reached every rank
             gather_ok = int(gathered["checksum"].tolist() == [k * 1000 + base for k in range(P)])
@@ -528,10 +545,15 @@ def run_rank(args) -> int:
                 gather_ok = int(int(gathered["checksum"][kg].item()) == want)
         except ImportError as e:                                 # no oracle on this machine: report "not checked"
             print(f"[bench] parity check skipped on rank {rank}: {e}", file=sys.stderr)
-    ok_all = D.min_over_ranks(-1 if ok is None else ok, dev)
+    # mismatches and skips are reduced separately: a rank that had nothing to check (no pairs, no oracle) must not hide
+    # another rank's mismatch
+    ok_min = D.min_over_ranks(1 if ok is None else ok, dev)                 # 0 = at least one rank saw a mismatch
+    skipped = world - int(round(D.sum_over_ranks(0 if ok is None else 1, dev)))
+    mismatch = ok_min == 0 or gather_ok == 0
     if out is not None:
         out["parity_check"] = {"what": "one searched pair per rank vs the CPU oracle, bit for bit", "ranks": world,
-                               "ok": None if ok_all < 0 else bool(ok_all)}
+                               "ranks_checked": world - skipped, "ranks_skipped": skipped,
+                               "ok": False if ok_min == 0 else (True if skipped < world else None)}
         if args.scaling == "strong":
             out["parity_check"]["gathered_checksum_of_last_pair_matches_oracle"] = None if gather_ok is None else bool(gather_ok)
 
@@ -544,6 +566,19 @@ def run_rank(args) -> int:
                 out["end_to_end"] = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
             except Exception as e:
                 out["end_to_end"] = {"error": repr(e)[:300]}
+        if not args.no_legs:
+            # BASELINE configs[2], [3], [4] beside the line (bench_legs.py; fresh process, own oracle spot-checks)
+            import subprocess
+            try:
+                p = subprocess.run([sys.executable, os.path.join(ROOT, "bench_legs.py")], capture_output=True, text=True, timeout=600,
+                                   check=True)
+                legs = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+            except Exception as e:
+                legs = {k: {"error": repr(e)[:300]} for k in ("cfg3_chain", "cfg4", "cfg5_stream")}
+            out.update(legs)
+            for k, v in legs.items():
+                if isinstance(v, dict) and isinstance(v.get("parity_check"), dict) and v["parity_check"].get("ok") is False:
+                    mismatch = True
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(np.ascontiguousarray(frames[:, :, :W]) if stride != W else frames, B, R, args.cpu_seconds)
     if rank == 0:
@@ -553,6 +588,9 @@ def run_rank(args) -> int:
     if D.active():
         import torch.distributed as dist
         dist.destroy_process_group()
+    if mismatch:
+        print(f"[bench] rank {rank}: PARITY MISMATCH against the oracle -- the line above is not a valid measurement", file=sys.stderr)
+        return 3
     return 0
 
 

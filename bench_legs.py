@@ -1,0 +1,288 @@
+#!/usr/bin/env python3
+"""Bounded legs of bench.py for the BASELINE.json configs the headline line is NOT quoted on (N = 1 only; never `value`):
+
+  cfg3_chain   configs[2]: 1080p pair -> 3-level pyramidal LK (hip_lk) -> per-pixel records -> densify 150x84 -> Almeida
+               LSQ on 2,073,600 records; per-stage HIP-event times, chain wall time, rooflines of the two dominant kernels
+               (LK level kernel: f32 VALU operations of the spec; cluster solver: record bytes read once vs HBM);
+  cfg4         configs[3] at one GPU: 4K, 8x8 blocks, +-32, one resident batch of 64 pairs; Mvectors/s and the SAD-unit
+               fraction;
+  cfg5_stream  configs[4]: 1080p@60 over loop-back TCP, SAD + block-motion + Almeida fused per frame
+               (ofps_hip_push_frame); frame received -> island + quaternion on the host, p50 / p99.
+
+Every leg runs its own oracle spot-check AFTER its timed region (the oracle is the checker, never the thing measured).
+bench.py starts this file in a fresh process (`python bench_legs.py`), so the legs see the HIP runtime state of a plugin
+host, and merges the JSON object it prints into the bench line.
+"""
+from __future__ import annotations
+
+import json
+import os
+import socket
+import struct
+import sys
+import threading
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0
+# f32 VALU: 256 CU x 4 SIMD x 32 lanes per clock x 2.4 GHz (one v_add/v_mul/v_fma_f32 per lane; tools/ubench_valu measures
+# 2.5 cycles per wave64 instruction, i.e. 25.6 lanes per clock: the nominal figure is the stricter peak)
+VALU_F32_PEAK_OPS = 256 * 4 * 32 * 2.4e9
+SAD_PEAK = 256 * 4 * 2.4e9 * 64.0                          # |a-b| per second, see bench.py
+LK_SPEC_OPS_PER_TAP = 11                                   # 81 taps x 11 f32 operations per pixel-step (r = 4)
+
+
+def _event_ms(ctx, fn, reps, warm=3):
+    """Average milliseconds of fn() between HIP events on the context's stream."""
+    for _ in range(warm):
+        fn()
+    ctx.sync()
+    ctx.timer_start()
+    for _ in range(reps):
+        fn()
+    return ctx.timer_stop() / reps
+
+
+def cfg3_chain_leg(device: int = 0, reps: int = 30) -> dict:
+    import torch
+    from ofps_amd import synth
+    from ofps_amd.runtime import HipContext
+    W, H, LV, RAD, IT, GW, GH = 1920, 1080, 3, 4, 3, 150, 84
+    fr = synth.luma_sequence(2, W, H, max_step=3, seed=11)
+    ctx = HipContext(device)
+    ctx.use_torch_stream()
+    dfr = torch.from_numpy(fr).cuda()
+    n = W * H
+    d_ent = torch.empty((n, 4), dtype=torch.float32, device="cuda")
+    d_fld = torch.empty((GW * GH, 2), dtype=torch.float32, device="cuda")
+    d_q = torch.empty((1, 4), dtype=torch.float32, device="cuda")
+
+    def lk():
+        ctx.lk_flow_dev(dfr[0].data_ptr(), dfr[1].data_ptr(), W, H, W, LV, RAD, IT, None, d_ent.data_ptr())
+
+    def den():
+        ctx.densify_raster_dev(d_ent.data_ptr(), None, W, H, GW, GH, d_fld.data_ptr())
+
+    def alm():
+        ctx.almeida_dev(d_ent.data_ptr(), n, 1, W / H, 39.6 * H / W, False, 0, 0.05, 0, 0, d_q.data_ptr())
+
+    def chain():
+        lk(); den(); alm()
+    lk_ms = _event_ms(ctx, lk, reps)
+    den_ms = _event_ms(ctx, den, reps)
+    alm_ms = _event_ms(ctx, alm, reps)
+    chain()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        chain()
+    torch.cuda.synchronize()
+    chain_ms = (time.perf_counter() - t0) / reps * 1e3
+    # spec operations of the Gauss-Newton steps over the pyramid (the level kernels; pyramid / gradient / tensor kernels
+    # are not counted as useful work, their time IS in lk_ms)
+    px = sum((W >> l) * (H >> l) for l in range(LV))
+    lk_ops = px * IT * (2 * RAD + 1) ** 2 * LK_SPEC_OPS_PER_TAP
+    out = {"what": "BASELINE configs[2]: 1080p pair -> 3-level LK (r=4, 3 steps) -> 2,073,600 per-pixel records -> densify 150x84 "
+                   "-> Almeida LSQ, device resident",
+           "lk_ms": round(lk_ms, 4), "densify_ms": round(den_ms, 4), "almeida_ms": round(alm_ms, 4), "chain_ms": round(chain_ms, 4),
+           "Mvectors_per_s_chain": round(n / chain_ms / 1e3, 1), "reps": reps,
+           "roofline_lk": {"bound": "valu_f32", "unit": "Tops/s", "spec_ops_per_pair": lk_ops,
+                           "achieved": round(lk_ops / (lk_ms * 1e-3) / 1e12, 3), "peak": round(VALU_F32_PEAK_OPS / 1e12, 2),
+                           "frac": round(lk_ops / (lk_ms * 1e-3) / VALU_F32_PEAK_OPS, 4),
+                           "note": "spec operations of all level steps / the time of the WHOLE lk_flow call (pyramid, gradient, "
+                                   "tensor and hand-over launches included)"},
+           "roofline_almeida": {"bound": "hbm", "unit": "GB/s", "algorithmic_bytes": 16 * n,
+                                "achieved": round(16 * n / (alm_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
+                                "frac": round(16 * n / (alm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                "note": "records read once; the solve is a 30-link dependent chain, not a stream"}}
+    # ---- parity, outside the timed region
+    ent = d_ent.cpu().numpy()
+    q = d_q.cpu().numpy()[0]
+    fld = d_fld.cpu().numpy()
+    ctx.close()
+    try:
+        import oracle
+        flow_o = oracle.lk_flow(fr[0], fr[1], LV, RAD, IT)
+        ent_o = oracle.flow_to_entries(flow_o)
+        thr = min(16, oracle.num_threads())
+        q_o = oracle.solve_ypr_given(ent_o, oracle.camera(W / H, 39.6 * H / W), threads=thr)
+        out["parity_check"] = {"lk_records_bit_exact": bool((ent.view(np.uint32) == ent_o.view(np.uint32)).all()),
+                               "densify_field_bit_exact": bool((fld.view(np.uint32).reshape(-1)
+                                                                == oracle.densify(ent_o, GW, GH).view(np.uint32).reshape(-1)).all()),
+                               "almeida_max_abs_dq": float(np.abs(q - q_o).max()), "almeida_tolerance": 2e-6,
+                               "ok": None}
+        pc = out["parity_check"]
+        pc["ok"] = bool(pc["lk_records_bit_exact"] and pc["densify_field_bit_exact"] and pc["almeida_max_abs_dq"] <= 2e-6)
+    except ImportError as e:
+        out["parity_check"] = {"ok": None, "skipped": str(e)}
+    return out
+
+
+def cfg4_leg(device: int = 0, steps: int = 8, warmup: int = 2) -> dict:
+    import torch
+    from ofps_amd import synth
+    from ofps_amd.runtime import HipContext
+    W, H, B, R, P, G = 3840, 2160, 8, 32, 64, 4
+    nblk = (W // B) * (H // B)
+    gen = synth.luma_sequence(G + 1, W, H, max_step=R, seed=synth.SEED0 + 4)
+    walk = np.abs(((np.arange(P + 1) + G) % (2 * G)) - G)                 # every consecutive pair is a generated pair
+    ctx = HipContext(device)
+    ctx.use_torch_stream()
+    d_frames = torch.from_numpy(gen[walk]).cuda().contiguous()
+    d_out = torch.empty((P, nblk, 4), dtype=torch.float32, device="cuda")
+    d_best = torch.empty((P, nblk, 3), dtype=torch.int32, device="cuda")
+
+    def step(best=False):
+        ctx.sad_flow_dev(d_frames.data_ptr(), P + 1, W, H, W, W * H, 0, B, R, d_out.data_ptr(), d_best.data_ptr() if best else None)
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    launch_ms = _event_ms(ctx, step, steps, warm=0)
+    absd = P * nblk * B * B * (2 * R + 1) ** 2
+    algo = P * (2 * W * H + 16 * nblk)
+    out = {"what": "BASELINE configs[3] on one GPU: 3840x2160, 8x8 blocks, +-32 full search, one resident batch of 64 pairs",
+           "Mvectors_per_s": round(P * nblk * steps / el / 1e6, 2), "ms_per_step": round(el / steps * 1e3, 3),
+           "ms_per_frame_pair": round(el / steps / P * 1e3, 4), "steps": steps, "pairs_per_step": P, "vectors_per_pair": nblk,
+           "kernel": "sad_strip_kernel<8,32>", "launch_ms": round(launch_ms, 3),
+           "valu": {"abs_diffs_per_launch": absd, "achieved_Tops": round(absd / (launch_ms * 1e-3) / 1e12, 2),
+                    "peak_Tops": round(SAD_PEAK / 1e12, 2), "frac": round(absd / (launch_ms * 1e-3) / SAD_PEAK, 4)},
+           "hbm": {"algorithmic_bytes_per_launch": algo, "achieved_GBs": round(algo / (launch_ms * 1e-3) / 1e9, 1),
+                   "frac": round(algo / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}}
+    # ---- parity: an exhaustive search is local, so a block whose +-R window lies inside an aligned crop gets the same
+    # (dx, dy, SAD) from the oracle run on the crop alone (the full 4K pair would take the oracle half a minute)
+    step(best=True)
+    torch.cuda.synchronize()
+    try:
+        import oracle
+        ok = True
+        for k, (cx, cy, cw, ch) in ((0, (0, 0, 256, 160)), (P - 1, (W - 256, H - 160, 256, 160)), (P // 2, (1792, 1000, 256, 160))):
+            best = d_best[k].cpu().numpy().reshape(H // B, W // B, 3)
+            a, b = gen[walk[k]], gen[walk[k + 1]]
+            _, bo = oracle.sad_flow(a[cy:cy + ch, cx:cx + cw], b[cy:cy + ch, cx:cx + cw], B, R, threads=8)
+            bo = bo.reshape(ch // B, cw // B, 3)
+            x_lo = 0 if cx == 0 else R // B; x_hi = cw // B if cx + cw == W else cw // B - R // B
+            y_lo = 0 if cy == 0 else R // B; y_hi = ch // B if cy + ch == H else ch // B - R // B
+            got = best[cy // B + y_lo:cy // B + y_hi, cx // B + x_lo:cx // B + x_hi]
+            ok = ok and bool((got == bo[y_lo:y_hi, x_lo:x_hi]).all())
+        out["parity_check"] = {"what": "three pairs of the batch, blocks of an aligned crop vs the oracle on the crop, (dx, dy, SAD) exact",
+                               "ok": ok}
+    except ImportError as e:
+        out["parity_check"] = {"ok": None, "skipped": str(e)}
+    ctx.close()
+    return out
+
+
+def _recv_exact(sock, n, buf):
+    view = memoryview(buf)[:n]
+    got = 0
+    while got < n:
+        r = sock.recv_into(view[got:], n - got)
+        if r == 0:
+            raise EOFError
+        got += r
+
+
+def cfg5_stream_leg(device: int = 0, frames: int = 330, fps: float = 60.0, use_ransac: bool = False) -> dict:
+    """The feeder thread paces raw luma frames (8-byte header: u32 W, u32 H, then W*H bytes) through a loop-back socket, the
+    way ofps::utils::open_file("tcp://...") feeds a decoder (ofps/src/utils.rs:92-118); latency = frame fully received ->
+    island + quaternion on the host."""
+    from ofps_amd import synth
+    from ofps_amd.runtime import HipContext
+    W, H = 1920, 1080
+    clip = synth.luma_sequence(8, W, H, max_step=16)              # looped
+    srv = socket.socket(); srv.bind(("127.0.0.1", 0)); srv.listen(1)
+    port = srv.getsockname()[1]
+
+    def feeder():
+        c, _ = srv.accept()
+        c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+        t_next = time.perf_counter()
+        for k in range(frames):
+            now = time.perf_counter()
+            if now < t_next:
+                time.sleep(t_next - now)
+            t_next += 1.0 / fps
+            c.sendall(struct.pack("<II", W, H)); c.sendall(clip[k % len(clip)].tobytes())
+        c.close()
+    th = threading.Thread(target=feeder, daemon=True); th.start()
+    sock = socket.create_connection(("127.0.0.1", port))
+    ctx = HipContext(device)
+    pinned = ctx.pinned_frame(H, W)                               # recv_into writes the frame where the DMA engine reads it
+    buf = memoryview(pinned).cast("B")
+    lat, islands, results = [], 0, {}
+    check_at = (frames - 3, frames - 2)                           # frames whose results are compared with the oracle afterwards
+    hdr = bytearray(8)
+    for k in range(frames):
+        _recv_exact(sock, 8, hdr)
+        w, h = struct.unpack("<II", hdr)
+        _recv_exact(sock, w * h, buf)
+        t_arr = time.perf_counter()
+        r = ctx.push_frame(pinned, block=16, search_range=16, aspect=W / H, fov_y_deg=39.6 * H / W, use_ransac=use_ransac, seed=k)
+        t_done = time.perf_counter()
+        if k >= 10:
+            lat.append((t_done - t_arr) * 1e3)
+        islands += r["motion"] is not None
+        if k in check_at:
+            results[k] = r
+    lat = np.array(lat)
+    recov = ctx.almeida_recoveries()
+    ctx.close()
+    out = {"what": f"BASELINE configs[4]: {W}x{H}@{fps:g} over loop-back TCP, 16x16 +-16 SAD + block-motion + almeida "
+                   f"({'RANSAC' if use_ransac else 'LSQ'}) fused per frame; frame received -> island + quaternion on the host",
+           "frames": frames, "measured_frames": int(len(lat)),
+           "latency_ms": {"p50": round(float(np.percentile(lat, 50)), 3), "p90": round(float(np.percentile(lat, 90)), 3),
+                          "p99": round(float(np.percentile(lat, 99)), 3), "max": round(float(lat.max()), 3)},
+           "frame_budget_ms": round(1e3 / fps, 2), "frames_with_motion_island": int(islands),
+           "almeida_in_kernel_recoveries": int(recov)}
+    try:
+        import oracle
+        cam = oracle.camera(W / H, 39.6 * H / W)
+        ok = True
+        worst = 0.0
+        for k, r in results.items():
+            ent_o, _ = oracle.sad_flow(clip[(k - 1) % len(clip)], clip[k % len(clip)], 16, 16, threads=4)
+            q_o = oracle.solve_ypr_given(ent_o, cam) if not use_ransac else oracle.solve_ypr_ransac(ent_o, cam, 200, 0.05, 1000, seed=k)
+            det_o = oracle.detect_motion(ent_o)
+            worst = max(worst, float(np.abs(r["quat"] - q_o).max()))
+            ok = ok and (r["motion"] is None) == (det_o is None) and (det_o is None or r["motion"][0] == det_o[0])
+        tol = 1e-4 if use_ransac else 2e-6
+        out["parity_check"] = {"what": "two streamed frames: island area exact, quaternion vs the oracle on the oracle's vectors",
+                               "max_abs_dq": worst, "tolerance": tol, "ok": bool(ok and worst <= tol)}
+    except ImportError as e:
+        out["parity_check"] = {"ok": None, "skipped": str(e)}
+    return out
+
+
+def all_legs(device: int = 0) -> dict:
+    out = {}
+    for name, fn in (("cfg3_chain", cfg3_chain_leg), ("cfg4", cfg4_leg), ("cfg5_stream", cfg5_stream_leg)):
+        t0 = time.perf_counter()
+        try:
+            out[name] = fn(device)
+        except Exception as e:                                  # a leg is evidence beside the bench line, never the line itself
+            out[name] = {"error": repr(e)[:300]}
+        out[name]["leg_wall_s"] = round(time.perf_counter() - t0, 1)
+    return out
+
+
+if __name__ == "__main__":
+    only = sys.argv[1:] or None
+    legs = {"cfg3_chain": cfg3_chain_leg, "cfg4": cfg4_leg, "cfg5_stream": cfg5_stream_leg}
+    if only:
+        res = {}
+        for nme in only:
+            t0 = time.perf_counter()
+            res[nme] = legs[nme](0)
+            res[nme]["leg_wall_s"] = round(time.perf_counter() - t0, 1)
+    else:
+        res = all_legs(0)
+    print(json.dumps(res), flush=True)

@@ -63,6 +63,14 @@ int   ofps_hip_set_stream(ofps_hip_ctx* ctx, void* hip_stream);
 int   ofps_hip_use_own_stream(ofps_hip_ctx* ctx);
 void* ofps_hip_get_stream(ofps_hip_ctx* ctx);
 int   ofps_hip_sync(ofps_hip_ctx* ctx);
+/* Diagnostic / A-B switches (table in INTEGRATION.md).  `name` is the switch's environment-variable name, e.g.
+ * "OFPS_HIP_ALMEIDA_HIER"; value NULL or "" restores the default.  ofps_hip_init reads the same variables from the
+ * environment ONCE; no other entry point looks at the environment.  The two fault injectors
+ * (OFPS_HIP_ALMEIDA_TEST_FAULT, OFPS_HIP_LK_TEST_FALL) exist only in libofps_hip_testhooks.so (built with
+ * -DOFPS_HIP_TEST_HOOKS, used by the parity tests), can only be armed through this call, and are refused with
+ * OFPS_HIP_EUNSUPPORTED by the product library. */
+int   ofps_hip_set_option(ofps_hip_ctx* ctx, const char* name, const char* value);
+int   ofps_hip_has_test_hooks(void);                         /* 1 in libofps_hip_testhooks.so, 0 in libofps_hip.so */
 
 /* ---- device memory plumbing for hosts without their own HIP binding ---- */
 int ofps_hip_malloc(ofps_hip_ctx* ctx, size_t bytes, void** dptr);
@@ -137,8 +145,8 @@ int ofps_hip_lk_decode(ofps_hip_ctx* ctx, const uint8_t* prev, const uint8_t* cu
                        float* out_entries, size_t* n_out, int* out_w, int* out_h);
 /* The same for a STREAM of frames (cv-decoder keeps its previous gray frame and starts emitting with the second one,
  * cv-decoder/src/lib.rs:142-158): `frame` is uploaded once and is the next call's previous frame.  *have_vectors = 0 for
- * the first frame of a stream -- after ofps_hip_init, ofps_hip_lk_reset, a change of W/H, or an interleaved
- * ofps_hip_lk_decode, which uses the same two device slots. */
+ * the first frame of a stream -- after ofps_hip_init, ofps_hip_lk_reset or a change of W/H.  The stream's two frames
+ * live in device slots of their own: no other entry point of the context disturbs them. */
 int ofps_hip_lk_push_frame(ofps_hip_ctx* ctx, const uint8_t* frame, int W, int H, int stride,
                            int levels, int radius, int iters, int max_w, int max_h, unsigned flags,
                            float* out_entries, size_t* n_out, int* out_w, int* out_h, int* have_vectors);
@@ -189,8 +197,11 @@ int ofps_hip_detect_dev(ofps_hip_ctx* ctx, const void* d_entries, size_t n_per_i
  * thread_rng): callers should advance it per call -- a constant seed samples the same positions every frame -- and
  * in a batched call item b uses seed + b.  Fields of more than 65,536 vectors (per-pixel records) are solved with
  * reciprocal-multiply quotients instead of IEEE division and fused multiply-adds (<= 1 ulp per operation; quaternion
- * within 2e-6 of the exact path).  A quaternion whose w is NaN (device-pointer entry points only) means a cluster launch gave up waiting
- * for workgroups that never became resident; the host-pointer entry point re-solves by itself. */
+ * within 2e-6 of the exact path).  Like the reference's estimator (singular system -> zero step,
+ * almeida-estimator/src/lib.rs:181-185; < 3 inliers -> identity, :246-250) no entry point ever returns NaN: a cluster
+ * launch whose workgroups were not all resident (another process holding CUs) finishes the solve inside the same
+ * launch after its bounded wait (~0.3 s), on every entry point incl. the device-pointer and per-frame ones;
+ * ofps_hip_almeida_recoveries counts how often that happened on this context (diagnostics; synchronises). */
 int ofps_hip_almeida(ofps_hip_ctx* ctx, const float* entries, size_t n,
                      float aspect, float fov_y_deg, int use_ransac, size_t num_iters,
                      float inlier_deg, size_t num_samples, uint64_t seed,
@@ -199,6 +210,7 @@ int ofps_hip_almeida_dev(ofps_hip_ctx* ctx, const void* d_entries, size_t n_per_
                          float aspect, float fov_y_deg, int use_ransac, size_t num_iters,
                          float inlier_deg, size_t num_samples, uint64_t seed,
                          void* d_out_quat /* 4 f32 per item */);
+int ofps_hip_almeida_recoveries(ofps_hip_ctx* ctx, uint64_t* count);
 
 /* ---- fused per-frame path (live streams): decoder -> detector + estimator, vectors stay on the device ----
  * One call per arriving luma frame = one iteration of the reference's worker loops

@@ -27,6 +27,9 @@ PROTOTYPES = {
     "ofps_hip_use_own_stream": (C.c_int, [_ctx]),
     "ofps_hip_get_stream": (_vp, [_ctx]),
     "ofps_hip_sync": (C.c_int, [_ctx]),
+    "ofps_hip_set_option": (C.c_int, [_ctx, C.c_char_p, C.c_char_p]),
+    "ofps_hip_has_test_hooks": (C.c_int, []),
+    "ofps_hip_almeida_recoveries": (C.c_int, [_ctx, C.POINTER(C.c_uint64)]),
     "ofps_hip_malloc": (C.c_int, [_ctx, C.c_size_t, C.POINTER(_vp)]),
     "ofps_hip_free": (C.c_int, [_ctx, _vp]),
     "ofps_hip_memcpy_h2d": (C.c_int, [_ctx, _vp, _vp, C.c_size_t]),
@@ -91,6 +94,8 @@ PROTOTYPES["ofps_hip_push_frame_async"] = (C.c_int, [_ctx, _u8p, C.c_int, C.c_in
 PROTOTYPES["ofps_hip_frame_wait"] = (C.c_int, [_ctx, C.c_int, C.POINTER(FrameResult)])
 
 _lib = None
+_lib_hooks = None
+LIB_HOOKS_PATH = os.path.join(HERE, "libofps_hip_testhooks.so")
 
 
 class OfpsHipError(RuntimeError):
@@ -99,20 +104,15 @@ class OfpsHipError(RuntimeError):
         self.code = code
 
 
-def load():
-    """dlopen libofps_hip.so.  torch (when importable) is imported first so that both share one
-    libamdhip64.so.7 (torch bundles its own copy; the SONAMEs match, the first one loaded wins)."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
-        raise ImportError(f"{LIB_PATH} is missing: run `python -m ofps_amd.build` "
+def _open(path: str):
+    if not os.path.exists(path):
+        raise ImportError(f"{path} is missing: run `python -m ofps_amd.build` "
                           "(or __graft_entry__.build()); there is no CPU fallback")
     try:
         import torch  # noqa: F401  (plumbing only: shares the HIP runtime, streams, distributed)
     except Exception:
         pass
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     missing = []
     for name, (res, args) in PROTOTYPES.items():
         try:
@@ -123,6 +123,24 @@ def load():
         fn.restype = res
         fn.argtypes = args
     if missing:
-        raise ImportError(f"{LIB_PATH} does not export: {', '.join(missing)}")
-    _lib = lib
+        raise ImportError(f"{path} does not export: {', '.join(missing)}")
     return lib
+
+
+def load():
+    """dlopen libofps_hip.so.  torch (when importable) is imported first so that both share one
+    libamdhip64.so.7 (torch bundles its own copy; the SONAMEs match, the first one loaded wins)."""
+    global _lib
+    if _lib is None:
+        _lib = _open(LIB_PATH)
+    return _lib
+
+
+def load_test_hooks():
+    """The same library built with -DOFPS_HIP_TEST_HOOKS: the only build whose fault injectors can be armed
+    (ofps_hip_set_option).  Parity tests only; nothing in the product package loads it."""
+    global _lib_hooks
+    if _lib_hooks is None:
+        _lib_hooks = _open(LIB_HOOKS_PATH)
+        assert _lib_hooks.ofps_hip_has_test_hooks() == 1
+    return _lib_hooks

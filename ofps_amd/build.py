@@ -33,22 +33,44 @@ def _stale(out: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    hdrs = glob.glob(os.path.join(CSRC, "*.hpp")) + glob.glob(os.path.join(HERE, "..", "include", "*.h"))
-    objs = []
-    for src in sources():
-        obj = os.path.join(CSRC, os.path.basename(src)[:-4] + ".o")
-        if force or _stale(obj, [src] + hdrs):
-            cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
-            if verbose:
-                print(" ".join(cmd), file=sys.stderr)
-            subprocess.check_call(cmd)
-        objs.append(obj)
-    if force or _stale(LIB, objs):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-Wl,-rpath,/opt/rocm/lib"]
+# The parity tests' fault injectors (a withheld granule in the cluster Almeida solver, a forced hand-over in the LK level
+# kernel) are compiled only into this second library; the product library refuses to arm them.
+LIB_HOOKS = os.path.join(HERE, "libofps_hip_testhooks.so")
+HOOKED = ("ctx", "almeida", "lk")            # translation units that look at OFPS_HIP_TEST_HOOKS
+
+
+def _compile(src: str, obj: str, extra, force: bool, verbose: bool, hdrs) -> None:
+    if force or _stale(obj, [src] + hdrs):
+        cmd = [HIPCC] + FLAGS + list(extra) + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)
+
+
+def _link(lib: str, objs, force: bool, verbose: bool) -> None:
+    if force or _stale(lib, objs):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs + ["-Wl,-rpath,/opt/rocm/lib"]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    hdrs = glob.glob(os.path.join(CSRC, "*.hpp")) + glob.glob(os.path.join(HERE, "..", "include", "*.h"))
+    objs, objs_hooks = [], []
+    for src in sources():
+        stem = os.path.basename(src)[:-4]
+        obj = os.path.join(CSRC, stem + ".o")
+        _compile(src, obj, [], force, verbose, hdrs)
+        objs.append(obj)
+        if stem in HOOKED:
+            obj_h = os.path.join(CSRC, stem + ".hooks.o")
+            _compile(src, obj_h, ["-DOFPS_HIP_TEST_HOOKS"], force, verbose, hdrs)
+            objs_hooks.append(obj_h)
+        else:
+            objs_hooks.append(obj)
+    _link(LIB, objs, force, verbose)
+    _link(LIB_HOOKS, objs_hooks, force, verbose)
     return LIB
 
 

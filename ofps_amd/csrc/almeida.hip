@@ -736,8 +736,8 @@ __global__ __launch_bounds__(1024) void almeida_lsq_step_kernel(const float4* __
 // one step ahead of the slowest, so it never overwrites a granule somebody still has to read.  Tags = tag_base + step
 // + 1 with a per-call tag_base (the buffer is zeroed when allocated, never between calls).  Every spin is bounded: on
 // a timeout (the workgroups were not co-resident, e.g. another process holds CUs with a persistent kernel of its
-// own) the kernel writes a NaN quaternion and returns; the host-pointer entry point then re-solves with the
-// launch-per-step kernel.
+// own) the workgroups leave the step loop and the last one to leave solves the item alone (almeida_solo_solve):
+// no caller ever sees a NaN.
 // A granule = ONE naturally aligned 16-byte write-through (sc0 sc1) store of three f32 sums.  Each 8-byte half carries
 // the step's 16-bit tag, so a reader accepts a granule only when both halves belong to the step it waits for -- correct
 // even if the two halves of the store became visible separately (not observed on gfx950, not an architectural promise
@@ -781,8 +781,22 @@ __device__ __forceinline__ void gran_load3_local(const gran_u4* p0, gran_u4& x) 
 
 constexpr unsigned kSpinLimit = 1u << 18;            // ~0.3 s of polling before giving up
 
+// The item's fail word (holds the launch's tag once a workgroup's spin expired; see almeida_solo_solve).  Pollers look at
+// it every 256th poll, so that workgroups which only became resident after the first ones left do not sit out a
+// timeout of their own.
+struct FailFlag { uint32_t* p; uint32_t tag; };
+__device__ __forceinline__ bool fail_flag_up(const FailFlag& f) {
+    uint32_t v;
+    asm volatile("global_load_dword %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(f.p) : "memory");
+    return v == f.tag;
+}
+__device__ __forceinline__ bool spin_expired(unsigned spins, const FailFlag& f) {
+    if (spins >= kSpinLimit) return true;
+    return (spins & 255u) == 255u && fail_flag_up(f);
+}
+
 // same-XCD form of gran_sweep_sum3 for at most 64 granules
-__device__ __forceinline__ bool gran_sweep_sum3_local(const gran_u4* g, int count, uint32_t tag16, float& ta, float& tb, float& tc) {
+__device__ __forceinline__ bool gran_sweep_sum3_local(const gran_u4* g, int count, uint32_t tag16, const FailFlag& ff, float& ta, float& tb, float& tc) {
     const int lane = threadIdx.x & 63;
     const gran_u4* p = g + (lane < count ? lane : count - 1);
     gran_u4 x;
@@ -790,7 +804,7 @@ __device__ __forceinline__ bool gran_sweep_sum3_local(const gran_u4* g, int coun
         gran_load3_local(p, x);
         const bool ok = (x.y >> 16) == tag16 && (x.w >> 16) == tag16;
         if (__all(ok)) break;
-        if (spins >= kSpinLimit) return false;
+        if (spin_expired(spins, ff)) return false;
         __builtin_amdgcn_s_sleep(1);
     }
     const bool in = lane < count;
@@ -801,7 +815,7 @@ __device__ __forceinline__ bool gran_sweep_sum3_local(const gran_u4* g, int coun
 }
 // every workgroup's XCC_ID, published once per launch: all workgroups read all of them and reach the same verdict on
 // whether workgroup b runs on XCD b % 8 (round-robin dispatch), the premise of the two-level gather.  false = timed out.
-__device__ __forceinline__ bool xcc_sweep_check(const uint32_t* xccs, int nblk, uint32_t tag16, bool& round_robin) {
+__device__ __forceinline__ bool xcc_sweep_check(const uint32_t* xccs, int nblk, uint32_t tag16, const FailFlag& ff, bool& round_robin) {
     const int lane = threadIdx.x & 63;
     bool rr = true;
     for (int j0 = 0; j0 < nblk; j0 += 64) {
@@ -810,7 +824,7 @@ __device__ __forceinline__ bool xcc_sweep_check(const uint32_t* xccs, int nblk, 
         for (unsigned spins = 0;; ++spins) {
             asm volatile("global_load_dword %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(xccs + idx) : "memory");
             if (__all((v >> 16) == tag16)) break;
-            if (spins >= kSpinLimit) return false;
+            if (spin_expired(spins, ff)) return false;
             __builtin_amdgcn_s_sleep(1);
         }
         rr = rr && ((int)(v & 0xFFu) == (idx & 7));
@@ -821,7 +835,7 @@ __device__ __forceinline__ bool xcc_sweep_check(const uint32_t* xccs, int nblk, 
 
 // wave-wide: component sums over the nblk (<= 256) granules of one triple once all carry `tag16`; fixed order
 // (lane-strided, then the DPP tree), identical in every workgroup.  false = timed out.
-__device__ __forceinline__ bool gran_sweep_sum3(const gran_u4* g, int nblk, uint32_t tag16, float& ta, float& tb, float& tc) {
+__device__ __forceinline__ bool gran_sweep_sum3(const gran_u4* g, int nblk, uint32_t tag16, const FailFlag& ff, float& ta, float& tb, float& tc) {
     const int lane = threadIdx.x & 63;
     const int last = nblk - 1;
     const gran_u4* p[4];
@@ -837,7 +851,7 @@ __device__ __forceinline__ bool gran_sweep_sum3(const gran_u4* g, int nblk, uint
         for (int j = 0; j < 4; ++j)
             if (64 * j < nblk) ok = ok && (x[j].y >> 16) == tag16 && (x[j].w >> 16) == tag16;
         if (__all(ok)) break;
-        if (spins >= kSpinLimit) return false;
+        if (spin_expired(spins, ff)) return false;
         __builtin_amdgcn_s_sleep(1);
     }
     float va[4], vb[4], vc[4];
@@ -854,18 +868,80 @@ __device__ __forceinline__ bool gran_sweep_sum3(const gran_u4* g, int nblk, uint
     return true;
 }
 
+// ---- what a cluster launch does when its workgroups were NOT all there (bounded spin expired): the reference's
+// estimator cannot fail (singular LU -> zero step, almeida-estimator/src/lib.rs:181-185; < 3 inliers -> identity,
+// :246-250), so neither may this one, on ANY entry point -- device-pointer callers never synchronise, so the recovery
+// cannot live on the host.  A workgroup whose spin expired swaps the launch's tag into the item's fail word; the FIRST
+// one to do so (the swap returns something else) solves the item alone, right away, from the records in memory -- it
+// needs nothing from the others: 30 passes over all N records by one workgroup (milliseconds; after a 0.3 s stall nobody
+// counts them).  Everybody else who gives up, or sees the word while polling, just leaves.  The path that completes
+// pays nothing for this: no atomics, no extra barrier.  Same operations per record as the launch-per-step kernel (no
+// folded delta), fixed summation order: inside the 2e-6 parity bound like every other path.  (A spin that expires in
+// the LAST step while other workgroups still complete it leaves two writers of the same estimate -- the solo result
+// and the cluster's, equal to rounding; whichever lands last stays.)
+template <bool FAST, int BLOCK>
+__device__ __forceinline__ void almeida_solo_solve(const float4* __restrict__ ent, size_t n, const Camera& cam, float (*red)[9],
+                                                   Quat* rot_sh, float4* __restrict__ out) {
+    float eps = almeida_eps();
+    asm volatile("" : "+v"(eps));        // opaque: keeps the compiler from sharing the prototype matrices with the caller's step
+                                         // loop, which would keep 27 registers alive through it for this cold path
+    const Mat3 mroll = mat3_from_euler(0.0f, eps, 0.0f);
+    const Mat3 mpitch = mat3_from_euler(eps, 0.0f, 0.0f);
+    const Mat3 myaw = mat3_from_euler(0.0f, 0.0f, -eps);
+    Quat rotation = {1.0f, 0.0f, 0.0f, 0.0f};
+    for (int it = 0; it < kIters; ++it) {
+        const float alpha = (it == kIters - 1) ? 1.0f : 0.5f;
+        const Mat3 rotm = quat_to_mat3(rotation);
+        float s[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll 1
+        for (size_t i = threadIdx.x; i < n; i += BLOCK) {
+            const float4 e = ent[i];
+            const Unproj un = cam_unproject<FAST>(cam, e.x, e.y);
+            const float2 d = cam_delta_w<FAST>(cam, e.x, e.y, un, rotm);
+            const float2 pr = cam_delta_w<FAST>(cam, e.x, e.y, un, mroll);
+            const float2 pp = cam_delta_w<FAST>(cam, e.x, e.y, un, mpitch);
+            const float2 py = cam_delta_w<FAST>(cam, e.x, e.y, un, myaw);
+            const float rx = e.z - d.x, ry = e.w - d.y;
+            s[0] += pr.x * pr.x + pr.y * pr.y;
+            s[1] += pr.x * pp.x + pr.y * pp.y;
+            s[2] += pr.x * py.x + pr.y * py.y;
+            s[3] += pp.x * pp.x + pp.y * pp.y;
+            s[4] += pp.x * py.x + pp.y * py.y;
+            s[5] += py.x * py.x + py.y * py.y;
+            s[6] += pr.x * rx + pr.y * ry;
+            s[7] += pp.x * rx + pp.y * ry;
+            s[8] += py.x * rx + py.y * ry;
+        }
+        block_sum9(s, red);
+        if (threadIdx.x == 0) rot_sh[it & 1] = almeida_update(rotation, s, eps, alpha);
+        __syncthreads();
+        rotation = rot_sh[it & 1];
+    }
+    if (threadIdx.x == 0) *out = make_float4(rotation.w, -rotation.i, -rotation.j, -rotation.k);   // :199
+}
+
 constexpr int kXcdSlots = 32;                 // workgroups per XCD at most (256 / 8)
 constexpr int kHierMinBlocks = 32;            // below this the flat gather is as fast
-// granules per item: the flat exchange, the per-XCD partials and sums, the XCC_ID table (256 dwords = 64 granules)
-__host__ __device__ inline size_t cluster_gran_per_item(int nblk) { return 6 * (size_t)nblk + 2 * 8 * kXcdSlots + 2 * 8 + 64; }
+// granules per item: the flat exchange, the per-XCD partials and sums, the XCC_ID table (256 dwords = 64 granules), the
+// status word (one granule of its own)
+__host__ __device__ inline size_t cluster_gran_per_item(int nblk) { return 6 * (size_t)nblk + 2 * 8 * kXcdSlots + 2 * 8 + 64 + 1; }
+
+#ifdef OFPS_HIP_TEST_HOOKS
+#define OFPS_TEST_FAULT(x) (x)
+#else
+#define OFPS_TEST_FAULT(x) 0u          /* the fault injector does not exist in the product library */
+#endif
 
 template <bool FAST, int EPT, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void almeida_lsq_cluster_kernel(const float4* __restrict__ entries, size_t n, Camera cam,
                                                                    const DeltaConsts dk, gran_u4* gran, uint32_t tag_base,
                                                                    float4* __restrict__ out_quat,
-                                                                   unsigned long long* __restrict__ prof, uint32_t fault, int hier_mode) {
-    // fault (tests only, normally 0): workgroup fault-1 withholds its step-3 granule, which is what a workgroup that
-    // never became resident looks like to the others -- exercises the timeout and the host's re-solve
+                                                                   unsigned long long* __restrict__ prof, uint32_t fault_arg, int hier_mode,
+                                                                   unsigned long long* __restrict__ recoveries) {
+    // fault (libofps_hip_testhooks.so only; compiled out of the product library): workgroup fault-1 withholds its step-3
+    // granule, which is what a workgroup that never became resident looks like to the others -- exercises the timeout
+    // and the in-kernel recovery (almeida_solo_solve)
+    const uint32_t fault = OFPS_TEST_FAULT(fault_arg);
     // prof (diagnostics, normally null): thread 0 of every workgroup stamps s_memtime at the phase boundaries of each step
 #define OFPS_STAMP(slot) do { if (prof && threadIdx.x == 0) prof[(((size_t)blockIdx.y * gridDim.x + blockIdx.x) * kIters + it) * kProfSlots + (slot)] = __builtin_readcyclecounter(); } while (0)
 #define OFPS_STAMP_W2(slot) do { if (prof && threadIdx.x == 128) prof[(((size_t)blockIdx.y * gridDim.x + blockIdx.x) * kIters + it) * kProfSlots + (slot)] = __builtin_readcyclecounter(); } while (0)
@@ -876,6 +952,7 @@ __global__ __launch_bounds__(BLOCK) void almeida_lsq_cluster_kernel(const float4
     __shared__ Quat rot_sh[2];
     __shared__ DeltaAffine aff_sh[2];                   // dense regime: the folded camera + rotation of rot_sh[], same slots
     __shared__ int fail_sh;
+    __shared__ struct { const float4* entries; size_t n; float4* out; unsigned long long* recoveries; uint32_t* flag; uint32_t tag; Camera cam; } cold_sh;   // what the recovery path needs, parked
     __shared__ int hier_sh;                             // steps >= 1 gather in two levels (per XCD through its L2, then across)
     __shared__ Lu3 lu_sh;                               // factorisation of the folded A, made in step 0 by the updating wave
     __shared__ float4 plds[P_LDS ? EPT * BLOCK : 1];     // (roll.x, roll.y, pitch.x, pitch.y) per record
@@ -885,6 +962,9 @@ __global__ __launch_bounds__(BLOCK) void almeida_lsq_cluster_kernel(const float4
     gran_u4* xl = g + 6 * (size_t)nblk;                                // [parity][XCD][rank in XCD]: per-XCD partials (same-XCD readers)
     gran_u4* xg = xl + 2 * 8 * kXcdSlots;                              // [parity][XCD]: per-XCD sums (every reader)
     uint32_t* xccs = reinterpret_cast<uint32_t*>(xg + 2 * 8);          // [workgroup]: tag << 16 | XCC_ID
+    // the item's fail word (a granule of its own) and this launch's value for it: unique per launch until the tags wrap
+    // (the buffer is re-zeroed then)
+    const FailFlag ff = {reinterpret_cast<uint32_t*>(xg + 2 * 8 + 64), (tag_base + 1u) | 0x80000000u};
     const int xcd = blk & 7, xrank = blk >> 3;                         // where round-robin dispatch puts this workgroup
     const int xmembers = (nblk - xcd + 7) / 8, nxcd = nblk < 8 ? nblk : 8;
     const float eps = almeida_eps();
@@ -902,6 +982,8 @@ __global__ __launch_bounds__(BLOCK) void almeida_lsq_cluster_kernel(const float4
     float s[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (threadIdx.x == 0) {                              // slot 1 = rotation entering step 0
         fail_sh = 0; hier_sh = 0; rot_sh[1] = Quat{1.0f, 0.0f, 0.0f, 0.0f};
+        cold_sh.entries = entries + item * n; cold_sh.n = n; cold_sh.cam = cam; cold_sh.out = out_quat + item;
+        cold_sh.recoveries = recoveries; cold_sh.flag = ff.p; cold_sh.tag = ff.tag;
         if (hier_mode) {
             const uint32_t me = (((tag_base + 1u) & 0xFFFFu) << 16) | ((uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xFFu);   // HW_REG_XCC_ID
             asm volatile("global_store_dword %0, %1, off sc0 sc1" :: "v"(xccs + blk), "v"(me) : "memory");
@@ -1006,15 +1088,15 @@ __global__ __launch_bounds__(BLOCK) void almeida_lsq_cluster_kernel(const float4
         if (hier) {
             if (xrank == 0 && wave == 3) {
                 float la = 0.0f, lb = 0.0f, lc = 0.0f;
-                const bool lgot = gran_sweep_sum3_local(xl + ((size_t)(it & 1) * 8 + xcd) * kXcdSlots, xmembers, tag, la, lb, lc);
+                const bool lgot = gran_sweep_sum3_local(xl + ((size_t)(it & 1) * 8 + xcd) * kXcdSlots, xmembers, tag, ff, la, lb, lc);
                 if (lane == 0) {
                     if (lgot) gran_store3(xg + (size_t)(it & 1) * 8 + xcd, tag, la, lb, lc);
                     else fail_sh = 1;
                 }
             }
-            if (wave == 2) got = gran_sweep_sum3(xg + (size_t)(it & 1) * 8, nxcd, tag, ta, tb, tc);
+            if (wave == 2) got = gran_sweep_sum3(xg + (size_t)(it & 1) * 8, nxcd, tag, ff, ta, tb, tc);
         } else if (wave < 3 && (wave == 2 || it == 0)) {
-            got = gran_sweep_sum3(gp + (size_t)wave * nblk, nblk, tag, ta, tb, tc);
+            got = gran_sweep_sum3(gp + (size_t)wave * nblk, nblk, tag, ff, ta, tb, tc);
         }
         if (it == 0) {
             if (wave < 2 && lane == 0) {
@@ -1023,7 +1105,7 @@ __global__ __launch_bounds__(BLOCK) void almeida_lsq_cluster_kernel(const float4
             }
             if (wave == 3 && hier_mode) {               // does workgroup b sit on XCD b % 8?  every workgroup reaches the same verdict
                 bool rr = false;
-                const bool xgot = xcc_sweep_check(xccs, nblk, tag, rr);
+                const bool xgot = xcc_sweep_check(xccs, nblk, tag, ff, rr);
                 if (lane == 0) {
                     if (!xgot) fail_sh = 1;
                     else hier_sh = rr ? 1 : 0;
@@ -1055,16 +1137,27 @@ __global__ __launch_bounds__(BLOCK) void almeida_lsq_cluster_kernel(const float4
             }
         }
         __syncthreads();
-        if (fail_sh) {
-            if (threadIdx.x == 0) out_quat[item] = make_float4(__builtin_nanf(""), 0.0f, 0.0f, 0.0f);
-            return;
-        }
+        if (fail_sh) break;                              // a bounded spin expired somewhere in this workgroup
         OFPS_STAMP(4);
     }
-    const Quat rotation = rot_sh[(kIters - 1) & 1];
 #undef OFPS_STAMP
 #undef OFPS_STAMP_W2
-    if (blk == 0 && threadIdx.x == 0) out_quat[item] = make_float4(rotation.w, -rotation.i, -rotation.j, -rotation.k);  // :199
+    if (!fail_sh) {
+        const Quat rotation = rot_sh[(kIters - 1) & 1];
+        if (blk == 0 && threadIdx.x == 0) out_quat[item] = make_float4(rotation.w, -rotation.i, -rotation.j, -rotation.k);  // :199
+        return;
+    }
+    // ---- a spin expired: see almeida_solo_solve.  Everything this path needs was parked in LDS by the prologue, so
+    // the step loop above carries no state for it.
+    __shared__ int solo_sh;
+    if (threadIdx.x == 0) {
+        const uint32_t old = __hip_atomic_exchange(cold_sh.flag, cold_sh.tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        solo_sh = old != cold_sh.tag;
+        if (solo_sh && cold_sh.recoveries) atomicAdd(cold_sh.recoveries, 1ull);
+    }
+    __syncthreads();
+    if (!solo_sh) return;
+    almeida_solo_solve<FAST, BLOCK>(cold_sh.entries, cold_sh.n, cold_sh.cam, red, rot_sh, cold_sh.out);
 }
 
 // ---- RANSAC sampler: must stay bit-identical to orc_sample_index (oracle/ofps_oracle.c)
@@ -1290,16 +1383,14 @@ struct ClusterGate {
 static ClusterGate g_cluster_gate;
 
 template <bool FAST, int EPT, int BLOCK = 1024>
-static void launch_cluster(hipStream_t s, int nblk, int items, const float4* d_entries, size_t n, const Camera& cam,
-                           gran_u4* gran, uint32_t tag_base, float4* d_quat, unsigned long long* prof) {
-    uint32_t fault = 0;
-    if (const char* f = getenv("OFPS_HIP_ALMEIDA_TEST_FAULT")) fault = (uint32_t)atoi(f);     // tests only
-    int hier_mode = 1;                                        // 0 never, 1 when it pays (>= kHierMinBlocks workgroups), 2 always (A/B, tests)
-    if (const char* f = getenv("OFPS_HIP_ALMEIDA_HIER")) hier_mode = atoi(f);
+static void launch_cluster(ofps_hip_ctx* ctx, hipStream_t s, int nblk, int items, const float4* d_entries, size_t n, const Camera& cam,
+                           gran_u4* gran, uint32_t tag_base, float4* d_quat, unsigned long long* prof, unsigned long long* recoveries) {
+    const uint32_t fault = (uint32_t)ctx->opt.test_almeida_fault;   // always 0 in the product library (ofps_hip_set_option refuses it)
+    int hier_mode = ctx->opt.almeida_hier;                    // 0 never, 1 when it pays (>= kHierMinBlocks workgroups), 2 always (A/B, tests)
     if (hier_mode == 1 && nblk < kHierMinBlocks) hier_mode = 0;     // few workgroups: the flat gather is as fast and needs no XCC_ID round
     hipLaunchKernelGGL((almeida_lsq_cluster_kernel<FAST, EPT, BLOCK>), dim3(nblk, items), dim3(BLOCK), 0, s, d_entries, n, cam,
                        delta_consts(cam), gran,
-                       tag_base, d_quat, prof, fault, hier_mode);
+                       tag_base, d_quat, prof, fault, hier_mode, recoveries);
 }
 
 // -> 1 launched, 0 not applicable (caller falls back to the launch-per-step kernel), < 0 error
@@ -1324,8 +1415,8 @@ static int lsq_cluster(ofps_hip_ctx* ctx, const float4* d_entries, size_t n, int
     // to 1.3k cycles per step but the gather waits that much longer: a step ends one cross-XCD exchange after the LAST
     // workgroup published, 0.104 vs 0.105 ms at 8,040 vectors; OFPS_HIP_ALMEIDA_BLOCK=256 keeps the variant for A/B runs)
     int block = 1024;
-    if (const char* f = getenv("OFPS_HIP_ALMEIDA_EPT")) { const int v = atoi(f); if (v == 1 || v == 2 || v == 4 || v == 8) ept = v; }   // A/B
-    if (const char* f = getenv("OFPS_HIP_ALMEIDA_BLOCK")) { const int v = atoi(f); if (v == 256 || v == 1024) block = v; }              // A/B
+    if (ctx->opt.almeida_ept) ept = ctx->opt.almeida_ept;            // A/B (OFPS_HIP_ALMEIDA_EPT)
+    if (ctx->opt.almeida_block) block = ctx->opt.almeida_block;      // A/B (OFPS_HIP_ALMEIDA_BLOCK)
     if (block == 256 && ept > 2) ept = 2;
     const size_t per_wg = (size_t)ept * block;
     const size_t nblk_sz = (n + per_wg - 1) / per_wg;
@@ -1333,22 +1424,29 @@ static int lsq_cluster(ofps_hip_ctx* ctx, const float4* d_entries, size_t n, int
     const int nblk = (int)nblk_sz;
     const int per_launch = ctx->num_cus / nblk;              // items whose workgroups are all co-resident (1 per CU)
     bool dense = n > 65536;                                  // per-pixel regime: reciprocal-multiply quotients, see fdiv
-    if (const char* f = getenv("OFPS_HIP_ALMEIDA_FAST")) dense = atoi(f) != 0;                  // A/B
+    if (ctx->opt.almeida_fast >= 0) dense = ctx->opt.almeida_fast != 0;                        // A/B (OFPS_HIP_ALMEIDA_FAST)
     const size_t gran_bytes = (size_t)per_launch * cluster_gran_per_item(nblk) * sizeof(gran_u4);
     auto* gran = static_cast<gran_u4*>(scratch(ctx, S_GRAN, gran_bytes));
     if (!gran) return OFPS_HIP_ENOMEM;
     hipStream_t s = ctx->stream;
     unsigned long long* prof = nullptr;
-    if (getenv("OFPS_HIP_ALMEIDA_PROF")) {
+    if (ctx->opt.almeida_prof) {
         prof = static_cast<unsigned long long*>(scratch(ctx, S_ALM_PROF, (size_t)per_launch * nblk * kIters * kProfSlots * sizeof(unsigned long long)));
         if (!prof) return OFPS_HIP_ENOMEM;
     }
+    // how many launches of this context had to be finished by almeida_solo_solve (ofps_hip_almeida_recoveries)
+    const bool fresh_counter = ctx->scratch[S_ALM_RECOVER].p == nullptr;
+    auto* recoveries = static_cast<unsigned long long*>(scratch(ctx, S_ALM_RECOVER, sizeof(unsigned long long)));
+    if (!recoveries) return OFPS_HIP_ENOMEM;
+    if (fresh_counter) OFPS_HIP_TRY(ctx, hipMemsetAsync(recoveries, 0, sizeof(unsigned long long), s));
     const size_t cap = ctx->scratch[S_GRAN].cap;
     for (int b0 = 0; b0 < batch; b0 += per_launch) {
         const int items = batch - b0 < per_launch ? batch - b0 : per_launch;
-        if (ctx->gran_zeroed != gran || ctx->gran_tag_base > 0xFF00u) {        // 16-bit tags: re-zero before they wrap
+        // zeroed once per ALLOCATION (the generation counts them: a regrown buffer may come back at the old address with
+        // a tail nobody zeroed) and before the 16-bit tags wrap
+        if (ctx->gran_zeroed_gen != ctx->scratch[S_GRAN].gen || ctx->gran_tag_base > 0xFF00u) {
             OFPS_HIP_TRY(ctx, hipMemsetAsync(gran, 0, cap, s));
-            ctx->gran_zeroed = gran; ctx->gran_tag_base = 0;
+            ctx->gran_zeroed_gen = ctx->scratch[S_GRAN].gen; ctx->gran_tag_base = 0;
         }
         const uint32_t tag_base = ctx->gran_tag_base;
         ctx->gran_tag_base += 32;
@@ -1360,16 +1458,16 @@ static int lsq_cluster(ofps_hip_ctx* ctx, const float4* d_entries, size_t n, int
         if (!ev) OFPS_HIP_TRY(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
         else if (last != s) OFPS_HIP_TRY(ctx, hipStreamWaitEvent(s, ev, 0));      // (a barrier packet costs ~4 us in front of the kernel)
         last = s;
-        if (block == 256 && ept == 2) launch_cluster<false, 2, 256>(s, nblk, items, ent, n, cam, gran, tag_base, q, prof);
-        else if (block == 256) launch_cluster<false, 1, 256>(s, nblk, items, ent, n, cam, gran, tag_base, q, prof);
-        else if (dense && ept == 8) launch_cluster<true, 8>(s, nblk, items, ent, n, cam, gran, tag_base, q, prof);
-        else if (dense && ept == 4) launch_cluster<true, 4>(s, nblk, items, ent, n, cam, gran, tag_base, q, prof);
-        else if (dense && ept == 2) launch_cluster<true, 2>(s, nblk, items, ent, n, cam, gran, tag_base, q, prof);
-        else if (dense) launch_cluster<true, 1>(s, nblk, items, ent, n, cam, gran, tag_base, q, prof);
-        else if (ept == 8) launch_cluster<false, 8>(s, nblk, items, ent, n, cam, gran, tag_base, q, prof);
-        else if (ept == 4) launch_cluster<false, 4>(s, nblk, items, ent, n, cam, gran, tag_base, q, prof);
-        else if (ept == 2) launch_cluster<false, 2>(s, nblk, items, ent, n, cam, gran, tag_base, q, prof);
-        else launch_cluster<false, 1>(s, nblk, items, ent, n, cam, gran, tag_base, q, prof);
+        if (block == 256 && ept == 2) launch_cluster<false, 2, 256>(ctx, s, nblk, items, ent, n, cam, gran, tag_base, q, prof, recoveries);
+        else if (block == 256) launch_cluster<false, 1, 256>(ctx, s, nblk, items, ent, n, cam, gran, tag_base, q, prof, recoveries);
+        else if (dense && ept == 8) launch_cluster<true, 8>(ctx, s, nblk, items, ent, n, cam, gran, tag_base, q, prof, recoveries);
+        else if (dense && ept == 4) launch_cluster<true, 4>(ctx, s, nblk, items, ent, n, cam, gran, tag_base, q, prof, recoveries);
+        else if (dense && ept == 2) launch_cluster<true, 2>(ctx, s, nblk, items, ent, n, cam, gran, tag_base, q, prof, recoveries);
+        else if (dense) launch_cluster<true, 1>(ctx, s, nblk, items, ent, n, cam, gran, tag_base, q, prof, recoveries);
+        else if (ept == 8) launch_cluster<false, 8>(ctx, s, nblk, items, ent, n, cam, gran, tag_base, q, prof, recoveries);
+        else if (ept == 4) launch_cluster<false, 4>(ctx, s, nblk, items, ent, n, cam, gran, tag_base, q, prof, recoveries);
+        else if (ept == 2) launch_cluster<false, 2>(ctx, s, nblk, items, ent, n, cam, gran, tag_base, q, prof, recoveries);
+        else launch_cluster<false, 1>(ctx, s, nblk, items, ent, n, cam, gran, tag_base, q, prof, recoveries);
         OFPS_HIP_TRY(ctx, hipGetLastError());
         OFPS_HIP_TRY(ctx, hipEventRecord(ev, s));
     }
@@ -1423,9 +1521,8 @@ static int lsq_stepped(ofps_hip_ctx* ctx, const float4* d_entries, size_t n_max,
     return OFPS_HIP_OK;
 }
 
-// allow_cluster = false: the caller is re-solving after a cluster launch timed out
 static int lsq_device(ofps_hip_ctx* ctx, const float4* d_entries, size_t stride, size_t n_max, const uint32_t* d_n,
-                      uint32_t min_n, int batch, const Camera& cam, float4* d_quat, bool allow_cluster = true) {
+                      uint32_t min_n, int batch, const Camera& cam, float4* d_quat) {
     hipStream_t s = ctx->stream;
     // One-workgroup solver: one launch, 30 steps at 2.5-6 us each on a single CU (0.076 ms at N = 576, 0.185 ms at
     // N = 8,040, flat up to 256 items) -- the path for batches of block-vector sized problems and mandatory when the
@@ -1433,13 +1530,11 @@ static int lsq_device(ofps_hip_ctx* ctx, const float4* d_entries, size_t stride,
     // the cluster solver (one launch, granule exchange between co-resident workgroups); what it cannot hold
     // (N > 256 x 8192) or a forced A/B run takes one launch per step.
     bool wg_path = n_max <= 8192;
-    bool cluster = allow_cluster && d_n == nullptr && stride == n_max;
+    bool cluster = d_n == nullptr && stride == n_max;
     size_t cluster_min = batch == 1 ? 4096 : 8192;                       // lone problems above this size use the cluster
-    if (const char* force = getenv("OFPS_HIP_ALMEIDA_PATH")) {          // A/B experiments only
-        if (!strcmp(force, "step") && d_n == nullptr) { wg_path = false; cluster = false; }
-        if (!strcmp(force, "wg")) cluster = false;
-        if (!strcmp(force, "cluster")) cluster_min = 0;
-    }
+    if (ctx->opt.almeida_path == 1 && d_n == nullptr) { wg_path = false; cluster = false; }   // A/B experiments only (OFPS_HIP_ALMEIDA_PATH)
+    if (ctx->opt.almeida_path == 2) cluster = false;
+    if (ctx->opt.almeida_path == 3) cluster_min = 0;
     if (cluster && n_max > cluster_min && n_max > 0) {
         const int rc = lsq_cluster(ctx, d_entries, n_max, batch, cam, d_quat);
         if (rc != 0) return rc < 0 ? rc : OFPS_HIP_OK;
@@ -1459,13 +1554,13 @@ static int lsq_device(ofps_hip_ctx* ctx, const float4* d_entries, size_t stride,
 
 int almeida_device(ofps_hip_ctx* ctx, const float4* d_entries, size_t n, int batch, float aspect, float fov_y_deg,
                           int use_ransac, size_t num_iters, float inlier_deg, size_t num_samples, uint64_t seed,
-                          float4* d_quat, bool allow_cluster) {
+                          float4* d_quat) {
     OFPS_REQUIRE(ctx, batch >= 1 && batch <= 65535, "almeida: batch %d out of range", batch);
     OFPS_REQUIRE(ctx, n < (1ull << 31), "almeida: too many entries");
     OFPS_REQUIRE(ctx, aspect > 0.0f && fov_y_deg > 0.0f && fov_y_deg < 180.0f, "almeida: bad camera (aspect=%g fov_y=%g)",
                  (double)aspect, (double)fov_y_deg);
     const Camera cam = camera_new(aspect, fov_y_deg);
-    if (!use_ransac) return lsq_device(ctx, d_entries, n, n, nullptr, 0, batch, cam, d_quat, allow_cluster);
+    if (!use_ransac) return lsq_device(ctx, d_entries, n, n, nullptr, 0, batch, cam, d_quat);
 
     OFPS_REQUIRE(ctx, num_iters >= 1 && num_iters <= 65535, "almeida: ransac iters %zu out of range", num_iters);
     OFPS_REQUIRE(ctx, num_samples >= 1, "almeida: ransac samples must be >= 1");
@@ -1502,7 +1597,7 @@ int almeida_device(ofps_hip_ctx* ctx, const float4* d_entries, size_t n, int bat
         OFPS_HIP_TRY(ctx, hipStreamSynchronize(s));
         int rc;
         if (cnt <= 8192) rc = lsq_device(ctx, sel + (size_t)b * cap, cap, cnt < 1 ? 1 : cnt, sel_n + b, 3, 1, cam, d_quat + b);
-        else rc = lsq_device(ctx, sel + (size_t)b * cap, cnt, cnt, nullptr, 0, 1, cam, d_quat + b, allow_cluster);
+        else rc = lsq_device(ctx, sel + (size_t)b * cap, cnt, cnt, nullptr, 0, 1, cam, d_quat + b);
         if (rc != OFPS_HIP_OK) return rc;
     }
     return OFPS_HIP_OK;
@@ -1537,15 +1632,6 @@ int ofps_hip_almeida(ofps_hip_ctx* ctx, const float* entries, size_t n, float as
     if (rc != OFPS_HIP_OK) return rc;
     OFPS_HIP_TRY(ctx, hipMemcpyAsync(out_quat, d_q, 4 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     OFPS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    if (out_quat[0] != out_quat[0]) {
-        // NaN: a cluster launch gave up waiting for workgroups that were not co-resident (see almeida_lsq_cluster_kernel);
-        // solve again with one launch per step -- still the HIP path, no spin-waits
-        rc = ofps::almeida_device(ctx, d_ent, n, 1, aspect, fov_y_deg, use_ransac, num_iters, inlier_deg, num_samples, seed, d_q,
-                                  /*allow_cluster=*/false);
-        if (rc != OFPS_HIP_OK) return rc;
-        OFPS_HIP_TRY(ctx, hipMemcpyAsync(out_quat, d_q, 4 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
-        OFPS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    }
     if (out_tr) { out_tr[0] = out_tr[1] = out_tr[2] = 0.0f; }                       // lib.rs:120
     return OFPS_HIP_OK;
 }

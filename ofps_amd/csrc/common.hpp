@@ -20,9 +20,28 @@ struct ofps_hip_ctx {
     int sad_mode = OFPS_HIP_SAD_EXHAUSTIVE;
     char err[512] = {0};
 
+    // Diagnostic / A-B switches (INTEGRATION.md lists them).  Read from the environment ONCE, in ofps_hip_init; a live
+    // context changes them through ofps_hip_set_option.  No entry point reads the environment after that.
+    struct Options {
+        int sad_force_block = 0;         // OFPS_HIP_SAD_KERNEL=block
+        int densify_no_small = 0;        // OFPS_HIP_DENSIFY_NO_SMALL
+        int almeida_path = 0;            // OFPS_HIP_ALMEIDA_PATH: 0 default, 1 step, 2 wg, 3 cluster
+        int almeida_ept = 0;             // OFPS_HIP_ALMEIDA_EPT: 0 = cost model, else 1/2/4/8
+        int almeida_block = 0;           // OFPS_HIP_ALMEIDA_BLOCK: 0 = 1024, else 256/1024
+        int almeida_hier = 1;            // OFPS_HIP_ALMEIDA_HIER: 0 never, 1 when it pays, 2 always
+        int almeida_fast = -1;           // OFPS_HIP_ALMEIDA_FAST: -1 by size, 0 exact, 1 folded
+        int almeida_prof = 0;            // OFPS_HIP_ALMEIDA_PROF
+        int lk_prof = 0;                 // OFPS_HIP_LK_PROF
+        // fault injectors: only builds with -DOFPS_HIP_TEST_HOOKS (libofps_hip_testhooks.so) can set them, and only
+        // through ofps_hip_set_option -- never from the environment
+        int test_almeida_fault = 0;      // OFPS_HIP_ALMEIDA_TEST_FAULT: workgroup (value - 1) withholds its step-3 granule
+        int test_lk_fall = -1;           // OFPS_HIP_LK_TEST_FALL: every other tile hands over at this step
+    } opt;
+
     // hip_lk stream state (lk.hip: ofps_hip_lk_push_frame): frame k of the stream lives in slot k % 2 of S_FRAMES
     int lk_w = 0, lk_h = 0;
     long lk_frames = 0;
+    uint64_t lk_frames_gen = 0;          // generation of the S_LK_FRAMES allocation the count refers to
     void* lk_pinned = nullptr;           // page-locked staging for a frame's records + their count (one D2H, one wait)
     size_t lk_pinned_cap = 0;
 
@@ -50,11 +69,11 @@ struct ofps_hip_ctx {
     // cluster Almeida solver (almeida.hip): granule exchange buffer state.  Tags are unique per call (tag base advances
     // by 32 per launch), so the buffer is zeroed only when (re)allocated or when the 32-bit tag space wraps.
     uint32_t gran_tag_base = 0;
-    void* gran_zeroed = nullptr;         // the allocation the zeroing was done for
+    uint64_t gran_zeroed_gen = 0;        // generation (Scratch::gen) of the allocation the zeroing was done for
 
     // grow-only device scratch owned by the context (staging for host-pointer entry points and
     // kernel workspaces); never shrinks, freed in ofps_hip_destroy.
-    struct Scratch { void* p = nullptr; size_t cap = 0; };
+    struct Scratch { void* p = nullptr; size_t cap = 0; uint64_t gen = 0; };   // gen: bumped by every (re)allocation of the slot
     static constexpr int kNumScratch = 32;
     Scratch scratch[kNumScratch];
 };
@@ -65,7 +84,8 @@ enum ScratchSlot {
     S_FRAMES = 0, S_ENTRIES, S_BEST, S_FIELD, S_CELLS, S_WORK0, S_WORK1, S_WORK2, S_WORK3, S_RESULT,
     S_QUAT, S_WORK4, S_PIPE_FRAMES, S_PIPE_ENTRIES, S_PIPE_OUT, S_MASK, S_ENTRIES2, S_GRAN, S_SAD_LIST,
     // the estimator's own workspaces: it may run beside the detector (pipeline.hip), so the two share no slot
-    S_ALM_PART, S_ALM_STATE, S_ALM_HYP, S_ALM_COUNTS, S_ALM_SEL, S_ALM_SELN, S_ALM_PROF
+    S_ALM_PART, S_ALM_STATE, S_ALM_HYP, S_ALM_COUNTS, S_ALM_SEL, S_ALM_SELN, S_ALM_PROF, S_ALM_RECOVER,
+    S_LK_FRAMES
 };
 
 int set_error(ofps_hip_ctx* ctx, int code, const char* fmt, ...);
@@ -94,8 +114,7 @@ int compact_entries_device(ofps_hip_ctx* ctx, const float4* d_in, const uint8_t*
 int detect_device(ofps_hip_ctx* ctx, const float4* d_entries, size_t n, int batch, float min_size, size_t subdivide,
                   float target_motion, int* d_result, float2* d_out_field, int* out_dim);
 int almeida_device(ofps_hip_ctx* ctx, const float4* d_entries, size_t n, int batch, float aspect, float fov_y_deg,
-                   int use_ransac, size_t num_iters, float inlier_deg, size_t num_samples, uint64_t seed, float4* d_quat,
-                   bool allow_cluster = true);
+                   int use_ransac, size_t num_iters, float inlier_deg, size_t num_samples, uint64_t seed, float4* d_quat);
 
 // rows of `width` bytes, host -> device; one linear copy when both sides are dense (the 2-D path is slower)
 inline hipError_t upload_rows(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t height,

@@ -2,6 +2,8 @@
 // behind include/ofps_hip.h.  No compute lives here.
 #include "common.hpp"
 
+#include <cstdlib>
+
 static thread_local char g_init_err[512] = {0};
 
 namespace ofps {
@@ -39,8 +41,62 @@ void* scratch(ofps_hip_ctx* ctx, int slot, size_t bytes) {
         return nullptr;
     }
     s.cap = cap;
+    s.gen += 1;
     return s.p;
 }
+
+// One table for the diagnostic switches: the environment variable read once by ofps_hip_init and the name
+// ofps_hip_set_option takes are the same string.  value == nullptr or "" restores the default.
+int apply_option(ofps_hip_ctx* ctx, const char* name, const char* value, bool from_env) {
+    auto& o = ctx->opt;
+    const ofps_hip_ctx::Options dflt{};
+    const bool unset = !value || !*value;
+    const int iv = unset ? 0 : atoi(value);
+    if (!strcmp(name, "OFPS_HIP_SAD_KERNEL")) {
+        if (!unset && strcmp(value, "block") && strcmp(value, "strip"))
+            return set_error(ctx, OFPS_HIP_EINVAL, "%s: '%s' is not block|strip", name, value);
+        o.sad_force_block = !unset && !strcmp(value, "block");
+    } else if (!strcmp(name, "OFPS_HIP_DENSIFY_NO_SMALL")) {
+        o.densify_no_small = unset ? dflt.densify_no_small : (iv != 0);
+    } else if (!strcmp(name, "OFPS_HIP_ALMEIDA_PATH")) {
+        if (unset) o.almeida_path = 0;
+        else if (!strcmp(value, "step")) o.almeida_path = 1;
+        else if (!strcmp(value, "wg")) o.almeida_path = 2;
+        else if (!strcmp(value, "cluster")) o.almeida_path = 3;
+        else return set_error(ctx, OFPS_HIP_EINVAL, "%s: '%s' is not step|wg|cluster", name, value);
+    } else if (!strcmp(name, "OFPS_HIP_ALMEIDA_EPT")) {
+        if (!unset && iv != 1 && iv != 2 && iv != 4 && iv != 8) return set_error(ctx, OFPS_HIP_EINVAL, "%s: %d is not 1|2|4|8", name, iv);
+        o.almeida_ept = unset ? 0 : iv;
+    } else if (!strcmp(name, "OFPS_HIP_ALMEIDA_BLOCK")) {
+        if (!unset && iv != 256 && iv != 1024) return set_error(ctx, OFPS_HIP_EINVAL, "%s: %d is not 256|1024", name, iv);
+        o.almeida_block = unset ? 0 : iv;
+    } else if (!strcmp(name, "OFPS_HIP_ALMEIDA_HIER")) {
+        if (!unset && (iv < 0 || iv > 2)) return set_error(ctx, OFPS_HIP_EINVAL, "%s: %d is not 0|1|2", name, iv);
+        o.almeida_hier = unset ? dflt.almeida_hier : iv;
+    } else if (!strcmp(name, "OFPS_HIP_ALMEIDA_FAST")) {
+        o.almeida_fast = unset ? -1 : (iv != 0);
+    } else if (!strcmp(name, "OFPS_HIP_ALMEIDA_PROF")) {
+        o.almeida_prof = unset ? 0 : (iv != 0);
+    } else if (!strcmp(name, "OFPS_HIP_LK_PROF")) {
+        o.lk_prof = unset ? 0 : (iv != 0);
+    } else if (!strcmp(name, "OFPS_HIP_ALMEIDA_TEST_FAULT") || !strcmp(name, "OFPS_HIP_LK_TEST_FALL")) {
+#ifdef OFPS_HIP_TEST_HOOKS
+        if (from_env) return OFPS_HIP_OK;                    // fault injectors are never armed from the environment
+        if (!strcmp(name, "OFPS_HIP_ALMEIDA_TEST_FAULT")) o.test_almeida_fault = unset ? 0 : iv;
+        else o.test_lk_fall = unset ? -1 : iv;
+#else
+        if (from_env) return OFPS_HIP_OK;
+        return set_error(ctx, OFPS_HIP_EUNSUPPORTED, "%s is a test hook: this library was built without OFPS_HIP_TEST_HOOKS", name);
+#endif
+    } else {
+        return set_error(ctx, OFPS_HIP_EINVAL, "unknown option '%s'", name);
+    }
+    return OFPS_HIP_OK;
+}
+
+static const char* const kOptionNames[] = {
+    "OFPS_HIP_SAD_KERNEL", "OFPS_HIP_DENSIFY_NO_SMALL", "OFPS_HIP_ALMEIDA_PATH", "OFPS_HIP_ALMEIDA_EPT", "OFPS_HIP_ALMEIDA_BLOCK",
+    "OFPS_HIP_ALMEIDA_HIER", "OFPS_HIP_ALMEIDA_FAST", "OFPS_HIP_ALMEIDA_PROF", "OFPS_HIP_LK_PROF"};
 
 }  // namespace ofps
 
@@ -83,7 +139,44 @@ int ofps_hip_init(int device, ofps_hip_ctx** out) {
         return rc;
     }
     ctx->stream = ctx->own_stream;
+    // the only place the library looks at the environment (OFPS_HIP_SAD_PRUNED is the host layers' business)
+    for (const char* name : ofps::kOptionNames)
+        if (const char* v = getenv(name)) {
+            const int rc = ofps::apply_option(ctx, name, v, /*from_env=*/true);
+            if (rc != OFPS_HIP_OK) {
+                snprintf(g_init_err, sizeof(g_init_err), "ofps_hip_init: %s", ctx->err);
+                ofps_hip_destroy(ctx);
+                return rc;
+            }
+        }
     *out = ctx;
+    return OFPS_HIP_OK;
+}
+
+int ofps_hip_set_option(ofps_hip_ctx* ctx, const char* name, const char* value) {
+    if (!ctx) return OFPS_HIP_EINVAL;
+    OFPS_REQUIRE(ctx, name, "set_option: null name");
+    return ofps::apply_option(ctx, name, value, /*from_env=*/false);
+}
+
+int ofps_hip_has_test_hooks(void) {
+#ifdef OFPS_HIP_TEST_HOOKS
+    return 1;
+#else
+    return 0;
+#endif
+}
+
+int ofps_hip_almeida_recoveries(ofps_hip_ctx* ctx, uint64_t* count) {
+    if (!ctx || !count) return OFPS_HIP_EINVAL;
+    *count = 0;
+    const void* d = ctx->scratch[ofps::S_ALM_RECOVER].p;
+    if (!d) return OFPS_HIP_OK;                              // no cluster launch yet
+    OFPS_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    unsigned long long v = 0;
+    OFPS_HIP_TRY(ctx, hipMemcpyAsync(&v, d, sizeof(v), hipMemcpyDeviceToHost, ctx->stream));
+    OFPS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    *count = v;
     return OFPS_HIP_OK;
 }
 

@@ -633,7 +633,7 @@ int densify_device_raw(ofps_hip_ctx* ctx, const float4* d_entries, size_t n, int
     if (out_begin) *out_begin = begin;
     if (out_end) *out_end = end;
     if (n > 0 && n <= (size_t)kSmallMaxN && cells <= (size_t)kSmallMaxCells && !d_cells && !d_sum && !d_cnt && !d_weights && d_field &&
-        !getenv("OFPS_HIP_DENSIFY_NO_SMALL")) {                              // (the variable: A/B runs and tests of the general path)
+        !ctx->opt.densify_no_small) {                              // (the variable: A/B runs and tests of the general path)
         static bool attr_set[64] = {};
         if (!attr_set[ctx->device & 63]) {
             OFPS_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(densify_small_kernel),

@@ -488,9 +488,15 @@ __global__ __launch_bounds__(256, LkStepShared<RADIUS>::WAVES_PER_SIMD) void lk_
                                                            const float* __restrict__ gx, const float* __restrict__ gy,
                                                            const float4* __restrict__ G, int w, int h, int iters, const LkFlowIO io,
                                                            uint32_t* __restrict__ fb_count, uint2* __restrict__ fb_tiles,
-                                                           float2* fb_flow, unsigned long long* __restrict__ prof, int force_fall) {
-    // force_fall (tests only, normally -1): every other tile is treated as not fitting at that step, so that the hand-over
-    // to lk_level_general_kernel in the middle of a level is exercised on inputs that would never trigger it
+                                                           float2* fb_flow, unsigned long long* __restrict__ prof, int force_fall_arg) {
+    // force_fall (libofps_hip_testhooks.so only; compiled out of the product library): every other tile is treated as not
+    // fitting at that step, so that the hand-over to lk_level_general_kernel in the middle of a level is exercised on
+    // inputs that would never trigger it
+#ifdef OFPS_HIP_TEST_HOOKS
+    const int force_fall = force_fall_arg;
+#else
+    constexpr int force_fall = -1;
+#endif
     // prof (diagnostics, normally null): per-workgroup s_memtime stamps at the phase boundaries of the first step
 #define OFPS_LK_STAMP(slot) do { if (prof && threadIdx.x == 0) prof[((size_t)tile_y * tiles_x + tile_x) * 6 + (slot)] = __builtin_readcyclecounter(); } while (0)
     using T = LkTile<RADIUS>;
@@ -786,7 +792,7 @@ int lk_flow_device(ofps_hip_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_cu
         fb_count = static_cast<uint32_t*>(scratch(ctx, S_WORK3, (head + 2 * (size_t)levels * tiles0) * sizeof(uint32_t)));
         if (!fb_count) return OFPS_HIP_ENOMEM;
         fb_tiles = reinterpret_cast<uint2*>(fb_count + head);
-        if (getenv("OFPS_HIP_LK_PROF")) {
+        if (ctx->opt.lk_prof) {
             prof = static_cast<unsigned long long*>(scratch(ctx, S_WORK2, tiles0 * 6 * sizeof(unsigned long long)));
             if (!prof) return OFPS_HIP_ENOMEM;
         }
@@ -813,8 +819,7 @@ int lk_flow_device(ofps_hip_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_cu
         plain_flow = static_cast<float2*>(scratch(ctx, S_WORK1, plane0 * sizeof(float2)));
         if (!plain_flow) return OFPS_HIP_ENOMEM;
     }
-    int force_fall = -1;
-    if (const char* f = getenv("OFPS_HIP_LK_TEST_FALL")) force_fall = atoi(f);                 // tests only
+    const int force_fall = ctx->opt.test_lk_fall;       // -1 in the product library (a test hook of libofps_hip_testhooks.so)
     {   // gradients of every level: one launch (64 x 4 pixels per block, per-level block ranges padded to multiples of 8)
         LkPyr P{};
         P.levels = levels;
@@ -1015,7 +1020,6 @@ int ofps_hip_lk_decode(ofps_hip_ctx* ctx, const uint8_t* prev, const uint8_t* cu
     const size_t px = (size_t)W * H;
     auto* d_frames = static_cast<uint8_t*>(ofps::scratch(ctx, ofps::S_FRAMES, 2 * px));
     if (!d_frames) return OFPS_HIP_ENOMEM;
-    ctx->lk_frames = 0;                                             // the stateless call overwrites the stream's frames
     OFPS_HIP_TRY(ctx, ofps::upload_rows(d_frames, W, prev, stride, W, H, ctx->stream));
     OFPS_HIP_TRY(ctx, ofps::upload_rows(d_frames + px, W, cur, stride, W, H, ctx->stream));
     return lk_decode_resident(ctx, d_frames, 0, 1, W, H, levels, radius, iters, max_w, max_h, flags, out_entries, n_out, out_w, out_h);
@@ -1031,8 +1035,14 @@ int ofps_hip_lk_push_frame(ofps_hip_ctx* ctx, const uint8_t* frame, int W, int H
     OFPS_HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (ctx->lk_w != W || ctx->lk_h != H) { ctx->lk_w = W; ctx->lk_h = H; ctx->lk_frames = 0; }    // a new geometry restarts the stream
     const size_t px = (size_t)W * H;
-    auto* d_frames = static_cast<uint8_t*>(ofps::scratch(ctx, ofps::S_FRAMES, 2 * px));
+    // the stream's two frames have a slot of their own: no other entry point (lk_decode, lk_flow, sad_flow,
+    // contrast_mask stage their frames in S_FRAMES) can overwrite or reallocate the previous frame behind the stream's back
+    auto* d_frames = static_cast<uint8_t*>(ofps::scratch(ctx, ofps::S_LK_FRAMES, 2 * px));
     if (!d_frames) return OFPS_HIP_ENOMEM;
+    if (ctx->lk_frames_gen != ctx->scratch[ofps::S_LK_FRAMES].gen) {         // (re)allocated: whatever was there is gone
+        ctx->lk_frames_gen = ctx->scratch[ofps::S_LK_FRAMES].gen;
+        ctx->lk_frames = 0;
+    }
     const int slot = (int)(ctx->lk_frames & 1);
     OFPS_HIP_TRY(ctx, ofps::upload_rows(d_frames + (size_t)slot * px, W, frame, stride, W, H, ctx->stream));
     ctx->lk_frames += 1;

@@ -969,8 +969,7 @@ int sad_pairs_device(ofps_hip_ctx* ctx, const uint8_t* prev_base, size_t prev_pi
     OFPS_HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
     const int key = block * 1000 + range;
-    const char* force = getenv("OFPS_HIP_SAD_KERNEL");
-    const bool force_block = force && strcmp(force, "block") == 0;
+    const bool force_block = ctx->opt.sad_force_block != 0;     // OFPS_HIP_SAD_KERNEL=block (A/B profiling)
     const bool strip_ok = !force_block && stride % 16 == 0 && ((uintptr_t)prev_base % 16) == 0 &&
                           ((uintptr_t)cur_base % 16) == 0 && prev_pitch % 16 == 0 && cur_pitch % 16 == 0 &&
                           (long long)p.nbx * p.nby * pairs < (1ll << 30);

@@ -160,6 +160,16 @@ def min_over_ranks(value: int, device=None) -> int:
     return int(t.item())
 
 
+def sum_over_ranks(value: int, device=None) -> int:
+    import torch
+    import torch.distributed as dist
+    if not active() or dist.get_world_size() == 1:
+        return value
+    t = torch.tensor([value], dtype=torch.int64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return int(t.item())
+
+
 def gather_counts(count: int, device=None) -> list[int]:
     """Every rank's pair count, in rank order."""
     import torch

@@ -18,8 +18,9 @@ def _fp(a):
 class HipContext:
     """One ofps_hip_ctx (one per plugin instance, ofps/src/plugins/mod.rs:244-278 'Send, not Sync')."""
 
-    def __init__(self, device: int = 0):
-        self._lib = _lib.load()
+    def __init__(self, device: int = 0, test_hooks: bool = False):
+        # test_hooks: bind libofps_hip_testhooks.so (fault injectors compiled in) instead of the product library
+        self._lib = _lib.load_test_hooks() if test_hooks else _lib.load()
         h = C.c_void_p()
         rc = self._lib.ofps_hip_init(device, C.byref(h))
         if rc != 0:
@@ -60,6 +61,16 @@ class HipContext:
 
     def sync(self):
         self._check(self._lib.ofps_hip_sync(self._h))
+
+    def set_option(self, name: str, value=None):
+        """Diagnostic / A-B switch by its environment-variable name; None restores the default."""
+        v = None if value is None else str(value).encode()
+        self._check(self._lib.ofps_hip_set_option(self._h, name.encode(), v))
+
+    def almeida_recoveries(self) -> int:
+        n = C.c_uint64(0)
+        self._check(self._lib.ofps_hip_almeida_recoveries(self._h, C.byref(n)))
+        return int(n.value)
 
     # device memory for hosts without a HIP binding of their own (what the Rust shim uses for resident chains)
     def malloc(self, nbytes: int) -> int:

@@ -48,6 +48,28 @@ def _value_noise(xs: np.ndarray, ys: np.ndarray, period: int, salt: int) -> np.n
     return top + (bot - top) * fy
 
 
+def _value_noise_grid(x1: np.ndarray, y1: np.ndarray, period: int, salt: int) -> np.ndarray:
+    """_value_noise on the mesh y1 (rows) x x1 (columns) of int64 coordinates: the lattice is hashed once per lattice point
+    instead of four times per pixel; same f32 operations per element, same bits."""
+    ix = np.floor_divide(x1, period); iy = np.floor_divide(y1, period)
+    fx = (((x1 - ix * period).astype(np.float32) + np.float32(0.5)) / np.float32(period))[None, :]
+    fy = (((y1 - iy * period).astype(np.float32) + np.float32(0.5)) / np.float32(period))[:, None]
+    ux = np.arange(ix.min(), ix.max() + 2, dtype=np.int64); uy = np.arange(iy.min(), iy.max() + 2, dtype=np.int64)
+    lat = _lattice(np.broadcast_to(ux[None, :], (len(uy), len(ux))), np.broadcast_to(uy[:, None], (len(uy), len(ux))), salt)
+    cx = (ix - ux[0]).astype(np.intp); cy = (iy - uy[0]).astype(np.intp)
+    rows0 = lat[cy]; rows1 = lat[cy + 1]                       # [h, lattice columns]
+    v00 = rows0[:, cx]; v10 = rows0[:, cx + 1]; v01 = rows1[:, cx]; v11 = rows1[:, cx + 1]
+    top = v00 + (v10 - v00) * fx
+    bot = v01 + (v11 - v01) * fx
+    return top + (bot - top) * fy
+
+
+def _texture_grid(x1: np.ndarray, y1: np.ndarray, seed: int) -> np.ndarray:
+    """_texture on a mesh (rows y1, columns x1)."""
+    return (np.float32(4) * _value_noise_grid(x1, y1, 64, seed) + np.float32(2) * _value_noise_grid(x1, y1, 16, seed + 1)
+            + _value_noise_grid(x1, y1, 4, seed + 2)) / np.float32(7)
+
+
 def _texture(xs: np.ndarray, ys: np.ndarray, seed: int) -> np.ndarray:
     """Octaves at 64/16/4 px, weights 4:2:1 -> float32 in [0,1)."""
     n = (np.float32(4) * _value_noise(xs, ys, 64, seed) + np.float32(2) * _value_noise(xs, ys, 16, seed + 1)
@@ -80,8 +102,7 @@ def luma_sequence(n_frames: int, width: int, height: int, max_step: int, seed: i
     lo_y, hi_y = int(offs[..., 1].min()), int(offs[..., 1].max())
     cw, ch = width + hi_x - lo_x, height + hi_y - lo_y
     if cw * ch <= 64 * 1024 * 1024:
-        cyy, cxx = np.meshgrid(np.arange(ch, dtype=np.int64) + lo_y + 100000, np.arange(cw, dtype=np.int64) + lo_x + 100000, indexing="ij")
-        canvas = _texture(cxx, cyy, seed)
+        canvas = _texture_grid(np.arange(cw, dtype=np.int64) + lo_x + 100000, np.arange(ch, dtype=np.int64) + lo_y + 100000, seed)
     else:
         canvas = None                                     # very long sequences: fall back to per-frame evaluation
     for k in range(n_frames):

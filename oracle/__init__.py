@@ -68,6 +68,9 @@ def lib():
         L.orc_detect_motion.restype = C.c_int
         L.orc_solve_ypr_given.argtypes = [fp, C.c_size_t, C.POINTER(Camera), fp]
         L.orc_solve_ypr_given_ex.argtypes = [fp, C.c_size_t, C.POINTER(Camera), C.c_float, C.c_size_t, C.c_int, fp, fp]
+        L.orc_solve_ypr_given_mt.argtypes = [fp, C.c_size_t, C.POINTER(Camera), C.c_int, fp]
+        L.orc_solve_ypr_ransac_mt.argtypes = [fp, C.c_size_t, C.POINTER(Camera), C.c_size_t, C.c_float, C.c_size_t, C.c_uint64,
+                                              C.c_int, fp]
         L.orc_quat_inverse.argtypes = [fp, fp]
         L.orc_almeida_model.argtypes = [fp, C.c_size_t, C.POINTER(Camera), fp, fp]
         L.orc_solve_ypr_ransac.argtypes = [fp, C.c_size_t, C.POINTER(Camera), C.c_size_t, C.c_float,
@@ -226,9 +229,13 @@ def detect_motion(entries, min_size=0.05, subdivide=3, target_motion=0.003):
     return (int(area.value), field) if some else None
 
 
-def solve_ypr_given(entries, cam: Camera) -> np.ndarray:
+def solve_ypr_given(entries, cam: Camera, threads: int = 1) -> np.ndarray:
+    """threads > 1: the per-vector loop and the twelve dot products on that many host threads -- same bits."""
     e = _f32(entries).reshape(-1, 4); q = np.zeros(4, np.float32)
-    lib().orc_solve_ypr_given(_fp(e), e.shape[0], C.byref(cam), _fp(q))
+    if threads > 1:
+        lib().orc_solve_ypr_given_mt(_fp(e), e.shape[0], C.byref(cam), threads, _fp(q))
+    else:
+        lib().orc_solve_ypr_given(_fp(e), e.shape[0], C.byref(cam), _fp(q))
     return q
 
 
@@ -255,8 +262,13 @@ def quat_mul(a, b) -> np.ndarray:
 
 
 def solve_ypr_ransac(entries, cam: Camera, num_iters=200, inlier_deg=0.05, num_samples=1000,
-                     seed=0, want_inliers=False):
+                     seed=0, want_inliers=False, threads: int = 1):
+    """threads > 1: the hypotheses on that many host threads (first maximum wins, as in the loop) -- same bits."""
     e = _f32(entries).reshape(-1, 4); q = np.zeros(4, np.float32)
+    if threads > 1:
+        assert not want_inliers
+        lib().orc_solve_ypr_ransac_mt(_fp(e), e.shape[0], C.byref(cam), num_iters, inlier_deg, num_samples, seed, threads, _fp(q))
+        return q
     inl = np.zeros(max(num_samples, 1), np.uint32); n_inl = C.c_size_t(0)
     lib().orc_solve_ypr_ransac(_fp(e), e.shape[0], C.byref(cam), num_iters, inlier_deg, num_samples,
                                seed, _fp(q), inl.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(n_inl))

@@ -546,7 +546,16 @@ static float almeida_eps(void) { return 0.001f * 3.14159265358979323846264338327
 
 /* One pass of the loop body, :140-183: residual and the three prototypes per vector, A and b as sequential f32 sums in
  * input order, partial-pivot LU; `model` is the raw solution (in units of EPS; zero when LU fails, :183). */
+/* threads > 1 (bench.py's all-core CPU leg): the per-vector loop is split over OpenMP threads and the
+ * twelve dot products -- each still ONE sequential f32 sum in input order -- run side by side, so the result is the
+ * single-thread result bit for bit (tests/test_oracle.py). */
+static void almeida_model_mt(const float* entries, size_t n, const orc_camera* cam, const float rotation[4], float model[3],
+                             int threads);
 void orc_almeida_model(const float* entries, size_t n, const orc_camera* cam, const float rotation[4], float model[3]) {
+    almeida_model_mt(entries, n, cam, rotation, model, 1);
+}
+static void almeida_model_mt(const float* entries, size_t n, const orc_camera* cam, const float rotation[4], float model[3],
+                             int threads) {
     const float EPS = almeida_eps();
     float m_roll[16], m_pitch[16], m_yaw[16], rotm[16];
     orc_mat4_from_euler(0.0f, EPS, 0.0f, m_roll);                     /* :30-34 */
@@ -554,6 +563,8 @@ void orc_almeida_model(const float* entries, size_t n, const orc_camera* cam, co
     orc_mat4_from_euler(0.0f, 0.0f, -EPS, m_yaw);                     /* :40-42 */
     orc_quat_to_homogeneous(rotation, rotm);                          /* :140 */
     float* v = (float*)malloc((8 * n + 8) * sizeof(float));           /* [motion-delta, roll, pitch, yaw] */
+    if (threads < 1) threads = 1;
+#pragma omp parallel for schedule(static) num_threads(threads) if (threads > 1)
     for (size_t i = 0; i < n; ++i) {                                  /* :142-157 */
         const float* e = entries + 4 * i;
         float d[2];
@@ -566,8 +577,10 @@ void orc_almeida_model(const float* entries, size_t n, const orc_camera* cam, co
     }
     /* :159-179: each dot summed over the Vec in input order, starting from 0 */
     float a[9], b[3];
-    for (int c = 0; c < 3; ++c)
-        for (int r = 0; r < 3; ++r) {
+#pragma omp parallel for schedule(static, 1) num_threads(threads < 12 ? threads : 12) if (threads > 1)
+    for (int k = 0; k < 12; ++k) {
+        if (k < 9) {
+            const int c = k / 3, r = k % 3;
             float acc = 0.0f;
             for (size_t i = 0; i < n; ++i) {
                 const float* p = v + 8 * i + 2 * (c + 1);
@@ -575,15 +588,16 @@ void orc_almeida_model(const float* entries, size_t n, const orc_camera* cam, co
                 acc += p[0] * s[0] + p[1] * s[1];
             }
             a[3 * r + c] = acc;       /* from_iterator is column-major: element k -> (k%3, k/3) */
+        } else {
+            const int r = k - 9;
+            float acc = 0.0f;
+            for (size_t i = 0; i < n; ++i) {
+                const float* p = v + 8 * i + 2 * (r + 1);
+                const float* s = v + 8 * i;
+                acc += p[0] * s[0] + p[1] * s[1];
+            }
+            b[r] = acc;
         }
-    for (int r = 0; r < 3; ++r) {
-        float acc = 0.0f;
-        for (size_t i = 0; i < n; ++i) {
-            const float* p = v + 8 * i + 2 * (r + 1);
-            const float* s = v + 8 * i;
-            acc += p[0] * s[0] + p[1] * s[1];
-        }
-        b[r] = acc;
     }
     free(v);
     if (!orc_lu3_solve(a, b, model)) { model[0] = model[1] = model[2] = 0.0f; }   /* :181-183 */
@@ -593,14 +607,20 @@ void orc_almeida_model(const float* entries, size_t n, const orc_camera* cam, co
  * today is (ALPHA 0.5, limit ceil(15/ALPHA) = 30, order 0 = pitch*roll*yaw, :18,:132,:193); order 1 = yaw*pitch*roll
  * is what the build that drew docs/report/mfield used (tests/test_reference_vectors.py).  q_steps (optional): the
  * cumulative `rotation` after every step, 4 floats each -- NOT inverted. */
+static void solve_ypr_given_mt(const float* entries, size_t n, const orc_camera* cam, float alpha_c, size_t limit,
+                               int order, float* q_steps, float q_out[4], int threads);
 void orc_solve_ypr_given_ex(const float* entries, size_t n, const orc_camera* cam, float alpha_c, size_t limit,
                             int order, float* q_steps, float q_out[4]) {
+    solve_ypr_given_mt(entries, n, cam, alpha_c, limit, order, q_steps, q_out, 1);
+}
+static void solve_ypr_given_mt(const float* entries, size_t n, const orc_camera* cam, float alpha_c, size_t limit,
+                               int order, float* q_steps, float q_out[4], int threads) {
     const float EPS = almeida_eps();
     float rotation[4] = {1.0f, 0.0f, 0.0f, 0.0f};
     for (size_t it = 0; it < limit; ++it) {
         float alpha = (it == limit - 1) ? 1.0f : alpha_c;             /* :138 */
         float model[3];
-        orc_almeida_model(entries, n, cam, rotation, model);
+        almeida_model_mt(entries, n, cam, rotation, model, threads);
         model[0] = model[0] * EPS * alpha;                            /* :185 */
         model[1] = model[1] * EPS * alpha;
         model[2] = model[2] * EPS * alpha;
@@ -624,6 +644,10 @@ void orc_solve_ypr_given_ex(const float* entries, size_t n, const orc_camera* ca
 
 void orc_solve_ypr_given(const float* entries, size_t n, const orc_camera* cam, float q_out[4]) {
     orc_solve_ypr_given_ex(entries, n, cam, ORC_ALPHA, (size_t)ceilf(15.0f / ORC_ALPHA) /* :132 */, 0, NULL, q_out);
+}
+/* the same solve on `threads` host threads: identical bits (see almeida_model_mt) */
+void orc_solve_ypr_given_mt(const float* entries, size_t n, const orc_camera* cam, int threads, float q_out[4]) {
+    solve_ypr_given_mt(entries, n, cam, ORC_ALPHA, (size_t)ceilf(15.0f / ORC_ALPHA), 0, NULL, q_out, threads);
 }
 
 /* --- counter-based sampler standing in for rand::thread_rng + choose_multiple.
@@ -655,6 +679,77 @@ uint32_t orc_sample_index(uint64_t seed, uint32_t iter, uint32_t stream, uint32_
         x = (l << half) | r;
     } while (x >= n);
     return x;
+}
+
+/* The hypotheses of :214-245 are independent of each other: on `threads` host threads each thread evaluates a strided
+ * share of them and the winner is the FIRST hypothesis with the largest inlier set, as in the sequential loop -> the same
+ * bits as orc_solve_ypr_ransac (tests/test_oracle.py).  bench.py's all-core CPU leg. */
+void orc_solve_ypr_ransac_mt(const float* entries, size_t n, const orc_camera* cam, size_t num_iters, float inlier_deg,
+                             size_t num_samples, uint64_t seed, int threads, float q_out[4]) {
+    float target_delta = to_radians(inlier_deg);
+    size_t ns = num_samples < n ? num_samples : n;
+    size_t n3 = n < 3 ? n : 3;
+    float thr2 = target_delta * target_delta;
+    if (threads < 1) threads = 1;
+    size_t* lens = (size_t*)calloc(num_iters + 1, sizeof(size_t));
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads) if (threads > 1)
+    for (size_t it = 0; it < num_iters; ++it) {
+        float samples[12];
+        for (size_t j = 0; j < n3; ++j) {
+            uint32_t idx = orc_sample_index(seed, (uint32_t)it, 0, (uint32_t)j, (uint32_t)n);
+            memcpy(samples + 4 * j, entries + 4 * (size_t)idx, 4 * sizeof(float));
+        }
+        float fit[4], inv[4], mat[16];
+        orc_solve_ypr_given(samples, n3, cam, fit);
+        orc_quat_inverse(fit, inv);
+        orc_quat_to_homogeneous(inv, mat);
+        size_t len = 0;
+        for (size_t j = 0; j < ns; ++j) {
+            uint32_t idx = orc_sample_index(seed, (uint32_t)it, 1, (uint32_t)j, (uint32_t)n);
+            const float* e = entries + 4 * (size_t)idx;
+            float d[2], sample[2], vec[2], ang[2];
+            orc_camera_delta(cam, e, mat, d);
+            sample[0] = e[0] + d[0]; sample[1] = e[1] + d[1];
+            vec[0] = e[2] - d[0]; vec[1] = e[3] - d[1];
+            orc_camera_point_angle(cam, sample, ang);
+            float vx = vec[0] * cosf(ang[0]), vy = vec[1] * cosf(ang[1]);
+            if (vx * vx + vy * vy <= thr2) ++len;
+        }
+        lens[it] = len;
+    }
+    size_t best_it = 0, best_len = 0;
+    for (size_t it = 0; it < num_iters; ++it)
+        if (lens[it] > best_len) { best_len = lens[it]; best_it = it; }      /* strict >: the first maximum, :243 */
+    free(lens);
+    if (best_len >= 3) {
+        /* the winner's inlier set again, in sample order, then the refit (:247-251) */
+        float samples[12];
+        for (size_t j = 0; j < n3; ++j) {
+            uint32_t idx = orc_sample_index(seed, (uint32_t)best_it, 0, (uint32_t)j, (uint32_t)n);
+            memcpy(samples + 4 * j, entries + 4 * (size_t)idx, 4 * sizeof(float));
+        }
+        float fit[4], inv[4], mat[16];
+        orc_solve_ypr_given(samples, n3, cam, fit);
+        orc_quat_inverse(fit, inv);
+        orc_quat_to_homogeneous(inv, mat);
+        float* sel = (float*)malloc((4 * best_len + 4) * sizeof(float));
+        size_t len = 0;
+        for (size_t j = 0; j < ns; ++j) {
+            uint32_t idx = orc_sample_index(seed, (uint32_t)best_it, 1, (uint32_t)j, (uint32_t)n);
+            const float* e = entries + 4 * (size_t)idx;
+            float d[2], sample[2], vec[2], ang[2];
+            orc_camera_delta(cam, e, mat, d);
+            sample[0] = e[0] + d[0]; sample[1] = e[1] + d[1];
+            vec[0] = e[2] - d[0]; vec[1] = e[3] - d[1];
+            orc_camera_point_angle(cam, sample, ang);
+            float vx = vec[0] * cosf(ang[0]), vy = vec[1] * cosf(ang[1]);
+            if (vx * vx + vy * vy <= thr2 && len < best_len) { memcpy(sel + 4 * len, e, 4 * sizeof(float)); ++len; }
+        }
+        solve_ypr_given_mt(sel, len, cam, ORC_ALPHA, (size_t)ceilf(15.0f / ORC_ALPHA), 0, NULL, q_out, threads);
+        free(sel);
+    } else {
+        q_out[0] = 1.0f; q_out[1] = q_out[2] = q_out[3] = 0.0f;
+    }
 }
 
 void orc_solve_ypr_ransac(const float* entries, size_t n, const orc_camera* cam,

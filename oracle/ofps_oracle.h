@@ -109,6 +109,11 @@ void orc_solve_ypr_given_ex(const float* entries, size_t n, const orc_camera* ca
 void orc_solve_ypr_ransac(const float* entries, size_t n, const orc_camera* cam,
                           size_t num_iters, float inlier_deg, size_t num_samples, uint64_t seed,
                           float q[4], uint32_t* out_inliers, size_t* out_n_inliers);
+/* The two solvers on `threads` host threads, same bits as the single-thread forms (the per-vector loops and the
+ * hypotheses are independent; every sum keeps its sequential order): the all-core CPU baseline of bench.py. */
+void orc_solve_ypr_given_mt(const float* entries, size_t n, const orc_camera* cam, int threads, float q[4]);
+void orc_solve_ypr_ransac_mt(const float* entries, size_t n, const orc_camera* cam, size_t num_iters, float inlier_deg,
+                             size_t num_samples, uint64_t seed, int threads, float q[4]);
 /* The sampler itself (shared definition with the HIP kernels, DESIGN.md "RANSAC sampler"):
  * i-th of the distinct indices drawn for (seed, iter, stream) out of [0,n). */
 uint32_t orc_sample_index(uint64_t seed, uint32_t iter, uint32_t stream, uint32_t i, uint32_t n);

@@ -80,6 +80,18 @@ def test_gpus_2_weak_reports_whole_job_pairs():
     assert d["scaling"] == "weak" and d["config"]["pairs_per_rank"] == [6, 6] and d["config"]["pairs_per_step"] == 12
 
 
+def test_a_skipping_rank_cannot_hide_another_ranks_mismatch_and_a_mismatch_fails_the_run():
+    """Mismatches and skips are reduced separately; any mismatch makes the process exit non-zero (a driver that looks
+    only at the return code and `value` must not accept wrong vectors)."""
+    p, d = _run("--gpus", "2", "--stub", "--pairs", "4", "--steps", "1", "--warmup", "0", "--stub-parity", "skip,0")
+    assert p.returncode != 0 and "PARITY MISMATCH" in p.stderr
+    assert d["parity_check"]["ok"] is False and d["parity_check"]["ranks_skipped"] == 1 and d["parity_check"]["ranks_checked"] == 1
+    p, d = _run("--gpus", "2", "--stub", "--pairs", "4", "--steps", "1", "--warmup", "0", "--stub-parity", "skip,1")
+    assert p.returncode == 0 and d["parity_check"]["ok"] is True and d["parity_check"]["ranks_skipped"] == 1
+    p, d = _run("--gpus", "2", "--stub", "--pairs", "4", "--steps", "1", "--warmup", "0", "--stub-parity", "skip,skip")
+    assert p.returncode == 0 and d["parity_check"]["ok"] is None and d["parity_check"]["ranks_skipped"] == 2
+
+
 def test_world_size_must_match_gpus():
     # a launcher that started 1 rank while --gpus says 2: fail loudly instead of measuring one GPU and printing n_gpus=1
     p, d = _run("--gpus", "2", "--stub", env={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})

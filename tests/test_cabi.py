@@ -41,6 +41,27 @@ def test_api_version_and_pure_helpers():
     assert lib.ofps_hip_block_dim(0.01, 16) == 160
 
 
+def test_fault_injectors_live_only_in_the_test_hooks_library():
+    """libofps_hip.so is built without OFPS_HIP_TEST_HOOKS; libofps_hip_testhooks.so (same sources, same ABI) with it.
+    The product library never reads the environment outside ofps_hip_init and holds no injector code path."""
+    assert _lib.load().ofps_hip_has_test_hooks() == 0
+    assert _lib.load_test_hooks().ofps_hip_has_test_hooks() == 1
+    for name in _declared_symbols():
+        assert hasattr(_lib.load_test_hooks(), name)
+    csrc = os.path.join(ROOT, "ofps_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".hip", ".hpp")):
+            src = open(os.path.join(csrc, f)).read()
+            if f != "ctx.hip":
+                assert "getenv" not in src, f"{f} reads the environment on a call path"
+    ctx_src = open(os.path.join(csrc, "ctx.hip")).read()
+    assert ctx_src.count("getenv(") == 1                                     # the one loop in ofps_hip_init
+    # nothing in the product package binds the hooks library except the explicit test_hooks=True switch of the runtime
+    for f in ("plugins.py", "distributed.py", "mvec.py", "synth.py", "build.py"):
+        assert "load_test_hooks" not in open(os.path.join(ROOT, "ofps_amd", f)).read()
+    assert "load_test_hooks" not in open(os.path.join(ROOT, "bench.py")).read()
+
+
 def test_no_gpu_means_loud_failure_not_fallback():
     import torch
     if torch.cuda.is_available():

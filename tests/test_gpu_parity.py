@@ -19,6 +19,15 @@ def ctx():
     c.close()
 
 
+@pytest.fixture(scope="module")
+def hooks_ctx():
+    """libofps_hip_testhooks.so: the build whose fault injectors / forced hand-overs can be armed."""
+    from ofps_amd.runtime import HipContext
+    c = HipContext(0, test_hooks=True)
+    yield c
+    c.close()
+
+
 # ------------------------------------------------------------------ N1: SAD block matcher
 SAD_CASES = [
     # (W, H, B, R, kind)
@@ -267,7 +276,7 @@ def test_densify_bit_exact(ctx, n, w, h):
 @pytest.mark.parametrize("n,w,h", [(1, 1, 1), (63, 14, 14), (64, 14, 14), (65, 16, 16), (880, 14, 14), (8040, 14, 14), (8192, 16, 16),
                                    (8192, 256, 1), (5000, 1, 1), (4097, 3, 85), (8193, 14, 14)])
 @pytest.mark.parametrize("spread", ["uniform", "one_cell", "out_of_range"])
-def test_densify_one_workgroup_path_matches_the_general_path_and_the_oracle(ctx, monkeypatch, n, w, h, spread):
+def test_densify_one_workgroup_path_matches_the_general_path_and_the_oracle(ctx, n, w, h, spread):
     """Up to 8,192 entries on up to 256 cells the densifier is one workgroup per item (densify_small_kernel); above that,
     or with OFPS_HIP_DENSIFY_NO_SMALL, the six-kernel stable sort.  Same bits either way, and the oracle's: slot edges
     (63 / 64 / 65 entries), the size limits on both sides, every entry in one cell, positions the clamp collapses."""
@@ -279,8 +288,11 @@ def test_densify_one_workgroup_path_matches_the_general_path_and_the_oracle(ctx,
     f_o = oracle.densify(e, w, h)
     f_small = ctx.densify(e, w, h)
     np.testing.assert_array_equal(f_small.view(np.uint32), f_o.view(np.uint32))
-    monkeypatch.setenv("OFPS_HIP_DENSIFY_NO_SMALL", "1")
-    f_gen = ctx.densify(e, w, h)
+    ctx.set_option("OFPS_HIP_DENSIFY_NO_SMALL", "1")
+    try:
+        f_gen = ctx.densify(e, w, h)
+    finally:
+        ctx.set_option("OFPS_HIP_DENSIFY_NO_SMALL", None)
     np.testing.assert_array_equal(f_gen.view(np.uint32), f_o.view(np.uint32))
 
 
@@ -516,12 +528,13 @@ def test_lk_flow_bit_exact_vs_oracle(ctx, W, H, levels, radius, iters):
 
 @pytest.mark.parametrize("fall_step", [0, 1, 2])
 @pytest.mark.parametrize("radius", [2, 4, 6])
-def test_lk_flow_hand_over_in_the_middle_of_a_level(ctx, monkeypatch, fall_step, radius):
+def test_lk_flow_hand_over_in_the_middle_of_a_level(hooks_ctx, fall_step, radius):
     """The level kernel keeps a tile's flow on chip across the Gauss-Newton steps of a level; a tile whose current-frame
     rectangle stops fitting LDS at step k parks its flow and the general kernel finishes steps k.. of the level.  The
     test hook makes every other tile fall at step k (0 = the whole level, 1 / 2 = mid-level), with and without the
     records output: same bits as the oracle either way."""
-    monkeypatch.setenv("OFPS_HIP_LK_TEST_FALL", str(fall_step))
+    ctx = hooks_ctx                     # the hook is compiled only into libofps_hip_testhooks.so
+    ctx.set_option("OFPS_HIP_LK_TEST_FALL", str(fall_step))
     W, H, levels, iters = 320, 180, 3, 3
     fr = synth.luma_sequence(2, W, H, max_step=3, seed=77 + radius)
     f_o = oracle.lk_flow(fr[0], fr[1], levels, radius, iters)
@@ -667,23 +680,44 @@ def test_lk_decode_with_contrast_mask(ctx):
 def test_lk_push_frame_stream_matches_pairwise_decode(ctx):
     """ofps_hip_lk_push_frame keeps the previous frame on the device: over a sequence it must return what the stateless
     ofps_hip_lk_decode returns for each consecutive pair (masked and unmasked, down-sampled and per pixel), nothing for
-    the first frame, and start over after a reset, a geometry change or an interleaved stateless call."""
+    the first frame, and start over after a reset or a geometry change."""
     fr = synth.flatten_regions(synth.luma_sequence(5, 320, 180, max_step=2, seed=21), region=40, seed=3)
     for kw in (dict(), dict(contrast_mask=True), dict(per_pixel=True), dict(contrast_mask=True, per_pixel=True)):
         ctx.lk_reset()
         assert ctx.lk_push_frame(fr[0], **kw) is None
         for k in range(1, 5):
             ent, grid = ctx.lk_push_frame(fr[k], **kw)
-            ent_o, grid_o = ctx.lk_decode(fr[k - 1], fr[k], **kw)            # clobbers the stream's slots ...
+            ent_o, grid_o = ctx.lk_decode(fr[k - 1], fr[k], **kw)            # stateless: does not touch the stream's frames
             assert grid == grid_o
             np.testing.assert_array_equal(ent.view(np.uint32), ent_o.view(np.uint32))
-            assert ctx.lk_push_frame(fr[k]) is None                          # ... so the stream starts over
     ctx.lk_reset()
     assert ctx.lk_push_frame(fr[0]) is None
     assert ctx.lk_push_frame(fr[1]) is not None
     assert ctx.lk_push_frame(fr[0][:90, :160].copy()) is None                # geometry change
     ctx.lk_reset()
     assert ctx.lk_push_frame(fr[2]) is None
+
+
+def test_lk_push_frame_stream_survives_every_other_entry_point(ctx):
+    """The stream's previous frame lives in a device slot of its own: stateless calls that stage LARGER frames (they used to
+    share -- and reallocate -- the slot) between two pushes leave the stream intact: the second push returns the vectors
+    of (frame 0, frame 1), not of whatever the other call left behind."""
+    fr = synth.flatten_regions(synth.luma_sequence(3, 320, 180, max_step=2, seed=22), region=40, seed=4)
+    big = synth.luma_sequence(2, 640, 360, max_step=8, seed=23)
+    want = {k: ctx.lk_decode(fr[k - 1], fr[k]) for k in (1, 2)}
+    ctx.lk_reset()
+    assert ctx.lk_push_frame(fr[0]) is None
+    ctx.sad_flow(big[0], big[1], 16, 8)                                      # S_FRAMES regrown and overwritten
+    ctx.lk_flow(big[0], big[1], 3, 4, 3)
+    ctx.contrast_mask(big[1])
+    ctx.lk_decode(big[0], big[1])
+    ent, grid = ctx.lk_push_frame(fr[1])
+    assert grid == want[1][1]
+    np.testing.assert_array_equal(ent.view(np.uint32), want[1][0].view(np.uint32))
+    ctx.lk_decode(big[1], big[0], per_pixel=True)
+    ent, grid = ctx.lk_push_frame(fr[2])
+    assert grid == want[2][1]
+    np.testing.assert_array_equal(ent.view(np.uint32), want[2][0].view(np.uint32))
 
 
 @pytest.mark.parametrize("W,H,gw,gh", [(480, 270, 150, 84), (321, 123, 150, 57), (97, 61, 14, 14), (64, 48, 64, 48), (40, 30, 150, 84),

@@ -161,6 +161,25 @@ def test_sad_openmp_equals_scalar():
     np.testing.assert_array_equal(e1.view(np.uint32), e2.view(np.uint32))
 
 
+def test_almeida_all_core_forms_equal_the_single_thread_oracle_bit_for_bit():
+    """bench.py's all-core CPU leg times orc_solve_ypr_given_mt / orc_solve_ypr_ransac_mt: the
+    per-vector loops and the hypotheses are spread over OpenMP threads, every sum keeps its sequential order, the first
+    maximum wins -- so they are the single-thread restatement bit for bit, whatever the thread count."""
+    cam = oracle.camera(16 / 9, 22.275)
+    for shape, frac in (((120, 67), 0.2), ((64, 36), 0.0), ((7, 3), 0.0)):
+        e = synth.rotation_field(*shape, outlier_frac=frac)
+        q1 = oracle.solve_ypr_given(e, cam)
+        r1 = oracle.solve_ypr_ransac(e, cam, 50, 0.05, 1000, seed=9)
+        for t in (2, 3, 8):
+            np.testing.assert_array_equal(oracle.solve_ypr_given(e, cam, threads=t).view(np.uint32), q1.view(np.uint32))
+            np.testing.assert_array_equal(oracle.solve_ypr_ransac(e, cam, 50, 0.05, 1000, seed=9, threads=t).view(np.uint32),
+                                          r1.view(np.uint32))
+    # fewer than 3 inliers -> identity, in both forms (almeida-estimator/src/lib.rs:246-250)
+    e = synth.rotation_field(2, 1)
+    np.testing.assert_array_equal(oracle.solve_ypr_ransac(e, cam, 10, 0.05, 1000, seed=1, threads=4),
+                                  oracle.solve_ypr_ransac(e, cam, 10, 0.05, 1000, seed=1))
+
+
 def test_interpolate_empty_cells_fills_everything():
     e = _entries(40, 8)
     f = oracle.densify_interpolated(e, 12, 9)

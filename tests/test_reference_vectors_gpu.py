@@ -139,56 +139,153 @@ def test_hip_push_frame_1080p_matches_stagewise_oracle(ctx):
 
 
 # ---- cluster solver: what happens when its workgroups are not all there ------------------------------------------------
-def test_hip_almeida_cluster_timeout_falls_back_to_the_stepped_solver(ctx, monkeypatch):
-    """One workgroup withholds a granule (test hook): the others give up after their bounded spin, the kernel returns
-    NaN, and the host-pointer entry point re-solves with one launch per step -- same answer, no hang."""
+# The reference's estimator cannot fail (singular LU -> zero step, almeida-estimator/src/lib.rs:181-185; < 3 inliers ->
+# identity, :246-250).  The cluster kernel's bounded spin can expire (another process holding CUs); the LAST workgroup to
+# leave then solves the item alone inside the same launch.  The fault injector (one workgroup withholds its step-3
+# granule) exists only in libofps_hip_testhooks.so; the product library refuses to arm it.
+@pytest.fixture(scope="module")
+def hooks():
+    from ofps_amd.runtime import HipContext
+    c = HipContext(0, test_hooks=True)
+    yield c
+    c.set_option("OFPS_HIP_ALMEIDA_TEST_FAULT", None)
+    c.close()
+
+
+def test_product_library_refuses_the_fault_injectors(ctx):
+    from ofps_amd._lib import OfpsHipError
+    for name in ("OFPS_HIP_ALMEIDA_TEST_FAULT", "OFPS_HIP_LK_TEST_FALL"):
+        with pytest.raises(OfpsHipError) as ei:
+            ctx.set_option(name, "2")
+        assert ei.value.code == -3                     # OFPS_HIP_EUNSUPPORTED
+    with pytest.raises(OfpsHipError):
+        ctx.set_option("OFPS_HIP_NO_SUCH_SWITCH", "1")
+
+
+def test_hip_almeida_cluster_timeout_is_recovered_inside_the_launch(hooks):
+    """Host-pointer entry: same answer as the undisturbed launch and the oracle, no NaN, no hang; the recovery counter
+    says the in-kernel solve ran; the cluster path works again afterwards."""
     import time
     e = synth.rotation_field(480, 270)                       # 129,600 records -> 127 workgroups
     cam = oracle.camera(16 / 9, 22.275)
-    q_ok, _ = ctx.almeida(e, 16 / 9, 22.275, use_ransac=False)
-    monkeypatch.setenv("OFPS_HIP_ALMEIDA_TEST_FAULT", "2")
+    q_ok, _ = hooks.almeida(e, 16 / 9, 22.275, use_ransac=False)
+    r0 = hooks.almeida_recoveries()
+    hooks.set_option("OFPS_HIP_ALMEIDA_TEST_FAULT", "2")
     t0 = time.perf_counter()
-    q_fb, _ = ctx.almeida(e, 16 / 9, 22.275, use_ransac=False)
+    q_fb, _ = hooks.almeida(e, 16 / 9, 22.275, use_ransac=False)
     dt = time.perf_counter() - t0
-    monkeypatch.delenv("OFPS_HIP_ALMEIDA_TEST_FAULT")
+    hooks.set_option("OFPS_HIP_ALMEIDA_TEST_FAULT", None)
+    assert hooks.almeida_recoveries() == r0 + 1
     assert np.isfinite(q_fb).all() and dt < 20.0
     np.testing.assert_allclose(q_fb, oracle.solve_ypr_given(e, cam), atol=2e-6, rtol=0)
     np.testing.assert_allclose(q_fb, q_ok, atol=2e-6, rtol=0)
-    q_again, _ = ctx.almeida(e, 16 / 9, 22.275, use_ransac=False)          # and the cluster path works again afterwards
+    q_again, _ = hooks.almeida(e, 16 / 9, 22.275, use_ransac=False)          # and the cluster path works again afterwards
     np.testing.assert_allclose(q_again, q_ok, atol=0, rtol=0)
+    assert hooks.almeida_recoveries() == r0 + 1
+
+
+def test_hip_almeida_dev_batch_timeout_is_recovered_per_item(hooks):
+    """Device-pointer entry (never synchronises, so nothing on the host could re-solve): batch of 3 fields, every item's
+    cluster loses a granule, every item comes back finite and within 2e-6 of the oracle."""
+    import torch
+    shape = (160, 90)                                        # 14,400 records per item: cluster path for batches (> 8,192)
+    fields = [synth.rotation_field(*shape, euler_deg=(0.5 + 0.2 * k, 0.3 - 0.1 * k, -0.2 + 0.15 * k), seed=synth.SEED0 + 40 + k)
+              for k in range(3)]
+    cam = oracle.camera(16 / 9, 22.275)
+    d_ent = torch.from_numpy(np.stack(fields)).cuda()
+    d_q = torch.full((3, 4), float("nan"), dtype=torch.float32, device="cuda")
+    r0 = hooks.almeida_recoveries()
+    hooks.set_option("OFPS_HIP_ALMEIDA_TEST_FAULT", "1")
+    hooks.use_torch_stream()
+    try:
+        hooks.almeida_dev(d_ent.data_ptr(), shape[0] * shape[1], 3, 16 / 9, 22.275, False, 200, 0.05, 1000, 0, d_q.data_ptr())
+        torch.cuda.synchronize()
+    finally:
+        hooks.use_own_stream()
+        hooks.set_option("OFPS_HIP_ALMEIDA_TEST_FAULT", None)
+    q = d_q.cpu().numpy()
+    assert np.isfinite(q).all()
+    assert hooks.almeida_recoveries() == r0 + 3
+    for k in range(3):
+        np.testing.assert_allclose(q[k], oracle.solve_ypr_given(fields[k], cam), atol=2e-6, rtol=0)
+
+
+def test_hip_push_frame_async_ticket_survives_a_cluster_timeout(hooks):
+    """cfg5's product path: a 1080p ticket (8,040 block vectors -> 8-workgroup cluster) whose estimator launch loses a
+    granule still hands frame_wait the oracle's quaternion -- never NaN."""
+    W, H = 1920, 1080
+    fr = synth.luma_sequence(3, W, H, max_step=16, seed=synth.SEED0 + 81)
+    cam = oracle.camera(16 / 9, 22.275)
+    kw = dict(block=16, search_range=16, aspect=16 / 9, fov_y_deg=22.275)
+    pinned = [hooks.pinned_array((H, W), np.uint8) for _ in range(3)]
+    for k in range(3):
+        pinned[k][...] = fr[k]
+    hooks.reset_frames()
+    r0 = hooks.almeida_recoveries()
+    hooks.set_option("OFPS_HIP_ALMEIDA_TEST_FAULT", "3")
+    try:
+        t0 = hooks.push_frame_async(pinned[0], **kw)
+        res0 = hooks.frame_wait(t0)
+        assert not res0["have_vectors"]
+        t1 = hooks.push_frame_async(pinned[1], **kw)
+        t2 = hooks.push_frame_async(pinned[2], **kw)
+        res = [hooks.frame_wait(t1), hooks.frame_wait(t2)]
+    finally:
+        hooks.set_option("OFPS_HIP_ALMEIDA_TEST_FAULT", None)
+    assert hooks.almeida_recoveries() == r0 + 2
+    for k, r in enumerate(res):
+        assert r["have_vectors"] and np.isfinite(r["quat"]).all()
+        ent_o, _ = oracle.sad_flow(fr[k], fr[k + 1], 16, 16)
+        np.testing.assert_allclose(r["quat"], oracle.solve_ypr_given(ent_o, cam), atol=2e-6, rtol=0)
+    # the synchronous form too
+    hooks.reset_frames()
+    hooks.push_frame(fr[0], **kw)
+    hooks.set_option("OFPS_HIP_ALMEIDA_TEST_FAULT", "1")
+    try:
+        r = hooks.push_frame(fr[1], **kw)
+    finally:
+        hooks.set_option("OFPS_HIP_ALMEIDA_TEST_FAULT", None)
+    ent_o, _ = oracle.sad_flow(fr[0], fr[1], 16, 16)
+    np.testing.assert_allclose(r["quat"], oracle.solve_ypr_given(ent_o, cam), atol=2e-6, rtol=0)
 
 
 @pytest.mark.parametrize("shape", [(120, 67), (480, 270), (960, 540)])
-def test_hip_almeida_cluster_two_level_gather_matches_the_flat_gather(ctx, monkeypatch, shape):
+def test_hip_almeida_cluster_two_level_gather_matches_the_flat_gather(hooks, shape):
     """Steps >= 1 of launches with >= 32 workgroups gather per XCD first (plain stores found in the XCD's L2), then across
     the XCDs; OFPS_HIP_ALMEIDA_HIER=0 forces the flat all-to-all gather, =2 the two-level one at any size.  Both are fixed
-    summation orders of the same partials: each within 2e-6 of the oracle and of the other; a withheld granule times
-    out in the two-level form as well."""
+    summation orders of the same partials: each within 2e-6 of the oracle and of the other; a withheld granule is
+    recovered in the two-level form as well."""
     e = synth.rotation_field(*shape)
     cam = oracle.camera(16 / 9, 22.275)
     q_o = oracle.solve_ypr_given(e, cam)
     qs = {}
-    for mode in ("0", "2"):
-        monkeypatch.setenv("OFPS_HIP_ALMEIDA_HIER", mode)
-        qs[mode], _ = ctx.almeida(e, 16 / 9, 22.275, use_ransac=False)
-        np.testing.assert_allclose(qs[mode], q_o, atol=2e-6, rtol=0)
-    np.testing.assert_allclose(qs["0"], qs["2"], atol=2e-6, rtol=0)
-    monkeypatch.setenv("OFPS_HIP_ALMEIDA_TEST_FAULT", "2")
-    q_fb, _ = ctx.almeida(e, 16 / 9, 22.275, use_ransac=False)
-    monkeypatch.delenv("OFPS_HIP_ALMEIDA_TEST_FAULT")
+    try:
+        for mode in ("0", "2"):
+            hooks.set_option("OFPS_HIP_ALMEIDA_HIER", mode)
+            qs[mode], _ = hooks.almeida(e, 16 / 9, 22.275, use_ransac=False)
+            np.testing.assert_allclose(qs[mode], q_o, atol=2e-6, rtol=0)
+        np.testing.assert_allclose(qs["0"], qs["2"], atol=2e-6, rtol=0)
+        hooks.set_option("OFPS_HIP_ALMEIDA_TEST_FAULT", "2")
+        q_fb, _ = hooks.almeida(e, 16 / 9, 22.275, use_ransac=False)
+    finally:
+        hooks.set_option("OFPS_HIP_ALMEIDA_TEST_FAULT", None)
+        hooks.set_option("OFPS_HIP_ALMEIDA_HIER", None)
     np.testing.assert_allclose(q_fb, q_o, atol=2e-6, rtol=0)
 
 
 @pytest.mark.parametrize("fast", ["0", "1"])
-def test_hip_almeida_arithmetic_switch_stays_inside_the_parity_bound(ctx, monkeypatch, fast):
+def test_hip_almeida_arithmetic_switch_stays_inside_the_parity_bound(ctx, fast):
     """OFPS_HIP_ALMEIDA_FAST forces the exact (IEEE division, unfused) or the folded arithmetic of the cluster solver at any
     field size (A/B runs): either way the quaternion stays within 2e-6 of the oracle's, below and above the 65,536 switch."""
-    monkeypatch.setenv("OFPS_HIP_ALMEIDA_FAST", fast)
-    cam = oracle.camera(16 / 9, 22.275)
-    for shape in ((120, 67), (480, 270)):
-        e = synth.rotation_field(*shape)
-        q, _ = ctx.almeida(e, 16 / 9, 22.275, use_ransac=False)
-        np.testing.assert_allclose(q, oracle.solve_ypr_given(e, cam), atol=2e-6, rtol=0)
+    ctx.set_option("OFPS_HIP_ALMEIDA_FAST", fast)
+    try:
+        cam = oracle.camera(16 / 9, 22.275)
+        for shape in ((120, 67), (480, 270)):
+            e = synth.rotation_field(*shape)
+            q, _ = ctx.almeida(e, 16 / 9, 22.275, use_ransac=False)
+            np.testing.assert_allclose(q, oracle.solve_ypr_given(e, cam), atol=2e-6, rtol=0)
+    finally:
+        ctx.set_option("OFPS_HIP_ALMEIDA_FAST", None)
 
 
 # ---- read-ahead form of the per-frame path: same bits as the synchronous call, two tickets in flight -------------------

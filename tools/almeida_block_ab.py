@@ -15,13 +15,12 @@ for (w, h) in ((120, 67), (150, 84), (240, 135), (480, 270), (1920, 1080)):
     q = torch.empty((1, 4), dtype=torch.float32, device="cuda")
     for block, ept in ((1024, 0), (256, 1), (256, 2)):
         if block == 256 and (n + ept * 256 - 1) // (ept * 256) > 256: continue
-        os.environ["OFPS_HIP_ALMEIDA_PATH"] = "cluster"
-        os.environ["OFPS_HIP_ALMEIDA_BLOCK"] = str(block)
-        if ept: os.environ["OFPS_HIP_ALMEIDA_EPT"] = str(ept)
-        else: os.environ.pop("OFPS_HIP_ALMEIDA_EPT", None)
-        os.environ.pop("OFPS_HIP_ALMEIDA_PROF", None)
+        ctx.set_option("OFPS_HIP_ALMEIDA_PATH", "cluster")
+        ctx.set_option("OFPS_HIP_ALMEIDA_BLOCK", block)
+        ctx.set_option("OFPS_HIP_ALMEIDA_EPT", ept or None)
+        ctx.set_option("OFPS_HIP_ALMEIDA_PROF", None)
         f = lambda: ctx.almeida_dev(d.data_ptr(), n, 1, 16 / 9, 22.275, False, 0, 0.05, 0, 0, q.data_ptr())
         ms = timeit(f)
         print(f"n={n} block={block} ept={ept or 'auto'}: {ms:.4f} ms  q={q.cpu().numpy().ravel()}", file=sys.stderr, flush=True)
-        os.environ["OFPS_HIP_ALMEIDA_PROF"] = "1"
+        ctx.set_option("OFPS_HIP_ALMEIDA_PROF", 1)
         f(); torch.cuda.synchronize()

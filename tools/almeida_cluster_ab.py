@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """A/B of the LSQ drivers on one MI355X: cluster solver (one launch, granule exchange) vs one launch per step vs the
 one-workgroup kernel, over problem sizes; prints JSON with ms per estimate and the quaternion each path returns.
-Paths are forced with OFPS_HIP_ALMEIDA_PATH / OFPS_HIP_ALMEIDA_EPT (read per call by almeida.hip)."""
+Paths are forced with the OFPS_HIP_ALMEIDA_PATH / OFPS_HIP_ALMEIDA_EPT switches (ofps_hip_set_option on the live context)."""
 import json, os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -16,13 +16,15 @@ def timeit(fn, n=20, warm=3):
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e3
 
 
+ctx = HipContext(0); ctx.use_torch_stream()
+
+
 def setenv(path, ept):
     for k, v in (("OFPS_HIP_ALMEIDA_PATH", path), ("OFPS_HIP_ALMEIDA_EPT", ept)):
-        if v is None: os.environ.pop(k, None)
-        else: os.environ[k] = str(v)
+        ctx.set_option(k, v)
 
 
-ctx = HipContext(0); ctx.use_torch_stream()
+
 out = {}
 sizes = [(64, 36), (120, 67), (150, 84), (240, 135), (480, 270), (960, 540), (1920, 1080)]
 for (w, h) in sizes:

@@ -6,7 +6,7 @@ from ofps_amd import synth
 from ofps_amd.runtime import HipContext
 ctx = HipContext(0); ctx.use_torch_stream()
 for mode in ("0", "1"):
-    os.environ["OFPS_HIP_ALMEIDA_FAST"] = mode
+    ctx.set_option("OFPS_HIP_ALMEIDA_FAST", mode)
     worst = 0.0
     for (w, h) in ((120, 67), (150, 84), (240, 135)):
         d = synth.rotation_field(w, h); n = w * h

@@ -20,10 +20,10 @@ for (w, h) in ((120, 67), (150, 84), (480, 270), (960, 540), (1920, 1080)):
     q = torch.empty((1, 4), dtype=torch.float32, device="cuda")
     for ept in (1, 2, 4, 8):
         if (n + ept * 1024 - 1) // (ept * 1024) > 256: continue
-        os.environ["OFPS_HIP_ALMEIDA_PATH"] = "cluster"; os.environ["OFPS_HIP_ALMEIDA_EPT"] = str(ept)
-        os.environ.pop("OFPS_HIP_ALMEIDA_PROF", None)
+        ctx.set_option("OFPS_HIP_ALMEIDA_PATH", "cluster"); ctx.set_option("OFPS_HIP_ALMEIDA_EPT", ept)
+        ctx.set_option("OFPS_HIP_ALMEIDA_PROF", None)
         ms = timeit(lambda: ctx.almeida_dev(d.data_ptr(), n, 1, 16 / 9, 22.275, False, 0, 0.05, 0, 0, q.data_ptr()))
         print(f"n={n} ept={ept}: {ms:.4f} ms", file=sys.stderr, flush=True)
-        os.environ["OFPS_HIP_ALMEIDA_PROF"] = "1"
+        ctx.set_option("OFPS_HIP_ALMEIDA_PROF", 1)
         ctx.almeida_dev(d.data_ptr(), n, 1, 16 / 9, 22.275, False, 0, 0.05, 0, 0, q.data_ptr())
         torch.cuda.synchronize()
