@@ -36,7 +36,7 @@ SAD_PEAK = 256 * 4 * 2.4e9 * 64.0                          # |a-b| per second, s
 LK_SPEC_OPS_PER_TAP = 11                                   # 81 taps x 11 f32 operations per pixel-step (r = 4)
 
 
-def _event_ms(ctx, fn, reps, warm=3):
+def _event_ms(ctx, fn, reps, warm=25):
     """Average milliseconds of fn() between HIP events on the context's stream."""
     for _ in range(warm):
         fn()
@@ -47,7 +47,7 @@ def _event_ms(ctx, fn, reps, warm=3):
     return ctx.timer_stop() / reps
 
 
-def cfg3_chain_leg(device: int = 0, reps: int = 30) -> dict:
+def cfg3_chain_leg(device: int = 0, reps: int = 60) -> dict:
     import torch
     from ofps_amd import synth
     from ofps_amd.runtime import HipContext
@@ -75,7 +75,8 @@ def cfg3_chain_leg(device: int = 0, reps: int = 30) -> dict:
     lk_ms = _event_ms(ctx, lk, reps)
     den_ms = _event_ms(ctx, den, reps)
     alm_ms = _event_ms(ctx, alm, reps)
-    chain()
+    for _ in range(10):
+        chain()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(reps):

@@ -23,6 +23,29 @@ namespace ofps {
 
 __device__ __forceinline__ int lk_clampi(int v, int lo, int hi) { return max(lo, min(v, hi)); }   // lo <= hi everywhere: v_max_i32 + v_min_i32 (or one v_med3_i32)
 
+// The arithmetic of one window tap, in ONE place (spec: oracle/ofps_oracle.c:orc_lk_flow, DESIGN.md "N2").
+// Revision 2 of the build-defined spec fuses the multiply-adds of the bilinear sample and of the two residual sums --
+// lerp(a, b, t) = fma(t, b - a, a); b += g * d as fma(g, d, b) -- 7 operations per tap instead of 11, each result rounded
+// once instead of twice.  OFPS_LK_SPEC_FMA = 0 rebuilds revision 1 (separate multiply and add) for A/B runs; the oracle
+// (oracle/ofps_oracle.c) carries the same switch and the two must be built alike.
+#ifndef OFPS_LK_SPEC_FMA
+#define OFPS_LK_SPEC_FMA 0
+#endif
+__device__ __forceinline__ float lk_lerp(float a, float b, float t) {
+#if OFPS_LK_SPEC_FMA
+    return __builtin_fmaf(t, b - a, a);
+#else
+    return a + t * (b - a);
+#endif
+}
+__device__ __forceinline__ void lk_accum(float g, float d, float& b) {
+#if OFPS_LK_SPEC_FMA
+    b = __builtin_fmaf(g, d, b);
+#else
+    b += g * d;
+#endif
+}
+
 // wave-wide integer min / max on the DPP data path (cross-lane operands of ordinary VALU instructions; __shfl_xor is
 // six dependent ds_bpermute_b32 per value).  Result is wave-uniform (read from lane 63).
 template <bool MAX, int CTRL, int ROW_MASK = 0xF>
@@ -193,9 +216,9 @@ __device__ __forceinline__ float lk_bilinear(const float* __restrict__ J, int w,
     const int xa = lk_clampi(x0, 0, w - 1), xb = lk_clampi(x0 + 1, 0, w - 1);
     const int ya = lk_clampi(y0, 0, h - 1), yb = lk_clampi(y0 + 1, 0, h - 1);
     const float j00 = J[(size_t)ya * w + xa], j10 = J[(size_t)ya * w + xb], j01 = J[(size_t)yb * w + xa], j11 = J[(size_t)yb * w + xb];
-    const float top = j00 + ax * (j10 - j00);
-    const float bot = j01 + ax * (j11 - j01);
-    return top + ay * (bot - top);
+    const float top = lk_lerp(j00, j10, ax);
+    const float bot = lk_lerp(j01, j11, ax);
+    return lk_lerp(top, bot, ay);
 }
 
 // One Gauss-Newton step for every pixel.  RADIUS > 0: compile-time window; the per-sample floor/clamp of the
@@ -240,11 +263,11 @@ __global__ __launch_bounds__(256) void lk_step_kernel(const float* __restrict__ 
 #pragma unroll
             for (int k = 0; k < N; ++k) {
                 const float j00 = ra[xa[k]], j10 = ra[xb[k]], j01 = rb[xa[k]], j11 = rb[xb[k]];
-                const float top = j00 + ax[k] * (j10 - j00);
-                const float bot = j01 + ax[k] * (j11 - j01);
-                const float d = I[row + qx[k]] - (top + ay * (bot - top));
-                bx += gx[row + qx[k]] * d;
-                by += gy[row + qx[k]] * d;
+                const float top = lk_lerp(j00, j10, ax[k]);
+                const float bot = lk_lerp(j01, j11, ax[k]);
+                const float d = I[row + qx[k]] - lk_lerp(top, bot, ay);
+                lk_accum(gx[row + qx[k]], d, bx);
+                lk_accum(gy[row + qx[k]], d, by);
             }
         }
     } else {
@@ -254,8 +277,8 @@ __global__ __launch_bounds__(256) void lk_step_kernel(const float* __restrict__ 
             for (int dx = -radius; dx <= radius; ++dx) {
                 const int qx = lk_clampi(x + dx, 0, w - 1);
                 const float d = I[row + qx] - lk_bilinear(J, w, h, (float)qx + f.x, (float)qy + f.y);
-                bx += gx[row + qx] * d;
-                by += gy[row + qx] * d;
+                lk_accum(gx[row + qx], d, bx);
+                lk_accum(gy[row + qx], d, by);
             }
         }
     }
@@ -613,7 +636,7 @@ __global__ __launch_bounds__(256, LkStepShared<RADIUS>::WAVES_PER_SIMD) void lk_
 #pragma unroll
                         for (int k = 0; k <= N; ++k) jb[k] = ra[k];
 #pragma unroll
-                        for (int k = 0; k < N; ++k) hup[k] = jb[k] + ax[k] * (jb[k + 1] - jb[k]);
+                        for (int k = 0; k < N; ++k) hup[k] = lk_lerp(jb[k], jb[k + 1], ax[k]);
                     }
                     const float* rb = &sh.jl[yi + 1][xo];
 #pragma unroll
@@ -621,11 +644,11 @@ __global__ __launch_bounds__(256, LkStepShared<RADIUS>::WAVES_PER_SIMD) void lk_
 #pragma unroll
                     for (int k = 0; k < N; ++k) {
                         const float top = hup[k];
-                        const float bot = jb[k] + ax[k] * (jb[k + 1] - jb[k]);
+                        const float bot = lk_lerp(jb[k], jb[k + 1], ax[k]);
                         const lk_f4 t = lk_lds_read4(&sh.tile[ly + r][lx + k]);
-                        const float d = t.x - (top + ay * (bot - top));
-                        bx += t.y * d;
-                        by += t.z * d;
+                        const float d = t.x - lk_lerp(top, bot, ay);
+                        lk_accum(t.y, d, bx);
+                        lk_accum(t.z, d, by);
                         hup[k] = bot;
                     }
                 }
@@ -641,18 +664,18 @@ __global__ __launch_bounds__(256, LkStepShared<RADIUS>::WAVES_PER_SIMD) void lk_
                     if (!reuse) {
                         const float* ra = &sh.jl[yi][0];
 #pragma unroll
-                        for (int k = 0; k < N; ++k) { const float j0 = ra[xi[k]], j1 = ra[xi[k] + 1]; hup[k] = j0 + ax[k] * (j1 - j0); }
+                        for (int k = 0; k < N; ++k) { const float j0 = ra[xi[k]], j1 = ra[xi[k] + 1]; hup[k] = lk_lerp(j0, j1, ax[k]); }
                     }
                     const float* rb = &sh.jl[yi + 1][0];
 #pragma unroll
                     for (int k = 0; k < N; ++k) {
                         const float j0 = rb[xi[k]], j1 = rb[xi[k] + 1];
                         const float top = hup[k];
-                        const float bot = j0 + ax[k] * (j1 - j0);
+                        const float bot = lk_lerp(j0, j1, ax[k]);
                         const lk_f4 t = lk_lds_read4(&sh.tile[ly + r][lx + k]);
-                        const float d = t.x - (top + ay * (bot - top));
-                        bx += t.y * d;
-                        by += t.z * d;
+                        const float d = t.x - lk_lerp(top, bot, ay);
+                        lk_accum(t.y, d, bx);
+                        lk_accum(t.z, d, by);
                         hup[k] = bot;
                     }
                 }
@@ -725,12 +748,12 @@ __global__ __launch_bounds__(256) void lk_level_general_kernel(const float* __re
                     float j10 = jt[k + 1], j11 = jb[k + 1];
                     if (k < N - 1 && xb[k] != xa[k + 1]) { j10 = ra[xb[k]]; j11 = rb[xb[k]]; }     // clamped border / rounding: rare
                     const float j00 = jt[k], j01 = jb[k];
-                    const float top = j00 + ax[k] * (j10 - j00);
-                    const float bot = j01 + ax[k] * (j11 - j01);
+                    const float top = lk_lerp(j00, j10, ax[k]);
+                    const float bot = lk_lerp(j01, j11, ax[k]);
                     const float4 t = tile[ly + r][lx + k];
-                    const float d = t.x - (top + ay * (bot - top));
-                    bx += t.y * d;
-                    by += t.z * d;
+                    const float d = t.x - lk_lerp(top, bot, ay);
+                    lk_accum(t.y, d, bx);
+                    lk_accum(t.z, d, by);
                 }
             }
             f = lk_solve(g, f, bx, by);
