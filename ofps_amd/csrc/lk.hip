@@ -29,7 +29,7 @@ __device__ __forceinline__ int lk_clampi(int v, int lo, int hi) { return max(lo,
 // once instead of twice.  OFPS_LK_SPEC_FMA = 0 rebuilds revision 1 (separate multiply and add) for A/B runs; the oracle
 // (oracle/ofps_oracle.c) carries the same switch and the two must be built alike.
 #ifndef OFPS_LK_SPEC_FMA
-#define OFPS_LK_SPEC_FMA 0
+#define OFPS_LK_SPEC_FMA 1
 #endif
 __device__ __forceinline__ float lk_lerp(float a, float b, float t) {
 #if OFPS_LK_SPEC_FMA
@@ -305,6 +305,7 @@ __global__ __launch_bounds__(256) void lk_step_kernel(const float* __restrict__ 
 // tile stages fewer window elements per pixel (2.5 vs 3.4) and its rectangle tolerates wilder flows; 16 lanes per row
 // lose on the 16-byte staging rows.
 constexpr int kTX = 32, kTY = 8;
+constexpr int kJMargin = 2;          // pixels of slack staged around the current frame's rectangle (lk_level_lds_kernel)
 
 template <int RADIUS>
 struct LkTile {
@@ -424,6 +425,77 @@ __global__ __launch_bounds__(256) void lk_tensor_tiled_kernel(const float* __res
         if (y0 + ly + q < h) G[(size_t)(y0 + ly + q) * w + x] = make_float4(gxx[q], gxy[q], gyy[q], 0.0f);
 }
 
+// One window row of the level kernel at radius 4 (9 taps), spec revision 2, hand-scheduled.  hipcc's own code for this loop
+// copies the carried interpolation row (8 v_mov per row), re-reads every tile record into the same four registers with a
+// full wait in front of each use, and -- asked to unroll by two so that the carried row could change name instead of
+// registers -- hoists LDS reads until it spills 100 registers.  Here:
+//   * l0..l9 receive the ten texels of sample row yi + 1 and are turned IN PLACE into that row's nine horizontal
+//     interpolations (v_fmac: l[k] = ax[k] * (l[k+1] - l[k]) + l[k]); t0..t8 hold the previous sample row's and are
+//     consumed in place (t[k] = ay * (l[k] - t[k]) + t[k], the bilinear sample).  The caller alternates two register sets
+//     between the roles, so nothing is ever copied;
+//   * the tile records (I, gx, gy, -) are double-buffered in two fixed register quads, the read of tap k + 2 issued as
+//     soon as tap k's quad is free: one LDS latency is exposed per row instead of nine;
+//   * 7 VALU operations per tap (the spec's count), 63 per row.
+// Same operations on the same operands in the same order as the C++ form (lk_lerp / lk_accum): same bits.
+// The quads are v[72:75] / v[76:79]: the top of the 80-register budget of a 256-thread workgroup at 6 waves per SIMD.
+#define LK_ROW9_TAP(K, KN, WAIT, NEXT)                                        \
+    "v_sub_f32 %[tmp], %[l" #KN "], %[l" #K "]\n\t"                             \
+    "v_fmac_f32 %[l" #K "], %[a" #K "], %[tmp]\n\t"                             \
+    "v_sub_f32 %[tmp], %[l" #K "], %[t" #K "]\n\t"                              \
+    "v_fmac_f32 %[t" #K "], %[ay], %[tmp]\n\t"                                  \
+    "s_waitcnt lgkmcnt(" #WAIT ")\n\t"                                          \
+    NEXT
+#define LK_ROW9_USE(K, Q0, Q1, Q2, ISSUE)                                     \
+    "v_sub_f32 %[tmp], " Q0 ", %[t" #K "]\n\t"                                 \
+    "v_fmac_f32 %[bx], " Q1 ", %[tmp]\n\t"                                     \
+    "v_fmac_f32 %[by], " Q2 ", %[tmp]\n\t"                                     \
+    ISSUE
+// r[0..18] are the two register sets: PARITY 0: l = r[0..9], t = r[10..18]; PARITY 1: l = r[10..18] + r[9], t = r[0..8] --
+// after a PARITY 0 row the nine interpolations of its lower sample row sit in r[0..8], exactly where a PARITY 1 row
+// expects its upper row, and vice versa.
+template <int PARITY>
+__device__ __forceinline__ void lk_row9_asm(float (&r)[19], const float (&a)[9], float ay, float& bx, float& by, uint32_t jaddr,
+                                            uint32_t taddr) {
+    constexpr auto L = [](int k) constexpr { return PARITY ? (k < 9 ? 10 + k : 9) : k; };
+    constexpr auto T = [](int k) constexpr { return PARITY ? k : 10 + k; };
+    float tmp;
+    asm volatile(
+        "ds_read_b32 %[l0], %[ja]\n\t"
+        "ds_read_b32 %[l1], %[ja] offset:4\n\t"
+        "ds_read_b32 %[l2], %[ja] offset:8\n\t"
+        "ds_read_b32 %[l3], %[ja] offset:12\n\t"
+        "ds_read_b32 %[l4], %[ja] offset:16\n\t"
+        "ds_read_b32 %[l5], %[ja] offset:20\n\t"
+        "ds_read_b32 %[l6], %[ja] offset:24\n\t"
+        "ds_read_b32 %[l7], %[ja] offset:28\n\t"
+        "ds_read_b32 %[l8], %[ja] offset:32\n\t"
+        "ds_read_b32 %[l9], %[ja] offset:36\n\t"
+        "ds_read_b128 v[72:75], %[ta]\n\t"
+        "ds_read_b128 v[76:79], %[ta] offset:16\n\t"
+        "s_waitcnt lgkmcnt(10)\n\t"                                            // l0, l1 are there
+        // tap k: horizontal + vertical interpolation while its tile record is in flight, then the residual sums; the quad
+        // it used is refilled with tap k + 2's record.  Waits: 12 reads issued; before tap k's first use of l[k+1] at most
+        // 10 - k of the texel reads ... may be outstanding behind the two tile reads (counted below per tap).
+        LK_ROW9_TAP(0, 1, 1, "") LK_ROW9_USE(0, "v72", "v73", "v74", "ds_read_b128 v[72:75], %[ta] offset:32\n\t")
+        LK_ROW9_TAP(1, 2, 1, "") LK_ROW9_USE(1, "v76", "v77", "v78", "ds_read_b128 v[76:79], %[ta] offset:48\n\t")
+        LK_ROW9_TAP(2, 3, 1, "") LK_ROW9_USE(2, "v72", "v73", "v74", "ds_read_b128 v[72:75], %[ta] offset:64\n\t")
+        LK_ROW9_TAP(3, 4, 1, "") LK_ROW9_USE(3, "v76", "v77", "v78", "ds_read_b128 v[76:79], %[ta] offset:80\n\t")
+        LK_ROW9_TAP(4, 5, 1, "") LK_ROW9_USE(4, "v72", "v73", "v74", "ds_read_b128 v[72:75], %[ta] offset:96\n\t")
+        LK_ROW9_TAP(5, 6, 1, "") LK_ROW9_USE(5, "v76", "v77", "v78", "ds_read_b128 v[76:79], %[ta] offset:112\n\t")
+        LK_ROW9_TAP(6, 7, 1, "") LK_ROW9_USE(6, "v72", "v73", "v74", "ds_read_b128 v[72:75], %[ta] offset:128\n\t")
+        LK_ROW9_TAP(7, 8, 1, "") LK_ROW9_USE(7, "v76", "v77", "v78", "")
+        LK_ROW9_TAP(8, 9, 0, "") LK_ROW9_USE(8, "v72", "v73", "v74", "")
+        : [l0] "=&v"(r[L(0)]), [l1] "=&v"(r[L(1)]), [l2] "=&v"(r[L(2)]), [l3] "=&v"(r[L(3)]), [l4] "=&v"(r[L(4)]), [l5] "=&v"(r[L(5)]),
+          [l6] "=&v"(r[L(6)]), [l7] "=&v"(r[L(7)]), [l8] "=&v"(r[L(8)]), [l9] "=&v"(r[L(9)]),
+          [t0] "+v"(r[T(0)]), [t1] "+v"(r[T(1)]), [t2] "+v"(r[T(2)]), [t3] "+v"(r[T(3)]), [t4] "+v"(r[T(4)]), [t5] "+v"(r[T(5)]),
+          [t6] "+v"(r[T(6)]), [t7] "+v"(r[T(7)]), [t8] "+v"(r[T(8)]), [bx] "+v"(bx), [by] "+v"(by), [tmp] "=&v"(tmp)
+        : [a0] "v"(a[0]), [a1] "v"(a[1]), [a2] "v"(a[2]), [a3] "v"(a[3]), [a4] "v"(a[4]), [a5] "v"(a[5]), [a6] "v"(a[6]), [a7] "v"(a[7]),
+          [a8] "v"(a[8]), [ay] "v"(ay), [ja] "v"(jaddr), [ta] "v"(taddr)
+        : "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "memory");
+}
+#undef LK_ROW9_TAP
+#undef LK_ROW9_USE
+
 // Current-frame window in LDS.  The bilinear fetches J(q + flow(p)) of a workgroup land in the rectangle
 // [tile + window] shifted by the flows of its pixels; when those flows differ by at most SPREAD_X / SPREAD_Y pixels (almost every
 // tile) the rectangle fits jl[][] and is staged once, coordinates clamped at staging time exactly like the oracle
@@ -445,7 +517,7 @@ struct LkStepShared {
     // row are reachable from one address register, behind the tile each pair costs a v_add_u32
     alignas(16) float jl[LH][JS];
     float4 tile[T::TH][T::TW];         // (I, gx, gy, -) of the previous frame's window
-    int box[4][4];                     // per wave: min x0, max x0+1, min y0, max y0+1
+    int box[2][4][5];                  // [step parity][wave]: min x0, max x0+1, min y0, max y0+1, every lane's window columns consecutive
     // what the LDS footprint allows (160 KB per CU, 4 waves per workgroup): the register budget hipcc is held to
     // (radius 4 measured at 5 / 6 / 7 waves per SIMD: 0.396 / 0.380 / 0.411 ms -- 94 registers without spills, 80 with 3
     // spilled outside the row loop, 72 with 11)
@@ -536,6 +608,8 @@ __global__ __launch_bounds__(256, LkStepShared<RADIUS>::WAVES_PER_SIMD) void lk_
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const bool active = px < w && py < h;
     float2 f = active ? lk_flow_read(io, px, py) : make_float2(0.0f, 0.0f);
+    bool st_valid = false;                                   // the rectangle of the current frame held in jl[][] (uniform)
+    int st_x0 = 0, st_x1 = -1, st_y0 = 0, st_y1 = -1, st_xs = 0;
 #pragma unroll 1
     for (int it = 0; it < iters; ++it) {
         // the pixel coordinates pass through an empty asm so that the compiler does not hoist the clamped window
@@ -560,55 +634,67 @@ __global__ __launch_bounds__(256, LkStepShared<RADIUS>::WAVES_PER_SIMD) void lk_
             int by0 = active ? yt : 0x7FFFFFFF, by1 = active ? yb_ + 1 : -0x7FFFFFFF;
             bx0 = lk_wave_minmax<false>(bx0); bx1 = lk_wave_minmax<true>(bx1);
             by0 = lk_wave_minmax<false>(by0); by1 = lk_wave_minmax<true>(by1);
-            // (the previous step's readers of box[] are all past that step's later barriers)
-            if (lane == 0) { sh.box[wave][0] = bx0; sh.box[wave][1] = bx1; sh.box[wave][2] = by0; sh.box[wave][3] = by1; }
+            // window columns that sample consecutive texels (x0[k+1] == x0[k] + 1: everywhere but at the left/right image
+            // border, where the clamped window columns repeat) share one row of N+1 texels; otherwise every column reads
+            // its own pair.  Decided per workgroup, through the same exchange as the box (no barrier of its own).
+            const int cons = __all(consecutive || !active) ? 1 : 0;
+            // (slots alternate with the step: a step that reuses the staged rectangle has no second barrier, so a fast wave
+            // may write the next step's box while a slow one still reads this step's)
+            if (lane == 0) { int* b = sh.box[it & 1][wave]; b[0] = bx0; b[1] = bx1; b[2] = by0; b[3] = by1; b[4] = cons; }
         }
         if (it == 0) OFPS_LK_STAMP(1);
         __syncthreads();                                                 // also: everybody is done reading jl[] of the previous step
         if (it == 0) OFPS_LK_STAMP(2);
-        const int xmin = min(min(sh.box[0][0], sh.box[1][0]), min(sh.box[2][0], sh.box[3][0]));
-        const int xmax = max(max(sh.box[0][1], sh.box[1][1]), max(sh.box[2][1], sh.box[3][1]));
-        const int ymin = min(min(sh.box[0][2], sh.box[1][2]), min(sh.box[2][2], sh.box[3][2]));
-        const int ymax = max(max(sh.box[0][3], sh.box[1][3]), max(sh.box[2][3], sh.box[3][3]));
-        const int fits = xmax >= xmin && xmax - xmin < S::LW && ymax - ymin < S::LH &&
+        const int (*bq)[5] = sh.box[it & 1];
+        const int xmin = min(min(bq[0][0], bq[1][0]), min(bq[2][0], bq[3][0]));
+        const int xmax = max(max(bq[0][1], bq[1][1]), max(bq[2][1], bq[3][1]));
+        const int bymin = min(min(bq[0][2], bq[1][2]), min(bq[2][2], bq[3][2]));
+        const int ymax = max(max(bq[0][3], bq[1][3]), max(bq[2][3], bq[3][3]));
+        const bool all_consecutive = (bq[0][4] & bq[1][4] & bq[2][4] & bq[3][4]) != 0;
+        const int fits = xmax >= xmin && xmax - xmin < S::LW && ymax - bymin < S::LH &&
                          !(it == force_fall && ((tile_x + tile_y) & 1));
         if (!fits) {                                                     // uniform: box[] is the same for every thread
             if (threadIdx.x == 0) fb_tiles[atomicAdd(fb_count, 1u)] = make_uint2((uint32_t)tile_x | ((uint32_t)tile_y << 16), (uint32_t)it);
             if (active) fb_flow[(size_t)y * w + x] = f;
             return;
         }
-        // window columns that sample consecutive texels (x0[k+1] == x0[k] + 1: everywhere but at the left/right image
-        // border, where the clamped window columns repeat) share one row of N+1 texels; otherwise every column reads its
-        // own pair.  Uniform over the workgroup.
-        const bool all_consecutive = __syncthreads_and(consecutive || !active);
-        // rows [ymin, ymax] x columns [xs, xmax] of the current frame, xs = xmin rounded down to a multiple of 4 when the
-        // padded rectangle lies inside the frame and the plane is 16-byte aligned (16-byte loads), xmin otherwise
-        int xs = xmin;
-        {
-            const int chh = ymax - ymin + 1;
-            const int xa4 = xmin & ~3, cw4 = (xmax - xa4 + 4) >> 2;                      // float4 per row after padding
-            const bool vec = xmin >= 0 && xa4 + 4 * cw4 <= w && 4 * cw4 <= S::JS && (w & 3) == 0 &&
+        // The current frame's rectangle is staged with a margin and KEPT: a later step whose box still lies inside it (flows
+        // move by a fraction of a pixel per step once the coarser levels have done their work) reuses it -- no global loads,
+        // no second barrier in that step.  Everything below is uniform (derived from box[]).
+        const bool inside = st_valid && xmin >= st_x0 && xmax <= st_x1 && bymin >= st_y0 && ymax <= st_y1;
+        if (!inside) {
+            // margins: up to kJMargin pixels on every side, as far as the capacity allows
+            const int mx = min(kJMargin, (S::LW - (xmax - xmin + 1)) / 2), my = min(kJMargin, (S::LH - (ymax - bymin + 1)) / 2);
+            const int rx0 = xmin - mx, rx1 = xmax + mx, ry0 = bymin - my, ry1 = ymax + my;
+            // rows [ry0, ry1] x columns [xs, rx1], xs = rx0 rounded down to a multiple of 4 when the padded rectangle lies
+            // inside the frame and the plane is 16-byte aligned (16-byte loads), rx0 otherwise
+            int xs_new = rx0;
+            const int chh = ry1 - ry0 + 1;
+            const int xa4 = rx0 & ~3, cw4 = (rx1 - xa4 + 4) >> 2;                        // float4 per row after padding
+            const bool vec = rx0 >= 0 && xa4 + 4 * cw4 <= w && 4 * cw4 <= S::JS && (w & 3) == 0 &&
                              (reinterpret_cast<uintptr_t>(J) & 15) == 0;
             if (vec) {                                                   // uniform
-                xs = xa4;
+                xs_new = xa4;
                 // 32 lanes per rectangle row (cw4 <= JS / 4 <= 32), 8 rows per pass: no division by the run-time width
                 static_assert(S::JS / 4 <= 32, "J staging assumes at most 32 float4 per rectangle row");
                 const int c4 = threadIdx.x & 31;
                 if (c4 < cw4) {
                     for (int cy = threadIdx.x >> 5; cy < chh; cy += 8)
                         *reinterpret_cast<float4*>(&sh.jl[cy][4 * c4]) =
-                            *reinterpret_cast<const float4*>(J + (size_t)lk_clampi(ymin + cy, 0, h - 1) * w + xa4 + 4 * c4);
+                            *reinterpret_cast<const float4*>(J + (size_t)lk_clampi(ry0 + cy, 0, h - 1) * w + xa4 + 4 * c4);
                 }
             } else {
-                const int cw = xmax - xmin + 1;
+                const int cw = rx1 - rx0 + 1;
                 const int cx = threadIdx.x & 127, cy0 = threadIdx.x >> 7;            // 128 threads per row, two rows per pass
                 if (cx < cw) {
-                    const int gxc = lk_clampi(xmin + cx, 0, w - 1);
-                    for (int cy = cy0; cy < chh; cy += 2) sh.jl[cy][cx] = J[(size_t)lk_clampi(ymin + cy, 0, h - 1) * w + gxc];
+                    const int gxc = lk_clampi(rx0 + cx, 0, w - 1);
+                    for (int cy = cy0; cy < chh; cy += 2) sh.jl[cy][cx] = J[(size_t)lk_clampi(ry0 + cy, 0, h - 1) * w + gxc];
                 }
             }
+            st_valid = true; st_x0 = rx0; st_x1 = rx1; st_y0 = ry0; st_y1 = ry1; st_xs = xs_new;
+            __syncthreads();
         }
-        __syncthreads();
+        const int xs = st_xs, ymin = st_y0;                              // origin of jl[][] in frame coordinates
         if (it == 0) OFPS_LK_STAMP(3);
         if (active) {
             // hup[k] = horizontal interpolation of the UPPER sample row at column k.  The lower row of one window row is the
@@ -618,65 +704,102 @@ __global__ __launch_bounds__(256, LkStepShared<RADIUS>::WAVES_PER_SIMD) void lk_
             // same inputs, 11 instead of 14 VALU operations per tap.  Decided per wave so the branch is uniform; recomputing
             // is always correct.
             float bx = 0.0f, by = 0.0f;
-            float hup[N];
-            int prev_yi = -0x7FFFFFFF;
-            if (all_consecutive) {
-                const int xo = xi[0] - xs;
-                float jb[N + 1];
-                // (measured and rejected: unrolling the row loop, fully or by two/three with ping-pong hup arrays -- hipcc
-                // then hoists the next row's LDS reads, 104+ VGPRs, 4 waves per SIMD, 0.53 vs 0.50 ms)
+            bool done = false;
+            if constexpr (RADIUS == 4 && OFPS_LK_SPEC_FMA) {
+                if (all_consecutive) {
+                    // hand-scheduled rows (lk_row9_asm): two register sets alternate between "this row's texels, turned into
+                    // its interpolations" and "the previous row's interpolations", so the row loop runs in pairs
+                    float rr[19];
+                    int prev_yi = -0x7FFFFFFF;
+                    const uint32_t jl0 = (uint32_t)reinterpret_cast<uintptr_t>(&sh.jl[0][xi[0] - xs]);
+                    const uint32_t tl0 = (uint32_t)reinterpret_cast<uintptr_t>(&sh.tile[ly][lx]);
+                    auto row = [&](int r, auto parity) {
+                        constexpr int P = decltype(parity)::value;
+                        float ay;
+                        const int yi = lk_origin(lk_clampi(y + r - RADIUS, 0, h - 1), f.y, h, ay) - ymin;
+                        const bool reuse = __all(yi == prev_yi + 1);
+                        prev_yi = yi;
+                        if (!reuse) {                              // the upper sample row is not the one carried over: make it
+                            const float* ra = &sh.jl[yi][xi[0] - xs];
+                            float jb[N + 1];
+#pragma unroll
+                            for (int k = 0; k <= N; ++k) jb[k] = ra[k];
+#pragma unroll
+                            for (int k = 0; k < N; ++k) rr[P ? k : 10 + k] = lk_lerp(jb[k], jb[k + 1], ax[k]);
+                        }
+                        lk_row9_asm<P>(rr, ax, ay, bx, by, jl0 + (uint32_t)(yi + 1) * (uint32_t)(S::JS * sizeof(float)),
+                                       tl0 + (uint32_t)r * (uint32_t)(T::TW * sizeof(float4)));
+                    };
 #pragma unroll 1
-                for (int r = 0; r < N; ++r) {
-                    float ay;
-                    const int yi = lk_origin(lk_clampi(y + r - RADIUS, 0, h - 1), f.y, h, ay) - ymin;
-                    const bool reuse = __all(yi == prev_yi + 1);
-                    prev_yi = yi;
-                    if (!reuse) {
-                        const float* ra = &sh.jl[yi][xo];
-#pragma unroll
-                        for (int k = 0; k <= N; ++k) jb[k] = ra[k];
-#pragma unroll
-                        for (int k = 0; k < N; ++k) hup[k] = lk_lerp(jb[k], jb[k + 1], ax[k]);
+                    for (int r = 0; r < N - 1; r += 2) {
+                        row(r, std::integral_constant<int, 0>{});
+                        row(r + 1, std::integral_constant<int, 1>{});
                     }
-                    const float* rb = &sh.jl[yi + 1][xo];
-#pragma unroll
-                    for (int k = 0; k <= N; ++k) jb[k] = rb[k];
-#pragma unroll
-                    for (int k = 0; k < N; ++k) {
-                        const float top = hup[k];
-                        const float bot = lk_lerp(jb[k], jb[k + 1], ax[k]);
-                        const lk_f4 t = lk_lds_read4(&sh.tile[ly + r][lx + k]);
-                        const float d = t.x - lk_lerp(top, bot, ay);
-                        lk_accum(t.y, d, bx);
-                        lk_accum(t.z, d, by);
-                        hup[k] = bot;
-                    }
+                    row(N - 1, std::integral_constant<int, 0>{});
+                    done = true;
                 }
-            } else {
-#pragma unroll
-                for (int k = 0; k < N; ++k) xi[k] -= xs;
-#pragma unroll 1
-                for (int r = 0; r < N; ++r) {
-                    float ay;
-                    const int yi = lk_origin(lk_clampi(y + r - RADIUS, 0, h - 1), f.y, h, ay) - ymin;
-                    const bool reuse = __all(yi == prev_yi + 1);
-                    prev_yi = yi;
-                    if (!reuse) {
-                        const float* ra = &sh.jl[yi][0];
-#pragma unroll
-                        for (int k = 0; k < N; ++k) { const float j0 = ra[xi[k]], j1 = ra[xi[k] + 1]; hup[k] = lk_lerp(j0, j1, ax[k]); }
+            }
+            if (!done) {
+                float hup[N];
+                int prev_yi = -0x7FFFFFFF;
+                if (all_consecutive) {
+                    const int xo = xi[0] - xs;
+                    float jb[N + 1];
+                    // (measured and rejected: unrolling the row loop, fully or by two/three with ping-pong hup arrays -- hipcc
+                    // then hoists the next row's LDS reads, 104+ VGPRs, 4 waves per SIMD, 0.53 vs 0.50 ms)
+    #pragma unroll 1
+                    for (int r = 0; r < N; ++r) {
+                        float ay;
+                        const int yi = lk_origin(lk_clampi(y + r - RADIUS, 0, h - 1), f.y, h, ay) - ymin;
+                        const bool reuse = __all(yi == prev_yi + 1);
+                        prev_yi = yi;
+                        if (!reuse) {
+                            const float* ra = &sh.jl[yi][xo];
+    #pragma unroll
+                            for (int k = 0; k <= N; ++k) jb[k] = ra[k];
+    #pragma unroll
+                            for (int k = 0; k < N; ++k) hup[k] = lk_lerp(jb[k], jb[k + 1], ax[k]);
+                        }
+                        const float* rb = &sh.jl[yi + 1][xo];
+    #pragma unroll
+                        for (int k = 0; k <= N; ++k) jb[k] = rb[k];
+    #pragma unroll
+                        for (int k = 0; k < N; ++k) {
+                            const float top = hup[k];
+                            const float bot = lk_lerp(jb[k], jb[k + 1], ax[k]);
+                            const lk_f4 t = lk_lds_read4(&sh.tile[ly + r][lx + k]);
+                            const float d = t.x - lk_lerp(top, bot, ay);
+                            lk_accum(t.y, d, bx);
+                            lk_accum(t.z, d, by);
+                            hup[k] = bot;
+                        }
                     }
-                    const float* rb = &sh.jl[yi + 1][0];
-#pragma unroll
-                    for (int k = 0; k < N; ++k) {
-                        const float j0 = rb[xi[k]], j1 = rb[xi[k] + 1];
-                        const float top = hup[k];
-                        const float bot = lk_lerp(j0, j1, ax[k]);
-                        const lk_f4 t = lk_lds_read4(&sh.tile[ly + r][lx + k]);
-                        const float d = t.x - lk_lerp(top, bot, ay);
-                        lk_accum(t.y, d, bx);
-                        lk_accum(t.z, d, by);
-                        hup[k] = bot;
+                } else {
+    #pragma unroll
+                    for (int k = 0; k < N; ++k) xi[k] -= xs;
+    #pragma unroll 1
+                    for (int r = 0; r < N; ++r) {
+                        float ay;
+                        const int yi = lk_origin(lk_clampi(y + r - RADIUS, 0, h - 1), f.y, h, ay) - ymin;
+                        const bool reuse = __all(yi == prev_yi + 1);
+                        prev_yi = yi;
+                        if (!reuse) {
+                            const float* ra = &sh.jl[yi][0];
+    #pragma unroll
+                            for (int k = 0; k < N; ++k) { const float j0 = ra[xi[k]], j1 = ra[xi[k] + 1]; hup[k] = lk_lerp(j0, j1, ax[k]); }
+                        }
+                        const float* rb = &sh.jl[yi + 1][0];
+    #pragma unroll
+                        for (int k = 0; k < N; ++k) {
+                            const float j0 = rb[xi[k]], j1 = rb[xi[k] + 1];
+                            const float top = hup[k];
+                            const float bot = lk_lerp(j0, j1, ax[k]);
+                            const lk_f4 t = lk_lds_read4(&sh.tile[ly + r][lx + k]);
+                            const float d = t.x - lk_lerp(top, bot, ay);
+                            lk_accum(t.y, d, bx);
+                            lk_accum(t.z, d, by);
+                            hup[k] = bot;
+                        }
                     }
                 }
             }

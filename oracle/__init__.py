@@ -275,6 +275,11 @@ def solve_ypr_ransac(entries, cam: Camera, num_iters=200, inlier_deg=0.05, num_s
     return (q, inl[:n_inl.value].copy()) if want_inliers else q
 
 
+def lk_spec_revision() -> int:
+    """2 = fused multiply-adds in the bilinear sample and the residual sums (ofps_oracle.c: ORC_LK_SPEC_FMA)."""
+    return int(lib().orc_lk_spec_revision())
+
+
 def sample_index(seed, it, stream, i, n) -> int:
     return int(lib().orc_sample_index(seed, it, stream, i, n))
 

@@ -250,6 +250,38 @@ def _lk_pyr_down(img):
     return o.astype(F)
 
 
+def fma32(a, b, c):
+    """Correctly rounded f32 fused multiply-add on arrays, without a hardware fma: the product of two f32 is exact in f64
+    (48 bits), the f64 sum p + c is made ROUND-TO-ODD with the error term of a TwoSum (if the sum was inexact, the result
+    whose last mantissa bit is 1 of the two f64 neighbours of the exact value), and a round-to-odd value with 53 >= 2 * 24 + 2
+    bits rounds to f32 exactly like the infinitely precise one (no double rounding)."""
+    a = np.asarray(a, F).astype(np.float64); b = np.asarray(b, F).astype(np.float64); c = np.asarray(c, F).astype(np.float64)
+    a, b, c = np.broadcast_arrays(a, b, c)
+    p = a * b                                             # exact
+    s = p + c
+    bb = s - p
+    err = (p - (s - bb)) + (c - bb)                       # exact error of the sum (TwoSum)
+    s = np.array(s, np.float64)                           # writable copy
+    bits = s.view(np.int64)
+    inexact = (err != 0) & np.isfinite(s)
+    even = (bits & 1) == 0
+    # the exact value lies strictly between s and its neighbour in the direction of err: if s is even, that neighbour is odd
+    toward_larger_magnitude = (err > 0) == (s > 0)
+    step = np.where(toward_larger_magnitude, 1, -1).astype(np.int64)
+    fix = inexact & even & (s != 0)
+    bits[fix] += step[fix]
+    return s.astype(F)
+
+
+LK_SPEC_FMA = True          # revision 2 of the build-defined N2 spec (oracle/ofps_oracle.c: ORC_LK_SPEC_FMA)
+
+
+def _lk_lerp(a, b, t):
+    if LK_SPEC_FMA:
+        return fma32(t, (b - a).astype(F), a)
+    return (a + t * (b - a)).astype(F)
+
+
 def _lk_bilinear(J, fx, fy):
     h, w = J.shape
     x0f, y0f = np.floor(fx), np.floor(fy)
@@ -259,9 +291,9 @@ def _lk_bilinear(J, fx, fy):
     xa, xb = np.clip(x0, 0, w - 1), np.clip(x0 + 1, 0, w - 1)
     ya, yb = np.clip(y0, 0, h - 1), np.clip(y0 + 1, 0, h - 1)
     j00, j10, j01, j11 = J[ya, xa], J[ya, xb], J[yb, xa], J[yb, xb]
-    top = (j00 + ax * (j10 - j00)).astype(F)
-    bot = (j01 + ax * (j11 - j01)).astype(F)
-    return (top + ay * (bot - top)).astype(F)
+    top = _lk_lerp(j00, j10, ax)
+    bot = _lk_lerp(j01, j11, ax)
+    return _lk_lerp(top, bot, ay)
 
 
 def lk_flow(prev, cur, levels=3, radius=4, iters=3):
@@ -293,7 +325,10 @@ def lk_flow(prev, cur, levels=3, radius=4, iters=3):
                     ix, iy = gx[qy, qx], gy[qy, qx]
                     d = (Il[qy, qx] - _lk_bilinear(Jl, (qx.astype(F) + u).astype(F), (qy.astype(F) + v).astype(F))).astype(F)
                     gxx = (gxx + ix * ix).astype(F); gxy = (gxy + ix * iy).astype(F); gyy = (gyy + iy * iy).astype(F)
-                    bx = (bx + ix * d).astype(F); by = (by + iy * d).astype(F)
+                    if LK_SPEC_FMA:
+                        bx = fma32(ix, d, bx); by = fma32(iy, d, by)
+                    else:
+                        bx = (bx + ix * d).astype(F); by = (by + iy * d).astype(F)
             det = (gxx * gyy - gxy * gxy).astype(F)
             ok = det > F(0.01)
             with np.errstate(divide="ignore", invalid="ignore"):

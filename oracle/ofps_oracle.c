@@ -1065,7 +1065,32 @@ static void lk_pyr_down(const float* in, int w, int h, float* out, int w1, int h
         }
 }
 
-static float lk_bilinear(const float* J, int w, int h, float fx, float fy) {
+/* N2 spec, revision 2 (DESIGN.md "N2"): the bilinear sample and the two residual sums fuse their multiply-adds --
+ * lerp(a, b, t) = fma(t, b - a, a), b += g * d as fma(g, d, b): 7 operations per window tap instead of 11, each result
+ * rounded once instead of twice.  ORC_LK_SPEC_FMA = 0 rebuilds revision 1 (separate multiply and add) for A/B runs;
+ * ofps_amd/csrc/lk.hip carries the same switch (OFPS_LK_SPEC_FMA) and the two must be built alike.  fmaf() is the
+ * correctly rounded fused operation whatever the host: orc_lk_flow is cloned for FMA3 hosts (one vfmadd instruction) with
+ * the libm call as the portable clone. */
+#ifndef ORC_LK_SPEC_FMA
+#define ORC_LK_SPEC_FMA 1
+#endif
+static inline float lk_lerp(float a, float b, float t) {
+#if ORC_LK_SPEC_FMA
+    return fmaf(t, b - a, a);
+#else
+    return a + t * (b - a);
+#endif
+}
+static inline float lk_accum(float g, float d, float b) {
+#if ORC_LK_SPEC_FMA
+    return fmaf(g, d, b);
+#else
+    return b + g * d;
+#endif
+}
+int orc_lk_spec_revision(void) { return ORC_LK_SPEC_FMA ? 2 : 1; }
+
+static inline float lk_bilinear(const float* J, int w, int h, float fx, float fy) {
     float x0f = floorf(fx), y0f = floorf(fy);
     float ax = fx - x0f, ay = fy - y0f;
     /* clamp in float first so wild flows cannot overflow the int conversion */
@@ -1075,11 +1100,14 @@ static float lk_bilinear(const float* J, int w, int h, float fx, float fy) {
     int xa = lk_clampi(x0, 0, w - 1), xb = lk_clampi(x0 + 1, 0, w - 1);
     int ya = lk_clampi(y0, 0, h - 1), yb = lk_clampi(y0 + 1, 0, h - 1);
     float j00 = J[(size_t)ya * w + xa], j10 = J[(size_t)ya * w + xb], j01 = J[(size_t)yb * w + xa], j11 = J[(size_t)yb * w + xb];
-    float top = j00 + ax * (j10 - j00);
-    float bot = j01 + ax * (j11 - j01);
-    return top + ay * (bot - top);
+    float top = lk_lerp(j00, j10, ax);
+    float bot = lk_lerp(j01, j11, ax);
+    return lk_lerp(top, bot, ay);
 }
 
+#if defined(__x86_64__) && defined(__GNUC__) && !defined(__clang__)
+__attribute__((target_clones("fma", "default")))
+#endif
 int orc_lk_flow(const uint8_t* prev, const uint8_t* cur, int W, int H, int stride, int levels, int radius, int iters,
                 float* out_flow) {
     if (levels < 1 || levels > 8 || radius < 1 || radius > 15 || iters < 1 || W < 1 || H < 1) return 0;
@@ -1139,7 +1167,7 @@ int orc_lk_flow(const uint8_t* prev, const uint8_t* cur, int W, int H, int strid
                             const float ix = gx[(size_t)qy * w + qx], iy = gy[(size_t)qy * w + qx];
                             const float d = Il[(size_t)qy * w + qx] - lk_bilinear(Jl, w, h, (float)qx + u, (float)qy + v);
                             gxx += ix * ix; gxy += ix * iy; gyy += iy * iy;
-                            bx += ix * d; by += iy * d;
+                            bx = lk_accum(ix, d, bx); by = lk_accum(iy, d, by);
                         }
                     const float det = gxx * gyy - gxy * gxy;
                     float du = 0.0f, dv = 0.0f;

@@ -135,6 +135,7 @@ size_t orc_sad_flow_ex(const uint8_t* prev, const uint8_t* cur, int W, int H, in
 /* ---- N2: dense pyramidal Lucas-Kanade flow (build-defined spec; no reference arithmetic exists:
  * the reference calls OpenCV's calcOpticalFlowFarneback, cv-decoder/src/lib.rs:188-199) -> "parity unpinned".
  * out_flow: 2*W*H floats (u,v) per pixel, prev(x,y) ~ cur(x+u,y+v).  Returns 1, or 0 on bad parameters. */
+int orc_lk_spec_revision(void);   /* 2: fused multiply-adds in the bilinear sample and the residual sums (current); 1: unfused */
 int orc_lk_flow(const uint8_t* prev, const uint8_t* cur, int W, int H, int stride, int levels, int radius, int iters,
                 float* out_flow);
 /* per-pixel MotionEntry records in cv-decoder's convention (cv-decoder/src/lib.rs:239-243,262-269) */

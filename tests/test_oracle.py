@@ -180,6 +180,38 @@ def test_almeida_all_core_forms_equal_the_single_thread_oracle_bit_for_bit():
                                   oracle.solve_ypr_ransac(e, cam, 10, 0.05, 1000, seed=1))
 
 
+def test_numpy_fma32_is_correctly_rounded():
+    """The NumPy restatement of the LK spec (revision 2) needs an f32 fused multiply-add without hardware help: exact f64
+    product, round-to-odd f64 sum, one final rounding.  Checked against libm's fmaf on random operands with heavy
+    cancellation and on the double-rounding trap: exact results a hair below / above a tie between two f32 neighbours,
+    where rounding through plain f64 picks the wrong one."""
+    import ctypes
+    libm = ctypes.CDLL("libm.so.6"); libm.fmaf.restype = ctypes.c_float; libm.fmaf.argtypes = [ctypes.c_float] * 3
+    rng = np.random.default_rng(3)
+    n = 20000
+    a = (rng.standard_normal(n) * 10 ** rng.uniform(-3, 3, n)).astype(np.float32)
+    b = (rng.standard_normal(n) * 10 ** rng.uniform(-3, 3, n)).astype(np.float32)
+    c = (-a.astype(np.float64) * b.astype(np.float64) * (1 + rng.uniform(-1e-6, 1e-6, n))).astype(np.float32)
+    c[::3] = (rng.standard_normal(len(c[::3])) * 10 ** rng.uniform(-3, 3, len(c[::3]))).astype(np.float32)
+    # the trap: a * b = 2^-24 (1 - 2^-46 k^2) or 2^-24 (1 + 2^-46 k^2 + ...), c = r with an odd or even last bit
+    ta, tb, tc = [], [], []
+    for k in range(1, 6):
+        for r in (1.0 + 2.0 ** -23, 1.0 + 2.0 ** -22, 1.5, 1.0 + 3 * 2.0 ** -23):
+            for sg in (1.0, -1.0):
+                for sb in (1.0, -1.0):
+                    ta.append(sg * 2.0 ** -12 * (1 + k * 2.0 ** -23)); tb.append(2.0 ** -12 * (1 + sb * k * 2.0 ** -23)); tc.append(sg * r)
+    a = np.concatenate([a, np.array(ta, np.float32)]); b = np.concatenate([b, np.array(tb, np.float32)])
+    c = np.concatenate([c, np.array(tc, np.float32)])
+    want = np.array([libm.fmaf(float(x), float(y), float(z)) for x, y, z in zip(a, b, c)], np.float32)
+    np.testing.assert_array_equal(npo.fma32(a, b, c).view(np.uint32), want.view(np.uint32))
+    naive = (a.astype(np.float64) * b.astype(np.float64) + c.astype(np.float64)).astype(np.float32)
+    assert (naive.view(np.uint32) != want.view(np.uint32)).any(), "the trap cases should defeat rounding through plain f64"
+
+
+def test_lk_spec_revision_is_the_fused_one_in_both_restatements():
+    assert oracle.lk_spec_revision() == 2 and npo.LK_SPEC_FMA is True
+
+
 def test_interpolate_empty_cells_fills_everything():
     e = _entries(40, 8)
     f = oracle.densify_interpolated(e, 12, 9)

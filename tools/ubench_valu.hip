@@ -28,6 +28,9 @@ OP32(v_add_f32, "v_add_f32 %0, %1, %0")
 OP32(v_mul_f32, "v_mul_f32 %0, %1, %0")
 OP32(v_fma_f32, "v_fma_f32 %0, %1, %1, %0")
 OP32(v_rcp_f32, "v_rcp_f32 %0, %0")
+OP32(v_fmac_f32, "v_fmac_f32 %0, %1, %1")
+OP32(v_fma_mix_f32, "v_fma_mix_f32 %0, %1, %1, %0 op_sel_hi:[1,0,0]")
+OP32(v_cvt_f32_f16, "v_cvt_f32_f16 %0, %0")
 OP32(v_min_u32, "v_min_u32 %0, %1, %0")
 OP32(v_max_f32, "v_max_f32 %0, %1, %0")
 OP32(v_cndmask_b32, "v_cndmask_b32 %0, %0, %1, vcc")
@@ -88,6 +91,7 @@ int main() {
     const int cus = p.multiProcessorCount;
     run<v_add_u32>(d, cus); run<v_add_f32>(d, cus); run<v_mul_f32>(d, cus); run<v_fma_f32>(d, cus);
     run<v_pk_add_f32>(d, cus); run<v_pk_mul_f32>(d, cus); run<v_pk_fma_f32>(d, cus);
+    run<v_fmac_f32>(d, cus); run<v_fma_mix_f32>(d, cus); run<v_cvt_f32_f16>(d, cus);
     run<v_rcp_f32>(d, cus); run<v_max_f32>(d, cus); run<v_min_u32>(d, cus); run<v_cndmask_b32>(d, cus);
     run<v_pk_min_u16>(d, cus); run<v_pk_add_u16>(d, cus); run<v_cvt_f32_ubyte0>(d, cus); run<v_perm_b32>(d, cus);
     run<v_alignbit_b32>(d, cus); run<v_lshlrev_b64>(d, cus);
