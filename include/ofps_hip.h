@@ -248,6 +248,34 @@ int ofps_hip_push_frame_async(ofps_hip_ctx* ctx, const uint8_t* luma, int W, int
                               float* out_field /* 2*dim*dim or NULL */, int* ticket);
 int ofps_hip_frame_wait(ofps_hip_ctx* ctx, int ticket, ofps_hip_frame_result* out);
 
+/* ---- one host process, several GPUs: frame pairs are independent units, so a batch is split into
+ * contiguous pair ranges, one worker thread + one context + one stream per entry of `devices` (an entry may repeat: the
+ * workers are then independent contexts on one GPU).  No collective on the data path; in key mode (ref_mode 1: pair k =
+ * frames 0, k+1) the key frame is uploaded once and fanned out device to device (hipMemcpyPeerAsync, xGMI point to
+ * point).  Results come back in pair order.  The reference's counterpart is its worker-thread model
+ * (ofps-suite/src/app/tracking/worker.rs:251-260,347-352); it has no multi-GPU code of its own. ---- */
+typedef struct ofps_hip_multi ofps_hip_multi;
+int  ofps_hip_multi_init(const int* devices, int n, ofps_hip_multi** out);
+void ofps_hip_multi_destroy(ofps_hip_multi* m);
+const char* ofps_hip_multi_last_error(const ofps_hip_multi* m);       /* m may be NULL: last init error */
+int  ofps_hip_multi_worker_count(const ofps_hip_multi* m);
+/* The partition, as pure functions (no device needed): worker k of n gets pairs [first, first + count) -- the first
+ * n_pairs % n workers one more -- and keeps frames [first_frame, first_frame + n_frames) resident: count + 1 frames in
+ * pair mode (one halo frame shared with the next worker), count frames in key mode (frame 0 arrives by the fan-out). */
+void ofps_hip_multi_pair_range(size_t n_pairs, int n_workers, int k, size_t* first, size_t* count);
+void ofps_hip_multi_frame_range(size_t n_pairs, int n_workers, int k, int ref_mode, size_t* first_frame, size_t* n_frames);
+/* Host frames in (n_frames luma frames at frames + k * frame_pitch), vectors out in pair order:
+ * out_entries [(n_frames - 1) * nblk * 4] f32.  = stage_frames + run_resident(1 step) + fetch. */
+int ofps_hip_multi_sad_flow(ofps_hip_multi* m, const uint8_t* frames, int n_frames, int W, int H, int stride,
+                            size_t frame_pitch, int ref_mode, int block, int range, float* out_entries);
+/* The same in three parts, for callers that search a resident batch repeatedly (bench.py --launcher threads): upload and
+ * partition; `steps` searches of every worker's resident pairs back to back (returns when all workers are through); copy
+ * the last results back in pair order. */
+int ofps_hip_multi_stage_frames(ofps_hip_multi* m, const uint8_t* frames, int n_frames, int W, int H, int stride,
+                                size_t frame_pitch, int ref_mode);
+int ofps_hip_multi_run_resident(ofps_hip_multi* m, int block, int range, int steps);
+int ofps_hip_multi_fetch(ofps_hip_multi* m, int block, float* out_entries);
+
 #ifdef __cplusplus
 }
 #endif

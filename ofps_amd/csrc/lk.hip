@@ -617,20 +617,29 @@ __global__ __launch_bounds__(256, LkStepShared<RADIUS>::WAVES_PER_SIMD) void lk_
         // per SIMD for a handful of integer operations per step
         int x = px, y = py;
         asm volatile("" : "+v"(x), "+v"(y));
-        float ax[N];
-        int xi[N];
+        // first pass over the window columns: only what the workgroup's box needs (first and last origin, "consecutive").
+        // The origins and fractions the rows use are made AGAIN after the barrier / staging below (same operations, same
+        // values): kept alive across that phase they were spilled to scratch in every step (76 B per pixel-step of HBM
+        // traffic, rocprofv3 WRITE_SIZE); nine floors are cheaper
+        int xi_first = 0, xi_last = 0;
         bool consecutive = true;
+        {
+            float dummy_a;
+            int prev = 0;
 #pragma unroll
-        for (int k = 0; k < N; ++k) {
-            xi[k] = lk_origin(lk_clampi(x + k - RADIUS, 0, w - 1), f.x, w, ax[k]);
-            if (k > 0) consecutive = consecutive && (xi[k] == xi[k - 1] + 1);
+            for (int k = 0; k < N; ++k) {
+                const int o = lk_origin(lk_clampi(x + k - RADIUS, 0, w - 1), f.x, w, dummy_a);
+                if (k > 0) consecutive = consecutive && (o == prev + 1);
+                if (k == 0) xi_first = o;
+                xi_last = o; prev = o;
+            }
         }
         float dummy;
         const int yt = lk_origin(lk_clampi(y - RADIUS, 0, h - 1), f.y, h, dummy);
         const int yb_ = lk_origin(lk_clampi(y + RADIUS, 0, h - 1), f.y, h, dummy);
         {
             // window columns / rows are monotone in k / r, so the extremes are the first and the last
-            int bx0 = active ? xi[0] : 0x7FFFFFFF, bx1 = active ? xi[N - 1] + 1 : -0x7FFFFFFF;
+            int bx0 = active ? xi_first : 0x7FFFFFFF, bx1 = active ? xi_last + 1 : -0x7FFFFFFF;
             int by0 = active ? yt : 0x7FFFFFFF, by1 = active ? yb_ + 1 : -0x7FFFFFFF;
             bx0 = lk_wave_minmax<false>(bx0); bx1 = lk_wave_minmax<true>(bx1);
             by0 = lk_wave_minmax<false>(by0); by1 = lk_wave_minmax<true>(by1);
@@ -663,6 +672,10 @@ __global__ __launch_bounds__(256, LkStepShared<RADIUS>::WAVES_PER_SIMD) void lk_
         // no second barrier in that step.  Everything below is uniform (derived from box[]).
         const bool inside = st_valid && xmin >= st_x0 && xmax <= st_x1 && bymin >= st_y0 && ymax <= st_y1;
         if (!inside) {
+            // (thread index through an empty asm: the staging addresses are made here, per staging, not hoisted out of the step
+            // loop into registers that are then spilled for the whole level)
+            int tid = (int)threadIdx.x;
+            asm volatile("" : "+v"(tid));
             // margins: up to kJMargin pixels on every side, as far as the capacity allows
             const int mx = min(kJMargin, (S::LW - (xmax - xmin + 1)) / 2), my = min(kJMargin, (S::LH - (ymax - bymin + 1)) / 2);
             const int rx0 = xmin - mx, rx1 = xmax + mx, ry0 = bymin - my, ry1 = ymax + my;
@@ -677,15 +690,15 @@ __global__ __launch_bounds__(256, LkStepShared<RADIUS>::WAVES_PER_SIMD) void lk_
                 xs_new = xa4;
                 // 32 lanes per rectangle row (cw4 <= JS / 4 <= 32), 8 rows per pass: no division by the run-time width
                 static_assert(S::JS / 4 <= 32, "J staging assumes at most 32 float4 per rectangle row");
-                const int c4 = threadIdx.x & 31;
+                const int c4 = tid & 31;
                 if (c4 < cw4) {
-                    for (int cy = threadIdx.x >> 5; cy < chh; cy += 8)
+                    for (int cy = tid >> 5; cy < chh; cy += 8)
                         *reinterpret_cast<float4*>(&sh.jl[cy][4 * c4]) =
                             *reinterpret_cast<const float4*>(J + (size_t)lk_clampi(ry0 + cy, 0, h - 1) * w + xa4 + 4 * c4);
                 }
             } else {
                 const int cw = rx1 - rx0 + 1;
-                const int cx = threadIdx.x & 127, cy0 = threadIdx.x >> 7;            // 128 threads per row, two rows per pass
+                const int cx = tid & 127, cy0 = tid >> 7;            // 128 threads per row, two rows per pass
                 if (cx < cw) {
                     const int gxc = lk_clampi(rx0 + cx, 0, w - 1);
                     for (int cy = cy0; cy < chh; cy += 2) sh.jl[cy][cx] = J[(size_t)lk_clampi(ry0 + cy, 0, h - 1) * w + gxc];
@@ -695,6 +708,14 @@ __global__ __launch_bounds__(256, LkStepShared<RADIUS>::WAVES_PER_SIMD) void lk_
             __syncthreads();
         }
         const int xs = st_xs, ymin = st_y0;                              // origin of jl[][] in frame coordinates
+        float ax[N];
+        int xi[N];
+        {
+            int xr = x;
+            asm volatile("" : "+v"(xr));                                  // opaque: a second evaluation, not the first one kept alive
+#pragma unroll
+            for (int k = 0; k < N; ++k) xi[k] = lk_origin(lk_clampi(xr + k - RADIUS, 0, w - 1), f.x, w, ax[k]);
+        }
         if (it == 0) OFPS_LK_STAMP(3);
         if (active) {
             // hup[k] = horizontal interpolation of the UPPER sample row at column k.  The lower row of one window row is the
@@ -717,7 +738,9 @@ __global__ __launch_bounds__(256, LkStepShared<RADIUS>::WAVES_PER_SIMD) void lk_
                         constexpr int P = decltype(parity)::value;
                         float ay;
                         const int yi = lk_origin(lk_clampi(y + r - RADIUS, 0, h - 1), f.y, h, ay) - ymin;
-                        const bool reuse = __all(yi == prev_yi + 1);
+                        // (the first row always makes its upper sample row: stated at compile time, so that the carried
+                        // registers are not live into the loop -- hipcc spilled their undefined contents around every step)
+                        const bool reuse = r > 0 && __all(yi == prev_yi + 1);
                         prev_yi = yi;
                         if (!reuse) {                              // the upper sample row is not the one carried over: make it
                             const float* ra = &sh.jl[yi][xi[0] - xs];
@@ -730,12 +753,12 @@ __global__ __launch_bounds__(256, LkStepShared<RADIUS>::WAVES_PER_SIMD) void lk_
                         lk_row9_asm<P>(rr, ax, ay, bx, by, jl0 + (uint32_t)(yi + 1) * (uint32_t)(S::JS * sizeof(float)),
                                        tl0 + (uint32_t)r * (uint32_t)(T::TW * sizeof(float4)));
                     };
+                    row(0, std::integral_constant<int, 0>{});
 #pragma unroll 1
-                    for (int r = 0; r < N - 1; r += 2) {
-                        row(r, std::integral_constant<int, 0>{});
-                        row(r + 1, std::integral_constant<int, 1>{});
+                    for (int r = 1; r < N; r += 2) {
+                        row(r, std::integral_constant<int, 1>{});
+                        row(r + 1, std::integral_constant<int, 0>{});
                     }
-                    row(N - 1, std::integral_constant<int, 0>{});
                     done = true;
                 }
             }

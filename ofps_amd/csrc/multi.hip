@@ -1,0 +1,301 @@
+// multi.hip -- in-process multi-device dispatcher behind the C ABI ("one host thread + one HIP stream per
+// device").  A host that binds libofps_hip.so directly -- the Rust shim of INTEGRATION.md, ofps_amd/host/ -- spreads a batch
+// of independent frame pairs (BASELINE configs[3]: 64 pairs of 4K frames) over the GPUs of one node without a launcher
+// of its own; the reference's threading model is one worker per plugin object, decoders on their own threads
+// (ofps-suite/src/app/tracking/worker.rs:251-260,347-352).
+//
+//   * one ofps_hip_ctx + one worker thread per entry of the device list (a device may be listed more than once: the
+//     workers are then independent contexts on one GPU -- how the one-GPU tests exercise the partitioning);
+//   * pairs are split into contiguous ranges (first n_pairs % n workers get one more: distributed.pair_range's rule),
+//     ref_mode 0 (pair k = frames k, k+1): a worker's range + ONE halo frame; ref_mode 1 (pair k = frames 0, k+1): the key
+//     frame is uploaded to the first worker's device once and fanned out device-to-device (hipMemcpyPeerAsync: xGMI
+//     point to point, no ring -- RCCL is not linked), every worker holds its own `cur` frames;
+//   * no collective on the data path; results come back in pair order into caller memory.
+// Frame pairs are independent units, so the workers never talk to each other except for that one fan-out.
+#include "common.hpp"
+
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+struct ofps_hip_multi {
+    struct Worker {
+        int device = 0;
+        ofps_hip_ctx* ctx = nullptr;
+        std::thread th;
+        std::mutex m;
+        std::condition_variable cv;
+        std::function<int(Worker&)> job;      // set by the dispatcher, cleared by the worker
+        bool has_job = false, done = true, quit = false;
+        int rc = OFPS_HIP_OK;
+        // resident batch (ofps_hip_multi_stage_frames)
+        uint8_t* d_frames = nullptr; size_t frames_cap = 0;
+        float* d_out = nullptr; size_t out_cap = 0;
+        size_t first_pair = 0, n_pairs = 0, n_res_frames = 0;
+        hipEvent_t key_ready = nullptr;        // worker 0: the key frame is on its device
+    };
+    std::vector<Worker*> w;
+    char err[512] = {0};
+    // geometry of the resident batch
+    int W = 0, H = 0, dstride = 0, ref_mode = 0;
+    size_t pitch = 0, total_pairs = 0;
+    bool staged = false;
+};
+
+static thread_local char g_multi_init_err[512] = {0};
+
+namespace {
+
+using Worker = ofps_hip_multi::Worker;
+
+int multi_error(ofps_hip_multi* m, int code, const char* fmt, ...) {
+    char* dst = m ? m->err : g_multi_init_err;
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(dst, 512, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+void worker_main(Worker* w) {
+    for (;;) {
+        std::unique_lock<std::mutex> lk(w->m);
+        w->cv.wait(lk, [&] { return w->has_job || w->quit; });
+        if (w->quit) return;
+        auto job = std::move(w->job);
+        w->has_job = false;
+        lk.unlock();
+        const int rc = job(*w);
+        lk.lock();
+        w->rc = rc; w->done = true;
+        w->cv.notify_all();
+    }
+}
+
+// runs job on every worker concurrently, joins, returns the first failure (message copied from that worker's context)
+int run_all(ofps_hip_multi* m, const std::function<int(Worker&, int)>& job) {
+    for (size_t k = 0; k < m->w.size(); ++k) {
+        Worker* w = m->w[k];
+        std::lock_guard<std::mutex> lk(w->m);
+        const int idx = (int)k;
+        w->job = [job, idx](Worker& ww) { return job(ww, idx); };
+        w->has_job = true; w->done = false;
+        w->cv.notify_all();
+    }
+    int rc = OFPS_HIP_OK;
+    for (size_t k = 0; k < m->w.size(); ++k) {
+        Worker* w = m->w[k];
+        std::unique_lock<std::mutex> lk(w->m);
+        w->cv.wait(lk, [&] { return w->done; });
+        if (w->rc != OFPS_HIP_OK && rc == OFPS_HIP_OK) {
+            rc = w->rc;
+            snprintf(m->err, sizeof(m->err), "worker %zu (device %d): %s", k, w->device, ofps_hip_last_error(w->ctx));
+        }
+    }
+    return rc;
+}
+
+int grow(Worker& w, uint8_t** p, size_t* cap, size_t bytes) {
+    if (*cap >= bytes) return OFPS_HIP_OK;
+    if (*p) { OFPS_HIP_TRY(w.ctx, hipStreamSynchronize(w.ctx->stream)); OFPS_HIP_TRY(w.ctx, hipFree(*p)); *p = nullptr; *cap = 0; }
+    OFPS_HIP_TRY(w.ctx, hipMalloc(reinterpret_cast<void**>(p), bytes ? bytes : 16));
+    *cap = bytes;
+    return OFPS_HIP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+void ofps_hip_multi_pair_range(size_t n_pairs, int n_workers, int k, size_t* first, size_t* count) {
+    size_t f = 0, c = 0;
+    if (n_workers >= 1 && k >= 0 && k < n_workers) {
+        const size_t base = n_pairs / (size_t)n_workers, extra = n_pairs % (size_t)n_workers;
+        c = base + ((size_t)k < extra ? 1 : 0);
+        f = (size_t)k * base + ((size_t)k < extra ? (size_t)k : extra);
+    }
+    if (first) *first = f;
+    if (count) *count = c;
+}
+
+void ofps_hip_multi_frame_range(size_t n_pairs, int n_workers, int k, int ref_mode, size_t* first_frame, size_t* n_frames) {
+    size_t f = 0, c = 0;
+    ofps_hip_multi_pair_range(n_pairs, n_workers, k, &f, &c);
+    size_t ff = f, fc = 0;
+    if (c) {
+        if (ref_mode == 0) { ff = f; fc = c + 1; }        // count pairs need count + 1 frames: one halo frame shared with the next worker
+        else { ff = f + 1; fc = c; }                      // the key frame (frame 0) arrives by the fan-out
+    }
+    if (first_frame) *first_frame = ff;
+    if (n_frames) *n_frames = fc;
+}
+
+int ofps_hip_multi_init(const int* devices, int n, ofps_hip_multi** out) {
+    if (!out) return multi_error(nullptr, OFPS_HIP_EINVAL, "multi_init: out is NULL");
+    *out = nullptr;
+    if (!devices || n < 1 || n > 64) return multi_error(nullptr, OFPS_HIP_EINVAL, "multi_init: need 1..64 devices");
+    auto* m = new ofps_hip_multi();
+    for (int k = 0; k < n; ++k) {
+        auto* w = new Worker();
+        w->device = devices[k];
+        const int rc = ofps_hip_init(devices[k], &w->ctx);
+        if (rc != OFPS_HIP_OK) {
+            snprintf(g_multi_init_err, sizeof(g_multi_init_err), "multi_init: device %d: %s", devices[k], ofps_hip_last_error(nullptr));
+            delete w;
+            ofps_hip_multi_destroy(m);
+            return rc;
+        }
+        m->w.push_back(w);
+    }
+    // peer access towards the first worker's device (the key-frame fan-out); failure is not fatal: hipMemcpyPeerAsync
+    // stages through the host when there is no direct path
+    for (size_t k = 1; k < m->w.size(); ++k) {
+        if (m->w[k]->device == m->w[0]->device) continue;
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, m->w[k]->device, m->w[0]->device) == hipSuccess && can) {
+            (void)hipSetDevice(m->w[k]->device);
+            const hipError_t e = hipDeviceEnablePeerAccess(m->w[0]->device, 0);
+            if (e != hipSuccess) (void)hipGetLastError();          // already enabled / unsupported: ignore
+        }
+    }
+    for (auto* w : m->w) w->th = std::thread(worker_main, w);
+    *out = m;
+    return OFPS_HIP_OK;
+}
+
+void ofps_hip_multi_destroy(ofps_hip_multi* m) {
+    if (!m) return;
+    for (auto* w : m->w) {
+        if (w->th.joinable()) {
+            { std::lock_guard<std::mutex> lk(w->m); w->quit = true; w->cv.notify_all(); }
+            w->th.join();
+        }
+        if (w->ctx) {
+            (void)hipSetDevice(w->device);
+            (void)hipDeviceSynchronize();
+            if (w->d_frames) (void)hipFree(w->d_frames);
+            if (w->d_out) (void)hipFree(w->d_out);
+            if (w->key_ready) (void)hipEventDestroy(w->key_ready);
+            ofps_hip_destroy(w->ctx);
+        }
+        delete w;
+    }
+    delete m;
+}
+
+const char* ofps_hip_multi_last_error(const ofps_hip_multi* m) { return m ? m->err : g_multi_init_err; }
+int ofps_hip_multi_worker_count(const ofps_hip_multi* m) { return m ? (int)m->w.size() : 0; }
+
+// Uploads a batch and leaves it resident: worker k gets the frames of its pair range (ofps_hip_multi_frame_range).
+int ofps_hip_multi_stage_frames(ofps_hip_multi* m, const uint8_t* frames, int n_frames, int W, int H, int stride, size_t frame_pitch,
+                                int ref_mode) {
+    if (!m) return OFPS_HIP_EINVAL;
+    if (!frames || n_frames < 1 || W < 1 || H < 1 || stride < W || frame_pitch < (size_t)stride * H || (ref_mode != 0 && ref_mode != 1))
+        return multi_error(m, OFPS_HIP_EINVAL, "multi_stage_frames: bad arguments (n_frames=%d W=%d H=%d stride=%d ref_mode=%d)", n_frames, W, H,
+                           stride, ref_mode);
+    const int n = (int)m->w.size();
+    m->W = W; m->H = H; m->dstride = (W + 63) & ~63; m->pitch = (size_t)m->dstride * H; m->ref_mode = ref_mode;
+    m->total_pairs = (size_t)n_frames - 1;
+    m->staged = false;
+    // phase 1: every worker uploads its own frames; worker 0 also the key frame (slot 0 of its buffer) in key mode
+    int rc = run_all(m, [&](Worker& w, int k) -> int {
+        OFPS_HIP_TRY(w.ctx, hipSetDevice(w.device));
+        size_t ff = 0, fc = 0;
+        ofps_hip_multi_pair_range(m->total_pairs, n, k, &w.first_pair, &w.n_pairs);
+        ofps_hip_multi_frame_range(m->total_pairs, n, k, ref_mode, &ff, &fc);
+        const size_t slots = fc + ((ref_mode == 1 && fc) ? 1 : 0);          // key mode: slot 0 holds the key frame
+        w.n_res_frames = slots;
+        int r = grow(w, &w.d_frames, &w.frames_cap, (slots ? slots : 1) * m->pitch);
+        if (r != OFPS_HIP_OK) return r;
+        if (!w.key_ready) OFPS_HIP_TRY(w.ctx, hipEventCreateWithFlags(&w.key_ready, hipEventDisableTiming));
+        hipStream_t s = w.ctx->stream;
+        const size_t base_slot = (ref_mode == 1 && fc) ? 1 : 0;
+        for (size_t j = 0; j < fc; ++j)
+            OFPS_HIP_TRY(w.ctx, ofps::upload_rows(w.d_frames + (base_slot + j) * m->pitch, m->dstride, frames + (ff + j) * frame_pitch, stride, W,
+                                                  H, s));
+        if (ref_mode == 1 && k == 0) {
+            if (!fc) { r = grow(w, &w.d_frames, &w.frames_cap, m->pitch); if (r != OFPS_HIP_OK) return r; }
+            OFPS_HIP_TRY(w.ctx, ofps::upload_rows(w.d_frames, m->dstride, frames, stride, W, H, s));
+            OFPS_HIP_TRY(w.ctx, hipEventRecord(w.key_ready, s));
+        }
+        OFPS_HIP_TRY(w.ctx, hipStreamSynchronize(s));
+        return OFPS_HIP_OK;
+    });
+    if (rc != OFPS_HIP_OK) return rc;
+    // phase 2 (key mode): the key frame travels device to device from worker 0's copy -- one xGMI hop per receiver
+    if (ref_mode == 1 && n > 1) {
+        Worker* w0 = m->w[0];
+        rc = run_all(m, [&](Worker& w, int k) -> int {
+            if (k == 0 || !w.n_pairs) return OFPS_HIP_OK;
+            OFPS_HIP_TRY(w.ctx, hipSetDevice(w.device));
+            hipStream_t s = w.ctx->stream;
+            OFPS_HIP_TRY(w.ctx, hipStreamWaitEvent(s, w0->key_ready, 0));
+            if (w.device == w0->device)
+                OFPS_HIP_TRY(w.ctx, hipMemcpyAsync(w.d_frames, w0->d_frames, m->pitch, hipMemcpyDeviceToDevice, s));
+            else
+                OFPS_HIP_TRY(w.ctx, hipMemcpyPeerAsync(w.d_frames, w.device, w0->d_frames, w0->device, m->pitch, s));
+            OFPS_HIP_TRY(w.ctx, hipStreamSynchronize(s));
+            return OFPS_HIP_OK;
+        });
+        if (rc != OFPS_HIP_OK) return rc;
+    }
+    m->staged = true;
+    return OFPS_HIP_OK;
+}
+
+// `steps` searches of every worker's resident pairs, back to back on its stream; returns when all workers are through.
+int ofps_hip_multi_run_resident(ofps_hip_multi* m, int block, int range, int steps) {
+    if (!m) return OFPS_HIP_EINVAL;
+    if (!m->staged) return multi_error(m, OFPS_HIP_EINVAL, "multi_run_resident: no staged batch");
+    if (steps < 1) return multi_error(m, OFPS_HIP_EINVAL, "multi_run_resident: steps must be >= 1");
+    const size_t nblk = ofps_hip_sad_block_count(m->W, m->H, block);
+    return run_all(m, [&](Worker& w, int) -> int {
+        if (!w.n_pairs) return OFPS_HIP_OK;
+        OFPS_HIP_TRY(w.ctx, hipSetDevice(w.device));
+        uint8_t* out8 = reinterpret_cast<uint8_t*>(w.d_out);
+        size_t cap = w.out_cap;
+        int r = grow(w, &out8, &cap, w.n_pairs * nblk * 4 * sizeof(float));
+        w.d_out = reinterpret_cast<float*>(out8); w.out_cap = cap;
+        if (r != OFPS_HIP_OK) return r;
+        for (int sidx = 0; sidx < steps; ++sidx) {
+            r = ofps_hip_sad_flow_dev(w.ctx, w.d_frames, (int)w.n_res_frames, m->W, m->H, m->dstride, m->pitch, m->ref_mode, block, range,
+                                      w.d_out, nullptr);
+            if (r != OFPS_HIP_OK) return r;
+        }
+        OFPS_HIP_TRY(w.ctx, hipStreamSynchronize(w.ctx->stream));
+        return OFPS_HIP_OK;
+    });
+}
+
+// results of the last run, in pair order: out_entries [(n_frames - 1) * nblk * 4] floats
+int ofps_hip_multi_fetch(ofps_hip_multi* m, int block, float* out_entries) {
+    if (!m || !out_entries) return OFPS_HIP_EINVAL;
+    if (!m->staged) return multi_error(m, OFPS_HIP_EINVAL, "multi_fetch: no staged batch");
+    const size_t nblk = ofps_hip_sad_block_count(m->W, m->H, block);
+    return run_all(m, [&](Worker& w, int) -> int {
+        if (!w.n_pairs) return OFPS_HIP_OK;
+        if (!w.d_out || w.out_cap < w.n_pairs * nblk * 4 * sizeof(float))
+            return ofps::set_error(w.ctx, OFPS_HIP_EINVAL, "multi_fetch: no results (run first, same block size)");
+        OFPS_HIP_TRY(w.ctx, hipSetDevice(w.device));
+        OFPS_HIP_TRY(w.ctx, hipMemcpyAsync(out_entries + w.first_pair * nblk * 4, w.d_out, w.n_pairs * nblk * 4 * sizeof(float),
+                                           hipMemcpyDeviceToHost, w.ctx->stream));
+        OFPS_HIP_TRY(w.ctx, hipStreamSynchronize(w.ctx->stream));
+        return OFPS_HIP_OK;
+    });
+}
+
+int ofps_hip_multi_sad_flow(ofps_hip_multi* m, const uint8_t* frames, int n_frames, int W, int H, int stride, size_t frame_pitch,
+                            int ref_mode, int block, int range, float* out_entries) {
+    if (!m) return OFPS_HIP_EINVAL;
+    if (!out_entries) return multi_error(m, OFPS_HIP_EINVAL, "multi_sad_flow: out_entries is NULL");
+    int rc = ofps_hip_multi_stage_frames(m, frames, n_frames, W, H, stride, frame_pitch, ref_mode);
+    if (rc != OFPS_HIP_OK) return rc;
+    if (n_frames < 2) return OFPS_HIP_OK;
+    rc = ofps_hip_multi_run_resident(m, block, range, 1);
+    if (rc != OFPS_HIP_OK) return rc;
+    return ofps_hip_multi_fetch(m, block, out_entries);
+}
+
+}  // extern "C"

@@ -359,3 +359,71 @@ class HipContext:
 
 def device_count() -> int:
     return int(_lib.load().ofps_hip_device_count())
+
+
+class MultiDevice:
+    """In-process multi-device dispatcher (include/ofps_hip.h: ofps_hip_multi_*): one worker thread + one context per entry
+    of `devices` (entries may repeat), frame pairs split into contiguous ranges, results in pair order."""
+
+    def __init__(self, devices):
+        self._lib = _lib.load()
+        devs = (C.c_int * len(devices))(*devices)
+        h = C.c_void_p()
+        rc = self._lib.ofps_hip_multi_init(devs, len(devices), C.byref(h))
+        if rc != 0:
+            raise OfpsHipError(rc, (self._lib.ofps_hip_multi_last_error(None) or b"").decode())
+        self._h = h
+        self.devices = list(devices)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.ofps_hip_multi_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int):
+        if rc != 0:
+            raise OfpsHipError(rc, (self._lib.ofps_hip_multi_last_error(self._h) or b"").decode())
+
+    @staticmethod
+    def pair_range(n_pairs: int, n_workers: int, k: int):
+        f, c = C.c_size_t(0), C.c_size_t(0)
+        _lib.load().ofps_hip_multi_pair_range(n_pairs, n_workers, k, C.byref(f), C.byref(c))
+        return int(f.value), int(c.value)
+
+    @staticmethod
+    def frame_range(n_pairs: int, n_workers: int, k: int, ref_mode: int):
+        f, c = C.c_size_t(0), C.c_size_t(0)
+        _lib.load().ofps_hip_multi_frame_range(n_pairs, n_workers, k, ref_mode, C.byref(f), C.byref(c))
+        return int(f.value), int(c.value)
+
+    def sad_flow(self, frames: np.ndarray, block: int, search_range: int, ref_mode: int = 0) -> np.ndarray:
+        """frames: uint8 [n_frames, H, stride>=W is the array's row pitch] -> entries [n_frames-1, nblk, 4]."""
+        frames = np.ascontiguousarray(frames, np.uint8)
+        n, H, W = frames.shape
+        nb = int(self._lib.ofps_hip_sad_block_count(W, H, block))
+        out = np.zeros((max(n - 1, 0), nb, 4), np.float32)
+        self._check(self._lib.ofps_hip_multi_sad_flow(self._h, frames.ctypes.data_as(C.POINTER(C.c_uint8)), n, W, H, W, W * H, ref_mode,
+                                                      block, search_range, _fp(out)))
+        return out
+
+    def stage_frames(self, frames: np.ndarray, ref_mode: int = 0):
+        frames = np.ascontiguousarray(frames, np.uint8)
+        n, H, W = frames.shape
+        self._geom = (n, H, W)
+        self._check(self._lib.ofps_hip_multi_stage_frames(self._h, frames.ctypes.data_as(C.POINTER(C.c_uint8)), n, W, H, W, W * H, ref_mode))
+
+    def run_resident(self, block: int, search_range: int, steps: int = 1):
+        self._check(self._lib.ofps_hip_multi_run_resident(self._h, block, search_range, steps))
+
+    def fetch(self, block: int) -> np.ndarray:
+        n, H, W = self._geom
+        nb = int(self._lib.ofps_hip_sad_block_count(W, H, block))
+        out = np.zeros((max(n - 1, 0), nb, 4), np.float32)
+        self._check(self._lib.ofps_hip_multi_fetch(self._h, block, _fp(out)))
+        return out
