@@ -83,6 +83,13 @@ def parse(argv=None):
                          "broadcasts to all ranks over RCCL inside the timed step")
     ap.add_argument("--pipeline", action="store_true",
                     help="the step also runs the fused tail (detect + Almeida LSQ) on the device-resident vectors")
+    ap.add_argument("--launcher", choices=["torchrun", "threads"], default="torchrun",
+                    help="torchrun (default): one process per GPU over RCCL (what the driver starts).  threads: ONE process, one "
+                         "worker thread + context per GPU through the C ABI's in-process dispatcher (ofps_hip_multi_*); the batch is "
+                         "split into contiguous pair ranges, no collective at all")
+    ap.add_argument("--prewarm-seconds", type=float, default=0.25,
+                    help="untimed steps run before the W warm-ups until this much wall time has passed: a short timed region right "
+                         "after an idle GPU reads up to 10 %% low while the clocks ramp (DESIGN.md 3)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="gloo only with --stub (CPU tests)")
     ap.add_argument("--stub", action="store_true",
                     help="TEST ONLY: no GPU, the step is a no-op that fills a deterministic result table; exercises the launch / "
@@ -136,6 +143,18 @@ def shard_plan(scaling: str, pairs: int, gen_pairs: int, world: int, rank: int, 
         ids = [int(walk[0])] + ids                     # slot 0 = the key frame (arrives by broadcast on ranks != 0)
     return {"first": int(first), "count": int(count), "frame_ids": [int(i) for i in ids], "seed_rank": seed_rank,
             "generated_pairs": int(G), "walk": walk}
+
+
+def pair_checksums(d_out, ctx=None, scratch=None):
+    """Per-pair 64-bit checksum of the records on the device: the wrapping sum of each pair's bytes read as int64 words --
+    through the library's one-launch kernel (ofps_hip_checksum_dev) when a context is given: torch's generic reduction took
+    0.11 ms of a 2.4 ms strong-scaling step."""
+    import torch
+    if ctx is None or d_out.shape[0] == 0:
+        return torch.sum(d_out.view(torch.int64).reshape(d_out.shape[0], -1), dim=1)
+    out = scratch if scratch is not None else torch.empty((d_out.shape[0],), dtype=torch.int64, device=d_out.device)
+    ctx.checksum_dev(d_out.data_ptr(), d_out[0].numel() * d_out.element_size(), d_out.shape[0], out.data_ptr())
+    return out
 
 
 def time_steps(step, steps: int, warmup: int, sync, barrier) -> float:
@@ -424,6 +443,7 @@ def run_rank(args) -> int:
         else:
             d_frames = torch.zeros((1, H, stride), dtype=torch.uint8, device=dev)
         d_out = torch.empty((max(count, 1), nblk, 4), dtype=torch.float32, device=dev)
+        d_chk = torch.zeros((count,), dtype=torch.int64, device=dev)
         ctx = HipContext(local_rank)
         ctx.use_torch_stream()            # launches go to torch's current stream: torch events see them
         ctx.set_sad_mode(ctx.SAD_PRUNED if args.sad_mode == "pruned" else ctx.SAD_EXHAUSTIVE)
@@ -458,7 +478,7 @@ def run_rank(args) -> int:
         if args.scaling == "strong":
             # per-pair results back to every rank in pair order: the only other collective, a few bytes per pair
             if not args.stub:
-                local = torch.sum(d_out[:count].view(torch.int32).reshape(count, -1), dim=1, dtype=torch.int64)
+                local = pair_checksums(d_out[:count], ctx, d_chk)
             else:
                 local = d_sum
             gathered["checksum"] = D.gather_results(local, P)
@@ -468,7 +488,17 @@ def run_rank(args) -> int:
 
     sync = (lambda: None) if args.stub else torch.cuda.synchronize
     barrier = D.StreamBarrier(dev)
-    el = D.max_over_ranks(time_steps(step, args.steps, args.warmup, sync, barrier), device=dev)
+    if not args.stub and args.prewarm_seconds > 0:
+        # clocks: a rank's first launches after an idle period run slow; with strong scaling a step is a few milliseconds
+        # (8 pairs of 4K frames at N = 8), so the W warm-ups alone do not cover the ramp
+        t_pw = time.perf_counter()
+        while time.perf_counter() - t_pw < args.prewarm_seconds:
+            for _ in range(4):
+                kernel_only()
+            sync()
+    el_local = time_steps(step, args.steps, args.warmup, sync, barrier)
+    el = D.max_over_ranks(el_local, device=dev)
+    el_min = -D.max_over_ranks(-el_local, device=dev)
 
     # ---- per-launch duration of the dominant kernel with HIP events on the launch stream (roofline leg)
     if args.stub:
@@ -480,6 +510,20 @@ def run_rank(args) -> int:
         torch.cuda.synchronize()
         launch_ms = float(np.mean([a.elapsed_time(b) for a, b in evs])) if count else 0.0
 
+    # ---- the gather alone (strong scaling): HIP events around K gathers, nothing else on the stream
+    gather_ms = None
+    if args.scaling == "strong" and not args.stub and D.active() and world > 1:
+        local = pair_checksums(d_out[:count], ctx, d_chk)
+        ga, gb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        D.gather_results(local, P)
+        torch.cuda.synchronize()
+        ga.record()
+        for _ in range(args.steps):
+            D.gather_results(local, P)
+        gb.record()
+        torch.cuda.synchronize()
+        gather_ms = D.max_over_ranks(ga.elapsed_time(gb) / args.steps, device=dev)
+
     seen = D.ranks_seen(dev)
     counts = D.gather_counts(count, dev)
     if seen != args.gpus:
@@ -489,6 +533,10 @@ def run_rank(args) -> int:
     if rank == 0:
         out = build_line(args, world, el, launch_ms, count, counts, nblk, seen,
                          None if args.stub else committed_traffic_per_pair(W, H, B, R))
+        out["launcher"] = "torchrun (one process per GPU, RCCL)" if D.active() else "single process"
+        out["per_rank_ms_per_step"] = {"min": round(el_min / args.steps * 1e3, 4), "max": round(el / args.steps * 1e3, 4)}
+        if gather_ms is not None:
+            out["gather_ms_per_step"] = round(gather_ms, 4)
 
     if args.pipeline and not args.stub:
         def full():
@@ -541,7 +589,8 @@ def run_rank(args) -> int:
             if args.scaling == "strong" and rank == 0:
                 kg = P - 1                                       # searched by the last rank that holds pairs
                 ent_g, _ = oracle.sad_flow(*host_pair(kg), B, R, threads=4)
-                want = int(ent_g.view(np.int32).astype(np.int64).sum())
+                with np.errstate(over="ignore"):
+                    want = int(np.ascontiguousarray(ent_g).view(np.int64).sum(dtype=np.int64))   # wrapping, like the device sum
                 gather_ok = int(int(gathered["checksum"][kg].item()) == want)
         except ImportError as e:                                 # no oracle on this machine: report "not checked"
             print(f"[bench] parity check skipped on rank {rank}: {e}", file=sys.stderr)
@@ -594,6 +643,73 @@ def run_rank(args) -> int:
     return 0
 
 
+def run_threads(args) -> int:
+    """`--launcher threads`: one process drives N GPUs through ofps_hip_multi_* (one worker thread + context per device).  The
+    batch is ONE sequence split into contiguous pair ranges (strong: P pairs in total; weak: N * P pairs, P per worker); a
+    step is one search of every worker's resident pairs; the timed region is K steps per worker, bracketed by the
+    dispatcher's join on both sides (every worker synchronises its stream before it reports back)."""
+    import torch
+    from ofps_amd import synth
+    from ofps_amd.runtime import MultiDevice
+    if args.stub or args.pipeline or args.ref_mode == "key" and args.scaling == "weak":
+        raise SystemExit("bench.py --launcher threads: supports the SAD step, pairs or key mode (key mode with --scaling strong)")
+    if not torch.cuda.is_available() or torch.cuda.device_count() < args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} needs that many GPUs; this node has "
+                         f"{torch.cuda.device_count() if torch.cuda.is_available() else 0} (no CPU fallback)")
+    N, W, H, B, R, P = args.gpus, args.width, args.height, args.block, args.search_range, args.pairs
+    total = P if args.scaling == "strong" else N * P
+    key_mode = args.ref_mode == "key"
+    nblk = (W // B) * (H // B)
+    G = max(1, min(total, args.gen_pairs))
+    gen = dict(max_step=R) if args.content == "regions" else dict(max_step=min(R, 12), region=1 << 14, noise=1)
+    frames = synth.luma_sequence(G + 1, W, H, seed=synth.SEED0, **gen)
+    walk = np.abs(((np.arange(total + 1) + G) % (2 * G)) - G) if G > 1 else np.arange(total + 1) % 2
+    host = np.ascontiguousarray(frames[walk])
+    md = MultiDevice(list(range(N)))
+    try:
+        md.stage_frames(host, 1 if key_mode else 0)
+        t_pw = time.perf_counter()
+        while time.perf_counter() - t_pw < args.prewarm_seconds:
+            md.run_resident(B, R, 4)
+        if args.warmup:
+            md.run_resident(B, R, args.warmup)
+        t0 = time.perf_counter()
+        md.run_resident(B, R, args.steps)
+        el = time.perf_counter() - t0
+        ms = md.run_resident(B, R, args.steps, timed=True)              # per-worker HIP events (roofline leg)
+        got = md.fetch(B)
+    finally:
+        md.close()
+    counts = [MultiDevice.pair_range(total, N, k)[1] for k in range(N)]
+    args_line = argparse.Namespace(**vars(args))
+    args_line.pairs = total if args.scaling == "strong" else P
+    out = build_line(args_line, N, el, float(ms[0]) / args.steps, counts[0], counts, nblk, N, committed_traffic_per_pair(W, H, B, R))
+    out["launcher"] = "threads (one process, ofps_hip_multi_*: one worker thread + context per GPU, no collective)"
+    out["per_rank_ms_per_step"] = {"min": round(float(ms[ms > 0].min()) / args.steps, 4) if (ms > 0).any() else 0.0,
+                                   "max": round(float(ms.max()) / args.steps, 4), "what": "HIP events per worker"}
+    mismatch = False
+    try:
+        import oracle
+        ok = True
+        for k in range(N):                                           # one pair of every worker's range
+            first, cnt = MultiDevice.pair_range(total, N, k)
+            if not cnt:
+                continue
+            kp = first + (3 * k + 1) % cnt
+            prev = host[0] if key_mode else host[kp]
+            ent_o, _ = oracle.sad_flow(prev, host[kp + 1], B, R, threads=4)
+            ok = ok and bool((got[kp].view(np.uint32) == ent_o.view(np.uint32)).all())
+        out["parity_check"] = {"what": "one searched pair per worker vs the CPU oracle, bit for bit", "ranks": N, "ok": ok}
+        mismatch = not ok
+    except ImportError as e:
+        out["parity_check"] = {"ok": None, "skipped": str(e)}
+    print(json.dumps(out), flush=True)
+    if mismatch:
+        print("[bench] PARITY MISMATCH against the oracle -- the line above is not a valid measurement", file=sys.stderr)
+        return 3
+    return 0
+
+
 def main(argv=None) -> int:
     args = parse(argv)
     if args.end_to_end_only:
@@ -604,6 +720,8 @@ def main(argv=None) -> int:
     from ofps_amd import distributed as D
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
+    if args.launcher == "threads":
+        return run_threads(args)
     if args.gpus > 1 and not D.launched_by_torchrun():
         # `python bench.py --gpus N` without a launcher: become the launcher (one rank per GPU, RCCL)
         if not args.stub:

@@ -254,6 +254,10 @@ int ofps_hip_frame_wait(ofps_hip_ctx* ctx, int ticket, ofps_hip_frame_result* ou
  * frames 0, k+1) the key frame is uploaded once and fanned out device to device (hipMemcpyPeerAsync, xGMI point to
  * point).  Results come back in pair order.  The reference's counterpart is its worker-thread model
  * (ofps-suite/src/app/tracking/worker.rs:251-260,347-352); it has no multi-GPU code of its own. ---- */
+/* Per-item checksum of device-resident data (records, fields): d_out_u64[item] = wrapping sum of the item's bytes read
+ * as u64 words -- what a host gathers across GPUs instead of the records when it only needs to confirm them.  Enqueues on
+ * the context's stream; bytes_per_item % 8 == 0. */
+int ofps_hip_checksum_dev(ofps_hip_ctx* ctx, const void* d_data, size_t bytes_per_item, int batch, void* d_out_u64);
 typedef struct ofps_hip_multi ofps_hip_multi;
 int  ofps_hip_multi_init(const int* devices, int n, ofps_hip_multi** out);
 void ofps_hip_multi_destroy(ofps_hip_multi* m);
@@ -273,7 +277,8 @@ int ofps_hip_multi_sad_flow(ofps_hip_multi* m, const uint8_t* frames, int n_fram
  * the last results back in pair order. */
 int ofps_hip_multi_stage_frames(ofps_hip_multi* m, const uint8_t* frames, int n_frames, int W, int H, int stride,
                                 size_t frame_pitch, int ref_mode);
-int ofps_hip_multi_run_resident(ofps_hip_multi* m, int block, int range, int steps);
+int ofps_hip_multi_run_resident(ofps_hip_multi* m, int block, int range, int steps,
+                                float* worker_ms /* NULL, or one entry per worker: HIP-event time of its `steps` launches */);
 int ofps_hip_multi_fetch(ofps_hip_multi* m, int block, float* out_entries);
 
 #ifdef __cplusplus

@@ -94,6 +94,7 @@ PROTOTYPES["ofps_hip_push_frame_async"] = (C.c_int, [_ctx, _u8p, C.c_int, C.c_in
 PROTOTYPES["ofps_hip_frame_wait"] = (C.c_int, [_ctx, C.c_int, C.POINTER(FrameResult)])
 
 _multi = C.c_void_p
+PROTOTYPES["ofps_hip_checksum_dev"] = (C.c_int, [_ctx, _vp, C.c_size_t, C.c_int, _vp])
 PROTOTYPES["ofps_hip_multi_init"] = (C.c_int, [C.POINTER(C.c_int), C.c_int, C.POINTER(_multi)])
 PROTOTYPES["ofps_hip_multi_destroy"] = (None, [_multi])
 PROTOTYPES["ofps_hip_multi_last_error"] = (C.c_char_p, [_multi])
@@ -102,7 +103,7 @@ PROTOTYPES["ofps_hip_multi_pair_range"] = (None, [C.c_size_t, C.c_int, C.c_int, 
 PROTOTYPES["ofps_hip_multi_frame_range"] = (None, [C.c_size_t, C.c_int, C.c_int, C.c_int, _szp, _szp])
 PROTOTYPES["ofps_hip_multi_sad_flow"] = (C.c_int, [_multi, _u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_int, _f32p])
 PROTOTYPES["ofps_hip_multi_stage_frames"] = (C.c_int, [_multi, _u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_int])
-PROTOTYPES["ofps_hip_multi_run_resident"] = (C.c_int, [_multi, C.c_int, C.c_int, C.c_int])
+PROTOTYPES["ofps_hip_multi_run_resident"] = (C.c_int, [_multi, C.c_int, C.c_int, C.c_int, _f32p])
 PROTOTYPES["ofps_hip_multi_fetch"] = (C.c_int, [_multi, C.c_int, _f32p])
 
 _lib = None

@@ -1400,10 +1400,16 @@ static int lsq_cluster(ofps_hip_ctx* ctx, const float4* d_entries, size_t n, int
     // tools/almeida_prof.py (ms per launch ~ 0.11 + 0.004 * ept + 0.00001 * workgroups per item -- with the two-level gather
     // a workgroup more costs next to nothing, a record more per thread is arithmetic on the critical path); the count that
     // minimises launches x cost wins (lone problems: the smallest that fits; 64 x 129,600 vectors: 8 -> 4 launches).
-    int ept = 8;
+    // The exact-arithmetic variant (fields of <= 65,536 vectors) stops at 4 records per thread: with 8, the hoisted
+    // unprojection beside 8 records and their prototypes does not fit 128 VGPRs (13 spilled, 56 B of scratch per lane);
+    // the dense variant does not keep the unprojection and fits.
+    const bool dense_by_size = ctx->opt.almeida_fast >= 0 ? ctx->opt.almeida_fast != 0 : n > 65536;
+    const int ept_max = dense_by_size ? 8 : 4;
+    int ept = ept_max;
     {
         double best = 1e30;
         for (int e : {1, 2, 4, 8}) {
+            if (e > ept_max) continue;
             const size_t nb = (n + (size_t)e * 1024 - 1) / ((size_t)e * 1024);
             if (nb < 1 || nb > 256 || nb > (size_t)ctx->num_cus) continue;
             const int per = ctx->num_cus / (int)nb;
@@ -1415,7 +1421,7 @@ static int lsq_cluster(ofps_hip_ctx* ctx, const float4* d_entries, size_t n, int
     // to 1.3k cycles per step but the gather waits that much longer: a step ends one cross-XCD exchange after the LAST
     // workgroup published, 0.104 vs 0.105 ms at 8,040 vectors; OFPS_HIP_ALMEIDA_BLOCK=256 keeps the variant for A/B runs)
     int block = 1024;
-    if (ctx->opt.almeida_ept) ept = ctx->opt.almeida_ept;            // A/B (OFPS_HIP_ALMEIDA_EPT)
+    if (ctx->opt.almeida_ept) ept = ctx->opt.almeida_ept < ept_max ? ctx->opt.almeida_ept : ept_max;   // A/B (OFPS_HIP_ALMEIDA_EPT)
     if (ctx->opt.almeida_block) block = ctx->opt.almeida_block;      // A/B (OFPS_HIP_ALMEIDA_BLOCK)
     if (block == 256 && ept > 2) ept = 2;
     const size_t per_wg = (size_t)ept * block;
@@ -1423,8 +1429,7 @@ static int lsq_cluster(ofps_hip_ctx* ctx, const float4* d_entries, size_t n, int
     if (nblk_sz < 1 || nblk_sz > 256 || nblk_sz > (size_t)ctx->num_cus) return 0;
     const int nblk = (int)nblk_sz;
     const int per_launch = ctx->num_cus / nblk;              // items whose workgroups are all co-resident (1 per CU)
-    bool dense = n > 65536;                                  // per-pixel regime: reciprocal-multiply quotients, see fdiv
-    if (ctx->opt.almeida_fast >= 0) dense = ctx->opt.almeida_fast != 0;                        // A/B (OFPS_HIP_ALMEIDA_FAST)
+    const bool dense = dense_by_size;                        // per-pixel regime: reciprocal-multiply quotients, see fdiv (A/B: OFPS_HIP_ALMEIDA_FAST)
     const size_t gran_bytes = (size_t)per_launch * cluster_gran_per_item(nblk) * sizeof(gran_u4);
     auto* gran = static_cast<gran_u4*>(scratch(ctx, S_GRAN, gran_bytes));
     if (!gran) return OFPS_HIP_ENOMEM;
@@ -1464,7 +1469,6 @@ static int lsq_cluster(ofps_hip_ctx* ctx, const float4* d_entries, size_t n, int
         else if (dense && ept == 4) launch_cluster<true, 4>(ctx, s, nblk, items, ent, n, cam, gran, tag_base, q, prof, recoveries);
         else if (dense && ept == 2) launch_cluster<true, 2>(ctx, s, nblk, items, ent, n, cam, gran, tag_base, q, prof, recoveries);
         else if (dense) launch_cluster<true, 1>(ctx, s, nblk, items, ent, n, cam, gran, tag_base, q, prof, recoveries);
-        else if (ept == 8) launch_cluster<false, 8>(ctx, s, nblk, items, ent, n, cam, gran, tag_base, q, prof, recoveries);
         else if (ept == 4) launch_cluster<false, 4>(ctx, s, nblk, items, ent, n, cam, gran, tag_base, q, prof, recoveries);
         else if (ept == 2) launch_cluster<false, 2>(ctx, s, nblk, items, ent, n, cam, gran, tag_base, q, prof, recoveries);
         else launch_cluster<false, 1>(ctx, s, nblk, items, ent, n, cam, gran, tag_base, q, prof, recoveries);

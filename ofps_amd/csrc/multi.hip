@@ -48,6 +48,23 @@ static thread_local char g_multi_init_err[512] = {0};
 
 namespace {
 
+// Per-item checksum of device-resident records: the wrapping sum of an item's bytes read as u64 words.  What a host that
+// gathers per-pair results across GPUs exchanges instead of the records themselves (bench.py's strong-scaling step: 8 B
+// per pair on the wire), and what it compares against the same sum over a CPU result.
+__global__ __launch_bounds__(256) void checksum_kernel(const unsigned long long* __restrict__ words, size_t words_per_item,
+                                                       unsigned long long* __restrict__ out) {
+    __shared__ unsigned long long part[4];
+    const size_t item = blockIdx.y;
+    const unsigned long long* w = words + item * words_per_item;
+    unsigned long long acc = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < words_per_item; i += (size_t)gridDim.x * 256) acc += w[i];
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out + item, part[0] + part[1] + part[2] + part[3]);
+}
+
 using Worker = ofps_hip_multi::Worker;
 
 int multi_error(ofps_hip_multi* m, int code, const char* fmt, ...) {
@@ -108,6 +125,23 @@ int grow(Worker& w, uint8_t** p, size_t* cap, size_t bytes) {
 }  // namespace
 
 extern "C" {
+
+int ofps_hip_checksum_dev(ofps_hip_ctx* ctx, const void* d_data, size_t bytes_per_item, int batch, void* d_out_u64) {
+    if (!ctx) return OFPS_HIP_EINVAL;
+    OFPS_REQUIRE(ctx, d_out_u64 && (d_data || bytes_per_item == 0) && batch >= 0 && batch <= 65535, "checksum: bad arguments");
+    OFPS_REQUIRE(ctx, bytes_per_item % 8 == 0 && (reinterpret_cast<uintptr_t>(d_data) & 7) == 0, "checksum: items must be whole, 8-byte aligned u64 words");
+    if (batch == 0) return OFPS_HIP_OK;
+    OFPS_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    OFPS_HIP_TRY(ctx, hipMemsetAsync(d_out_u64, 0, (size_t)batch * sizeof(unsigned long long), ctx->stream));
+    const size_t words = bytes_per_item / 8;
+    if (words == 0) return OFPS_HIP_OK;
+    unsigned gx = (unsigned)((words + 4 * 256 - 1) / (4 * 256));
+    if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(checksum_kernel, dim3(gx ? gx : 1, batch), dim3(256), 0, ctx->stream, static_cast<const unsigned long long*>(d_data), words,
+                       static_cast<unsigned long long*>(d_out_u64));
+    OFPS_HIP_TRY(ctx, hipGetLastError());
+    return OFPS_HIP_OK;
+}
 
 void ofps_hip_multi_pair_range(size_t n_pairs, int n_workers, int k, size_t* first, size_t* count) {
     size_t f = 0, c = 0;
@@ -246,12 +280,13 @@ int ofps_hip_multi_stage_frames(ofps_hip_multi* m, const uint8_t* frames, int n_
 }
 
 // `steps` searches of every worker's resident pairs, back to back on its stream; returns when all workers are through.
-int ofps_hip_multi_run_resident(ofps_hip_multi* m, int block, int range, int steps) {
+int ofps_hip_multi_run_resident(ofps_hip_multi* m, int block, int range, int steps, float* worker_ms) {
     if (!m) return OFPS_HIP_EINVAL;
     if (!m->staged) return multi_error(m, OFPS_HIP_EINVAL, "multi_run_resident: no staged batch");
     if (steps < 1) return multi_error(m, OFPS_HIP_EINVAL, "multi_run_resident: steps must be >= 1");
     const size_t nblk = ofps_hip_sad_block_count(m->W, m->H, block);
-    return run_all(m, [&](Worker& w, int) -> int {
+    return run_all(m, [&](Worker& w, int k) -> int {
+        if (worker_ms) worker_ms[k] = 0.0f;
         if (!w.n_pairs) return OFPS_HIP_OK;
         OFPS_HIP_TRY(w.ctx, hipSetDevice(w.device));
         uint8_t* out8 = reinterpret_cast<uint8_t*>(w.d_out);
@@ -259,11 +294,13 @@ int ofps_hip_multi_run_resident(ofps_hip_multi* m, int block, int range, int ste
         int r = grow(w, &out8, &cap, w.n_pairs * nblk * 4 * sizeof(float));
         w.d_out = reinterpret_cast<float*>(out8); w.out_cap = cap;
         if (r != OFPS_HIP_OK) return r;
+        if (worker_ms) { r = ofps_hip_timer_start(w.ctx); if (r != OFPS_HIP_OK) return r; }
         for (int sidx = 0; sidx < steps; ++sidx) {
             r = ofps_hip_sad_flow_dev(w.ctx, w.d_frames, (int)w.n_res_frames, m->W, m->H, m->dstride, m->pitch, m->ref_mode, block, range,
                                       w.d_out, nullptr);
             if (r != OFPS_HIP_OK) return r;
         }
+        if (worker_ms) return ofps_hip_timer_stop(w.ctx, &worker_ms[k]);      // HIP events on the worker's stream; synchronises
         OFPS_HIP_TRY(w.ctx, hipStreamSynchronize(w.ctx->stream));
         return OFPS_HIP_OK;
     });
@@ -293,7 +330,7 @@ int ofps_hip_multi_sad_flow(ofps_hip_multi* m, const uint8_t* frames, int n_fram
     int rc = ofps_hip_multi_stage_frames(m, frames, n_frames, W, H, stride, frame_pitch, ref_mode);
     if (rc != OFPS_HIP_OK) return rc;
     if (n_frames < 2) return OFPS_HIP_OK;
-    rc = ofps_hip_multi_run_resident(m, block, range, 1);
+    rc = ofps_hip_multi_run_resident(m, block, range, 1, nullptr);
     if (rc != OFPS_HIP_OK) return rc;
     return ofps_hip_multi_fetch(m, block, out_entries);
 }

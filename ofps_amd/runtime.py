@@ -276,6 +276,10 @@ class HipContext:
                                                    C.c_void_p(d_out_quat)))
 
 
+    def checksum_dev(self, d_data: int, bytes_per_item: int, batch: int, d_out_u64: int):
+        """Per-item wrapping u64 sum of device-resident data (ofps_hip_checksum_dev); enqueue only."""
+        self._check(self._lib.ofps_hip_checksum_dev(self._h, C.c_void_p(d_data), bytes_per_item, batch, C.c_void_p(d_out_u64)))
+
     # ---- fused per-frame path
     def reset_frames(self):
         self._check(self._lib.ofps_hip_reset_frames(self._h))
@@ -418,8 +422,11 @@ class MultiDevice:
         self._geom = (n, H, W)
         self._check(self._lib.ofps_hip_multi_stage_frames(self._h, frames.ctypes.data_as(C.POINTER(C.c_uint8)), n, W, H, W, W * H, ref_mode))
 
-    def run_resident(self, block: int, search_range: int, steps: int = 1):
-        self._check(self._lib.ofps_hip_multi_run_resident(self._h, block, search_range, steps))
+    def run_resident(self, block: int, search_range: int, steps: int = 1, timed: bool = False):
+        """-> None, or with timed=True the per-worker HIP-event milliseconds of the `steps` launches."""
+        ms = np.zeros(len(self.devices), np.float32) if timed else None
+        self._check(self._lib.ofps_hip_multi_run_resident(self._h, block, search_range, steps, _fp(ms) if timed else None))
+        return ms
 
     def fetch(self, block: int) -> np.ndarray:
         n, H, W = self._geom

@@ -104,3 +104,26 @@ def test_multi_resident_batch_more_workers_than_pairs_and_repeated_runs():
     for k in range(F - 1):
         ent_o, _ = oracle.sad_flow(fr[k], fr[k + 1], B, R)
         np.testing.assert_array_equal(got[k].view(np.uint32), ent_o.view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_checksum_dev_is_the_wrapping_u64_sum_per_item():
+    """ofps_hip_checksum_dev: what bench.py's strong-scaling step gathers across ranks instead of the records."""
+    import torch
+    from ofps_amd.runtime import HipContext
+    rng = np.random.default_rng(5)
+    for batch, words in ((1, 1), (3, 1000), (8, 129600 * 2), (5, 257)):
+        a = rng.integers(0, 2 ** 63, size=(batch, words), dtype=np.uint64) * 2 + rng.integers(0, 2, size=(batch, words), dtype=np.uint64)
+        d = torch.from_numpy(a.view(np.int64)).cuda()
+        out = torch.full((batch,), -1, dtype=torch.int64, device="cuda")
+        ctx = HipContext(0)
+        try:
+            ctx.use_torch_stream()
+            ctx.checksum_dev(d.data_ptr(), words * 8, batch, out.data_ptr())
+            torch.cuda.synchronize()
+            ctx.use_own_stream()
+        finally:
+            ctx.close()
+        with np.errstate(over="ignore"):
+            want = a.sum(axis=1, dtype=np.uint64)
+        np.testing.assert_array_equal(out.cpu().numpy().view(np.uint64), want)
