@@ -247,6 +247,18 @@ int ofps_hip_push_frame_async(ofps_hip_ctx* ctx, const uint8_t* luma, int W, int
                               const ofps_hip_frame_params* params, float* out_entries /* 4*nblk or NULL */,
                               float* out_field /* 2*dim*dim or NULL */, int* ticket);
 int ofps_hip_frame_wait(ofps_hip_ctx* ctx, int ticket, ofps_hip_frame_result* out);
+/* Batched read-ahead form: n consecutive frames of a stream per ticket (a decoder running n frames ahead).  `frames` holds
+ * them frame_pitch bytes apart; ONE upload, one search launch over the batch's pairs, one detector chain and one
+ * estimator launch over the batch, one read-back: a handful of HIP calls per batch instead of ~9 per frame.  Frame j is
+ * paired with the stream's previous frame (the last frame of the previous batch for j = 0; the very first frame of a
+ * stream yields have_vectors = 0).  Vectors and detector results equal n single pushes bit for bit; the quaternions agree
+ * to the solver's parity bound (2e-6: a batch is solved by one launch over its items, a lone frame by the cluster solver --
+ * two fixed summation orders), frame j's RANSAC seed = params->seed + j.  out_entries (n * nblk * 4 floats, or NULL) receives every frame's vectors at j * nblk * 4.  Up to 2 batches in
+ * flight; `frames` / `out_entries` must stay valid until ofps_hip_frames_wait(ticket) returns, which fills out[0..n-1].
+ * The batched stream is separate from the single-frame calls' (its own previous frame); ofps_hip_reset_frames resets both. */
+int ofps_hip_push_frames_async(ofps_hip_ctx* ctx, const uint8_t* frames, int n, int W, int H, int stride, size_t frame_pitch,
+                               const ofps_hip_frame_params* params, float* out_entries /* n*4*nblk or NULL */, int* ticket);
+int ofps_hip_frames_wait(ofps_hip_ctx* ctx, int ticket, ofps_hip_frame_result* out /* n entries */);
 
 /* ---- one host process, several GPUs: frame pairs are independent units, so a batch is split into
  * contiguous pair ranges, one worker thread + one context + one stream per entry of `devices` (an entry may repeat: the

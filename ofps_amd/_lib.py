@@ -92,6 +92,9 @@ PROTOTYPES["ofps_hip_push_frame"] = (C.c_int, [_ctx, _u8p, C.c_int, C.c_int, C.c
 PROTOTYPES["ofps_hip_push_frame_async"] = (C.c_int, [_ctx, _u8p, C.c_int, C.c_int, C.c_int, C.POINTER(FrameParams), _f32p, _f32p,
                                                      C.POINTER(C.c_int)])
 PROTOTYPES["ofps_hip_frame_wait"] = (C.c_int, [_ctx, C.c_int, C.POINTER(FrameResult)])
+PROTOTYPES["ofps_hip_push_frames_async"] = (C.c_int, [_ctx, _u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t, C.POINTER(FrameParams), _f32p,
+                                                      C.POINTER(C.c_int)])
+PROTOTYPES["ofps_hip_frames_wait"] = (C.c_int, [_ctx, C.c_int, C.POINTER(FrameResult)])
 
 _multi = C.c_void_p
 PROTOTYPES["ofps_hip_checksum_dev"] = (C.c_int, [_ctx, _vp, C.c_size_t, C.c_int, _vp])

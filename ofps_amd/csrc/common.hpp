@@ -66,6 +66,24 @@ struct ofps_hip_ctx {
     } pipe_ticket[kPipeTickets];
     long pipe_next_ticket = 0;
 
+    // batched form of the same pipeline (ofps_hip_push_frames_async): n frames per ticket, ONE upload, ONE search launch
+    // over the batch's pairs, ONE read-back.  Two batch buffers of (capacity + 1) frames alternate: slot 0 holds the last
+    // frame of the previous batch (the first pair's previous frame).  Its stream of frames is separate from the
+    // single-frame calls'.
+    static constexpr int kBatchTickets = 2;
+    struct BatchTicket {
+        bool pending = false;
+        hipEvent_t done = nullptr, uploaded = nullptr, prev_copied = nullptr;
+        bool prev_copied_valid = false;
+        void* pinned = nullptr; size_t pinned_cap = 0;       // n x {result[4], quat[4]}
+        int n = 0, first_has_prev = 0, run_detector = 0, run_estimator = 0;
+        size_t n_vectors = 0;
+    } batch_ticket[kBatchTickets];
+    long batch_next_ticket = 0;
+    long batch_frames = 0;               // frames pushed through the batched form since the last reset
+    int batch_w = 0, batch_h = 0;
+    void* batch_last_frame = nullptr;    // device address of the newest frame of the batched stream
+
     // cluster Almeida solver (almeida.hip): granule exchange buffer state.  Tags are unique per call (tag base advances
     // by 32 per launch), so the buffer is zeroed only when (re)allocated or when the 32-bit tag space wraps.
     uint32_t gran_tag_base = 0;
@@ -74,7 +92,7 @@ struct ofps_hip_ctx {
     // grow-only device scratch owned by the context (staging for host-pointer entry points and
     // kernel workspaces); never shrinks, freed in ofps_hip_destroy.
     struct Scratch { void* p = nullptr; size_t cap = 0; uint64_t gen = 0; };   // gen: bumped by every (re)allocation of the slot
-    static constexpr int kNumScratch = 32;
+    static constexpr int kNumScratch = 40;
     Scratch scratch[kNumScratch];
 };
 
@@ -85,7 +103,7 @@ enum ScratchSlot {
     S_QUAT, S_WORK4, S_PIPE_FRAMES, S_PIPE_ENTRIES, S_PIPE_OUT, S_MASK, S_ENTRIES2, S_GRAN, S_SAD_LIST,
     // the estimator's own workspaces: it may run beside the detector (pipeline.hip), so the two share no slot
     S_ALM_PART, S_ALM_STATE, S_ALM_HYP, S_ALM_COUNTS, S_ALM_SEL, S_ALM_SELN, S_ALM_PROF, S_ALM_RECOVER,
-    S_LK_FRAMES
+    S_LK_FRAMES, S_BATCH_FRAMES, S_BATCH_ENTRIES, S_BATCH_OUT, S_BATCH_FIELD
 };
 
 int set_error(ofps_hip_ctx* ctx, int code, const char* fmt, ...);

@@ -190,6 +190,12 @@ void ofps_hip_destroy(ofps_hip_ctx* ctx) {
         if (t.pinned) (void)hipHostFree(t.pinned);
         if (t.done) (void)hipEventDestroy(t.done);
     }
+    for (auto& t : ctx->batch_ticket) {
+        if (t.pinned) (void)hipHostFree(t.pinned);
+        if (t.done) (void)hipEventDestroy(t.done);
+        if (t.uploaded) (void)hipEventDestroy(t.uploaded);
+        if (t.prev_copied) (void)hipEventDestroy(t.prev_copied);
+    }
     for (int k = 0; k < ofps_hip_ctx::kPipeSlots; ++k) {
         if (ctx->pipe_uploaded[k]) (void)hipEventDestroy(ctx->pipe_uploaded[k]);
         if (ctx->pipe_slot_read[k]) (void)hipEventDestroy(ctx->pipe_slot_read[k]);

@@ -115,6 +115,11 @@ extern "C" {
 int ofps_hip_reset_frames(ofps_hip_ctx* ctx) {
     if (!ctx) return OFPS_HIP_EINVAL;
     OFPS_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    for (auto& bt : ctx->batch_ticket) {
+        if (bt.pending && bt.done) OFPS_HIP_TRY(ctx, hipEventSynchronize(bt.done));
+        bt.pending = false;
+    }
+    ctx->batch_frames = 0; ctx->batch_last_frame = nullptr;
     return pipe_drain(ctx);
 }
 
@@ -273,6 +278,172 @@ int ofps_hip_frame_wait(ofps_hip_ctx* ctx, int ticket, ofps_hip_frame_result* ou
             out->dim = host->result[2];
         }
         if (t.run_estimator) memcpy(out->quat, host->quat, sizeof(out->quat));
+    }
+    return OFPS_HIP_OK;
+}
+
+// ---- batched read-ahead form: n consecutive frames of the stream per ticket.  What a decoder that runs n frames ahead
+// (ofps-suite/src/app/tracking/worker.rs:165-226 decodes into a buffer on its own thread) hands over in one go: ONE H2D of the
+// n frames (contiguous at frame_pitch), one search launch over the batch's pairs, one detector chain and one estimator
+// launch over the batch, one read-back -- a handful of HIP calls per BATCH instead of ~9 per frame, which is what kept
+// the single-frame loop 20 % under the PCIe ceiling.  Frame j of the batch is pair (previous frame of the stream, frame
+// j); the previous frame of frame 0 is the last frame of the previous batch, kept in slot 0 of the other batch buffer.
+int ofps_hip_push_frames_async(ofps_hip_ctx* ctx, const uint8_t* frames, int n, int W, int H, int stride, size_t frame_pitch,
+                               const ofps_hip_frame_params* prm, float* out_entries, int* ticket) {
+    if (!ctx) return OFPS_HIP_EINVAL;
+    OFPS_REQUIRE(ctx, frames && prm && ticket && n >= 1 && n <= 4096, "push_frames_async: bad arguments (n=%d)", n);
+    OFPS_REQUIRE(ctx, W > 0 && H > 0 && stride >= W && frame_pitch >= (size_t)stride * H, "push_frames_async: bad geometry W=%d H=%d stride=%d", W, H, stride);
+    OFPS_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc = pipe_setup(ctx);
+    if (rc != OFPS_HIP_OK) return rc;
+    const long tno = ctx->batch_next_ticket;
+    auto& t = ctx->batch_ticket[tno % ofps_hip_ctx::kBatchTickets];
+    OFPS_REQUIRE(ctx, !t.pending, "push_frames_async: ticket %ld has not been collected (at most %d batches in flight)",
+                 tno - ofps_hip_ctx::kBatchTickets, ofps_hip_ctx::kBatchTickets);
+    if (!t.done) {
+        OFPS_HIP_TRY(ctx, hipEventCreateWithFlags(&t.done, hipEventDisableTiming));
+        OFPS_HIP_TRY(ctx, hipEventCreateWithFlags(&t.uploaded, hipEventDisableTiming));
+        OFPS_HIP_TRY(ctx, hipEventCreateWithFlags(&t.prev_copied, hipEventDisableTiming));
+    }
+    if (W != ctx->batch_w || H != ctx->batch_h) {              // geometry change restarts the stream
+        for (auto& bt : ctx->batch_ticket)
+            if (bt.pending && bt.done) { OFPS_HIP_TRY(ctx, hipEventSynchronize(bt.done)); bt.pending = false; }
+        ctx->batch_w = W; ctx->batch_h = H; ctx->batch_frames = 0; ctx->batch_last_frame = nullptr;
+    }
+    const int dstride = (W + 63) & ~63;
+    const size_t pitch = (size_t)dstride * H;
+    const size_t nblk = ofps_hip_sad_block_count(W, H, prm->block);
+    const int tix = (int)(tno % ofps_hip_ctx::kBatchTickets);
+    // capacity: both buffers and the per-ticket outputs are sized for the largest batch seen (grow-only; growing waits
+    // for work in flight)
+    constexpr size_t kOutBytes = 32;                             // {result[4], quat[4]} per frame
+    const size_t cap_frames = (size_t)n + 1;
+    auto& fs = ctx->scratch[ofps::S_BATCH_FRAMES];
+    size_t per_buf = fs.cap / ofps_hip_ctx::kBatchTickets / (pitch ? pitch : 1);
+    if (per_buf < cap_frames) {
+        for (auto& bt : ctx->batch_ticket)
+            if (bt.pending && bt.done) OFPS_HIP_TRY(ctx, hipEventSynchronize(bt.done));
+        // the newest frame of the stream lives in the old allocation: keep a copy
+        void* keep = nullptr;
+        if (ctx->batch_last_frame) {
+            OFPS_HIP_TRY(ctx, hipMalloc(&keep, pitch));
+            OFPS_HIP_TRY(ctx, hipMemcpyAsync(keep, ctx->batch_last_frame, pitch, hipMemcpyDeviceToDevice, ctx->stream));
+            OFPS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        }
+        auto* nb = static_cast<uint8_t*>(ofps::scratch(ctx, ofps::S_BATCH_FRAMES, ofps_hip_ctx::kBatchTickets * cap_frames * pitch));
+        if (!nb) { if (keep) (void)hipFree(keep); return OFPS_HIP_ENOMEM; }
+        per_buf = cap_frames;
+        if (keep) {
+            // parked in the LAST slot of the buffer this ticket does not use: nothing writes there before it is consumed
+            uint8_t* park = nb + ((size_t)(tix ^ 1) * per_buf + (per_buf - 1)) * pitch;
+            OFPS_HIP_TRY(ctx, hipMemcpyAsync(park, keep, pitch, hipMemcpyDeviceToDevice, ctx->stream));
+            OFPS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            (void)hipFree(keep);
+            ctx->batch_last_frame = park;
+        }
+    }
+    auto* bufs = static_cast<uint8_t*>(fs.p);
+    uint8_t* buf = bufs + (size_t)tix * per_buf * pitch;        // [slot 0 = previous frame][n frames]
+    auto* d_ent_all = static_cast<float4*>(ofps::scratch(ctx, ofps::S_BATCH_ENTRIES, ofps_hip_ctx::kBatchTickets * (size_t)n * nblk * sizeof(float4)));
+    auto* d_out_all = static_cast<char*>(ofps::scratch(ctx, ofps::S_BATCH_OUT, ofps_hip_ctx::kBatchTickets * (size_t)n * kOutBytes));
+    if (!d_ent_all || !d_out_all) return OFPS_HIP_ENOMEM;
+    const size_t ent_per_ticket = ctx->scratch[ofps::S_BATCH_ENTRIES].cap / ofps_hip_ctx::kBatchTickets / sizeof(float4);
+    const size_t out_per_ticket = ctx->scratch[ofps::S_BATCH_OUT].cap / ofps_hip_ctx::kBatchTickets;
+    float4* d_ent = d_ent_all + (size_t)tix * ent_per_ticket;
+    char* d_out = d_out_all + (size_t)tix * out_per_ticket;
+    if (t.pinned_cap < (size_t)n * kOutBytes) {
+        if (t.pinned) OFPS_HIP_TRY(ctx, hipHostFree(t.pinned));
+        t.pinned = nullptr; t.pinned_cap = 0;
+        OFPS_HIP_TRY(ctx, hipHostMalloc(&t.pinned, (size_t)n * kOutBytes, hipHostMallocDefault));
+        t.pinned_cap = (size_t)n * kOutBytes;
+    }
+    hipStream_t s = ctx->stream, up = ctx->pipe_copy_stream;
+    // ---- copy stream: the n frames in one transfer (the buffer's previous tenant, ticket tno - 2, has been collected:
+    // its work is done); compute stream: the previous frame into slot 0
+    // the other ticket's copy of ITS previous frame reads slot n of this buffer's previous tenant: wait for it
+    auto& other = ctx->batch_ticket[(tno + 1) % ofps_hip_ctx::kBatchTickets];
+    if (other.pending && other.prev_copied_valid) OFPS_HIP_TRY(ctx, hipStreamWaitEvent(up, other.prev_copied, 0));
+    if (frame_pitch == (size_t)W * H && stride == W && dstride == W) {
+        OFPS_HIP_TRY(ctx, hipMemcpyAsync(buf + pitch, frames, (size_t)n * pitch, hipMemcpyHostToDevice, up));       // the whole batch
+    } else {
+        for (int j = 0; j < n; ++j)
+            OFPS_HIP_TRY(ctx, ofps::upload_rows(buf + (size_t)(j + 1) * pitch, dstride, frames + (size_t)j * frame_pitch, stride, W, H, up));
+    }
+    OFPS_HIP_TRY(ctx, hipEventRecord(t.uploaded, up));
+    const bool has_prev = ctx->batch_last_frame != nullptr;
+    t.prev_copied_valid = false;
+    if (has_prev) {
+        OFPS_HIP_TRY(ctx, hipMemcpyAsync(buf, ctx->batch_last_frame, pitch, hipMemcpyDeviceToDevice, s));
+        OFPS_HIP_TRY(ctx, hipEventRecord(t.prev_copied, s));
+        t.prev_copied_valid = true;
+    }
+    OFPS_HIP_TRY(ctx, hipStreamWaitEvent(s, t.uploaded, 0));
+    // ---- compute stream: pairs (slot j, slot j + 1), j = first .. n - 1
+    const int first = has_prev ? 0 : 1;                           // the stream's very first frame has no pair
+    const int pairs = n - first;
+    t.n = n; t.first_has_prev = has_prev ? 1 : 0; t.run_detector = prm->run_detector; t.run_estimator = prm->run_estimator; t.n_vectors = nblk;
+    if (pairs > 0) {
+        float4* ent0 = d_ent + (size_t)first * nblk;
+        rc = ofps::sad_pairs_device(ctx, buf + (size_t)first * pitch, pitch, buf + (size_t)(first + 1) * pitch, pitch, pairs, W, H, dstride,
+                                    prm->block, prm->range, ent0, nullptr);
+        if (rc != OFPS_HIP_OK) return rc;
+        int* d_res = reinterpret_cast<int*>(d_out);                                 // [n][4]
+        float4* d_quat = reinterpret_cast<float4*>(d_out + (size_t)n * 16);          // [n]
+        if (prm->run_estimator) {
+            rc = ofps::almeida_device(ctx, ent0, nblk, pairs, prm->aspect, prm->fov_y_deg, prm->use_ransac, prm->num_iters, prm->inlier_deg,
+                                      prm->num_samples, prm->seed + (uint64_t)first, d_quat + first);
+            if (rc != OFPS_HIP_OK) return rc;
+        }
+        if (prm->run_detector) {
+            int dim = 0;
+            auto* d_field = static_cast<float2*>(ofps::scratch(ctx, ofps::S_BATCH_FIELD, (size_t)pairs * 160 * 160 * sizeof(float2)));   // its own slot: the densifier works in S_WORK*
+            if (!d_field) return OFPS_HIP_ENOMEM;
+            rc = ofps::detect_device(ctx, ent0, nblk, pairs, prm->min_size, prm->subdivide, prm->target_motion, d_res + 4 * first, d_field, &dim);
+            if (rc != OFPS_HIP_OK) return rc;
+        }
+        if (prm->run_detector || prm->run_estimator) {
+            rc = pipe_read_back(ctx, t.pinned, d_out, (size_t)n * kOutBytes, s);
+            if (rc != OFPS_HIP_OK) return rc;
+        }
+        if (out_entries) {
+            rc = pipe_read_back(ctx, out_entries + (size_t)first * nblk * 4, ent0, (size_t)pairs * nblk * sizeof(float4), s);
+            if (rc != OFPS_HIP_OK) return rc;
+        }
+    }
+    OFPS_HIP_TRY(ctx, hipEventRecord(t.done, s));
+    ctx->batch_last_frame = buf + (size_t)n * pitch;
+    ctx->batch_frames += n;
+    t.pending = true;
+    *ticket = (int)(tno & 0x7FFFFFFF);
+    ctx->batch_next_ticket = tno + 1;
+    return OFPS_HIP_OK;
+}
+
+int ofps_hip_frames_wait(ofps_hip_ctx* ctx, int ticket, ofps_hip_frame_result* out /* n of them */) {
+    if (!ctx) return OFPS_HIP_EINVAL;
+    OFPS_REQUIRE(ctx, out, "frames_wait: null pointer");
+    OFPS_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const long newest = ctx->batch_next_ticket - 1;
+    long tno = -1;
+    for (long k = newest; k >= 0 && k > newest - ofps_hip_ctx::kBatchTickets; --k)
+        if ((int)(k & 0x7FFFFFFF) == ticket) { tno = k; break; }
+    OFPS_REQUIRE(ctx, tno >= 0, "frames_wait: ticket %d is not in flight", ticket);
+    auto& t = ctx->batch_ticket[tno % ofps_hip_ctx::kBatchTickets];
+    OFPS_REQUIRE(ctx, t.pending, "frames_wait: ticket %d was already collected", ticket);
+    OFPS_HIP_TRY(ctx, hipEventSynchronize(t.done));
+    t.pending = false;
+    const auto* res = static_cast<const int*>(t.pinned);
+    const auto* quat = reinterpret_cast<const float*>(static_cast<const char*>(t.pinned) + (size_t)t.n * 16);
+    for (int j = 0; j < t.n; ++j) {
+        ofps_hip_frame_result& o = out[j];
+        memset(&o, 0, sizeof(o));
+        o.quat[0] = 1.0f;
+        const bool has = j > 0 || t.first_has_prev;
+        o.have_vectors = has ? 1 : 0;
+        o.n_vectors = has ? t.n_vectors : 0;
+        if (!has) continue;
+        if (t.run_detector) { o.has_motion = res[4 * j]; o.area = (size_t)res[4 * j + 1]; o.dim = res[4 * j + 2]; }
+        if (t.run_estimator) memcpy(o.quat, quat + 4 * j, sizeof(o.quat));
     }
     return OFPS_HIP_OK;
 }

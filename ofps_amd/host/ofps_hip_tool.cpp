@@ -5,7 +5,7 @@
 //                                                       the same loop from a saved MotionDetectionConfig (detection.rs:45-50):
 //                                                       plugins, their saved properties, max_frame_gap / min_frames
 //   parse-config <saved.json>                           prints what a saved configuration says (no GPU)
-//   stream-bench <w> <h> <frames> [sync|ahead]          PCIe-inclusive per-frame time of the hip_sad process_frame shape
+//   stream-bench <w> <h> <frames> [sync|ahead|batch <n>] PCIe-inclusive per-frame time of the hip_sad process_frame shape
 //   track   <decoder> <arg> [aspect fov_y] [lsq|ransac] tracking loop, ofps-suite/src/app/tracking/worker.rs:305-412
 //   mvec-copy <in.mvec> <out.mvec>                      CPU-only .mvec round trip (reader + writer)
 // decoder = hip_sad / hip_lk ("<input>?w=..&h=..&fps=..") or mvec ("<input>"); <input> is a file path, "tcp://host:port"
@@ -131,6 +131,39 @@ int main(int argc, char** argv) {
             const int W = std::atoi(argv[2]), H = std::atoi(argv[3]);
             const int frames = std::atoi(argv[4]);
             const bool ahead = !(argc > 5 && std::string(argv[5]) == "sync");
+            const int batch = (argc > 6 && std::string(argv[5]) == "batch") ? std::atoi(argv[6]) : 0;
+            if (batch > 0) {
+                // batched read-ahead form: `batch` frames per ticket from ONE page-locked block, two tickets in flight
+                HipContext ctx;
+                const size_t nblk = ofps_hip_sad_block_count(W, H, 16);
+                uint8_t* pin[2]; float* ent[2];
+                for (auto& p : pin) { void* q; ctx.check(ofps_hip_host_alloc(ctx.get(), (size_t)batch * W * H, &q)); p = static_cast<uint8_t*>(q); }
+                for (auto& p : ent) { void* q; ctx.check(ofps_hip_host_alloc(ctx.get(), (size_t)batch * nblk * 16, &q)); p = static_cast<float*>(q); }
+                uint32_t st = 12345;
+                for (auto& p : pin) for (size_t i = 0; i < (size_t)batch * W * H; ++i) { st = st * 1664525u + 1013904223u; p[i] = (uint8_t)(st >> 24); }
+                ofps_hip_frame_params prm{}; prm.block = 16; prm.range = 16;
+                std::vector<ofps_hip_frame_result> res((size_t)batch);
+                auto run = [&](int nb) {
+                    ctx.check(ofps_hip_reset_frames(ctx.get()));
+                    int prev = -1, t = 0;
+                    for (int k = 0; k < nb; ++k) {
+                        ctx.check(ofps_hip_push_frames_async(ctx.get(), pin[k % 2], batch, W, H, W, (size_t)W * H, &prm, ent[k % 2], &t));
+                        if (prev >= 0) ctx.check(ofps_hip_frames_wait(ctx.get(), prev, res.data()));
+                        prev = t;
+                    }
+                    if (prev >= 0) ctx.check(ofps_hip_frames_wait(ctx.get(), prev, res.data()));
+                };
+                const int nb = (frames + batch - 1) / batch;
+                run(4);
+                const auto t0 = std::chrono::steady_clock::now();
+                run(nb);
+                const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / ((double)nb * batch);
+                std::printf("{\"mode\": \"read_ahead_batched\", \"batch\": %d, \"frames\": %d, \"ms_per_frame\": %.4f, \"Mvectors_per_s\": %.2f}\n", batch,
+                            nb * batch, ms, (double)nblk / ms / 1e3);
+                for (auto p : pin) ofps_hip_host_free(ctx.get(), p);
+                for (auto p : ent) ofps_hip_host_free(ctx.get(), p);
+                return 0;
+            }
             HipContext ctx;
             uint8_t* pin[3]; float* ent[2];
             const size_t nblk = ofps_hip_sad_block_count(W, H, 16);

@@ -334,6 +334,29 @@ class HipContext:
                                                         _fp(out_field) if out_field is not None else None, C.byref(t)))
         return int(t.value)
 
+    def push_frames_async(self, frames: np.ndarray, block=16, search_range=16, detector=True, min_size=0.05, subdivide=3,
+                          target_motion=0.003, estimator=True, aspect=16 / 9, fov_y_deg=39.6 * 9 / 16, use_ransac=False,
+                          num_iters=200, inlier_deg=0.05, num_samples=1000, seed=0, out_entries: np.ndarray | None = None) -> int:
+        """Batched form (ofps_hip_push_frames_async): frames uint8 [n, H, W] contiguous -> ticket; keep `frames` and
+        `out_entries` ([n, nblk, 4] float32) alive until frames_wait(ticket)."""
+        assert frames.dtype == np.uint8 and frames.ndim == 3 and frames.flags["C_CONTIGUOUS"]
+        n, H, W = frames.shape
+        prm = self._frame_params(block, search_range, detector, min_size, subdivide, target_motion, estimator, aspect, fov_y_deg,
+                                 use_ransac, num_iters, inlier_deg, num_samples, seed)
+        t = C.c_int(0)
+        self._check(self._lib.ofps_hip_push_frames_async(self._h, frames.ctypes.data_as(C.POINTER(C.c_uint8)), n, W, H, W, W * H, C.byref(prm),
+                                                         _fp(out_entries) if out_entries is not None else None, C.byref(t)))
+        self._batch_n = getattr(self, "_batch_n", {})
+        self._batch_n[t.value] = n
+        return t.value
+
+    def frames_wait(self, ticket: int) -> list:
+        n = self._batch_n.pop(ticket)
+        res = (_lib.FrameResult * n)()
+        self._check(self._lib.ofps_hip_frames_wait(self._h, ticket, res))
+        return [{"have_vectors": bool(r.have_vectors), "n_vectors": int(r.n_vectors),
+                 "motion": (int(r.area), int(r.dim)) if r.has_motion else None, "quat": np.array(list(r.quat), np.float32)} for r in res]
+
     def frame_wait(self, ticket: int) -> dict:
         res = _lib.FrameResult()
         self._check(self._lib.ofps_hip_frame_wait(self._h, ticket, C.byref(res)))

@@ -402,3 +402,52 @@ def test_hip_new_entry_points_reject_nonsense_loudly(ctx):
     assert not r1["have_vectors"]
     ctx.reset_frames()
     ctx.free_pinned(a); ctx.free_pinned(b)
+
+
+# ---- batched read-ahead form: n frames per ticket == n single pushes, bit for bit --------------------------------------
+@pytest.mark.parametrize("use_ransac", [False, True])
+def test_hip_push_frames_async_equals_single_pushes(ctx, use_ransac):
+    """ofps_hip_push_frames_async: one upload, one search launch, one detector chain and one estimator launch per BATCH.
+    Over a 1080p stream cut into batches of different sizes (one frame, many frames, a batch that makes the buffers grow)
+    every frame's vectors and island equal what n calls of ofps_hip_push_frame return bit for bit, its quaternion to the
+    solver's parity bound (RANSAC: frame j of a batch uses seed + j), and all of them the oracle's."""
+    W, H, F = 1920, 1080, 12
+    fr = synth.luma_sequence(F, W, H, max_step=16, seed=synth.SEED0 + 90)
+    cam = oracle.camera(16 / 9, 22.275)
+    kw = dict(block=16, search_range=16, aspect=16 / 9, fov_y_deg=22.275, use_ransac=use_ransac, num_iters=60)
+    ctx.reset_frames()
+    single = [ctx.push_frame(fr[k], seed=1000 + k, want_entries=True, **kw) for k in range(F)]
+    ctx.reset_frames()
+    nb = (W // 16) * (H // 16)
+    cuts = [(0, 1), (1, 3), (3, 8), (8, 12)]                 # batch sizes 1, 2, 5 (buffers grow), 4
+    pinned_frames = [ctx.pinned_array((b - a, H, W), np.uint8) for a, b in cuts]
+    pinned_ent = [ctx.pinned_array((b - a, nb, 4), np.float32) for a, b in cuts]
+    got = []
+    pending = None
+    for i, (a, b) in enumerate(cuts):
+        pinned_frames[i][...] = fr[a:b]
+        pinned_ent[i][...] = 0
+        t = ctx.push_frames_async(pinned_frames[i], seed=1000 + a, out_entries=pinned_ent[i], **kw)
+        if pending is not None:                              # two batches in flight
+            got += [(r, e.copy()) for r, e in zip(ctx.frames_wait(pending[0]), pending[1])]
+        pending = (t, pinned_ent[i])
+    got += [(r, e.copy()) for r, e in zip(ctx.frames_wait(pending[0]), pending[1])]
+    assert len(got) == F
+    for k, ((r, ent), sref) in enumerate(zip(got, single)):
+        assert r["have_vectors"] == sref["have_vectors"] == (k > 0)
+        if k == 0:
+            continue
+        np.testing.assert_array_equal(ent.view(np.uint32), sref["entries"].view(np.uint32))
+        assert (r["motion"] is None) == (sref["motion"] is None)
+        if r["motion"] is not None:
+            assert r["motion"][0] == sref["motion"][0]
+        # the estimator of a batch is one launch over its items (one workgroup per item at this size), a lone frame's is the
+        # 8-workgroup cluster solver: two fixed summation orders of the same terms, each within 2e-6 of the oracle
+        np.testing.assert_allclose(r["quat"], sref["quat"], atol=1e-4 if use_ransac else 2e-6, rtol=0)
+    # and the oracle, on two frames
+    for k in (1, 9):
+        ent_o, _ = oracle.sad_flow(fr[k - 1], fr[k], 16, 16)
+        np.testing.assert_array_equal(got[k][1].view(np.uint32), ent_o.view(np.uint32))
+        q_o = oracle.solve_ypr_ransac(ent_o, cam, 60, 0.05, 1000, seed=1000 + k) if use_ransac else oracle.solve_ypr_given(ent_o, cam)
+        np.testing.assert_allclose(got[k][0]["quat"], q_o, atol=1e-4 if use_ransac else 2e-6, rtol=0)
+    ctx.reset_frames()
