@@ -286,3 +286,53 @@ def test_detector_hand_derived_cases(name, impl):
         return
     assert got is not None and int(got[0]) == want[0]
     np.testing.assert_array_equal(np.ascontiguousarray(got[1], np.float32).view(np.uint32).reshape(14, 14, 2), want[1])
+
+
+# ---- interpolate_empty_cells (ofps/src/motion_field.rs:193-294): a case small enough to walk by hand ------------------------
+# 3 x 1 grid, ONE vector (pos (0.1, 0.5) -> cell 0, motion (0.5, -0.25)).  By the Rust text:
+#   counts start at eps = 2^-23; cell 0: counts 1 + eps, sum (0.5, -0.25).
+#   queue (BTreeSet ordered by (neighbors, idx)): cell 1 has one filled 6-neighbour (cell 0, offset (-1, 0)) -> (-1, 1);
+#   cell 2 has none -> (0, 2).
+#   pop (-1, 1): neighbour cell 0, scale = 1 - sqrt(1) * 0.5 = 0.5, inv_cnt = 1 / (1 + eps) = 1 - 2^-23 (0x3F7FFFFE),
+#     scale * inv_cnt = 0.5 - 2^-24, times column (0.5, -0.25) = (0.25 - 2^-25, -(0.125 - 2^-26)); add_vector_idx(1, that, 0.5):
+#     counts[1] = eps + 0.5, sum[1] = that * 0.5 = (0.125 - 2^-26, -(0.0625 - 2^-27)).  Re-keying: cell 2 now has one filled
+#     neighbour: (0, 2) -> (-1, 2).
+#   pop (-1, 2): neighbour cell 1, scale 0.5, inv_cnt = 1 / (0.5 + 2^-23) = 2 - 2^-21, scale * inv_cnt = 1 - 2^-22, times
+#     column sum[1] = (0.125 - 6 * 2^-27, -(0.0625 - 6 * 2^-28)); weight 0.5: counts[2] = eps + 0.5,
+#     sum[2] = (0.0625 - 6 * 2^-28, -(0.03125 - 6 * 2^-29)).
+#   MotionField::from divides sums by counts (every quotient below is exact to well under half an ulp):
+#     cell 0: (0.5, -0.25) / (1 + 2^-23)                  = (0.5 - 2^-24,        -(0.25 - 2^-25))
+#     cell 1: sum[1] / (0.5 + 2^-23) = 2 sum[1] (1-2^-22) = (0.25 - 6 * 2^-26,   -(0.125 - 6 * 2^-27))
+#     cell 2: sum[2] / (0.5 + 2^-23)                      = (0.125 - 10 * 2^-27, -(0.0625 - 10 * 2^-28))
+INTERP_ENTRIES = np.array([[0.1, 0.5, 0.5, -0.25]], np.float32)
+INTERP_FIELD_BITS = [0x3EFFFFFE, 0xBE7FFFFE, 0x3E7FFFFA, 0xBDFFFFFA, 0x3DFFFFF6, 0xBD7FFFF6]
+
+
+@pytest.mark.parametrize("impl", ["c", "numpy"])
+def test_interpolate_empty_cells_hand_derived_case(impl):
+    from oracle import np_oracle as npo
+    f = (oracle.densify_interpolated if impl == "c" else npo.densify_interpolated)(INTERP_ENTRIES, 3, 1)
+    assert [int(x) for x in np.asarray(f, np.float32).view(np.uint32).ravel()] == INTERP_FIELD_BITS
+
+
+# ---- the RANSAC inlier predicate (almeida-estimator/src/lib.rs:224-241) at its boundary ---------------------------------
+# Every vector sits at the image centre (0.5, 0.5).  There the unprojected ray is the rotation axis of the "roll"
+# prototype (Matrix4::from_euler_angles(0, EPS, 0), :30-34): its delta is exactly (0, 0), A = J^T J has a zero row and
+# column, Matrix3::lu().solve returns None and the step is zero (:181-185) -- every 3-sample hypothesis is EXACTLY the
+# identity, whatever the samples.  With mat = identity, camera.delta(centre, mat) = (0.5 - 0.5, 0.5 - 0.5) = 0 exactly,
+# point_angle(centre) = atan(0) = 0, cos = 1: the predicate of :237 is  mx^2 + my^2 <= thr^2  in f32, thr =
+# 0.05f32.to_radians().  So the inlier set can be written down: the `<=` keeps a vector of length exactly thr and drops
+# the next representable length.
+def test_ransac_inlier_predicate_hand_derived_boundary():
+    thr = np.float32(0.05) * (np.float32(np.pi) / np.float32(180.0))
+    up = np.nextafter(thr, np.float32(1.0))
+    motions = [(thr, 0), (0, thr), (up, 0), (0, 0), (-thr, 0), (thr, thr), (0, -up), (np.float32(0.5) * thr, np.float32(0.5) * thr)]
+    want = [0, 1, 3, 4, 7]                                    # (thr,thr): 2 thr^2 > thr^2; +-up: just over; (thr/2, thr/2): thr^2/2
+    e = np.array([[0.5, 0.5, mx, my] for mx, my in motions], np.float32)
+    cam = oracle.camera(16 / 9, 22.275)
+    q, inl = oracle.solve_ypr_ransac(e, cam, 5, 0.05, 1000, seed=3, want_inliers=True)
+    assert sorted(int(i) for i in inl) == want
+    np.testing.assert_array_equal(q, np.array([1, 0, 0, 0], np.float32))     # the refit on the inliers is singular as well: identity
+    # fewer than 3 inliers -> Default::default() = identity (:246-250)
+    q2, inl2 = oracle.solve_ypr_ransac(e[[2, 5, 6, 0]], cam, 5, 0.05, 1000, seed=3, want_inliers=True)
+    assert [int(i) for i in inl2] == [3] and np.array_equal(q2, np.array([1, 0, 0, 0], np.float32))

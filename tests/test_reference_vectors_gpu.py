@@ -451,3 +451,21 @@ def test_hip_push_frames_async_equals_single_pushes(ctx, use_ransac):
         q_o = oracle.solve_ypr_ransac(ent_o, cam, 60, 0.05, 1000, seed=1000 + k) if use_ransac else oracle.solve_ypr_given(ent_o, cam)
         np.testing.assert_allclose(got[k][0]["quat"], q_o, atol=1e-4 if use_ransac else 2e-6, rtol=0)
     ctx.reset_frames()
+
+
+def test_hip_interpolate_empty_cells_hand_derived_case(ctx):
+    f = ctx.densify_interpolated(rv.INTERP_ENTRIES, 3, 1)
+    assert [int(x) for x in np.asarray(f, np.float32).view(np.uint32).ravel()] == rv.INTERP_FIELD_BITS
+
+
+def test_hip_ransac_at_the_image_centre_is_the_identity(ctx):
+    """The hand-derived RANSAC case of tests/test_reference_vectors.py through the HIP path: every hypothesis and the refit
+    are exactly singular (zero step, lib.rs:181-185), so the estimate is the identity quaternion, bit for bit; with fewer
+    than 3 inliers it is the identity by lib.rs:246-250."""
+    thr = np.float32(0.05) * (np.float32(np.pi) / np.float32(180.0))
+    up = np.nextafter(thr, np.float32(1.0))
+    motions = [(thr, 0), (0, thr), (up, 0), (0, 0), (-thr, 0), (thr, thr), (0, -up), (np.float32(0.5) * thr, np.float32(0.5) * thr)]
+    e = np.array([[0.5, 0.5, mx, my] for mx, my in motions], np.float32)
+    for sub in (slice(None), [2, 5, 6, 0]):
+        q, _ = ctx.almeida(e[sub], 16 / 9, 22.275, use_ransac=True, num_iters=5, inlier_deg=0.05, num_samples=1000, seed=3)
+        np.testing.assert_array_equal(q, np.array([1, 0, 0, 0], np.float32))
