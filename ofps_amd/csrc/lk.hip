@@ -201,7 +201,7 @@ __global__ __launch_bounds__(256) void lk_tensor_kernel(const float* __restrict_
         for (int dx = -radius; dx <= radius; ++dx) {
             const int qx = lk_clampi(x + dx, 0, w - 1);
             const float ix = gx[row + qx], iy = gy[row + qx];
-            gxx += ix * ix; gxy += ix * iy; gyy += iy * iy;
+            lk_accum(ix, ix, gxx); lk_accum(ix, iy, gxy); lk_accum(iy, iy, gyy);
         }
     }
     G[(size_t)y * w + x] = make_float4(gxx, gxy, gyy, 0.0f);
@@ -362,69 +362,6 @@ __device__ __forceinline__ void lk_stage3(const float* __restrict__ p0, const fl
     }
 }
 
-// Structure tensor, tiled.  Two savings over the plain kernel, neither of which touches a bit of the result:
-//   * the three products of a window element (ix*ix, ix*iy, iy*iy) are the same numbers for every pixel whose window
-//     holds it: they are formed once per staged element and the 81-tap loop only ADDS them, in the oracle's order;
-//   * a thread owns kTP vertically adjacent pixels: one LDS read of a product record feeds up to kTP running sums (each
-//     pixel still meets its taps row by row, left to right), so the loop makes (kTP + 2R) * N reads for kTP pixels instead
-//     of kTP * N * N -- the kernel was LDS-bound (one 16-byte read per tap).
-constexpr int kTP = 4;                       // pixels per thread (vertical)
-constexpr int kTTX = 32, kTTY = 8 * kTP;     // pixels per workgroup: 32 x 32
-template <int RADIUS>
-__global__ __launch_bounds__(256) void lk_tensor_tiled_kernel(const float* __restrict__ gxp, const float* __restrict__ gyp, const LkPyr P,
-                                                              float4* __restrict__ Gp) {
-    constexpr int R = RADIUS, N = 2 * RADIUS + 1, TW = kTTX + 2 * RADIUS, TH = kTTY + 2 * RADIUS;
-    __shared__ float4 prod[TH][TW];
-    int l, tx, ty;
-    if (!lk_level_tile_of_block(P, kTTX, kTTY, l, tx, ty)) return;     // every level of the pyramid in one launch
-    const int w = P.w[l], h = P.h[l];
-    const float* gx = gxp + P.off[l];
-    const float* gy = gyp + P.off[l];
-    float4* G = Gp + P.off[l];
-    const int x0 = tx * kTTX, y0 = ty * kTTY;
-    {
-        constexpr int ROWS_PER_PASS = 256 / TW;
-        const int sx = threadIdx.x % TW, sy0 = threadIdx.x / TW;
-        if (sy0 < ROWS_PER_PASS) {
-            const int cx = lk_clampi(x0 - R + sx, 0, w - 1);
-            for (int sy = sy0; sy < TH; sy += ROWS_PER_PASS) {
-                const size_t g = (size_t)lk_clampi(y0 - R + sy, 0, h - 1) * w + cx;
-                const float ix = gx[g], iy = gy[g];
-                prod[sy][sx] = make_float4(ix * ix, ix * iy, iy * iy, 0.0f);
-            }
-        }
-    }
-    __syncthreads();
-    const int lx = threadIdx.x % kTTX, ly = (threadIdx.x / kTTX) * kTP, x = x0 + lx;
-    if (x >= w || y0 + ly >= h) return;
-    float gxx[kTP], gxy[kTP], gyy[kTP];
-#pragma unroll
-    for (int q = 0; q < kTP; ++q) { gxx[q] = 0.0f; gxy[q] = 0.0f; gyy[q] = 0.0f; }
-    // window row rr of the thread's kTP-pixel column is row rr - q of pixel q.  Rows kTP-1 .. N-1 belong to every pixel
-    // (the hot loop, no predicates); the kTP-1 rows above and below belong to some (uniform branches).  The row loops are
-    // real loops: fully unrolled, hipcc hoists all (kTP + 2R) * N reads at once and spills hundreds of registers.
-    auto row = [&](int rr, auto all) {
-#pragma unroll
-        for (int k = 0; k < N; ++k) {
-            const lk_f4 p = lk_lds_read4(&prod[ly + rr][lx + k]);
-#pragma unroll
-            for (int q = 0; q < kTP; ++q) {
-                if (decltype(all)::value || (rr - q >= 0 && rr - q < N)) { gxx[q] += p.x; gxy[q] += p.y; gyy[q] += p.z; }
-            }
-        }
-    };
-    static_assert(N >= kTP, "the all-pixels row range assumes a window at least kTP rows tall");
-#pragma unroll 1
-    for (int rr = 0; rr < kTP - 1; ++rr) row(rr, std::false_type{});
-#pragma unroll 1
-    for (int rr = kTP - 1; rr < N; ++rr) row(rr, std::true_type{});
-#pragma unroll 1
-    for (int rr = N; rr < kTP + 2 * R; ++rr) row(rr, std::false_type{});
-#pragma unroll
-    for (int q = 0; q < kTP; ++q)
-        if (y0 + ly + q < h) G[(size_t)(y0 + ly + q) * w + x] = make_float4(gxx[q], gxy[q], gyy[q], 0.0f);
-}
-
 // One window row of the level kernel at radius 4 (9 taps), spec revision 2, hand-scheduled.  hipcc's own code for this loop
 // copies the carried interpolation row (8 v_mov per row), re-reads every tile record into the same four registers with a
 // full wait in front of each use, and -- asked to unroll by two so that the carried row could change name instead of
@@ -449,6 +386,15 @@ __global__ __launch_bounds__(256) void lk_tensor_tiled_kernel(const float* __res
     "v_sub_f32 %[tmp], " Q0 ", %[t" #K "]\n\t"                                 \
     "v_fmac_f32 %[bx], " Q1 ", %[tmp]\n\t"                                     \
     "v_fmac_f32 %[by], " Q2 ", %[tmp]\n\t"                                     \
+    ISSUE
+// the same with the tap's share of the structure tensor (first step of a level): gxx += gx gx, gxy += gx gy, gyy += gy gy
+#define LK_ROW9_USE_G(K, Q0, Q1, Q2, ISSUE)                                   \
+    "v_sub_f32 %[tmp], " Q0 ", %[t" #K "]\n\t"                                 \
+    "v_fmac_f32 %[gxx], " Q1 ", " Q1 "\n\t"                                    \
+    "v_fmac_f32 %[bx], " Q1 ", %[tmp]\n\t"                                     \
+    "v_fmac_f32 %[gxy], " Q1 ", " Q2 "\n\t"                                    \
+    "v_fmac_f32 %[by], " Q2 ", %[tmp]\n\t"                                     \
+    "v_fmac_f32 %[gyy], " Q2 ", " Q2 "\n\t"                                    \
     ISSUE
 // r[0..18] are the two register sets: PARITY 0: l = r[0..9], t = r[10..18]; PARITY 1: l = r[10..18] + r[9], t = r[0..8] --
 // after a PARITY 0 row the nine interpolations of its lower sample row sit in r[0..8], exactly where a PARITY 1 row
@@ -493,8 +439,53 @@ __device__ __forceinline__ void lk_row9_asm(float (&r)[19], const float (&a)[9],
           [a8] "v"(a[8]), [ay] "v"(ay), [ja] "v"(jaddr), [ta] "v"(taddr)
         : "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "memory");
 }
+// lk_row9_asm with the structure-tensor sums (first step of a level).
+// r[0..18] are the two register sets: PARITY 0: l = r[0..9], t = r[10..18]; PARITY 1: l = r[10..18] + r[9], t = r[0..8] --
+// after a PARITY 0 row the nine interpolations of its lower sample row sit in r[0..8], exactly where a PARITY 1 row
+// expects its upper row, and vice versa.
+template <int PARITY>
+__device__ __forceinline__ void lk_row9_asm_g(float (&r)[19], const float (&a)[9], float ay, float& bx, float& by, float& gxx,
+                                              float& gxy, float& gyy, uint32_t jaddr, uint32_t taddr) {
+    constexpr auto L = [](int k) constexpr { return PARITY ? (k < 9 ? 10 + k : 9) : k; };
+    constexpr auto T = [](int k) constexpr { return PARITY ? k : 10 + k; };
+    float tmp;
+    asm volatile(
+        "ds_read_b32 %[l0], %[ja]\n\t"
+        "ds_read_b32 %[l1], %[ja] offset:4\n\t"
+        "ds_read_b32 %[l2], %[ja] offset:8\n\t"
+        "ds_read_b32 %[l3], %[ja] offset:12\n\t"
+        "ds_read_b32 %[l4], %[ja] offset:16\n\t"
+        "ds_read_b32 %[l5], %[ja] offset:20\n\t"
+        "ds_read_b32 %[l6], %[ja] offset:24\n\t"
+        "ds_read_b32 %[l7], %[ja] offset:28\n\t"
+        "ds_read_b32 %[l8], %[ja] offset:32\n\t"
+        "ds_read_b32 %[l9], %[ja] offset:36\n\t"
+        "ds_read_b128 v[72:75], %[ta]\n\t"
+        "ds_read_b128 v[76:79], %[ta] offset:16\n\t"
+        "s_waitcnt lgkmcnt(10)\n\t"                                            // l0, l1 are there
+        // tap k: horizontal + vertical interpolation while its tile record is in flight, then the residual sums; the quad
+        // it used is refilled with tap k + 2's record.  Waits: 12 reads issued; before tap k's first use of l[k+1] at most
+        // 10 - k of the texel reads ... may be outstanding behind the two tile reads (counted below per tap).
+        LK_ROW9_TAP(0, 1, 1, "") LK_ROW9_USE_G(0, "v72", "v73", "v74", "ds_read_b128 v[72:75], %[ta] offset:32\n\t")
+        LK_ROW9_TAP(1, 2, 1, "") LK_ROW9_USE_G(1, "v76", "v77", "v78", "ds_read_b128 v[76:79], %[ta] offset:48\n\t")
+        LK_ROW9_TAP(2, 3, 1, "") LK_ROW9_USE_G(2, "v72", "v73", "v74", "ds_read_b128 v[72:75], %[ta] offset:64\n\t")
+        LK_ROW9_TAP(3, 4, 1, "") LK_ROW9_USE_G(3, "v76", "v77", "v78", "ds_read_b128 v[76:79], %[ta] offset:80\n\t")
+        LK_ROW9_TAP(4, 5, 1, "") LK_ROW9_USE_G(4, "v72", "v73", "v74", "ds_read_b128 v[72:75], %[ta] offset:96\n\t")
+        LK_ROW9_TAP(5, 6, 1, "") LK_ROW9_USE_G(5, "v76", "v77", "v78", "ds_read_b128 v[76:79], %[ta] offset:112\n\t")
+        LK_ROW9_TAP(6, 7, 1, "") LK_ROW9_USE_G(6, "v72", "v73", "v74", "ds_read_b128 v[72:75], %[ta] offset:128\n\t")
+        LK_ROW9_TAP(7, 8, 1, "") LK_ROW9_USE_G(7, "v76", "v77", "v78", "")
+        LK_ROW9_TAP(8, 9, 0, "") LK_ROW9_USE_G(8, "v72", "v73", "v74", "")
+        : [l0] "=&v"(r[L(0)]), [l1] "=&v"(r[L(1)]), [l2] "=&v"(r[L(2)]), [l3] "=&v"(r[L(3)]), [l4] "=&v"(r[L(4)]), [l5] "=&v"(r[L(5)]),
+          [l6] "=&v"(r[L(6)]), [l7] "=&v"(r[L(7)]), [l8] "=&v"(r[L(8)]), [l9] "=&v"(r[L(9)]),
+          [t0] "+v"(r[T(0)]), [t1] "+v"(r[T(1)]), [t2] "+v"(r[T(2)]), [t3] "+v"(r[T(3)]), [t4] "+v"(r[T(4)]), [t5] "+v"(r[T(5)]),
+          [t6] "+v"(r[T(6)]), [t7] "+v"(r[T(7)]), [t8] "+v"(r[T(8)]), [bx] "+v"(bx), [by] "+v"(by), [gxx] "+v"(gxx), [gxy] "+v"(gxy), [gyy] "+v"(gyy), [tmp] "=&v"(tmp)
+        : [a0] "v"(a[0]), [a1] "v"(a[1]), [a2] "v"(a[2]), [a3] "v"(a[3]), [a4] "v"(a[4]), [a5] "v"(a[5]), [a6] "v"(a[6]), [a7] "v"(a[7]),
+          [a8] "v"(a[8]), [ay] "v"(ay), [ja] "v"(jaddr), [ta] "v"(taddr)
+        : "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "memory");
+}
 #undef LK_ROW9_TAP
 #undef LK_ROW9_USE
+#undef LK_ROW9_USE_G
 
 // Current-frame window in LDS.  The bilinear fetches J(q + flow(p)) of a workgroup land in the rectangle
 // [tile + window] shifted by the flows of its pixels; when those flows differ by at most SPREAD_X / SPREAD_Y pixels (almost every
@@ -581,7 +572,7 @@ __device__ __forceinline__ void lk_store(const float2 out, int x, int y, int w, 
 template <int RADIUS>
 __global__ __launch_bounds__(256, LkStepShared<RADIUS>::WAVES_PER_SIMD) void lk_level_lds_kernel(const float* __restrict__ I, const float* __restrict__ J,
                                                            const float* __restrict__ gx, const float* __restrict__ gy,
-                                                           const float4* __restrict__ G, int w, int h, int iters, const LkFlowIO io,
+                                                           int w, int h, int iters, const LkFlowIO io,
                                                            uint32_t* __restrict__ fb_count, uint2* __restrict__ fb_tiles,
                                                            float2* fb_flow, unsigned long long* __restrict__ prof, int force_fall_arg) {
     // force_fall (libofps_hip_testhooks.so only; compiled out of the product library): every other tile is treated as not
@@ -608,6 +599,11 @@ __global__ __launch_bounds__(256, LkStepShared<RADIUS>::WAVES_PER_SIMD) void lk_
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const bool active = px < w && py < h;
     float2 f = active ? lk_flow_read(io, px, py) : make_float2(0.0f, 0.0f);
+    // The 2x2 structure tensor of the pixel's window does not depend on the flow: it is summed by the level's FIRST step, from
+    // the very tile records that step reads for the residual (three fused multiply-adds per tap more, no LDS traffic of
+    // its own), and stays in three registers for the later steps -- the separate tensor launch, its float4 plane (42 MB of
+    // writes and as many reads per 1080p pair) and the per-step re-read are gone.
+    float gxx = 0.0f, gxy = 0.0f, gyy = 0.0f;
     bool st_valid = false;                                   // the rectangle of the current frame held in jl[][] (uniform)
     int st_x0 = 0, st_x1 = -1, st_y0 = 0, st_y1 = -1, st_xs = 0;
 #pragma unroll 1
@@ -615,8 +611,10 @@ __global__ __launch_bounds__(256, LkStepShared<RADIUS>::WAVES_PER_SIMD) void lk_
         // the pixel coordinates pass through an empty asm so that the compiler does not hoist the clamped window
         // coordinates (2N integers + their float conversions) out of the step loop: that costs 40 VGPRs and two waves
         // per SIMD for a handful of integer operations per step
-        int x = px, y = py;
-        asm volatile("" : "+v"(x), "+v"(y));
+        // (made from the thread index every step instead of copied from px / py: two registers less across the row loop)
+        int tidx = (int)threadIdx.x;
+        asm volatile("" : "+v"(tidx));
+        const int x = x0 + tidx % kTX, y = y0 + tidx / kTX;
         // first pass over the window columns: only what the workgroup's box needs (first and last origin, "consecutive").
         // The origins and fractions the rows use are made AGAIN after the barrier / staging below (same operations, same
         // values): kept alive across that phase they were spilled to scratch in every step (76 B per pixel-step of HBM
@@ -654,12 +652,15 @@ __global__ __launch_bounds__(256, LkStepShared<RADIUS>::WAVES_PER_SIMD) void lk_
         if (it == 0) OFPS_LK_STAMP(1);
         __syncthreads();                                                 // also: everybody is done reading jl[] of the previous step
         if (it == 0) OFPS_LK_STAMP(2);
+        // (box[] holds the same numbers for every thread: read into SCALAR registers -- the rectangle's bounds live across
+        // the whole level, and as vector registers they were part of what got spilled around the row loop)
         const int (*bq)[5] = sh.box[it & 1];
-        const int xmin = min(min(bq[0][0], bq[1][0]), min(bq[2][0], bq[3][0]));
-        const int xmax = max(max(bq[0][1], bq[1][1]), max(bq[2][1], bq[3][1]));
-        const int bymin = min(min(bq[0][2], bq[1][2]), min(bq[2][2], bq[3][2]));
-        const int ymax = max(max(bq[0][3], bq[1][3]), max(bq[2][3], bq[3][3]));
-        const bool all_consecutive = (bq[0][4] & bq[1][4] & bq[2][4] & bq[3][4]) != 0;
+        auto uni = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
+        const int xmin = min(min(uni(bq[0][0]), uni(bq[1][0])), min(uni(bq[2][0]), uni(bq[3][0])));
+        const int xmax = max(max(uni(bq[0][1]), uni(bq[1][1])), max(uni(bq[2][1]), uni(bq[3][1])));
+        const int bymin = min(min(uni(bq[0][2]), uni(bq[1][2])), min(uni(bq[2][2]), uni(bq[3][2])));
+        const int ymax = max(max(uni(bq[0][3]), uni(bq[1][3])), max(uni(bq[2][3]), uni(bq[3][3])));
+        const bool all_consecutive = (uni(bq[0][4]) & uni(bq[1][4]) & uni(bq[2][4]) & uni(bq[3][4])) != 0;
         const int fits = xmax >= xmin && xmax - xmin < S::LW && ymax - bymin < S::LH &&
                          !(it == force_fall && ((tile_x + tile_y) & 1));
         if (!fits) {                                                     // uniform: box[] is the same for every thread
@@ -709,12 +710,13 @@ __global__ __launch_bounds__(256, LkStepShared<RADIUS>::WAVES_PER_SIMD) void lk_
         }
         const int xs = st_xs, ymin = st_y0;                              // origin of jl[][] in frame coordinates
         float ax[N];
-        int xi[N];
+        int xi0;                                                         // origin of window column 0 (all the consecutive-column rows need)
         {
             int xr = x;
             asm volatile("" : "+v"(xr));                                  // opaque: a second evaluation, not the first one kept alive
+            float frac;
 #pragma unroll
-            for (int k = 0; k < N; ++k) xi[k] = lk_origin(lk_clampi(xr + k - RADIUS, 0, w - 1), f.x, w, ax[k]);
+            for (int k = 0; k < N; ++k) { const int o = lk_origin(lk_clampi(xr + k - RADIUS, 0, w - 1), f.x, w, frac); ax[k] = frac; if (k == 0) xi0 = o; }
         }
         if (it == 0) OFPS_LK_STAMP(3);
         if (active) {
@@ -732,9 +734,9 @@ __global__ __launch_bounds__(256, LkStepShared<RADIUS>::WAVES_PER_SIMD) void lk_
                     // its interpolations" and "the previous row's interpolations", so the row loop runs in pairs
                     float rr[19];
                     int prev_yi = -0x7FFFFFFF;
-                    const uint32_t jl0 = (uint32_t)reinterpret_cast<uintptr_t>(&sh.jl[0][xi[0] - xs]);
+                    const uint32_t jl0 = (uint32_t)reinterpret_cast<uintptr_t>(&sh.jl[0][xi0 - xs]);
                     const uint32_t tl0 = (uint32_t)reinterpret_cast<uintptr_t>(&sh.tile[ly][lx]);
-                    auto row = [&](int r, auto parity) {
+                    auto row = [&](int r, auto parity, auto with_g) {
                         constexpr int P = decltype(parity)::value;
                         float ay;
                         const int yi = lk_origin(lk_clampi(y + r - RADIUS, 0, h - 1), f.y, h, ay) - ymin;
@@ -743,21 +745,27 @@ __global__ __launch_bounds__(256, LkStepShared<RADIUS>::WAVES_PER_SIMD) void lk_
                         const bool reuse = r > 0 && __all(yi == prev_yi + 1);
                         prev_yi = yi;
                         if (!reuse) {                              // the upper sample row is not the one carried over: make it
-                            const float* ra = &sh.jl[yi][xi[0] - xs];
+                            const float* ra = &sh.jl[yi][xi0 - xs];
                             float jb[N + 1];
 #pragma unroll
                             for (int k = 0; k <= N; ++k) jb[k] = ra[k];
 #pragma unroll
                             for (int k = 0; k < N; ++k) rr[P ? k : 10 + k] = lk_lerp(jb[k], jb[k + 1], ax[k]);
                         }
-                        lk_row9_asm<P>(rr, ax, ay, bx, by, jl0 + (uint32_t)(yi + 1) * (uint32_t)(S::JS * sizeof(float)),
-                                       tl0 + (uint32_t)r * (uint32_t)(T::TW * sizeof(float4)));
+                        const uint32_t ja = jl0 + (uint32_t)(yi + 1) * (uint32_t)(S::JS * sizeof(float));
+                        const uint32_t ta = tl0 + (uint32_t)r * (uint32_t)(T::TW * sizeof(float4));
+                        if constexpr (decltype(with_g)::value) lk_row9_asm_g<P>(rr, ax, ay, bx, by, gxx, gxy, gyy, ja, ta);
+                        else lk_row9_asm<P>(rr, ax, ay, bx, by, ja, ta);
                     };
-                    row(0, std::integral_constant<int, 0>{});
+                    using P0 = std::integral_constant<int, 0>; using P1 = std::integral_constant<int, 1>;
+                    if (it == 0) {                                 // the level's first step also sums the structure tensor
+                        row(0, P0{}, std::true_type{});
 #pragma unroll 1
-                    for (int r = 1; r < N; r += 2) {
-                        row(r, std::integral_constant<int, 1>{});
-                        row(r + 1, std::integral_constant<int, 0>{});
+                        for (int r = 1; r < N; r += 2) { row(r, P1{}, std::true_type{}); row(r + 1, P0{}, std::true_type{}); }
+                    } else {
+                        row(0, P0{}, std::false_type{});
+#pragma unroll 1
+                        for (int r = 1; r < N; r += 2) { row(r, P1{}, std::false_type{}); row(r + 1, P0{}, std::false_type{}); }
                     }
                     done = true;
                 }
@@ -766,7 +774,7 @@ __global__ __launch_bounds__(256, LkStepShared<RADIUS>::WAVES_PER_SIMD) void lk_
                 float hup[N];
                 int prev_yi = -0x7FFFFFFF;
                 if (all_consecutive) {
-                    const int xo = xi[0] - xs;
+                    const int xo = xi0 - xs;
                     float jb[N + 1];
                     // (measured and rejected: unrolling the row loop, fully or by two/three with ping-pong hup arrays -- hipcc
                     // then hoists the next row's LDS reads, 104+ VGPRs, 4 waves per SIMD, 0.53 vs 0.50 ms)
@@ -794,12 +802,21 @@ __global__ __launch_bounds__(256, LkStepShared<RADIUS>::WAVES_PER_SIMD) void lk_
                             const float d = t.x - lk_lerp(top, bot, ay);
                             lk_accum(t.y, d, bx);
                             lk_accum(t.z, d, by);
+                            if (it == 0) { lk_accum(t.y, t.y, gxx); lk_accum(t.y, t.z, gxy); lk_accum(t.z, t.z, gyy); }
                             hup[k] = bot;
                         }
                     }
                 } else {
+                    // (image-border tiles only: every column's own origin, made here -- kept alive from the pass above they
+                    // were spilled around the hand-scheduled rows of every other tile)
+                    int xi[N];
+                    {
+                        int xr = x;
+                        asm volatile("" : "+v"(xr));
+                        float frac;
     #pragma unroll
-                    for (int k = 0; k < N; ++k) xi[k] -= xs;
+                        for (int k = 0; k < N; ++k) xi[k] = lk_origin(lk_clampi(xr + k - RADIUS, 0, w - 1), f.x, w, frac) - xs;
+                    }
     #pragma unroll 1
                     for (int r = 0; r < N; ++r) {
                         float ay;
@@ -821,16 +838,21 @@ __global__ __launch_bounds__(256, LkStepShared<RADIUS>::WAVES_PER_SIMD) void lk_
                             const float d = t.x - lk_lerp(top, bot, ay);
                             lk_accum(t.y, d, bx);
                             lk_accum(t.z, d, by);
+                            if (it == 0) { lk_accum(t.y, t.y, gxx); lk_accum(t.y, t.z, gxy); lk_accum(t.z, t.z, gyy); }
                             hup[k] = bot;
                         }
                     }
                 }
             }
-            f = lk_solve(G[(size_t)y * w + x], f, bx, by);       // re-read per step (L2): four registers less across the row loop
+            f = lk_solve(make_float4(gxx, gxy, gyy, 0.0f), f, bx, by);
         }
         if (it == 0) OFPS_LK_STAMP(4);
     }
-    if (active) lk_store(f, px, py, w, io);
+    if (active) {
+        int tidx = (int)threadIdx.x;
+        asm volatile("" : "+v"(tidx));
+        lk_store(f, x0 + tidx % kTX, y0 + tidx / kTX, w, io);
+    }
     OFPS_LK_STAMP(5);
 #undef OFPS_LK_STAMP
 }
@@ -841,7 +863,7 @@ __global__ __launch_bounds__(256, LkStepShared<RADIUS>::WAVES_PER_SIMD) void lk_
 template <int RADIUS>
 __global__ __launch_bounds__(256) void lk_level_general_kernel(const float* __restrict__ I, const float* __restrict__ J,
                                                                const float* __restrict__ gx, const float* __restrict__ gy,
-                                                               const float4* __restrict__ G, int w, int h, int iters, const LkFlowIO io,
+                                                               int w, int h, int iters, const LkFlowIO io,
                                                                const uint32_t* __restrict__ fb_count,
                                                                const uint2* __restrict__ fb_tiles,
                                                                const float2* fb_flow) {
@@ -858,7 +880,17 @@ __global__ __launch_bounds__(256) void lk_level_general_kernel(const float* __re
         const int lx = threadIdx.x % kTX, ly = threadIdx.x / kTX, x = x0 + lx, y = y0 + ly;
         if (x >= w || y >= h) continue;
         float2 f = fb_flow[(size_t)y * w + x];
-        const float4 g = G[(size_t)y * w + x];
+        // the structure tensor, from the staged window in the spec's order (dy outer, dx inner): the same sums the level
+        // kernel's first step makes, whichever step the tile fell at
+        float4 g = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll 1
+        for (int r = 0; r < N; ++r) {
+#pragma unroll
+            for (int k = 0; k < N; ++k) {
+                const float4 t = tile[ly + r][lx + k];
+                lk_accum(t.y, t.y, g.x); lk_accum(t.y, t.z, g.y); lk_accum(t.z, t.z, g.z);
+            }
+        }
         for (int it = (int)id.y; it < iters; ++it) {
             int xa[N], xb[N];
             float ax[N];
@@ -999,20 +1031,8 @@ int lk_flow_device(ofps_hip_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_cu
         }
         P.start[levels] = nb;
         if (nb) hipLaunchKernelGGL(lk_grad_all_kernel, dim3(nb), dim3(256), 0, s, Ip, P, gxp, gyp);
-        if (tiled) {
-            // structure tensors of every level: one launch (32 x 32 pixels per block).
-            // (measured and rejected: forming the gradients while staging -- five loads per window record instead of three,
-            // 0.53 ms -- and summing G inside the level kernel -- 0.50 ms: that kernel is held to 80 VGPRs and lives at the
-            // VALU limit, the tensor kernel runs at twice its occupancy)
-            nb = 0;
-            for (int l = 0; l < levels; ++l) { P.start[l] = nb; nb += lk_grid_xcd(ws[l], hs[l], kTTX, kTTY).x; }
-            P.start[levels] = nb;
-            switch (radius) {
-                case 2: hipLaunchKernelGGL(lk_tensor_tiled_kernel<2>, dim3(nb), dim3(256), 0, s, gxp, gyp, P, Gp); break;
-                case 4: hipLaunchKernelGGL(lk_tensor_tiled_kernel<4>, dim3(nb), dim3(256), 0, s, gxp, gyp, P, Gp); break;
-                default: hipLaunchKernelGGL(lk_tensor_tiled_kernel<6>, dim3(nb), dim3(256), 0, s, gxp, gyp, P, Gp); break;
-            }
-        }
+        // (the structure tensors of the tiled path are summed inside the level kernels' first step; the run-time-radius path
+        // below keeps its tensor launch and plane)
     }
     for (int l = levels - 1; l >= 0; --l) {
         const int w = ws[l], h = hs[l];
@@ -1036,9 +1056,9 @@ int lk_flow_device(ofps_hip_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_cu
             // is read back by the very thread that later overwrites it with the result
             float2* park = other;
 #define OFPS_LK_LEVEL(R)                                                                                                     \
-    hipLaunchKernelGGL(lk_level_lds_kernel<R>, lk_grid_xcd(w, h, kTX, kTY), dim3(256), 0, s, Ip + off[l], Jp + off[l], gx, gy, G, w, h, iters, io, cnt,      \
+    hipLaunchKernelGGL(lk_level_lds_kernel<R>, lk_grid_xcd(w, h, kTX, kTY), dim3(256), 0, s, Ip + off[l], Jp + off[l], gx, gy, w, h, iters, io, cnt,         \
                        tiles, park, last ? prof : nullptr, force_fall);                                                     \
-    hipLaunchKernelGGL(lk_level_general_kernel<R>, gg, dim3(256), 0, s, Ip + off[l], Jp + off[l], gx, gy, G, w, h, iters, io, cnt, \
+    hipLaunchKernelGGL(lk_level_general_kernel<R>, gg, dim3(256), 0, s, Ip + off[l], Jp + off[l], gx, gy, w, h, iters, io, cnt,    \
                        tiles, park)
             switch (radius) {
                 case 2: OFPS_LK_LEVEL(2); break;

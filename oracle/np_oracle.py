@@ -324,10 +324,11 @@ def lk_flow(prev, cur, levels=3, radius=4, iters=3):
                     qx, qy = np.clip(xx + dx, 0, w - 1), np.clip(yy + dy, 0, h - 1)
                     ix, iy = gx[qy, qx], gy[qy, qx]
                     d = (Il[qy, qx] - _lk_bilinear(Jl, (qx.astype(F) + u).astype(F), (qy.astype(F) + v).astype(F))).astype(F)
-                    gxx = (gxx + ix * ix).astype(F); gxy = (gxy + ix * iy).astype(F); gyy = (gyy + iy * iy).astype(F)
                     if LK_SPEC_FMA:
+                        gxx = fma32(ix, ix, gxx); gxy = fma32(ix, iy, gxy); gyy = fma32(iy, iy, gyy)
                         bx = fma32(ix, d, bx); by = fma32(iy, d, by)
                     else:
+                        gxx = (gxx + ix * ix).astype(F); gxy = (gxy + ix * iy).astype(F); gyy = (gyy + iy * iy).astype(F)
                         bx = (bx + ix * d).astype(F); by = (by + iy * d).astype(F)
             det = (gxx * gyy - gxy * gxy).astype(F)
             ok = det > F(0.01)

@@ -1065,9 +1065,10 @@ static void lk_pyr_down(const float* in, int w, int h, float* out, int w1, int h
         }
 }
 
-/* N2 spec, revision 2 (DESIGN.md "N2"): the bilinear sample and the two residual sums fuse their multiply-adds --
- * lerp(a, b, t) = fma(t, b - a, a), b += g * d as fma(g, d, b): 7 operations per window tap instead of 11, each result
- * rounded once instead of twice.  ORC_LK_SPEC_FMA = 0 rebuilds revision 1 (separate multiply and add) for A/B runs;
+/* N2 spec, revision 2 (DESIGN.md "N2"): the bilinear sample, the two residual sums and the three structure-tensor sums
+ * fuse their multiply-adds -- lerp(a, b, t) = fma(t, b - a, a), b += g * d as fma(g, d, b), gxx += ix * ix as
+ * fma(ix, ix, gxx): 7 operations per window tap and step instead of 11 (+ 3 instead of 6 per tap for the tensor), each
+ * result rounded once instead of twice.  ORC_LK_SPEC_FMA = 0 rebuilds revision 1 (separate multiply and add) for A/B runs;
  * ofps_amd/csrc/lk.hip carries the same switch (OFPS_LK_SPEC_FMA) and the two must be built alike.  fmaf() is the
  * correctly rounded fused operation whatever the host: orc_lk_flow is cloned for FMA3 hosts (one vfmadd instruction) with
  * the libm call as the portable clone. */
@@ -1166,7 +1167,7 @@ int orc_lk_flow(const uint8_t* prev, const uint8_t* cur, int W, int H, int strid
                             const int qx = lk_clampi(x + dx, 0, w - 1), qy = lk_clampi(y + dy, 0, h - 1);
                             const float ix = gx[(size_t)qy * w + qx], iy = gy[(size_t)qy * w + qx];
                             const float d = Il[(size_t)qy * w + qx] - lk_bilinear(Jl, w, h, (float)qx + u, (float)qy + v);
-                            gxx += ix * ix; gxy += ix * iy; gyy += iy * iy;
+                            gxx = lk_accum(ix, ix, gxx); gxy = lk_accum(ix, iy, gxy); gyy = lk_accum(iy, iy, gyy);
                             bx = lk_accum(ix, d, bx); by = lk_accum(iy, d, by);
                         }
                     const float det = gxx * gyy - gxy * gxy;

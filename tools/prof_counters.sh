@@ -7,7 +7,7 @@ TAG=${1:-prof}; shift || true
 cd /tmp && export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
-CMD="python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-end-to-end $*"   # same steps/warm-up as the default bench line
+CMD="python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-end-to-end --no-legs $*"   # same steps/warm-up as the default bench line
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o k -- $CMD > $OUT/trace_run.txt 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY --output-format csv -d $OUT/pmc_sq1 -o k -- $CMD > $OUT/pmc_sq1_run.txt 2>&1
 rocprofv3 --pmc SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sq2 -o k -- $CMD > $OUT/pmc_sq2_run.txt 2>&1
