@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256) void lk_pyr0_kernel(const TIn* __restrict__ s0
     __syncthreads();
     // the previous frame's level-0 gradients from the same window (an element holds I at its clamped coordinates, so its
     // neighbours are lk_grad's clamped taps): the gradient launch then only has the coarser levels left
-    if (blockIdx.z == 0) {
+    if (blockIdx.z == 0 && gx0p) {
         for (int t = threadIdx.x; t < 2 * kP0X * 2 * kP0Y; t += 256) {
             const int r = 2 + t / (2 * kP0X), c = 2 + t % (2 * kP0X);
             const int gx = gx0 + c, gy = gy0 + r;
@@ -362,6 +362,120 @@ __device__ __forceinline__ void lk_stage3(const float* __restrict__ p0, const fl
     }
 }
 
+// Level 0 straight from the u8 frames (round 3).  The previous frame's window records (I, gx, gy) are made from ONE u8
+// window with a 1-pixel rim -- 42 x 18 bytes instead of three f32 planes' 40 x 16 x 12 bytes -- in two phases through an
+// LDS scratch: (A) the window as f32 at clamped image coordinates, (B) per tile element its value and central differences
+// at ITS clamped coordinates (the expressions lk_pyr0_kernel used to write to the level-0 gradient planes: same operands,
+// same bits).  (float)u8 is exact, so are all the values downstream.  `scratch` needs (TH + 2) * (TW + 2) floats (the
+// level kernel lends its rectangle buffer, which is not in use yet).  Ends with the barrier phase B's readers need.
+template <int RADIUS>
+struct LkU8Window {                                   // the f32 copy of the u8 window in LDS: TH + 2 rows of WP floats
+    using T = LkTile<RADIUS>;
+    static constexpr int WH = T::TH + 2;
+    static constexpr int WP = (T::TW + 2 + 3 + 3) / 4 * 4;          // room for a dword-aligned start (up to 3 pixels early)
+    static constexpr int FLOATS = WH * WP;
+};
+// in three parts, so that a caller can put work between the request and the use of the window's bytes: `issue` requests them
+// (registers), `spill` writes them to the scratch as f32 (a barrier must follow), `records` makes the tile records from the
+// scratch (a barrier must follow before the tile is read).
+template <int RADIUS>
+struct LkU8Regs {
+    using T = LkTile<RADIUS>;
+    using U = LkU8Window<RADIUS>;
+    static constexpr int NQ = (U::WP / 4 * U::WH + 255) / 256;              // dwords per thread, aligned form
+    static constexpr int NB = ((T::TW + 2) * U::WH + 255) / 256;           // bytes per thread, element form
+    bool vec;
+    int ox;
+    uint32_t q[NQ];
+    uint8_t b[NB];
+};
+template <int RADIUS>
+__device__ __forceinline__ void lk_stage3_u8_issue(const uint8_t* __restrict__ src, int stride, int w, int h, int x0, int y0, LkU8Regs<RADIUS>& g) {
+    using T = LkTile<RADIUS>;
+    using U = LkU8Window<RADIUS>;
+    constexpr int WW = T::TW + 2, WH = U::WH, WP = U::WP;
+    int ox = x0 - T::R - 1;                                           // image x of scratch column 0
+    const int oy = y0 - T::R - 1;
+    // interior tiles of dword-aligned frames: the window starts at the dword boundary at or before its first pixel and is
+    // loaded four pixels per request (one request per thread for the whole window at radius 4); everything else byte by
+    // byte with the coordinates clamped per element.  Uniform branch.
+    g.vec = ox >= 0 && oy >= 0 && oy + WH <= h && (ox & ~3) + WP <= w && (stride & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 3) == 0;
+    if (g.vec) {
+        ox &= ~3;
+        constexpr int Q = WP / 4;
+#pragma unroll
+        for (int k = 0; k < LkU8Regs<RADIUS>::NQ; ++k) {
+            const int t = threadIdx.x + 256 * k;
+            if (t < Q * WH) {
+                const int r = t / Q, c4 = t - r * Q;
+                g.q[k] = *reinterpret_cast<const uint32_t*>(src + (size_t)(oy + r) * stride + ox + 4 * c4);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < LkU8Regs<RADIUS>::NB; ++k) {
+            const int t = threadIdx.x + 256 * k;
+            if (t < WW * WH) {
+                const int r = t / WW, c = t - r * WW;
+                g.b[k] = src[(size_t)lk_clampi(oy + r, 0, h - 1) * stride + lk_clampi(ox + c, 0, w - 1)];
+            }
+        }
+    }
+    g.ox = ox;
+}
+template <int RADIUS>
+__device__ __forceinline__ void lk_stage3_u8_spill(float* scratch, const LkU8Regs<RADIUS>& g) {
+    using T = LkTile<RADIUS>;
+    using U = LkU8Window<RADIUS>;
+    constexpr int WW = T::TW + 2, WH = U::WH, WP = U::WP;
+    if (g.vec) {
+        constexpr int Q = WP / 4;
+#pragma unroll
+        for (int k = 0; k < LkU8Regs<RADIUS>::NQ; ++k) {
+            const int t = threadIdx.x + 256 * k;
+            if (t < Q * WH) {
+                const int r = t / Q, c4 = t - r * Q;
+                const uint32_t q = g.q[k];
+                *reinterpret_cast<float4*>(scratch + r * WP + 4 * c4) =
+                    make_float4((float)(q & 0xFFu), (float)((q >> 8) & 0xFFu), (float)((q >> 16) & 0xFFu), (float)(q >> 24));
+            }
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < LkU8Regs<RADIUS>::NB; ++k) {
+            const int t = threadIdx.x + 256 * k;
+            if (t < WW * WH) { const int r = t / WW, c = t - r * WW; scratch[r * WP + c] = (float)g.b[k]; }
+        }
+    }
+}
+template <int RADIUS>
+__device__ __forceinline__ void lk_stage3_u8_records(const float* scratch, float4 (*tile)[LkTile<RADIUS>::TW], int ox, int w, int h, int x0, int y0) {
+    using T = LkTile<RADIUS>;
+    constexpr int WP = LkU8Window<RADIUS>::WP;
+    const int oy = y0 - T::R - 1;
+    for (int t = threadIdx.x; t < T::TW * T::TH; t += 256) {
+        const int r = t / T::TW, c = t - r * T::TW;
+        const int xc = lk_clampi(x0 - T::R + c, 0, w - 1), yc = lk_clampi(y0 - T::R + r, 0, h - 1);
+        const int ix = xc - ox, iy = yc - oy;                         // where (xc, yc) sits in the scratch window
+        const int il = lk_clampi(xc - 1, 0, w - 1) - ox, ir = lk_clampi(xc + 1, 0, w - 1) - ox;
+        const int iu = lk_clampi(yc - 1, 0, h - 1) - oy, id = lk_clampi(yc + 1, 0, h - 1) - oy;
+        const float v = scratch[iy * WP + ix];
+        const float gxv = (scratch[iy * WP + ir] - scratch[iy * WP + il]) * 0.5f;
+        const float gyv = (scratch[id * WP + ix] - scratch[iu * WP + ix]) * 0.5f;
+        tile[r][c] = make_float4(v, gxv, gyv, 0.0f);
+    }
+}
+// the three parts back to back (callers with nothing to put in between: the hand-over kernel)
+template <int RADIUS>
+__device__ __forceinline__ void lk_stage3_u8(const uint8_t* __restrict__ src, int stride, float* scratch, float4 (*tile)[LkTile<RADIUS>::TW],
+                                             int w, int h, int x0, int y0) {
+    LkU8Regs<RADIUS> g;
+    lk_stage3_u8_issue<RADIUS>(src, stride, w, h, x0, y0, g);
+    lk_stage3_u8_spill<RADIUS>(scratch, g);
+    __syncthreads();
+    lk_stage3_u8_records<RADIUS>(scratch, tile, g.ox, w, h, x0, y0);
+}
+
 // One window row of the level kernel at radius 4 (9 taps), spec revision 2, hand-scheduled.  hipcc's own code for this loop
 // copies the carried interpolation row (8 v_mov per row), re-reads every tile record into the same four registers with a
 // full wait in front of each use, and -- asked to unroll by two so that the carried row could change name instead of
@@ -495,7 +609,7 @@ __device__ __forceinline__ void lk_row9_asm_g(float (&r)[19], const float (&a)[9
 // they are NOT handled here: the main kernel (GENERAL = false, 57 VGPRs -> 6 waves per SIMD instead of 4) appends them
 // to a list and a small second launch (GENERAL = true) walks that list with the register-reuse global path.  Same
 // values, same operation order either way, hence the same bits.
-template <int RADIUS>
+template <int RADIUS, bool U8 = false>
 struct LkStepShared {
     using T = LkTile<RADIUS>;
     // capacity of the current-frame rectangle: flows inside a tile may differ by up to SPREAD_X / SPREAD_Y pixels; only the
@@ -509,6 +623,9 @@ struct LkStepShared {
     alignas(16) float jl[LH][JS];
     float4 tile[T::TH][T::TW];         // (I, gx, gy, -) of the previous frame's window
     int box[2][4][5];                  // [step parity][wave]: min x0, max x0+1, min y0, max y0+1, every lane's window columns consecutive
+    // level 0 (u8 source): the f32 copy of the u8 window the tile records are made from.  A buffer of its own (3.4 KB at
+    // radius 4; 6 workgroups per CU still fit): the records are made while the first rectangle's loads are in flight
+    alignas(16) float u8win[U8 ? LkU8Window<RADIUS>::FLOATS : 4];
     // what the LDS footprint allows (160 KB per CU, 4 waves per workgroup): the register budget hipcc is held to
     // (radius 4 measured at 5 / 6 / 7 waves per SIMD: 0.396 / 0.380 / 0.411 ms -- 94 registers without spills, 80 with 3
     // spilled outside the row loop, 72 with 11)
@@ -569,9 +686,11 @@ __device__ __forceinline__ void lk_store(const float2 out, int x, int y, int w, 
 // stay on chip between steps; only the current frame's rectangle is restaged (it moves with the flow).  A tile whose
 // rectangle does not fit at step `it` parks its flow in fb_flow, appends (tile, it) to fb_tiles (count in *fb_count)
 // and leaves the remaining steps to lk_level_general_kernel.
-template <int RADIUS>
-__global__ __launch_bounds__(256, LkStepShared<RADIUS>::WAVES_PER_SIMD) void lk_level_lds_kernel(const float* __restrict__ I, const float* __restrict__ J,
-                                                           const float* __restrict__ gx, const float* __restrict__ gy,
+// U8 = true (level 0): I_ / J_ are the u8 frames themselves, rows src_stride bytes apart; no f32 level-0 planes and no
+// level-0 gradient planes exist (lk_stage3_u8; the rectangle is converted while it is staged).
+template <int RADIUS, bool U8>
+__global__ __launch_bounds__(256, LkStepShared<RADIUS>::WAVES_PER_SIMD) void lk_level_lds_kernel(const void* __restrict__ I_, const void* __restrict__ J_,
+                                                           const float* __restrict__ gx, const float* __restrict__ gy, int src_stride,
                                                            int w, int h, int iters, const LkFlowIO io,
                                                            uint32_t* __restrict__ fb_count, uint2* __restrict__ fb_tiles,
                                                            float2* fb_flow, unsigned long long* __restrict__ prof, int force_fall_arg) {
@@ -586,7 +705,7 @@ __global__ __launch_bounds__(256, LkStepShared<RADIUS>::WAVES_PER_SIMD) void lk_
     // prof (diagnostics, normally null): per-workgroup s_memtime stamps at the phase boundaries of the first step
 #define OFPS_LK_STAMP(slot) do { if (prof && threadIdx.x == 0) prof[((size_t)tile_y * tiles_x + tile_x) * 6 + (slot)] = __builtin_readcyclecounter(); } while (0)
     using T = LkTile<RADIUS>;
-    using S = LkStepShared<RADIUS>;
+    using S = LkStepShared<RADIUS, U8>;
     const int tiles_x = (w + kTX - 1) / kTX;
     int tile_x, tile_y;
     if (!lk_tile_of_block(tiles_x, tiles_x * ((h + kTY - 1) / kTY), tile_x, tile_y)) return;
@@ -594,11 +713,18 @@ __global__ __launch_bounds__(256, LkStepShared<RADIUS>::WAVES_PER_SIMD) void lk_
     constexpr int N = T::N;
     __shared__ S sh;
     const int x0 = tile_x * kTX, y0 = tile_y * kTY;
-    lk_stage3<RADIUS>(I, gx, gy, sh.tile, w, h, x0, y0);
+    const float* I = static_cast<const float*>(I_);
+    const float* J = static_cast<const float*>(J_);
+    const uint8_t* J8 = static_cast<const uint8_t*>(J_);
     const int lx = threadIdx.x % kTX, ly = threadIdx.x / kTX, px = x0 + lx, py = y0 + ly;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const bool active = px < w && py < h;
-    float2 f = active ? lk_flow_read(io, px, py) : make_float2(0.0f, 0.0f);
+    float2 f = active ? lk_flow_read(io, px, py) : make_float2(0.0f, 0.0f);      // requested first: in flight during the staging
+    // u8 source: the window's bytes are requested here and used after the first box exchange (front(), step 0): their
+    // latency runs beside the flow read, the column origins and the exchange instead of in front of them
+    LkU8Regs<RADIUS> u8g;
+    if constexpr (U8) lk_stage3_u8_issue<RADIUS>(static_cast<const uint8_t*>(I_), src_stride, w, h, x0, y0, u8g);
+    else lk_stage3<RADIUS>(I, gx, gy, sh.tile, w, h, x0, y0);
     // The 2x2 structure tensor of the pixel's window does not depend on the flow: it is summed by the level's FIRST step, from
     // the very tile records that step reads for the residual (three fused multiply-adds per tap more, no LDS traffic of
     // its own), and stays in three registers for the later steps -- the separate tensor launch, its float4 plane (42 MB of
@@ -606,108 +732,131 @@ __global__ __launch_bounds__(256, LkStepShared<RADIUS>::WAVES_PER_SIMD) void lk_
     float gxx = 0.0f, gxy = 0.0f, gyy = 0.0f;
     bool st_valid = false;                                   // the rectangle of the current frame held in jl[][] (uniform)
     int st_x0 = 0, st_x1 = -1, st_y0 = 0, st_y1 = -1, st_xs = 0;
+    // The front half of a step -- box exchange, fit test, (re)staging of the current frame's rectangle -- as a function of
+    // the step: instantiated once in front of the step loop for step 0 (the only instance that touches the u8 window's
+    // staging registers, whose lives therefore end before the loop) and once inside it.  false = the tile fell.
+    int x = 0, y = 0;
+    bool all_consecutive = false;
+    auto front = [&](int it, auto first) -> bool {
+            // the pixel coordinates pass through an empty asm so that the compiler does not hoist the clamped window
+            // coordinates (2N integers + their float conversions) out of the step loop: that costs 40 VGPRs and two waves
+            // per SIMD for a handful of integer operations per step
+            // (made from the thread index every step instead of copied from px / py: two registers less across the row loop)
+            int tidx = (int)threadIdx.x;
+            asm volatile("" : "+v"(tidx));
+            x = x0 + tidx % kTX; y = y0 + tidx / kTX;
+            // first pass over the window columns: only what the workgroup's box needs (first and last origin, "consecutive").
+            // The origins and fractions the rows use are made AGAIN after the barrier / staging below (same operations, same
+            // values): kept alive across that phase they were spilled to scratch in every step (76 B per pixel-step of HBM
+            // traffic, rocprofv3 WRITE_SIZE); nine floors are cheaper
+            int xi_first = 0, xi_last = 0;
+            bool consecutive = true;
+            {
+                float dummy_a;
+                int prev = 0;
+    #pragma unroll
+                for (int k = 0; k < N; ++k) {
+                    const int o = lk_origin(lk_clampi(x + k - RADIUS, 0, w - 1), f.x, w, dummy_a);
+                    if (k > 0) consecutive = consecutive && (o == prev + 1);
+                    if (k == 0) xi_first = o;
+                    xi_last = o; prev = o;
+                }
+            }
+            float dummy;
+            const int yt = lk_origin(lk_clampi(y - RADIUS, 0, h - 1), f.y, h, dummy);
+            const int yb_ = lk_origin(lk_clampi(y + RADIUS, 0, h - 1), f.y, h, dummy);
+            {
+                // window columns / rows are monotone in k / r, so the extremes are the first and the last
+                int bx0 = active ? xi_first : 0x7FFFFFFF, bx1 = active ? xi_last + 1 : -0x7FFFFFFF;
+                int by0 = active ? yt : 0x7FFFFFFF, by1 = active ? yb_ + 1 : -0x7FFFFFFF;
+                bx0 = lk_wave_minmax<false>(bx0); bx1 = lk_wave_minmax<true>(bx1);
+                by0 = lk_wave_minmax<false>(by0); by1 = lk_wave_minmax<true>(by1);
+                // window columns that sample consecutive texels (x0[k+1] == x0[k] + 1: everywhere but at the left/right image
+                // border, where the clamped window columns repeat) share one row of N+1 texels; otherwise every column reads
+                // its own pair.  Decided per workgroup, through the same exchange as the box (no barrier of its own).
+                const int cons = __all(consecutive || !active) ? 1 : 0;
+                // (slots alternate with the step: a step that reuses the staged rectangle has no second barrier, so a fast wave
+                // may write the next step's box while a slow one still reads this step's)
+                if (lane == 0) { int* b = sh.box[it & 1][wave]; b[0] = bx0; b[1] = bx1; b[2] = by0; b[3] = by1; b[4] = cons; }
+            }
+            if constexpr (U8 && decltype(first)::value) lk_stage3_u8_spill<RADIUS>(sh.u8win, u8g);   // the window's bytes, requested in the prologue; same barrier as the box
+            if (it == 0) OFPS_LK_STAMP(1);
+            __syncthreads();                                                 // also: everybody is done reading jl[] of the previous step
+            if (it == 0) OFPS_LK_STAMP(2);
+            // (box[] holds the same numbers for every thread: read into SCALAR registers -- the rectangle's bounds live across
+            // the whole level, and as vector registers they were part of what got spilled around the row loop)
+            const int (*bq)[5] = sh.box[it & 1];
+            auto uni = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
+            const int xmin = min(min(uni(bq[0][0]), uni(bq[1][0])), min(uni(bq[2][0]), uni(bq[3][0])));
+            const int xmax = max(max(uni(bq[0][1]), uni(bq[1][1])), max(uni(bq[2][1]), uni(bq[3][1])));
+            const int bymin = min(min(uni(bq[0][2]), uni(bq[1][2])), min(uni(bq[2][2]), uni(bq[3][2])));
+            const int ymax = max(max(uni(bq[0][3]), uni(bq[1][3])), max(uni(bq[2][3]), uni(bq[3][3])));
+            all_consecutive = (uni(bq[0][4]) & uni(bq[1][4]) & uni(bq[2][4]) & uni(bq[3][4])) != 0;
+            const int fits = xmax >= xmin && xmax - xmin < S::LW && ymax - bymin < S::LH &&
+                             !(it == force_fall && ((tile_x + tile_y) & 1));
+            if (!fits) {                                                     // uniform: box[] is the same for every thread
+                if (threadIdx.x == 0) fb_tiles[atomicAdd(fb_count, 1u)] = make_uint2((uint32_t)tile_x | ((uint32_t)tile_y << 16), (uint32_t)it);
+                if (active) fb_flow[(size_t)y * w + x] = f;
+                return false;
+            }
+            // The current frame's rectangle is staged with a margin and KEPT: a later step whose box still lies inside it (flows
+            // move by a fraction of a pixel per step once the coarser levels have done their work) reuses it -- no global loads,
+            // no second barrier in that step.  Everything below is uniform (derived from box[]).
+            const bool inside = st_valid && xmin >= st_x0 && xmax <= st_x1 && bymin >= st_y0 && ymax <= st_y1;
+            if (!inside) {
+                // (thread index through an empty asm: the staging addresses are made here, per staging, not hoisted out of the step
+                // loop into registers that are then spilled for the whole level)
+                int tid = (int)threadIdx.x;
+                asm volatile("" : "+v"(tid));
+                if constexpr (U8 && decltype(first)::value) lk_stage3_u8_records<RADIUS>(sh.u8win, sh.tile, u8g.ox, w, h, x0, y0);   // visible after the barrier that ends this block
+                // margins: up to kJMargin pixels on every side, as far as the capacity allows
+                const int mx = min(kJMargin, (S::LW - (xmax - xmin + 1)) / 2), my = min(kJMargin, (S::LH - (ymax - bymin + 1)) / 2);
+                const int rx0 = xmin - mx, rx1 = xmax + mx, ry0 = bymin - my, ry1 = ymax + my;
+                // rows [ry0, ry1] x columns [xs, rx1], xs = rx0 rounded down to a multiple of 4 when the padded rectangle lies
+                // inside the frame and the plane is 16-byte aligned (16-byte loads), rx0 otherwise
+                int xs_new = rx0;
+                const int chh = ry1 - ry0 + 1;
+                const int xa4 = rx0 & ~3, cw4 = (rx1 - xa4 + 4) >> 2;                        // float4 per row after padding
+                const bool vec = rx0 >= 0 && xa4 + 4 * cw4 <= w && 4 * cw4 <= S::JS &&
+                                 (U8 ? (src_stride & 3) == 0 && (reinterpret_cast<uintptr_t>(J8) & 3) == 0
+                                     : (w & 3) == 0 && (reinterpret_cast<uintptr_t>(J) & 15) == 0);
+                if (vec) {                                                   // uniform
+                    xs_new = xa4;
+                    // 32 lanes per rectangle row (cw4 <= JS / 4 <= 32), 8 rows per pass: no division by the run-time width
+                    static_assert(S::JS / 4 <= 32, "J staging assumes at most 32 float4 per rectangle row");
+                    const int c4 = tid & 31;
+                    if (c4 < cw4) {
+                        for (int cy = tid >> 5; cy < chh; cy += 8) {
+                            if constexpr (U8) {                              // four pixels per dword, converted on the way in
+                                const uint32_t q = *reinterpret_cast<const uint32_t*>(J8 + (size_t)lk_clampi(ry0 + cy, 0, h - 1) * src_stride + xa4 + 4 * c4);
+                                *reinterpret_cast<float4*>(&sh.jl[cy][4 * c4]) =
+                                    make_float4((float)(q & 0xFFu), (float)((q >> 8) & 0xFFu), (float)((q >> 16) & 0xFFu), (float)(q >> 24));
+                            } else {
+                                *reinterpret_cast<float4*>(&sh.jl[cy][4 * c4]) =
+                                    *reinterpret_cast<const float4*>(J + (size_t)lk_clampi(ry0 + cy, 0, h - 1) * w + xa4 + 4 * c4);
+                            }
+                        }
+                    }
+                } else {
+                    const int cw = rx1 - rx0 + 1;
+                    const int cx = tid & 127, cy0 = tid >> 7;            // 128 threads per row, two rows per pass
+                    if (cx < cw) {
+                        const int gxc = lk_clampi(rx0 + cx, 0, w - 1);
+                        for (int cy = cy0; cy < chh; cy += 2) {
+                            if constexpr (U8) sh.jl[cy][cx] = (float)J8[(size_t)lk_clampi(ry0 + cy, 0, h - 1) * src_stride + gxc];
+                            else sh.jl[cy][cx] = J[(size_t)lk_clampi(ry0 + cy, 0, h - 1) * w + gxc];
+                        }
+                    }
+                }
+                st_valid = true; st_x0 = rx0; st_x1 = rx1; st_y0 = ry0; st_y1 = ry1; st_xs = xs_new;
+                __syncthreads();
+            }
+        return true;
+    };
+    if (iters > 0 && !front(0, std::true_type{})) return;
 #pragma unroll 1
     for (int it = 0; it < iters; ++it) {
-        // the pixel coordinates pass through an empty asm so that the compiler does not hoist the clamped window
-        // coordinates (2N integers + their float conversions) out of the step loop: that costs 40 VGPRs and two waves
-        // per SIMD for a handful of integer operations per step
-        // (made from the thread index every step instead of copied from px / py: two registers less across the row loop)
-        int tidx = (int)threadIdx.x;
-        asm volatile("" : "+v"(tidx));
-        const int x = x0 + tidx % kTX, y = y0 + tidx / kTX;
-        // first pass over the window columns: only what the workgroup's box needs (first and last origin, "consecutive").
-        // The origins and fractions the rows use are made AGAIN after the barrier / staging below (same operations, same
-        // values): kept alive across that phase they were spilled to scratch in every step (76 B per pixel-step of HBM
-        // traffic, rocprofv3 WRITE_SIZE); nine floors are cheaper
-        int xi_first = 0, xi_last = 0;
-        bool consecutive = true;
-        {
-            float dummy_a;
-            int prev = 0;
-#pragma unroll
-            for (int k = 0; k < N; ++k) {
-                const int o = lk_origin(lk_clampi(x + k - RADIUS, 0, w - 1), f.x, w, dummy_a);
-                if (k > 0) consecutive = consecutive && (o == prev + 1);
-                if (k == 0) xi_first = o;
-                xi_last = o; prev = o;
-            }
-        }
-        float dummy;
-        const int yt = lk_origin(lk_clampi(y - RADIUS, 0, h - 1), f.y, h, dummy);
-        const int yb_ = lk_origin(lk_clampi(y + RADIUS, 0, h - 1), f.y, h, dummy);
-        {
-            // window columns / rows are monotone in k / r, so the extremes are the first and the last
-            int bx0 = active ? xi_first : 0x7FFFFFFF, bx1 = active ? xi_last + 1 : -0x7FFFFFFF;
-            int by0 = active ? yt : 0x7FFFFFFF, by1 = active ? yb_ + 1 : -0x7FFFFFFF;
-            bx0 = lk_wave_minmax<false>(bx0); bx1 = lk_wave_minmax<true>(bx1);
-            by0 = lk_wave_minmax<false>(by0); by1 = lk_wave_minmax<true>(by1);
-            // window columns that sample consecutive texels (x0[k+1] == x0[k] + 1: everywhere but at the left/right image
-            // border, where the clamped window columns repeat) share one row of N+1 texels; otherwise every column reads
-            // its own pair.  Decided per workgroup, through the same exchange as the box (no barrier of its own).
-            const int cons = __all(consecutive || !active) ? 1 : 0;
-            // (slots alternate with the step: a step that reuses the staged rectangle has no second barrier, so a fast wave
-            // may write the next step's box while a slow one still reads this step's)
-            if (lane == 0) { int* b = sh.box[it & 1][wave]; b[0] = bx0; b[1] = bx1; b[2] = by0; b[3] = by1; b[4] = cons; }
-        }
-        if (it == 0) OFPS_LK_STAMP(1);
-        __syncthreads();                                                 // also: everybody is done reading jl[] of the previous step
-        if (it == 0) OFPS_LK_STAMP(2);
-        // (box[] holds the same numbers for every thread: read into SCALAR registers -- the rectangle's bounds live across
-        // the whole level, and as vector registers they were part of what got spilled around the row loop)
-        const int (*bq)[5] = sh.box[it & 1];
-        auto uni = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
-        const int xmin = min(min(uni(bq[0][0]), uni(bq[1][0])), min(uni(bq[2][0]), uni(bq[3][0])));
-        const int xmax = max(max(uni(bq[0][1]), uni(bq[1][1])), max(uni(bq[2][1]), uni(bq[3][1])));
-        const int bymin = min(min(uni(bq[0][2]), uni(bq[1][2])), min(uni(bq[2][2]), uni(bq[3][2])));
-        const int ymax = max(max(uni(bq[0][3]), uni(bq[1][3])), max(uni(bq[2][3]), uni(bq[3][3])));
-        const bool all_consecutive = (uni(bq[0][4]) & uni(bq[1][4]) & uni(bq[2][4]) & uni(bq[3][4])) != 0;
-        const int fits = xmax >= xmin && xmax - xmin < S::LW && ymax - bymin < S::LH &&
-                         !(it == force_fall && ((tile_x + tile_y) & 1));
-        if (!fits) {                                                     // uniform: box[] is the same for every thread
-            if (threadIdx.x == 0) fb_tiles[atomicAdd(fb_count, 1u)] = make_uint2((uint32_t)tile_x | ((uint32_t)tile_y << 16), (uint32_t)it);
-            if (active) fb_flow[(size_t)y * w + x] = f;
-            return;
-        }
-        // The current frame's rectangle is staged with a margin and KEPT: a later step whose box still lies inside it (flows
-        // move by a fraction of a pixel per step once the coarser levels have done their work) reuses it -- no global loads,
-        // no second barrier in that step.  Everything below is uniform (derived from box[]).
-        const bool inside = st_valid && xmin >= st_x0 && xmax <= st_x1 && bymin >= st_y0 && ymax <= st_y1;
-        if (!inside) {
-            // (thread index through an empty asm: the staging addresses are made here, per staging, not hoisted out of the step
-            // loop into registers that are then spilled for the whole level)
-            int tid = (int)threadIdx.x;
-            asm volatile("" : "+v"(tid));
-            // margins: up to kJMargin pixels on every side, as far as the capacity allows
-            const int mx = min(kJMargin, (S::LW - (xmax - xmin + 1)) / 2), my = min(kJMargin, (S::LH - (ymax - bymin + 1)) / 2);
-            const int rx0 = xmin - mx, rx1 = xmax + mx, ry0 = bymin - my, ry1 = ymax + my;
-            // rows [ry0, ry1] x columns [xs, rx1], xs = rx0 rounded down to a multiple of 4 when the padded rectangle lies
-            // inside the frame and the plane is 16-byte aligned (16-byte loads), rx0 otherwise
-            int xs_new = rx0;
-            const int chh = ry1 - ry0 + 1;
-            const int xa4 = rx0 & ~3, cw4 = (rx1 - xa4 + 4) >> 2;                        // float4 per row after padding
-            const bool vec = rx0 >= 0 && xa4 + 4 * cw4 <= w && 4 * cw4 <= S::JS && (w & 3) == 0 &&
-                             (reinterpret_cast<uintptr_t>(J) & 15) == 0;
-            if (vec) {                                                   // uniform
-                xs_new = xa4;
-                // 32 lanes per rectangle row (cw4 <= JS / 4 <= 32), 8 rows per pass: no division by the run-time width
-                static_assert(S::JS / 4 <= 32, "J staging assumes at most 32 float4 per rectangle row");
-                const int c4 = tid & 31;
-                if (c4 < cw4) {
-                    for (int cy = tid >> 5; cy < chh; cy += 8)
-                        *reinterpret_cast<float4*>(&sh.jl[cy][4 * c4]) =
-                            *reinterpret_cast<const float4*>(J + (size_t)lk_clampi(ry0 + cy, 0, h - 1) * w + xa4 + 4 * c4);
-                }
-            } else {
-                const int cw = rx1 - rx0 + 1;
-                const int cx = tid & 127, cy0 = tid >> 7;            // 128 threads per row, two rows per pass
-                if (cx < cw) {
-                    const int gxc = lk_clampi(rx0 + cx, 0, w - 1);
-                    for (int cy = cy0; cy < chh; cy += 2) sh.jl[cy][cx] = J[(size_t)lk_clampi(ry0 + cy, 0, h - 1) * w + gxc];
-                }
-            }
-            st_valid = true; st_x0 = rx0; st_x1 = rx1; st_y0 = ry0; st_y1 = ry1; st_xs = xs_new;
-            __syncthreads();
-        }
+        if (it > 0 && !front(it, std::false_type{})) return;
         const int xs = st_xs, ymin = st_y0;                              // origin of jl[][] in frame coordinates
         float ax[N];
         int xi0;                                                         // origin of window column 0 (all the consecutive-column rows need)
@@ -860,9 +1009,9 @@ __global__ __launch_bounds__(256, LkStepShared<RADIUS>::WAVES_PER_SIMD) void lk_
 // second launch: the listed (tile, first step) pairs, per-lane gathers from global memory with register reuse (inside a
 // window row j10 of column k is j00 of column k+1 whenever xb[k] == xa[k+1], and the bottom row of one window row is
 // the top row of the next whenever yb == next ya -- both almost always true; the rare exceptions reload)
-template <int RADIUS>
-__global__ __launch_bounds__(256) void lk_level_general_kernel(const float* __restrict__ I, const float* __restrict__ J,
-                                                               const float* __restrict__ gx, const float* __restrict__ gy,
+template <int RADIUS, bool U8>
+__global__ __launch_bounds__(256) void lk_level_general_kernel(const void* __restrict__ I_, const void* __restrict__ J_,
+                                                               const float* __restrict__ gx, const float* __restrict__ gy, int src_stride,
                                                                int w, int h, int iters, const LkFlowIO io,
                                                                const uint32_t* __restrict__ fb_count,
                                                                const uint2* __restrict__ fb_tiles,
@@ -870,12 +1019,20 @@ __global__ __launch_bounds__(256) void lk_level_general_kernel(const float* __re
     using T = LkTile<RADIUS>;
     constexpr int N = T::N;
     __shared__ float4 tile[T::TH][T::TW];
+    __shared__ __attribute__((aligned(16))) float u8win[U8 ? LkU8Window<RADIUS>::FLOATS : 4];
+    const float* I = static_cast<const float*>(I_);
+    // the current frame, read per lane: an f32 plane (row pitch w) or the u8 frame itself (row pitch src_stride)
+    const float* Jf = static_cast<const float*>(J_);
+    const uint8_t* J8 = static_cast<const uint8_t*>(J_);
+    const int jpitch = U8 ? src_stride : w;
+    auto jat = [&](size_t idx) -> float { if constexpr (U8) return (float)J8[idx]; else return Jf[idx]; };
     const uint32_t count = *fb_count;
     for (uint32_t li = blockIdx.x; li < count; li += gridDim.x) {
         const uint2 id = fb_tiles[li];
         const int x0 = (int)(id.x & 0xFFFFu) * kTX, y0 = (int)(id.x >> 16) * kTY;
         __syncthreads();                                   // the previous tile's readers are done with `tile`
-        lk_stage3<RADIUS>(I, gx, gy, tile, w, h, x0, y0);
+        if constexpr (U8) lk_stage3_u8<RADIUS>(static_cast<const uint8_t*>(I_), src_stride, u8win, tile, w, h, x0, y0);
+        else lk_stage3<RADIUS>(I, gx, gy, tile, w, h, x0, y0);
         __syncthreads();
         const int lx = threadIdx.x % kTX, ly = threadIdx.x / kTX, x = x0 + lx, y = y0 + ly;
         if (x >= w || y >= h) continue;
@@ -907,24 +1064,23 @@ __global__ __launch_bounds__(256) void lk_level_general_kernel(const float* __re
                 float ay;
                 const int yi = lk_origin(lk_clampi(y + r - RADIUS, 0, h - 1), f.y, h, ay);
                 const int ya = lk_clampi(yi, 0, h - 1), yb = lk_clampi(yi + 1, 0, h - 1);
-                const float* ra = J + (size_t)ya * w;
-                const float* rb = J + (size_t)yb * w;
+                const size_t ra = (size_t)ya * jpitch, rb = (size_t)yb * jpitch;
                 if (ya == prev_yb) {
 #pragma unroll
                     for (int k = 0; k <= N; ++k) jt[k] = jb[k];
                 } else {
 #pragma unroll
-                    for (int k = 0; k < N; ++k) jt[k] = ra[xa[k]];
-                    jt[N] = ra[xb[N - 1]];
+                    for (int k = 0; k < N; ++k) jt[k] = jat(ra + xa[k]);
+                    jt[N] = jat(ra + xb[N - 1]);
                 }
 #pragma unroll
-                for (int k = 0; k < N; ++k) jb[k] = rb[xa[k]];
-                jb[N] = rb[xb[N - 1]];
+                for (int k = 0; k < N; ++k) jb[k] = jat(rb + xa[k]);
+                jb[N] = jat(rb + xb[N - 1]);
                 prev_yb = yb;
 #pragma unroll
                 for (int k = 0; k < N; ++k) {
                     float j10 = jt[k + 1], j11 = jb[k + 1];
-                    if (k < N - 1 && xb[k] != xa[k + 1]) { j10 = ra[xb[k]]; j11 = rb[xb[k]]; }     // clamped border / rounding: rare
+                    if (k < N - 1 && xb[k] != xa[k + 1]) { j10 = jat(ra + xb[k]); j11 = jat(rb + xb[k]); }     // clamped border / rounding: rare
                     const float j00 = jt[k], j01 = jb[k];
                     const float top = lk_lerp(j00, j10, ax[k]);
                     const float bot = lk_lerp(j01, j11, ax[k]);
@@ -998,10 +1154,14 @@ int lk_flow_device(ofps_hip_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_cu
             if (!prof) return OFPS_HIP_ENOMEM;
         }
     }
-    if (levels >= 2) {                                            // level 1 from the u8 frames, level-0 f32 planes on the way
+    if (levels >= 2) {                                            // level 1 from the u8 frames
+        // (the tiled path's level 0 works on the u8 frames themselves: no f32 level-0 planes, no level-0 gradient planes)
         dim3 g2 = lk_grid_xcd(ws[1], hs[1], kP0X, kP0Y); g2.z = 2;
-        hipLaunchKernelGGL(lk_pyr0_kernel<uint8_t>, g2, dim3(256), 0, s, d_prev, d_cur, W, H, stride, Ip, Jp, Ip + off[1], Jp + off[1], ws[1],
-                           hs[1], gxp, gyp, fb_count, fb_count ? levels : 0);
+        hipLaunchKernelGGL(lk_pyr0_kernel<uint8_t>, g2, dim3(256), 0, s, d_prev, d_cur, W, H, stride, tiled ? (float*)nullptr : Ip,
+                           tiled ? (float*)nullptr : Jp, Ip + off[1], Jp + off[1], ws[1], hs[1], tiled ? (float*)nullptr : gxp,
+                           tiled ? (float*)nullptr : gyp, fb_count, fb_count ? levels : 0);
+    } else if (tiled) {
+        OFPS_HIP_TRY(ctx, hipMemsetAsync(fb_count, 0, (size_t)levels * sizeof(uint32_t), s));       // the hand-over counters
     } else {
         dim3 g2 = lk_grid(W, H); g2.z = 2;
         hipLaunchKernelGGL(lk_u8_to_f32_pair_kernel, g2, dim3(256), 0, s, d_prev, d_cur, W, H, stride, Ip, Jp, fb_count,
@@ -1027,7 +1187,7 @@ int lk_flow_device(ofps_hip_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_cu
         unsigned nb = 0;
         for (int l = 0; l < levels; ++l) {
             P.w[l] = ws[l]; P.h[l] = hs[l]; P.off[l] = (unsigned)off[l]; P.start[l] = nb;
-            if (l == levels - 1) nb += lk_grid_xcd(ws[l], hs[l], 64, 4).x;           // the finer levels: the pyramid kernels wrote them
+            if (l == levels - 1 && !(tiled && l == 0)) nb += lk_grid_xcd(ws[l], hs[l], 64, 4).x;   // the finer levels: the pyramid kernels wrote them (level 0 of the tiled path: made in the level kernel)
         }
         P.start[levels] = nb;
         if (nb) hipLaunchKernelGGL(lk_grad_all_kernel, dim3(nb), dim3(256), 0, s, Ip, P, gxp, gyp);
@@ -1056,10 +1216,18 @@ int lk_flow_device(ofps_hip_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_cu
             // is read back by the very thread that later overwrites it with the result
             float2* park = other;
 #define OFPS_LK_LEVEL(R)                                                                                                     \
-    hipLaunchKernelGGL(lk_level_lds_kernel<R>, lk_grid_xcd(w, h, kTX, kTY), dim3(256), 0, s, Ip + off[l], Jp + off[l], gx, gy, w, h, iters, io, cnt,         \
-                       tiles, park, last ? prof : nullptr, force_fall);                                                     \
-    hipLaunchKernelGGL(lk_level_general_kernel<R>, gg, dim3(256), 0, s, Ip + off[l], Jp + off[l], gx, gy, w, h, iters, io, cnt,    \
-                       tiles, park)
+    if (last) {            /* level 0: straight from the u8 frames */                                                       \
+        hipLaunchKernelGGL((lk_level_lds_kernel<R, true>), lk_grid_xcd(w, h, kTX, kTY), dim3(256), 0, s, (const void*)d_prev, (const void*)d_cur,        \
+                           (const float*)nullptr, (const float*)nullptr, stride, w, h, iters, io, cnt, tiles, park, prof, force_fall);                 \
+        hipLaunchKernelGGL((lk_level_general_kernel<R, true>), gg, dim3(256), 0, s, (const void*)d_prev, (const void*)d_cur, (const float*)nullptr,       \
+                           (const float*)nullptr, stride, w, h, iters, io, cnt, tiles, park);                                                         \
+    } else {                                                                                                                \
+        hipLaunchKernelGGL((lk_level_lds_kernel<R, false>), lk_grid_xcd(w, h, kTX, kTY), dim3(256), 0, s, (const void*)(Ip + off[l]),                     \
+                           (const void*)(Jp + off[l]), (const float*)gx, (const float*)gy, w, w, h, iters, io, cnt, tiles, park,                       \
+                           (unsigned long long*)nullptr, force_fall);                                                                                 \
+        hipLaunchKernelGGL((lk_level_general_kernel<R, false>), gg, dim3(256), 0, s, (const void*)(Ip + off[l]), (const void*)(Jp + off[l]),              \
+                           (const float*)gx, (const float*)gy, w, w, h, iters, io, cnt, tiles, park);                                                 \
+    }
             switch (radius) {
                 case 2: OFPS_LK_LEVEL(2); break;
                 case 4: OFPS_LK_LEVEL(4); break;
