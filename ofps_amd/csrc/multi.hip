@@ -184,7 +184,10 @@ int ofps_hip_multi_init(const int* devices, int n, ofps_hip_multi** out) {
         m->w.push_back(w);
     }
     // peer access towards the first worker's device (the key-frame fan-out); failure is not fatal: hipMemcpyPeerAsync
-    // stages through the host when there is no direct path
+    // stages through the host when there is no direct path.  (The calling thread's current device is put back afterwards:
+    // a library call must not leave it changed.)
+    int caller_device = -1;
+    (void)hipGetDevice(&caller_device);
     for (size_t k = 1; k < m->w.size(); ++k) {
         if (m->w[k]->device == m->w[0]->device) continue;
         int can = 0;
@@ -194,6 +197,7 @@ int ofps_hip_multi_init(const int* devices, int n, ofps_hip_multi** out) {
             if (e != hipSuccess) (void)hipGetLastError();          // already enabled / unsupported: ignore
         }
     }
+    if (caller_device >= 0) (void)hipSetDevice(caller_device);
     for (auto* w : m->w) w->th = std::thread(worker_main, w);
     *out = m;
     return OFPS_HIP_OK;
