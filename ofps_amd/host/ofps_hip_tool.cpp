@@ -8,6 +8,7 @@
 //   stream-bench <w> <h> <frames> [sync|ahead|batch <n>] PCIe-inclusive per-frame time of the hip_sad process_frame shape
 //   track   <decoder> <arg> [aspect fov_y] [lsq|ransac] tracking loop, ofps-suite/src/app/tracking/worker.rs:305-412
 //   mvec-copy <in.mvec> <out.mvec>                      CPU-only .mvec round trip (reader + writer)
+//   multi-extract <raw.y> <w> <h> <out.mvec> [dev ...]  the whole clip over several GPUs (ofps_hip_multi_*): same bytes as `extract hip_sad`
 // decoder = hip_sad / hip_lk ("<input>?w=..&h=..&fps=..") or mvec ("<input>"); <input> is a file path, "tcp://host:port"
 // (connect) or "tcp://@:port" (listen, accept one connection) as in ofps/src/utils.rs:92-118.
 #include <chrono>
@@ -15,6 +16,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <iterator>
 #include <iostream>
 #include <sstream>
 
@@ -58,6 +60,25 @@ int main(int argc, char** argv) {
                 ++frames; total += mv.size();
             }
             std::printf("{\"frames\": %zu, \"vectors\": %zu}\n", frames, total);
+            return 0;
+        }
+        if (cmd == "multi-extract" && argc >= 6) {
+            // the whole clip at once over several GPUs (or several workers on one): same .mvec as `extract hip_sad`
+            const size_t W = std::strtoull(argv[3], nullptr, 10), H = std::strtoull(argv[4], nullptr, 10);
+            std::ifstream in(argv[2], std::ios::binary);
+            if (!in) throw Error(std::string("cannot open ") + argv[2]);
+            std::vector<uint8_t> clip((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
+            const size_t n_frames = clip.size() / (W * H);
+            std::vector<int> devices;
+            for (int a = 6; a < argc; ++a) devices.push_back(std::atoi(argv[a]));
+            if (devices.empty()) devices.push_back(0);
+            MultiDeviceSad md(devices);
+            const auto pairs = md.search(clip.data(), n_frames, W, H, 16, 16);
+            std::ofstream out(argv[5], std::ios::binary);
+            if (n_frames) write_mvec_frame(out, MotionVectors{});             // first frame of a stream: no vectors
+            size_t total = 0;
+            for (const auto& mv : pairs) { write_mvec_frame(out, mv); total += mv.size(); }
+            std::printf("{\"frames\": %zu, \"vectors\": %zu, \"workers\": %d}\n", n_frames, total, md.workers());
             return 0;
         }
         if (cmd == "detect" && argc >= 4 && std::string(argv[2]) == "--config") {

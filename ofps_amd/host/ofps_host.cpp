@@ -482,6 +482,29 @@ void transfer_props(const std::vector<std::pair<std::string, Property>>& saved, 
 // ------------------------------------------------------------------ creation by name
 static std::unique_ptr<std::istream> open_input(const std::string& path) { return open_file(path); }
 
+// ------------------------------------------------------------------ several GPUs behind one object
+MultiDeviceSad::MultiDeviceSad(const std::vector<int>& devices) {
+    const int rc = ofps_hip_multi_init(devices.data(), (int)devices.size(), &m_);
+    if (rc != OFPS_HIP_OK) throw Error(std::string("ofps_hip_multi_init: ") + ofps_hip_multi_last_error(nullptr));
+}
+MultiDeviceSad::~MultiDeviceSad() { ofps_hip_multi_destroy(m_); }
+int MultiDeviceSad::workers() const { return ofps_hip_multi_worker_count(m_); }
+std::vector<MotionVectors> MultiDeviceSad::search(const uint8_t* frames, size_t n_frames, size_t w, size_t h, int block, int range, int ref_mode) {
+    std::vector<MotionVectors> out;
+    if (n_frames < 2) return out;
+    const size_t nblk = ofps_hip_sad_block_count((int)w, (int)h, block);
+    std::vector<float> ent((n_frames - 1) * nblk * 4);
+    const int rc = ofps_hip_multi_sad_flow(m_, frames, (int)n_frames, (int)w, (int)h, (int)w, w * h, ref_mode, block, range, ent.data());
+    if (rc != OFPS_HIP_OK) throw Error(std::string("ofps_hip_multi_sad_flow: ") + ofps_hip_multi_last_error(m_));
+    out.resize(n_frames - 1);
+    for (size_t k = 0; k + 1 < n_frames; ++k) {
+        out[k].reserve(nblk);
+        const float* e = ent.data() + k * nblk * 4;
+        for (size_t i = 0; i < nblk; ++i) out[k].push_back(MotionEntry{e[4 * i], e[4 * i + 1], e[4 * i + 2], e[4 * i + 3]});
+    }
+    return out;
+}
+
 std::unique_ptr<Decoder> create_decoder(const std::string& name, const std::string& arg) {
     if (name == "mvec") return std::make_unique<MvecFileDecoder>(open_input(arg));
     if (name == "hip_sad" || name == "hip_lk") {                      // "<path>?w=1920&h=1080&fps=60"

@@ -118,6 +118,23 @@ private:
     ofps_hip_ctx* ctx_ = nullptr;
 };
 
+// One process, several GPUs: ofps_hip_multi_* (include/ofps_hip.h).  A batch of frame pairs is split into contiguous ranges
+// over the devices and comes back in pair order -- the host-side counterpart of the reference's one-worker-per-plugin
+// threading (ofps-suite/src/app/tracking/worker.rs:251-260,347-352) for a machine with more than one GPU.
+class MultiDeviceSad {
+public:
+    explicit MultiDeviceSad(const std::vector<int>& devices);
+    ~MultiDeviceSad();
+    MultiDeviceSad(const MultiDeviceSad&) = delete;
+    MultiDeviceSad& operator=(const MultiDeviceSad&) = delete;
+    // frames: n_frames luma frames of w x h bytes, back to back; ref_mode 0: pairs (k, k+1), 1: pairs (0, k+1).
+    // -> one MotionVectors per pair, in pair order
+    std::vector<MotionVectors> search(const uint8_t* frames, size_t n_frames, size_t w, size_t h, int block, int range, int ref_mode = 0);
+    int workers() const;
+private:
+    ofps_hip_multi* m_ = nullptr;
+};
+
 // ---- plugins on the HIP path
 // "hip_sad": raw 8-bit luma frames (W*H bytes, back to back) from a stream -> MotionEntry per block.
 class HipSadDecoder : public Decoder {

@@ -345,3 +345,18 @@ def test_two_processes_contending_for_every_cu_never_see_a_nan(tmp_path):
         assert r["finite"] and r["worst"] <= 2e-6, r
         total_recoveries += r["recoveries"]
     print(f"[two-process contention] in-kernel recoveries: {total_recoveries}")
+
+
+@pytest.mark.gpu
+def test_multi_extract_writes_the_same_mvec_as_the_single_decoder(tmp_path):
+    """ofps_hip_multi_* behind the C++ host layer (MultiDeviceSad): three workers on the one GPU of the box split a clip's
+    pairs; the .mvec file equals the one `extract hip_sad` writes frame by frame, byte for byte."""
+    W, H, F = 320, 192, 7
+    fr = synth.luma_sequence(F, W, H, max_step=16, seed=33)
+    raw = tmp_path / "clip.y"
+    raw.write_bytes(fr.tobytes())
+    one = tmp_path / "one.mvec"; many = tmp_path / "many.mvec"
+    json.loads(_tool("extract", "hip_sad", f"{raw}?w={W}&h={H}&fps=30", one))
+    info = json.loads(_tool("multi-extract", raw, W, H, many, 0, 0, 0))
+    assert info["workers"] == 3 and info["frames"] == F
+    assert one.read_bytes() == many.read_bytes()
