@@ -449,10 +449,34 @@ __device__ __forceinline__ void lk_stage3_u8_spill(float* scratch, const LkU8Reg
     }
 }
 template <int RADIUS>
-__device__ __forceinline__ void lk_stage3_u8_records(const float* scratch, float4 (*tile)[LkTile<RADIUS>::TW], int ox, int w, int h, int x0, int y0) {
+__device__ __forceinline__ void lk_stage3_u8_records(const float* scratch, float4 (*tile)[LkTile<RADIUS>::TW], int ox, bool interior, int w, int h,
+                                                     int x0, int y0) {
     using T = LkTile<RADIUS>;
     constexpr int WP = LkU8Window<RADIUS>::WP;
     const int oy = y0 - T::R - 1;
+    if (interior) {
+        // no coordinate leaves the image: a thread owns column c of rows r0, r0 + RPP, ...; its fifteen-odd scratch reads are
+        // independent of each other and issued together (the clamped form below waits on one element after the other)
+        constexpr int RPP = 256 / T::TW, PASSES = (T::TH + RPP - 1) / RPP;
+        const int c = threadIdx.x % T::TW, r0 = threadIdx.x / T::TW;
+        if (r0 >= RPP) return;
+        const int ix = x0 - T::R + c - ox;                            // scratch column of tile column c
+        float v[PASSES], xl[PASSES], xr[PASSES], yu[PASSES], yd[PASSES];
+#pragma unroll
+        for (int k = 0; k < PASSES; ++k) {
+            const int r = r0 + k * RPP;
+            if (r < T::TH) {
+                const float* p = scratch + (r + 1) * WP + ix;         // scratch row of tile row r is r + 1 (the rim)
+                v[k] = p[0]; xl[k] = p[-1]; xr[k] = p[1]; yu[k] = p[-WP]; yd[k] = p[WP];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < PASSES; ++k) {
+            const int r = r0 + k * RPP;
+            if (r < T::TH) tile[r][c] = make_float4(v[k], (xr[k] - xl[k]) * 0.5f, (yd[k] - yu[k]) * 0.5f, 0.0f);
+        }
+        return;
+    }
     for (int t = threadIdx.x; t < T::TW * T::TH; t += 256) {
         const int r = t / T::TW, c = t - r * T::TW;
         const int xc = lk_clampi(x0 - T::R + c, 0, w - 1), yc = lk_clampi(y0 - T::R + r, 0, h - 1);
@@ -473,7 +497,7 @@ __device__ __forceinline__ void lk_stage3_u8(const uint8_t* __restrict__ src, in
     lk_stage3_u8_issue<RADIUS>(src, stride, w, h, x0, y0, g);
     lk_stage3_u8_spill<RADIUS>(scratch, g);
     __syncthreads();
-    lk_stage3_u8_records<RADIUS>(scratch, tile, g.ox, w, h, x0, y0);
+    lk_stage3_u8_records<RADIUS>(scratch, tile, g.ox, g.vec, w, h, x0, y0);
 }
 
 // One window row of the level kernel at radius 4 (9 taps), spec revision 2, hand-scheduled.  hipcc's own code for this loop
@@ -808,7 +832,7 @@ __global__ __launch_bounds__(256, LkStepShared<RADIUS>::WAVES_PER_SIMD) void lk_
                 // loop into registers that are then spilled for the whole level)
                 int tid = (int)threadIdx.x;
                 asm volatile("" : "+v"(tid));
-                if constexpr (U8 && decltype(first)::value) lk_stage3_u8_records<RADIUS>(sh.u8win, sh.tile, u8g.ox, w, h, x0, y0);   // visible after the barrier that ends this block
+                if constexpr (U8 && decltype(first)::value) lk_stage3_u8_records<RADIUS>(sh.u8win, sh.tile, u8g.ox, u8g.vec, w, h, x0, y0);   // visible after the barrier that ends this block
                 // margins: up to kJMargin pixels on every side, as far as the capacity allows
                 const int mx = min(kJMargin, (S::LW - (xmax - xmin + 1)) / 2), my = min(kJMargin, (S::LH - (ymax - bymin + 1)) / 2);
                 const int rx0 = xmin - mx, rx1 = xmax + mx, ry0 = bymin - my, ry1 = ymax + my;
