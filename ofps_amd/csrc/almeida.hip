@@ -469,23 +469,47 @@ __device__ __forceinline__ float wave_sum(float x) {         // -> total, unifor
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63));
 }
 
+// three sums at once: the same operations per value as wave_sum (same bits), issued in lockstep so that the DPP wait
+// states of one chain are filled by the other two (hipcc emits three separate wave_sum calls back to back, 6 dependent
+// DPP adds each)
+__device__ __forceinline__ void row_sum16x3(float& a, float& b, float& c) {
+    a = dpp_add<0xB1>(a); b = dpp_add<0xB1>(b); c = dpp_add<0xB1>(c);
+    a = dpp_add<0x4E>(a); b = dpp_add<0x4E>(b); c = dpp_add<0x4E>(c);
+    a = dpp_add<0x141>(a); b = dpp_add<0x141>(b); c = dpp_add<0x141>(c);
+    a = dpp_add<0x140>(a); b = dpp_add<0x140>(b); c = dpp_add<0x140>(c);
+}
+__device__ __forceinline__ void wave_sum3(float& a, float& b, float& c) {
+    row_sum16x3(a, b, c);
+    a = dpp_add<0x142, 0xA>(a); b = dpp_add<0x142, 0xA>(b); c = dpp_add<0x142, 0xA>(c);
+    a = dpp_add<0x143, 0xC>(a); b = dpp_add<0x143, 0xC>(b); c = dpp_add<0x143, 0xC>(c);
+    a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a), 63));
+    b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b), 63));
+    c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c), 63));
+}
+
 // fixed-shape sum over a 1024-thread workgroup of the values v[K0..K1) of every thread; result valid in thread 0
-// (in lanes 0..15 of wave 0).  Each component is reduced independently, so reducing a sub-range gives the same bits as
+// (in lanes 0..15 of wave W).  Each component is reduced independently, so reducing a sub-range gives the same bits as
 // reducing all nine.
-template <int K0, int K1>
+template <int K0, int K1, int W = 0>
 __device__ __forceinline__ void block_sum(float v[9], float (*red)[9]) {
+    static_assert((K1 - K0) % 3 == 0, "values are reduced three at a time");
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
-    for (int k = K0; k < K1; ++k) {
-        const float t = wave_sum(v[k]);
-        if (lane == 0) red[wave][k] = t;
+    for (int k = K0; k < K1; k += 3) {
+        float a = v[k], b = v[k + 1], c = v[k + 2];
+        wave_sum3(a, b, c);
+        if (lane == 0) { red[wave][k] = a; red[wave][k + 1] = b; red[wave][k + 2] = c; }
     }
     __syncthreads();
-    // second level: the first 16 lanes of wave 0 hold one wave-partial each and finish with a row sum
-    if (threadIdx.x < 64) {
+    // second level: the first 16 lanes of wave W hold one wave-partial each and finish with a row sum
+    if (wave == W) {
         const int nw = blockDim.x >> 6;
 #pragma unroll
-        for (int k = K0; k < K1; ++k) v[k] = row_sum16((lane < nw) ? red[lane][k] : 0.0f);
+        for (int k = K0; k < K1; k += 3) {
+            float a = (lane < nw) ? red[lane][k] : 0.0f, b = (lane < nw) ? red[lane][k + 1] : 0.0f, c = (lane < nw) ? red[lane][k + 2] : 0.0f;
+            row_sum16x3(a, b, c);
+            v[k] = a; v[k + 1] = b; v[k + 2] = c;
+        }
     }
 }
 __device__ __forceinline__ void block_sum9(float v[9], float (*red)[9]) { block_sum<0, 9>(v, red); }
@@ -808,9 +832,10 @@ __device__ __forceinline__ bool gran_sweep_sum3_local(const gran_u4* g, int coun
         __builtin_amdgcn_s_sleep(1);
     }
     const bool in = lane < count;
-    ta = wave_sum(in ? __uint_as_float(x.x) : 0.0f);
-    tb = wave_sum(in ? __uint_as_float((x.y << 16) | (x.w & 0xFFFFu)) : 0.0f);
-    tc = wave_sum(in ? __uint_as_float(x.z) : 0.0f);
+    ta = in ? __uint_as_float(x.x) : 0.0f;
+    tb = in ? __uint_as_float((x.y << 16) | (x.w & 0xFFFFu)) : 0.0f;
+    tc = in ? __uint_as_float(x.z) : 0.0f;
+    wave_sum3(ta, tb, tc);
     return true;
 }
 // every workgroup's XCC_ID, published once per launch: all workgroups read all of them and reach the same verdict on
@@ -835,12 +860,12 @@ __device__ __forceinline__ bool xcc_sweep_check(const uint32_t* xccs, int nblk, 
 
 // wave-wide: component sums over the nblk (<= 256) granules of one triple once all carry `tag16`; fixed order
 // (lane-strided, then the DPP tree), identical in every workgroup.  false = timed out.
-__device__ __forceinline__ bool gran_sweep_sum3(const gran_u4* g, int nblk, uint32_t tag16, const FailFlag& ff, float& ta, float& tb, float& tc) {
+__device__ __forceinline__ bool gran_sweep_sum3(const gran_u4* g, int gs, int nblk, uint32_t tag16, const FailFlag& ff, float& ta, float& tb, float& tc) {
     const int lane = threadIdx.x & 63;
     const int last = nblk - 1;
     const gran_u4* p[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) p[j] = g + (lane + 64 * j <= last ? lane + 64 * j : last);   // out-of-range lanes re-read a valid one
+    for (int j = 0; j < 4; ++j) p[j] = g + (size_t)(lane + 64 * j <= last ? lane + 64 * j : last) * gs;   // out-of-range lanes re-read a valid one
     gran_u4 x[4];
     for (unsigned spins = 0;; ++spins) {
         if (nblk <= 64) gran_load3x1(p[0], x);
@@ -862,9 +887,10 @@ __device__ __forceinline__ bool gran_sweep_sum3(const gran_u4* g, int nblk, uint
         vb[j] = in ? __uint_as_float((x[j].y << 16) | (x[j].w & 0xFFFFu)) : 0.0f;
         vc[j] = in ? __uint_as_float(x[j].z) : 0.0f;
     }
-    ta = wave_sum(((va[0] + va[1]) + va[2]) + va[3]);
-    tb = wave_sum(((vb[0] + vb[1]) + vb[2]) + vb[3]);
-    tc = wave_sum(((vc[0] + vc[1]) + vc[2]) + vc[3]);
+    ta = ((va[0] + va[1]) + va[2]) + va[3];
+    tb = ((vb[0] + vb[1]) + vb[2]) + vb[3];
+    tc = ((vc[0] + vc[1]) + vc[2]) + vc[3];
+    wave_sum3(ta, tb, tc);
     return true;
 }
 
@@ -924,7 +950,20 @@ constexpr int kXcdSlots = 32;                 // workgroups per XCD at most (256
 constexpr int kHierMinBlocks = 32;            // below this the flat gather is as fast
 // granules per item: the flat exchange, the per-XCD partials and sums, the XCC_ID table (256 dwords = 64 granules), the
 // status word (one granule of its own)
-__host__ __device__ inline size_t cluster_gran_per_item(int nblk) { return 6 * (size_t)nblk + 2 * 8 * kXcdSlots + 2 * 8 + 64 + 1; }
+// Granules that cross XCDs (the workgroup partials of the flat gather, the XCD sums of the two-level one) sit `gs`
+// granules apart: 1 (16 bytes: one cache line holds eight) for at most 8 publishers, kGranLine (128 bytes: a line each)
+// above.  tools/ubench_allgather (profiles/ubench_allgather_r03.txt), publish -> all seen, cycles: 8 workgroups 1.9k
+// packed / 2.45k a line each; 32 workgroups 3.3k packed -- 32 publishers and 32 x 64 polling lanes meet in four lines of
+// one memory channel -- / 2.55k a line each.
+constexpr int kGranLine = 8;
+#ifndef OFPS_ALMEIDA_XG_STRIDE
+#define OFPS_ALMEIDA_XG_STRIDE 8
+#endif
+constexpr int kXgStride = OFPS_ALMEIDA_XG_STRIDE;   // the 8 XCD sums, polled by every workgroup of a two-level launch
+__host__ __device__ inline int cluster_gran_stride(int nblk) { return nblk <= 8 ? 1 : kGranLine; }
+__host__ __device__ inline size_t cluster_gran_per_item(int nblk) {     // a multiple of 8 granules: every item starts on a cache line
+    return 6 * (size_t)nblk * cluster_gran_stride(nblk) + 2 * 8 * kXgStride + 2 * 8 * kXcdSlots + 64 + 8;
+}
 
 #ifdef OFPS_HIP_TEST_HOOKS
 #define OFPS_TEST_FAULT(x) (x)
@@ -942,10 +981,12 @@ __global__ __launch_bounds__(BLOCK) void almeida_lsq_cluster_kernel(const float4
     // granule, which is what a workgroup that never became resident looks like to the others -- exercises the timeout
     // and the in-kernel recovery (almeida_solo_solve)
     const uint32_t fault = OFPS_TEST_FAULT(fault_arg);
-    // prof (diagnostics, normally null): thread 0 of every workgroup stamps s_memtime at the phase boundaries of each step
-#define OFPS_STAMP(slot) do { if (prof && threadIdx.x == 0) prof[(((size_t)blockIdx.y * gridDim.x + blockIdx.x) * kIters + it) * kProfSlots + (slot)] = __builtin_readcyclecounter(); } while (0)
+    // prof (diagnostics, normally null): the serial wave of every workgroup stamps s_memtime at the phase boundaries of each step
+#define OFPS_STAMP(slot) do { if (prof && threadIdx.x == kSerialWave * 64) prof[(((size_t)blockIdx.y * gridDim.x + blockIdx.x) * kIters + it) * kProfSlots + (slot)] = __builtin_readcyclecounter(); } while (0)
 #define OFPS_STAMP_W2(slot) do { if (prof && threadIdx.x == 128) prof[(((size_t)blockIdx.y * gridDim.x + blockIdx.x) * kIters + it) * kProfSlots + (slot)] = __builtin_readcyclecounter(); } while (0)
     constexpr bool P_LDS = EPT >= 8;
+    // the wave that carries a step's serial chain: finishes the block sum, publishes the granule, gathers, updates
+    constexpr int kSerialWave = 2;
     __shared__ float red[BLOCK / 64][9];
     __shared__ float apart_sh[6];                       // this workgroup's partial of A = J^T J, published in step 0
     __shared__ float a_sh[6];                           // A folded over all workgroups (rotation-independent)
@@ -959,12 +1000,13 @@ __global__ __launch_bounds__(BLOCK) void almeida_lsq_cluster_kernel(const float4
     const int nblk = gridDim.x, blk = blockIdx.x;
     const size_t item = blockIdx.y;
     gran_u4* g = gran + item * cluster_gran_per_item(nblk);            // [parity][triple: A0-2, A3-5, b][workgroup], then:
-    gran_u4* xl = g + 6 * (size_t)nblk;                                // [parity][XCD][rank in XCD]: per-XCD partials (same-XCD readers)
+    const int gs = cluster_gran_stride(nblk);
+    gran_u4* xl = g + 6 * (size_t)nblk * gs;                                // [parity][XCD][rank in XCD]: per-XCD partials (same-XCD readers)
     gran_u4* xg = xl + 2 * 8 * kXcdSlots;                              // [parity][XCD]: per-XCD sums (every reader)
-    uint32_t* xccs = reinterpret_cast<uint32_t*>(xg + 2 * 8);          // [workgroup]: tag << 16 | XCC_ID
+    uint32_t* xccs = reinterpret_cast<uint32_t*>(xg + 2 * 8 * kXgStride);          // [workgroup]: tag << 16 | XCC_ID
     // the item's fail word (a granule of its own) and this launch's value for it: unique per launch until the tags wrap
     // (the buffer is re-zeroed then)
-    const FailFlag ff = {reinterpret_cast<uint32_t*>(xg + 2 * 8 + 64), (tag_base + 1u) | 0x80000000u};
+    const FailFlag ff = {reinterpret_cast<uint32_t*>(xg + 2 * 8 * kXgStride + 64), (tag_base + 1u) | 0x80000000u};
     const int xcd = blk & 7, xrank = blk >> 3;                         // where round-robin dispatch puts this workgroup
     const int xmembers = (nblk - xcd + 7) / 8, nxcd = nblk < 8 ? nblk : 8;
     const float eps = almeida_eps();
@@ -1062,19 +1104,19 @@ __global__ __launch_bounds__(BLOCK) void almeida_lsq_cluster_kernel(const float4
             if constexpr (EPT >= 8) __builtin_amdgcn_sched_barrier(0);
         }
         OFPS_STAMP(1);
-        block_sum<6, 9>(s, red);
+        block_sum<6, 9, kSerialWave>(s, red);
         OFPS_STAMP(2);
         const uint32_t tag = (tag_base + (uint32_t)it + 1u) & 0xFFFFu;
-        gran_u4* gp = g + (size_t)(it & 1) * 3 * nblk;
+        gran_u4* gp = g + (size_t)(it & 1) * 3 * nblk * gs;
         const bool hier = it > 0 && hier_sh != 0;        // uniform: written before the barrier that ended step 0
-        if (threadIdx.x == 0) {
+        if (threadIdx.x == kSerialWave * 64) {
             if (it == 0) {
-                gran_store3(gp + blk, tag, apart_sh[0], apart_sh[1], apart_sh[2]);
-                gran_store3(gp + nblk + blk, tag, apart_sh[3], apart_sh[4], apart_sh[5]);
+                gran_store3(gp + (size_t)blk * gs, tag, apart_sh[0], apart_sh[1], apart_sh[2]);
+                gran_store3(gp + (size_t)(nblk + blk) * gs, tag, apart_sh[3], apart_sh[4], apart_sh[5]);
             }
             if (!(fault && it == 3 && (uint32_t)blk == fault - 1u)) {
                 if (hier) gran_store3_local(xl + ((size_t)(it & 1) * 8 + xcd) * kXcdSlots + xrank, tag, s[6], s[7], s[8]);
-                else gran_store3(gp + 2 * (size_t)nblk + blk, tag, s[6], s[7], s[8]);
+                else gran_store3(gp + (2 * (size_t)nblk + blk) * gs, tag, s[6], s[7], s[8]);
             }
         }
         // wave k gathers triple k (the A triples in step 0 only); wave 2, which gathers the right-hand side, goes straight
@@ -1090,13 +1132,13 @@ __global__ __launch_bounds__(BLOCK) void almeida_lsq_cluster_kernel(const float4
                 float la = 0.0f, lb = 0.0f, lc = 0.0f;
                 const bool lgot = gran_sweep_sum3_local(xl + ((size_t)(it & 1) * 8 + xcd) * kXcdSlots, xmembers, tag, ff, la, lb, lc);
                 if (lane == 0) {
-                    if (lgot) gran_store3(xg + (size_t)(it & 1) * 8 + xcd, tag, la, lb, lc);
+                    if (lgot) gran_store3(xg + ((size_t)(it & 1) * 8 + xcd) * kXgStride, tag, la, lb, lc);
                     else fail_sh = 1;
                 }
             }
-            if (wave == 2) got = gran_sweep_sum3(xg + (size_t)(it & 1) * 8, nxcd, tag, ff, ta, tb, tc);
+            if (wave == 2) got = gran_sweep_sum3(xg + (size_t)(it & 1) * 8 * kXgStride, kXgStride, nxcd, tag, ff, ta, tb, tc);
         } else if (wave < 3 && (wave == 2 || it == 0)) {
-            got = gran_sweep_sum3(gp + (size_t)wave * nblk, nblk, tag, ff, ta, tb, tc);
+            got = gran_sweep_sum3(gp + (size_t)wave * nblk * gs, gs, nblk, tag, ff, ta, tb, tc);
         }
         if (it == 0) {
             if (wave < 2 && lane == 0) {
@@ -1489,6 +1531,18 @@ static int lsq_cluster(ofps_hip_ctx* ctx, const float4* d_entries, size_t n, int
                 ph[0] += (double)(r[1] - r[0]); ph[1] += (double)(r[2] - r[1]); ph[2] += (double)(r[3] - r[2]);
                 ph[3] += (double)(r[5] - r[3]); ph[4] += (double)(r[6] - r[5]); ph[5] += (double)(r[4] - r[6]);
             }
+        if (nblk <= 64) {                                      // per workgroup: step start -> granule published, published -> all seen
+            fprintf(stderr, "[almeida cluster prof] per workgroup (to publish / gather):");
+            for (int b = 0; b < nblk; ++b) {
+                double tp = 0, tg = 0;
+                for (int it = 1; it < kIters; ++it) {
+                    const unsigned long long* r = h.data() + ((size_t)b * kIters + it) * kProfSlots;
+                    tp += (double)(r[3] - r[0]); tg += (double)(r[5] - r[3]);
+                }
+                fprintf(stderr, " %d:%.0f/%.0f", b, tp / (kIters - 1), tg / (kIters - 1));
+            }
+            fprintf(stderr, "\n");
+        }
         const double den = (double)nblk * kIters;
         fprintf(stderr, "[almeida cluster prof] n=%zu nblk=%d ept=%d block=%d  cycles/step: records %.0f  block_sum %.0f  publish %.0f  "
                         "gather (wave 2) %.0f  update (wave 2) %.0f  barrier %.0f   wg0 total %.0f\n",
