@@ -346,6 +346,7 @@ __device__ __forceinline__ Lu3 lu3_factor(const float a_in[9]) {
     for (int c = 0; c < 3; ++c) { f.r0[c] = r0[c]; f.r1[c] = r1[c]; f.r2[c] = r2[c]; }
     return f;
 }
+template <bool FAST = false>
 __device__ __forceinline__ bool lu3_apply(const Lu3& f, const float b_in[3], float x[3]) {
     float b0 = b_in[0], b1 = b_in[1], b2 = b_in[2];
     { float t; if (f.piv0 == 1) { t = b0; b0 = b1; b1 = t; } if (f.piv0 == 2) { t = b0; b0 = b2; b2 = t; } if (f.p2) { t = b1; b1 = b2; b2 = t; } }
@@ -357,14 +358,14 @@ __device__ __forceinline__ bool lu3_apply(const Lu3& f, const float b_in[3], flo
         b2 = (-c1) * f.r2[1] + b2;
     }
     if (f.r2[2] == 0.0f) return false;
-    const float x2 = b2 / f.r2[2];
+    const float x2 = fdiv<FAST>(b2, f.r2[2]);
     b0 = (-x2) * f.r0[2] + b0;
     b1 = (-x2) * f.r1[2] + b1;
     if (f.r1[1] == 0.0f) return false;
-    const float x1 = b1 / f.r1[1];
+    const float x1 = fdiv<FAST>(b1, f.r1[1]);
     b0 = (-x1) * f.r0[1] + b0;
     if (f.r0[0] == 0.0f) return false;
-    const float x0 = b0 / f.r0[0];
+    const float x0 = fdiv<FAST>(b0, f.r0[0]);
     x[0] = x0; x[1] = x1; x[2] = x2;
     return true;
 }
@@ -420,11 +421,12 @@ __device__ __forceinline__ void sincos_small(float x, float& sn, float& cs) {
 // The Gauss-Newton update run by a whole wave on a factorisation made once per solve (A is the same in every step): the
 // three half-angle sincos evaluations go to lanes 0..2 in parallel and come back through v_readlane; everything else is
 // wave-uniform.
+template <bool FAST = false>
 __device__ __forceinline__ Quat almeida_update_wave_lu(const Quat& rotation, const Lu3& f, float b0, float b1, float b2, float eps,
                                                        float alpha) {
     const float b[3] = {b0, b1, b2};
     float model[3];
-    if (!lu3_apply(f, b, model)) { model[0] = model[1] = model[2] = 0.0f; }       // :181-183
+    if (!lu3_apply<FAST>(f, b, model)) { model[0] = model[1] = model[2] = 0.0f; }       // :181-183
     model[0] = model[0] * eps * alpha;                                            // :185
     model[1] = model[1] * eps * alpha;
     model[2] = model[2] * eps * alpha;
@@ -435,10 +437,11 @@ __device__ __forceinline__ Quat almeida_update_wave_lu(const Quat& rotation, con
     const float s0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sn), 0)), c0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cs), 0));
     const float s1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sn), 1)), c1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cs), 1));
     const float s2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sn), 2)), c2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cs), 2));
-    const Quat roll = {c0, 0.0f, s0, 0.0f};
-    const Quat pitch = {c1, s1, 0.0f, 0.0f};
-    const Quat yaw = {c2, 0.0f, 0.0f, s2};
-    const Quat rot = quat_mul(quat_mul(pitch, roll), yaw);                        // :193
+    // :193, (pitch * roll) * yaw with pitch = (c1, s1, 0, 0), roll = (c0, 0, s0, 0), yaw = (c2, 0, 0, s2): the Hamilton products
+    // with the terms that are exact zeros left out -- x * 0 is an exact zero and adding it changes nothing, so these are
+    // quat_mul's values (16 operations instead of 56 on the step's serial chain; a lone wave issues one every ~5 cycles)
+    const Quat pr = {c1 * c0, s1 * c0, c1 * s0, s1 * s0};
+    const Quat rot = {pr.w * c2 - pr.k * s2, pr.i * c2 + pr.j * s2, pr.j * c2 - pr.i * s2, pr.w * s2 + pr.k * c2};
     return quat_mul(rotation, rot);                                               // :195
 }
 
@@ -860,38 +863,44 @@ __device__ __forceinline__ bool xcc_sweep_check(const uint32_t* xccs, int nblk, 
 
 // wave-wide: component sums over the nblk (<= 256) granules of one triple once all carry `tag16`; fixed order
 // (lane-strided, then the DPP tree), identical in every workgroup.  false = timed out.
-__device__ __forceinline__ bool gran_sweep_sum3(const gran_u4* g, int gs, int nblk, uint32_t tag16, const FailFlag& ff, float& ta, float& tb, float& tc) {
+template <int J>
+__device__ __forceinline__ bool gran_sweep_sum3_j(const gran_u4* g, int gs, int nblk, uint32_t tag16, const FailFlag& ff, float& ta, float& tb, float& tc) {
     const int lane = threadIdx.x & 63;
     const int last = nblk - 1;
-    const gran_u4* p[4];
+    const gran_u4* p[J];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) p[j] = g + (size_t)(lane + 64 * j <= last ? lane + 64 * j : last) * gs;   // out-of-range lanes re-read a valid one
+    for (int j = 0; j < J; ++j) p[j] = g + (size_t)(lane + 64 * j <= last ? lane + 64 * j : last) * gs;   // out-of-range lanes re-read a valid one
     gran_u4 x[4];
     for (unsigned spins = 0;; ++spins) {
-        if (nblk <= 64) gran_load3x1(p[0], x);
-        else if (nblk <= 128) gran_load3x2(p[0], p[1], x);
+        if constexpr (J == 1) gran_load3x1(p[0], x);
+        else if constexpr (J == 2) gran_load3x2(p[0], p[1], x);
         else gran_load3x4(p[0], p[1], p[2], p[3], x);
         bool ok = true;
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < J; ++j)
             if (64 * j < nblk) ok = ok && (x[j].y >> 16) == tag16 && (x[j].w >> 16) == tag16;
         if (__all(ok)) break;
         if (spin_expired(spins, ff)) return false;
         __builtin_amdgcn_s_sleep(1);
     }
-    float va[4], vb[4], vc[4];
+    // lane-strided partial sums in the order ((x0 + x1) + x2) + x3; absent terms are exact zeros
+    ta = 0.0f; tb = 0.0f; tc = 0.0f;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < J; ++j) {
         const bool in = lane + 64 * j < nblk;
-        va[j] = in ? __uint_as_float(x[j].x) : 0.0f;
-        vb[j] = in ? __uint_as_float((x[j].y << 16) | (x[j].w & 0xFFFFu)) : 0.0f;
-        vc[j] = in ? __uint_as_float(x[j].z) : 0.0f;
+        const float va = in ? __uint_as_float(x[j].x) : 0.0f;
+        const float vb = in ? __uint_as_float((x[j].y << 16) | (x[j].w & 0xFFFFu)) : 0.0f;
+        const float vc = in ? __uint_as_float(x[j].z) : 0.0f;
+        if (j == 0) { ta = va; tb = vb; tc = vc; }
+        else { ta += va; tb += vb; tc += vc; }
     }
-    ta = ((va[0] + va[1]) + va[2]) + va[3];
-    tb = ((vb[0] + vb[1]) + vb[2]) + vb[3];
-    tc = ((vc[0] + vc[1]) + vc[2]) + vc[3];
     wave_sum3(ta, tb, tc);
     return true;
+}
+__device__ __forceinline__ bool gran_sweep_sum3(const gran_u4* g, int gs, int nblk, uint32_t tag16, const FailFlag& ff, float& ta, float& tb, float& tc) {
+    if (nblk <= 64) return gran_sweep_sum3_j<1>(g, gs, nblk, tag16, ff, ta, tb, tc);
+    if (nblk <= 128) return gran_sweep_sum3_j<2>(g, gs, nblk, tag16, ff, ta, tb, tc);
+    return gran_sweep_sum3_j<4>(g, gs, nblk, tag16, ff, ta, tb, tc);
 }
 
 // ---- what a cluster launch does when its workgroups were NOT all there (bounded spin expired): the reference's
@@ -947,7 +956,7 @@ __device__ __forceinline__ void almeida_solo_solve(const float4* __restrict__ en
 }
 
 constexpr int kXcdSlots = 32;                 // workgroups per XCD at most (256 / 8)
-constexpr int kHierMinBlocks = 32;            // below this the flat gather is as fast
+constexpr int kHierMinBlocks = 65;            // up to 64 workgroups (one granule per polling lane, a cache line each) the flat gather is faster: 0.083 vs 0.091 ms at 64
 // granules per item: the flat exchange, the per-XCD partials and sums, the XCC_ID table (256 dwords = 64 granules), the
 // status word (one granule of its own)
 // Granules that cross XCDs (the workgroup partials of the flat gather, the XCD sums of the two-level one) sit `gs`
@@ -1167,7 +1176,7 @@ __global__ __launch_bounds__(BLOCK) void almeida_lsq_cluster_kernel(const float4
                 } else {
                     lu = lu_sh;
                 }
-                const Quat q = almeida_update_wave_lu(rot_sh[(it + 1) & 1], lu, ta, tb, tc, eps, alpha);
+                const Quat q = almeida_update_wave_lu<FAST>(rot_sh[(it + 1) & 1], lu, ta, tb, tc, eps, alpha);
                 if constexpr (FAST) {                   // fold camera and new rotation once, here, for every wave's next step
                     const DeltaAffine A = delta_affine(dk, quat_to_mat3(q));
                     if (lane == 0) aff_sh[it & 1] = A;
@@ -1439,7 +1448,8 @@ static void launch_cluster(ofps_hip_ctx* ctx, hipStream_t s, int nblk, int items
 static int lsq_cluster(ofps_hip_ctx* ctx, const float4* d_entries, size_t n, int batch, const Camera& cam, float4* d_quat) {
     // records per thread: fewer = less arithmetic per step on the critical path, more = fewer workgroups to gather from
     // and -- for batches -- more items whose workgroups are co-resident in one launch.  Cost model fitted to
-    // tools/almeida_prof.py (ms per launch ~ 0.11 + 0.004 * ept + 0.00001 * workgroups per item -- with the two-level gather
+    // tools/almeida_prof.py (ms per launch ~ 0.11 + 0.004 * ept + 0.00001 * workgroups per item, + 0.006 when the gather has
+    // two levels (more than 64 workgroups): 129,600 vectors 64 x 2 flat 0.090 ms, 127 x 1 two-level 0.096 -- with the two-level gather
     // a workgroup more costs next to nothing, a record more per thread is arithmetic on the critical path); the count that
     // minimises launches x cost wins (lone problems: the smallest that fits; 64 x 129,600 vectors: 8 -> 4 launches).
     // The exact-arithmetic variant (fields of <= 65,536 vectors) stops at 4 records per thread: with 8, the hoisted
@@ -1455,17 +1465,25 @@ static int lsq_cluster(ofps_hip_ctx* ctx, const float4* d_entries, size_t n, int
             const size_t nb = (n + (size_t)e * 1024 - 1) / ((size_t)e * 1024);
             if (nb < 1 || nb > 256 || nb > (size_t)ctx->num_cus) continue;
             const int per = ctx->num_cus / (int)nb;
-            const double cost = (double)((batch + per - 1) / per) * (0.11 + 0.004 * e + 0.00001 * (double)nb);
+            const double cost = (double)((batch + per - 1) / per) * (0.11 + 0.004 * e + 0.00001 * (double)nb + (nb >= (size_t)kHierMinBlocks ? 0.006 : 0.0));
             if (cost < best) { best = cost; ept = e; }
         }
     }
-    // (measured and rejected: 256-thread workgroups for block-vector sized problems -- the block reduction drops from 2.4k
-    // to 1.3k cycles per step but the gather waits that much longer: a step ends one cross-XCD exchange after the LAST
-    // workgroup published, 0.104 vs 0.105 ms at 8,040 vectors; OFPS_HIP_ALMEIDA_BLOCK=256 keeps the variant for A/B runs)
+    // Block-vector sized fields (exact arithmetic, <= 65,536 vectors) whose items all fit one launch: 256-thread workgroups,
+    // at most 64 of them per item (one granule per polling lane).  A step's serial chain runs on one wave per workgroup;
+    // with one wave per SIMD the records + block sum in front of it take 1.3k cycles instead of 2.5k, and since the
+    // granules sit a cache line apart (cluster_gran_stride) 16-64 publishers cost the exchange 0.6k more than 8, not
+    // 1.4k (round 2 had measured this variant at 0.104 vs 0.105 ms and rejected it: its granules were packed).  Records per
+    // thread: the fewest that keep an item within 64 workgroups (8,040 vectors: 32 x 1: 0.076 ms, 16 x 2: 0.080, 8 x 4: 0.083).
     int block = 1024;
-    if (ctx->opt.almeida_ept) ept = ctx->opt.almeida_ept < ept_max ? ctx->opt.almeida_ept : ept_max;   // A/B (OFPS_HIP_ALMEIDA_EPT)
+    const int e256 = n <= 16384 ? 1 : (n <= 32768 ? 2 : 4);
+    if (!dense_by_size) {
+        const size_t nb256 = (n + (size_t)e256 * 256 - 1) / ((size_t)e256 * 256);
+        if (nb256 <= 64 && nb256 * (size_t)batch <= (size_t)ctx->num_cus) block = 256;
+    }
     if (ctx->opt.almeida_block) block = ctx->opt.almeida_block;      // A/B (OFPS_HIP_ALMEIDA_BLOCK)
-    if (block == 256 && ept > 2) ept = 2;
+    if (block == 256) ept = e256;
+    if (ctx->opt.almeida_ept) ept = ctx->opt.almeida_ept < ept_max ? ctx->opt.almeida_ept : ept_max;   // A/B (OFPS_HIP_ALMEIDA_EPT)
     const size_t per_wg = (size_t)ept * block;
     const size_t nblk_sz = (n + per_wg - 1) / per_wg;
     if (nblk_sz < 1 || nblk_sz > 256 || nblk_sz > (size_t)ctx->num_cus) return 0;
@@ -1505,7 +1523,8 @@ static int lsq_cluster(ofps_hip_ctx* ctx, const float4* d_entries, size_t n, int
         if (!ev) OFPS_HIP_TRY(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
         else if (last != s) OFPS_HIP_TRY(ctx, hipStreamWaitEvent(s, ev, 0));      // (a barrier packet costs ~4 us in front of the kernel)
         last = s;
-        if (block == 256 && ept == 2) launch_cluster<false, 2, 256>(ctx, s, nblk, items, ent, n, cam, gran, tag_base, q, prof, recoveries);
+        if (block == 256 && ept >= 4) launch_cluster<false, 4, 256>(ctx, s, nblk, items, ent, n, cam, gran, tag_base, q, prof, recoveries);
+        else if (block == 256 && ept == 2) launch_cluster<false, 2, 256>(ctx, s, nblk, items, ent, n, cam, gran, tag_base, q, prof, recoveries);
         else if (block == 256) launch_cluster<false, 1, 256>(ctx, s, nblk, items, ent, n, cam, gran, tag_base, q, prof, recoveries);
         else if (dense && ept == 8) launch_cluster<true, 8>(ctx, s, nblk, items, ent, n, cam, gran, tag_base, q, prof, recoveries);
         else if (dense && ept == 4) launch_cluster<true, 4>(ctx, s, nblk, items, ent, n, cam, gran, tag_base, q, prof, recoveries);
@@ -1589,7 +1608,7 @@ static int lsq_device(ofps_hip_ctx* ctx, const float4* d_entries, size_t stride,
     // (N > 256 x 8192) or a forced A/B run takes one launch per step.
     bool wg_path = n_max <= 8192;
     bool cluster = d_n == nullptr && stride == n_max;
-    size_t cluster_min = batch == 1 ? 4096 : 8192;                       // lone problems above this size use the cluster
+    size_t cluster_min = batch == 1 ? 2048 : 8192;                       // lone problems above this size use the cluster (3,600 vectors: 0.074 vs 0.093 ms)
     if (ctx->opt.almeida_path == 1 && d_n == nullptr) { wg_path = false; cluster = false; }   // A/B experiments only (OFPS_HIP_ALMEIDA_PATH)
     if (ctx->opt.almeida_path == 2) cluster = false;
     if (ctx->opt.almeida_path == 3) cluster_min = 0;
