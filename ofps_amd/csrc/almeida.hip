@@ -446,7 +446,7 @@ __device__ __forceinline__ Quat almeida_update_wave_lu(const Quat& rotation, con
 }
 
 constexpr int kIters = 30;                      // ceil(15 / ALPHA), lib.rs:132
-constexpr int kProfSlots = 7;                   // OFPS_HIP_ALMEIDA_PROF: stamps per step (5 by thread 0, 2 by wave 2)
+constexpr int kProfSlots = 7;                   // OFPS_HIP_ALMEIDA_PROF: stamps per step, all by the wave that carries the serial chain
 __device__ __forceinline__ float almeida_eps() { return 0.001f * 3.14159265358979323846264338327950288f / 180.0f; }
 
 // Wave-wide f32 sum on the DPP data path (cross-lane operands of ordinary VALU adds: no LDS round trip -- the
@@ -832,7 +832,6 @@ __device__ __forceinline__ bool gran_sweep_sum3_local(const gran_u4* g, int coun
         const bool ok = (x.y >> 16) == tag16 && (x.w >> 16) == tag16;
         if (__all(ok)) break;
         if (spin_expired(spins, ff)) return false;
-        __builtin_amdgcn_s_sleep(1);
     }
     const bool in = lane < count;
     ta = in ? __uint_as_float(x.x) : 0.0f;
@@ -881,7 +880,7 @@ __device__ __forceinline__ bool gran_sweep_sum3_j(const gran_u4* g, int gs, int 
             if (64 * j < nblk) ok = ok && (x[j].y >> 16) == tag16 && (x[j].w >> 16) == tag16;
         if (__all(ok)) break;
         if (spin_expired(spins, ff)) return false;
-        __builtin_amdgcn_s_sleep(1);
+        if (gridDim.x > 64) __builtin_amdgcn_s_sleep(1);        // hundreds of pollers on the same lines: leave the channel some air (measured)
     }
     // lane-strided partial sums in the order ((x0 + x1) + x2) + x3; absent terms are exact zeros
     ta = 0.0f; tb = 0.0f; tc = 0.0f;
@@ -965,6 +964,9 @@ constexpr int kHierMinBlocks = 65;            // up to 64 workgroups (one granul
 // packed / 2.45k a line each; 32 workgroups 3.3k packed -- 32 publishers and 32 x 64 polling lanes meet in four lines of
 // one memory channel -- / 2.55k a line each.
 constexpr int kGranLine = 8;
+#ifndef OFPS_ALMEIDA_REC_GROUP
+#define OFPS_ALMEIDA_REC_GROUP 1
+#endif
 #ifndef OFPS_ALMEIDA_XG_STRIDE
 #define OFPS_ALMEIDA_XG_STRIDE 8
 #endif
@@ -1068,6 +1070,10 @@ __global__ __launch_bounds__(BLOCK) void almeida_lsq_cluster_kernel(const float4
         s[5] += py[t].x * py[t].x + py[t].y * py[t].y;
         if constexpr (EPT >= 8) __builtin_amdgcn_sched_barrier(0);  // one record at a time: see the step loop
     }
+    if constexpr (FAST) {
+#pragma unroll
+        for (int t = 0; t < EPT; ++t) { e[t].z += e[t].x - 0.5f; e[t].w += e[t].y - 0.5f; }    // see the step loop
+    }
     // the six A partials leave the registers before the step loop (they would stay live through all 30 steps otherwise)
     block_sum<0, 6>(s, red);
     if (threadIdx.x == 0) {
@@ -1088,14 +1094,20 @@ __global__ __launch_bounds__(BLOCK) void almeida_lsq_cluster_kernel(const float4
         s[6] = 0.0f; s[7] = 0.0f; s[8] = 0.0f;
 #pragma unroll
         for (int t = 0; t < EPT; ++t) {
-            float2 d;
+            float rx, ry;                                          // motion - delta
             if constexpr (FAST) {
-                d = cam_delta_affine(aff, e[t].x, e[t].y);
+                // delta = (X / D + 0.5) - p: the record keeps motion + p - 0.5 (folded once, below the prologue), so the
+                // residual is one fused operation per component after the quotient
+                const float X = __builtin_fmaf(aff.xa, e[t].x, __builtin_fmaf(aff.xb, e[t].y, aff.xc));
+                const float Y = __builtin_fmaf(aff.ya, e[t].x, __builtin_fmaf(aff.yb, e[t].y, aff.yc));
+                const float D = __builtin_fmaf(aff.da, e[t].x, __builtin_fmaf(aff.db, e[t].y, aff.dc));
+                const float ninv = -__builtin_amdgcn_rcpf(D);
+                rx = __builtin_fmaf(X, ninv, e[t].z); ry = __builtin_fmaf(Y, ninv, e[t].w);
             } else {
                 const Unproj un = Unproj{uwx[t], uwy, uwz[t]};
-                d = cam_delta_w<false>(cam, e[t].x, e[t].y, un, rotm);
+                const float2 d = cam_delta_w<false>(cam, e[t].x, e[t].y, un, rotm);
+                rx = e[t].z - d.x; ry = e[t].w - d.y;
             }
-            const float rx = e[t].z - d.x, ry = e[t].w - d.y;      // motion - delta
             float2 r, p;
             if constexpr (P_LDS) { const float4 v = plds[t * BLOCK + threadIdx.x]; r = make_float2(v.x, v.y); p = make_float2(v.z, v.w); }
             else { r = pr[t]; p = pp[t]; }
@@ -1110,7 +1122,7 @@ __global__ __launch_bounds__(BLOCK) void almeida_lsq_cluster_kernel(const float4
             }
             // 8 records x ~15 temporaries interleaved do not fit beside the 64 resident registers: keep the scheduler
             // from overlapping more than two records (4 waves per SIMD hide the latency instead)
-            if constexpr (EPT >= 8) __builtin_amdgcn_sched_barrier(0);
+            if constexpr (EPT >= 8) { if ((t & (OFPS_ALMEIDA_REC_GROUP - 1)) == OFPS_ALMEIDA_REC_GROUP - 1) __builtin_amdgcn_sched_barrier(0); }
         }
         OFPS_STAMP(1);
         block_sum<6, 9, kSerialWave>(s, red);
@@ -1541,8 +1553,8 @@ static int lsq_cluster(ofps_hip_ctx* ctx, const float4* d_entries, size_t n, int
         std::vector<unsigned long long> h(cnt);
         OFPS_HIP_TRY(ctx, hipMemcpyAsync(h.data(), prof, cnt * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
         OFPS_HIP_TRY(ctx, hipStreamSynchronize(s));
-        // thread 0: 0 step start, 1 records done, 2 block sum done, 3 granule published (+ A gathered in step 0), 4 step end;
-        // wave 2: 5 right-hand side gathered, 6 rotation updated
+        // 0 step start, 1 records done, 2 block sum done, 3/5 granule published and every workgroup's gathered, 6 rotation
+        // updated, 4 step end (after the barrier)
         double ph[6] = {0, 0, 0, 0, 0, 0};
         for (int b = 0; b < nblk; ++b)
             for (int it = 0; it < kIters; ++it) {
@@ -1563,9 +1575,9 @@ static int lsq_cluster(ofps_hip_ctx* ctx, const float4* d_entries, size_t n, int
             fprintf(stderr, "\n");
         }
         const double den = (double)nblk * kIters;
-        fprintf(stderr, "[almeida cluster prof] n=%zu nblk=%d ept=%d block=%d  cycles/step: records %.0f  block_sum %.0f  publish %.0f  "
-                        "gather (wave 2) %.0f  update (wave 2) %.0f  barrier %.0f   wg0 total %.0f\n",
-                n, nblk, ept, block, ph[0] / den, ph[1] / den, ph[2] / den, ph[3] / den, ph[4] / den, ph[5] / den,
+        fprintf(stderr, "[almeida cluster prof] n=%zu nblk=%d ept=%d block=%d  cycles/step on the serial wave: records %.0f  block sum %.0f  "
+                        "publish + gather %.0f  update %.0f  barrier %.0f   wg0 total %.0f\n",
+                n, nblk, ept, block, ph[0] / den, ph[1] / den, (ph[2] + ph[3]) / den, ph[4] / den, ph[5] / den,
                 (double)(h[(size_t)(kIters - 1) * kProfSlots + 4] - h[0]));
     }
     return 1;
