@@ -24,6 +24,8 @@ python tools/lk_decode_time.py > $O/lk_decode_time.txt 2>&1
 python tools/measure_misc.py > $O/misc.json 2>/dev/null
 ./tools/ubench_lds > $O/ubench_lds.txt 2>&1
 ./tools/ubench_valu > $O/ubench_valu.txt 2>&1
+timeout 120 ./tools/ubench_allgather > $O/ubench_allgather.txt 2>&1
+python tools/almeida_block_ab.py > $O/almeida_block_ab.txt 2>/dev/null
 for m in sync ahead; do ./ofps_amd/host/ofps_hip_tool stream-bench 1920 1080 1000 $m; done > $O/stream_bench_native.txt 2>&1
 for b in 4 8 16 32; do ./ofps_amd/host/ofps_hip_tool stream-bench 1920 1080 1024 batch $b; done >> $O/stream_bench_native.txt 2>&1
 python - <<PY 2>&1 | grep "lk prof" | tail -1 > $O/lk_phase_table.txt

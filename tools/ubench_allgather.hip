@@ -145,8 +145,8 @@ int main() {
     CHECK(hipMalloc(&slots, bytes)); CHECK(hipMemset(slots, 0, bytes));
     CHECK(hipMalloc(&d_out, 3 * 256 * sizeof(unsigned long long)));
     unsigned base = 16;
-    for (int nwg : {8, 32})
-        for (int stride : {1, 8}) {
+    for (int nwg : {2, 8, 32, 64})
+        for (int stride : {1, 8, 16, 256}) {
             const int work = 8;
             run<0>("load/wait/check/sleep", slots, d_out, nwg, work, stride, 1, base);
             run<1>("load/wait/check", slots, d_out, nwg, work, stride, 1, base);
