@@ -278,7 +278,13 @@ struct StripCfg {
     // small ranges: (d2 << 6 | dy index) fits the low 16 bits of the lane key, so the key alone identifies the
     // candidate and the scan needs no separate index tracking
     static constexpr bool COMPACT_KEY = ((2 * R * R) << 6) + NCAND < 65536 && NCAND <= 64;
-    static constexpr int KSHIFT = COMPACT_KEY ? 6 : 0;
+    // wider ranges (+-24 .. +-32): d2 << 3 | code still fits the low 16 bits, where the 3-bit code orders the (at most 8)
+    // candidates of one lane that share a d2 -- inside a group of 4 consecutive dx the |dx| are distinct, so given d2 a
+    // candidate is (which of the 4 dx, sign of dy): code = rank of |dx| for dy <= 0 (more negative dy = smaller |dx|
+    // first), 7 - rank for dy > 0 (smaller dy = larger |dx| first).  The key alone is then the spec's (SAD, d2, dy, dx)
+    // order within the lane and identifies the candidate: a plain min per dy, no index tracked beside it.
+    static constexpr bool RANK_KEY = !COMPACT_KEY && ((2 * R * R) << 3) + 7 < 65536;
+    static constexpr int KSHIFT = COMPACT_KEY ? 6 : (RANK_KEY ? 3 : 0);
 };
 
 // ds_read2_b32 reaches 255 dwords from its base register; left to itself hipcc spends one v_add per read on
@@ -329,7 +335,7 @@ __device__ __forceinline__ void strip_rows(unsigned long long (&acc)[StripCfg<B,
 // keeps it saturated.
 template <int B, int R, int I0>
 __device__ __forceinline__ void strip_pass(const uint32_t (&c)[B][B / 4], const uint32_t* lds, uint32_t tile_off,
-                                           const uint32_t (&colk)[4], int y0, int H, uint32_t& bkey, int& bi) {
+                                           const uint32_t (&colk)[4], const uint32_t (&colk_pos)[4], int y0, int H, uint32_t& bkey, int& bi) {
     using C = StripCfg<B, R>;
     unsigned long long acc[C::NP];
 #pragma unroll
@@ -344,11 +350,14 @@ __device__ __forceinline__ void strip_pass(const uint32_t (&c)[B][B / 4], const 
         const int dy = -R + i;
         if (i < C::NCAND && y0 + dy >= 0 && y0 + dy + B <= H) {          // uniform over the strip: scalar branch
             const uint32_t lo = (uint32_t)acc[ii], hi = (uint32_t)(acc[ii] >> 32);
-            const uint32_t k0 = (lo << 16) | colk[0];
-            const uint32_t k1 = (lo & 0xFFFF0000u) | colk[1];
-            const uint32_t k2 = (hi << 16) | colk[2];
-            const uint32_t k3 = (hi & 0xFFFF0000u) | colk[3];
-            if constexpr (C::COMPACT_KEY) {
+            const uint32_t (&ck)[4] = (C::RANK_KEY && dy > 0) ? colk_pos : colk;
+            const uint32_t k0 = (lo << 16) | ck[0];
+            const uint32_t k1 = (lo & 0xFFFF0000u) | ck[1];
+            const uint32_t k2 = (hi << 16) | ck[2];
+            const uint32_t k3 = (hi & 0xFFFF0000u) | ck[3];
+            if constexpr (C::RANK_KEY) {
+                bkey = min(bkey, __builtin_elementwise_add_sat(min(min(k0, k1), min(k2, k3)), (uint32_t)((dy * dy) << 3)));
+            } else if constexpr (C::COMPACT_KEY) {
                 const uint32_t m = __builtin_elementwise_add_sat(min(min(k0, k1), min(k2, k3)), (uint32_t)((dy * dy) << 6 | i));
                 bkey = min(bkey, m);            // ascending dy + the dy index inside the key: ties keep the smaller dy
             } else {
@@ -363,9 +372,9 @@ __device__ __forceinline__ void strip_pass(const uint32_t (&c)[B][B / 4], const 
 
 template <int B, int R, int... S>
 __device__ __forceinline__ void strip_passes(const uint32_t (&c)[B][B / 4], const uint32_t* lds, uint32_t tile_off,
-                                             const uint32_t (&colk)[4], int y0, int H, uint32_t& bkey, int& bi,
+                                             const uint32_t (&colk)[4], const uint32_t (&colk_pos)[4], int y0, int H, uint32_t& bkey, int& bi,
                                              std::integer_sequence<int, S...>) {
-    (strip_pass<B, R, S * StripCfg<B, R>::NP>(c, lds, tile_off, colk, y0, H, bkey, bi), ...);
+    (strip_pass<B, R, S * StripCfg<B, R>::NP>(c, lds, tile_off, colk, colk_pos, y0, H, bkey, bi), ...);
 }
 
 constexpr int kStripWaves = 4;      // independent waves (strips) per workgroup; no workgroup barrier
@@ -437,28 +446,40 @@ __device__ __forceinline__ void strip_body(const SadParams& p, int strips_per_ro
     // leaves the row index dynamic and sends the c[][] block to scratch memory.
     // colk[j] = dx_j^2, or all-ones for a column clipped by the frame.
     const int dx0 = -R + 4 * g;
-    uint32_t colk[4];
+    // (RANK_KEY: + the rank code of the column, colk for dy <= 0 and colk_pos for dy > 0; see StripCfg)
+    uint32_t colk[4], colk_pos[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int dx = dx0 + j;
         const int x = bx * B + dx;
         const bool v = blk_on && g < C::NGA && x >= 0 && x + B <= p.W;
-        colk[j] = v ? (uint32_t)(dx * dx) << C::KSHIFT : 0xFFFFFFFFu;
+        const uint32_t rank = dx0 < 0 ? 3u - j : (uint32_t)j;      // rank of |dx| inside the group (a group never straddles 0)
+        colk[j] = v ? ((uint32_t)(dx * dx) << C::KSHIFT) | (C::RANK_KEY ? rank : 0u) : 0xFFFFFFFFu;
+        colk_pos[j] = v ? ((uint32_t)(dx * dx) << C::KSHIFT) | (7u - rank) : 0xFFFFFFFFu;
     }
     uint32_t bkey = 0xFFFFFFFFu;
     int bi = 0;
-    strip_passes<B, R>(c, tiles, (uint32_t)(wave * C::TILE_DWORDS + b * C::BW + g), colk, y0, p.H, bkey, bi,
+    strip_passes<B, R>(c, tiles, (uint32_t)(wave * C::TILE_DWORDS + b * C::BW + g), colk, colk_pos, y0, p.H, bkey, bi,
                        std::make_integer_sequence<int, C::SPLIT>{});
     // decode (d2, dy) -> dx; build the cross-lane key (SAD, d2, dy, dx)
     unsigned long long best = ~0ull;
     if (bkey != 0xFFFFFFFFu) {
-        if constexpr (C::COMPACT_KEY) bi = (int)(bkey & 63u);
-        const int dy = -R + bi;
         const uint32_t d2 = (bkey & 0xFFFFu) >> C::KSHIFT;
-        const int dxsq = (int)d2 - dy * dy;
-        int dx = dx0;
+        int dx = dx0, dy;
+        if constexpr (C::RANK_KEY) {
+            const int code = (int)(bkey & 7u);
+            const bool neg = code < 4;
+            const int rank = neg ? code : 7 - code;
+            dx = dx0 + (dx0 < 0 ? 3 - rank : rank);
+            const int ady = (int)(__builtin_sqrtf((float)((int)d2 - dx * dx)) + 0.5f);     // exact: a perfect square below 2^12
+            dy = neg ? -ady : ady;
+        } else {
+            if constexpr (C::COMPACT_KEY) bi = (int)(bkey & 63u);
+            dy = -R + bi;
+            const int dxsq = (int)d2 - dy * dy;
 #pragma unroll
-        for (int j = 1; j < 4; ++j) dx = ((dx0 + j) * (dx0 + j) == dxsq) ? dx0 + j : dx;
+            for (int j = 1; j < 4; ++j) dx = ((dx0 + j) * (dx0 + j) == dxsq) ? dx0 + j : dx;
+        }
         // cross-lane key in the spec's layout: (SAD << 16 | d2) << 32 | (dy+R) << 8 | (dx+R)
         best = ((unsigned long long)((bkey & 0xFFFF0000u) | d2) << 32) | (unsigned long long)(uint32_t)(((dy + R) << 8) | (dx + R));
     }
