@@ -33,7 +33,9 @@ HBM_PEAK_GBS = 8000.0
 # 2.5 cycles per wave64 instruction, i.e. 25.6 lanes per clock: the nominal figure is the stricter peak)
 VALU_F32_PEAK_OPS = 256 * 4 * 32 * 2.4e9
 SAD_PEAK = 256 * 4 * 2.4e9 * 64.0                          # |a-b| per second, see bench.py
-LK_SPEC_OPS_PER_TAP = 11                                   # 81 taps x 11 f32 operations per pixel-step (r = 4)
+LK_SPEC_OPS_PER_TAP = 11                                   # 81 taps x 11 f32 operations per pixel-step (r = 4); spec revision 2
+                                                           # issues them as 7 instructions (a fused multiply-add counts as two operations,
+                                                           # so the figure stays comparable with round 2's)
 
 
 def _event_ms(ctx, fn, reps, warm=25):
@@ -94,8 +96,9 @@ def cfg3_chain_leg(device: int = 0, reps: int = 60) -> dict:
            "roofline_lk": {"bound": "valu_f32", "unit": "Tops/s", "spec_ops_per_pair": lk_ops,
                            "achieved": round(lk_ops / (lk_ms * 1e-3) / 1e12, 3), "peak": round(VALU_F32_PEAK_OPS / 1e12, 2),
                            "frac": round(lk_ops / (lk_ms * 1e-3) / VALU_F32_PEAK_OPS, 4),
-                           "note": "spec operations of all level steps / the time of the WHOLE lk_flow call (pyramid, gradient, "
-                                   "tensor and hand-over launches included)"},
+                           "note": "spec operations of all level steps (11 per tap, a fused multiply-add = 2; 7 instructions per tap in "
+                                   "spec revision 2) / the time of the WHOLE lk_flow call (pyramid, gradient and hand-over launches included); "
+                                   "peak = 32 lanes x 4 SIMDs x 256 CUs x 2.4 GHz instruction-lanes, i.e. an fma-only stream could reach 2x"},
            "roofline_almeida": {"bound": "hbm", "unit": "GB/s", "algorithmic_bytes": 16 * n,
                                 "achieved": round(16 * n / (alm_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
                                 "frac": round(16 * n / (alm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
