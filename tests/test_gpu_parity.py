@@ -49,6 +49,13 @@ SAD_CASES = [
     (256, 136, 8, 24, "random"),
     (320, 200, 8, 28, "seq"),
     (192, 96, 16, 24, "flat"),
+    # two-level cells of 4x4 pixels: thousands of exact SAD ties between candidates with EQUAL d2 and different (dx, dy) --
+    # the order inside a lane's key (rank code of the +-24..32 kernels, dy index of the narrower ones) decides the winner
+    (256, 136, 8, 32, "blocky"),
+    (320, 200, 8, 28, "blocky"),
+    (256, 160, 16, 24, "blocky"),
+    (256, 144, 16, 32, "blocky"),
+    (256, 144, 16, 16, "blocky"),
     (192, 112, 16, 10, "seq"),     # range not a multiple of 4: generic kernel
     (96, 96, 12, 5, "seq"),        # generic kernel (block/range outside the packed-SAD table)
     (64, 48, 32, 4, "seq"),        # generic kernel, SAD beyond 16 bits possible
@@ -60,6 +67,10 @@ def _frames(W, H, R, kind):
         return synth.luma_sequence(2, W, H, max_step=R, seed=synth.SEED0 + W + H)
     if kind == "random":
         return synth.random_luma(2, W, H, seed=7)
+    if kind == "blocky":
+        rng = np.random.default_rng(W * 131 + H)
+        cells = (rng.integers(0, 2, (2, (H + 3) // 4, (W + 3) // 4)) * 200 + 20).astype(np.uint8)
+        return np.ascontiguousarray(np.repeat(np.repeat(cells, 4, axis=1), 4, axis=2)[:, :H, :W])
     return np.full((2, H, W), 77, np.uint8)
 
 

@@ -273,6 +273,30 @@ def test_hip_almeida_cluster_two_level_gather_matches_the_flat_gather(hooks, sha
     np.testing.assert_allclose(q_fb, q_o, atol=2e-6, rtol=0)
 
 
+@pytest.mark.parametrize("shape,block,ept", [((120, 67), 256, 1), ((120, 67), 256, 2), ((120, 67), 256, 4), ((120, 67), 1024, 1), ((120, 67), 1024, 4),
+                                             ((60, 40), 256, 1), ((240, 135), 256, 2), ((240, 135), 256, 4), ((240, 135), 1024, 1),
+                                             ((320, 180), 256, 4), ((320, 180), 1024, 2)])
+def test_hip_almeida_cluster_every_workgroup_shape_inside_the_parity_bound(ctx, shape, block, ept):
+    """Round 3's cluster launches pick 256-thread workgroups (1, 2 or 4 records per thread, at most 64 per item, flat gather
+    with a cache line per granule) for block-vector sized fields and 1024-thread ones elsewhere; OFPS_HIP_ALMEIDA_BLOCK /
+    _EPT force either.  Every shape is a fixed summation order of the same terms: within 2e-6 of the oracle, and of the
+    shape the library picks by itself."""
+    e = synth.rotation_field(*shape)
+    q_o = oracle.solve_ypr_given(e, oracle.camera(16 / 9, 22.275))
+    rec0 = ctx.almeida_recoveries()
+    try:
+        ctx.set_option("OFPS_HIP_ALMEIDA_PATH", "cluster")
+        q_auto, _ = ctx.almeida(e, 16 / 9, 22.275, use_ransac=False)
+        ctx.set_option("OFPS_HIP_ALMEIDA_BLOCK", block); ctx.set_option("OFPS_HIP_ALMEIDA_EPT", ept)
+        q, _ = ctx.almeida(e, 16 / 9, 22.275, use_ransac=False)
+    finally:
+        for k in ("OFPS_HIP_ALMEIDA_PATH", "OFPS_HIP_ALMEIDA_BLOCK", "OFPS_HIP_ALMEIDA_EPT"): ctx.set_option(k, None)
+    assert np.isfinite(q).all()
+    np.testing.assert_allclose(q, q_o, atol=2e-6, rtol=0)
+    np.testing.assert_allclose(q, q_auto, atol=2e-6, rtol=0)
+    assert ctx.almeida_recoveries() == rec0                  # the workgroups were all there: nobody had to finish alone
+
+
 @pytest.mark.parametrize("fast", ["0", "1"])
 def test_hip_almeida_arithmetic_switch_stays_inside_the_parity_bound(ctx, fast):
     """OFPS_HIP_ALMEIDA_FAST forces the exact (IEEE division, unfused) or the folded arithmetic of the cluster solver at any
