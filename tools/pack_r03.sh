@@ -12,3 +12,4 @@ cp $S/*.json $S/*.txt $D/
 cp $S/ubench_lds.txt profiles/ubench_lds_r03.txt; cp $S/ubench_valu.txt profiles/ubench_valu_r03.txt
 cp $S/ubench_allgather.txt profiles/ubench_allgather_r03.txt
 rm -f $D/ubench_lds.txt $D/ubench_valu.txt $D/ubench_allgather.txt
+python tools/make_hbm_traffic.py
