@@ -3,6 +3,11 @@
 set -u
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r03p; mkdir -p $O
 cd $R
+# the PMC passes first: bench.py's roofline.traffic quotes profiles/hbm_traffic.json, which is made from them
+bash tools/prof_counters.sh r03p/sad_strip > /dev/null 2>&1
+bash tools/prof_counters.sh r03p/sad_strip_cfg4 --config cfg4 --steps 10 > /dev/null 2>&1
+for p in sad_strip sad_strip_cfg4; do python tools/pack_profile.py $O/$p profiles/r03/$p; done
+python tools/make_hbm_traffic.py > /dev/null && cp profiles/hbm_traffic.json $O/hbm_traffic.json
 python bench.py > $O/bench_n1.json 2> $O/bench_n1.err
 python bench.py --no-cpu-baseline --no-end-to-end --no-legs --config cfg4 > $O/bench_cfg4_strong_n1.json 2>/dev/null
 python bench.py --no-cpu-baseline --no-end-to-end --no-legs --config cfg4 --pairs 8 > $O/bench_cfg4_strong_8pairs_n1.json 2>/dev/null
@@ -10,8 +15,6 @@ python bench.py --no-cpu-baseline --no-end-to-end --no-legs --launcher threads >
 python bench.py --no-cpu-baseline --no-end-to-end --no-legs --launcher threads --config cfg4 > $O/bench_threads_cfg4_n1.json 2>/dev/null
 python bench.py --no-cpu-baseline --no-end-to-end --no-legs --pipeline > $O/bench_pipeline_n1.json 2>/dev/null
 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --no-cpu-baseline --no-end-to-end --no-legs 2>/dev/null | tail -n 1 > $O/bench_torchrun_world1.json
-bash tools/prof_counters.sh r03p/sad_strip > /dev/null 2>&1
-bash tools/prof_counters.sh r03p/sad_strip_cfg4 --config cfg4 --steps 10 > /dev/null 2>&1
 bash tools/cfg3_profile.sh r03p/cfg3_chain 20 > /dev/null 2>&1
 python tools/cfg3_time.py > $O/cfg3_chain/stage_times.json 2>/dev/null
 mkdir -p $O/cfg5_stream

@@ -13,3 +13,4 @@ cp $S/ubench_lds.txt profiles/ubench_lds_r03.txt; cp $S/ubench_valu.txt profiles
 cp $S/ubench_allgather.txt profiles/ubench_allgather_r03.txt
 rm -f $D/ubench_lds.txt $D/ubench_valu.txt $D/ubench_allgather.txt
 python tools/make_hbm_traffic.py
+cmp -s profiles/hbm_traffic.json $S/hbm_traffic.json || echo "note: hbm_traffic.json differs from the one the bench line of this collection read"
