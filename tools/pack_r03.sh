@@ -11,6 +11,6 @@ mkdir -p $D/cfg5_stream && cp $S/cfg5_stream/*.json $D/cfg5_stream/
 cp $S/*.json $S/*.txt $D/
 cp $S/ubench_lds.txt profiles/ubench_lds_r03.txt; cp $S/ubench_valu.txt profiles/ubench_valu_r03.txt
 cp $S/ubench_allgather.txt profiles/ubench_allgather_r03.txt
-rm -f $D/ubench_lds.txt $D/ubench_valu.txt $D/ubench_allgather.txt
+rm -f $D/ubench_lds.txt $D/ubench_valu.txt $D/ubench_allgather.txt $D/hbm_traffic.json
 python tools/make_hbm_traffic.py
 cmp -s profiles/hbm_traffic.json $S/hbm_traffic.json || echo "note: hbm_traffic.json differs from the one the bench line of this collection read"
