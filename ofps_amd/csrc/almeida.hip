@@ -490,8 +490,8 @@ __device__ __forceinline__ void wave_sum3(float& a, float& b, float& c) {
     c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c), 63));
 }
 
-// fixed-shape sum over a 1024-thread workgroup of the values v[K0..K1) of every thread; result valid in thread 0
-// (in lanes 0..15 of wave W).  Each component is reduced independently, so reducing a sub-range gives the same bits as
+// fixed-shape sum over a workgroup (up to 1024 threads) of the values v[K0..K1) of every thread; result valid in the first
+// thread of wave W (in its lanes 0..15).  Each component is reduced independently, so reducing a sub-range gives the same bits as
 // reducing all nine.
 template <int K0, int K1, int W = 0>
 __device__ __forceinline__ void block_sum(float v[9], float (*red)[9]) {
@@ -994,10 +994,11 @@ __global__ __launch_bounds__(BLOCK) void almeida_lsq_cluster_kernel(const float4
     const uint32_t fault = OFPS_TEST_FAULT(fault_arg);
     // prof (diagnostics, normally null): the serial wave of every workgroup stamps s_memtime at the phase boundaries of each step
 #define OFPS_STAMP(slot) do { if (prof && threadIdx.x == kSerialWave * 64) prof[(((size_t)blockIdx.y * gridDim.x + blockIdx.x) * kIters + it) * kProfSlots + (slot)] = __builtin_readcyclecounter(); } while (0)
-#define OFPS_STAMP_W2(slot) do { if (prof && threadIdx.x == 128) prof[(((size_t)blockIdx.y * gridDim.x + blockIdx.x) * kIters + it) * kProfSlots + (slot)] = __builtin_readcyclecounter(); } while (0)
+#define OFPS_STAMP_W2(slot) do { if (prof && threadIdx.x == kSerialWave * 64) prof[(((size_t)blockIdx.y * gridDim.x + blockIdx.x) * kIters + it) * kProfSlots + (slot)] = __builtin_readcyclecounter(); } while (0)
     constexpr bool P_LDS = EPT >= 8;
     // the wave that carries a step's serial chain: finishes the block sum, publishes the granule, gathers, updates
-    constexpr int kSerialWave = 2;
+    constexpr int kSerialWave = 2;                       // (waves 0 and 1 gather the A triples in step 0)
+    static_assert(kSerialWave == 2 && BLOCK >= 256, "the step-0 gather of A uses waves 0 and 1, the two-level gather wave 3");
     __shared__ float red[BLOCK / 64][9];
     __shared__ float apart_sh[6];                       // this workgroup's partial of A = J^T J, published in step 0
     __shared__ float a_sh[6];                           // A folded over all workgroups (rotation-independent)
@@ -1140,8 +1141,9 @@ __global__ __launch_bounds__(BLOCK) void almeida_lsq_cluster_kernel(const float4
                 else gran_store3(gp + (2 * (size_t)nblk + blk) * gs, tag, s[6], s[7], s[8]);
             }
         }
-        // wave k gathers triple k (the A triples in step 0 only); wave 2, which gathers the right-hand side, goes straight
-        // on to the LU + quaternion update -- no barrier and no LDS round trip between the gather and the update.
+        // wave k gathers triple k (the A triples in step 0 only); wave 2 -- the serial wave: it finished the block sum and
+        // published the granule above -- gathers the right-hand side and goes straight on to the LU + quaternion update: no
+        // barrier and no LDS round trip anywhere between a step's block sum and its new rotation.
         // Two-level form (steps >= 1 of launches with many workgroups, round-robin dispatch verified in step 0): wave 3 of
         // each XCD's first workgroup sums that XCD's partials -- plain stores found in the shared L2 by `sc1` loads -- and
         // publishes the XCD's sum write-through; wave 2 of EVERY workgroup then gathers the <= 8 XCD sums instead of up to
@@ -1157,8 +1159,8 @@ __global__ __launch_bounds__(BLOCK) void almeida_lsq_cluster_kernel(const float4
                     else fail_sh = 1;
                 }
             }
-            if (wave == 2) got = gran_sweep_sum3(xg + (size_t)(it & 1) * 8 * kXgStride, kXgStride, nxcd, tag, ff, ta, tb, tc);
-        } else if (wave < 3 && (wave == 2 || it == 0)) {
+            if (wave == kSerialWave) got = gran_sweep_sum3(xg + (size_t)(it & 1) * 8 * kXgStride, kXgStride, nxcd, tag, ff, ta, tb, tc);
+        } else if (wave < 3 && (wave == kSerialWave || it == 0)) {
             got = gran_sweep_sum3(gp + (size_t)wave * nblk * gs, gs, nblk, tag, ff, ta, tb, tc);
         }
         if (it == 0) {
@@ -1177,7 +1179,7 @@ __global__ __launch_bounds__(BLOCK) void almeida_lsq_cluster_kernel(const float4
             __syncthreads();
         }
         OFPS_STAMP(3);
-        if (wave == 2) {
+        if (wave == kSerialWave) {
             OFPS_STAMP_W2(5);
             if (got) {
                 Lu3 lu;
