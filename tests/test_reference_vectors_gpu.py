@@ -297,6 +297,34 @@ def test_hip_almeida_cluster_every_workgroup_shape_inside_the_parity_bound(ctx, 
     assert ctx.almeida_recoveries() == rec0                  # the workgroups were all there: nobody had to finish alone
 
 
+def test_hip_almeida_cluster_launches_of_changing_shapes_back_to_back_are_reproducible(ctx):
+    """The granule buffer is shared by all cluster launches of a context and never cleared between them: tags advance per
+    launch, layouts differ with the workgroup count (packed granules up to 8 workgroups, a cache line each above, XCD slabs
+    of the two-level gather).  2,300 launches of five shapes in rotation -- across the 16-bit tag wrap, where the buffer IS
+    cleared -- must each return the bits their shape returned the first time, and nobody may have had to finish alone."""
+    import torch
+    shapes = [(120, 67), (60, 40), (80, 45), (240, 135), (480, 270)]        # 32, 10, 15 workgroups flat; 64 flat; 127 two-level
+    fields = [torch.from_numpy(synth.rotation_field(w, h)).cuda() for (w, h) in shapes]
+    outs = [torch.empty((1, 4), dtype=torch.float32, device="cuda") for _ in shapes]
+    first = [None] * len(shapes)
+    rec0 = ctx.almeida_recoveries()
+    ctx.use_torch_stream()
+    for k in range(2300):
+        i = k % len(shapes)
+        n = shapes[i][0] * shapes[i][1]
+        ctx.almeida_dev(fields[i].data_ptr(), n, 1, 16 / 9, 22.275, False, 0, 0.05, 0, 0, outs[i].data_ptr())
+        if k < len(shapes) or k % 97 == 0 or k > 2290:
+            q = outs[i].cpu().numpy().copy()
+            assert np.isfinite(q).all()
+            if first[i] is None: first[i] = q
+            else: np.testing.assert_array_equal(q.view(np.uint32), first[i].view(np.uint32))
+    torch.cuda.synchronize()
+    assert ctx.almeida_recoveries() == rec0
+    cam = oracle.camera(16 / 9, 22.275)
+    for i, (w, h) in enumerate(shapes):
+        np.testing.assert_allclose(first[i].ravel(), oracle.solve_ypr_given(synth.rotation_field(w, h), cam), atol=2e-6, rtol=0)
+
+
 @pytest.mark.parametrize("fast", ["0", "1"])
 def test_hip_almeida_arithmetic_switch_stays_inside_the_parity_bound(ctx, fast):
     """OFPS_HIP_ALMEIDA_FAST forces the exact (IEEE division, unfused) or the folded arithmetic of the cluster solver at any
