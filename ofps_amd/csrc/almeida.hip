@@ -1130,7 +1130,9 @@ __global__ __launch_bounds__(BLOCK) void almeida_lsq_cluster_kernel(const float4
         OFPS_STAMP(2);
         const uint32_t tag = (tag_base + (uint32_t)it + 1u) & 0xFFFFu;
         gran_u4* gp = g + (size_t)(it & 1) * 3 * nblk * gs;
-        const bool hier = it > 0 && hier_sh != 0;        // uniform: written before the barrier that ended step 0
+        // (uniform: hier_sh was written before the barrier that ended step 0; launches without the two-level gather do not
+        // even read it -- an LDS round trip less on the serial wave's chain)
+        const bool hier = hier_mode != 0 && it > 0 && hier_sh != 0;
         if (threadIdx.x == kSerialWave * 64) {
             if (it == 0) {
                 gran_store3(gp + (size_t)blk * gs, tag, apart_sh[0], apart_sh[1], apart_sh[2]);
