@@ -198,6 +198,16 @@ int ofps_hip_push_frame_async(ofps_hip_ctx* ctx, const uint8_t* luma, int W, int
     int* d_res = reinterpret_cast<int*>(d_out);
     float4* d_quat = reinterpret_cast<float4*>(d_out + 16);
     float2* d_field = reinterpret_cast<float2*>(d_out + 4096);
+    // The 32 bytes the caller waits for (island result, quaternion) are written by the detector's and the estimator's last
+    // kernels STRAIGHT into the ticket's page-locked block -- it is device-addressable, each is one thread's store at the
+    // end of a kernel -- instead of into device scratch and from there by a copy launch behind the join: that launch and
+    // the gap in front of it were 14 us of a 170 us frame (rocprofv3 kernel trace, tools/trace_stream.sh).
+    void* mapped_out = nullptr;
+    const bool direct = device_can_write(t.pinned, &mapped_out);
+    if (direct) {
+        d_res = reinterpret_cast<int*>(static_cast<char*>(mapped_out) + offsetof(PipeOut, result));
+        d_quat = reinterpret_cast<float4*>(static_cast<char*>(mapped_out) + offsetof(PipeOut, quat));
+    }
     // detector and estimator read the same device-resident vectors and share no workspace: with both enabled the
     // detector's chain of small launches runs on an auxiliary stream beside the estimator (fork after the search, join
     // before the read-back) instead of in front of it
@@ -220,7 +230,7 @@ int ofps_hip_push_frame_async(ofps_hip_ctx* ctx, const uint8_t* luma, int W, int
         if (rc != OFPS_HIP_OK) return rc;
     }
     if (fork) OFPS_HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->pipe_join, 0));
-    if (prm->run_detector || prm->run_estimator) {
+    if ((prm->run_detector || prm->run_estimator) && !direct) {
         rc = pipe_read_back(ctx, t.pinned, d_out, sizeof(PipeOut), s);
         if (rc != OFPS_HIP_OK) return rc;
     }
