@@ -761,6 +761,7 @@ __global__ __launch_bounds__(256, LkStepShared<RADIUS>::WAVES_PER_SIMD) void lk_
     // staging registers, whose lives therefore end before the loop) and once inside it.  false = the tile fell.
     int x = 0, y = 0;
     bool all_consecutive = false;
+    const bool tile_in_x = x0 >= RADIUS && x0 + kTX - 1 + RADIUS <= w - 1;   // uniform: no window column of this tile is clamped
     auto front = [&](int it, auto first) -> bool {
             // the pixel coordinates pass through an empty asm so that the compiler does not hoist the clamped window
             // coordinates (2N integers + their float conversions) out of the step loop: that costs 40 VGPRs and two waves
@@ -775,7 +776,16 @@ __global__ __launch_bounds__(256, LkStepShared<RADIUS>::WAVES_PER_SIMD) void lk_
             // traffic, rocprofv3 WRITE_SIZE); nine floors are cheaper
             int xi_first = 0, xi_last = 0;
             bool consecutive = true;
-            {
+            if (tile_in_x) {
+                // No window column of this tile is clamped: the sums fq_k = (x + k - R) + u grow with k, and while they are
+                // >= 0 so does their rounding step -- a sum that rounds up to an integer is followed by sums that do too, so
+                // the floors advance by 1 or (across a binade) 2, never 0: the columns are consecutive exactly when the last
+                // floor is 2R above the first.  Two floor chains instead of N.
+                float dummy_a;
+                xi_first = lk_origin(x - RADIUS, f.x, w, dummy_a);
+                xi_last = lk_origin(x + RADIUS, f.x, w, dummy_a);
+                consecutive = xi_first >= 0 && xi_last - xi_first == 2 * RADIUS;
+            } else {
                 float dummy_a;
                 int prev = 0;
     #pragma unroll
@@ -887,9 +897,22 @@ __global__ __launch_bounds__(256, LkStepShared<RADIUS>::WAVES_PER_SIMD) void lk_
         {
             int xr = x;
             asm volatile("" : "+v"(xr));                                  // opaque: a second evaluation, not the first one kept alive
-            float frac;
+            if (tile_in_x && all_consecutive) {
+                // unclamped columns with floors 0 <= xi0, xi0 + 1, ... <= w (front()): no clamp is active, and for a sum
+                // fq >= 0 the fraction fq - floor(fq) is exact, which is what v_fract_f32 returns -- the oracle's values in
+                // 3 operations per column instead of 7
+                const float xf0 = (float)(xr - RADIUS);
 #pragma unroll
-            for (int k = 0; k < N; ++k) { const int o = lk_origin(lk_clampi(xr + k - RADIUS, 0, w - 1), f.x, w, frac); ax[k] = frac; if (k == 0) xi0 = o; }
+                for (int k = 0; k < N; ++k) {
+                    const float fq = (xf0 + (float)k) + f.x;                // (float)(x + k - R), exact, + u: the oracle's sum
+                    ax[k] = __builtin_amdgcn_fractf(fq);
+                    if (k == 0) xi0 = (int)__builtin_floorf(fq);
+                }
+            } else {
+                float frac;
+#pragma unroll
+                for (int k = 0; k < N; ++k) { const int o = lk_origin(lk_clampi(xr + k - RADIUS, 0, w - 1), f.x, w, frac); ax[k] = frac; if (k == 0) xi0 = o; }
+            }
         }
         if (it == 0) OFPS_LK_STAMP(3);
         if (active) {
