@@ -64,6 +64,30 @@ __device__ __forceinline__ int lk_wave_minmax(int x) {
     return __builtin_amdgcn_readlane(x, 63);
 }
 
+// The box of a workgroup's sample origins: two minima and two maxima at once, one DPP instruction per value and step (the
+// intrinsic form above is a v_mov_dpp + v_min per step, and hipcc runs the four trees one after the other with wait states
+// in between); the four chains interleave, so every DPP operand was written three instructions earlier.  Results are
+// wave-uniform (lane 63).
+__device__ __forceinline__ void lk_wave_box(int& mn0, int& mx0, int& mn1, int& mx1) {
+#define LK_BOX_STEP(CTRL)                                   \
+    "v_min_i32_dpp %0, %0, %0 " CTRL "\n\t"                  \
+    "v_max_i32_dpp %1, %1, %1 " CTRL "\n\t"                  \
+    "v_min_i32_dpp %2, %2, %2 " CTRL "\n\t"                  \
+    "v_max_i32_dpp %3, %3, %3 " CTRL "\n\t"
+    asm volatile(
+        "s_nop 1\n\t"
+        LK_BOX_STEP("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
+        LK_BOX_STEP("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
+        LK_BOX_STEP("row_half_mirror row_mask:0xf bank_mask:0xf")
+        LK_BOX_STEP("row_mirror row_mask:0xf bank_mask:0xf")
+        LK_BOX_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf")
+        LK_BOX_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf")
+        : "+v"(mn0), "+v"(mx0), "+v"(mn1), "+v"(mx1));
+#undef LK_BOX_STEP
+    mn0 = __builtin_amdgcn_readlane(mn0, 63); mx0 = __builtin_amdgcn_readlane(mx0, 63);
+    mn1 = __builtin_amdgcn_readlane(mn1, 63); mx1 = __builtin_amdgcn_readlane(mx1, 63);
+}
+
 // XCD-aware workgroup -> tile mapping for the tiled kernels: a launch is a 1-D grid padded to a multiple of 8 workgroups;
 // workgroup b runs on XCD b % 8 (round-robin dispatch), and each XCD takes a contiguous run of tiles in raster order, so
 // vertically adjacent tiles -- which share 2R of their 4 + 2R window rows -- meet in one L2 instead of eight.
@@ -814,8 +838,7 @@ __global__ __launch_bounds__(256, LkStepShared<RADIUS>::WAVES_PER_SIMD) void lk_
                 // window columns / rows are monotone in k / r, so the extremes are the first and the last
                 int bx0 = active ? xi_first : 0x7FFFFFFF, bx1 = active ? xi_last + 1 : -0x7FFFFFFF;
                 int by0 = active ? yt : 0x7FFFFFFF, by1 = active ? yb_ + 1 : -0x7FFFFFFF;
-                bx0 = lk_wave_minmax<false>(bx0); bx1 = lk_wave_minmax<true>(bx1);
-                by0 = lk_wave_minmax<false>(by0); by1 = lk_wave_minmax<true>(by1);
+                lk_wave_box(bx0, bx1, by0, by1);
                 // window columns that sample consecutive texels (x0[k+1] == x0[k] + 1: everywhere but at the left/right image
                 // border, where the clamped window columns repeat) share one row of N+1 texels; otherwise every column reads
                 // its own pair.  Decided per workgroup, through the same exchange as the box (no barrier of its own).
