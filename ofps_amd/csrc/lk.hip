@@ -785,15 +785,12 @@ __global__ __launch_bounds__(256, LkStepShared<RADIUS>::WAVES_PER_SIMD) void lk_
     // staging registers, whose lives therefore end before the loop) and once inside it.  false = the tile fell.
     int x = 0, y = 0;
     bool all_consecutive = false;
-#ifdef OFPS_LK_NO_FAST_ORIGINS                              // A/B: every tile takes the clamped, per-column / per-row origin chains
+#ifdef OFPS_LK_NO_FAST_ORIGINS                              // A/B: every tile takes the clamped, per-column origin chains
     constexpr bool kFastOrigins = false;
 #else
     constexpr bool kFastOrigins = true;
 #endif
     const bool tile_in_x = kFastOrigins && x0 >= RADIUS && x0 + kTX - 1 + RADIUS <= w - 1;   // uniform: no window column of this tile is clamped
-    const bool tile_in_y = kFastOrigins && y0 >= RADIUS && y0 + kTY - 1 + RADIUS <= h - 1;   // ... and no window row
-    bool rows_cons = false;                                  // wave-uniform: this wave's window rows sample consecutive rows (front())
-    int yt_keep = 0;                                         // origin of window row 0 (front())
     auto front = [&](int it, auto first) -> bool {
             // the pixel coordinates pass through an empty asm so that the compiler does not hoist the clamped window
             // coordinates (2N integers + their float conversions) out of the step loop: that costs 40 VGPRs and two waves
@@ -831,9 +828,6 @@ __global__ __launch_bounds__(256, LkStepShared<RADIUS>::WAVES_PER_SIMD) void lk_
             float dummy;
             const int yt = lk_origin(lk_clampi(y - RADIUS, 0, h - 1), f.y, h, dummy);
             const int yb_ = lk_origin(lk_clampi(y + RADIUS, 0, h - 1), f.y, h, dummy);
-            // (the rows of an unclamped window are consecutive under the same condition as its columns, see above)
-            rows_cons = tile_in_y && __all(!active || (yt >= 0 && yb_ - yt == 2 * RADIUS));
-            yt_keep = yt;
             {
                 // window columns / rows are monotone in k / r, so the extremes are the first and the last
                 int bx0 = active ? xi_first : 0x7FFFFFFF, bx1 = active ? xi_last + 1 : -0x7FFFFFFF;
@@ -966,29 +960,14 @@ __global__ __launch_bounds__(256, LkStepShared<RADIUS>::WAVES_PER_SIMD) void lk_
                     int prev_yi = -0x7FFFFFFF;
                     const uint32_t jl0 = (uint32_t)reinterpret_cast<uintptr_t>(&sh.jl[0][xi0 - xs]);
                     const uint32_t tl0 = (uint32_t)reinterpret_cast<uintptr_t>(&sh.tile[ly][lx]);
-                    // unclamped, consecutive window rows (every wave of an interior tile, as a rule): row r samples rows
-                    // yi0 + r and yi0 + r + 1, its fraction is v_fract of the oracle's sum (exact for a sum >= 0) -- 5 instead
-                    // of 14 operations per row in front of the hand-scheduled taps
-                    const int yi0 = yt_keep - ymin;
-                    float yfr = (float)(y - RADIUS);
                     auto row = [&](int r, auto parity, auto with_g) {
                         constexpr int P = decltype(parity)::value;
                         float ay;
-                        int yi;
-                        bool reuse;
-                        if (rows_cons) {                           // wave-uniform
-                            const float fq = yfr + f.y;            // (float)(y + r - R), exact, + v: the oracle's sum
-                            yfr += 1.0f;
-                            ay = __builtin_amdgcn_fractf(fq);
-                            yi = yi0 + r;
-                            reuse = r > 0;
-                        } else {
-                            yi = lk_origin(lk_clampi(y + r - RADIUS, 0, h - 1), f.y, h, ay) - ymin;
-                            // (the first row always makes its upper sample row: stated at compile time, so that the carried
-                            // registers are not live into the loop -- hipcc spilled their undefined contents around every step)
-                            reuse = r > 0 && __all(yi == prev_yi + 1);
-                            prev_yi = yi;
-                        }
+                        const int yi = lk_origin(lk_clampi(y + r - RADIUS, 0, h - 1), f.y, h, ay) - ymin;
+                        // (the first row always makes its upper sample row: stated at compile time, so that the carried
+                        // registers are not live into the loop -- hipcc spilled their undefined contents around every step)
+                        const bool reuse = r > 0 && __all(yi == prev_yi + 1);
+                        prev_yi = yi;
                         if (!reuse) {                              // the upper sample row is not the one carried over: make it
                             const float* ra = &sh.jl[yi][xi0 - xs];
                             float jb[N + 1];
