@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of whole lk.hip variants (tools/_lkv/*.hip) on the GPU box: level-kernel time (rocprofv3 kernel stats) and WRITE_SIZE
+# A/B of whole lk.hip variants on the GPU box (put the candidate files under tools/_lkv/ -- untracked -- before the gpurun call): level-kernel time (rocprofv3 kernel stats) and WRITE_SIZE
 # (scratch traffic shows up there: the level-0 kernel's records are 32,400 KB per launch).
 set -u
 cd $GRAFT_REPO_ROOT
