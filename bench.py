@@ -90,7 +90,14 @@ def parse(argv=None):
     ap.add_argument("--prewarm-seconds", type=float, default=0.25,
                     help="untimed steps run before the W warm-ups until this much wall time has passed: a short timed region right "
                          "after an idle GPU reads up to 10 %% low while the clocks ramp (DESIGN.md 3)")
-    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="gloo only with --stub (CPU tests)")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="nccl (default) = RCCL, one rank per GPU.  gloo: host-side collectives -- with --stub (CPU tests), or with real "
+                         "compute for the one-GPU REHEARSAL of an N-rank run (--device-map 0,0,...): every rank runs the HIP step on its "
+                         "mapped device, barrier / ranks_seen / gather_results / key-frame broadcast go through host tensors")
+    ap.add_argument("--device-map", default=None,
+                    help="comma-separated device index per rank (default: rank r uses GPU LOCAL_RANK).  Repeats are allowed only with "
+                         "--backend gloo (RCCL refuses two ranks on one device): `--gpus 2 --backend gloo --device-map 0,0` runs both "
+                         "ranks' real steps on GPU 0 -- plumbing rehearsal, not a scaling measurement (the line says so)")
     ap.add_argument("--stub", action="store_true",
                     help="TEST ONLY: no GPU, the step is a no-op that fills a deterministic result table; exercises the launch / "
                          "sharding / gather / reduce logic under gloo.  The line it prints is marked data='stub' and is not a measurement")
@@ -111,8 +118,15 @@ def parse(argv=None):
         args.scaling = "weak"
     if args.stub:
         args.backend = "gloo" if "--backend" not in given else args.backend
-    elif args.backend != "nccl":
-        ap.error("--backend gloo is only valid with --stub: the hot path has no CPU fallback")
+    if args.device_map is not None:
+        try:
+            args.device_map = [int(v) for v in args.device_map.split(",")]
+        except ValueError:
+            ap.error("--device-map: comma-separated integers")
+        if len(args.device_map) != args.gpus or min(args.device_map) < 0:
+            ap.error(f"--device-map needs one non-negative device index per rank ({args.gpus})")
+        if len(set(args.device_map)) != len(args.device_map) and args.backend != "gloo":
+            ap.error("--device-map with a repeated device needs --backend gloo (RCCL refuses two ranks on one device)")
     return args
 
 
@@ -169,8 +183,16 @@ def time_steps(step, steps: int, warmup: int, sync, barrier) -> float:
     return time.perf_counter() - t0
 
 
+# What each row of the hot path is pinned to: a reader of the line alone must not mistake "bit-exact vs the
+# oracle" on the headline kernel for parity with reference output -- the reference has no SAD search and no per-pixel flow.
+PARITY_PIN = {"A6-A12 (camera + Almeida)": "reference-held mfield tables (docs/report/mfield/*.csv) + the reference's own known-answer test",
+              "A1-A5 (densifier, detector)": "hand-derived literals from the Rust text (no reference-held vectors exist)",
+              "N1 (full-search SAD, this line's kernel)": "build-defined spec: bit-exact vs the build's own CPU restatement only (reference has no SAD)",
+              "N2 (dense LK flow)": "build-defined spec: bit-exact vs the build's own CPU restatement only (reference calls OpenCV Farneback)"}
+
+
 def build_line(args, world: int, el: float, launch_ms: float, launch_pairs: int, counts: list, nblk: int, ranks_seen: int,
-               traffic_per_pair=None) -> dict:
+               traffic_per_pair=None, traffic_stale=None) -> dict:
     """The JSON line from measured times (pure function: tests/test_bench_contract.py feeds it synthetic timings)."""
     W, H, B, R, P = args.width, args.height, args.block, args.search_range, args.pairs
     total_pairs = sum(counts)
@@ -212,6 +234,7 @@ def build_line(args, world: int, el: float, launch_ms: float, launch_pairs: int,
                      "frac": round(achieved / HBM_PEAK_GBS, 5),
                      "traffic": None if traffic_per_pair is None else traffic_per_pair * launch_pairs,
                      "traffic_source": None if traffic_per_pair is None else "profiles/hbm_traffic.json (rocprofv3 --pmc passes of this command; not re-measured in this run)",
+                     "traffic_stale": None if traffic_per_pair is None else traffic_stale,
                      "algorithmic_bytes_per_launch": algo_bytes, "launch_ms": round(launch_ms, 5), "pairs_per_launch": launch_pairs,
                      "note": "full search is VALU-bound (SURVEY.md 8d): see 'valu'",
                      "valu": {"abs_diffs_per_launch": abs_diffs,
@@ -220,6 +243,10 @@ def build_line(args, world: int, el: float, launch_ms: float, launch_pairs: int,
                               "frac": round(abs_diffs / (launch_ms * 1e-3) / valu_peak, 4) if launch_ms > 0 else 0.0,
                               "peak_basis": "SAD unit: 64 |a-b| per clock per SIMD (v_qsad_pk_u16_u8 16 cyc, measured)"}},
     }
+    out["parity_pin"] = PARITY_PIN
+    if getattr(args, "device_map", None) and len(set(args.device_map)) != len(args.device_map):
+        out["rehearsal"] = (f"{world} ranks on devices {args.device_map} over gloo: real HIP steps, host-side collectives -- a plumbing "
+                            "rehearsal of the N-GPU run on fewer GPUs, NOT a scaling measurement")
     if args.sad_mode == "pruned":
         out["roofline"]["valu"]["note"] = ("exhaustive-equivalent rate: the pruned search returns the same winners but "
                                            "evaluates fewer |a-b|, so this fraction can exceed 1")
@@ -227,12 +254,21 @@ def build_line(args, world: int, el: float, launch_ms: float, launch_pairs: int,
     return out
 
 
+def kernel_source_sha16(name: str = "sad.hip") -> str:
+    import hashlib
+    return hashlib.sha256(open(os.path.join(ROOT, "ofps_amd", "csrc", name), "rb").read()).hexdigest()[:16]
+
+
 def committed_traffic_per_pair(W, H, B, R):
+    """-> (HBM bytes per pair from the committed PMC passes or None, stale): stale = the kernel source the passes were taken
+    on (sha stored by tools/make_hbm_traffic.py) is not the sad.hip in the tree -- the figure may no longer describe it."""
     tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     try:
-        return json.load(open(tpath)).get(f"sad_{W}x{H}_b{B}_r{R}", {}).get("hbm_bytes_per_pair")
+        d = json.load(open(tpath)).get(f"sad_{W}x{H}_b{B}_r{R}", {})
+        v = d.get("hbm_bytes_per_pair")
+        return v, (None if v is None else d.get("kernel_source_sha16") != kernel_source_sha16())
     except Exception:
-        return None
+        return None, None
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -363,9 +399,26 @@ def end_to_end_leg(frames, W, H, B, R, device, n_frames=300):
     s = timed(run_sync)
     a = timed(run_read_ahead, False)
     c = timed(run_read_ahead, True)
+    # the link itself, measured in this run: 16 frames' worth of page-locked bytes host -> device in one copy, and one frame
+    # alone (what a per-frame upload pays); the ceiling below is derived from the first, not from a constant
+    big = ctx.pinned_frame(16 * H, W)
+    d_big = ctx.malloc(big.nbytes)
+
+    def h2d_rate(arr, reps):
+        ctx.memcpy_h2d(d_big, arr)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            ctx.memcpy_h2d(d_big, arr)
+        return arr.nbytes * reps / (time.perf_counter() - t0) / 1e9
+    h2d_bulk, h2d_frame = h2d_rate(big, 20), h2d_rate(pins[0], 200)
+    ctx.free(d_big)
+    ceiling = nblk / (W * H / (h2d_bulk * 1e9)) / 1e6
     out = {"what": "Decoder::process_frame shape: one luma frame H2D from page-locked memory per call, previous frame resident, "
                    "vectors D2H to page-locked memory",
            "frames": n_frames, "bytes_h2d_per_frame": W * H, "bytes_d2h_per_frame": 16 * nblk,
+           "h2d_GBs_measured": {"bulk_16_frames_per_copy": round(h2d_bulk, 1), "one_frame_per_blocking_copy": round(h2d_frame, 1)},
+           "pcie_ceiling_Mvectors_per_s": round(ceiling, 1),
+           "pcie_ceiling_basis": "every frame crosses the link once: vectors per frame / (frame bytes / the bulk H2D rate measured in this run)",
            "sync": row(s, entry_points="ofps_hip_push_frame"),
            "read_ahead": row(a, entry_points="ofps_hip_push_frame_async + ofps_hip_frame_wait, 2 tickets in flight"),
            "read_ahead_with_host_copy": row(c, includes="a host memcpy of every frame into the next page-locked buffer while the GPU works")}
@@ -386,7 +439,7 @@ def end_to_end_leg(frames, W, H, B, R, device, n_frames=300):
             out["read_ahead_batched_native_host"] = {"ms_per_frame": r["ms_per_frame"], "Mvectors_per_s": r["Mvectors_per_s"], "batch": r["batch"],
                                                      "entry_points": "ofps_hip_push_frames_async + ofps_hip_frames_wait: 16 frames per ticket, 2 tickets "
                                                                      "in flight, one H2D + one search launch + one read-back per batch",
-                                                     "pcie_ceiling_Mvectors_per_s": "one 2.07 MB frame H2D at ~49 GB/s = 42.6 us -> 189"}
+                                                     "frac_of_measured_pcie_ceiling": round(r["Mvectors_per_s"] / ceiling, 3)}
     except Exception as e:                                    # the tool is optional evidence, never the bench line
         out["native_host_error"] = repr(e)[:200]
     return out
@@ -404,15 +457,19 @@ def run_rank(args) -> int:
     if env_world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {env_world} rank(s): --gpus is the number of "
                          f"ranks, one per GPU")
+    env_rank, env_local = int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+    dev_index = args.device_map[env_rank] if args.device_map else env_local
     if not args.stub:
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
-        if torch.cuda.device_count() < int(os.environ.get("LOCAL_WORLD_SIZE", env_world)):
-            raise SystemExit(f"bench.py: {env_world} ranks need {env_world} GPUs, this node has {torch.cuda.device_count()}")
-    rank, world, local_rank = D.init_from_env(args.backend)
-    dev = torch.device("cpu") if args.stub else torch.device("cuda", local_rank)
+        need = (max(args.device_map) + 1) if args.device_map else int(os.environ.get("LOCAL_WORLD_SIZE", env_world))
+        if torch.cuda.device_count() < need:
+            raise SystemExit(f"bench.py: {env_world} ranks need {need} GPUs"
+                             + (f" (--device-map {args.device_map})" if args.device_map else "") + f", this node has {torch.cuda.device_count()}")
+    rank, world, local_rank = D.init_from_env(args.backend, device_index=dev_index)
+    dev = torch.device("cpu") if args.stub else torch.device("cuda", dev_index)
     if not args.stub:
-        torch.cuda.set_device(local_rank)
+        torch.cuda.set_device(dev_index)
 
     W, H, B, R, P = args.width, args.height, args.block, args.search_range, args.pairs
     key_mode = args.ref_mode == "key"
@@ -450,7 +507,7 @@ def run_rank(args) -> int:
             d_frames = torch.zeros((1, H, stride), dtype=torch.uint8, device=dev)
         d_out = torch.empty((max(count, 1), nblk, 4), dtype=torch.float32, device=dev)
         d_chk = torch.zeros((count,), dtype=torch.int64, device=dev)
-        ctx = HipContext(local_rank)
+        ctx = HipContext(dev_index)
         ctx.use_torch_stream()            # launches go to torch's current stream: torch events see them
         ctx.set_sad_mode(ctx.SAD_PRUNED if args.sad_mode == "pruned" else ctx.SAD_EXHAUSTIVE)
 
@@ -530,6 +587,36 @@ def run_rank(args) -> int:
         torch.cuda.synchronize()
         gather_ms = D.max_over_ranks(ga.elapsed_time(gb) / args.steps, device=dev)
 
+    # ---- strong scaling, time to solution WITH the vectors on the host (the results come home by hipMemcpyAsync
+    # D2H): every rank copies its pairs' records to page-locked memory inside the step.  The search writes into two device
+    # buffers in turn and the copy runs on a side stream behind an event, so the D2H of step k overlaps the search of step k+1;
+    # a buffer is searched into again only after its previous copy finished.  Never `value` (the metric is device-resident).
+    d2h_ms = None
+    if args.scaling == "strong" and not args.stub and count:
+        side = torch.cuda.Stream(device=dev)
+        host = [torch.empty((count, nblk, 4), dtype=torch.float32).pin_memory() for _ in range(2)]
+        outs = [d_out, torch.empty_like(d_out)]
+        searched = [torch.cuda.Event() for _ in range(2)]
+        copied = [None, None]
+        kstep = [0]
+
+        def step_d2h():
+            b = kstep[0] & 1
+            kstep[0] += 1
+            if copied[b] is not None:
+                torch.cuda.current_stream().wait_event(copied[b])       # the copy that still reads this buffer
+            if key_mode:
+                D.broadcast_reference(d_frames[0], src=0)
+            ctx.sad_flow_dev(d_frames.data_ptr(), n_res, W, H, stride, stride * H, 1 if key_mode else 0, B, R, outs[b].data_ptr(), None)
+            searched[b].record()
+            with torch.cuda.stream(side):
+                side.wait_event(searched[b])
+                host[b].copy_(outs[b][:count], non_blocking=True)
+                ev = torch.cuda.Event(); ev.record(side); copied[b] = ev
+        el_d2h = D.max_over_ranks(time_steps(step_d2h, args.steps, args.warmup, sync, barrier), device=dev)
+        d2h_ms = el_d2h / args.steps * 1e3
+        d2h_same = bool((host[(kstep[0] - 1) & 1].numpy().view(np.uint32) == outs[(kstep[0] - 1) & 1][:count].cpu().numpy().view(np.uint32)).all())
+
     seen = D.ranks_seen(dev)
     counts = D.gather_counts(count, dev)
     if seen != args.gpus:
@@ -538,11 +625,20 @@ def run_rank(args) -> int:
     out = None
     if rank == 0:
         out = build_line(args, world, el, launch_ms, count, counts, nblk, seen,
-                         None if args.stub else committed_traffic_per_pair(W, H, B, R))
-        out["launcher"] = "torchrun (one process per GPU, RCCL)" if D.active() else "single process"
+                         *((None, None) if args.stub else committed_traffic_per_pair(W, H, B, R)))
+        out["launcher"] = (("torchrun (one process per GPU, RCCL)" if args.backend == "nccl" else
+                            "torchrun (one process per rank, gloo: host-side collectives)") if D.active() else "single process")
         out["per_rank_ms_per_step"] = {"min": round(el_min / args.steps * 1e3, 4), "max": round(el / args.steps * 1e3, 4)}
         if gather_ms is not None:
             out["gather_ms_per_step"] = round(gather_ms, 4)
+        if d2h_ms is not None:
+            out["ms_per_step_with_d2h"] = round(d2h_ms, 4)
+            out["with_d2h"] = {"what": "the same step with every rank's records copied to page-locked host memory inside it (D2H on a side "
+                                       "stream behind an event, two device buffers in turn; no gather collective): time to solution with "
+                                       "the vectors on the host",
+                               "bytes_d2h_per_rank_and_step": int(count) * nblk * 16,
+                               "Mvectors_per_s": round(sum(counts) * nblk * args.steps / (d2h_ms * 1e-3 * args.steps) / 1e6, 3),
+                               "host_copy_equals_device_records": d2h_same}
 
     if args.pipeline and not args.stub:
         def full():
@@ -689,7 +785,7 @@ def run_threads(args) -> int:
     counts = [MultiDevice.pair_range(total, N, k)[1] for k in range(N)]
     args_line = argparse.Namespace(**vars(args))
     args_line.pairs = total if args.scaling == "strong" else P
-    out = build_line(args_line, N, el, float(ms[0]) / args.steps, counts[0], counts, nblk, N, committed_traffic_per_pair(W, H, B, R))
+    out = build_line(args_line, N, el, float(ms[0]) / args.steps, counts[0], counts, nblk, N, *committed_traffic_per_pair(W, H, B, R))
     out["launcher"] = "threads (one process, ofps_hip_multi_*: one worker thread + context per GPU, no collective)"
     out["per_rank_ms_per_step"] = {"min": round(float(ms[ms > 0].min()) / args.steps, 4) if (ms > 0).any() else 0.0,
                                    "max": round(float(ms.max()) / args.steps, 4), "what": "HIP events per worker"}
@@ -732,8 +828,9 @@ def main(argv=None) -> int:
         # `python bench.py --gpus N` without a launcher: become the launcher (one rank per GPU, RCCL)
         if not args.stub:
             import torch
-            if torch.cuda.device_count() < args.gpus:
-                raise SystemExit(f"bench.py: --gpus {args.gpus} but this node has {torch.cuda.device_count()} GPU(s)")
+            need = (max(args.device_map) + 1) if args.device_map else args.gpus
+            if torch.cuda.device_count() < need:
+                raise SystemExit(f"bench.py: --gpus {args.gpus} needs {need} GPU(s), this node has {torch.cuda.device_count()}")
         return D.launch_ranks(os.path.abspath(__file__), sys.argv[1:] if argv is None else list(argv), args.gpus)
     return run_rank(args)
 

@@ -29,13 +29,17 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0
-# f32 VALU: 256 CU x 4 SIMD x 32 lanes per clock x 2.4 GHz (one v_add/v_mul/v_fma_f32 per lane; tools/ubench_valu measures
-# 2.5 cycles per wave64 instruction, i.e. 25.6 lanes per clock: the nominal figure is the stricter peak)
-VALU_F32_PEAK_OPS = 256 * 4 * 32 * 2.4e9
+# f32 vector peak of MI355X_MICROARCH.md: 157.3 TFLOP/s = 256 CU x 4 SIMD x 32 lanes per clock x 2.4 GHz x 2 (a fused
+# multiply-add counts as two flops).  The same machine in INSTRUCTIONS: 78.6 T lane-instructions/s (tools/ubench_valu measures 2.5
+# cycles per wave64 instruction, i.e. 25.6 lanes per clock: the nominal figure is the stricter peak).  One unit on both sides
+# of each fraction (round 3 divided fma = 2 operations by the instruction rate).
+VALU_F32_PEAK_FLOPS = 256 * 4 * 32 * 2.4e9 * 2
+VALU_F32_PEAK_INSTR = 256 * 4 * 32 * 2.4e9
 SAD_PEAK = 256 * 4 * 2.4e9 * 64.0                          # |a-b| per second, see bench.py
-LK_SPEC_OPS_PER_TAP = 11                                   # 81 taps x 11 f32 operations per pixel-step (r = 4); spec revision 2
-                                                           # issues them as 7 instructions (a fused multiply-add counts as two operations,
-                                                           # so the figure stays comparable with round 2's)
+LK_SPEC_FLOPS_PER_TAP = 11                                 # DESIGN.md N2, spec revision 2: per tap and step 3 subtractions + 3 lerp fma + 2 residual fma
+                                                           # = 8 instructions' worth of arithmetic of which the kernel issues 7 (the horizontal lerp of a
+                                                           # sample row serves two window rows); flops with fma = 2: 11
+LK_SPEC_INSTR_PER_TAP = 7
 
 
 def _event_ms(ctx, fn, reps, warm=25):
@@ -54,73 +58,98 @@ def cfg3_chain_leg(device: int = 0, reps: int = 60) -> dict:
     from ofps_amd import synth
     from ofps_amd.runtime import HipContext
     W, H, LV, RAD, IT, GW, GH = 1920, 1080, 3, 4, 3, 150, 84
-    fr = synth.luma_sequence(2, W, H, max_step=3, seed=11)
     ctx = HipContext(device)
     ctx.use_torch_stream()
-    dfr = torch.from_numpy(fr).cuda()
     n = W * H
     d_ent = torch.empty((n, 4), dtype=torch.float32, device="cuda")
     d_fld = torch.empty((GW * GH, 2), dtype=torch.float32, device="cuda")
     d_q = torch.empty((1, 4), dtype=torch.float32, device="cuda")
-
-    def lk():
-        ctx.lk_flow_dev(dfr[0].data_ptr(), dfr[1].data_ptr(), W, H, W, LV, RAD, IT, None, d_ent.data_ptr())
-
-    def den():
-        ctx.densify_raster_dev(d_ent.data_ptr(), None, W, H, GW, GH, d_fld.data_ptr())
-
-    def alm():
-        ctx.almeida_dev(d_ent.data_ptr(), n, 1, W / H, 39.6 * H / W, False, 0, 0.05, 0, 0, d_q.data_ptr())
-
-    def chain():
-        lk(); den(); alm()
-    lk_ms = _event_ms(ctx, lk, reps)
-    den_ms = _event_ms(ctx, den, reps)
-    alm_ms = _event_ms(ctx, alm, reps)
-    for _ in range(10):
-        chain()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        chain()
-    torch.cuda.synchronize()
-    chain_ms = (time.perf_counter() - t0) / reps * 1e3
-    # spec operations of the Gauss-Newton steps over the pyramid (the level kernels; pyramid / gradient / tensor kernels
-    # are not counted as useful work, their time IS in lk_ms)
+    # two contents: +-3 px motion, and the +-16 px region motion the SAD bench line itself uses, whose
+    # region borders give tiles with incoherent flows (the grouped path of the level kernel)
+    contents = {"pm3": synth.luma_sequence(2, W, H, max_step=3, seed=11), "pm16": synth.luma_sequence(2, W, H, max_step=16, seed=11)}
     px = sum((W >> l) * (H >> l) for l in range(LV))
-    lk_ops = px * IT * (2 * RAD + 1) ** 2 * LK_SPEC_OPS_PER_TAP
+    taps = px * IT * (2 * RAD + 1) ** 2
+    per = {}
+    kept = {}
+    for name, fr in contents.items():
+        dfr = torch.from_numpy(fr).cuda()
+
+        def lk():
+            ctx.lk_flow_dev(dfr[0].data_ptr(), dfr[1].data_ptr(), W, H, W, LV, RAD, IT, None, d_ent.data_ptr())
+
+        def den():
+            ctx.densify_raster_dev(d_ent.data_ptr(), None, W, H, GW, GH, d_fld.data_ptr())
+
+        def alm():
+            ctx.almeida_dev(d_ent.data_ptr(), n, 1, W / H, 39.6 * H / W, False, 0, 0.05, 0, 0, d_q.data_ptr())
+
+        def chain():
+            lk(); den(); alm()
+        lk_ms = _event_ms(ctx, lk, reps)
+        den_ms = _event_ms(ctx, den, reps)
+        alm_ms = _event_ms(ctx, alm, reps)
+        for _ in range(10):
+            chain()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            chain()
+        torch.cuda.synchronize()
+        chain_ms = (time.perf_counter() - t0) / reps * 1e3
+        per[name] = {"lk_ms": round(lk_ms, 4), "densify_ms": round(den_ms, 4), "almeida_ms": round(alm_ms, 4), "chain_ms": round(chain_ms, 4),
+                     "Mvectors_per_s_chain": round(n / chain_ms / 1e3, 1),
+                     "lk_frac_of_f32_peak": round(taps * LK_SPEC_FLOPS_PER_TAP / (lk_ms * 1e-3) / VALU_F32_PEAK_FLOPS, 4)}
+        kept[name] = (d_ent.cpu().numpy(), d_q.cpu().numpy()[0], d_fld.cpu().numpy())
+        del dfr
+    ctx.close()
+    lk_ms, alm_ms = per["pm3"]["lk_ms"], per["pm3"]["almeida_ms"]
     out = {"what": "BASELINE configs[2]: 1080p pair -> 3-level LK (r=4, 3 steps) -> 2,073,600 per-pixel records -> densify 150x84 "
-                   "-> Almeida LSQ, device resident",
-           "lk_ms": round(lk_ms, 4), "densify_ms": round(den_ms, 4), "almeida_ms": round(alm_ms, 4), "chain_ms": round(chain_ms, 4),
-           "Mvectors_per_s_chain": round(n / chain_ms / 1e3, 1), "reps": reps,
-           "roofline_lk": {"bound": "valu_f32", "unit": "Tops/s", "spec_ops_per_pair": lk_ops,
-                           "achieved": round(lk_ops / (lk_ms * 1e-3) / 1e12, 3), "peak": round(VALU_F32_PEAK_OPS / 1e12, 2),
-                           "frac": round(lk_ops / (lk_ms * 1e-3) / VALU_F32_PEAK_OPS, 4),
-                           "note": "spec operations of all level steps (11 per tap, a fused multiply-add = 2; 7 instructions per tap in "
-                                   "spec revision 2) / the time of the WHOLE lk_flow call (pyramid, gradient and hand-over launches included); "
-                                   "peak = 32 lanes x 4 SIMDs x 256 CUs x 2.4 GHz instruction-lanes, i.e. an fma-only stream could reach 2x"},
+                   "-> Almeida LSQ, device resident; two contents",
+           "content": {"pm3": "+-3 px region motion (seed 11)", "pm16": "+-16 px region motion (seed 11): the SAD bench line's kind of content"},
+           "per_content": per,
+           # the round-3 keys, on the +-3 content (continuity)
+           "lk_ms": per["pm3"]["lk_ms"], "densify_ms": per["pm3"]["densify_ms"], "almeida_ms": per["pm3"]["almeida_ms"],
+           "chain_ms": per["pm3"]["chain_ms"], "Mvectors_per_s_chain": per["pm3"]["Mvectors_per_s_chain"], "reps": reps,
+           "roofline_lk": {"bound": "valu_f32", "unit": "TFLOP/s", "spec_flops_per_pair": taps * LK_SPEC_FLOPS_PER_TAP,
+                           "achieved": round(taps * LK_SPEC_FLOPS_PER_TAP / (lk_ms * 1e-3) / 1e12, 3), "peak": round(VALU_F32_PEAK_FLOPS / 1e12, 2),
+                           "frac": round(taps * LK_SPEC_FLOPS_PER_TAP / (lk_ms * 1e-3) / VALU_F32_PEAK_FLOPS, 4),
+                           "frac_pm16": per["pm16"]["lk_frac_of_f32_peak"],
+                           "instr_view": {"spec_instr_lanes_per_pair": taps * LK_SPEC_INSTR_PER_TAP, "peak_T_instr_lanes_per_s": round(VALU_F32_PEAK_INSTR / 1e12, 2),
+                                          "frac": round(taps * LK_SPEC_INSTR_PER_TAP / (lk_ms * 1e-3) / VALU_F32_PEAK_INSTR, 4)},
+                           "note": "flops of the spec's window taps over all level steps (11 per tap with a fused multiply-add = 2; the structure "
+                                   "tensor, pyramid and staging are not counted as useful work) / the time of the WHOLE lk_flow call, against the "
+                                   "guide's f32 vector peak (157.3 TFLOP/s, fma = 2: the same unit); instr_view: the 7 instructions per tap "
+                                   "against 78.6 T lane-instructions/s.  The row phase is LDS-pipe bound (DESIGN.md N2)"},
            "roofline_almeida": {"bound": "hbm", "unit": "GB/s", "algorithmic_bytes": 16 * n,
                                 "achieved": round(16 * n / (alm_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
                                 "frac": round(16 * n / (alm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                 "note": "records read once; the solve is a 30-link dependent chain, not a stream"}}
-    # ---- parity, outside the timed region
-    ent = d_ent.cpu().numpy()
-    q = d_q.cpu().numpy()[0]
-    fld = d_fld.cpu().numpy()
-    ctx.close()
+    # ---- parity + the CPU path beside it, outside the timed region
     try:
         import oracle
-        flow_o = oracle.lk_flow(fr[0], fr[1], LV, RAD, IT)
-        ent_o = oracle.flow_to_entries(flow_o)
         thr = min(16, oracle.num_threads())
-        q_o = oracle.solve_ypr_given(ent_o, oracle.camera(W / H, 39.6 * H / W), threads=thr)
-        out["parity_check"] = {"lk_records_bit_exact": bool((ent.view(np.uint32) == ent_o.view(np.uint32)).all()),
-                               "densify_field_bit_exact": bool((fld.view(np.uint32).reshape(-1)
-                                                                == oracle.densify(ent_o, GW, GH).view(np.uint32).reshape(-1)).all()),
-                               "almeida_max_abs_dq": float(np.abs(q - q_o).max()), "almeida_tolerance": 2e-6,
-                               "ok": None}
-        pc = out["parity_check"]
-        pc["ok"] = bool(pc["lk_records_bit_exact"] and pc["densify_field_bit_exact"] and pc["almeida_max_abs_dq"] <= 2e-6)
+        cam = oracle.camera(W / H, 39.6 * H / W)
+        pcs, cpu = {}, {}
+        for name, fr in contents.items():
+            ent, q, fld = kept[name]
+            if name == "pm3":                                      # N2 on the host: one thread (how the reference runs a decoder) and all the cores
+                prev_thr = oracle.set_num_threads(1)
+                t0 = time.perf_counter(); oracle.lk_flow(fr[0], fr[1], LV, RAD, IT); cpu["lk_flow_1_thread_ms"] = round((time.perf_counter() - t0) * 1e3, 1)
+                oracle.set_num_threads(prev_thr)
+            t0 = time.perf_counter()
+            flow_o = oracle.lk_flow(fr[0], fr[1], LV, RAD, IT)
+            cpu[f"lk_flow_all_cores_ms_{name}"] = round((time.perf_counter() - t0) * 1e3, 1)
+            ent_o = oracle.flow_to_entries(flow_o)
+            q_o = oracle.solve_ypr_given(ent_o, cam, threads=thr)
+            pc = {"lk_records_bit_exact": bool((ent.view(np.uint32) == ent_o.view(np.uint32)).all()),
+                  "densify_field_bit_exact": bool((fld.view(np.uint32).reshape(-1) == oracle.densify(ent_o, GW, GH).view(np.uint32).reshape(-1)).all()),
+                  "almeida_max_abs_dq": float(np.abs(q - q_o).max()), "almeida_tolerance": 2e-6}
+            pc["ok"] = bool(pc["lk_records_bit_exact"] and pc["densify_field_bit_exact"] and pc["almeida_max_abs_dq"] <= 2e-6)
+            pcs[name] = pc
+        cpu.update({"threads_all_cores": oracle.num_threads(), "kind": "port (oracle/ofps_oracle.c:orc_lk_flow, OpenMP over rows)",
+                    "speedup_vs_all_cores_pm3": round(cpu["lk_flow_all_cores_ms_pm3"] / per["pm3"]["lk_ms"], 1)})
+        out["cpu_lk"] = cpu
+        out["parity_check"] = dict(pcs["pm3"], per_content=pcs, ok=bool(all(v["ok"] for v in pcs.values())))
     except ImportError as e:
         out["parity_check"] = {"ok": None, "skipped": str(e)}
     return out
@@ -266,9 +295,22 @@ def cfg5_stream_leg(device: int = 0, frames: int = 330, fps: float = 60.0, use_r
     return out
 
 
+def cfg5_both_leg(device: int = 0) -> dict:
+    """cfg5 with the estimator both ways: LSQ (the top-level keys, as in round 3) and the reference's DEFAULT, RANSAC with 200
+    hypotheses x 1000 samples (almeida-estimator/src/lib.rs:69-78: use_ransac = true), per-frame seeds, parity per seed."""
+    out = cfg5_stream_leg(device, use_ransac=False)
+    r = cfg5_stream_leg(device, frames=210, use_ransac=True)
+    out["ransac"] = {k: r[k] for k in ("what", "frames", "measured_frames", "latency_ms", "parity_check", "almeida_in_kernel_recoveries")}
+    out["lsq"] = {"latency_ms": out["latency_ms"], "parity_check": out["parity_check"]}
+    out["parity_check"] = dict(out["parity_check"], ok=(None if out["parity_check"].get("ok") is None or r["parity_check"].get("ok") is None
+                                                         else bool(out["parity_check"]["ok"] and r["parity_check"]["ok"])),
+                               ransac_max_abs_dq=r["parity_check"].get("max_abs_dq"))
+    return out
+
+
 def all_legs(device: int = 0) -> dict:
     out = {}
-    for name, fn in (("cfg3_chain", cfg3_chain_leg), ("cfg4", cfg4_leg), ("cfg5_stream", cfg5_stream_leg)):
+    for name, fn in (("cfg3_chain", cfg3_chain_leg), ("cfg4", cfg4_leg), ("cfg5_stream", cfg5_both_leg)):
         t0 = time.perf_counter()
         try:
             out[name] = fn(device)
@@ -280,7 +322,7 @@ def all_legs(device: int = 0) -> dict:
 
 if __name__ == "__main__":
     only = sys.argv[1:] or None
-    legs = {"cfg3_chain": cfg3_chain_leg, "cfg4": cfg4_leg, "cfg5_stream": cfg5_stream_leg}
+    legs = {"cfg3_chain": cfg3_chain_leg, "cfg4": cfg4_leg, "cfg5_stream": cfg5_both_leg}
     if only:
         res = {}
         for nme in only:

@@ -123,6 +123,10 @@ int ofps_hip_sad_flow_dev(ofps_hip_ctx* ctx, const void* d_frames, int n_frames,
  * out_flow: 2*W*H f32 (u,v) or NULL; out_entries: 4*W*H f32 or NULL (at least one of them). */
 int ofps_hip_lk_flow(ofps_hip_ctx* ctx, const uint8_t* prev, const uint8_t* cur, int W, int H, int stride,
                      int levels, int radius, int iters, float* out_flow, float* out_entries);
+/* Revision of the build-defined N2 arithmetic this library was compiled with: 2 = fused multiply-adds in the bilinear
+ * sample, the residual sums and the structure tensor (the default), 1 = separate multiply and add (-DOFPS_LK_SPEC_FMA=0,
+ * A/B builds).  The oracle exports the same number (orc_lk_spec_revision); the parity tests assert they agree. */
+int ofps_hip_lk_spec_revision(void);
 /* cv-decoder's contrast mask (cv-decoder/src/lib.rs:203-237): Sobel(gray, CV_32F, 1, 1, ksize 5) -> threshold(> 20)
  * -> dilate(MORPH_ELLIPSE 11x11); a pixel contributes a record only where the mask is set (:253-257).  Restated
  * from OpenCV's published definitions (oracle/ofps_oracle.c:orc_contrast_mask; "parity unpinned": OpenCV is not
@@ -153,6 +157,13 @@ int ofps_hip_lk_push_frame(ofps_hip_ctx* ctx, const uint8_t* frame, int W, int H
 int ofps_hip_lk_reset(ofps_hip_ctx* ctx);
 int ofps_hip_lk_flow_dev(ofps_hip_ctx* ctx, const void* d_prev, const void* d_cur, int W, int H, int stride,
                          int levels, int radius, int iters, void* d_out_flow, void* d_out_entries);
+/* The same with a starting flow for the COARSEST pyramid level (d_init_flow: 2 f32 per pixel of that level, whose size is
+ * W, H halved -- rounding up -- levels - 1 times; NULL = zero = ofps_hip_lk_flow_dev): a temporal prior, e.g. the previous
+ * pair's flow reduced to that level -- the role of OPTFLOW_USE_INITIAL_FLOW in the call cv-decoder makes with flags 0
+ * (cv-decoder/src/lib.rs:188-199).  Spec: oracle/ofps_oracle.c:orc_lk_flow_init. */
+int ofps_hip_lk_flow_init_dev(ofps_hip_ctx* ctx, const void* d_prev, const void* d_cur, int W, int H, int stride,
+                              int levels, int radius, int iters, const void* d_init_flow, void* d_out_flow,
+                              void* d_out_entries);
 
 /* ---- A1-A4: MotionFieldDensifier ---- */
 int ofps_hip_densify(ofps_hip_ctx* ctx, const float* entries, size_t n, int w, int h,

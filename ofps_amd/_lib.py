@@ -44,6 +44,7 @@ PROTOTYPES = {
     "ofps_hip_sad_flow_dev": (C.c_int, [_ctx, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_int,
                                         C.c_int, C.c_int, _vp, _vp]),
     "ofps_hip_lk_flow": (C.c_int, [_ctx, _u8p, _u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _f32p, _f32p]),
+    "ofps_hip_lk_spec_revision": (C.c_int, []),
     "ofps_hip_contrast_mask": (C.c_int, [_ctx, _u8p, C.c_int, C.c_int, C.c_int, _u8p]),
     "ofps_hip_contrast_mask_dev": (C.c_int, [_ctx, _vp, C.c_int, C.c_int, C.c_int, _vp]),
     "ofps_hip_lk_decode": (C.c_int, [_ctx, _u8p, _u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
@@ -52,6 +53,7 @@ PROTOTYPES = {
                                          C.c_uint, _f32p, _szp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "ofps_hip_lk_reset": (C.c_int, [_ctx]),
     "ofps_hip_lk_flow_dev": (C.c_int, [_ctx, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp]),
+    "ofps_hip_lk_flow_init_dev": (C.c_int, [_ctx, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp]),
     "ofps_hip_densify": (C.c_int, [_ctx, _f32p, C.c_size_t, C.c_int, C.c_int, _f32p, _u32p]),
     "ofps_hip_densify_raster_dev": (C.c_int, [_ctx, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_int]),
     "ofps_hip_densify_weighted": (C.c_int, [_ctx, _f32p, _f32p, C.c_size_t, C.c_int, C.c_int, _f32p, _u32p]),

@@ -142,11 +142,11 @@ int ofps_hip_init(int device, ofps_hip_ctx** out) {
     // the only place the library looks at the environment (OFPS_HIP_SAD_PRUNED is the host layers' business)
     for (const char* name : ofps::kOptionNames)
         if (const char* v = getenv(name)) {
-            const int rc = ofps::apply_option(ctx, name, v, /*from_env=*/true);
-            if (rc != OFPS_HIP_OK) {
-                snprintf(g_init_err, sizeof(g_init_err), "ofps_hip_init: %s", ctx->err);
-                ofps_hip_destroy(ctx);
-                return rc;
+            // a malformed A/B variable left in a production environment must not take the backend (with
+            // ofps_hip_multi_init: every worker) down: it is reported once and ignored; only ofps_hip_set_option is strict
+            if (ofps::apply_option(ctx, name, v, /*from_env=*/true) != OFPS_HIP_OK) {
+                fprintf(stderr, "[ofps_hip] warning: ignoring environment variable %s=%s (%s)\n", name, v, ctx->err);
+                ctx->err[0] = '\0';
             }
         }
     *out = ctx;

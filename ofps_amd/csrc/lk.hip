@@ -132,11 +132,10 @@ template <typename TIn>
 __global__ __launch_bounds__(256) void lk_pyr0_kernel(const TIn* __restrict__ s0, const TIn* __restrict__ s1, int W, int H, int stride,
                                                       float* __restrict__ f0, float* __restrict__ f1, float* __restrict__ o0,
                                                       float* __restrict__ o1, int w1, int h1, float* __restrict__ gx0p,
-                                                      float* __restrict__ gy0p, uint32_t* __restrict__ zero, int n_zero) {
+                                                      float* __restrict__ gy0p) {
     constexpr int RW = 2 * kP0X + 4, RH = 2 * kP0Y + 4;           // level-0 window
     __shared__ float win[RH][RW + 1];
     __shared__ float hor[RH][kP0X + 1];
-    if (zero && blockIdx.x == 0 && blockIdx.z == 0 && (int)threadIdx.x < n_zero) zero[threadIdx.x] = 0;   // hand-over counters
     int tx, ty;
     if (!lk_tile_of_block((w1 + kP0X - 1) / kP0X, ((w1 + kP0X - 1) / kP0X) * ((h1 + kP0Y - 1) / kP0Y), tx, ty)) return;
     const TIn* src = blockIdx.z ? s1 : s0;
@@ -179,10 +178,7 @@ __global__ __launch_bounds__(256) void lk_pyr0_kernel(const TIn* __restrict__ s0
 }
 
 __global__ __launch_bounds__(256) void lk_u8_to_f32_pair_kernel(const uint8_t* __restrict__ s0, const uint8_t* __restrict__ s1, int W, int H,
-                                                                int stride, float* __restrict__ d0, float* __restrict__ d1,
-                                                                uint32_t* __restrict__ zero, int n_zero) {
-    // the first launch of a flow computation also clears the per-level hand-over counters (one memset launch less)
-    if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && (int)threadIdx.x < n_zero) zero[threadIdx.x] = 0;
+                                                                int stride, float* __restrict__ d0, float* __restrict__ d1) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= W || y >= H) return;
     const uint8_t* src = blockIdx.z ? s1 : s0;
@@ -537,6 +533,16 @@ __device__ __forceinline__ void lk_stage3_u8(const uint8_t* __restrict__ src, in
 //   * 7 VALU operations per tap (the spec's count), 63 per row.
 // Same operations on the same operands in the same order as the C++ form (lk_lerp / lk_accum): same bits.
 // The quads are v[72:75] / v[76:79]: the top of the 80-register budget of a 256-thread workgroup at 6 waves per SIMD.
+#ifdef OFPS_LK_X_HALF_TILE
+#define LK_X_ODD(S) ""
+#else
+#define LK_X_ODD(S) S
+#endif
+#ifdef OFPS_LK_X_HALF_TEXEL
+#define LK_X_TEX(S) ""
+#else
+#define LK_X_TEX(S) S
+#endif
 #define LK_ROW9_TAP(K, KN, WAIT, NEXT)                                        \
     "v_sub_f32 %[tmp], %[l" #KN "], %[l" #K "]\n\t"                             \
     "v_fmac_f32 %[l" #K "], %[a" #K "], %[tmp]\n\t"                             \
@@ -569,27 +575,27 @@ __device__ __forceinline__ void lk_row9_asm(float (&r)[19], const float (&a)[9],
     float tmp;
     asm volatile(
         "ds_read_b32 %[l0], %[ja]\n\t"
-        "ds_read_b32 %[l1], %[ja] offset:4\n\t"
+        LK_X_TEX("ds_read_b32 %[l1], %[ja] offset:4\n\t")
         "ds_read_b32 %[l2], %[ja] offset:8\n\t"
-        "ds_read_b32 %[l3], %[ja] offset:12\n\t"
+        LK_X_TEX("ds_read_b32 %[l3], %[ja] offset:12\n\t")
         "ds_read_b32 %[l4], %[ja] offset:16\n\t"
-        "ds_read_b32 %[l5], %[ja] offset:20\n\t"
+        LK_X_TEX("ds_read_b32 %[l5], %[ja] offset:20\n\t")
         "ds_read_b32 %[l6], %[ja] offset:24\n\t"
-        "ds_read_b32 %[l7], %[ja] offset:28\n\t"
+        LK_X_TEX("ds_read_b32 %[l7], %[ja] offset:28\n\t")
         "ds_read_b32 %[l8], %[ja] offset:32\n\t"
-        "ds_read_b32 %[l9], %[ja] offset:36\n\t"
+        LK_X_TEX("ds_read_b32 %[l9], %[ja] offset:36\n\t")
         "ds_read_b128 v[72:75], %[ta]\n\t"
-        "ds_read_b128 v[76:79], %[ta] offset:16\n\t"
+        LK_X_ODD("ds_read_b128 v[76:79], %[ta] offset:16\n\t")
         "s_waitcnt lgkmcnt(10)\n\t"                                            // l0, l1 are there
         // tap k: horizontal + vertical interpolation while its tile record is in flight, then the residual sums; the quad
         // it used is refilled with tap k + 2's record.  Waits: 12 reads issued; before tap k's first use of l[k+1] at most
         // 10 - k of the texel reads ... may be outstanding behind the two tile reads (counted below per tap).
         LK_ROW9_TAP(0, 1, 1, "") LK_ROW9_USE(0, "v72", "v73", "v74", "ds_read_b128 v[72:75], %[ta] offset:32\n\t")
-        LK_ROW9_TAP(1, 2, 1, "") LK_ROW9_USE(1, "v76", "v77", "v78", "ds_read_b128 v[76:79], %[ta] offset:48\n\t")
+        LK_ROW9_TAP(1, 2, 1, "") LK_ROW9_USE(1, "v76", "v77", "v78", LK_X_ODD("ds_read_b128 v[76:79], %[ta] offset:48\n\t"))
         LK_ROW9_TAP(2, 3, 1, "") LK_ROW9_USE(2, "v72", "v73", "v74", "ds_read_b128 v[72:75], %[ta] offset:64\n\t")
-        LK_ROW9_TAP(3, 4, 1, "") LK_ROW9_USE(3, "v76", "v77", "v78", "ds_read_b128 v[76:79], %[ta] offset:80\n\t")
+        LK_ROW9_TAP(3, 4, 1, "") LK_ROW9_USE(3, "v76", "v77", "v78", LK_X_ODD("ds_read_b128 v[76:79], %[ta] offset:80\n\t"))
         LK_ROW9_TAP(4, 5, 1, "") LK_ROW9_USE(4, "v72", "v73", "v74", "ds_read_b128 v[72:75], %[ta] offset:96\n\t")
-        LK_ROW9_TAP(5, 6, 1, "") LK_ROW9_USE(5, "v76", "v77", "v78", "ds_read_b128 v[76:79], %[ta] offset:112\n\t")
+        LK_ROW9_TAP(5, 6, 1, "") LK_ROW9_USE(5, "v76", "v77", "v78", LK_X_ODD("ds_read_b128 v[76:79], %[ta] offset:112\n\t"))
         LK_ROW9_TAP(6, 7, 1, "") LK_ROW9_USE(6, "v72", "v73", "v74", "ds_read_b128 v[72:75], %[ta] offset:128\n\t")
         LK_ROW9_TAP(7, 8, 1, "") LK_ROW9_USE(7, "v76", "v77", "v78", "")
         LK_ROW9_TAP(8, 9, 0, "") LK_ROW9_USE(8, "v72", "v73", "v74", "")
@@ -613,27 +619,27 @@ __device__ __forceinline__ void lk_row9_asm_g(float (&r)[19], const float (&a)[9
     float tmp;
     asm volatile(
         "ds_read_b32 %[l0], %[ja]\n\t"
-        "ds_read_b32 %[l1], %[ja] offset:4\n\t"
+        LK_X_TEX("ds_read_b32 %[l1], %[ja] offset:4\n\t")
         "ds_read_b32 %[l2], %[ja] offset:8\n\t"
-        "ds_read_b32 %[l3], %[ja] offset:12\n\t"
+        LK_X_TEX("ds_read_b32 %[l3], %[ja] offset:12\n\t")
         "ds_read_b32 %[l4], %[ja] offset:16\n\t"
-        "ds_read_b32 %[l5], %[ja] offset:20\n\t"
+        LK_X_TEX("ds_read_b32 %[l5], %[ja] offset:20\n\t")
         "ds_read_b32 %[l6], %[ja] offset:24\n\t"
-        "ds_read_b32 %[l7], %[ja] offset:28\n\t"
+        LK_X_TEX("ds_read_b32 %[l7], %[ja] offset:28\n\t")
         "ds_read_b32 %[l8], %[ja] offset:32\n\t"
-        "ds_read_b32 %[l9], %[ja] offset:36\n\t"
+        LK_X_TEX("ds_read_b32 %[l9], %[ja] offset:36\n\t")
         "ds_read_b128 v[72:75], %[ta]\n\t"
-        "ds_read_b128 v[76:79], %[ta] offset:16\n\t"
+        LK_X_ODD("ds_read_b128 v[76:79], %[ta] offset:16\n\t")
         "s_waitcnt lgkmcnt(10)\n\t"                                            // l0, l1 are there
         // tap k: horizontal + vertical interpolation while its tile record is in flight, then the residual sums; the quad
         // it used is refilled with tap k + 2's record.  Waits: 12 reads issued; before tap k's first use of l[k+1] at most
         // 10 - k of the texel reads ... may be outstanding behind the two tile reads (counted below per tap).
         LK_ROW9_TAP(0, 1, 1, "") LK_ROW9_USE_G(0, "v72", "v73", "v74", "ds_read_b128 v[72:75], %[ta] offset:32\n\t")
-        LK_ROW9_TAP(1, 2, 1, "") LK_ROW9_USE_G(1, "v76", "v77", "v78", "ds_read_b128 v[76:79], %[ta] offset:48\n\t")
+        LK_ROW9_TAP(1, 2, 1, "") LK_ROW9_USE_G(1, "v76", "v77", "v78", LK_X_ODD("ds_read_b128 v[76:79], %[ta] offset:48\n\t"))
         LK_ROW9_TAP(2, 3, 1, "") LK_ROW9_USE_G(2, "v72", "v73", "v74", "ds_read_b128 v[72:75], %[ta] offset:64\n\t")
-        LK_ROW9_TAP(3, 4, 1, "") LK_ROW9_USE_G(3, "v76", "v77", "v78", "ds_read_b128 v[76:79], %[ta] offset:80\n\t")
+        LK_ROW9_TAP(3, 4, 1, "") LK_ROW9_USE_G(3, "v76", "v77", "v78", LK_X_ODD("ds_read_b128 v[76:79], %[ta] offset:80\n\t"))
         LK_ROW9_TAP(4, 5, 1, "") LK_ROW9_USE_G(4, "v72", "v73", "v74", "ds_read_b128 v[72:75], %[ta] offset:96\n\t")
-        LK_ROW9_TAP(5, 6, 1, "") LK_ROW9_USE_G(5, "v76", "v77", "v78", "ds_read_b128 v[76:79], %[ta] offset:112\n\t")
+        LK_ROW9_TAP(5, 6, 1, "") LK_ROW9_USE_G(5, "v76", "v77", "v78", LK_X_ODD("ds_read_b128 v[76:79], %[ta] offset:112\n\t"))
         LK_ROW9_TAP(6, 7, 1, "") LK_ROW9_USE_G(6, "v72", "v73", "v74", "ds_read_b128 v[72:75], %[ta] offset:128\n\t")
         LK_ROW9_TAP(7, 8, 1, "") LK_ROW9_USE_G(7, "v76", "v77", "v78", "")
         LK_ROW9_TAP(8, 9, 0, "") LK_ROW9_USE_G(8, "v72", "v73", "v74", "")
@@ -670,7 +676,8 @@ struct LkStepShared {
     // row are reachable from one address register, behind the tile each pair costs a v_add_u32
     alignas(16) float jl[LH][JS];
     float4 tile[T::TH][T::TW];         // (I, gx, gy, -) of the previous frame's window
-    int box[2][4][5];                  // [step parity][wave]: min x0, max x0+1, min y0, max y0+1, every lane's window columns consecutive
+    int box[2][4][4];                  // [step parity][wave]: min x0, max x0+1, min y0, max y0+1 of the wave's sample origins
+    int anchor[2][4][8];               // grouped tiles, [round parity][wave]: has a pending pixel, that pixel's box (x0, x0+1, y0, y0+1)
     // level 0 (u8 source): the f32 copy of the u8 window the tile records are made from.  A buffer of its own (3.4 KB at
     // radius 4; 6 workgroups per CU still fit): the records are made while the first rectangle's loads are in flight
     alignas(16) float u8win[U8 ? LkU8Window<RADIUS>::FLOATS : 4];
@@ -697,7 +704,8 @@ __device__ __forceinline__ int lk_origin(int q, float fl, int lim, float& frac) 
 //   * end of level 0: the per-pixel records cv-decoder emits (lk_entries_kernel's expressions) are written directly; the
 //     flow plane itself only if somebody asked for it.
 struct LkFlowIO {
-    const float2* coarse;       // flow of the next coarser level (w1 x h1), or nullptr: the level starts from zero flow
+    const float2* coarse;       // flow of the next coarser level (w1 x h1), or nullptr: the level starts from `init` / zero flow
+    const float2* init;         // coarsest level only: the caller's starting flow (w1 = its row pitch), or nullptr = zero
     int w1, h1;
     float2* flow_out;           // or nullptr
     float4* out_entries;        // or nullptr
@@ -709,6 +717,7 @@ __device__ __forceinline__ float2 lk_flow_read(const LkFlowIO& io, int x, int y)
         const float2 c = io.coarse[(size_t)lk_clampi(y / 2, 0, io.h1 - 1) * io.w1 + lk_clampi(x / 2, 0, io.w1 - 1)];
         return make_float2(2.0f * c.x, 2.0f * c.y);
     }
+    if (io.init) return io.init[(size_t)y * io.w1 + x];               // uniform
     return make_float2(0.0f, 0.0f);
 }
 
@@ -731,24 +740,33 @@ __device__ __forceinline__ void lk_store(const float2 out, int x, int y, int w, 
 
 // main kernel: one workgroup per kTX x kTY tile runs ALL `iters` Gauss-Newton steps of a pyramid level -- a step of a pixel
 // depends on nothing but that pixel's own flow, so the previous frame's window (I, gx, gy), the tensor G and the flow
-// stay on chip between steps; only the current frame's rectangle is restaged (it moves with the flow).  A tile whose
-// rectangle does not fit at step `it` parks its flow in fb_flow, appends (tile, it) to fb_tiles (count in *fb_count)
-// and leaves the remaining steps to lk_level_general_kernel.
+// stay on chip between steps; only the current frame's rectangle is restaged (it moves with the flow).
+// A tile whose rectangle does not fit LDS at some step (flows that disagree by more than SPREAD_X / SPREAD_Y pixels: region
+// borders of +-16 px content, 8 % of the level-0 tiles there) is finished INSIDE this launch (round 4; rounds 2-3 parked
+// its flow for a second, per-lane-gather kernel: three launches per pair, +34 % on such content): its pixels are taken in
+// GROUPS -- the first pixel not yet done anchors a capacity-sized rectangle, every pending pixel whose own sample box lies
+// inside it joins, the rectangle is staged and the members run the ordinary rows; 2-3 rounds for a region border
+// (tools/lk_tile_stats.py), at most kMaxRounds -- and whatever is still pending after that (flows without any
+// coherence) takes the oracle's per-sample form from global memory, tile records from LDS.  A pixel's arithmetic does not
+// depend on which path it takes: same operands, same operations, same order.
 // U8 = true (level 0): I_ / J_ are the u8 frames themselves, rows src_stride bytes apart; no f32 level-0 planes and no
 // level-0 gradient planes exist (lk_stage3_u8; the rectangle is converted while it is staged).
+constexpr int kLkMaxRounds = 8;
 template <int RADIUS, bool U8>
 __global__ __launch_bounds__(256, LkStepShared<RADIUS>::WAVES_PER_SIMD) void lk_level_lds_kernel(const void* __restrict__ I_, const void* __restrict__ J_,
                                                            const float* __restrict__ gx, const float* __restrict__ gy, int src_stride,
                                                            int w, int h, int iters, const LkFlowIO io,
-                                                           uint32_t* __restrict__ fb_count, uint2* __restrict__ fb_tiles,
-                                                           float2* fb_flow, unsigned long long* __restrict__ prof, int force_fall_arg) {
-    // force_fall (libofps_hip_testhooks.so only; compiled out of the product library): every other tile is treated as not
-    // fitting at that step, so that the hand-over to lk_level_general_kernel in the middle of a level is exercised on
-    // inputs that would never trigger it
+                                                           unsigned long long* __restrict__ prof, int force_fall_arg) {
+    // force_fall (libofps_hip_testhooks.so only; compiled out of the product library): low 4 bits = a step at which every
+    // other tile is treated as not fitting, so that the grouped path in the middle of a level is exercised on inputs that
+    // would never trigger it; bits 4.. = how many grouping rounds those tiles get (0 = the default kLkMaxRounds; 1 + n = n
+    // rounds, so 1 sends every pixel through the per-sample leftover path)
 #ifdef OFPS_HIP_TEST_HOOKS
-    const int force_fall = force_fall_arg;
+    const int force_fall = force_fall_arg < 0 ? -1 : (force_fall_arg & 15);
+    const int max_rounds = force_fall_arg >= 16 ? (force_fall_arg >> 4) - 1 : kLkMaxRounds;
 #else
     constexpr int force_fall = -1;
+    constexpr int max_rounds = kLkMaxRounds;
 #endif
     // prof (diagnostics, normally null): per-workgroup s_memtime stamps at the phase boundaries of the first step
 #define OFPS_LK_STAMP(slot) do { if (prof && threadIdx.x == 0) prof[((size_t)tile_y * tiles_x + tile_x) * 6 + (slot)] = __builtin_readcyclecounter(); } while (0)
@@ -768,304 +786,419 @@ __global__ __launch_bounds__(256, LkStepShared<RADIUS>::WAVES_PER_SIMD) void lk_
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const bool active = px < w && py < h;
     float2 f = active ? lk_flow_read(io, px, py) : make_float2(0.0f, 0.0f);      // requested first: in flight during the staging
-    // u8 source: the window's bytes are requested here and used after the first box exchange (front(), step 0): their
-    // latency runs beside the flow read, the column origins and the exchange instead of in front of them
+    // u8 source: the window's bytes are requested here and used after the first box exchange: their latency runs beside the
+    // flow read, the column origins and the exchange instead of in front of them
     LkU8Regs<RADIUS> u8g;
     if constexpr (U8) lk_stage3_u8_issue<RADIUS>(static_cast<const uint8_t*>(I_), src_stride, w, h, x0, y0, u8g);
     else lk_stage3<RADIUS>(I, gx, gy, sh.tile, w, h, x0, y0);
     // The 2x2 structure tensor of the pixel's window does not depend on the flow: it is summed by the level's FIRST step, from
     // the very tile records that step reads for the residual (three fused multiply-adds per tap more, no LDS traffic of
-    // its own), and stays in three registers for the later steps -- the separate tensor launch, its float4 plane (42 MB of
-    // writes and as many reads per 1080p pair) and the per-step re-read are gone.
+    // its own), and stays in three registers for the later steps.
     float gxx = 0.0f, gxy = 0.0f, gyy = 0.0f;
     bool st_valid = false;                                   // the rectangle of the current frame held in jl[][] (uniform)
     int st_x0 = 0, st_x1 = -1, st_y0 = 0, st_y1 = -1, st_xs = 0;
-    // The front half of a step -- box exchange, fit test, (re)staging of the current frame's rectangle -- as a function of
-    // the step: instantiated once in front of the step loop for step 0 (the only instance that touches the u8 window's
-    // staging registers, whose lives therefore end before the loop) and once inside it.  false = the tile fell.
     int x = 0, y = 0;
-    bool all_consecutive = false;
+    bool cons_x = false, cons_y = false;                     // per lane: the window's columns / rows sample consecutive texels
 #ifdef OFPS_LK_NO_FAST_ORIGINS                              // A/B: every tile takes the clamped, per-column origin chains
     constexpr bool kFastOrigins = false;
 #else
     constexpr bool kFastOrigins = true;
 #endif
-    const bool tile_in_x = kFastOrigins && x0 >= RADIUS && x0 + kTX - 1 + RADIUS <= w - 1;   // uniform: no window column of this tile is clamped
-    auto front = [&](int it, auto first) -> bool {
-            // the pixel coordinates pass through an empty asm so that the compiler does not hoist the clamped window
-            // coordinates (2N integers + their float conversions) out of the step loop: that costs 40 VGPRs and two waves
-            // per SIMD for a handful of integer operations per step
-            // (made from the thread index every step instead of copied from px / py: two registers less across the row loop)
-            int tidx = (int)threadIdx.x;
-            asm volatile("" : "+v"(tidx));
-            x = x0 + tidx % kTX; y = y0 + tidx / kTX;
-            // first pass over the window columns: only what the workgroup's box needs (first and last origin, "consecutive").
-            // The origins and fractions the rows use are made AGAIN after the barrier / staging below (same operations, same
-            // values): kept alive across that phase they were spilled to scratch in every step (76 B per pixel-step of HBM
-            // traffic, rocprofv3 WRITE_SIZE); nine floors are cheaper
-            int xi_first = 0, xi_last = 0;
-            bool consecutive = true;
-            if (tile_in_x) {
-                // No window column of this tile is clamped: the sums fq_k = (x + k - R) + u grow with k, and while they are
-                // >= 0 so does their rounding step -- a sum that rounds up to an integer is followed by sums that do too, so
-                // the floors advance by 1 or (across a binade) 2, never 0: the columns are consecutive exactly when the last
-                // floor is 2R above the first.  Two floor chains instead of N.
-                float dummy_a;
-                xi_first = lk_origin(x - RADIUS, f.x, w, dummy_a);
-                xi_last = lk_origin(x + RADIUS, f.x, w, dummy_a);
-                consecutive = xi_first >= 0 && xi_last - xi_first == 2 * RADIUS;
-            } else {
-                float dummy_a;
-                int prev = 0;
-    #pragma unroll
-                for (int k = 0; k < N; ++k) {
-                    const int o = lk_origin(lk_clampi(x + k - RADIUS, 0, w - 1), f.x, w, dummy_a);
-                    if (k > 0) consecutive = consecutive && (o == prev + 1);
-                    if (k == 0) xi_first = o;
-                    xi_last = o; prev = o;
+    // uniform: no window column / row of this tile is clamped to the image
+    const bool tile_in_x = kFastOrigins && x0 >= RADIUS && x0 + kTX - 1 + RADIUS <= w - 1;
+    const bool tile_in_y = kFastOrigins && y0 >= RADIUS && y0 + kTY - 1 + RADIUS <= h - 1;
+    // A pixel's sample box: origins of its first / last window column and row (the last + 1: the texel the interpolation also
+    // reads), and whether its columns / rows sample consecutive texels.  Unclamped windows (interior tiles): the sums
+    // fq_k = (x + k - R) + u grow with k, and while they are >= 0 so does their rounding step -- a sum that rounds up to an
+    // integer is followed by sums that do too, so the floors advance by 1 or (across a binade) 2, never 0: consecutive exactly
+    // when the last floor is 2R above the first.  Two floor chains instead of N per axis (tests/test_lk_origin_claims.py).
+    // The lemma is about UNCLAMPED floors and lk_origin clamps to [-1, lim]: a last floor that reached lim may have been
+    // clamped down to it (floors 1022, 1023, 1025, ..., 1031 across the 1024 binade at w = 1030 read as 1022 .. 1030), so
+    // such windows count as not consecutive; a first floor below 0 likewise.
+    auto lane_box = [&](int xq, int yq, int& a0, int& a1, int& b0, int& b1, bool& cx, bool& cy) {
+        float dm;
+        if (tile_in_x) {
+            a0 = lk_origin(xq - RADIUS, f.x, w, dm);
+            const int al = lk_origin(xq + RADIUS, f.x, w, dm);
+            cx = a0 >= 0 && al < w && al - a0 == 2 * RADIUS;
+            a1 = al + 1;
+        } else {
+            int prev = 0, al = 0;
+            cx = true;
+#pragma unroll
+            for (int k = 0; k < N; ++k) {
+                const int o = lk_origin(lk_clampi(xq + k - RADIUS, 0, w - 1), f.x, w, dm);
+                if (k > 0) cx = cx && (o == prev + 1);
+                if (k == 0) a0 = o;
+                al = o; prev = o;
+            }
+            a1 = al + 1;
+        }
+        if (tile_in_y) {
+            b0 = lk_origin(yq - RADIUS, f.y, h, dm);
+            const int bl = lk_origin(yq + RADIUS, f.y, h, dm);
+            cy = b0 >= 0 && bl < h && bl - b0 == 2 * RADIUS;
+            b1 = bl + 1;
+        } else {
+            // window rows are monotone in r, so the extremes are the first and the last
+            b0 = lk_origin(lk_clampi(yq - RADIUS, 0, h - 1), f.y, h, dm);
+            b1 = lk_origin(lk_clampi(yq + RADIUS, 0, h - 1), f.y, h, dm) + 1;
+            cy = false;
+        }
+    };
+    // the pixel coordinates pass through an empty asm so that the compiler does not hoist the clamped window coordinates (2N
+    // integers + their float conversions) out of the step loop: that costs 40 VGPRs and two waves per SIMD for a handful of
+    // integer operations per step (made from the thread index every time instead of copied from px / py: two registers less
+    // across the row loop)
+    auto remake_xy = [&]() {
+        int tidx = (int)threadIdx.x;
+        asm volatile("" : "+v"(tidx));
+        x = x0 + tidx % kTX; y = y0 + tidx / kTX;
+    };
+    // The box exchange that opens a step: every wave's box of sample origins goes to sh.box (slots alternate with the step: a
+    // step that reuses the staged rectangle has no second barrier, so a fast wave may write the next step's box while a slow
+    // one still reads this step's).  The caller's barrier follows.
+    auto box_exchange = [&](int it) {
+        remake_xy();
+        int a0, a1, b0, b1;
+        lane_box(x, y, a0, a1, b0, b1, cons_x, cons_y);
+        int bx0 = active ? a0 : 0x7FFFFFFF, bx1 = active ? a1 : -0x7FFFFFFF;
+        int by0 = active ? b0 : 0x7FFFFFFF, by1 = active ? b1 : -0x7FFFFFFF;
+        lk_wave_box(bx0, bx1, by0, by1);
+        if (lane == 0) { int* b = sh.box[it & 1][wave]; b[0] = bx0; b[1] = bx1; b[2] = by0; b[3] = by1; }
+    };
+    auto uni = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
+    // (Re)stages columns [rx0, rx1] x rows [ry0, ry1] of the current frame into jl[][], coordinates clamped per element exactly
+    // like the oracle clamps xa / xb / ya / yb; 16-byte loads when the padded rectangle lies inside the frame.  Uniform.
+    auto stage_rect = [&](int rx0, int rx1, int ry0, int ry1) {
+        // (thread index through an empty asm: the staging addresses are made here, per staging, not hoisted out of the step
+        // loop into registers that are then spilled for the whole level)
+        int tid = (int)threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        int xs_new = rx0;
+        const int chh = ry1 - ry0 + 1;
+        const int xa4 = rx0 & ~3, cw4 = (rx1 - xa4 + 4) >> 2;                        // float4 per row after padding
+        const bool vec = rx0 >= 0 && xa4 + 4 * cw4 <= w && 4 * cw4 <= S::JS &&
+                         (U8 ? (src_stride & 3) == 0 && (reinterpret_cast<uintptr_t>(J8) & 3) == 0
+                             : (w & 3) == 0 && (reinterpret_cast<uintptr_t>(J) & 15) == 0);
+        if (vec) {                                                   // uniform
+            xs_new = xa4;
+            // 32 lanes per rectangle row (cw4 <= JS / 4 <= 32), 8 rows per pass: no division by the run-time width
+            static_assert(S::JS / 4 <= 32, "J staging assumes at most 32 float4 per rectangle row");
+            const int c4 = tid & 31;
+            if (c4 < cw4) {
+                for (int cy = tid >> 5; cy < chh; cy += 8) {
+                    if constexpr (U8) {                              // four pixels per dword, converted on the way in
+                        const uint32_t q = *reinterpret_cast<const uint32_t*>(J8 + (size_t)lk_clampi(ry0 + cy, 0, h - 1) * src_stride + xa4 + 4 * c4);
+                        *reinterpret_cast<float4*>(&sh.jl[cy][4 * c4]) =
+                            make_float4((float)(q & 0xFFu), (float)((q >> 8) & 0xFFu), (float)((q >> 16) & 0xFFu), (float)(q >> 24));
+                    } else {
+                        *reinterpret_cast<float4*>(&sh.jl[cy][4 * c4]) =
+                            *reinterpret_cast<const float4*>(J + (size_t)lk_clampi(ry0 + cy, 0, h - 1) * w + xa4 + 4 * c4);
+                    }
                 }
             }
-            float dummy;
-            const int yt = lk_origin(lk_clampi(y - RADIUS, 0, h - 1), f.y, h, dummy);
-            const int yb_ = lk_origin(lk_clampi(y + RADIUS, 0, h - 1), f.y, h, dummy);
-            {
-                // window columns / rows are monotone in k / r, so the extremes are the first and the last
-                int bx0 = active ? xi_first : 0x7FFFFFFF, bx1 = active ? xi_last + 1 : -0x7FFFFFFF;
-                int by0 = active ? yt : 0x7FFFFFFF, by1 = active ? yb_ + 1 : -0x7FFFFFFF;
-                lk_wave_box(bx0, bx1, by0, by1);
-                // window columns that sample consecutive texels (x0[k+1] == x0[k] + 1: everywhere but at the left/right image
-                // border, where the clamped window columns repeat) share one row of N+1 texels; otherwise every column reads
-                // its own pair.  Decided per workgroup, through the same exchange as the box (no barrier of its own).
-                const int cons = __all(consecutive || !active) ? 1 : 0;
-                // (slots alternate with the step: a step that reuses the staged rectangle has no second barrier, so a fast wave
-                // may write the next step's box while a slow one still reads this step's)
-                if (lane == 0) { int* b = sh.box[it & 1][wave]; b[0] = bx0; b[1] = bx1; b[2] = by0; b[3] = by1; b[4] = cons; }
+        } else {
+            const int cw = rx1 - rx0 + 1;
+            const int cx = tid & 127, cy0 = tid >> 7;            // 128 threads per row, two rows per pass
+            if (cx < cw) {
+                const int gxc = lk_clampi(rx0 + cx, 0, w - 1);
+                for (int cy = cy0; cy < chh; cy += 2) {
+                    if constexpr (U8) sh.jl[cy][cx] = (float)J8[(size_t)lk_clampi(ry0 + cy, 0, h - 1) * src_stride + gxc];
+                    else sh.jl[cy][cx] = J[(size_t)lk_clampi(ry0 + cy, 0, h - 1) * w + gxc];
+                }
             }
-            if constexpr (U8 && decltype(first)::value) lk_stage3_u8_spill<RADIUS>(sh.u8win, u8g);   // the window's bytes, requested in the prologue; same barrier as the box
-            if (it == 0) OFPS_LK_STAMP(1);
-            __syncthreads();                                                 // also: everybody is done reading jl[] of the previous step
-            if (it == 0) OFPS_LK_STAMP(2);
-            // (box[] holds the same numbers for every thread: read into SCALAR registers -- the rectangle's bounds live across
-            // the whole level, and as vector registers they were part of what got spilled around the row loop)
-            const int (*bq)[5] = sh.box[it & 1];
-            auto uni = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
-            const int xmin = min(min(uni(bq[0][0]), uni(bq[1][0])), min(uni(bq[2][0]), uni(bq[3][0])));
-            const int xmax = max(max(uni(bq[0][1]), uni(bq[1][1])), max(uni(bq[2][1]), uni(bq[3][1])));
-            const int bymin = min(min(uni(bq[0][2]), uni(bq[1][2])), min(uni(bq[2][2]), uni(bq[3][2])));
-            const int ymax = max(max(uni(bq[0][3]), uni(bq[1][3])), max(uni(bq[2][3]), uni(bq[3][3])));
-            all_consecutive = (uni(bq[0][4]) & uni(bq[1][4]) & uni(bq[2][4]) & uni(bq[3][4])) != 0;
-            const int fits = xmax >= xmin && xmax - xmin < S::LW && ymax - bymin < S::LH &&
-                             !(it == force_fall && ((tile_x + tile_y) & 1));
-            if (!fits) {                                                     // uniform: box[] is the same for every thread
-                if (threadIdx.x == 0) fb_tiles[atomicAdd(fb_count, 1u)] = make_uint2((uint32_t)tile_x | ((uint32_t)tile_y << 16), (uint32_t)it);
-                if (active) fb_flow[(size_t)y * w + x] = f;
-                return false;
+        }
+        st_x0 = rx0; st_x1 = rx1; st_y0 = ry0; st_y1 = ry1; st_xs = xs_new;
+    };
+
+    // ---- step 0's box exchange in front of the loop: the only place that touches the u8 window's staging registers, whose
+    // lives therefore end before the loop
+    if (iters > 0) {
+        box_exchange(0);
+        if constexpr (U8) lk_stage3_u8_spill<RADIUS>(sh.u8win, u8g);     // the window's bytes, requested in the prologue; same barrier as the box
+        OFPS_LK_STAMP(1);
+        __syncthreads();
+        OFPS_LK_STAMP(2);
+        // the tile records from the f32 copy of the u8 window: visible after the barrier that follows the first staging
+        if constexpr (U8) lk_stage3_u8_records<RADIUS>(sh.u8win, sh.tile, u8g.ox, u8g.vec, w, h, x0, y0);
+    }
+#pragma unroll 1
+    for (int it = 0; it < iters; ++it) {
+        if (it > 0) {
+            box_exchange(it);
+            __syncthreads();                                             // also: everybody is done reading jl[] of the previous step
+        }
+        // (box[] holds the same numbers for every thread: read into SCALAR registers -- the rectangle's bounds live across
+        // the whole level, and as vector registers they were part of what got spilled around the row loop)
+        const int (*bq)[4] = sh.box[it & 1];
+        const int xmin = min(min(uni(bq[0][0]), uni(bq[1][0])), min(uni(bq[2][0]), uni(bq[3][0])));
+        const int xmax = max(max(uni(bq[0][1]), uni(bq[1][1])), max(uni(bq[2][1]), uni(bq[3][1])));
+        const int bymin = min(min(uni(bq[0][2]), uni(bq[1][2])), min(uni(bq[2][2]), uni(bq[3][2])));
+        const int ymax = max(max(uni(bq[0][3]), uni(bq[1][3])), max(uni(bq[2][3]), uni(bq[3][3])));
+        const bool fits = xmax >= xmin && xmax - xmin < S::LW && ymax - bymin < S::LH &&
+                          !(it == force_fall && ((tile_x + tile_y) & 1));
+        bool pending = active;
+        // One pass for a tile whose rectangle fits (every pixel is a member); otherwise up to max_rounds grouping rounds.
+#pragma unroll 1
+        for (int round = 0;; ++round) {
+            bool member;
+            if (fits) {                                                      // uniform: box[] is the same for every thread
+                member = pending;
+                // The rectangle is staged with a margin and KEPT: a later step whose box still lies inside it (flows move by a
+                // fraction of a pixel per step once the coarser levels have done their work) reuses it -- no global loads, no
+                // second barrier in that step.
+                const bool inside = st_valid && xmin >= st_x0 && xmax <= st_x1 && bymin >= st_y0 && ymax <= st_y1;
+                if (!inside) {
+                    // margins: up to kJMargin pixels on every side, as far as the capacity allows
+                    const int mx = min(kJMargin, (S::LW - (xmax - xmin + 1)) / 2), my = min(kJMargin, (S::LH - (ymax - bymin + 1)) / 2);
+                    stage_rect(xmin - mx, xmax + mx, bymin - my, ymax + my);
+                    st_valid = true;
+                    __syncthreads();
+                }
+            } else {
+                if (round >= max_rounds) break;
+                // anchor of this round: the first pending pixel of the first wave that has one.  Its box is made again here (kept
+                // alive across the rows it would be four more registers around the hot loop of every tile).
+                remake_xy();
+                int a0, a1, b0, b1;
+                bool c1, c2;
+                lane_box(x, y, a0, a1, b0, b1, c1, c2);
+                int* an = sh.anchor[round & 1][wave];
+                const bool any_pending = __any(pending);
+                if (lane == 0) an[0] = any_pending ? 1 : 0;
+                if (pending) {                                               // the first active lane is the first pending one; every pending lane stores its numbers
+                    an[1] = uni(a0); an[2] = uni(a1); an[3] = uni(b0); an[4] = uni(b1);
+                }
+                __syncthreads();                                             // also: the previous round's members are done reading jl[]
+                const int (*aq)[8] = sh.anchor[round & 1];
+                const int h0 = uni(aq[0][0]), h1 = uni(aq[1][0]), h2 = uni(aq[2][0]), h3 = uni(aq[3][0]);
+                if (!(h0 | h1 | h2 | h3)) break;                             // uniform: nothing pending anywhere
+                const int wv = h0 ? 0 : h1 ? 1 : h2 ? 2 : 3;
+                const int A0 = uni(aq[wv][1]), A1 = uni(aq[wv][2]), B0 = uni(aq[wv][3]), B1 = uni(aq[wv][4]);
+                // the capacity-sized rectangle centred on the anchor's own box; its left edge on a multiple of 4 so that the
+                // 16-byte staging applies (a pixel's box is at most 2R + 2 wide and high: the anchor itself always fits)
+                const int rx0 = (A0 - (S::LW - 4 - (A1 - A0 + 1)) / 2) & ~3, rx1 = rx0 + S::LW - 1;
+                const int ry0 = B0 - (S::LH - (B1 - B0 + 1)) / 2, ry1 = ry0 + S::LH - 1;
+                member = pending && a0 >= rx0 && a1 <= rx1 && b0 >= ry0 && b1 <= ry1;
+                stage_rect(rx0, rx1, ry0, ry1);
+                st_valid = false;                                            // not the tile's rectangle: the next step stages its own
+                __syncthreads();
             }
-            // The current frame's rectangle is staged with a margin and KEPT: a later step whose box still lies inside it (flows
-            // move by a fraction of a pixel per step once the coarser levels have done their work) reuses it -- no global loads,
-            // no second barrier in that step.  Everything below is uniform (derived from box[]).
-            const bool inside = st_valid && xmin >= st_x0 && xmax <= st_x1 && bymin >= st_y0 && ymax <= st_y1;
-            if (!inside) {
-                // (thread index through an empty asm: the staging addresses are made here, per staging, not hoisted out of the step
-                // loop into registers that are then spilled for the whole level)
-                int tid = (int)threadIdx.x;
-                asm volatile("" : "+v"(tid));
-                if constexpr (U8 && decltype(first)::value) lk_stage3_u8_records<RADIUS>(sh.u8win, sh.tile, u8g.ox, u8g.vec, w, h, x0, y0);   // visible after the barrier that ends this block
-                // margins: up to kJMargin pixels on every side, as far as the capacity allows
-                const int mx = min(kJMargin, (S::LW - (xmax - xmin + 1)) / 2), my = min(kJMargin, (S::LH - (ymax - bymin + 1)) / 2);
-                const int rx0 = xmin - mx, rx1 = xmax + mx, ry0 = bymin - my, ry1 = ymax + my;
-                // rows [ry0, ry1] x columns [xs, rx1], xs = rx0 rounded down to a multiple of 4 when the padded rectangle lies
-                // inside the frame and the plane is 16-byte aligned (16-byte loads), rx0 otherwise
-                int xs_new = rx0;
-                const int chh = ry1 - ry0 + 1;
-                const int xa4 = rx0 & ~3, cw4 = (rx1 - xa4 + 4) >> 2;                        // float4 per row after padding
-                const bool vec = rx0 >= 0 && xa4 + 4 * cw4 <= w && 4 * cw4 <= S::JS &&
-                                 (U8 ? (src_stride & 3) == 0 && (reinterpret_cast<uintptr_t>(J8) & 3) == 0
-                                     : (w & 3) == 0 && (reinterpret_cast<uintptr_t>(J) & 15) == 0);
-                if (vec) {                                                   // uniform
-                    xs_new = xa4;
-                    // 32 lanes per rectangle row (cw4 <= JS / 4 <= 32), 8 rows per pass: no division by the run-time width
-                    static_assert(S::JS / 4 <= 32, "J staging assumes at most 32 float4 per rectangle row");
-                    const int c4 = tid & 31;
-                    if (c4 < cw4) {
-                        for (int cy = tid >> 5; cy < chh; cy += 8) {
-                            if constexpr (U8) {                              // four pixels per dword, converted on the way in
-                                const uint32_t q = *reinterpret_cast<const uint32_t*>(J8 + (size_t)lk_clampi(ry0 + cy, 0, h - 1) * src_stride + xa4 + 4 * c4);
-                                *reinterpret_cast<float4*>(&sh.jl[cy][4 * c4]) =
-                                    make_float4((float)(q & 0xFFu), (float)((q >> 8) & 0xFFu), (float)((q >> 16) & 0xFFu), (float)(q >> 24));
+            if (it == 0 && round == 0) OFPS_LK_STAMP(3);
+            if (member) {
+                const int xs = st_xs, ymin = st_y0;                          // origin of jl[][] in frame coordinates
+                // wave-uniform: every member lane's window columns / rows sample consecutive texels
+                const bool all_cons = __all(cons_x);
+                const bool fast_x = tile_in_x && all_cons;
+#ifdef OFPS_LK_X_SLOW_Y
+                const bool fast_y = false;
+#else
+                const bool fast_y = tile_in_y && __all(cons_y);
+#endif
+                float ax[N];
+                int xi0;                                                     // origin of window column 0 (all the consecutive-column rows need)
+                {
+                    int xr = x;
+                    asm volatile("" : "+v"(xr));                              // opaque: a second evaluation, not the first one kept alive
+                    if (fast_x) {
+                        // unclamped columns with floors 0 <= xi0, xi0 + 1, ... < w: no clamp is active, and for a sum fq >= 0 the
+                        // fraction fq - floor(fq) is exact, which is what v_fract_f32 returns -- the oracle's values in 3
+                        // operations per column instead of 7
+                        const float xf0 = (float)(xr - RADIUS);
+#pragma unroll
+                        for (int k = 0; k < N; ++k) {
+                            const float fq = (xf0 + (float)k) + f.x;            // (float)(x + k - R), exact, + u: the oracle's sum
+                            ax[k] = __builtin_amdgcn_fractf(fq);
+                            if (k == 0) xi0 = (int)__builtin_floorf(fq);
+                        }
+                    } else {
+                        float frac;
+#pragma unroll
+                        for (int k = 0; k < N; ++k) { const int o = lk_origin(lk_clampi(xr + k - RADIUS, 0, w - 1), f.x, w, frac); ax[k] = frac; if (k == 0) xi0 = o; }
+                    }
+                }
+                // hup[k] = horizontal interpolation of the UPPER sample row at column k.  The lower row of one window row is the
+                // upper row of the next whenever the sample row advanced by exactly one (always, away from the top/bottom
+                // border), and its interpolation j01 + ax[k] * (j11 - j01) is then the very expression the next row evaluates
+                // as j00 + ax[k] * (j10 - j00) on the same texels: carried over instead of recomputed -- same operations on the
+                // same inputs, 11 instead of 14 VALU operations per tap.  Decided per wave so the branch is uniform; recomputing
+                // is always correct.
+                float bx = 0.0f, by = 0.0f;
+                bool done = false;
+                if constexpr (RADIUS == 4 && OFPS_LK_SPEC_FMA) {
+                    if (all_cons) {
+                        // hand-scheduled rows (lk_row9_asm): two register sets alternate between "this row's texels, turned into
+                        // its interpolations" and "the previous row's interpolations", so the row loop runs in pairs
+                        float rr[19];
+                        int prev_yi = -0x7FFFFFFF;
+                        const uint32_t jl0 = (uint32_t)reinterpret_cast<uintptr_t>(&sh.jl[0][xi0 - xs]);
+                        const uint32_t tl0 = (uint32_t)reinterpret_cast<uintptr_t>(&sh.tile[ly][lx]);
+                        // rows of an interior tile whose floors are consecutive (fast_y): sample row of window row r = the first
+                        // one + r, its fraction v_fract_f32 of the oracle's sum (exact for sums >= 0, like the columns'), and the
+                        // upper sample row is always the one carried over -- 5 operations per row instead of a floor chain, two
+                        // clamps and a vote
+                        float yf0 = 0.0f;
+                        int yi0 = 0;
+                        if (fast_y) {
+                            int yr = y;
+                            asm volatile("" : "+v"(yr));
+                            yf0 = (float)(yr - RADIUS);
+                            yi0 = (int)__builtin_floorf(yf0 + f.y) - ymin;
+                        }
+                        auto row = [&](int r, auto parity, auto with_g, auto fasty) {
+                            constexpr int P = decltype(parity)::value;
+                            float ay;
+                            int yi;
+                            bool reuse;
+                            if constexpr (decltype(fasty)::value) {
+                                ay = __builtin_amdgcn_fractf((yf0 + (float)r) + f.y);
+                                yi = yi0 + r;
+                                reuse = r > 0;
                             } else {
-                                *reinterpret_cast<float4*>(&sh.jl[cy][4 * c4]) =
-                                    *reinterpret_cast<const float4*>(J + (size_t)lk_clampi(ry0 + cy, 0, h - 1) * w + xa4 + 4 * c4);
+                                yi = lk_origin(lk_clampi(y + r - RADIUS, 0, h - 1), f.y, h, ay) - ymin;
+                                // (the first row always makes its upper sample row: stated at compile time, so that the carried
+                                // registers are not live into the loop -- hipcc spilled their undefined contents around every step)
+                                reuse = r > 0 && __all(yi == prev_yi + 1);
+                                prev_yi = yi;
+                            }
+                            if (!reuse) {                              // the upper sample row is not the one carried over: make it
+                                const float* ra = &sh.jl[yi][xi0 - xs];
+                                float jb[N + 1];
+#pragma unroll
+                                for (int k = 0; k <= N; ++k) jb[k] = ra[k];
+#pragma unroll
+                                for (int k = 0; k < N; ++k) rr[P ? k : 10 + k] = lk_lerp(jb[k], jb[k + 1], ax[k]);
+                            }
+                            const uint32_t ja = jl0 + (uint32_t)(yi + 1) * (uint32_t)(S::JS * sizeof(float));
+                            const uint32_t ta = tl0 + (uint32_t)r * (uint32_t)(T::TW * sizeof(float4));
+                            if constexpr (decltype(with_g)::value) lk_row9_asm_g<P>(rr, ax, ay, bx, by, gxx, gxy, gyy, ja, ta);
+                            else lk_row9_asm<P>(rr, ax, ay, bx, by, ja, ta);
+                        };
+                        using P0 = std::integral_constant<int, 0>; using P1 = std::integral_constant<int, 1>;
+                        auto rows = [&](auto with_g, auto fasty) {
+                            row(0, P0{}, with_g, fasty);
+#pragma unroll 1
+                            for (int r = 1; r < N; r += 2) { row(r, P1{}, with_g, fasty); row(r + 1, P0{}, with_g, fasty); }
+                        };
+                        if (it == 0) {                                 // the level's first step also sums the structure tensor
+                            if (fast_y) rows(std::true_type{}, std::true_type{}); else rows(std::true_type{}, std::false_type{});
+                        } else {
+                            if (fast_y) rows(std::false_type{}, std::true_type{}); else rows(std::false_type{}, std::false_type{});
+                        }
+                        done = true;
+                    }
+                }
+                if (!done) {
+                    float hup[N];
+                    int prev_yi = -0x7FFFFFFF;
+                    if (all_cons) {
+                        const int xo = xi0 - xs;
+                        float jb[N + 1];
+                        // (measured and rejected: unrolling the row loop, fully or by two/three with ping-pong hup arrays -- hipcc
+                        // then hoists the next row's LDS reads, 104+ VGPRs, 4 waves per SIMD, 0.53 vs 0.50 ms)
+#pragma unroll 1
+                        for (int r = 0; r < N; ++r) {
+                            float ay;
+                            const int yi = lk_origin(lk_clampi(y + r - RADIUS, 0, h - 1), f.y, h, ay) - ymin;
+                            const bool reuse = __all(yi == prev_yi + 1);
+                            prev_yi = yi;
+                            if (!reuse) {
+                                const float* ra = &sh.jl[yi][xo];
+#pragma unroll
+                                for (int k = 0; k <= N; ++k) jb[k] = ra[k];
+#pragma unroll
+                                for (int k = 0; k < N; ++k) hup[k] = lk_lerp(jb[k], jb[k + 1], ax[k]);
+                            }
+                            const float* rb = &sh.jl[yi + 1][xo];
+#pragma unroll
+                            for (int k = 0; k <= N; ++k) jb[k] = rb[k];
+#pragma unroll
+                            for (int k = 0; k < N; ++k) {
+                                const float top = hup[k];
+                                const float bot = lk_lerp(jb[k], jb[k + 1], ax[k]);
+                                const lk_f4 t = lk_lds_read4(&sh.tile[ly + r][lx + k]);
+                                const float d = t.x - lk_lerp(top, bot, ay);
+                                lk_accum(t.y, d, bx);
+                                lk_accum(t.z, d, by);
+                                if (it == 0) { lk_accum(t.y, t.y, gxx); lk_accum(t.y, t.z, gxy); lk_accum(t.z, t.z, gyy); }
+                                hup[k] = bot;
+                            }
+                        }
+                    } else {
+                        // (image-border tiles and windows across a binade only: every column's own origin, made here -- kept alive
+                        // from the pass above they were spilled around the hand-scheduled rows of every other tile)
+                        int xi[N];
+                        {
+                            int xr = x;
+                            asm volatile("" : "+v"(xr));
+                            float frac;
+#pragma unroll
+                            for (int k = 0; k < N; ++k) xi[k] = lk_origin(lk_clampi(xr + k - RADIUS, 0, w - 1), f.x, w, frac) - xs;
+                        }
+#pragma unroll 1
+                        for (int r = 0; r < N; ++r) {
+                            float ay;
+                            const int yi = lk_origin(lk_clampi(y + r - RADIUS, 0, h - 1), f.y, h, ay) - ymin;
+                            const bool reuse = __all(yi == prev_yi + 1);
+                            prev_yi = yi;
+                            if (!reuse) {
+                                const float* ra = &sh.jl[yi][0];
+#pragma unroll
+                                for (int k = 0; k < N; ++k) { const float j0 = ra[xi[k]], j1 = ra[xi[k] + 1]; hup[k] = lk_lerp(j0, j1, ax[k]); }
+                            }
+                            const float* rb = &sh.jl[yi + 1][0];
+#pragma unroll
+                            for (int k = 0; k < N; ++k) {
+                                const float j0 = rb[xi[k]], j1 = rb[xi[k] + 1];
+                                const float top = hup[k];
+                                const float bot = lk_lerp(j0, j1, ax[k]);
+                                const lk_f4 t = lk_lds_read4(&sh.tile[ly + r][lx + k]);
+                                const float d = t.x - lk_lerp(top, bot, ay);
+                                lk_accum(t.y, d, bx);
+                                lk_accum(t.z, d, by);
+                                if (it == 0) { lk_accum(t.y, t.y, gxx); lk_accum(t.y, t.z, gxy); lk_accum(t.z, t.z, gyy); }
+                                hup[k] = bot;
                             }
                         }
                     }
-                } else {
-                    const int cw = rx1 - rx0 + 1;
-                    const int cx = tid & 127, cy0 = tid >> 7;            // 128 threads per row, two rows per pass
-                    if (cx < cw) {
-                        const int gxc = lk_clampi(rx0 + cx, 0, w - 1);
-                        for (int cy = cy0; cy < chh; cy += 2) {
-                            if constexpr (U8) sh.jl[cy][cx] = (float)J8[(size_t)lk_clampi(ry0 + cy, 0, h - 1) * src_stride + gxc];
-                            else sh.jl[cy][cx] = J[(size_t)lk_clampi(ry0 + cy, 0, h - 1) * w + gxc];
-                        }
-                    }
                 }
-                st_valid = true; st_x0 = rx0; st_x1 = rx1; st_y0 = ry0; st_y1 = ry1; st_xs = xs_new;
-                __syncthreads();
+#ifdef OFPS_LK_X_NO_UPDATE                                  // timing experiments only: the arithmetic runs, the flow stays what it was
+                { const float2 fn = lk_solve(make_float4(gxx, gxy, gyy, 0.0f), f, bx, by); asm volatile("" :: "v"(fn.x), "v"(fn.y)); }
+#else
+                f = lk_solve(make_float4(gxx, gxy, gyy, 0.0f), f, bx, by);
+#endif
+                pending = false;
             }
-        return true;
-    };
-    if (iters > 0 && !front(0, std::true_type{})) return;
-#pragma unroll 1
-    for (int it = 0; it < iters; ++it) {
-        if (it > 0 && !front(it, std::false_type{})) return;
-        const int xs = st_xs, ymin = st_y0;                              // origin of jl[][] in frame coordinates
-        float ax[N];
-        int xi0;                                                         // origin of window column 0 (all the consecutive-column rows need)
-        {
-            int xr = x;
-            asm volatile("" : "+v"(xr));                                  // opaque: a second evaluation, not the first one kept alive
-            if (tile_in_x && all_consecutive) {
-                // unclamped columns with floors 0 <= xi0, xi0 + 1, ... <= w (front()): no clamp is active, and for a sum
-                // fq >= 0 the fraction fq - floor(fq) is exact, which is what v_fract_f32 returns -- the oracle's values in
-                // 3 operations per column instead of 7
-                const float xf0 = (float)(xr - RADIUS);
-#pragma unroll
-                for (int k = 0; k < N; ++k) {
-                    const float fq = (xf0 + (float)k) + f.x;                // (float)(x + k - R), exact, + u: the oracle's sum
-                    ax[k] = __builtin_amdgcn_fractf(fq);
-                    if (k == 0) xi0 = (int)__builtin_floorf(fq);
-                }
-            } else {
-                float frac;
-#pragma unroll
-                for (int k = 0; k < N; ++k) { const int o = lk_origin(lk_clampi(xr + k - RADIUS, 0, w - 1), f.x, w, frac); ax[k] = frac; if (k == 0) xi0 = o; }
-            }
+            if (fits) break;
         }
-        if (it == 0) OFPS_LK_STAMP(3);
-        if (active) {
-            // hup[k] = horizontal interpolation of the UPPER sample row at column k.  The lower row of one window row is the
-            // upper row of the next whenever the sample row advanced by exactly one (always, away from the top/bottom
-            // border), and its interpolation j01 + ax[k] * (j11 - j01) is then the very expression the next row evaluates
-            // as j00 + ax[k] * (j10 - j00) on the same texels: carried over instead of recomputed -- same operations on the
-            // same inputs, 11 instead of 14 VALU operations per tap.  Decided per wave so the branch is uniform; recomputing
-            // is always correct.
+        if (!fits && pending) {
+            // Leftover of a tile without coherent flows: the oracle's per-sample form for this pixel, the current frame read from
+            // global memory (two clamped texel pairs per tap), the previous frame's records from the tile.  Small and slow on
+            // purpose (it bounds the work of an incoherent tile at what the per-lane-gather kernel of rounds 2-3 cost); same
+            // operands, same operations, same order as every other path.
             float bx = 0.0f, by = 0.0f;
-            bool done = false;
-            if constexpr (RADIUS == 4 && OFPS_LK_SPEC_FMA) {
-                if (all_consecutive) {
-                    // hand-scheduled rows (lk_row9_asm): two register sets alternate between "this row's texels, turned into
-                    // its interpolations" and "the previous row's interpolations", so the row loop runs in pairs
-                    float rr[19];
-                    int prev_yi = -0x7FFFFFFF;
-                    const uint32_t jl0 = (uint32_t)reinterpret_cast<uintptr_t>(&sh.jl[0][xi0 - xs]);
-                    const uint32_t tl0 = (uint32_t)reinterpret_cast<uintptr_t>(&sh.tile[ly][lx]);
-                    auto row = [&](int r, auto parity, auto with_g) {
-                        constexpr int P = decltype(parity)::value;
-                        float ay;
-                        const int yi = lk_origin(lk_clampi(y + r - RADIUS, 0, h - 1), f.y, h, ay) - ymin;
-                        // (the first row always makes its upper sample row: stated at compile time, so that the carried
-                        // registers are not live into the loop -- hipcc spilled their undefined contents around every step)
-                        const bool reuse = r > 0 && __all(yi == prev_yi + 1);
-                        prev_yi = yi;
-                        if (!reuse) {                              // the upper sample row is not the one carried over: make it
-                            const float* ra = &sh.jl[yi][xi0 - xs];
-                            float jb[N + 1];
-#pragma unroll
-                            for (int k = 0; k <= N; ++k) jb[k] = ra[k];
-#pragma unroll
-                            for (int k = 0; k < N; ++k) rr[P ? k : 10 + k] = lk_lerp(jb[k], jb[k + 1], ax[k]);
-                        }
-                        const uint32_t ja = jl0 + (uint32_t)(yi + 1) * (uint32_t)(S::JS * sizeof(float));
-                        const uint32_t ta = tl0 + (uint32_t)r * (uint32_t)(T::TW * sizeof(float4));
-                        if constexpr (decltype(with_g)::value) lk_row9_asm_g<P>(rr, ax, ay, bx, by, gxx, gxy, gyy, ja, ta);
-                        else lk_row9_asm<P>(rr, ax, ay, bx, by, ja, ta);
-                    };
-                    using P0 = std::integral_constant<int, 0>; using P1 = std::integral_constant<int, 1>;
-                    if (it == 0) {                                 // the level's first step also sums the structure tensor
-                        row(0, P0{}, std::true_type{});
+            const int jpitch = U8 ? src_stride : w;
+            auto jat = [&](size_t idx) -> float { if constexpr (U8) return (float)J8[idx]; else return J[idx]; };
+            int xr = x, yr = y;
+            asm volatile("" : "+v"(xr), "+v"(yr));
 #pragma unroll 1
-                        for (int r = 1; r < N; r += 2) { row(r, P1{}, std::true_type{}); row(r + 1, P0{}, std::true_type{}); }
-                    } else {
-                        row(0, P0{}, std::false_type{});
+            for (int r = 0; r < N; ++r) {
+                float ay;
+                const int yi = lk_origin(lk_clampi(yr + r - RADIUS, 0, h - 1), f.y, h, ay);
+                const size_t ra = (size_t)lk_clampi(yi, 0, h - 1) * jpitch, rb = (size_t)lk_clampi(yi + 1, 0, h - 1) * jpitch;
 #pragma unroll 1
-                        for (int r = 1; r < N; r += 2) { row(r, P1{}, std::false_type{}); row(r + 1, P0{}, std::false_type{}); }
-                    }
-                    done = true;
-                }
-            }
-            if (!done) {
-                float hup[N];
-                int prev_yi = -0x7FFFFFFF;
-                if (all_consecutive) {
-                    const int xo = xi0 - xs;
-                    float jb[N + 1];
-                    // (measured and rejected: unrolling the row loop, fully or by two/three with ping-pong hup arrays -- hipcc
-                    // then hoists the next row's LDS reads, 104+ VGPRs, 4 waves per SIMD, 0.53 vs 0.50 ms)
-    #pragma unroll 1
-                    for (int r = 0; r < N; ++r) {
-                        float ay;
-                        const int yi = lk_origin(lk_clampi(y + r - RADIUS, 0, h - 1), f.y, h, ay) - ymin;
-                        const bool reuse = __all(yi == prev_yi + 1);
-                        prev_yi = yi;
-                        if (!reuse) {
-                            const float* ra = &sh.jl[yi][xo];
-    #pragma unroll
-                            for (int k = 0; k <= N; ++k) jb[k] = ra[k];
-    #pragma unroll
-                            for (int k = 0; k < N; ++k) hup[k] = lk_lerp(jb[k], jb[k + 1], ax[k]);
-                        }
-                        const float* rb = &sh.jl[yi + 1][xo];
-    #pragma unroll
-                        for (int k = 0; k <= N; ++k) jb[k] = rb[k];
-    #pragma unroll
-                        for (int k = 0; k < N; ++k) {
-                            const float top = hup[k];
-                            const float bot = lk_lerp(jb[k], jb[k + 1], ax[k]);
-                            const lk_f4 t = lk_lds_read4(&sh.tile[ly + r][lx + k]);
-                            const float d = t.x - lk_lerp(top, bot, ay);
-                            lk_accum(t.y, d, bx);
-                            lk_accum(t.z, d, by);
-                            if (it == 0) { lk_accum(t.y, t.y, gxx); lk_accum(t.y, t.z, gxy); lk_accum(t.z, t.z, gyy); }
-                            hup[k] = bot;
-                        }
-                    }
-                } else {
-                    // (image-border tiles only: every column's own origin, made here -- kept alive from the pass above they
-                    // were spilled around the hand-scheduled rows of every other tile)
-                    int xi[N];
-                    {
-                        int xr = x;
-                        asm volatile("" : "+v"(xr));
-                        float frac;
-    #pragma unroll
-                        for (int k = 0; k < N; ++k) xi[k] = lk_origin(lk_clampi(xr + k - RADIUS, 0, w - 1), f.x, w, frac) - xs;
-                    }
-    #pragma unroll 1
-                    for (int r = 0; r < N; ++r) {
-                        float ay;
-                        const int yi = lk_origin(lk_clampi(y + r - RADIUS, 0, h - 1), f.y, h, ay) - ymin;
-                        const bool reuse = __all(yi == prev_yi + 1);
-                        prev_yi = yi;
-                        if (!reuse) {
-                            const float* ra = &sh.jl[yi][0];
-    #pragma unroll
-                            for (int k = 0; k < N; ++k) { const float j0 = ra[xi[k]], j1 = ra[xi[k] + 1]; hup[k] = lk_lerp(j0, j1, ax[k]); }
-                        }
-                        const float* rb = &sh.jl[yi + 1][0];
-    #pragma unroll
-                        for (int k = 0; k < N; ++k) {
-                            const float j0 = rb[xi[k]], j1 = rb[xi[k] + 1];
-                            const float top = hup[k];
-                            const float bot = lk_lerp(j0, j1, ax[k]);
-                            const lk_f4 t = lk_lds_read4(&sh.tile[ly + r][lx + k]);
-                            const float d = t.x - lk_lerp(top, bot, ay);
-                            lk_accum(t.y, d, bx);
-                            lk_accum(t.z, d, by);
-                            if (it == 0) { lk_accum(t.y, t.y, gxx); lk_accum(t.y, t.z, gxy); lk_accum(t.z, t.z, gyy); }
-                            hup[k] = bot;
-                        }
-                    }
+                for (int k = 0; k < N; ++k) {
+                    float axk;
+                    const int xi = lk_origin(lk_clampi(xr + k - RADIUS, 0, w - 1), f.x, w, axk);
+                    const int xa = lk_clampi(xi, 0, w - 1), xb = lk_clampi(xi + 1, 0, w - 1);
+                    const float top = lk_lerp(jat(ra + xa), jat(ra + xb), axk);
+                    const float bot = lk_lerp(jat(rb + xa), jat(rb + xb), axk);
+                    const lk_f4 t = lk_lds_read4(&sh.tile[ly + r][lx + k]);
+                    const float d = t.x - lk_lerp(top, bot, ay);
+                    lk_accum(t.y, d, bx);
+                    lk_accum(t.z, d, by);
+                    if (it == 0) { lk_accum(t.y, t.y, gxx); lk_accum(t.y, t.z, gxy); lk_accum(t.z, t.z, gyy); }
                 }
             }
             f = lk_solve(make_float4(gxx, gxy, gyy, 0.0f), f, bx, by);
@@ -1079,96 +1212,6 @@ __global__ __launch_bounds__(256, LkStepShared<RADIUS>::WAVES_PER_SIMD) void lk_
     }
     OFPS_LK_STAMP(5);
 #undef OFPS_LK_STAMP
-}
-
-// second launch: the listed (tile, first step) pairs, per-lane gathers from global memory with register reuse (inside a
-// window row j10 of column k is j00 of column k+1 whenever xb[k] == xa[k+1], and the bottom row of one window row is
-// the top row of the next whenever yb == next ya -- both almost always true; the rare exceptions reload)
-template <int RADIUS, bool U8>
-__global__ __launch_bounds__(256) void lk_level_general_kernel(const void* __restrict__ I_, const void* __restrict__ J_,
-                                                               const float* __restrict__ gx, const float* __restrict__ gy, int src_stride,
-                                                               int w, int h, int iters, const LkFlowIO io,
-                                                               const uint32_t* __restrict__ fb_count,
-                                                               const uint2* __restrict__ fb_tiles,
-                                                               const float2* fb_flow) {
-    using T = LkTile<RADIUS>;
-    constexpr int N = T::N;
-    __shared__ float4 tile[T::TH][T::TW];
-    __shared__ __attribute__((aligned(16))) float u8win[U8 ? LkU8Window<RADIUS>::FLOATS : 4];
-    const float* I = static_cast<const float*>(I_);
-    // the current frame, read per lane: an f32 plane (row pitch w) or the u8 frame itself (row pitch src_stride)
-    const float* Jf = static_cast<const float*>(J_);
-    const uint8_t* J8 = static_cast<const uint8_t*>(J_);
-    const int jpitch = U8 ? src_stride : w;
-    auto jat = [&](size_t idx) -> float { if constexpr (U8) return (float)J8[idx]; else return Jf[idx]; };
-    const uint32_t count = *fb_count;
-    for (uint32_t li = blockIdx.x; li < count; li += gridDim.x) {
-        const uint2 id = fb_tiles[li];
-        const int x0 = (int)(id.x & 0xFFFFu) * kTX, y0 = (int)(id.x >> 16) * kTY;
-        __syncthreads();                                   // the previous tile's readers are done with `tile`
-        if constexpr (U8) lk_stage3_u8<RADIUS>(static_cast<const uint8_t*>(I_), src_stride, u8win, tile, w, h, x0, y0);
-        else lk_stage3<RADIUS>(I, gx, gy, tile, w, h, x0, y0);
-        __syncthreads();
-        const int lx = threadIdx.x % kTX, ly = threadIdx.x / kTX, x = x0 + lx, y = y0 + ly;
-        if (x >= w || y >= h) continue;
-        float2 f = fb_flow[(size_t)y * w + x];
-        // the structure tensor, from the staged window in the spec's order (dy outer, dx inner): the same sums the level
-        // kernel's first step makes, whichever step the tile fell at
-        float4 g = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-#pragma unroll 1
-        for (int r = 0; r < N; ++r) {
-#pragma unroll
-            for (int k = 0; k < N; ++k) {
-                const float4 t = tile[ly + r][lx + k];
-                lk_accum(t.y, t.y, g.x); lk_accum(t.y, t.z, g.y); lk_accum(t.z, t.z, g.z);
-            }
-        }
-        for (int it = (int)id.y; it < iters; ++it) {
-            int xa[N], xb[N];
-            float ax[N];
-#pragma unroll
-            for (int k = 0; k < N; ++k) {
-                const int xi = lk_origin(lk_clampi(x + k - RADIUS, 0, w - 1), f.x, w, ax[k]);
-                xa[k] = lk_clampi(xi, 0, w - 1); xb[k] = lk_clampi(xi + 1, 0, w - 1);
-            }
-            float bx = 0.0f, by = 0.0f;
-            float jt[N + 1], jb[N + 1];          // rows ya / yb of the current frame at columns xa[0..N-1], xb[N-1]
-            int prev_yb = -1;
-#pragma unroll 1
-            for (int r = 0; r < N; ++r) {
-                float ay;
-                const int yi = lk_origin(lk_clampi(y + r - RADIUS, 0, h - 1), f.y, h, ay);
-                const int ya = lk_clampi(yi, 0, h - 1), yb = lk_clampi(yi + 1, 0, h - 1);
-                const size_t ra = (size_t)ya * jpitch, rb = (size_t)yb * jpitch;
-                if (ya == prev_yb) {
-#pragma unroll
-                    for (int k = 0; k <= N; ++k) jt[k] = jb[k];
-                } else {
-#pragma unroll
-                    for (int k = 0; k < N; ++k) jt[k] = jat(ra + xa[k]);
-                    jt[N] = jat(ra + xb[N - 1]);
-                }
-#pragma unroll
-                for (int k = 0; k < N; ++k) jb[k] = jat(rb + xa[k]);
-                jb[N] = jat(rb + xb[N - 1]);
-                prev_yb = yb;
-#pragma unroll
-                for (int k = 0; k < N; ++k) {
-                    float j10 = jt[k + 1], j11 = jb[k + 1];
-                    if (k < N - 1 && xb[k] != xa[k + 1]) { j10 = jat(ra + xb[k]); j11 = jat(rb + xb[k]); }     // clamped border / rounding: rare
-                    const float j00 = jt[k], j01 = jb[k];
-                    const float top = lk_lerp(j00, j10, ax[k]);
-                    const float bot = lk_lerp(j01, j11, ax[k]);
-                    const float4 t = tile[ly + r][lx + k];
-                    const float d = t.x - lk_lerp(top, bot, ay);
-                    lk_accum(t.y, d, bx);
-                    lk_accum(t.z, d, by);
-                }
-            }
-            f = lk_solve(g, f, bx, by);
-        }
-        lk_store(f, x, y, w, io);
-    }
 }
 
 // cv-decoder/src/lib.rs:239-243,262-269: per-pixel records, raster order
@@ -1190,7 +1233,7 @@ static dim3 lk_grid_xcd(int w, int h, int tx = 64, int ty = 4) {
 // d_prev/d_cur: u8 luma on the device.  d_flow: W*H float2.  Workspace comes from the context.
 // d_flow (W*H float2) and/or d_entries (W*H float4 records) receive the result; at least one of them.
 int lk_flow_device(ofps_hip_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_cur, int W, int H, int stride, int levels,
-                   int radius, int iters, float2* d_flow, float4* d_entries) {
+                   int radius, int iters, float2* d_flow, float4* d_entries, const float2* d_init = nullptr) {
     OFPS_REQUIRE(ctx, W >= 1 && H >= 1 && stride >= W, "lk_flow: bad geometry W=%d H=%d stride=%d", W, H, stride);
     OFPS_REQUIRE(ctx, levels >= 1 && levels <= 8 && radius >= 1 && radius <= 15 && iters >= 1 && iters <= 64,
                  "lk_flow: levels=%d radius=%d iters=%d out of range", levels, radius, iters);
@@ -1213,40 +1256,28 @@ int lk_flow_device(ofps_hip_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_cu
     float2* fa = reinterpret_cast<float2*>(reinterpret_cast<float*>(Gp) + 4 * pyr);
     float2* fb = fa + plane0;
 
-    // per level: the (tile, first step) pairs the LDS kernel hands to the general kernel, and where their flows are parked
     const size_t tiles0 = (size_t)((W + kTX - 1) / kTX) * (size_t)((H + kTY - 1) / kTY);     // tiles of the tiled kernels at level 0
     const bool tiled = radius == 2 || radius == 4 || radius == 6;      // kernels that run a whole level and fold the upsample / record passes in
-    uint32_t* fb_count = nullptr;
-    uint2* fb_tiles = nullptr;
     unsigned long long* prof = nullptr;                           // OFPS_HIP_LK_PROF=1: phase table of level 0
-    if (tiled) {
-        const size_t head = ((size_t)levels + 1) & ~size_t(1);     // keeps the uint2 list 8-byte aligned
-        fb_count = static_cast<uint32_t*>(scratch(ctx, S_WORK3, (head + 2 * (size_t)levels * tiles0) * sizeof(uint32_t)));
-        if (!fb_count) return OFPS_HIP_ENOMEM;
-        fb_tiles = reinterpret_cast<uint2*>(fb_count + head);
-        if (ctx->opt.lk_prof) {
-            prof = static_cast<unsigned long long*>(scratch(ctx, S_WORK2, tiles0 * 6 * sizeof(unsigned long long)));
-            if (!prof) return OFPS_HIP_ENOMEM;
-        }
+    if (tiled && ctx->opt.lk_prof) {
+        prof = static_cast<unsigned long long*>(scratch(ctx, S_WORK2, tiles0 * 6 * sizeof(unsigned long long)));
+        if (!prof) return OFPS_HIP_ENOMEM;
     }
     if (levels >= 2) {                                            // level 1 from the u8 frames
         // (the tiled path's level 0 works on the u8 frames themselves: no f32 level-0 planes, no level-0 gradient planes)
         dim3 g2 = lk_grid_xcd(ws[1], hs[1], kP0X, kP0Y); g2.z = 2;
         hipLaunchKernelGGL(lk_pyr0_kernel<uint8_t>, g2, dim3(256), 0, s, d_prev, d_cur, W, H, stride, tiled ? (float*)nullptr : Ip,
                            tiled ? (float*)nullptr : Jp, Ip + off[1], Jp + off[1], ws[1], hs[1], tiled ? (float*)nullptr : gxp,
-                           tiled ? (float*)nullptr : gyp, fb_count, fb_count ? levels : 0);
-    } else if (tiled) {
-        OFPS_HIP_TRY(ctx, hipMemsetAsync(fb_count, 0, (size_t)levels * sizeof(uint32_t), s));       // the hand-over counters
-    } else {
+                           tiled ? (float*)nullptr : gyp);
+    } else if (!tiled) {
         dim3 g2 = lk_grid(W, H); g2.z = 2;
-        hipLaunchKernelGGL(lk_u8_to_f32_pair_kernel, g2, dim3(256), 0, s, d_prev, d_cur, W, H, stride, Ip, Jp, fb_count,
-                           fb_count ? levels : 0);
+        hipLaunchKernelGGL(lk_u8_to_f32_pair_kernel, g2, dim3(256), 0, s, d_prev, d_cur, W, H, stride, Ip, Jp);
     }
     for (int l = 2; l < levels; ++l) {                            // level l from level l-1, whose gradients come out of the same window
         dim3 g2 = lk_grid_xcd(ws[l], hs[l], kP0X, kP0Y); g2.z = 2;
         hipLaunchKernelGGL(lk_pyr0_kernel<float>, g2, dim3(256), 0, s, (const float*)(Ip + off[l - 1]), (const float*)(Jp + off[l - 1]),
                            ws[l - 1], hs[l - 1], ws[l - 1], (float*)nullptr, (float*)nullptr, Ip + off[l], Jp + off[l], ws[l], hs[l],
-                           gxp + off[l - 1], gyp + off[l - 1], (uint32_t*)nullptr, 0);
+                           gxp + off[l - 1], gyp + off[l - 1]);
     }
     float2* cur_flow = fa;
     float2* other = fb;
@@ -1276,32 +1307,21 @@ int lk_flow_device(ofps_hip_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_cu
         if (tiled) {
             // one launch runs all `iters` steps of the level: in = the coarser level's flow (cur_flow), out = `other`
             const bool last = l == 0;
-            uint32_t* cnt = fb_count + l;
-            uint2* tiles = fb_tiles + (size_t)l * tiles0;
-            const unsigned ntiles = (unsigned)((w + kTX - 1) / kTX) * (unsigned)((h + kTY - 1) / kTY);
-            const dim3 gg(ntiles < (unsigned)(8 * ctx->num_cus) ? ntiles : (unsigned)(8 * ctx->num_cus));
             LkFlowIO io{};
             io.coarse = l == levels - 1 ? nullptr : cur_flow;
-            io.w1 = l + 1 < levels ? ws[l + 1] : 0; io.h1 = l + 1 < levels ? hs[l + 1] : 0;
+            io.init = l == levels - 1 ? d_init : nullptr;
+            io.w1 = l + 1 < levels ? ws[l + 1] : w; io.h1 = l + 1 < levels ? hs[l + 1] : h;
             io.flow_out = last ? d_flow : other;                       // the last level skips the flow plane nobody asked for
             io.out_entries = last ? d_entries : nullptr;
             io.nx = 1.0f / (float)W; io.ny = 1.0f / (float)H;
-            // fallen tiles park their flow in `other`: never the level's input (neighbouring tiles still read `coarse`);
-            // at the last level `other` is free, elsewhere it is the level's output plane, where a pixel's parked flow
-            // is read back by the very thread that later overwrites it with the result
-            float2* park = other;
 #define OFPS_LK_LEVEL(R)                                                                                                     \
     if (last) {            /* level 0: straight from the u8 frames */                                                       \
         hipLaunchKernelGGL((lk_level_lds_kernel<R, true>), lk_grid_xcd(w, h, kTX, kTY), dim3(256), 0, s, (const void*)d_prev, (const void*)d_cur,        \
-                           (const float*)nullptr, (const float*)nullptr, stride, w, h, iters, io, cnt, tiles, park, prof, force_fall);                 \
-        hipLaunchKernelGGL((lk_level_general_kernel<R, true>), gg, dim3(256), 0, s, (const void*)d_prev, (const void*)d_cur, (const float*)nullptr,       \
-                           (const float*)nullptr, stride, w, h, iters, io, cnt, tiles, park);                                                         \
+                           (const float*)nullptr, (const float*)nullptr, stride, w, h, iters, io, prof, force_fall);                                  \
     } else {                                                                                                                \
         hipLaunchKernelGGL((lk_level_lds_kernel<R, false>), lk_grid_xcd(w, h, kTX, kTY), dim3(256), 0, s, (const void*)(Ip + off[l]),                     \
-                           (const void*)(Jp + off[l]), (const float*)gx, (const float*)gy, w, w, h, iters, io, cnt, tiles, park,                       \
-                           (unsigned long long*)nullptr, force_fall);                                                                                 \
-        hipLaunchKernelGGL((lk_level_general_kernel<R, false>), gg, dim3(256), 0, s, (const void*)(Ip + off[l]), (const void*)(Jp + off[l]),              \
-                           (const float*)gx, (const float*)gy, w, w, h, iters, io, cnt, tiles, park);                                                 \
+                           (const void*)(Jp + off[l]), (const float*)gx, (const float*)gy, w, w, h, iters, io, (unsigned long long*)nullptr,         \
+                           force_fall);                                                                                                               \
     }
             switch (radius) {
                 case 2: OFPS_LK_LEVEL(2); break;
@@ -1314,7 +1334,8 @@ int lk_flow_device(ofps_hip_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_cu
         }
         hipLaunchKernelGGL(lk_tensor_kernel, lk_grid(w, h), dim3(256), 0, s, gx, gy, w, h, radius, G);
         if (l == levels - 1) {
-            OFPS_HIP_TRY(ctx, hipMemsetAsync(cur_flow, 0, (size_t)w * h * sizeof(float2), s));
+            if (d_init) OFPS_HIP_TRY(ctx, hipMemcpyAsync(cur_flow, d_init, (size_t)w * h * sizeof(float2), hipMemcpyDeviceToDevice, s));
+            else OFPS_HIP_TRY(ctx, hipMemsetAsync(cur_flow, 0, (size_t)w * h * sizeof(float2), s));
         } else {
             hipLaunchKernelGGL(lk_upsample_kernel, lk_grid(w, h), dim3(256), 0, s, cur_flow, ws[l + 1], hs[l + 1], other, w, h);
             float2* t = cur_flow; cur_flow = other; other = t;
@@ -1351,6 +1372,8 @@ int lk_flow_device(ofps_hip_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_cu
 
 extern "C" {
 
+int ofps_hip_lk_spec_revision(void) { return OFPS_LK_SPEC_FMA ? 2 : 1; }
+
 int ofps_hip_lk_flow_dev(ofps_hip_ctx* ctx, const void* d_prev, const void* d_cur, int W, int H, int stride, int levels,
                          int radius, int iters, void* d_out_flow, void* d_out_entries) {
     if (!ctx) return OFPS_HIP_EINVAL;
@@ -1358,6 +1381,16 @@ int ofps_hip_lk_flow_dev(ofps_hip_ctx* ctx, const void* d_prev, const void* d_cu
     OFPS_HIP_TRY(ctx, hipSetDevice(ctx->device));
     return ofps::lk_flow_device(ctx, static_cast<const uint8_t*>(d_prev), static_cast<const uint8_t*>(d_cur), W, H, stride, levels,
                                 radius, iters, static_cast<float2*>(d_out_flow), static_cast<float4*>(d_out_entries));
+}
+
+int ofps_hip_lk_flow_init_dev(ofps_hip_ctx* ctx, const void* d_prev, const void* d_cur, int W, int H, int stride, int levels,
+                              int radius, int iters, const void* d_init_flow, void* d_out_flow, void* d_out_entries) {
+    if (!ctx) return OFPS_HIP_EINVAL;
+    OFPS_REQUIRE(ctx, d_prev && d_cur && (d_out_flow || d_out_entries), "lk_flow_init: null device pointer");
+    OFPS_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return ofps::lk_flow_device(ctx, static_cast<const uint8_t*>(d_prev), static_cast<const uint8_t*>(d_cur), W, H, stride, levels,
+                                radius, iters, static_cast<float2*>(d_out_flow), static_cast<float4*>(d_out_entries),
+                                static_cast<const float2*>(d_init_flow));
 }
 
 // The body of a "hip_lk" Decoder::process_frame (cv-decoder/src/lib.rs:82-294): dense flow, per-pixel records,

@@ -35,11 +35,30 @@ def frame_range(n_pairs: int, world: int, rank: int, ref_mode: int = 0) -> tuple
     return first + 1, count
 
 
+def _host_collectives() -> bool:
+    """True when the process group cannot take device tensors (gloo: the CPU tests, and the one-GPU rehearsal of an N-rank
+    run -- bench.py --backend gloo --device-map 0,0 -- where RCCL refuses two ranks on one device)."""
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized() and dist.get_backend() == "gloo"
+
+
+def _coll_device(device):
+    import torch
+    return torch.device("cpu") if _host_collectives() else device
+
+
 def broadcast_reference(frame, src: int = 0):
-    """In-place broadcast of the shared reference frame (torch tensor, device or host)."""
+    """In-place broadcast of the shared reference frame (torch tensor, device or host).  Under gloo a device tensor travels
+    through a host copy (the source rank's bytes out, everybody's bytes in)."""
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.broadcast(frame, src=src)
+        if frame.is_cuda and _host_collectives():
+            host = frame.cpu()
+            dist.broadcast(host, src=src)
+            if dist.get_rank() != src:
+                frame.copy_(host)
+        else:
+            dist.broadcast(frame, src=src)
     return frame
 
 
@@ -51,6 +70,8 @@ def gather_results(local, n_pairs: int):
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return local
     world = dist.get_world_size()
+    if local.is_cuda and _host_collectives():
+        local = local.cpu()                                   # gloo: the table is gathered (and returned) on the host
     counts = [pair_range(n_pairs, world, r)[1] for r in range(world)]
     cap = max(counts) if counts else 0
     pad = torch.zeros((cap,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
@@ -65,7 +86,7 @@ def max_over_ranks(value: float, device=None) -> float:
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return value
-    t = torch.tensor([value], dtype=torch.float64, device=device)
+    t = torch.tensor([value], dtype=torch.float64, device=_coll_device(device))
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
@@ -130,7 +151,7 @@ class StreamBarrier:
 
     def __init__(self, device):
         import torch
-        self._token = torch.zeros(1, dtype=torch.int32, device=device) if active() else None
+        self._token = torch.zeros(1, dtype=torch.int32, device=_coll_device(device)) if active() else None
 
     def __call__(self):
         import torch.distributed as dist
@@ -145,7 +166,7 @@ def ranks_seen(device=None) -> int:
     import torch.distributed as dist
     if not active():
         return 1
-    t = torch.ones(1, dtype=torch.int32, device=device)
+    t = torch.ones(1, dtype=torch.int32, device=_coll_device(device))
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return int(t.item())
 
@@ -155,7 +176,7 @@ def min_over_ranks(value: int, device=None) -> int:
     import torch.distributed as dist
     if not active() or dist.get_world_size() == 1:
         return value
-    t = torch.tensor([value], dtype=torch.int32, device=device)
+    t = torch.tensor([value], dtype=torch.int32, device=_coll_device(device))
     dist.all_reduce(t, op=dist.ReduceOp.MIN)
     return int(t.item())
 
@@ -165,7 +186,7 @@ def sum_over_ranks(value: int, device=None) -> int:
     import torch.distributed as dist
     if not active() or dist.get_world_size() == 1:
         return value
-    t = torch.tensor([value], dtype=torch.int64, device=device)
+    t = torch.tensor([value], dtype=torch.int64, device=_coll_device(device))
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return int(t.item())
 
@@ -176,7 +197,7 @@ def gather_counts(count: int, device=None) -> list[int]:
     import torch.distributed as dist
     if not active() or dist.get_world_size() == 1:
         return [count]
-    t = torch.tensor([count], dtype=torch.int64, device=device)
+    t = torch.tensor([count], dtype=torch.int64, device=_coll_device(device))
     parts = [torch.empty_like(t) for _ in range(dist.get_world_size())]
     dist.all_gather(parts, t)
     return [int(p.item()) for p in parts]

@@ -144,6 +144,27 @@ class HipContext:
                                                iters, _fp(flow), _fp(ent) if want_entries else None))
         return (flow, ent) if want_entries else flow
 
+    def lk_spec_revision(self) -> int:
+        return int(self._lib.ofps_hip_lk_spec_revision())
+
+    def lk_flow_init(self, prev: np.ndarray, cur: np.ndarray, levels, radius, iters, init: np.ndarray):
+        """ofps_hip_lk_flow_init_dev through library-owned device buffers: `init` [h_L, w_L, 2] is the coarsest level's
+        starting flow.  -> flow[H, W, 2]."""
+        prev = np.ascontiguousarray(prev, np.uint8); cur = np.ascontiguousarray(cur, np.uint8)
+        init = np.ascontiguousarray(init, np.float32)
+        H, W = prev.shape
+        flow = np.zeros((H, W, 2), np.float32)
+        bufs = [self.malloc(prev.nbytes), self.malloc(cur.nbytes), self.malloc(init.nbytes), self.malloc(flow.nbytes)]
+        try:
+            self.memcpy_h2d(bufs[0], prev); self.memcpy_h2d(bufs[1], cur); self.memcpy_h2d(bufs[2], init)
+            self._check(self._lib.ofps_hip_lk_flow_init_dev(self._h, C.c_void_p(bufs[0]), C.c_void_p(bufs[1]), W, H, W, levels, radius,
+                                                            iters, C.c_void_p(bufs[2]), C.c_void_p(bufs[3]), C.c_void_p(0)))
+            self.memcpy_d2h(flow, bufs[3])
+        finally:
+            for b in bufs:
+                self.free(b)
+        return flow
+
     LK_CONTRAST_MASK, LK_PER_PIXEL = 1, 2
 
     def lk_decode(self, prev: np.ndarray, cur: np.ndarray, levels=3, radius=4, iters=3, max_w=150, max_h=150,

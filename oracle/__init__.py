@@ -86,11 +86,17 @@ def lib():
         L.orc_lk_flow.argtypes = [C.POINTER(C.c_uint8), C.POINTER(C.c_uint8), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                   C.c_int, fp]
         L.orc_lk_flow.restype = C.c_int
+        L.orc_lk_flow_init.argtypes = L.orc_lk_flow.argtypes[:-1] + [fp, fp]
+        L.orc_lk_flow_init.restype = C.c_int
+        L.orc_lk_flow_trace.argtypes = L.orc_lk_flow_init.argtypes + [fp]
+        L.orc_lk_flow_trace.restype = C.c_int
         L.orc_flow_to_entries.argtypes = [fp, C.c_int, C.c_int, fp]
         L.orc_contrast_mask.argtypes = [C.POINTER(C.c_uint8), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint8)]
         L.orc_masked_flow_to_entries.argtypes = [fp, C.POINTER(C.c_uint8), C.c_int, C.c_int, fp]
         L.orc_masked_flow_to_entries.restype = C.c_size_t
         L.orc_num_threads.restype = C.c_int
+        L.orc_set_num_threads.argtypes = [C.c_int]
+        L.orc_set_num_threads.restype = C.c_int
         L.orc_sad_simd_level.restype = C.c_int
         _lib = L
     return _lib
@@ -299,16 +305,51 @@ def sad_flow(prev, cur, B: int, R: int, threads: int = 1, stride=None, simd: boo
     return ent[:nb], best[:nb]
 
 
-def lk_flow(prev, cur, levels: int = 3, radius: int = 4, iters: int = 3) -> np.ndarray:
-    """-> flow[H, W, 2] f32 (u, v): prev(x,y) ~ cur(x+u, y+v)"""
+def lk_coarsest_shape(W: int, H: int, levels: int):
+    """(h, w) of the coarsest pyramid level: W, H halved (rounding up) levels - 1 times."""
+    for _ in range(1, levels):
+        W, H = (W + 1) // 2, (H + 1) // 2
+    return H, W
+
+
+def lk_flow(prev, cur, levels: int = 3, radius: int = 4, iters: int = 3, init=None) -> np.ndarray:
+    """-> flow[H, W, 2] f32 (u, v): prev(x,y) ~ cur(x+u, y+v).  init: the coarsest level's starting flow [h_L, w_L, 2]."""
     prev = np.ascontiguousarray(prev, np.uint8); cur = np.ascontiguousarray(cur, np.uint8)
     H, W = prev.shape
     out = np.zeros((H, W, 2), np.float32)
     u8 = C.POINTER(C.c_uint8)
-    ok = lib().orc_lk_flow(prev.ctypes.data_as(u8), cur.ctypes.data_as(u8), W, H, W, levels, radius, iters, _fp(out))
+    if init is None:
+        ok = lib().orc_lk_flow(prev.ctypes.data_as(u8), cur.ctypes.data_as(u8), W, H, W, levels, radius, iters, _fp(out))
+    else:
+        init = _f32(init)
+        assert init.shape == lk_coarsest_shape(W, H, levels) + (2,), init.shape
+        ok = lib().orc_lk_flow_init(prev.ctypes.data_as(u8), cur.ctypes.data_as(u8), W, H, W, levels, radius, iters, _fp(init), _fp(out))
     if not ok:
         raise ValueError("orc_lk_flow: bad parameters")
     return out
+
+
+def lk_flow_trace(prev, cur, levels: int = 3, radius: int = 4, iters: int = 3, init=None):
+    """-> (flow[H, W, 2], trace): trace[l][it] = the flow [h_l, w_l, 2] entering step `it` of pyramid level l (l = 0 finest)."""
+    prev = np.ascontiguousarray(prev, np.uint8); cur = np.ascontiguousarray(cur, np.uint8)
+    H, W = prev.shape
+    shapes = [(H, W)]
+    for _ in range(1, levels):
+        shapes.append(((shapes[-1][0] + 1) // 2, (shapes[-1][1] + 1) // 2))
+    out = np.zeros((H, W, 2), np.float32)
+    buf = np.zeros(sum(2 * h * w * iters for h, w in shapes), np.float32)
+    u8 = C.POINTER(C.c_uint8)
+    ini = None if init is None else _f32(init)
+    ok = lib().orc_lk_flow_trace(prev.ctypes.data_as(u8), cur.ctypes.data_as(u8), W, H, W, levels, radius, iters,
+                                 None if ini is None else _fp(ini), _fp(out), _fp(buf))
+    if not ok:
+        raise ValueError("orc_lk_flow_trace: bad parameters")
+    trace, o = {}, 0
+    for l in range(levels - 1, -1, -1):
+        h, w = shapes[l]
+        trace[l] = buf[o:o + 2 * h * w * iters].reshape(iters, h, w, 2)
+        o += 2 * h * w * iters
+    return out, trace
 
 
 def flow_to_entries(flow) -> np.ndarray:
@@ -342,3 +383,8 @@ def sad_simd_level() -> str:
 
 def num_threads() -> int:
     return int(lib().orc_num_threads())
+
+
+def set_num_threads(n: int) -> int:
+    """Threads of the OpenMP loops that take no thread argument (lk_flow); returns the previous setting."""
+    return int(lib().orc_set_num_threads(int(n)))

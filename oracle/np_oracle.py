@@ -296,7 +296,7 @@ def _lk_bilinear(J, fx, fy):
     return _lk_lerp(top, bot, ay)
 
 
-def lk_flow(prev, cur, levels=3, radius=4, iters=3):
+def lk_flow(prev, cur, levels=3, radius=4, iters=3, init=None):
     """Second restatement of the build-defined pyramidal LK (oracle/ofps_oracle.c:orc_lk_flow): same f32 operations in the
     same order, vectorised over pixels with explicit loops over the window taps -> the same bits."""
     I = [np.asarray(prev, np.uint8).astype(F)]
@@ -308,7 +308,9 @@ def lk_flow(prev, cur, levels=3, radius=4, iters=3):
         Il, Jl = I[l], J[l]
         h, w = Il.shape
         yy, xx = np.meshgrid(np.arange(h), np.arange(w), indexing="ij")
-        if flow is None:
+        if flow is None and init is not None:                # caller-supplied prior for the coarsest level (orc_lk_flow_init)
+            u = np.asarray(init, F)[..., 0].copy(); v = np.asarray(init, F)[..., 1].copy()
+        elif flow is None:
             u = np.zeros((h, w), F); v = np.zeros((h, w), F)
         else:
             h1, w1 = flow[0].shape

@@ -1032,6 +1032,19 @@ int orc_num_threads(void) {
 #endif
 }
 
+/* threads the OpenMP loops without a thread argument of their own (orc_lk_flow*) use from now on; returns the previous
+ * setting.  bench_legs.py times the N2 restatement on one thread and on all the host cores with it. */
+int orc_set_num_threads(int n) {
+#ifdef _OPENMP
+    const int prev = omp_get_max_threads();
+    if (n >= 1) omp_set_num_threads(n);
+    return prev;
+#else
+    (void)n;
+    return 1;
+#endif
+}
+
 /* ------------------------------------------------------------------------------------ */
 /* N2: dense pyramidal Lucas-Kanade flow (build-defined; the reference only calls OpenCV) */
 /* ------------------------------------------------------------------------------------ */
@@ -1109,8 +1122,9 @@ static inline float lk_bilinear(const float* J, int w, int h, float fx, float fy
 #if defined(__x86_64__) && defined(__GNUC__) && !defined(__clang__)
 __attribute__((target_clones("fma", "default")))
 #endif
-int orc_lk_flow(const uint8_t* prev, const uint8_t* cur, int W, int H, int stride, int levels, int radius, int iters,
-                float* out_flow) {
+int orc_lk_flow_trace(const uint8_t* prev, const uint8_t* cur, int W, int H, int stride, int levels, int radius, int iters,
+                      const float* init /* coarsest level's starting flow, 2 * ws * hs floats, or NULL = zero */, float* out_flow,
+                      float* trace /* or NULL: the flow ENTERING every step, coarsest level first, iters planes of 2 * w * h per level */) {
     if (levels < 1 || levels > 8 || radius < 1 || radius > 15 || iters < 1 || W < 1 || H < 1) return 0;
     int ws[8], hs[8];
     float *I[8], *J[8];
@@ -1146,6 +1160,8 @@ int orc_lk_flow(const uint8_t* prev, const uint8_t* cur, int W, int H, int strid
                     next[2 * ((size_t)y * w + x) + 1] = 2.0f * flow[2 * ((size_t)sy * w1 + sx) + 1];
                 }
             memcpy(flow, next, (size_t)2 * w * h * sizeof(float));
+        } else if (init) {                                      /* a caller-supplied prior (the role of OpenCV's OPTFLOW_USE_INITIAL_FLOW) */
+            memcpy(flow, init, (size_t)2 * w * h * sizeof(float));
         } else {
             memset(flow, 0, (size_t)2 * w * h * sizeof(float));
         }
@@ -1155,6 +1171,7 @@ int orc_lk_flow(const uint8_t* prev, const uint8_t* cur, int W, int H, int strid
                 gy[(size_t)y * w + x] = (Il[(size_t)lk_clampi(y + 1, 0, h - 1) * w + x] - Il[(size_t)lk_clampi(y - 1, 0, h - 1) * w + x]) * 0.5f;
             }
         for (int it = 0; it < iters; ++it) {
+            if (trace) { memcpy(trace, flow, (size_t)2 * w * h * sizeof(float)); trace += (size_t)2 * w * h; }
 #ifdef _OPENMP
 #pragma omp parallel for schedule(static)
 #endif
@@ -1186,6 +1203,15 @@ int orc_lk_flow(const uint8_t* prev, const uint8_t* cur, int W, int H, int strid
     for (int l = 0; l < levels; ++l) { free(I[l]); free(J[l]); }
     free(tmp); free(flow); free(next); free(gx); free(gy);
     return 1;
+}
+
+int orc_lk_flow_init(const uint8_t* prev, const uint8_t* cur, int W, int H, int stride, int levels, int radius, int iters,
+                     const float* init, float* out_flow) {
+    return orc_lk_flow_trace(prev, cur, W, H, stride, levels, radius, iters, init, out_flow, NULL);
+}
+int orc_lk_flow(const uint8_t* prev, const uint8_t* cur, int W, int H, int stride, int levels, int radius, int iters,
+                float* out_flow) {
+    return orc_lk_flow_trace(prev, cur, W, H, stride, levels, radius, iters, NULL, out_flow, NULL);
 }
 
 /* cv-decoder's record convention for per-pixel flow (cv-decoder/src/lib.rs:239-243, 262-269):

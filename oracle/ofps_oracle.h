@@ -138,6 +138,15 @@ size_t orc_sad_flow_ex(const uint8_t* prev, const uint8_t* cur, int W, int H, in
 int orc_lk_spec_revision(void);   /* 2: fused multiply-adds in the bilinear sample and the residual sums (current); 1: unfused */
 int orc_lk_flow(const uint8_t* prev, const uint8_t* cur, int W, int H, int stride, int levels, int radius, int iters,
                 float* out_flow);
+/* the same with a caller-supplied starting flow for the COARSEST level (2 floats per pixel of that level, whose size is
+ * W, H halved (rounding up) levels - 1 times; NULL = zero = orc_lk_flow): a temporal prior, the role of OpenCV's
+ * OPTFLOW_USE_INITIAL_FLOW -- and the way the parity tests put chosen flows into a level's first step */
+int orc_lk_flow_init(const uint8_t* prev, const uint8_t* cur, int W, int H, int stride, int levels, int radius, int iters,
+                     const float* init, float* out_flow);
+/* ... and with the flow ENTERING every Gauss-Newton step written to `trace` (coarsest level first; per level `iters` planes
+ * of 2 * w * h floats): what tools/lk_tile_stats.py and the tile-grouping tests look at (which tiles' sample rectangles fit) */
+int orc_lk_flow_trace(const uint8_t* prev, const uint8_t* cur, int W, int H, int stride, int levels, int radius, int iters,
+                      const float* init, float* out_flow, float* trace);
 /* per-pixel MotionEntry records in cv-decoder's convention (cv-decoder/src/lib.rs:239-243,262-269) */
 void orc_flow_to_entries(const float* flow, int W, int H, float* out_entries);
 
@@ -148,6 +157,7 @@ void orc_contrast_mask(const uint8_t* gray, int W, int H, int stride, uint8_t* o
 size_t orc_masked_flow_to_entries(const float* flow, const uint8_t* mask, int W, int H, float* out_entries);
 
 int orc_num_threads(void);
+int orc_set_num_threads(int n);   /* for the OpenMP loops without a thread argument (orc_lk_flow*); returns the previous setting */
 
 #ifdef __cplusplus
 }

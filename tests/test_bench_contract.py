@@ -64,7 +64,40 @@ def test_defaults_are_baseline_configs_1():
     assert b.pairs == 16 and b.width == 3840
 
 
-def test_gloo_backend_is_refused_without_stub():
+def test_device_map_rules():
+    """gloo with real compute is the one-GPU rehearsal of an N-rank run: allowed, with one device per rank; a
+    repeated device needs gloo (RCCL refuses two ranks on one GPU); the line then says it is a rehearsal."""
     import pytest
-    with pytest.raises(SystemExit):
-        bench.parse(["--backend", "gloo"])
+    a = bench.parse(["--gpus", "2", "--backend", "gloo", "--device-map", "0,0"])
+    assert a.device_map == [0, 0] and a.backend == "gloo" and not a.stub
+    assert bench.parse(["--gpus", "2", "--device-map", "1,0"]).device_map == [1, 0]            # distinct devices: RCCL is fine
+    for bad in (["--gpus", "2", "--device-map", "0,0"],                                         # repeated device under nccl
+                ["--gpus", "2", "--backend", "gloo", "--device-map", "0"],                      # one entry per rank
+                ["--gpus", "1", "--backend", "gloo", "--device-map", "x"]):
+        with pytest.raises(SystemExit):
+            bench.parse(bad)
+    args = bench.parse(["--gpus", "2", "--backend", "gloo", "--device-map", "0,0", "--config", "cfg4"])
+    d = bench.build_line(args, 2, 1.0, 1.0, 32, [32, 32], 129600, 2)
+    assert "rehearsal" in d and "NOT a scaling measurement" in d["rehearsal"]
+    assert "rehearsal" not in bench.build_line(bench.parse([]), 1, 1.0, 1.0, 256, [256], 8040, 1)
+
+
+def test_line_says_what_each_row_is_pinned_to():
+    _, d = _line([], 1, 20 * 4.1e-3, 4.08, [256])
+    pin = d["parity_pin"]
+    assert any(k.startswith("N1") and "build-defined spec" in v for k, v in pin.items())
+    assert any(k.startswith("N2") and "build-defined spec" in v for k, v in pin.items())
+    assert any(k.startswith("A6-A12") and "reference-held" in v for k, v in pin.items())
+    assert any(k.startswith("A1-A5") and "hand-derived" in v for k, v in pin.items())
+
+
+def test_traffic_is_flagged_stale_when_the_kernel_source_changed(tmp_path, monkeypatch):
+    import json as _json
+    v, stale = bench.committed_traffic_per_pair(1920, 1080, 16, 16)
+    d = _json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))["sad_1920x1080_b16_r16"]
+    assert v == d["hbm_bytes_per_pair"]
+    assert stale == (d.get("kernel_source_sha16") != bench.kernel_source_sha16())
+    monkeypatch.setattr(bench, "kernel_source_sha16", lambda name="sad.hip": "0" * 16)
+    assert bench.committed_traffic_per_pair(1920, 1080, 16, 16)[1] is True
+    _, line = _line([], 1, 1.0, 1.0, [256])
+    assert "traffic_stale" in line["roofline"]

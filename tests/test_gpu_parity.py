@@ -537,13 +537,16 @@ def test_lk_flow_bit_exact_vs_oracle(ctx, W, H, levels, radius, iters):
     np.testing.assert_array_equal(e_g.view(np.uint32), oracle.flow_to_entries(f_o).view(np.uint32))   # cv-decoder records
 
 
-@pytest.mark.parametrize("fall_step", [0, 1, 2])
+@pytest.mark.parametrize("fall_step", [0, 1, 2, 16 + 0, 16 + 1, 16 + 2, 32 + 0, 32 + 2, 48 + 1])
 @pytest.mark.parametrize("radius", [2, 4, 6])
 def test_lk_flow_hand_over_in_the_middle_of_a_level(hooks_ctx, fall_step, radius):
     """The level kernel keeps a tile's flow on chip across the Gauss-Newton steps of a level; a tile whose current-frame
-    rectangle stops fitting LDS at step k parks its flow and the general kernel finishes steps k.. of the level.  The
-    test hook makes every other tile fall at step k (0 = the whole level, 1 / 2 = mid-level), with and without the
-    records output: same bits as the oracle either way."""
+    rectangle does not fit LDS at step k is finished inside the same launch: its pixels in groups around an anchor pixel's
+    rectangle (up to 8 rounds), whatever is left by the oracle's per-sample form from global memory.  The test hook makes
+    every other tile take that path at step k (low 4 bits: 0 = the level's first step, tensor sums included, 1 / 2 =
+    mid-level) and limits the grouping rounds (bits 4..: 0 = default, 1 + n = n rounds -> 16 + k: every pixel through the
+    leftover path, 32 + k / 48 + k: one / two rounds, then leftovers), with and without the records output: same bits as the
+    oracle either way."""
     ctx = hooks_ctx                     # the hook is compiled only into libofps_hip_testhooks.so
     ctx.set_option("OFPS_HIP_LK_TEST_FALL", str(fall_step))
     W, H, levels, iters = 320, 180, 3, 3
@@ -575,6 +578,85 @@ def test_lk_flow_recovers_planted_translation(ctx):
     f = ctx.lk_flow(prev, cur, 3, 4, 3)
     inner = f[32:-32, 32:-32]
     assert np.abs(inner - np.array([dx, dy], np.float32)).mean() < 1e-3
+
+
+@pytest.mark.parametrize("W,H,dx,levels", [(1030, 40, 5, 1), (1030, 48, 5, 3), (1027, 40, 4, 2), (518, 64, 6, 2), (2053, 40, 5, 1),
+                                           (1030, 40, -5, 1)])
+def test_lk_flow_width_just_above_a_power_of_two_with_flows_leaving_the_right_edge(ctx, W, H, dx, levels):
+    """ADVICE r3 (lk.hip fast column origins): a planted translation of dx pixels makes the sums x + k - r + u of the right-most
+    interior tile straddle the power of two just below W with fractions within rounding of an integer, and push the last
+    sample origin onto / past the frame's right edge where lk_origin clamps it: windows whose floors skip one across the
+    binade must not pass for consecutive.  Same bits as the oracle."""
+    base = synth.luma_sequence(1, W + 64, H + 64, max_step=0, noise=0, seed=9 + W)[0]
+    prev = np.ascontiguousarray(base[32:32 + H, 32:32 + W])
+    cur = np.ascontiguousarray(base[32:32 + H, 32 - dx:32 - dx + W])                  # cur(x + dx, y) = prev(x, y)
+    f_o = oracle.lk_flow(prev, cur, levels, 4, 3)
+    f_g = ctx.lk_flow(prev, cur, levels, 4, 3)
+    np.testing.assert_array_equal(f_g.view(np.uint32), f_o.view(np.uint32))
+    if levels >= 2:
+        assert np.abs(f_o[8:-8, 16:-16, 0] - dx).mean() < 0.5                          # the flows do point where the case needs them
+
+
+def test_lk_spec_revision_of_the_library_is_the_oracles(ctx):
+    """OFPS_LK_SPEC_FMA (lk.hip) and ORC_LK_SPEC_FMA (oracle) are independent build switches: they must be set alike, or
+    every bit-exact LK test compares two different specs."""
+    assert ctx.lk_spec_revision() == oracle.lk_spec_revision() == 2
+
+
+def _crafted_binade_init(W, H):
+    """Starting flow (one level) whose last-column pixels of the right-most interior tile have window floors that skip one
+    across the power of two below W while the LAST floor is clamped to W -- the input of ADVICE r3's counterexample -- and
+    every other pixel of the tile has consecutive floors, so nothing else in the workgroup vetoes the fast path."""
+    R = 4
+    init = np.zeros((H, W, 2), np.float32)
+    init[..., 0] = 2.0
+    p2 = 1 << (W.bit_length() - 1)
+    assert p2 < W <= p2 + 2 * R + 1 and (W - 36) % 32 == 0       # tile x0 = W - 36 is interior and its last pixel is p2 - 1 (W = p2 + 4)
+    xs = p2 - 1
+    init[:, xs, 0] = np.float32(2.0) - np.float32(4.6e-5)        # (with exactly 2.0 the clamped last floor repeats: end difference 2r - 1, vetoed)
+    k = np.arange(2 * R + 1)
+    x = np.arange(W)[None, :].repeat(H, 0)
+    fl = np.floor((x[..., None] + k - R).astype(np.float32) + init[..., 0:1])
+    cl = np.clip(fl, -1, W)
+    unguarded = (cl[..., 0] >= 0) & (cl[..., -1] - cl[..., 0] == 2 * R)
+    truth = (np.diff(cl, axis=-1) == 1).all(-1)
+    tile = np.s_[:, W - 36:W - 4]
+    assert unguarded[tile].all() and not truth[tile].all()       # round 3's test passes the tile, the floors are not consecutive
+    return init
+
+
+@pytest.mark.parametrize("iters", [1, 3])
+def test_lk_flow_clamped_last_origin_across_a_binade_is_not_consecutive(ctx, iters):
+    """The deterministic form of ADVICE r3's counterexample (lk.hip:812): W = 1028, r = 4, flows 2 - 4.6e-5 in column 1023:
+    floors 1020 .. 1023, 1025 .. 1029 with the last clamped to W -- end difference 2r although a floor is skipped.  The
+    starting flow goes in through ofps_hip_lk_flow_init_dev (oracle: orc_lk_flow_init); same bits."""
+    W, H = 1028, 16
+    fr = synth.luma_sequence(2, W, H, max_step=2, seed=31)
+    init = _crafted_binade_init(W, H)
+    f_o = oracle.lk_flow(fr[0], fr[1], 1, 4, iters, init=init)
+    f_g = ctx.lk_flow_init(fr[0], fr[1], 1, 4, iters, init)
+    np.testing.assert_array_equal(f_g.view(np.uint32), f_o.view(np.uint32))
+
+
+@pytest.mark.parametrize("W,H,levels,radius,amp,seed", [(200, 120, 1, 4, 30.0, 1), (200, 120, 3, 4, 12.0, 2), (333, 77, 2, 4, 40.0, 3),
+                                                        (1030, 24, 1, 4, 8.0, 4), (160, 96, 2, 2, 25.0, 5), (160, 96, 2, 6, 25.0, 6),
+                                                        (90, 70, 2, 3, 10.0, 7), (520, 40, 2, 4, 600.0, 8)])
+def test_lk_flow_with_wild_starting_flows(ctx, W, H, levels, radius, amp, seed):
+    """Starting flows no pyramid would produce -- per-pixel noise of +-amp pixels on top of region jumps, rows and columns of
+    exact integers and of values one ulp below them, flows far outside the frame -- put every tile of the coarsest level
+    through the rectangle-does-not-fit path, the per-column origins, the clamped rows and the row-reuse exceptions.  Same
+    bits as the oracle."""
+    rng = np.random.default_rng(seed)
+    fr = synth.luma_sequence(2, W, H, max_step=3, seed=50 + seed)
+    h, w = oracle.lk_coarsest_shape(W, H, levels)
+    init = rng.uniform(-amp, amp, (h, w, 2)).astype(np.float32)
+    init[: h // 3] = np.round(init[: h // 3])                                        # integers: fractions exactly 0
+    init[h // 3: h // 2] = np.nextafter(np.round(init[h // 3: h // 2]), np.float32(-np.inf)).astype(np.float32)
+    init[:, : w // 4] = init[0, 0]                                                   # a coherent region (the staged path)
+    init[:, w // 4: w // 2] *= np.float32(0.02)                                      # ordinary sub-pixel flows
+    f_o = oracle.lk_flow(fr[0], fr[1], levels, radius, 2, init=init)
+    f_g = ctx.lk_flow_init(fr[0], fr[1], levels, radius, 2, init)
+    np.testing.assert_array_equal(f_g.view(np.uint32), f_o.view(np.uint32))
 
 
 def test_lk_to_rotation_end_to_end(ctx):

@@ -51,3 +51,40 @@ def test_fraction_of_a_nonnegative_float32_is_exact():
     frac_exact = fq.astype(np.float64) - np.floor(fq.astype(np.float64))
     np.testing.assert_array_equal(frac32.astype(np.float64), frac_exact)
     assert (frac32 < 1).all() and (frac32 >= 0).all()
+
+
+def test_clamped_last_floor_defeats_the_end_difference_test_and_the_guard_restores_it():
+    """lk_origin clamps a floor to [-1, w].  Across a binade the unclamped floors may advance by 2, and a last floor that was
+    clamped down to w can make the END DIFFERENCE read 2r although a floor was skipped (w = 1030, r = 4,
+    fq_0 = 1022.99995 -> floors 1022, 1023, 1025, ..., 1031, the last clamped to 1030).  lk.hip therefore accepts the
+    two-chain verdict only when the clamped last floor is < w (and the first >= 0): with that guard the verdict equals
+    "every clamped floor is its predecessor + 1 and no clamp is active" on random and adversarial inputs."""
+    w = 1030
+    u = np.float32(1022.99995) - np.float32(1018.0)
+    k = np.arange(2 * R + 1, dtype=np.int64)
+    fq = (np.int64(1022) + k - R).astype(np.float32) + u
+    fl = np.floor(fq)
+    assert fl[0] == 1022 and (np.diff(fl) == 2).any()              # a floor is skipped across 1024 ...
+    cl = np.clip(fl, -1, w)
+    assert cl[-1] - cl[0] == 2 * R                                  # ... and the clamped ends hide it
+    assert not (cl[0] >= 0 and cl[-1] < w and cl[-1] - cl[0] == 2 * R)   # the guarded test does not
+
+    rng = np.random.default_rng(20260929)
+    n = 400_000
+    ws = np.concatenate([2 ** rng.integers(4, 12, n // 2) + rng.integers(1, 2 * R + 2, n // 2), rng.integers(2 * R + 2, 4096, n - n // 2)]).astype(np.int64)
+    x = np.clip(ws - 1 - R - rng.integers(0, 3 * R, n), R, None)                        # interior tiles: no window COLUMN is clamped
+    ok_tile = x + R <= ws - 1
+    uu = rng.uniform(-2.0, 12.0, n).astype(np.float32)
+    near = rng.random(n) < 0.5                                                          # sums that land on / next to a power of two
+    p2 = (2.0 ** np.floor(np.log2(np.maximum(x - R, 2)) + 1)).astype(np.float32)
+    uu[near] = (p2[near] - (x[near] - R).astype(np.float32) + rng.integers(-2, 3, near.sum()).astype(np.float32)
+                - (2.0 ** rng.integers(-16, -8, near.sum())).astype(np.float32))
+    q = (x[:, None] + k[None, :] - R).astype(np.float32)
+    fl = np.floor(q + uu[:, None])
+    cl = np.clip(fl, -1, ws[:, None].astype(np.float32))
+    guarded = (cl[:, 0] >= 0) & (cl[:, -1] < ws) & (cl[:, -1] - cl[:, 0] == 2 * R)
+    truth = (np.diff(cl, axis=1) == 1).all(axis=1) & (cl[:, 0] >= 0) & (cl[:, -1] < ws)
+    np.testing.assert_array_equal(guarded[ok_tile], truth[ok_tile])
+    unguarded = (cl[:, 0] >= 0) & (cl[:, -1] - cl[:, 0] == 2 * R)
+    wrong = unguarded & ~(np.diff(cl, axis=1) == 1).all(axis=1) & ok_tile
+    assert wrong.sum() > 0                                          # the random set does contain the round-3 bug's inputs
