@@ -154,7 +154,20 @@ int ofps_hip_lk_decode(ofps_hip_ctx* ctx, const uint8_t* prev, const uint8_t* cu
 int ofps_hip_lk_push_frame(ofps_hip_ctx* ctx, const uint8_t* frame, int W, int H, int stride,
                            int levels, int radius, int iters, int max_w, int max_h, unsigned flags,
                            float* out_entries, size_t* n_out, int* out_w, int* out_h, int* have_vectors);
-int ofps_hip_lk_reset(ofps_hip_ctx* ctx);
+/* The same iteration split in two for read-ahead callers (cv-decoder's loop, cv-decoder/src/lib.rs:82-158, run one frame
+ * ahead on a decoder thread as ofps-suite/src/app/tracking/worker.rs:165-226 does): push_frame_async returns once the frame's
+ * H2D copy (on a copy stream when another ticket is in flight), the flow of (previous frame, this frame) and the output
+ * stage are enqueued; the stage's last kernel writes the records and their count straight into the ticket's page-locked
+ * block.  ofps_hip_lk_frame_wait(ticket) blocks until they are there and copies them to out_entries.  Up to 2 tickets in
+ * flight: the upload of frame k+1 overlaps the flow of pair (k-1, k), and the host collects pair k-1's records meanwhile.
+ * `frame` must stay valid until its ticket is collected (page-locked memory: ofps_hip_host_alloc; pageable memory makes the
+ * copy synchronous).  ofps_hip_lk_push_frame == push_frame_async + frame_wait, bit for bit; both forms share one stream
+ * of frames.  out_entries capacity as for ofps_hip_lk_decode. */
+int ofps_hip_lk_push_frame_async(ofps_hip_ctx* ctx, const uint8_t* frame, int W, int H, int stride,
+                                 int levels, int radius, int iters, int max_w, int max_h, unsigned flags, int* ticket);
+int ofps_hip_lk_frame_wait(ofps_hip_ctx* ctx, int ticket, float* out_entries, size_t* n_out, int* out_w, int* out_h,
+                           int* have_vectors);
+int ofps_hip_lk_reset(ofps_hip_ctx* ctx);                  /* waits for tickets in flight; the next frame starts a new stream */
 int ofps_hip_lk_flow_dev(ofps_hip_ctx* ctx, const void* d_prev, const void* d_cur, int W, int H, int stride,
                          int levels, int radius, int iters, void* d_out_flow, void* d_out_entries);
 /* The same with a starting flow for the COARSEST pyramid level (d_init_flow: 2 f32 per pixel of that level, whose size is

@@ -51,6 +51,9 @@ PROTOTYPES = {
                                      C.c_uint, _f32p, _szp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "ofps_hip_lk_push_frame": (C.c_int, [_ctx, _u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                          C.c_uint, _f32p, _szp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "ofps_hip_lk_push_frame_async": (C.c_int, [_ctx, _u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                               C.c_uint, C.POINTER(C.c_int)]),
+    "ofps_hip_lk_frame_wait": (C.c_int, [_ctx, C.c_int, _f32p, _szp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "ofps_hip_lk_reset": (C.c_int, [_ctx]),
     "ofps_hip_lk_flow_dev": (C.c_int, [_ctx, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp]),
     "ofps_hip_lk_flow_init_dev": (C.c_int, [_ctx, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp]),

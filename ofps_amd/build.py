@@ -56,7 +56,7 @@ def _link(lib: str, objs, force: bool, verbose: bool) -> None:
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
-    hdrs = glob.glob(os.path.join(CSRC, "*.hpp")) + glob.glob(os.path.join(HERE, "..", "include", "*.h"))
+    hdrs = glob.glob(os.path.join(CSRC, "*.hpp")) + glob.glob(os.path.join(CSRC, "*.inc")) + glob.glob(os.path.join(HERE, "..", "include", "*.h"))
     objs, objs_hooks = [], []
     for src in sources():
         stem = os.path.basename(src)[:-4]

@@ -44,6 +44,20 @@ struct ofps_hip_ctx {
     uint64_t lk_frames_gen = 0;          // generation of the S_LK_FRAMES allocation the count refers to
     void* lk_pinned = nullptr;           // page-locked staging for a frame's records + their count (one D2H, one wait)
     size_t lk_pinned_cap = 0;
+    // read-ahead form (ofps_hip_lk_push_frame_async / ofps_hip_lk_frame_wait): a ring of three device frame slots, the new frame
+    // uploaded on a copy stream while the previous pair's flow runs, two tickets in flight, each with a page-locked block
+    // [count, pad x 3][records] that the last kernels of the ticket write directly
+    static constexpr int kLkSlots = 3, kLkTickets = 2;
+    hipStream_t lk_copy_stream = nullptr;
+    struct LkTicket {
+        bool pending = false;
+        hipEvent_t done = nullptr, uploaded = nullptr;
+        void* pinned = nullptr; size_t pinned_cap = 0;
+        int have_vectors = 0, gw = 0, gh = 0;
+        size_t max_records = 0;
+        long fixed_count = -1;           // >= 0: the record count is known on the host (per-pixel output without a mask)
+    } lk_ticket[kLkTickets];
+    long lk_next_ticket = 0;
 
     // per-frame pipeline state (pipeline.hip): a ring of three device frame slots (the new frame is uploaded on the copy
     // stream while the previous pair is still being searched), two tickets in flight
@@ -133,6 +147,12 @@ int detect_device(ofps_hip_ctx* ctx, const float4* d_entries, size_t n, int batc
                   float target_motion, int* d_result, float2* d_out_field, int* out_dim);
 int almeida_device(ofps_hip_ctx* ctx, const float4* d_entries, size_t n, int batch, float aspect, float fov_y_deg,
                    int use_ransac, size_t num_iters, float inlier_deg, size_t num_samples, uint64_t seed, float4* d_quat);
+
+// device -> host: by a copy KERNEL when the destination is page-locked (device-addressable) -- a D2H DMA would queue behind the
+// next frame's H2D --, by hipMemcpyAsync otherwise (pipeline.hip).  bytes % 4 == 0.
+int read_back_device(ofps_hip_ctx* ctx, void* host_dst, const void* dev_src, size_t bytes, hipStream_t s);
+// the device address of page-locked host memory, or false for pageable memory
+bool device_address_of(const void* host_ptr, void** dev_ptr);
 
 // rows of `width` bytes, host -> device; one linear copy when both sides are dense (the 2-D path is slower)
 inline hipError_t upload_rows(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t height,

@@ -201,6 +201,12 @@ void ofps_hip_destroy(ofps_hip_ctx* ctx) {
         if (ctx->pipe_slot_read[k]) (void)hipEventDestroy(ctx->pipe_slot_read[k]);
     }
     if (ctx->lk_pinned) (void)hipHostFree(ctx->lk_pinned);
+    for (auto& t : ctx->lk_ticket) {
+        if (t.pinned) (void)hipHostFree(t.pinned);
+        if (t.done) (void)hipEventDestroy(t.done);
+        if (t.uploaded) (void)hipEventDestroy(t.uploaded);
+    }
+    if (ctx->lk_copy_stream) (void)hipStreamDestroy(ctx->lk_copy_stream);
     if (ctx->pipe_copy_stream) (void)hipStreamDestroy(ctx->pipe_copy_stream);
     if (ctx->pipe_aux_stream) (void)hipStreamDestroy(ctx->pipe_aux_stream);
     if (ctx->pipe_fork) (void)hipEventDestroy(ctx->pipe_fork);
@@ -222,6 +228,7 @@ static int switch_stream(ofps_hip_ctx* ctx, hipStream_t next) {
     OFPS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->pipe_copy_stream) OFPS_HIP_TRY(ctx, hipStreamSynchronize(ctx->pipe_copy_stream));
     if (ctx->pipe_aux_stream) OFPS_HIP_TRY(ctx, hipStreamSynchronize(ctx->pipe_aux_stream));
+    if (ctx->lk_copy_stream) OFPS_HIP_TRY(ctx, hipStreamSynchronize(ctx->lk_copy_stream));
     ctx->stream = next;
     return OFPS_HIP_OK;
 }
@@ -263,7 +270,9 @@ int ofps_hip_free(ofps_hip_ctx* ctx, void* dptr) {
 int ofps_hip_host_alloc(ofps_hip_ctx* ctx, size_t bytes, void** hptr) {
     if (!ctx || !hptr) return OFPS_HIP_EINVAL;
     OFPS_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    OFPS_HIP_TRY(ctx, hipHostMalloc(hptr, bytes ? bytes : 16, hipHostMallocDefault));
+    // fine-grained (coherent) explicitly: callers hand these buffers to push_frame_async as out_entries / out_field, which
+    // kernels write directly and the host reads after an event without a system-scope release of its own
+    OFPS_HIP_TRY(ctx, hipHostMalloc(hptr, bytes ? bytes : 16, hipHostMallocCoherent));
     return OFPS_HIP_OK;
 }
 

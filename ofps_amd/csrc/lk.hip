@@ -533,16 +533,6 @@ __device__ __forceinline__ void lk_stage3_u8(const uint8_t* __restrict__ src, in
 //   * 7 VALU operations per tap (the spec's count), 63 per row.
 // Same operations on the same operands in the same order as the C++ form (lk_lerp / lk_accum): same bits.
 // The quads are v[72:75] / v[76:79]: the top of the 80-register budget of a 256-thread workgroup at 6 waves per SIMD.
-#ifdef OFPS_LK_X_HALF_TILE
-#define LK_X_ODD(S) ""
-#else
-#define LK_X_ODD(S) S
-#endif
-#ifdef OFPS_LK_X_HALF_TEXEL
-#define LK_X_TEX(S) ""
-#else
-#define LK_X_TEX(S) S
-#endif
 #define LK_ROW9_TAP(K, KN, WAIT, NEXT)                                        \
     "v_sub_f32 %[tmp], %[l" #KN "], %[l" #K "]\n\t"                             \
     "v_fmac_f32 %[l" #K "], %[a" #K "], %[tmp]\n\t"                             \
@@ -575,27 +565,27 @@ __device__ __forceinline__ void lk_row9_asm(float (&r)[19], const float (&a)[9],
     float tmp;
     asm volatile(
         "ds_read_b32 %[l0], %[ja]\n\t"
-        LK_X_TEX("ds_read_b32 %[l1], %[ja] offset:4\n\t")
+        "ds_read_b32 %[l1], %[ja] offset:4\n\t"
         "ds_read_b32 %[l2], %[ja] offset:8\n\t"
-        LK_X_TEX("ds_read_b32 %[l3], %[ja] offset:12\n\t")
+        "ds_read_b32 %[l3], %[ja] offset:12\n\t"
         "ds_read_b32 %[l4], %[ja] offset:16\n\t"
-        LK_X_TEX("ds_read_b32 %[l5], %[ja] offset:20\n\t")
+        "ds_read_b32 %[l5], %[ja] offset:20\n\t"
         "ds_read_b32 %[l6], %[ja] offset:24\n\t"
-        LK_X_TEX("ds_read_b32 %[l7], %[ja] offset:28\n\t")
+        "ds_read_b32 %[l7], %[ja] offset:28\n\t"
         "ds_read_b32 %[l8], %[ja] offset:32\n\t"
-        LK_X_TEX("ds_read_b32 %[l9], %[ja] offset:36\n\t")
+        "ds_read_b32 %[l9], %[ja] offset:36\n\t"
         "ds_read_b128 v[72:75], %[ta]\n\t"
-        LK_X_ODD("ds_read_b128 v[76:79], %[ta] offset:16\n\t")
+        "ds_read_b128 v[76:79], %[ta] offset:16\n\t"
         "s_waitcnt lgkmcnt(10)\n\t"                                            // l0, l1 are there
         // tap k: horizontal + vertical interpolation while its tile record is in flight, then the residual sums; the quad
         // it used is refilled with tap k + 2's record.  Waits: 12 reads issued; before tap k's first use of l[k+1] at most
         // 10 - k of the texel reads ... may be outstanding behind the two tile reads (counted below per tap).
         LK_ROW9_TAP(0, 1, 1, "") LK_ROW9_USE(0, "v72", "v73", "v74", "ds_read_b128 v[72:75], %[ta] offset:32\n\t")
-        LK_ROW9_TAP(1, 2, 1, "") LK_ROW9_USE(1, "v76", "v77", "v78", LK_X_ODD("ds_read_b128 v[76:79], %[ta] offset:48\n\t"))
+        LK_ROW9_TAP(1, 2, 1, "") LK_ROW9_USE(1, "v76", "v77", "v78", "ds_read_b128 v[76:79], %[ta] offset:48\n\t")
         LK_ROW9_TAP(2, 3, 1, "") LK_ROW9_USE(2, "v72", "v73", "v74", "ds_read_b128 v[72:75], %[ta] offset:64\n\t")
-        LK_ROW9_TAP(3, 4, 1, "") LK_ROW9_USE(3, "v76", "v77", "v78", LK_X_ODD("ds_read_b128 v[76:79], %[ta] offset:80\n\t"))
+        LK_ROW9_TAP(3, 4, 1, "") LK_ROW9_USE(3, "v76", "v77", "v78", "ds_read_b128 v[76:79], %[ta] offset:80\n\t")
         LK_ROW9_TAP(4, 5, 1, "") LK_ROW9_USE(4, "v72", "v73", "v74", "ds_read_b128 v[72:75], %[ta] offset:96\n\t")
-        LK_ROW9_TAP(5, 6, 1, "") LK_ROW9_USE(5, "v76", "v77", "v78", LK_X_ODD("ds_read_b128 v[76:79], %[ta] offset:112\n\t"))
+        LK_ROW9_TAP(5, 6, 1, "") LK_ROW9_USE(5, "v76", "v77", "v78", "ds_read_b128 v[76:79], %[ta] offset:112\n\t")
         LK_ROW9_TAP(6, 7, 1, "") LK_ROW9_USE(6, "v72", "v73", "v74", "ds_read_b128 v[72:75], %[ta] offset:128\n\t")
         LK_ROW9_TAP(7, 8, 1, "") LK_ROW9_USE(7, "v76", "v77", "v78", "")
         LK_ROW9_TAP(8, 9, 0, "") LK_ROW9_USE(8, "v72", "v73", "v74", "")
@@ -619,27 +609,27 @@ __device__ __forceinline__ void lk_row9_asm_g(float (&r)[19], const float (&a)[9
     float tmp;
     asm volatile(
         "ds_read_b32 %[l0], %[ja]\n\t"
-        LK_X_TEX("ds_read_b32 %[l1], %[ja] offset:4\n\t")
+        "ds_read_b32 %[l1], %[ja] offset:4\n\t"
         "ds_read_b32 %[l2], %[ja] offset:8\n\t"
-        LK_X_TEX("ds_read_b32 %[l3], %[ja] offset:12\n\t")
+        "ds_read_b32 %[l3], %[ja] offset:12\n\t"
         "ds_read_b32 %[l4], %[ja] offset:16\n\t"
-        LK_X_TEX("ds_read_b32 %[l5], %[ja] offset:20\n\t")
+        "ds_read_b32 %[l5], %[ja] offset:20\n\t"
         "ds_read_b32 %[l6], %[ja] offset:24\n\t"
-        LK_X_TEX("ds_read_b32 %[l7], %[ja] offset:28\n\t")
+        "ds_read_b32 %[l7], %[ja] offset:28\n\t"
         "ds_read_b32 %[l8], %[ja] offset:32\n\t"
-        LK_X_TEX("ds_read_b32 %[l9], %[ja] offset:36\n\t")
+        "ds_read_b32 %[l9], %[ja] offset:36\n\t"
         "ds_read_b128 v[72:75], %[ta]\n\t"
-        LK_X_ODD("ds_read_b128 v[76:79], %[ta] offset:16\n\t")
+        "ds_read_b128 v[76:79], %[ta] offset:16\n\t"
         "s_waitcnt lgkmcnt(10)\n\t"                                            // l0, l1 are there
         // tap k: horizontal + vertical interpolation while its tile record is in flight, then the residual sums; the quad
         // it used is refilled with tap k + 2's record.  Waits: 12 reads issued; before tap k's first use of l[k+1] at most
         // 10 - k of the texel reads ... may be outstanding behind the two tile reads (counted below per tap).
         LK_ROW9_TAP(0, 1, 1, "") LK_ROW9_USE_G(0, "v72", "v73", "v74", "ds_read_b128 v[72:75], %[ta] offset:32\n\t")
-        LK_ROW9_TAP(1, 2, 1, "") LK_ROW9_USE_G(1, "v76", "v77", "v78", LK_X_ODD("ds_read_b128 v[76:79], %[ta] offset:48\n\t"))
+        LK_ROW9_TAP(1, 2, 1, "") LK_ROW9_USE_G(1, "v76", "v77", "v78", "ds_read_b128 v[76:79], %[ta] offset:48\n\t")
         LK_ROW9_TAP(2, 3, 1, "") LK_ROW9_USE_G(2, "v72", "v73", "v74", "ds_read_b128 v[72:75], %[ta] offset:64\n\t")
-        LK_ROW9_TAP(3, 4, 1, "") LK_ROW9_USE_G(3, "v76", "v77", "v78", LK_X_ODD("ds_read_b128 v[76:79], %[ta] offset:80\n\t"))
+        LK_ROW9_TAP(3, 4, 1, "") LK_ROW9_USE_G(3, "v76", "v77", "v78", "ds_read_b128 v[76:79], %[ta] offset:80\n\t")
         LK_ROW9_TAP(4, 5, 1, "") LK_ROW9_USE_G(4, "v72", "v73", "v74", "ds_read_b128 v[72:75], %[ta] offset:96\n\t")
-        LK_ROW9_TAP(5, 6, 1, "") LK_ROW9_USE_G(5, "v76", "v77", "v78", LK_X_ODD("ds_read_b128 v[76:79], %[ta] offset:112\n\t"))
+        LK_ROW9_TAP(5, 6, 1, "") LK_ROW9_USE_G(5, "v76", "v77", "v78", "ds_read_b128 v[76:79], %[ta] offset:112\n\t")
         LK_ROW9_TAP(6, 7, 1, "") LK_ROW9_USE_G(6, "v72", "v73", "v74", "ds_read_b128 v[72:75], %[ta] offset:128\n\t")
         LK_ROW9_TAP(7, 8, 1, "") LK_ROW9_USE_G(7, "v76", "v77", "v78", "")
         LK_ROW9_TAP(8, 9, 0, "") LK_ROW9_USE_G(8, "v72", "v73", "v74", "")
@@ -654,6 +644,38 @@ __device__ __forceinline__ void lk_row9_asm_g(float (&r)[19], const float (&a)[9
 #undef LK_ROW9_TAP
 #undef LK_ROW9_USE
 #undef LK_ROW9_USE_G
+
+// All nine rows of a step as ONE asm statement, LDS reads software-pipelined across the rows (tools/gen_lk_rows9.py has the
+// schedule and derives every wait count; lk_rows9.inc is its output).  For waves all of whose member pixels have consecutive
+// window columns AND rows: sample row of window row r = the first + r, so every address is the base + an immediate.
+//   ja: LDS address of texel 0 of the UPPER sample row of window row 0;  ta: of the record of window row 0, tap 0
+//   yf0 = (float)(y - R), fy = the flow's v: row r's fraction is v_fract_f32((yf0 + r) + fy), the oracle's sum
+#include "lk_rows9.inc"
+template <bool WITH_G>
+__device__ __forceinline__ void lk_rows9_asm(const float (&a)[9], float fy, float yf0, float& bx, float& by, float& gxx, float& gxy,
+                                             float& gyy, uint32_t ja, uint32_t ta) {
+    float r0, r1, r2, r3, r4, r5, r6, r7, r8, r9, r10, r11, r12, r13, r14, r15, r16, r17, r18, tmp, ay;
+#define LK_ROWS9_REGS                                                                                                             \
+    [r0] "=&v"(r0), [r1] "=&v"(r1), [r2] "=&v"(r2), [r3] "=&v"(r3), [r4] "=&v"(r4), [r5] "=&v"(r5), [r6] "=&v"(r6), [r7] "=&v"(r7),  \
+    [r8] "=&v"(r8), [r9] "=&v"(r9), [r10] "=&v"(r10), [r11] "=&v"(r11), [r12] "=&v"(r12), [r13] "=&v"(r13), [r14] "=&v"(r14),       \
+    [r15] "=&v"(r15), [r16] "=&v"(r16), [r17] "=&v"(r17), [r18] "=&v"(r18), [tmp] "=&v"(tmp), [ay] "=&v"(ay)
+#define LK_ROWS9_INS                                                                                                              \
+    [a0] "v"(a[0]), [a1] "v"(a[1]), [a2] "v"(a[2]), [a3] "v"(a[3]), [a4] "v"(a[4]), [a5] "v"(a[5]), [a6] "v"(a[6]), [a7] "v"(a[7]),    \
+    [a8] "v"(a[8]), [fy] "v"(fy), [yf0] "v"(yf0), [ja] "v"(ja), [ta] "v"(ta)
+    if constexpr (WITH_G) {
+        asm volatile(LK_ROWS9_BODY_G
+                     : LK_ROWS9_REGS, [bx] "+v"(bx), [by] "+v"(by), [gxx] "+v"(gxx), [gxy] "+v"(gxy), [gyy] "+v"(gyy)
+                     : LK_ROWS9_INS
+                     : "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "memory");
+    } else {
+        asm volatile(LK_ROWS9_BODY
+                     : LK_ROWS9_REGS, [bx] "+v"(bx), [by] "+v"(by)
+                     : LK_ROWS9_INS
+                     : "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "memory");
+    }
+#undef LK_ROWS9_REGS
+#undef LK_ROWS9_INS
+}
 
 // Current-frame window in LDS.  The bilinear fetches J(q + flow(p)) of a workgroup land in the rectangle
 // [tile + window] shifted by the flows of its pixels; when those flows differ by at most SPREAD_X / SPREAD_Y pixels (almost every
@@ -938,26 +960,197 @@ __global__ __launch_bounds__(256, LkStepShared<RADIUS>::WAVES_PER_SIMD) void lk_
         const int ymax = max(max(uni(bq[0][3]), uni(bq[1][3])), max(uni(bq[2][3]), uni(bq[3][3])));
         const bool fits = xmax >= xmin && xmax - xmin < S::LW && ymax - bymin < S::LH &&
                           !(it == force_fall && ((tile_x + tile_y) & 1));
-        bool pending = active;
-        // One pass for a tile whose rectangle fits (every pixel is a member); otherwise up to max_rounds grouping rounds.
-#pragma unroll 1
-        for (int round = 0;; ++round) {
-            bool member;
-            if (fits) {                                                      // uniform: box[] is the same for every thread
-                member = pending;
-                // The rectangle is staged with a margin and KEPT: a later step whose box still lies inside it (flows move by a
-                // fraction of a pixel per step once the coarser levels have done their work) reuses it -- no global loads, no
-                // second barrier in that step.
-                const bool inside = st_valid && xmin >= st_x0 && xmax <= st_x1 && bymin >= st_y0 && ymax <= st_y1;
-                if (!inside) {
-                    // margins: up to kJMargin pixels on every side, as far as the capacity allows
-                    const int mx = min(kJMargin, (S::LW - (xmax - xmin + 1)) / 2), my = min(kJMargin, (S::LH - (ymax - bymin + 1)) / 2);
-                    stage_rect(xmin - mx, xmax + mx, bymin - my, ymax + my);
-                    st_valid = true;
-                    __syncthreads();
+        // The rows of one Gauss-Newton step for the lanes that call it (the members of the staged rectangle), ending with the flow
+        // update: instantiated for the ordinary path (the whole tile) and once more inside the grouping rounds of an unfit tile,
+        // so that nothing of the rare path is live across the ordinary one.
+        auto rows_and_solve = [&]() {
+            const int xs = st_xs, ymin = st_y0;                          // origin of jl[][] in frame coordinates
+            // wave-uniform: every member lane's window columns / rows sample consecutive texels
+            const bool all_cons = __all(cons_x);
+            const bool fast_x = tile_in_x && all_cons;
+            const bool fast_y = tile_in_y && __all(cons_y);
+            float ax[N];
+            int xi0;                                                     // origin of window column 0 (all the consecutive-column rows need)
+            {
+                int xr = x;
+                asm volatile("" : "+v"(xr));                              // opaque: a second evaluation, not the first one kept alive
+                if (fast_x) {
+                    // unclamped columns with floors 0 <= xi0, xi0 + 1, ... < w: no clamp is active, and for a sum fq >= 0 the
+                    // fraction fq - floor(fq) is exact, which is what v_fract_f32 returns -- the oracle's values in 3
+                    // operations per column instead of 7
+                    const float xf0 = (float)(xr - RADIUS);
+#pragma unroll
+                    for (int k = 0; k < N; ++k) {
+                        const float fq = (xf0 + (float)k) + f.x;            // (float)(x + k - R), exact, + u: the oracle's sum
+                        ax[k] = __builtin_amdgcn_fractf(fq);
+                        if (k == 0) xi0 = (int)__builtin_floorf(fq);
+                    }
+                } else {
+                    float frac;
+#pragma unroll
+                    for (int k = 0; k < N; ++k) { const int o = lk_origin(lk_clampi(xr + k - RADIUS, 0, w - 1), f.x, w, frac); ax[k] = frac; if (k == 0) xi0 = o; }
                 }
-            } else {
-                if (round >= max_rounds) break;
+            }
+            // hup[k] = horizontal interpolation of the UPPER sample row at column k.  The lower row of one window row is the
+            // upper row of the next whenever the sample row advanced by exactly one (always, away from the top/bottom
+            // border), and its interpolation j01 + ax[k] * (j11 - j01) is then the very expression the next row evaluates
+            // as j00 + ax[k] * (j10 - j00) on the same texels: carried over instead of recomputed -- same operations on the
+            // same inputs, 11 instead of 14 VALU operations per tap.  Decided per wave so the branch is uniform; recomputing
+            // is always correct.
+            float bx = 0.0f, by = 0.0f;
+            bool done = false;
+            if constexpr (RADIUS == 4 && OFPS_LK_SPEC_FMA) {
+                if (fast_x && fast_y) {
+                    // interior tile, every member's columns and rows consecutive (the ordinary case): all nine rows in one
+                    // hand-scheduled block whose LDS reads are pipelined across the rows (lk_rows9_asm)
+                    static_assert(S::JS * sizeof(float) == LK_ROWS9_JSB && T::TW * sizeof(float4) == LK_ROWS9_TRB, "lk_rows9.inc was generated for other pitches");
+                    int yr = y;
+                    asm volatile("" : "+v"(yr));
+                    const float yf0 = (float)(yr - RADIUS);
+                    const int yi0 = (int)__builtin_floorf(yf0 + f.y) - ymin;
+                    const uint32_t ja = (uint32_t)reinterpret_cast<uintptr_t>(&sh.jl[yi0][xi0 - xs]);
+                    const uint32_t ta = (uint32_t)reinterpret_cast<uintptr_t>(&sh.tile[ly][lx]);
+                    if (it == 0) lk_rows9_asm<true>(ax, f.y, yf0, bx, by, gxx, gxy, gyy, ja, ta);      // the level's first step also sums the structure tensor
+                    else lk_rows9_asm<false>(ax, f.y, yf0, bx, by, gxx, gxy, gyy, ja, ta);
+                    done = true;
+                } else if (all_cons) {
+                    // consecutive columns but clamped or irregular rows (top / bottom image border, flows that jump in y):
+                    // hand-scheduled rows one at a time (lk_row9_asm): two register sets alternate between "this row's texels,
+                    // turned into its interpolations" and "the previous row's interpolations", so the row loop runs in pairs
+                    float rr[19];
+                    int prev_yi = -0x7FFFFFFF;
+                    const uint32_t jl0 = (uint32_t)reinterpret_cast<uintptr_t>(&sh.jl[0][xi0 - xs]);
+                    const uint32_t tl0 = (uint32_t)reinterpret_cast<uintptr_t>(&sh.tile[ly][lx]);
+                    auto row = [&](int r, auto parity, auto with_g) {
+                        constexpr int P = decltype(parity)::value;
+                        float ay;
+                        const int yi = lk_origin(lk_clampi(y + r - RADIUS, 0, h - 1), f.y, h, ay) - ymin;
+                        // (the first row always makes its upper sample row: stated at compile time, so that the carried
+                        // registers are not live into the loop -- hipcc spilled their undefined contents around every step)
+                        const bool reuse = r > 0 && __all(yi == prev_yi + 1);
+                        prev_yi = yi;
+                        if (!reuse) {                              // the upper sample row is not the one carried over: make it
+                            const float* ra = &sh.jl[yi][xi0 - xs];
+                            float jb[N + 1];
+#pragma unroll
+                            for (int k = 0; k <= N; ++k) jb[k] = ra[k];
+#pragma unroll
+                            for (int k = 0; k < N; ++k) rr[P ? k : 10 + k] = lk_lerp(jb[k], jb[k + 1], ax[k]);
+                        }
+                        const uint32_t ja = jl0 + (uint32_t)(yi + 1) * (uint32_t)(S::JS * sizeof(float));
+                        const uint32_t ta = tl0 + (uint32_t)r * (uint32_t)(T::TW * sizeof(float4));
+                        if constexpr (decltype(with_g)::value) lk_row9_asm_g<P>(rr, ax, ay, bx, by, gxx, gxy, gyy, ja, ta);
+                        else lk_row9_asm<P>(rr, ax, ay, bx, by, ja, ta);
+                    };
+                    using P0 = std::integral_constant<int, 0>; using P1 = std::integral_constant<int, 1>;
+                    if (it == 0) {                                 // the level's first step also sums the structure tensor
+                        row(0, P0{}, std::true_type{});
+#pragma unroll 1
+                        for (int r = 1; r < N; r += 2) { row(r, P1{}, std::true_type{}); row(r + 1, P0{}, std::true_type{}); }
+                    } else {
+                        row(0, P0{}, std::false_type{});
+#pragma unroll 1
+                        for (int r = 1; r < N; r += 2) { row(r, P1{}, std::false_type{}); row(r + 1, P0{}, std::false_type{}); }
+                    }
+                    done = true;
+                }
+            }
+            if (!done) {
+                float hup[N];
+                int prev_yi = -0x7FFFFFFF;
+                if (all_cons) {
+                    const int xo = xi0 - xs;
+                    float jb[N + 1];
+                    // (measured and rejected: unrolling the row loop, fully or by two/three with ping-pong hup arrays -- hipcc
+                    // then hoists the next row's LDS reads, 104+ VGPRs, 4 waves per SIMD, 0.53 vs 0.50 ms)
+#pragma unroll 1
+                    for (int r = 0; r < N; ++r) {
+                        float ay;
+                        const int yi = lk_origin(lk_clampi(y + r - RADIUS, 0, h - 1), f.y, h, ay) - ymin;
+                        const bool reuse = __all(yi == prev_yi + 1);
+                        prev_yi = yi;
+                        if (!reuse) {
+                            const float* ra = &sh.jl[yi][xo];
+#pragma unroll
+                            for (int k = 0; k <= N; ++k) jb[k] = ra[k];
+#pragma unroll
+                            for (int k = 0; k < N; ++k) hup[k] = lk_lerp(jb[k], jb[k + 1], ax[k]);
+                        }
+                        const float* rb = &sh.jl[yi + 1][xo];
+#pragma unroll
+                        for (int k = 0; k <= N; ++k) jb[k] = rb[k];
+#pragma unroll
+                        for (int k = 0; k < N; ++k) {
+                            const float top = hup[k];
+                            const float bot = lk_lerp(jb[k], jb[k + 1], ax[k]);
+                            const lk_f4 t = lk_lds_read4(&sh.tile[ly + r][lx + k]);
+                            const float d = t.x - lk_lerp(top, bot, ay);
+                            lk_accum(t.y, d, bx);
+                            lk_accum(t.z, d, by);
+                            if (it == 0) { lk_accum(t.y, t.y, gxx); lk_accum(t.y, t.z, gxy); lk_accum(t.z, t.z, gyy); }
+                            hup[k] = bot;
+                        }
+                    }
+                } else {
+                    // (image-border tiles and windows across a binade only: every column's own origin, made here -- kept alive
+                    // from the pass above they were spilled around the hand-scheduled rows of every other tile)
+                    int xi[N];
+                    {
+                        int xr = x;
+                        asm volatile("" : "+v"(xr));
+                        float frac;
+#pragma unroll
+                        for (int k = 0; k < N; ++k) xi[k] = lk_origin(lk_clampi(xr + k - RADIUS, 0, w - 1), f.x, w, frac) - xs;
+                    }
+#pragma unroll 1
+                    for (int r = 0; r < N; ++r) {
+                        float ay;
+                        const int yi = lk_origin(lk_clampi(y + r - RADIUS, 0, h - 1), f.y, h, ay) - ymin;
+                        const bool reuse = __all(yi == prev_yi + 1);
+                        prev_yi = yi;
+                        if (!reuse) {
+                            const float* ra = &sh.jl[yi][0];
+#pragma unroll
+                            for (int k = 0; k < N; ++k) { const float j0 = ra[xi[k]], j1 = ra[xi[k] + 1]; hup[k] = lk_lerp(j0, j1, ax[k]); }
+                        }
+                        const float* rb = &sh.jl[yi + 1][0];
+#pragma unroll
+                        for (int k = 0; k < N; ++k) {
+                            const float j0 = rb[xi[k]], j1 = rb[xi[k] + 1];
+                            const float top = hup[k];
+                            const float bot = lk_lerp(j0, j1, ax[k]);
+                            const lk_f4 t = lk_lds_read4(&sh.tile[ly + r][lx + k]);
+                            const float d = t.x - lk_lerp(top, bot, ay);
+                            lk_accum(t.y, d, bx);
+                            lk_accum(t.z, d, by);
+                            if (it == 0) { lk_accum(t.y, t.y, gxx); lk_accum(t.y, t.z, gxy); lk_accum(t.z, t.z, gyy); }
+                            hup[k] = bot;
+                        }
+                    }
+                }
+            }
+            f = lk_solve(make_float4(gxx, gxy, gyy, 0.0f), f, bx, by);
+        };
+        if (fits) {                                                          // uniform: box[] is the same for every thread
+            // The rectangle is staged with a margin and KEPT: a later step whose box still lies inside it (flows move by a
+            // fraction of a pixel per step once the coarser levels have done their work) reuses it -- no global loads, no
+            // second barrier in that step.
+            const bool inside = st_valid && xmin >= st_x0 && xmax <= st_x1 && bymin >= st_y0 && ymax <= st_y1;
+            if (!inside) {
+                // margins: up to kJMargin pixels on every side, as far as the capacity allows
+                const int mx = min(kJMargin, (S::LW - (xmax - xmin + 1)) / 2), my = min(kJMargin, (S::LH - (ymax - bymin + 1)) / 2);
+                stage_rect(xmin - mx, xmax + mx, bymin - my, ymax + my);
+                st_valid = true;
+                __syncthreads();
+            }
+            if (it == 0) OFPS_LK_STAMP(3);
+            if (active) rows_and_solve();
+        } else {
+            // ---- a tile whose sample rectangle does not fit: its pixels in groups, at most max_rounds of them
+            bool pending = active;
+            st_valid = false;                                                // whatever jl[][] holds after this step is not the tile's rectangle
+#pragma unroll 1
+            for (int round = 0; round < max_rounds; ++round) {
                 // anchor of this round: the first pending pixel of the first wave that has one.  Its box is made again here (kept
                 // alive across the rows it would be four more registers around the hot loop of every tile).
                 remake_xy();
@@ -980,228 +1173,42 @@ __global__ __launch_bounds__(256, LkStepShared<RADIUS>::WAVES_PER_SIMD) void lk_
                 // 16-byte staging applies (a pixel's box is at most 2R + 2 wide and high: the anchor itself always fits)
                 const int rx0 = (A0 - (S::LW - 4 - (A1 - A0 + 1)) / 2) & ~3, rx1 = rx0 + S::LW - 1;
                 const int ry0 = B0 - (S::LH - (B1 - B0 + 1)) / 2, ry1 = ry0 + S::LH - 1;
-                member = pending && a0 >= rx0 && a1 <= rx1 && b0 >= ry0 && b1 <= ry1;
+                const bool member = pending && a0 >= rx0 && a1 <= rx1 && b0 >= ry0 && b1 <= ry1;
                 stage_rect(rx0, rx1, ry0, ry1);
-                st_valid = false;                                            // not the tile's rectangle: the next step stages its own
                 __syncthreads();
+                if (member) { rows_and_solve(); pending = false; }
             }
-            if (it == 0 && round == 0) OFPS_LK_STAMP(3);
-            if (member) {
-                const int xs = st_xs, ymin = st_y0;                          // origin of jl[][] in frame coordinates
-                // wave-uniform: every member lane's window columns / rows sample consecutive texels
-                const bool all_cons = __all(cons_x);
-                const bool fast_x = tile_in_x && all_cons;
-#ifdef OFPS_LK_X_SLOW_Y
-                const bool fast_y = false;
-#else
-                const bool fast_y = tile_in_y && __all(cons_y);
-#endif
-                float ax[N];
-                int xi0;                                                     // origin of window column 0 (all the consecutive-column rows need)
-                {
-                    int xr = x;
-                    asm volatile("" : "+v"(xr));                              // opaque: a second evaluation, not the first one kept alive
-                    if (fast_x) {
-                        // unclamped columns with floors 0 <= xi0, xi0 + 1, ... < w: no clamp is active, and for a sum fq >= 0 the
-                        // fraction fq - floor(fq) is exact, which is what v_fract_f32 returns -- the oracle's values in 3
-                        // operations per column instead of 7
-                        const float xf0 = (float)(xr - RADIUS);
-#pragma unroll
-                        for (int k = 0; k < N; ++k) {
-                            const float fq = (xf0 + (float)k) + f.x;            // (float)(x + k - R), exact, + u: the oracle's sum
-                            ax[k] = __builtin_amdgcn_fractf(fq);
-                            if (k == 0) xi0 = (int)__builtin_floorf(fq);
-                        }
-                    } else {
-                        float frac;
-#pragma unroll
-                        for (int k = 0; k < N; ++k) { const int o = lk_origin(lk_clampi(xr + k - RADIUS, 0, w - 1), f.x, w, frac); ax[k] = frac; if (k == 0) xi0 = o; }
-                    }
-                }
-                // hup[k] = horizontal interpolation of the UPPER sample row at column k.  The lower row of one window row is the
-                // upper row of the next whenever the sample row advanced by exactly one (always, away from the top/bottom
-                // border), and its interpolation j01 + ax[k] * (j11 - j01) is then the very expression the next row evaluates
-                // as j00 + ax[k] * (j10 - j00) on the same texels: carried over instead of recomputed -- same operations on the
-                // same inputs, 11 instead of 14 VALU operations per tap.  Decided per wave so the branch is uniform; recomputing
-                // is always correct.
+            if (pending) {
+                // Leftover of a tile without coherent flows: the oracle's per-sample form for this pixel, the current frame read from
+                // global memory (two clamped texel pairs per tap), the previous frame's records from the tile.  Small and slow on
+                // purpose (it bounds the work of an incoherent tile at what the per-lane-gather kernel of rounds 2-3 cost); same
+                // operands, same operations, same order as every other path.
                 float bx = 0.0f, by = 0.0f;
-                bool done = false;
-                if constexpr (RADIUS == 4 && OFPS_LK_SPEC_FMA) {
-                    if (all_cons) {
-                        // hand-scheduled rows (lk_row9_asm): two register sets alternate between "this row's texels, turned into
-                        // its interpolations" and "the previous row's interpolations", so the row loop runs in pairs
-                        float rr[19];
-                        int prev_yi = -0x7FFFFFFF;
-                        const uint32_t jl0 = (uint32_t)reinterpret_cast<uintptr_t>(&sh.jl[0][xi0 - xs]);
-                        const uint32_t tl0 = (uint32_t)reinterpret_cast<uintptr_t>(&sh.tile[ly][lx]);
-                        // rows of an interior tile whose floors are consecutive (fast_y): sample row of window row r = the first
-                        // one + r, its fraction v_fract_f32 of the oracle's sum (exact for sums >= 0, like the columns'), and the
-                        // upper sample row is always the one carried over -- 5 operations per row instead of a floor chain, two
-                        // clamps and a vote
-                        float yf0 = 0.0f;
-                        int yi0 = 0;
-                        if (fast_y) {
-                            int yr = y;
-                            asm volatile("" : "+v"(yr));
-                            yf0 = (float)(yr - RADIUS);
-                            yi0 = (int)__builtin_floorf(yf0 + f.y) - ymin;
-                        }
-                        auto row = [&](int r, auto parity, auto with_g, auto fasty) {
-                            constexpr int P = decltype(parity)::value;
-                            float ay;
-                            int yi;
-                            bool reuse;
-                            if constexpr (decltype(fasty)::value) {
-                                ay = __builtin_amdgcn_fractf((yf0 + (float)r) + f.y);
-                                yi = yi0 + r;
-                                reuse = r > 0;
-                            } else {
-                                yi = lk_origin(lk_clampi(y + r - RADIUS, 0, h - 1), f.y, h, ay) - ymin;
-                                // (the first row always makes its upper sample row: stated at compile time, so that the carried
-                                // registers are not live into the loop -- hipcc spilled their undefined contents around every step)
-                                reuse = r > 0 && __all(yi == prev_yi + 1);
-                                prev_yi = yi;
-                            }
-                            if (!reuse) {                              // the upper sample row is not the one carried over: make it
-                                const float* ra = &sh.jl[yi][xi0 - xs];
-                                float jb[N + 1];
-#pragma unroll
-                                for (int k = 0; k <= N; ++k) jb[k] = ra[k];
-#pragma unroll
-                                for (int k = 0; k < N; ++k) rr[P ? k : 10 + k] = lk_lerp(jb[k], jb[k + 1], ax[k]);
-                            }
-                            const uint32_t ja = jl0 + (uint32_t)(yi + 1) * (uint32_t)(S::JS * sizeof(float));
-                            const uint32_t ta = tl0 + (uint32_t)r * (uint32_t)(T::TW * sizeof(float4));
-                            if constexpr (decltype(with_g)::value) lk_row9_asm_g<P>(rr, ax, ay, bx, by, gxx, gxy, gyy, ja, ta);
-                            else lk_row9_asm<P>(rr, ax, ay, bx, by, ja, ta);
-                        };
-                        using P0 = std::integral_constant<int, 0>; using P1 = std::integral_constant<int, 1>;
-                        auto rows = [&](auto with_g, auto fasty) {
-                            row(0, P0{}, with_g, fasty);
-#pragma unroll 1
-                            for (int r = 1; r < N; r += 2) { row(r, P1{}, with_g, fasty); row(r + 1, P0{}, with_g, fasty); }
-                        };
-                        if (it == 0) {                                 // the level's first step also sums the structure tensor
-                            if (fast_y) rows(std::true_type{}, std::true_type{}); else rows(std::true_type{}, std::false_type{});
-                        } else {
-                            if (fast_y) rows(std::false_type{}, std::true_type{}); else rows(std::false_type{}, std::false_type{});
-                        }
-                        done = true;
+                const int jpitch = U8 ? src_stride : w;
+                auto jat = [&](size_t idx) -> float { if constexpr (U8) return (float)J8[idx]; else return J[idx]; };
+                int xr = x, yr = y;
+                asm volatile("" : "+v"(xr), "+v"(yr));
+    #pragma unroll 1
+                for (int r = 0; r < N; ++r) {
+                    float ay;
+                    const int yi = lk_origin(lk_clampi(yr + r - RADIUS, 0, h - 1), f.y, h, ay);
+                    const size_t ra = (size_t)lk_clampi(yi, 0, h - 1) * jpitch, rb = (size_t)lk_clampi(yi + 1, 0, h - 1) * jpitch;
+    #pragma unroll 1
+                    for (int k = 0; k < N; ++k) {
+                        float axk;
+                        const int xi = lk_origin(lk_clampi(xr + k - RADIUS, 0, w - 1), f.x, w, axk);
+                        const int xa = lk_clampi(xi, 0, w - 1), xb = lk_clampi(xi + 1, 0, w - 1);
+                        const float top = lk_lerp(jat(ra + xa), jat(ra + xb), axk);
+                        const float bot = lk_lerp(jat(rb + xa), jat(rb + xb), axk);
+                        const lk_f4 t = lk_lds_read4(&sh.tile[ly + r][lx + k]);
+                        const float d = t.x - lk_lerp(top, bot, ay);
+                        lk_accum(t.y, d, bx);
+                        lk_accum(t.z, d, by);
+                        if (it == 0) { lk_accum(t.y, t.y, gxx); lk_accum(t.y, t.z, gxy); lk_accum(t.z, t.z, gyy); }
                     }
                 }
-                if (!done) {
-                    float hup[N];
-                    int prev_yi = -0x7FFFFFFF;
-                    if (all_cons) {
-                        const int xo = xi0 - xs;
-                        float jb[N + 1];
-                        // (measured and rejected: unrolling the row loop, fully or by two/three with ping-pong hup arrays -- hipcc
-                        // then hoists the next row's LDS reads, 104+ VGPRs, 4 waves per SIMD, 0.53 vs 0.50 ms)
-#pragma unroll 1
-                        for (int r = 0; r < N; ++r) {
-                            float ay;
-                            const int yi = lk_origin(lk_clampi(y + r - RADIUS, 0, h - 1), f.y, h, ay) - ymin;
-                            const bool reuse = __all(yi == prev_yi + 1);
-                            prev_yi = yi;
-                            if (!reuse) {
-                                const float* ra = &sh.jl[yi][xo];
-#pragma unroll
-                                for (int k = 0; k <= N; ++k) jb[k] = ra[k];
-#pragma unroll
-                                for (int k = 0; k < N; ++k) hup[k] = lk_lerp(jb[k], jb[k + 1], ax[k]);
-                            }
-                            const float* rb = &sh.jl[yi + 1][xo];
-#pragma unroll
-                            for (int k = 0; k <= N; ++k) jb[k] = rb[k];
-#pragma unroll
-                            for (int k = 0; k < N; ++k) {
-                                const float top = hup[k];
-                                const float bot = lk_lerp(jb[k], jb[k + 1], ax[k]);
-                                const lk_f4 t = lk_lds_read4(&sh.tile[ly + r][lx + k]);
-                                const float d = t.x - lk_lerp(top, bot, ay);
-                                lk_accum(t.y, d, bx);
-                                lk_accum(t.z, d, by);
-                                if (it == 0) { lk_accum(t.y, t.y, gxx); lk_accum(t.y, t.z, gxy); lk_accum(t.z, t.z, gyy); }
-                                hup[k] = bot;
-                            }
-                        }
-                    } else {
-                        // (image-border tiles and windows across a binade only: every column's own origin, made here -- kept alive
-                        // from the pass above they were spilled around the hand-scheduled rows of every other tile)
-                        int xi[N];
-                        {
-                            int xr = x;
-                            asm volatile("" : "+v"(xr));
-                            float frac;
-#pragma unroll
-                            for (int k = 0; k < N; ++k) xi[k] = lk_origin(lk_clampi(xr + k - RADIUS, 0, w - 1), f.x, w, frac) - xs;
-                        }
-#pragma unroll 1
-                        for (int r = 0; r < N; ++r) {
-                            float ay;
-                            const int yi = lk_origin(lk_clampi(y + r - RADIUS, 0, h - 1), f.y, h, ay) - ymin;
-                            const bool reuse = __all(yi == prev_yi + 1);
-                            prev_yi = yi;
-                            if (!reuse) {
-                                const float* ra = &sh.jl[yi][0];
-#pragma unroll
-                                for (int k = 0; k < N; ++k) { const float j0 = ra[xi[k]], j1 = ra[xi[k] + 1]; hup[k] = lk_lerp(j0, j1, ax[k]); }
-                            }
-                            const float* rb = &sh.jl[yi + 1][0];
-#pragma unroll
-                            for (int k = 0; k < N; ++k) {
-                                const float j0 = rb[xi[k]], j1 = rb[xi[k] + 1];
-                                const float top = hup[k];
-                                const float bot = lk_lerp(j0, j1, ax[k]);
-                                const lk_f4 t = lk_lds_read4(&sh.tile[ly + r][lx + k]);
-                                const float d = t.x - lk_lerp(top, bot, ay);
-                                lk_accum(t.y, d, bx);
-                                lk_accum(t.z, d, by);
-                                if (it == 0) { lk_accum(t.y, t.y, gxx); lk_accum(t.y, t.z, gxy); lk_accum(t.z, t.z, gyy); }
-                                hup[k] = bot;
-                            }
-                        }
-                    }
-                }
-#ifdef OFPS_LK_X_NO_UPDATE                                  // timing experiments only: the arithmetic runs, the flow stays what it was
-                { const float2 fn = lk_solve(make_float4(gxx, gxy, gyy, 0.0f), f, bx, by); asm volatile("" :: "v"(fn.x), "v"(fn.y)); }
-#else
                 f = lk_solve(make_float4(gxx, gxy, gyy, 0.0f), f, bx, by);
-#endif
-                pending = false;
             }
-            if (fits) break;
-        }
-        if (!fits && pending) {
-            // Leftover of a tile without coherent flows: the oracle's per-sample form for this pixel, the current frame read from
-            // global memory (two clamped texel pairs per tap), the previous frame's records from the tile.  Small and slow on
-            // purpose (it bounds the work of an incoherent tile at what the per-lane-gather kernel of rounds 2-3 cost); same
-            // operands, same operations, same order as every other path.
-            float bx = 0.0f, by = 0.0f;
-            const int jpitch = U8 ? src_stride : w;
-            auto jat = [&](size_t idx) -> float { if constexpr (U8) return (float)J8[idx]; else return J[idx]; };
-            int xr = x, yr = y;
-            asm volatile("" : "+v"(xr), "+v"(yr));
-#pragma unroll 1
-            for (int r = 0; r < N; ++r) {
-                float ay;
-                const int yi = lk_origin(lk_clampi(yr + r - RADIUS, 0, h - 1), f.y, h, ay);
-                const size_t ra = (size_t)lk_clampi(yi, 0, h - 1) * jpitch, rb = (size_t)lk_clampi(yi + 1, 0, h - 1) * jpitch;
-#pragma unroll 1
-                for (int k = 0; k < N; ++k) {
-                    float axk;
-                    const int xi = lk_origin(lk_clampi(xr + k - RADIUS, 0, w - 1), f.x, w, axk);
-                    const int xa = lk_clampi(xi, 0, w - 1), xb = lk_clampi(xi + 1, 0, w - 1);
-                    const float top = lk_lerp(jat(ra + xa), jat(ra + xb), axk);
-                    const float bot = lk_lerp(jat(rb + xa), jat(rb + xb), axk);
-                    const lk_f4 t = lk_lds_read4(&sh.tile[ly + r][lx + k]);
-                    const float d = t.x - lk_lerp(top, bot, ay);
-                    lk_accum(t.y, d, bx);
-                    lk_accum(t.z, d, by);
-                    if (it == 0) { lk_accum(t.y, t.y, gxx); lk_accum(t.y, t.z, gxy); lk_accum(t.z, t.z, gyy); }
-                }
-            }
-            f = lk_solve(make_float4(gxx, gxy, gyy, 0.0f), f, bx, by);
         }
         if (it == 0) OFPS_LK_STAMP(4);
     }
@@ -1399,80 +1406,120 @@ int ofps_hip_lk_flow_init_dev(ofps_hip_ctx* ctx, const void* d_prev, const void*
 // :98-121 with one record per visited cell in BTreeSet<(x,y)> order ("Process Fullres" = true, the default), or
 // returned per pixel in raster order (OFPS_HIP_LK_PER_PIXEL: the `mf.push` branch; the reference resizes its
 // frames to the capped grid first, which is the caller's job here).  Only the final records leave the device.
-// the part of a hip_lk process_frame that follows the uploads: d_frames holds two W-pitched frames, slot_prev / slot_cur
-// say which is which
-static int lk_decode_resident(ofps_hip_ctx* ctx, uint8_t* d_frames, int slot_prev, int slot_cur, int W, int H, int levels, int radius,
-                              int iters, int max_w, int max_h, unsigned flags, float* out_entries, size_t* n_out, int* out_w,
-                              int* out_h) {
-    const bool use_mask = flags & OFPS_HIP_LK_CONTRAST_MASK, per_pixel = flags & OFPS_HIP_LK_PER_PIXEL;
+}  // extern "C"
+
+namespace {
+
+struct LkGrid {                 // what a process_frame returns for this geometry / these flags
+    int gw = 0, gh = 0;         // the record grid
+    bool per_pixel = false, use_mask = false;
+    size_t max_records = 0;     // capacity the records need
+};
+
+int lk_grid_of(ofps_hip_ctx* ctx, int W, int H, int max_w, int max_h, unsigned flags, LkGrid* g) {
+    g->use_mask = flags & OFPS_HIP_LK_CONTRAST_MASK; g->per_pixel = flags & OFPS_HIP_LK_PER_PIXEL;
     // cv-decoder/src/lib.rs:98-121 with aspect_ratio_scale = (1, 1): usize arithmetic
     const size_t cw = (size_t)(max_w < W ? max_w : W), ch = (size_t)(max_h < H ? max_h : H);
     const size_t wb0 = cw, wb1 = cw * (size_t)H / (size_t)W, hb0 = ch * (size_t)W / (size_t)H, hb1 = ch;
     const int gw = (int)(wb0 < hb0 ? wb0 : hb0), gh = (int)(wb0 < hb0 ? wb1 : hb1);
-    if (!per_pixel)
+    if (!g->per_pixel)
         OFPS_REQUIRE(ctx, gw >= 1 && gh >= 1 && (size_t)gw * gh <= 65536, "lk_decode: field %dx%d unsupported", gw, gh);
-    const size_t px = (size_t)W * H, cells = per_pixel ? 1 : (size_t)gw * gh;
+    g->gw = g->per_pixel ? W : gw; g->gh = g->per_pixel ? H : gh;
+    g->max_records = g->per_pixel ? (size_t)W * H : (size_t)gw * gh;
+    return OFPS_HIP_OK;
+}
+
+// records 0 .. *d_count - 1 (or n_max when d_count is null) to a device-addressable destination, the count to cnt_dst
+__global__ __launch_bounds__(256) void lk_copy_records_kernel(const float4* __restrict__ src, float4* __restrict__ dst,
+                                                              const uint32_t* __restrict__ d_count, size_t n_max, uint32_t* __restrict__ cnt_dst) {
+    size_t n = d_count ? (size_t)*d_count : n_max;
+    if (n > n_max) n = n_max;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+    if (cnt_dst && blockIdx.x == 0 && threadIdx.x == 0) *cnt_dst = (uint32_t)n;
+}
+
+// Enqueues everything of a process_frame that follows the uploads on ctx->stream: flow [-> contrast mask] -> output stage.
+// The record count lands at cnt_dst and the records at rec_dst -- device scratch, or the device address of a page-locked
+// block (the kernels store there directly: no read-back launch of their own).
+int lk_enqueue_frame(ofps_hip_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_cur, int W, int H, int levels, int radius, int iters,
+                     const LkGrid& g, float4* rec_dst, uint32_t* cnt_dst) {
+    const size_t px = (size_t)W * H, cells = g.per_pixel ? 1 : (size_t)g.gw * g.gh;
     auto* d_ent = static_cast<float4*>(ofps::scratch(ctx, ofps::S_ENTRIES, px * sizeof(float4)));
     auto* d_field = static_cast<float2*>(ofps::scratch(ctx, ofps::S_FIELD, cells * sizeof(float2)));
-    auto* d_out = static_cast<float4*>(ofps::scratch(ctx, ofps::S_BEST, cells * sizeof(float4)));
     auto* d_cnt = static_cast<uint32_t*>(ofps::scratch(ctx, ofps::S_RESULT, 16));
-    if (!d_ent || !d_field || !d_out || !d_cnt) return OFPS_HIP_ENOMEM;
-    const uint8_t* d_prev = d_frames + (size_t)slot_prev * px;
-    const uint8_t* d_cur = d_frames + (size_t)slot_cur * px;
+    if (!d_ent || !d_field || !d_cnt) return OFPS_HIP_ENOMEM;
     int rc = ofps_hip_lk_flow_dev(ctx, d_prev, d_cur, W, H, W, levels, radius, iters, nullptr, d_ent);
     if (rc != OFPS_HIP_OK) return rc;
     const uint8_t* d_mask = nullptr;
-    if (use_mask) {
+    if (g.use_mask) {
         auto* m = static_cast<uint8_t*>(ofps::scratch(ctx, ofps::S_MASK, px));
         if (!m) return OFPS_HIP_ENOMEM;
         rc = ofps::contrast_mask_device(ctx, d_cur, W, H, W, m);
         if (rc != OFPS_HIP_OK) return rc;
         d_mask = m;
     }
-    if (out_w) *out_w = per_pixel ? W : gw;
-    if (out_h) *out_h = per_pixel ? H : gh;
-    if (per_pixel) {
-        size_t n_rec = px;
+    if (g.per_pixel) {
         const float4* d_rec = d_ent;
-        if (use_mask) {                                  // the masked records themselves: order-preserving compaction
+        const uint32_t* d_n = nullptr;
+        if (g.use_mask) {                                  // the masked records themselves: order-preserving compaction
             auto* d_ent2 = static_cast<float4*>(ofps::scratch(ctx, ofps::S_ENTRIES2, px * sizeof(float4)));
             if (!d_ent2) return OFPS_HIP_ENOMEM;
             rc = ofps::compact_entries_device(ctx, d_ent, d_mask, px, d_ent2, d_cnt + 1);
             if (rc != OFPS_HIP_OK) return rc;
-            uint32_t kept = 0;
-            OFPS_HIP_TRY(ctx, hipMemcpyAsync(&kept, d_cnt + 1, sizeof(kept), hipMemcpyDeviceToHost, ctx->stream));
-            OFPS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-            n_rec = kept;
-            d_rec = d_ent2;
+            d_rec = d_ent2; d_n = d_cnt + 1;
         }
-        if (n_rec) OFPS_HIP_TRY(ctx, hipMemcpyAsync(out_entries, d_rec, n_rec * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
-        OFPS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        *n_out = n_rec;
+        hipLaunchKernelGGL(lk_copy_records_kernel, dim3(1024), dim3(256), 0, ctx->stream, d_rec, rec_dst, d_n, px, cnt_dst);
+        OFPS_HIP_TRY(ctx, hipGetLastError());
         return OFPS_HIP_OK;
     }
     // down-sampled output (cv-decoder/src/lib.rs:244-291): the records are this call's own per-pixel lattice, so the
     // densifier walks each cell's rectangle of pixels (masked ones skipped in place) instead of sorting 2 M records
-    rc = ofps::densify_raster_entries_device(ctx, d_ent, d_mask, W, H, gw, gh, d_field, d_out, d_cnt);
-    if (rc != OFPS_HIP_OK) return rc;
-    // the count and all candidate records come back in ONE transfer to page-locked memory and one wait (the count first and
-    // the records after it was known cost a second round trip); only the visited cells' records reach the caller's buffer
-    const size_t need = 16 + cells * sizeof(float4);
-    if (ctx->lk_pinned_cap < need) {
-        if (ctx->lk_pinned) { OFPS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); OFPS_HIP_TRY(ctx, hipHostFree(ctx->lk_pinned)); ctx->lk_pinned = nullptr; ctx->lk_pinned_cap = 0; }
-        OFPS_HIP_TRY(ctx, hipHostMalloc(&ctx->lk_pinned, need, hipHostMallocDefault));
-        ctx->lk_pinned_cap = need;
-    }
-    auto* pin = static_cast<char*>(ctx->lk_pinned);
-    OFPS_HIP_TRY(ctx, hipMemcpyAsync(pin, d_cnt, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-    OFPS_HIP_TRY(ctx, hipMemcpyAsync(pin + 16, d_out, cells * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
-    OFPS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    uint32_t cnt = 0;
-    memcpy(&cnt, pin, sizeof(cnt));
-    if (cnt > cells) cnt = (uint32_t)cells;
-    if (cnt) memcpy(out_entries, pin + 16, (size_t)cnt * sizeof(float4));
-    *n_out = cnt;
+    return ofps::densify_raster_entries_device(ctx, d_ent, d_mask, W, H, g.gw, g.gh, d_field, rec_dst, cnt_dst);
+}
+
+// a page-locked block [count, pad x 3][records]; grows, never shrinks
+int lk_pinned_block(ofps_hip_ctx* ctx, void** p, size_t* cap, size_t max_records) {
+    const size_t need = 16 + max_records * sizeof(float4);
+    if (*cap >= need) return OFPS_HIP_OK;
+    if (*p) { OFPS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); OFPS_HIP_TRY(ctx, hipHostFree(*p)); *p = nullptr; *cap = 0; }
+    OFPS_HIP_TRY(ctx, hipHostMalloc(p, need, hipHostMallocCoherent));      // fine-grained: kernels write it, the host reads it after an event
+    *cap = need;
     return OFPS_HIP_OK;
 }
+
+// count + records of a finished block -> the caller's buffer
+void lk_collect(const void* pinned, size_t max_records, float* out_entries, size_t* n_out) {
+    uint32_t cnt = 0;
+    memcpy(&cnt, pinned, sizeof(cnt));
+    if (cnt > max_records) cnt = (uint32_t)max_records;
+    if (cnt) memcpy(out_entries, static_cast<const char*>(pinned) + 16, (size_t)cnt * sizeof(float4));
+    *n_out = cnt;
+}
+
+int lk_stream_setup(ofps_hip_ctx* ctx) {
+    if (ctx->lk_copy_stream) return OFPS_HIP_OK;
+    OFPS_HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->lk_copy_stream, hipStreamNonBlocking));
+    for (auto& t : ctx->lk_ticket) {
+        OFPS_HIP_TRY(ctx, hipEventCreateWithFlags(&t.done, hipEventDisableTiming));
+        OFPS_HIP_TRY(ctx, hipEventCreateWithFlags(&t.uploaded, hipEventDisableTiming));
+    }
+    return OFPS_HIP_OK;
+}
+
+// waits for every ticket in flight and forgets the stream position (reset / geometry change / reallocation of the ring)
+int lk_stream_drain(ofps_hip_ctx* ctx) {
+    for (auto& t : ctx->lk_ticket) {
+        if (t.pending && t.done) OFPS_HIP_TRY(ctx, hipEventSynchronize(t.done));
+        t.pending = false;
+    }
+    if (ctx->lk_copy_stream) OFPS_HIP_TRY(ctx, hipStreamSynchronize(ctx->lk_copy_stream));
+    ctx->lk_frames = 0;
+    return OFPS_HIP_OK;
+}
+
+}  // namespace
+
+extern "C" {
 
 int ofps_hip_lk_decode(ofps_hip_ctx* ctx, const uint8_t* prev, const uint8_t* cur, int W, int H, int stride, int levels,
                        int radius, int iters, int max_w, int max_h, unsigned flags, float* out_entries, size_t* n_out,
@@ -1482,12 +1529,116 @@ int ofps_hip_lk_decode(ofps_hip_ctx* ctx, const uint8_t* prev, const uint8_t* cu
     OFPS_REQUIRE(ctx, W >= 1 && H >= 1 && stride >= W && max_w >= 1 && max_h >= 1, "lk_decode: bad geometry");
     OFPS_REQUIRE(ctx, (flags & ~(unsigned)(OFPS_HIP_LK_CONTRAST_MASK | OFPS_HIP_LK_PER_PIXEL)) == 0, "lk_decode: unknown flags 0x%x", flags);
     OFPS_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    LkGrid g;
+    int rc = lk_grid_of(ctx, W, H, max_w, max_h, flags, &g);
+    if (rc != OFPS_HIP_OK) return rc;
     const size_t px = (size_t)W * H;
     auto* d_frames = static_cast<uint8_t*>(ofps::scratch(ctx, ofps::S_FRAMES, 2 * px));
     if (!d_frames) return OFPS_HIP_ENOMEM;
     OFPS_HIP_TRY(ctx, ofps::upload_rows(d_frames, W, prev, stride, W, H, ctx->stream));
     OFPS_HIP_TRY(ctx, ofps::upload_rows(d_frames + px, W, cur, stride, W, H, ctx->stream));
-    return lk_decode_resident(ctx, d_frames, 0, 1, W, H, levels, radius, iters, max_w, max_h, flags, out_entries, n_out, out_w, out_h);
+    // the count and the records come back in ONE page-locked block and one wait; only the visited cells' records reach the
+    // caller's buffer
+    rc = lk_pinned_block(ctx, &ctx->lk_pinned, &ctx->lk_pinned_cap, g.max_records);
+    if (rc != OFPS_HIP_OK) return rc;
+    void* mapped = nullptr;
+    OFPS_REQUIRE(ctx, ofps::device_address_of(ctx->lk_pinned, &mapped), "lk_decode: page-locked block is not device-addressable");
+    rc = lk_enqueue_frame(ctx, d_frames, d_frames + px, W, H, levels, radius, iters, g, reinterpret_cast<float4*>(static_cast<char*>(mapped) + 16),
+                          static_cast<uint32_t*>(mapped));
+    if (rc != OFPS_HIP_OK) return rc;
+    OFPS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    lk_collect(ctx->lk_pinned, g.max_records, out_entries, n_out);
+    if (out_w) *out_w = g.gw;
+    if (out_h) *out_h = g.gh;
+    return OFPS_HIP_OK;
+}
+
+int ofps_hip_lk_push_frame_async(ofps_hip_ctx* ctx, const uint8_t* frame, int W, int H, int stride, int levels, int radius, int iters,
+                                 int max_w, int max_h, unsigned flags, int* ticket) {
+    if (!ctx) return OFPS_HIP_EINVAL;
+    OFPS_REQUIRE(ctx, frame && ticket, "lk_push_frame_async: null pointer");
+    OFPS_REQUIRE(ctx, W >= 1 && H >= 1 && stride >= W && max_w >= 1 && max_h >= 1, "lk_push_frame_async: bad geometry");
+    OFPS_REQUIRE(ctx, (flags & ~(unsigned)(OFPS_HIP_LK_CONTRAST_MASK | OFPS_HIP_LK_PER_PIXEL)) == 0, "lk_push_frame_async: unknown flags 0x%x", flags);
+    OFPS_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc = lk_stream_setup(ctx);
+    if (rc != OFPS_HIP_OK) return rc;
+    LkGrid g;
+    rc = lk_grid_of(ctx, W, H, max_w, max_h, flags, &g);
+    if (rc != OFPS_HIP_OK) return rc;
+    const long tno = ctx->lk_next_ticket;
+    auto& t = ctx->lk_ticket[tno % ofps_hip_ctx::kLkTickets];
+    OFPS_REQUIRE(ctx, !t.pending, "lk_push_frame_async: ticket %ld has not been collected (at most %d frames in flight)",
+                 tno - ofps_hip_ctx::kLkTickets, ofps_hip_ctx::kLkTickets);
+    if (ctx->lk_w != W || ctx->lk_h != H) {                         // a new geometry restarts the stream
+        rc = lk_stream_drain(ctx);
+        if (rc != OFPS_HIP_OK) return rc;
+        ctx->lk_w = W; ctx->lk_h = H;
+    }
+    const size_t px = (size_t)W * H;
+    // the stream's frames have slots of their own: no other entry point (lk_decode, lk_flow, sad_flow, contrast_mask stage
+    // their frames in S_FRAMES) can overwrite or reallocate a previous frame behind the stream's back.  Three slots: frame
+    // k + 1 is uploaded (copy stream) into the slot of frame k - 2, whose last reader -- ticket k - 1 -- has been collected
+    // by the time a third push is accepted.
+    if (ctx->scratch[ofps::S_LK_FRAMES].cap < ofps_hip_ctx::kLkSlots * px) {          // the ring is about to be (re)allocated: nothing may be in flight
+        rc = lk_stream_drain(ctx);
+        if (rc != OFPS_HIP_OK) return rc;
+    }
+    auto* d_frames = static_cast<uint8_t*>(ofps::scratch(ctx, ofps::S_LK_FRAMES, ofps_hip_ctx::kLkSlots * px));
+    if (!d_frames) return OFPS_HIP_ENOMEM;
+    if (ctx->lk_frames_gen != ctx->scratch[ofps::S_LK_FRAMES].gen) {         // (re)allocated: whatever was there is gone
+        ctx->lk_frames_gen = ctx->scratch[ofps::S_LK_FRAMES].gen;
+        ctx->lk_frames = 0;
+    }
+    hipStream_t s = ctx->stream;
+    // with another ticket in flight the upload goes to the copy stream and overlaps that ticket's flow; a lone frame is
+    // copied on the compute stream itself (no cross-stream event on the latency path of the synchronous call)
+    const bool overlap = ctx->lk_ticket[(tno + 1) % ofps_hip_ctx::kLkTickets].pending;
+    const int slot = (int)(ctx->lk_frames % ofps_hip_ctx::kLkSlots);
+    hipStream_t up = overlap ? ctx->lk_copy_stream : s;
+    OFPS_HIP_TRY(ctx, ofps::upload_rows(d_frames + (size_t)slot * px, W, frame, stride, W, H, up));
+    if (overlap) {
+        OFPS_HIP_TRY(ctx, hipEventRecord(t.uploaded, up));
+        OFPS_HIP_TRY(ctx, hipStreamWaitEvent(s, t.uploaded, 0));       // everything of this ticket on the compute stream comes after the upload
+    }
+    ctx->lk_frames += 1;
+    t.have_vectors = 0; t.gw = g.gw; t.gh = g.gh; t.max_records = g.max_records; t.fixed_count = -1;
+    if (ctx->lk_frames >= 2) {                                      // cv-decoder/src/lib.rs:156-158: flow needs two frames
+        rc = lk_pinned_block(ctx, &t.pinned, &t.pinned_cap, g.max_records);
+        if (rc != OFPS_HIP_OK) return rc;
+        void* mapped = nullptr;
+        OFPS_REQUIRE(ctx, ofps::device_address_of(t.pinned, &mapped), "lk_push_frame_async: page-locked block is not device-addressable");
+        const int prev_slot = (int)((ctx->lk_frames - 2) % ofps_hip_ctx::kLkSlots);
+        rc = lk_enqueue_frame(ctx, d_frames + (size_t)prev_slot * px, d_frames + (size_t)slot * px, W, H, levels, radius, iters, g,
+                              reinterpret_cast<float4*>(static_cast<char*>(mapped) + 16), static_cast<uint32_t*>(mapped));
+        if (rc != OFPS_HIP_OK) return rc;
+        t.have_vectors = 1;
+    }
+    OFPS_HIP_TRY(ctx, hipEventRecord(t.done, s));
+    t.pending = true;
+    *ticket = (int)(tno & 0x7FFFFFFF);
+    ctx->lk_next_ticket = tno + 1;
+    return OFPS_HIP_OK;
+}
+
+int ofps_hip_lk_frame_wait(ofps_hip_ctx* ctx, int ticket, float* out_entries, size_t* n_out, int* out_w, int* out_h, int* have_vectors) {
+    if (!ctx) return OFPS_HIP_EINVAL;
+    OFPS_REQUIRE(ctx, out_entries && n_out && have_vectors, "lk_frame_wait: null pointer");
+    OFPS_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const long newest = ctx->lk_next_ticket - 1;
+    long tno = -1;
+    for (long k = newest; k >= 0 && k > newest - ofps_hip_ctx::kLkTickets; --k)
+        if ((int)(k & 0x7FFFFFFF) == ticket) { tno = k; break; }
+    OFPS_REQUIRE(ctx, tno >= 0, "lk_frame_wait: ticket %d is not in flight", ticket);
+    auto& t = ctx->lk_ticket[tno % ofps_hip_ctx::kLkTickets];
+    OFPS_REQUIRE(ctx, t.pending, "lk_frame_wait: ticket %d has already been collected", ticket);
+    OFPS_HIP_TRY(ctx, hipEventSynchronize(t.done));
+    t.pending = false;
+    *n_out = 0;
+    *have_vectors = t.have_vectors;
+    if (out_w) *out_w = t.gw;
+    if (out_h) *out_h = t.gh;
+    if (t.have_vectors) lk_collect(t.pinned, t.max_records, out_entries, n_out);
+    return OFPS_HIP_OK;
 }
 
 int ofps_hip_lk_push_frame(ofps_hip_ctx* ctx, const uint8_t* frame, int W, int H, int stride, int levels, int radius, int iters,
@@ -1495,37 +1646,18 @@ int ofps_hip_lk_push_frame(ofps_hip_ctx* ctx, const uint8_t* frame, int W, int H
                            int* have_vectors) {
     if (!ctx) return OFPS_HIP_EINVAL;
     OFPS_REQUIRE(ctx, frame && out_entries && n_out && have_vectors, "lk_push_frame: null host pointer");
-    OFPS_REQUIRE(ctx, W >= 1 && H >= 1 && stride >= W && max_w >= 1 && max_h >= 1, "lk_push_frame: bad geometry");
-    OFPS_REQUIRE(ctx, (flags & ~(unsigned)(OFPS_HIP_LK_CONTRAST_MASK | OFPS_HIP_LK_PER_PIXEL)) == 0, "lk_push_frame: unknown flags 0x%x", flags);
-    OFPS_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    if (ctx->lk_w != W || ctx->lk_h != H) { ctx->lk_w = W; ctx->lk_h = H; ctx->lk_frames = 0; }    // a new geometry restarts the stream
-    const size_t px = (size_t)W * H;
-    // the stream's two frames have a slot of their own: no other entry point (lk_decode, lk_flow, sad_flow,
-    // contrast_mask stage their frames in S_FRAMES) can overwrite or reallocate the previous frame behind the stream's back
-    auto* d_frames = static_cast<uint8_t*>(ofps::scratch(ctx, ofps::S_LK_FRAMES, 2 * px));
-    if (!d_frames) return OFPS_HIP_ENOMEM;
-    if (ctx->lk_frames_gen != ctx->scratch[ofps::S_LK_FRAMES].gen) {         // (re)allocated: whatever was there is gone
-        ctx->lk_frames_gen = ctx->scratch[ofps::S_LK_FRAMES].gen;
-        ctx->lk_frames = 0;
-    }
-    const int slot = (int)(ctx->lk_frames & 1);
-    OFPS_HIP_TRY(ctx, ofps::upload_rows(d_frames + (size_t)slot * px, W, frame, stride, W, H, ctx->stream));
-    ctx->lk_frames += 1;
-    *n_out = 0;
-    if (ctx->lk_frames < 2) {                                       // cv-decoder/src/lib.rs:156-158: flow needs two frames
-        *have_vectors = 0;
-        OFPS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));       // the caller may reuse `frame` right away
-        return OFPS_HIP_OK;
-    }
-    *have_vectors = 1;
-    return lk_decode_resident(ctx, d_frames, slot ^ 1, slot, W, H, levels, radius, iters, max_w, max_h, flags, out_entries, n_out, out_w,
-                              out_h);
+    for (const auto& t : ctx->lk_ticket)
+        OFPS_REQUIRE(ctx, !t.pending, "lk_push_frame: a read-ahead ticket is in flight (collect it with ofps_hip_lk_frame_wait first)");
+    int ticket = 0;
+    const int rc = ofps_hip_lk_push_frame_async(ctx, frame, W, H, stride, levels, radius, iters, max_w, max_h, flags, &ticket);
+    if (rc != OFPS_HIP_OK) return rc;
+    return ofps_hip_lk_frame_wait(ctx, ticket, out_entries, n_out, out_w, out_h, have_vectors);     // the caller may reuse `frame` right away
 }
 
 int ofps_hip_lk_reset(ofps_hip_ctx* ctx) {
     if (!ctx) return OFPS_HIP_EINVAL;
-    ctx->lk_frames = 0;
-    return OFPS_HIP_OK;
+    OFPS_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return lk_stream_drain(ctx);
 }
 
 int ofps_hip_lk_flow(ofps_hip_ctx* ctx, const uint8_t* prev, const uint8_t* cur, int W, int H, int stride, int levels,

@@ -63,7 +63,10 @@ int pipe_setup(ofps_hip_ctx* ctx) {
     }
     for (auto& t : ctx->pipe_ticket) {
         OFPS_HIP_TRY(ctx, hipEventCreateWithFlags(&t.done, hipEventDisableTiming));
-        OFPS_HIP_TRY(ctx, hipHostMalloc(&t.pinned, sizeof(PipeOut), hipHostMallocDefault));
+        // kernels store the result record straight into this block and the host reads it after a hipEventDisableTiming event
+        // (no release-to-system fence of its own): the block must be FINE-GRAINED host memory whatever HIP_HOST_COHERENT or
+        // a future runtime default says -- asked for explicitly
+        OFPS_HIP_TRY(ctx, hipHostMalloc(&t.pinned, sizeof(PipeOut), hipHostMallocCoherent));
     }
     return OFPS_HIP_OK;
 }
@@ -109,6 +112,13 @@ int pipe_upload(ofps_hip_ctx* ctx, const uint8_t* luma, int W, int H, int stride
     return OFPS_HIP_OK;
 }
 }  // namespace
+
+namespace ofps {
+int read_back_device(ofps_hip_ctx* ctx, void* host_dst, const void* dev_src, size_t bytes, hipStream_t s) {
+    return pipe_read_back(ctx, host_dst, dev_src, bytes, s);
+}
+bool device_address_of(const void* host_ptr, void** dev_ptr) { return device_can_write(host_ptr, dev_ptr); }
+}  // namespace ofps
 
 extern "C" {
 
@@ -364,7 +374,7 @@ int ofps_hip_push_frames_async(ofps_hip_ctx* ctx, const uint8_t* frames, int n, 
     if (t.pinned_cap < (size_t)n * kOutBytes) {
         if (t.pinned) OFPS_HIP_TRY(ctx, hipHostFree(t.pinned));
         t.pinned = nullptr; t.pinned_cap = 0;
-        OFPS_HIP_TRY(ctx, hipHostMalloc(&t.pinned, (size_t)n * kOutBytes, hipHostMallocDefault));
+        OFPS_HIP_TRY(ctx, hipHostMalloc(&t.pinned, (size_t)n * kOutBytes, hipHostMallocCoherent));   // fine-grained: written by kernels, read after an event
         t.pinned_cap = (size_t)n * kOutBytes;
     }
     hipStream_t s = ctx->stream, up = ctx->pipe_copy_stream;

@@ -197,6 +197,33 @@ class HipContext:
             return None
         return out[:n.value].copy(), (gw.value, gh.value)
 
+    def lk_push_frame_async(self, frame: np.ndarray, levels=3, radius=4, iters=3, max_w=150, max_h=150, contrast_mask=False,
+                            per_pixel=False) -> int:
+        """Read-ahead form: returns a ticket once the upload, the flow and the output stage are enqueued.  `frame` must be
+        C-contiguous u8 and stay alive (ideally page-locked: pinned_frame) until lk_frame_wait(ticket)."""
+        assert frame.dtype == np.uint8 and frame.flags["C_CONTIGUOUS"] and frame.ndim == 2
+        H, W = frame.shape
+        flags = (self.LK_CONTRAST_MASK if contrast_mask else 0) | (self.LK_PER_PIXEL if per_pixel else 0)
+        t = C.c_int(0)
+        self._check(self._lib.ofps_hip_lk_push_frame_async(self._h, frame.ctypes.data_as(C.POINTER(C.c_uint8)), W, H, W, levels, radius,
+                                                           iters, max_w, max_h, flags, C.byref(t)))
+        self._lk_cap = getattr(self, "_lk_cap", {})
+        self._lk_cap[t.value] = W * H if per_pixel else min(max_w, W) * min(max_h, H)
+        return t.value
+
+    def lk_frame_wait(self, ticket: int, out: np.ndarray | None = None):
+        """-> None for the first frame of a stream, else (entries[n,4], (grid_w, grid_h)).  `out`: a caller buffer of the
+        capacity lk_decode documents (the result is then a view of it)."""
+        cap = getattr(self, "_lk_cap", {}).pop(ticket, 1)    # an unknown ticket: the library says so
+        if out is None:
+            out = np.zeros((cap, 4), np.float32)
+        assert out.dtype == np.float32 and out.size >= 4 * cap and out.flags["C_CONTIGUOUS"]
+        n = C.c_size_t(0); gw = C.c_int(0); gh = C.c_int(0); have = C.c_int(0)
+        self._check(self._lib.ofps_hip_lk_frame_wait(self._h, ticket, _fp(out), C.byref(n), C.byref(gw), C.byref(gh), C.byref(have)))
+        if not have.value:
+            return None
+        return out.reshape(-1, 4)[:n.value], (gw.value, gh.value)
+
     def lk_reset(self):
         self._check(self._lib.ofps_hip_lk_reset(self._h))
 

@@ -5,6 +5,8 @@ inputs.  Bit-exact for integer/index work; floats to the tolerance written next 
 import numpy as np
 import pytest
 
+from ofps_amd._lib import OfpsHipError
+
 import oracle
 from ofps_amd import synth
 
@@ -789,6 +791,68 @@ def test_lk_push_frame_stream_matches_pairwise_decode(ctx):
     assert ctx.lk_push_frame(fr[0][:90, :160].copy()) is None                # geometry change
     ctx.lk_reset()
     assert ctx.lk_push_frame(fr[2]) is None
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(contrast_mask=True), dict(per_pixel=True), dict(per_pixel=True, contrast_mask=True)])
+def test_lk_push_frame_async_equals_the_synchronous_decoder(ctx, kw):
+    """The ticketed read-ahead form (ofps_hip_lk_push_frame_async / _frame_wait, two tickets in flight: the upload of frame k+1
+    on the copy stream beside the flow of pair (k-1, k), the records written by the ticket's last kernel straight into its
+    page-locked block) returns, frame by frame, exactly what ofps_hip_lk_decode returns for the pair -- every output mode;
+    cv-decoder/src/lib.rs:82-158 is the loop it serves."""
+    W, H, F = 320, 180, 7
+    fr = synth.flatten_regions(synth.luma_sequence(F, W, H, max_step=3, seed=synth.SEED0 + 21), region=48, seed=3)
+    pins = [ctx.pinned_frame(H, W) for _ in range(3)]
+    ctx.lk_reset()
+    got, prev = [], None
+    for k in range(F):                                     # push k, then collect k - 1: two tickets in flight
+        np.copyto(pins[k % 3], fr[k])
+        t = ctx.lk_push_frame_async(pins[k % 3], max_w=60, max_h=60, **kw)
+        if prev is not None:
+            got.append(ctx.lk_frame_wait(prev))
+        prev = t
+    got.append(ctx.lk_frame_wait(prev))
+    assert got[0] is None                                  # the first frame of a stream yields no vectors
+    for k in range(1, F):
+        want, grid = ctx.lk_decode(fr[k - 1], fr[k], max_w=60, max_h=60, **kw)
+        assert got[k][1] == grid
+        np.testing.assert_array_equal(got[k][0].view(np.uint32), want.view(np.uint32))
+    # the synchronous form shares the stream: it continues it, and refuses to jump a ticket in flight
+    r = ctx.lk_push_frame(fr[0], max_w=60, max_h=60, **kw)
+    want, _ = ctx.lk_decode(fr[F - 1], fr[0], max_w=60, max_h=60, **kw)
+    np.testing.assert_array_equal(r[0].view(np.uint32), want.view(np.uint32))
+    t = ctx.lk_push_frame_async(pins[0], max_w=60, max_h=60, **kw)
+    with pytest.raises(OfpsHipError):
+        ctx.lk_push_frame(fr[1], max_w=60, max_h=60, **kw)
+    ctx.lk_frame_wait(t)
+    with pytest.raises(OfpsHipError):
+        ctx.lk_frame_wait(t)                                 # collected already
+    t0 = ctx.lk_push_frame_async(pins[1], max_w=60, max_h=60, **kw)
+    t1 = ctx.lk_push_frame_async(pins[2], max_w=60, max_h=60, **kw)
+    with pytest.raises(OfpsHipError):
+        ctx.lk_push_frame_async(pins[0], max_w=60, max_h=60, **kw)      # a third frame needs the first ticket collected
+    ctx.lk_frame_wait(t0); ctx.lk_frame_wait(t1)
+    ctx.lk_reset()
+    for p in pins:
+        ctx.free_pinned(p)
+
+
+def test_lk_push_frame_async_1080p_default_grid(ctx):
+    """cfg3's shape: 1080p frames, the default 150 x 150 cap (150 x 84 cells), pageable AND page-locked sources."""
+    W, H = 1920, 1080
+    fr = synth.luma_sequence(4, W, H, max_step=3, seed=synth.SEED0 + 22)
+    ctx.lk_reset()
+    prev, got = None, []
+    for k in range(4):
+        t = ctx.lk_push_frame_async(fr[k])                 # pageable source: the copy is synchronous, the results are the same
+        if prev is not None:
+            got.append(ctx.lk_frame_wait(prev))
+        prev = t
+    got.append(ctx.lk_frame_wait(prev))
+    for k in range(1, 4):
+        want, grid = ctx.lk_decode(fr[k - 1], fr[k])
+        assert grid == (150, 84) and got[k][1] == grid
+        np.testing.assert_array_equal(got[k][0].view(np.uint32), want.view(np.uint32))
+    ctx.lk_reset()
 
 
 def test_lk_push_frame_stream_survives_every_other_entry_point(ctx):

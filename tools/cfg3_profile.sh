@@ -10,6 +10,7 @@ mkdir -p $OUT
 CMD="python $GRAFT_REPO_ROOT/tools/prof_lk.py $N"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o k -- $CMD > $OUT/trace_run.txt 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS --output-format csv -d $OUT/pmc_sq -o k -- $CMD > $OUT/pmc_sq_run.txt 2>&1
+rocprofv3 --pmc SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sq2 -o k -- $CMD > $OUT/pmc_sq2_run.txt 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o k -- $CMD > $OUT/pmc_fetch_run.txt 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o k -- $CMD > $OUT/pmc_write_run.txt 2>&1
 python $GRAFT_REPO_ROOT/tools/cfg3_profile_summary.py $OUT $N > $OUT/summary.json

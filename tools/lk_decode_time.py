@@ -20,3 +20,19 @@ for mask in (False, True):
     t0 = time.perf_counter()
     for k in range(20): ctx.lk_push_frame(fr4[k % 4], contrast_mask=mask)
     print(f"lk_push_frame 1080p (stream form, one upload), contrast_mask={mask}: {(time.perf_counter() - t0) / 20 * 1e3:.3f} ms per frame")
+# read-ahead form: frames in page-locked memory, two tickets in flight (the upload of frame k+1 beside the flow of pair k-1, k)
+pins = [ctx.pinned_frame(1080, 1920) for _ in range(4)]
+for k in range(4): np.copyto(pins[k], fr4[k])
+out = [np.zeros((150 * 150, 4), np.float32) for _ in range(2)]     # capacity: min(max_w, W) * min(max_h, H) records
+for mask in (False, True):
+    ctx.lk_reset()
+    def run(n):
+        prev = None
+        for k in range(n):
+            t = ctx.lk_push_frame_async(pins[k % 4], contrast_mask=mask)
+            if prev is not None: ctx.lk_frame_wait(prev, out[k & 1])
+            prev = t
+        ctx.lk_frame_wait(prev, out[n & 1])
+    run(8)
+    t0 = time.perf_counter(); run(200)
+    print(f"lk_push_frame_async + lk_frame_wait 1080p (read-ahead, 2 tickets), contrast_mask={mask}: {(time.perf_counter() - t0) / 200 * 1e3:.3f} ms per frame")
