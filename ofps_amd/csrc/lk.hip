@@ -344,44 +344,6 @@ __device__ __forceinline__ lk_f4 lk_lds_read4(const float4* p) {
     return r;
 }
 
-// The step kernel's three window planes interleaved: one 16-byte LDS read per tap instead of three 4-byte ones
-// (ds_read_b128 moves 256 B per LDS clock, ds_read_b32 128).
-template <int RADIUS>
-__device__ __forceinline__ void lk_stage3(const float* __restrict__ p0, const float* __restrict__ p1, const float* __restrict__ p2,
-                                          float4 (*tile)[LkTile<RADIUS>::TW], int w, int h, int x0, int y0) {
-    using T = LkTile<RADIUS>;
-    // interior tiles of 16-byte aligned planes: 16-byte loads (a quarter of the memory requests -- the staging phases
-    // are queueing-latency bound: 8k + 5.7k of the 29k cycles a workgroup lives, OFPS_HIP_LK_PROF).  Uniform branch.
-    if constexpr (T::TW % 4 == 0 && T::R % 4 == 0) {
-        const bool vec = x0 - T::R >= 0 && x0 - T::R + T::TW <= w && (w & 3) == 0 &&
-                         ((reinterpret_cast<uintptr_t>(p0) | reinterpret_cast<uintptr_t>(p1) | reinterpret_cast<uintptr_t>(p2)) & 15) == 0;
-        if (vec) {
-            constexpr int Q = T::TW / 4;                              // float4 per window row
-            for (int t = threadIdx.x; t < Q * T::TH; t += 256) {
-                const int row = t / Q, c4 = t - row * Q;
-                const size_t g = (size_t)lk_clampi(y0 - T::R + row, 0, h - 1) * w + (x0 - T::R + 4 * c4);
-                const float4 a = *reinterpret_cast<const float4*>(p0 + g);
-                const float4 b = *reinterpret_cast<const float4*>(p1 + g);
-                const float4 c = *reinterpret_cast<const float4*>(p2 + g);
-                tile[row][4 * c4 + 0] = make_float4(a.x, b.x, c.x, 0.0f);
-                tile[row][4 * c4 + 1] = make_float4(a.y, b.y, c.y, 0.0f);
-                tile[row][4 * c4 + 2] = make_float4(a.z, b.z, c.z, 0.0f);
-                tile[row][4 * c4 + 3] = make_float4(a.w, b.w, c.w, 0.0f);
-            }
-            return;
-        }
-    }
-    constexpr int ROWS_PER_PASS = 256 / T::TW;
-    const int tx = threadIdx.x % T::TW, ty0 = threadIdx.x / T::TW;
-    if (ty0 >= ROWS_PER_PASS) return;
-    const int gx = lk_clampi(x0 - T::R + tx, 0, w - 1);
-#pragma unroll
-    for (int ty = ty0; ty < T::TH; ty += ROWS_PER_PASS) {
-        const size_t g = (size_t)lk_clampi(y0 - T::R + ty, 0, h - 1) * w + gx;
-        tile[ty][tx] = make_float4(p0[g], p1[g], p2[g], 0.0f);
-    }
-}
-
 // Level 0 straight from the u8 frames (round 3).  The previous frame's window records (I, gx, gy) are made from ONE u8
 // window with a 1-pixel rim -- 42 x 18 bytes instead of three f32 planes' 40 x 16 x 12 bytes -- in two phases through an
 // LDS scratch: (A) the window as f32 at clamped image coordinates, (B) per tile element its value and central differences
@@ -398,42 +360,49 @@ struct LkU8Window {                                   // the f32 copy of the u8 
 // in three parts, so that a caller can put work between the request and the use of the window's bytes: `issue` requests them
 // (registers), `spill` writes them to the scratch as f32 (a barrier must follow), `records` makes the tile records from the
 // scratch (a barrier must follow before the tile is read).
-template <int RADIUS>
+template <int RADIUS, typename TIn = uint8_t>
 struct LkU8Regs {
     using T = LkTile<RADIUS>;
     using U = LkU8Window<RADIUS>;
-    static constexpr int NQ = (U::WP / 4 * U::WH + 255) / 256;              // dwords per thread, aligned form
-    static constexpr int NB = ((T::TW + 2) * U::WH + 255) / 256;           // bytes per thread, element form
+    // aligned form: one request = 4 pixels (a dword of u8 / a float4); element form: one pixel
+    static constexpr int NQ = (U::WP / 4 * U::WH + 255) / 256;              // requests per thread, aligned form
+    static constexpr int NB = ((T::TW + 2) * U::WH + 255) / 256;           // pixels per thread, element form
+    using Quad = std::conditional_t<std::is_same_v<TIn, uint8_t>, uint32_t, float4>;
     bool vec;
     int ox;
-    uint32_t q[NQ];
-    uint8_t b[NB];
+    Quad q[NQ];
+    TIn b[NB];
 };
-template <int RADIUS>
-__device__ __forceinline__ void lk_stage3_u8_issue(const uint8_t* __restrict__ src, int stride, int w, int h, int x0, int y0, LkU8Regs<RADIUS>& g) {
+// The window's source is the u8 frame (level 0) or an f32 pyramid plane (levels >= 1, round 4: the f32 levels used to stage
+// three planes -- I and its two gradient planes, written by the pyramid / gradient launches -- and now make the gradients from
+// the I window like level 0 does: no gradient planes, no gradient launch, a third of the staging bytes).
+template <int RADIUS, typename TIn>
+__device__ __forceinline__ void lk_stage3_u8_issue(const TIn* __restrict__ src, int stride, int w, int h, int x0, int y0, LkU8Regs<RADIUS, TIn>& g) {
     using T = LkTile<RADIUS>;
     using U = LkU8Window<RADIUS>;
     constexpr int WW = T::TW + 2, WH = U::WH, WP = U::WP;
+    constexpr bool kU8 = std::is_same_v<TIn, uint8_t>;
     int ox = x0 - T::R - 1;                                           // image x of scratch column 0
     const int oy = y0 - T::R - 1;
-    // interior tiles of dword-aligned frames: the window starts at the dword boundary at or before its first pixel and is
-    // loaded four pixels per request (one request per thread for the whole window at radius 4); everything else byte by
-    // byte with the coordinates clamped per element.  Uniform branch.
-    g.vec = ox >= 0 && oy >= 0 && oy + WH <= h && (ox & ~3) + WP <= w && (stride & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 3) == 0;
+    // interior tiles of aligned sources: the window starts at the 4-pixel boundary at or before its first pixel and is
+    // loaded four pixels per request (one request per thread for the whole window at radius 4); everything else pixel by
+    // pixel with the coordinates clamped per element.  Uniform branch.
+    g.vec = ox >= 0 && oy >= 0 && oy + WH <= h && (ox & ~3) + WP <= w && (stride & 3) == 0 &&
+            (reinterpret_cast<uintptr_t>(src) & (kU8 ? 3 : 15)) == 0;
     if (g.vec) {
         ox &= ~3;
         constexpr int Q = WP / 4;
 #pragma unroll
-        for (int k = 0; k < LkU8Regs<RADIUS>::NQ; ++k) {
+        for (int k = 0; k < LkU8Regs<RADIUS, TIn>::NQ; ++k) {
             const int t = threadIdx.x + 256 * k;
             if (t < Q * WH) {
                 const int r = t / Q, c4 = t - r * Q;
-                g.q[k] = *reinterpret_cast<const uint32_t*>(src + (size_t)(oy + r) * stride + ox + 4 * c4);
+                g.q[k] = *reinterpret_cast<const typename LkU8Regs<RADIUS, TIn>::Quad*>(src + (size_t)(oy + r) * stride + ox + 4 * c4);
             }
         }
     } else {
 #pragma unroll
-        for (int k = 0; k < LkU8Regs<RADIUS>::NB; ++k) {
+        for (int k = 0; k < LkU8Regs<RADIUS, TIn>::NB; ++k) {
             const int t = threadIdx.x + 256 * k;
             if (t < WW * WH) {
                 const int r = t / WW, c = t - r * WW;
@@ -443,26 +412,30 @@ __device__ __forceinline__ void lk_stage3_u8_issue(const uint8_t* __restrict__ s
     }
     g.ox = ox;
 }
-template <int RADIUS>
-__device__ __forceinline__ void lk_stage3_u8_spill(float* scratch, const LkU8Regs<RADIUS>& g) {
+template <int RADIUS, typename TIn>
+__device__ __forceinline__ void lk_stage3_u8_spill(float* scratch, const LkU8Regs<RADIUS, TIn>& g) {
     using T = LkTile<RADIUS>;
     using U = LkU8Window<RADIUS>;
     constexpr int WW = T::TW + 2, WH = U::WH, WP = U::WP;
     if (g.vec) {
         constexpr int Q = WP / 4;
 #pragma unroll
-        for (int k = 0; k < LkU8Regs<RADIUS>::NQ; ++k) {
+        for (int k = 0; k < LkU8Regs<RADIUS, TIn>::NQ; ++k) {
             const int t = threadIdx.x + 256 * k;
             if (t < Q * WH) {
                 const int r = t / Q, c4 = t - r * Q;
-                const uint32_t q = g.q[k];
-                *reinterpret_cast<float4*>(scratch + r * WP + 4 * c4) =
-                    make_float4((float)(q & 0xFFu), (float)((q >> 8) & 0xFFu), (float)((q >> 16) & 0xFFu), (float)(q >> 24));
+                if constexpr (std::is_same_v<TIn, uint8_t>) {
+                    const uint32_t q = g.q[k];
+                    *reinterpret_cast<float4*>(scratch + r * WP + 4 * c4) =
+                        make_float4((float)(q & 0xFFu), (float)((q >> 8) & 0xFFu), (float)((q >> 16) & 0xFFu), (float)(q >> 24));
+                } else {
+                    *reinterpret_cast<float4*>(scratch + r * WP + 4 * c4) = g.q[k];
+                }
             }
         }
     } else {
 #pragma unroll
-        for (int k = 0; k < LkU8Regs<RADIUS>::NB; ++k) {
+        for (int k = 0; k < LkU8Regs<RADIUS, TIn>::NB; ++k) {
             const int t = threadIdx.x + 256 * k;
             if (t < WW * WH) { const int r = t / WW, c = t - r * WW; scratch[r * WP + c] = (float)g.b[k]; }
         }
@@ -509,17 +482,6 @@ __device__ __forceinline__ void lk_stage3_u8_records(const float* scratch, float
         tile[r][c] = make_float4(v, gxv, gyv, 0.0f);
     }
 }
-// the three parts back to back (callers with nothing to put in between: the hand-over kernel)
-template <int RADIUS>
-__device__ __forceinline__ void lk_stage3_u8(const uint8_t* __restrict__ src, int stride, float* scratch, float4 (*tile)[LkTile<RADIUS>::TW],
-                                             int w, int h, int x0, int y0) {
-    LkU8Regs<RADIUS> g;
-    lk_stage3_u8_issue<RADIUS>(src, stride, w, h, x0, y0, g);
-    lk_stage3_u8_spill<RADIUS>(scratch, g);
-    __syncthreads();
-    lk_stage3_u8_records<RADIUS>(scratch, tile, g.ox, g.vec, w, h, x0, y0);
-}
-
 // One window row of the level kernel at radius 4 (9 taps), spec revision 2, hand-scheduled.  hipcc's own code for this loop
 // copies the carried interpolation row (8 v_mov per row), re-reads every tile record into the same four registers with a
 // full wait in front of each use, and -- asked to unroll by two so that the carried row could change name instead of
@@ -700,9 +662,10 @@ struct LkStepShared {
     float4 tile[T::TH][T::TW];         // (I, gx, gy, -) of the previous frame's window
     int box[2][4][4];                  // [step parity][wave]: min x0, max x0+1, min y0, max y0+1 of the wave's sample origins
     int anchor[2][4][8];               // grouped tiles, [round parity][wave]: has a pending pixel, that pixel's box (x0, x0+1, y0, y0+1)
-    // level 0 (u8 source): the f32 copy of the u8 window the tile records are made from.  A buffer of its own (3.4 KB at
-    // radius 4; 6 workgroups per CU still fit): the records are made while the first rectangle's loads are in flight
-    alignas(16) float u8win[U8 ? LkU8Window<RADIUS>::FLOATS : 4];
+    // the f32 copy of the previous frame's window (u8 frame at level 0, f32 plane above) the tile records are made from.  A
+    // buffer of its own (3.4 KB at radius 4; 6 workgroups per CU still fit): the records are made while the first rectangle's
+    // loads are in flight
+    alignas(16) float u8win[LkU8Window<RADIUS>::FLOATS];
     // what the LDS footprint allows (160 KB per CU, 4 waves per workgroup): the register budget hipcc is held to
     // (radius 4 measured at 5 / 6 / 7 waves per SIMD: 0.396 / 0.380 / 0.411 ms -- 94 registers without spills, 80 with 3
     // spilled outside the row loop, 72 with 11)
@@ -776,8 +739,7 @@ __device__ __forceinline__ void lk_store(const float2 out, int x, int y, int w, 
 constexpr int kLkMaxRounds = 8;
 template <int RADIUS, bool U8>
 __global__ __launch_bounds__(256, LkStepShared<RADIUS>::WAVES_PER_SIMD) void lk_level_lds_kernel(const void* __restrict__ I_, const void* __restrict__ J_,
-                                                           const float* __restrict__ gx, const float* __restrict__ gy, int src_stride,
-                                                           int w, int h, int iters, const LkFlowIO io,
+                                                           int src_stride, int w, int h, int iters, const LkFlowIO io,
                                                            unsigned long long* __restrict__ prof, int force_fall_arg) {
     // force_fall (libofps_hip_testhooks.so only; compiled out of the product library): low 4 bits = a step at which every
     // other tile is treated as not fitting, so that the grouped path in the middle of a level is exercised on inputs that
@@ -801,18 +763,17 @@ __global__ __launch_bounds__(256, LkStepShared<RADIUS>::WAVES_PER_SIMD) void lk_
     constexpr int N = T::N;
     __shared__ S sh;
     const int x0 = tile_x * kTX, y0 = tile_y * kTY;
-    const float* I = static_cast<const float*>(I_);
+    using TIn = std::conditional_t<U8, uint8_t, float>;
     const float* J = static_cast<const float*>(J_);
     const uint8_t* J8 = static_cast<const uint8_t*>(J_);
     const int lx = threadIdx.x % kTX, ly = threadIdx.x / kTX, px = x0 + lx, py = y0 + ly;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const bool active = px < w && py < h;
     float2 f = active ? lk_flow_read(io, px, py) : make_float2(0.0f, 0.0f);      // requested first: in flight during the staging
-    // u8 source: the window's bytes are requested here and used after the first box exchange: their latency runs beside the
-    // flow read, the column origins and the exchange instead of in front of them
-    LkU8Regs<RADIUS> u8g;
-    if constexpr (U8) lk_stage3_u8_issue<RADIUS>(static_cast<const uint8_t*>(I_), src_stride, w, h, x0, y0, u8g);
-    else lk_stage3<RADIUS>(I, gx, gy, sh.tile, w, h, x0, y0);
+    // the previous frame's window is requested here and used after the first box exchange: its latency runs beside the flow
+    // read, the column origins and the exchange instead of in front of them
+    LkU8Regs<RADIUS, TIn> u8g;
+    lk_stage3_u8_issue<RADIUS, TIn>(static_cast<const TIn*>(I_), U8 ? src_stride : w, w, h, x0, y0, u8g);
     // The 2x2 structure tensor of the pixel's window does not depend on the flow: it is summed by the level's FIRST step, from
     // the very tile records that step reads for the residual (three fused multiply-adds per tap more, no LDS traffic of
     // its own), and stays in three registers for the later steps.
@@ -938,12 +899,12 @@ __global__ __launch_bounds__(256, LkStepShared<RADIUS>::WAVES_PER_SIMD) void lk_
     // lives therefore end before the loop
     if (iters > 0) {
         box_exchange(0);
-        if constexpr (U8) lk_stage3_u8_spill<RADIUS>(sh.u8win, u8g);     // the window's bytes, requested in the prologue; same barrier as the box
+        lk_stage3_u8_spill<RADIUS, TIn>(sh.u8win, u8g);                  // the window's pixels, requested in the prologue; same barrier as the box
         OFPS_LK_STAMP(1);
         __syncthreads();
         OFPS_LK_STAMP(2);
         // the tile records from the f32 copy of the u8 window: visible after the barrier that follows the first staging
-        if constexpr (U8) lk_stage3_u8_records<RADIUS>(sh.u8win, sh.tile, u8g.ox, u8g.vec, w, h, x0, y0);
+        lk_stage3_u8_records<RADIUS>(sh.u8win, sh.tile, u8g.ox, u8g.vec, w, h, x0, y0);
     }
 #pragma unroll 1
     for (int it = 0; it < iters; ++it) {
@@ -1284,7 +1245,7 @@ int lk_flow_device(ofps_hip_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_cu
         dim3 g2 = lk_grid_xcd(ws[l], hs[l], kP0X, kP0Y); g2.z = 2;
         hipLaunchKernelGGL(lk_pyr0_kernel<float>, g2, dim3(256), 0, s, (const float*)(Ip + off[l - 1]), (const float*)(Jp + off[l - 1]),
                            ws[l - 1], hs[l - 1], ws[l - 1], (float*)nullptr, (float*)nullptr, Ip + off[l], Jp + off[l], ws[l], hs[l],
-                           gxp + off[l - 1], gyp + off[l - 1]);
+                           tiled ? (float*)nullptr : gxp + off[l - 1], tiled ? (float*)nullptr : gyp + off[l - 1]);   // (the tiled level kernels make their gradients from the I window)
     }
     float2* cur_flow = fa;
     float2* other = fb;
@@ -1294,18 +1255,18 @@ int lk_flow_device(ofps_hip_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_cu
         if (!plain_flow) return OFPS_HIP_ENOMEM;
     }
     const int force_fall = ctx->opt.test_lk_fall;       // -1 in the product library (a test hook of libofps_hip_testhooks.so)
-    {   // gradients of every level: one launch (64 x 4 pixels per block, per-level block ranges padded to multiples of 8)
+    if (!tiled) {   // run-time-radius path: gradients of the coarsest level (the pyramid kernels wrote the finer ones), 64 x 4 pixels per block
         LkPyr P{};
         P.levels = levels;
         unsigned nb = 0;
         for (int l = 0; l < levels; ++l) {
             P.w[l] = ws[l]; P.h[l] = hs[l]; P.off[l] = (unsigned)off[l]; P.start[l] = nb;
-            if (l == levels - 1 && !(tiled && l == 0)) nb += lk_grid_xcd(ws[l], hs[l], 64, 4).x;   // the finer levels: the pyramid kernels wrote them (level 0 of the tiled path: made in the level kernel)
+            if (l == levels - 1) nb += lk_grid_xcd(ws[l], hs[l], 64, 4).x;
         }
         P.start[levels] = nb;
         if (nb) hipLaunchKernelGGL(lk_grad_all_kernel, dim3(nb), dim3(256), 0, s, Ip, P, gxp, gyp);
-        // (the structure tensors of the tiled path are summed inside the level kernels' first step; the run-time-radius path
-        // below keeps its tensor launch and plane)
+        // (the tiled path has neither gradient planes nor tensor planes: its level kernels make the gradients from the window
+        // they stage and sum the structure tensor inside the level's first step)
     }
     for (int l = levels - 1; l >= 0; --l) {
         const int w = ws[l], h = hs[l];
@@ -1324,11 +1285,10 @@ int lk_flow_device(ofps_hip_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_cu
 #define OFPS_LK_LEVEL(R)                                                                                                     \
     if (last) {            /* level 0: straight from the u8 frames */                                                       \
         hipLaunchKernelGGL((lk_level_lds_kernel<R, true>), lk_grid_xcd(w, h, kTX, kTY), dim3(256), 0, s, (const void*)d_prev, (const void*)d_cur,        \
-                           (const float*)nullptr, (const float*)nullptr, stride, w, h, iters, io, prof, force_fall);                                  \
+                           stride, w, h, iters, io, prof, force_fall);                                                                               \
     } else {                                                                                                                \
         hipLaunchKernelGGL((lk_level_lds_kernel<R, false>), lk_grid_xcd(w, h, kTX, kTY), dim3(256), 0, s, (const void*)(Ip + off[l]),                     \
-                           (const void*)(Jp + off[l]), (const float*)gx, (const float*)gy, w, w, h, iters, io, (unsigned long long*)nullptr,         \
-                           force_fall);                                                                                                               \
+                           (const void*)(Jp + off[l]), w, w, h, iters, io, (unsigned long long*)nullptr, force_fall);                                \
     }
             switch (radius) {
                 case 2: OFPS_LK_LEVEL(2); break;
