@@ -42,6 +42,8 @@ struct ofps_hip_ctx {
     int lk_w = 0, lk_h = 0;
     long lk_frames = 0;
     uint64_t lk_frames_gen = 0;          // generation of the S_LK_FRAMES allocation the count refers to
+    uint32_t lk_epoch = 0;               // lk_levels_kernel: tag of the last launch in the tile flags (S_WORK3)
+    uint64_t lk_flags_gen = 0;           // generation of the flag buffer the tags refer to
     void* lk_pinned = nullptr;           // page-locked staging for a frame's records + their count (one D2H, one wait)
     size_t lk_pinned_cap = 0;
     // read-ahead form (ofps_hip_lk_push_frame_async / ofps_hip_lk_frame_wait): a ring of three device frame slots, the new frame

@@ -647,7 +647,7 @@ __device__ __forceinline__ void lk_rows9_asm(const float (&a)[9], float fy, floa
 // they are NOT handled here: the main kernel (GENERAL = false, 57 VGPRs -> 6 waves per SIMD instead of 4) appends them
 // to a list and a small second launch (GENERAL = true) walks that list with the register-reuse global path.  Same
 // values, same operation order either way, hence the same bits.
-template <int RADIUS, bool U8 = false>
+template <int RADIUS>
 struct LkStepShared {
     using T = LkTile<RADIUS>;
     // capacity of the current-frame rectangle: flows inside a tile may differ by up to SPREAD_X / SPREAD_Y pixels; only the
@@ -695,11 +695,28 @@ struct LkFlowIO {
     float2* flow_out;           // or nullptr
     float4* out_entries;        // or nullptr
     float nx, ny;               // 1/W, 1/H for the records
+    // One launch runs the whole pyramid (lk_levels_kernel): a level's flow plane is written by workgroups of that launch and
+    // read by others, possibly on another XCD (own L2): such planes are written through (sc0 sc1 stores) and read past the
+    // caches (sc0 sc1 loads), the idiom of the cluster Almeida solver's granules (almeida.hip).
+    int coarse_shared;          // `coarse` was written by this launch
+    int out_shared;             // `flow_out` is read by this launch
 };
+
+typedef float lk_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float2 lk_load_shared(const float2* p) {
+    lk_f2 v;
+    asm volatile("global_load_dwordx2 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p) : "memory");
+    return make_float2(v.x, v.y);
+}
+__device__ __forceinline__ void lk_store_shared(float2* p, float2 v) {
+    const lk_f2 q = {v.x, v.y};
+    asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" :: "v"(p), "v"(q) : "memory");
+}
 
 __device__ __forceinline__ float2 lk_flow_read(const LkFlowIO& io, int x, int y) {
     if (io.coarse) {                                                   // uniform
-        const float2 c = io.coarse[(size_t)lk_clampi(y / 2, 0, io.h1 - 1) * io.w1 + lk_clampi(x / 2, 0, io.w1 - 1)];
+        const float2* p = io.coarse + (size_t)lk_clampi(y / 2, 0, io.h1 - 1) * io.w1 + lk_clampi(x / 2, 0, io.w1 - 1);
+        const float2 c = io.coarse_shared ? lk_load_shared(p) : *p;
         return make_float2(2.0f * c.x, 2.0f * c.y);
     }
     if (io.init) return io.init[(size_t)y * io.w1 + x];               // uniform
@@ -719,7 +736,7 @@ __device__ __forceinline__ float2 lk_solve(const float4 g, const float2 f, float
 
 __device__ __forceinline__ void lk_store(const float2 out, int x, int y, int w, const LkFlowIO& io) {
     const size_t idx = (size_t)y * w + x;
-    if (io.flow_out) io.flow_out[idx] = out;
+    if (io.flow_out) { if (io.out_shared) lk_store_shared(io.flow_out + idx, out); else io.flow_out[idx] = out; }
     if (io.out_entries) io.out_entries[idx] = make_float4(((float)x + 0.5f) * io.nx, ((float)y + 0.5f) * io.ny, out.x * io.nx, out.y * io.ny);
 }
 
@@ -738,9 +755,10 @@ __device__ __forceinline__ void lk_store(const float2 out, int x, int y, int w, 
 // level-0 gradient planes exist (lk_stage3_u8; the rectangle is converted while it is staged).
 constexpr int kLkMaxRounds = 8;
 template <int RADIUS, bool U8>
-__global__ __launch_bounds__(256, LkStepShared<RADIUS>::WAVES_PER_SIMD) void lk_level_lds_kernel(const void* __restrict__ I_, const void* __restrict__ J_,
-                                                           int src_stride, int w, int h, int iters, const LkFlowIO io,
-                                                           unsigned long long* __restrict__ prof, int force_fall_arg) {
+__device__ __forceinline__ void lk_level_body(LkStepShared<RADIUS>& sh, const void* __restrict__ I_, const void* __restrict__ J_, int src_stride,
+                                              int w, int h, int iters, const LkFlowIO io, unsigned long long* __restrict__ prof,
+                                              int force_fall_arg, int tile_x, int tile_y, const uint32_t* parent_flag, uint32_t* done_flag,
+                                              uint32_t epoch) {
     // force_fall (libofps_hip_testhooks.so only; compiled out of the product library): low 4 bits = a step at which every
     // other tile is treated as not fitting, so that the grouped path in the middle of a level is exercised on inputs that
     // would never trigger it; bits 4.. = how many grouping rounds those tiles get (0 = the default kLkMaxRounds; 1 + n = n
@@ -755,13 +773,10 @@ __global__ __launch_bounds__(256, LkStepShared<RADIUS>::WAVES_PER_SIMD) void lk_
     // prof (diagnostics, normally null): per-workgroup s_memtime stamps at the phase boundaries of the first step
 #define OFPS_LK_STAMP(slot) do { if (prof && threadIdx.x == 0) prof[((size_t)tile_y * tiles_x + tile_x) * 6 + (slot)] = __builtin_readcyclecounter(); } while (0)
     using T = LkTile<RADIUS>;
-    using S = LkStepShared<RADIUS, U8>;
+    using S = LkStepShared<RADIUS>;
     const int tiles_x = (w + kTX - 1) / kTX;
-    int tile_x, tile_y;
-    if (!lk_tile_of_block(tiles_x, tiles_x * ((h + kTY - 1) / kTY), tile_x, tile_y)) return;
     OFPS_LK_STAMP(0);
     constexpr int N = T::N;
-    __shared__ S sh;
     const int x0 = tile_x * kTX, y0 = tile_y * kTY;
     using TIn = std::conditional_t<U8, uint8_t, float>;
     const float* J = static_cast<const float*>(J_);
@@ -769,11 +784,28 @@ __global__ __launch_bounds__(256, LkStepShared<RADIUS>::WAVES_PER_SIMD) void lk_
     const int lx = threadIdx.x % kTX, ly = threadIdx.x / kTX, px = x0 + lx, py = y0 + ly;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const bool active = px < w && py < h;
-    float2 f = active ? lk_flow_read(io, px, py) : make_float2(0.0f, 0.0f);      // requested first: in flight during the staging
-    // the previous frame's window is requested here and used after the first box exchange: its latency runs beside the flow
-    // read, the column origins and the exchange instead of in front of them
+    // the previous frame's window is requested first (it depends on nothing) and used after the first box exchange: its
+    // latency runs beside the wait for the parent tile, the flow read, the column origins and the exchange
     LkU8Regs<RADIUS, TIn> u8g;
     lk_stage3_u8_issue<RADIUS, TIn>(static_cast<const TIn*>(I_), U8 ? src_stride : w, w, h, x0, y0, u8g);
+    // One launch runs the whole pyramid (lk_levels_kernel): this tile's starting flows are the results of ONE tile of the next
+    // coarser level (its parent), a workgroup of the same launch with a lower block index.  Thread 0 polls the parent's flag
+    // past the caches until it carries this launch's epoch.  The wait is bounded (~0.3 s): workgroups are dispatched in block
+    // order, so a parent is always resident or done before its children get a slot; should that ever not hold, the tile goes
+    // on with whatever the plane holds instead of hanging the device (a wrong answer a parity check sees, not a hang).
+    if (parent_flag) {                                                   // uniform
+        if (threadIdx.x == 0) {
+            uint32_t v;
+            int budget = 1 << 18;
+            do {
+                asm volatile("global_load_dword %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(parent_flag) : "memory");
+                if (v == epoch) break;
+                __builtin_amdgcn_s_sleep(16);
+            } while (--budget);
+        }
+        __syncthreads();
+    }
+    float2 f = active ? lk_flow_read(io, px, py) : make_float2(0.0f, 0.0f);
     // The 2x2 structure tensor of the pixel's window does not depend on the flow: it is summed by the level's FIRST step, from
     // the very tile records that step reads for the residual (three fused multiply-adds per tap more, no LDS traffic of
     // its own), and stays in three registers for the later steps.
@@ -912,13 +944,16 @@ __global__ __launch_bounds__(256, LkStepShared<RADIUS>::WAVES_PER_SIMD) void lk_
             box_exchange(it);
             __syncthreads();                                             // also: everybody is done reading jl[] of the previous step
         }
-        // (box[] holds the same numbers for every thread: read into SCALAR registers -- the rectangle's bounds live across
-        // the whole level, and as vector registers they were part of what got spilled around the row loop)
-        const int (*bq)[4] = sh.box[it & 1];
-        const int xmin = min(min(uni(bq[0][0]), uni(bq[1][0])), min(uni(bq[2][0]), uni(bq[3][0])));
-        const int xmax = max(max(uni(bq[0][1]), uni(bq[1][1])), max(uni(bq[2][1]), uni(bq[3][1])));
-        const int bymin = min(min(uni(bq[0][2]), uni(bq[1][2])), min(uni(bq[2][2]), uni(bq[3][2])));
-        const int ymax = max(max(uni(bq[0][3]), uni(bq[1][3])), max(uni(bq[2][3]), uni(bq[3][3])));
+        // (box[] holds the same numbers for every thread: they go to SCALAR registers -- the rectangle's bounds live across the
+        // whole level, and as vector registers they were part of what got spilled around the row loop.  One dword per lane
+        // and sixteen v_readlane: four 16-byte reads per lane took sixteen vector registers for a moment, and the allocator
+        // spilled three live values around them in every step)
+        const int bv = reinterpret_cast<const int*>(sh.box[it & 1])[lane & 15];
+        auto bl = [&](int k) { return __builtin_amdgcn_readlane(bv, k); };
+        const int xmin = min(min(bl(0), bl(4)), min(bl(8), bl(12)));
+        const int xmax = max(max(bl(1), bl(5)), max(bl(9), bl(13)));
+        const int bymin = min(min(bl(2), bl(6)), min(bl(10), bl(14)));
+        const int ymax = max(max(bl(3), bl(7)), max(bl(11), bl(15)));
         const bool fits = xmax >= xmin && xmax - xmin < S::LW && ymax - bymin < S::LH &&
                           !(it == force_fall && ((tile_x + tile_y) & 1));
         // The rows of one Gauss-Newton step for the lanes that call it (the members of the staged rectangle), ending with the flow
@@ -1092,7 +1127,8 @@ __global__ __launch_bounds__(256, LkStepShared<RADIUS>::WAVES_PER_SIMD) void lk_
             }
             f = lk_solve(make_float4(gxx, gxy, gyy, 0.0f), f, bx, by);
         };
-        if (fits) {                                                          // uniform: box[] is the same for every thread
+        if (__builtin_expect(fits, 1)) {                                     // uniform: box[] is the same for every thread.  (expect: the register
+            // allocator must keep the rare path's spills inside the rare path, not in front of the branch)
             // The rectangle is staged with a margin and KEPT: a later step whose box still lies inside it (flows move by a
             // fraction of a pixel per step once the coarser levels have done their work) reuses it -- no global loads, no
             // second barrier in that step.
@@ -1178,8 +1214,55 @@ __global__ __launch_bounds__(256, LkStepShared<RADIUS>::WAVES_PER_SIMD) void lk_
         asm volatile("" : "+v"(tidx));
         lk_store(f, x0 + tidx % kTX, y0 + tidx / kTX, w, io);
     }
+    if (done_flag) {                                                     // uniform: children of this tile are waiting for it
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // this thread's write-through flow stores have been acknowledged
+        __syncthreads();                                                 // ... everybody's
+        if (threadIdx.x == 0) asm volatile("global_store_dword %0, %1, off sc0 sc1" :: "v"(done_flag), "v"(epoch) : "memory");
+    }
     OFPS_LK_STAMP(5);
 #undef OFPS_LK_STAMP
+}
+
+// The whole pyramid in ONE launch.  Blocks are ordered coarsest level first (each level's range padded to a multiple of 8 so
+// that a block's XCD -- block % 8 -- is the same seen from the launch and from its level, and lk_tile_of_block's XCD-contiguous
+// raster runs apply inside the range); a tile starts once its parent tile has published its flows (lk_level_body).  Launched
+// level by level the coarse levels leave most of the chip idle -- 510 and 2,040 tiles of a 1080p pyramid on 1,536 workgroup
+// slots: 25 + 56 us for a quarter of level 0's work -- and each launch ends with a partly filled last round; in one launch
+// the levels' tiles share the slots.
+struct LkLevelArgs {
+    const void* I; const void* J;
+    int stride, w, h;
+    LkFlowIO io;
+    unsigned start, count;        // first block of the level, blocks of the level (a multiple of 8)
+    int tiles_x, ntiles;
+    unsigned flag_off;            // the level's tile flags inside LkLevelsArgs::flags (levels with children)
+};
+struct LkLevelsArgs {
+    int levels, iters, force_fall;
+    uint32_t epoch;
+    uint32_t* flags;
+    unsigned long long* prof;
+    LkLevelArgs lv[8];            // lv[0] = the coarsest level ... lv[levels - 1] = level 0
+};
+template <int RADIUS>
+__global__ __launch_bounds__(256, LkStepShared<RADIUS>::WAVES_PER_SIMD) void lk_levels_kernel(const LkLevelsArgs A) {
+    __shared__ LkStepShared<RADIUS> sh;
+    const unsigned b = blockIdx.x;
+    int k = 0;
+#pragma unroll
+    for (int i = 1; i < 8; ++i) k += (i < A.levels && b >= A.lv[i].start) ? 1 : 0;
+    const LkLevelArgs& L = A.lv[k];
+    const unsigned local = b - L.start;
+    const int t = (int)((local % 8u) * (L.count / 8u) + local / 8u);
+    if (t >= L.ntiles) return;
+    const int ty = t / L.tiles_x, tx = t - ty * L.tiles_x;
+    // the parent: the tile of the next coarser level (lv[k - 1]) that holds this tile's half-resolution pixels
+    const uint32_t* parent = k > 0 ? A.flags + A.lv[k - 1].flag_off + (size_t)(ty / 2) * A.lv[k - 1].tiles_x + tx / 2 : nullptr;
+    uint32_t* done = k < A.levels - 1 ? A.flags + L.flag_off + (size_t)ty * L.tiles_x + tx : nullptr;
+    if (k == A.levels - 1)
+        lk_level_body<RADIUS, true>(sh, L.I, L.J, L.stride, L.w, L.h, A.iters, L.io, A.prof, A.force_fall, tx, ty, parent, done, A.epoch);
+    else
+        lk_level_body<RADIUS, false>(sh, L.I, L.J, L.stride, L.w, L.h, A.iters, L.io, nullptr, A.force_fall, tx, ty, parent, done, A.epoch);
 }
 
 // cv-decoder/src/lib.rs:239-243,262-269: per-pixel records, raster order
@@ -1268,37 +1351,52 @@ int lk_flow_device(ofps_hip_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_cu
         // (the tiled path has neither gradient planes nor tensor planes: its level kernels make the gradients from the window
         // they stage and sum the structure tensor inside the level's first step)
     }
-    for (int l = levels - 1; l >= 0; --l) {
+    if (tiled) {
+        // ---- the whole pyramid in one launch (lk_levels_kernel).  Flow planes of the levels above 0: a packed pyramid inside `fa`
+        // (every level its own plane: all levels are in flight together)
+        LkLevelsArgs A{};
+        A.levels = levels; A.iters = iters; A.force_fall = force_fall; A.prof = prof;
+        unsigned nb = 0, nflags = 0;
+        for (int k = 0; k < levels; ++k) {                            // k = 0: the coarsest level
+            const int l = levels - 1 - k;
+            LkLevelArgs& L = A.lv[k];
+            const bool last = l == 0;
+            L.I = last ? (const void*)d_prev : (const void*)(Ip + off[l]);
+            L.J = last ? (const void*)d_cur : (const void*)(Jp + off[l]);
+            L.stride = last ? stride : ws[l]; L.w = ws[l]; L.h = hs[l];
+            L.tiles_x = (ws[l] + kTX - 1) / kTX; L.ntiles = L.tiles_x * ((hs[l] + kTY - 1) / kTY);
+            L.start = nb; L.count = ((unsigned)L.ntiles + 7u) / 8u * 8u; nb += L.count;
+            L.flag_off = nflags; if (!last) nflags += (unsigned)L.ntiles;
+            LkFlowIO& io = L.io;
+            io.coarse = l == levels - 1 ? nullptr : fa + (off[l + 1] - off[1]);
+            io.coarse_shared = 1;
+            io.init = l == levels - 1 ? d_init : nullptr;
+            io.w1 = l + 1 < levels ? ws[l + 1] : ws[l]; io.h1 = l + 1 < levels ? hs[l + 1] : hs[l];
+            io.flow_out = last ? d_flow : fa + (off[l] - off[1]);      // the last level skips the flow plane nobody asked for
+            io.out_shared = last ? 0 : 1;
+            io.out_entries = last ? d_entries : nullptr;
+            io.nx = 1.0f / (float)W; io.ny = 1.0f / (float)H;
+        }
+        // tile flags carry the launch's epoch: no clearing between calls (zeroed when (re)allocated or when the counter wraps)
+        auto* flags = static_cast<uint32_t*>(scratch(ctx, S_WORK3, (size_t)(nflags ? nflags : 1) * sizeof(uint32_t)));
+        if (!flags) return OFPS_HIP_ENOMEM;
+        if (ctx->lk_flags_gen != ctx->scratch[S_WORK3].gen || ctx->lk_epoch == 0xFFFFFFFFu) {
+            OFPS_HIP_TRY(ctx, hipMemsetAsync(flags, 0, ctx->scratch[S_WORK3].cap, s));
+            ctx->lk_flags_gen = ctx->scratch[S_WORK3].gen;
+            ctx->lk_epoch = 0;
+        }
+        A.epoch = ++ctx->lk_epoch;
+        A.flags = flags;
+        switch (radius) {
+            case 2: hipLaunchKernelGGL(lk_levels_kernel<2>, dim3(nb), dim3(256), 0, s, A); break;
+            case 4: hipLaunchKernelGGL(lk_levels_kernel<4>, dim3(nb), dim3(256), 0, s, A); break;
+            default: hipLaunchKernelGGL(lk_levels_kernel<6>, dim3(nb), dim3(256), 0, s, A); break;
+        }
+    }
+    for (int l = levels - 1; l >= 0 && !tiled; --l) {
         const int w = ws[l], h = hs[l];
         float* gx = gxp + off[l]; float* gy = gyp + off[l];
         float4* G = Gp + off[l];
-        if (tiled) {
-            // one launch runs all `iters` steps of the level: in = the coarser level's flow (cur_flow), out = `other`
-            const bool last = l == 0;
-            LkFlowIO io{};
-            io.coarse = l == levels - 1 ? nullptr : cur_flow;
-            io.init = l == levels - 1 ? d_init : nullptr;
-            io.w1 = l + 1 < levels ? ws[l + 1] : w; io.h1 = l + 1 < levels ? hs[l + 1] : h;
-            io.flow_out = last ? d_flow : other;                       // the last level skips the flow plane nobody asked for
-            io.out_entries = last ? d_entries : nullptr;
-            io.nx = 1.0f / (float)W; io.ny = 1.0f / (float)H;
-#define OFPS_LK_LEVEL(R)                                                                                                     \
-    if (last) {            /* level 0: straight from the u8 frames */                                                       \
-        hipLaunchKernelGGL((lk_level_lds_kernel<R, true>), lk_grid_xcd(w, h, kTX, kTY), dim3(256), 0, s, (const void*)d_prev, (const void*)d_cur,        \
-                           stride, w, h, iters, io, prof, force_fall);                                                                               \
-    } else {                                                                                                                \
-        hipLaunchKernelGGL((lk_level_lds_kernel<R, false>), lk_grid_xcd(w, h, kTX, kTY), dim3(256), 0, s, (const void*)(Ip + off[l]),                     \
-                           (const void*)(Jp + off[l]), w, w, h, iters, io, (unsigned long long*)nullptr, force_fall);                                \
-    }
-            switch (radius) {
-                case 2: OFPS_LK_LEVEL(2); break;
-                case 4: OFPS_LK_LEVEL(4); break;
-                default: OFPS_LK_LEVEL(6); break;
-            }
-#undef OFPS_LK_LEVEL
-            if (!last) { float2* t = cur_flow; cur_flow = other; other = t; }
-            continue;
-        }
         hipLaunchKernelGGL(lk_tensor_kernel, lk_grid(w, h), dim3(256), 0, s, gx, gy, w, h, radius, G);
         if (l == levels - 1) {
             if (d_init) OFPS_HIP_TRY(ctx, hipMemcpyAsync(cur_flow, d_init, (size_t)w * h * sizeof(float2), hipMemcpyDeviceToDevice, s));
