@@ -789,6 +789,21 @@ def run_threads(args) -> int:
     out["launcher"] = "threads (one process, ofps_hip_multi_*: one worker thread + context per GPU, no collective)"
     out["per_rank_ms_per_step"] = {"min": round(float(ms[ms > 0].min()) / args.steps, 4) if (ms > 0).any() else 0.0,
                                    "max": round(float(ms.max()) / args.steps, 4), "what": "HIP events per worker"}
+    # ---- PCIe-inclusive stream form through the same dispatcher (ofps_hip_multi_push_frames_async: batches of 16 frames dealt to
+    # the workers, vectors + island + quaternion per frame back in frame order), C++ host, frames in page-locked memory
+    if not args.no_end_to_end and (W, H, B, R) == (1920, 1080, 16, 16):
+        try:
+            import subprocess
+            from ofps_amd.build import TOOL
+            r = json.loads(subprocess.run([TOOL, "stream-bench", str(W), str(H), str(1024 * N), "multi", "16"] + [str(d) for d in range(N)],
+                                          capture_output=True, text=True, timeout=300, check=True).stdout.strip().splitlines()[-1])
+            out["end_to_end"] = {"what": "one stream of 1080p frames over the workers: every frame crosses PCIe once, 16 frames per batch, 2 batches in "
+                                         "flight per worker; per frame the vectors (16 B each), the block-motion island and the Almeida quaternion come back",
+                                 "entry_points": "ofps_hip_multi_push_frames_async + ofps_hip_multi_frames_wait (C++ host layer)",
+                                 "workers": r["workers"], "batch": r["batch"], "frames": r["frames"], "ms_per_frame": r["ms_per_frame"],
+                                 "Mvectors_per_s": r["Mvectors_per_s"]}
+        except Exception as e:
+            out["end_to_end"] = {"error": repr(e)[:300]}
     mismatch = False
     try:
         import oracle

@@ -315,7 +315,26 @@ int ofps_hip_multi_stage_frames(ofps_hip_multi* m, const uint8_t* frames, int n_
                                 size_t frame_pitch, int ref_mode);
 int ofps_hip_multi_run_resident(ofps_hip_multi* m, int block, int range, int steps,
                                 float* worker_ms /* NULL, or one entry per worker: HIP-event time of its `steps` launches */);
-int ofps_hip_multi_fetch(ofps_hip_multi* m, int block, float* out_entries);
+int ofps_hip_multi_fetch(ofps_hip_multi* m, int block, float* out_entries);     /* results of the LAST run of the staged batch, same block size */
+/* The dispatcher's entry points are serialised among themselves (one lock per handle): several host threads may share a handle,
+ * they just do not overlap inside it (ofps_hip_multi_frames_wait blocks outside the lock). */
+
+/* A STREAM of frames over several devices: the multi-device form of ofps_hip_push_frames_async / ofps_hip_frames_wait (same
+ * parameters, same results per frame).  Batch g of n consecutive frames goes to worker g % n_workers together with the one frame
+ * in front of it (kept by the dispatcher in page-locked memory), through that worker's two-ticket batched read-ahead: upload on
+ * a copy stream, one search launch, detector and estimator over the batch, results read back by kernel.  Up to 2 * n_workers
+ * batches in flight; ofps_hip_multi_frames_wait(ticket) fills out[0..n-1] -- frame order is batch order.  `frames` and
+ * `out_entries` must stay valid until the wait returns; batches in pageable memory are copied into a worker's page-locked
+ * staging on that worker's thread.  Vectors and detector results equal the single-context stream's bit for bit, quaternions
+ * too for equal batch sizes (one launch per batch either way).  The reference's counterpart: the decoder thread + double
+ * buffer and the estimator fan-out of ofps-suite/src/app/tracking/worker.rs:165-226,347-361. */
+int ofps_hip_multi_push_frames_async(ofps_hip_multi* m, const uint8_t* frames, int n, int W, int H, int stride, size_t frame_pitch,
+                                     const ofps_hip_frame_params* params, float* out_entries /* n*4*nblk or NULL */, int* ticket);
+int ofps_hip_multi_frames_wait(ofps_hip_multi* m, int ticket, ofps_hip_frame_result* out /* n entries */);
+int ofps_hip_multi_reset_frames(ofps_hip_multi* m);
+/* The dealing, as a pure function (no device needed): batch g of a stream -> the worker that takes it, the halo buffer that
+ * holds the frame in front of it, and the ticket slot it occupies (at most two batches in flight per worker). */
+void ofps_hip_multi_stream_plan(long batch, int n_workers, int* worker, int* halo_slot, int* ticket_slot);
 
 #ifdef __cplusplus
 }

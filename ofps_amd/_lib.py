@@ -113,6 +113,11 @@ PROTOTYPES["ofps_hip_multi_sad_flow"] = (C.c_int, [_multi, _u8p, C.c_int, C.c_in
 PROTOTYPES["ofps_hip_multi_stage_frames"] = (C.c_int, [_multi, _u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_int])
 PROTOTYPES["ofps_hip_multi_run_resident"] = (C.c_int, [_multi, C.c_int, C.c_int, C.c_int, _f32p])
 PROTOTYPES["ofps_hip_multi_fetch"] = (C.c_int, [_multi, C.c_int, _f32p])
+PROTOTYPES["ofps_hip_multi_push_frames_async"] = (C.c_int, [_multi, _u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t, C.POINTER(FrameParams), _f32p,
+                                                            C.POINTER(C.c_int)])
+PROTOTYPES["ofps_hip_multi_frames_wait"] = (C.c_int, [_multi, C.c_int, C.POINTER(FrameResult)])
+PROTOTYPES["ofps_hip_multi_reset_frames"] = (C.c_int, [_multi])
+PROTOTYPES["ofps_hip_multi_stream_plan"] = (None, [C.c_long, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)])
 
 _lib = None
 _lib_hooks = None

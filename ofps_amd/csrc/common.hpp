@@ -156,6 +156,10 @@ int read_back_device(ofps_hip_ctx* ctx, void* host_dst, const void* dev_src, siz
 // the device address of page-locked host memory, or false for pageable memory
 bool device_address_of(const void* host_ptr, void** dev_ptr);
 
+// the batched read-ahead push with the previous frame supplied by the caller (pipeline.hip; multi.hip deals batches to workers)
+int push_frames_impl(ofps_hip_ctx* ctx, const uint8_t* frames, int n, int W, int H, int stride, size_t frame_pitch,
+                     const ofps_hip_frame_params* prm, float* out_entries, int* ticket, int halo_mode, const uint8_t* halo);
+
 // rows of `width` bytes, host -> device; one linear copy when both sides are dense (the 2-D path is slower)
 inline hipError_t upload_rows(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t height,
                               hipStream_t stream) {

@@ -325,7 +325,7 @@ __global__ __launch_bounds__(256) void lk_step_kernel(const float* __restrict__ 
 // tile stages fewer window elements per pixel (2.5 vs 3.4) and its rectangle tolerates wilder flows; 16 lanes per row
 // lose on the 16-byte staging rows.
 constexpr int kTX = 32, kTY = 8;
-constexpr int kJMargin = 2;          // pixels of slack staged around the current frame's rectangle (lk_level_lds_kernel)
+constexpr int kJMargin = 2;          // pixels of slack staged around the current frame's rectangle (lk_level_body)
 
 template <int RADIUS>
 struct LkTile {
@@ -1134,7 +1134,8 @@ __device__ __forceinline__ void lk_level_body(LkStepShared<RADIUS>& sh, const vo
             // second barrier in that step.
             const bool inside = st_valid && xmin >= st_x0 && xmax <= st_x1 && bymin >= st_y0 && ymax <= st_y1;
             if (!inside) {
-                // margins: up to kJMargin pixels on every side, as far as the capacity allows
+                // margins: up to kJMargin pixels on every side, as far as the capacity allows (measured in round 4: a wider margin
+                // for tiles that have to stage again at a later step -- 4, 6, 10 pixels -- changes nothing on either content)
                 const int mx = min(kJMargin, (S::LW - (xmax - xmin + 1)) / 2), my = min(kJMargin, (S::LH - (ymax - bymin + 1)) / 2);
                 stage_rect(xmin - mx, xmax + mx, bymin - my, ymax + my);
                 st_valid = true;

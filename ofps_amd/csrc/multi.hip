@@ -15,7 +15,9 @@
 #include "common.hpp"
 
 #include <condition_variable>
+#include <deque>
 #include <functional>
+#include <memory>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -27,21 +29,39 @@ struct ofps_hip_multi {
         std::thread th;
         std::mutex m;
         std::condition_variable cv;
-        std::function<int(Worker&)> job;      // set by the dispatcher, cleared by the worker
-        bool has_job = false, done = true, quit = false;
-        int rc = OFPS_HIP_OK;
+        std::deque<std::function<void(Worker&)>> jobs;   // FIFO: a worker's context is only ever touched by its own thread
+        bool quit = false;
         // resident batch (ofps_hip_multi_stage_frames)
         uint8_t* d_frames = nullptr; size_t frames_cap = 0;
         float* d_out = nullptr; size_t out_cap = 0;
         size_t first_pair = 0, n_pairs = 0, n_res_frames = 0;
         hipEvent_t key_ready = nullptr;        // worker 0: the key frame is on its device
+        uint64_t run_gen = 0; int run_block = 0, run_range = 0; size_t run_pairs = 0;   // what d_out holds (ofps_hip_multi_fetch checks it)
+        // stream pipeline (ofps_hip_multi_push_frames_async): page-locked staging for batches that arrive in pageable memory
+        uint8_t* stage[2] = {nullptr, nullptr}; size_t stage_cap[2] = {0, 0};
+        long stream_batches = 0;               // batches this worker has taken
     };
     std::vector<Worker*> w;
+    std::recursive_mutex api;                  // the dispatcher's entry points are serialised (they were not re-entrant)
     char err[512] = {0};
     // geometry of the resident batch
     int W = 0, H = 0, dstride = 0, ref_mode = 0;
     size_t pitch = 0, total_pairs = 0;
     bool staged = false;
+    uint64_t stage_gen = 0;                    // bumped by every ofps_hip_multi_stage_frames
+    // ---- stream pipeline: batches of consecutive frames dealt to the workers round-robin, results back in frame order
+    struct StreamTicket {
+        bool pending = false;
+        int worker = 0, worker_ticket = 0, n = 0, rc = OFPS_HIP_OK;
+        bool enqueued = false;                 // the worker has run the push job (rc is valid)
+        std::mutex m; std::condition_variable cv;
+    };
+    std::vector<std::unique_ptr<StreamTicket>> tickets;     // ring of 2 * n_workers
+    long next_ticket = 0;
+    std::vector<uint8_t*> halo;                // page-locked copies of every batch's last frame (ring of 2 * n_workers + 1)
+    size_t halo_bytes = 0;
+    int sW = 0, sH = 0;
+    long stream_frames = 0;
 };
 
 static thread_local char g_multi_init_err[512] = {0};
@@ -79,39 +99,42 @@ int multi_error(ofps_hip_multi* m, int code, const char* fmt, ...) {
 void worker_main(Worker* w) {
     for (;;) {
         std::unique_lock<std::mutex> lk(w->m);
-        w->cv.wait(lk, [&] { return w->has_job || w->quit; });
-        if (w->quit) return;
-        auto job = std::move(w->job);
-        w->has_job = false;
+        w->cv.wait(lk, [&] { return !w->jobs.empty() || w->quit; });
+        if (w->jobs.empty()) return;             // quit, and nothing left to do
+        auto job = std::move(w->jobs.front());
+        w->jobs.pop_front();
         lk.unlock();
-        const int rc = job(*w);
-        lk.lock();
-        w->rc = rc; w->done = true;
-        w->cv.notify_all();
+        job(*w);
     }
 }
 
-// runs job on every worker concurrently, joins, returns the first failure (message copied from that worker's context)
+void enqueue(Worker* w, std::function<void(Worker&)> job) {
+    std::lock_guard<std::mutex> lk(w->m);
+    w->jobs.push_back(std::move(job));
+    w->cv.notify_all();
+}
+
+// runs job on every worker concurrently (behind whatever each has queued), joins, returns the first failure (message copied
+// from that worker's context)
 int run_all(ofps_hip_multi* m, const std::function<int(Worker&, int)>& job) {
+    struct Join { std::mutex m; std::condition_variable cv; size_t left; std::vector<int> rc; } j;
+    j.left = m->w.size(); j.rc.assign(m->w.size(), OFPS_HIP_OK);
     for (size_t k = 0; k < m->w.size(); ++k) {
-        Worker* w = m->w[k];
-        std::lock_guard<std::mutex> lk(w->m);
         const int idx = (int)k;
-        w->job = [job, idx](Worker& ww) { return job(ww, idx); };
-        w->has_job = true; w->done = false;
-        w->cv.notify_all();
+        enqueue(m->w[k], [&j, &job, idx](Worker& ww) {
+            const int rc = job(ww, idx);
+            std::lock_guard<std::mutex> lk(j.m);
+            j.rc[idx] = rc;
+            if (--j.left == 0) j.cv.notify_all();
+        });
     }
-    int rc = OFPS_HIP_OK;
-    for (size_t k = 0; k < m->w.size(); ++k) {
-        Worker* w = m->w[k];
-        std::unique_lock<std::mutex> lk(w->m);
-        w->cv.wait(lk, [&] { return w->done; });
-        if (w->rc != OFPS_HIP_OK && rc == OFPS_HIP_OK) {
-            rc = w->rc;
-            snprintf(m->err, sizeof(m->err), "worker %zu (device %d): %s", k, w->device, ofps_hip_last_error(w->ctx));
+    { std::unique_lock<std::mutex> lk(j.m); j.cv.wait(lk, [&] { return j.left == 0; }); }
+    for (size_t k = 0; k < m->w.size(); ++k)
+        if (j.rc[k] != OFPS_HIP_OK) {
+            snprintf(m->err, sizeof(m->err), "worker %zu (device %d): %s", k, m->w[k]->device, ofps_hip_last_error(m->w[k]->ctx));
+            return j.rc[k];
         }
-    }
-    return rc;
+    return OFPS_HIP_OK;
 }
 
 int grow(Worker& w, uint8_t** p, size_t* cap, size_t bytes) {
@@ -215,11 +238,13 @@ void ofps_hip_multi_destroy(ofps_hip_multi* m) {
             (void)hipDeviceSynchronize();
             if (w->d_frames) (void)hipFree(w->d_frames);
             if (w->d_out) (void)hipFree(w->d_out);
+            for (auto* st : w->stage) if (st) (void)hipHostFree(st);
             if (w->key_ready) (void)hipEventDestroy(w->key_ready);
             ofps_hip_destroy(w->ctx);
         }
         delete w;
     }
+    for (auto* h : m->halo) if (h) (void)hipHostFree(h);
     delete m;
 }
 
@@ -230,6 +255,7 @@ int ofps_hip_multi_worker_count(const ofps_hip_multi* m) { return m ? (int)m->w.
 int ofps_hip_multi_stage_frames(ofps_hip_multi* m, const uint8_t* frames, int n_frames, int W, int H, int stride, size_t frame_pitch,
                                 int ref_mode) {
     if (!m) return OFPS_HIP_EINVAL;
+    std::lock_guard<std::recursive_mutex> api(m->api);
     if (!frames || n_frames < 1 || W < 1 || H < 1 || stride < W || frame_pitch < (size_t)stride * H || (ref_mode != 0 && ref_mode != 1))
         return multi_error(m, OFPS_HIP_EINVAL, "multi_stage_frames: bad arguments (n_frames=%d W=%d H=%d stride=%d ref_mode=%d)", n_frames, W, H,
                            stride, ref_mode);
@@ -237,6 +263,7 @@ int ofps_hip_multi_stage_frames(ofps_hip_multi* m, const uint8_t* frames, int n_
     m->W = W; m->H = H; m->dstride = (W + 63) & ~63; m->pitch = (size_t)m->dstride * H; m->ref_mode = ref_mode;
     m->total_pairs = (size_t)n_frames - 1;
     m->staged = false;
+    m->stage_gen += 1;                         // whatever the workers' result buffers hold belongs to an older batch now
     // phase 1: every worker uploads its own frames; worker 0 also the key frame (slot 0 of its buffer) in key mode
     int rc = run_all(m, [&](Worker& w, int k) -> int {
         OFPS_HIP_TRY(w.ctx, hipSetDevice(w.device));
@@ -286,6 +313,7 @@ int ofps_hip_multi_stage_frames(ofps_hip_multi* m, const uint8_t* frames, int n_
 // `steps` searches of every worker's resident pairs, back to back on its stream; returns when all workers are through.
 int ofps_hip_multi_run_resident(ofps_hip_multi* m, int block, int range, int steps, float* worker_ms) {
     if (!m) return OFPS_HIP_EINVAL;
+    std::lock_guard<std::recursive_mutex> api(m->api);
     if (!m->staged) return multi_error(m, OFPS_HIP_EINVAL, "multi_run_resident: no staged batch");
     if (steps < 1) return multi_error(m, OFPS_HIP_EINVAL, "multi_run_resident: steps must be >= 1");
     const size_t nblk = ofps_hip_sad_block_count(m->W, m->H, block);
@@ -298,6 +326,7 @@ int ofps_hip_multi_run_resident(ofps_hip_multi* m, int block, int range, int ste
         int r = grow(w, &out8, &cap, w.n_pairs * nblk * 4 * sizeof(float));
         w.d_out = reinterpret_cast<float*>(out8); w.out_cap = cap;
         if (r != OFPS_HIP_OK) return r;
+        w.run_gen = m->stage_gen; w.run_block = block; w.run_range = range; w.run_pairs = w.n_pairs;       // what d_out is about to hold
         if (worker_ms) { r = ofps_hip_timer_start(w.ctx); if (r != OFPS_HIP_OK) return r; }
         for (int sidx = 0; sidx < steps; ++sidx) {
             r = ofps_hip_sad_flow_dev(w.ctx, w.d_frames, (int)w.n_res_frames, m->W, m->H, m->dstride, m->pitch, m->ref_mode, block, range,
@@ -313,12 +342,15 @@ int ofps_hip_multi_run_resident(ofps_hip_multi* m, int block, int range, int ste
 // results of the last run, in pair order: out_entries [(n_frames - 1) * nblk * 4] floats
 int ofps_hip_multi_fetch(ofps_hip_multi* m, int block, float* out_entries) {
     if (!m || !out_entries) return OFPS_HIP_EINVAL;
+    std::lock_guard<std::recursive_mutex> api(m->api);
     if (!m->staged) return multi_error(m, OFPS_HIP_EINVAL, "multi_fetch: no staged batch");
     const size_t nblk = ofps_hip_sad_block_count(m->W, m->H, block);
     return run_all(m, [&](Worker& w, int) -> int {
         if (!w.n_pairs) return OFPS_HIP_OK;
-        if (!w.d_out || w.out_cap < w.n_pairs * nblk * 4 * sizeof(float))
-            return ofps::set_error(w.ctx, OFPS_HIP_EINVAL, "multi_fetch: no results (run first, same block size)");
+        // the results must be those of THIS staged batch, searched with this block size (a re-stage without a
+        // new run, or a run with another block size that happened to fit the buffer, used to return stale vectors)
+        if (!w.d_out || w.run_gen != m->stage_gen || w.run_block != block || w.run_pairs != w.n_pairs)
+            return ofps::set_error(w.ctx, OFPS_HIP_EINVAL, "multi_fetch: no results for the staged batch (run_resident after stage_frames, same block size)");
         OFPS_HIP_TRY(w.ctx, hipSetDevice(w.device));
         OFPS_HIP_TRY(w.ctx, hipMemcpyAsync(out_entries + w.first_pair * nblk * 4, w.d_out, w.n_pairs * nblk * 4 * sizeof(float),
                                            hipMemcpyDeviceToHost, w.ctx->stream));
@@ -327,9 +359,147 @@ int ofps_hip_multi_fetch(ofps_hip_multi* m, int block, float* out_entries) {
     });
 }
 
+// ---- stream pipeline across devices.  Batches of n consecutive frames of ONE stream are dealt to the workers round-robin (batch g
+// -> worker g % n_workers); every batch travels with the one frame in front of it (the last frame of batch g - 1, kept in a
+// page-locked halo buffer), so the workers never talk to each other; per worker the batch goes through the context's
+// two-ticket batched read-ahead (pipeline.hip: one H2D on the copy stream, one search launch, one detector chain, one estimator
+// launch, read-back by kernel into the ticket's page-locked block).  Results come back per batch, i.e. in frame order.  The
+// reference decodes on its own thread into a double buffer and runs its estimators beside it
+// (ofps-suite/src/app/tracking/worker.rs:165-226,347-361; detection.rs:111-148); it has no multi-device code.
+void ofps_hip_multi_stream_plan(long batch, int n_workers, int* worker, int* halo_slot, int* ticket_slot) {
+    const int nw = n_workers < 1 ? 1 : n_workers;
+    if (worker) *worker = (int)(batch % nw);
+    if (halo_slot) *halo_slot = (int)(batch % (2 * nw + 1));       // the frame in front of batch g lives in halo[g % (2 nw + 1)]
+    if (ticket_slot) *ticket_slot = (int)(batch % (2 * nw));       // at most two batches in flight per worker
+}
+
+int ofps_hip_multi_reset_frames(ofps_hip_multi* m) {
+    if (!m) return OFPS_HIP_EINVAL;
+    std::lock_guard<std::recursive_mutex> api(m->api);
+    for (auto& tp : m->tickets)
+        if (tp && tp->pending) return multi_error(m, OFPS_HIP_EINVAL, "multi_reset_frames: ticket(s) in flight: collect them first");
+    const int rc = run_all(m, [&](Worker& w, int) -> int { w.stream_batches = 0; return ofps_hip_reset_frames(w.ctx); });
+    m->stream_frames = 0; m->next_ticket = 0; m->sW = m->sH = 0;
+    return rc;
+}
+
+int ofps_hip_multi_push_frames_async(ofps_hip_multi* m, const uint8_t* frames, int n, int W, int H, int stride, size_t frame_pitch,
+                                     const ofps_hip_frame_params* params, float* out_entries, int* ticket) {
+    if (!m) return OFPS_HIP_EINVAL;
+    std::lock_guard<std::recursive_mutex> api(m->api);
+    if (!frames || !params || !ticket || n < 1 || n > 4096 || W < 1 || H < 1 || stride < W || frame_pitch < (size_t)stride * H)
+        return multi_error(m, OFPS_HIP_EINVAL, "multi_push_frames_async: bad arguments (n=%d W=%d H=%d stride=%d)", n, W, H, stride);
+    const int nw = (int)m->w.size();
+    if (m->tickets.empty())
+        for (int k = 0; k < 2 * nw; ++k) m->tickets.emplace_back(new ofps_hip_multi::StreamTicket());
+    if (W != m->sW || H != m->sH) {                               // a new geometry restarts the stream (decoder.rs:66-72)
+        for (auto& tp : m->tickets)
+            if (tp->pending) return multi_error(m, OFPS_HIP_EINVAL, "multi_push_frames_async: geometry change with tickets in flight");
+        const int rc = ofps_hip_multi_reset_frames(m);
+        if (rc != OFPS_HIP_OK) return rc;
+        m->sW = W; m->sH = H;
+    }
+    const long g = m->next_ticket;
+    int wk, hs, ts;
+    ofps_hip_multi_stream_plan(g, nw, &wk, &hs, &ts);
+    auto* t = m->tickets[ts].get();
+    if (t->pending)
+        return multi_error(m, OFPS_HIP_EINVAL, "multi_push_frames_async: ticket %ld has not been collected (at most %d batches in flight)",
+                           g - 2 * nw, 2 * nw);
+    // halo buffers: page-locked, one frame of `stride` x H bytes each
+    const size_t hbytes = (size_t)stride * H;
+    if (m->halo.empty() || m->halo_bytes < hbytes) {
+        for (auto& tp : m->tickets)
+            if (tp->pending) return multi_error(m, OFPS_HIP_EINVAL, "multi_push_frames_async: frame size grew with tickets in flight");
+        for (auto* h : m->halo) if (h) (void)hipHostFree(h);
+        m->halo.assign((size_t)(2 * nw + 1), nullptr);
+        for (auto& h : m->halo)
+            if (hipHostMalloc(reinterpret_cast<void**>(&h), hbytes, hipHostMallocDefault) != hipSuccess)
+                return multi_error(m, OFPS_HIP_ENOMEM, "multi_push_frames_async: hipHostMalloc(%zu) failed", hbytes);
+        m->halo_bytes = hbytes;
+        m->stream_frames = 0;                                      // whatever halo there was is gone: the stream starts over
+    }
+    const uint8_t* halo = m->stream_frames ? m->halo[hs] : nullptr;    // the stream's first batch has no frame in front of it
+    // the last frame of THIS batch is the halo of the next one (copied now: the caller's buffer is only promised until its wait)
+    int nhs;
+    ofps_hip_multi_stream_plan(g + 1, nw, nullptr, &nhs, nullptr);
+    memcpy(m->halo[nhs], frames + (size_t)(n - 1) * frame_pitch, hbytes);
+    t->pending = true; t->enqueued = false; t->worker = wk; t->n = n; t->rc = OFPS_HIP_OK;
+    const ofps_hip_frame_params prm = *params;
+    enqueue(m->w[wk], [=](Worker& w) {
+        int rc = OFPS_HIP_OK, wt = 0;
+        const uint8_t* src = frames;
+        size_t pitch = frame_pitch;
+        void* dev = nullptr;
+        if (!ofps::device_address_of(frames, &dev)) {
+            // pageable source: into this worker's page-locked staging (two buffers in turn, like its two tickets) -- the copy
+            // runs on the worker's thread, beside the other workers' copies
+            const int sb = (int)(w.stream_batches & 1);
+            const size_t need = (size_t)n * frame_pitch;
+            if (w.stage_cap[sb] < need) {
+                if (w.stage[sb]) (void)hipHostFree(w.stage[sb]);
+                w.stage[sb] = nullptr; w.stage_cap[sb] = 0;
+                if (hipHostMalloc(reinterpret_cast<void**>(&w.stage[sb]), need, hipHostMallocDefault) != hipSuccess)
+                    rc = ofps::set_error(w.ctx, OFPS_HIP_ENOMEM, "multi_push_frames_async: hipHostMalloc(%zu) for staging failed", need);
+                else w.stage_cap[sb] = need;
+            }
+            if (rc == OFPS_HIP_OK) { memcpy(w.stage[sb], frames, need); src = w.stage[sb]; }
+        }
+        if (rc == OFPS_HIP_OK)
+            rc = ofps::push_frames_impl(w.ctx, src, n, W, H, stride, pitch, &prm, out_entries, &wt, /*halo_mode=*/1, halo);
+        w.stream_batches += 1;
+        std::lock_guard<std::mutex> lk(t->m);
+        t->rc = rc; t->worker_ticket = wt; t->enqueued = true;
+        t->cv.notify_all();
+    });
+    m->stream_frames += n;
+    m->next_ticket = g + 1;
+    *ticket = (int)(g & 0x7FFFFFFF);
+    return OFPS_HIP_OK;
+}
+
+int ofps_hip_multi_frames_wait(ofps_hip_multi* m, int ticket, ofps_hip_frame_result* out) {
+    if (!m || !out) return OFPS_HIP_EINVAL;
+    ofps_hip_multi::StreamTicket* t = nullptr;
+    {
+        std::lock_guard<std::recursive_mutex> api(m->api);
+        const int nw = (int)m->w.size();
+        const long newest = m->next_ticket - 1;
+        long g = -1;
+        for (long k = newest; k >= 0 && k > newest - 2 * nw; --k)
+            if ((int)(k & 0x7FFFFFFF) == ticket) { g = k; break; }
+        if (g < 0 || m->tickets.empty()) return multi_error(m, OFPS_HIP_EINVAL, "multi_frames_wait: ticket %d is not in flight", ticket);
+        int ts;
+        ofps_hip_multi_stream_plan(g, nw, nullptr, nullptr, &ts);
+        t = m->tickets[ts].get();
+        if (!t->pending) return multi_error(m, OFPS_HIP_EINVAL, "multi_frames_wait: ticket %d was already collected", ticket);
+    }
+    // (outside the dispatcher's lock: another host thread may push the next batch while this one waits)
+    { std::unique_lock<std::mutex> lk(t->m); t->cv.wait(lk, [&] { return t->enqueued; }); }
+    Worker* w = m->w[t->worker];
+    int rc = t->rc;
+    if (rc == OFPS_HIP_OK) {
+        struct Done { std::mutex m; std::condition_variable cv; bool done = false; int rc = 0; } d;
+        const int wt = t->worker_ticket;
+        enqueue(w, [&d, wt, out](Worker& ww) {
+            const int r = ofps_hip_frames_wait(ww.ctx, wt, out);
+            std::lock_guard<std::mutex> lk(d.m);
+            d.rc = r; d.done = true; d.cv.notify_all();
+        });
+        std::unique_lock<std::mutex> lk(d.m);
+        d.cv.wait(lk, [&] { return d.done; });
+        rc = d.rc;
+    }
+    std::lock_guard<std::recursive_mutex> api(m->api);
+    if (rc != OFPS_HIP_OK) snprintf(m->err, sizeof(m->err), "worker %d (device %d): %s", t->worker, w->device, ofps_hip_last_error(w->ctx));
+    t->pending = false;
+    return rc;
+}
+
 int ofps_hip_multi_sad_flow(ofps_hip_multi* m, const uint8_t* frames, int n_frames, int W, int H, int stride, size_t frame_pitch,
                             int ref_mode, int block, int range, float* out_entries) {
     if (!m) return OFPS_HIP_EINVAL;
+    std::lock_guard<std::recursive_mutex> api(m->api);
     if (!out_entries) return multi_error(m, OFPS_HIP_EINVAL, "multi_sad_flow: out_entries is NULL");
     int rc = ofps_hip_multi_stage_frames(m, frames, n_frames, W, H, stride, frame_pitch, ref_mode);
     if (rc != OFPS_HIP_OK) return rc;

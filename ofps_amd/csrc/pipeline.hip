@@ -308,8 +308,15 @@ int ofps_hip_frame_wait(ofps_hip_ctx* ctx, int ticket, ofps_hip_frame_result* ou
 // launch over the batch, one read-back -- a handful of HIP calls per BATCH instead of ~9 per frame, which is what kept
 // the single-frame loop 20 % under the PCIe ceiling.  Frame j of the batch is pair (previous frame of the stream, frame
 // j); the previous frame of frame 0 is the last frame of the previous batch, kept in slot 0 of the other batch buffer.
-int ofps_hip_push_frames_async(ofps_hip_ctx* ctx, const uint8_t* frames, int n, int W, int H, int stride, size_t frame_pitch,
-                               const ofps_hip_frame_params* prm, float* out_entries, int* ticket) {
+}  // extern "C"
+
+namespace ofps {
+// halo_mode 0: frame 0 of the batch is paired with the context's own previous frame (ofps_hip_push_frames_async).
+// halo_mode 1: the caller supplies the previous frame (`halo`, host memory, same row stride as `frames`) or says there is none
+// (halo == nullptr: the very first frame of a stream) -- the multi-device dispatcher's form (multi.hip): a worker sees every
+// n_workers-th batch of a stream, so the frame in front of its batch is not the last one IT saw.
+int push_frames_impl(ofps_hip_ctx* ctx, const uint8_t* frames, int n, int W, int H, int stride, size_t frame_pitch,
+                     const ofps_hip_frame_params* prm, float* out_entries, int* ticket, int halo_mode, const uint8_t* halo) {
     if (!ctx) return OFPS_HIP_EINVAL;
     OFPS_REQUIRE(ctx, frames && prm && ticket && n >= 1 && n <= 4096, "push_frames_async: bad arguments (n=%d)", n);
     OFPS_REQUIRE(ctx, W > 0 && H > 0 && stride >= W && frame_pitch >= (size_t)stride * H, "push_frames_async: bad geometry W=%d H=%d stride=%d", W, H, stride);
@@ -389,10 +396,11 @@ int ofps_hip_push_frames_async(ofps_hip_ctx* ctx, const uint8_t* frames, int n, 
         for (int j = 0; j < n; ++j)
             OFPS_HIP_TRY(ctx, ofps::upload_rows(buf + (size_t)(j + 1) * pitch, dstride, frames + (size_t)j * frame_pitch, stride, W, H, up));
     }
+    if (halo_mode && halo) OFPS_HIP_TRY(ctx, ofps::upload_rows(buf, dstride, halo, stride, W, H, up));       // the caller's previous frame into slot 0
     OFPS_HIP_TRY(ctx, hipEventRecord(t.uploaded, up));
-    const bool has_prev = ctx->batch_last_frame != nullptr;
+    const bool has_prev = halo_mode ? halo != nullptr : ctx->batch_last_frame != nullptr;
     t.prev_copied_valid = false;
-    if (has_prev) {
+    if (has_prev && !halo_mode) {
         OFPS_HIP_TRY(ctx, hipMemcpyAsync(buf, ctx->batch_last_frame, pitch, hipMemcpyDeviceToDevice, s));
         OFPS_HIP_TRY(ctx, hipEventRecord(t.prev_copied, s));
         t.prev_copied_valid = true;
@@ -437,6 +445,14 @@ int ofps_hip_push_frames_async(ofps_hip_ctx* ctx, const uint8_t* frames, int n, 
     *ticket = (int)(tno & 0x7FFFFFFF);
     ctx->batch_next_ticket = tno + 1;
     return OFPS_HIP_OK;
+}
+}  // namespace ofps
+
+extern "C" {
+
+int ofps_hip_push_frames_async(ofps_hip_ctx* ctx, const uint8_t* frames, int n, int W, int H, int stride, size_t frame_pitch,
+                               const ofps_hip_frame_params* prm, float* out_entries, int* ticket) {
+    return ofps::push_frames_impl(ctx, frames, n, W, H, stride, frame_pitch, prm, out_entries, ticket, 0, nullptr);
 }
 
 int ofps_hip_frames_wait(ofps_hip_ctx* ctx, int ticket, ofps_hip_frame_result* out /* n of them */) {

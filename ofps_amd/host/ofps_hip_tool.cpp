@@ -5,7 +5,10 @@
 //                                                       the same loop from a saved MotionDetectionConfig (detection.rs:45-50):
 //                                                       plugins, their saved properties, max_frame_gap / min_frames
 //   parse-config <saved.json>                           prints what a saved configuration says (no GPU)
-//   stream-bench <w> <h> <frames> [sync|ahead|batch <n>] PCIe-inclusive per-frame time of the hip_sad process_frame shape
+//   stream-bench <w> <h> <frames> [sync|ahead|batch <n>|multi <n> [dev ...]]
+//                                                       PCIe-inclusive per-frame time of the hip_sad process_frame shape; `multi`:
+//                                                       the stream over several workers (ofps_hip_multi_push_frames_async), with
+//                                                       detector + estimator per frame
 //   track   <decoder> <arg> [aspect fov_y] [lsq|ransac] tracking loop, ofps-suite/src/app/tracking/worker.rs:305-412
 //   mvec-copy <in.mvec> <out.mvec>                      CPU-only .mvec round trip (reader + writer)
 //   multi-extract <raw.y> <w> <h> <out.mvec> [dev ...]  the whole clip over several GPUs (ofps_hip_multi_*): same bytes as `extract hip_sad`
@@ -153,6 +156,53 @@ int main(int argc, char** argv) {
             const int frames = std::atoi(argv[4]);
             const bool ahead = !(argc > 5 && std::string(argv[5]) == "sync");
             const int batch = (argc > 6 && std::string(argv[5]) == "batch") ? std::atoi(argv[6]) : 0;
+            if (argc > 6 && std::string(argv[5]) == "multi") {
+                // the same stream dealt to several workers (one context + thread per device entry; entries may repeat): batches of
+                // `mb` frames from page-locked blocks, 2 per worker in flight, vectors + island + quaternion per frame come back
+                const int mb = std::atoi(argv[6]);
+                std::vector<int> devices;
+                for (int a = 7; a < argc; ++a) devices.push_back(std::atoi(argv[a]));
+                if (devices.empty()) devices.push_back(0);
+                ofps_hip_multi* m = nullptr;
+                if (ofps_hip_multi_init(devices.data(), (int)devices.size(), &m) != OFPS_HIP_OK) throw Error(ofps_hip_multi_last_error(nullptr));
+                const int nw = (int)devices.size(), slots = 2 * nw;
+                const size_t nblk = ofps_hip_sad_block_count(W, H, 16);
+                HipContext alloc;                                           // page-locked memory comes from any context
+                std::vector<uint8_t*> pin((size_t)slots); std::vector<float*> ent((size_t)slots);
+                for (auto& p : pin) { void* q; alloc.check(ofps_hip_host_alloc(alloc.get(), (size_t)mb * W * H, &q)); p = static_cast<uint8_t*>(q); }
+                for (auto& p : ent) { void* q; alloc.check(ofps_hip_host_alloc(alloc.get(), (size_t)mb * nblk * 16, &q)); p = static_cast<float*>(q); }
+                uint32_t st = 12345;
+                for (auto& p : pin) for (size_t i = 0; i < (size_t)mb * W * H; ++i) { st = st * 1664525u + 1013904223u; p[i] = (uint8_t)(st >> 24); }
+                ofps_hip_frame_params prm{};
+                prm.block = 16; prm.range = 16; prm.run_detector = 1; prm.min_size = 0.05f; prm.subdivide = 3; prm.target_motion = 0.003f;
+                prm.run_estimator = 1; prm.aspect = (float)W / (float)H; prm.fov_y_deg = 39.6f * (float)H / (float)W;
+                std::vector<ofps_hip_frame_result> res((size_t)mb);
+                auto mcheck = [&](int rc) { if (rc != OFPS_HIP_OK) throw Error(ofps_hip_multi_last_error(m)); };
+                auto run = [&](int nb) {
+                    mcheck(ofps_hip_multi_reset_frames(m));
+                    std::vector<int> q;
+                    for (int k = 0; k < nb; ++k) {
+                        if ((int)q.size() == slots) { mcheck(ofps_hip_multi_frames_wait(m, q.front(), res.data())); q.erase(q.begin()); }
+                        int t = 0;
+                        prm.seed = (uint64_t)k * (uint64_t)mb;
+                        mcheck(ofps_hip_multi_push_frames_async(m, pin[(size_t)(k % slots)], mb, W, H, W, (size_t)W * H, &prm, ent[(size_t)(k % slots)], &t));
+                        q.push_back(t);
+                    }
+                    for (int t : q) mcheck(ofps_hip_multi_frames_wait(m, t, res.data()));
+                };
+                const int nb = (frames + mb - 1) / mb;
+                run(2 * slots);
+                const auto t0 = std::chrono::steady_clock::now();
+                run(nb);
+                const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / ((double)nb * mb);
+                std::printf("{\"mode\": \"multi_read_ahead_batched\", \"workers\": %d, \"batch\": %d, \"frames\": %d, \"ms_per_frame\": %.4f, "
+                            "\"Mvectors_per_s\": %.2f, \"per_frame\": \"vectors + block-motion island + almeida LSQ quaternion\"}\n", nw, mb, nb * mb, ms,
+                            (double)nblk / ms / 1e3);
+                for (auto p : pin) ofps_hip_host_free(alloc.get(), p);
+                for (auto p : ent) ofps_hip_host_free(alloc.get(), p);
+                ofps_hip_multi_destroy(m);
+                return 0;
+            }
             if (batch > 0) {
                 // batched read-ahead form: `batch` frames per ticket from ONE page-locked block, two tickets in flight
                 HipContext ctx;

@@ -477,6 +477,39 @@ class MultiDevice:
         _lib.load().ofps_hip_multi_frame_range(n_pairs, n_workers, k, ref_mode, C.byref(f), C.byref(c))
         return int(f.value), int(c.value)
 
+    @staticmethod
+    def stream_plan(batch: int, n_workers: int):
+        """-> (worker, halo_slot, ticket_slot) of batch number `batch` of a stream (pure function, no device needed)."""
+        w, h, t = C.c_int(0), C.c_int(0), C.c_int(0)
+        _lib.load().ofps_hip_multi_stream_plan(batch, n_workers, C.byref(w), C.byref(h), C.byref(t))
+        return int(w.value), int(h.value), int(t.value)
+
+    def push_frames_async(self, frames: np.ndarray, block=16, search_range=16, detector=True, min_size=0.05, subdivide=3,
+                          target_motion=0.003, estimator=True, aspect=16 / 9, fov_y_deg=39.6 * 9 / 16, use_ransac=False,
+                          num_iters=200, inlier_deg=0.05, num_samples=1000, seed=0, out_entries: np.ndarray | None = None) -> int:
+        """One batch of consecutive frames of the stream (uint8 [n, H, W] contiguous) -> ticket; keep `frames` and `out_entries`
+        ([n, nblk, 4] float32) alive until frames_wait(ticket).  Batches are dealt to the workers round-robin."""
+        assert frames.dtype == np.uint8 and frames.ndim == 3 and frames.flags["C_CONTIGUOUS"]
+        n, H, W = frames.shape
+        prm = _lib.FrameParams(block, search_range, int(detector), min_size, subdivide, target_motion, int(estimator),
+                               aspect, fov_y_deg, int(use_ransac), num_iters, inlier_deg, num_samples, seed)
+        t = C.c_int(0)
+        self._check(self._lib.ofps_hip_multi_push_frames_async(self._h, frames.ctypes.data_as(C.POINTER(C.c_uint8)), n, W, H, W, W * H,
+                                                               C.byref(prm), _fp(out_entries) if out_entries is not None else None, C.byref(t)))
+        self._batch_n = getattr(self, "_batch_n", {})
+        self._batch_n[t.value] = n
+        return t.value
+
+    def frames_wait(self, ticket: int) -> list:
+        n = getattr(self, "_batch_n", {}).pop(ticket, 1)
+        res = (_lib.FrameResult * n)()
+        self._check(self._lib.ofps_hip_multi_frames_wait(self._h, ticket, res))
+        return [{"have_vectors": bool(r.have_vectors), "n_vectors": int(r.n_vectors),
+                 "motion": (int(r.area), int(r.dim)) if r.has_motion else None, "quat": np.array(list(r.quat), np.float32)} for r in res]
+
+    def reset_frames(self):
+        self._check(self._lib.ofps_hip_multi_reset_frames(self._h))
+
     def sad_flow(self, frames: np.ndarray, block: int, search_range: int, ref_mode: int = 0) -> np.ndarray:
         """frames: uint8 [n_frames, H, stride>=W is the array's row pitch] -> entries [n_frames-1, nblk, 4]."""
         frames = np.ascontiguousarray(frames, np.uint8)

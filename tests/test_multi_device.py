@@ -37,6 +37,26 @@ def test_cfg4_batch_over_a_fake_node_of_eight():
         assert MultiDevice.frame_range(64, 8, k, 1) == (8 * k + 1, 8)
 
 
+@pytest.mark.parametrize("workers", [1, 2, 3, 8])
+def test_stream_batches_are_dealt_round_robin_and_no_slot_is_reused_while_it_may_be_in_flight(workers):
+    """The stream pipeline's dealing (ofps_hip_multi_stream_plan), for a fake list of up to 8 devices: batch g goes to worker
+    g % n; with at most two batches in flight per worker (2 n tickets) neither a ticket slot nor the halo buffer of a batch that
+    may still be in flight is handed out again -- batch g + 1's halo (the copy of batch g's last frame) is written while
+    batches g - 2 n + 1 .. g may be in flight, so it must differ from all of THEIR halo slots."""
+    plan = [MultiDevice.stream_plan(g, workers) for g in range(6 * workers + 5)]
+    for g, (w, h, t) in enumerate(plan):
+        assert w == g % workers
+        in_flight = range(max(0, g - 2 * workers + 1), g)            # pushed, possibly uncollected, when batch g is pushed
+        assert all(plan[k][2] != t for k in in_flight), "ticket slot handed out twice"
+        if g + 1 < len(plan):
+            nh = plan[g + 1][1]                                        # written during push g
+            assert all(plan[k][1] != nh for k in list(in_flight) + [g]), "halo buffer overwritten while its batch may be in flight"
+    # every worker sees every n-th batch, in order
+    for k in range(workers):
+        mine = [g for g, (w, _, _) in enumerate(plan) if w == k]
+        assert mine == list(range(k, len(plan), workers))
+
+
 def test_bad_device_list_fails_loudly():
     import torch
     from ofps_amd._lib import OfpsHipError
@@ -127,3 +147,83 @@ def test_checksum_dev_is_the_wrapping_u64_sum_per_item():
         with np.errstate(over="ignore"):
             want = a.sum(axis=1, dtype=np.uint64)
         np.testing.assert_array_equal(out.cpu().numpy().view(np.uint64), want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("workers", [1, 2, 3])
+@pytest.mark.parametrize("pinned", [False, True])
+def test_multi_stream_pipeline_equals_the_single_context_stream(workers, pinned):
+    """ofps_hip_multi_push_frames_async / _frames_wait with 1-3 workers on one GPU (repeated entries of device 0): vectors,
+    detector results and quaternions of every frame equal ofps_hip_push_frames_async on ONE context fed the same batches, bit
+    for bit (the quaternions too: a batch is one solver launch either way).  Frames in pageable memory (staged by the workers)
+    and in page-locked memory; RANSAC on odd batches, per-batch seeds."""
+    from ofps_amd import synth
+    from ofps_amd.runtime import HipContext
+    W, H, B, R, nb, per = 320, 192, 16, 8, 7, 3                     # 7 batches of 3 frames
+    fr = synth.luma_sequence(nb * per, W, H, max_step=6, seed=synth.SEED0 + 31)
+    nblk = (W // B) * (H // B)
+    ctx = HipContext(0)
+    ref, ref_ent = [], np.zeros((nb, per, nblk, 4), np.float32)
+    ctx.reset_frames()
+    for b in range(nb):
+        t = ctx.push_frames_async(np.ascontiguousarray(fr[b * per:(b + 1) * per]), block=B, search_range=R, use_ransac=bool(b & 1), num_iters=40,
+                                  seed=100 * b, out_entries=ref_ent[b])
+        ref += ctx.frames_wait(t)
+    md = MultiDevice([0] * workers)
+    try:
+        got, got_ent = [], np.zeros((nb, per, nblk, 4), np.float32)
+        bufs = [ctx.pinned_frame(per * H, W).reshape(per, H, W) if pinned else np.empty((per, H, W), np.uint8) for _ in range(2 * workers)]
+        tickets = []
+        for b in range(nb):                                          # keep 2 * workers batches in flight
+            if len(tickets) == 2 * workers:
+                got += md.frames_wait(tickets.pop(0))
+            buf = bufs[b % len(bufs)]
+            np.copyto(buf, fr[b * per:(b + 1) * per])
+            tickets.append(md.push_frames_async(buf, block=B, search_range=R, use_ransac=bool(b & 1), num_iters=40, seed=100 * b,
+                                                out_entries=got_ent[b]))
+        while tickets:
+            got += md.frames_wait(tickets.pop(0))
+        assert len(got) == len(ref) == nb * per
+        assert not got[0]["have_vectors"] and all(g["have_vectors"] for g in got[1:])
+        for k, (g, r) in enumerate(zip(got, ref)):
+            assert g["have_vectors"] == r["have_vectors"] and g["motion"] == r["motion"], k
+            np.testing.assert_array_equal(g["quat"].view(np.uint32), r["quat"].view(np.uint32))
+        np.testing.assert_array_equal(got_ent.reshape(-1, nblk, 4)[1:].view(np.uint32), ref_ent.reshape(-1, nblk, 4)[1:].view(np.uint32))
+        # a third batch per worker without collecting is refused; a reset with tickets in flight too
+        md.reset_frames()
+        ts = [md.push_frames_async(bufs[k % len(bufs)], block=B, search_range=R) for k in range(2 * workers)]
+        with pytest.raises(Exception):
+            md.push_frames_async(bufs[0], block=B, search_range=R)
+        with pytest.raises(Exception):
+            md.reset_frames()
+        for t in ts:
+            md.frames_wait(t)
+        with pytest.raises(Exception):
+            md.frames_wait(ts[0])
+    finally:
+        md.close()
+        ctx.close()
+
+
+@pytest.mark.gpu
+def test_multi_fetch_refuses_results_of_another_batch_or_block_size():
+    """ofps_hip_multi_fetch used to check only the buffer's capacity."""
+    from ofps_amd import synth
+    from ofps_amd._lib import OfpsHipError
+    fr = synth.luma_sequence(5, 256, 128, max_step=4, seed=3)
+    md = MultiDevice([0, 0])
+    try:
+        md.stage_frames(fr)
+        with pytest.raises(OfpsHipError):
+            md.fetch(16)                                             # nothing searched yet
+        md.run_resident(16, 8)
+        a = md.fetch(16)
+        with pytest.raises(OfpsHipError):
+            md.fetch(8)                                              # searched with another block size
+        md.stage_frames(fr[:4])                                      # a new (smaller) batch: the old results are not its results
+        with pytest.raises(OfpsHipError):
+            md.fetch(16)
+        md.run_resident(16, 8)
+        np.testing.assert_array_equal(md.fetch(16).view(np.uint32), a[:3].view(np.uint32))
+    finally:
+        md.close()
