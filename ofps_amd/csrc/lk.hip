@@ -177,6 +177,68 @@ __global__ __launch_bounds__(256) void lk_pyr0_kernel(const TIn* __restrict__ s0
                                    hor[2 * ly + 4][lx]) * 0.0625f;
 }
 
+// Levels 1 AND 2 of both frames' pyramids from the u8 frames in one launch (round 4: the two pyramid steps used to be two
+// launches, 10 + 6 us, the second one latency-bound).  A workgroup owns a 32 x 8 tile of level 2 = 64 x 16 of level 1; it
+// stages the 140 x 44 level-0 window those need, makes the 68 x 20 level-1 window (its own 64 x 16 and the 2-pixel rim the
+// level-2 filter reads: a quarter more level-1 values than the tile owns) and from it the level-2 tile.  Every value is the
+// oracle's lk_pyr_down expression on the oracle's operands (coordinates clamped per element: a window element at level-1
+// coordinate x holds level1[clamp(x)], made from level-0 taps clamp(2 clamp(x) + d)) -- same bits whoever computes it.
+__global__ __launch_bounds__(256) void lk_pyr12_kernel(const uint8_t* __restrict__ s0, const uint8_t* __restrict__ s1, int W, int H, int stride,
+                                                       float* __restrict__ a1, float* __restrict__ b1, int w1, int h1,
+                                                       float* __restrict__ a2, float* __restrict__ b2, int w2, int h2) {
+    constexpr int W1 = 2 * kP0X + 4, H1 = 2 * kP0Y + 4;           // level-1 window: 68 x 20
+    constexpr int W0 = 2 * W1 + 4, H0 = 2 * H1 + 4;               // level-0 window: 140 x 44
+    __shared__ uint8_t win0[H0][W0 + 4];
+    __shared__ float hor1[H0][W1 + 1];
+    __shared__ float lvl1[H1][W1 + 1];
+    __shared__ float hor2[H1][kP0X + 1];
+    int tx, ty;
+    if (!lk_tile_of_block((w2 + kP0X - 1) / kP0X, ((w2 + kP0X - 1) / kP0X) * ((h2 + kP0Y - 1) / kP0Y), tx, ty)) return;
+    const uint8_t* src = blockIdx.z ? s1 : s0;
+    float* o1 = blockIdx.z ? b1 : a1;
+    float* o2 = blockIdx.z ? b2 : a2;
+    const int x2_0 = tx * kP0X, y2_0 = ty * kP0Y;                 // level-2 tile origin
+    const int x1_0 = 2 * x2_0 - 2, y1_0 = 2 * y2_0 - 2;           // level-1 window origin
+    const int gx0 = 2 * x1_0 - 2, gy0 = 2 * y1_0 - 2;             // level-0 window origin
+    for (int t = threadIdx.x; t < W0 * H0; t += 256) {
+        const int r = t / W0, c = t - r * W0;
+        win0[r][c] = src[(size_t)lk_clampi(gy0 + r, 0, H - 1) * stride + lk_clampi(gx0 + c, 0, W - 1)];
+    }
+    __syncthreads();
+    // rows pass of level 1: every level-0 row of the window, at the window's 68 (clamped) level-1 columns
+    for (int t = threadIdx.x; t < W1 * H0; t += 256) {
+        const int r = t / W1, i = t - r * W1;
+        const int cx = lk_clampi(x1_0 + i, 0, w1 - 1);
+        const uint8_t* p = &win0[r][2 * cx - gx0 - 2];
+        hor1[r][i] = ((((float)p[0] + 4.0f * (float)p[1]) + 6.0f * (float)p[2]) + 4.0f * (float)p[3]) + (float)p[4];
+        hor1[r][i] *= 0.0625f;
+    }
+    __syncthreads();
+    // columns pass: the 68 x 20 level-1 window; its centre is this tile's share of the level-1 plane
+    for (int t = threadIdx.x; t < W1 * H1; t += 256) {
+        const int j = t / W1, i = t - j * W1;
+        const int cy = lk_clampi(y1_0 + j, 0, h1 - 1);
+        const int r = 2 * cy - gy0 - 2;
+        const float v = ((((hor1[r][i] + 4.0f * hor1[r + 1][i]) + 6.0f * hor1[r + 2][i]) + 4.0f * hor1[r + 3][i]) + hor1[r + 4][i]) * 0.0625f;
+        lvl1[j][i] = v;
+        const int x1 = x1_0 + i, y1 = y1_0 + j;
+        if (i >= 2 && i < W1 - 2 && j >= 2 && j < H1 - 2 && x1 < w1 && y1 < h1) o1[(size_t)y1 * w1 + x1] = v;
+    }
+    __syncthreads();
+    // level 2 from the level-1 window (whose elements sit at their clamped coordinates already)
+    for (int t = threadIdx.x; t < kP0X * H1; t += 256) {
+        const int j = t / kP0X, x = t - j * kP0X;
+        const float* p = &lvl1[j][2 * x];
+        hor2[j][x] = ((((p[0] + 4.0f * p[1]) + 6.0f * p[2]) + 4.0f * p[3]) + p[4]) * 0.0625f;
+    }
+    __syncthreads();
+    const int lx = threadIdx.x % kP0X, ly = threadIdx.x / kP0X;
+    const int x2 = x2_0 + lx, y2 = y2_0 + ly;
+    if (x2 < w2 && y2 < h2)
+        o2[(size_t)y2 * w2 + x2] = ((((hor2[2 * ly][lx] + 4.0f * hor2[2 * ly + 1][lx]) + 6.0f * hor2[2 * ly + 2][lx]) + 4.0f * hor2[2 * ly + 3][lx]) +
+                                    hor2[2 * ly + 4][lx]) * 0.0625f;
+}
+
 __global__ __launch_bounds__(256) void lk_u8_to_f32_pair_kernel(const uint8_t* __restrict__ s0, const uint8_t* __restrict__ s1, int W, int H,
                                                                 int stride, float* __restrict__ d0, float* __restrict__ d1) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
@@ -1315,7 +1377,13 @@ int lk_flow_device(ofps_hip_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_cu
         prof = static_cast<unsigned long long*>(scratch(ctx, S_WORK2, tiles0 * 6 * sizeof(unsigned long long)));
         if (!prof) return OFPS_HIP_ENOMEM;
     }
-    if (levels >= 2) {                                            // level 1 from the u8 frames
+    int pyr_from = 2;                                             // first level the per-level pyramid launches below still have to make
+    if (tiled && levels >= 3) {                                   // levels 1 and 2 from the u8 frames in one launch
+        dim3 g2 = lk_grid_xcd(ws[2], hs[2], kP0X, kP0Y); g2.z = 2;
+        hipLaunchKernelGGL(lk_pyr12_kernel, g2, dim3(256), 0, s, d_prev, d_cur, W, H, stride, Ip + off[1], Jp + off[1], ws[1], hs[1],
+                           Ip + off[2], Jp + off[2], ws[2], hs[2]);
+        pyr_from = 3;
+    } else if (levels >= 2) {                                     // level 1 from the u8 frames
         // (the tiled path's level 0 works on the u8 frames themselves: no f32 level-0 planes, no level-0 gradient planes)
         dim3 g2 = lk_grid_xcd(ws[1], hs[1], kP0X, kP0Y); g2.z = 2;
         hipLaunchKernelGGL(lk_pyr0_kernel<uint8_t>, g2, dim3(256), 0, s, d_prev, d_cur, W, H, stride, tiled ? (float*)nullptr : Ip,
@@ -1325,7 +1393,7 @@ int lk_flow_device(ofps_hip_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_cu
         dim3 g2 = lk_grid(W, H); g2.z = 2;
         hipLaunchKernelGGL(lk_u8_to_f32_pair_kernel, g2, dim3(256), 0, s, d_prev, d_cur, W, H, stride, Ip, Jp);
     }
-    for (int l = 2; l < levels; ++l) {                            // level l from level l-1, whose gradients come out of the same window
+    for (int l = pyr_from; l < levels; ++l) {                     // level l from level l-1 (the untiled path's gradients of level l-1 come out of the same window)
         dim3 g2 = lk_grid_xcd(ws[l], hs[l], kP0X, kP0Y); g2.z = 2;
         hipLaunchKernelGGL(lk_pyr0_kernel<float>, g2, dim3(256), 0, s, (const float*)(Ip + off[l - 1]), (const float*)(Jp + off[l - 1]),
                            ws[l - 1], hs[l - 1], ws[l - 1], (float*)nullptr, (float*)nullptr, Ip + off[l], Jp + off[l], ws[l], hs[l],
