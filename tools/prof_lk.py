@@ -13,9 +13,10 @@ from ofps_amd.runtime import HipContext  # noqa: E402
 
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+    max_step = int(sys.argv[2]) if len(sys.argv) > 2 else 3      # 3: the +-3 px content; 16: the SAD bench's +-16 px regions
     ctx = HipContext(0)
     ctx.use_torch_stream()
-    fr = synth.luma_sequence(2, 1920, 1080, max_step=3, seed=11)
+    fr = synth.luma_sequence(2, 1920, 1080, max_step=max_step, seed=11)
     dfr = torch.from_numpy(fr).cuda()
     d_ent = torch.empty((1920 * 1080, 4), dtype=torch.float32, device="cuda")
     f84 = torch.empty((150 * 84, 2), dtype=torch.float32, device="cuda")
