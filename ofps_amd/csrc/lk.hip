@@ -557,6 +557,31 @@ __device__ __forceinline__ void lk_stage3_u8_records(const float* scratch, float
 //   * 7 VALU operations per tap (the spec's count), 63 per row.
 // Same operations on the same operands in the same order as the C++ form (lk_lerp / lk_accum): same bits.
 // The quads are v[72:75] / v[76:79]: the top of the 80-register budget of a 256-thread workgroup at 6 waves per SIMD.
+// the two record quads: the top eight registers of the kernel's budget (80 at 6 waves per SIMD; OFPS_LK_WAVES4 = 7: 72)
+#ifndef OFPS_LK_WAVES4
+#define OFPS_LK_WAVES4 6
+#endif
+#if OFPS_LK_WAVES4 >= 7
+#define LK_QE "v[64:67]"
+#define LK_QE0 "v64"
+#define LK_QE1 "v65"
+#define LK_QE2 "v66"
+#define LK_QO "v[68:71]"
+#define LK_QO0 "v68"
+#define LK_QO1 "v69"
+#define LK_QO2 "v70"
+#define LK_Q_CLOBBERS "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71"
+#else
+#define LK_QE "v[72:75]"
+#define LK_QE0 "v72"
+#define LK_QE1 "v73"
+#define LK_QE2 "v74"
+#define LK_QO "v[76:79]"
+#define LK_QO0 "v76"
+#define LK_QO1 "v77"
+#define LK_QO2 "v78"
+#define LK_Q_CLOBBERS LK_QE0, LK_QE1, LK_QE2, "v75", LK_QO0, LK_QO1, LK_QO2, "v79"
+#endif
 #define LK_ROW9_TAP(K, KN, WAIT, NEXT)                                        \
     "v_sub_f32 %[tmp], %[l" #KN "], %[l" #K "]\n\t"                             \
     "v_fmac_f32 %[l" #K "], %[a" #K "], %[tmp]\n\t"                             \
@@ -598,28 +623,28 @@ __device__ __forceinline__ void lk_row9_asm(float (&r)[19], const float (&a)[9],
         "ds_read_b32 %[l7], %[ja] offset:28\n\t"
         "ds_read_b32 %[l8], %[ja] offset:32\n\t"
         "ds_read_b32 %[l9], %[ja] offset:36\n\t"
-        "ds_read_b128 v[72:75], %[ta]\n\t"
-        "ds_read_b128 v[76:79], %[ta] offset:16\n\t"
+        "ds_read_b128 " LK_QE ", %[ta]\n\t"
+        "ds_read_b128 " LK_QO ", %[ta] offset:16\n\t"
         "s_waitcnt lgkmcnt(10)\n\t"                                            // l0, l1 are there
         // tap k: horizontal + vertical interpolation while its tile record is in flight, then the residual sums; the quad
         // it used is refilled with tap k + 2's record.  Waits: 12 reads issued; before tap k's first use of l[k+1] at most
         // 10 - k of the texel reads ... may be outstanding behind the two tile reads (counted below per tap).
-        LK_ROW9_TAP(0, 1, 1, "") LK_ROW9_USE(0, "v72", "v73", "v74", "ds_read_b128 v[72:75], %[ta] offset:32\n\t")
-        LK_ROW9_TAP(1, 2, 1, "") LK_ROW9_USE(1, "v76", "v77", "v78", "ds_read_b128 v[76:79], %[ta] offset:48\n\t")
-        LK_ROW9_TAP(2, 3, 1, "") LK_ROW9_USE(2, "v72", "v73", "v74", "ds_read_b128 v[72:75], %[ta] offset:64\n\t")
-        LK_ROW9_TAP(3, 4, 1, "") LK_ROW9_USE(3, "v76", "v77", "v78", "ds_read_b128 v[76:79], %[ta] offset:80\n\t")
-        LK_ROW9_TAP(4, 5, 1, "") LK_ROW9_USE(4, "v72", "v73", "v74", "ds_read_b128 v[72:75], %[ta] offset:96\n\t")
-        LK_ROW9_TAP(5, 6, 1, "") LK_ROW9_USE(5, "v76", "v77", "v78", "ds_read_b128 v[76:79], %[ta] offset:112\n\t")
-        LK_ROW9_TAP(6, 7, 1, "") LK_ROW9_USE(6, "v72", "v73", "v74", "ds_read_b128 v[72:75], %[ta] offset:128\n\t")
-        LK_ROW9_TAP(7, 8, 1, "") LK_ROW9_USE(7, "v76", "v77", "v78", "")
-        LK_ROW9_TAP(8, 9, 0, "") LK_ROW9_USE(8, "v72", "v73", "v74", "")
+        LK_ROW9_TAP(0, 1, 1, "") LK_ROW9_USE(0, LK_QE0, LK_QE1, LK_QE2, "ds_read_b128 " LK_QE ", %[ta] offset:32\n\t")
+        LK_ROW9_TAP(1, 2, 1, "") LK_ROW9_USE(1, LK_QO0, LK_QO1, LK_QO2, "ds_read_b128 " LK_QO ", %[ta] offset:48\n\t")
+        LK_ROW9_TAP(2, 3, 1, "") LK_ROW9_USE(2, LK_QE0, LK_QE1, LK_QE2, "ds_read_b128 " LK_QE ", %[ta] offset:64\n\t")
+        LK_ROW9_TAP(3, 4, 1, "") LK_ROW9_USE(3, LK_QO0, LK_QO1, LK_QO2, "ds_read_b128 " LK_QO ", %[ta] offset:80\n\t")
+        LK_ROW9_TAP(4, 5, 1, "") LK_ROW9_USE(4, LK_QE0, LK_QE1, LK_QE2, "ds_read_b128 " LK_QE ", %[ta] offset:96\n\t")
+        LK_ROW9_TAP(5, 6, 1, "") LK_ROW9_USE(5, LK_QO0, LK_QO1, LK_QO2, "ds_read_b128 " LK_QO ", %[ta] offset:112\n\t")
+        LK_ROW9_TAP(6, 7, 1, "") LK_ROW9_USE(6, LK_QE0, LK_QE1, LK_QE2, "ds_read_b128 " LK_QE ", %[ta] offset:128\n\t")
+        LK_ROW9_TAP(7, 8, 1, "") LK_ROW9_USE(7, LK_QO0, LK_QO1, LK_QO2, "")
+        LK_ROW9_TAP(8, 9, 0, "") LK_ROW9_USE(8, LK_QE0, LK_QE1, LK_QE2, "")
         : [l0] "=&v"(r[L(0)]), [l1] "=&v"(r[L(1)]), [l2] "=&v"(r[L(2)]), [l3] "=&v"(r[L(3)]), [l4] "=&v"(r[L(4)]), [l5] "=&v"(r[L(5)]),
           [l6] "=&v"(r[L(6)]), [l7] "=&v"(r[L(7)]), [l8] "=&v"(r[L(8)]), [l9] "=&v"(r[L(9)]),
           [t0] "+v"(r[T(0)]), [t1] "+v"(r[T(1)]), [t2] "+v"(r[T(2)]), [t3] "+v"(r[T(3)]), [t4] "+v"(r[T(4)]), [t5] "+v"(r[T(5)]),
           [t6] "+v"(r[T(6)]), [t7] "+v"(r[T(7)]), [t8] "+v"(r[T(8)]), [bx] "+v"(bx), [by] "+v"(by), [tmp] "=&v"(tmp)
         : [a0] "v"(a[0]), [a1] "v"(a[1]), [a2] "v"(a[2]), [a3] "v"(a[3]), [a4] "v"(a[4]), [a5] "v"(a[5]), [a6] "v"(a[6]), [a7] "v"(a[7]),
           [a8] "v"(a[8]), [ay] "v"(ay), [ja] "v"(jaddr), [ta] "v"(taddr)
-        : "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "memory");
+        : LK_Q_CLOBBERS, "memory");
 }
 // lk_row9_asm with the structure-tensor sums (first step of a level).
 // r[0..18] are the two register sets: PARITY 0: l = r[0..9], t = r[10..18]; PARITY 1: l = r[10..18] + r[9], t = r[0..8] --
@@ -642,28 +667,28 @@ __device__ __forceinline__ void lk_row9_asm_g(float (&r)[19], const float (&a)[9
         "ds_read_b32 %[l7], %[ja] offset:28\n\t"
         "ds_read_b32 %[l8], %[ja] offset:32\n\t"
         "ds_read_b32 %[l9], %[ja] offset:36\n\t"
-        "ds_read_b128 v[72:75], %[ta]\n\t"
-        "ds_read_b128 v[76:79], %[ta] offset:16\n\t"
+        "ds_read_b128 " LK_QE ", %[ta]\n\t"
+        "ds_read_b128 " LK_QO ", %[ta] offset:16\n\t"
         "s_waitcnt lgkmcnt(10)\n\t"                                            // l0, l1 are there
         // tap k: horizontal + vertical interpolation while its tile record is in flight, then the residual sums; the quad
         // it used is refilled with tap k + 2's record.  Waits: 12 reads issued; before tap k's first use of l[k+1] at most
         // 10 - k of the texel reads ... may be outstanding behind the two tile reads (counted below per tap).
-        LK_ROW9_TAP(0, 1, 1, "") LK_ROW9_USE_G(0, "v72", "v73", "v74", "ds_read_b128 v[72:75], %[ta] offset:32\n\t")
-        LK_ROW9_TAP(1, 2, 1, "") LK_ROW9_USE_G(1, "v76", "v77", "v78", "ds_read_b128 v[76:79], %[ta] offset:48\n\t")
-        LK_ROW9_TAP(2, 3, 1, "") LK_ROW9_USE_G(2, "v72", "v73", "v74", "ds_read_b128 v[72:75], %[ta] offset:64\n\t")
-        LK_ROW9_TAP(3, 4, 1, "") LK_ROW9_USE_G(3, "v76", "v77", "v78", "ds_read_b128 v[76:79], %[ta] offset:80\n\t")
-        LK_ROW9_TAP(4, 5, 1, "") LK_ROW9_USE_G(4, "v72", "v73", "v74", "ds_read_b128 v[72:75], %[ta] offset:96\n\t")
-        LK_ROW9_TAP(5, 6, 1, "") LK_ROW9_USE_G(5, "v76", "v77", "v78", "ds_read_b128 v[76:79], %[ta] offset:112\n\t")
-        LK_ROW9_TAP(6, 7, 1, "") LK_ROW9_USE_G(6, "v72", "v73", "v74", "ds_read_b128 v[72:75], %[ta] offset:128\n\t")
-        LK_ROW9_TAP(7, 8, 1, "") LK_ROW9_USE_G(7, "v76", "v77", "v78", "")
-        LK_ROW9_TAP(8, 9, 0, "") LK_ROW9_USE_G(8, "v72", "v73", "v74", "")
+        LK_ROW9_TAP(0, 1, 1, "") LK_ROW9_USE_G(0, LK_QE0, LK_QE1, LK_QE2, "ds_read_b128 " LK_QE ", %[ta] offset:32\n\t")
+        LK_ROW9_TAP(1, 2, 1, "") LK_ROW9_USE_G(1, LK_QO0, LK_QO1, LK_QO2, "ds_read_b128 " LK_QO ", %[ta] offset:48\n\t")
+        LK_ROW9_TAP(2, 3, 1, "") LK_ROW9_USE_G(2, LK_QE0, LK_QE1, LK_QE2, "ds_read_b128 " LK_QE ", %[ta] offset:64\n\t")
+        LK_ROW9_TAP(3, 4, 1, "") LK_ROW9_USE_G(3, LK_QO0, LK_QO1, LK_QO2, "ds_read_b128 " LK_QO ", %[ta] offset:80\n\t")
+        LK_ROW9_TAP(4, 5, 1, "") LK_ROW9_USE_G(4, LK_QE0, LK_QE1, LK_QE2, "ds_read_b128 " LK_QE ", %[ta] offset:96\n\t")
+        LK_ROW9_TAP(5, 6, 1, "") LK_ROW9_USE_G(5, LK_QO0, LK_QO1, LK_QO2, "ds_read_b128 " LK_QO ", %[ta] offset:112\n\t")
+        LK_ROW9_TAP(6, 7, 1, "") LK_ROW9_USE_G(6, LK_QE0, LK_QE1, LK_QE2, "ds_read_b128 " LK_QE ", %[ta] offset:128\n\t")
+        LK_ROW9_TAP(7, 8, 1, "") LK_ROW9_USE_G(7, LK_QO0, LK_QO1, LK_QO2, "")
+        LK_ROW9_TAP(8, 9, 0, "") LK_ROW9_USE_G(8, LK_QE0, LK_QE1, LK_QE2, "")
         : [l0] "=&v"(r[L(0)]), [l1] "=&v"(r[L(1)]), [l2] "=&v"(r[L(2)]), [l3] "=&v"(r[L(3)]), [l4] "=&v"(r[L(4)]), [l5] "=&v"(r[L(5)]),
           [l6] "=&v"(r[L(6)]), [l7] "=&v"(r[L(7)]), [l8] "=&v"(r[L(8)]), [l9] "=&v"(r[L(9)]),
           [t0] "+v"(r[T(0)]), [t1] "+v"(r[T(1)]), [t2] "+v"(r[T(2)]), [t3] "+v"(r[T(3)]), [t4] "+v"(r[T(4)]), [t5] "+v"(r[T(5)]),
           [t6] "+v"(r[T(6)]), [t7] "+v"(r[T(7)]), [t8] "+v"(r[T(8)]), [bx] "+v"(bx), [by] "+v"(by), [gxx] "+v"(gxx), [gxy] "+v"(gxy), [gyy] "+v"(gyy), [tmp] "=&v"(tmp)
         : [a0] "v"(a[0]), [a1] "v"(a[1]), [a2] "v"(a[2]), [a3] "v"(a[3]), [a4] "v"(a[4]), [a5] "v"(a[5]), [a6] "v"(a[6]), [a7] "v"(a[7]),
           [a8] "v"(a[8]), [ay] "v"(ay), [ja] "v"(jaddr), [ta] "v"(taddr)
-        : "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "memory");
+        : LK_Q_CLOBBERS, "memory");
 }
 #undef LK_ROW9_TAP
 #undef LK_ROW9_USE
@@ -690,12 +715,12 @@ __device__ __forceinline__ void lk_rows9_asm(const float (&a)[9], float fy, floa
         asm volatile(LK_ROWS9_BODY_G
                      : LK_ROWS9_REGS, [bx] "+v"(bx), [by] "+v"(by), [gxx] "+v"(gxx), [gxy] "+v"(gxy), [gyy] "+v"(gyy)
                      : LK_ROWS9_INS
-                     : "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "memory");
+                     : LK_Q_CLOBBERS, "memory");
     } else {
         asm volatile(LK_ROWS9_BODY
                      : LK_ROWS9_REGS, [bx] "+v"(bx), [by] "+v"(by)
                      : LK_ROWS9_INS
-                     : "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "memory");
+                     : LK_Q_CLOBBERS, "memory");
     }
 #undef LK_ROWS9_REGS
 #undef LK_ROWS9_INS
@@ -716,7 +741,10 @@ struct LkStepShared {
     // rectangle a tile really needs is staged, so the capacity costs LDS space, not time.  Horizontally the capacity stops
     // where the row stride reaches 64 floats at radius 4 (a wider stride, e.g. 76 for +-32, costs 5 % on ordinary content:
     // measured 0.399 vs 0.380 ms); vertically it is only rows (+-16 px region jumps: 0.535 -> 0.475 ms)
-    static constexpr int SPREAD_X = 22, SPREAD_Y = 32, LW = T::TW + 1 + SPREAD_X, LH = T::TH + 1 + SPREAD_Y;
+#ifndef OFPS_LK_SPREAD_Y
+#define OFPS_LK_SPREAD_Y 32
+#endif
+    static constexpr int SPREAD_X = 22, SPREAD_Y = OFPS_LK_SPREAD_Y, LW = T::TW + 1 + SPREAD_X, LH = T::TH + 1 + SPREAD_Y;
     static constexpr int JS = (LW + 4) / 4 * 4;     // row stride in floats: a multiple of 4, so rows start 16-byte aligned
     // jl first: its reads are ds_read2_b32, whose two offsets are 8 bits of dwords -- at LDS offset 0 the N+1 texels of a
     // row are reachable from one address register, behind the tile each pair costs a v_add_u32
@@ -731,7 +759,10 @@ struct LkStepShared {
     // what the LDS footprint allows (160 KB per CU, 4 waves per workgroup): the register budget hipcc is held to
     // (radius 4 measured at 5 / 6 / 7 waves per SIMD: 0.396 / 0.380 / 0.411 ms -- 94 registers without spills, 80 with 3
     // spilled outside the row loop, 72 with 11)
-    static constexpr int WAVES_PER_SIMD = RADIUS <= 2 ? 8 : RADIUS <= 4 ? 6 : 4;
+#ifndef OFPS_LK_WAVES4
+#define OFPS_LK_WAVES4 6
+#endif
+    static constexpr int WAVES_PER_SIMD = RADIUS <= 2 ? 8 : RADIUS <= 4 ? OFPS_LK_WAVES4 : 4;
 };
 
 // integer sample origin of a window column / row: the oracle's floor + float clamp to [-1, lim]

@@ -347,6 +347,43 @@ def test_two_processes_contending_for_every_cu_never_see_a_nan(tmp_path):
     print(f"[two-process contention] in-kernel recoveries: {total_recoveries}")
 
 
+_LK_CONTEND_WORKER = r"""
+import json, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+from ofps_amd.runtime import HipContext
+fr = np.load(sys.argv[2]); want = np.load(sys.argv[3])
+ctx = HipContext(0)
+bad = 0
+for k in range(int(sys.argv[4])):
+    f = ctx.lk_flow(fr[0], fr[1], 3, 4, 3)
+    bad += int((f.view(np.uint32) != want.view(np.uint32)).any())
+print(json.dumps({"runs": int(sys.argv[4]), "mismatching_runs": bad}))
+"""
+
+
+@pytest.mark.gpu
+def test_two_processes_running_the_one_launch_pyramid_flow_get_the_oracles_bits(tmp_path):
+    """lk_levels_kernel runs the whole pyramid in one launch: a tile spins (bounded) until its parent tile of the coarser level --
+    a workgroup of the same launch -- has published its flows.  Two PROCESSES running 1080p flows back to back on one GPU share its
+    CUs, so each launch's workgroups become resident in whatever order the two launches interleave; whatever happens, every run of
+    either process returns the oracle's flow bit for bit (a spin that expired would show as a mismatch, not as a hang)."""
+    import sys
+    import oracle
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    fr = synth.luma_sequence(2, 1920, 1080, max_step=16, seed=synth.SEED0 + 91)       # region jumps: unfit tiles at level 0 too
+    np.save(tmp_path / "fr.npy", fr); np.save(tmp_path / "flow.npy", oracle.lk_flow(fr[0], fr[1], 3, 4, 3))
+    script = tmp_path / "worker.py"
+    script.write_text(_LK_CONTEND_WORKER)
+    procs = [subprocess.Popen([sys.executable, str(script), root, str(tmp_path / "fr.npy"), str(tmp_path / "flow.npy"), "40"],
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for _ in range(2)]
+    outs = [p.communicate(timeout=600) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-1500:]
+        r = json.loads(so.strip().splitlines()[-1])
+        assert r["runs"] == 40 and r["mismatching_runs"] == 0, r
+
+
 @pytest.mark.gpu
 def test_multi_extract_writes_the_same_mvec_as_the_single_decoder(tmp_path):
     """ofps_hip_multi_* behind the C++ host layer (MultiDeviceSad): three workers on the one GPU of the box split a clip's

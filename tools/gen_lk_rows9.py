@@ -18,7 +18,8 @@ load in flight), hence one block per step with immediate offsets for every addre
 The arithmetic is the per-row kernel's (lk_row9_asm): same operations on the same operands in the same order -> same bits.
 
 Register sets: r0..r18.  Row r has parity P = r & 1.  P = 0: l[k] = r[k] (k = 0..9), t[k] = r[10 + k]; P = 1: l[k] = r[10 + k]
-(k < 9), l[9] = r[9], t[k] = r[k].  Record quads: v[72:75] (even taps), v[76:79] (odd taps): the top of the 80-register budget.
+(k < 9), l[9] = r[9], t[k] = r[k].  Record quads: LK_QE (even taps), LK_QO (odd taps) -- string macros lk.hip defines: the top eight
+registers of the kernel's register budget (v[72:79] at 6 waves per SIMD).
 Every s_waitcnt count is derived below from the queue of reads in flight (LDS returns in issue order).
 """
 import os
@@ -66,8 +67,8 @@ def body(with_g: bool) -> str:
     up = [T(0, k) for k in range(9)] + ["%[r9]"]
     for k in range(10):
         e.read(("U", k), f"ds_read_b32 {up[k]}, %[ja] offset:{4 * k}")
-    e.read(("Q", 0, 0), "ds_read_b128 v[72:75], %[ta]")
-    e.read(("Q", 0, 1), "ds_read_b128 v[76:79], %[ta] offset:16")
+    e.read(("Q", 0, 0), 'ds_read_b128 " LK_QE ", %[ta]')
+    e.read(("Q", 0, 1), 'ds_read_b128 " LK_QO ", %[ta] offset:16')
     for k in range(9):                                    # (the lower texels are requested between the interpolations: lgkmcnt counts to 15)
         e.wait_for([("U", k), ("U", k + 1)])
         e.op(f"v_sub_f32 %[tmp], {up[k + 1]}, {up[k]}")
@@ -84,7 +85,7 @@ def body(with_g: bool) -> str:
             e.op("v_add_f32 %[ay], %[ay], %[fy]")
         e.op("v_fract_f32 %[ay], %[ay]")
         for k in range(N):
-            q = ("v72", "v73", "v74") if k % 2 == 0 else ("v76", "v77", "v78")
+            q = ('" LK_QE0 "', '" LK_QE1 "', '" LK_QE2 "') if k % 2 == 0 else ('" LK_QO0 "', '" LK_QO1 "', '" LK_QO2 "')
             e.wait_for([("X", r, k), ("X", r, k + 1)])
             e.op(f"v_sub_f32 %[tmp], {L(P, k + 1)}, {L(P, k)}")
             if k == 8 and not last:                      # l[9] (r9) has been read for the last time: row r + 1's tenth texel
@@ -103,7 +104,7 @@ def body(with_g: bool) -> str:
             else:
                 e.op(f"v_fmac_f32 %[bx], {q[1]}, %[tmp]")
                 e.op(f"v_fmac_f32 %[by], {q[2]}, %[tmp]")
-            quad = "v[72:75]" if k % 2 == 0 else "v[76:79]"
+            quad = '" LK_QE "' if k % 2 == 0 else '" LK_QO "'
             if k + 2 < N:                                # the quad this tap used: the record of tap k + 2
                 e.read(("Q", r, k + 2), f"ds_read_b128 {quad}, %[ta] offset:{r * TRB + 16 * (k + 2)}")
             elif not last:                               # taps 7, 8: row r + 1's records of taps 1, 0
