@@ -31,6 +31,9 @@ __device__ __forceinline__ int lk_clampi(int v, int lo, int hi) { return max(lo,
 #ifndef OFPS_LK_SPEC_FMA
 #define OFPS_LK_SPEC_FMA 1
 #endif
+#ifndef OFPS_LK_JS
+#define OFPS_LK_JS 64            // row pitch of the staged current-frame rectangle, floats
+#endif
 __device__ __forceinline__ float lk_lerp(float a, float b, float t) {
 #if OFPS_LK_SPEC_FMA
     return __builtin_fmaf(t, b - a, a);
@@ -745,7 +748,10 @@ struct LkStepShared {
 #define OFPS_LK_SPREAD_Y 32
 #endif
     static constexpr int SPREAD_X = 22, SPREAD_Y = OFPS_LK_SPREAD_Y, LW = T::TW + 1 + SPREAD_X, LH = T::TH + 1 + SPREAD_Y;
-    static constexpr int JS = (LW + 4) / 4 * 4;     // row stride in floats: a multiple of 4, so rows start 16-byte aligned
+    // row stride in floats: a multiple of 4, so rows start 16-byte aligned.  OFPS_LK_JS (64 or 68; lk_rows9.inc carries a body
+    // for each): at 64 -- the number of LDS banks -- two lanes that read the same column of different rows collide
+    static constexpr int JS = RADIUS == 4 ? OFPS_LK_JS : (LW + 4) / 4 * 4;
+    static_assert(JS >= (LW + 4) / 4 * 4, "row stride shorter than the rectangle");
     // jl first: its reads are ds_read2_b32, whose two offsets are 8 bits of dwords -- at LDS offset 0 the N+1 texels of a
     // row are reachable from one address register, behind the tile each pair costs a v_add_u32
     alignas(16) float jl[LH][JS];

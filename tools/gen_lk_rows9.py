@@ -24,7 +24,7 @@ Every s_waitcnt count is derived below from the queue of reads in flight (LDS re
 """
 import os
 
-JSB, TRB, N = 256, 640, 9
+JSB, TRB, N = 256, 640, 9          # JSB is overridden per generated variant (main)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -59,7 +59,9 @@ class Emit:
         self.queue = self.queue[max(idx) + 1:]          # everything up to the youngest needed read has landed
 
 
-def body(with_g: bool) -> str:
+def body(with_g: bool, jsb: int = 256) -> str:
+    global JSB
+    JSB = jsb
     e = Emit()
     e.op("s_waitcnt lgkmcnt(0)")                          # scalar loads the compiler may have in flight return out of order: none past here
     # ---- prologue: upper sample row of window row 0 -> its nine horizontal interpolations in row 0's t-set (P = 0: r10..r18),
@@ -117,14 +119,17 @@ def body(with_g: bool) -> str:
 
 def main():
     out = ['// GENERATED by tools/gen_lk_rows9.py -- do not edit.  See that file for the schedule and the derivation of every wait count.',
-           f'// JSB = {JSB} (jl[][] row pitch in bytes), TRB = {TRB} (tile[][] row pitch in bytes): lk.hip static_asserts both.',
-           '#define LK_ROWS9_JSB ' + str(JSB), '#define LK_ROWS9_TRB ' + str(TRB),
-           '#define LK_ROWS9_BODY \\', body(False).replace("\n", " \\\n"), '',
-           '#define LK_ROWS9_BODY_G \\', body(True).replace("\n", " \\\n"), '']
+           f'// TRB = {TRB} (tile[][] row pitch in bytes); one pair of bodies per jl[][] row pitch (OFPS_LK_JS floats): lk.hip static_asserts both.',
+           '#define LK_ROWS9_TRB ' + str(TRB)]
+    for k, js in enumerate((64,)):          # (68 was measured in round 4: more bank conflicts, 238 vs 221 us; profiles/r04/lk_lds_experiments.txt)
+        out += [('#if' if k == 0 else '#elif') + f' OFPS_LK_JS == {js}', f'#define LK_ROWS9_JSB {4 * js}',
+                '#define LK_ROWS9_BODY \\', body(False, 4 * js).replace("\n", " \\\n"), '',
+                '#define LK_ROWS9_BODY_G \\', body(True, 4 * js).replace("\n", " \\\n"), '']
+    out += ['#else', '#error "lk_rows9.inc has no body for this OFPS_LK_JS"', '#endif', '']
     path = os.path.join(ROOT, "ofps_amd", "csrc", "lk_rows9.inc")
     with open(path, "w") as f:
         f.write("\n".join(out))
-    print(path, sum(1 for ln in out[5].split("\n")), "lines per body")
+    print(path, len(out), "blocks")
 
 
 if __name__ == "__main__":

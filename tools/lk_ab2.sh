@@ -8,7 +8,7 @@ for FL in "$@"; do
   echo "=== '$FL'"
   python bench_legs.py cfg3_chain 2>/dev/null | python -c "
 import json,sys; d=json.load(sys.stdin)['cfg3_chain']; print('  leg', {k:(v['lk_ms'],v['chain_ms']) for k,v in d['per_content'].items()}, 'parity', d['parity_check']['ok'])"
-  (cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/ab_t /tmp/ab_w && timeout 120 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ab_t -o k -- python $GRAFT_REPO_ROOT/tools/prof_lk.py 20 > /dev/null 2>&1; timeout 120 rocprofv3 --pmc WRITE_SIZE SQ_INSTS_VALU SQ_WAVES --output-format csv -d /tmp/ab_w -o k -- python $GRAFT_REPO_ROOT/tools/prof_lk.py 10 > /dev/null 2>&1)
+  (cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/ab_t /tmp/ab_w && timeout 120 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ab_t -o k -- python $GRAFT_REPO_ROOT/tools/prof_lk.py 20 > /dev/null 2>&1; timeout 120 rocprofv3 --pmc WRITE_SIZE SQ_INSTS_VALU SQ_WAVES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d /tmp/ab_w -o k -- python $GRAFT_REPO_ROOT/tools/prof_lk.py 10 > /dev/null 2>&1)
   python - <<'PY'
 import csv, glob, collections
 f = glob.glob("/tmp/ab_t/**/*kernel_stats.csv", recursive=True)[0]
