@@ -127,6 +127,11 @@ int ofps_hip_lk_flow(ofps_hip_ctx* ctx, const uint8_t* prev, const uint8_t* cur,
  * sample, the residual sums and the structure tensor (the default), 1 = separate multiply and add (-DOFPS_LK_SPEC_FMA=0,
  * A/B builds).  The oracle exports the same number (orc_lk_spec_revision); the parity tests assert they agree. */
 int ofps_hip_lk_spec_revision(void);
+/* Diagnostics (synchronises): the flow runs its whole pyramid as ONE launch in which a tile waits -- bounded, ~0.3 s -- for its parent
+ * tile of the coarser level to publish its flows; a wait that expired (it cannot while workgroups are dispatched in block order) is
+ * counted here since the flag buffer was last allocated and makes that call's flows unspecified.  0 = every flow this context
+ * computed had all its dependencies.  The counterpart of ofps_hip_almeida_recoveries for the other spin-waiting kernel. */
+int ofps_hip_lk_wait_timeouts(ofps_hip_ctx* ctx, uint64_t* count);
 /* cv-decoder's contrast mask (cv-decoder/src/lib.rs:203-237): Sobel(gray, CV_32F, 1, 1, ksize 5) -> threshold(> 20)
  * -> dilate(MORPH_ELLIPSE 11x11); a pixel contributes a record only where the mask is set (:253-257).  Restated
  * from OpenCV's published definitions (oracle/ofps_oracle.c:orc_contrast_mask; "parity unpinned": OpenCV is not

@@ -857,7 +857,7 @@ template <int RADIUS, bool U8>
 __device__ __forceinline__ void lk_level_body(LkStepShared<RADIUS>& sh, const void* __restrict__ I_, const void* __restrict__ J_, int src_stride,
                                               int w, int h, int iters, const LkFlowIO io, unsigned long long* __restrict__ prof,
                                               int force_fall_arg, int tile_x, int tile_y, const uint32_t* parent_flag, uint32_t* done_flag,
-                                              uint32_t epoch) {
+                                              uint32_t epoch, uint32_t* timeouts) {
     // force_fall (libofps_hip_testhooks.so only; compiled out of the product library): low 4 bits = a step at which every
     // other tile is treated as not fitting, so that the grouped path in the middle of a level is exercised on inputs that
     // would never trigger it; bits 4.. = how many grouping rounds those tiles get (0 = the default kLkMaxRounds; 1 + n = n
@@ -901,6 +901,7 @@ __device__ __forceinline__ void lk_level_body(LkStepShared<RADIUS>& sh, const vo
                 if (v == epoch) break;
                 __builtin_amdgcn_s_sleep(16);
             } while (--budget);
+            if (!budget && timeouts) atomicAdd(timeouts, 1u);            // ofps_hip_lk_wait_timeouts reports it: never silent
         }
         __syncthreads();
     }
@@ -1360,9 +1361,9 @@ __global__ __launch_bounds__(256, LkStepShared<RADIUS>::WAVES_PER_SIMD) void lk_
     const uint32_t* parent = k > 0 ? A.flags + A.lv[k - 1].flag_off + (size_t)(ty / 2) * A.lv[k - 1].tiles_x + tx / 2 : nullptr;
     uint32_t* done = k < A.levels - 1 ? A.flags + L.flag_off + (size_t)ty * L.tiles_x + tx : nullptr;
     if (k == A.levels - 1)
-        lk_level_body<RADIUS, true>(sh, L.I, L.J, L.stride, L.w, L.h, A.iters, L.io, A.prof, A.force_fall, tx, ty, parent, done, A.epoch);
+        lk_level_body<RADIUS, true>(sh, L.I, L.J, L.stride, L.w, L.h, A.iters, L.io, A.prof, A.force_fall, tx, ty, parent, done, A.epoch, A.flags);
     else
-        lk_level_body<RADIUS, false>(sh, L.I, L.J, L.stride, L.w, L.h, A.iters, L.io, nullptr, A.force_fall, tx, ty, parent, done, A.epoch);
+        lk_level_body<RADIUS, false>(sh, L.I, L.J, L.stride, L.w, L.h, A.iters, L.io, nullptr, A.force_fall, tx, ty, parent, done, A.epoch, A.flags);
 }
 
 // cv-decoder/src/lib.rs:239-243,262-269: per-pixel records, raster order
@@ -1462,7 +1463,7 @@ int lk_flow_device(ofps_hip_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_cu
         // (every level its own plane: all levels are in flight together)
         LkLevelsArgs A{};
         A.levels = levels; A.iters = iters; A.force_fall = force_fall; A.prof = prof;
-        unsigned nb = 0, nflags = 0;
+        unsigned nb = 0, nflags = 2;                                  // word 0 of the flag buffer counts expired waits (ofps_hip_lk_wait_timeouts)
         for (int k = 0; k < levels; ++k) {                            // k = 0: the coarsest level
             const int l = levels - 1 - k;
             LkLevelArgs& L = A.lv[k];
@@ -1484,7 +1485,7 @@ int lk_flow_device(ofps_hip_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_cu
             io.nx = 1.0f / (float)W; io.ny = 1.0f / (float)H;
         }
         // tile flags carry the launch's epoch: no clearing between calls (zeroed when (re)allocated or when the counter wraps)
-        auto* flags = static_cast<uint32_t*>(scratch(ctx, S_WORK3, (size_t)(nflags ? nflags : 1) * sizeof(uint32_t)));
+        auto* flags = static_cast<uint32_t*>(scratch(ctx, S_WORK3, (size_t)nflags * sizeof(uint32_t)));
         if (!flags) return OFPS_HIP_ENOMEM;
         if (ctx->lk_flags_gen != ctx->scratch[S_WORK3].gen || ctx->lk_epoch == 0xFFFFFFFFu) {
             OFPS_HIP_TRY(ctx, hipMemsetAsync(flags, 0, ctx->scratch[S_WORK3].cap, s));
@@ -1544,6 +1545,19 @@ int lk_flow_device(ofps_hip_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_cu
 extern "C" {
 
 int ofps_hip_lk_spec_revision(void) { return OFPS_LK_SPEC_FMA ? 2 : 1; }
+
+int ofps_hip_lk_wait_timeouts(ofps_hip_ctx* ctx, uint64_t* count) {
+    if (!ctx || !count) return OFPS_HIP_EINVAL;
+    *count = 0;
+    const void* d = ctx->scratch[ofps::S_WORK3].p;
+    if (!d || !ctx->lk_flags_gen) return OFPS_HIP_OK;            // no pyramid launch on this context yet
+    OFPS_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    uint32_t v = 0;
+    OFPS_HIP_TRY(ctx, hipMemcpyAsync(&v, d, sizeof(v), hipMemcpyDeviceToHost, ctx->stream));
+    OFPS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    *count = v;
+    return OFPS_HIP_OK;
+}
 
 int ofps_hip_lk_flow_dev(ofps_hip_ctx* ctx, const void* d_prev, const void* d_cur, int W, int H, int stride, int levels,
                          int radius, int iters, void* d_out_flow, void* d_out_entries) {

@@ -147,6 +147,12 @@ class HipContext:
     def lk_spec_revision(self) -> int:
         return int(self._lib.ofps_hip_lk_spec_revision())
 
+    def lk_wait_timeouts(self) -> int:
+        """Expired parent-tile waits of the one-launch pyramid flow on this context (0 = none; diagnostics, synchronises)."""
+        n = C.c_uint64(0)
+        self._check(self._lib.ofps_hip_lk_wait_timeouts(self._h, C.byref(n)))
+        return int(n.value)
+
     def lk_flow_init(self, prev: np.ndarray, cur: np.ndarray, levels, radius, iters, init: np.ndarray):
         """ofps_hip_lk_flow_init_dev through library-owned device buffers: `init` [h_L, w_L, 2] is the coarsest level's
         starting flow.  -> flow[H, W, 2]."""

@@ -358,7 +358,7 @@ bad = 0
 for k in range(int(sys.argv[4])):
     f = ctx.lk_flow(fr[0], fr[1], 3, 4, 3)
     bad += int((f.view(np.uint32) != want.view(np.uint32)).any())
-print(json.dumps({"runs": int(sys.argv[4]), "mismatching_runs": bad}))
+print(json.dumps({"runs": int(sys.argv[4]), "mismatching_runs": bad, "wait_timeouts": ctx.lk_wait_timeouts()}))
 """
 
 
@@ -381,7 +381,7 @@ def test_two_processes_running_the_one_launch_pyramid_flow_get_the_oracles_bits(
     for p, (so, se) in zip(procs, outs):
         assert p.returncode == 0, se[-1500:]
         r = json.loads(so.strip().splitlines()[-1])
-        assert r["runs"] == 40 and r["mismatching_runs"] == 0, r
+        assert r["runs"] == 40 and r["mismatching_runs"] == 0 and r["wait_timeouts"] == 0, r
 
 
 @pytest.mark.gpu
