@@ -33,7 +33,7 @@ def _stale(out: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-# The parity tests' fault injectors (a withheld granule in the cluster Almeida solver, a forced hand-over in the LK level
+# The parity tests' fault injectors (a withheld granule in the cluster Almeida solver, a forced grouped path in the LK level
 # kernel) are compiled only into this second library; the product library refuses to arm them.
 LIB_HOOKS = os.path.join(HERE, "libofps_hip_testhooks.so")
 HOOKED = ("ctx", "almeida", "lk")            # translation units that look at OFPS_HIP_TEST_HOOKS

@@ -7,11 +7,13 @@
 // "Parity unpinned" w.r.t. the reference; bit-exact vs the build's own CPU restatement: every thread owns one
 // pixel and runs the oracle's loops in the oracle's order (f32, no FMA contraction, IEEE divide).
 //
-// Kernels per pyramid level: u8->f32 (level 0) / [1 4 6 4 1]/16 x [1 4 6 4 1]/16 downsample (both passes fused), central-difference
-// gradients of the previous frame, the 2x2 structure tensor G summed over the (2r+1)^2 window (once per
-// level: it does not depend on the flow), then ONE launch that runs all `iters` Gauss-Newton steps of the level
-// (b = sum grad * (I - J(q+flow)), flow += G^-1 b) with the previous frame's window and the flow kept on chip.
-// All of it is window/stencil work on f32 planes: L1/L2-resident reads, VALU-bound on the bilinear sampling -- no
+// Launches per frame pair (radius 2 / 4 / 6, the tiled path): ONE for levels 1 and 2 of both pyramids ([1 4 6 4 1]/16 x [1 4 6 4 1]/16
+// down-sampling straight from the u8 frames, lk_pyr12_kernel; further levels one launch each) and ONE for the whole pyramid of
+// Gauss-Newton steps (lk_levels_kernel): a 32 x 8 tile of a level is a workgroup that keeps the previous frame's window (I and its
+// central-difference gradients, made from the staged window), the flow and the 2x2 structure tensor G (summed by the level's first
+// step: it does not depend on the flow) on chip for all `iters` steps (b = sum grad * (I - J(q + flow)), flow += G^-1 b), and starts
+// when its parent tile of the next coarser level -- a workgroup of the same launch -- has published its flows.  Other radii take
+// the plain per-step kernels further down.  All of it is window/stencil work: LDS- and VALU-bound on the bilinear sampling -- no
 // contraction wide enough for MFMA (the normal equations are 2x2 per pixel).
 #include "common.hpp"
 
@@ -377,13 +379,12 @@ __global__ __launch_bounds__(256) void lk_step_kernel(const float* __restrict__ 
     flow_out[(size_t)y * w + x] = make_float2(f.x + du, f.y + dv);
 }
 
-// ---- tiled variants (compile-time radius).  A workgroup owns kTX x kTY = 32 x 8 pixels; the window planes (previous
-// frame and its gradients) are staged once in LDS with the oracle's coordinate clamping applied at staging
-// time, so tile[ly+dy+R][lx+dx+R] is exactly plane[clamp(y+dy)][clamp(x+dx)].  The bilinear fetches of the
-// current frame keep their per-lane indices (they depend on the flow) but reuse registers: inside a window row
-// j10 of column k is j00 of column k+1 whenever xb[k] == xa[k+1], and the bottom row of one window row is the
-// top row of the next whenever yb == next ya -- both almost always true; the rare exceptions reload.  Same
-// values, same operation order as the untiled kernels, hence the same bits; ~5x fewer L1 requests.
+// ---- tiled variants (compile-time radius).  A workgroup owns kTX x kTY = 32 x 8 pixels; the previous frame's window (I and
+// its gradients, one 16-byte record per element) is staged once in LDS with the oracle's coordinate clamping applied at
+// staging time, so tile[ly+dy+R][lx+dx+R] is exactly (I, gx, gy)[clamp(y+dy)][clamp(x+dx)]; the current frame's sample rectangle
+// is staged the same way, and inside a window the horizontal interpolation of a sample row serves two window rows (the
+// bottom row of one is the top row of the next whenever the rows are consecutive: almost always; the rare exceptions
+// recompute).  Same values, same operation order as the untiled kernels, hence the same bits.
 
 // pixels per workgroup of the tiled kernels (kTX * kTY = 256 threads; a wave covers 64 / kTX tile rows).  Measured at
 // 1080p, radius 4: 64 x 4 0.385 ms (0.58 on +-16 px region jumps), 32 x 8 0.38 (0.535), 16 x 16 0.43 (0.55): the squarer
@@ -732,11 +733,11 @@ __device__ __forceinline__ void lk_rows9_asm(const float (&a)[9], float fy, floa
 // Current-frame window in LDS.  The bilinear fetches J(q + flow(p)) of a workgroup land in the rectangle
 // [tile + window] shifted by the flows of its pixels; when those flows differ by at most SPREAD_X / SPREAD_Y pixels (almost every
 // tile) the rectangle fits jl[][] and is staged once, coordinates clamped at staging time exactly like the oracle
-// clamps xa/xb/ya/yb -- the inner loop then has no global loads at all.  Tiles with wilder flows, and tiles whose window
-// columns do not sample consecutive texels (left/right image border), need per-lane gathers with twice the registers;
-// they are NOT handled here: the main kernel (GENERAL = false, 57 VGPRs -> 6 waves per SIMD instead of 4) appends them
-// to a list and a small second launch (GENERAL = true) walks that list with the register-reuse global path.  Same
-// values, same operation order either way, hence the same bits.
+// clamps xa/xb/ya/yb -- the inner loop then has no global loads at all.  Tiles with wilder flows are taken in groups of pixels
+// whose boxes share a capacity-sized rectangle, and whatever no group takes reads the current frame from global memory
+// (lk_level_body); tiles whose window columns do not sample consecutive texels (left/right image border, windows across a
+// binade) read every column's own texel pair from the same rectangle.  Same values, same operation order either way,
+// hence the same bits.
 template <int RADIUS>
 struct LkStepShared {
     using T = LkTile<RADIUS>;

@@ -23,7 +23,7 @@ def ctx():
 
 @pytest.fixture(scope="module")
 def hooks_ctx():
-    """libofps_hip_testhooks.so: the build whose fault injectors / forced hand-overs can be armed."""
+    """libofps_hip_testhooks.so: the build whose fault injectors / forced rare paths can be armed."""
     from ofps_amd.runtime import HipContext
     c = HipContext(0, test_hooks=True)
     yield c
