@@ -708,10 +708,16 @@ template <bool WITH_G>
 __device__ __forceinline__ void lk_rows9_asm(const float (&a)[9], float fy, float yf0, float& bx, float& by, float& gxx, float& gxy,
                                              float& gyy, uint32_t ja, uint32_t ta) {
     float r0, r1, r2, r3, r4, r5, r6, r7, r8, r9, r10, r11, r12, r13, r14, r15, r16, r17, r18, tmp, ay;
+#ifdef OFPS_LK_X_DUMMY
+    float ay2;
+#define LK_ROWS9_X , [ay2] "=&v"(ay2)
+#else
+#define LK_ROWS9_X
+#endif
 #define LK_ROWS9_REGS                                                                                                             \
     [r0] "=&v"(r0), [r1] "=&v"(r1), [r2] "=&v"(r2), [r3] "=&v"(r3), [r4] "=&v"(r4), [r5] "=&v"(r5), [r6] "=&v"(r6), [r7] "=&v"(r7),  \
     [r8] "=&v"(r8), [r9] "=&v"(r9), [r10] "=&v"(r10), [r11] "=&v"(r11), [r12] "=&v"(r12), [r13] "=&v"(r13), [r14] "=&v"(r14),       \
-    [r15] "=&v"(r15), [r16] "=&v"(r16), [r17] "=&v"(r17), [r18] "=&v"(r18), [tmp] "=&v"(tmp), [ay] "=&v"(ay)
+    [r15] "=&v"(r15), [r16] "=&v"(r16), [r17] "=&v"(r17), [r18] "=&v"(r18), [tmp] "=&v"(tmp), [ay] "=&v"(ay) LK_ROWS9_X
 #define LK_ROWS9_INS                                                                                                              \
     [a0] "v"(a[0]), [a1] "v"(a[1]), [a2] "v"(a[2]), [a3] "v"(a[3]), [a4] "v"(a[4]), [a5] "v"(a[5]), [a6] "v"(a[6]), [a7] "v"(a[7]),    \
     [a8] "v"(a[8]), [fy] "v"(fy), [yf0] "v"(yf0), [ja] "v"(ja), [ta] "v"(ta)
@@ -719,12 +725,12 @@ __device__ __forceinline__ void lk_rows9_asm(const float (&a)[9], float fy, floa
         asm volatile(LK_ROWS9_BODY_G
                      : LK_ROWS9_REGS, [bx] "+v"(bx), [by] "+v"(by), [gxx] "+v"(gxx), [gxy] "+v"(gxy), [gyy] "+v"(gyy)
                      : LK_ROWS9_INS
-                     : LK_Q_CLOBBERS, "memory");
+                     : LK_ROWS9_CLOBBERS, "memory");
     } else {
         asm volatile(LK_ROWS9_BODY
                      : LK_ROWS9_REGS, [bx] "+v"(bx), [by] "+v"(by)
                      : LK_ROWS9_INS
-                     : LK_Q_CLOBBERS, "memory");
+                     : LK_ROWS9_CLOBBERS, "memory");
     }
 #undef LK_ROWS9_REGS
 #undef LK_ROWS9_INS

@@ -23,6 +23,18 @@ registers of the kernel's register budget (v[72:79] at 6 waves per SIMD).
 Every s_waitcnt count is derived below from the queue of reads in flight (LDS returns in issue order).
 """
 import os
+DUMMY = int(os.environ.get("LK_GEN_DUMMY", "0"))      # timing experiments only: that many extra full-rate VALU instructions per tap
+DUMMYQ = int(os.environ.get("LK_GEN_DUMMYQ", "0"))    # timing experiments only: extra ds_read_b128 per row into v[80:83] (96-register build)
+NQ = int(os.environ.get("LK_GEN_NQ", "2"))            # record quads in flight (2: v[72:79] at the 80-register budget)
+QB = int(os.environ.get("LK_GEN_QBASE", "72"))        # first register of the quads
+
+
+def QR(slot):
+    return f"v[{QB + 4 * slot}:{QB + 4 * slot + 3}]"
+
+
+def QC(slot, c):
+    return f"v{QB + 4 * slot + c}"
 
 JSB, TRB, N = 256, 640, 9          # JSB is overridden per generated variant (main)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -54,7 +66,7 @@ class Emit:
         if not idx:
             return
         n = len(self.queue) - 1 - max(idx)
-        assert 0 <= n <= 15, n
+        n = min(n, 15)                                   # (the counter has four bits: waiting for more than needed is safe)
         self.lines.append(f"s_waitcnt lgkmcnt({n})")
         self.queue = self.queue[max(idx) + 1:]          # everything up to the youngest needed read has landed
 
@@ -69,8 +81,8 @@ def body(with_g: bool, jsb: int = 256) -> str:
     up = [T(0, k) for k in range(9)] + ["%[r9]"]
     for k in range(10):
         e.read(("U", k), f"ds_read_b32 {up[k]}, %[ja] offset:{4 * k}")
-    e.read(("Q", 0, 0), 'ds_read_b128 " LK_QE ", %[ta]')
-    e.read(("Q", 0, 1), 'ds_read_b128 " LK_QO ", %[ta] offset:16')
+    for g in range(NQ):                                   # the first NQ records (taps are numbered 0..80 across the rows; tap g uses quad g % NQ)
+        e.read(("Q", g), f"ds_read_b128 {QR(g % NQ)}, %[ta] offset:{(g // N) * TRB + 16 * (g % N)}")
     for k in range(9):                                    # (the lower texels are requested between the interpolations: lgkmcnt counts to 15)
         e.wait_for([("U", k), ("U", k + 1)])
         e.op(f"v_sub_f32 %[tmp], {up[k + 1]}, {up[k]}")
@@ -87,7 +99,8 @@ def body(with_g: bool, jsb: int = 256) -> str:
             e.op("v_add_f32 %[ay], %[ay], %[fy]")
         e.op("v_fract_f32 %[ay], %[ay]")
         for k in range(N):
-            q = ('" LK_QE0 "', '" LK_QE1 "', '" LK_QE2 "') if k % 2 == 0 else ('" LK_QO0 "', '" LK_QO1 "', '" LK_QO2 "')
+            g = r * N + k
+            q = (QC(g % NQ, 0), QC(g % NQ, 1), QC(g % NQ, 2))
             e.wait_for([("X", r, k), ("X", r, k + 1)])
             e.op(f"v_sub_f32 %[tmp], {L(P, k + 1)}, {L(P, k)}")
             if k == 8 and not last:                      # l[9] (r9) has been read for the last time: row r + 1's tenth texel
@@ -95,7 +108,11 @@ def body(with_g: bool, jsb: int = 256) -> str:
             e.op(f"v_fmac_f32 {L(P, k)}, %[a{k}], %[tmp]")
             e.op(f"v_sub_f32 %[tmp], {L(P, k)}, {T(P, k)}")
             e.op(f"v_fmac_f32 {T(P, k)}, %[ay], %[tmp]")
-            e.wait_for([("Q", r, k)])
+            for _ in range(DUMMY):
+                e.op("v_mul_f32 %[ay2], %[fy], %[fy]")
+            if k < DUMMYQ:
+                e.read(("D", g), f"ds_read_b128 v[80:83], %[ta] offset:{r * TRB + 16 * k}")
+            e.wait_for([("Q", g)])
             e.op(f"v_sub_f32 %[tmp], {q[0]}, {T(P, k)}")
             if with_g:
                 e.op(f"v_fmac_f32 %[gxx], {q[1]}, {q[1]}")
@@ -106,11 +123,8 @@ def body(with_g: bool, jsb: int = 256) -> str:
             else:
                 e.op(f"v_fmac_f32 %[bx], {q[1]}, %[tmp]")
                 e.op(f"v_fmac_f32 %[by], {q[2]}, %[tmp]")
-            quad = '" LK_QE "' if k % 2 == 0 else '" LK_QO "'
-            if k + 2 < N:                                # the quad this tap used: the record of tap k + 2
-                e.read(("Q", r, k + 2), f"ds_read_b128 {quad}, %[ta] offset:{r * TRB + 16 * (k + 2)}")
-            elif not last:                               # taps 7, 8: row r + 1's records of taps 1, 0
-                e.read(("Q", r + 1, k - 7 + 1 if k == 7 else 0), f"ds_read_b128 {quad}, %[ta] offset:{(r + 1) * TRB + (16 if k == 7 else 0)}")
+            if g + NQ < N * N:                           # the quad this tap used: the record of tap g + NQ (the next row's first ones at a row's end)
+                e.read(("Q", g + NQ), f"ds_read_b128 {QR(g % NQ)}, %[ta] offset:{((g + NQ) // N) * TRB + 16 * ((g + NQ) % N)}")
             if not last:                                 # t[k] is dead: it is row r + 1's l[k]
                 e.read(("X", r + 1, k), f"ds_read_b32 {T(P, k)}, %[ja] offset:{(r + 2) * JSB + 4 * k}")
     e.op("s_waitcnt lgkmcnt(0)")
@@ -120,7 +134,9 @@ def body(with_g: bool, jsb: int = 256) -> str:
 def main():
     out = ['// GENERATED by tools/gen_lk_rows9.py -- do not edit.  See that file for the schedule and the derivation of every wait count.',
            f'// TRB = {TRB} (tile[][] row pitch in bytes); one pair of bodies per jl[][] row pitch (OFPS_LK_JS floats): lk.hip static_asserts both.',
-           '#define LK_ROWS9_TRB ' + str(TRB)]
+           '#define LK_ROWS9_TRB ' + str(TRB),
+           '#define LK_ROWS9_CLOBBERS ' + ", ".join(f'"v{QB + i}"' for i in range(4 * NQ)) + (', "v80", "v81", "v82", "v83"' if DUMMYQ else ""),
+           f'#define LK_ROWS9_TOP_REG {QB + 4 * NQ - 1}']
     for k, js in enumerate((64,)):          # (68 was measured in round 4: more bank conflicts, 238 vs 221 us; profiles/r04/lk_lds_experiments.txt)
         out += [('#if' if k == 0 else '#elif') + f' OFPS_LK_JS == {js}', f'#define LK_ROWS9_JSB {4 * js}',
                 '#define LK_ROWS9_BODY \\', body(False, 4 * js).replace("\n", " \\\n"), '',
