@@ -392,11 +392,23 @@ __global__ __launch_bounds__(256) void lk_step_kernel(const float* __restrict__ 
 // lose on the 16-byte staging rows.
 constexpr int kTX = 32, kTY = 8;
 constexpr int kJMargin = 2;          // pixels of slack staged around the current frame's rectangle (lk_level_body)
+// Pixels per thread (round 4, radius 4): a lane owns two vertically adjacent pixels, the tile is kTX x 2 kTY.  The second
+// pixel's window row r holds the records of the first one's row r + 1, so the ten record rows under the pair are read from LDS
+// once: 90 ds_read_b128 per pair and step instead of 162 -- the step's time follows the LDS cycles more than anything else
+// (profiles/r04/lk_lds_experiments.txt).  OFPS_LK_PP = 1 rebuilds the one-pixel kernel for A/B runs.
+#ifndef OFPS_LK_PP
+#define OFPS_LK_PP 1
+#endif
+template <int RADIUS>
+constexpr int kLkPP = (RADIUS == 4 && OFPS_LK_SPEC_FMA) ? OFPS_LK_PP : 1;
+static_assert(OFPS_LK_PP == 1 || OFPS_LK_PP == 2, "one or two pixels per thread");
 
 template <int RADIUS>
 struct LkTile {
-    static constexpr int R = RADIUS, N = 2 * RADIUS + 1, TW = kTX + 2 * RADIUS, TH = kTY + 2 * RADIUS;
+    static constexpr int R = RADIUS, N = 2 * RADIUS + 1, PP = kLkPP<RADIUS>, TY = kTY * PP, TW = kTX + 2 * RADIUS, TH = TY + 2 * RADIUS;
 };
+// rows of a tile of the tiled kernels at a run-time radius (host side: tile counts, flags)
+static inline int lk_tile_rows(int radius) { return radius == 4 ? LkTile<4>::TY : kTY; }
 
 // One whole 16-byte LDS read (ds_read_b128: 4 LDS cycles per wave).  Left to itself the compiler narrows a float4 read
 // whose .w is unused to ds_read_b96, which takes 8; an empty asm statement that "uses" .w keeps the read whole without
@@ -565,7 +577,17 @@ __device__ __forceinline__ void lk_stage3_u8_records(const float* scratch, float
 #ifndef OFPS_LK_WAVES4
 #define OFPS_LK_WAVES4 6
 #endif
-#if OFPS_LK_WAVES4 >= 7
+#if OFPS_LK_PP == 2                      // two pixels per thread: 4 waves per SIMD, 128 registers
+#define LK_QE "v[120:123]"
+#define LK_QE0 "v120"
+#define LK_QE1 "v121"
+#define LK_QE2 "v122"
+#define LK_QO "v[124:127]"
+#define LK_QO0 "v124"
+#define LK_QO1 "v125"
+#define LK_QO2 "v126"
+#define LK_Q_CLOBBERS LK_QE0, LK_QE1, LK_QE2, "v123", LK_QO0, LK_QO1, LK_QO2, "v127"
+#elif OFPS_LK_WAVES4 >= 7
 #define LK_QE "v[64:67]"
 #define LK_QE0 "v64"
 #define LK_QE1 "v65"
@@ -586,6 +608,8 @@ __device__ __forceinline__ void lk_stage3_u8_records(const float* scratch, float
 #define LK_QO2 "v78"
 #define LK_Q_CLOBBERS LK_QE0, LK_QE1, LK_QE2, "v75", LK_QO0, LK_QO1, LK_QO2, "v79"
 #endif
+#define LK_QUADS LK_QE, LK_QE0, LK_QE1, LK_QE2, LK_QO, LK_QO0, LK_QO1, LK_QO2
+#define LK_ROWS9_APPLY(M, ...) M(__VA_ARGS__)          // (LK_QUADS expands to the eight arguments before M is invoked)
 #define LK_ROW9_TAP(K, KN, WAIT, NEXT)                                        \
     "v_sub_f32 %[tmp], %[l" #KN "], %[l" #K "]\n\t"                             \
     "v_fmac_f32 %[l" #K "], %[a" #K "], %[tmp]\n\t"                             \
@@ -708,7 +732,7 @@ template <bool WITH_G>
 __device__ __forceinline__ void lk_rows9_asm(const float (&a)[9], float fy, float yf0, float& bx, float& by, float& gxx, float& gxy,
                                              float& gyy, uint32_t ja, uint32_t ta) {
     float r0, r1, r2, r3, r4, r5, r6, r7, r8, r9, r10, r11, r12, r13, r14, r15, r16, r17, r18, tmp, ay;
-#ifdef OFPS_LK_X_DUMMY
+#ifdef OFPS_LK_X_DUMMY                   // timing experiments (LK_GEN_DUMMY of the generator): a scratch register for the extra instructions
     float ay2;
 #define LK_ROWS9_X , [ay2] "=&v"(ay2)
 #else
@@ -722,15 +746,52 @@ __device__ __forceinline__ void lk_rows9_asm(const float (&a)[9], float fy, floa
     [a0] "v"(a[0]), [a1] "v"(a[1]), [a2] "v"(a[2]), [a3] "v"(a[3]), [a4] "v"(a[4]), [a5] "v"(a[5]), [a6] "v"(a[6]), [a7] "v"(a[7]),    \
     [a8] "v"(a[8]), [fy] "v"(fy), [yf0] "v"(yf0), [ja] "v"(ja), [ta] "v"(ta)
     if constexpr (WITH_G) {
-        asm volatile(LK_ROWS9_BODY_G
+        asm volatile(LK_ROWS9_APPLY(LK_ROWS9_BODY_G, LK_QUADS)
                      : LK_ROWS9_REGS, [bx] "+v"(bx), [by] "+v"(by), [gxx] "+v"(gxx), [gxy] "+v"(gxy), [gyy] "+v"(gyy)
                      : LK_ROWS9_INS
-                     : LK_ROWS9_CLOBBERS, "memory");
+                     : LK_Q_CLOBBERS, "memory");
     } else {
-        asm volatile(LK_ROWS9_BODY
+        asm volatile(LK_ROWS9_APPLY(LK_ROWS9_BODY, LK_QUADS)
                      : LK_ROWS9_REGS, [bx] "+v"(bx), [by] "+v"(by)
                      : LK_ROWS9_INS
-                     : LK_ROWS9_CLOBBERS, "memory");
+                     : LK_Q_CLOBBERS, "memory");
+    }
+#undef LK_ROWS9_REGS
+#undef LK_ROWS9_INS
+}
+
+// The same for the two pixels of a lane (A above B; LK_ROWS9_PAIR_BODY): the ten record rows under the pair are read once.
+//   a / b: the column fractions of A / B;  fy / fz: their flows' v;  yf0 = (float)(yA - R): B's row r has the fraction
+//   v_fract_f32((yf0 + (r + 1)) + fz), the oracle's sum for y = yA + 1;  ja / jb: LDS address of texel 0 of the upper sample
+//   row of each pixel's window row 0;  ta: of the record of A's window row 0, tap 0.  sums[0..4] = bx, by, gxx, gxy, gyy of A,
+//   sums[5..9] of B (the tensors only read and written WITH_G).
+template <bool WITH_G>
+__device__ __forceinline__ void lk_rows9_pair_asm(const float (&a)[9], const float (&b)[9], float fy, float fz, float yf0, float (&sums)[10],
+                                                  uint32_t ja, uint32_t jb, uint32_t ta) {
+    float r0, r1, r2, r3, r4, r5, r6, r7, r8, r9, r10, r11, r12, r13, r14, r15, r16, r17, r18, tmp, ay;
+    float s0, s1, s2, s3, s4, s5, s6, s7, s8, s9, s10, s11, s12, s13, s14, s15, s16, s17, s18, tmq, az;
+#define LK_ROWS9_REGS                                                                                                             \
+    [r0] "=&v"(r0), [r1] "=&v"(r1), [r2] "=&v"(r2), [r3] "=&v"(r3), [r4] "=&v"(r4), [r5] "=&v"(r5), [r6] "=&v"(r6), [r7] "=&v"(r7),  \
+    [r8] "=&v"(r8), [r9] "=&v"(r9), [r10] "=&v"(r10), [r11] "=&v"(r11), [r12] "=&v"(r12), [r13] "=&v"(r13), [r14] "=&v"(r14),       \
+    [r15] "=&v"(r15), [r16] "=&v"(r16), [r17] "=&v"(r17), [r18] "=&v"(r18), [tmp] "=&v"(tmp), [ay] "=&v"(ay),                       \
+    [s0] "=&v"(s0), [s1] "=&v"(s1), [s2] "=&v"(s2), [s3] "=&v"(s3), [s4] "=&v"(s4), [s5] "=&v"(s5), [s6] "=&v"(s6), [s7] "=&v"(s7),  \
+    [s8] "=&v"(s8), [s9] "=&v"(s9), [s10] "=&v"(s10), [s11] "=&v"(s11), [s12] "=&v"(s12), [s13] "=&v"(s13), [s14] "=&v"(s14),       \
+    [s15] "=&v"(s15), [s16] "=&v"(s16), [s17] "=&v"(s17), [s18] "=&v"(s18), [tmq] "=&v"(tmq), [az] "=&v"(az)
+#define LK_ROWS9_INS                                                                                                              \
+    [a0] "v"(a[0]), [a1] "v"(a[1]), [a2] "v"(a[2]), [a3] "v"(a[3]), [a4] "v"(a[4]), [a5] "v"(a[5]), [a6] "v"(a[6]), [a7] "v"(a[7]),    \
+    [a8] "v"(a[8]), [b0] "v"(b[0]), [b1] "v"(b[1]), [b2] "v"(b[2]), [b3] "v"(b[3]), [b4] "v"(b[4]), [b5] "v"(b[5]), [b6] "v"(b[6]),    \
+    [b7] "v"(b[7]), [b8] "v"(b[8]), [fy] "v"(fy), [fz] "v"(fz), [yf0] "v"(yf0), [ja] "v"(ja), [jb] "v"(jb), [ta] "v"(ta)
+    if constexpr (WITH_G) {
+        asm volatile(LK_ROWS9_APPLY(LK_ROWS9_PAIR_BODY_G, LK_QUADS)
+                     : LK_ROWS9_REGS, [bx] "+v"(sums[0]), [by] "+v"(sums[1]), [gxx] "+v"(sums[2]), [gxy] "+v"(sums[3]), [gyy] "+v"(sums[4]),
+                       [cx] "+v"(sums[5]), [cy] "+v"(sums[6]), [hxx] "+v"(sums[7]), [hxy] "+v"(sums[8]), [hyy] "+v"(sums[9])
+                     : LK_ROWS9_INS
+                     : LK_Q_CLOBBERS, "memory");
+    } else {
+        asm volatile(LK_ROWS9_APPLY(LK_ROWS9_PAIR_BODY, LK_QUADS)
+                     : LK_ROWS9_REGS, [bx] "+v"(sums[0]), [by] "+v"(sums[1]), [cx] "+v"(sums[5]), [cy] "+v"(sums[6])
+                     : LK_ROWS9_INS
+                     : LK_Q_CLOBBERS, "memory");
     }
 #undef LK_ROWS9_REGS
 #undef LK_ROWS9_INS
@@ -775,7 +836,8 @@ struct LkStepShared {
 #ifndef OFPS_LK_WAVES4
 #define OFPS_LK_WAVES4 6
 #endif
-    static constexpr int WAVES_PER_SIMD = RADIUS <= 2 ? 8 : RADIUS <= 4 ? OFPS_LK_WAVES4 : 4;
+    // (two pixels per thread: 35 KB of LDS per workgroup -> 4 workgroups per CU -> 128 registers)
+    static constexpr int WAVES_PER_SIMD = RADIUS <= 2 ? 8 : RADIUS <= 4 ? (T::PP == 2 ? 4 : OFPS_LK_WAVES4) : 4;
 };
 
 // integer sample origin of a window column / row: the oracle's floor + float clamp to [-1, lim]
@@ -883,13 +945,16 @@ __device__ __forceinline__ void lk_level_body(LkStepShared<RADIUS>& sh, const vo
     const int tiles_x = (w + kTX - 1) / kTX;
     OFPS_LK_STAMP(0);
     constexpr int N = T::N;
-    const int x0 = tile_x * kTX, y0 = tile_y * kTY;
+    constexpr int PP = T::PP;                                // pixels per lane: lane (lx, lq) owns tile rows PP lq ... PP lq + PP - 1
+    const int x0 = tile_x * kTX, y0 = tile_y * T::TY;
     using TIn = std::conditional_t<U8, uint8_t, float>;
     const float* J = static_cast<const float*>(J_);
     const uint8_t* J8 = static_cast<const uint8_t*>(J_);
-    const int lx = threadIdx.x % kTX, ly = threadIdx.x / kTX, px = x0 + lx, py = y0 + ly;
+    const int lx = threadIdx.x % kTX, ly = (threadIdx.x / kTX) * PP, px = x0 + lx, py = y0 + ly;     // the lane's first pixel
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const bool active = px < w && py < h;
+    bool active[PP];                                         // (a lane's second pixel is only active if its first one is)
+#pragma unroll
+    for (int p = 0; p < PP; ++p) active[p] = px < w && py + p < h;
     // the previous frame's window is requested first (it depends on nothing) and used after the first box exchange: its
     // latency runs beside the wait for the parent tile, the flow read, the column origins and the exchange
     LkU8Regs<RADIUS, TIn> u8g;
@@ -912,15 +977,21 @@ __device__ __forceinline__ void lk_level_body(LkStepShared<RADIUS>& sh, const vo
         }
         __syncthreads();
     }
-    float2 f = active ? lk_flow_read(io, px, py) : make_float2(0.0f, 0.0f);
+    float2 f[PP];
+#pragma unroll
+    for (int p = 0; p < PP; ++p) f[p] = active[p] ? lk_flow_read(io, px, py + p) : make_float2(0.0f, 0.0f);
     // The 2x2 structure tensor of the pixel's window does not depend on the flow: it is summed by the level's FIRST step, from
     // the very tile records that step reads for the residual (three fused multiply-adds per tap more, no LDS traffic of
     // its own), and stays in three registers for the later steps.
-    float gxx = 0.0f, gxy = 0.0f, gyy = 0.0f;
+    float gxx[PP], gxy[PP], gyy[PP];
+#pragma unroll
+    for (int p = 0; p < PP; ++p) gxx[p] = gxy[p] = gyy[p] = 0.0f;
     bool st_valid = false;                                   // the rectangle of the current frame held in jl[][] (uniform)
     int st_x0 = 0, st_x1 = -1, st_y0 = 0, st_y1 = -1, st_xs = 0;
-    int x = 0, y = 0;
-    bool cons_x = false, cons_y = false;                     // per lane: the window's columns / rows sample consecutive texels
+    int x = 0, y = 0;                                        // the lane's first pixel (remake_xy)
+    bool cons_x[PP], cons_y[PP];                             // per pixel: the window's columns / rows sample consecutive texels
+#pragma unroll
+    for (int p = 0; p < PP; ++p) cons_x[p] = cons_y[p] = false;
 #ifdef OFPS_LK_NO_FAST_ORIGINS                              // A/B: every tile takes the clamped, per-column origin chains
     constexpr bool kFastOrigins = false;
 #else
@@ -928,7 +999,7 @@ __device__ __forceinline__ void lk_level_body(LkStepShared<RADIUS>& sh, const vo
 #endif
     // uniform: no window column / row of this tile is clamped to the image
     const bool tile_in_x = kFastOrigins && x0 >= RADIUS && x0 + kTX - 1 + RADIUS <= w - 1;
-    const bool tile_in_y = kFastOrigins && y0 >= RADIUS && y0 + kTY - 1 + RADIUS <= h - 1;
+    const bool tile_in_y = kFastOrigins && y0 >= RADIUS && y0 + T::TY - 1 + RADIUS <= h - 1;
     // A pixel's sample box: origins of its first / last window column and row (the last + 1: the texel the interpolation also
     // reads), and whether its columns / rows sample consecutive texels.  Unclamped windows (interior tiles): the sums
     // fq_k = (x + k - R) + u grow with k, and while they are >= 0 so does their rounding step -- a sum that rounds up to an
@@ -937,11 +1008,11 @@ __device__ __forceinline__ void lk_level_body(LkStepShared<RADIUS>& sh, const vo
     // The lemma is about UNCLAMPED floors and lk_origin clamps to [-1, lim]: a last floor that reached lim may have been
     // clamped down to it (floors 1022, 1023, 1025, ..., 1031 across the 1024 binade at w = 1030 read as 1022 .. 1030), so
     // such windows count as not consecutive; a first floor below 0 likewise.
-    auto lane_box = [&](int xq, int yq, int& a0, int& a1, int& b0, int& b1, bool& cx, bool& cy) {
+    auto lane_box = [&](int xq, int yq, const float2 fl, int& a0, int& a1, int& b0, int& b1, bool& cx, bool& cy) {
         float dm;
         if (tile_in_x) {
-            a0 = lk_origin(xq - RADIUS, f.x, w, dm);
-            const int al = lk_origin(xq + RADIUS, f.x, w, dm);
+            a0 = lk_origin(xq - RADIUS, fl.x, w, dm);
+            const int al = lk_origin(xq + RADIUS, fl.x, w, dm);
             cx = a0 >= 0 && al < w && al - a0 == 2 * RADIUS;
             a1 = al + 1;
         } else {
@@ -949,7 +1020,7 @@ __device__ __forceinline__ void lk_level_body(LkStepShared<RADIUS>& sh, const vo
             cx = true;
 #pragma unroll
             for (int k = 0; k < N; ++k) {
-                const int o = lk_origin(lk_clampi(xq + k - RADIUS, 0, w - 1), f.x, w, dm);
+                const int o = lk_origin(lk_clampi(xq + k - RADIUS, 0, w - 1), fl.x, w, dm);
                 if (k > 0) cx = cx && (o == prev + 1);
                 if (k == 0) a0 = o;
                 al = o; prev = o;
@@ -957,14 +1028,14 @@ __device__ __forceinline__ void lk_level_body(LkStepShared<RADIUS>& sh, const vo
             a1 = al + 1;
         }
         if (tile_in_y) {
-            b0 = lk_origin(yq - RADIUS, f.y, h, dm);
-            const int bl = lk_origin(yq + RADIUS, f.y, h, dm);
+            b0 = lk_origin(yq - RADIUS, fl.y, h, dm);
+            const int bl = lk_origin(yq + RADIUS, fl.y, h, dm);
             cy = b0 >= 0 && bl < h && bl - b0 == 2 * RADIUS;
             b1 = bl + 1;
         } else {
             // window rows are monotone in r, so the extremes are the first and the last
-            b0 = lk_origin(lk_clampi(yq - RADIUS, 0, h - 1), f.y, h, dm);
-            b1 = lk_origin(lk_clampi(yq + RADIUS, 0, h - 1), f.y, h, dm) + 1;
+            b0 = lk_origin(lk_clampi(yq - RADIUS, 0, h - 1), fl.y, h, dm);
+            b1 = lk_origin(lk_clampi(yq + RADIUS, 0, h - 1), fl.y, h, dm) + 1;
             cy = false;
         }
     };
@@ -975,17 +1046,21 @@ __device__ __forceinline__ void lk_level_body(LkStepShared<RADIUS>& sh, const vo
     auto remake_xy = [&]() {
         int tidx = (int)threadIdx.x;
         asm volatile("" : "+v"(tidx));
-        x = x0 + tidx % kTX; y = y0 + tidx / kTX;
+        x = x0 + tidx % kTX; y = y0 + tidx / kTX * PP;
     };
     // The box exchange that opens a step: every wave's box of sample origins goes to sh.box (slots alternate with the step: a
     // step that reuses the staged rectangle has no second barrier, so a fast wave may write the next step's box while a slow
     // one still reads this step's).  The caller's barrier follows.
     auto box_exchange = [&](int it) {
         remake_xy();
-        int a0, a1, b0, b1;
-        lane_box(x, y, a0, a1, b0, b1, cons_x, cons_y);
-        int bx0 = active ? a0 : 0x7FFFFFFF, bx1 = active ? a1 : -0x7FFFFFFF;
-        int by0 = active ? b0 : 0x7FFFFFFF, by1 = active ? b1 : -0x7FFFFFFF;
+        int bx0 = 0x7FFFFFFF, bx1 = -0x7FFFFFFF, by0 = 0x7FFFFFFF, by1 = -0x7FFFFFFF;
+#pragma unroll
+        for (int p = 0; p < PP; ++p) {
+            int a0, a1, b0, b1;
+            lane_box(x, y + p, f[p], a0, a1, b0, b1, cons_x[p], cons_y[p]);
+            bx0 = active[p] ? min(bx0, a0) : bx0; bx1 = active[p] ? max(bx1, a1) : bx1;
+            by0 = active[p] ? min(by0, b0) : by0; by1 = active[p] ? max(by1, b1) : by1;
+        }
         lk_wave_box(bx0, bx1, by0, by1);
         if (lane == 0) { int* b = sh.box[it & 1][wave]; b[0] = bx0; b[1] = bx1; b[2] = by0; b[3] = by1; }
     };
@@ -1066,12 +1141,17 @@ __device__ __forceinline__ void lk_level_body(LkStepShared<RADIUS>& sh, const vo
         // The rows of one Gauss-Newton step for the lanes that call it (the members of the staged rectangle), ending with the flow
         // update: instantiated for the ordinary path (the whole tile) and once more inside the grouping rounds of an unfit tile,
         // so that nothing of the rare path is live across the ordinary one.
-        auto rows_and_solve = [&]() {
+        auto rows_one = [&](const int p) {
             const int xs = st_xs, ymin = st_y0;                          // origin of jl[][] in frame coordinates
+            // this pixel's state (p is uniform: selects, not indexed registers) -- written back at the end
+            const bool second = PP == 2 && p != 0;
+            float2 fl = second ? f[PP - 1] : f[0];
+            float g0 = second ? gxx[PP - 1] : gxx[0], g1 = second ? gxy[PP - 1] : gxy[0], g2 = second ? gyy[PP - 1] : gyy[0];
+            const int yp = y + p, lyp = ly + p;
             // wave-uniform: every member lane's window columns / rows sample consecutive texels
-            const bool all_cons = __all(cons_x);
+            const bool all_cons = __all(second ? cons_x[PP - 1] : cons_x[0]);
             const bool fast_x = tile_in_x && all_cons;
-            const bool fast_y = tile_in_y && __all(cons_y);
+            const bool fast_y = tile_in_y && __all(second ? cons_y[PP - 1] : cons_y[0]);
             float ax[N];
             int xi0;                                                     // origin of window column 0 (all the consecutive-column rows need)
             {
@@ -1084,14 +1164,14 @@ __device__ __forceinline__ void lk_level_body(LkStepShared<RADIUS>& sh, const vo
                     const float xf0 = (float)(xr - RADIUS);
 #pragma unroll
                     for (int k = 0; k < N; ++k) {
-                        const float fq = (xf0 + (float)k) + f.x;            // (float)(x + k - R), exact, + u: the oracle's sum
+                        const float fq = (xf0 + (float)k) + fl.x;            // (float)(x + k - R), exact, + u: the oracle's sum
                         ax[k] = __builtin_amdgcn_fractf(fq);
                         if (k == 0) xi0 = (int)__builtin_floorf(fq);
                     }
                 } else {
                     float frac;
 #pragma unroll
-                    for (int k = 0; k < N; ++k) { const int o = lk_origin(lk_clampi(xr + k - RADIUS, 0, w - 1), f.x, w, frac); ax[k] = frac; if (k == 0) xi0 = o; }
+                    for (int k = 0; k < N; ++k) { const int o = lk_origin(lk_clampi(xr + k - RADIUS, 0, w - 1), fl.x, w, frac); ax[k] = frac; if (k == 0) xi0 = o; }
                 }
             }
             // hup[k] = horizontal interpolation of the UPPER sample row at column k.  The lower row of one window row is the
@@ -1107,14 +1187,14 @@ __device__ __forceinline__ void lk_level_body(LkStepShared<RADIUS>& sh, const vo
                     // interior tile, every member's columns and rows consecutive (the ordinary case): all nine rows in one
                     // hand-scheduled block whose LDS reads are pipelined across the rows (lk_rows9_asm)
                     static_assert(S::JS * sizeof(float) == LK_ROWS9_JSB && T::TW * sizeof(float4) == LK_ROWS9_TRB, "lk_rows9.inc was generated for other pitches");
-                    int yr = y;
+                    int yr = yp;
                     asm volatile("" : "+v"(yr));
                     const float yf0 = (float)(yr - RADIUS);
-                    const int yi0 = (int)__builtin_floorf(yf0 + f.y) - ymin;
+                    const int yi0 = (int)__builtin_floorf(yf0 + fl.y) - ymin;
                     const uint32_t ja = (uint32_t)reinterpret_cast<uintptr_t>(&sh.jl[yi0][xi0 - xs]);
-                    const uint32_t ta = (uint32_t)reinterpret_cast<uintptr_t>(&sh.tile[ly][lx]);
-                    if (it == 0) lk_rows9_asm<true>(ax, f.y, yf0, bx, by, gxx, gxy, gyy, ja, ta);      // the level's first step also sums the structure tensor
-                    else lk_rows9_asm<false>(ax, f.y, yf0, bx, by, gxx, gxy, gyy, ja, ta);
+                    const uint32_t ta = (uint32_t)reinterpret_cast<uintptr_t>(&sh.tile[lyp][lx]);
+                    if (it == 0) lk_rows9_asm<true>(ax, fl.y, yf0, bx, by, g0, g1, g2, ja, ta);      // the level's first step also sums the structure tensor
+                    else lk_rows9_asm<false>(ax, fl.y, yf0, bx, by, g0, g1, g2, ja, ta);
                     done = true;
                 } else if (all_cons) {
                     // consecutive columns but clamped or irregular rows (top / bottom image border, flows that jump in y):
@@ -1123,11 +1203,11 @@ __device__ __forceinline__ void lk_level_body(LkStepShared<RADIUS>& sh, const vo
                     float rr[19];
                     int prev_yi = -0x7FFFFFFF;
                     const uint32_t jl0 = (uint32_t)reinterpret_cast<uintptr_t>(&sh.jl[0][xi0 - xs]);
-                    const uint32_t tl0 = (uint32_t)reinterpret_cast<uintptr_t>(&sh.tile[ly][lx]);
+                    const uint32_t tl0 = (uint32_t)reinterpret_cast<uintptr_t>(&sh.tile[lyp][lx]);
                     auto row = [&](int r, auto parity, auto with_g) {
                         constexpr int P = decltype(parity)::value;
                         float ay;
-                        const int yi = lk_origin(lk_clampi(y + r - RADIUS, 0, h - 1), f.y, h, ay) - ymin;
+                        const int yi = lk_origin(lk_clampi(yp + r - RADIUS, 0, h - 1), fl.y, h, ay) - ymin;
                         // (the first row always makes its upper sample row: stated at compile time, so that the carried
                         // registers are not live into the loop -- hipcc spilled their undefined contents around every step)
                         const bool reuse = r > 0 && __all(yi == prev_yi + 1);
@@ -1142,7 +1222,7 @@ __device__ __forceinline__ void lk_level_body(LkStepShared<RADIUS>& sh, const vo
                         }
                         const uint32_t ja = jl0 + (uint32_t)(yi + 1) * (uint32_t)(S::JS * sizeof(float));
                         const uint32_t ta = tl0 + (uint32_t)r * (uint32_t)(T::TW * sizeof(float4));
-                        if constexpr (decltype(with_g)::value) lk_row9_asm_g<P>(rr, ax, ay, bx, by, gxx, gxy, gyy, ja, ta);
+                        if constexpr (decltype(with_g)::value) lk_row9_asm_g<P>(rr, ax, ay, bx, by, g0, g1, g2, ja, ta);
                         else lk_row9_asm<P>(rr, ax, ay, bx, by, ja, ta);
                     };
                     using P0 = std::integral_constant<int, 0>; using P1 = std::integral_constant<int, 1>;
@@ -1169,7 +1249,7 @@ __device__ __forceinline__ void lk_level_body(LkStepShared<RADIUS>& sh, const vo
 #pragma unroll 1
                     for (int r = 0; r < N; ++r) {
                         float ay;
-                        const int yi = lk_origin(lk_clampi(y + r - RADIUS, 0, h - 1), f.y, h, ay) - ymin;
+                        const int yi = lk_origin(lk_clampi(yp + r - RADIUS, 0, h - 1), fl.y, h, ay) - ymin;
                         const bool reuse = __all(yi == prev_yi + 1);
                         prev_yi = yi;
                         if (!reuse) {
@@ -1186,11 +1266,11 @@ __device__ __forceinline__ void lk_level_body(LkStepShared<RADIUS>& sh, const vo
                         for (int k = 0; k < N; ++k) {
                             const float top = hup[k];
                             const float bot = lk_lerp(jb[k], jb[k + 1], ax[k]);
-                            const lk_f4 t = lk_lds_read4(&sh.tile[ly + r][lx + k]);
+                            const lk_f4 t = lk_lds_read4(&sh.tile[lyp + r][lx + k]);
                             const float d = t.x - lk_lerp(top, bot, ay);
                             lk_accum(t.y, d, bx);
                             lk_accum(t.z, d, by);
-                            if (it == 0) { lk_accum(t.y, t.y, gxx); lk_accum(t.y, t.z, gxy); lk_accum(t.z, t.z, gyy); }
+                            if (it == 0) { lk_accum(t.y, t.y, g0); lk_accum(t.y, t.z, g1); lk_accum(t.z, t.z, g2); }
                             hup[k] = bot;
                         }
                     }
@@ -1203,12 +1283,12 @@ __device__ __forceinline__ void lk_level_body(LkStepShared<RADIUS>& sh, const vo
                         asm volatile("" : "+v"(xr));
                         float frac;
 #pragma unroll
-                        for (int k = 0; k < N; ++k) xi[k] = lk_origin(lk_clampi(xr + k - RADIUS, 0, w - 1), f.x, w, frac) - xs;
+                        for (int k = 0; k < N; ++k) xi[k] = lk_origin(lk_clampi(xr + k - RADIUS, 0, w - 1), fl.x, w, frac) - xs;
                     }
 #pragma unroll 1
                     for (int r = 0; r < N; ++r) {
                         float ay;
-                        const int yi = lk_origin(lk_clampi(y + r - RADIUS, 0, h - 1), f.y, h, ay) - ymin;
+                        const int yi = lk_origin(lk_clampi(yp + r - RADIUS, 0, h - 1), fl.y, h, ay) - ymin;
                         const bool reuse = __all(yi == prev_yi + 1);
                         prev_yi = yi;
                         if (!reuse) {
@@ -1222,17 +1302,62 @@ __device__ __forceinline__ void lk_level_body(LkStepShared<RADIUS>& sh, const vo
                             const float j0 = rb[xi[k]], j1 = rb[xi[k] + 1];
                             const float top = hup[k];
                             const float bot = lk_lerp(j0, j1, ax[k]);
-                            const lk_f4 t = lk_lds_read4(&sh.tile[ly + r][lx + k]);
+                            const lk_f4 t = lk_lds_read4(&sh.tile[lyp + r][lx + k]);
                             const float d = t.x - lk_lerp(top, bot, ay);
                             lk_accum(t.y, d, bx);
                             lk_accum(t.z, d, by);
-                            if (it == 0) { lk_accum(t.y, t.y, gxx); lk_accum(t.y, t.z, gxy); lk_accum(t.z, t.z, gyy); }
+                            if (it == 0) { lk_accum(t.y, t.y, g0); lk_accum(t.y, t.z, g1); lk_accum(t.z, t.z, g2); }
                             hup[k] = bot;
                         }
                     }
                 }
             }
-            f = lk_solve(make_float4(gxx, gxy, gyy, 0.0f), f, bx, by);
+            fl = lk_solve(make_float4(g0, g1, g2, 0.0f), fl, bx, by);
+            if (second) { f[PP - 1] = fl; gxx[PP - 1] = g0; gxy[PP - 1] = g1; gyy[PP - 1] = g2; }
+            else { f[0] = fl; gxx[0] = g0; gxy[0] = g1; gyy[0] = g2; }
+        };
+        // The rows of one Gauss-Newton step for the member pixels m[] of the lanes that call it, ending with the flow update.
+        auto rows_and_solve = [&](const bool (&m)[PP]) {
+            if constexpr (PP == 2) {
+                // interior tile, both pixels of every lane here are members with consecutive columns and rows (the ordinary case):
+                // the two-pixel block -- the ten record rows under the pair are read once (lk_rows9_pair_asm)
+                const bool pair_lane = m[0] && m[1] && cons_x[0] && cons_x[1] && cons_y[0] && cons_y[1];
+                if (tile_in_x && tile_in_y && __all(pair_lane)) {
+                    static_assert(S::JS * sizeof(float) == LK_ROWS9_JSB && T::TW * sizeof(float4) == LK_ROWS9_TRB, "lk_rows9.inc was generated for other pitches");
+                    const int xs = st_xs, ymin = st_y0;
+                    int xr = x, yr = y;
+                    asm volatile("" : "+v"(xr), "+v"(yr));                // opaque: evaluated here, not kept alive from the box exchange
+                    // (the single-pixel path's expressions: rows_one)
+                    const float xf0 = (float)(xr - RADIUS), yf0 = (float)(yr - RADIUS);
+                    float axa[N], axb[N];
+                    int xia = 0, xib = 0;
+#pragma unroll
+                    for (int k = 0; k < N; ++k) {
+                        const float fa = (xf0 + (float)k) + f[0].x, fb = (xf0 + (float)k) + f[PP - 1].x;
+                        axa[k] = __builtin_amdgcn_fractf(fa); axb[k] = __builtin_amdgcn_fractf(fb);
+                        if (k == 0) { xia = (int)__builtin_floorf(fa); xib = (int)__builtin_floorf(fb); }
+                    }
+                    const int yia = (int)__builtin_floorf(yf0 + f[0].y) - ymin;
+                    const int yib = (int)__builtin_floorf((yf0 + 1.0f) + f[PP - 1].y) - ymin;        // (float)(y + 1 - R) = yf0 + 1, exact
+                    const uint32_t ja = (uint32_t)reinterpret_cast<uintptr_t>(&sh.jl[yia][xia - xs]);
+                    const uint32_t jb = (uint32_t)reinterpret_cast<uintptr_t>(&sh.jl[yib][xib - xs]);
+                    const uint32_t ta = (uint32_t)reinterpret_cast<uintptr_t>(&sh.tile[ly][lx]);
+                    float sums[10] = {0.0f, 0.0f, gxx[0], gxy[0], gyy[0], 0.0f, 0.0f, gxx[PP - 1], gxy[PP - 1], gyy[PP - 1]};
+                    if (it == 0) {                                        // the level's first step also sums the structure tensors
+                        lk_rows9_pair_asm<true>(axa, axb, f[0].y, f[PP - 1].y, yf0, sums, ja, jb, ta);
+                        gxx[0] = sums[2]; gxy[0] = sums[3]; gyy[0] = sums[4]; gxx[PP - 1] = sums[7]; gxy[PP - 1] = sums[8]; gyy[PP - 1] = sums[9];
+                    } else {
+                        lk_rows9_pair_asm<false>(axa, axb, f[0].y, f[PP - 1].y, yf0, sums, ja, jb, ta);
+                    }
+                    f[0] = lk_solve(make_float4(gxx[0], gxy[0], gyy[0], 0.0f), f[0], sums[0], sums[1]);
+                    f[PP - 1] = lk_solve(make_float4(gxx[PP - 1], gxy[PP - 1], gyy[PP - 1], 0.0f), f[PP - 1], sums[5], sums[6]);
+                    return;
+                }
+            }
+#pragma unroll 1
+            for (int p = 0; p < PP; ++p) {
+                if (p ? m[PP - 1] : m[0]) rows_one(p);
+            }
         };
         if (__builtin_expect(fits, 1)) {                                     // uniform: box[] is the same for every thread.  (expect: the register
             // allocator must keep the rare path's spills inside the rare path, not in front of the branch)
@@ -1249,24 +1374,30 @@ __device__ __forceinline__ void lk_level_body(LkStepShared<RADIUS>& sh, const vo
                 __syncthreads();
             }
             if (it == 0) OFPS_LK_STAMP(3);
-            if (active) rows_and_solve();
+            if (active[0]) rows_and_solve(active);
         } else {
             // ---- a tile whose sample rectangle does not fit: its pixels in groups, at most max_rounds of them
-            bool pending = active;
+            bool pending[PP];
+#pragma unroll
+            for (int p = 0; p < PP; ++p) pending[p] = active[p];
             st_valid = false;                                                // whatever jl[][] holds after this step is not the tile's rectangle
 #pragma unroll 1
             for (int round = 0; round < max_rounds; ++round) {
-                // anchor of this round: the first pending pixel of the first wave that has one.  Its box is made again here (kept
-                // alive across the rows it would be four more registers around the hot loop of every tile).
+                // anchor of this round: the first pending pixel of the first wave that has one.  The boxes are made again here (kept
+                // alive across the rows they would be four more registers per pixel around the hot loop of every tile).
                 remake_xy();
-                int a0, a1, b0, b1;
+                int a0[PP], a1[PP], b0[PP], b1[PP];
                 bool c1, c2;
-                lane_box(x, y, a0, a1, b0, b1, c1, c2);
+#pragma unroll
+                for (int p = 0; p < PP; ++p) lane_box(x, y + p, f[p], a0[p], a1[p], b0[p], b1[p], c1, c2);
+                const bool lane_pending = pending[0] || pending[PP - 1];
+                const bool first = pending[0];                               // the lane's first pending pixel is its first one
                 int* an = sh.anchor[round & 1][wave];
-                const bool any_pending = __any(pending);
+                const bool any_pending = __any(lane_pending);
                 if (lane == 0) an[0] = any_pending ? 1 : 0;
-                if (pending) {                                               // the first active lane is the first pending one; every pending lane stores its numbers
-                    an[1] = uni(a0); an[2] = uni(a1); an[3] = uni(b0); an[4] = uni(b1);
+                if (lane_pending) {                                          // the first active lane is the first pending one; every pending lane stores its numbers
+                    an[1] = uni(first ? a0[0] : a0[PP - 1]); an[2] = uni(first ? a1[0] : a1[PP - 1]);
+                    an[3] = uni(first ? b0[0] : b0[PP - 1]); an[4] = uni(first ? b1[0] : b1[PP - 1]);
                 }
                 __syncthreads();                                             // also: the previous round's members are done reading jl[]
                 const int (*aq)[8] = sh.anchor[round & 1];
@@ -1278,49 +1409,66 @@ __device__ __forceinline__ void lk_level_body(LkStepShared<RADIUS>& sh, const vo
                 // 16-byte staging applies (a pixel's box is at most 2R + 2 wide and high: the anchor itself always fits)
                 const int rx0 = (A0 - (S::LW - 4 - (A1 - A0 + 1)) / 2) & ~3, rx1 = rx0 + S::LW - 1;
                 const int ry0 = B0 - (S::LH - (B1 - B0 + 1)) / 2, ry1 = ry0 + S::LH - 1;
-                const bool member = pending && a0 >= rx0 && a1 <= rx1 && b0 >= ry0 && b1 <= ry1;
+                bool member[PP];
+#pragma unroll
+                for (int p = 0; p < PP; ++p) member[p] = pending[p] && a0[p] >= rx0 && a1[p] <= rx1 && b0[p] >= ry0 && b1[p] <= ry1;
                 stage_rect(rx0, rx1, ry0, ry1);
                 __syncthreads();
-                if (member) { rows_and_solve(); pending = false; }
+                if (member[0] || member[PP - 1]) {
+                    rows_and_solve(member);
+#pragma unroll
+                    for (int p = 0; p < PP; ++p) pending[p] = pending[p] && !member[p];
+                }
             }
-            if (pending) {
+#pragma unroll 1
+            for (int p = 0; p < PP; ++p) {
+                if (!(p ? pending[PP - 1] : pending[0])) continue;
                 // Leftover of a tile without coherent flows: the oracle's per-sample form for this pixel, the current frame read from
                 // global memory (two clamped texel pairs per tap), the previous frame's records from the tile.  Small and slow on
                 // purpose (it bounds the work of an incoherent tile at what the per-lane-gather kernel of rounds 2-3 cost); same
                 // operands, same operations, same order as every other path.
+                const bool second = PP == 2 && p != 0;
+                float2 fl = second ? f[PP - 1] : f[0];
+                float g0 = second ? gxx[PP - 1] : gxx[0], g1 = second ? gxy[PP - 1] : gxy[0], g2 = second ? gyy[PP - 1] : gyy[0];
                 float bx = 0.0f, by = 0.0f;
                 const int jpitch = U8 ? src_stride : w;
                 auto jat = [&](size_t idx) -> float { if constexpr (U8) return (float)J8[idx]; else return J[idx]; };
-                int xr = x, yr = y;
+                int xr = x, yr = y + p;
+                const int lyp = ly + p;
                 asm volatile("" : "+v"(xr), "+v"(yr));
     #pragma unroll 1
                 for (int r = 0; r < N; ++r) {
                     float ay;
-                    const int yi = lk_origin(lk_clampi(yr + r - RADIUS, 0, h - 1), f.y, h, ay);
+                    const int yi = lk_origin(lk_clampi(yr + r - RADIUS, 0, h - 1), fl.y, h, ay);
                     const size_t ra = (size_t)lk_clampi(yi, 0, h - 1) * jpitch, rb = (size_t)lk_clampi(yi + 1, 0, h - 1) * jpitch;
     #pragma unroll 1
                     for (int k = 0; k < N; ++k) {
                         float axk;
-                        const int xi = lk_origin(lk_clampi(xr + k - RADIUS, 0, w - 1), f.x, w, axk);
+                        const int xi = lk_origin(lk_clampi(xr + k - RADIUS, 0, w - 1), fl.x, w, axk);
                         const int xa = lk_clampi(xi, 0, w - 1), xb = lk_clampi(xi + 1, 0, w - 1);
                         const float top = lk_lerp(jat(ra + xa), jat(ra + xb), axk);
                         const float bot = lk_lerp(jat(rb + xa), jat(rb + xb), axk);
-                        const lk_f4 t = lk_lds_read4(&sh.tile[ly + r][lx + k]);
+                        const lk_f4 t = lk_lds_read4(&sh.tile[lyp + r][lx + k]);
                         const float d = t.x - lk_lerp(top, bot, ay);
                         lk_accum(t.y, d, bx);
                         lk_accum(t.z, d, by);
-                        if (it == 0) { lk_accum(t.y, t.y, gxx); lk_accum(t.y, t.z, gxy); lk_accum(t.z, t.z, gyy); }
+                        if (it == 0) { lk_accum(t.y, t.y, g0); lk_accum(t.y, t.z, g1); lk_accum(t.z, t.z, g2); }
                     }
                 }
-                f = lk_solve(make_float4(gxx, gxy, gyy, 0.0f), f, bx, by);
+                fl = lk_solve(make_float4(g0, g1, g2, 0.0f), fl, bx, by);
+                if (second) { f[PP - 1] = fl; gxx[PP - 1] = g0; gxy[PP - 1] = g1; gyy[PP - 1] = g2; }
+                else { f[0] = fl; gxx[0] = g0; gxy[0] = g1; gyy[0] = g2; }
             }
         }
         if (it == 0) OFPS_LK_STAMP(4);
     }
-    if (active) {
-        int tidx = (int)threadIdx.x;
-        asm volatile("" : "+v"(tidx));
-        lk_store(f, x0 + tidx % kTX, y0 + tidx / kTX, w, io);
+#pragma unroll
+    for (int p = 0; p < PP; ++p) {
+        if (active[p]) {
+            int tidx = (int)threadIdx.x;
+            asm volatile("" : "+v"(tidx));
+            lk_store(f[p], x0 + tidx % kTX, y0 + tidx / kTX * PP + p, w, io);
+        }
     }
     if (done_flag) {                                                     // uniform: children of this tile are waiting for it
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // this thread's write-through flow stores have been acknowledged
@@ -1415,7 +1563,8 @@ int lk_flow_device(ofps_hip_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_cu
     float2* fa = reinterpret_cast<float2*>(reinterpret_cast<float*>(Gp) + 4 * pyr);
     float2* fb = fa + plane0;
 
-    const size_t tiles0 = (size_t)((W + kTX - 1) / kTX) * (size_t)((H + kTY - 1) / kTY);     // tiles of the tiled kernels at level 0
+    const int tile_rows = lk_tile_rows(radius);
+    const size_t tiles0 = (size_t)((W + kTX - 1) / kTX) * (size_t)((H + tile_rows - 1) / tile_rows);     // tiles of the tiled kernels at level 0
     const bool tiled = radius == 2 || radius == 4 || radius == 6;      // kernels that run a whole level and fold the upsample / record passes in
     unsigned long long* prof = nullptr;                           // OFPS_HIP_LK_PROF=1: phase table of level 0
     if (tiled && ctx->opt.lk_prof) {
@@ -1478,7 +1627,7 @@ int lk_flow_device(ofps_hip_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_cu
             L.I = last ? (const void*)d_prev : (const void*)(Ip + off[l]);
             L.J = last ? (const void*)d_cur : (const void*)(Jp + off[l]);
             L.stride = last ? stride : ws[l]; L.w = ws[l]; L.h = hs[l];
-            L.tiles_x = (ws[l] + kTX - 1) / kTX; L.ntiles = L.tiles_x * ((hs[l] + kTY - 1) / kTY);
+            L.tiles_x = (ws[l] + kTX - 1) / kTX; L.ntiles = L.tiles_x * ((hs[l] + tile_rows - 1) / tile_rows);
             L.start = nb; L.count = ((unsigned)L.ntiles + 7u) / 8u * 8u; nb += L.count;
             L.flag_off = nflags; if (!last) nflags += (unsigned)L.ntiles;
             LkFlowIO& io = L.io;

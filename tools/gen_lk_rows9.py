@@ -24,17 +24,19 @@ Every s_waitcnt count is derived below from the queue of reads in flight (LDS re
 """
 import os
 DUMMY = int(os.environ.get("LK_GEN_DUMMY", "0"))      # timing experiments only: that many extra full-rate VALU instructions per tap
-DUMMYQ = int(os.environ.get("LK_GEN_DUMMYQ", "0"))    # timing experiments only: extra ds_read_b128 per row into v[80:83] (96-register build)
-NQ = int(os.environ.get("LK_GEN_NQ", "2"))            # record quads in flight (2: v[72:79] at the 80-register budget)
-QB = int(os.environ.get("LK_GEN_QBASE", "72"))        # first register of the quads
+NQ = 2                                                # record quads in flight.  (3, 4, 6 were measured in round 4 with fixed registers
+#                                                       v[72:95]: 228 / 225 / 229 us against 222 -- profiles/r04/lk_lds_experiments.txt)
 
 
-def QR(slot):
-    return f"v[{QB + 4 * slot}:{QB + 4 * slot + 3}]"
+def QR(slot):                                         # the bodies are function-like macros: lk.hip passes the quads' register names
+    return f'" Q{slot} "'                             # (the top eight registers of the kernel's budget, which depends on the build)
 
 
 def QC(slot, c):
-    return f"v{QB + 4 * slot + c}"
+    return f'" Q{slot}_{c} "'
+
+
+QARGS = ", ".join(f"Q{i}, Q{i}_0, Q{i}_1, Q{i}_2" for i in range(NQ))
 
 JSB, TRB, N = 256, 640, 9          # JSB is overridden per generated variant (main)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -110,8 +112,6 @@ def body(with_g: bool, jsb: int = 256) -> str:
             e.op(f"v_fmac_f32 {T(P, k)}, %[ay], %[tmp]")
             for _ in range(DUMMY):
                 e.op("v_mul_f32 %[ay2], %[fy], %[fy]")
-            if k < DUMMYQ:
-                e.read(("D", g), f"ds_read_b128 v[80:83], %[ta] offset:{r * TRB + 16 * k}")
             e.wait_for([("Q", g)])
             e.op(f"v_sub_f32 %[tmp], {q[0]}, {T(P, k)}")
             if with_g:
@@ -131,16 +131,130 @@ def body(with_g: bool, jsb: int = 256) -> str:
     return "\n".join(f'    "{ln}\\n\\t"' for ln in e.lines)
 
 
+class Stream:
+    """One pixel's operands inside the two-pixel block: register sets, fractions, sums, addresses -- named per stream."""
+
+    def __init__(self, tag, reg, a, tmp, ay, fy, ja, acc, yoff):
+        self.tag, self.reg, self.a, self.tmp, self.ay, self.fy, self.ja, self.acc, self.yoff = tag, reg, a, tmp, ay, fy, ja, acc, yoff
+
+    def L(self, P, k):
+        return f"%[{self.reg}{k}]" if P == 0 else (f"%[{self.reg}{10 + k}]" if k < 9 else f"%[{self.reg}9]")
+
+    def T(self, P, k):
+        return f"%[{self.reg}{10 + k}]" if P == 0 else f"%[{self.reg}{k}]"
+
+
+def body_pair(with_g: bool, jsb: int = 256) -> str:
+    """Two vertically adjacent pixels per lane (A above B): B's window row r reads the records of A's window row r + 1, so the ten
+    record rows R = 0..9 are read ONCE -- record (R, k) serves A's tap (R, k) and B's tap (R - 1, k): 90 ds_read_b128 for two
+    pixels instead of 162.  Each pixel keeps its own texel registers, fractions and sums (the current frame is sampled at ITS
+    flow); per pixel the operations and their order are the single-pixel block's.  B's first-row set-up (ten texels, nine
+    interpolations) rides in record row 0, where only A has taps."""
+    A = Stream("A", "r", "a", "%[tmp]", "%[ay]", "%[fy]", "%[ja]", ("%[bx]", "%[by]", "%[gxx]", "%[gxy]", "%[gyy]"), 0)
+    B = Stream("B", "s", "b", "%[tmq]", "%[az]", "%[fz]", "%[jb]", ("%[cx]", "%[cy]", "%[hxx]", "%[hxy]", "%[hyy]"), 1)
+    e = Emit()
+    e.op("s_waitcnt lgkmcnt(0)")
+
+    def upper(S, k):                                       # where the set-up keeps the upper sample row of window row 0
+        return S.T(0, k) if k < 9 else f"%[{S.reg}9]"
+
+    def issue_upper(S):
+        for k in range(10):
+            e.read(("U", S.tag, k), f"ds_read_b32 {upper(S, k)}, {S.ja} offset:{4 * k}")
+
+    def setup_piece(S, k):                                 # interpolation k of the first upper row; its register's successor read
+        e.wait_for([("U", S.tag, k), ("U", S.tag, k + 1)])
+        e.op(f"v_sub_f32 {S.tmp}, {upper(S, k + 1)}, {upper(S, k)}")
+        e.op(f"v_fmac_f32 {upper(S, k)}, %[{S.a}{k}], {S.tmp}")
+        e.read(("X", S.tag, 0, k), f"ds_read_b32 {S.L(0, k)}, {S.ja} offset:{jsb + 4 * k}")
+        if k == 8:
+            e.read(("X", S.tag, 0, 9), f"ds_read_b32 {S.L(0, 9)}, {S.ja} offset:{jsb + 36}")
+
+    def row_fraction(S, r):                                # v_fract_f32 of the oracle's sum ((float)(y + r - R)) + v; B's y is A's + 1
+        c = r + S.yoff
+        if c == 0:
+            e.op(f"v_add_f32 {S.ay}, %[yf0], {S.fy}")
+        else:
+            e.op(f"v_add_f32 {S.ay}, {float(c)}, %[yf0]")
+            e.op(f"v_add_f32 {S.ay}, {S.ay}, {S.fy}")
+        e.op(f"v_fract_f32 {S.ay}, {S.ay}")
+
+    def tap(S, r, k):
+        P = r & 1
+        e.wait_for([("X", S.tag, r, k), ("X", S.tag, r, k + 1)])
+        e.op(f"v_sub_f32 {S.tmp}, {S.L(P, k + 1)}, {S.L(P, k)}")
+        if k == 8 and r < N - 1:
+            e.read(("X", S.tag, r + 1, 9), f"ds_read_b32 %[{S.reg}9], {S.ja} offset:{(r + 2) * jsb + 36}")
+        e.op(f"v_fmac_f32 {S.L(P, k)}, %[{S.a}{k}], {S.tmp}")
+        e.op(f"v_sub_f32 {S.tmp}, {S.L(P, k)}, {S.T(P, k)}")
+        e.op(f"v_fmac_f32 {S.T(P, k)}, {S.ay}, {S.tmp}")
+
+    def use(S, r, k, q):
+        P = r & 1
+        bx, by, gxx, gxy, gyy = S.acc
+        e.op(f"v_sub_f32 {S.tmp}, {q[0]}, {S.T(P, k)}")
+        if with_g:
+            e.op(f"v_fmac_f32 {gxx}, {q[1]}, {q[1]}")
+            e.op(f"v_fmac_f32 {bx}, {q[1]}, {S.tmp}")
+            e.op(f"v_fmac_f32 {gxy}, {q[1]}, {q[2]}")
+            e.op(f"v_fmac_f32 {by}, {q[2]}, {S.tmp}")
+            e.op(f"v_fmac_f32 {gyy}, {q[2]}, {q[2]}")
+        else:
+            e.op(f"v_fmac_f32 {bx}, {q[1]}, {S.tmp}")
+            e.op(f"v_fmac_f32 {by}, {q[2]}, {S.tmp}")
+
+    def prefetch(S, r, k):                                 # t[k] of window row r is dead: it becomes row r + 1's l[k]
+        if r < N - 1:
+            e.read(("X", S.tag, r + 1, k), f"ds_read_b32 {S.T(r & 1, k)}, {S.ja} offset:{(r + 2) * jsb + 4 * k}")
+
+    NR = N + 1                                             # record rows
+    issue_upper(A)
+    for g in range(NQ):
+        e.read(("Q", g), f"ds_read_b128 {QR(g % NQ)}, %[ta] offset:{(g // N) * TRB + 16 * (g % N)}")
+    for k in range(9):
+        setup_piece(A, k)
+    issue_upper(B)
+    for R in range(NR):
+        if R < N:
+            row_fraction(A, R)
+        if R >= 1:
+            row_fraction(B, R - 1)
+        for k in range(N):
+            g = R * N + k
+            q = (QC(g % NQ, 0), QC(g % NQ, 1), QC(g % NQ, 2))
+            if R < N:
+                tap(A, R, k)
+            if R == 0:
+                setup_piece(B, k)
+            else:
+                tap(B, R - 1, k)
+            e.wait_for([("Q", g)])
+            if R < N:
+                use(A, R, k, q)
+            if R >= 1:
+                use(B, R - 1, k, q)
+            if g + NQ < NR * N:
+                e.read(("Q", g + NQ), f"ds_read_b128 {QR(g % NQ)}, %[ta] offset:{((g + NQ) // N) * TRB + 16 * ((g + NQ) % N)}")
+            if R < N:
+                prefetch(A, R, k)
+            if R >= 1:
+                prefetch(B, R - 1, k)
+    e.op("s_waitcnt lgkmcnt(0)")
+    return "\n".join(f'    "{ln}\\n\\t"' for ln in e.lines)
+
+
 def main():
     out = ['// GENERATED by tools/gen_lk_rows9.py -- do not edit.  See that file for the schedule and the derivation of every wait count.',
            f'// TRB = {TRB} (tile[][] row pitch in bytes); one pair of bodies per jl[][] row pitch (OFPS_LK_JS floats): lk.hip static_asserts both.',
-           '#define LK_ROWS9_TRB ' + str(TRB),
-           '#define LK_ROWS9_CLOBBERS ' + ", ".join(f'"v{QB + i}"' for i in range(4 * NQ)) + (', "v80", "v81", "v82", "v83"' if DUMMYQ else ""),
-           f'#define LK_ROWS9_TOP_REG {QB + 4 * NQ - 1}']
+           '// Every body is a function-like macro of the record quads: (Q0, Q0_0, Q0_1, Q0_2, Q1, Q1_0, Q1_1, Q1_2) = the quad as a register',
+           '// range and its first three registers, as string literals.',
+           '#define LK_ROWS9_TRB ' + str(TRB)]
     for k, js in enumerate((64,)):          # (68 was measured in round 4: more bank conflicts, 238 vs 221 us; profiles/r04/lk_lds_experiments.txt)
         out += [('#if' if k == 0 else '#elif') + f' OFPS_LK_JS == {js}', f'#define LK_ROWS9_JSB {4 * js}',
-                '#define LK_ROWS9_BODY \\', body(False, 4 * js).replace("\n", " \\\n"), '',
-                '#define LK_ROWS9_BODY_G \\', body(True, 4 * js).replace("\n", " \\\n"), '']
+                '#define LK_ROWS9_BODY(' + QARGS + ') \\', body(False, 4 * js).replace("\n", " \\\n"), '',
+                '#define LK_ROWS9_BODY_G(' + QARGS + ') \\', body(True, 4 * js).replace("\n", " \\\n"), '',
+                '#define LK_ROWS9_PAIR_BODY(' + QARGS + ') \\', body_pair(False, 4 * js).replace("\n", " \\\n"), '',
+                '#define LK_ROWS9_PAIR_BODY_G(' + QARGS + ') \\', body_pair(True, 4 * js).replace("\n", " \\\n"), '']
     out += ['#else', '#error "lk_rows9.inc has no body for this OFPS_LK_JS"', '#endif', '']
     path = os.path.join(ROOT, "ofps_amd", "csrc", "lk_rows9.inc")
     with open(path, "w") as f:

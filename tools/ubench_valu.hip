@@ -1,100 +1,81 @@
-// ubench_valu.hip -- issue-rate microbenchmark of the VALU instructions the hot path is made of (gfx950).
-// Build: hipcc --offload-arch=gfx950 -O3 tools/ubench_valu.hip -o tools/ubench_valu ; run on the GPU box.
-// Every measured instruction is an `asm volatile` statement (the compiler can neither fold nor reorder it away:
-// the r01 table's v_add_u32 row was folded by the optimiser and read 0.6 cycles).  Each wave runs ITER x 32
-// instructions over 8 independent accumulator chains per lane; 32 waves per CU.  Cycles are per wave64 instruction
-// per SIMD at the nominal 2.4 GHz; the effective clock (lower under load) is printed from s_memtime-free wall time
-// of a pure v_mov chain for scale.
+// ubench_valu.hip -- f32 VALU issue rates on gfx950 (round 4): cycles per wave64 instruction per SIMD for
+//   dep:   v_fmac_f32 chains where every instruction depends on the one before (the LK rows' shape: one tmp register)
+//   ind:   eight independent accumulators
+//   pk:    v_pk_fma_f32, eight independent accumulator pairs (two FMAs per lane and instruction)
+//   mix:   the LK tap (sub, fmac, sub, fmac, sub, fmac, fmac through one tmp), two taps interleaved on two tmps
+// at 1..8 waves per SIMD.  build: hipcc --offload-arch=gfx950 -O3 tools/ubench_valu.hip -o tools/ubench_valu ; run on the GPU box.
 #include <hip/hip_runtime.h>
-
 #include <cstdio>
 #include <cstdlib>
-
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
-
 constexpr int ITER = 2000;
+#define R8(X) X X X X X X X X
 
-#define OP32(name, text) \
-    struct name { static constexpr const char* label = #name; \
-        __device__ static __forceinline__ void op(unsigned long long& a, unsigned long long w, unsigned c) { \
-            unsigned lo = (unsigned)a; asm volatile(text : "+v"(lo) : "v"((unsigned)w), "s"(c)); a = lo; } };
-#define OP64(name, text) \
-    struct name { static constexpr const char* label = #name; \
-        __device__ static __forceinline__ void op(unsigned long long& a, unsigned long long w, unsigned c) { \
-            asm volatile(text : "+v"(a) : "v"(w), "s"(c)); } };
-
-OP32(v_add_u32, "v_add_u32 %0, %1, %0")
-OP32(v_add_f32, "v_add_f32 %0, %1, %0")
-OP32(v_mul_f32, "v_mul_f32 %0, %1, %0")
-OP32(v_fma_f32, "v_fma_f32 %0, %1, %1, %0")
-OP32(v_rcp_f32, "v_rcp_f32 %0, %0")
-OP32(v_fmac_f32, "v_fmac_f32 %0, %1, %1")
-OP32(v_fma_mix_f32, "v_fma_mix_f32 %0, %1, %1, %0 op_sel_hi:[1,0,0]")
-OP32(v_cvt_f32_f16, "v_cvt_f32_f16 %0, %0")
-OP32(v_min_u32, "v_min_u32 %0, %1, %0")
-OP32(v_max_f32, "v_max_f32 %0, %1, %0")
-OP32(v_cndmask_b32, "v_cndmask_b32 %0, %0, %1, vcc")
-OP32(v_sad_u8, "v_sad_u8 %0, %1, %2, %0")
-OP32(v_pk_min_u16, "v_pk_min_u16 %0, %1, %0")
-OP32(v_pk_add_u16, "v_pk_add_u16 %0, %1, %0")
-OP32(v_cvt_f32_ubyte0, "v_cvt_f32_ubyte0 %0, %0")
-OP32(v_perm_b32, "v_perm_b32 %0, %1, %0, %2")
-OP32(v_alignbit_b32, "v_alignbit_b32 %0, %1, %0, 8")
-OP64(v_pk_add_f32, "v_pk_add_f32 %0, %1, %0")
-OP64(v_pk_mul_f32, "v_pk_mul_f32 %0, %1, %0")
-OP64(v_pk_fma_f32, "v_pk_fma_f32 %0, %1, %1, %0")
-OP64(v_qsad_pk_u16_u8, "v_qsad_pk_u16_u8 %0, %1, %2, %0")
-OP64(v_lshlrev_b64, "v_lshlrev_b64 %0, 1, %0")
-
-template <class O>
-__global__ __launch_bounds__(256) void rate_kernel(unsigned* out, unsigned seed) {
-    unsigned long long a[8];
-    unsigned long long w = ((unsigned long long)(threadIdx.x * 2654435761u) << 32) | (seed + threadIdx.x);
-    unsigned c = __builtin_amdgcn_readfirstlane(seed * 77u + blockIdx.x);
-#pragma unroll
-    for (int k = 0; k < 8; ++k) a[k] = k + 0x3f8000003f800000ull;
+template <int MODE>
+__global__ __launch_bounds__(256) void k(float* out, float seed) {
+    float a0 = seed, a1 = seed + 1, a2 = seed + 2, a3 = seed + 3, a4 = seed + 4, a5 = seed + 5, a6 = seed + 6, a7 = seed + 7;
+    float b = seed * 0.5f, c = seed * 0.25f, t0 = 0, t1 = 0;
     for (int it = 0; it < ITER; ++it) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) O::op(a[k], w, c);
+        if constexpr (MODE == 0) {           // 64 dependent
+            asm volatile(R8(R8("v_fmac_f32 %0, %1, %0\n\t")) : "+v"(a0) : "v"(b));
+        } else if constexpr (MODE == 1) {    // 64 = 8 x 8 independent
+            asm volatile(R8("v_fmac_f32 %0, %8, %9\n\tv_fmac_f32 %1, %8, %9\n\tv_fmac_f32 %2, %8, %9\n\tv_fmac_f32 %3, %8, %9\n\t"
+                            "v_fmac_f32 %4, %8, %9\n\tv_fmac_f32 %5, %8, %9\n\tv_fmac_f32 %6, %8, %9\n\tv_fmac_f32 %7, %8, %9\n\t")
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));
+        } else if constexpr (MODE == 2) {    // 64 packed, 4 independent pairs
+            asm volatile(R8(R8("v_pk_fma_f32 v[100:101], v[102:103], v[104:105], v[100:101]\n\t")) ::: "v100", "v101", "v102", "v103", "v104", "v105");
+        } else if constexpr (MODE == 3) {    // 64 packed, 4 independent pairs
+            asm volatile(R8("v_pk_fma_f32 v[100:101], v[108:109], v[110:111], v[100:101]\n\tv_pk_fma_f32 v[102:103], v[108:109], v[110:111], v[102:103]\n\t"
+                            "v_pk_fma_f32 v[104:105], v[108:109], v[110:111], v[104:105]\n\tv_pk_fma_f32 v[106:107], v[108:109], v[110:111], v[106:107]\n\t"
+                            "v_pk_fma_f32 v[100:101], v[108:109], v[110:111], v[100:101]\n\tv_pk_fma_f32 v[102:103], v[108:109], v[110:111], v[102:103]\n\t"
+                            "v_pk_fma_f32 v[104:105], v[108:109], v[110:111], v[104:105]\n\tv_pk_fma_f32 v[106:107], v[108:109], v[110:111], v[106:107]\n\t")
+                         ::: "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111");
+        } else if constexpr (MODE == 4) {    // the LK tap, 9 taps through one tmp: 63 instructions
+#define TAP(L0, L1, T) "v_sub_f32 %8, " L1 ", " L0 "\n\tv_fmac_f32 " L0 ", %10, %8\n\tv_sub_f32 %8, " L0 ", " T "\n\tv_fmac_f32 " T ", %11, %8\n\t" \
+                       "v_sub_f32 %8, %10, " T "\n\tv_fmac_f32 %6, %11, %8\n\tv_fmac_f32 %7, %10, %8\n\t"
+            asm volatile(TAP("%0", "%1", "%2") TAP("%1", "%2", "%3") TAP("%2", "%3", "%4") TAP("%3", "%4", "%5") TAP("%4", "%5", "%0")
+                         TAP("%5", "%0", "%1") TAP("%0", "%1", "%2") TAP("%1", "%2", "%3") TAP("%2", "%3", "%4")
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+v"(t0), "+v"(t1) : "v"(b), "v"(c));
+        } else {                             // the same, two taps interleaved instruction by instruction on two tmps (two pixels per lane): 56 instructions
+#define TAP2(L0, L1, T, M0, M1, U) "v_sub_f32 %8, " L1 ", " L0 "\n\tv_sub_f32 %9, " M1 ", " M0 "\n\tv_fmac_f32 " L0 ", %10, %8\n\tv_fmac_f32 " M0 ", %10, %9\n\t" \
+                       "v_sub_f32 %8, " L0 ", " T "\n\tv_sub_f32 %9, " M0 ", " U "\n\tv_fmac_f32 " T ", %11, %8\n\tv_fmac_f32 " U ", %11, %9\n\t" \
+                       "v_sub_f32 %8, %10, " T "\n\tv_sub_f32 %9, %10, " U "\n\tv_fmac_f32 %6, %11, %8\n\tv_fmac_f32 %7, %11, %9\n\tv_fmac_f32 %6, %10, %8\n\tv_fmac_f32 %7, %10, %9\n\t"
+            asm volatile(TAP2("%0", "%1", "%2", "%3", "%4", "%5") TAP2("%1", "%2", "%0", "%4", "%5", "%3") TAP2("%2", "%0", "%1", "%5", "%3", "%4")
+                         TAP2("%0", "%1", "%2", "%3", "%4", "%5")
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+v"(t0), "+v"(t1) : "v"(b), "v"(c));
         }
     }
-    unsigned long long s = 0;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) s ^= a[k];
-    if ((unsigned)(s ^ (s >> 32)) == 0x12345678u) out[0] = (unsigned)s;
+    if (a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + t0 + t1 == 123456.0f) out[0] = a0;
 }
 
-template <class O>
-void run(unsigned* d_out, int cus) {
-    const int blocks = cus * 8;          // 8 WGs x 4 waves = 32 waves per CU
-    hipEvent_t e0, e1;
-    CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
-    hipLaunchKernelGGL(rate_kernel<O>, dim3(blocks), dim3(256), 0, 0, d_out, 1u);
-    CHECK(hipDeviceSynchronize());
-    CHECK(hipEventRecord(e0));
-    hipLaunchKernelGGL(rate_kernel<O>, dim3(blocks), dim3(256), 0, 0, d_out, 2u);
-    CHECK(hipEventRecord(e1));
-    CHECK(hipEventSynchronize(e1));
-    float ms = 0; CHECK(hipEventElapsedTime(&ms, e0, e1));
-    const double wave_instr = (double)blocks * 4 * ITER * 32;
-    const double per_cu_per_s = wave_instr / cus / (ms * 1e-3);
-    printf("%-22s %8.3f ms  %7.3f wave-instr/clk/CU @2.4GHz  => %5.2f cycles per wave-instr per SIMD\n", O::label, ms,
-           per_cu_per_s / 2.4e9, 4.0 / (per_cu_per_s / 2.4e9));
+template <int MODE>
+void run(const char* name, int per_iter, float* d, int cus) {
+    printf("%-44s", name);
+    for (int wps : {1, 2, 4, 6, 8}) {
+        hipEvent_t e0, e1;
+        CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+        const int blocks = cus * wps;                     // 256 threads = one wave per SIMD per block
+        hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(256), 0, 0, d, 1.0f);
+        CHECK(hipDeviceSynchronize());
+        CHECK(hipEventRecord(e0));
+        hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(256), 0, 0, d, 1.0f);
+        CHECK(hipEventRecord(e1));
+        CHECK(hipEventSynchronize(e1));
+        float ms = 0; CHECK(hipEventElapsedTime(&ms, e0, e1));
+        printf("  %d w/SIMD %5.2f", wps, ms * 1e-3 * 2.4e9 / ((double)wps * ITER * per_iter));
+    }
+    printf("   (clocks at 2.4 GHz per wave instruction per SIMD)\n");
 }
 
 int main() {
     hipDeviceProp_t p; CHECK(hipGetDeviceProperties(&p, 0));
-    printf("device %s, %d CUs, clock %d kHz\n", p.gcnArchName, p.multiProcessorCount, p.clockRate);
-    unsigned* d; CHECK(hipMalloc(&d, 64));
-    const int cus = p.multiProcessorCount;
-    run<v_add_u32>(d, cus); run<v_add_f32>(d, cus); run<v_mul_f32>(d, cus); run<v_fma_f32>(d, cus);
-    run<v_pk_add_f32>(d, cus); run<v_pk_mul_f32>(d, cus); run<v_pk_fma_f32>(d, cus);
-    run<v_fmac_f32>(d, cus); run<v_fma_mix_f32>(d, cus); run<v_cvt_f32_f16>(d, cus);
-    run<v_rcp_f32>(d, cus); run<v_max_f32>(d, cus); run<v_min_u32>(d, cus); run<v_cndmask_b32>(d, cus);
-    run<v_pk_min_u16>(d, cus); run<v_pk_add_u16>(d, cus); run<v_cvt_f32_ubyte0>(d, cus); run<v_perm_b32>(d, cus);
-    run<v_alignbit_b32>(d, cus); run<v_lshlrev_b64>(d, cus);
-    run<v_sad_u8>(d, cus); run<v_qsad_pk_u16_u8>(d, cus);
+    float* d; CHECK(hipMalloc(&d, 64));
+    printf("%s, %d CUs\n", p.gcnArchName, p.multiProcessorCount);
+    run<0>("v_fmac_f32, dependent chain", 64, d, p.multiProcessorCount);
+    run<1>("v_fmac_f32, 8 independent accumulators", 64, d, p.multiProcessorCount);
+    run<2>("v_pk_fma_f32, dependent chain", 64, d, p.multiProcessorCount);
+    run<3>("v_pk_fma_f32, 4 independent pairs", 64, d, p.multiProcessorCount);
+    run<4>("LK tap x 9 through one tmp", 63, d, p.multiProcessorCount);
+    run<5>("LK tap, two pixels interleaved, two tmps", 56, d, p.multiProcessorCount);
     return 0;
 }
