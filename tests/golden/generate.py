@@ -84,12 +84,31 @@ def main():
     rec = oracle.masked_flow_to_entries(flow, mask)
     np.savez_compressed(os.path.join(HERE, "flow.npz"), frames=fr, flow=flow, mask=mask, records=rec,
                         cells_60x36=oracle.densify_to_entries(rec, 60, 36))
+    flow_revisions(fr)
     # ---- cfg3-sized Almeida LSQ: 1920x1080 per-pixel records (inputs are regenerated from synth; 18 s of oracle time)
     e = synth.rotation_field(1920, 1080)
     np.savez_compressed(os.path.join(HERE, "almeida_dense.npz"), q_lsq=oracle.solve_ypr_given(e, oracle.camera(16 / 9, 22.275)),
                         checksum=np.float64(e.astype(np.float64).sum()), first=e[:4], last=e[-4:])
     for f in sorted(os.listdir(HERE)):
         print(f, os.path.getsize(os.path.join(HERE, f)))
+
+
+def flow_revisions(fr=None):
+    """flow_rev1.npz: the N2 spec's two revisions on one small pair (a 64 x 40 crop of flow.npz's frames) -- revision 1 (separate
+    multiply and add) from the numpy restatement with its switch off, revision 2 (fused, the shipped spec) from the C oracle.
+    The test that reads it fails if the shipped spec drifts back to revision 1 arithmetic, or away from both."""
+    from oracle import np_oracle
+    if fr is None:
+        fr = synth.flatten_regions(synth.luma_sequence(2, 160, 96, max_step=2, seed=synth.SEED0 + 5), region=32, seed=4)
+    crop = np.ascontiguousarray(fr[:, 20:60, 40:104])
+    np_oracle.LK_SPEC_FMA = False
+    try:
+        rev1 = np_oracle.lk_flow(crop[0], crop[1], 2, 4, 3)
+    finally:
+        np_oracle.LK_SPEC_FMA = True
+    rev2 = oracle.lk_flow(crop[0], crop[1], 2, 4, 3)
+    assert oracle.lk_spec_revision() == 2 and (rev1.view(np.uint32) != rev2.view(np.uint32)).any()
+    np.savez_compressed(os.path.join(HERE, "flow_rev1.npz"), frames=crop, flow_rev1=rev1, flow_rev2=rev2)
 
 
 if __name__ == "__main__":

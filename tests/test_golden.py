@@ -69,6 +69,25 @@ def test_oracle_reproduces_flow_golden():
     np.testing.assert_array_equal(oracle.densify_to_entries(rec, 60, 36).view(np.uint32), g["cells_60x36"].view(np.uint32))
 
 
+def test_flow_revision_1_golden_guards_the_spec_against_drift():
+    """the N2 spec is build-defined, so the only guard against an accidental change of its arithmetic is a vector of
+    the OTHER revision: revision 1 (separate multiply and add) is reproduced by the numpy restatement with its switch off, the
+    shipped revision 2 by both restatements, and the two differ on this input."""
+    from oracle import np_oracle
+    g = _load("flow_rev1.npz")
+    fr = g["frames"]
+    np_oracle.LK_SPEC_FMA = False
+    try:
+        rev1 = np_oracle.lk_flow(fr[0], fr[1], 2, 4, 3)
+    finally:
+        np_oracle.LK_SPEC_FMA = True
+    np.testing.assert_array_equal(rev1.view(np.uint32), g["flow_rev1"].view(np.uint32))
+    for f2 in (oracle.lk_flow(fr[0], fr[1], 2, 4, 3), np_oracle.lk_flow(fr[0], fr[1], 2, 4, 3)):
+        np.testing.assert_array_equal(f2.view(np.uint32), g["flow_rev2"].view(np.uint32))
+    differing = (g["flow_rev1"].view(np.uint32) != g["flow_rev2"].view(np.uint32)).mean()
+    assert differing > 0.05, differing                     # the revisions are far enough apart for a drift to show
+
+
 # ---------------------------------------------------------------- HIP path vs golden (GPU)
 @pytest.fixture(scope="module")
 def ctx():
@@ -115,6 +134,15 @@ def test_hip_almeida_matches_golden(ctx):
         q, _ = ctx.almeida(f, 1.0, 90.0, use_ransac=True, num_iters=100, inlier_deg=0.05, num_samples=1000,
                            seed=int(g["ransac_seed0"]) + int(i))
         np.testing.assert_allclose(q, g["q_ransac"][i], atol=1e-4, rtol=0)
+
+
+@pytest.mark.gpu
+def test_hip_flow_is_revision_2_on_the_two_revision_golden(ctx):
+    g = _load("flow_rev1.npz")
+    fr = g["frames"]
+    f = ctx.lk_flow(fr[0], fr[1], 2, 4, 3)
+    np.testing.assert_array_equal(f.view(np.uint32), g["flow_rev2"].view(np.uint32))
+    assert (f.view(np.uint32) != g["flow_rev1"].view(np.uint32)).any()
 
 
 @pytest.mark.gpu
