@@ -65,8 +65,8 @@ void* ofps_hip_get_stream(ofps_hip_ctx* ctx);
 int   ofps_hip_sync(ofps_hip_ctx* ctx);
 /* Diagnostic / A-B switches (table in INTEGRATION.md).  `name` is the switch's environment-variable name, e.g.
  * "OFPS_HIP_ALMEIDA_HIER"; value NULL or "" restores the default.  ofps_hip_init reads the same variables from the
- * environment ONCE; no other entry point looks at the environment.  The two fault injectors
- * (OFPS_HIP_ALMEIDA_TEST_FAULT, OFPS_HIP_LK_TEST_FALL) exist only in libofps_hip_testhooks.so (built with
+ * environment ONCE; no other entry point looks at the environment.  The fault injectors
+ * (OFPS_HIP_ALMEIDA_TEST_FAULT, OFPS_HIP_LK_TEST_FALL, OFPS_HIP_LK_TEST_WAIT_BUDGET) exist only in libofps_hip_testhooks.so (built with
  * -DOFPS_HIP_TEST_HOOKS, used by the parity tests), can only be armed through this call, and are refused with
  * OFPS_HIP_EUNSUPPORTED by the product library. */
 int   ofps_hip_set_option(ofps_hip_ctx* ctx, const char* name, const char* value);
@@ -129,9 +129,15 @@ int ofps_hip_lk_flow(ofps_hip_ctx* ctx, const uint8_t* prev, const uint8_t* cur,
 int ofps_hip_lk_spec_revision(void);
 /* Diagnostics (synchronises): the flow runs its whole pyramid as ONE launch in which a tile waits -- bounded, ~0.3 s -- for its parent
  * tile of the coarser level to publish its flows; a wait that expired (it cannot while workgroups are dispatched in block order) is
- * counted here since the flag buffer was last allocated and makes that call's flows unspecified.  0 = every flow this context
- * computed had all its dependencies.  The counterpart of ofps_hip_almeida_recoveries for the other spin-waiting kernel. */
+ * counted here since the flag buffer was last allocated.  The entry points that hand results to the HOST (ofps_hip_lk_flow,
+ * ofps_hip_lk_decode, ofps_hip_lk_push_frame, ofps_hip_lk_frame_wait) see the count arrive with their results and, if it moved,
+ * repeat the call with one launch per pyramid level (nothing waits there) before they return: their results always had all their
+ * dependencies, and ofps_hip_lk_recoveries counts the repeats.  The device-pointer entry points (ofps_hip_lk_flow_dev,
+ * ofps_hip_lk_flow_init_dev) cannot look without synchronising: a caller that needs the guarantee checks this count after its
+ * own synchronisation (unchanged = every flow since had its dependencies) or sets OFPS_HIP_LK_SERIAL=1.  The counterpart of
+ * ofps_hip_almeida_recoveries for the other spin-waiting kernel. */
 int ofps_hip_lk_wait_timeouts(ofps_hip_ctx* ctx, uint64_t* count);
+int ofps_hip_lk_recoveries(ofps_hip_ctx* ctx, uint64_t* count);
 /* cv-decoder's contrast mask (cv-decoder/src/lib.rs:203-237): Sobel(gray, CV_32F, 1, 1, ksize 5) -> threshold(> 20)
  * -> dilate(MORPH_ELLIPSE 11x11); a pixel contributes a record only where the mask is set (:253-257).  Restated
  * from OpenCV's published definitions (oracle/ofps_oracle.c:orc_contrast_mask; "parity unpinned": OpenCV is not

@@ -32,10 +32,12 @@ struct ofps_hip_ctx {
         int almeida_fast = -1;           // OFPS_HIP_ALMEIDA_FAST: -1 by size, 0 exact, 1 folded
         int almeida_prof = 0;            // OFPS_HIP_ALMEIDA_PROF
         int lk_prof = 0;                 // OFPS_HIP_LK_PROF
+        int lk_serial = 0;               // OFPS_HIP_LK_SERIAL: one launch per pyramid level instead of one for the pyramid
         // fault injectors: only builds with -DOFPS_HIP_TEST_HOOKS (libofps_hip_testhooks.so) can set them, and only
         // through ofps_hip_set_option -- never from the environment
         int test_almeida_fault = 0;      // OFPS_HIP_ALMEIDA_TEST_FAULT: workgroup (value - 1) withholds its step-3 granule
         int test_lk_fall = -1;           // OFPS_HIP_LK_TEST_FALL: every other tile hands over at this step
+        int test_lk_wait_budget = 0;     // OFPS_HIP_LK_TEST_WAIT_BUDGET: polls a tile spends on its parent's flag (0 = the product's 2^18)
     } opt;
 
     // hip_lk stream state (lk.hip: ofps_hip_lk_push_frame): frame k of the stream lives in slot k % 2 of S_FRAMES
@@ -44,6 +46,8 @@ struct ofps_hip_ctx {
     uint64_t lk_frames_gen = 0;          // generation of the S_LK_FRAMES allocation the count refers to
     uint32_t lk_epoch = 0;               // lk_levels_kernel: tag of the last launch in the tile flags (S_WORK3)
     uint64_t lk_flags_gen = 0;           // generation of the flag buffer the tags refer to
+    uint32_t lk_timeouts_seen = 0;       // expired parent-tile waits (word 0 of the flag buffer) the host has accounted for
+    uint64_t lk_recoveries = 0;          // calls repeated level by level because a wait had expired (ofps_hip_lk_recoveries)
     void* lk_pinned = nullptr;           // page-locked staging for a frame's records + their count (one D2H, one wait)
     size_t lk_pinned_cap = 0;
     // read-ahead form (ofps_hip_lk_push_frame_async / ofps_hip_lk_frame_wait): a ring of three device frame slots, the new frame
@@ -58,6 +62,11 @@ struct ofps_hip_ctx {
         int have_vectors = 0, gw = 0, gh = 0;
         size_t max_records = 0;
         long fixed_count = -1;           // >= 0: the record count is known on the host (per-pixel output without a mask)
+        // what the ticket computed, for the repeat after an expired parent-tile wait (lk.hip: ofps_hip_lk_frame_wait)
+        bool wired = false;              // the block's second word carries the device's expired-wait count
+        const uint8_t* d_prev = nullptr; const uint8_t* d_cur = nullptr;
+        int W = 0, H = 0, levels = 0, radius = 0, iters = 0, max_w = 0, max_h = 0;
+        unsigned flags = 0;
     } lk_ticket[kLkTickets];
     long lk_next_ticket = 0;
 
@@ -119,8 +128,13 @@ enum ScratchSlot {
     S_QUAT, S_WORK4, S_PIPE_FRAMES, S_PIPE_ENTRIES, S_PIPE_OUT, S_MASK, S_ENTRIES2, S_GRAN, S_SAD_LIST,
     // the estimator's own workspaces: it may run beside the detector (pipeline.hip), so the two share no slot
     S_ALM_PART, S_ALM_STATE, S_ALM_HYP, S_ALM_COUNTS, S_ALM_SEL, S_ALM_SELN, S_ALM_PROF, S_ALM_RECOVER,
-    S_LK_FRAMES, S_BATCH_FRAMES, S_BATCH_ENTRIES, S_BATCH_OUT, S_BATCH_FIELD
+    S_LK_FRAMES, S_BATCH_FRAMES, S_BATCH_ENTRIES, S_BATCH_OUT, S_BATCH_FIELD,
+    // the one-launch LK pyramid's tile flags + expired-wait counter: they carry state ACROSS calls (epoch tags, never cleared), so the slot
+    // is nobody else's (round 4: they sat in S_WORK3, which the densifier's per-cell tables also use -- a decode call wiped the counter,
+    // and a begin[] value equal to a later launch's epoch would have read as "parent tile done")
+    S_LK_FLAGS
 };
+static_assert(S_LK_FLAGS < ofps_hip_ctx::kNumScratch, "scratch table too small");
 
 int set_error(ofps_hip_ctx* ctx, int code, const char* fmt, ...);
 int check_hip(ofps_hip_ctx* ctx, hipError_t e, const char* what);
@@ -141,7 +155,7 @@ int densify_entries_device(ofps_hip_ctx* ctx, const float4* d_entries, size_t n,
 int densify_raster_device(ofps_hip_ctx* ctx, const float4* d_entries, const uint8_t* d_mask, int W, int H, int w, int h,
                           float2* d_field, uint32_t** out_begin, uint32_t** out_end);
 int densify_raster_entries_device(ofps_hip_ctx* ctx, const float4* d_entries, const uint8_t* d_mask, int W, int H, int w, int h,
-                                  float2* d_field, float4* d_out_entries, uint32_t* d_count);
+                                  float2* d_field, float4* d_out_entries, uint32_t* d_count, const uint32_t* d_aux = nullptr);
 int contrast_mask_device(ofps_hip_ctx* ctx, const uint8_t* d_gray, int W, int H, int stride, uint8_t* d_mask);
 int compact_entries_device(ofps_hip_ctx* ctx, const float4* d_in, const uint8_t* d_mask, size_t n, float4* d_out,
                            uint32_t* d_count);

@@ -79,10 +79,14 @@ int apply_option(ofps_hip_ctx* ctx, const char* name, const char* value, bool fr
         o.almeida_prof = unset ? 0 : (iv != 0);
     } else if (!strcmp(name, "OFPS_HIP_LK_PROF")) {
         o.lk_prof = unset ? 0 : (iv != 0);
-    } else if (!strcmp(name, "OFPS_HIP_ALMEIDA_TEST_FAULT") || !strcmp(name, "OFPS_HIP_LK_TEST_FALL")) {
+    } else if (!strcmp(name, "OFPS_HIP_LK_SERIAL")) {
+        o.lk_serial = unset ? 0 : (iv != 0);
+    } else if (!strcmp(name, "OFPS_HIP_ALMEIDA_TEST_FAULT") || !strcmp(name, "OFPS_HIP_LK_TEST_FALL") ||
+               !strcmp(name, "OFPS_HIP_LK_TEST_WAIT_BUDGET")) {
 #ifdef OFPS_HIP_TEST_HOOKS
         if (from_env) return OFPS_HIP_OK;                    // fault injectors are never armed from the environment
         if (!strcmp(name, "OFPS_HIP_ALMEIDA_TEST_FAULT")) o.test_almeida_fault = unset ? 0 : iv;
+        else if (!strcmp(name, "OFPS_HIP_LK_TEST_WAIT_BUDGET")) o.test_lk_wait_budget = unset || iv < 0 ? 0 : iv;
         else o.test_lk_fall = unset ? -1 : iv;
 #else
         if (from_env) return OFPS_HIP_OK;
@@ -96,7 +100,7 @@ int apply_option(ofps_hip_ctx* ctx, const char* name, const char* value, bool fr
 
 static const char* const kOptionNames[] = {
     "OFPS_HIP_SAD_KERNEL", "OFPS_HIP_DENSIFY_NO_SMALL", "OFPS_HIP_ALMEIDA_PATH", "OFPS_HIP_ALMEIDA_EPT", "OFPS_HIP_ALMEIDA_BLOCK",
-    "OFPS_HIP_ALMEIDA_HIER", "OFPS_HIP_ALMEIDA_FAST", "OFPS_HIP_ALMEIDA_PROF", "OFPS_HIP_LK_PROF"};
+    "OFPS_HIP_ALMEIDA_HIER", "OFPS_HIP_ALMEIDA_FAST", "OFPS_HIP_ALMEIDA_PROF", "OFPS_HIP_LK_PROF", "OFPS_HIP_LK_SERIAL"};
 
 }  // namespace ofps
 

@@ -464,7 +464,9 @@ __global__ __launch_bounds__(1024) void cells_to_entries_kernel(const float2* __
                                                                 const uint32_t* __restrict__ cell_begin,
                                                                 const uint32_t* __restrict__ cell_end, int w, int h,
                                                                 float4* __restrict__ out_entries,
-                                                                uint32_t* __restrict__ out_count) {
+                                                                uint32_t* __restrict__ out_count,
+                                                                const uint32_t* __restrict__ aux_src = nullptr) {
+    // (aux_src: one more word copied to out_count[1] -- the hip_lk decoder's expired-wait counter travels with the count)
     // ordered compaction, 1024 cells per round: rank inside the wave from a ballot, the 16 wave totals through LDS
     // (two barriers per round; a 10-step scan over the workgroup with its 20 barriers took 37 us at 150 x 84)
     __shared__ uint32_t wave_cnt[2][16];
@@ -493,7 +495,7 @@ __global__ __launch_bounds__(1024) void cells_to_entries_kernel(const float2* __
         }
         base += total;
     }
-    if (threadIdx.x == 0) out_count[item] = base;
+    if (threadIdx.x == 0) { out_count[item] = base; if (aux_src) out_count[1] = *aux_src; }
 }
 
 // MotionFieldDensifier::interpolate_empty_cells (motion_field.rs:193-294) + MotionField::from.
@@ -706,12 +708,12 @@ int densify_raster_device(ofps_hip_ctx* ctx, const float4* d_entries, const uint
 }
 
 int densify_raster_entries_device(ofps_hip_ctx* ctx, const float4* d_entries, const uint8_t* d_mask, int W, int H, int w, int h,
-                                  float2* d_field, float4* d_out_entries, uint32_t* d_count) {
+                                  float2* d_field, float4* d_out_entries, uint32_t* d_count, const uint32_t* d_aux) {
     uint32_t *begin = nullptr, *end = nullptr;
     int rc = densify_raster_device(ctx, d_entries, d_mask, W, H, w, h, d_field, &begin, &end);
     if (rc != OFPS_HIP_OK) return rc;
     hipLaunchKernelGGL(cells_to_entries_kernel, dim3(1), dim3(1024), 0, ctx->stream, d_field, begin, end, w, h, d_out_entries,
-                       d_count);
+                       d_count, d_aux);
     OFPS_HIP_TRY(ctx, hipGetLastError());
     return OFPS_HIP_OK;
 }

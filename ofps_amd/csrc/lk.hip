@@ -926,7 +926,7 @@ template <int RADIUS, bool U8>
 __device__ __forceinline__ void lk_level_body(LkStepShared<RADIUS>& sh, const void* __restrict__ I_, const void* __restrict__ J_, int src_stride,
                                               int w, int h, int iters, const LkFlowIO io, unsigned long long* __restrict__ prof,
                                               int force_fall_arg, int tile_x, int tile_y, const uint32_t* parent_flag, uint32_t* done_flag,
-                                              uint32_t epoch, uint32_t* timeouts) {
+                                              uint32_t epoch, uint32_t* timeouts, int wait_budget_arg) {
     // force_fall (libofps_hip_testhooks.so only; compiled out of the product library): low 4 bits = a step at which every
     // other tile is treated as not fitting, so that the grouped path in the middle of a level is exercised on inputs that
     // would never trigger it; bits 4.. = how many grouping rounds those tiles get (0 = the default kLkMaxRounds; 1 + n = n
@@ -967,13 +967,19 @@ __device__ __forceinline__ void lk_level_body(LkStepShared<RADIUS>& sh, const vo
     if (parent_flag) {                                                   // uniform
         if (threadIdx.x == 0) {
             uint32_t v;
+#ifdef OFPS_HIP_TEST_HOOKS                       // OFPS_HIP_LK_TEST_WAIT_BUDGET: a budget of one poll makes most waits expire (the recovery's test)
+            int budget = wait_budget_arg > 0 ? wait_budget_arg : 1 << 18;
+#else
             int budget = 1 << 18;
+#endif
             do {
                 asm volatile("global_load_dword %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(parent_flag) : "memory");
                 if (v == epoch) break;
                 __builtin_amdgcn_s_sleep(16);
             } while (--budget);
-            if (!budget && timeouts) atomicAdd(timeouts, 1u);            // ofps_hip_lk_wait_timeouts reports it: never silent
+            // never silent: counted (ofps_hip_lk_wait_timeouts); the host-output entry points see the count with their results and
+            // repeat the call level by level (lk_flow_device: serial), the device-pointer ones document the check
+            if (!budget && timeouts) atomicAdd(timeouts, 1u);
         }
         __syncthreads();
     }
@@ -1492,9 +1498,10 @@ struct LkLevelArgs {
     unsigned start, count;        // first block of the level, blocks of the level (a multiple of 8)
     int tiles_x, ntiles;
     unsigned flag_off;            // the level's tile flags inside LkLevelsArgs::flags (levels with children)
+    int u8;                       // level 0: I / J are the u8 frames
 };
 struct LkLevelsArgs {
-    int levels, iters, force_fall;
+    int levels, iters, force_fall, wait_budget;
     uint32_t epoch;
     uint32_t* flags;
     unsigned long long* prof;
@@ -1515,10 +1522,12 @@ __global__ __launch_bounds__(256, LkStepShared<RADIUS>::WAVES_PER_SIMD) void lk_
     // the parent: the tile of the next coarser level (lv[k - 1]) that holds this tile's half-resolution pixels
     const uint32_t* parent = k > 0 ? A.flags + A.lv[k - 1].flag_off + (size_t)(ty / 2) * A.lv[k - 1].tiles_x + tx / 2 : nullptr;
     uint32_t* done = k < A.levels - 1 ? A.flags + L.flag_off + (size_t)ty * L.tiles_x + tx : nullptr;
-    if (k == A.levels - 1)
-        lk_level_body<RADIUS, true>(sh, L.I, L.J, L.stride, L.w, L.h, A.iters, L.io, A.prof, A.force_fall, tx, ty, parent, done, A.epoch, A.flags);
+    if (L.u8)
+        lk_level_body<RADIUS, true>(sh, L.I, L.J, L.stride, L.w, L.h, A.iters, L.io, A.prof, A.force_fall, tx, ty, parent, done, A.epoch, A.flags,
+                                    A.wait_budget);
     else
-        lk_level_body<RADIUS, false>(sh, L.I, L.J, L.stride, L.w, L.h, A.iters, L.io, nullptr, A.force_fall, tx, ty, parent, done, A.epoch, A.flags);
+        lk_level_body<RADIUS, false>(sh, L.I, L.J, L.stride, L.w, L.h, A.iters, L.io, nullptr, A.force_fall, tx, ty, parent, done, A.epoch, A.flags,
+                                     A.wait_budget);
 }
 
 // cv-decoder/src/lib.rs:239-243,262-269: per-pixel records, raster order
@@ -1540,7 +1549,7 @@ static dim3 lk_grid_xcd(int w, int h, int tx = 64, int ty = 4) {
 // d_prev/d_cur: u8 luma on the device.  d_flow: W*H float2.  Workspace comes from the context.
 // d_flow (W*H float2) and/or d_entries (W*H float4 records) receive the result; at least one of them.
 int lk_flow_device(ofps_hip_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_cur, int W, int H, int stride, int levels,
-                   int radius, int iters, float2* d_flow, float4* d_entries, const float2* d_init = nullptr) {
+                   int radius, int iters, float2* d_flow, float4* d_entries, const float2* d_init = nullptr, bool force_serial = false) {
     OFPS_REQUIRE(ctx, W >= 1 && H >= 1 && stride >= W, "lk_flow: bad geometry W=%d H=%d stride=%d", W, H, stride);
     OFPS_REQUIRE(ctx, levels >= 1 && levels <= 8 && radius >= 1 && radius <= 15 && iters >= 1 && iters <= 64,
                  "lk_flow: levels=%d radius=%d iters=%d out of range", levels, radius, iters);
@@ -1619,6 +1628,7 @@ int lk_flow_device(ofps_hip_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_cu
         // (every level its own plane: all levels are in flight together)
         LkLevelsArgs A{};
         A.levels = levels; A.iters = iters; A.force_fall = force_fall; A.prof = prof;
+        A.wait_budget = ctx->opt.test_lk_wait_budget;          // 0 in the product library (a test hook of libofps_hip_testhooks.so)
         unsigned nb = 0, nflags = 2;                                  // word 0 of the flag buffer counts expired waits (ofps_hip_lk_wait_timeouts)
         for (int k = 0; k < levels; ++k) {                            // k = 0: the coarsest level
             const int l = levels - 1 - k;
@@ -1630,6 +1640,7 @@ int lk_flow_device(ofps_hip_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_cu
             L.tiles_x = (ws[l] + kTX - 1) / kTX; L.ntiles = L.tiles_x * ((hs[l] + tile_rows - 1) / tile_rows);
             L.start = nb; L.count = ((unsigned)L.ntiles + 7u) / 8u * 8u; nb += L.count;
             L.flag_off = nflags; if (!last) nflags += (unsigned)L.ntiles;
+            L.u8 = last ? 1 : 0;
             LkFlowIO& io = L.io;
             io.coarse = l == levels - 1 ? nullptr : fa + (off[l + 1] - off[1]);
             io.coarse_shared = 1;
@@ -1641,19 +1652,35 @@ int lk_flow_device(ofps_hip_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_cu
             io.nx = 1.0f / (float)W; io.ny = 1.0f / (float)H;
         }
         // tile flags carry the launch's epoch: no clearing between calls (zeroed when (re)allocated or when the counter wraps)
-        auto* flags = static_cast<uint32_t*>(scratch(ctx, S_WORK3, (size_t)nflags * sizeof(uint32_t)));
+        auto* flags = static_cast<uint32_t*>(scratch(ctx, S_LK_FLAGS, (size_t)nflags * sizeof(uint32_t)));
         if (!flags) return OFPS_HIP_ENOMEM;
-        if (ctx->lk_flags_gen != ctx->scratch[S_WORK3].gen || ctx->lk_epoch == 0xFFFFFFFFu) {
-            OFPS_HIP_TRY(ctx, hipMemsetAsync(flags, 0, ctx->scratch[S_WORK3].cap, s));
-            ctx->lk_flags_gen = ctx->scratch[S_WORK3].gen;
+        if (ctx->lk_flags_gen != ctx->scratch[S_LK_FLAGS].gen || ctx->lk_epoch == 0xFFFFFFFFu) {
+            OFPS_HIP_TRY(ctx, hipMemsetAsync(flags, 0, ctx->scratch[S_LK_FLAGS].cap, s));
+            ctx->lk_flags_gen = ctx->scratch[S_LK_FLAGS].gen;
             ctx->lk_epoch = 0;
+            ctx->lk_timeouts_seen = 0;
         }
         A.epoch = ++ctx->lk_epoch;
         A.flags = flags;
-        switch (radius) {
-            case 2: hipLaunchKernelGGL(lk_levels_kernel<2>, dim3(nb), dim3(256), 0, s, A); break;
-            case 4: hipLaunchKernelGGL(lk_levels_kernel<4>, dim3(nb), dim3(256), 0, s, A); break;
-            default: hipLaunchKernelGGL(lk_levels_kernel<6>, dim3(nb), dim3(256), 0, s, A); break;
+        auto launch = [&](const LkLevelsArgs& B, unsigned blocks) {
+            switch (radius) {
+                case 2: hipLaunchKernelGGL(lk_levels_kernel<2>, dim3(blocks), dim3(256), 0, s, B); break;
+                case 4: hipLaunchKernelGGL(lk_levels_kernel<4>, dim3(blocks), dim3(256), 0, s, B); break;
+                default: hipLaunchKernelGGL(lk_levels_kernel<6>, dim3(blocks), dim3(256), 0, s, B); break;
+            }
+        };
+        if (force_serial || ctx->opt.lk_serial) {
+            // one launch per level, coarsest first: a level's parents are complete before its launch starts, nothing waits on a
+            // flag.  OFPS_HIP_LK_SERIAL for A/B runs, and what a host-output call is repeated with after an expired wait.
+            for (int k = 0; k < levels; ++k) {
+                LkLevelsArgs B = A;
+                B.levels = 1;
+                B.lv[0] = A.lv[k];
+                B.lv[0].start = 0;
+                launch(B, A.lv[k].count);
+            }
+        } else {
+            launch(A, nb);
         }
     }
     for (int l = levels - 1; l >= 0 && !tiled; --l) {
@@ -1705,13 +1732,19 @@ int ofps_hip_lk_spec_revision(void) { return OFPS_LK_SPEC_FMA ? 2 : 1; }
 int ofps_hip_lk_wait_timeouts(ofps_hip_ctx* ctx, uint64_t* count) {
     if (!ctx || !count) return OFPS_HIP_EINVAL;
     *count = 0;
-    const void* d = ctx->scratch[ofps::S_WORK3].p;
+    const void* d = ctx->scratch[ofps::S_LK_FLAGS].p;
     if (!d || !ctx->lk_flags_gen) return OFPS_HIP_OK;            // no pyramid launch on this context yet
     OFPS_HIP_TRY(ctx, hipSetDevice(ctx->device));
     uint32_t v = 0;
     OFPS_HIP_TRY(ctx, hipMemcpyAsync(&v, d, sizeof(v), hipMemcpyDeviceToHost, ctx->stream));
     OFPS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     *count = v;
+    return OFPS_HIP_OK;
+}
+
+int ofps_hip_lk_recoveries(ofps_hip_ctx* ctx, uint64_t* count) {
+    if (!ctx || !count) return OFPS_HIP_EINVAL;
+    *count = ctx->lk_recoveries;
     return OFPS_HIP_OK;
 }
 
@@ -1765,25 +1798,48 @@ int lk_grid_of(ofps_hip_ctx* ctx, int W, int H, int max_w, int max_h, unsigned f
 
 // records 0 .. *d_count - 1 (or n_max when d_count is null) to a device-addressable destination, the count to cnt_dst
 __global__ __launch_bounds__(256) void lk_copy_records_kernel(const float4* __restrict__ src, float4* __restrict__ dst,
-                                                              const uint32_t* __restrict__ d_count, size_t n_max, uint32_t* __restrict__ cnt_dst) {
+                                                              const uint32_t* __restrict__ d_count, size_t n_max, uint32_t* __restrict__ cnt_dst,
+                                                              const uint32_t* __restrict__ aux_src) {
     size_t n = d_count ? (size_t)*d_count : n_max;
     if (n > n_max) n = n_max;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = src[i];
-    if (cnt_dst && blockIdx.x == 0 && threadIdx.x == 0) *cnt_dst = (uint32_t)n;
+    if (cnt_dst && blockIdx.x == 0 && threadIdx.x == 0) { *cnt_dst = (uint32_t)n; if (aux_src) cnt_dst[1] = *aux_src; }
+}
+
+// Expired parent-tile waits of the one-launch pyramid (lk_level_body): word 0 of the flag buffer counts them; the decoder's last
+// kernel copies the count into the second word of the frame's page-locked block, so the host sees with the records whether the
+// flow that made them may have started a tile from unfinished parent flows -- and repeats the frame level by level if so.
+bool lk_is_tiled(int radius) { return radius == 2 || radius == 4 || radius == 6; }
+const uint32_t* lk_timeout_word(ofps_hip_ctx* ctx, int radius) {
+    return lk_is_tiled(radius) ? static_cast<const uint32_t*>(ctx->scratch[ofps::S_LK_FLAGS].p) : nullptr;
+}
+// -> waits expired in the launches since the last look; `count` is the device's running count as the caller's results saw it
+bool lk_waits_expired(ofps_hip_ctx* ctx, uint32_t count) {
+    const bool hit = count != ctx->lk_timeouts_seen;
+    ctx->lk_timeouts_seen = count;
+    return hit;
+}
+uint32_t lk_block_waits(const void* pinned) {
+    uint32_t c = 0;
+    memcpy(&c, static_cast<const char*>(pinned) + 4, sizeof(c));
+    return c;
 }
 
 // Enqueues everything of a process_frame that follows the uploads on ctx->stream: flow [-> contrast mask] -> output stage.
 // The record count lands at cnt_dst and the records at rec_dst -- device scratch, or the device address of a page-locked
 // block (the kernels store there directly: no read-back launch of their own).
+// serial: the pyramid level by level (the repeat after an expired wait).  *wired: the block's second word carries the wait count.
 int lk_enqueue_frame(ofps_hip_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_cur, int W, int H, int levels, int radius, int iters,
-                     const LkGrid& g, float4* rec_dst, uint32_t* cnt_dst) {
+                     const LkGrid& g, float4* rec_dst, uint32_t* cnt_dst, bool serial, bool* wired) {
     const size_t px = (size_t)W * H, cells = g.per_pixel ? 1 : (size_t)g.gw * g.gh;
     auto* d_ent = static_cast<float4*>(ofps::scratch(ctx, ofps::S_ENTRIES, px * sizeof(float4)));
     auto* d_field = static_cast<float2*>(ofps::scratch(ctx, ofps::S_FIELD, cells * sizeof(float2)));
     auto* d_cnt = static_cast<uint32_t*>(ofps::scratch(ctx, ofps::S_RESULT, 16));
     if (!d_ent || !d_field || !d_cnt) return OFPS_HIP_ENOMEM;
-    int rc = ofps_hip_lk_flow_dev(ctx, d_prev, d_cur, W, H, W, levels, radius, iters, nullptr, d_ent);
+    int rc = ofps::lk_flow_device(ctx, d_prev, d_cur, W, H, W, levels, radius, iters, nullptr, d_ent, nullptr, serial);
     if (rc != OFPS_HIP_OK) return rc;
+    const uint32_t* d_waits = lk_timeout_word(ctx, radius);
+    *wired = d_waits != nullptr;
     const uint8_t* d_mask = nullptr;
     if (g.use_mask) {
         auto* m = static_cast<uint8_t*>(ofps::scratch(ctx, ofps::S_MASK, px));
@@ -1802,13 +1858,13 @@ int lk_enqueue_frame(ofps_hip_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_
             if (rc != OFPS_HIP_OK) return rc;
             d_rec = d_ent2; d_n = d_cnt + 1;
         }
-        hipLaunchKernelGGL(lk_copy_records_kernel, dim3(1024), dim3(256), 0, ctx->stream, d_rec, rec_dst, d_n, px, cnt_dst);
+        hipLaunchKernelGGL(lk_copy_records_kernel, dim3(1024), dim3(256), 0, ctx->stream, d_rec, rec_dst, d_n, px, cnt_dst, d_waits);
         OFPS_HIP_TRY(ctx, hipGetLastError());
         return OFPS_HIP_OK;
     }
     // down-sampled output (cv-decoder/src/lib.rs:244-291): the records are this call's own per-pixel lattice, so the
     // densifier walks each cell's rectangle of pixels (masked ones skipped in place) instead of sorting 2 M records
-    return ofps::densify_raster_entries_device(ctx, d_ent, d_mask, W, H, g.gw, g.gh, d_field, rec_dst, cnt_dst);
+    return ofps::densify_raster_entries_device(ctx, d_ent, d_mask, W, H, g.gw, g.gh, d_field, rec_dst, cnt_dst, d_waits);
 }
 
 // a page-locked block [count, pad x 3][records]; grows, never shrinks
@@ -1877,10 +1933,18 @@ int ofps_hip_lk_decode(ofps_hip_ctx* ctx, const uint8_t* prev, const uint8_t* cu
     if (rc != OFPS_HIP_OK) return rc;
     void* mapped = nullptr;
     OFPS_REQUIRE(ctx, ofps::device_address_of(ctx->lk_pinned, &mapped), "lk_decode: page-locked block is not device-addressable");
+    bool wired = false;
     rc = lk_enqueue_frame(ctx, d_frames, d_frames + px, W, H, levels, radius, iters, g, reinterpret_cast<float4*>(static_cast<char*>(mapped) + 16),
-                          static_cast<uint32_t*>(mapped));
+                          static_cast<uint32_t*>(mapped), false, &wired);
     if (rc != OFPS_HIP_OK) return rc;
     OFPS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (wired && lk_waits_expired(ctx, lk_block_waits(ctx->lk_pinned))) {        // a tile may have started from unfinished parent flows: level by level
+        rc = lk_enqueue_frame(ctx, d_frames, d_frames + px, W, H, levels, radius, iters, g, reinterpret_cast<float4*>(static_cast<char*>(mapped) + 16),
+                              static_cast<uint32_t*>(mapped), true, &wired);
+        if (rc != OFPS_HIP_OK) return rc;
+        OFPS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->lk_recoveries += 1;
+    }
     lk_collect(ctx->lk_pinned, g.max_records, out_entries, n_out);
     if (out_w) *out_w = g.gw;
     if (out_h) *out_h = g.gh;
@@ -1942,10 +2006,15 @@ int ofps_hip_lk_push_frame_async(ofps_hip_ctx* ctx, const uint8_t* frame, int W,
         void* mapped = nullptr;
         OFPS_REQUIRE(ctx, ofps::device_address_of(t.pinned, &mapped), "lk_push_frame_async: page-locked block is not device-addressable");
         const int prev_slot = (int)((ctx->lk_frames - 2) % ofps_hip_ctx::kLkSlots);
+        bool wired = false;
         rc = lk_enqueue_frame(ctx, d_frames + (size_t)prev_slot * px, d_frames + (size_t)slot * px, W, H, levels, radius, iters, g,
-                              reinterpret_cast<float4*>(static_cast<char*>(mapped) + 16), static_cast<uint32_t*>(mapped));
+                              reinterpret_cast<float4*>(static_cast<char*>(mapped) + 16), static_cast<uint32_t*>(mapped), false, &wired);
         if (rc != OFPS_HIP_OK) return rc;
         t.have_vectors = 1;
+        // what a repeat of this ticket needs (ofps_hip_lk_frame_wait, after an expired wait): its two frames stay in the ring
+        // until the ticket after the next one is pushed, which cannot happen before this one is collected
+        t.wired = wired; t.d_prev = d_frames + (size_t)prev_slot * px; t.d_cur = d_frames + (size_t)slot * px;
+        t.W = W; t.H = H; t.levels = levels; t.radius = radius; t.iters = iters; t.max_w = max_w; t.max_h = max_h; t.flags = flags;
     }
     OFPS_HIP_TRY(ctx, hipEventRecord(t.done, s));
     t.pending = true;
@@ -1971,6 +2040,21 @@ int ofps_hip_lk_frame_wait(ofps_hip_ctx* ctx, int ticket, float* out_entries, si
     *have_vectors = t.have_vectors;
     if (out_w) *out_w = t.gw;
     if (out_h) *out_h = t.gh;
+    if (t.have_vectors && t.wired && lk_waits_expired(ctx, lk_block_waits(t.pinned))) {
+        // (the count looked at is the one this ticket's last kernel saw; the repeat below rewrites the block, with whatever
+        // later tickets added -- theirs to notice when they are collected)
+        LkGrid g;
+        int rc = lk_grid_of(ctx, t.W, t.H, t.max_w, t.max_h, t.flags, &g);
+        if (rc != OFPS_HIP_OK) return rc;
+        void* mapped = nullptr;
+        OFPS_REQUIRE(ctx, ofps::device_address_of(t.pinned, &mapped), "lk_frame_wait: page-locked block is not device-addressable");
+        bool wired = false;
+        rc = lk_enqueue_frame(ctx, t.d_prev, t.d_cur, t.W, t.H, t.levels, t.radius, t.iters, g,
+                              reinterpret_cast<float4*>(static_cast<char*>(mapped) + 16), static_cast<uint32_t*>(mapped), true, &wired);
+        if (rc != OFPS_HIP_OK) return rc;
+        OFPS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->lk_recoveries += 1;
+    }
     if (t.have_vectors) lk_collect(t.pinned, t.max_records, out_entries, n_out);
     return OFPS_HIP_OK;
 }
@@ -2009,9 +2093,23 @@ int ofps_hip_lk_flow(ofps_hip_ctx* ctx, const uint8_t* prev, const uint8_t* cur,
     OFPS_HIP_TRY(ctx, ofps::upload_rows(d_frames + px, W, cur, stride, W, H, ctx->stream));
     int rc = ofps_hip_lk_flow_dev(ctx, d_frames, d_frames + px, W, H, W, levels, radius, iters, d_flow, d_ent);
     if (rc != OFPS_HIP_OK) return rc;
-    if (out_flow) OFPS_HIP_TRY(ctx, hipMemcpyAsync(out_flow, d_flow, px * sizeof(float2), hipMemcpyDeviceToHost, ctx->stream));
-    if (out_entries) OFPS_HIP_TRY(ctx, hipMemcpyAsync(out_entries, d_ent, px * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
-    OFPS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    auto read_back = [&](uint32_t* waits) -> int {
+        if (out_flow) OFPS_HIP_TRY(ctx, hipMemcpyAsync(out_flow, d_flow, px * sizeof(float2), hipMemcpyDeviceToHost, ctx->stream));
+        if (out_entries) OFPS_HIP_TRY(ctx, hipMemcpyAsync(out_entries, d_ent, px * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
+        if (waits) OFPS_HIP_TRY(ctx, hipMemcpyAsync(waits, lk_timeout_word(ctx, radius), sizeof(*waits), hipMemcpyDeviceToHost, ctx->stream));
+        OFPS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        return OFPS_HIP_OK;
+    };
+    uint32_t waits = ctx->lk_timeouts_seen;
+    rc = read_back(lk_timeout_word(ctx, radius) ? &waits : nullptr);
+    if (rc != OFPS_HIP_OK) return rc;
+    if (lk_waits_expired(ctx, waits)) {                     // a tile may have started from unfinished parent flows: level by level
+        rc = ofps::lk_flow_device(ctx, d_frames, d_frames + px, W, H, W, levels, radius, iters, d_flow, d_ent, nullptr, true);
+        if (rc != OFPS_HIP_OK) return rc;
+        rc = read_back(nullptr);
+        if (rc != OFPS_HIP_OK) return rc;
+        ctx->lk_recoveries += 1;
+    }
     return OFPS_HIP_OK;
 }
 

@@ -572,6 +572,112 @@ def test_lk_flow_hand_over_in_the_middle_of_a_level(hooks_ctx, fall_step, radius
     np.testing.assert_array_equal(d_ent.cpu().numpy().view(np.uint32), oracle.flow_to_entries(f_o).view(np.uint32))
 
 
+def test_lk_expired_parent_waits_are_repaired_before_results_reach_the_host(hooks_ctx):
+    """The pyramid is one launch in which a tile waits for its parent tile's flows (bounded).  With the hook a tile polls its
+    parent's flag ONCE, so most waits expire and the one-launch flows are wrong; the entry points that hand results to the
+    host see the expired-wait count arrive with the results and repeat the call level by level: same bits as the oracle, the
+    repeat counted -- on the pair call, the decoder call, the synchronous stream and the read-ahead stream."""
+    ctx = hooks_ctx
+    W, H, levels, radius, iters = 640, 360, 3, 4, 3
+    fr = synth.luma_sequence(4, W, H, max_step=3, seed=311)
+    f_o = oracle.lk_flow(fr[0], fr[1], levels, radius, iters)
+    ref_dec = [ctx.lk_decode(fr[k], fr[k + 1], levels, radius, iters) for k in range(3)]     # undisturbed
+    assert ctx.lk_wait_timeouts() == 0 and ctx.lk_recoveries() == 0
+    ctx.set_option("OFPS_HIP_LK_TEST_WAIT_BUDGET", "1")
+    try:
+        r0 = ctx.lk_recoveries()
+        f_g, e_g = ctx.lk_flow(fr[0], fr[1], levels, radius, iters, want_entries=True)
+        np.testing.assert_array_equal(f_g.view(np.uint32), f_o.view(np.uint32))
+        np.testing.assert_array_equal(e_g.view(np.uint32), oracle.flow_to_entries(f_o).view(np.uint32))
+        t1 = ctx.lk_wait_timeouts()
+        assert t1 > 0 and ctx.lk_recoveries() == r0 + 1              # waits did expire, and the call was repeated once
+        ent, grid = ctx.lk_decode(fr[0], fr[1], levels, radius, iters)
+        assert grid == ref_dec[0][1]
+        np.testing.assert_array_equal(ent.view(np.uint32), ref_dec[0][0].view(np.uint32))
+        assert ctx.lk_recoveries() == r0 + 2
+        # synchronous stream form
+        ctx.lk_reset()
+        assert ctx.lk_push_frame(fr[0], levels, radius, iters) is None
+        for k in range(1, 4):
+            ent, grid = ctx.lk_push_frame(fr[k], levels, radius, iters)
+            np.testing.assert_array_equal(ent.view(np.uint32), ref_dec[k - 1][0].view(np.uint32))
+        # read-ahead form, two tickets in flight: every ticket notices its own launch's expired waits
+        ctx.lk_reset()
+        r1 = ctx.lk_recoveries()
+        pins = [ctx.pinned_frame(H, W) for _ in range(4)]
+        for k in range(4): np.copyto(pins[k], fr[k])
+        tickets = [ctx.lk_push_frame_async(pins[0], levels, radius, iters), ctx.lk_push_frame_async(pins[1], levels, radius, iters)]
+        got = [ctx.lk_frame_wait(tickets[0])]
+        tickets.append(ctx.lk_push_frame_async(pins[2], levels, radius, iters))
+        got.append(ctx.lk_frame_wait(tickets[1]))
+        tickets.append(ctx.lk_push_frame_async(pins[3], levels, radius, iters))
+        got.append(ctx.lk_frame_wait(tickets[2]))
+        got.append(ctx.lk_frame_wait(tickets[3]))
+        assert got[0] is None
+        for k in range(1, 4):
+            np.testing.assert_array_equal(got[k][0].view(np.uint32), ref_dec[k - 1][0].view(np.uint32))
+        assert ctx.lk_recoveries() == r1 + 3
+        # the device-pointer entry point cannot look: the count is the caller's to check
+        import torch
+        dfr = torch.from_numpy(fr[:2]).cuda()
+        d_ent = torch.zeros((W * H, 4), dtype=torch.float32, device="cuda")
+        ctx.use_torch_stream()
+        try:
+            ctx.lk_flow_dev(dfr[0].data_ptr(), dfr[1].data_ptr(), W, H, W, levels, radius, iters, None, d_ent.data_ptr())
+            torch.cuda.synchronize()
+        finally:
+            ctx.use_own_stream()
+        assert ctx.lk_wait_timeouts() > t1
+    finally:
+        ctx.set_option("OFPS_HIP_LK_TEST_WAIT_BUDGET", None)
+        ctx.lk_reset()
+    # the hook is off.  The expired waits of the unchecked device-pointer call are still unaccounted for: the next host-output
+    # call cannot tell them from its own and repeats once (harmless); after that one launch again, nothing to repair
+    f_g = ctx.lk_flow(fr[0], fr[1], levels, radius, iters)
+    np.testing.assert_array_equal(f_g.view(np.uint32), f_o.view(np.uint32))
+    before, waits = ctx.lk_recoveries(), ctx.lk_wait_timeouts()
+    f_g = ctx.lk_flow(fr[0], fr[1], levels, radius, iters)
+    np.testing.assert_array_equal(f_g.view(np.uint32), f_o.view(np.uint32))
+    assert ctx.lk_recoveries() == before and ctx.lk_wait_timeouts() == waits
+
+
+def test_lk_tile_flags_are_nobodys_scratch(ctx):
+    """The one-launch pyramid tags its tile flags with a per-call epoch and never clears them, so the flag buffer must not be
+    anybody else's workspace: in round 4 it shared a slot with the densifier's per-cell begin[] table, whose values (record
+    indices: small integers) would have read as "parent tile done" for the launch whose epoch they equal.  Densify calls whose
+    begin[] covers 0..n interleaved with flows for a run of epochs: every flow has the oracle's bits."""
+    W, H = 160, 96
+    fr = synth.luma_sequence(2, W, H, max_step=2, seed=5)
+    f_o = oracle.lk_flow(fr[0], fr[1], 3, 4, 2)
+    rng = np.random.default_rng(3)
+    for k in range(24):
+        n = 40 + 7 * k                                       # begin[] of a 16 x 9 field then holds most integers below n
+        e = np.zeros((n, 4), np.float32)
+        e[:, 0] = (np.arange(n) % 16 + 0.5) / 16; e[:, 1] = (np.arange(n) // 16 % 9 + 0.5) / 9
+        e[:, 2:] = rng.uniform(-0.01, 0.01, (n, 2)).astype(np.float32)
+        ctx.densify(e, 16, 9)
+        f_g = ctx.lk_flow(fr[0], fr[1], 3, 4, 2)
+        np.testing.assert_array_equal(f_g.view(np.uint32), f_o.view(np.uint32))
+    assert ctx.lk_wait_timeouts() == 0
+
+
+@pytest.mark.parametrize("radius", [2, 4, 6])
+def test_lk_one_launch_per_level_gives_the_same_bits(ctx, radius):
+    """OFPS_HIP_LK_SERIAL=1: the pyramid level by level (what the repair above runs) -- same bits as the one-launch form."""
+    W, H, levels, iters = 322, 181, 3, 2
+    fr = synth.luma_sequence(2, W, H, max_step=3, seed=17 + radius)
+    f_one, e_one = ctx.lk_flow(fr[0], fr[1], levels, radius, iters, want_entries=True)
+    ctx.set_option("OFPS_HIP_LK_SERIAL", "1")
+    try:
+        f_ser, e_ser = ctx.lk_flow(fr[0], fr[1], levels, radius, iters, want_entries=True)
+    finally:
+        ctx.set_option("OFPS_HIP_LK_SERIAL", None)
+    np.testing.assert_array_equal(f_ser.view(np.uint32), f_one.view(np.uint32))
+    np.testing.assert_array_equal(e_ser.view(np.uint32), e_one.view(np.uint32))
+    np.testing.assert_array_equal(f_ser.view(np.uint32), oracle.lk_flow(fr[0], fr[1], levels, radius, iters).view(np.uint32))
+    assert ctx.lk_wait_timeouts() == 0 and ctx.lk_recoveries() == 0
+
+
 def test_lk_flow_recovers_planted_translation(ctx):
     base = synth.luma_sequence(1, 640 + 64, 360 + 64, max_step=0, noise=0, seed=5)[0]
     dx, dy = 5, -3

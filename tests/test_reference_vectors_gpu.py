@@ -155,7 +155,7 @@ def hooks():
 
 def test_product_library_refuses_the_fault_injectors(ctx):
     from ofps_amd._lib import OfpsHipError
-    for name in ("OFPS_HIP_ALMEIDA_TEST_FAULT", "OFPS_HIP_LK_TEST_FALL"):
+    for name in ("OFPS_HIP_ALMEIDA_TEST_FAULT", "OFPS_HIP_LK_TEST_FALL", "OFPS_HIP_LK_TEST_WAIT_BUDGET"):
         with pytest.raises(OfpsHipError) as ei:
             ctx.set_option(name, "2")
         assert ei.value.code == -3                     # OFPS_HIP_EUNSUPPORTED
