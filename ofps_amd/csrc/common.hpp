@@ -44,7 +44,7 @@ struct ofps_hip_ctx {
     int lk_w = 0, lk_h = 0;
     long lk_frames = 0;
     uint64_t lk_frames_gen = 0;          // generation of the S_LK_FRAMES allocation the count refers to
-    uint32_t lk_epoch = 0;               // lk_levels_kernel: tag of the last launch in the tile flags (S_WORK3)
+    uint32_t lk_epoch = 0;               // lk_levels_kernel: tag of the last launch in the tile flags (S_LK_FLAGS)
     uint64_t lk_flags_gen = 0;           // generation of the flag buffer the tags refer to
     uint32_t lk_timeouts_seen = 0;       // expired parent-tile waits (word 0 of the flag buffer) the host has accounted for
     uint64_t lk_recoveries = 0;          // calls repeated level by level because a wait had expired (ofps_hip_lk_recoveries)
