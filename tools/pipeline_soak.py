@@ -10,6 +10,7 @@ from ofps_amd import synth
 from ofps_amd.runtime import HipContext
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 600
+RANSAC = bool(int(os.environ.get("SOAK_RANSAC", "0")))       # the stream's estimator: the reference's default RANSAC instead of LSQ
 NEG = int(os.environ.get("SOAK_NEGATIVE_CONTROL", "0"))     # 1: compare with the NEXT frame's expectation -- every frame must then mismatch
 W, H, B, R = 640, 360, 16, 16
 ctx, ref = HipContext(0), HipContext(0)
@@ -24,7 +25,7 @@ def expect(j):
     if k not in want:
         ref.reset_frames()
         ref.push_frame(fr[(k - 1) % 12])
-        want[k] = ref.push_frame(fr[k], block=B, search_range=R, want_entries=True)
+        want[k] = ref.push_frame(fr[k], block=B, search_range=R, want_entries=True, use_ransac=RANSAC, num_iters=50, num_samples=300, seed=7)
     return want[k]
 nb = (W // B) * (H // B)
 pins = [ctx.pinned_frame(H, W) for _ in range(3)]
@@ -43,7 +44,7 @@ t0 = time.perf_counter()
 prev = None
 for k in range(N):
     np.copyto(pins[k % 3], fr[k % 12])
-    t = ctx.push_frame_async(pins[k % 3], block=B, search_range=R, out_entries=outs[k % 3])
+    t = ctx.push_frame_async(pins[k % 3], block=B, search_range=R, out_entries=outs[k % 3], use_ransac=RANSAC, num_iters=50, num_samples=300, seed=7)
     which = k % 6                                            # a different disturbance after every push, while the ticket is in flight
     if which == 0: ctx.sad_flow(small[0], small[1], 8, 8)
     elif which == 1:
@@ -60,6 +61,6 @@ for k in range(N):
         check(prev[1], res, outs[prev[1] % 3])
     prev = (t, k)
 res = ctx.frame_wait(prev[0]); check(prev[1], res, outs[prev[1] % 3])
-print(f"pipeline soak: {N} frames {W}x{H} b{B} r{R} in {time.perf_counter() - t0:.1f} s with six kinds of other calls in between, "
+print(f"pipeline soak ({'RANSAC' if RANSAC else 'LSQ'} estimator in the stream): {N} frames {W}x{H} b{B} r{R} in {time.perf_counter() - t0:.1f} s with six kinds of other calls in between, "
       f"mismatching frames {bad}")
 sys.exit(1 if bad else 0)
