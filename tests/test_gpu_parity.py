@@ -539,6 +539,21 @@ def test_lk_flow_bit_exact_vs_oracle(ctx, W, H, levels, radius, iters):
     np.testing.assert_array_equal(e_g.view(np.uint32), oracle.flow_to_entries(f_o).view(np.uint32))   # cv-decoder records
 
 
+@pytest.mark.parametrize("radius", [2, 4, 6, 3])
+@pytest.mark.parametrize("W,H,levels", [(1, 1, 1), (2, 2, 3), (5, 3, 2), (31, 7, 3), (33, 9, 4), (40, 30, 8), (17, 200, 5), (200, 17, 5),
+                                        (32, 8, 1), (64, 16, 2), (65, 17, 3)])
+def test_lk_flow_degenerate_geometries(ctx, W, H, levels, radius):
+    """Frames smaller than a tile, one-pixel pyramid levels (40 x 30 at 8 levels ends in 1 x 1), strips one tile wide or high,
+    exact multiples of the tile: every window sample is clamped somewhere.  Same bits as the oracle, with and without records."""
+    fr = synth.luma_sequence(2, max(W, 8), max(H, 8), max_step=1, seed=1000 + W + H)[:, :H, :W]
+    fr = np.ascontiguousarray(fr)
+    f_o = oracle.lk_flow(fr[0], fr[1], levels, radius, 2)
+    f_g, e_g = ctx.lk_flow(fr[0], fr[1], levels, radius, 2, want_entries=True)
+    np.testing.assert_array_equal(f_g.view(np.uint32), f_o.view(np.uint32))
+    np.testing.assert_array_equal(e_g.view(np.uint32), oracle.flow_to_entries(f_o).view(np.uint32))
+    assert ctx.lk_wait_timeouts() == 0
+
+
 @pytest.mark.parametrize("fall_step", [0, 1, 2, 16 + 0, 16 + 1, 16 + 2, 32 + 0, 32 + 2, 48 + 1])
 @pytest.mark.parametrize("radius", [2, 4, 6])
 def test_lk_flow_hand_over_in_the_middle_of_a_level(hooks_ctx, fall_step, radius):
