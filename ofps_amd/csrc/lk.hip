@@ -193,7 +193,7 @@ __global__ __launch_bounds__(256) void lk_pyr12_kernel(const uint8_t* __restrict
                                                        float* __restrict__ a2, float* __restrict__ b2, int w2, int h2) {
     constexpr int W1 = 2 * kP0X + 4, H1 = 2 * kP0Y + 4;           // level-1 window: 68 x 20
     constexpr int W0 = 2 * W1 + 4, H0 = 2 * H1 + 4;               // level-0 window: 140 x 44
-    __shared__ uint8_t win0[H0][W0 + 4];
+    __shared__ alignas(16) uint8_t win0[H0][W0 + 4];
     __shared__ float hor1[H0][W1 + 1];
     __shared__ float lvl1[H1][W1 + 1];
     __shared__ float hor2[H1][kP0X + 1];
@@ -205,16 +205,30 @@ __global__ __launch_bounds__(256) void lk_pyr12_kernel(const uint8_t* __restrict
     const int x2_0 = tx * kP0X, y2_0 = ty * kP0Y;                 // level-2 tile origin
     const int x1_0 = 2 * x2_0 - 2, y1_0 = 2 * y2_0 - 2;           // level-1 window origin
     const int gx0 = 2 * x1_0 - 2, gy0 = 2 * y1_0 - 2;             // level-0 window origin
-    for (int t = threadIdx.x; t < W0 * H0; t += 256) {
-        const int r = t / W0, c = t - r * W0;
-        win0[r][c] = src[(size_t)lk_clampi(gy0 + r, 0, H - 1) * stride + lk_clampi(gx0 + c, 0, W - 1)];
+    // interior tiles of aligned frames: the window's rows as dwords.  gx0 = 4 x2_0 - 6 sits two bytes behind a 4-byte boundary, so
+    // the row is loaded from gx0 - 2: (W0 + 4) / 4 = 36 dwords, 6 loads per thread for the window instead of 24 clamped byte loads
+    // (the window then starts at column `lead` = 2 of win0's rows).  Uniform branch; same bytes either way.
+    static_assert((W0 + 4) % 4 == 0, "window row is a whole number of dwords");
+    const bool vec = gx0 >= 2 && gy0 >= 0 && gx0 + W0 + 2 <= W && gy0 + H0 <= H && (stride & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 3) == 0;
+    const int lead = vec ? 2 : 0;
+    if (vec) {
+        constexpr int Q = (W0 + 4) / 4;
+        for (int t = threadIdx.x; t < Q * H0; t += 256) {
+            const int r = t / Q, q = t - r * Q;
+            *reinterpret_cast<uint32_t*>(&win0[r][4 * q]) = *reinterpret_cast<const uint32_t*>(src + (size_t)(gy0 + r) * stride + (gx0 - 2) + 4 * q);
+        }
+    } else {
+        for (int t = threadIdx.x; t < W0 * H0; t += 256) {
+            const int r = t / W0, c = t - r * W0;
+            win0[r][c] = src[(size_t)lk_clampi(gy0 + r, 0, H - 1) * stride + lk_clampi(gx0 + c, 0, W - 1)];
+        }
     }
     __syncthreads();
     // rows pass of level 1: every level-0 row of the window, at the window's 68 (clamped) level-1 columns
     for (int t = threadIdx.x; t < W1 * H0; t += 256) {
         const int r = t / W1, i = t - r * W1;
         const int cx = lk_clampi(x1_0 + i, 0, w1 - 1);
-        const uint8_t* p = &win0[r][2 * cx - gx0 - 2];
+        const uint8_t* p = &win0[r][2 * cx - gx0 - 2 + lead];
         hor1[r][i] = ((((float)p[0] + 4.0f * (float)p[1]) + 6.0f * (float)p[2]) + 4.0f * (float)p[3]) + (float)p[4];
         hor1[r][i] *= 0.0625f;
     }
