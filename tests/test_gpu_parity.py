@@ -693,6 +693,22 @@ def test_lk_one_launch_per_level_gives_the_same_bits(ctx, radius):
     assert ctx.lk_wait_timeouts() == 0 and ctx.lk_recoveries() == 0
 
 
+def test_lk_flow_on_a_smooth_subpixel_camera_warp(ctx):
+    """Sub-pixel flows that vary smoothly over the frame (roll + zoom + shift): sample origins flip along lines instead of per
+    region, every lane of a tile has its own fractions.  Same bits as the oracle; the recovered flow is the planted field."""
+    W, H = 384, 216
+    fr = synth.camera_warp_pair(W, H, roll_deg=0.6, zoom=1.006, shift=(2.3, -1.6), seed=3)
+    f_o = oracle.lk_flow(fr[0], fr[1], 3, 4, 3)
+    f_g = ctx.lk_flow(fr[0], fr[1], 3, 4, 3)
+    np.testing.assert_array_equal(f_g.view(np.uint32), f_o.view(np.uint32))
+    yy, xx = np.meshgrid(np.arange(H, dtype=np.float32), np.arange(W, dtype=np.float32), indexing="ij")
+    a, cx, cy = np.deg2rad(0.6), (W - 1) / 2, (H - 1) / 2
+    ex = cx + 1.006 * (np.cos(a) * (xx - cx) - np.sin(a) * (yy - cy)) + 2.3 - xx      # prev(x, y) ~ cur(x + u, y + v): the inverse of the warp
+    ey = cy + 1.006 * (np.sin(a) * (xx - cx) + np.cos(a) * (yy - cy)) - 1.6 - yy
+    inner = np.s_[24:-24, 24:-24]
+    assert np.abs(f_g[..., 0][inner] + ex[inner]).mean() < 0.25 and np.abs(f_g[..., 1][inner] + ey[inner]).mean() < 0.25
+
+
 def test_lk_flow_recovers_planted_translation(ctx):
     base = synth.luma_sequence(1, 640 + 64, 360 + 64, max_step=0, noise=0, seed=5)[0]
     dx, dy = 5, -3

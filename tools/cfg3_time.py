@@ -15,29 +15,10 @@ def timeit(fn, n=20, warm=3):
     torch.cuda.synchronize(); return round((time.perf_counter() - t0) / n * 1e3, 4)
 
 
-def camera_warp_pair(W=1920, H=1080, roll_deg=0.5, zoom=1.004, shift=(3.3, -2.6), seed=11):
-    """A pair related by a SMOOTH sub-pixel motion field (small roll + zoom + shift about the image centre: up to ~+-12 px at the
-    corners of a 1080p frame, no discontinuities): the kind of flow a moving camera produces, against the region-wise integer
-    jumps of synth.luma_sequence.  The second frame is the first one's texture sampled bilinearly at the displaced positions."""
-    from scipy import ndimage
-    rng = np.random.default_rng(seed)
-    tex = ndimage.gaussian_filter(rng.uniform(0, 255, (H + 64, W + 64)).astype(np.float32), 1.2)
-    tex = (tex - tex.min()) / (tex.max() - tex.min()) * 255.0
-    yy, xx = np.meshgrid(np.arange(H, dtype=np.float32), np.arange(W, dtype=np.float32), indexing="ij")
-    cx, cy, a = (W - 1) / 2, (H - 1) / 2, np.deg2rad(roll_deg)
-    dx, dy = xx - cx, yy - cy
-    sx = cx + zoom * (np.cos(a) * dx - np.sin(a) * dy) + shift[0]
-    sy = cy + zoom * (np.sin(a) * dx + np.cos(a) * dy) + shift[1]
-    f0 = tex[32:32 + H, 32:32 + W]
-    f1 = ndimage.map_coordinates(tex, [sy + 32, sx + 32], order=1, mode="nearest")
-    noise = rng.integers(-1, 2, (2, H, W))
-    return np.clip(np.rint(np.stack([f0, f1])) + noise, 0, 255).astype(np.uint8)
-
-
 ctx = HipContext(0); ctx.use_torch_stream()
 out = {}
 for name, step in (("small_motion_pm3", 3), ("bench_motion_pm16", 16), ("camera_warp_subpixel", None)):
-    fr = synth.luma_sequence(2, 1920, 1080, max_step=step, seed=11) if step else camera_warp_pair()
+    fr = synth.luma_sequence(2, 1920, 1080, max_step=step, seed=11) if step else synth.camera_warp_pair()
     dfr = torch.from_numpy(fr).cuda()
     d_ent = torch.empty((1920 * 1080, 4), dtype=torch.float32, device="cuda")
     f84 = torch.empty((150 * 84, 2), dtype=torch.float32, device="cuda")
