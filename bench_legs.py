@@ -116,10 +116,17 @@ def cfg3_chain_leg(device: int = 0, reps: int = 60) -> dict:
                            "frac_pm16": per["pm16"]["lk_frac_of_f32_peak"],
                            "instr_view": {"spec_instr_lanes_per_pair": taps * LK_SPEC_INSTR_PER_TAP, "peak_T_instr_lanes_per_s": round(VALU_F32_PEAK_INSTR / 1e12, 2),
                                           "frac": round(taps * LK_SPEC_INSTR_PER_TAP / (lk_ms * 1e-3) / VALU_F32_PEAK_INSTR, 4)},
+                           # the pipe that binds the rows: LDS-array cycles of the reads the spec's access pattern needs (per wave and tap one
+                           # 16-byte record read = 4 cycles, per window row ten texel reads = 2 cycles each; MI355X_MICROARCH.md, LDS table),
+                           # conflict-free, against one LDS array per CU at the guide's clock
+                           "lds_view": {"spec_lds_cycles_per_pair": round(taps / 64 * (4 + 20 / 9)), "peak_cycles_per_s": 256 * 2.4e9,
+                                        "frac": round(taps / 64 * (4 + 20 / 9) / (lk_ms * 1e-3) / (256 * 2.4e9), 4),
+                                        "frac_pm16": round(taps / 64 * (4 + 20 / 9) / (per["pm16"]["lk_ms"] * 1e-3) / (256 * 2.4e9), 4)},
                            "note": "flops of the spec's window taps over all level steps (11 per tap with a fused multiply-add = 2; the structure "
                                    "tensor, pyramid and staging are not counted as useful work) / the time of the WHOLE lk_flow call, against the "
                                    "guide's f32 vector peak (157.3 TFLOP/s, fma = 2: the same unit); instr_view: the 7 instructions per tap "
-                                   "against 78.6 T lane-instructions/s.  The row phase is LDS-pipe bound (DESIGN.md N2)"},
+                                   "against 78.6 T lane-instructions/s; lds_view: the LDS-array cycles of the spec's reads against 256 arrays at 2.4 GHz -- "
+                                   "the pipe that binds the rows (measured with conflicts: ~64 % busy over the launch, ~76 % inside the rows; DESIGN.md N2)"},
            "roofline_almeida": {"bound": "hbm", "unit": "GB/s", "algorithmic_bytes": 16 * n,
                                 "achieved": round(16 * n / (alm_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
                                 "frac": round(16 * n / (alm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
