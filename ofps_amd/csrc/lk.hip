@@ -851,7 +851,7 @@ struct LkStepShared {
 #define OFPS_LK_WAVES4 6
 #endif
     // (two pixels per thread: 35 KB of LDS per workgroup -> 4 workgroups per CU -> 128 registers)
-    static constexpr int WAVES_PER_SIMD = RADIUS <= 2 ? 8 : RADIUS <= 4 ? (T::PP == 2 ? 4 : OFPS_LK_WAVES4) : 4;
+    static constexpr int WAVES_PER_SIMD = RADIUS <= 2 ? 7 : RADIUS <= 4 ? (T::PP == 2 ? 4 : OFPS_LK_WAVES4) : 4;      // (radius 2: 69 registers -> 7, and 7 x 20.5 KB of LDS fit)
 };
 
 // integer sample origin of a window column / row: the oracle's floor + float clamp to [-1, lim]
