@@ -26,3 +26,11 @@ def test_fused_per_frame_stream_soak_with_other_entry_points_in_between():
     assert r.returncode == 0 and "mismatching frames 0" in r.stdout, r.stdout + r.stderr
     r = _run("pipeline_soak.py", "24", env={"SOAK_NEGATIVE_CONTROL": "1"})          # the comparison does see a wrong frame
     assert r.returncode == 1 and "mismatching frames 23" in r.stdout, r.stdout + r.stderr
+
+
+def test_stateful_api_fuzz_on_one_context():
+    """1,500 random entry-point calls on one context, each compared with the same call on an otherwise idle context (state leaking
+    from one call into another: scratch slots, flags, tickets, rings).  100,000 calls: profiles/r04/api_fuzz.txt."""
+    r = _run("api_fuzz.py", "1500", "11")
+    assert r.returncode == 0 and "mismatches 0 []" in r.stdout, r.stdout + r.stderr
+
