@@ -34,3 +34,10 @@ def test_stateful_api_fuzz_on_one_context():
     r = _run("api_fuzz.py", "1500", "11")
     assert r.returncode == 0 and "mismatches 0 []" in r.stdout, r.stdout + r.stderr
 
+
+def test_multi_device_stream_fuzz_on_one_gpu():
+    """Random batch sizes, batches in flight, restarts and source kinds through 1, 2 and 3 workers on device 0 against one plain
+    context replaying the stream.  63,000 frames: profiles/r04/api_fuzz.txt."""
+    r = _run("multi_fuzz.py", "240", "5")
+    assert r.returncode == 0 and "mismatching frames 0" in r.stdout, r.stdout + r.stderr
+
