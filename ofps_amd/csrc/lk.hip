@@ -1971,6 +1971,9 @@ int ofps_hip_lk_push_frame_async(ofps_hip_ctx* ctx, const uint8_t* frame, int W,
     OFPS_REQUIRE(ctx, frame && ticket, "lk_push_frame_async: null pointer");
     OFPS_REQUIRE(ctx, W >= 1 && H >= 1 && stride >= W && max_w >= 1 && max_h >= 1, "lk_push_frame_async: bad geometry");
     OFPS_REQUIRE(ctx, (flags & ~(unsigned)(OFPS_HIP_LK_CONTRAST_MASK | OFPS_HIP_LK_PER_PIXEL)) == 0, "lk_push_frame_async: unknown flags 0x%x", flags);
+    // (a stream's first frame runs no flow: the flow's parameters are refused here, not one frame later)
+    OFPS_REQUIRE(ctx, levels >= 1 && levels <= 8 && radius >= 1 && radius <= 15 && iters >= 1 && iters <= 64,
+                 "lk_push_frame_async: levels=%d radius=%d iters=%d out of range", levels, radius, iters);
     OFPS_HIP_TRY(ctx, hipSetDevice(ctx->device));
     int rc = lk_stream_setup(ctx);
     if (rc != OFPS_HIP_OK) return rc;

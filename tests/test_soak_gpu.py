@@ -41,3 +41,8 @@ def test_multi_device_stream_fuzz_on_one_gpu():
     r = _run("multi_fuzz.py", "240", "5")
     assert r.returncode == 0 and "mismatching frames 0" in r.stdout, r.stdout + r.stderr
 
+
+def test_hostile_arguments_get_error_codes_and_leave_the_context_intact():
+    r = _run("badarg_fuzz.py")
+    assert r.returncode == 0 and "gives a fresh context's bits: True" in r.stdout, r.stdout + r.stderr
+
