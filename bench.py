@@ -172,15 +172,26 @@ def pair_checksums(d_out, ctx=None, scratch=None):
 
 
 def time_steps(step, steps: int, warmup: int, sync, barrier) -> float:
-    """W untimed warm-ups, then exactly K steps between (sync, barrier, sync) brackets -> seconds on this rank."""
-    for _ in range(warmup):
-        step()
-    sync(); barrier(); sync()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
-    sync(); barrier(); sync()
-    return time.perf_counter() - t0
+    """W untimed warm-ups, then exactly K steps between (sync, barrier, sync) brackets -> seconds on this rank.
+    The interpreter's objects are frozen out of CPython's cyclic collector for the duration (bench_legs.QuietGC: a generation-2
+    pass after `import torch` stops the host thread for ~40 ms, ten steps' worth, at an arbitrary iteration); collections that
+    still run inside the bracket are kept in time_steps.gc_inside (the line reports them)."""
+    from bench_legs import QuietGC
+    with QuietGC() as quiet:
+        for _ in range(warmup):
+            step()
+        sync(); barrier(); sync()
+        quiet.events.clear()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        sync(); barrier(); sync()
+        el = time.perf_counter() - t0
+    time_steps.gc_inside = quiet.summary()
+    return el
+
+
+time_steps.gc_inside = None
 
 
 # What each row of the hot path is pinned to (SURVEY.md 0, 8c): a reader of the line alone must not mistake "bit-exact vs the
@@ -388,17 +399,30 @@ def end_to_end_leg(frames, W, H, B, R, device, n_frames=300):
             prev = t
         ctx.frame_wait(prev)
 
+    # Every number of this leg is the MEDIAN of `repeats` runs of n_frames frames, with the fastest and the slowest beside it
+    # (one-shot timings of a host loop made round 4's read_ahead look 3x slower than round 3's -- a 40 ms
+    # generation-2 pass of CPython's garbage collector landed in that loop; bench_legs.QuietGC, profiles/r05/read_ahead_bisect.txt).
+    from bench_legs import QuietGC, median_min_max
+    repeats = 7
+
     def timed(fn, *a):
         fn(20, *a)
-        t0 = time.perf_counter()
-        fn(n_frames, *a)
-        return (time.perf_counter() - t0) / n_frames
+        v = []
+        for _ in range(repeats):
+            t0 = time.perf_counter()
+            fn(n_frames, *a)
+            v.append((time.perf_counter() - t0) / n_frames * 1e3)
+        return median_min_max(v)
 
-    def row(sec, **extra):
-        return dict({"ms_per_frame": round(sec * 1e3, 4), "Mvectors_per_s": round(nblk / sec / 1e6, 2)}, **extra)
-    s = timed(run_sync)
-    a = timed(run_read_ahead, False)
-    c = timed(run_read_ahead, True)
+    def row(mm, **extra):
+        sec = mm["median"] * 1e-3
+        return dict({"ms_per_frame": mm["median"], "ms_per_frame_min": mm["min"], "ms_per_frame_max": mm["max"], "repeats": mm["repeats"],
+                     "Mvectors_per_s": round(nblk / sec / 1e6, 2)}, **extra)
+    with QuietGC() as quiet:
+        s = timed(run_sync)
+        a = timed(run_read_ahead, False)
+        c = timed(run_read_ahead, True)
+    gc_inside = quiet.summary()
     # the link itself, measured in this run: 16 frames' worth of page-locked bytes host -> device in one copy, and one frame
     # alone (what a per-frame upload pays); the ceiling below is derived from the first, not from a constant
     big = ctx.pinned_frame(16 * H, W)
@@ -410,12 +434,16 @@ def end_to_end_leg(frames, W, H, B, R, device, n_frames=300):
         for _ in range(reps):
             ctx.memcpy_h2d(d_big, arr)
         return arr.nbytes * reps / (time.perf_counter() - t0) / 1e9
-    h2d_bulk, h2d_frame = h2d_rate(big, 20), h2d_rate(pins[0], 200)
+    h2d_bulk = median_min_max([h2d_rate(big, 20) for _ in range(5)], 1)["median"]
+    h2d_frame = median_min_max([h2d_rate(pins[0], 200) for _ in range(5)], 1)["median"]
     ctx.free(d_big)
     ceiling = nblk / (W * H / (h2d_bulk * 1e9)) / 1e6
     out = {"what": "Decoder::process_frame shape: one luma frame H2D from page-locked memory per call, previous frame resident, "
                    "vectors D2H to page-locked memory",
            "frames": n_frames, "bytes_h2d_per_frame": W * H, "bytes_d2h_per_frame": 16 * nblk,
+           "timing": f"median of {repeats} runs of {n_frames} frames per form (min / max beside it); objects alive at the start are frozen out of "
+                     "CPython's collector for the timed loops, collections that still ran inside them are counted here",
+           "python_gc_inside_timed_loops": gc_inside,
            "h2d_GBs_measured": {"bulk_16_frames_per_copy": round(h2d_bulk, 1), "one_frame_per_blocking_copy": round(h2d_frame, 1)},
            "pcie_ceiling_Mvectors_per_s": round(ceiling, 1),
            "pcie_ceiling_basis": "every frame crosses the link once: vectors per frame / (frame bytes / the bulk H2D rate measured in this run)",
@@ -429,17 +457,20 @@ def end_to_end_leg(frames, W, H, B, R, device, n_frames=300):
         from ofps_amd.build import TOOL
         if (W, H, B, R) == (1920, 1080, 16, 16) and os.path.exists(TOOL):
             env = dict(os.environ, HIP_VISIBLE_DEVICES=os.environ.get("HIP_VISIBLE_DEVICES", str(device)))
+            def native(*mode_args, runs=5):
+                rs = [json.loads(subprocess.run([TOOL, "stream-bench", str(W), str(H)] + list(mode_args), capture_output=True, text=True,
+                                                timeout=120, env=env, check=True).stdout.strip().splitlines()[-1]) for _ in range(runs)]
+                mm = median_min_max([r["ms_per_frame"] for r in rs])
+                return rs[0], {"ms_per_frame": mm["median"], "ms_per_frame_min": mm["min"], "ms_per_frame_max": mm["max"], "repeats": runs,
+                               "Mvectors_per_s": round(nblk / (mm["median"] * 1e-3) / 1e6, 2)}
             for mode, key in (("sync", "sync_native_host"), ("ahead", "read_ahead_native_host")):
-                r = json.loads(subprocess.run([TOOL, "stream-bench", str(W), str(H), "1000", mode], capture_output=True, text=True,
-                                              timeout=120, env=env, check=True).stdout.strip().splitlines()[-1])
-                out[key] = {"ms_per_frame": r["ms_per_frame"], "Mvectors_per_s": r["Mvectors_per_s"],
-                            "entry_points": "C++ host layer, frames already in page-locked memory"}
-            r = json.loads(subprocess.run([TOOL, "stream-bench", str(W), str(H), "1024", "batch", "16"], capture_output=True, text=True,
-                                          timeout=120, env=env, check=True).stdout.strip().splitlines()[-1])
-            out["read_ahead_batched_native_host"] = {"ms_per_frame": r["ms_per_frame"], "Mvectors_per_s": r["Mvectors_per_s"], "batch": r["batch"],
-                                                     "entry_points": "ofps_hip_push_frames_async + ofps_hip_frames_wait: 16 frames per ticket, 2 tickets "
-                                                                     "in flight, one H2D + one search launch + one read-back per batch",
-                                                     "frac_of_measured_pcie_ceiling": round(r["Mvectors_per_s"] / ceiling, 3)}
+                _, r = native("1000", mode)
+                out[key] = dict(r, entry_points="C++ host layer, frames already in page-locked memory; each repeat a fresh process")
+            r0, r = native("1024", "batch", "16")
+            out["read_ahead_batched_native_host"] = dict(r, batch=r0["batch"],
+                                                         entry_points="ofps_hip_push_frames_async + ofps_hip_frames_wait: 16 frames per ticket, 2 tickets "
+                                                                      "in flight, one H2D + one search launch + one read-back per batch",
+                                                         frac_of_measured_pcie_ceiling=round(r["Mvectors_per_s"] / ceiling, 3))
     except Exception as e:                                    # the tool is optional evidence, never the bench line
         out["native_host_error"] = repr(e)[:200]
     return out
@@ -560,6 +591,7 @@ def run_rank(args) -> int:
                 kernel_only()
             sync()
     el_local = time_steps(step, args.steps, args.warmup, sync, barrier)
+    gc_main = time_steps.gc_inside
     el = D.max_over_ranks(el_local, device=dev)
     el_min = -D.max_over_ranks(-el_local, device=dev)
 
@@ -629,6 +661,7 @@ def run_rank(args) -> int:
         out["launcher"] = (("torchrun (one process per GPU, RCCL)" if args.backend == "nccl" else
                             "torchrun (one process per rank, gloo: host-side collectives)") if D.active() else "single process")
         out["per_rank_ms_per_step"] = {"min": round(el_min / args.steps * 1e3, 4), "max": round(el / args.steps * 1e3, 4)}
+        out["python_gc_inside_timed_region"] = gc_main
         if gather_ms is not None:
             out["gather_ms_per_step"] = round(gather_ms, 4)
         if d2h_ms is not None:

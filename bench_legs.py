@@ -42,6 +42,47 @@ LK_SPEC_FLOPS_PER_TAP = 11                                 # DESIGN.md N2, spec 
 LK_SPEC_INSTR_PER_TAP = 7
 
 
+class QuietGC:
+    """CPython's cyclic collector inside a host-timed loop is an artefact of the measuring process, not of the path measured: after
+    `import torch` a generation-2 collection walks ~170,000 objects and stops the thread for 35-50 ms -- once, at an allocation
+    count that lands in whichever loop happens to be running (round 4: 40 ms inside the 300-frame read-ahead loop = +0.13 ms per
+    frame; round 3: the same pause inside the host-copy loop; profiles/r05/read_ahead_bisect.txt).  Inside the block everything
+    alive is moved to the permanent generation (gc.freeze, what a long-running Python host does after start-up); the young
+    generations keep running, and every collection that still happens inside the block is counted and timed, so a number
+    measured here says what the collector cost it."""
+
+    def __enter__(self):
+        import gc
+        self._gc = gc
+        gc.collect()
+        gc.freeze()
+        self.events = []                                      # [generation, ms]
+        self._t = 0.0
+
+        def cb(phase, info):
+            if phase == "start":
+                self._t = time.perf_counter()
+            else:
+                self.events.append([info["generation"], round((time.perf_counter() - self._t) * 1e3, 3)])
+        self._cb = cb
+        gc.callbacks.append(cb)
+        return self
+
+    def __exit__(self, *exc):
+        self._gc.callbacks.remove(self._cb)
+        self._gc.unfreeze()
+        return False
+
+    def summary(self):
+        return {"collections": len(self.events), "oldest_generation": max((e[0] for e in self.events), default=None),
+                "total_ms": round(sum(e[1] for e in self.events), 3), "longest_ms": max((e[1] for e in self.events), default=0.0)}
+
+
+def median_min_max(values, digits=4):
+    v = sorted(values)
+    return {"median": round(v[len(v) // 2], digits), "min": round(v[0], digits), "max": round(v[-1], digits), "repeats": len(v)}
+
+
 def _event_ms(ctx, fn, reps, warm=25):
     """Average milliseconds of fn() between HIP events on the context's stream."""
     for _ in range(warm):
@@ -71,6 +112,7 @@ def cfg3_chain_leg(device: int = 0, reps: int = 60) -> dict:
     taps = px * IT * (2 * RAD + 1) ** 2
     per = {}
     kept = {}
+    waits0 = ctx.lk_wait_timeouts()
     for name, fr in contents.items():
         dfr = torch.from_numpy(fr).cuda()
 
@@ -101,6 +143,11 @@ def cfg3_chain_leg(device: int = 0, reps: int = 60) -> dict:
                      "lk_frac_of_f32_peak": round(taps * LK_SPEC_FLOPS_PER_TAP / (lk_ms * 1e-3) / VALU_F32_PEAK_FLOPS, 4)}
         kept[name] = (d_ent.cpu().numpy(), d_q.cpu().numpy()[0], d_fld.cpu().numpy())
         del dfr
+    # lk_flow_dev cannot repair an expired parent-tile wait of the one-launch pyramid itself (include/ofps_hip.h): a timed region in
+    # which one expired would have measured flows with broken dependencies -- refused, not published
+    lk_waits = ctx.lk_wait_timeouts() - waits0
+    if lk_waits:
+        raise RuntimeError(f"cfg3 leg: {lk_waits} parent-tile waits of the LK pyramid expired inside the timed region")
     ctx.close()
     lk_ms, alm_ms = per["pm3"]["lk_ms"], per["pm3"]["almeida_ms"]
     out = {"what": "BASELINE configs[2]: 1080p pair -> 3-level LK (r=4, 3 steps) -> 2,073,600 per-pixel records -> densify 150x84 "
@@ -110,6 +157,7 @@ def cfg3_chain_leg(device: int = 0, reps: int = 60) -> dict:
            # the round-3 keys, on the +-3 content (continuity)
            "lk_ms": per["pm3"]["lk_ms"], "densify_ms": per["pm3"]["densify_ms"], "almeida_ms": per["pm3"]["almeida_ms"],
            "chain_ms": per["pm3"]["chain_ms"], "Mvectors_per_s_chain": per["pm3"]["Mvectors_per_s_chain"], "reps": reps,
+           "lk_expired_parent_waits_in_timed_region": lk_waits,
            "roofline_lk": {"bound": "valu_f32", "unit": "TFLOP/s", "spec_flops_per_pair": taps * LK_SPEC_FLOPS_PER_TAP,
                            "achieved": round(taps * LK_SPEC_FLOPS_PER_TAP / (lk_ms * 1e-3) / 1e12, 3), "peak": round(VALU_F32_PEAK_FLOPS / 1e12, 2),
                            "frac": round(taps * LK_SPEC_FLOPS_PER_TAP / (lk_ms * 1e-3) / VALU_F32_PEAK_FLOPS, 4),
@@ -320,7 +368,9 @@ def all_legs(device: int = 0) -> dict:
     for name, fn in (("cfg3_chain", cfg3_chain_leg), ("cfg4", cfg4_leg), ("cfg5_stream", cfg5_both_leg)):
         t0 = time.perf_counter()
         try:
-            out[name] = fn(device)
+            with QuietGC() as quiet:                            # host-timed loops inside: see QuietGC
+                out[name] = fn(device)
+            out[name]["python_gc_inside_leg"] = quiet.summary()
         except Exception as e:                                  # a leg is evidence beside the bench line, never the line itself
             out[name] = {"error": repr(e)[:300]}
         out[name]["leg_wall_s"] = round(time.perf_counter() - t0, 1)
@@ -334,7 +384,9 @@ if __name__ == "__main__":
         res = {}
         for nme in only:
             t0 = time.perf_counter()
-            res[nme] = legs[nme](0)
+            with QuietGC() as quiet:
+                res[nme] = legs[nme](0)
+            res[nme]["python_gc_inside_leg"] = quiet.summary()
             res[nme]["leg_wall_s"] = round(time.perf_counter() - t0, 1)
     else:
         res = all_legs(0)

@@ -46,7 +46,8 @@ enum {
     OFPS_HIP_EINVAL = -1,      /* bad argument (message says which) */
     OFPS_HIP_EDEVICE = -2,     /* HIP runtime error / no device */
     OFPS_HIP_EUNSUPPORTED = -3, /* parameter combination has no kernel */
-    OFPS_HIP_ENOMEM = -4
+    OFPS_HIP_ENOMEM = -4,
+    OFPS_HIP_ESTALE = -5       /* ofps_hip_sync only: a device-pointer LK call since the last sync must be repeated (see ofps_hip_lk_flow_dev) */
 };
 
 typedef struct ofps_hip_ctx ofps_hip_ctx;
@@ -128,14 +129,16 @@ int ofps_hip_lk_flow(ofps_hip_ctx* ctx, const uint8_t* prev, const uint8_t* cur,
  * A/B builds).  The oracle exports the same number (orc_lk_spec_revision); the parity tests assert they agree. */
 int ofps_hip_lk_spec_revision(void);
 /* Diagnostics (synchronises): the flow runs its whole pyramid as ONE launch in which a tile waits -- bounded, ~0.3 s -- for its parent
- * tile of the coarser level to publish its flows; a wait that expired (it cannot while workgroups are dispatched in block order) is
- * counted here since the flag buffer was last allocated.  The entry points that hand results to the HOST (ofps_hip_lk_flow,
- * ofps_hip_lk_decode, ofps_hip_lk_push_frame, ofps_hip_lk_frame_wait) see the count arrive with their results and, if it moved,
- * repeat the call with one launch per pyramid level (nothing waits there) before they return: their results always had all their
- * dependencies, and ofps_hip_lk_recoveries counts the repeats.  The device-pointer entry points (ofps_hip_lk_flow_dev,
- * ofps_hip_lk_flow_init_dev) cannot look without synchronising: a caller that needs the guarantee checks this count after its
- * own synchronisation (unchanged = every flow since had its dependencies) or sets OFPS_HIP_LK_SERIAL=1.  The counterpart of
- * ofps_hip_almeida_recoveries for the other spin-waiting kernel. */
+ * tile of the coarser level to publish its flows; a wait that expired (it cannot while workgroups are dispatched in block order: an
+ * assumption about the dispatcher, INTEGRATION.md "Forward progress") is counted here since the flag buffer was last allocated.
+ * The entry points that hand results to the HOST (ofps_hip_lk_flow, ofps_hip_lk_decode, ofps_hip_lk_push_frame,
+ * ofps_hip_lk_frame_wait) see, with their results, whether THEIR launch had an expired wait (each call compares with its own
+ * launch's epoch) and, if so, repeat the call with one launch per pyramid level (nothing waits there) before they return: their
+ * results always had all their dependencies, and ofps_hip_lk_recoveries counts the repeats.  The device-pointer entry points
+ * (ofps_hip_lk_flow_dev, ofps_hip_lk_flow_init_dev) return before anything ran: the next ofps_hip_sync() returns OFPS_HIP_ESTALE
+ * -- once -- when one of their launches since the previous ofps_hip_sync had an expired wait; the caller repeats those calls
+ * (or sets OFPS_HIP_LK_SERIAL=1).  A caller that synchronises its own stream instead checks this count (unchanged = every flow
+ * since had its dependencies).  The counterpart of ofps_hip_almeida_recoveries for the other spin-waiting kernel. */
 int ofps_hip_lk_wait_timeouts(ofps_hip_ctx* ctx, uint64_t* count);
 int ofps_hip_lk_recoveries(ofps_hip_ctx* ctx, uint64_t* count);
 /* cv-decoder's contrast mask (cv-decoder/src/lib.rs:203-237): Sobel(gray, CV_32F, 1, 1, ksize 5) -> threshold(> 20)

@@ -46,7 +46,7 @@ struct ofps_hip_ctx {
     uint64_t lk_frames_gen = 0;          // generation of the S_LK_FRAMES allocation the count refers to
     uint32_t lk_epoch = 0;               // lk_levels_kernel: tag of the last launch in the tile flags (S_LK_FLAGS)
     uint64_t lk_flags_gen = 0;           // generation of the flag buffer the tags refer to
-    uint32_t lk_timeouts_seen = 0;       // expired parent-tile waits (word 0 of the flag buffer) the host has accounted for
+    uint32_t lk_dev_unchecked_epoch = 0; // epoch of the first device-pointer LK launch since ofps_hip_sync last looked (0 = none)
     uint64_t lk_recoveries = 0;          // calls repeated level by level because a wait had expired (ofps_hip_lk_recoveries)
     void* lk_pinned = nullptr;           // page-locked staging for a frame's records + their count (one D2H, one wait)
     size_t lk_pinned_cap = 0;
@@ -63,7 +63,7 @@ struct ofps_hip_ctx {
         size_t max_records = 0;
         long fixed_count = -1;           // >= 0: the record count is known on the host (per-pixel output without a mask)
         // what the ticket computed, for the repeat after an expired parent-tile wait (lk.hip: ofps_hip_lk_frame_wait)
-        bool wired = false;              // the block's second word carries the device's expired-wait count
+        uint32_t epoch = 0;              // the flow launch's epoch (0: nothing to compare the block's second word with)
         const uint8_t* d_prev = nullptr; const uint8_t* d_cur = nullptr;
         int W = 0, H = 0, levels = 0, radius = 0, iters = 0, max_w = 0, max_h = 0;
         unsigned flags = 0;
@@ -136,6 +136,18 @@ enum ScratchSlot {
 };
 static_assert(S_LK_FLAGS < ofps_hip_ctx::kNumScratch, "scratch table too small");
 
+// Page-locked blocks that kernels write directly and the host reads after an event (ticket result blocks, ofps_hip_host_alloc):
+// fine-grained host memory, asked for explicitly.  A/B builds (tools/read_ahead_bisect.sh) override the two constants with -D.
+#ifndef OFPS_HIP_HOST_BLOCK_FLAGS
+#define OFPS_HIP_HOST_BLOCK_FLAGS hipHostMallocCoherent
+#endif
+#ifndef OFPS_HIP_HOST_USER_FLAGS
+#define OFPS_HIP_HOST_USER_FLAGS hipHostMallocCoherent
+#endif
+#ifndef OFPS_HIP_FRAME_WAIT_SPIN_US
+#define OFPS_HIP_FRAME_WAIT_SPIN_US 500
+#endif
+
 int set_error(ofps_hip_ctx* ctx, int code, const char* fmt, ...);
 int check_hip(ofps_hip_ctx* ctx, hipError_t e, const char* what);
 // returns nullptr (and sets the error) on failure
@@ -161,6 +173,7 @@ int compact_entries_device(ofps_hip_ctx* ctx, const float4* d_in, const uint8_t*
                            uint32_t* d_count);
 int detect_device(ofps_hip_ctx* ctx, const float4* d_entries, size_t n, int batch, float min_size, size_t subdivide,
                   float target_motion, int* d_result, float2* d_out_field, int* out_dim);
+int lk_check_dev_calls(ofps_hip_ctx* ctx);          // lk.hip: did a device-pointer LK launch since the last look have an expired wait?
 int almeida_device(ofps_hip_ctx* ctx, const float4* d_entries, size_t n, int batch, float aspect, float fov_y_deg,
                    int use_ransac, size_t num_iters, float inlier_deg, size_t num_samples, uint64_t seed, float4* d_quat);
 

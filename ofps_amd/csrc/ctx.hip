@@ -253,7 +253,8 @@ int ofps_hip_sync(ofps_hip_ctx* ctx) {
     if (!ctx) return OFPS_HIP_EINVAL;
     OFPS_HIP_TRY(ctx, hipSetDevice(ctx->device));
     OFPS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    return OFPS_HIP_OK;
+    // device-pointer LK calls cannot repair an expired parent-tile wait themselves: reported here, once (OFPS_HIP_ESTALE)
+    return ofps::lk_check_dev_calls(ctx);
 }
 
 int ofps_hip_malloc(ofps_hip_ctx* ctx, size_t bytes, void** dptr) {
@@ -276,7 +277,7 @@ int ofps_hip_host_alloc(ofps_hip_ctx* ctx, size_t bytes, void** hptr) {
     OFPS_HIP_TRY(ctx, hipSetDevice(ctx->device));
     // fine-grained (coherent) explicitly: callers hand these buffers to push_frame_async as out_entries / out_field, which
     // kernels write directly and the host reads after an event without a system-scope release of its own
-    OFPS_HIP_TRY(ctx, hipHostMalloc(hptr, bytes ? bytes : 16, hipHostMallocCoherent));
+    OFPS_HIP_TRY(ctx, hipHostMalloc(hptr, bytes ? bytes : 16, OFPS_HIP_HOST_USER_FLAGS));
     return OFPS_HIP_OK;
 }
 

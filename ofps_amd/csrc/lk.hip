@@ -993,7 +993,9 @@ __device__ __forceinline__ void lk_level_body(LkStepShared<RADIUS>& sh, const vo
             } while (--budget);
             // never silent: counted (ofps_hip_lk_wait_timeouts); the host-output entry points see the count with their results and
             // repeat the call level by level (lk_flow_device: serial), the device-pointer ones document the check
-            if (!budget && timeouts) atomicAdd(timeouts, 1u);
+            // word 0: running count (diagnostics); word 1: the epoch of the newest launch in which a wait expired -- what a call
+            // compares with ITS launch's epoch, so concurrent tickets and calls never share a watermark
+            if (!budget && timeouts) { atomicAdd(timeouts, 1u); atomicMax(timeouts + 1, epoch); }
         }
         __syncthreads();
     }
@@ -1672,7 +1674,7 @@ int lk_flow_device(ofps_hip_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_cu
             OFPS_HIP_TRY(ctx, hipMemsetAsync(flags, 0, ctx->scratch[S_LK_FLAGS].cap, s));
             ctx->lk_flags_gen = ctx->scratch[S_LK_FLAGS].gen;
             ctx->lk_epoch = 0;
-            ctx->lk_timeouts_seen = 0;
+            ctx->lk_dev_unchecked_epoch = 0;                     // (what the old buffer said about earlier device-pointer calls is gone with it)
         }
         A.epoch = ++ctx->lk_epoch;
         A.flags = flags;
@@ -1756,10 +1758,45 @@ int ofps_hip_lk_wait_timeouts(ofps_hip_ctx* ctx, uint64_t* count) {
     return OFPS_HIP_OK;
 }
 
+}  // extern "C"
+
+namespace ofps {
+// ofps_hip_sync's look at the device-pointer LK calls since the last look (the stream has just been synchronised)
+int lk_check_dev_calls(ofps_hip_ctx* ctx) {
+    const uint32_t first = ctx->lk_dev_unchecked_epoch;
+    if (!first) return OFPS_HIP_OK;
+    ctx->lk_dev_unchecked_epoch = 0;
+    const void* d = ctx->scratch[S_LK_FLAGS].p;
+    if (!d) return OFPS_HIP_OK;
+    uint32_t newest = 0;
+    OFPS_HIP_TRY(ctx, hipMemcpy(&newest, static_cast<const uint32_t*>(d) + 1, sizeof(newest), hipMemcpyDeviceToHost));
+    if (newest >= first)
+        return set_error(ctx, OFPS_HIP_ESTALE, "lk_flow_dev: a parent-tile wait of the one-launch pyramid expired in a launch since the last "
+                         "ofps_hip_sync (launch %u; first unchecked %u): the flow / records of the device-pointer LK calls since then may "
+                         "come from unfinished coarse levels -- repeat them (OFPS_HIP_LK_SERIAL=1 runs one launch per level)", newest, first);
+    return OFPS_HIP_OK;
+}
+}  // namespace ofps
+
+extern "C" {
+
 int ofps_hip_lk_recoveries(ofps_hip_ctx* ctx, uint64_t* count) {
     if (!ctx || !count) return OFPS_HIP_EINVAL;
     *count = ctx->lk_recoveries;
     return OFPS_HIP_OK;
+}
+
+// The device-pointer forms return before anything ran, so an expired parent-tile wait cannot be repaired inside the call the way
+// the host-output forms do it: the first such call since the last check is remembered, and the next ofps_hip_sync() looks at the
+// flag buffer's "newest epoch with an expired wait" and answers OFPS_HIP_ESTALE once if it is one of theirs.
+static int lk_flow_dev_call(ofps_hip_ctx* ctx, const void* d_prev, const void* d_cur, int W, int H, int stride, int levels, int radius,
+                            int iters, const void* d_init, void* d_out_flow, void* d_out_entries) {
+    const int rc = ofps::lk_flow_device(ctx, static_cast<const uint8_t*>(d_prev), static_cast<const uint8_t*>(d_cur), W, H, stride, levels,
+                                        radius, iters, static_cast<float2*>(d_out_flow), static_cast<float4*>(d_out_entries),
+                                        static_cast<const float2*>(d_init));
+    if (rc == OFPS_HIP_OK && (radius == 2 || radius == 4 || radius == 6) && !ctx->opt.lk_serial && !ctx->lk_dev_unchecked_epoch)
+        ctx->lk_dev_unchecked_epoch = ctx->lk_epoch;             // the epoch lk_flow_device just launched with
+    return rc;
 }
 
 int ofps_hip_lk_flow_dev(ofps_hip_ctx* ctx, const void* d_prev, const void* d_cur, int W, int H, int stride, int levels,
@@ -1767,8 +1804,7 @@ int ofps_hip_lk_flow_dev(ofps_hip_ctx* ctx, const void* d_prev, const void* d_cu
     if (!ctx) return OFPS_HIP_EINVAL;
     OFPS_REQUIRE(ctx, d_prev && d_cur && (d_out_flow || d_out_entries), "lk_flow: null device pointer");
     OFPS_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    return ofps::lk_flow_device(ctx, static_cast<const uint8_t*>(d_prev), static_cast<const uint8_t*>(d_cur), W, H, stride, levels,
-                                radius, iters, static_cast<float2*>(d_out_flow), static_cast<float4*>(d_out_entries));
+    return lk_flow_dev_call(ctx, d_prev, d_cur, W, H, stride, levels, radius, iters, nullptr, d_out_flow, d_out_entries);
 }
 
 int ofps_hip_lk_flow_init_dev(ofps_hip_ctx* ctx, const void* d_prev, const void* d_cur, int W, int H, int stride, int levels,
@@ -1776,9 +1812,7 @@ int ofps_hip_lk_flow_init_dev(ofps_hip_ctx* ctx, const void* d_prev, const void*
     if (!ctx) return OFPS_HIP_EINVAL;
     OFPS_REQUIRE(ctx, d_prev && d_cur && (d_out_flow || d_out_entries), "lk_flow_init: null device pointer");
     OFPS_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    return ofps::lk_flow_device(ctx, static_cast<const uint8_t*>(d_prev), static_cast<const uint8_t*>(d_cur), W, H, stride, levels,
-                                radius, iters, static_cast<float2*>(d_out_flow), static_cast<float4*>(d_out_entries),
-                                static_cast<const float2*>(d_init_flow));
+    return lk_flow_dev_call(ctx, d_prev, d_cur, W, H, stride, levels, radius, iters, d_init_flow, d_out_flow, d_out_entries);
 }
 
 // The body of a "hip_lk" Decoder::process_frame (cv-decoder/src/lib.rs:82-294): dense flow, per-pixel records,
@@ -1820,19 +1854,18 @@ __global__ __launch_bounds__(256) void lk_copy_records_kernel(const float4* __re
     if (cnt_dst && blockIdx.x == 0 && threadIdx.x == 0) { *cnt_dst = (uint32_t)n; if (aux_src) cnt_dst[1] = *aux_src; }
 }
 
-// Expired parent-tile waits of the one-launch pyramid (lk_level_body): word 0 of the flag buffer counts them; the decoder's last
-// kernel copies the count into the second word of the frame's page-locked block, so the host sees with the records whether the
-// flow that made them may have started a tile from unfinished parent flows -- and repeats the frame level by level if so.
+// Expired parent-tile waits of the one-launch pyramid (lk_level_body): word 0 of the flag buffer counts them, word 1 holds the epoch
+// of the newest launch in which one expired.  The decoder's last kernel copies word 1 into the second word of the frame's
+// page-locked block; launches of one context run in stream order, so what that kernel reads is >= the epoch of the frame's own
+// launch exactly when that launch had an expired wait.  The host then sees with the records whether the flow that made them may
+// have started a tile from unfinished parent flows -- and repeats the frame level by level if so.  Every call / ticket compares
+// with its own launch's epoch: no watermark shared between calls.
 bool lk_is_tiled(int radius) { return radius == 2 || radius == 4 || radius == 6; }
-const uint32_t* lk_timeout_word(ofps_hip_ctx* ctx, int radius) {
-    return lk_is_tiled(radius) ? static_cast<const uint32_t*>(ctx->scratch[ofps::S_LK_FLAGS].p) : nullptr;
+const uint32_t* lk_stale_word(ofps_hip_ctx* ctx, int radius) {
+    return lk_is_tiled(radius) ? static_cast<const uint32_t*>(ctx->scratch[ofps::S_LK_FLAGS].p) + 1 : nullptr;
 }
-// -> waits expired in the launches since the last look; `count` is the device's running count as the caller's results saw it
-bool lk_waits_expired(ofps_hip_ctx* ctx, uint32_t count) {
-    const bool hit = count != ctx->lk_timeouts_seen;
-    ctx->lk_timeouts_seen = count;
-    return hit;
-}
+// `seen`: flag word 1 as the call's results saw it; `epoch`: the call's own launch
+bool lk_waits_expired(uint32_t seen, uint32_t epoch) { return epoch != 0 && seen >= epoch; }
 uint32_t lk_block_waits(const void* pinned) {
     uint32_t c = 0;
     memcpy(&c, static_cast<const char*>(pinned) + 4, sizeof(c));
@@ -1842,9 +1875,10 @@ uint32_t lk_block_waits(const void* pinned) {
 // Enqueues everything of a process_frame that follows the uploads on ctx->stream: flow [-> contrast mask] -> output stage.
 // The record count lands at cnt_dst and the records at rec_dst -- device scratch, or the device address of a page-locked
 // block (the kernels store there directly: no read-back launch of their own).
-// serial: the pyramid level by level (the repeat after an expired wait).  *wired: the block's second word carries the wait count.
+// serial: the pyramid level by level (the repeat after an expired wait).  *epoch: the flow launch's epoch when the block's second
+// word carries flag word 1 (0 otherwise: nothing to compare).
 int lk_enqueue_frame(ofps_hip_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_cur, int W, int H, int levels, int radius, int iters,
-                     const LkGrid& g, float4* rec_dst, uint32_t* cnt_dst, bool serial, bool* wired) {
+                     const LkGrid& g, float4* rec_dst, uint32_t* cnt_dst, bool serial, uint32_t* epoch) {
     const size_t px = (size_t)W * H, cells = g.per_pixel ? 1 : (size_t)g.gw * g.gh;
     auto* d_ent = static_cast<float4*>(ofps::scratch(ctx, ofps::S_ENTRIES, px * sizeof(float4)));
     auto* d_field = static_cast<float2*>(ofps::scratch(ctx, ofps::S_FIELD, cells * sizeof(float2)));
@@ -1852,8 +1886,8 @@ int lk_enqueue_frame(ofps_hip_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_
     if (!d_ent || !d_field || !d_cnt) return OFPS_HIP_ENOMEM;
     int rc = ofps::lk_flow_device(ctx, d_prev, d_cur, W, H, W, levels, radius, iters, nullptr, d_ent, nullptr, serial);
     if (rc != OFPS_HIP_OK) return rc;
-    const uint32_t* d_waits = lk_timeout_word(ctx, radius);
-    *wired = d_waits != nullptr;
+    const uint32_t* d_waits = lk_stale_word(ctx, radius);
+    *epoch = d_waits && !serial && !ctx->opt.lk_serial ? ctx->lk_epoch : 0;
     const uint8_t* d_mask = nullptr;
     if (g.use_mask) {
         auto* m = static_cast<uint8_t*>(ofps::scratch(ctx, ofps::S_MASK, px));
@@ -1886,7 +1920,7 @@ int lk_pinned_block(ofps_hip_ctx* ctx, void** p, size_t* cap, size_t max_records
     const size_t need = 16 + max_records * sizeof(float4);
     if (*cap >= need) return OFPS_HIP_OK;
     if (*p) { OFPS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); OFPS_HIP_TRY(ctx, hipHostFree(*p)); *p = nullptr; *cap = 0; }
-    OFPS_HIP_TRY(ctx, hipHostMalloc(p, need, hipHostMallocCoherent));      // fine-grained: kernels write it, the host reads it after an event
+    OFPS_HIP_TRY(ctx, hipHostMalloc(p, need, OFPS_HIP_HOST_BLOCK_FLAGS));      // fine-grained: kernels write it, the host reads it after an event
     *cap = need;
     return OFPS_HIP_OK;
 }
@@ -1947,14 +1981,14 @@ int ofps_hip_lk_decode(ofps_hip_ctx* ctx, const uint8_t* prev, const uint8_t* cu
     if (rc != OFPS_HIP_OK) return rc;
     void* mapped = nullptr;
     OFPS_REQUIRE(ctx, ofps::device_address_of(ctx->lk_pinned, &mapped), "lk_decode: page-locked block is not device-addressable");
-    bool wired = false;
+    uint32_t epoch = 0;
     rc = lk_enqueue_frame(ctx, d_frames, d_frames + px, W, H, levels, radius, iters, g, reinterpret_cast<float4*>(static_cast<char*>(mapped) + 16),
-                          static_cast<uint32_t*>(mapped), false, &wired);
+                          static_cast<uint32_t*>(mapped), false, &epoch);
     if (rc != OFPS_HIP_OK) return rc;
     OFPS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    if (wired && lk_waits_expired(ctx, lk_block_waits(ctx->lk_pinned))) {        // a tile may have started from unfinished parent flows: level by level
+    if (lk_waits_expired(lk_block_waits(ctx->lk_pinned), epoch)) {        // a tile may have started from unfinished parent flows: level by level
         rc = lk_enqueue_frame(ctx, d_frames, d_frames + px, W, H, levels, radius, iters, g, reinterpret_cast<float4*>(static_cast<char*>(mapped) + 16),
-                              static_cast<uint32_t*>(mapped), true, &wired);
+                              static_cast<uint32_t*>(mapped), true, &epoch);
         if (rc != OFPS_HIP_OK) return rc;
         OFPS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         ctx->lk_recoveries += 1;
@@ -1984,20 +2018,23 @@ int ofps_hip_lk_push_frame_async(ofps_hip_ctx* ctx, const uint8_t* frame, int W,
     auto& t = ctx->lk_ticket[tno % ofps_hip_ctx::kLkTickets];
     OFPS_REQUIRE(ctx, !t.pending, "lk_push_frame_async: ticket %ld has not been collected (at most %d frames in flight)",
                  tno - ofps_hip_ctx::kLkTickets, ofps_hip_ctx::kLkTickets);
-    if (ctx->lk_w != W || ctx->lk_h != H) {                         // a new geometry restarts the stream
+    const size_t px = (size_t)W * H;
+    // A new geometry restarts the stream and may reallocate the ring.  With a ticket in flight that would throw its records away
+    // (draining marks it collected: the caller's later lk_frame_wait would fail with "already collected"): refused, like the
+    // multi-device form does -- collect first, or ofps_hip_lk_reset.
+    const bool other_pending = ctx->lk_ticket[(tno + 1) % ofps_hip_ctx::kLkTickets].pending;
+    const bool restart = ctx->lk_w != W || ctx->lk_h != H || ctx->scratch[ofps::S_LK_FRAMES].cap < ofps_hip_ctx::kLkSlots * px;
+    OFPS_REQUIRE(ctx, !(restart && other_pending), "lk_push_frame_async: geometry change %dx%d -> %dx%d with a ticket in flight "
+                 "(collect it with ofps_hip_lk_frame_wait first)", ctx->lk_w, ctx->lk_h, W, H);
+    if (restart) {
         rc = lk_stream_drain(ctx);
         if (rc != OFPS_HIP_OK) return rc;
         ctx->lk_w = W; ctx->lk_h = H;
     }
-    const size_t px = (size_t)W * H;
     // the stream's frames have slots of their own: no other entry point (lk_decode, lk_flow, sad_flow, contrast_mask stage
     // their frames in S_FRAMES) can overwrite or reallocate a previous frame behind the stream's back.  Three slots: frame
     // k + 1 is uploaded (copy stream) into the slot of frame k - 2, whose last reader -- ticket k - 1 -- has been collected
     // by the time a third push is accepted.
-    if (ctx->scratch[ofps::S_LK_FRAMES].cap < ofps_hip_ctx::kLkSlots * px) {          // the ring is about to be (re)allocated: nothing may be in flight
-        rc = lk_stream_drain(ctx);
-        if (rc != OFPS_HIP_OK) return rc;
-    }
     auto* d_frames = static_cast<uint8_t*>(ofps::scratch(ctx, ofps::S_LK_FRAMES, ofps_hip_ctx::kLkSlots * px));
     if (!d_frames) return OFPS_HIP_ENOMEM;
     if (ctx->lk_frames_gen != ctx->scratch[ofps::S_LK_FRAMES].gen) {         // (re)allocated: whatever was there is gone
@@ -2007,7 +2044,7 @@ int ofps_hip_lk_push_frame_async(ofps_hip_ctx* ctx, const uint8_t* frame, int W,
     hipStream_t s = ctx->stream;
     // with another ticket in flight the upload goes to the copy stream and overlaps that ticket's flow; a lone frame is
     // copied on the compute stream itself (no cross-stream event on the latency path of the synchronous call)
-    const bool overlap = ctx->lk_ticket[(tno + 1) % ofps_hip_ctx::kLkTickets].pending;
+    const bool overlap = other_pending;
     const int slot = (int)(ctx->lk_frames % ofps_hip_ctx::kLkSlots);
     hipStream_t up = overlap ? ctx->lk_copy_stream : s;
     OFPS_HIP_TRY(ctx, ofps::upload_rows(d_frames + (size_t)slot * px, W, frame, stride, W, H, up));
@@ -2015,25 +2052,31 @@ int ofps_hip_lk_push_frame_async(ofps_hip_ctx* ctx, const uint8_t* frame, int W,
         OFPS_HIP_TRY(ctx, hipEventRecord(t.uploaded, up));
         OFPS_HIP_TRY(ctx, hipStreamWaitEvent(s, t.uploaded, 0));       // everything of this ticket on the compute stream comes after the upload
     }
-    ctx->lk_frames += 1;
-    t.have_vectors = 0; t.gw = g.gw; t.gh = g.gh; t.max_records = g.max_records; t.fixed_count = -1;
-    if (ctx->lk_frames >= 2) {                                      // cv-decoder/src/lib.rs:156-158: flow needs two frames
+    // the stream position and the ticket change only once everything is enqueued: a failure below leaves both as they were (the
+    // frame's slot is simply uploaded again by the next push) -- ADVICE r4
+    const long frames_after = ctx->lk_frames + 1;
+    int have_vectors = 0;
+    uint32_t epoch = 0;
+    const uint8_t *tp = nullptr, *tc = nullptr;
+    if (frames_after >= 2) {                                        // cv-decoder/src/lib.rs:156-158: flow needs two frames
         rc = lk_pinned_block(ctx, &t.pinned, &t.pinned_cap, g.max_records);
         if (rc != OFPS_HIP_OK) return rc;
         void* mapped = nullptr;
         OFPS_REQUIRE(ctx, ofps::device_address_of(t.pinned, &mapped), "lk_push_frame_async: page-locked block is not device-addressable");
-        const int prev_slot = (int)((ctx->lk_frames - 2) % ofps_hip_ctx::kLkSlots);
-        bool wired = false;
-        rc = lk_enqueue_frame(ctx, d_frames + (size_t)prev_slot * px, d_frames + (size_t)slot * px, W, H, levels, radius, iters, g,
-                              reinterpret_cast<float4*>(static_cast<char*>(mapped) + 16), static_cast<uint32_t*>(mapped), false, &wired);
+        const int prev_slot = (int)((frames_after - 2) % ofps_hip_ctx::kLkSlots);
+        tp = d_frames + (size_t)prev_slot * px; tc = d_frames + (size_t)slot * px;
+        rc = lk_enqueue_frame(ctx, tp, tc, W, H, levels, radius, iters, g,
+                              reinterpret_cast<float4*>(static_cast<char*>(mapped) + 16), static_cast<uint32_t*>(mapped), false, &epoch);
         if (rc != OFPS_HIP_OK) return rc;
-        t.have_vectors = 1;
-        // what a repeat of this ticket needs (ofps_hip_lk_frame_wait, after an expired wait): its two frames stay in the ring
-        // until the ticket after the next one is pushed, which cannot happen before this one is collected
-        t.wired = wired; t.d_prev = d_frames + (size_t)prev_slot * px; t.d_cur = d_frames + (size_t)slot * px;
-        t.W = W; t.H = H; t.levels = levels; t.radius = radius; t.iters = iters; t.max_w = max_w; t.max_h = max_h; t.flags = flags;
+        have_vectors = 1;
     }
     OFPS_HIP_TRY(ctx, hipEventRecord(t.done, s));
+    ctx->lk_frames = frames_after;
+    t.have_vectors = have_vectors; t.gw = g.gw; t.gh = g.gh; t.max_records = g.max_records; t.fixed_count = -1;
+    // what a repeat of this ticket needs (ofps_hip_lk_frame_wait, after an expired wait): its two frames stay in the ring
+    // until the ticket after the next one is pushed, which cannot happen before this one is collected
+    t.epoch = epoch; t.d_prev = tp; t.d_cur = tc;
+    t.W = W; t.H = H; t.levels = levels; t.radius = radius; t.iters = iters; t.max_w = max_w; t.max_h = max_h; t.flags = flags;
     t.pending = true;
     *ticket = (int)(tno & 0x7FFFFFFF);
     ctx->lk_next_ticket = tno + 1;
@@ -2057,17 +2100,17 @@ int ofps_hip_lk_frame_wait(ofps_hip_ctx* ctx, int ticket, float* out_entries, si
     *have_vectors = t.have_vectors;
     if (out_w) *out_w = t.gw;
     if (out_h) *out_h = t.gh;
-    if (t.have_vectors && t.wired && lk_waits_expired(ctx, lk_block_waits(t.pinned))) {
-        // (the count looked at is the one this ticket's last kernel saw; the repeat below rewrites the block, with whatever
-        // later tickets added -- theirs to notice when they are collected)
+    if (t.have_vectors && lk_waits_expired(lk_block_waits(t.pinned), t.epoch)) {
+        // (the word looked at is the one this ticket's last kernel saw, compared with this ticket's own launch; the repeat below
+        // rewrites the block; a later ticket compares what ITS last kernel saw with ITS epoch)
         LkGrid g;
         int rc = lk_grid_of(ctx, t.W, t.H, t.max_w, t.max_h, t.flags, &g);
         if (rc != OFPS_HIP_OK) return rc;
         void* mapped = nullptr;
         OFPS_REQUIRE(ctx, ofps::device_address_of(t.pinned, &mapped), "lk_frame_wait: page-locked block is not device-addressable");
-        bool wired = false;
+        uint32_t epoch = 0;
         rc = lk_enqueue_frame(ctx, t.d_prev, t.d_cur, t.W, t.H, t.levels, t.radius, t.iters, g,
-                              reinterpret_cast<float4*>(static_cast<char*>(mapped) + 16), static_cast<uint32_t*>(mapped), true, &wired);
+                              reinterpret_cast<float4*>(static_cast<char*>(mapped) + 16), static_cast<uint32_t*>(mapped), true, &epoch);
         if (rc != OFPS_HIP_OK) return rc;
         OFPS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         ctx->lk_recoveries += 1;
@@ -2108,19 +2151,20 @@ int ofps_hip_lk_flow(ofps_hip_ctx* ctx, const uint8_t* prev, const uint8_t* cur,
     if (!d_frames || !d_flow || (out_entries && !d_ent)) return OFPS_HIP_ENOMEM;
     OFPS_HIP_TRY(ctx, ofps::upload_rows(d_frames, W, prev, stride, W, H, ctx->stream));
     OFPS_HIP_TRY(ctx, ofps::upload_rows(d_frames + px, W, cur, stride, W, H, ctx->stream));
-    int rc = ofps_hip_lk_flow_dev(ctx, d_frames, d_frames + px, W, H, W, levels, radius, iters, d_flow, d_ent);
+    int rc = ofps::lk_flow_device(ctx, d_frames, d_frames + px, W, H, W, levels, radius, iters, d_flow, d_ent);
     if (rc != OFPS_HIP_OK) return rc;
+    const uint32_t epoch = lk_is_tiled(radius) && !ctx->opt.lk_serial ? ctx->lk_epoch : 0;     // this call's launch
     auto read_back = [&](uint32_t* waits) -> int {
         if (out_flow) OFPS_HIP_TRY(ctx, hipMemcpyAsync(out_flow, d_flow, px * sizeof(float2), hipMemcpyDeviceToHost, ctx->stream));
         if (out_entries) OFPS_HIP_TRY(ctx, hipMemcpyAsync(out_entries, d_ent, px * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
-        if (waits) OFPS_HIP_TRY(ctx, hipMemcpyAsync(waits, lk_timeout_word(ctx, radius), sizeof(*waits), hipMemcpyDeviceToHost, ctx->stream));
+        if (waits) OFPS_HIP_TRY(ctx, hipMemcpyAsync(waits, lk_stale_word(ctx, radius), sizeof(*waits), hipMemcpyDeviceToHost, ctx->stream));
         OFPS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         return OFPS_HIP_OK;
     };
-    uint32_t waits = ctx->lk_timeouts_seen;
-    rc = read_back(lk_timeout_word(ctx, radius) ? &waits : nullptr);
+    uint32_t waits = 0;
+    rc = read_back(epoch ? &waits : nullptr);
     if (rc != OFPS_HIP_OK) return rc;
-    if (lk_waits_expired(ctx, waits)) {                     // a tile may have started from unfinished parent flows: level by level
+    if (lk_waits_expired(waits, epoch)) {                     // a tile may have started from unfinished parent flows: level by level
         rc = ofps::lk_flow_device(ctx, d_frames, d_frames + px, W, H, W, levels, radius, iters, d_flow, d_ent, nullptr, true);
         if (rc != OFPS_HIP_OK) return rc;
         rc = read_back(nullptr);

@@ -66,7 +66,7 @@ int pipe_setup(ofps_hip_ctx* ctx) {
         // kernels store the result record straight into this block and the host reads it after a hipEventDisableTiming event
         // (no release-to-system fence of its own): the block must be FINE-GRAINED host memory whatever HIP_HOST_COHERENT or
         // a future runtime default says -- asked for explicitly
-        OFPS_HIP_TRY(ctx, hipHostMalloc(&t.pinned, sizeof(PipeOut), hipHostMallocCoherent));
+        OFPS_HIP_TRY(ctx, hipHostMalloc(&t.pinned, sizeof(PipeOut), OFPS_HIP_HOST_BLOCK_FLAGS));
     }
     return OFPS_HIP_OK;
 }
@@ -277,7 +277,7 @@ int ofps_hip_frame_wait(ofps_hip_ctx* ctx, int ticket, ofps_hip_frame_result* ou
         const auto t0 = std::chrono::steady_clock::now();
         hipError_t q;
         while ((q = hipEventQuery(t.done)) == hipErrorNotReady) {
-            if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(500)) break;
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(OFPS_HIP_FRAME_WAIT_SPIN_US)) break;
         }
         if (q != hipSuccess) {
             if (q != hipErrorNotReady) OFPS_HIP_TRY(ctx, q);
@@ -381,7 +381,7 @@ int push_frames_impl(ofps_hip_ctx* ctx, const uint8_t* frames, int n, int W, int
     if (t.pinned_cap < (size_t)n * kOutBytes) {
         if (t.pinned) OFPS_HIP_TRY(ctx, hipHostFree(t.pinned));
         t.pinned = nullptr; t.pinned_cap = 0;
-        OFPS_HIP_TRY(ctx, hipHostMalloc(&t.pinned, (size_t)n * kOutBytes, hipHostMallocCoherent));   // fine-grained: written by kernels, read after an event
+        OFPS_HIP_TRY(ctx, hipHostMalloc(&t.pinned, (size_t)n * kOutBytes, OFPS_HIP_HOST_BLOCK_FLAGS));   // fine-grained: written by kernels, read after an event
         t.pinned_cap = (size_t)n * kOutBytes;
     }
     hipStream_t s = ctx->stream, up = ctx->pipe_copy_stream;

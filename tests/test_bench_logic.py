@@ -106,3 +106,59 @@ def test_no_gpu_means_loud_failure():
     assert p.returncode != 0 and d is None and "no CPU fallback" in p.stderr
     p, d = _run("--gpus", "2", "--steps", "1")
     assert p.returncode != 0 and d is None and "GPU" in p.stderr
+
+
+# ---- the performance gate (tools/perf_gate.py)
+
+def _gate():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("perf_gate", os.path.join(ROOT, "tools", "perf_gate.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_perf_gate_would_have_caught_round_4s_read_ahead_leg():
+    """Round 4's committed line went out with the read-ahead loop three times slower than the synchronous call (a 40 ms
+    garbage-collector pause inside a one-shot timing) and the batched form at 0.79 of the PCIe ceiling measured in the same
+    run: the in-run relations of the gate fail on exactly those two."""
+    import json
+    g = _gate()
+    line = json.load(open(os.path.join(ROOT, "profiles", "r04", "bench_n1.json")))
+    rows = {name: ok for name, ok, _ in g.gate(line, line, 0.05)}
+    assert rows["read-ahead <= synchronous (Python loop)"] is False
+    assert rows["batched read-ahead >= 0.9 x PCIe ceiling of this run"] is False
+    assert rows["headline Mvectors/s (cfg2)"] and rows["cfg4 Mvectors/s"] and rows["parity_check.ok"]
+
+
+def test_perf_gate_is_one_sided_and_tolerant():
+    import copy
+    import json
+    g = _gate()
+    base = json.load(open(os.path.join(ROOT, "profiles", "perf_baseline.json")))
+    base = base.get("parsed", base)
+    line = copy.deepcopy(base)
+    line["value"] = base["value"] * 0.96                       # 4 % slower: inside the tolerance
+    line["cfg4"]["Mvectors_per_s"] = base["cfg4"]["Mvectors_per_s"] * 1.30    # faster never fails
+    line["cfg3_chain"]["per_content"]["pm3"]["lk_ms"] = base["cfg3_chain"]["per_content"]["pm3"]["lk_ms"] * 1.06   # 6 % slower: fails
+    rows = {name: ok for name, ok, _ in g.gate(line, base, 0.05)}
+    assert rows["headline Mvectors/s (cfg2)"] and rows["cfg4 Mvectors/s"]
+    assert rows["LK flow ms, +-3 px content"] is False
+    line["cfg4"]["parity_check"]["ok"] = False                 # a parity failure is a gate failure
+    rows = {name: ok for name, ok, _ in g.gate(line, base, 0.05)}
+    assert rows["cfg4.parity_check.ok"] is False
+
+
+def test_quiet_gc_counts_what_still_runs_and_restores_the_collector():
+    import gc
+    from bench_legs import QuietGC, median_min_max
+    before = gc.get_freeze_count()
+    with QuietGC() as q:
+        assert gc.get_freeze_count() > before
+        junk = [[i] for i in range(5000)]                      # young objects are still collected
+        gc.collect(0)
+        del junk
+    s = q.summary()
+    assert s["collections"] >= 1 and s["oldest_generation"] is not None
+    assert gc.get_freeze_count() == 0 and q._cb not in gc.callbacks
+    assert median_min_max([3.0, 1.0, 2.0, 10.0, 2.5]) == {"median": 2.5, "min": 1.0, "max": 10.0, "repeats": 5}

@@ -632,28 +632,83 @@ def test_lk_expired_parent_waits_are_repaired_before_results_reach_the_host(hook
         for k in range(1, 4):
             np.testing.assert_array_equal(got[k][0].view(np.uint32), ref_dec[k - 1][0].view(np.uint32))
         assert ctx.lk_recoveries() == r1 + 3
-        # the device-pointer entry point cannot look: the count is the caller's to check
+        # the ADVICE r4 interleaving: ticket A's launch has expired waits; a decode call queued behind it notices ITS OWN launch's
+        # (and only those), and A still notices A's when it is collected -- no watermark shared between calls
+        ctx.lk_reset()
+        r2 = ctx.lk_recoveries()
+        ta0 = ctx.lk_push_frame_async(pins[0], levels, radius, iters)
+        ta = ctx.lk_push_frame_async(pins[1], levels, radius, iters)
+        ent, grid = ctx.lk_decode(fr[1], fr[2], levels, radius, iters)
+        np.testing.assert_array_equal(ent.view(np.uint32), ref_dec[1][0].view(np.uint32))
+        assert ctx.lk_recoveries() == r2 + 1
+        assert ctx.lk_frame_wait(ta0) is None
+        got_a = ctx.lk_frame_wait(ta)
+        np.testing.assert_array_equal(got_a[0].view(np.uint32), ref_dec[0][0].view(np.uint32))
+        assert ctx.lk_recoveries() == r2 + 2
+        # the device-pointer entry point returns before anything ran: the next ofps_hip_sync answers OFPS_HIP_ESTALE, once
         import torch
+        from ofps_amd.runtime import OfpsHipError
         dfr = torch.from_numpy(fr[:2]).cuda()
         d_ent = torch.zeros((W * H, 4), dtype=torch.float32, device="cuda")
         ctx.use_torch_stream()
         try:
             ctx.lk_flow_dev(dfr[0].data_ptr(), dfr[1].data_ptr(), W, H, W, levels, radius, iters, None, d_ent.data_ptr())
-            torch.cuda.synchronize()
+            with pytest.raises(OfpsHipError) as ei:
+                ctx.sync()
+            assert ei.value.code == -5 and "expired" in str(ei.value)            # OFPS_HIP_ESTALE
+            ctx.sync()                                                           # reported once
+            assert ctx.lk_wait_timeouts() > t1
+            # the repeat the message asks for, level by level: the oracle's bits, and the sync after it is clean
+            ctx.set_option("OFPS_HIP_LK_SERIAL", "1")
+            ctx.lk_flow_dev(dfr[0].data_ptr(), dfr[1].data_ptr(), W, H, W, levels, radius, iters, None, d_ent.data_ptr())
+            ctx.set_option("OFPS_HIP_LK_SERIAL", None)
+            ctx.sync()
+            np.testing.assert_array_equal(d_ent.cpu().numpy().view(np.uint32), oracle.flow_to_entries(f_o).view(np.uint32))
         finally:
+            ctx.set_option("OFPS_HIP_LK_SERIAL", None)
             ctx.use_own_stream()
-        assert ctx.lk_wait_timeouts() > t1
     finally:
         ctx.set_option("OFPS_HIP_LK_TEST_WAIT_BUDGET", None)
         ctx.lk_reset()
-    # the hook is off.  The expired waits of the unchecked device-pointer call are still unaccounted for: the next host-output
-    # call cannot tell them from its own and repeats once (harmless); after that one launch again, nothing to repair
-    f_g = ctx.lk_flow(fr[0], fr[1], levels, radius, iters)
-    np.testing.assert_array_equal(f_g.view(np.uint32), f_o.view(np.uint32))
+    # the hook is off: every call compares with its own launch's epoch, so the expired waits of earlier launches (the device-pointer
+    # call's included) cost nothing now -- one launch per call, nothing to repair, the count stands still
     before, waits = ctx.lk_recoveries(), ctx.lk_wait_timeouts()
     f_g = ctx.lk_flow(fr[0], fr[1], levels, radius, iters)
     np.testing.assert_array_equal(f_g.view(np.uint32), f_o.view(np.uint32))
+    ent, grid = ctx.lk_decode(fr[0], fr[1], levels, radius, iters)
+    np.testing.assert_array_equal(ent.view(np.uint32), ref_dec[0][0].view(np.uint32))
     assert ctx.lk_recoveries() == before and ctx.lk_wait_timeouts() == waits
+    import torch
+    dfr = torch.from_numpy(fr[:2]).cuda()
+    d_ent = torch.zeros((W * H, 4), dtype=torch.float32, device="cuda")
+    ctx.use_torch_stream()
+    try:
+        ctx.lk_flow_dev(dfr[0].data_ptr(), dfr[1].data_ptr(), W, H, W, levels, radius, iters, None, d_ent.data_ptr())
+        ctx.sync()                                                               # clean: OFPS_HIP_OK
+    finally:
+        ctx.use_own_stream()
+    np.testing.assert_array_equal(d_ent.cpu().numpy().view(np.uint32), oracle.flow_to_entries(f_o).view(np.uint32))
+
+
+def test_lk_read_ahead_refuses_a_geometry_change_with_a_ticket_in_flight(ctx):
+    """a push with a new geometry used to drain the stream, which marked the other ticket collected and lost its
+    records; it is refused now (like the multi-device form), and a failed push leaves the stream position alone."""
+    from ofps_amd.runtime import OfpsHipError
+    fr = synth.luma_sequence(3, 320, 192, max_step=2, seed=9)
+    small = np.ascontiguousarray(fr[2][:96, :160])
+    ref = ctx.lk_decode(fr[0], fr[1], 3, 4, 2)
+    ctx.lk_reset()
+    t0 = ctx.lk_push_frame_async(fr[0], 3, 4, 2)
+    t1 = ctx.lk_push_frame_async(fr[1], 3, 4, 2)
+    assert ctx.lk_frame_wait(t0) is None
+    with pytest.raises(OfpsHipError) as ei:
+        ctx.lk_push_frame_async(small, 3, 4, 2)                                  # t1 is in flight
+    assert ei.value.code == -1 and "in flight" in str(ei.value)
+    got = ctx.lk_frame_wait(t1)                                                  # still collectable, records intact
+    np.testing.assert_array_equal(got[0].view(np.uint32), ref[0].view(np.uint32))
+    t2 = ctx.lk_push_frame_async(small, 3, 4, 2)                                 # nothing in flight: the new geometry restarts the stream
+    assert ctx.lk_frame_wait(t2) is None
+    ctx.lk_reset()
 
 
 def test_lk_tile_flags_are_nobodys_scratch(ctx):

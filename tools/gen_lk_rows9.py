@@ -256,7 +256,8 @@ def main():
                 '#define LK_ROWS9_PAIR_BODY(' + QARGS + ') \\', body_pair(False, 4 * js).replace("\n", " \\\n"), '',
                 '#define LK_ROWS9_PAIR_BODY_G(' + QARGS + ') \\', body_pair(True, 4 * js).replace("\n", " \\\n"), '']
     out += ['#else', '#error "lk_rows9.inc has no body for this OFPS_LK_JS"', '#endif', '']
-    path = os.path.join(ROOT, "ofps_amd", "csrc", "lk_rows9.inc")
+    import sys
+    path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "ofps_amd", "csrc", "lk_rows9.inc")   # a path: tests diff against the committed file
     with open(path, "w") as f:
         f.write("\n".join(out))
     print(path, len(out), "blocks")

@@ -1,0 +1,124 @@
+#!/usr/bin/env python3
+"""Performance gate: fails when a leg of the bench line got slower.  The reference times every stage of every
+frame and keeps the series (ofps-suite/src/app/utils/perf_stats.rs:27-34,86-121); this is the build-side counterpart: one bench
+line checked against the committed line of the previous round and against relations that must hold inside one run.
+
+  python tools/perf_gate.py <bench_line.json> [--baseline profiles/perf_baseline.json] [--tolerance 0.05]
+  python tools/perf_gate.py --run                      runs `python bench.py` itself (N = 1, a few minutes)
+
+Checks (each prints PASS / FAIL with both numbers; exit code 1 on any FAIL):
+  against the baseline, slower-only, `tolerance` (5 %):  headline Mvectors/s, cfg4 Mvectors/s, LK ms (+-3 px and +-16 px content),
+      Almeida cluster-solver ms, cfg5 p50 (LSQ and RANSAC; 15 %: a host-side latency)
+  inside the run:  read-ahead (Python loop) <= synchronous call;  read-ahead with host copy <= 1.15 x synchronous;
+      native read-ahead <= native synchronous;  batched read-ahead >= 0.9 x the PCIe ceiling measured in the same run;
+      every parity_check ok;  no expired LK parent waits in the timed region
+`min`/`max` beside every median are printed so that a noisy run shows as noisy, not as a regression."""
+import argparse
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DEFAULT_BASELINE = os.path.join(ROOT, "profiles", "perf_baseline.json")
+
+
+def get(d, path, default=None):
+    for k in path.split("."):
+        if not isinstance(d, dict) or k not in d:
+            return default
+        d = d[k]
+    return d
+
+
+# name, path in the line, higher_is_better, tolerance override
+BASELINE_CHECKS = [
+    ("headline Mvectors/s (cfg2)", "value", True, None),
+    ("cfg4 Mvectors/s", "cfg4.Mvectors_per_s", True, None),
+    ("LK flow ms, +-3 px content", "cfg3_chain.per_content.pm3.lk_ms", False, None),
+    ("LK flow ms, +-16 px content", "cfg3_chain.per_content.pm16.lk_ms", False, None),
+    ("Almeida cluster solve ms (2.07 M records)", "cfg3_chain.almeida_ms", False, None),
+    ("cfg3 chain ms", "cfg3_chain.chain_ms", False, None),
+    ("cfg5 p50 ms (LSQ)", "cfg5_stream.latency_ms.p50", False, 0.15),
+    ("cfg5 p50 ms (RANSAC)", "cfg5_stream.ransac.latency_ms.p50", False, 0.15),
+    ("native read-ahead ms/frame", "end_to_end.read_ahead_native_host.ms_per_frame", False, 0.10),
+]
+
+
+def gate(line: dict, base: dict, tol: float):
+    rows = []
+
+    def add(name, ok, detail):
+        rows.append((name, bool(ok), detail))
+    for name, path, higher, t in BASELINE_CHECKS:
+        now, was = get(line, path), get(base, path)
+        if now is None or was is None:
+            add(name, now is not None or was is None, f"missing in {'the line' if now is None else 'the baseline'} ({path})")
+            continue
+        t = tol if t is None else t
+        ok = now >= was * (1 - t) if higher else now <= was * (1 + t)
+        add(name, ok, f"{now} vs baseline {was} ({'>=' if higher else '<='} within {t:.0%})")
+    e = line.get("end_to_end") or {}
+    if e and "error" not in e:
+        def mm(key):
+            r = e.get(key) or {}
+            return r.get("ms_per_frame"), f"{r.get('ms_per_frame')} [{r.get('ms_per_frame_min')}..{r.get('ms_per_frame_max')}]"
+        s, ss = mm("sync"); a, aa = mm("read_ahead"); c, cc = mm("read_ahead_with_host_copy")
+        add("read-ahead <= synchronous (Python loop)", a is not None and s is not None and a <= s, f"{aa} vs {ss} ms/frame")
+        add("read-ahead + host copy <= 1.15 x synchronous", c is not None and s is not None and c <= 1.15 * s, f"{cc} vs {ss} ms/frame")
+        ns, nss = mm("sync_native_host"); na, naa = mm("read_ahead_native_host")
+        if ns is not None and na is not None:
+            add("native read-ahead <= native synchronous", na <= ns, f"{naa} vs {nss} ms/frame")
+        b = get(e, "read_ahead_batched_native_host.Mvectors_per_s"); ceil = e.get("pcie_ceiling_Mvectors_per_s")
+        if b is not None and ceil:
+            add("batched read-ahead >= 0.9 x PCIe ceiling of this run", b >= 0.9 * ceil, f"{b} vs ceiling {ceil} Mvectors/s ({b / ceil:.3f})")
+        g = e.get("python_gc_inside_timed_loops") or {}
+        add("no generation-2 collection inside the end_to_end loops", (g.get("oldest_generation") or 0) < 2 or g.get("longest_ms", 0) < 5.0, json.dumps(g))
+    else:
+        add("end_to_end leg present", False, str(e)[:200])
+    for key in ("parity_check", "cfg3_chain.parity_check", "cfg4.parity_check", "cfg5_stream.parity_check", "cfg5_stream.ransac.parity_check"):
+        pc = get(line, key)
+        add(f"{key}.ok", isinstance(pc, dict) and pc.get("ok") is True, str(pc.get("ok") if isinstance(pc, dict) else pc))
+    w = get(line, "cfg3_chain.lk_expired_parent_waits_in_timed_region")
+    add("no expired LK parent waits in the cfg3 timed region", w == 0, str(w))
+    return rows
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("line", nargs="?")
+    ap.add_argument("--baseline", default=DEFAULT_BASELINE)
+    ap.add_argument("--tolerance", type=float, default=0.05)
+    ap.add_argument("--run", action="store_true")
+    ap.add_argument("--save", help="write the line that was gated here")
+    args = ap.parse_args()
+    if args.run:
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")], capture_output=True, text=True, timeout=1500)
+        lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+        if p.returncode != 0 or not lines:
+            print(p.stdout[-2000:], p.stderr[-2000:], file=sys.stderr)
+            raise SystemExit(f"perf_gate: bench.py exited {p.returncode}")
+        line = json.loads(lines[-1])
+    else:
+        if not args.line:
+            ap.error("a bench line (JSON file) or --run")
+        txt = open(args.line).read()
+        line = json.loads([ln for ln in txt.splitlines() if ln.startswith("{")][-1])
+        line = line.get("parsed", line)
+    if args.save:
+        with open(args.save, "w") as f:
+            json.dump(line, f)
+            f.write("\n")
+    base = json.load(open(args.baseline))
+    base = base.get("parsed", base)
+    rows = gate(line, base, args.tolerance)
+    bad = 0
+    for name, ok, detail in rows:
+        print(f"{'PASS' if ok else 'FAIL'}  {name}: {detail}")
+        bad += not ok
+    print(f"perf_gate: {len(rows) - bad} passed, {bad} failed (baseline {os.path.relpath(args.baseline, ROOT)})")
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
