@@ -125,8 +125,8 @@ def parse(argv=None):
             ap.error("--device-map: comma-separated integers")
         if len(args.device_map) != args.gpus or min(args.device_map) < 0:
             ap.error(f"--device-map needs one non-negative device index per rank ({args.gpus})")
-        if len(set(args.device_map)) != len(args.device_map) and args.backend != "gloo":
-            ap.error("--device-map with a repeated device needs --backend gloo (RCCL refuses two ranks on one device)")
+        if len(set(args.device_map)) != len(args.device_map) and args.backend != "gloo" and args.launcher != "threads":
+            ap.error("--device-map with a repeated device needs --backend gloo (RCCL refuses two ranks on one device) or --launcher threads")
     return args
 
 
@@ -788,8 +788,9 @@ def run_threads(args) -> int:
     from ofps_amd.runtime import MultiDevice
     if args.stub or args.pipeline or args.ref_mode == "key" and args.scaling == "weak":
         raise SystemExit("bench.py --launcher threads: supports the SAD step, pairs or key mode (key mode with --scaling strong)")
-    if not torch.cuda.is_available() or torch.cuda.device_count() < args.gpus:
-        raise SystemExit(f"bench.py: --gpus {args.gpus} needs that many GPUs; this node has "
+    devices = list(args.device_map) if args.device_map else list(range(args.gpus))      # repeats: N workers on fewer GPUs (rehearsal)
+    if not torch.cuda.is_available() or torch.cuda.device_count() < max(devices) + 1:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} on devices {devices} needs {max(devices) + 1} GPU(s); this node has "
                          f"{torch.cuda.device_count() if torch.cuda.is_available() else 0} (no CPU fallback)")
     N, W, H, B, R, P = args.gpus, args.width, args.height, args.block, args.search_range, args.pairs
     total = P if args.scaling == "strong" else N * P
@@ -800,7 +801,7 @@ def run_threads(args) -> int:
     frames = synth.luma_sequence(G + 1, W, H, seed=synth.SEED0, **gen)
     walk = np.abs(((np.arange(total + 1) + G) % (2 * G)) - G) if G > 1 else np.arange(total + 1) % 2
     host = np.ascontiguousarray(frames[walk])
-    md = MultiDevice(list(range(N)))
+    md = MultiDevice(devices)
     try:
         md.stage_frames(host, 1 if key_mode else 0)
         t_pw = time.perf_counter()
@@ -820,17 +821,22 @@ def run_threads(args) -> int:
     args_line.pairs = total if args.scaling == "strong" else P
     out = build_line(args_line, N, el, float(ms[0]) / args.steps, counts[0], counts, nblk, N, *committed_traffic_per_pair(W, H, B, R))
     out["launcher"] = "threads (one process, ofps_hip_multi_*: one worker thread + context per GPU, no collective)"
+    if len(set(devices)) != len(devices):
+        out["rehearsal"] = (f"{N} workers on devices {devices}: real HIP steps through the in-process dispatcher, several workers per GPU -- "
+                            "a plumbing rehearsal of the N-GPU run on fewer GPUs, NOT a scaling measurement")
     out["per_rank_ms_per_step"] = {"min": round(float(ms[ms > 0].min()) / args.steps, 4) if (ms > 0).any() else 0.0,
                                    "max": round(float(ms.max()) / args.steps, 4), "what": "HIP events per worker"}
     # ---- PCIe-inclusive stream form through the same dispatcher (ofps_hip_multi_push_frames_async: batches of 16 frames dealt to
     # the workers, vectors + island + quaternion per frame back in frame order), C++ host, frames in page-locked memory
-    if not args.no_end_to_end and (W, H, B, R) == (1920, 1080, 16, 16):
+    if not args.no_end_to_end and (B, R) in ((16, 16), (8, 32)):
         try:
             import subprocess
             from ofps_amd.build import TOOL
-            r = json.loads(subprocess.run([TOOL, "stream-bench", str(W), str(H), str(1024 * N), "multi", "16"] + [str(d) for d in range(N)],
-                                          capture_output=True, text=True, timeout=300, check=True).stdout.strip().splitlines()[-1])
-            out["end_to_end"] = {"what": "one stream of 1080p frames over the workers: every frame crosses PCIe once, 16 frames per batch, 2 batches in "
+            sb, sf = (16, 1024 * N) if W * H <= 1920 * 1080 else (4, 32 * N)          # 4K: 4 frames per batch (33 MB), 32 frames per worker
+            r = json.loads(subprocess.run([TOOL, "stream-bench", str(W), str(H), str(sf), "multi", str(sb)] + [str(d) for d in devices] +
+                                          ["--block", str(B), "--range", str(R)],
+                                          capture_output=True, text=True, timeout=600, check=True).stdout.strip().splitlines()[-1])
+            out["end_to_end"] = {"what": f"one stream of {W}x{H} frames over the workers: every frame crosses PCIe once, {sb} frames per batch, 2 batches in "
                                          "flight per worker; per frame the vectors (16 B each), the block-motion island and the Almeida quaternion come back",
                                  "entry_points": "ofps_hip_multi_push_frames_async + ofps_hip_multi_frames_wait (C++ host layer)",
                                  "workers": r["workers"], "batch": r["batch"], "frames": r["frames"], "ms_per_frame": r["ms_per_frame"],

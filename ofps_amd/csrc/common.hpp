@@ -185,7 +185,7 @@ bool device_address_of(const void* host_ptr, void** dev_ptr);
 
 // the batched read-ahead push with the previous frame supplied by the caller (pipeline.hip; multi.hip deals batches to workers)
 int push_frames_impl(ofps_hip_ctx* ctx, const uint8_t* frames, int n, int W, int H, int stride, size_t frame_pitch,
-                     const ofps_hip_frame_params* prm, float* out_entries, int* ticket, int halo_mode, const uint8_t* halo);
+                     const ofps_hip_frame_params* prm, float* out_entries, int* ticket, int halo_mode, const uint8_t* halo, int halo_stride);
 
 // rows of `width` bytes, host -> device; one linear copy when both sides are dense (the 2-D path is slower)
 inline hipError_t upload_rows(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t height,

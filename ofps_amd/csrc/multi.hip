@@ -406,8 +406,10 @@ int ofps_hip_multi_push_frames_async(ofps_hip_multi* m, const uint8_t* frames, i
     if (t->pending)
         return multi_error(m, OFPS_HIP_EINVAL, "multi_push_frames_async: ticket %ld has not been collected (at most %d batches in flight)",
                            g - 2 * nw, 2 * nw);
-    // halo buffers: page-locked, one frame of `stride` x H bytes each
-    const size_t hbytes = (size_t)stride * H;
+    // halo buffers: page-locked, one frame each, stored DENSELY (W bytes per row): the batch that consumes a halo may arrive with
+    // another row stride than the batch that produced it (it used to be saved with the producer's stride and uploaded
+    // with the consumer's), and the buffers no longer grow -- and restart the stream -- when only the stride does
+    const size_t hbytes = (size_t)W * H;
     if (m->halo.empty() || m->halo_bytes < hbytes) {
         for (auto& tp : m->tickets)
             if (tp->pending) return multi_error(m, OFPS_HIP_EINVAL, "multi_push_frames_async: frame size grew with tickets in flight");
@@ -423,7 +425,11 @@ int ofps_hip_multi_push_frames_async(ofps_hip_multi* m, const uint8_t* frames, i
     // the last frame of THIS batch is the halo of the next one (copied now: the caller's buffer is only promised until its wait)
     int nhs;
     ofps_hip_multi_stream_plan(g + 1, nw, nullptr, &nhs, nullptr);
-    memcpy(m->halo[nhs], frames + (size_t)(n - 1) * frame_pitch, hbytes);
+    {
+        const uint8_t* last = frames + (size_t)(n - 1) * frame_pitch;
+        if (stride == W) memcpy(m->halo[nhs], last, hbytes);
+        else for (int y = 0; y < H; ++y) memcpy(m->halo[nhs] + (size_t)y * W, last + (size_t)y * stride, (size_t)W);
+    }
     t->pending = true; t->enqueued = false; t->worker = wk; t->n = n; t->rc = OFPS_HIP_OK;
     const ofps_hip_frame_params prm = *params;
     enqueue(m->w[wk], [=](Worker& w) {
@@ -446,7 +452,7 @@ int ofps_hip_multi_push_frames_async(ofps_hip_multi* m, const uint8_t* frames, i
             if (rc == OFPS_HIP_OK) { memcpy(w.stage[sb], frames, need); src = w.stage[sb]; }
         }
         if (rc == OFPS_HIP_OK)
-            rc = ofps::push_frames_impl(w.ctx, src, n, W, H, stride, pitch, &prm, out_entries, &wt, /*halo_mode=*/1, halo);
+            rc = ofps::push_frames_impl(w.ctx, src, n, W, H, stride, pitch, &prm, out_entries, &wt, /*halo_mode=*/1, halo, /*halo_stride=*/W);
         w.stream_batches += 1;
         std::lock_guard<std::mutex> lk(t->m);
         t->rc = rc; t->worker_ticket = wt; t->enqueued = true;

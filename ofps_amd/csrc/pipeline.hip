@@ -312,11 +312,11 @@ int ofps_hip_frame_wait(ofps_hip_ctx* ctx, int ticket, ofps_hip_frame_result* ou
 
 namespace ofps {
 // halo_mode 0: frame 0 of the batch is paired with the context's own previous frame (ofps_hip_push_frames_async).
-// halo_mode 1: the caller supplies the previous frame (`halo`, host memory, same row stride as `frames`) or says there is none
+// halo_mode 1: the caller supplies the previous frame (`halo`, host memory, rows `halo_stride` bytes apart; 0 = `stride`) or says there is none
 // (halo == nullptr: the very first frame of a stream) -- the multi-device dispatcher's form (multi.hip): a worker sees every
 // n_workers-th batch of a stream, so the frame in front of its batch is not the last one IT saw.
 int push_frames_impl(ofps_hip_ctx* ctx, const uint8_t* frames, int n, int W, int H, int stride, size_t frame_pitch,
-                     const ofps_hip_frame_params* prm, float* out_entries, int* ticket, int halo_mode, const uint8_t* halo) {
+                     const ofps_hip_frame_params* prm, float* out_entries, int* ticket, int halo_mode, const uint8_t* halo, int halo_stride) {
     if (!ctx) return OFPS_HIP_EINVAL;
     OFPS_REQUIRE(ctx, frames && prm && ticket && n >= 1 && n <= 4096, "push_frames_async: bad arguments (n=%d)", n);
     OFPS_REQUIRE(ctx, W > 0 && H > 0 && stride >= W && frame_pitch >= (size_t)stride * H, "push_frames_async: bad geometry W=%d H=%d stride=%d", W, H, stride);
@@ -396,7 +396,7 @@ int push_frames_impl(ofps_hip_ctx* ctx, const uint8_t* frames, int n, int W, int
         for (int j = 0; j < n; ++j)
             OFPS_HIP_TRY(ctx, ofps::upload_rows(buf + (size_t)(j + 1) * pitch, dstride, frames + (size_t)j * frame_pitch, stride, W, H, up));
     }
-    if (halo_mode && halo) OFPS_HIP_TRY(ctx, ofps::upload_rows(buf, dstride, halo, stride, W, H, up));       // the caller's previous frame into slot 0
+    if (halo_mode && halo) OFPS_HIP_TRY(ctx, ofps::upload_rows(buf, dstride, halo, halo_stride ? halo_stride : stride, W, H, up));       // the caller's previous frame into slot 0
     OFPS_HIP_TRY(ctx, hipEventRecord(t.uploaded, up));
     const bool has_prev = halo_mode ? halo != nullptr : ctx->batch_last_frame != nullptr;
     t.prev_copied_valid = false;
@@ -452,7 +452,7 @@ extern "C" {
 
 int ofps_hip_push_frames_async(ofps_hip_ctx* ctx, const uint8_t* frames, int n, int W, int H, int stride, size_t frame_pitch,
                                const ofps_hip_frame_params* prm, float* out_entries, int* ticket) {
-    return ofps::push_frames_impl(ctx, frames, n, W, H, stride, frame_pitch, prm, out_entries, ticket, 0, nullptr);
+    return ofps::push_frames_impl(ctx, frames, n, W, H, stride, frame_pitch, prm, out_entries, ticket, 0, nullptr, 0);
 }
 
 int ofps_hip_frames_wait(ofps_hip_ctx* ctx, int ticket, ofps_hip_frame_result* out /* n of them */) {

@@ -5,7 +5,7 @@
 //                                                       the same loop from a saved MotionDetectionConfig (detection.rs:45-50):
 //                                                       plugins, their saved properties, max_frame_gap / min_frames
 //   parse-config <saved.json>                           prints what a saved configuration says (no GPU)
-//   stream-bench <w> <h> <frames> [sync|ahead|batch <n>|multi <n> [dev ...]]
+//   stream-bench <w> <h> <frames> [sync|ahead|batch <n>|multi <n> [dev ...]] [--block B --range R  (multi; default 16 16)]
 //                                                       PCIe-inclusive per-frame time of the hip_sad process_frame shape; `multi`:
 //                                                       the stream over several workers (ofps_hip_multi_push_frames_async), with
 //                                                       detector + estimator per frame
@@ -150,6 +150,17 @@ int main(int argc, char** argv) {
             return 0;
         }
         if (cmd == "stream-bench" && argc >= 5) {
+            // optional `--block B --range R` anywhere behind the mode (default 16 / 16): BASELINE configs[3] is 8 / 32
+            int sb_block = 16, sb_range = 16;
+            {
+                int keep = 0;
+                for (int a = 0; a < argc; ++a) {
+                    if (a + 1 < argc && std::string(argv[a]) == "--block") { sb_block = std::atoi(argv[++a]); continue; }
+                    if (a + 1 < argc && std::string(argv[a]) == "--range") { sb_range = std::atoi(argv[++a]); continue; }
+                    argv[keep++] = argv[a];
+                }
+                argc = keep;
+            }
             // the Decoder::process_frame shape without Python in the loop: frames are already in page-locked buffers (a
             // decoder that writes there), one H2D + search + 16 B/vector D2H per frame
             const int W = std::atoi(argv[2]), H = std::atoi(argv[3]);
@@ -166,7 +177,7 @@ int main(int argc, char** argv) {
                 ofps_hip_multi* m = nullptr;
                 if (ofps_hip_multi_init(devices.data(), (int)devices.size(), &m) != OFPS_HIP_OK) throw Error(ofps_hip_multi_last_error(nullptr));
                 const int nw = (int)devices.size(), slots = 2 * nw;
-                const size_t nblk = ofps_hip_sad_block_count(W, H, 16);
+                const size_t nblk = ofps_hip_sad_block_count(W, H, sb_block);
                 HipContext alloc;                                           // page-locked memory comes from any context
                 std::vector<uint8_t*> pin((size_t)slots); std::vector<float*> ent((size_t)slots);
                 for (auto& p : pin) { void* q; alloc.check(ofps_hip_host_alloc(alloc.get(), (size_t)mb * W * H, &q)); p = static_cast<uint8_t*>(q); }
@@ -174,7 +185,7 @@ int main(int argc, char** argv) {
                 uint32_t st = 12345;
                 for (auto& p : pin) for (size_t i = 0; i < (size_t)mb * W * H; ++i) { st = st * 1664525u + 1013904223u; p[i] = (uint8_t)(st >> 24); }
                 ofps_hip_frame_params prm{};
-                prm.block = 16; prm.range = 16; prm.run_detector = 1; prm.min_size = 0.05f; prm.subdivide = 3; prm.target_motion = 0.003f;
+                prm.block = sb_block; prm.range = sb_range; prm.run_detector = 1; prm.min_size = 0.05f; prm.subdivide = 3; prm.target_motion = 0.003f;
                 prm.run_estimator = 1; prm.aspect = (float)W / (float)H; prm.fov_y_deg = 39.6f * (float)H / (float)W;
                 std::vector<ofps_hip_frame_result> res((size_t)mb);
                 auto mcheck = [&](int rc) { if (rc != OFPS_HIP_OK) throw Error(ofps_hip_multi_last_error(m)); };
@@ -195,9 +206,9 @@ int main(int argc, char** argv) {
                 const auto t0 = std::chrono::steady_clock::now();
                 run(nb);
                 const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / ((double)nb * mb);
-                std::printf("{\"mode\": \"multi_read_ahead_batched\", \"workers\": %d, \"batch\": %d, \"frames\": %d, \"ms_per_frame\": %.4f, "
-                            "\"Mvectors_per_s\": %.2f, \"per_frame\": \"vectors + block-motion island + almeida LSQ quaternion\"}\n", nw, mb, nb * mb, ms,
-                            (double)nblk / ms / 1e3);
+                std::printf("{\"mode\": \"multi_read_ahead_batched\", \"workers\": %d, \"batch\": %d, \"frames\": %d, \"block\": %d, \"range\": %d, "
+                            "\"ms_per_frame\": %.4f, \"Mvectors_per_s\": %.2f, \"per_frame\": \"vectors + block-motion island + almeida LSQ quaternion\"}\n",
+                            nw, mb, nb * mb, sb_block, sb_range, ms, (double)nblk / ms / 1e3);
                 for (auto p : pin) ofps_hip_host_free(alloc.get(), p);
                 for (auto p : ent) ofps_hip_host_free(alloc.get(), p);
                 ofps_hip_multi_destroy(m);

@@ -500,14 +500,18 @@ class MultiDevice:
                           target_motion=0.003, estimator=True, aspect=16 / 9, fov_y_deg=39.6 * 9 / 16, use_ransac=False,
                           num_iters=200, inlier_deg=0.05, num_samples=1000, seed=0, out_entries: np.ndarray | None = None) -> int:
         """One batch of consecutive frames of the stream (uint8 [n, H, W] contiguous) -> ticket; keep `frames` and `out_entries`
-        ([n, nblk, 4] float32) alive until frames_wait(ticket).  Batches are dealt to the workers round-robin."""
-        assert frames.dtype == np.uint8 and frames.ndim == 3 and frames.flags["C_CONTIGUOUS"]
+        ([n, nblk, 4] float32) alive until frames_wait(ticket).  Batches are dealt to the workers round-robin.  A view with
+        padded rows (unit stride along x, rows `stride` >= W bytes apart, frames `stride * H` or more apart) is passed as it is."""
+        assert frames.dtype == np.uint8 and frames.ndim == 3
         n, H, W = frames.shape
+        pitch, stride, unit = frames.strides
+        assert unit == 1 and stride >= W and (n == 1 or pitch >= stride * H), "frames: rows must be byte-contiguous"
         prm = _lib.FrameParams(block, search_range, int(detector), min_size, subdivide, target_motion, int(estimator),
                                aspect, fov_y_deg, int(use_ransac), num_iters, inlier_deg, num_samples, seed)
         t = C.c_int(0)
-        self._check(self._lib.ofps_hip_multi_push_frames_async(self._h, frames.ctypes.data_as(C.POINTER(C.c_uint8)), n, W, H, W, W * H,
-                                                               C.byref(prm), _fp(out_entries) if out_entries is not None else None, C.byref(t)))
+        self._check(self._lib.ofps_hip_multi_push_frames_async(self._h, C.cast(C.c_void_p(frames.ctypes.data), C.POINTER(C.c_uint8)), n, W, H, stride,
+                                                               max(pitch, stride * H), C.byref(prm),
+                                                               _fp(out_entries) if out_entries is not None else None, C.byref(t)))
         self._batch_n = getattr(self, "_batch_n", {})
         self._batch_n[t.value] = n
         return t.value

@@ -206,6 +206,43 @@ def test_multi_stream_pipeline_equals_the_single_context_stream(workers, pinned)
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("workers", [1, 2])
+def test_multi_stream_row_stride_may_change_between_batches(workers):
+    """the frame in front of a batch (its halo) was saved with the PRODUCING batch's row stride and uploaded with the
+    consuming batch's; with another stride the first pair of the next batch was searched against a sheared frame, and a larger
+    stride silently restarted the stream (first frame without vectors, no error).  The halo is kept dense now: batches with row
+    strides W, W + 64, W + 32, W give the bits of the all-dense stream."""
+    from ofps_amd import synth
+    from ofps_amd.runtime import HipContext
+    W, H, B, R, nb, per = 320, 192, 16, 8, 6, 2
+    fr = synth.luma_sequence(nb * per, W, H, max_step=6, seed=synth.SEED0 + 77)
+    nblk = (W // B) * (H // B)
+    ctx = HipContext(0)
+    ref, ref_ent = [], np.zeros((nb, per, nblk, 4), np.float32)
+    for b in range(nb):
+        ref += ctx.frames_wait(ctx.push_frames_async(np.ascontiguousarray(fr[b * per:(b + 1) * per]), block=B, search_range=R, seed=b,
+                                                     out_entries=ref_ent[b]))
+    ctx.close()
+    md = MultiDevice([0] * workers)
+    try:
+        got, got_ent = [], np.zeros((nb, per, nblk, 4), np.float32)
+        keep = []
+        for b in range(nb):
+            pad = (0, 64, 32, 0, 64, 0)[b]
+            buf = np.full((per, H, W + pad), 0xA5, np.uint8)                      # the padding holds junk
+            buf[:, :, :W] = fr[b * per:(b + 1) * per]
+            keep.append(buf)
+            got += md.frames_wait(md.push_frames_async(buf[:, :, :W], block=B, search_range=R, seed=b, out_entries=got_ent[b]))
+        assert not got[0]["have_vectors"] and all(g["have_vectors"] for g in got[1:])
+        for k, (g, r) in enumerate(zip(got, ref)):
+            assert g["motion"] == r["motion"], k
+            np.testing.assert_array_equal(g["quat"].view(np.uint32), r["quat"].view(np.uint32))
+        np.testing.assert_array_equal(got_ent.reshape(-1, nblk, 4)[1:].view(np.uint32), ref_ent.reshape(-1, nblk, 4)[1:].view(np.uint32))
+    finally:
+        md.close()
+
+
+@pytest.mark.gpu
 def test_multi_fetch_refuses_results_of_another_batch_or_block_size():
     """ofps_hip_multi_fetch used to check only the buffer's capacity."""
     from ofps_amd import synth
