@@ -206,3 +206,73 @@ def camera_warp_pair(W=1920, H=1080, roll_deg=0.5, zoom=1.004, shift=(3.3, -2.6)
     f1 = ndimage.map_coordinates(tex, [sy + 32, sx + 32], order=1, mode="nearest")
     noise = rng.integers(-1, 2, (2, H, W))
     return np.clip(np.rint(np.stack([f0, f1])) + noise, 0, 255).astype(np.uint8)
+
+
+def rotation_clip(per_frame_euler_deg, W=1920, H=1080, fov_y_deg=60.0, seed=21, distractor=None, margin=0.5, noise=1):
+    """A clip rendered from planted per-frame CAMERA ROTATIONS (what the reference evaluates against:
+    ground-truth camera orientations per frame, ofps-suite/src/app/tracking/mod.rs:125-217).
+
+    per_frame_euler_deg: [n, 3] (roll, pitch, yaw) in nalgebra's from_euler_angles order, the rotation q_k between frame k and
+    frame k + 1 in the convention of the reference's own estimator test (almeida-estimator/src/lib.rs:280-306: frame k + 1 is
+    frame k seen through calc_view(q_k)), i.e. the quaternion Estimator::estimate should return for the pair.  In image terms, with
+    the reference's Z-up / Y-forward world: roll = about X = tilt, pitch = about Y (the view axis) = image roll, yaw = about Z = pan.
+    The scene is a texture at infinity (pure rotation has no parallax): frame k samples it, bilinearly, where the pinhole
+    homography of the accumulated rotation Q_k = q_0 q_1 ... q_{k-1} puts each pixel centre -- float64, no small-angle
+    approximation, no NDC-z quirk (a physical camera, not the estimator's model).
+    distractor: None | dict(size=(w, h) px, start=(x, y) px, velocity=(vx, vy) px per frame): an independently moving foreground
+    rectangle with its own texture pasted over every frame (a dynamic object: the reference's "dyn" clips).
+    -> (frames uint8 [n + 1, H, W], quats float64 [n, 4] (w, i, j, k) = the q_k)."""
+    from scipy import ndimage
+    from scipy.spatial.transform import Rotation
+    eul = np.radians(np.asarray(per_frame_euler_deg, np.float64).reshape(-1, 3))
+    n = len(eul)
+    rng = np.random.default_rng(seed)
+    mw, mh = int(round(W * margin)), int(round(H * margin))
+    TW, TH = W + 2 * mw, H + 2 * mh
+    u = rng.uniform(0, 1, (TH, TW)).astype(np.float32)
+    tex = ndimage.gaussian_filter(u, 1.2) * 3.0 + ndimage.gaussian_filter(u, 4.0) * 6.0 + ndimage.gaussian_filter(u, 16.0) * 12.0
+    tex = (tex - tex.min()) / (tex.max() - tex.min()) * 219.0 + 16.0
+    yy, xx = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    pos = np.stack([(xx.ravel() + 0.5) / W, (yy.ravel() + 0.5) / H], 1)
+    aspect = W / H
+    if distractor:
+        dw, dh = distractor["size"]
+        du = rng.uniform(0, 1, (dh, dw)).astype(np.float32)
+        dtex = ndimage.gaussian_filter(du, 1.0) * 3.0 + ndimage.gaussian_filter(du, 3.0) * 6.0
+        dtex = (dtex - dtex.min()) / (dtex.max() - dtex.min()) * 219.0 + 16.0
+    frames = np.empty((n + 1, H, W), np.uint8)
+    Q = np.eye(3)
+    quats = np.empty((n, 4))
+    for k in range(n + 1):
+        p0 = pos + rotation_delta(pos, aspect, fov_y_deg, Q)                         # M(Q_k)^-1: where this frame's pixels sit in frame 0
+        sx = p0[:, 0] * W - 0.5 + mw
+        sy = p0[:, 1] * H - 0.5 + mh
+        if sx.min() < 0 or sy.min() < 0 or sx.max() > TW - 1 or sy.max() > TH - 1:
+            raise ValueError(f"rotation_clip: frame {k} looks outside the texture (accumulated rotation too large for margin {margin})")
+        img = ndimage.map_coordinates(tex, [sy.reshape(H, W), sx.reshape(H, W)], order=1, mode="nearest")
+        if distractor:
+            x0 = int(round(distractor["start"][0] + k * distractor["velocity"][0]))
+            y0 = int(round(distractor["start"][1] + k * distractor["velocity"][1]))
+            xa, ya, xb, yb = max(x0, 0), max(y0, 0), min(x0 + dw, W), min(y0 + dh, H)
+            if xb > xa and yb > ya:
+                img[ya:yb, xa:xb] = dtex[ya - y0:yb - y0, xa - x0:xb - x0]
+        if noise:
+            img = img + rng.integers(-noise, noise + 1, (H, W))
+        frames[k] = np.clip(np.rint(img), 0, 255).astype(np.uint8)
+        if k < n:
+            Rq = euler_rot3(*eul[k])
+            x, y, z, w = Rotation.from_matrix(Rq).as_quat()
+            quats[k] = (w, x, y, z)
+            Q = Q @ Rq                                                            # Q_{k+1} = Q_k q_k
+    return frames, quats
+
+
+def quat_angle_deg(a, b) -> float:
+    """Angle of the rotation that takes a to b (UnitQuaternion::angle_to), degrees; (w, i, j, k).  From the VECTOR part of
+    a^-1 b (atan2), not from arccos of the dot product: for rotations of hundredths of a degree 1 - dot is ~1e-9."""
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    a = a / np.linalg.norm(a); b = b / np.linalg.norm(b)
+    aw, av = a[0], -a[1:]                                   # conj(a)
+    w = aw * b[0] - float(np.dot(av, b[1:]))
+    v = aw * b[1:] + b[0] * av + np.cross(av, b[1:])
+    return float(np.degrees(2.0 * np.arctan2(np.linalg.norm(v), abs(w))))
