@@ -28,6 +28,47 @@ __global__ __launch_bounds__(256) void pipe_copy_out_kernel(const uint32_t* __re
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n_words; i += (size_t)gridDim.x * 256) dst[i] = src[i];
 }
 
+// Host -> device by a copy KERNEL reading the page-locked source over PCIe: the batched read-ahead form's upload (round 5).
+// hipMemcpyAsync leaves the choice of SDMA engine to the runtime, which binds a stream to the lowest-numbered engine that happens to be
+// free at the stream's first copy; which engine the copy stream ends up with depends on what else was in flight at that moment, and
+// the engines are not equally fast for 33 MB copies: the batched form ran at 0.0385 ms per 1080p frame in most processes and 0.046 in
+// the rest (round 4's "0.95 vs 0.79 of the PCIe ceiling").  A 16-workgroup copy kernel on the copy stream sustains the same link rate
+// (0.0389, every process), leaves the CUs to the search that runs beside it (64 workgroups: 0.043, 128: 0.046) and makes small
+// batches faster (4 frames per batch: 0.042 against 0.050).  The single-frame form keeps the DMA engine: a lone 2 MB frame is on the
+// latency path and crosses faster that way (0.0545 against 0.0628 / 0.0558 with 16 / 32 workgroups).  profiles/r05/batched_bimodal.txt;
+// -DOFPS_HIP_UPLOAD_WGS=n for A/B builds (tools/upload_ab.sh).
+#ifndef OFPS_HIP_UPLOAD_WGS
+#define OFPS_HIP_UPLOAD_WGS 16
+#endif
+#ifndef OFPS_HIP_UPLOAD_KERNEL_SINGLE
+#define OFPS_HIP_UPLOAD_KERNEL_SINGLE 0          // A/B: the single-frame form through the copy kernel as well
+#endif
+typedef unsigned int pipe_u32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void pipe_upload_kernel(const pipe_u32x4* __restrict__ src, pipe_u32x4* __restrict__ dst, size_t n16) {
+    const size_t stride = (size_t)gridDim.x * 256;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 3 * stride < n16; i += 4 * stride) {                // four 16-byte reads in flight per lane
+        const pipe_u32x4 a = __builtin_nontemporal_load(src + i), b = __builtin_nontemporal_load(src + i + stride);
+        const pipe_u32x4 c = __builtin_nontemporal_load(src + i + 2 * stride), d = __builtin_nontemporal_load(src + i + 3 * stride);
+        dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
+    }
+    for (; i < n16; i += stride) dst[i] = __builtin_nontemporal_load(src + i);
+}
+
+bool device_can_write(const void* host_ptr, void** dev_ptr);
+// dense bytes, host -> device on stream s; by_kernel: through pipe_upload_kernel when the source is page-locked (else the DMA engine)
+int pipe_h2d(ofps_hip_ctx* ctx, void* dst, const void* src, size_t bytes, hipStream_t s, bool by_kernel) {
+    void* mapped = nullptr;
+    if (by_kernel && OFPS_HIP_UPLOAD_WGS > 0 && bytes % 16 == 0 && ((uintptr_t)dst % 16) == 0 && ((uintptr_t)src % 16) == 0 && device_can_write(src, &mapped)) {
+        hipLaunchKernelGGL(pipe_upload_kernel, dim3(OFPS_HIP_UPLOAD_WGS), dim3(256), 0, s, static_cast<const pipe_u32x4*>(mapped), static_cast<pipe_u32x4*>(dst),
+                           bytes / 16);
+        OFPS_HIP_TRY(ctx, hipGetLastError());
+        return OFPS_HIP_OK;
+    }
+    OFPS_HIP_TRY(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, s));
+    return OFPS_HIP_OK;
+}
+
 bool device_can_write(const void* host_ptr, void** dev_ptr) {
     hipPointerAttribute_t a{};
     if (hipPointerGetAttributes(&a, host_ptr) != hipSuccess) { (void)hipGetLastError(); return false; }   // pageable memory
@@ -104,7 +145,12 @@ int pipe_upload(ofps_hip_ctx* ctx, const uint8_t* luma, int W, int H, int stride
     hipStream_t up = overlap ? ctx->pipe_copy_stream : ctx->stream;
     // the slot's previous tenant (frame number - 3) may still be read by the search of ticket number - 2
     if (overlap && ctx->pipe_slot_read_valid[slot]) OFPS_HIP_TRY(ctx, hipStreamWaitEvent(up, ctx->pipe_slot_read[slot], 0));
-    OFPS_HIP_TRY(ctx, ofps::upload_rows(slots + (size_t)slot * pitch, dstride, luma, stride, W, H, up));
+    if (dstride == W && stride == W) {
+        rc = pipe_h2d(ctx, slots + (size_t)slot * pitch, luma, pitch, up, OFPS_HIP_UPLOAD_KERNEL_SINGLE != 0);
+        if (rc != OFPS_HIP_OK) return rc;
+    } else {
+        OFPS_HIP_TRY(ctx, ofps::upload_rows(slots + (size_t)slot * pitch, dstride, luma, stride, W, H, up));
+    }
     if (overlap) OFPS_HIP_TRY(ctx, hipEventRecord(ctx->pipe_uploaded[slot], up));
     ctx->pipe_uploaded_on_compute[slot] = !overlap;       // ... in which case the compute stream never has to wait for it
     ctx->pipe_frames += 1;
@@ -391,7 +437,8 @@ int push_frames_impl(ofps_hip_ctx* ctx, const uint8_t* frames, int n, int W, int
     auto& other = ctx->batch_ticket[(tno + 1) % ofps_hip_ctx::kBatchTickets];
     if (other.pending && other.prev_copied_valid) OFPS_HIP_TRY(ctx, hipStreamWaitEvent(up, other.prev_copied, 0));
     if (frame_pitch == (size_t)W * H && stride == W && dstride == W) {
-        OFPS_HIP_TRY(ctx, hipMemcpyAsync(buf + pitch, frames, (size_t)n * pitch, hipMemcpyHostToDevice, up));       // the whole batch
+        rc = pipe_h2d(ctx, buf + pitch, frames, (size_t)n * pitch, up, true);                                       // the whole batch
+        if (rc != OFPS_HIP_OK) return rc;
     } else {
         for (int j = 0; j < n; ++j)
             OFPS_HIP_TRY(ctx, ofps::upload_rows(buf + (size_t)(j + 1) * pitch, dstride, frames + (size_t)j * frame_pitch, stride, W, H, up));
@@ -401,7 +448,13 @@ int push_frames_impl(ofps_hip_ctx* ctx, const uint8_t* frames, int n, int W, int
     const bool has_prev = halo_mode ? halo != nullptr : ctx->batch_last_frame != nullptr;
     t.prev_copied_valid = false;
     if (has_prev && !halo_mode) {
-        OFPS_HIP_TRY(ctx, hipMemcpyAsync(buf, ctx->batch_last_frame, pitch, hipMemcpyDeviceToDevice, s));
+        // by a copy KERNEL, not hipMemcpyAsync: the runtime may hand a device-to-device copy to the SDMA engine that is busy with the
+        // NEXT batch's 33 MB upload, and then this 2 MB copy -- and the search behind it -- waits 0.1-0.6 ms for that upload.  Which
+        // engine a stream's copies get is decided per process: the batched form ran at 209 Mvectors/s in some processes and 173 in
+        // others (round 4's 0.95 vs 0.79 of the PCIe ceiling; profiles/r05/batched_bimodal.txt)
+        hipLaunchKernelGGL(pipe_copy_out_kernel, dim3(256), dim3(256), 0, s, reinterpret_cast<const uint32_t*>(ctx->batch_last_frame),
+                           reinterpret_cast<uint32_t*>(buf), pitch / 4);
+        OFPS_HIP_TRY(ctx, hipGetLastError());
         OFPS_HIP_TRY(ctx, hipEventRecord(t.prev_copied, s));
         t.prev_copied_valid = true;
     }

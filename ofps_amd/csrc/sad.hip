@@ -71,7 +71,13 @@ struct SadParams {
     float nx, ny;           // 1/W, 1/H computed on the host in f32 (av-decoder/src/lib.rs:404-405)
     float4* out_entries;
     int* out_best;          // may be null
+    // strip kernels: ceil(2^48 / d) for d = strips per pair and strips per row -- the wave's strip index is split into (pair, block
+    // row, first block) on the scalar unit (multiply-high + shift) instead of two emulated VALU divisions per strip
+    unsigned long long div_spp, div_spr;
 };
+inline unsigned long long div_magic48(unsigned d) { return ((1ull << 48) + d - 1) / d; }
+// floor(n / d) for n * d < 2^48 and n / d < 2^16 (strip indices: asserted where the magic numbers are made)
+__device__ __forceinline__ unsigned div48(unsigned n, unsigned long long m) { return (unsigned)(((unsigned long long)n * m) >> 48); }
 
 __device__ __forceinline__ void write_block_result(const SadParams& p, int pair, int bx, int by, int B, int R,
                                                    unsigned long long key) {
@@ -265,7 +271,10 @@ struct StripCfg {
     static constexpr int MAXCOL = (NB - 1) * BW + (NG - 1) + BW;  // highest dword a lane touches
     static constexpr int SW = ((MAXCOL + 1 > TILE_WG * GDW ? MAXCOL + 1 : TILE_WG * GDW) + 3) / 4 * 4;  // 16-B rows
     static_assert((NB - 1) * BW + EDGE_COL + BW <= SW, "edge column must lie inside a window row");
-    static constexpr int TILE_DWORDS = TILE_H * SW;
+    // the dx = +R pass gives lane chunk g the window rows g*KE .. g*KE + B + KE - 2: the last chunks run past the window (those dy are
+    // masked); the tile is allocated that much taller so the walk needs no row clamp (uninitialised LDS, never used in a result)
+    static constexpr int TILE_ROWS = TILE_H > NG * KE + B - 1 ? TILE_H : NG * KE + B - 1;
+    static constexpr int TILE_DWORDS = TILE_ROWS * SW;
     static_assert(2 * R * R < 65536, "lane key holds d2 in 16 bits");
     // accumulators + current block + ~40 working registers: ask for 3 waves/SIMD (<= 168 VGPRs) when that fits,
     // otherwise hipcc spreads into all 256 registers it is allowed and occupancy drops to 2 for nothing
@@ -333,9 +342,23 @@ __device__ __forceinline__ void strip_rows(unsigned long long (&acc)[StripCfg<B,
 // the row minimum afterwards -- adding the same constant to four keys does not change their order, and
 // dx^2 + dy^2 < 65536 cannot carry into the SAD field; a clipped column holds all-ones and the clamped add
 // keeps it saturated.
+// The argmin's running minimum (round 5; profiles/r05/sad_colkeys.txt).  The kernel is bound by the VALU's SAD unit, and everything
+// else it issues on the VALU is overhead: per dy the argmin used to cost 8 operations (4 key builds, 3 to reduce the 4 dx, 1 running
+// min).  Now there is one running key per COLUMN (dx fixed: within a column the spec's order is (SAD, dy^2, dy), so the key's low
+// half is a per-dy constant in an SGPR) and the running minimum is kept by the LDS UNIT, which has cycles to spare: ds_min_u32
+// (no return) into a per-lane slot -- 4 key builds on the VALU per dy, 4 LDS atomics beside them.  The four column minima are joined
+// with dx^2 once per strip.  -DOFPS_SAD_COLKEYS=0 (per-lane keys, rounds 1-4) and =1 (per-column keys, v_min3_u32 on the VALU) stay
+// selectable for A/B builds (tools/sad_colkeys_ab.sh): 8x8 +-32: 17.28 / 16.98 / 16.73 ms per 64-pair 4K batch, same bits.
+#ifndef OFPS_SAD_COLKEYS
+#define OFPS_SAD_COLKEYS 2
+#endif
+constexpr int kSadColKeys = OFPS_SAD_COLKEYS;
+constexpr int kColSlotDwords = kSadColKeys == 2 ? 4 * 64 : 0;       // LDS per wave for the column minima
+
 template <int B, int R, int I0>
 __device__ __forceinline__ void strip_pass(const uint32_t (&c)[B][B / 4], const uint32_t* lds, uint32_t tile_off,
-                                           const uint32_t (&colk)[4], const uint32_t (&colk_pos)[4], int y0, int H, uint32_t& bkey, int& bi) {
+                                           const uint32_t (&colk)[4], const uint32_t (&colk_pos)[4], int y0, int H, uint32_t& bkey, int& bi,
+                                           uint32_t (&colmin)[4], uint32_t* amin) {
     using C = StripCfg<B, R>;
     unsigned long long acc[C::NP];
 #pragma unroll
@@ -344,6 +367,53 @@ __device__ __forceinline__ void strip_pass(const uint32_t (&c)[B][B / 4], const 
     strip_rows<B, R, I0>(acc, c, lds, tile_off, std::make_integer_sequence<int, ROWS>{});
 #pragma unroll
     for (int ii = 0; ii < C::NP; ++ii) asm volatile("" : "+v"(acc[ii]));
+    if constexpr (kSadColKeys != 0 && (C::RANK_KEY || C::COMPACT_KEY)) {
+        // per-column keys: SAD << 16 | low, low = dy^2 << 1 | (dy > 0) (RANK_KEY) or dy^2 << 6 | dy index (COMPACT_KEY): the order
+        // (SAD, dy^2, dy) inside a column.  A dy clipped by the frame (uniform over the strip) takes the all-ones constant, which
+        // turns both build forms into all-ones: no branch.
+        auto low_of = [&](int ii) -> uint32_t {
+            const int i = I0 + ii, dy = -R + i;
+            const bool ok = i < C::NCAND && y0 + dy >= 0 && y0 + dy + B <= H;
+            return ok ? (uint32_t)(C::RANK_KEY ? ((dy * dy) << 1 | (dy > 0 ? 1 : 0)) : ((dy * dy) << 6 | i)) : 0xFFFFFFFFu;
+        };
+        // `low` lives in an SGPR; (x & 0xFFFF0000) | low with the mask as a literal would put TWO scalar operands on one VOP3
+        // (gfx9: one constant-bus read per instruction) and hipcc splits it into v_and_b32 + v_or_b32 -- 6 operations per dy
+        // for the four builds instead of 4, which is what made round 4's per-column variant slower than the per-lane one
+        // (profiles/r05/sad_colkeys.txt).  With the mask in a VGPR the build is one v_and_or_b32.
+        uint32_t hmask = 0xFFFF0000u;
+        asm volatile("" : "+v"(hmask));
+        auto keys_of = [&](int ii, uint32_t low, uint32_t (&k)[4]) {
+            const uint32_t lo = (uint32_t)acc[ii], hi = (uint32_t)(acc[ii] >> 32);
+            k[0] = (lo << 16) | low; k[1] = (lo & hmask) | low; k[2] = (hi << 16) | low; k[3] = (hi & hmask) | low;
+        };
+        if constexpr (kSadColKeys == 1) {
+#pragma unroll
+            for (int ii = 0; ii < C::NP; ii += 2) {                          // two dy per v_min3_u32 and column
+                if (I0 + ii >= C::NCAND) break;
+                uint32_t ka[4], kb[4];
+                keys_of(ii, low_of(ii), ka);
+                if (ii + 1 < C::NP && I0 + ii + 1 < C::NCAND) {
+                    keys_of(ii + 1, low_of(ii + 1), kb);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)      // (left to itself hipcc forms v_min3_u32 for half of these and two v_min_u32 for the rest)
+                        asm("v_min3_u32 %0, %1, %2, %3" : "=v"(colmin[j]) : "v"(colmin[j]), "v"(ka[j]), "v"(kb[j]));
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) colmin[j] = min(colmin[j], ka[j]);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int ii = 0; ii < C::NP; ++ii) {
+                if (I0 + ii >= C::NCAND) break;
+                uint32_t k[4];
+                keys_of(ii, low_of(ii), k);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) __hip_atomic_fetch_min(amin + 64 * j, k[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int ii = 0; ii < C::NP; ++ii) {
         const int i = I0 + ii;
@@ -373,8 +443,8 @@ __device__ __forceinline__ void strip_pass(const uint32_t (&c)[B][B / 4], const 
 template <int B, int R, int... S>
 __device__ __forceinline__ void strip_passes(const uint32_t (&c)[B][B / 4], const uint32_t* lds, uint32_t tile_off,
                                              const uint32_t (&colk)[4], const uint32_t (&colk_pos)[4], int y0, int H, uint32_t& bkey, int& bi,
-                                             std::integer_sequence<int, S...>) {
-    (strip_pass<B, R, S * StripCfg<B, R>::NP>(c, lds, tile_off, colk, colk_pos, y0, H, bkey, bi), ...);
+                                             uint32_t (&colmin)[4], uint32_t* amin, std::integer_sequence<int, S...>) {
+    (strip_pass<B, R, S * StripCfg<B, R>::NP>(c, lds, tile_off, colk, colk_pos, y0, H, bkey, bi, colmin, amin), ...);
 }
 
 constexpr int kStripWaves = 4;      // independent waves (strips) per workgroup; no workgroup barrier
@@ -384,9 +454,9 @@ template <int B, int R>
 __device__ __forceinline__ void strip_body(const SadParams& p, int strips_per_row, int strip, uint32_t* tiles, int wave, int lane) {
     using C = StripCfg<B, R>;
     const int strips_per_pair = strips_per_row * p.nby;
-    const int pair = strip / strips_per_pair;
+    const int pair = (int)div48((unsigned)strip, p.div_spp);                   // strip / strips_per_pair, scalar unit
     const int rem = strip - pair * strips_per_pair;
-    const int by = rem / strips_per_row;
+    const int by = (int)div48((unsigned)rem, p.div_spr);                       // rem / strips_per_row
     const int bx0 = (rem - by * strips_per_row) * C::NB;
 
     const uint8_t* __restrict__ prev = p.prev_base + (size_t)pair * p.prev_pitch;
@@ -422,18 +492,29 @@ __device__ __forceinline__ void strip_body(const SadParams& p, int strips_per_ro
         }
     }
 
-    // ---- stage the strip's search window: GRAN-byte granules, coalesced along rows
+    // ---- stage the strip's search window: GRAN-byte granules, coalesced along rows.  A lane keeps ONE granule column and walks
+    // the rows LR at a time: its source pointer advances by a row pitch, its LDS destination is base + immediate -- no
+    // per-granule division, no per-granule address arithmetic (the flat index / TILE_WG form cost ~20 VALU operations per
+    // step, 140-160 per strip: 2 % of a strip that is otherwise packed SADs; profiles/r05/sad_colkeys.txt)
     {
+        constexpr int LR = 64 / C::TILE_WG;                            // window rows per step (TILE_WG <= 64 lanes)
+        constexpr int STEPS = (C::TILE_H + LR - 1) / LR;
         const int tx0 = bx0 * B - R, ty0 = y0 - R;
-        for (int idx = lane; idx < C::TILE_H * C::TILE_WG; idx += 64) {
-            const int row = idx / C::TILE_WG, col = idx - row * C::TILE_WG;
-            const int gx = tx0 + C::GRAN * col, gy = ty0 + row;
-            if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) {
-                const uint8_t* src = prev + (size_t)gy * p.stride + gx;
-                uint32_t* dst = tile + row * C::SW + C::GDW * col;
-                if constexpr (C::GRAN == 16) *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(src);
-                else if constexpr (C::GRAN == 8) *reinterpret_cast<uint2*>(dst) = *reinterpret_cast<const uint2*>(src);
-                else *dst = *reinterpret_cast<const uint32_t*>(src);
+        const int sr = lane / C::TILE_WG, sc = lane - sr * C::TILE_WG;
+        const int gx = tx0 + C::GRAN * sc;
+        const bool lane_on = sr < LR && gx >= 0 && gx < p.W;
+        const uint8_t* src = prev + (ptrdiff_t)(ty0 + sr) * p.stride + gx;       // dereferenced only for rows inside the frame
+        uint32_t* dst = tile + sr * C::SW + C::GDW * sc;
+#pragma unroll
+        for (int it = 0; it < STEPS; ++it) {
+            const int row = sr + it * LR;
+            const bool row_in_tile = (it + 1) * LR <= C::TILE_H || row < C::TILE_H;
+            if (lane_on && row_in_tile && (unsigned)(ty0 + row) < (unsigned)p.H) {
+                const uint8_t* sp = src + (ptrdiff_t)(it * LR) * p.stride;
+                uint32_t* dp = dst + it * LR * C::SW;
+                if constexpr (C::GRAN == 16) *reinterpret_cast<uint4*>(dp) = *reinterpret_cast<const uint4*>(sp);
+                else if constexpr (C::GRAN == 8) *reinterpret_cast<uint2*>(dp) = *reinterpret_cast<const uint2*>(sp);
+                else *dp = *reinterpret_cast<const uint32_t*>(sp);
             }
         }
     }
@@ -459,8 +540,34 @@ __device__ __forceinline__ void strip_body(const SadParams& p, int strips_per_ro
     }
     uint32_t bkey = 0xFFFFFFFFu;
     int bi = 0;
-    strip_passes<B, R>(c, tiles, (uint32_t)(wave * C::TILE_DWORDS + b * C::BW + g), colk, colk_pos, y0, p.H, bkey, bi,
+    uint32_t colmin[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    uint32_t* amin = nullptr;
+    if constexpr (kSadColKeys == 2 && (C::RANK_KEY || C::COMPACT_KEY)) {
+        amin = tiles + kStripWaves * C::TILE_DWORDS + wave * kColSlotDwords + lane;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) amin[64 * j] = 0xFFFFFFFFu;
+    }
+    strip_passes<B, R>(c, tiles, (uint32_t)(wave * C::TILE_DWORDS + b * C::BW + g), colk, colk_pos, y0, p.H, bkey, bi, colmin, amin,
                        std::make_integer_sequence<int, C::SPLIT>{});
+    if constexpr (kSadColKeys != 0 && (C::RANK_KEY || C::COMPACT_KEY)) {
+        // column minima -> the lane key of the product layout (SAD << 16 | d2 << KSHIFT | code / dy index), once per strip
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            uint32_t kc;
+            if constexpr (kSadColKeys == 2) kc = __hip_atomic_load(amin + 64 * j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            else kc = colmin[j];
+            uint32_t lk;
+            if constexpr (C::RANK_KEY) {
+                // low = dy^2 << 1 | (dy > 0)  ->  (dx^2 + dy^2) << 3 | code, code = rank for dy <= 0, 7 - rank = rank ^ 7 for dy > 0
+                const uint32_t x = (((kc & 0xFFFEu) << 2) + colk[j]) ^ ((kc & 1u) * 7u);
+                lk = (kc & 0xFFFF0000u) | x;
+            } else {
+                lk = (kc & 0xFFFF0000u) | ((kc & 0xFFFFu) + colk[j]);
+            }
+            lk = (colk[j] == 0xFFFFFFFFu || kc == 0xFFFFFFFFu) ? 0xFFFFFFFFu : lk;
+            bkey = min(bkey, lk);
+        }
+    }
     // decode (d2, dy) -> dx; build the cross-lane key (SAD, d2, dy, dx)
     unsigned long long best = ~0ull;
     if (bkey != 0xFFFFFFFFu) {
@@ -495,15 +602,15 @@ __device__ __forceinline__ void strip_body(const SadParams& p, int strips_per_ro
         // B+KE-1 rows of LDS reads above the loop (80 extra live VGPRs next to acc[] and c[][])
         uint32_t nxt[C::BW];
 #pragma unroll
-        for (int q = 0; q < C::BW; ++q) nxt[q] = ecol[min(erow0, C::TILE_H - 1) * C::SW + q];
+        for (int q = 0; q < C::BW; ++q) nxt[q] = ecol[erow0 * C::SW + q];
 #pragma unroll
         for (int rr = 0; rr < B + C::KE - 1; ++rr) {
             uint32_t ref[C::BW];
 #pragma unroll
             for (int q = 0; q < C::BW; ++q) ref[q] = nxt[q];
             if (rr + 1 < B + C::KE - 1) {
-                // the last chunk overshoots the window by up to KE*NG - NCAND rows: clamp (those dy are masked)
-                const int row = min(erow0 + rr + 1, C::TILE_H - 1);
+                // the last chunks overshoot the window by up to KE*NG - NCAND rows (those dy are masked): the tile has the rows
+                const int row = erow0 + rr + 1;
 #pragma unroll
                 for (int q = 0; q < C::BW; ++q) nxt[q] = ecol[row * C::SW + q];
             }
@@ -560,7 +667,7 @@ template <int B, int R>
 __global__ __launch_bounds__(64 * kStripWaves, (StripCfg<B, R>::MIN_WAVES)) void sad_strip_kernel(const SadParams p, int strips_per_row,
                                                                       int total_strips) {
     using C = StripCfg<B, R>;
-    __shared__ __attribute__((aligned(16))) uint32_t tiles[kStripWaves * C::TILE_DWORDS];
+    __shared__ __attribute__((aligned(16))) uint32_t tiles[kStripWaves * (C::TILE_DWORDS + kColSlotDwords)];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     // XCD-aware remap: workgroup w lands on XCD w % 8; give each XCD a contiguous run of strips
@@ -579,7 +686,7 @@ template <int B, int R>
 __global__ __launch_bounds__(64 * kStripWaves, (StripCfg<B, R>::MIN_WAVES)) void sad_strip_list_kernel(const SadParams p, int strips_per_row,
                                                                            const uint32_t* __restrict__ strip_list) {
     using C = StripCfg<B, R>;
-    __shared__ __attribute__((aligned(16))) uint32_t tiles[kStripWaves * C::TILE_DWORDS];
+    __shared__ __attribute__((aligned(16))) uint32_t tiles[kStripWaves * (C::TILE_DWORDS + kColSlotDwords)];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const int count = (int)strip_list[0];
@@ -929,13 +1036,22 @@ void launch_qsad(const SadParams& p, int pairs, hipStream_t s) {
     hipLaunchKernelGGL((sad_qsad_kernel<B, R, K>), grid, dim3(256), 0, s, p);
 }
 
+// div48's preconditions (n * d < 2^48, n / d < 2^16) are sad_pairs_device's `strip_ok`: < 2^28 blocks per batch (a 4K 8x8 batch of
+// 2,000 pairs), < 2^20 blocks per frame, <= 65,535 pairs; anything larger takes the per-block kernel
+inline void strip_div_magic(SadParams& q, int strips_per_row) {
+    q.div_spp = div_magic48((unsigned)strips_per_row * (unsigned)q.nby);
+    q.div_spr = div_magic48((unsigned)strips_per_row);
+}
+
 template <int B, int R>
 void launch_strip(const SadParams& p, int pairs, hipStream_t s) {
     using C = StripCfg<B, R>;
     const int strips_per_row = (p.nbx + C::NB - 1) / C::NB;
     const int total = strips_per_row * p.nby * pairs;
     const int nwg = ((total + kStripWaves - 1) / kStripWaves + 7) / 8 * 8;     // multiple of 8: see the XCD remap
-    hipLaunchKernelGGL((sad_strip_kernel<B, R>), dim3(nwg), dim3(64 * kStripWaves), 0, s, p, strips_per_row, total);
+    SadParams q = p;
+    strip_div_magic(q, strips_per_row);
+    hipLaunchKernelGGL((sad_strip_kernel<B, R>), dim3(nwg), dim3(64 * kStripWaves), 0, s, q, strips_per_row, total);
 }
 
 // pruned search: sad_pde_kernel over every strip, then the exhaustive kernel over the overflow strips
@@ -949,7 +1065,9 @@ int launch_pde_16_16(ofps_hip_ctx* ctx, const SadParams& p, int pairs, hipStream
     const int nwg = ((total + kStripWaves - 1) / kStripWaves + 7) / 8 * 8;     // multiple of 8: see the XCD remap
     hipLaunchKernelGGL(sad_pde_kernel, dim3(nwg), dim3(64 * kStripWaves), 0, s, p, strips_per_row, total, strip_list);
     const int nwg_ind = nwg < 8 * ctx->num_cus ? nwg : 8 * ctx->num_cus;      // grid-stride walk of the overflow list
-    hipLaunchKernelGGL((sad_strip_list_kernel<16, 16>), dim3(nwg_ind), dim3(64 * kStripWaves), 0, s, p, strips_per_row,
+    SadParams q = p;
+    strip_div_magic(q, strips_per_row);
+    hipLaunchKernelGGL((sad_strip_list_kernel<16, 16>), dim3(nwg_ind), dim3(64 * kStripWaves), 0, s, q, strips_per_row,
                        (const uint32_t*)strip_list);
     return OFPS_HIP_OK;
 }
@@ -977,7 +1095,7 @@ int sad_pairs_device(ofps_hip_ctx* ctx, const uint8_t* prev_base, size_t prev_pi
                  "sad_flow: rows must be 4-byte aligned (stride=%d)", stride);
     OFPS_REQUIRE(ctx, block >= 1 && block <= 64 && range >= 0 && range <= 64,
                  "sad_flow: block=%d range=%d outside [1,64]/[0,64]", block, range);
-    SadParams p;
+    SadParams p{};
     p.prev_base = prev_base; p.cur_base = cur_base;
     p.prev_pitch = prev_pitch; p.cur_pitch = cur_pitch;
     p.W = W; p.H = H; p.stride = stride;
@@ -993,7 +1111,7 @@ int sad_pairs_device(ofps_hip_ctx* ctx, const uint8_t* prev_base, size_t prev_pi
     const bool force_block = ctx->opt.sad_force_block != 0;     // OFPS_HIP_SAD_KERNEL=block (A/B profiling)
     const bool strip_ok = !force_block && stride % 16 == 0 && ((uintptr_t)prev_base % 16) == 0 &&
                           ((uintptr_t)cur_base % 16) == 0 && prev_pitch % 16 == 0 && cur_pitch % 16 == 0 &&
-                          (long long)p.nbx * p.nby * pairs < (1ll << 30);
+                          (long long)p.nbx * p.nby * pairs < (1ll << 28) && (long long)p.nbx * p.nby < (1ll << 20);
     switch (key) {
         // strip kernels need 16-byte aligned rows; otherwise (or with OFPS_HIP_SAD_KERNEL=block, A/B
         // profiling only) the per-block kernel handles the pair.

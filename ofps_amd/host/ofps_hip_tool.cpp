@@ -23,6 +23,10 @@
 #include <iostream>
 #include <sstream>
 
+#include <sched.h>
+#include <sys/syscall.h>
+#include <unistd.h>
+
 #include "ofps_host.hpp"
 
 using namespace ofps;
@@ -151,10 +155,14 @@ int main(int argc, char** argv) {
         }
         if (cmd == "stream-bench" && argc >= 5) {
             // optional `--block B --range R` anywhere behind the mode (default 16 / 16): BASELINE configs[3] is 8 / 32
+            // `--probe` (batch mode): also print the bare H2D rate of one batch buffer, the CPU this thread runs on and the NUMA
+            // node the page-locked buffers landed on (the batched form is bimodal from process to process: profiles/r05/batched_bimodal.txt)
             int sb_block = 16, sb_range = 16;
+            bool sb_probe = false;
             {
                 int keep = 0;
                 for (int a = 0; a < argc; ++a) {
+                    if (std::string(argv[a]) == "--probe") { sb_probe = true; continue; }
                     if (a + 1 < argc && std::string(argv[a]) == "--block") { sb_block = std::atoi(argv[++a]); continue; }
                     if (a + 1 < argc && std::string(argv[a]) == "--range") { sb_range = std::atoi(argv[++a]); continue; }
                     argv[keep++] = argv[a];
@@ -223,6 +231,23 @@ int main(int argc, char** argv) {
                 for (auto& p : ent) { void* q; ctx.check(ofps_hip_host_alloc(ctx.get(), (size_t)batch * nblk * 16, &q)); p = static_cast<float*>(q); }
                 uint32_t st = 12345;
                 for (auto& p : pin) for (size_t i = 0; i < (size_t)batch * W * H; ++i) { st = st * 1664525u + 1013904223u; p[i] = (uint8_t)(st >> 24); }
+                double probe_gbs[2] = {0, 0};
+                int probe_node[2] = {-1, -1}, probe_cpu = -1;
+                if (sb_probe) {
+                    void* d = nullptr;
+                    const size_t bytes = (size_t)batch * W * H;
+                    ctx.check(ofps_hip_malloc(ctx.get(), bytes, &d));
+                    for (int k = 0; k < 2; ++k) {
+                        ctx.check(ofps_hip_memcpy_h2d(ctx.get(), d, pin[k], bytes));
+                        const auto t0 = std::chrono::steady_clock::now();
+                        for (int r = 0; r < 8; ++r) ctx.check(ofps_hip_memcpy_h2d(ctx.get(), d, pin[k], bytes));
+                        probe_gbs[k] = 8.0 * (double)bytes / std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() / 1e9;
+                        void* page = pin[k]; int status = -1;
+                        if (syscall(SYS_move_pages, 0, 1UL, &page, nullptr, &status, 0) == 0) probe_node[k] = status;
+                    }
+                    probe_cpu = sched_getcpu();
+                    ctx.check(ofps_hip_free(ctx.get(), d));
+                }
                 ofps_hip_frame_params prm{}; prm.block = 16; prm.range = 16;
                 std::vector<ofps_hip_frame_result> res((size_t)batch);
                 auto run = [&](int nb) {
@@ -240,6 +265,11 @@ int main(int argc, char** argv) {
                 const auto t0 = std::chrono::steady_clock::now();
                 run(nb);
                 const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / ((double)nb * batch);
+                if (sb_probe)
+                    std::printf("{\"mode\": \"read_ahead_batched\", \"batch\": %d, \"frames\": %d, \"ms_per_frame\": %.4f, \"Mvectors_per_s\": %.2f, "
+                                "\"bare_h2d_GBs\": [%.1f, %.1f], \"buffer_numa_node\": [%d, %d], \"cpu\": %d}\n", batch, nb * batch, ms,
+                                (double)nblk / ms / 1e3, probe_gbs[0], probe_gbs[1], probe_node[0], probe_node[1], probe_cpu);
+                else
                 std::printf("{\"mode\": \"read_ahead_batched\", \"batch\": %d, \"frames\": %d, \"ms_per_frame\": %.4f, \"Mvectors_per_s\": %.2f}\n", batch,
                             nb * batch, ms, (double)nblk / ms / 1e3);
                 for (auto p : pin) ofps_hip_host_free(ctx.get(), p);
