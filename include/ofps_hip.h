@@ -151,6 +151,7 @@ int ofps_hip_contrast_mask_dev(ofps_hip_ctx* ctx, const void* d_gray, int W, int
 /* ofps_hip_lk_decode flags */
 #define OFPS_HIP_LK_CONTRAST_MASK 1u /* drop records of pixels outside the contrast mask of `cur` (the reference's
                                         Farneback path always masks, :203-237,253-257) */
+#define OFPS_HIP_FLOW_FARNEBACK   4u /* the flow is Farneback's (ofps_hip_farneback_flow) instead of the iterative Lucas-Kanade: the "hip_flow" decoder */
 #define OFPS_HIP_LK_PER_PIXEL     2u /* "Process Fullres" = false: one record per (unmasked) pixel in raster order,
                                         no down-sampling (:274-276); the reference resizes its frames to the capped
                                         grid before the flow (:124-133), which is the caller's job here */
@@ -192,6 +193,19 @@ int ofps_hip_lk_flow_init_dev(ofps_hip_ctx* ctx, const void* d_prev, const void*
                               int levels, int radius, int iters, const void* d_init_flow, void* d_out_flow,
                               void* d_out_entries);
 
+/* ---- N2 in the reference's own algorithm family: Farneback's polynomial-expansion flow as cv-decoder calls it
+ * (cv-decoder/src/lib.rs:188-199: pyr_scale 0.5, levels 5, winsize 13, iterations 3, poly_n 7, poly_sigma 1.5; pyr_scale is fixed at 0.5).
+ * The arithmetic the reference runs is OpenCV's (not part of the reference tree: PARITY UNPINNED); this is the published algorithm in the
+ * form calcOpticalFlowFarneback gives it (flags = 0: box window), precision per stage as in OpenCV's CPU path -- DESIGN.md "N2b".
+ * out_flow: 2*W*H f32 (dx, dy) per pixel of `prev` (prev(x,y) ~ cur(x+dx, y+dy)) or NULL; out_entries: 4*W*H f32 records or NULL (at least
+ * one).  init_flow: NULL, or a 2*W*H flow to start from (OPTFLOW_USE_INITIAL_FLOW: cv-decoder passes its previous result).
+ * winsize odd <= 15, poly_n <= 15, at most 6 + 1 pyramid layers of blur taps (levels <= 6 at any size): else OFPS_HIP_EUNSUPPORTED.
+ * OFPS_HIP_FLOW_FARNEBACK in the `flags` of ofps_hip_lk_decode / _lk_push_frame / _lk_push_frame_async selects this flow for the
+ * decoder entry points (levels = pyramid levels, winsize = 2 * radius + 1, iters = iterations; poly_n 7, poly_sigma 1.5). */
+int ofps_hip_farneback_flow(ofps_hip_ctx* ctx, const uint8_t* prev, const uint8_t* cur, int W, int H, int stride, int levels, int winsize,
+                            int iters, int poly_n, float poly_sigma, const float* init_flow, float* out_flow, float* out_entries);
+int ofps_hip_farneback_flow_dev(ofps_hip_ctx* ctx, const void* d_prev, const void* d_cur, int W, int H, int stride, int levels, int winsize,
+                                int iters, int poly_n, float poly_sigma, const void* d_init_flow, void* d_out_flow, void* d_out_entries);
 /* ---- A1-A4: MotionFieldDensifier ---- */
 int ofps_hip_densify(ofps_hip_ctx* ctx, const float* entries, size_t n, int w, int h,
                      float* out_field /* 2*w*h, cell (x,y) at 2*(y*w+x) */,

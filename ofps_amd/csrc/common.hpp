@@ -132,9 +132,10 @@ enum ScratchSlot {
     // the one-launch LK pyramid's tile flags + expired-wait counter: they carry state ACROSS calls (epoch tags, never cleared), so the slot
     // is nobody else's (round 4: they sat in S_WORK3, which the densifier's per-cell tables also use -- a decode call wiped the counter,
     // and a begin[] value equal to a later launch's epoch would have read as "parent tile done")
-    S_LK_FLAGS
+    S_LK_FLAGS,
+    S_FB_WORK               // farneback.hip: blur / image / expansion / flow planes of one pair
 };
-static_assert(S_LK_FLAGS < ofps_hip_ctx::kNumScratch, "scratch table too small");
+static_assert(S_FB_WORK < ofps_hip_ctx::kNumScratch, "scratch table too small");
 
 // Page-locked blocks that kernels write directly and the host reads after an event (ticket result blocks, ofps_hip_host_alloc):
 // fine-grained host memory, asked for explicitly.  A/B builds (tools/read_ahead_bisect.sh) override the two constants with -D.
@@ -173,6 +174,8 @@ int compact_entries_device(ofps_hip_ctx* ctx, const float4* d_in, const uint8_t*
                            uint32_t* d_count);
 int detect_device(ofps_hip_ctx* ctx, const float4* d_entries, size_t n, int batch, float min_size, size_t subdivide,
                   float target_motion, int* d_result, float2* d_out_field, int* out_dim);
+int farneback_flow_device(ofps_hip_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_cur, int W, int H, int stride, int levels, int winsize,
+                          int iters, int poly_n, double poly_sigma, const float2* d_init, float2* d_flow, float4* d_entries);
 int lk_check_dev_calls(ofps_hip_ctx* ctx);          // lk.hip: did a device-pointer LK launch since the last look have an expired wait?
 int almeida_device(ofps_hip_ctx* ctx, const float4* d_entries, size_t n, int batch, float aspect, float fov_y_deg,
                    int use_ransac, size_t num_iters, float inlier_deg, size_t num_samples, uint64_t seed, float4* d_quat);

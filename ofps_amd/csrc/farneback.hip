@@ -1,0 +1,629 @@
+// farneback.hip -- N2 in the reference's own algorithm family: Farneback's polynomial-expansion dense flow as cv-decoder calls it
+//   cv-decoder/src/lib.rs:188-199:  calc_optical_flow_farneback(old_gray, gray, flow, 0.5, 5, 13, 3, 7, 1.5, flags)
+// (the "hip_flow" decoder's compute; hip_lk is the build-defined iterative Lucas-Kanade).  The arithmetic the reference runs lives in
+// OpenCV (not under /root/reference, not installed: PARITY UNPINNED); what is implemented is the published algorithm in the form
+// OpenCV's calcOpticalFlowFarneback gives it, stage by stage with the same precision per stage (f32 blur / resize / vertical half of
+// the expansion / matrices, f64 horizontal half / window sums / 2x2 solve) -- DESIGN.md "N2b", oracle/farneback_oracle.c.
+//
+// Per pyramid layer k = K .. 0 (scale 0.5^k, every layer made from the ORIGINAL frames):
+//   fb_hblur_kernel      Gaussian row filter of the u8 frame at the columns the resize will sample        -> T   [2][H][ncol]
+//   fb_vblur_kernel      column filter at the rows the resize samples + the bilinear combine              -> I_k [2][h][w]
+//   fb_polyexp_kernel    15-tap separable polynomial expansion (tile + halo in LDS)                        -> R   [2][5][h][w]  (planar)
+//   fb_iter_kernel x iters   ONE kernel per update: a workgroup owns a 32 x 16 tile of the flow; it computes the five matrix
+//                        channels of every pixel of the tile + window halo from R0, R1 (bilinear at x + flow) and the current
+//                        flow straight into LDS -- FarnebackUpdateMatrices never goes to memory --, forms the window sums
+//                        (f64, rows then columns) and solves the 2 x 2 system                              -> flow' [h][w]
+//                        The first update of a layer reads the COARSER layer's flow and resizes it on the fly (x 2).
+// All streaming: the honest roofline of this path is HBM (R0 + R1 + flow per update).
+#include "common.hpp"
+
+#include <cmath>
+#include <vector>
+
+namespace {
+
+constexpr int kMaxBlurTaps = 128;       // 2 r + 1 <= 79 for six layers; up to nine layers (r = 639) would not fit: refused
+constexpr int kMaxPolyN = 15;
+
+struct FbBlur {                         // Gaussian taps of one layer (getGaussianKernel(ksize, sigma, CV_32F))
+    int r;
+    float taps[kMaxBlurTaps];
+};
+struct FbPoly {                         // FarnebackPrepareGaussian
+    int n;
+    float g[kMaxPolyN + 1], xg[kMaxPolyN + 1], xxg[kMaxPolyN + 1];
+    double ig11, ig03, ig33, ig55;
+};
+
+int round_half_even(double v) { return (int)std::nearbyint(v); }       // cvRound
+
+bool make_blur(int k, FbBlur* b) {
+    double scale = 1.0;
+    for (int i = 0; i < k; ++i) scale *= 0.5;
+    const double sigma = (1.0 / scale - 1.0) * 0.5;
+    int ksize = round_half_even(sigma * 5) | 1;
+    if (ksize < 3) ksize = 3;
+    if (ksize > kMaxBlurTaps) return false;
+    b->r = ksize / 2;
+    if (sigma <= 0) { b->taps[0] = 0.25f; b->taps[1] = 0.5f; b->taps[2] = 0.25f; return true; }
+    const double s2 = -0.5 / (sigma * sigma);
+    double sum = 0;
+    for (int i = 0; i < ksize; ++i) {
+        const double x = i - (ksize - 1) * 0.5;
+        b->taps[i] = (float)std::exp(s2 * x * x);
+        sum += b->taps[i];
+    }
+    sum = 1.0 / sum;
+    for (int i = 0; i < ksize; ++i) b->taps[i] = (float)(b->taps[i] * sum);
+    return true;
+}
+
+void make_poly(int n, double sigma, FbPoly* p) {
+    if (sigma < 1.1920929e-07) sigma = n * 0.3;
+    std::vector<float> full((size_t)(2 * n + 1));
+    double s = 0;
+    for (int x = -n; x <= n; ++x) { full[(size_t)(x + n)] = (float)std::exp(-x * x / (2 * sigma * sigma)); s += full[(size_t)(x + n)]; }
+    s = 1.0 / s;
+    double b = 0, c = 0;
+    for (int x = -n; x <= n; ++x) {
+        const float gv = (float)(full[(size_t)(x + n)] * s);
+        if (x >= 0) { p->g[x] = gv; p->xg[x] = (float)(x * gv); p->xxg[x] = (float)(x * x * gv); }
+        b += (double)gv * x * x; c += (double)gv * x * x * x * x;
+    }
+    double a = 0;
+    for (int x = -n; x <= n; ++x) a += (double)p->g[x < 0 ? -x : x];
+    // moment matrix in the basis (1, x, y, x^2, y^2, xy): G00 = a^2, G11 = G03 = a b, G33 = a c, G34 = G55 = b^2; closed-form inverse
+    const double A = a * a, B = a * b, C = a * c, D = b * b;
+    const double det = (C - D) * (A * (C + D) - 2 * B * B);
+    p->n = n;
+    p->ig11 = 1.0 / B; p->ig03 = -B * (C - D) / det; p->ig33 = (A * C - B * B) / det; p->ig55 = 1.0 / D;
+}
+
+__device__ __forceinline__ int reflect101(int i, int n) {
+    if (n == 1) return 0;
+    while (i < 0 || i >= n) i = i < 0 ? -i : 2 * n - 2 - i;
+    return i;
+}
+
+// resize INTER_LINEAR, one axis: source index and fraction of destination index d (half-pixel centres, clamped); inv = 1 / (dn / sn) in f64
+__device__ __forceinline__ void resize_axis(int d, int sn, double inv, int* s0, int* s1, float* f) {
+    float fr = (float)((d + 0.5) * inv - 0.5);
+    int s = (int)floorf(fr);
+    fr -= (float)s;
+    if (s < 0) { fr = 0; s = 0; }
+    if (s >= sn - 1) { fr = 0; s = sn - 1; }
+    *s0 = s; *s1 = s + 1 < sn ? s + 1 : sn - 1; *f = fr;
+}
+
+// ---- the pyramid above layer 0, both passes for ALL layers in one launch each -----------------------------------------------------
+// Every layer is OpenCV's "blur the original, then resize": the resize samples two columns and two rows per output, so the row filter
+// is evaluated only at those columns (T_k [2][H][2 w_k]) and the column filter only at those rows.
+constexpr int kMaxLayers = 7;           // k = 0 .. 6
+constexpr int kMaxTaps = 320;           // 3 + 9 + 19 + 39 + 79 + 159 for k = 1 .. 6
+struct FbPyr {
+    int K;                              // layers 1 .. K are made here (layer 0 inside the expansion kernel)
+    int w[kMaxLayers], h[kMaxLayers], r[kMaxLayers], toff[kMaxLayers];
+    double inv_x[kMaxLayers], inv_y[kMaxLayers];
+    size_t t_off[kMaxLayers];           // T_k inside T (floats, per image block of the layer: [2][H][2 w_k])
+    size_t i_off[kMaxLayers];           // I_k inside I (floats: [2][h_k][w_k])
+    int blk0[kMaxLayers + 1];           // fb_pyr_v_kernel / multi-layer launches: first block of layer k
+    float taps[kMaxTaps];
+};
+
+// one workgroup per (frame row, image): the row goes to LDS once, every layer's sampled columns come out of it.  The sampled columns of
+// layer k are 2^k apart: the row is stored with one pad word per 32 so that a wave's reads do not all fall into two banks.
+__device__ __forceinline__ int fb_pad(int i) { return i + (i >> 5); }
+__global__ __launch_bounds__(256) void fb_pyr_h_kernel(const uint8_t* __restrict__ img0, const uint8_t* __restrict__ img1, int W, int H, int stride,
+                                                       const FbPyr P, float* __restrict__ T) {
+    extern __shared__ float srow[];
+    __shared__ float staps[kMaxTaps];                  // (indexing the kernel-argument copy costs a scalar load + wait per tap)
+    const int row = blockIdx.x, z = blockIdx.y;
+    const uint8_t* img = (z ? img1 : img0) + (size_t)row * stride;
+    for (int x = threadIdx.x; x < W; x += 256) srow[fb_pad(x)] = (float)img[x];
+    for (int i = threadIdx.x; i < kMaxTaps; i += 256) staps[i] = P.taps[i];
+    __syncthreads();
+    for (int k = 1; k <= P.K; ++k) {
+        const int ncol = 2 * P.w[k], r = P.r[k];
+        const float* taps = staps + P.toff[k];
+        float* Tk = T + P.t_off[k] + ((size_t)z * H + row) * ncol;
+        for (int c = threadIdx.x; c < ncol; c += 256) {
+            int s0, s1; float f;
+            resize_axis(c >> 1, W, P.inv_x[k], &s0, &s1, &f);
+            const int xs = (c & 1) ? s1 : s0;
+            float s = taps[r] * srow[fb_pad(xs)];
+            if (xs - r >= 0 && xs + r < W) {                      // interior: no border arithmetic per tap
+                for (int j = 1; j <= r; ++j) s += taps[r + j] * (srow[fb_pad(xs - j)] + srow[fb_pad(xs + j)]);
+            } else {
+                for (int j = 1; j <= r; ++j) s += taps[r + j] * (srow[fb_pad(reflect101(xs - j, W))] + srow[fb_pad(reflect101(xs + j, W))]);
+            }
+            Tk[c] = s;
+        }
+    }
+}
+
+// column filter at the sampled rows + HResizeLinear / VResizeLinear; 1-D grid over (layer, 16 x 4 tile), blockIdx.y = image.  A thread
+// owns ONE of an output's four column sums (the long serial part: up to 159 taps), the quad's first lane combines them.
+__global__ __launch_bounds__(256) void fb_pyr_v_kernel(const float* __restrict__ T, int W, int H, const FbPyr P, float* __restrict__ I) {
+    __shared__ float staps[kMaxTaps];
+    for (int i = threadIdx.x; i < kMaxTaps; i += 256) staps[i] = P.taps[i];
+    __syncthreads();
+    int k = 1;
+    while (k < P.K && (int)blockIdx.x >= P.blk0[k + 1]) ++k;
+    const int w = P.w[k], h = P.h[k], r = P.r[k];
+    const int tiles_x = (w + 15) / 16, b = (int)blockIdx.x - P.blk0[k];
+    const int o = threadIdx.x >> 2, corner = threadIdx.x & 3;
+    int x = (b % tiles_x) * 16 + (o & 15), y = (b / tiles_x) * 4 + (o >> 4);
+    const bool live = x < w && y < h;
+    x = x < w ? x : w - 1; y = y < h ? y : h - 1;                 // (every lane takes part in the shuffles)
+    const int ncol = 2 * w, z = blockIdx.y;
+    const float* Tz = T + P.t_off[k] + (size_t)z * H * ncol;
+    const float* taps = staps + P.toff[k];
+    int y0, y1, xs0, xs1; float a1, b1;
+    resize_axis(x, W, P.inv_x[k], &xs0, &xs1, &a1);               // (the two source columns are T's columns 2 x and 2 x + 1)
+    resize_axis(y, H, P.inv_y[k], &y0, &y1, &b1);
+    const int ys = (corner & 2) ? y1 : y0, c = 2 * x + (corner & 1);
+    const float* p = Tz + (size_t)ys * ncol + c;
+    float s = taps[r] * p[0];
+    if (ys - r >= 0 && ys + r < H) {                              // interior: eight tap pairs' loads in flight at a time, summed in order
+        int j = 1;
+        for (; j + 7 <= r; j += 8) {
+            float lo[8], hi[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { lo[q] = p[-(ptrdiff_t)(j + q) * ncol]; hi[q] = p[(ptrdiff_t)(j + q) * ncol]; }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) s += taps[r + j + q] * (lo[q] + hi[q]);
+        }
+        for (; j <= r; ++j) s += taps[r + j] * (p[-(ptrdiff_t)j * ncol] + p[(ptrdiff_t)j * ncol]);
+    } else {
+        for (int j = 1; j <= r; ++j) s += taps[r + j] * (Tz[(size_t)reflect101(ys - j, H) * ncol + c] + Tz[(size_t)reflect101(ys + j, H) * ncol + c]);
+    }
+    const float c01 = __shfl_down(s, 1), c10 = __shfl_down(s, 2), c11 = __shfl_down(s, 3);
+    if (corner == 0 && live) {
+        const float a0 = 1.0f - a1, b0 = 1.0f - b1;
+        const float h0 = s * a0 + c01 * a1;
+        const float h1 = c10 * a0 + c11 * a1;
+        I[P.i_off[k] + ((size_t)z * h + y) * w + x] = h0 * b0 + h1 * b1;
+    }
+}
+
+// ---- FarnebackPolyExp: I -> R [5][h][w] planar; tile 64 x 16, halo n, replicate border.  One launch covers a list of (layer, image)
+// jobs.  Layer 0's image is never stored: its [1 2 1]/4 x [1 2 1]/4 blur of the u8 frame is evaluated while the tile is filled.
+constexpr int kPX = 64, kPY = 16;
+struct FbExpJob { const float* I; const uint8_t* u8; int stride; int w, h; float* R; int blk0, tiles_x; };
+struct FbExp { int njobs; FbExpJob job[2 * kMaxLayers]; };
+
+template <int N_>                               // N_ > 0: poly_n known at compile time (loops unrolled, taps in registers); 0: any
+__global__ __launch_bounds__(256) void fb_polyexp_kernel(const FbExp E, const FbPoly P, float t_c, float t_s) {
+    extern __shared__ float sh[];
+    int jb = 0;
+    while (jb + 1 < E.njobs && (int)blockIdx.x >= E.job[jb + 1].blk0) ++jb;
+    const FbExpJob J = E.job[jb];
+    const int w = J.w, h = J.h;
+    const int b = (int)blockIdx.x - J.blk0;
+    const int n = N_ > 0 ? N_ : P.n, HW = kPX + 2 * n, HH = kPY + 2 * n;
+    float* sI = sh;                               // [HH][HW]
+    float* sV = sh + HH * HW;                     // [3][kPY][HW]
+    const int x0 = (b % J.tiles_x) * kPX, y0 = (b / J.tiles_x) * kPY;
+    for (int i = threadIdx.x; i < HH * HW; i += 256) {
+        const int hy = i / HW, hx = i - hy * HW;
+        int gx = x0 - n + hx, gy = y0 - n + hy;
+        gx = gx < 0 ? 0 : (gx > w - 1 ? w - 1 : gx);
+        gy = gy < 0 ? 0 : (gy > h - 1 ? h - 1 : gy);
+        float v;
+        if (J.u8) {                               // layer 0: row filter then column filter of the u8 frame, reflect-101, taps (t_s, t_c, t_s)
+            const int xm = reflect101(gx - 1, w), xp = reflect101(gx + 1, w);
+            const uint8_t* r0 = J.u8 + (size_t)gy * J.stride;
+            const uint8_t* rm = J.u8 + (size_t)reflect101(gy - 1, h) * J.stride;
+            const uint8_t* rp = J.u8 + (size_t)reflect101(gy + 1, h) * J.stride;
+            const float h0 = t_c * (float)r0[gx] + t_s * ((float)r0[xm] + (float)r0[xp]);
+            const float hm = t_c * (float)rm[gx] + t_s * ((float)rm[xm] + (float)rm[xp]);
+            const float hp = t_c * (float)rp[gx] + t_s * ((float)rp[xm] + (float)rp[xp]);
+            v = t_c * h0 + t_s * (hm + hp);
+        } else {
+            v = J.I[(size_t)gy * w + gx];
+        }
+        sI[i] = v;
+    }
+    __syncthreads();
+    // vertical half (f32).  The oracle clamps ROW INDICES (y - k, y + k) to the image, which the clamped fill above reproduces.
+    for (int i = threadIdx.x; i < kPY * HW; i += 256) {
+        const int ty = i / HW, hx = i - ty * HW;
+        const float* c = sI + (ty + n) * HW + hx;
+        float t0 = c[0] * P.g[0], t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int k = 1; k <= n; ++k) {
+            const float a = c[-k * HW], bb = c[k * HW];
+            const float p = a + bb;
+            t0 = t0 + P.g[k] * p;
+            t1 = t1 + P.xg[k] * (bb - a);
+            t2 = t2 + P.xxg[k] * p;
+        }
+        sV[i] = t0; sV[kPY * HW + i] = t1; sV[2 * kPY * HW + i] = t2;
+    }
+    __syncthreads();
+    const size_t plane = (size_t)w * h;
+    for (int i = threadIdx.x; i < kPY * kPX; i += 256) {
+        const int ty = i / kPX, tx = i - ty * kPX;
+        const int gx = x0 + tx, gy = y0 + ty;
+        if (gx >= w || gy >= h) continue;
+        const float* r0 = sV + ty * HW + tx + n;
+        const float* r1 = r0 + kPY * HW;
+        const float* r2 = r1 + kPY * HW;
+        const float g0 = P.g[0];
+        double b1 = r0[0] * g0, b2 = 0, b3 = r1[0] * g0, b4 = 0, b5 = r2[0] * g0, b6 = 0;
+#pragma unroll
+        for (int k = 1; k <= n; ++k) {
+            const double tg = r0[k] + r0[-k];
+            const float gk = P.g[k];
+            b1 += tg * gk;
+            b4 += tg * P.xxg[k];
+            b2 += (r0[k] - r0[-k]) * P.xg[k];
+            b3 += (r1[k] + r1[-k]) * gk;
+            b6 += (r1[k] - r1[-k]) * P.xg[k];
+            b5 += (r2[k] + r2[-k]) * gk;
+        }
+        const size_t o = (size_t)gy * w + gx;
+        J.R[o] = (float)(b3 * P.ig11);
+        J.R[plane + o] = (float)(b2 * P.ig11);
+        J.R[2 * plane + o] = (float)(b1 * P.ig03 + b5 * P.ig33);
+        J.R[3 * plane + o] = (float)(b1 * P.ig03 + b4 * P.ig33);
+        J.R[4 * plane + o] = (float)(b6 * P.ig55);
+    }
+}
+
+// ---- FarnebackUpdateMatrices for one pixel: R0, R1 planar [5][h][w]
+struct FbLayer { const float* R0; const float* R1; int w, h; };
+__device__ __forceinline__ void fb_matrices(const FbLayer& L, int x, int y, float dx, float dy, float (&m)[5]) {
+    const int w = L.w, h = L.h;
+    const size_t plane = (size_t)w * h, o = (size_t)y * w + x;
+    const float q0 = L.R0[o], q1 = L.R0[plane + o], q2 = L.R0[2 * plane + o], q3 = L.R0[3 * plane + o], q4 = L.R0[4 * plane + o];
+    float fx = x + dx, fy = y + dy;
+    const int x1 = (int)floorf(fx), y1 = (int)floorf(fy);
+    float r2, r3, r4, r5, r6;
+    fx -= x1; fy -= y1;
+    if ((unsigned)x1 < (unsigned)(w - 1) && (unsigned)y1 < (unsigned)(h - 1)) {
+        const float* p = L.R1 + (size_t)y1 * w + x1;
+        const float a00 = (1.f - fx) * (1.f - fy), a01 = fx * (1.f - fy), a10 = (1.f - fx) * fy, a11 = fx * fy;
+        r2 = a00 * p[0] + a01 * p[1] + a10 * p[w] + a11 * p[w + 1]; p += plane;
+        r3 = a00 * p[0] + a01 * p[1] + a10 * p[w] + a11 * p[w + 1]; p += plane;
+        r4 = a00 * p[0] + a01 * p[1] + a10 * p[w] + a11 * p[w + 1]; p += plane;
+        r5 = a00 * p[0] + a01 * p[1] + a10 * p[w] + a11 * p[w + 1]; p += plane;
+        r6 = a00 * p[0] + a01 * p[1] + a10 * p[w] + a11 * p[w + 1];
+        r4 = (q2 + r4) * 0.5f; r5 = (q3 + r5) * 0.5f; r6 = (q4 + r6) * 0.25f;
+    } else {
+        r2 = r3 = 0.f;
+        r4 = q2; r5 = q3; r6 = q4 * 0.5f;
+    }
+    r2 = (q0 - r2) * 0.5f; r3 = (q1 - r3) * 0.5f;
+    r2 += r4 * dy + r6 * dx;
+    r3 += r6 * dy + r5 * dx;
+    constexpr int BORDER = 5;
+    if ((unsigned)(x - BORDER) >= (unsigned)(w - BORDER * 2) || (unsigned)(y - BORDER) >= (unsigned)(h - BORDER * 2)) {
+        const float border[BORDER] = {0.14f, 0.14f, 0.4472f, 0.4472f, 0.4472f};
+        const float scale = (x < BORDER ? border[x] : 1.f) * (x >= w - BORDER ? border[w - x - 1] : 1.f) *
+                            (y < BORDER ? border[y] : 1.f) * (y >= h - BORDER ? border[h - y - 1] : 1.f);
+        r2 *= scale; r3 *= scale; r4 *= scale; r5 *= scale; r6 *= scale;
+    }
+    m[0] = r4 * r4 + r6 * r6;
+    m[1] = (r4 + r5) * r6;
+    m[2] = r5 * r5 + r6 * r6;
+    m[3] = r4 * r2 + r6 * r3;
+    m[4] = r6 * r2 + r5 * r3;
+}
+
+// ---- a layer's first matrices, from the flow the layer starts with: 0 = zero, 2 = the coarser layer's flow resized x 2,
+// 3 = the caller's full-resolution flow averaged over the pixel's footprint and scaled (OPTFLOW_USE_INITIAL_FLOW; coarsest layer only)
+struct FbStart { FbLayer L; int mode; const float2* flow_in; int pw, ph; double inv_x, inv_y; float init_scale; float* M; };
+
+__device__ __forceinline__ float2 fb_start_flow(const FbStart& a, int x, int y) {
+    if (a.mode == 2) {
+        int x0, x1, y0, y1; float a1, b1;
+        resize_axis(x, a.pw, a.inv_x, &x0, &x1, &a1);
+        resize_axis(y, a.ph, a.inv_y, &y0, &y1, &b1);
+        const float a0 = 1.0f - a1, b0 = 1.0f - b1;
+        const float2 p00 = a.flow_in[(size_t)y0 * a.pw + x0], p01 = a.flow_in[(size_t)y0 * a.pw + x1];
+        const float2 p10 = a.flow_in[(size_t)y1 * a.pw + x0], p11 = a.flow_in[(size_t)y1 * a.pw + x1];
+        float2 f;
+        { const float h0 = p00.x * a0 + p01.x * a1, h1 = p10.x * a0 + p11.x * a1; f.x = (h0 * b0 + h1 * b1) * 2.0f; }
+        { const float h0 = p00.y * a0 + p01.y * a1, h1 = p10.y * a0 + p11.y * a1; f.y = (h0 * b0 + h1 * b1) * 2.0f; }
+        return f;
+    }
+    if (a.mode == 3) {                         // INTER_AREA of the caller's flow (pw x ph) onto this layer, times the layer's scale
+        const double fx = (double)a.pw / a.L.w, fy = (double)a.ph / a.L.h;
+        const double xa = x * fx, xb = (x + 1) * fx, ya = y * fy, yb = (y + 1) * fy;
+        double sx = 0, sy = 0, sw = 0;
+        for (int yy = (int)floor(ya); yy < (int)ceil(yb) && yy < a.ph; ++yy) {
+            const double wy = fmin((double)(yy + 1), yb) - fmax((double)yy, ya);
+            for (int xx = (int)floor(xa); xx < (int)ceil(xb) && xx < a.pw; ++xx) {
+                const double wgt = wy * (fmin((double)(xx + 1), xb) - fmax((double)xx, xa));
+                const float2 v = a.flow_in[(size_t)yy * a.pw + xx];
+                sx += wgt * v.x; sy += wgt * v.y; sw += wgt;
+            }
+        }
+        return make_float2((float)(sx / sw * (double)a.init_scale), (float)(sy / sw * (double)a.init_scale));
+    }
+    return make_float2(0.f, 0.f);
+}
+
+__global__ __launch_bounds__(256) void fb_start_kernel(const FbStart a) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= a.L.w || y >= a.L.h) return;
+    const float2 f = fb_start_flow(a, x, y);
+    float m[5];
+    fb_matrices(a.L, x, y, f.x, f.y, m);
+    const size_t plane = (size_t)a.L.w * a.L.h, o = (size_t)y * a.L.w + x;
+#pragma unroll
+    for (int c = 0; c < 5; ++c) a.M[c * plane + o] = m[c];
+}
+
+// ---- one update: FarnebackUpdateFlow_Blur on a 32 x 16 tile (window radius m <= 7; window sums in f64, rows then columns, ascending)
+// and -- except in a layer's last update -- FarnebackUpdateMatrices for the tile's own pixels from the flow just solved: the next
+// update's matrices are written where the flow they depend on is produced, and the flow itself is stored only when somebody reads it
+// (the next layer's start, the caller).
+constexpr int kTX = 32, kTY = 16, kMaxM = 7;
+struct FbIter {
+    FbLayer L; int m;
+    const float* M_in;                         // [5][h][w]
+    float* M_out;                              // or nullptr (last update of the layer)
+    float2* flow_out;                          // or nullptr
+    float4* out_entries; float nx, ny;         // layer 0, last update: the per-pixel records (cv-decoder/src/lib.rs:262-269), or nullptr
+};
+
+template <int M_>
+__global__ __launch_bounds__(256) void fb_iter_kernel(const FbIter a) {
+    constexpr int HW = kTX + 2 * M_, HH = kTY + 2 * M_, WIN = 2 * M_ + 1;
+    __shared__ float sM[5][HH][HW];
+    __shared__ double sV[5][kTY][HW];
+    const int w = a.L.w, h = a.L.h;
+    const int x0 = blockIdx.x * kTX, y0 = blockIdx.y * kTY;
+    const size_t plane = (size_t)w * h;
+    for (int i = threadIdx.x; i < HH * HW; i += 256) {            // replicate border = the clamped pixel's matrices
+        const int hy = i / HW, hx = i - hy * HW;
+        int x = x0 - M_ + hx, y = y0 - M_ + hy;
+        x = x < 0 ? 0 : (x > w - 1 ? w - 1 : x);
+        y = y < 0 ? 0 : (y > h - 1 ? h - 1 : y);
+        const size_t o = (size_t)y * w + x;
+#pragma unroll
+        for (int c = 0; c < 5; ++c) sM[c][hy][hx] = a.M_in[c * plane + o];
+    }
+    __syncthreads();
+    // window sums over rows: an item is (channel, column, group of four rows): 4 + 2m values from LDS, four direct sums in registers
+    // (each ascending over its 2m + 1 rows, f64: the oracle's order)
+    constexpr int RG = 4;
+    for (int i = threadIdx.x; i < 5 * HW * (kTY / RG); i += 256) {
+        const int c = i / (HW * (kTY / RG)), rem = i - c * (HW * (kTY / RG)), g = rem / HW, hx = rem - g * HW;
+        float v[RG + 2 * M_];
+#pragma unroll
+        for (int j = 0; j < RG + 2 * M_; ++j) v[j] = sM[c][RG * g + j][hx];
+#pragma unroll
+        for (int q = 0; q < RG; ++q) {
+            double t = 0;
+#pragma unroll
+            for (int j = 0; j < WIN; ++j) t += v[q + j];
+            sV[c][RG * g + q][hx] = t;
+        }
+    }
+    __syncthreads();
+    const double scale = 1.0 / (WIN * WIN);
+    {   // one thread = two horizontally adjacent pixels
+        const int ty = threadIdx.x / (kTX / 2), tx = 2 * (threadIdx.x - ty * (kTX / 2));
+        double s[2][5];
+#pragma unroll
+        for (int c = 0; c < 5; ++c) {
+            double v[WIN + 1];
+#pragma unroll
+            for (int j = 0; j < WIN + 1; ++j) v[j] = sV[c][ty][tx + j];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                double t = 0;
+#pragma unroll
+                for (int j = 0; j < WIN; ++j) t += v[q + j];
+                s[q][c] = t;
+            }
+        }
+        const int y = y0 + ty;
+        float u[2], v[2], mm[2][5];
+        bool in[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            in[q] = x0 + tx + q < w && y < h;
+            const double g11 = s[q][0] * scale, g12 = s[q][1] * scale, g22 = s[q][2] * scale, h1 = s[q][3] * scale, h2 = s[q][4] * scale;
+            const double idet = 1. / (g11 * g22 - g12 * g12 + 1e-3);
+            u[q] = (float)((g11 * h2 - g12 * h1) * idet); v[q] = (float)((g22 * h1 - g12 * h2) * idet);
+        }
+        // the next update's matrices of both pixels before any store: their gathers overlap (a store in between would order them)
+        if (a.M_out) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+                if (in[q]) fb_matrices(a.L, x0 + tx + q, y, u[q], v[q], mm[q]);
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            if (!in[q]) continue;
+            const int x = x0 + tx + q;
+            const size_t o = (size_t)y * w + x;
+            if (a.flow_out) a.flow_out[o] = make_float2(u[q], v[q]);
+            if (a.out_entries) a.out_entries[o] = make_float4(((float)x + 0.5f) * a.nx, ((float)y + 0.5f) * a.ny, u[q] * a.nx, v[q] * a.ny);
+            if (a.M_out) {
+#pragma unroll
+                for (int c = 0; c < 5; ++c) a.M_out[c * plane + o] = mm[q][c];
+            }
+        }
+    }
+}
+
+template <int M_>
+void launch_iter(const FbIter& a, hipStream_t s) {
+    hipLaunchKernelGGL((fb_iter_kernel<M_>), dim3((a.L.w + kTX - 1) / kTX, (a.L.h + kTY - 1) / kTY), dim3(256), 0, s, a);
+}
+
+}  // namespace
+
+namespace ofps {
+
+// layers k = 0 .. result that calcOpticalFlowFarneback runs (a layer under 32 px ends the pyramid)
+int farneback_layers(int W, int H, int levels) {
+    double scale = 1.0;
+    int k;
+    for (k = 0; k < levels; ++k) {
+        scale *= 0.5;
+        if (W * scale < 32 || H * scale < 32) break;
+    }
+    return k;
+}
+
+// d_prev / d_cur: u8 luma on the device (row pitch `stride`).  d_init: nullptr or W x H float2 (OPTFLOW_USE_INITIAL_FLOW).  d_flow (W x H
+// float2) and / or d_entries (W x H float4 records) receive the result.  Everything is enqueued on ctx->stream.
+int farneback_flow_device(ofps_hip_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_cur, int W, int H, int stride, int levels, int winsize,
+                          int iters, int poly_n, double poly_sigma, const float2* d_init, float2* d_flow, float4* d_entries) {
+    OFPS_REQUIRE(ctx, W >= 1 && H >= 1 && stride >= W, "farneback: bad geometry W=%d H=%d stride=%d", W, H, stride);
+    OFPS_REQUIRE(ctx, levels >= 0 && levels <= 16 && iters >= 1 && iters <= 64 && winsize >= 1 && (winsize & 1) && poly_n >= 1,
+                 "farneback: levels=%d winsize=%d iters=%d poly_n=%d out of range", levels, winsize, iters, poly_n);
+    if (winsize / 2 > kMaxM || poly_n > kMaxPolyN)
+        return set_error(ctx, OFPS_HIP_EUNSUPPORTED, "farneback: winsize %d > %d or poly_n %d > %d has no kernel", winsize, 2 * kMaxM + 1, poly_n, kMaxPolyN);
+    OFPS_REQUIRE(ctx, d_flow || d_entries, "farneback: no output");
+    hipStream_t s = ctx->stream;
+    const int K = farneback_layers(W, H, levels);
+    if (K >= kMaxLayers || W > 16384)
+        return set_error(ctx, OFPS_HIP_EUNSUPPORTED, "farneback: %d pyramid layers above the frame (max %d) or width %d > 16384 has no kernel", K, kMaxLayers - 1, W);
+    FbPoly P;
+    make_poly(poly_n, poly_sigma, &P);
+    // ---- geometry of the layers and the workspace
+    FbPyr Y{};
+    Y.K = K;
+    size_t t_floats = 0, i_floats = 0, r_px = 0;
+    size_t r_off[kMaxLayers];
+    int ntaps = 0, vblocks = 0;
+    for (int k = 0; k <= K; ++k) {
+        double scale = 1.0;
+        for (int i = 0; i < k; ++i) scale *= 0.5;
+        Y.w[k] = round_half_even(W * scale); Y.h[k] = round_half_even(H * scale);
+        FbBlur blur;
+        if (!make_blur(k, &blur) || ntaps + 2 * blur.r + 1 > kMaxTaps) return set_error(ctx, OFPS_HIP_EUNSUPPORTED, "farneback: layer %d needs too many blur taps", k);
+        Y.r[k] = blur.r; Y.toff[k] = ntaps;
+        memcpy(Y.taps + ntaps, blur.taps, sizeof(float) * (size_t)(2 * blur.r + 1));
+        ntaps += 2 * blur.r + 1;
+        Y.inv_x[k] = 1.0 / ((double)Y.w[k] / W); Y.inv_y[k] = 1.0 / ((double)Y.h[k] / H);
+        r_off[k] = r_px; r_px += (size_t)Y.w[k] * Y.h[k];
+        Y.blk0[k] = vblocks;
+        if (k >= 1) {
+            if (Y.w[k] == W && Y.h[k] == H) return set_error(ctx, OFPS_HIP_EUNSUPPORTED, "farneback: degenerate layer %d", k);
+            Y.t_off[k] = t_floats; t_floats += (size_t)2 * H * 2 * Y.w[k];
+            Y.i_off[k] = i_floats; i_floats += (size_t)2 * Y.w[k] * Y.h[k];
+            vblocks += ((Y.w[k] + 15) / 16) * ((Y.h[k] + 3) / 4);
+        }
+    }
+    Y.blk0[K + 1] = vblocks;
+    const size_t px = (size_t)W * H;
+    // T | I (layers >= 1) | R [layer][2][5][h][w] | M x 2 [5][H][W] | two flow planes [H][W] float2
+    const size_t floats = t_floats + i_floats + 10 * r_px + 2 * 5 * px + 2 * 2 * px;
+    auto* base = static_cast<float*>(scratch(ctx, S_FB_WORK, floats * sizeof(float)));
+    if (!base) return OFPS_HIP_ENOMEM;
+    float* T = base; float* I = T + t_floats; float* R = I + i_floats;
+    float* Mb[2] = {R + 10 * r_px, R + 10 * r_px + 5 * px};
+    float2* Fp[2] = {reinterpret_cast<float2*>(Mb[1] + 5 * px), reinterpret_cast<float2*>(Mb[1] + 5 * px) + px};
+    auto Rk = [&](int k, int img) { return R + 10 * r_off[k] + (size_t)img * 5 * Y.w[k] * Y.h[k]; };
+    // ---- pyramid above layer 0: two launches
+    if (K >= 1) {
+        hipLaunchKernelGGL(fb_pyr_h_kernel, dim3(H, 2), dim3(256), (size_t)(W + W / 32 + 1) * sizeof(float), s, d_prev, d_cur, W, H, stride, Y, T);
+        hipLaunchKernelGGL(fb_pyr_v_kernel, dim3(vblocks, 2), dim3(256), 0, s, (const float*)T, W, H, Y, I);
+    }
+    // ---- polynomial expansion of every layer and both images: one launch (layer 0 blurs the u8 frame while it fills its tiles)
+    {
+        FbExp E{};
+        int blk = 0;
+        for (int k = 0; k <= K; ++k)
+            for (int img = 0; img < 2; ++img) {
+                FbExpJob& J = E.job[E.njobs++];
+                J.w = Y.w[k]; J.h = Y.h[k]; J.R = Rk(k, img); J.blk0 = blk; J.tiles_x = (J.w + kPX - 1) / kPX;
+                if (k == 0) { J.u8 = img ? d_cur : d_prev; J.stride = stride; J.I = nullptr; }
+                else { J.u8 = nullptr; J.stride = 0; J.I = I + Y.i_off[k] + (size_t)img * J.w * J.h; }
+                blk += J.tiles_x * ((J.h + kPY - 1) / kPY);
+            }
+        const size_t lds = (size_t)((kPY + 2 * poly_n) * (kPX + 2 * poly_n) + 3 * kPY * (kPX + 2 * poly_n)) * sizeof(float);
+        const float t_c = Y.taps[Y.toff[0] + 1], t_s = Y.taps[Y.toff[0] + 2];
+        if (poly_n == 7) hipLaunchKernelGGL((fb_polyexp_kernel<7>), dim3(blk), dim3(256), lds, s, E, P, t_c, t_s);
+        else if (poly_n == 5) hipLaunchKernelGGL((fb_polyexp_kernel<5>), dim3(blk), dim3(256), lds, s, E, P, t_c, t_s);
+        else hipLaunchKernelGGL((fb_polyexp_kernel<0>), dim3(blk), dim3(256), lds, s, E, P, t_c, t_s);
+    }
+    // ---- layers, coarsest first
+    int pw = 0, ph = 0;
+    const float2* coarse = nullptr;
+    for (int k = K; k >= 0; --k) {
+        const int w = Y.w[k], h = Y.h[k];
+        FbLayer L{Rk(k, 0), Rk(k, 1), w, h};
+        FbStart st{};
+        st.L = L; st.M = Mb[0];
+        if (k == K) {
+            if (d_init) { st.mode = 3; st.flow_in = d_init; st.pw = W; st.ph = H; double sc = 1.0; for (int i = 0; i < k; ++i) sc *= 0.5; st.init_scale = (float)sc; }
+            else st.mode = 0;
+        } else {
+            st.mode = 2; st.flow_in = coarse; st.pw = pw; st.ph = ph;
+            st.inv_x = 1.0 / ((double)w / pw); st.inv_y = 1.0 / ((double)h / ph);
+        }
+        hipLaunchKernelGGL(fb_start_kernel, dim3((w + 63) / 64, (h + 3) / 4), dim3(256), 0, s, st);
+        float2* layer_flow = coarse == Fp[0] ? Fp[1] : Fp[0];
+        for (int it = 0; it < iters; ++it) {
+            const bool last_it = it == iters - 1, last = k == 0 && last_it;
+            FbIter a{};
+            a.L = L; a.m = winsize / 2;
+            a.M_in = Mb[it & 1]; a.M_out = last_it ? nullptr : Mb[(it + 1) & 1];
+            a.flow_out = last ? d_flow : (last_it ? layer_flow : nullptr);
+            a.out_entries = last ? d_entries : nullptr;
+            a.nx = 1.0f / (float)W; a.ny = 1.0f / (float)H;
+            switch (a.m) {
+                case 0: launch_iter<0>(a, s); break;
+                case 1: launch_iter<1>(a, s); break;
+                case 2: launch_iter<2>(a, s); break;
+                case 3: launch_iter<3>(a, s); break;
+                case 4: launch_iter<4>(a, s); break;
+                case 5: launch_iter<5>(a, s); break;
+                case 6: launch_iter<6>(a, s); break;
+                default: launch_iter<7>(a, s); break;
+            }
+        }
+        coarse = layer_flow; pw = w; ph = h;
+    }
+    OFPS_HIP_TRY(ctx, hipGetLastError());
+    return OFPS_HIP_OK;
+}
+
+}  // namespace ofps
+
+extern "C" {
+
+int ofps_hip_farneback_flow_dev(ofps_hip_ctx* ctx, const void* d_prev, const void* d_cur, int W, int H, int stride, int levels, int winsize,
+                                int iters, int poly_n, float poly_sigma, const void* d_init_flow, void* d_out_flow, void* d_out_entries) {
+    if (!ctx) return OFPS_HIP_EINVAL;
+    OFPS_REQUIRE(ctx, d_prev && d_cur && (d_out_flow || d_out_entries), "farneback_flow: null device pointer");
+    OFPS_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return ofps::farneback_flow_device(ctx, static_cast<const uint8_t*>(d_prev), static_cast<const uint8_t*>(d_cur), W, H, stride, levels, winsize,
+                                       iters, poly_n, (double)poly_sigma, static_cast<const float2*>(d_init_flow), static_cast<float2*>(d_out_flow),
+                                       static_cast<float4*>(d_out_entries));
+}
+
+int ofps_hip_farneback_flow(ofps_hip_ctx* ctx, const uint8_t* prev, const uint8_t* cur, int W, int H, int stride, int levels, int winsize, int iters,
+                            int poly_n, float poly_sigma, const float* init_flow, float* out_flow, float* out_entries) {
+    if (!ctx) return OFPS_HIP_EINVAL;
+    OFPS_REQUIRE(ctx, prev && cur && (out_flow || out_entries), "farneback_flow: null host pointer");
+    OFPS_REQUIRE(ctx, W >= 1 && H >= 1 && stride >= W, "farneback_flow: bad geometry");
+    OFPS_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t px = (size_t)W * H;
+    auto* d_frames = static_cast<uint8_t*>(ofps::scratch(ctx, ofps::S_FRAMES, 2 * px));
+    auto* d_flow = static_cast<float2*>(ofps::scratch(ctx, ofps::S_WORK1, px * sizeof(float2)));
+    auto* d_ent = out_entries ? static_cast<float4*>(ofps::scratch(ctx, ofps::S_ENTRIES, px * sizeof(float4))) : nullptr;
+    auto* d_init = init_flow ? static_cast<float2*>(ofps::scratch(ctx, ofps::S_WORK2, px * sizeof(float2))) : nullptr;
+    if (!d_frames || !d_flow || (out_entries && !d_ent) || (init_flow && !d_init)) return OFPS_HIP_ENOMEM;
+    OFPS_HIP_TRY(ctx, ofps::upload_rows(d_frames, W, prev, stride, W, H, ctx->stream));
+    OFPS_HIP_TRY(ctx, ofps::upload_rows(d_frames + px, W, cur, stride, W, H, ctx->stream));
+    if (d_init) OFPS_HIP_TRY(ctx, hipMemcpyAsync(d_init, init_flow, px * sizeof(float2), hipMemcpyHostToDevice, ctx->stream));
+    const int rc = ofps::farneback_flow_device(ctx, d_frames, d_frames + px, W, H, W, levels, winsize, iters, poly_n, (double)poly_sigma, d_init,
+                                               d_flow, d_ent);
+    if (rc != OFPS_HIP_OK) return rc;
+    if (out_flow) OFPS_HIP_TRY(ctx, hipMemcpyAsync(out_flow, d_flow, px * sizeof(float2), hipMemcpyDeviceToHost, ctx->stream));
+    if (out_entries) OFPS_HIP_TRY(ctx, hipMemcpyAsync(out_entries, d_ent, px * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
+    OFPS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return OFPS_HIP_OK;
+}
+
+}  // extern "C"

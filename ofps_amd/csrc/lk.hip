@@ -1828,11 +1828,13 @@ namespace {
 struct LkGrid {                 // what a process_frame returns for this geometry / these flags
     int gw = 0, gh = 0;         // the record grid
     bool per_pixel = false, use_mask = false;
+    bool farneback = false;     // OFPS_HIP_FLOW_FARNEBACK: the flow is farneback.hip's (the "hip_flow" decoder), not the iterative LK
     size_t max_records = 0;     // capacity the records need
 };
 
 int lk_grid_of(ofps_hip_ctx* ctx, int W, int H, int max_w, int max_h, unsigned flags, LkGrid* g) {
     g->use_mask = flags & OFPS_HIP_LK_CONTRAST_MASK; g->per_pixel = flags & OFPS_HIP_LK_PER_PIXEL;
+    g->farneback = flags & OFPS_HIP_FLOW_FARNEBACK;
     // cv-decoder/src/lib.rs:98-121 with aspect_ratio_scale = (1, 1): usize arithmetic
     const size_t cw = (size_t)(max_w < W ? max_w : W), ch = (size_t)(max_h < H ? max_h : H);
     const size_t wb0 = cw, wb1 = cw * (size_t)H / (size_t)W, hb0 = ch * (size_t)W / (size_t)H, hb1 = ch;
@@ -1884,10 +1886,20 @@ int lk_enqueue_frame(ofps_hip_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_
     auto* d_field = static_cast<float2*>(ofps::scratch(ctx, ofps::S_FIELD, cells * sizeof(float2)));
     auto* d_cnt = static_cast<uint32_t*>(ofps::scratch(ctx, ofps::S_RESULT, 16));
     if (!d_ent || !d_field || !d_cnt) return OFPS_HIP_ENOMEM;
-    int rc = ofps::lk_flow_device(ctx, d_prev, d_cur, W, H, W, levels, radius, iters, nullptr, d_ent, nullptr, serial);
-    if (rc != OFPS_HIP_OK) return rc;
-    const uint32_t* d_waits = lk_stale_word(ctx, radius);
-    *epoch = d_waits && !serial && !ctx->opt.lk_serial ? ctx->lk_epoch : 0;
+    int rc;
+    const uint32_t* d_waits = nullptr;
+    if (g.farneback) {
+        // cv-decoder's call (cv-decoder/src/lib.rs:188-199): levels = pyramid levels, winsize = 2 * radius + 1, iters = iterations,
+        // poly_n 7, poly_sigma 1.5.  No tile waits on another in this flow: nothing to repair, *epoch = 0
+        rc = ofps::farneback_flow_device(ctx, d_prev, d_cur, W, H, W, levels, 2 * radius + 1, iters, 7, 1.5, nullptr, nullptr, d_ent);
+        if (rc != OFPS_HIP_OK) return rc;
+        *epoch = 0;
+    } else {
+        rc = ofps::lk_flow_device(ctx, d_prev, d_cur, W, H, W, levels, radius, iters, nullptr, d_ent, nullptr, serial);
+        if (rc != OFPS_HIP_OK) return rc;
+        d_waits = lk_stale_word(ctx, radius);
+        *epoch = d_waits && !serial && !ctx->opt.lk_serial ? ctx->lk_epoch : 0;
+    }
     const uint8_t* d_mask = nullptr;
     if (g.use_mask) {
         auto* m = static_cast<uint8_t*>(ofps::scratch(ctx, ofps::S_MASK, px));
@@ -1965,7 +1977,7 @@ int ofps_hip_lk_decode(ofps_hip_ctx* ctx, const uint8_t* prev, const uint8_t* cu
     if (!ctx) return OFPS_HIP_EINVAL;
     OFPS_REQUIRE(ctx, prev && cur && out_entries && n_out, "lk_decode: null host pointer");
     OFPS_REQUIRE(ctx, W >= 1 && H >= 1 && stride >= W && max_w >= 1 && max_h >= 1, "lk_decode: bad geometry");
-    OFPS_REQUIRE(ctx, (flags & ~(unsigned)(OFPS_HIP_LK_CONTRAST_MASK | OFPS_HIP_LK_PER_PIXEL)) == 0, "lk_decode: unknown flags 0x%x", flags);
+    OFPS_REQUIRE(ctx, (flags & ~(unsigned)(OFPS_HIP_LK_CONTRAST_MASK | OFPS_HIP_LK_PER_PIXEL | OFPS_HIP_FLOW_FARNEBACK)) == 0, "lk_decode: unknown flags 0x%x", flags);
     OFPS_HIP_TRY(ctx, hipSetDevice(ctx->device));
     LkGrid g;
     int rc = lk_grid_of(ctx, W, H, max_w, max_h, flags, &g);
@@ -2004,7 +2016,7 @@ int ofps_hip_lk_push_frame_async(ofps_hip_ctx* ctx, const uint8_t* frame, int W,
     if (!ctx) return OFPS_HIP_EINVAL;
     OFPS_REQUIRE(ctx, frame && ticket, "lk_push_frame_async: null pointer");
     OFPS_REQUIRE(ctx, W >= 1 && H >= 1 && stride >= W && max_w >= 1 && max_h >= 1, "lk_push_frame_async: bad geometry");
-    OFPS_REQUIRE(ctx, (flags & ~(unsigned)(OFPS_HIP_LK_CONTRAST_MASK | OFPS_HIP_LK_PER_PIXEL)) == 0, "lk_push_frame_async: unknown flags 0x%x", flags);
+    OFPS_REQUIRE(ctx, (flags & ~(unsigned)(OFPS_HIP_LK_CONTRAST_MASK | OFPS_HIP_LK_PER_PIXEL | OFPS_HIP_FLOW_FARNEBACK)) == 0, "lk_push_frame_async: unknown flags 0x%x", flags);
     // (a stream's first frame runs no flow: the flow's parameters are refused here, not one frame later)
     OFPS_REQUIRE(ctx, levels >= 1 && levels <= 8 && radius >= 1 && radius <= 15 && iters >= 1 && iters <= 64,
                  "lk_push_frame_async: levels=%d radius=%d iters=%d out of range", levels, radius, iters);

@@ -162,6 +162,37 @@ class HipLkDecoder(HipSadDecoder):
         return True
 
 
+class HipFlowDecoder(HipLkDecoder):
+    """The dense decoder in the reference's own algorithm family: Farneback's polynomial-expansion flow with cv-decoder's arguments
+    (cv-decoder/src/lib.rs:188-199: levels 5, winsize 13, iterations 3, poly_n 7, poly_sigma 1.5), then cv-decoder's contrast mask and
+    down-sampling exactly as HipLkDecoder (ofps_amd/csrc/farneback.hip; "Window radius" r means winsize 2 r + 1)."""
+
+    def __init__(self, frames, framerate=None, device: int = 0):
+        super().__init__(frames, framerate, device)
+        self.levels, self.radius, self.iters = 5, 6, 3
+
+    def process_frame(self, field: list, out_frame=None, skip_frames: int = 0) -> bool:
+        for _ in range(skip_frames + 1):
+            self._prev = self._cur
+            try:
+                self._cur = np.ascontiguousarray(next(self._it), np.uint8)
+            except StopIteration:
+                raise EOFError("failed to grab frame") from None
+        if out_frame is not None:
+            out_frame[:] = [self._cur]
+        if self._prev is None or self._prev.shape != self._cur.shape:
+            self._on_device = None
+            return False
+        kw = dict(contrast_mask=self.contrast_mask, per_pixel=not self.process_fullres, farneback=True)
+        if getattr(self, "_on_device", None) is not self._prev:
+            self.ctx.lk_reset()
+            self.ctx.lk_push_frame(self._prev, self.levels, self.radius, self.iters, self.max_w, self.max_h, **kw)
+        ent, _ = self.ctx.lk_push_frame(self._cur, self.levels, self.radius, self.iters, self.max_w, self.max_h, **kw)
+        self._on_device = self._cur
+        field.extend(ent)
+        return True
+
+
 class HipBlockMotionDetection(Properties):
     """Detector (ofps/src/detection.rs:11; block-motion-detector/src/lib.rs:13-46)."""
     _PROPS = (("Min size", "float", "min_size", 0.01, 1.0), ("Subdivisions", "usize", "subdivide", 1, 16),

@@ -18,10 +18,8 @@ _LIB_PATH = os.path.join(_HERE, "libofps_oracle.so")
 
 def build(force: bool = False) -> str:
     """Compile the oracle with gcc (see oracle/Makefile)."""
-    src = os.path.join(_HERE, "ofps_oracle.c")
-    stale = (not os.path.exists(_LIB_PATH)
-             or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src)
-             or os.path.getmtime(_LIB_PATH) < os.path.getmtime(os.path.join(_HERE, "ofps_oracle.h")))
+    srcs = [os.path.join(_HERE, f) for f in ("ofps_oracle.c", "farneback_oracle.c", "ofps_oracle.h")]
+    stale = not os.path.exists(_LIB_PATH) or any(os.path.getmtime(_LIB_PATH) < os.path.getmtime(f) for f in srcs)
     if force or stale:
         subprocess.check_call(["make", "-s", "-C", _HERE, "-B", "libofps_oracle.so"])
     return _LIB_PATH
@@ -327,6 +325,61 @@ def lk_flow(prev, cur, levels: int = 3, radius: int = 4, iters: int = 3, init=No
     if not ok:
         raise ValueError("orc_lk_flow: bad parameters")
     return out
+
+
+def farneback_layers(W: int, H: int, levels: int = 5):
+    """-> [(w_k, h_k) for k = 0 .. K]: the layers calcOpticalFlowFarneback runs (K <= levels; a layer under 32 px ends the pyramid)."""
+    K = lib().orc_farneback_layers(W, H, levels)
+    out = []
+    for k in range(K + 1):
+        w, h = C.c_int(0), C.c_int(0)
+        lib().orc_farneback_layer_size(W, H, k, C.byref(w), C.byref(h))
+        out.append((w.value, h.value))
+    return out
+
+
+def farneback_flow(prev, cur, levels: int = 5, winsize: int = 13, iters: int = 3, poly_n: int = 7, poly_sigma: float = 1.5, init=None) -> np.ndarray:
+    """cv-decoder's dense flow (cv-decoder/src/lib.rs:188-199; defaults = its arguments) -> flow[H, W, 2] f32 (dx, dy): prev(x, y) ~
+    cur(x + dx, y + dy).  init: None or a [H, W, 2] flow (OPTFLOW_USE_INITIAL_FLOW).  PARITY UNPINNED (OpenCV is not here)."""
+    prev = np.ascontiguousarray(prev, np.uint8); cur = np.ascontiguousarray(cur, np.uint8)
+    H, W = prev.shape
+    out = np.zeros((H, W, 2), np.float32)
+    u8 = C.POINTER(C.c_uint8)
+    f = lib().orc_farneback_flow
+    f.argtypes = [u8, u8, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    ini = None if init is None else _f32(init)
+    rc = f(prev.ctypes.data_as(u8), cur.ctypes.data_as(u8), W, H, W, levels, winsize, iters, poly_n, float(poly_sigma),
+           None if ini is None else _fp(ini), _fp(out))
+    if rc != 0:
+        raise ValueError("orc_farneback_flow: bad parameters")
+    return out
+
+
+def farneback_layer(img, k: int, poly_n: int = 7, poly_sigma: float = 1.5):
+    """Stage-wise view of layer k of one frame: -> (I [h, w] the blurred + resized image, R [h, w, 5] its polynomial expansion)."""
+    img = np.ascontiguousarray(img, np.uint8)
+    H, W = img.shape
+    w, h = C.c_int(0), C.c_int(0)
+    lib().orc_farneback_layer_size(W, H, k, C.byref(w), C.byref(h))
+    I = np.zeros((h.value, w.value), np.float32); R = np.zeros((h.value, w.value, 5), np.float32)
+    f = lib().orc_farneback_layer_debug
+    f.argtypes = [C.POINTER(C.c_uint8), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    assert f(img.ctypes.data_as(C.POINTER(C.c_uint8)), W, H, W, k, poly_n, float(poly_sigma), _fp(I), _fp(R)) == 0
+    return I, R
+
+
+def farneback_kernels(k: int, poly_n: int = 7, poly_sigma: float = 1.5):
+    """-> (blur taps of layer k [2 r + 1], g [n + 1], xg, xxg, (ig11, ig03, ig33, ig55))"""
+    taps = np.zeros(256, np.float32)
+    f = lib().orc_farneback_blur_kernel
+    f.argtypes = [C.c_int, C.POINTER(C.c_float)]
+    r = f(k, _fp(taps))
+    g = np.zeros((3, poly_n + 1), np.float32); ig = (C.c_double * 4)()
+    p = lib().orc_farneback_poly_kernel
+    p.argtypes = [C.c_int, C.c_double, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_double * 4]
+    p.restype = None
+    p(poly_n, float(poly_sigma), _fp(g[0]), _fp(g[1]), _fp(g[2]), ig)
+    return taps[:2 * r + 1].copy(), g[0], g[1], g[2], tuple(ig)
 
 
 def lk_flow_trace(prev, cur, levels: int = 3, radius: int = 4, iters: int = 3, init=None):

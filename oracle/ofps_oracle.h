@@ -159,6 +159,16 @@ size_t orc_masked_flow_to_entries(const float* flow, const uint8_t* mask, int W,
 int orc_num_threads(void);
 int orc_set_num_threads(int n);   /* for the OpenMP loops without a thread argument (orc_lk_flow*); returns the previous setting */
 
+/* ---- Farneback dense flow as cv-decoder calls it (cv-decoder/src/lib.rs:188-199; OpenCV's calcOpticalFlowFarneback restated from the
+ * published algorithm: farneback_oracle.c).  PARITY UNPINNED: OpenCV is neither under /root/reference nor installed. ---- */
+int orc_farneback_layers(int W, int H, int levels);                       /* highest layer index k kept (layers k = 0 .. result) */
+void orc_farneback_layer_size(int W, int H, int k, int* w, int* h);
+int orc_farneback_blur_kernel(int k, float* taps);                        /* -> radius; taps[2 r + 1] */
+void orc_farneback_poly_kernel(int n, double sigma, float* g, float* xg, float* xxg, double ig[4]);
+int orc_farneback_layer_debug(const uint8_t* img, int W, int H, int stride, int k, int poly_n, double poly_sigma, float* out_I, float* out_R);
+int orc_farneback_flow(const uint8_t* prev, const uint8_t* cur, int W, int H, int stride, int levels, int winsize, int iters, int poly_n,
+                       double poly_sigma, const float* init, float* out_flow);
+
 #ifdef __cplusplus
 }
 #endif

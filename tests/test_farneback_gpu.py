@@ -1,0 +1,137 @@
+"""hip_flow: Farneback's dense flow on the GPU (ofps_amd/csrc/farneback.hip) against its CPU restatement (oracle/farneback_oracle.c),
+which restates the published algorithm in the form the reference's cv-decoder gets from OpenCV (cv-decoder/src/lib.rs:188-199).
+PARITY UNPINNED: OpenCV is neither part of the reference tree nor installed; tools/external_parity/opencv_compare.py is the check
+anyone with cv2 can run.  The bound: every stage is restated with the precision OpenCV's CPU path uses, so the two agree to the last bit
+on most pixels; 1e-4 px (north_star's float tolerance) is what is asserted, the measured maximum is printed."""
+import numpy as np
+import pytest
+
+import oracle
+from ofps_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from ofps_amd.runtime import HipContext
+    c = HipContext(0)
+    yield c
+    c.close()
+
+
+def _check(f_g, f_o, tol=1e-4):
+    d = np.abs(f_g - f_o)
+    assert np.isfinite(f_g).all()
+    assert d.max() <= tol, (float(d.max()), np.unravel_index(d.argmax(), d.shape))
+    return float(d.max()), float((f_g.view(np.uint32) == f_o.view(np.uint32)).mean())
+
+
+@pytest.mark.parametrize("W,H", [(640, 360), (322, 181), (97, 64), (40, 33), (1000, 563)])
+def test_farneback_flow_matches_the_oracle(ctx, W, H):
+    """cv-decoder's arguments on region-motion content (flow discontinuities) and on a smooth camera rotation; sizes whose layers halve
+    exactly, sizes with rounding in every layer, a size with two layers only, and one below the 32 px floor of the second layer."""
+    fr = synth.luma_sequence(2, W, H, max_step=4, seed=W + H)
+    f_o = oracle.farneback_flow(fr[0], fr[1])
+    f_g, e_g = ctx.farneback_flow(fr[0], fr[1], want_entries=True)
+    worst, same = _check(f_g, f_o)
+    np.testing.assert_array_equal(e_g.view(np.uint32), oracle.flow_to_entries(f_g).view(np.uint32))
+    print(f"{W}x{H}: max |d| {worst:.2e}, bit-identical flow components {same:.6f}")
+    if min(W, H) >= 64:
+        cl, _ = synth.rotation_clip([(0.1, 0.05, 0.2)], W, H, 60.0, seed=3)
+        _check(ctx.farneback_flow(cl[0], cl[1]), oracle.farneback_flow(cl[0], cl[1]))
+
+
+def test_farneback_parameters_other_than_cv_decoders(ctx):
+    fr = synth.luma_sequence(2, 480, 270, max_step=3, seed=5)
+    for kw in (dict(levels=3, winsize=9, iters=2, poly_n=5, poly_sigma=1.1), dict(levels=0, winsize=15, iters=1, poly_n=7, poly_sigma=1.5),
+               dict(levels=5, winsize=13, iters=4, poly_n=3, poly_sigma=0.0)):
+        _check(ctx.farneback_flow(fr[0], fr[1], **kw), oracle.farneback_flow(fr[0], fr[1], **kw))
+
+
+def test_farneback_initial_flow(ctx):
+    """OPTFLOW_USE_INITIAL_FLOW: cv-decoder hands its previous flow back in (cv-decoder/src/lib.rs:161-165)."""
+    fr = synth.luma_sequence(3, 480, 270, max_step=3, seed=8)
+    first = oracle.farneback_flow(fr[0], fr[1])
+    _check(ctx.farneback_flow(fr[1], fr[2], init=first), oracle.farneback_flow(fr[1], fr[2], init=first))
+
+
+def test_farneback_flat_and_identical_frames(ctx):
+    flat = np.full((2, 128, 160), 77, np.uint8)
+    assert np.array_equal(ctx.farneback_flow(flat[0], flat[1]), np.zeros((128, 160, 2), np.float32))       # singular system: det + 1e-3 -> zero flow
+    fr = synth.luma_sequence(1, 320, 192, max_step=2, seed=1)
+    f = ctx.farneback_flow(fr[0], fr[0])
+    # identical frames: zero flow, except within a window of the last row / column, where the warp's "inside" test (x1 < w - 1)
+    # drops the second image's linear terms even at zero displacement -- OpenCV's behaviour, restated as it is
+    _check(f, oracle.farneback_flow(fr[0], fr[0]), tol=0.0)
+    assert np.abs(f).max() < 0.1                                # (the coarse layers carry the border's effect far inward)
+
+
+def test_farneback_rejects_what_it_has_no_kernel_for(ctx):
+    from ofps_amd.runtime import OfpsHipError
+    fr = synth.luma_sequence(2, 128, 96, max_step=2, seed=2)
+    for kw in (dict(winsize=17), dict(winsize=12), dict(poly_n=16), dict(iters=0)):
+        with pytest.raises(OfpsHipError):
+            ctx.farneback_flow(fr[0], fr[1], **kw)
+    _check(ctx.farneback_flow(fr[0], fr[1]), oracle.farneback_flow(fr[0], fr[1]))                            # the context stays usable
+
+
+def test_farneback_1080p_pair_and_the_truth(ctx):
+    """The size BASELINE quotes: against the oracle, and against the planted homography (median error of a few hundredths of a pixel)."""
+    W, H = 1920, 1080
+    cl, _ = synth.rotation_clip([(0.1, -0.05, 0.15)], W, H, 60.0, seed=4)
+    f_o = oracle.farneback_flow(cl[0], cl[1])
+    f_g = ctx.farneback_flow(cl[0], cl[1])
+    worst, same = _check(f_g, f_o)
+    yy, xx = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    pos = np.stack([(xx.ravel() + .5) / W, (yy.ravel() + .5) / H], 1)
+    truth = synth.rotation_delta(pos, W / H, 60.0, synth.euler_rot3(*np.radians((0.1, -0.05, 0.15))).T).reshape(H, W, 2) * [W, H]
+    err = np.linalg.norm(f_g - truth, axis=2)
+    print(f"1080p: max |d| vs oracle {worst:.2e}, identical bits {same:.6f}, median error vs the planted flow {np.median(err):.4f} px")
+    assert np.median(err) < 0.05
+
+
+def test_hip_flow_decoder_is_the_lk_decoders_output_stage_on_farnebacks_flow(ctx):
+    """OFPS_HIP_FLOW_FARNEBACK in the decoder entry points: Farneback's flow -> per-pixel records -> cv-decoder's contrast mask ->
+    densifier down-sampling to the capped grid, equal to the oracle's stages chained; pair call, stream form, read-ahead form, and
+    the plugin mirror (hip_flow)."""
+    from ofps_amd.plugins import HipFlowDecoder
+    fr = synth.luma_sequence(4, 480, 270, max_step=3, seed=21)
+
+    def chain(a, b, mask=True, per_pixel=False):
+        flow = oracle.farneback_flow(a, b)
+        ent = oracle.masked_flow_to_entries(flow, oracle.contrast_mask(b) if mask else None)
+        return ent if per_pixel else oracle.densify_to_entries(ent, 150, 84)
+    want = [chain(fr[k], fr[k + 1]) for k in range(3)]
+    ent, grid = ctx.lk_decode(fr[0], fr[1], 5, 6, 3, contrast_mask=True, farneback=True)
+    assert grid == (150, 84)
+    np.testing.assert_array_equal(ent.view(np.uint32), want[0].view(np.uint32))
+    ent, _ = ctx.lk_decode(fr[0], fr[1], 5, 6, 3, contrast_mask=False, per_pixel=True, farneback=True)
+    np.testing.assert_array_equal(ent.view(np.uint32), chain(fr[0], fr[1], mask=False, per_pixel=True).view(np.uint32))
+    ctx.lk_reset()
+    assert ctx.lk_push_frame(fr[0], 5, 6, 3, contrast_mask=True, farneback=True) is None
+    for k in range(1, 4):
+        ent, _ = ctx.lk_push_frame(fr[k], 5, 6, 3, contrast_mask=True, farneback=True)
+        np.testing.assert_array_equal(ent.view(np.uint32), want[k - 1].view(np.uint32))
+    ctx.lk_reset()
+    pins = [ctx.pinned_frame(270, 480) for _ in range(4)]
+    for k in range(4):
+        np.copyto(pins[k], fr[k])
+    t = [ctx.lk_push_frame_async(pins[0], 5, 6, 3, contrast_mask=True, farneback=True), ctx.lk_push_frame_async(pins[1], 5, 6, 3, contrast_mask=True, farneback=True)]
+    got = [ctx.lk_frame_wait(t[0])]
+    t.append(ctx.lk_push_frame_async(pins[2], 5, 6, 3, contrast_mask=True, farneback=True))
+    got.append(ctx.lk_frame_wait(t[1]))
+    t.append(ctx.lk_push_frame_async(pins[3], 5, 6, 3, contrast_mask=True, farneback=True))
+    got += [ctx.lk_frame_wait(t[2]), ctx.lk_frame_wait(t[3])]
+    assert got[0] is None
+    for k in range(1, 4):
+        np.testing.assert_array_equal(got[k][0].view(np.uint32), want[k - 1].view(np.uint32))
+    ctx.lk_reset()
+    dec = HipFlowDecoder(iter(fr))
+    field = []
+    assert dec.process_frame(field) is False
+    for k in range(3):
+        field = []
+        assert dec.process_frame(field) is True
+        np.testing.assert_array_equal(np.asarray(field, np.float32).view(np.uint32), want[k].view(np.uint32))
+    dec.ctx.close()

@@ -9,7 +9,8 @@ roll / mixed, 0.01 - 1 degree per frame, one clip with an independently moving f
 Every clip runs through the tracking loop of ofps-suite/src/app/tracking/worker.rs:305-412 written with the plugin mirrors
 (ofps_amd/plugins.py): decoder.process_frame -> estimator.motion_step (pose accumulation, ofps/src/estimator.rs:38-53), for
   decoders    hip_sad (16x16 blocks, +-16)  |  hip_lk (3-level pyramid, r = 4, 3 steps, contrast mask, 150 x 84 records)  |  hip_lk5 (the same
-              with "Pyramid levels" = 5, the reference's Farneback depth)
+              with "Pyramid levels" = 5, the reference's Farneback depth)  |  hip_flow (Farneback's polynomial-expansion flow with
+              cv-decoder's own arguments: levels 5, winsize 13, 3 iterations, poly_n 7, poly_sigma 1.5; same mask and records)
   estimators  hip_almeida LSQ  |  hip_almeida RANSAC (the reference's default: 200 hypotheses x 1000 samples, 0.05 degree inliers)
 Per clip and combination: mean and max of angle_to(planted q_k, estimated r_k) over the frames, that mean relative to the clip's mean
 rotation per frame (the reference's own test bound is 10 %: almeida-estimator/src/lib.rs:347-348), and the pose drift after the
@@ -113,12 +114,14 @@ def stats(est, truth):
 
 
 def run(quick=False, oracle_lk_pairs=3, with_oracle=True, only=None, log=print):
-    from ofps_amd.plugins import HipLkDecoder, HipSadDecoder, StandardCamera
+    from ofps_amd.plugins import HipFlowDecoder, HipLkDecoder, HipSadDecoder, StandardCamera
     combos = [("hip_sad", HipSadDecoder, False, {}), ("hip_sad", HipSadDecoder, True, {}), ("hip_lk", HipLkDecoder, False, {}),
               ("hip_lk", HipLkDecoder, True, {}),
               # the reference's dense decoder runs Farneback over FIVE pyramid levels (cv-decoder/src/lib.rs:188-199): the same decoder with
               # its "Pyramid levels" property at 5 (capture range x4)
-              ("hip_lk5", HipLkDecoder, False, {"Pyramid levels": 5}), ("hip_lk5", HipLkDecoder, True, {"Pyramid levels": 5})]
+              ("hip_lk5", HipLkDecoder, False, {"Pyramid levels": 5}), ("hip_lk5", HipLkDecoder, True, {"Pyramid levels": 5}),
+              # Farneback's flow itself with cv-decoder's arguments (the hip_flow decoder)
+              ("hip_flow", HipFlowDecoder, False, {}), ("hip_flow", HipFlowDecoder, True, {})]
     res = {}
     for name, (W, H, fov, eul, dis) in clip_table(quick).items():
         if only and name not in only:
@@ -157,7 +160,8 @@ def run(quick=False, oracle_lk_pairs=3, with_oracle=True, only=None, log=print):
 
 
 def table(res):
-    cols = ["hip_sad+lsq", "hip_sad+ransac", "hip_lk+lsq", "hip_lk+ransac", "hip_lk5+lsq", "hip_lk5+ransac", "cpu_oracle:sad+lsq"]
+    cols = ["hip_sad+lsq", "hip_sad+ransac", "hip_lk+lsq", "hip_lk+ransac", "hip_lk5+lsq", "hip_lk5+ransac", "hip_flow+lsq", "hip_flow+ransac",
+            "cpu_oracle:sad+lsq"]
     lines = []
     lines.append("mean rotation error per frame, degrees (docs/statistics/err_av.csv's unit); clip rows, decoder+estimator columns")
     lines.append("clip,geometry,mean_rot_deg_per_frame,px_per_deg," + ",".join(cols))
