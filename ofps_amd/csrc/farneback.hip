@@ -5,16 +5,19 @@
 // OpenCV's calcOpticalFlowFarneback gives it, stage by stage with the same precision per stage (f32 blur / resize / vertical half of
 // the expansion / matrices, f64 horizontal half / window sums / 2x2 solve) -- DESIGN.md "N2b", oracle/farneback_oracle.c.
 //
-// Per pyramid layer k = K .. 0 (scale 0.5^k, every layer made from the ORIGINAL frames):
-//   fb_hblur_kernel      Gaussian row filter of the u8 frame at the columns the resize will sample        -> T   [2][H][ncol]
-//   fb_vblur_kernel      column filter at the rows the resize samples + the bilinear combine              -> I_k [2][h][w]
-//   fb_polyexp_kernel    15-tap separable polynomial expansion (tile + halo in LDS)                        -> R   [2][5][h][w]  (planar)
-//   fb_iter_kernel x iters   ONE kernel per update: a workgroup owns a 32 x 16 tile of the flow; it computes the five matrix
-//                        channels of every pixel of the tile + window halo from R0, R1 (bilinear at x + flow) and the current
-//                        flow straight into LDS -- FarnebackUpdateMatrices never goes to memory --, forms the window sums
-//                        (f64, rows then columns) and solves the 2 x 2 system                              -> flow' [h][w]
-//                        The first update of a layer reads the COARSER layer's flow and resizes it on the fly (x 2).
-// All streaming: the honest roofline of this path is HBM (R0 + R1 + flow per update).
+// Kernels (layers k = K .. 0, scale 0.5^k; OpenCV makes every layer from the ORIGINAL frame: Gaussian blur, then bilinear resize):
+//   fb_pyr_h_kernel      ONE launch for all layers >= 1: a workgroup takes one frame row into LDS and evaluates every layer's row filter
+//                        at the columns that layer's resize will sample                                     -> T_k [2][H][2 w_k]
+//   fb_pyr_v_kernel      ONE launch for all layers >= 1: column filter at the sampled rows + the bilinear combine -> I_k [2][h_k][w_k]
+//   fb_polyexp_kernel    ONE launch for all layers and both frames: 15-tap separable polynomial expansion, tile + halo in LDS; layer 0's
+//                        image is never stored (its [1 2 1]/4 blur of the u8 frame is evaluated while the tile is filled) -> R [5][h][w] planar
+//   fb_start_kernel      per layer: FarnebackUpdateMatrices from the flow the layer starts with (zero / the coarser layer's flow resized
+//                        on the fly x 2 / the caller's initial flow)                                         -> M [5][h][w]
+//   fb_iter_kernel x iters   per update: a workgroup owns a 32 x 16 tile: M tile + window halo -> LDS, window sums (f64, rows then
+//                        columns, ascending: the oracle's order), the 2 x 2 solve, and -- except in a layer's last update -- the NEXT
+//                        update's matrices for its own pixels, written where the flow they depend on is produced; the flow itself is
+//                        stored only when somebody reads it (next layer, caller).  Tiles are dealt to the XCDs in contiguous runs.
+// All streaming: the honest roofline of this path is HBM (R0 + R1 + M in / out per update); measured numbers: DESIGN.md "N2b".
 #include "common.hpp"
 
 #include <cmath>
@@ -141,30 +144,74 @@ __global__ __launch_bounds__(256) void fb_pyr_h_kernel(const uint8_t* __restrict
     }
 }
 
-// column filter at the sampled rows + HResizeLinear / VResizeLinear; 1-D grid over (layer, 16 x 4 tile), blockIdx.y = image.  A thread
-// owns ONE of an output's four column sums (the long serial part: up to 159 taps), the quad's first lane combines them.
+// column filter at the sampled rows + HResizeLinear / VResizeLinear; 1-D grid over (layer, tile), blockIdx.y = image.  The launch is
+// bound by round trips, not by arithmetic (138 VALU instructions per wave): short filters (r <= 4: layers 1, 2 -- 97 % of the outputs) take
+// one thread per output with all 4 (2 r + 1) loads issued before the first sum; long filters one thread per column sum (the serial
+// part: up to 159 taps), eight tap pairs' loads in flight at a time, the quad's first lane combining the four sums.
+constexpr int kShortR = 4;
+template <int R_>
+__device__ __forceinline__ void fb_pyr_v_short(const float* __restrict__ Tz, int ncol, int W, int H, double inv_x, double inv_y,
+                                               const float* __restrict__ taps, int x, int y, float* __restrict__ out) {
+    int y0, y1, xs0, xs1; float a1, b1;
+    resize_axis(x, W, inv_x, &xs0, &xs1, &a1);
+    resize_axis(y, H, inv_y, &y0, &y1, &b1);
+    float v[2][2][2 * R_ + 1];                                   // [row y0 / y1][column 2 x / 2 x + 1][tap]
+#pragma unroll
+    for (int t = 0; t < 2 * R_ + 1; ++t)
+#pragma unroll
+        for (int ry = 0; ry < 2; ++ry) {
+            const int yy = reflect101((ry ? y1 : y0) + t - R_, H);
+            const float2 p = *reinterpret_cast<const float2*>(Tz + (size_t)yy * ncol + 2 * x);
+            v[ry][0][t] = p.x; v[ry][1][t] = p.y;
+        }
+    float cs[2][2];
+#pragma unroll
+    for (int ry = 0; ry < 2; ++ry)
+#pragma unroll
+        for (int cx = 0; cx < 2; ++cx) {
+            float s = taps[R_] * v[ry][cx][R_];
+#pragma unroll
+            for (int j = 1; j <= R_; ++j) s += taps[R_ + j] * (v[ry][cx][R_ - j] + v[ry][cx][R_ + j]);
+            cs[ry][cx] = s;
+        }
+    const float a0 = 1.0f - a1, b0 = 1.0f - b1;
+    const float h0 = cs[0][0] * a0 + cs[0][1] * a1;
+    const float h1 = cs[1][0] * a0 + cs[1][1] * a1;
+    *out = h0 * b0 + h1 * b1;
+}
+
 __global__ __launch_bounds__(256) void fb_pyr_v_kernel(const float* __restrict__ T, int W, int H, const FbPyr P, float* __restrict__ I) {
-    __shared__ float staps[kMaxTaps];
-    for (int i = threadIdx.x; i < kMaxTaps; i += 256) staps[i] = P.taps[i];
-    __syncthreads();
     int k = 1;
     while (k < P.K && (int)blockIdx.x >= P.blk0[k + 1]) ++k;
     const int w = P.w[k], h = P.h[k], r = P.r[k];
-    const int tiles_x = (w + 15) / 16, b = (int)blockIdx.x - P.blk0[k];
+    const int ncol = 2 * w, z = blockIdx.y, b = (int)blockIdx.x - P.blk0[k];
+    const float* Tz = T + P.t_off[k] + (size_t)z * H * ncol;
+    const float* taps = P.taps + P.toff[k];                      // wave-uniform indices: scalar loads
+    if (r <= kShortR) {
+        const int tiles_x = (w + 63) / 64;
+        const int x = (b % tiles_x) * 64 + (threadIdx.x & 63), y = (b / tiles_x) * 4 + (threadIdx.x >> 6);
+        if (x >= w || y >= h) return;
+        float* out = I + P.i_off[k] + ((size_t)z * h + y) * w + x;
+        switch (r) {                                              // compile-time tap counts: the tap arrays stay in registers
+            case 1: fb_pyr_v_short<1>(Tz, ncol, W, H, P.inv_x[k], P.inv_y[k], taps, x, y, out); break;
+            case 2: fb_pyr_v_short<2>(Tz, ncol, W, H, P.inv_x[k], P.inv_y[k], taps, x, y, out); break;
+            case 3: fb_pyr_v_short<3>(Tz, ncol, W, H, P.inv_x[k], P.inv_y[k], taps, x, y, out); break;
+            default: fb_pyr_v_short<4>(Tz, ncol, W, H, P.inv_x[k], P.inv_y[k], taps, x, y, out); break;
+        }
+        return;
+    }
+    const int tiles_x = (w + 15) / 16;
     const int o = threadIdx.x >> 2, corner = threadIdx.x & 3;
     int x = (b % tiles_x) * 16 + (o & 15), y = (b / tiles_x) * 4 + (o >> 4);
     const bool live = x < w && y < h;
     x = x < w ? x : w - 1; y = y < h ? y : h - 1;                 // (every lane takes part in the shuffles)
-    const int ncol = 2 * w, z = blockIdx.y;
-    const float* Tz = T + P.t_off[k] + (size_t)z * H * ncol;
-    const float* taps = staps + P.toff[k];
     int y0, y1, xs0, xs1; float a1, b1;
     resize_axis(x, W, P.inv_x[k], &xs0, &xs1, &a1);               // (the two source columns are T's columns 2 x and 2 x + 1)
     resize_axis(y, H, P.inv_y[k], &y0, &y1, &b1);
     const int ys = (corner & 2) ? y1 : y0, c = 2 * x + (corner & 1);
     const float* p = Tz + (size_t)ys * ncol + c;
     float s = taps[r] * p[0];
-    if (ys - r >= 0 && ys + r < H) {                              // interior: eight tap pairs' loads in flight at a time, summed in order
+    if (ys - r >= 0 && ys + r < H) {
         int j = 1;
         for (; j + 7 <= r; j += 8) {
             float lo[8], hi[8];
@@ -373,9 +420,15 @@ template <int M_>
 __global__ __launch_bounds__(256) void fb_iter_kernel(const FbIter a) {
     constexpr int HW = kTX + 2 * M_, HH = kTY + 2 * M_, WIN = 2 * M_ + 1;
     __shared__ float sM[5][HH][HW];
-    __shared__ double sV[5][kTY][HW];
+    __shared__ __attribute__((aligned(16))) double sV[5][kTY][HW];
     const int w = a.L.w, h = a.L.h;
-    const int x0 = blockIdx.x * kTX, y0 = blockIdx.y * kTY;
+    // XCD-aware tile order (workgroup b runs on XCD b % 8): every XCD takes a contiguous run of tiles in row-major order, so the
+    // halo a tile shares with its neighbours is in ONE L2 (the plain 2-D grid fetched the M planes 2.4 x from HBM: rocprofv3 FETCH_SIZE)
+    const int tiles_x = (w + kTX - 1) / kTX;
+    const int per_xcd = gridDim.x / 8;
+    const int tile = (int)(blockIdx.x % 8) * per_xcd + (int)(blockIdx.x / 8);
+    if (tile >= tiles_x * ((h + kTY - 1) / kTY)) return;
+    const int x0 = (tile % tiles_x) * kTX, y0 = (tile / tiles_x) * kTY;
     const size_t plane = (size_t)w * h;
     for (int i = threadIdx.x; i < HH * HW; i += 256) {            // replicate border = the clamped pixel's matrices
         const int hy = i / HW, hx = i - hy * HW;
@@ -410,9 +463,12 @@ __global__ __launch_bounds__(256) void fb_iter_kernel(const FbIter a) {
         double s[2][5];
 #pragma unroll
         for (int c = 0; c < 5; ++c) {
-            double v[WIN + 1];
+            double v[WIN + 1];                    // WIN + 1 is even and tx is even: 16-byte reads, conflict-free across the wave's four rows
 #pragma unroll
-            for (int j = 0; j < WIN + 1; ++j) v[j] = sV[c][ty][tx + j];
+            for (int j = 0; j < WIN + 1; j += 2) {
+                const double2 p = *reinterpret_cast<const double2*>(&sV[c][ty][tx + j]);
+                v[j] = p.x; v[j + 1] = p.y;
+            }
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 double t = 0;
@@ -454,7 +510,8 @@ __global__ __launch_bounds__(256) void fb_iter_kernel(const FbIter a) {
 
 template <int M_>
 void launch_iter(const FbIter& a, hipStream_t s) {
-    hipLaunchKernelGGL((fb_iter_kernel<M_>), dim3((a.L.w + kTX - 1) / kTX, (a.L.h + kTY - 1) / kTY), dim3(256), 0, s, a);
+    const int tiles = ((a.L.w + kTX - 1) / kTX) * ((a.L.h + kTY - 1) / kTY);
+    hipLaunchKernelGGL((fb_iter_kernel<M_>), dim3((tiles + 7) / 8 * 8), dim3(256), 0, s, a);
 }
 
 }  // namespace
@@ -510,7 +567,7 @@ int farneback_flow_device(ofps_hip_ctx* ctx, const uint8_t* d_prev, const uint8_
             if (Y.w[k] == W && Y.h[k] == H) return set_error(ctx, OFPS_HIP_EUNSUPPORTED, "farneback: degenerate layer %d", k);
             Y.t_off[k] = t_floats; t_floats += (size_t)2 * H * 2 * Y.w[k];
             Y.i_off[k] = i_floats; i_floats += (size_t)2 * Y.w[k] * Y.h[k];
-            vblocks += ((Y.w[k] + 15) / 16) * ((Y.h[k] + 3) / 4);
+            vblocks += (blur.r <= kShortR ? (Y.w[k] + 63) / 64 : (Y.w[k] + 15) / 16) * ((Y.h[k] + 3) / 4);
         }
     }
     Y.blk0[K + 1] = vblocks;

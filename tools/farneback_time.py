@@ -12,6 +12,7 @@ from ofps_amd import synth  # noqa: E402
 from ofps_amd.runtime import HipContext  # noqa: E402
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+levels = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 W, H = 1920, 1080
 ctx = HipContext(0)
 ctx.use_torch_stream()
@@ -21,16 +22,16 @@ d_ent = torch.empty((W * H, 4), dtype=torch.float32, device="cuda")
 
 
 def step():
-    ctx.farneback_flow_dev(d[0].data_ptr(), d[1].data_ptr(), W, H, W, d_out_entries=d_ent.data_ptr())
+    ctx.farneback_flow_dev(d[0].data_ptr(), d[1].data_ptr(), W, H, W, levels=levels, d_out_entries=d_ent.data_ptr())
 for _ in range(5):
     step()
 ctx.sync(); ctx.timer_start()
 for _ in range(reps):
     step()
 ms = ctx.timer_stop() / reps
-px = sum((W >> k) * (H >> k) for k in range(6))
+px = sum((W >> k) * (H >> k) for k in range(levels + 1))
 # algorithmic HBM bytes per pair: per layer pixel, I written + read once (8 B x 2 images), R written once (20 B x 2), per update R0 + R1 read
 # (40 B) + flow read + written (16 B); records 16 B per level-0 pixel
 algo = px * (2 * 8 + 2 * 20 + 3 * (40 + 16)) + W * H * 16
-print(json.dumps({"farneback_1080p_ms": round(ms, 4), "algorithmic_MB": round(algo / 1e6, 1), "GBs_at_algorithmic_bytes": round(algo / (ms * 1e-3) / 1e9, 1)}))
+print(json.dumps({"levels": levels, "farneback_1080p_ms": round(ms, 4), "algorithmic_MB": round(algo / 1e6, 1), "GBs_at_algorithmic_bytes": round(algo / (ms * 1e-3) / 1e9, 1)}))
 ctx.use_own_stream(); ctx.close()
