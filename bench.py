@@ -199,7 +199,10 @@ time_steps.gc_inside = None
 PARITY_PIN = {"A6-A12 (camera + Almeida)": "reference-held mfield tables (docs/report/mfield/*.csv) + the reference's own known-answer test",
               "A1-A5 (densifier, detector)": "hand-derived literals from the Rust text (no reference-held vectors exist)",
               "N1 (full-search SAD, this line's kernel)": "build-defined spec: bit-exact vs the build's own CPU restatement only (reference has no SAD)",
-              "N2 (dense LK flow)": "build-defined spec: bit-exact vs the build's own CPU restatement only (reference calls OpenCV Farneback)"}
+              "N2 (dense LK flow)": "build-defined spec: bit-exact vs the build's own CPU restatement only (reference calls OpenCV Farneback)",
+              "N2b (Farneback flow, hip_flow)": "the published algorithm in the form of OpenCV's calcOpticalFlowFarneback with cv-decoder's arguments: "
+                                                "bit-identical to the build's own CPU restatement; OpenCV itself is not part of the reference tree "
+                                                "(unpinned here; tools/external_parity/opencv_compare.py is the check for anyone who has cv2)"}
 
 
 def build_line(args, world: int, el: float, launch_ms: float, launch_pairs: int, counts: list, nblk: int, ranks_seen: int,

@@ -127,6 +127,11 @@ def cfg3_chain_leg(device: int = 0, reps: int = 60) -> dict:
 
         def chain():
             lk(); den(); alm()
+
+        def fb():            # the same stage in the reference's own algorithm family: Farneback with cv-decoder's arguments (hip_flow)
+            ctx.farneback_flow_dev(dfr[0].data_ptr(), dfr[1].data_ptr(), W, H, W, d_out_entries=d_ent.data_ptr())
+        fb_ms = _event_ms(ctx, fb, reps // 2, warm=5)
+        kept_fb = d_ent.cpu().numpy() if name == "pm3" else None
         lk_ms = _event_ms(ctx, lk, reps)
         den_ms = _event_ms(ctx, den, reps)
         alm_ms = _event_ms(ctx, alm, reps)
@@ -138,7 +143,10 @@ def cfg3_chain_leg(device: int = 0, reps: int = 60) -> dict:
             chain()
         torch.cuda.synchronize()
         chain_ms = (time.perf_counter() - t0) / reps * 1e3
-        per[name] = {"lk_ms": round(lk_ms, 4), "densify_ms": round(den_ms, 4), "almeida_ms": round(alm_ms, 4), "chain_ms": round(chain_ms, 4),
+        if kept_fb is not None:
+            kept["farneback_pm3"] = kept_fb
+        per[name] = {"lk_ms": round(lk_ms, 4), "farneback_ms": round(fb_ms, 4), "densify_ms": round(den_ms, 4), "almeida_ms": round(alm_ms, 4),
+                     "chain_ms": round(chain_ms, 4),
                      "Mvectors_per_s_chain": round(n / chain_ms / 1e3, 1),
                      "lk_frac_of_f32_peak": round(taps * LK_SPEC_FLOPS_PER_TAP / (lk_ms * 1e-3) / VALU_F32_PEAK_FLOPS, 4)}
         kept[name] = (d_ent.cpu().numpy(), d_q.cpu().numpy()[0], d_fld.cpu().numpy())
@@ -175,6 +183,18 @@ def cfg3_chain_leg(device: int = 0, reps: int = 60) -> dict:
                                    "guide's f32 vector peak (157.3 TFLOP/s, fma = 2: the same unit); instr_view: the 7 instructions per tap "
                                    "against 78.6 T lane-instructions/s; lds_view: the LDS-array cycles of the spec's reads against 256 arrays at 2.4 GHz -- "
                                    "the pipe that binds the rows (measured with conflicts: ~64 % busy over the launch, ~76 % inside the rows; DESIGN.md N2)"},
+           # hip_flow (farneback.hip): all streaming.  Algorithmic bytes per pair, per layer pixel: the expansion planes
+           # written once (2 x 20 B); the layer's first matrices: R0 + R1 read, M written (60 B); updates 1 and 2: M read, R0 + R1 read,
+           # next M written (80 B each); the last update: M read, flow written (28 B) = 288 B; + 16 B of records per frame pixel, both
+           # frames read once
+           "farneback_ms": per["pm3"]["farneback_ms"],
+           "roofline_farneback": (lambda fpx, fb: {"bound": "hbm", "unit": "GB/s", "algorithmic_bytes": fb,
+                                                   "achieved": round(fb / (per["pm3"]["farneback_ms"] * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
+                                                   "frac": round(fb / (per["pm3"]["farneback_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                                   "frac_pm16": round(fb / (per["pm16"]["farneback_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                                   "note": "six layers (1080p .. 60 x 34), three updates each; the pyramid's intermediate planes are not counted"})(
+               sum(((W + (1 << k) // 2) >> k) * ((H + (1 << k) // 2) >> k) for k in range(6)),
+               sum(((W + (1 << k) // 2) >> k) * ((H + (1 << k) // 2) >> k) for k in range(6)) * (40 + 60 + 2 * 80 + 28) + 16 * n + 2 * n),
            "roofline_almeida": {"bound": "hbm", "unit": "GB/s", "algorithmic_bytes": 16 * n,
                                 "achieved": round(16 * n / (alm_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
                                 "frac": round(16 * n / (alm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
@@ -196,6 +216,14 @@ def cfg3_chain_leg(device: int = 0, reps: int = 60) -> dict:
             cpu[f"lk_flow_all_cores_ms_{name}"] = round((time.perf_counter() - t0) * 1e3, 1)
             ent_o = oracle.flow_to_entries(flow_o)
             q_o = oracle.solve_ypr_given(ent_o, cam, threads=thr)
+            if name == "pm3":                                      # hip_flow's records against the Farneback restatement (all cores)
+                t0 = time.perf_counter()
+                fb_o = oracle.flow_to_entries(oracle.farneback_flow(fr[0], fr[1]))
+                cpu["farneback_all_cores_ms"] = round((time.perf_counter() - t0) * 1e3, 1)
+                d = np.abs(kept["farneback_pm3"] - fb_o)
+                farneback_pc = {"records_bit_exact": bool((kept["farneback_pm3"].view(np.uint32) == fb_o.view(np.uint32)).all()),
+                                "max_abs_diff_normalised": float(d.max()), "tolerance_px": 1e-4,
+                                "ok": bool((d[:, 2] * W).max() <= 1e-4 and (d[:, 3] * H).max() <= 1e-4)}
             pc = {"lk_records_bit_exact": bool((ent.view(np.uint32) == ent_o.view(np.uint32)).all()),
                   "densify_field_bit_exact": bool((fld.view(np.uint32).reshape(-1) == oracle.densify(ent_o, GW, GH).view(np.uint32).reshape(-1)).all()),
                   "almeida_max_abs_dq": float(np.abs(q - q_o).max()), "almeida_tolerance": 2e-6}
@@ -204,7 +232,8 @@ def cfg3_chain_leg(device: int = 0, reps: int = 60) -> dict:
         cpu.update({"threads_all_cores": oracle.num_threads(), "kind": "port (oracle/ofps_oracle.c:orc_lk_flow, OpenMP over rows)",
                     "speedup_vs_all_cores_pm3": round(cpu["lk_flow_all_cores_ms_pm3"] / per["pm3"]["lk_ms"], 1)})
         out["cpu_lk"] = cpu
-        out["parity_check"] = dict(pcs["pm3"], per_content=pcs, ok=bool(all(v["ok"] for v in pcs.values())))
+        out["parity_check"] = dict(pcs["pm3"], per_content=pcs, farneback=farneback_pc,
+                                   ok=bool(all(v["ok"] for v in pcs.values()) and farneback_pc["ok"]))
     except ImportError as e:
         out["parity_check"] = {"ok": None, "skipped": str(e)}
     return out

@@ -151,10 +151,11 @@ int ofps_hip_contrast_mask_dev(ofps_hip_ctx* ctx, const void* d_gray, int W, int
 /* ofps_hip_lk_decode flags */
 #define OFPS_HIP_LK_CONTRAST_MASK 1u /* drop records of pixels outside the contrast mask of `cur` (the reference's
                                         Farneback path always masks, :203-237,253-257) */
-#define OFPS_HIP_FLOW_FARNEBACK   4u /* the flow is Farneback's (ofps_hip_farneback_flow) instead of the iterative Lucas-Kanade: the "hip_flow" decoder */
 #define OFPS_HIP_LK_PER_PIXEL     2u /* "Process Fullres" = false: one record per (unmasked) pixel in raster order,
                                         no down-sampling (:274-276); the reference resizes its frames to the capped
                                         grid before the flow (:124-133), which is the caller's job here */
+#define OFPS_HIP_FLOW_FARNEBACK   4u /* the flow is Farneback's (ofps_hip_farneback_flow: levels = pyramid levels, winsize = 2 * radius + 1,
+                                        iters = iterations, poly_n 7, poly_sigma 1.5) instead of the iterative Lucas-Kanade: "hip_flow" */
 /* One Decoder::process_frame of a "hip_lk" plugin (cv-decoder/src/lib.rs:82-294): flow -> per-pixel records
  * [-> contrast mask] -> down-sampled through the densifier to the (max_w, max_h)-capped grid of :98-121 (defaults
  * 150 x 150 -> 150 x 84 at 16:9) -> one record per visited cell in (x, y)-sorted order.  out_entries capacity:

@@ -12,7 +12,7 @@
 //   track   <decoder> <arg> [aspect fov_y] [lsq|ransac] tracking loop, ofps-suite/src/app/tracking/worker.rs:305-412
 //   mvec-copy <in.mvec> <out.mvec>                      CPU-only .mvec round trip (reader + writer)
 //   multi-extract <raw.y> <w> <h> <out.mvec> [dev ...]  the whole clip over several GPUs (ofps_hip_multi_*): same bytes as `extract hip_sad`
-// decoder = hip_sad / hip_lk ("<input>?w=..&h=..&fps=..") or mvec ("<input>"); <input> is a file path, "tcp://host:port"
+// decoder = hip_sad / hip_lk / hip_flow ("<input>?w=..&h=..&fps=..") or mvec ("<input>"); <input> is a file path, "tcp://host:port"
 // (connect) or "tcp://@:port" (listen, accept one connection) as in ofps/src/utils.rs:92-118.
 #include <chrono>
 #include <cstdio>

@@ -153,8 +153,11 @@ std::vector<std::pair<std::string, PropertyMut>> HipSadDecoder::props_mut() {
 }
 
 // ------------------------------------------------------------------ hip_lk
-HipLkDecoder::HipLkDecoder(std::unique_ptr<std::istream> input, size_t width, size_t height, std::optional<double> fps, int device)
-    : ctx_(device), in_(std::move(input)), w_(width), h_(height), fps_(fps), prev_(width * height), cur_(width * height) {
+HipLkDecoder::HipLkDecoder(std::unique_ptr<std::istream> input, size_t width, size_t height, std::optional<double> fps, int device,
+                           bool farneback)
+    : ctx_(device), in_(std::move(input)), w_(width), h_(height), fps_(fps), prev_(width * height), cur_(width * height),
+      farneback_(farneback) {
+    if (farneback_) { levels_ = 5; radius_ = 6; iters_ = 3; }
     if (!in_ || !*in_) throw Error("hip_lk: cannot open input");
     if (w_ == 0 || h_ == 0) throw Error("hip_lk: frame size required (arg \"path?w=..&h=..\")");
 }
@@ -176,7 +179,8 @@ bool HipLkDecoder::process_frame(MotionVectors& field, std::vector<RGBA>* out_fr
     if (frames_read_ < 2) return false;
     out_.resize(process_fullres_ ? 4 * std::min(max_w_, w_) * std::min(max_h_, h_) : 4 * w_ * h_);
     size_t n_out = 0;
-    const unsigned flags = (contrast_mask_ ? OFPS_HIP_LK_CONTRAST_MASK : 0u) | (process_fullres_ ? 0u : OFPS_HIP_LK_PER_PIXEL);
+    const unsigned flags = (contrast_mask_ ? OFPS_HIP_LK_CONTRAST_MASK : 0u) | (process_fullres_ ? 0u : OFPS_HIP_LK_PER_PIXEL) |
+                           (farneback_ ? OFPS_HIP_FLOW_FARNEBACK : 0u);
     // the frame uploaded by the previous call is this call's previous frame unless frames were skipped in between:
     // then (and for the first pair) the previous frame goes up first
     int have = 0;
@@ -507,7 +511,7 @@ std::vector<MotionVectors> MultiDeviceSad::search(const uint8_t* frames, size_t 
 
 std::unique_ptr<Decoder> create_decoder(const std::string& name, const std::string& arg) {
     if (name == "mvec") return std::make_unique<MvecFileDecoder>(open_input(arg));
-    if (name == "hip_sad" || name == "hip_lk") {                      // "<path>?w=1920&h=1080&fps=60"
+    if (name == "hip_sad" || name == "hip_lk" || name == "hip_flow") {                      // "<path>?w=1920&h=1080&fps=60"
         std::string path = arg;
         size_t w = 0, h = 0;
         std::optional<double> fps;
@@ -523,6 +527,7 @@ std::unique_ptr<Decoder> create_decoder(const std::string& name, const std::stri
             }
         }
         if (name == "hip_lk") return std::make_unique<HipLkDecoder>(open_input(path), w, h, fps);
+        if (name == "hip_flow") return std::make_unique<HipLkDecoder>(open_input(path), w, h, fps, 0, /*farneback=*/true);
         return std::make_unique<HipSadDecoder>(open_input(path), w, h, fps);
     }
     throw Error("unknown decoder plugin: " + name);

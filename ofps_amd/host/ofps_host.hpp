@@ -159,7 +159,11 @@ private:
 // visited cell of the (Width, Height)-capped grid; property names as in cv-decoder (:35-52).
 class HipLkDecoder : public Decoder {
 public:
-    HipLkDecoder(std::unique_ptr<std::istream> input, size_t width, size_t height, std::optional<double> fps, int device = 0);
+    // farneback = true is the "hip_flow" plugin: Farneback's polynomial-expansion flow with cv-decoder's arguments
+    // (cv-decoder/src/lib.rs:188-199: levels 5, winsize 13 = 2 * 6 + 1, 3 iterations, poly_n 7, poly_sigma 1.5) through the same
+    // entry points (OFPS_HIP_FLOW_FARNEBACK); the properties keep their names, "Window radius" r means winsize 2 r + 1
+    HipLkDecoder(std::unique_ptr<std::istream> input, size_t width, size_t height, std::optional<double> fps, int device = 0,
+                 bool farneback = false);
     bool process_frame(MotionVectors& field, std::vector<RGBA>* out_frame, size_t* out_height, size_t skip_frames) override;
     std::optional<double> get_framerate() const override { return fps_; }
     std::optional<std::pair<size_t, size_t>> get_aspect() const override { return std::make_pair(w_, h_); }
@@ -174,6 +178,7 @@ private:
     std::vector<float> out_;
     size_t frames_read_ = 0;
     bool on_device_ = false;           // the last frame of the previous call is on the device (ofps_hip_lk_push_frame's state)
+    bool farneback_ = false;
 };
 
 // MvecFile of motion-loader/src/lib.rs:31-83 (pure host I/O, no GPU)
@@ -242,7 +247,7 @@ struct MotionDetectionConfig {
 void transfer_props(const std::vector<std::pair<std::string, Property>>& saved, Properties& plugin);
 
 // ---- creation by name (the part of PluginStore the hot path needs: ofps/src/plugins/mod.rs:396-453)
-std::unique_ptr<Decoder> create_decoder(const std::string& name, const std::string& arg);    // "hip_sad", "hip_lk", "mvec"
+std::unique_ptr<Decoder> create_decoder(const std::string& name, const std::string& arg);    // "hip_sad", "hip_lk", "hip_flow", "mvec"
 std::unique_ptr<Detector> create_detector(const std::string& name, const std::string& arg);  // "hip_block_motion"
 std::unique_ptr<Estimator> create_estimator(const std::string& name, const std::string& arg);// "hip_almeida"
 

@@ -115,6 +115,27 @@ def test_hip_lk_decoder_through_cpp_host(tmp_path):
         np.testing.assert_array_equal(frames[k].view(np.uint32), e_o.view(np.uint32))
 
 
+@pytest.mark.gpu
+def test_hip_flow_decoder_through_cpp_host(tmp_path):
+    """create_decoder("hip_flow"): the Farneback flow with cv-decoder's arguments (cv-decoder/src/lib.rs:188-199) behind the
+    same Decoder surface; records equal the oracle chain farneback_flow -> masked records -> densifier down-sampling."""
+    import oracle
+    W, H, F = 320, 180, 3
+    fr = synth.flatten_regions(synth.luma_sequence(F, W, H, max_step=2, seed=5), region=40, seed=2)
+    raw = tmp_path / "clip.y"
+    raw.write_bytes(fr.tobytes())
+    out = tmp_path / "clip_flow.mvec"
+    info = json.loads(_tool("extract", "hip_flow", f"{raw}?w={W}&h={H}", out))
+    frames = list(mvec.read_frames(open(out, "rb")))
+    assert info["frames"] == F and len(frames[0]) == 0
+    for k in range(1, F):
+        flow = oracle.farneback_flow(fr[k - 1], fr[k], 5, 13, 3, 7, 1.5)
+        rec = oracle.masked_flow_to_entries(flow, oracle.contrast_mask(fr[k]))
+        e_o = oracle.densify_to_entries(rec, 150, 84)
+        assert 0 < len(e_o) < 150 * 84
+        np.testing.assert_array_equal(frames[k].view(np.uint32), e_o.view(np.uint32))
+
+
 # ---- (f)2 surface added in round 2: tcp:// inputs, saved configurations, perf CSV export ------------------------------
 def _free_port():
     import socket
