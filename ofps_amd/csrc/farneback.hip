@@ -319,23 +319,33 @@ __global__ __launch_bounds__(256) void fb_polyexp_kernel(const FbExp E, const Fb
 }
 
 // ---- FarnebackUpdateMatrices for one pixel: R0, R1 planar [5][h][w]
+typedef float fb_f2u __attribute__((ext_vector_type(2), aligned(4)));       // two neighbouring floats at any 4-byte alignment: one global_load_dwordx2
 struct FbLayer { const float* R0; const float* R1; int w, h; };
-__device__ __forceinline__ void fb_matrices(const FbLayer& L, int x, int y, float dx, float dy, float (&m)[5]) {
+// q: the pixel's own coefficients R0[0..4][y][x] (loaded by the caller: they do not depend on the flow, so they can be on their way early)
+__device__ __forceinline__ void fb_matrices(const FbLayer& L, int x, int y, float dx, float dy, const float (&q)[5], float (&m)[5]) {
     const int w = L.w, h = L.h;
-    const size_t plane = (size_t)w * h, o = (size_t)y * w + x;
-    const float q0 = L.R0[o], q1 = L.R0[plane + o], q2 = L.R0[2 * plane + o], q3 = L.R0[3 * plane + o], q4 = L.R0[4 * plane + o];
+    const size_t plane = (size_t)w * h;
+    const float q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3], q4 = q[4];
     float fx = x + dx, fy = y + dy;
     const int x1 = (int)floorf(fx), y1 = (int)floorf(fy);
     float r2, r3, r4, r5, r6;
     fx -= x1; fy -= y1;
     if ((unsigned)x1 < (unsigned)(w - 1) && (unsigned)y1 < (unsigned)(h - 1)) {
+        // the two corners of a row are neighbours in memory: one 8-byte load (any 4-byte alignment) instead of two 4-byte loads --
+        // the update kernels are bound by the number of memory instructions their gathers issue, not by the bytes
         const float* p = L.R1 + (size_t)y1 * w + x1;
         const float a00 = (1.f - fx) * (1.f - fy), a01 = fx * (1.f - fy), a10 = (1.f - fx) * fy, a11 = fx * fy;
-        r2 = a00 * p[0] + a01 * p[1] + a10 * p[w] + a11 * p[w + 1]; p += plane;
-        r3 = a00 * p[0] + a01 * p[1] + a10 * p[w] + a11 * p[w + 1]; p += plane;
-        r4 = a00 * p[0] + a01 * p[1] + a10 * p[w] + a11 * p[w + 1]; p += plane;
-        r5 = a00 * p[0] + a01 * p[1] + a10 * p[w] + a11 * p[w + 1]; p += plane;
-        r6 = a00 * p[0] + a01 * p[1] + a10 * p[w] + a11 * p[w + 1];
+        fb_f2u t[5], b[5];
+#pragma unroll
+        for (int c = 0; c < 5; ++c) {
+            t[c] = *reinterpret_cast<const fb_f2u*>(p + c * plane);
+            b[c] = *reinterpret_cast<const fb_f2u*>(p + c * plane + w);
+        }
+        r2 = a00 * t[0].x + a01 * t[0].y + a10 * b[0].x + a11 * b[0].y;
+        r3 = a00 * t[1].x + a01 * t[1].y + a10 * b[1].x + a11 * b[1].y;
+        r4 = a00 * t[2].x + a01 * t[2].y + a10 * b[2].x + a11 * b[2].y;
+        r5 = a00 * t[3].x + a01 * t[3].y + a10 * b[3].x + a11 * b[3].y;
+        r6 = a00 * t[4].x + a01 * t[4].y + a10 * b[4].x + a11 * b[4].y;
         r4 = (q2 + r4) * 0.5f; r5 = (q3 + r5) * 0.5f; r6 = (q4 + r6) * 0.25f;
     } else {
         r2 = r3 = 0.f;
@@ -393,12 +403,20 @@ __device__ __forceinline__ float2 fb_start_flow(const FbStart& a, int x, int y) 
 }
 
 __global__ __launch_bounds__(256) void fb_start_kernel(const FbStart a) {
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    // 64 x 4 pixels per workgroup, dealt to the XCDs in contiguous row-major runs like fb_iter_kernel's tiles: the rows of R1 a
+    // workgroup gathers from are the rows its neighbours above / below gather from (the 2-D grid fetched 1.85 x the planes' bytes)
+    const int tiles_x = (a.L.w + 63) / 64;
+    const int per_xcd = gridDim.x / 8;
+    const int tile = (int)(blockIdx.x % 8) * per_xcd + (int)(blockIdx.x / 8);
+    const int x = (tile % tiles_x) * 64 + (threadIdx.x & 63), y = (tile / tiles_x) * 4 + (threadIdx.x >> 6);
     if (x >= a.L.w || y >= a.L.h) return;
+    const size_t plane = (size_t)a.L.w * a.L.h, o = (size_t)y * a.L.w + x;
+    float q[5];
+#pragma unroll
+    for (int c = 0; c < 5; ++c) q[c] = a.L.R0[c * plane + o];
     const float2 f = fb_start_flow(a, x, y);
     float m[5];
-    fb_matrices(a.L, x, y, f.x, f.y, m);
-    const size_t plane = (size_t)a.L.w * a.L.h, o = (size_t)y * a.L.w + x;
+    fb_matrices(a.L, x, y, f.x, f.y, q, m);
 #pragma unroll
     for (int c = 0; c < 5; ++c) a.M[c * plane + o] = m[c];
 }
@@ -419,7 +437,11 @@ struct FbIter {
 template <int M_>
 __global__ __launch_bounds__(256) void fb_iter_kernel(const FbIter a) {
     constexpr int HW = kTX + 2 * M_, HH = kTY + 2 * M_, WIN = 2 * M_ + 1;
-    __shared__ float sM[5][HH][HW];
+    static_assert(5 * HW <= 256, "one thread per (channel, column) of the tile + halo");
+    // the row sums (f64) of all five channels: the only LDS array.  Round 5: the f32 tile + halo used to be staged in LDS as well
+    // (52.8 KB per workgroup at m = 6 -> 3 workgroups per CU, and a tile is a chain of two global round trips and several LDS passes:
+    // the launch was bound by how many such chains a CU had in flight); now a thread takes its column of the tile + halo straight
+    // from global memory into registers and adds up the 16 row windows there.
     __shared__ __attribute__((aligned(16))) double sV[5][kTY][HW];
     const int w = a.L.w, h = a.L.h;
     // XCD-aware tile order (workgroup b runs on XCD b % 8): every XCD takes a contiguous run of tiles in row-major order, so the
@@ -430,80 +452,111 @@ __global__ __launch_bounds__(256) void fb_iter_kernel(const FbIter a) {
     if (tile >= tiles_x * ((h + kTY - 1) / kTY)) return;
     const int x0 = (tile % tiles_x) * kTX, y0 = (tile / tiles_x) * kTY;
     const size_t plane = (size_t)w * h;
-    for (int i = threadIdx.x; i < HH * HW; i += 256) {            // replicate border = the clamped pixel's matrices
-        const int hy = i / HW, hx = i - hy * HW;
-        int x = x0 - M_ + hx, y = y0 - M_ + hy;
+    // one thread = two horizontally adjacent pixels of the tile; their own coefficients (for the next update's matrices) are
+    // requested now, long before the flow that the rest of those matrices depends on exists
+    const int ty = threadIdx.x / (kTX / 2), tx = 2 * (threadIdx.x - ty * (kTX / 2));
+    const int y = y0 + ty;
+    const bool in0 = x0 + tx < w && y < h, in1 = x0 + tx + 1 < w && y < h;
+    // window sums over rows: thread (channel, column) loads the column's kTY + 2m values (replicate border = the clamped pixel's
+    // matrices) and makes the kTY sums, each ascending over its 2m + 1 rows in f64: the oracle's order
+    if (threadIdx.x < 5 * HW) {
+        const int c = threadIdx.x / HW, hx = threadIdx.x - c * HW;
+        int x = x0 - M_ + hx;
         x = x < 0 ? 0 : (x > w - 1 ? w - 1 : x);
-        y = y < 0 ? 0 : (y > h - 1 ? h - 1 : y);
-        const size_t o = (size_t)y * w + x;
+        const float* p = a.M_in + c * plane + x;
+        float v[HH];
+        if (y0 - M_ >= 0 && y0 + kTY + M_ <= h) {
 #pragma unroll
-        for (int c = 0; c < 5; ++c) sM[c][hy][hx] = a.M_in[c * plane + o];
-    }
-    __syncthreads();
-    // window sums over rows: an item is (channel, column, group of four rows): 4 + 2m values from LDS, four direct sums in registers
-    // (each ascending over its 2m + 1 rows, f64: the oracle's order)
-    constexpr int RG = 4;
-    for (int i = threadIdx.x; i < 5 * HW * (kTY / RG); i += 256) {
-        const int c = i / (HW * (kTY / RG)), rem = i - c * (HW * (kTY / RG)), g = rem / HW, hx = rem - g * HW;
-        float v[RG + 2 * M_];
+            for (int j = 0; j < HH; ++j) v[j] = p[(size_t)(y0 - M_ + j) * w];
+        } else {
 #pragma unroll
-        for (int j = 0; j < RG + 2 * M_; ++j) v[j] = sM[c][RG * g + j][hx];
+            for (int j = 0; j < HH; ++j) {
+                int yy = y0 - M_ + j;
+                yy = yy < 0 ? 0 : (yy > h - 1 ? h - 1 : yy);
+                v[j] = p[(size_t)yy * w];
+            }
+        }
 #pragma unroll
-        for (int q = 0; q < RG; ++q) {
+        for (int q = 0; q < kTY; ++q) {
             double t = 0;
 #pragma unroll
             for (int j = 0; j < WIN; ++j) t += v[q + j];
-            sV[c][RG * g + q][hx] = t;
+            sV[c][q][hx] = t;
+        }
+    }
+    fb_f2u q01[5];
+    if (a.M_out && in0) {
+        const float* p = a.L.R0 + (size_t)y * w + x0 + tx;
+        if (in1) {
+#pragma unroll
+            for (int c = 0; c < 5; ++c) q01[c] = *reinterpret_cast<const fb_f2u*>(p + c * plane);
+        } else {
+#pragma unroll
+            for (int c = 0; c < 5; ++c) { q01[c].x = p[c * plane]; q01[c].y = 0.f; }
         }
     }
     __syncthreads();
-    const double scale = 1.0 / (WIN * WIN);
-    {   // one thread = two horizontally adjacent pixels
-        const int ty = threadIdx.x / (kTX / 2), tx = 2 * (threadIdx.x - ty * (kTX / 2));
-        double s[2][5];
+    double s[2][5];
 #pragma unroll
-        for (int c = 0; c < 5; ++c) {
-            double v[WIN + 1];                    // WIN + 1 is even and tx is even: 16-byte reads, conflict-free across the wave's four rows
+    for (int c = 0; c < 5; ++c) {
+        double v[WIN + 1];                        // WIN + 1 is even and tx is even: 16-byte reads, conflict-free across the wave's four rows
 #pragma unroll
-            for (int j = 0; j < WIN + 1; j += 2) {
-                const double2 p = *reinterpret_cast<const double2*>(&sV[c][ty][tx + j]);
-                v[j] = p.x; v[j + 1] = p.y;
-            }
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                double t = 0;
-#pragma unroll
-                for (int j = 0; j < WIN; ++j) t += v[q + j];
-                s[q][c] = t;
-            }
+        for (int j = 0; j < WIN + 1; j += 2) {
+            const double2 p = *reinterpret_cast<const double2*>(&sV[c][ty][tx + j]);
+            v[j] = p.x; v[j + 1] = p.y;
         }
-        const int y = y0 + ty;
-        float u[2], v[2], mm[2][5];
-        bool in[2];
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            in[q] = x0 + tx + q < w && y < h;
-            const double g11 = s[q][0] * scale, g12 = s[q][1] * scale, g22 = s[q][2] * scale, h1 = s[q][3] * scale, h2 = s[q][4] * scale;
-            const double idet = 1. / (g11 * g22 - g12 * g12 + 1e-3);
-            u[q] = (float)((g11 * h2 - g12 * h1) * idet); v[q] = (float)((g22 * h1 - g12 * h2) * idet);
+            double t = 0;
+#pragma unroll
+            for (int j = 0; j < WIN; ++j) t += v[q + j];
+            s[q][c] = t;
         }
-        // the next update's matrices of both pixels before any store: their gathers overlap (a store in between would order them)
+        // (the sums are finished HERE: left to itself the scheduler keeps every channel's 2m + 2 row sums in registers)
+        asm volatile("" : "+v"(s[0][c]), "+v"(s[1][c]));
+    }
+    const double scale = 1.0 / (WIN * WIN);
+    float u[2], v[2], mm[2][5];
+    const bool in[2] = {in0, in1};
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const double g11 = s[q][0] * scale, g12 = s[q][1] * scale, g22 = s[q][2] * scale, h1 = s[q][3] * scale, h2 = s[q][4] * scale;
+        const double idet = 1. / (g11 * g22 - g12 * g12 + 1e-3);
+        u[q] = (float)((g11 * h2 - g12 * h1) * idet); v[q] = (float)((g22 * h1 - g12 * h2) * idet);
+    }
+    // the next update's matrices of both pixels before any store: their gathers overlap (a store in between would order them)
+    if (a.M_out) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+            if (in[q]) {
+                const float qq[5] = {q ? q01[0].y : q01[0].x, q ? q01[1].y : q01[1].x, q ? q01[2].y : q01[2].x, q ? q01[3].y : q01[3].x,
+                                     q ? q01[4].y : q01[4].x};
+                fb_matrices(a.L, x0 + tx + q, y, u[q], v[q], qq, mm[q]);
+            }
+    }
+    if (!in0) return;
+    const int x = x0 + tx;
+    const size_t o = (size_t)y * w + x;
+    if (in1) {                                   // both pixels: 8- and 16-byte stores (any 4-byte alignment) where the two are neighbours in memory
+        if (a.flow_out) {
+            typedef float fb_f4u __attribute__((ext_vector_type(4), aligned(4)));
+            fb_f4u f4; f4.x = u[0]; f4.y = v[0]; f4.z = u[1]; f4.w = v[1];
+            *reinterpret_cast<fb_f4u*>(a.flow_out + o) = f4;
+        }
+        if (a.out_entries) {
+            a.out_entries[o] = make_float4(((float)x + 0.5f) * a.nx, ((float)y + 0.5f) * a.ny, u[0] * a.nx, v[0] * a.ny);
+            a.out_entries[o + 1] = make_float4(((float)(x + 1) + 0.5f) * a.nx, ((float)y + 0.5f) * a.ny, u[1] * a.nx, v[1] * a.ny);
+        }
         if (a.M_out) {
 #pragma unroll
-            for (int q = 0; q < 2; ++q)
-                if (in[q]) fb_matrices(a.L, x0 + tx + q, y, u[q], v[q], mm[q]);
+            for (int c = 0; c < 5; ++c) { fb_f2u m2; m2.x = mm[0][c]; m2.y = mm[1][c]; *reinterpret_cast<fb_f2u*>(a.M_out + c * plane + o) = m2; }
         }
+    } else {
+        if (a.flow_out) a.flow_out[o] = make_float2(u[0], v[0]);
+        if (a.out_entries) a.out_entries[o] = make_float4(((float)x + 0.5f) * a.nx, ((float)y + 0.5f) * a.ny, u[0] * a.nx, v[0] * a.ny);
+        if (a.M_out) {
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            if (!in[q]) continue;
-            const int x = x0 + tx + q;
-            const size_t o = (size_t)y * w + x;
-            if (a.flow_out) a.flow_out[o] = make_float2(u[q], v[q]);
-            if (a.out_entries) a.out_entries[o] = make_float4(((float)x + 0.5f) * a.nx, ((float)y + 0.5f) * a.ny, u[q] * a.nx, v[q] * a.ny);
-            if (a.M_out) {
-#pragma unroll
-                for (int c = 0; c < 5; ++c) a.M_out[c * plane + o] = mm[q][c];
-            }
+            for (int c = 0; c < 5; ++c) a.M_out[c * plane + o] = mm[0][c];
         }
     }
 }
@@ -618,7 +671,7 @@ int farneback_flow_device(ofps_hip_ctx* ctx, const uint8_t* d_prev, const uint8_
             st.mode = 2; st.flow_in = coarse; st.pw = pw; st.ph = ph;
             st.inv_x = 1.0 / ((double)w / pw); st.inv_y = 1.0 / ((double)h / ph);
         }
-        hipLaunchKernelGGL(fb_start_kernel, dim3((w + 63) / 64, (h + 3) / 4), dim3(256), 0, s, st);
+        hipLaunchKernelGGL(fb_start_kernel, dim3((((w + 63) / 64) * ((h + 3) / 4) + 7) / 8 * 8), dim3(256), 0, s, st);
         float2* layer_flow = coarse == Fp[0] ? Fp[1] : Fp[0];
         for (int it = 0; it < iters; ++it) {
             const bool last_it = it == iters - 1, last = k == 0 && last_it;

@@ -29,9 +29,10 @@ ctx.sync(); ctx.timer_start()
 for _ in range(reps):
     step()
 ms = ctx.timer_stop() / reps
-px = sum((W >> k) * (H >> k) for k in range(levels + 1))
-# algorithmic HBM bytes per pair: per layer pixel, I written + read once (8 B x 2 images), R written once (20 B x 2), per update R0 + R1 read
-# (40 B) + flow read + written (16 B); records 16 B per level-0 pixel
-algo = px * (2 * 8 + 2 * 20 + 3 * (40 + 16)) + W * H * 16
+px = sum(((W + (1 << k) // 2) >> k) * ((H + (1 << k) // 2) >> k) for k in range(levels + 1))
+# algorithmic HBM bytes per pair -- the formula of bench_legs.py's roofline_farneback: per layer pixel 40 (expansion planes
+# written) + 60 (first matrices: R0 + R1 read, M written) + 2 x 80 (updates 1, 2: M + R0 + R1 read, next M written) + 28 (last update: M
+# read, flow written) = 288 B; + 16 B of records and 2 B of frames per frame pixel
+algo = px * 288 + W * H * 18
 print(json.dumps({"levels": levels, "farneback_1080p_ms": round(ms, 4), "algorithmic_MB": round(algo / 1e6, 1), "GBs_at_algorithmic_bytes": round(algo / (ms * 1e-3) / 1e9, 1)}))
 ctx.use_own_stream(); ctx.close()

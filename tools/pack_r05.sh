@@ -10,6 +10,7 @@ for p in sad_strip sad_strip_cfg4 cfg3_chain cfg3_chain_pm16; do
 done
 mkdir -p $D/cfg5_stream && cp $S/cfg5_stream/*.json $D/cfg5_stream/
 cp $S/*.json $S/*.txt $D/
+mv $D/accuracy_table.txt $D/accuracy.txt          # the name VERDICT r4 item 3 gave it
 rm -f $D/hbm_traffic.json
 python tools/make_hbm_traffic.py
 cmp -s profiles/hbm_traffic.json $S/hbm_traffic.json || echo "note: hbm_traffic.json differs from the one the bench line of this collection read"
