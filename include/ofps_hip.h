@@ -207,6 +207,10 @@ int ofps_hip_farneback_flow(ofps_hip_ctx* ctx, const uint8_t* prev, const uint8_
                             int iters, int poly_n, float poly_sigma, const float* init_flow, float* out_flow, float* out_entries);
 int ofps_hip_farneback_flow_dev(ofps_hip_ctx* ctx, const void* d_prev, const void* d_cur, int W, int H, int stride, int levels, int winsize,
                                 int iters, int poly_n, float poly_sigma, const void* d_init_flow, void* d_out_flow, void* d_out_entries);
+/* In the stream forms (ofps_hip_lk_push_frame[_async] with OFPS_HIP_FLOW_FARNEBACK) a pair's second frame is the next pair's first: its
+ * pyramid and polynomial expansion are kept on the device and only the new frame goes through them (same results, bit for bit).
+ * Diagnostics: how many calls of this context found the first frame's expansion already there. */
+int ofps_hip_flow_cache_hits(ofps_hip_ctx* ctx, uint64_t* count);
 /* ---- A1-A4: MotionFieldDensifier ---- */
 int ofps_hip_densify(ofps_hip_ctx* ctx, const float* entries, size_t n, int w, int h,
                      float* out_field /* 2*w*h, cell (x,y) at 2*(y*w+x) */,

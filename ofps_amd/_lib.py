@@ -49,6 +49,7 @@ PROTOTYPES = {
     "ofps_hip_lk_spec_revision": (C.c_int, []),
     "ofps_hip_lk_wait_timeouts": (C.c_int, [_ctx, C.POINTER(C.c_uint64)]),
     "ofps_hip_lk_recoveries": (C.c_int, [_ctx, C.POINTER(C.c_uint64)]),
+    "ofps_hip_flow_cache_hits": (C.c_int, [_ctx, C.POINTER(C.c_uint64)]),
     "ofps_hip_contrast_mask": (C.c_int, [_ctx, _u8p, C.c_int, C.c_int, C.c_int, _u8p]),
     "ofps_hip_contrast_mask_dev": (C.c_int, [_ctx, _vp, C.c_int, C.c_int, C.c_int, _vp]),
     "ofps_hip_lk_decode": (C.c_int, [_ctx, _u8p, _u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,

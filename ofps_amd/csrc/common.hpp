@@ -69,6 +69,18 @@ struct ofps_hip_ctx {
         unsigned flags = 0;
     } lk_ticket[kLkTickets];
     long lk_next_ticket = 0;
+    // hip_flow in the stream forms (farneback.hip): the pyramid + polynomial expansion of a pair's second frame is the next pair's
+    // first.  Frames of the stream carry ids (never reused); the expansion planes of the frame with id `fb_cache.id` are in R slot
+    // `fb_cache.slot` of the S_FB_WORK allocation of generation `gen`, made with these parameters.
+    uint64_t lk_frame_serial = 0;
+    uint64_t lk_slot_id[kLkSlots] = {0, 0, 0};
+    struct FbCache {
+        bool valid = false;
+        int slot = 0, W = 0, H = 0, K = 0, poly_n = 0;
+        double poly_sigma = 0;
+        uint64_t id = 0, gen = 0;
+    } fb_cache;
+    uint64_t fb_cache_hits = 0;          // (tests: how many calls skipped the first frame's pyramid + expansion)
 
     // per-frame pipeline state (pipeline.hip): a ring of three device frame slots (the new frame is uploaded on the copy
     // stream while the previous pair is still being searched), two tickets in flight
@@ -175,7 +187,8 @@ int compact_entries_device(ofps_hip_ctx* ctx, const float4* d_in, const uint8_t*
 int detect_device(ofps_hip_ctx* ctx, const float4* d_entries, size_t n, int batch, float min_size, size_t subdivide,
                   float target_motion, int* d_result, float2* d_out_field, int* out_dim);
 int farneback_flow_device(ofps_hip_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_cur, int W, int H, int stride, int levels, int winsize,
-                          int iters, int poly_n, double poly_sigma, const float2* d_init, float2* d_flow, float4* d_entries);
+                          int iters, int poly_n, double poly_sigma, const float2* d_init, float2* d_flow, float4* d_entries,
+                          uint64_t prev_id = 0, uint64_t cur_id = 0);     // ids != 0: frames of a stream (ofps_hip_ctx::fb_cache)
 int lk_check_dev_calls(ofps_hip_ctx* ctx);          // lk.hip: did a device-pointer LK launch since the last look have an expired wait?
 int almeida_device(ofps_hip_ctx* ctx, const float4* d_entries, size_t n, int batch, float aspect, float fov_y_deg,
                    int use_ransac, size_t num_iters, float inlier_deg, size_t num_samples, uint64_t seed, float4* d_quat);

@@ -585,7 +585,8 @@ int farneback_layers(int W, int H, int levels) {
 // d_prev / d_cur: u8 luma on the device (row pitch `stride`).  d_init: nullptr or W x H float2 (OPTFLOW_USE_INITIAL_FLOW).  d_flow (W x H
 // float2) and / or d_entries (W x H float4 records) receive the result.  Everything is enqueued on ctx->stream.
 int farneback_flow_device(ofps_hip_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_cur, int W, int H, int stride, int levels, int winsize,
-                          int iters, int poly_n, double poly_sigma, const float2* d_init, float2* d_flow, float4* d_entries) {
+                          int iters, int poly_n, double poly_sigma, const float2* d_init, float2* d_flow, float4* d_entries,
+                          uint64_t prev_id, uint64_t cur_id) {
     OFPS_REQUIRE(ctx, W >= 1 && H >= 1 && stride >= W, "farneback: bad geometry W=%d H=%d stride=%d", W, H, stride);
     OFPS_REQUIRE(ctx, levels >= 0 && levels <= 16 && iters >= 1 && iters <= 64 && winsize >= 1 && (winsize & 1) && poly_n >= 1,
                  "farneback: levels=%d winsize=%d iters=%d poly_n=%d out of range", levels, winsize, iters, poly_n);
@@ -632,22 +633,36 @@ int farneback_flow_device(ofps_hip_ctx* ctx, const uint8_t* d_prev, const uint8_
     float* T = base; float* I = T + t_floats; float* R = I + i_floats;
     float* Mb[2] = {R + 10 * r_px, R + 10 * r_px + 5 * px};
     float2* Fp[2] = {reinterpret_cast<float2*>(Mb[1] + 5 * px), reinterpret_cast<float2*>(Mb[1] + 5 * px) + px};
-    auto Rk = [&](int k, int img) { return R + 10 * r_off[k] + (size_t)img * 5 * Y.w[k] * Y.h[k]; };
+    // Stream forms (prev_id / cur_id != 0: frames of ofps_hip_lk_push_frame[_async]): the first frame's expansion planes are the ones
+    // the previous call made for ITS second frame, if that call was about the same frame (id), geometry and parameters and the
+    // workspace has not moved since -- then only the second frame goes through the pyramid and the expansion.  The two R slots of a
+    // layer swap roles from call to call.  Everything is on ctx->stream: the planes are complete before this call's kernels read them.
+    ofps_hip_ctx::FbCache& fc = ctx->fb_cache;
+    const uint64_t gen = ctx->scratch[S_FB_WORK].gen;
+    const bool reuse = prev_id != 0 && fc.valid && fc.id == prev_id && fc.gen == gen && fc.W == W && fc.H == H && fc.K == K &&
+                       fc.poly_n == poly_n && fc.poly_sigma == poly_sigma;
+    const int slot_prev = reuse ? fc.slot : 0, slot_cur = 1 - slot_prev;
+    fc.valid = false;                              // (until this call has enqueued everything)
+    auto Rk = [&](int k, int img) { return R + 10 * r_off[k] + (size_t)(img ? slot_cur : slot_prev) * 5 * Y.w[k] * Y.h[k]; };
+    const int n_img = reuse ? 1 : 2;               // images that go through the pyramid + expansion: (prev, cur) or (cur)
+    if (reuse) ctx->fb_cache_hits += 1;
     // ---- pyramid above layer 0: two launches
     if (K >= 1) {
-        hipLaunchKernelGGL(fb_pyr_h_kernel, dim3(H, 2), dim3(256), (size_t)(W + W / 32 + 1) * sizeof(float), s, d_prev, d_cur, W, H, stride, Y, T);
-        hipLaunchKernelGGL(fb_pyr_v_kernel, dim3(vblocks, 2), dim3(256), 0, s, (const float*)T, W, H, Y, I);
+        hipLaunchKernelGGL(fb_pyr_h_kernel, dim3(H, n_img), dim3(256), (size_t)(W + W / 32 + 1) * sizeof(float), s, reuse ? d_cur : d_prev, d_cur, W, H,
+                           stride, Y, T);
+        hipLaunchKernelGGL(fb_pyr_v_kernel, dim3(vblocks, n_img), dim3(256), 0, s, (const float*)T, W, H, Y, I);
     }
     // ---- polynomial expansion of every layer and both images: one launch (layer 0 blurs the u8 frame while it fills its tiles)
     {
         FbExp E{};
         int blk = 0;
         for (int k = 0; k <= K; ++k)
-            for (int img = 0; img < 2; ++img) {
+            for (int z = 0; z < n_img; ++z) {
+                const int img = reuse ? 1 : z;
                 FbExpJob& J = E.job[E.njobs++];
                 J.w = Y.w[k]; J.h = Y.h[k]; J.R = Rk(k, img); J.blk0 = blk; J.tiles_x = (J.w + kPX - 1) / kPX;
                 if (k == 0) { J.u8 = img ? d_cur : d_prev; J.stride = stride; J.I = nullptr; }
-                else { J.u8 = nullptr; J.stride = 0; J.I = I + Y.i_off[k] + (size_t)img * J.w * J.h; }
+                else { J.u8 = nullptr; J.stride = 0; J.I = I + Y.i_off[k] + (size_t)z * J.w * J.h; }
                 blk += J.tiles_x * ((J.h + kPY - 1) / kPY);
             }
         const size_t lds = (size_t)((kPY + 2 * poly_n) * (kPX + 2 * poly_n) + 3 * kPY * (kPX + 2 * poly_n)) * sizeof(float);
@@ -695,12 +710,21 @@ int farneback_flow_device(ofps_hip_ctx* ctx, const uint8_t* d_prev, const uint8_
         coarse = layer_flow; pw = w; ph = h;
     }
     OFPS_HIP_TRY(ctx, hipGetLastError());
+    if (cur_id != 0) {
+        fc.valid = true; fc.slot = slot_cur; fc.id = cur_id; fc.gen = gen; fc.W = W; fc.H = H; fc.K = K; fc.poly_n = poly_n; fc.poly_sigma = poly_sigma;
+    }
     return OFPS_HIP_OK;
 }
 
 }  // namespace ofps
 
 extern "C" {
+
+int ofps_hip_flow_cache_hits(ofps_hip_ctx* ctx, uint64_t* count) {
+    if (!ctx || !count) return OFPS_HIP_EINVAL;
+    *count = ctx->fb_cache_hits;
+    return OFPS_HIP_OK;
+}
 
 int ofps_hip_farneback_flow_dev(ofps_hip_ctx* ctx, const void* d_prev, const void* d_cur, int W, int H, int stride, int levels, int winsize,
                                 int iters, int poly_n, float poly_sigma, const void* d_init_flow, void* d_out_flow, void* d_out_entries) {

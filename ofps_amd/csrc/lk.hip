@@ -1880,7 +1880,8 @@ uint32_t lk_block_waits(const void* pinned) {
 // serial: the pyramid level by level (the repeat after an expired wait).  *epoch: the flow launch's epoch when the block's second
 // word carries flag word 1 (0 otherwise: nothing to compare).
 int lk_enqueue_frame(ofps_hip_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_cur, int W, int H, int levels, int radius, int iters,
-                     const LkGrid& g, float4* rec_dst, uint32_t* cnt_dst, bool serial, uint32_t* epoch) {
+                     const LkGrid& g, float4* rec_dst, uint32_t* cnt_dst, bool serial, uint32_t* epoch, uint64_t prev_id = 0,
+                     uint64_t cur_id = 0) {
     const size_t px = (size_t)W * H, cells = g.per_pixel ? 1 : (size_t)g.gw * g.gh;
     auto* d_ent = static_cast<float4*>(ofps::scratch(ctx, ofps::S_ENTRIES, px * sizeof(float4)));
     auto* d_field = static_cast<float2*>(ofps::scratch(ctx, ofps::S_FIELD, cells * sizeof(float2)));
@@ -1890,8 +1891,9 @@ int lk_enqueue_frame(ofps_hip_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_
     const uint32_t* d_waits = nullptr;
     if (g.farneback) {
         // cv-decoder's call (cv-decoder/src/lib.rs:188-199): levels = pyramid levels, winsize = 2 * radius + 1, iters = iterations,
-        // poly_n 7, poly_sigma 1.5.  No tile waits on another in this flow: nothing to repair, *epoch = 0
-        rc = ofps::farneback_flow_device(ctx, d_prev, d_cur, W, H, W, levels, 2 * radius + 1, iters, 7, 1.5, nullptr, nullptr, d_ent);
+        // poly_n 7, poly_sigma 1.5.  No tile waits on another in this flow: nothing to repair, *epoch = 0.  prev_id / cur_id: the
+        // stream's frame ids -- the first frame's pyramid + expansion are the previous call's (farneback.hip)
+        rc = ofps::farneback_flow_device(ctx, d_prev, d_cur, W, H, W, levels, 2 * radius + 1, iters, 7, 1.5, nullptr, nullptr, d_ent, prev_id, cur_id);
         if (rc != OFPS_HIP_OK) return rc;
         *epoch = 0;
     } else {
@@ -2060,6 +2062,7 @@ int ofps_hip_lk_push_frame_async(ofps_hip_ctx* ctx, const uint8_t* frame, int W,
     const int slot = (int)(ctx->lk_frames % ofps_hip_ctx::kLkSlots);
     hipStream_t up = overlap ? ctx->lk_copy_stream : s;
     OFPS_HIP_TRY(ctx, ofps::upload_rows(d_frames + (size_t)slot * px, W, frame, stride, W, H, up));
+    ctx->lk_slot_id[slot] = ++ctx->lk_frame_serial;               // (a new id for whatever is in the slot now, also if the push fails below)
     if (overlap) {
         OFPS_HIP_TRY(ctx, hipEventRecord(t.uploaded, up));
         OFPS_HIP_TRY(ctx, hipStreamWaitEvent(s, t.uploaded, 0));       // everything of this ticket on the compute stream comes after the upload
@@ -2078,7 +2081,8 @@ int ofps_hip_lk_push_frame_async(ofps_hip_ctx* ctx, const uint8_t* frame, int W,
         const int prev_slot = (int)((frames_after - 2) % ofps_hip_ctx::kLkSlots);
         tp = d_frames + (size_t)prev_slot * px; tc = d_frames + (size_t)slot * px;
         rc = lk_enqueue_frame(ctx, tp, tc, W, H, levels, radius, iters, g,
-                              reinterpret_cast<float4*>(static_cast<char*>(mapped) + 16), static_cast<uint32_t*>(mapped), false, &epoch);
+                              reinterpret_cast<float4*>(static_cast<char*>(mapped) + 16), static_cast<uint32_t*>(mapped), false, &epoch,
+                              ctx->lk_slot_id[prev_slot], ctx->lk_slot_id[slot]);
         if (rc != OFPS_HIP_OK) return rc;
         have_vectors = 1;
     }

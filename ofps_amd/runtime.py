@@ -180,6 +180,12 @@ class HipContext:
         self._check(self._lib.ofps_hip_lk_recoveries(self._h, C.byref(n)))
         return int(n.value)
 
+    def flow_cache_hits(self) -> int:
+        """hip_flow stream forms: calls of this context that found their first frame's pyramid + expansion already on the device."""
+        n = C.c_uint64(0)
+        self._check(self._lib.ofps_hip_flow_cache_hits(self._h, C.byref(n)))
+        return int(n.value)
+
     def lk_flow_init(self, prev: np.ndarray, cur: np.ndarray, levels, radius, iters, init: np.ndarray):
         """ofps_hip_lk_flow_init_dev through library-owned device buffers: `init` [h_L, w_L, 2] is the coarsest level's
         starting flow.  -> flow[H, W, 2]."""

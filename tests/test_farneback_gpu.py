@@ -135,3 +135,51 @@ def test_hip_flow_decoder_is_the_lk_decoders_output_stage_on_farnebacks_flow(ctx
         assert dec.process_frame(field) is True
         np.testing.assert_array_equal(np.asarray(field, np.float32).view(np.uint32), want[k].view(np.uint32))
     dec.ctx.close()
+
+
+def test_hip_flow_stream_reuses_the_previous_frames_expansion(ctx):
+    """Stream forms: the second frame's pyramid + polynomial expansion serve as the next pair's first (ofps_hip_flow_cache_hits counts it);
+    records stay those of the pair call, whatever happens in between: a pair call through the same workspace, other parameters, a
+    reset, a frame skipped by the caller (= a stream restart)."""
+    fr = synth.luma_sequence(7, 352, 200, max_step=3, seed=33)
+
+    def pair(a, b, levels=5, radius=6):
+        return ctx.lk_decode(a, b, levels, radius, 3, contrast_mask=True, farneback=True)[0]
+    want = [pair(fr[k], fr[k + 1]) for k in range(6)]
+    grid = ctx.lk_decode(fr[0], fr[1], 5, 6, 3, contrast_mask=True, farneback=True)[1]
+    np.testing.assert_array_equal(want[0].view(np.uint32),
+                                  oracle.densify_to_entries(oracle.masked_flow_to_entries(oracle.farneback_flow(fr[0], fr[1]), oracle.contrast_mask(fr[1])), *grid).view(np.uint32))
+    ctx.lk_reset()
+    h0 = ctx.flow_cache_hits()
+    assert ctx.lk_push_frame(fr[0], 5, 6, 3, contrast_mask=True, farneback=True) is None
+    got = [ctx.lk_push_frame(fr[k], 5, 6, 3, contrast_mask=True, farneback=True)[0] for k in (1, 2, 3)]
+    assert ctx.flow_cache_hits() - h0 == 2                            # pairs (1,2) and (2,3); pair (0,1) made both expansions
+    for k in range(3):
+        np.testing.assert_array_equal(got[k].view(np.uint32), want[k].view(np.uint32))
+    # a pair call in between uses the same planes: the stream's next pair must not trust them
+    ctx.farneback_flow(fr[5], fr[6])
+    e = ctx.lk_push_frame(fr[4], 5, 6, 3, contrast_mask=True, farneback=True)[0]
+    assert ctx.flow_cache_hits() - h0 == 2
+    np.testing.assert_array_equal(e.view(np.uint32), want[3].view(np.uint32))
+    # other parameters (fewer layers: 352 x 200 has three at levels >= 2, two at levels = 1): recomputed
+    e = ctx.lk_push_frame(fr[5], 1, 6, 3, contrast_mask=True, farneback=True)[0]
+    assert ctx.flow_cache_hits() - h0 == 2
+    np.testing.assert_array_equal(e.view(np.uint32), pair(fr[4], fr[5], levels=1).view(np.uint32))
+    ctx.lk_reset()
+    assert ctx.lk_push_frame(fr[2], 5, 6, 3, contrast_mask=True, farneback=True) is None
+    e = ctx.lk_push_frame(fr[3], 5, 6, 3, contrast_mask=True, farneback=True)[0]
+    np.testing.assert_array_equal(e.view(np.uint32), want[2].view(np.uint32))
+    # read-ahead form: two tickets in flight
+    pins = [ctx.pinned_frame(200, 352) for _ in range(3)]
+    t = []
+    for k in range(3):
+        np.copyto(pins[k], fr[4 + k])
+    h1 = ctx.flow_cache_hits()
+    t.append(ctx.lk_push_frame_async(pins[0], 5, 6, 3, contrast_mask=True, farneback=True))     # continues the stream: pair (3, 4)
+    t.append(ctx.lk_push_frame_async(pins[1], 5, 6, 3, contrast_mask=True, farneback=True))
+    r0 = ctx.lk_frame_wait(t[0]); t.append(ctx.lk_push_frame_async(pins[2], 5, 6, 3, contrast_mask=True, farneback=True))
+    r1 = ctx.lk_frame_wait(t[1]); r2 = ctx.lk_frame_wait(t[2])
+    assert ctx.flow_cache_hits() - h1 == 3
+    for r, k in ((r0, 3), (r1, 4), (r2, 5)):
+        np.testing.assert_array_equal(r[0].view(np.uint32), want[k].view(np.uint32))
+    ctx.lk_reset()
