@@ -6,17 +6,19 @@
 // the expansion / matrices, f64 horizontal half / window sums / 2x2 solve) -- DESIGN.md "N2b", oracle/farneback_oracle.c.
 //
 // Kernels (layers k = K .. 0, scale 0.5^k; OpenCV makes every layer from the ORIGINAL frame: Gaussian blur, then bilinear resize):
-//   fb_pyr_h_kernel      ONE launch for all layers >= 1: a workgroup takes one frame row into LDS and evaluates every layer's row filter
-//                        at the columns that layer's resize will sample                                     -> T_k [2][H][2 w_k]
+//   fb_pyr_h_kernel      ONE launch for all layers >= 1: a workgroup takes eight frame rows (bytes) into LDS and evaluates one layer's row
+//                        filter at the columns that layer's resize will sample                               -> T_k [2][H][2 w_k]
 //   fb_pyr_v_kernel      ONE launch for all layers >= 1: column filter at the sampled rows + the bilinear combine -> I_k [2][h_k][w_k]
 //   fb_polyexp_kernel    ONE launch for all layers and both frames: 15-tap separable polynomial expansion, tile + halo in LDS; layer 0's
 //                        image is never stored (its [1 2 1]/4 blur of the u8 frame is evaluated while the tile is filled) -> R [5][h][w] planar
 //   fb_start_kernel      per layer: FarnebackUpdateMatrices from the flow the layer starts with (zero / the coarser layer's flow resized
 //                        on the fly x 2 / the caller's initial flow)                                         -> M [5][h][w]
-//   fb_iter_kernel x iters   per update: a workgroup owns a 32 x 16 tile: M tile + window halo -> LDS, window sums (f64, rows then
-//                        columns, ascending: the oracle's order), the 2 x 2 solve, and -- except in a layer's last update -- the NEXT
-//                        update's matrices for its own pixels, written where the flow they depend on is produced; the flow itself is
-//                        stored only when somebody reads it (next layer, caller).  Tiles are dealt to the XCDs in contiguous runs.
+//   fb_iter_kernel x iters   per update: a workgroup owns a 32 x 16 tile: a thread per (channel, column) of tile + window halo takes its
+//                        column of M from global memory and makes the 16 row-window sums in registers (f64, ascending: the oracle's
+//                        order) -> LDS; then per pixel the column-window sums, the 2 x 2 solve, and -- except in a layer's last update --
+//                        the NEXT update's matrices for its own pixels, written where the flow they depend on is produced; the flow
+//                        itself is stored only when somebody reads it (next layer, caller).  Tiles are dealt to the XCDs in contiguous runs.
+// Stream forms keep the second frame's pyramid + expansion for the next pair (ofps_hip_ctx::fb_cache).
 // All streaming: the honest roofline of this path is HBM (R0 + R1 + M in / out per update); measured numbers: DESIGN.md "N2b".
 #include "common.hpp"
 
@@ -113,35 +115,94 @@ struct FbPyr {
     float taps[kMaxTaps];
 };
 
-// one workgroup per (frame row, image): the row goes to LDS once, every layer's sampled columns come out of it.  The sampled columns of
-// layer k are 2^k apart: the row is stored with one pad word per 32 so that a wave's reads do not all fall into two banks.
-__device__ __forceinline__ int fb_pad(int i) { return i + (i >> 5); }
-__global__ __launch_bounds__(256) void fb_pyr_h_kernel(const uint8_t* __restrict__ img0, const uint8_t* __restrict__ img1, int W, int H, int stride,
-                                                       const FbPyr P, float* __restrict__ T) {
-    extern __shared__ float srow[];
-    __shared__ float staps[kMaxTaps];                  // (indexing the kernel-argument copy costs a scalar load + wait per tap)
-    const int row = blockIdx.x, z = blockIdx.y;
-    const uint8_t* img = (z ? img1 : img0) + (size_t)row * stride;
-    for (int x = threadIdx.x; x < W; x += 256) srow[fb_pad(x)] = (float)img[x];
-    for (int i = threadIdx.x; i < kMaxTaps; i += 256) staps[i] = P.taps[i];
-    __syncthreads();
-    for (int k = 1; k <= P.K; ++k) {
-        const int ncol = 2 * P.w[k], r = P.r[k];
-        const float* taps = staps + P.toff[k];
-        float* Tk = T + P.t_off[k] + ((size_t)z * H + row) * ncol;
-        for (int c = threadIdx.x; c < ncol; c += 256) {
-            int s0, s1; float f;
-            resize_axis(c >> 1, W, P.inv_x[k], &s0, &s1, &f);
-            const int xs = (c & 1) ? s1 : s0;
-            float s = taps[r] * srow[fb_pad(xs)];
-            if (xs - r >= 0 && xs + r < W) {                      // interior: no border arithmetic per tap
-                for (int j = 1; j <= r; ++j) s += taps[r + j] * (srow[fb_pad(xs - j)] + srow[fb_pad(xs + j)]);
-            } else {
-                for (int j = 1; j <= r; ++j) s += taps[r + j] * (srow[fb_pad(reflect101(xs - j, W))] + srow[fb_pad(reflect101(xs + j, W))]);
+// One workgroup per (group of 8 frame rows, image, layer): the rows' bytes go to LDS once (dword copies, reflect-101 margins), the layer's
+// row filter is evaluated at the columns its resize samples.  Lanes are dealt so that a wave's LDS reads fall into different banks
+// without any index arithmetic: the sampled columns of layer k are 2^k bytes apart, i.e. 2^(k-2) dwords; a wave takes 64 / nr columns of
+// nr = 1, 1, 2, 4, 8 (k = 1 .. 5) different rows whose starts are 1 dword (mod 64) apart, and every lane walks the 8 / nr rows it owns
+// with one tap in a register -- round 5: the first form (one row per workgroup, f32 row with a pad word per 32, border branch per
+// column, the resize's f64 index arithmetic per column AND row) spent 2,340 VALU instructions per wave on 75 tap pairs.
+constexpr int kPR = 8;
+constexpr int kPyrRS0 = 4 * (32 * 18 + 2), kPyrRS1 = 4 * (32 * 34 + 2), kPyrRS2 = 4 * (32 * 132 + 2);     // 2,312 / 4,360 / 16,904 bytes: W + margins up to 16,384 + 2 x 160
+template <int NRL, int RS>                       // NRL rows per lane; nr = kPR / NRL rows per wave instruction; RS bytes from row to row (immediate offsets)
+__device__ __forceinline__ void fb_pyr_h_cols(const uint8_t* __restrict__ rp, const float* __restrict__ taps, int r, float (&s)[NRL]) {
+    constexpr int nr = kPR / NRL;
+    constexpr int JB = NRL >= 8 ? 1 : (NRL == 4 ? 2 : (NRL == 2 ? 4 : 8));      // taps per batch: 16 byte reads requested before the first is used
+    const float t0 = taps[r];                                                    // (a lane's sum is a chain over j: without batches every tap pair
+#pragma unroll                                                                   //  waited out its own LDS round trip -- 39 of them in layer 5)
+    for (int i = 0; i < NRL; ++i) s[i] = t0 * (float)rp[i * nr * RS];
+    int j = 1;
+    for (; j + JB - 1 <= r; j += JB) {
+        float t[JB];
+        uint8_t a[JB][NRL], b[JB][NRL];
+#pragma unroll
+        for (int jj = 0; jj < JB; ++jj) {
+            t[jj] = taps[r + j + jj];
+#pragma unroll
+            for (int i = 0; i < NRL; ++i) { a[jj][i] = rp[i * nr * RS - (j + jj)]; b[jj][i] = rp[i * nr * RS + (j + jj)]; }
+        }
+#pragma unroll
+        for (int jj = 0; jj < JB; ++jj)
+#pragma unroll
+            for (int i = 0; i < NRL; ++i) s[i] += t[jj] * (float)((int)a[jj][i] + (int)b[jj][i]);      // (= (float)a + (float)b exactly: one conversion)
+    }
+    for (; j <= r; ++j) {
+        const float t = taps[r + j];
+#pragma unroll
+        for (int i = 0; i < NRL; ++i) s[i] += t * (float)((int)rp[i * nr * RS - j] + (int)rp[i * nr * RS + j]);
+    }
+}
+
+template <int NRL, int RS>
+__device__ __forceinline__ void fb_pyr_h_layer(const uint8_t* __restrict__ rows, int PAD, const float* __restrict__ taps, int r, int W, int H,
+                                               double inv_x, int ncol, int y0, float* __restrict__ Tz) {
+    constexpr int nr = kPR / NRL, CW = 64 / nr;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, q0 = lane / CW, cl = lane - q0 * CW;
+    for (int c0 = wave * CW; c0 < ncol; c0 += 4 * CW) {
+        const int c = c0 + cl, cc = c < ncol ? c : ncol - 1;
+        int s0, s1; float f;
+        resize_axis(cc >> 1, W, inv_x, &s0, &s1, &f);
+        const int xs = (cc & 1) ? s1 : s0;
+        float s[NRL];
+        fb_pyr_h_cols<NRL, RS>(rows + q0 * RS + PAD + xs, taps, r, s);
+        if (c < ncol) {
+#pragma unroll
+            for (int i = 0; i < NRL; ++i) {
+                const int y = y0 + i * nr + q0;
+                if (y < H) Tz[(size_t)y * ncol + c] = s[i];
             }
-            Tk[c] = s;
         }
     }
+}
+
+template <int RS>
+__global__ __launch_bounds__(256) void fb_pyr_h_kernel(const uint8_t* __restrict__ img0, const uint8_t* __restrict__ img1, int W, int H, int stride,
+                                                       const FbPyr P, int PAD, float* __restrict__ T) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t srows[];      // [kPR][RS] bytes, then the layer's taps
+    const int y0 = blockIdx.x * kPR, z = blockIdx.y, k = P.K - (int)blockIdx.z, r = P.r[k];     // (the long filters' workgroups are dispatched first)
+    float* staps = reinterpret_cast<float*>(srows + kPR * RS);
+    const uint8_t* img = z ? img1 : img0;
+    for (int i = threadIdx.x; i < 2 * r + 1; i += 256) staps[i] = P.taps[P.toff[k] + i];
+    const bool dwords = (stride & 3) == 0 && (reinterpret_cast<uintptr_t>(img) & 3) == 0;
+    const int W4 = dwords ? W / 4 : 0;                                   // columns [0, 4 W4) as dwords, the rest and the margins byte by byte
+    {   // 32 threads per row
+        const int q = threadIdx.x >> 5, l = threadIdx.x & 31;
+        const int y = y0 + q < H ? y0 + q : H - 1;
+        const uint8_t* src = img + (size_t)y * stride;
+        uint8_t* dst = srows + q * RS + PAD;
+        for (int c4 = l; c4 < W4; c4 += 32) *reinterpret_cast<uint32_t*>(dst + 4 * c4) = *reinterpret_cast<const uint32_t*>(src + 4 * c4);
+        const int rest = W - 4 * W4 + 2 * r;                             // columns [4 W4, W) and the margins [-r, 0), [W, W + r)
+        for (int e = l; e < rest; e += 32) {
+            const int x = e < r ? e - r : (e < 2 * r ? W + (e - r) : 4 * W4 + (e - 2 * r));
+            dst[x] = src[reflect101(x, W)];
+        }
+    }
+    __syncthreads();
+    const int ncol = 2 * P.w[k];
+    float* Tz = T + P.t_off[k] + (size_t)z * H * ncol;
+    if (k <= 2) fb_pyr_h_layer<8, RS>(srows, PAD, staps, r, W, H, P.inv_x[k], ncol, y0, Tz);
+    else if (k == 3) fb_pyr_h_layer<4, RS>(srows, PAD, staps, r, W, H, P.inv_x[k], ncol, y0, Tz);
+    else if (k == 4) fb_pyr_h_layer<2, RS>(srows, PAD, staps, r, W, H, P.inv_x[k], ncol, y0, Tz);
+    else fb_pyr_h_layer<1, RS>(srows, PAD, staps, r, W, H, P.inv_x[k], ncol, y0, Tz);
 }
 
 // column filter at the sampled rows + HResizeLinear / VResizeLinear; 1-D grid over (layer, tile), blockIdx.y = image.  The launch is
@@ -181,10 +242,13 @@ __device__ __forceinline__ void fb_pyr_v_short(const float* __restrict__ Tz, int
 }
 
 __global__ __launch_bounds__(256) void fb_pyr_v_kernel(const float* __restrict__ T, int W, int H, const FbPyr P, float* __restrict__ I) {
+    // (dispatch order reversed: the long filters' few workgroups -- each a serial chain of up to 159 taps -- start first and run beside
+    // the bulk of the short ones instead of after them)
+    const int bx = (int)gridDim.x - 1 - (int)blockIdx.x;
     int k = 1;
-    while (k < P.K && (int)blockIdx.x >= P.blk0[k + 1]) ++k;
+    while (k < P.K && bx >= P.blk0[k + 1]) ++k;
     const int w = P.w[k], h = P.h[k], r = P.r[k];
-    const int ncol = 2 * w, z = blockIdx.y, b = (int)blockIdx.x - P.blk0[k];
+    const int ncol = 2 * w, z = blockIdx.y, b = bx - P.blk0[k];
     const float* Tz = T + P.t_off[k] + (size_t)z * H * ncol;
     const float* taps = P.taps + P.toff[k];                      // wave-uniform indices: scalar loads
     if (r <= kShortR) {
@@ -251,25 +315,51 @@ __global__ __launch_bounds__(256) void fb_polyexp_kernel(const FbExp E, const Fb
     float* sI = sh;                               // [HH][HW]
     float* sV = sh + HH * HW;                     // [3][kPY][HW]
     const int x0 = (b % J.tiles_x) * kPX, y0 = (b / J.tiles_x) * kPY;
-    for (int i = threadIdx.x; i < HH * HW; i += 256) {
-        const int hy = i / HW, hx = i - hy * HW;
-        int gx = x0 - n + hx, gy = y0 - n + hy;
-        gx = gx < 0 ? 0 : (gx > w - 1 ? w - 1 : gx);
-        gy = gy < 0 ? 0 : (gy > h - 1 ? h - 1 : gy);
-        float v;
-        if (J.u8) {                               // layer 0: row filter then column filter of the u8 frame, reflect-101, taps (t_s, t_c, t_s)
-            const int xm = reflect101(gx - 1, w), xp = reflect101(gx + 1, w);
-            const uint8_t* r0 = J.u8 + (size_t)gy * J.stride;
-            const uint8_t* rm = J.u8 + (size_t)reflect101(gy - 1, h) * J.stride;
-            const uint8_t* rp = J.u8 + (size_t)reflect101(gy + 1, h) * J.stride;
-            const float h0 = t_c * (float)r0[gx] + t_s * ((float)r0[xm] + (float)r0[xp]);
-            const float hm = t_c * (float)rm[gx] + t_s * ((float)rm[xm] + (float)rm[xp]);
-            const float hp = t_c * (float)rp[gx] + t_s * ((float)rp[xm] + (float)rp[xp]);
-            v = t_c * h0 + t_s * (hm + hp);
+    if (J.u8) {
+        // layer 0: [t_s t_c t_s] row filter then column filter of the u8 frame (reflect-101), evaluated at the CLAMPED pixel of every
+        // tile + halo element (the expansion's border is replicate).  The frame's bytes go to LDS once, as dwords (round 5: nine byte
+        // loads per element from global memory made this launch bound by its memory instructions), then rows, then columns.
+        const int PADX = (n + 4) & ~3, UW = kPX + 2 * PADX, UH = HH + 2;          // U: frame bytes of [UX0, UX0 + UW) x [UY0, UY0 + UH), reflected
+        const int UX0 = x0 - PADX, UY0 = y0 - n - 1;
+        uint8_t* U = reinterpret_cast<uint8_t*>(sI);                                 // (sI itself is written after U's last read)
+        float* Bh = sV;                                                              // [UH][HW] row-filtered values (sV is not in use yet)
+        const bool whole = UX0 >= 0 && UX0 + UW <= w && UY0 >= 0 && UY0 + UH <= h && (J.stride & 3) == 0 &&
+                           (reinterpret_cast<uintptr_t>(J.u8) & 3) == 0;
+        if (whole) {
+            for (int i = threadIdx.x; i < UH * (UW / 4); i += 256) {
+                const int r = i / (UW / 4), c4 = i - r * (UW / 4);
+                reinterpret_cast<uint32_t*>(U)[i] = *reinterpret_cast<const uint32_t*>(J.u8 + (size_t)(UY0 + r) * J.stride + UX0 + 4 * c4);
+            }
         } else {
-            v = J.I[(size_t)gy * w + gx];
+            for (int i = threadIdx.x; i < UH * UW; i += 256) {
+                const int r = i / UW, c = i - r * UW;
+                U[i] = J.u8[(size_t)reflect101(UY0 + r, h) * J.stride + reflect101(UX0 + c, w)];
+            }
         }
-        sI[i] = v;
+        __syncthreads();
+        for (int i = threadIdx.x; i < UH * HW; i += 256) {
+            const int r = i / HW, hx = i - r * HW;
+            int gx = x0 - n + hx;
+            gx = gx < 0 ? 0 : (gx > w - 1 ? w - 1 : gx);
+            const uint8_t* u = U + r * UW + (gx - UX0);
+            Bh[i] = t_c * (float)u[0] + t_s * ((float)u[-1] + (float)u[1]);
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < HH * HW; i += 256) {
+            const int hy = i / HW, hx = i - hy * HW;
+            int gy = y0 - n + hy;
+            gy = gy < 0 ? 0 : (gy > h - 1 ? h - 1 : gy);
+            const float* b = Bh + (gy - UY0) * HW + hx;
+            sI[i] = t_c * b[0] + t_s * (b[-HW] + b[HW]);
+        }
+    } else {
+        for (int i = threadIdx.x; i < HH * HW; i += 256) {
+            const int hy = i / HW, hx = i - hy * HW;
+            int gx = x0 - n + hx, gy = y0 - n + hy;
+            gx = gx < 0 ? 0 : (gx > w - 1 ? w - 1 : gx);
+            gy = gy < 0 ? 0 : (gy > h - 1 ? h - 1 : gy);
+            sI[i] = J.I[(size_t)gy * w + gx];
+        }
     }
     __syncthreads();
     // vertical half (f32).  The oracle clamps ROW INDICES (y - k, y + k) to the image, which the clamped fill above reproduces.
@@ -302,8 +392,10 @@ __global__ __launch_bounds__(256) void fb_polyexp_kernel(const FbExp E, const Fb
         for (int k = 1; k <= n; ++k) {
             const double tg = r0[k] + r0[-k];
             const float gk = P.g[k];
-            b1 += tg * gk;
-            b4 += tg * P.xxg[k];
+            // (tg and the taps are f32 values: their f64 product is exact, so the fused form rounds exactly where the oracle's separate
+            // multiply and add round -- one instruction instead of two on the quarter-rate f64 pipe)
+            b1 = __builtin_fma(tg, (double)gk, b1);
+            b4 = __builtin_fma(tg, (double)P.xxg[k], b4);
             b2 += (r0[k] - r0[-k]) * P.xg[k];
             b3 += (r1[k] + r1[-k]) * gk;
             b6 += (r1[k] - r1[-k]) * P.xg[k];
@@ -648,8 +740,23 @@ int farneback_flow_device(ofps_hip_ctx* ctx, const uint8_t* d_prev, const uint8_
     if (reuse) ctx->fb_cache_hits += 1;
     // ---- pyramid above layer 0: two launches
     if (K >= 1) {
-        hipLaunchKernelGGL(fb_pyr_h_kernel, dim3(H, n_img), dim3(256), (size_t)(W + W / 32 + 1) * sizeof(float), s, reuse ? d_cur : d_prev, d_cur, W, H,
-                           stride, Y, T);
+        // LDS rows: margins of the longest filter (a multiple of 4 bytes, so that the dword copies stay aligned), starts 1 dword (mod 64) apart
+        // (ds_read_u8: 32 banks of 4 bytes, lanes 0-31 and 32-63 apart; row starts 2 dwords (mod 32) apart keep a lane pair's two
+        // bytes clear of the next row's bank when they straddle a dword).  Three row pitches are compiled in (immediate offsets).
+        const int PAD = (Y.r[K] + 3) & ~3;
+        const int need = W + 2 * PAD;
+        const dim3 grid((H + kPR - 1) / kPR, n_img, K);
+        const uint8_t* i0 = reuse ? d_cur : d_prev;
+#define OFPS_FB_PYR_H(RS_) hipLaunchKernelGGL((fb_pyr_h_kernel<RS_>), grid, dim3(256), (size_t)kPR * RS_ + (size_t)(2 * Y.r[K] + 1) * sizeof(float), s, \
+                                              i0, d_cur, W, H, stride, Y, PAD, T)
+        if (need <= kPyrRS0) OFPS_FB_PYR_H(kPyrRS0);
+        else if (need <= kPyrRS1) OFPS_FB_PYR_H(kPyrRS1);
+        else {                                                                        // 135 KB of dynamic LDS: above the 64 KB a launch gets unasked
+            OFPS_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&fb_pyr_h_kernel<kPyrRS2>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                  (int)(kPR * kPyrRS2 + (2 * Y.r[K] + 1) * sizeof(float))));
+            OFPS_FB_PYR_H(kPyrRS2);
+        }
+#undef OFPS_FB_PYR_H
         hipLaunchKernelGGL(fb_pyr_v_kernel, dim3(vblocks, n_img), dim3(256), 0, s, (const float*)T, W, H, Y, I);
     }
     // ---- polynomial expansion of every layer and both images: one launch (layer 0 blurs the u8 frame while it fills its tiles)

@@ -1,7 +1,7 @@
 #!/bin/bash
 # rocprofv3 PMC passes of one 1080p Farneback pair (tools/farneback_time.py), summarised per kernel: gpurun_out/r05/fb_pmc/
 cd /tmp && export TMPDIR=/tmp
-O=$GRAFT_REPO_ROOT/gpurun_out/r05/fb_pmc; rm -rf $O; mkdir -p $O
+O=$GRAFT_REPO_ROOT/gpurun_out/r05x/fb_pmc; rm -rf $O; mkdir -p $O
 CMD="python $GRAFT_REPO_ROOT/tools/farneback_time.py 6"
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY --output-format csv -d $O/p1 -o k -- $CMD > /dev/null 2>&1
 rocprofv3 --pmc SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE --output-format csv -d $O/p2 -o k -- $CMD > /dev/null 2>&1
@@ -9,7 +9,7 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/p3 -o k -- $CMD > /dev/null
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/p4 -o k -- $CMD > /dev/null 2>&1
 python - <<'PY'
 import csv, glob, os, collections
-O = os.environ["GRAFT_REPO_ROOT"] + "/gpurun_out/r05/fb_pmc"
+O = os.environ["GRAFT_REPO_ROOT"] + "/gpurun_out/r05x/fb_pmc"
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(O + "/p*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
