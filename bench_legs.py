@@ -156,6 +156,38 @@ def cfg3_chain_leg(device: int = 0, reps: int = 60) -> dict:
     lk_waits = ctx.lk_wait_timeouts() - waits0
     if lk_waits:
         raise RuntimeError(f"cfg3 leg: {lk_waits} parent-tile waits of the LK pyramid expired inside the timed region")
+    # the two dense-flow DECODERS as a host drives them (cv-decoder's process_frame shape): frames from page-locked memory one by one,
+    # two tickets in flight, cv-decoder's contrast mask + 150 x 84 down-sampling, the frame's records back on the host.  hip_flow keeps
+    # the previous frame's pyramid + polynomial expansion on the device (ofps_hip_flow_cache_hits).
+    fr4 = synth.luma_sequence(4, W, H, max_step=3, seed=11)
+    pins = [ctx.pinned_frame(H, W) for _ in range(4)]
+    for k in range(4):
+        np.copyto(pins[k], fr4[k])
+    outs = [np.zeros((150 * 150, 4), np.float32) for _ in range(2)]
+
+    def stream(nfr, **kw):
+        prev = None
+        for k in range(nfr):
+            t = ctx.lk_push_frame_async(pins[k % 4], contrast_mask=True, **kw)
+            if prev is not None:
+                ctx.lk_frame_wait(prev, outs[k & 1])
+            prev = t
+        ctx.lk_frame_wait(prev, outs[nfr & 1])
+    decoders = {}
+    for name, kw in (("hip_lk", dict(levels=LV, radius=RAD, iters=IT)), ("hip_flow", dict(levels=5, radius=6, iters=3, farneback=True))):
+        ctx.lk_reset()
+        stream(8, **kw)
+        h0 = ctx.flow_cache_hits()
+        with QuietGC():
+            runs = []
+            for _ in range(5):
+                t0 = time.perf_counter()
+                stream(100, **kw)
+                runs.append((time.perf_counter() - t0) / 100 * 1e3)
+        mm = median_min_max(runs)
+        decoders[name] = {"ms_per_frame": mm["median"], "ms_per_frame_min": mm["min"], "ms_per_frame_max": mm["max"], "repeats": mm["repeats"],
+                          "frames_that_reused_the_previous_expansion": ctx.flow_cache_hits() - h0, "frames": 500}
+        ctx.lk_reset()
     ctx.close()
     lk_ms, alm_ms = per["pm3"]["lk_ms"], per["pm3"]["almeida_ms"]
     out = {"what": "BASELINE configs[2]: 1080p pair -> 3-level LK (r=4, 3 steps) -> 2,073,600 per-pixel records -> densify 150x84 "
@@ -188,6 +220,8 @@ def cfg3_chain_leg(device: int = 0, reps: int = 60) -> dict:
            # next M written (80 B each); the last update: M read, flow written (28 B) = 288 B; + 16 B of records per frame pixel, both
            # frames read once
            "farneback_ms": per["pm3"]["farneback_ms"],
+           "decoders_read_ahead": dict(decoders, what="ofps_hip_lk_push_frame_async + ofps_hip_lk_frame_wait, 1080p frames from page-locked memory, two "
+                                                      "tickets in flight, contrast mask + 150 x 84 records to the host; medians of 5 x 100 frames"),
            "roofline_farneback": (lambda fpx, fb: {"bound": "hbm", "unit": "GB/s", "algorithmic_bytes": fb,
                                                    "achieved": round(fb / (per["pm3"]["farneback_ms"] * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
                                                    "frac": round(fb / (per["pm3"]["farneback_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),

@@ -205,7 +205,7 @@ __global__ __launch_bounds__(256) void fb_pyr_h_kernel(const uint8_t* __restrict
     else fb_pyr_h_layer<1, RS>(srows, PAD, staps, r, W, H, P.inv_x[k], ncol, y0, Tz);
 }
 
-// column filter at the sampled rows + HResizeLinear / VResizeLinear; 1-D grid over (layer, tile), blockIdx.y = image.  The launch is
+// column filter at the sampled rows + HResizeLinear / VResizeLinear; 1-D grid over (layer, tile, image).  The launch is
 // bound by round trips, not by arithmetic (138 VALU instructions per wave): short filters (r <= 4: layers 1, 2 -- 97 % of the outputs) take
 // one thread per output with all 4 (2 r + 1) loads issued before the first sum; long filters one thread per column sum (the serial
 // part: up to 159 taps), eight tap pairs' loads in flight at a time, the quad's first lane combining the four sums.
@@ -241,14 +241,15 @@ __device__ __forceinline__ void fb_pyr_v_short(const float* __restrict__ Tz, int
     *out = h0 * b0 + h1 * b1;
 }
 
-__global__ __launch_bounds__(256) void fb_pyr_v_kernel(const float* __restrict__ T, int W, int H, const FbPyr P, float* __restrict__ I) {
+__global__ __launch_bounds__(256) void fb_pyr_v_kernel(const float* __restrict__ T, int W, int H, const FbPyr P, int n_img, float* __restrict__ I) {
     // (dispatch order reversed: the long filters' few workgroups -- each a serial chain of up to 159 taps -- start first and run beside
     // the bulk of the short ones instead of after them)
-    const int bx = (int)gridDim.x - 1 - (int)blockIdx.x;
+    // (1-D grid, the image in the lowest bit: BOTH images' long chains are at the front of the dispatch order)
+    const int bz = (int)gridDim.x - 1 - (int)blockIdx.x, bx = bz / n_img, z = bz - bx * n_img;
     int k = 1;
     while (k < P.K && bx >= P.blk0[k + 1]) ++k;
     const int w = P.w[k], h = P.h[k], r = P.r[k];
-    const int ncol = 2 * w, z = blockIdx.y, b = bx - P.blk0[k];
+    const int ncol = 2 * w, b = bx - P.blk0[k];
     const float* Tz = T + P.t_off[k] + (size_t)z * H * ncol;
     const float* taps = P.taps + P.toff[k];                      // wave-uniform indices: scalar loads
     if (r <= kShortR) {
@@ -276,15 +277,17 @@ __global__ __launch_bounds__(256) void fb_pyr_v_kernel(const float* __restrict__
     const float* p = Tz + (size_t)ys * ncol + c;
     float s = taps[r] * p[0];
     if (ys - r >= 0 && ys + r < H) {
-        int j = 1;
-        for (; j + 7 <= r; j += 8) {
-            float lo[8], hi[8];
+        // up to eight tap pairs' loads in flight (r is uniform: the guards are scalar branches): 39 pairs = five round trips, not four + seven single ones; more in flight costs the bulk its occupancy
+        constexpr int kB = 8;
+        for (int j = 1; j <= r; j += kB) {
+            float lo[kB], hi[kB];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) { lo[q] = p[-(ptrdiff_t)(j + q) * ncol]; hi[q] = p[(ptrdiff_t)(j + q) * ncol]; }
+            for (int q = 0; q < kB; ++q)
+                if (j + q <= r) { lo[q] = p[-(ptrdiff_t)(j + q) * ncol]; hi[q] = p[(ptrdiff_t)(j + q) * ncol]; }
 #pragma unroll
-            for (int q = 0; q < 8; ++q) s += taps[r + j + q] * (lo[q] + hi[q]);
+            for (int q = 0; q < kB; ++q)
+                if (j + q <= r) s += taps[r + j + q] * (lo[q] + hi[q]);
         }
-        for (; j <= r; ++j) s += taps[r + j] * (p[-(ptrdiff_t)j * ncol] + p[(ptrdiff_t)j * ncol]);
     } else {
         for (int j = 1; j <= r; ++j) s += taps[r + j] * (Tz[(size_t)reflect101(ys - j, H) * ncol + c] + Tz[(size_t)reflect101(ys + j, H) * ncol + c]);
     }
@@ -757,7 +760,7 @@ int farneback_flow_device(ofps_hip_ctx* ctx, const uint8_t* d_prev, const uint8_
             OFPS_FB_PYR_H(kPyrRS2);
         }
 #undef OFPS_FB_PYR_H
-        hipLaunchKernelGGL(fb_pyr_v_kernel, dim3(vblocks, n_img), dim3(256), 0, s, (const float*)T, W, H, Y, I);
+        hipLaunchKernelGGL(fb_pyr_v_kernel, dim3(vblocks * n_img), dim3(256), 0, s, (const float*)T, W, H, Y, n_img, I);
     }
     // ---- polynomial expansion of every layer and both images: one launch (layer 0 blurs the u8 frame while it fills its tiles)
     {

@@ -183,3 +183,14 @@ def test_hip_flow_stream_reuses_the_previous_frames_expansion(ctx):
     for r, k in ((r0, 3), (r1, 4), (r2, 5)):
         np.testing.assert_array_equal(r[0].view(np.uint32), want[k].view(np.uint32))
     ctx.lk_reset()
+
+
+@pytest.mark.parametrize("W,H", [(3000, 80), (4400, 80), (2400, 270)])
+def test_farneback_wide_frames_take_the_other_row_pitches(ctx, W, H):
+    """The pyramid's row filter compiles three LDS row pitches (farneback.hip: kPyrRS0 / 1 / 2; the widest needs 135 KB of dynamic LDS):
+    frames wider than 2,300 / 4,350 px go through the second / third, with one, one and three layers above the frame."""
+    fr = synth.luma_sequence(2, W, H, max_step=3, seed=W)
+    f_o = oracle.farneback_flow(fr[0], fr[1])
+    worst, same = _check(ctx.farneback_flow(fr[0], fr[1]), f_o)
+    print(f"{W}x{H}: max |d| {worst:.2e}, bit-identical flow components {same:.6f}")
+    assert same == 1.0

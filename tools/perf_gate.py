@@ -39,6 +39,9 @@ BASELINE_CHECKS = [
     ("LK flow ms, +-16 px content", "cfg3_chain.per_content.pm16.lk_ms", False, None),
     ("Almeida cluster solve ms (2.07 M records)", "cfg3_chain.almeida_ms", False, None),
     ("cfg3 chain ms", "cfg3_chain.chain_ms", False, None),
+    ("Farneback (hip_flow) ms per 1080p pair", "cfg3_chain.farneback_ms", False, None),
+    ("hip_flow decoder, read-ahead ms/frame", "cfg3_chain.decoders_read_ahead.hip_flow.ms_per_frame", False, 0.10),
+    ("hip_lk decoder, read-ahead ms/frame", "cfg3_chain.decoders_read_ahead.hip_lk.ms_per_frame", False, 0.10),
     ("cfg5 p50 ms (LSQ)", "cfg5_stream.latency_ms.p50", False, 0.15),
     ("cfg5 p50 ms (RANSAC)", "cfg5_stream.ransac.latency_ms.p50", False, 0.15),
     ("native read-ahead ms/frame", "end_to_end.read_ahead_native_host.ms_per_frame", False, 0.10),
@@ -76,6 +79,10 @@ def gate(line: dict, base: dict, tol: float):
         add("no generation-2 collection inside the end_to_end loops", (g.get("oldest_generation") or 0) < 2 or g.get("longest_ms", 0) < 5.0, json.dumps(g))
     else:
         add("end_to_end leg present", False, str(e)[:200])
+    fbd = get(line, "cfg3_chain.decoders_read_ahead.hip_flow")
+    if fbd is not None:
+        add("hip_flow stream frames reuse the previous frame's expansion", fbd.get("frames_that_reused_the_previous_expansion") == fbd.get("frames"),
+            f"{fbd.get('frames_that_reused_the_previous_expansion')} of {fbd.get('frames')}")
     for key in ("parity_check", "cfg3_chain.parity_check", "cfg4.parity_check", "cfg5_stream.parity_check", "cfg5_stream.ransac.parity_check"):
         pc = get(line, key)
         add(f"{key}.ok", isinstance(pc, dict) and pc.get("ok") is True, str(pc.get("ok") if isinstance(pc, dict) else pc))
