@@ -39,9 +39,10 @@ python tools/farneback_time.py 30 > $O/farneback_time.json 2>/dev/null
 python tools/kstats.py $O/fb_trace/k_kernel_stats.csv > $O/farneback_kernel_stats.txt 2>&1
 python tools/ktrace_seq.py $O/fb_trace/k_kernel_trace.csv fb_pyr_h > $O/farneback_dispatch_sequence.txt 2>&1
 bash tools/fb_counters.sh > $O/farneback_counters.txt 2>&1
+./tools/ubench_f64 > $O/ubench_f64.txt 2>&1; ./tools/ubench_dpp > $O/ubench_dpp.txt 2>&1
 python tools/accuracy_clips.py --out $O/accuracy_table.txt --json $O/accuracy.json > /dev/null 2> $O/accuracy.err
 python -m pytest tests -q -m gpu 2>&1 | tail -3 > $O/gpu_tests.txt
 # drop the bulky raw traces, keep the csv summaries
 find $O -name "*_kernel_trace.csv" -delete; find $O -name "*agent_info.csv" -delete; find $O -name "*.db" -delete
-rm -rf $O/fb_trace $R/gpurun_out/r05/fb_pmc
+rm -rf $O/fb_trace $R/gpurun_out/r05x/fb_pmc
 du -sh $O
