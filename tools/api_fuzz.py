@@ -38,7 +38,7 @@ def op_lk_flow():
     return same(ctx.lk_flow(frames[g][a], frames[g][b], L, Rr, it), clean.lk_flow(frames[g][a], frames[g][b], L, Rr, it))
 def op_lk_decode():
     g = GEOMS[rng.integers(len(GEOMS))]; a, b = rng.integers(6, size=2)
-    kw = dict(contrast_mask=bool(rng.integers(2)), per_pixel=bool(rng.integers(2)), max_w=int([40, 150][rng.integers(2)]))
+    kw = dict(contrast_mask=bool(rng.integers(2)), per_pixel=bool(rng.integers(2)), max_w=int([40, 150][rng.integers(2)]), farneback=bool(rng.integers(2)))
     r, e = ctx.lk_decode(frames[g][a], frames[g][b], 2, 4, 2, **kw), clean.lk_decode(frames[g][a], frames[g][b], 2, 4, 2, **kw)
     return r[1] == e[1] and same(r[0], e[0])
 def op_lk_stream():
@@ -46,9 +46,13 @@ def op_lk_stream():
     if s["geom"] is None or rng.random() < 0.08:                         # (re)start, maybe with a new geometry, tickets in flight collected first
         for t, _ in s["pending"]: ctx.lk_frame_wait(t)
         s["pending"] = []; ctx.lk_reset(); s["geom"] = GEOMS[rng.integers(len(GEOMS))]; s["k"] = 0; s["pins"] = [ctx.pinned_frame(s["geom"][1], s["geom"][0]) for _ in range(3)]
+        # half of the streams are hip_flow streams (round 5): their frames reuse the previous frame's pyramid + expansion, which every
+        # other Farneback call through this context (op_fb_flow, op_lk_decode) must invalidate
+        s["kw"] = dict(farneback=True) if rng.random() < 0.5 else {}
+        s["par"] = (int(rng.integers(1, 4)), int([2, 4, 6][rng.integers(3)]), 2) if s["kw"] else (2, 4, 2)
     g, k = s["geom"], s["k"]
     np.copyto(s["pins"][k % 3], frames[g][k % 6])
-    t = ctx.lk_push_frame_async(s["pins"][k % 3], 2, 4, 2)
+    t = ctx.lk_push_frame_async(s["pins"][k % 3], *s["par"], **s["kw"])
     s["pending"].append((t, k)); s["k"] += 1
     ok = True
     while len(s["pending"]) > int(rng.integers(1, 3)) - 1 and s["pending"]:      # keep 0 or 1 tickets in flight
@@ -56,9 +60,14 @@ def op_lk_stream():
         r = ctx.lk_frame_wait(t0)
         if k0 == 0: ok &= r is None
         else:
-            e = clean.lk_decode(frames[g][(k0 - 1) % 6], frames[g][k0 % 6], 2, 4, 2)
+            e = clean.lk_decode(frames[g][(k0 - 1) % 6], frames[g][k0 % 6], *s["par"], **s["kw"])
             ok &= r is not None and same(r[0], e[0])
     return ok
+def op_fb_flow():
+    g = GEOMS[rng.integers(len(GEOMS))]; a, b = rng.integers(6, size=2)
+    kw = dict(levels=int(rng.integers(0, 5)), winsize=int([5, 9, 13, 15][rng.integers(4)]), iters=int(rng.integers(1, 4)), poly_n=int([5, 7][rng.integers(2)]),
+              poly_sigma=float([1.1, 1.5][rng.integers(2)]))
+    return same(ctx.farneback_flow(frames[g][a], frames[g][b], **kw), clean.farneback_flow(frames[g][a], frames[g][b], **kw))
 def op_push_frame():
     s = pf_stream
     if s["geom"] is None or rng.random() < 0.08:
@@ -88,7 +97,7 @@ def op_mask():
     g = GEOMS[rng.integers(len(GEOMS))]; a = rng.integers(6)
     return same(ctx.contrast_mask(frames[g][a]), clean.contrast_mask(frames[g][a]))
 
-ops = [op_sad, op_lk_flow, op_lk_decode, op_lk_stream, op_lk_stream, op_push_frame, op_push_frame, op_densify, op_detect, op_almeida, op_mask]
+ops = [op_sad, op_lk_flow, op_lk_decode, op_fb_flow, op_lk_stream, op_lk_stream, op_push_frame, op_push_frame, op_densify, op_detect, op_almeida, op_mask]
 t0 = time.perf_counter()
 hist = {}
 for i in range(OPS):
@@ -96,5 +105,5 @@ for i in range(OPS):
     hist[f.__name__] = hist.get(f.__name__, 0) + 1
     if not f(): bad.append((i, f.__name__))
 print(f"api fuzz: {OPS} calls (seed {SEED}) in {time.perf_counter() - t0:.1f} s, {hist}, mismatches {len(bad)} {bad[:8]}, "
-      f"lk expired waits {ctx.lk_wait_timeouts()}, repeats {ctx.lk_recoveries()}")
+      f"lk expired waits {ctx.lk_wait_timeouts()}, repeats {ctx.lk_recoveries()}, hip_flow frames that reused the previous expansion {ctx.flow_cache_hits()}")
 sys.exit(1 if bad else 0)
