@@ -158,7 +158,8 @@ def cfg3_chain_leg(device: int = 0, reps: int = 60) -> dict:
         raise RuntimeError(f"cfg3 leg: {lk_waits} parent-tile waits of the LK pyramid expired inside the timed region")
     # the two dense-flow DECODERS as a host drives them (cv-decoder's process_frame shape): frames from page-locked memory one by one,
     # two tickets in flight, cv-decoder's contrast mask + 150 x 84 down-sampling, the frame's records back on the host.  hip_flow keeps
-    # the previous frame's pyramid + polynomial expansion on the device (ofps_hip_flow_cache_hits).
+    # the previous frame's pyramid + polynomial expansion on the device (ofps_hip_flow_cache_hits) and starts every pair after the first from
+    # the previous pair's flow, as cv-decoder does (OFPS_HIP_FLOW_USE_PREVIOUS; cv-decoder/src/lib.rs:161-165).
     fr4 = synth.luma_sequence(4, W, H, max_step=3, seed=11)
     pins = [ctx.pinned_frame(H, W) for _ in range(4)]
     for k in range(4):
@@ -174,7 +175,7 @@ def cfg3_chain_leg(device: int = 0, reps: int = 60) -> dict:
             prev = t
         ctx.lk_frame_wait(prev, outs[nfr & 1])
     decoders = {}
-    for name, kw in (("hip_lk", dict(levels=LV, radius=RAD, iters=IT)), ("hip_flow", dict(levels=5, radius=6, iters=3, farneback=True))):
+    for name, kw in (("hip_lk", dict(levels=LV, radius=RAD, iters=IT)), ("hip_flow", dict(levels=5, radius=6, iters=3, farneback=True, use_previous=True))):
         ctx.lk_reset()
         stream(8, **kw)
         h0 = ctx.flow_cache_hits()

@@ -156,6 +156,10 @@ int ofps_hip_contrast_mask_dev(ofps_hip_ctx* ctx, const void* d_gray, int W, int
                                         grid before the flow (:124-133), which is the caller's job here */
 #define OFPS_HIP_FLOW_FARNEBACK   4u /* the flow is Farneback's (ofps_hip_farneback_flow: levels = pyramid levels, winsize = 2 * radius + 1,
                                         iters = iterations, poly_n 7, poly_sigma 1.5) instead of the iterative Lucas-Kanade: "hip_flow" */
+#define OFPS_HIP_FLOW_USE_PREVIOUS 8u /* with OFPS_HIP_FLOW_FARNEBACK, stream forms: the flow of the stream's previous pair is this pair's initial
+                                        flow -- OPTFLOW_USE_INITIAL_FLOW exactly as cv-decoder sets it from its second pair on
+                                        (cv-decoder/src/lib.rs:161-165: `self.flow` persists between process_frame calls).  A stream's first
+                                        pair (and ofps_hip_lk_decode, a pair on its own) starts from zero flow, like cv-decoder's first. */
 /* One Decoder::process_frame of a "hip_lk" plugin (cv-decoder/src/lib.rs:82-294): flow -> per-pixel records
  * [-> contrast mask] -> down-sampled through the densifier to the (max_w, max_h)-capped grid of :98-121 (defaults
  * 150 x 150 -> 150 x 84 at 16:9) -> one record per visited cell in (x, y)-sorted order.  out_entries capacity:

@@ -81,6 +81,7 @@ struct ofps_hip_ctx {
         uint64_t id = 0, gen = 0;
     } fb_cache;
     uint64_t fb_cache_hits = 0;          // (tests: how many calls skipped the first frame's pyramid + expansion)
+    struct FbPrevFlow { bool valid = false; int W = 0, H = 0; uint64_t id = 0, gen = 0; } fb_prev_flow;     // S_FB_FLOW holds the flow of the pair whose second frame has this id
 
     // per-frame pipeline state (pipeline.hip): a ring of three device frame slots (the new frame is uploaded on the copy
     // stream while the previous pair is still being searched), two tickets in flight
@@ -145,9 +146,10 @@ enum ScratchSlot {
     // is nobody else's (round 4: they sat in S_WORK3, which the densifier's per-cell tables also use -- a decode call wiped the counter,
     // and a begin[] value equal to a later launch's epoch would have read as "parent tile done")
     S_LK_FLAGS,
-    S_FB_WORK               // farneback.hip: blur / image / expansion / flow planes of one pair
+    S_FB_WORK,              // farneback.hip: blur / image / expansion / flow planes of one pair
+    S_FB_FLOW               // hip_flow streams with OFPS_HIP_FLOW_USE_PREVIOUS: the last pair's flow (the next pair's initial flow)
 };
-static_assert(S_FB_WORK < ofps_hip_ctx::kNumScratch, "scratch table too small");
+static_assert(S_FB_FLOW < ofps_hip_ctx::kNumScratch, "scratch table too small");
 
 // Page-locked blocks that kernels write directly and the host reads after an event (ticket result blocks, ofps_hip_host_alloc):
 // fine-grained host memory, asked for explicitly.  A/B builds (tools/read_ahead_bisect.sh) override the two constants with -D.

@@ -1829,12 +1829,15 @@ struct LkGrid {                 // what a process_frame returns for this geometr
     int gw = 0, gh = 0;         // the record grid
     bool per_pixel = false, use_mask = false;
     bool farneback = false;     // OFPS_HIP_FLOW_FARNEBACK: the flow is farneback.hip's (the "hip_flow" decoder), not the iterative LK
+    bool use_previous = false;  // OFPS_HIP_FLOW_USE_PREVIOUS: the stream's previous flow is the initial flow (cv-decoder/src/lib.rs:161-165)
     size_t max_records = 0;     // capacity the records need
 };
 
 int lk_grid_of(ofps_hip_ctx* ctx, int W, int H, int max_w, int max_h, unsigned flags, LkGrid* g) {
     g->use_mask = flags & OFPS_HIP_LK_CONTRAST_MASK; g->per_pixel = flags & OFPS_HIP_LK_PER_PIXEL;
     g->farneback = flags & OFPS_HIP_FLOW_FARNEBACK;
+    g->use_previous = flags & OFPS_HIP_FLOW_USE_PREVIOUS;
+    OFPS_REQUIRE(ctx, !g->use_previous || g->farneback, "OFPS_HIP_FLOW_USE_PREVIOUS without OFPS_HIP_FLOW_FARNEBACK (the iterative LK has no initial flow across pairs)");
     // cv-decoder/src/lib.rs:98-121 with aspect_ratio_scale = (1, 1): usize arithmetic
     const size_t cw = (size_t)(max_w < W ? max_w : W), ch = (size_t)(max_h < H ? max_h : H);
     const size_t wb0 = cw, wb1 = cw * (size_t)H / (size_t)W, hb0 = ch * (size_t)W / (size_t)H, hb1 = ch;
@@ -1893,8 +1896,20 @@ int lk_enqueue_frame(ofps_hip_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_
         // cv-decoder's call (cv-decoder/src/lib.rs:188-199): levels = pyramid levels, winsize = 2 * radius + 1, iters = iterations,
         // poly_n 7, poly_sigma 1.5.  No tile waits on another in this flow: nothing to repair, *epoch = 0.  prev_id / cur_id: the
         // stream's frame ids -- the first frame's pyramid + expansion are the previous call's (farneback.hip)
-        rc = ofps::farneback_flow_device(ctx, d_prev, d_cur, W, H, W, levels, 2 * radius + 1, iters, 7, 1.5, nullptr, nullptr, d_ent, prev_id, cur_id);
+        // OFPS_HIP_FLOW_USE_PREVIOUS: the flow of the pair that ended with this pair's first frame is the initial flow, and this pair's flow is
+        // kept for the next one (read by the coarsest layer's first kernel, written by the last kernel of the call: one buffer)
+        float2* d_keep = nullptr;
+        const float2* d_init = nullptr;
+        ofps_hip_ctx::FbPrevFlow& pf = ctx->fb_prev_flow;
+        if (g.use_previous && cur_id != 0) {
+            d_keep = static_cast<float2*>(ofps::scratch(ctx, ofps::S_FB_FLOW, px * sizeof(float2)));
+            if (!d_keep) return OFPS_HIP_ENOMEM;
+            if (pf.valid && pf.id == prev_id && pf.W == W && pf.H == H && pf.gen == ctx->scratch[ofps::S_FB_FLOW].gen) d_init = d_keep;
+        }
+        if (d_keep) pf.valid = false;               // (until this call has enqueued everything; a call that keeps nothing leaves the buffer alone)
+        rc = ofps::farneback_flow_device(ctx, d_prev, d_cur, W, H, W, levels, 2 * radius + 1, iters, 7, 1.5, d_init, d_keep, d_ent, prev_id, cur_id);
         if (rc != OFPS_HIP_OK) return rc;
+        if (d_keep) { pf.valid = true; pf.id = cur_id; pf.W = W; pf.H = H; pf.gen = ctx->scratch[ofps::S_FB_FLOW].gen; }
         *epoch = 0;
     } else {
         rc = ofps::lk_flow_device(ctx, d_prev, d_cur, W, H, W, levels, radius, iters, nullptr, d_ent, nullptr, serial);
@@ -1979,7 +1994,7 @@ int ofps_hip_lk_decode(ofps_hip_ctx* ctx, const uint8_t* prev, const uint8_t* cu
     if (!ctx) return OFPS_HIP_EINVAL;
     OFPS_REQUIRE(ctx, prev && cur && out_entries && n_out, "lk_decode: null host pointer");
     OFPS_REQUIRE(ctx, W >= 1 && H >= 1 && stride >= W && max_w >= 1 && max_h >= 1, "lk_decode: bad geometry");
-    OFPS_REQUIRE(ctx, (flags & ~(unsigned)(OFPS_HIP_LK_CONTRAST_MASK | OFPS_HIP_LK_PER_PIXEL | OFPS_HIP_FLOW_FARNEBACK)) == 0, "lk_decode: unknown flags 0x%x", flags);
+    OFPS_REQUIRE(ctx, (flags & ~(unsigned)(OFPS_HIP_LK_CONTRAST_MASK | OFPS_HIP_LK_PER_PIXEL | OFPS_HIP_FLOW_FARNEBACK | OFPS_HIP_FLOW_USE_PREVIOUS)) == 0, "lk_decode: unknown flags 0x%x", flags);
     OFPS_HIP_TRY(ctx, hipSetDevice(ctx->device));
     LkGrid g;
     int rc = lk_grid_of(ctx, W, H, max_w, max_h, flags, &g);
@@ -2018,7 +2033,7 @@ int ofps_hip_lk_push_frame_async(ofps_hip_ctx* ctx, const uint8_t* frame, int W,
     if (!ctx) return OFPS_HIP_EINVAL;
     OFPS_REQUIRE(ctx, frame && ticket, "lk_push_frame_async: null pointer");
     OFPS_REQUIRE(ctx, W >= 1 && H >= 1 && stride >= W && max_w >= 1 && max_h >= 1, "lk_push_frame_async: bad geometry");
-    OFPS_REQUIRE(ctx, (flags & ~(unsigned)(OFPS_HIP_LK_CONTRAST_MASK | OFPS_HIP_LK_PER_PIXEL | OFPS_HIP_FLOW_FARNEBACK)) == 0, "lk_push_frame_async: unknown flags 0x%x", flags);
+    OFPS_REQUIRE(ctx, (flags & ~(unsigned)(OFPS_HIP_LK_CONTRAST_MASK | OFPS_HIP_LK_PER_PIXEL | OFPS_HIP_FLOW_FARNEBACK | OFPS_HIP_FLOW_USE_PREVIOUS)) == 0, "lk_push_frame_async: unknown flags 0x%x", flags);
     // (a stream's first frame runs no flow: the flow's parameters are refused here, not one frame later)
     OFPS_REQUIRE(ctx, levels >= 1 && levels <= 8 && radius >= 1 && radius <= 15 && iters >= 1 && iters <= 64,
                  "lk_push_frame_async: levels=%d radius=%d iters=%d out of range", levels, radius, iters);

@@ -180,7 +180,7 @@ bool HipLkDecoder::process_frame(MotionVectors& field, std::vector<RGBA>* out_fr
     out_.resize(process_fullres_ ? 4 * std::min(max_w_, w_) * std::min(max_h_, h_) : 4 * w_ * h_);
     size_t n_out = 0;
     const unsigned flags = (contrast_mask_ ? OFPS_HIP_LK_CONTRAST_MASK : 0u) | (process_fullres_ ? 0u : OFPS_HIP_LK_PER_PIXEL) |
-                           (farneback_ ? OFPS_HIP_FLOW_FARNEBACK : 0u);
+                           (farneback_ ? OFPS_HIP_FLOW_FARNEBACK | OFPS_HIP_FLOW_USE_PREVIOUS : 0u);   // cv-decoder/src/lib.rs:161-165: its previous flow is the initial flow
     // the frame uploaded by the previous call is this call's previous frame unless frames were skipped in between:
     // then (and for the first pair) the previous frame goes up first
     int have = 0;

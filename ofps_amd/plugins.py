@@ -170,6 +170,7 @@ class HipFlowDecoder(HipLkDecoder):
     def __init__(self, frames, framerate=None, device: int = 0):
         super().__init__(frames, framerate, device)
         self.levels, self.radius, self.iters = 5, 6, 3
+        self.use_previous_flow = True      # OPTFLOW_USE_INITIAL_FLOW as cv-decoder sets it (the library keeps the flow; a stream restart forgets it)
 
     def process_frame(self, field: list, out_frame=None, skip_frames: int = 0) -> bool:
         for _ in range(skip_frames + 1):
@@ -183,7 +184,8 @@ class HipFlowDecoder(HipLkDecoder):
         if self._prev is None or self._prev.shape != self._cur.shape:
             self._on_device = None
             return False
-        kw = dict(contrast_mask=self.contrast_mask, per_pixel=not self.process_fullres, farneback=True)
+        # cv-decoder/src/lib.rs:161-165: from its second pair on the decoder passes its previous flow as the initial flow
+        kw = dict(contrast_mask=self.contrast_mask, per_pixel=not self.process_fullres, farneback=True, use_previous=self.use_previous_flow)
         if getattr(self, "_on_device", None) is not self._prev:
             self.ctx.lk_reset()
             self.ctx.lk_push_frame(self._prev, self.levels, self.radius, self.iters, self.max_w, self.max_h, **kw)

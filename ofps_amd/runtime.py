@@ -204,9 +204,9 @@ class HipContext:
                 self.free(b)
         return flow
 
-    LK_CONTRAST_MASK, LK_PER_PIXEL, FLOW_FARNEBACK = 1, 2, 4
+    LK_CONTRAST_MASK, LK_PER_PIXEL, FLOW_FARNEBACK, FLOW_USE_PREVIOUS = 1, 2, 4, 8
 
-    def lk_decode(self, prev: np.ndarray, cur: np.ndarray, levels=3, radius=4, iters=3, max_w=150, max_h=150, farneback=False,
+    def lk_decode(self, prev: np.ndarray, cur: np.ndarray, levels=3, radius=4, iters=3, max_w=150, max_h=150, farneback=False, use_previous=False,
                   contrast_mask=False, per_pixel=False):
         """-> (entries[n,4], (grid_w, grid_h)): what a hip_lk Decoder appends per frame (cv-decoder/src/lib.rs:82-294)."""
         prev = np.ascontiguousarray(prev, np.uint8); cur = np.ascontiguousarray(cur, np.uint8)
@@ -214,21 +214,21 @@ class HipContext:
         out = np.zeros((W * H if per_pixel else min(max_w, W) * min(max_h, H), 4), np.float32)
         n = C.c_size_t(0); gw = C.c_int(0); gh = C.c_int(0)
         u8 = C.POINTER(C.c_uint8)
-        flags = (self.LK_CONTRAST_MASK if contrast_mask else 0) | (self.LK_PER_PIXEL if per_pixel else 0) | (self.FLOW_FARNEBACK if farneback else 0)
+        flags = (self.LK_CONTRAST_MASK if contrast_mask else 0) | (self.LK_PER_PIXEL if per_pixel else 0) | (self.FLOW_FARNEBACK if farneback else 0) | (self.FLOW_USE_PREVIOUS if use_previous else 0)
         self._check(self._lib.ofps_hip_lk_decode(self._h, prev.ctypes.data_as(u8), cur.ctypes.data_as(u8), W, H, W, levels, radius,
                                                  iters, max_w, max_h, flags, _fp(out), C.byref(n), C.byref(gw), C.byref(gh)))
         return out[:n.value].copy(), (gw.value, gh.value)
 
 
     def lk_push_frame(self, frame: np.ndarray, levels=3, radius=4, iters=3, max_w=150, max_h=150, contrast_mask=False,
-                      per_pixel=False, farneback=False):
+                      per_pixel=False, farneback=False, use_previous=False):
         """Stream form of lk_decode: the frame is uploaded once and is the next call's previous frame.
         -> None for the first frame of a stream, else (entries[n,4], (grid_w, grid_h))."""
         frame = np.ascontiguousarray(frame, np.uint8)
         H, W = frame.shape
         out = np.zeros((W * H if per_pixel else min(max_w, W) * min(max_h, H), 4), np.float32)
         n = C.c_size_t(0); gw = C.c_int(0); gh = C.c_int(0); have = C.c_int(0)
-        flags = (self.LK_CONTRAST_MASK if contrast_mask else 0) | (self.LK_PER_PIXEL if per_pixel else 0) | (self.FLOW_FARNEBACK if farneback else 0)
+        flags = (self.LK_CONTRAST_MASK if contrast_mask else 0) | (self.LK_PER_PIXEL if per_pixel else 0) | (self.FLOW_FARNEBACK if farneback else 0) | (self.FLOW_USE_PREVIOUS if use_previous else 0)
         self._check(self._lib.ofps_hip_lk_push_frame(self._h, frame.ctypes.data_as(C.POINTER(C.c_uint8)), W, H, W, levels, radius,
                                                      iters, max_w, max_h, flags, _fp(out), C.byref(n), C.byref(gw), C.byref(gh),
                                                      C.byref(have)))
@@ -237,12 +237,12 @@ class HipContext:
         return out[:n.value].copy(), (gw.value, gh.value)
 
     def lk_push_frame_async(self, frame: np.ndarray, levels=3, radius=4, iters=3, max_w=150, max_h=150, contrast_mask=False,
-                            per_pixel=False, farneback=False) -> int:
+                            per_pixel=False, farneback=False, use_previous=False) -> int:
         """Read-ahead form: returns a ticket once the upload, the flow and the output stage are enqueued.  `frame` must be
         C-contiguous u8 and stay alive (ideally page-locked: pinned_frame) until lk_frame_wait(ticket)."""
         assert frame.dtype == np.uint8 and frame.flags["C_CONTIGUOUS"] and frame.ndim == 2
         H, W = frame.shape
-        flags = (self.LK_CONTRAST_MASK if contrast_mask else 0) | (self.LK_PER_PIXEL if per_pixel else 0) | (self.FLOW_FARNEBACK if farneback else 0)
+        flags = (self.LK_CONTRAST_MASK if contrast_mask else 0) | (self.LK_PER_PIXEL if per_pixel else 0) | (self.FLOW_FARNEBACK if farneback else 0) | (self.FLOW_USE_PREVIOUS if use_previous else 0)
         t = C.c_int(0)
         self._check(self._lib.ofps_hip_lk_push_frame_async(self._h, frame.ctypes.data_as(C.POINTER(C.c_uint8)), W, H, W, levels, radius,
                                                            iters, max_w, max_h, flags, C.byref(t)))

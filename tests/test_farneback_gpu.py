@@ -127,14 +127,25 @@ def test_hip_flow_decoder_is_the_lk_decoders_output_stage_on_farnebacks_flow(ctx
     for k in range(1, 4):
         np.testing.assert_array_equal(got[k][0].view(np.uint32), want[k - 1].view(np.uint32))
     ctx.lk_reset()
+    # the plugin mirror does what cv-decoder does (cv-decoder/src/lib.rs:161-165): from the second pair on, the previous flow is the initial flow
     dec = HipFlowDecoder(iter(fr))
     field = []
     assert dec.process_frame(field) is False
+    flow = None
     for k in range(3):
         field = []
         assert dec.process_frame(field) is True
+        flow = oracle.farneback_flow(fr[k], fr[k + 1], init=flow)
+        e_o = oracle.densify_to_entries(oracle.masked_flow_to_entries(flow, oracle.contrast_mask(fr[k + 1])), 150, 84)
+        np.testing.assert_array_equal(np.asarray(field, np.float32).view(np.uint32), e_o.view(np.uint32))
+    dec.use_previous_flow = False                                   # "flags = 0" for every pair
+    dec2 = HipFlowDecoder(iter(fr)); dec2.use_previous_flow = False
+    assert dec2.process_frame([]) is False
+    for k in range(3):
+        field = []
+        assert dec2.process_frame(field) is True
         np.testing.assert_array_equal(np.asarray(field, np.float32).view(np.uint32), want[k].view(np.uint32))
-    dec.ctx.close()
+    dec.ctx.close(); dec2.ctx.close()
 
 
 def test_hip_flow_stream_reuses_the_previous_frames_expansion(ctx):
@@ -194,3 +205,51 @@ def test_farneback_wide_frames_take_the_other_row_pitches(ctx, W, H):
     worst, same = _check(ctx.farneback_flow(fr[0], fr[1]), f_o)
     print(f"{W}x{H}: max |d| {worst:.2e}, bit-identical flow components {same:.6f}")
     assert same == 1.0
+
+
+def test_hip_flow_stream_with_the_previous_flow_as_initial_flow(ctx):
+    """OFPS_HIP_FLOW_USE_PREVIOUS = OPTFLOW_USE_INITIAL_FLOW the way cv-decoder sets it (cv-decoder/src/lib.rs:161-165: its flow matrix
+    persists, so every pair after the first starts from the previous pair's flow): stream form and read-ahead form against the oracle
+    chained through `init`; a restart forgets the flow; a pair call in between does not disturb the stream; the flag without
+    OFPS_HIP_FLOW_FARNEBACK is refused."""
+    fr = synth.luma_sequence(6, 416, 240, max_step=3, seed=5)
+    kw = dict(contrast_mask=True, farneback=True, use_previous=True)
+
+    def chain(frames):
+        flow, out = None, []
+        for a, b in zip(frames[:-1], frames[1:]):
+            flow = oracle.farneback_flow(a, b, init=flow)
+            out.append(oracle.densify_to_entries(oracle.masked_flow_to_entries(flow, oracle.contrast_mask(b)), 150, 86))
+        return out
+    want = chain(fr)
+    assert not np.array_equal(want[1], oracle.densify_to_entries(oracle.masked_flow_to_entries(oracle.farneback_flow(fr[1], fr[2]), oracle.contrast_mask(fr[2])), 150, 86))
+    ctx.lk_reset()
+    assert ctx.lk_push_frame(fr[0], 5, 6, 3, **kw) is None
+    for k in range(1, 4):
+        ent, grid = ctx.lk_push_frame(fr[k], 5, 6, 3, **kw)
+        assert grid == (150, 86)
+        np.testing.assert_array_equal(ent.view(np.uint32), want[k - 1].view(np.uint32))
+        if k == 2:
+            ctx.lk_decode(fr[4], fr[5], 5, 6, 3, contrast_mask=True, farneback=True)       # a pair on its own: zero initial flow, the stream's flow stays
+    # restart: the first pair of the new stream starts from zero again
+    ctx.lk_reset()
+    assert ctx.lk_push_frame(fr[2], 5, 6, 3, **kw) is None
+    np.testing.assert_array_equal(ctx.lk_push_frame(fr[3], 5, 6, 3, **kw)[0].view(np.uint32), chain(fr[2:4])[0].view(np.uint32))
+    # read-ahead form, two tickets in flight
+    ctx.lk_reset()
+    pins = [ctx.pinned_frame(240, 416) for _ in range(6)]
+    for k in range(6):
+        np.copyto(pins[k], fr[k])
+    t = [ctx.lk_push_frame_async(pins[0], 5, 6, 3, **kw), ctx.lk_push_frame_async(pins[1], 5, 6, 3, **kw)]
+    got = []
+    for k in range(2, 6):
+        got.append(ctx.lk_frame_wait(t[k - 2]))
+        t.append(ctx.lk_push_frame_async(pins[k], 5, 6, 3, **kw))
+    got += [ctx.lk_frame_wait(t[4]), ctx.lk_frame_wait(t[5])]
+    assert got[0] is None
+    for k in range(1, 6):
+        np.testing.assert_array_equal(got[k][0].view(np.uint32), want[k - 1].view(np.uint32))
+    ctx.lk_reset()
+    with pytest.raises(Exception):
+        ctx.lk_push_frame(fr[0], 3, 4, 3, contrast_mask=True, use_previous=True)
+    ctx.lk_reset()

@@ -128,8 +128,9 @@ def test_hip_flow_decoder_through_cpp_host(tmp_path):
     info = json.loads(_tool("extract", "hip_flow", f"{raw}?w={W}&h={H}", out))
     frames = list(mvec.read_frames(open(out, "rb")))
     assert info["frames"] == F and len(frames[0]) == 0
+    flow = None
     for k in range(1, F):
-        flow = oracle.farneback_flow(fr[k - 1], fr[k], 5, 13, 3, 7, 1.5)
+        flow = oracle.farneback_flow(fr[k - 1], fr[k], 5, 13, 3, 7, 1.5, init=flow)      # cv-decoder/src/lib.rs:161-165: the previous flow is the initial flow
         rec = oracle.masked_flow_to_entries(flow, oracle.contrast_mask(fr[k]))
         e_o = oracle.densify_to_entries(rec, 150, 84)
         assert 0 < len(e_o) < 150 * 84

@@ -44,24 +44,29 @@ def op_lk_decode():
 def op_lk_stream():
     s = lk_stream
     if s["geom"] is None or rng.random() < 0.08:                         # (re)start, maybe with a new geometry, tickets in flight collected first
-        for t, _ in s["pending"]: ctx.lk_frame_wait(t)
+        for t, *_ in s["pending"]: ctx.lk_frame_wait(t)
         s["pending"] = []; ctx.lk_reset(); s["geom"] = GEOMS[rng.integers(len(GEOMS))]; s["k"] = 0; s["pins"] = [ctx.pinned_frame(s["geom"][1], s["geom"][0]) for _ in range(3)]
         # half of the streams are hip_flow streams (round 5): their frames reuse the previous frame's pyramid + expansion, which every
         # other Farneback call through this context (op_fb_flow, op_lk_decode) must invalidate
         s["kw"] = dict(farneback=True) if rng.random() < 0.5 else {}
         s["par"] = (int(rng.integers(1, 4)), int([2, 4, 6][rng.integers(3)]), 2) if s["kw"] else (2, 4, 2)
+        # half of those chain their flows (OFPS_HIP_FLOW_USE_PREVIOUS = cv-decoder's OPTFLOW_USE_INITIAL_FLOW): the expected records then come
+        # from the same stream run synchronously on the replay context, which does nothing else
+        s["chained"] = bool(s["kw"]) and rng.random() < 0.5
+        if s["chained"]: s["kw"]["use_previous"] = True; s["ctx"].lk_reset()
     g, k = s["geom"], s["k"]
     np.copyto(s["pins"][k % 3], frames[g][k % 6])
     t = ctx.lk_push_frame_async(s["pins"][k % 3], *s["par"], **s["kw"])
-    s["pending"].append((t, k)); s["k"] += 1
+    exp = s["ctx"].lk_push_frame(frames[g][k % 6], *s["par"], **s["kw"]) if s["chained"] else None
+    s["pending"].append((t, k, exp)); s["k"] += 1
     ok = True
     while len(s["pending"]) > int(rng.integers(1, 3)) - 1 and s["pending"]:      # keep 0 or 1 tickets in flight
-        t0, k0 = s["pending"].pop(0)
+        t0, k0, e0 = s["pending"].pop(0)
         r = ctx.lk_frame_wait(t0)
         if k0 == 0: ok &= r is None
         else:
-            e = clean.lk_decode(frames[g][(k0 - 1) % 6], frames[g][k0 % 6], *s["par"], **s["kw"])
-            ok &= r is not None and same(r[0], e[0])
+            e = e0 if s["chained"] else clean.lk_decode(frames[g][(k0 - 1) % 6], frames[g][k0 % 6], *s["par"], **s["kw"])
+            ok &= r is not None and e is not None and same(r[0], e[0])
     return ok
 def op_fb_flow():
     g = GEOMS[rng.integers(len(GEOMS))]; a, b = rng.integers(6, size=2)

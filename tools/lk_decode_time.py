@@ -39,7 +39,7 @@ for mask in (False, True):
     t0 = time.perf_counter(); run(200)
     print(f"lk_push_frame_async + lk_frame_wait 1080p (read-ahead, 2 tickets), contrast_mask={mask}: {(time.perf_counter() - t0) / 200 * 1e3:.3f} ms per frame")
 # hip_flow (OFPS_HIP_FLOW_FARNEBACK, cv-decoder's arguments: levels 5, winsize 13, 3 iterations): pair call / stream form / read-ahead form
-FB = dict(levels=5, radius=6, iters=3, contrast_mask=True, farneback=True)
+FB = dict(levels=5, radius=6, iters=3, contrast_mask=True, farneback=True, use_previous=True)     # cv-decoder's call incl. OPTFLOW_USE_INITIAL_FLOW from the second pair on
 for _ in range(3): ctx.lk_decode(fr[0], fr[1], **FB)
 t0 = time.perf_counter()
 for _ in range(20): ent, grid = ctx.lk_decode(fr[0], fr[1], **FB)
