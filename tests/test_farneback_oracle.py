@@ -74,6 +74,8 @@ def test_committed_vectors_of_the_external_kit_are_this_oracles_output():
     for name in ("camera", "regions"):
         f = oracle.farneback_flow(d[name + "_prev"], d[name + "_cur"])
         np.testing.assert_array_equal(f.view(np.uint32), d[name + "_flow"].view(np.uint32))
+        w = oracle.farneback_flow(d[name + "_prev"], d[name + "_cur"], init=f)          # OPTFLOW_USE_INITIAL_FLOW (cv-decoder/src/lib.rs:161-165)
+        np.testing.assert_array_equal(w.view(np.uint32), d[name + "_flow_warm"].view(np.uint32))
 
 
 def test_initial_flow_and_bad_arguments():

@@ -6,7 +6,7 @@ build's image has no cv2, so the result is not part of the build's own evidence)
 
 data/farneback_pairs.npz holds two seeded 256 x 144 luma pairs (a smooth camera rotation; region-wise integer motion with flow
 discontinuities) and the flow this build's CPU restatement (oracle/farneback_oracle.c, bit-identical to the HIP kernels:
-tests/test_farneback_gpu.py) computes for them.  The script runs cv2.calcOpticalFlowFarneback with the reference's arguments on the
+tests/test_farneback_gpu.py) computes for them, cold and started from that flow (make_farneback_pairs.py made the second set).  The script runs cv2.calcOpticalFlowFarneback with the reference's arguments on the
 same frames and prints how far apart the two flows are.
 
     python opencv_compare.py [data/farneback_pairs.npz]            # needs numpy + opencv-python, nothing from this repository
@@ -34,8 +34,13 @@ def main():
         print(f"{name:8s} {prev.shape[1]}x{prev.shape[0]}  |flow| mean {mag.mean():.3f} px   |cv2 - build| median {q[0]:.2e}  p90 {q[1]:.2e}  p99 {q[2]:.2e}  "
               f"max {q[3]:.2e} px")
         ok = ok and q[0] < 2e-3 and q[2] < 5e-2
-        # the same with the previous flow as a start (OPTFLOW_USE_INITIAL_FLOW, what cv-decoder does from its second frame on) is not
-        # part of the fixture: the build's restatement of that branch (INTER_AREA resize of the flow) is covered against its own oracle only
+        # the same pair started from that flow (OPTFLOW_USE_INITIAL_FLOW, what cv-decoder passes from its second frame on: cv-decoder/src/
+        # lib.rs:161-165): OpenCV area-resizes the flow to the coarsest layer and scales it; both sides start from the BUILD's cold flow
+        if name + "_flow_warm" in d:
+            cvw = cv2.calcOpticalFlowFarneback(prev, cur, ours.copy(), 0.5, 5, 13, 3, 7, 1.5, cv2.OPTFLOW_USE_INITIAL_FLOW)
+            qw = np.percentile(np.linalg.norm(cvw - d[name + "_flow_warm"], axis=2), [50, 90, 99, 100])
+            print(f"{'':8s} with OPTFLOW_USE_INITIAL_FLOW               |cv2 - build| median {qw[0]:.2e}  p90 {qw[1]:.2e}  p99 {qw[2]:.2e}  max {qw[3]:.2e} px")
+            ok = ok and qw[0] < 2e-3 and qw[2] < 5e-2
     print("verdict:", "same algorithm (within the stated bounds)" if ok else "DIFFERENT -- please report the numbers above")
     return 0 if ok else 1
 
