@@ -28,6 +28,15 @@ def test_fused_per_frame_stream_soak_with_other_entry_points_in_between():
     assert r.returncode == 1 and "mismatching frames 23" in r.stdout, r.stdout + r.stderr
 
 
+def test_hip_flow_read_ahead_stream_soak_with_other_stages_in_between():
+    """hip_flow with cv-decoder's flags (previous flow as initial flow) and the kept expansion, restarts, LK / Farneback / SAD / densify calls
+    in between, against the same stream run synchronously on an idle context.  4,000 frames: profiles/r05/flow_soak.txt."""
+    r = _run("flow_soak.py", "700")
+    assert r.returncode == 0 and "mismatching frames 0" in r.stdout, r.stdout + r.stderr
+    r = _run("flow_soak.py", "40", env={"SOAK_NEGATIVE_CONTROL": "1"})                 # the comparison does see a stream that forgets its flow
+    assert r.returncode == 1 and "mismatching frames 38" in r.stdout, r.stdout + r.stderr
+
+
 def test_stateful_api_fuzz_on_one_context():
     """1,500 random entry-point calls on one context, each compared with the same call on an otherwise idle context (state leaking
     from one call into another: scratch slots, flags, tickets, rings).  100,000 calls: profiles/r04/api_fuzz.txt."""
