@@ -464,8 +464,8 @@ __device__ __forceinline__ void fb_matrices(const FbLayer& L, int x, int y, floa
 }
 
 // ---- a layer's first matrices, from the flow the layer starts with: 0 = zero, 2 = the coarser layer's flow resized x 2,
-// 3 = the caller's full-resolution flow averaged over the pixel's footprint and scaled (OPTFLOW_USE_INITIAL_FLOW; coarsest layer only)
-struct FbStart { FbLayer L; int mode; const float2* flow_in; int pw, ph; double inv_x, inv_y; float init_scale; float* M; };
+// 3 = a flow already at this layer's size (the caller's initial flow after fb_area_kernel; coarsest layer only)
+struct FbStart { FbLayer L; int mode; const float2* flow_in; int pw, ph; double inv_x, inv_y; float* M; };
 
 __device__ __forceinline__ float2 fb_start_flow(const FbStart& a, int x, int y) {
     if (a.mode == 2) {
@@ -480,21 +480,65 @@ __device__ __forceinline__ float2 fb_start_flow(const FbStart& a, int x, int y) 
         { const float h0 = p00.y * a0 + p01.y * a1, h1 = p10.y * a0 + p11.y * a1; f.y = (h0 * b0 + h1 * b1) * 2.0f; }
         return f;
     }
-    if (a.mode == 3) {                         // INTER_AREA of the caller's flow (pw x ph) onto this layer, times the layer's scale
-        const double fx = (double)a.pw / a.L.w, fy = (double)a.ph / a.L.h;
-        const double xa = x * fx, xb = (x + 1) * fx, ya = y * fy, yb = (y + 1) * fy;
-        double sx = 0, sy = 0, sw = 0;
-        for (int yy = (int)floor(ya); yy < (int)ceil(yb) && yy < a.ph; ++yy) {
-            const double wy = fmin((double)(yy + 1), yb) - fmax((double)yy, ya);
-            for (int xx = (int)floor(xa); xx < (int)ceil(xb) && xx < a.pw; ++xx) {
-                const double wgt = wy * (fmin((double)(xx + 1), xb) - fmax((double)xx, xa));
-                const float2 v = a.flow_in[(size_t)yy * a.pw + xx];
-                sx += wgt * v.x; sy += wgt * v.y; sw += wgt;
-            }
-        }
-        return make_float2((float)(sx / sw * (double)a.init_scale), (float)(sy / sw * (double)a.init_scale));
-    }
+    if (a.mode == 3) return a.flow_in[(size_t)y * a.L.w + x];      // the caller's flow, already brought to this layer by fb_area_kernel
     return make_float2(0.f, 0.f);
+}
+
+// OPTFLOW_USE_INITIAL_FLOW: INTER_AREA of the caller's flow (pw x ph) onto the coarsest layer (w x h), times the layer's scale, in the
+// order OpenCV's resizeArea_ works in (the oracle's): every source row of a layer pixel's footprint (~2^K x 2^K source pixels) gives its
+// horizontal weighted sums (u, v, weight: f64 chains over the columns), then the rows' sums are accumulated with the row weights.
+// One 64-lane workgroup per layer pixel: the footprint comes into LDS with coalesced loads (rows one float2 apart in pitch, so that
+// lanes walking different rows hit different banks), lane r walks row r, lane 0 the rows' sums.  (Round 5, first form: a thread per
+// layer pixel walking its footprint in global memory, 1,024 loads 256 bytes apart from lane to lane, then one 1,024-term chain: 170 us.)
+struct FbArea { const float2* src; int pw, ph, w, h, max_n; float scale; float2* dst; };
+__global__ __launch_bounds__(64) void fb_area_kernel(const FbArea a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char fb_area_lds[];
+    double* wx = reinterpret_cast<double*>(fb_area_lds);
+    double* wy = wx + a.max_n;
+    double* rsum = wy + a.max_n;                                   // [max_n][3]: a row's sums
+    float2* blk = reinterpret_cast<float2*>(rsum + 3 * a.max_n);   // [ny][nx + 1]
+    const int x = (int)blockIdx.x % a.w, y = (int)blockIdx.x / a.w, lane = threadIdx.x;
+    const double fx = (double)a.pw / a.w, fy = (double)a.ph / a.h;
+    const double xa = x * fx, xb = (x + 1) * fx, ya = y * fy, yb = (y + 1) * fy;
+    const int x_lo = (int)floor(xa), y_lo = (int)floor(ya);
+    int x_hi = (int)ceil(xb), y_hi = (int)ceil(yb);
+    x_hi = x_hi < a.pw ? x_hi : a.pw; y_hi = y_hi < a.ph ? y_hi : a.ph;
+    const int nx = x_hi - x_lo, ny = y_hi - y_lo, pitch = nx + 1;
+    for (int i = lane; i < nx; i += 64) wx[i] = fmin((double)(x_lo + i + 1), xb) - fmax((double)(x_lo + i), xa);
+    for (int i = lane; i < ny; i += 64) wy[i] = fmin((double)(y_lo + i + 1), yb) - fmax((double)(y_lo + i), ya);
+    for (int i0 = 0; i0 < nx * ny; i0 += 64 * 8) {              // eight loads per lane in flight
+        float2 t[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int i = i0 + 64 * q + lane;
+            if (i < nx * ny) { const int r = i / nx; t[q] = a.src[(size_t)(y_lo + r) * a.pw + x_lo + (i - r * nx)]; }
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int i = i0 + 64 * q + lane;
+            if (i < nx * ny) { const int r = i / nx; blk[r * pitch + (i - r * nx)] = t[q]; }
+        }
+    }
+    __syncthreads();
+    for (int r = lane; r < ny; r += 64) {
+        const float2* br = blk + r * pitch;
+        double bx = 0, by = 0, bw = 0;
+        for (int c = 0; c < nx; ++c) {
+            const double wgt = wx[c];
+            const float2 v = br[c];
+            bx += wgt * v.x; by += wgt * v.y; bw += wgt;
+        }
+        rsum[3 * r] = bx; rsum[3 * r + 1] = by; rsum[3 * r + 2] = bw;
+    }
+    __syncthreads();
+    if (lane == 0) {
+        double sx = 0, sy = 0, sw = 0;
+        for (int r = 0; r < ny; ++r) {
+            const double wgt = wy[r];
+            sx += wgt * rsum[3 * r]; sy += wgt * rsum[3 * r + 1]; sw += wgt * rsum[3 * r + 2];
+        }
+        a.dst[(size_t)y * a.w + x] = make_float2((float)(sx / sw * (double)a.scale), (float)(sy / sw * (double)a.scale));
+    }
 }
 
 __global__ __launch_bounds__(256) void fb_start_kernel(const FbStart a) {
@@ -790,8 +834,14 @@ int farneback_flow_device(ofps_hip_ctx* ctx, const uint8_t* d_prev, const uint8_
         FbStart st{};
         st.L = L; st.M = Mb[0];
         if (k == K) {
-            if (d_init) { st.mode = 3; st.flow_in = d_init; st.pw = W; st.ph = H; double sc = 1.0; for (int i = 0; i < k; ++i) sc *= 0.5; st.init_scale = (float)sc; }
-            else st.mode = 0;
+            if (d_init) {
+                double sc = 1.0;
+                for (int i = 0; i < k; ++i) sc *= 0.5;
+                FbArea ar{d_init, W, H, w, h, 0, (float)sc, Fp[1]};
+                ar.max_n = (int)std::ceil(std::max((double)W / w, (double)H / h)) + 2;
+                hipLaunchKernelGGL(fb_area_kernel, dim3(w * h), dim3(64), (size_t)ar.max_n * 5 * sizeof(double) + (size_t)ar.max_n * (ar.max_n + 1) * sizeof(float2), s, ar);
+                st.mode = 3; st.flow_in = Fp[1];
+            } else st.mode = 0;
         } else {
             st.mode = 2; st.flow_in = coarse; st.pw = pw; st.ph = ph;
             st.inv_x = 1.0 / ((double)w / pw); st.inv_y = 1.0 / ((double)h / ph);

@@ -352,7 +352,9 @@ int orc_farneback_flow(const uint8_t* prev, const uint8_t* cur, int W, int H, in
                 else {
                     double scale = 1.0;
                     for (int i = 0; i < k; ++i) scale *= 0.5;
-                    /* INTER_AREA, general ratio: box average over [x/sx, (x+1)/sx) with fractional edge weights */
+                    /* INTER_AREA, general ratio: box average over [x/sx, (x+1)/sx) with fractional edge weights, in the order OpenCV's
+                     * resizeArea_ works in -- every source row's horizontal weighted sum first, the rows' sums accumulated with the row
+                     * weights after -- in f64 with unnormalised weights, divided by the footprint's weight at the end */
                     const double fx = (double)W / w, fy = (double)H / h;
                     for (int y = 0; y < h; ++y)
                         for (int x = 0; x < w; ++x) {
@@ -360,10 +362,12 @@ int orc_farneback_flow(const uint8_t* prev, const uint8_t* cur, int W, int H, in
                             double sx = 0, sy = 0, sw = 0;
                             for (int yy = (int)floor(y0); yy < (int)ceil(y1) && yy < H; ++yy) {
                                 const double wy = fmin(yy + 1, y1) - fmax(yy, y0);
+                                double bx = 0, by = 0, bw = 0;
                                 for (int xx = (int)floor(x0); xx < (int)ceil(x1) && xx < W; ++xx) {
-                                    const double wgt = wy * (fmin(xx + 1, x1) - fmax(xx, x0));
-                                    sx += wgt * init[((size_t)yy * W + xx) * 2]; sy += wgt * init[((size_t)yy * W + xx) * 2 + 1]; sw += wgt;
+                                    const double wx = fmin(xx + 1, x1) - fmax(xx, x0);
+                                    bx += wx * init[((size_t)yy * W + xx) * 2]; by += wx * init[((size_t)yy * W + xx) * 2 + 1]; bw += wx;
                                 }
+                                sx += wy * bx; sy += wy * by; sw += wy * bw;
                             }
                             f[((size_t)y * w + x) * 2] = (float)(sx / sw * scale);
                             f[((size_t)y * w + x) * 2 + 1] = (float)(sy / sw * scale);
