@@ -35,11 +35,12 @@ def get(d, path, default=None):
 BASELINE_CHECKS = [
     ("headline Mvectors/s (cfg2)", "value", True, None),
     ("cfg4 Mvectors/s", "cfg4.Mvectors_per_s", True, None),
-    ("LK flow ms, +-3 px content", "cfg3_chain.per_content.pm3.lk_ms", False, None),
-    ("LK flow ms, +-16 px content", "cfg3_chain.per_content.pm16.lk_ms", False, None),
+    # (the LK launch moves +-4 % from box to box and run to run -- 0.208 / 0.211 / 0.224 ms in round 5's three collections: 10 %)
+    ("LK flow ms, +-3 px content", "cfg3_chain.per_content.pm3.lk_ms", False, 0.10),
+    ("LK flow ms, +-16 px content", "cfg3_chain.per_content.pm16.lk_ms", False, 0.10),
     ("Almeida cluster solve ms (2.07 M records)", "cfg3_chain.almeida_ms", False, None),
-    ("cfg3 chain ms", "cfg3_chain.chain_ms", False, None),
-    ("Farneback (hip_flow) ms per 1080p pair", "cfg3_chain.farneback_ms", False, None),
+    ("cfg3 chain ms", "cfg3_chain.chain_ms", False, 0.10),
+    ("Farneback (hip_flow) ms per 1080p pair", "cfg3_chain.farneback_ms", False, 0.10),
     ("hip_flow decoder, read-ahead ms/frame", "cfg3_chain.decoders_read_ahead.hip_flow.ms_per_frame", False, 0.10),
     ("hip_lk decoder, read-ahead ms/frame", "cfg3_chain.decoders_read_ahead.hip_lk.ms_per_frame", False, 0.10),
     ("cfg5 p50 ms (LSQ)", "cfg5_stream.latency_ms.p50", False, 0.15),
