@@ -377,7 +377,8 @@ __device__ __forceinline__ int raster_first_at_least(int c, int n, float inv_n, 
 
 __global__ __launch_bounds__(256) void raster_cell_sum_kernel(const float4* __restrict__ entries, const uint8_t* __restrict__ mask,
                                                               int W, int H, int w, int h, float2* __restrict__ out_field,
-                                                              uint32_t* __restrict__ cell_begin, uint32_t* __restrict__ cell_end) {
+                                                              uint32_t* __restrict__ cell_begin, uint32_t* __restrict__ cell_end,
+                                                              float4* __restrict__ xmajor = nullptr) {
     __shared__ float2 stage[4][64];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int cell = blockIdx.x * 4 + wave;
@@ -441,6 +442,40 @@ __global__ __launch_bounds__(256) void raster_cell_sum_kernel(const float4* __re
     }
     if (lane < 2) reinterpret_cast<float*>(out_field + cell)[lane] = sum / cnt;   // :304
     if (lane == 0) { cell_begin[cell] = 0; cell_end[cell] = kept; }                // visited <=> end > begin
+    // the same cell in the order the records go out in ((x, y)-sorted: cv-decoder/src/lib.rs:279-291), with its visited flag, for
+    // cells_to_entries_x_kernel: that kernel then reads 16 coalesced bytes per cell instead of three words a row pitch apart
+    if (xmajor && lane < 3) reinterpret_cast<float*>(xmajor + (size_t)cx * h + cy)[lane] = lane < 2 ? sum / cnt : (kept ? 1.0f : 0.0f);
+}
+
+// cells_to_entries_kernel for one item whose cells arrive (x, y)-sorted with their visited flag (raster_cell_sum_kernel's xmajor).  One
+// workgroup per 1,024 cells: it counts the visited cells before its chunk itself (flags of at most 64 K cells: a few loads per thread),
+// so the chunks' records -- usually headed for a page-locked host block -- leave from several CUs at once instead of one.
+__global__ __launch_bounds__(1024) void cells_to_entries_x_kernel(const float4* __restrict__ xmajor, int w, int h, float4* __restrict__ out_entries,
+                                                                  uint32_t* __restrict__ out_count, const uint32_t* __restrict__ aux_src) {
+    __shared__ uint32_t wave_cnt[2][16];
+    const size_t cells = (size_t)w * h;
+    const float nx = 1.0f / (float)w, ny = 1.0f / (float)h;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t c0 = (size_t)blockIdx.x * 1024;
+    uint32_t mine = 0;
+    for (size_t i = threadIdx.x; i < c0; i += 1024) mine += xmajor[i].z != 0.0f ? 1u : 0u;
+    const size_t o = c0 + threadIdx.x;
+    const float4 v = o < cells ? xmajor[o] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool vis = v.z != 0.0f;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) mine += __shfl_xor(mine, d);
+    const unsigned long long bal = __ballot(vis);
+    if (lane == 0) { wave_cnt[0][wave] = mine; wave_cnt[1][wave] = (uint32_t)__popcll(bal); }
+    __syncthreads();
+    uint32_t base = 0, before = 0, total = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { base += wave_cnt[0][k]; const uint32_t c = wave_cnt[1][k]; total += c; before += k < wave ? c : 0u; }
+    if (vis) {
+        const int x = (int)(o / h), y = (int)(o % h);
+        const uint32_t pos = base + before + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+        out_entries[pos] = make_float4(((float)x + 0.5f) * nx, ((float)y + 0.5f) * ny, v.x, v.y);
+    }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) { out_count[0] = base + total; if (aux_src) out_count[1] = *aux_src; }
 }
 
 // test aid: does every record sit where the rectangle walk assumes?  flag[0] counts records whose stored position maps
@@ -692,7 +727,7 @@ int densify_entries_device(ofps_hip_ctx* ctx, const float4* d_entries, size_t n,
 // densify for per-pixel raster producers (see raster_cell_sum_kernel).  d_mask: W*H bytes or nullptr.  Leaves visited
 // tables in S_WORK3 / S_WORK4 like densify_device.
 int densify_raster_device(ofps_hip_ctx* ctx, const float4* d_entries, const uint8_t* d_mask, int W, int H, int w, int h,
-                          float2* d_field, uint32_t** out_begin, uint32_t** out_end) {
+                          float2* d_field, uint32_t** out_begin, uint32_t** out_end, float4* d_xmajor) {
     const size_t cells = (size_t)w * (size_t)h;
     OFPS_REQUIRE(ctx, W >= 1 && H >= 1 && (size_t)W * H < (1ull << 31), "densify_raster: bad frame %dx%d", W, H);
     OFPS_REQUIRE(ctx, w >= 1 && h >= 1 && cells <= 65536, "densify_raster: grid %dx%d unsupported (1..65536 cells)", w, h);
@@ -702,7 +737,7 @@ int densify_raster_device(ofps_hip_ctx* ctx, const float4* d_entries, const uint
     if (out_begin) *out_begin = begin;
     if (out_end) *out_end = end;
     hipLaunchKernelGGL(raster_cell_sum_kernel, dim3((unsigned)((cells + 3) / 4)), dim3(256), 0, ctx->stream, d_entries, d_mask, W, H,
-                       w, h, d_field, begin, end);
+                       w, h, d_field, begin, end, d_xmajor);
     OFPS_HIP_TRY(ctx, hipGetLastError());
     return OFPS_HIP_OK;
 }
@@ -710,10 +745,12 @@ int densify_raster_device(ofps_hip_ctx* ctx, const float4* d_entries, const uint
 int densify_raster_entries_device(ofps_hip_ctx* ctx, const float4* d_entries, const uint8_t* d_mask, int W, int H, int w, int h,
                                   float2* d_field, float4* d_out_entries, uint32_t* d_count, const uint32_t* d_aux) {
     uint32_t *begin = nullptr, *end = nullptr;
-    int rc = densify_raster_device(ctx, d_entries, d_mask, W, H, w, h, d_field, &begin, &end);
+    auto* xmajor = static_cast<float4*>(scratch(ctx, S_XMAJOR, (size_t)w * h * sizeof(float4)));
+    if (!xmajor) return OFPS_HIP_ENOMEM;
+    int rc = densify_raster_device(ctx, d_entries, d_mask, W, H, w, h, d_field, &begin, &end, xmajor);
     if (rc != OFPS_HIP_OK) return rc;
-    hipLaunchKernelGGL(cells_to_entries_kernel, dim3(1), dim3(1024), 0, ctx->stream, d_field, begin, end, w, h, d_out_entries,
-                       d_count, d_aux);
+    hipLaunchKernelGGL(cells_to_entries_x_kernel, dim3((unsigned)(((size_t)w * h + 1023) / 1024)), dim3(1024), 0, ctx->stream, (const float4*)xmajor, w, h,
+                       d_out_entries, d_count, d_aux);
     OFPS_HIP_TRY(ctx, hipGetLastError());
     return OFPS_HIP_OK;
 }
