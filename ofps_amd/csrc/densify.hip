@@ -429,17 +429,19 @@ __global__ __launch_bounds__(256) void raster_cell_sum_kernel(const float4* __re
 #pragma unroll
                     for (int u = 0; u < 8; ++u) v[u] = col[2 * (j + u)];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) { cnt += wgt; sum = v[u] * wgt + sum; }      // :142-146
+                    for (int u = 0; u < 8; ++u) sum = v[u] * wgt + sum;                      // :144-146 (motion * weight + column)
                 }
-                for (; j < m; ++j) {
-                    cnt += wgt;                            // :142-143
-                    sum = col[2 * j] * wgt + sum;          // :144-146 (motion * weight + column)
-                }
+                for (; j < m; ++j) sum = col[2 * j] * wgt + sum;
             }
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         }
     }
+    // :142-143 adds 1.0 to the count per vector, starting from f32::EPSILON (:133-138).  That chain has a closed form: eps + 1 = 1 + 2^-23
+    // exactly; (1 + 2^-23) + 1 is the tie 2 + 2^-23 and rounds to the even 2.0; from there every + 1 is exact -- so the count after k
+    // vectors is eps, 1 + eps, or min(k, 2^24) itself, and the walk carries ONE dependent chain per lane instead of two (it is bound by VALU issue:
+    // two lanes of a wave do the adding)
+    cnt = kept == 0 ? kF32Eps : (kept == 1 ? 1.0f + kF32Eps : (kept >= (1u << 24) ? 16777216.0f : (float)kept));      // (+ 1 stops changing 2^24)
     if (lane < 2) reinterpret_cast<float*>(out_field + cell)[lane] = sum / cnt;   // :304
     if (lane == 0) { cell_begin[cell] = 0; cell_end[cell] = kept; }                // visited <=> end > begin
     // the same cell in the order the records go out in ((x, y)-sorted: cv-decoder/src/lib.rs:279-291), with its visited flag, for
