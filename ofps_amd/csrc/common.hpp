@@ -148,9 +148,10 @@ enum ScratchSlot {
     S_LK_FLAGS,
     S_FB_WORK,              // farneback.hip: blur / image / expansion / flow planes of one pair
     S_FB_FLOW,              // hip_flow streams with OFPS_HIP_FLOW_USE_PREVIOUS: the last pair's flow (the next pair's initial flow)
-    S_XMAJOR                // densify.hip, raster producers: the field + visited flag in (x, y)-sorted cell order (the record order)
+    S_XMAJOR,               // densify.hip, raster producers: the field + visited flag in (x, y)-sorted cell order (the record order)
+    S_LK_MASKS              // dense decoders, stream forms: one contrast mask per ticket in flight (made on the upload's stream, beside the previous pair's flow)
 };
-static_assert(S_XMAJOR < ofps_hip_ctx::kNumScratch, "scratch table too small");
+static_assert(S_LK_MASKS < ofps_hip_ctx::kNumScratch, "scratch table too small");
 
 // Page-locked blocks that kernels write directly and the host reads after an event (ticket result blocks, ofps_hip_host_alloc):
 // fine-grained host memory, asked for explicitly.  A/B builds (tools/read_ahead_bisect.sh) override the two constants with -D.
@@ -184,7 +185,7 @@ int densify_raster_device(ofps_hip_ctx* ctx, const float4* d_entries, const uint
                           float2* d_field, uint32_t** out_begin, uint32_t** out_end, float4* d_xmajor = nullptr);
 int densify_raster_entries_device(ofps_hip_ctx* ctx, const float4* d_entries, const uint8_t* d_mask, int W, int H, int w, int h,
                                   float2* d_field, float4* d_out_entries, uint32_t* d_count, const uint32_t* d_aux = nullptr);
-int contrast_mask_device(ofps_hip_ctx* ctx, const uint8_t* d_gray, int W, int H, int stride, uint8_t* d_mask);
+int contrast_mask_device(ofps_hip_ctx* ctx, const uint8_t* d_gray, int W, int H, int stride, uint8_t* d_mask, hipStream_t st = nullptr);   // st: nullptr = ctx->stream
 int compact_entries_device(ofps_hip_ctx* ctx, const float4* d_in, const uint8_t* d_mask, size_t n, float4* d_out,
                            uint32_t* d_count);
 int detect_device(ofps_hip_ctx* ctx, const float4* d_entries, size_t n, int batch, float min_size, size_t subdivide,

@@ -1884,7 +1884,7 @@ uint32_t lk_block_waits(const void* pinned) {
 // word carries flag word 1 (0 otherwise: nothing to compare).
 int lk_enqueue_frame(ofps_hip_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_cur, int W, int H, int levels, int radius, int iters,
                      const LkGrid& g, float4* rec_dst, uint32_t* cnt_dst, bool serial, uint32_t* epoch, uint64_t prev_id = 0,
-                     uint64_t cur_id = 0) {
+                     uint64_t cur_id = 0, const uint8_t* d_mask_ready = nullptr) {
     const size_t px = (size_t)W * H, cells = g.per_pixel ? 1 : (size_t)g.gw * g.gh;
     auto* d_ent = static_cast<float4*>(ofps::scratch(ctx, ofps::S_ENTRIES, px * sizeof(float4)));
     auto* d_field = static_cast<float2*>(ofps::scratch(ctx, ofps::S_FIELD, cells * sizeof(float2)));
@@ -1917,8 +1917,8 @@ int lk_enqueue_frame(ofps_hip_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_
         d_waits = lk_stale_word(ctx, radius);
         *epoch = d_waits && !serial && !ctx->opt.lk_serial ? ctx->lk_epoch : 0;
     }
-    const uint8_t* d_mask = nullptr;
-    if (g.use_mask) {
+    const uint8_t* d_mask = d_mask_ready;          // (stream forms: made on the upload's stream already, beside the previous pair's flow)
+    if (g.use_mask && !d_mask) {
         auto* m = static_cast<uint8_t*>(ofps::scratch(ctx, ofps::S_MASK, px));
         if (!m) return OFPS_HIP_ENOMEM;
         rc = ofps::contrast_mask_device(ctx, d_cur, W, H, W, m);
@@ -2078,6 +2078,17 @@ int ofps_hip_lk_push_frame_async(ofps_hip_ctx* ctx, const uint8_t* frame, int W,
     hipStream_t up = overlap ? ctx->lk_copy_stream : s;
     OFPS_HIP_TRY(ctx, ofps::upload_rows(d_frames + (size_t)slot * px, W, frame, stride, W, H, up));
     ctx->lk_slot_id[slot] = ++ctx->lk_frame_serial;               // (a new id for whatever is in the slot now, also if the push fails below)
+    // cv-decoder's contrast mask depends on the new frame only: it is made right behind the upload, on the upload's stream -- with
+    // another ticket in flight that is beside that ticket's flow instead of after this one's (one mask buffer per ticket in flight)
+    const uint8_t* d_mask_ready = nullptr;
+    if (g.use_mask && ctx->lk_frames + 1 >= 2) {
+        auto* masks = static_cast<uint8_t*>(ofps::scratch(ctx, ofps::S_LK_MASKS, (size_t)ofps_hip_ctx::kLkTickets * px));
+        if (!masks) return OFPS_HIP_ENOMEM;
+        uint8_t* m = masks + (size_t)(tno % ofps_hip_ctx::kLkTickets) * px;
+        rc = ofps::contrast_mask_device(ctx, d_frames + (size_t)slot * px, W, H, W, m, up);
+        if (rc != OFPS_HIP_OK) return rc;
+        d_mask_ready = m;
+    }
     if (overlap) {
         OFPS_HIP_TRY(ctx, hipEventRecord(t.uploaded, up));
         OFPS_HIP_TRY(ctx, hipStreamWaitEvent(s, t.uploaded, 0));       // everything of this ticket on the compute stream comes after the upload
@@ -2097,7 +2108,7 @@ int ofps_hip_lk_push_frame_async(ofps_hip_ctx* ctx, const uint8_t* frame, int W,
         tp = d_frames + (size_t)prev_slot * px; tc = d_frames + (size_t)slot * px;
         rc = lk_enqueue_frame(ctx, tp, tc, W, H, levels, radius, iters, g,
                               reinterpret_cast<float4*>(static_cast<char*>(mapped) + 16), static_cast<uint32_t*>(mapped), false, &epoch,
-                              ctx->lk_slot_id[prev_slot], ctx->lk_slot_id[slot]);
+                              ctx->lk_slot_id[prev_slot], ctx->lk_slot_id[slot], d_mask_ready);
         if (rc != OFPS_HIP_OK) return rc;
         have_vectors = 1;
     }

@@ -170,9 +170,9 @@ __global__ __launch_bounds__(256) void compact_scatter_kernel(const float4* __re
         if (keep[k]) out[pos++] = in[base + k];
 }
 
-int contrast_mask_device(ofps_hip_ctx* ctx, const uint8_t* d_gray, int W, int H, int stride, uint8_t* d_mask) {
+int contrast_mask_device(ofps_hip_ctx* ctx, const uint8_t* d_gray, int W, int H, int stride, uint8_t* d_mask, hipStream_t st) {
     OFPS_REQUIRE(ctx, W >= 1 && H >= 1 && stride >= W, "contrast_mask: bad geometry W=%d H=%d stride=%d", W, H, stride);
-    hipLaunchKernelGGL(contrast_mask_kernel, dim3((W + MT_W - 1) / MT_W, (H + MT_H - 1) / MT_H), dim3(256), 0, ctx->stream,
+    hipLaunchKernelGGL(contrast_mask_kernel, dim3((W + MT_W - 1) / MT_W, (H + MT_H - 1) / MT_H), dim3(256), 0, st ? st : ctx->stream,
                        d_gray, W, H, stride, d_mask);
     OFPS_HIP_TRY(ctx, hipGetLastError());
     return OFPS_HIP_OK;
