@@ -43,8 +43,9 @@ BASELINE_CHECKS = [
     ("Farneback (hip_flow) ms per 1080p pair", "cfg3_chain.farneback_ms", False, 0.10),
     ("hip_flow decoder, read-ahead ms/frame", "cfg3_chain.decoders_read_ahead.hip_flow.ms_per_frame", False, 0.10),
     ("hip_lk decoder, read-ahead ms/frame", "cfg3_chain.decoders_read_ahead.hip_lk.ms_per_frame", False, 0.10),
-    ("cfg5 p50 ms (LSQ)", "cfg5_stream.latency_ms.p50", False, 0.15),
-    ("cfg5 p50 ms (RANSAC)", "cfg5_stream.ransac.latency_ms.p50", False, 0.15),
+    # (host + loop-back TCP + PCIe: 0.194-0.24 / 0.211-0.244 ms over round 5's collections on different boxes)
+    ("cfg5 p50 ms (LSQ)", "cfg5_stream.latency_ms.p50", False, 0.30),
+    ("cfg5 p50 ms (RANSAC)", "cfg5_stream.ransac.latency_ms.p50", False, 0.30),
     ("native read-ahead ms/frame", "end_to_end.read_ahead_native_host.ms_per_frame", False, 0.10),
 ]
 
