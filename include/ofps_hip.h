@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define OFPS_HIP_API_VERSION 1
+#define OFPS_HIP_API_VERSION 2
 
 enum {
     OFPS_HIP_OK = 0,
@@ -141,6 +141,22 @@ int ofps_hip_lk_spec_revision(void);
  * since had its dependencies).  The counterpart of ofps_hip_almeida_recoveries for the other spin-waiting kernel. */
 int ofps_hip_lk_wait_timeouts(ofps_hip_ctx* ctx, uint64_t* count);
 int ofps_hip_lk_recoveries(ofps_hip_ctx* ctx, uint64_t* count);
+/* ---- cv-decoder's frame front-end (cv-decoder/src/lib.rs:98-135): capped grid, resize(INTER_LINEAR), cvt_color(BGR2GRAY) ----
+ * OpenCV's 8-bit arithmetic restated integer for integer (oracle/frontend_oracle.c names the sources; "parity unpinned": OpenCV is not vendored
+ * by the reference): 11-bit bilinear coefficients with half-pixel centres, the horizontal edge rule, the uchar vertical pass
+ * (((b0*(D0>>4))>>16) + ((b1*(D1>>4))>>16) + 2) >> 2, exact 2 x 2 reductions as the area mean; gray = (B*1868 + G*9617 + R*4899 + 8192) >> 14. */
+enum { OFPS_HIP_FMT_LUMA = 0, OFPS_HIP_FMT_BGR = 1 /* VideoCapture's frames */, OFPS_HIP_FMT_RGBA = 2 /* ofps::RGBA's byte order */, OFPS_HIP_FMT_BGRA = 3 };
+int ofps_hip_frame_channels(int fmt);                                            /* bytes per pixel: 1, 3, 4, 4; 0 = unknown format */
+int ofps_hip_cv_grid(int W, int H, int max_w, int max_h, int* gw, int* gh);      /* :98-121 with aspect_ratio_scale (1, 1) */
+/* resize keeping the channels: src H rows of W pixels of `fmt`, `stride` bytes apart -> dst dh x dw x channels, dense */
+int ofps_hip_resize_linear(ofps_hip_ctx* ctx, const uint8_t* src, int W, int H, int stride, int fmt, uint8_t* dst, int dw, int dh);
+int ofps_hip_resize_linear_dev(ofps_hip_ctx* ctx, const void* d_src, int W, int H, int stride, int fmt, void* d_dst, int dw, int dh);
+/* what cv-decoder's read loop leaves in `self.gray` for one frame: [reduced != 0: resize to the capped grid ->] gray.  out_gray: *out_w x *out_h
+ * dense bytes (capacity W * H is always enough). */
+int ofps_hip_cv_frontend(ofps_hip_ctx* ctx, const uint8_t* frame, int W, int H, int stride, int fmt, int reduced, int max_w, int max_h,
+                         uint8_t* out_gray, int* out_w, int* out_h);
+int ofps_hip_cv_frontend_dev(ofps_hip_ctx* ctx, const void* d_frame, int W, int H, int stride, int fmt, int reduced, int max_w, int max_h,
+                             void* d_out_gray, int* out_w, int* out_h);
 /* cv-decoder's contrast mask (cv-decoder/src/lib.rs:203-237): Sobel(gray, CV_32F, 1, 1, ksize 5) -> threshold(> 20)
  * -> dilate(MORPH_ELLIPSE 11x11); a pixel contributes a record only where the mask is set (:253-257).  Restated
  * from OpenCV's published definitions (oracle/ofps_oracle.c:orc_contrast_mask; "parity unpinned": OpenCV is not
@@ -148,22 +164,35 @@ int ofps_hip_lk_recoveries(ofps_hip_ctx* ctx, uint64_t* count);
 int ofps_hip_contrast_mask(ofps_hip_ctx* ctx, const uint8_t* gray, int W, int H, int stride, uint8_t* out_mask);
 int ofps_hip_contrast_mask_dev(ofps_hip_ctx* ctx, const void* d_gray, int W, int H, int stride, void* d_out_mask);
 
-/* ofps_hip_lk_decode flags */
+/* ofps_hip_lk_decode / _lk_push_frame / _lk_push_frame_async flags */
 #define OFPS_HIP_LK_CONTRAST_MASK 1u /* drop records of pixels outside the contrast mask of `cur` (the reference's
                                         Farneback path always masks, :203-237,253-257) */
-#define OFPS_HIP_LK_PER_PIXEL     2u /* "Process Fullres" = false: one record per (unmasked) pixel in raster order,
-                                        no down-sampling (:274-276); the reference resizes its frames to the capped
-                                        grid before the flow (:124-133), which is the caller's job here */
+#define OFPS_HIP_LK_FULLRES_RECORDS 2u /* an output form of this build, NOT a cv-decoder mode: one record per (unmasked) pixel of the
+                                        full-resolution flow in raster order, no down-sampling -- the 2.07 M records of BASELINE
+                                        configs[2] that feed ofps_hip_densify_raster_dev / ofps_hip_almeida_dev directly
+                                        (API version 1 called this bit OFPS_HIP_LK_PER_PIXEL and mislabelled it "Process Fullres = false") */
 #define OFPS_HIP_FLOW_FARNEBACK   4u /* the flow is Farneback's (ofps_hip_farneback_flow: levels = pyramid levels, winsize = 2 * radius + 1,
                                         iters = iterations, poly_n 7, poly_sigma 1.5) instead of the iterative Lucas-Kanade: "hip_flow" */
 #define OFPS_HIP_FLOW_USE_PREVIOUS 8u /* with OFPS_HIP_FLOW_FARNEBACK, stream forms: the flow of the stream's previous pair is this pair's initial
                                         flow -- OPTFLOW_USE_INITIAL_FLOW exactly as cv-decoder sets it from its second pair on
                                         (cv-decoder/src/lib.rs:161-165: `self.flow` persists between process_frame calls).  A stream's first
                                         pair (and ofps_hip_lk_decode, a pair on its own) starts from zero flow, like cv-decoder's first. */
+#define OFPS_HIP_LK_REDUCED      16u /* cv-decoder's "Process Fullres" = false (cv-decoder/src/lib.rs:124-133,274-276): every frame is resized
+                                        (imgproc::resize, INTER_LINEAR) to the (max_w, max_h)-capped grid of :98-121 BEFORE the colour
+                                        conversion, mask and flow -- which therefore run on the ~150 x 84 frame -- and every unmasked
+                                        pixel of that REDUCED frame is one record at ((x+.5)/gw, (y+.5)/gh) in raster order; no densifier.
+                                        Excludes OFPS_HIP_LK_FULLRES_RECORDS. */
+/* The frames' pixel format, bits 8-9 of `flags` (one of the OFPS_HIP_FMT_* values below shifted left by 8; 0 = 8-bit luma, this build's
+ * raw-stream input).  With a colour format `stride` is the row pitch in BYTES (>= W * channels) and every frame goes through
+ * cvt_color(.., COLOR_BGR2GRAY)'s integer formula (cv-decoder/src/lib.rs:135) behind its upload -- after the resize when
+ * OFPS_HIP_LK_REDUCED is set, as in the reference. */
+#define OFPS_HIP_FRAME_FORMAT(fmt) ((unsigned)(fmt) << 8)
+#define OFPS_HIP_FRAME_FORMAT_MASK 0x300u
 /* One Decoder::process_frame of a "hip_lk" plugin (cv-decoder/src/lib.rs:82-294): flow -> per-pixel records
  * [-> contrast mask] -> down-sampled through the densifier to the (max_w, max_h)-capped grid of :98-121 (defaults
  * 150 x 150 -> 150 x 84 at 16:9) -> one record per visited cell in (x, y)-sorted order.  out_entries capacity:
- * 4 * min(max_w,W) * min(max_h,H) floats (4 * W * H with OFPS_HIP_LK_PER_PIXEL).  out_w/out_h: the record grid. */
+ * 4 * min(max_w,W) * min(max_h,H) floats (4 * W * H with OFPS_HIP_LK_FULLRES_RECORDS).  out_w/out_h: the record grid (with
+ * OFPS_HIP_LK_REDUCED also the size of the frames the flow ran on). */
 int ofps_hip_lk_decode(ofps_hip_ctx* ctx, const uint8_t* prev, const uint8_t* cur, int W, int H, int stride,
                        int levels, int radius, int iters, int max_w, int max_h, unsigned flags,
                        float* out_entries, size_t* n_out, int* out_w, int* out_h);
@@ -187,7 +216,10 @@ int ofps_hip_lk_push_frame_async(ofps_hip_ctx* ctx, const uint8_t* frame, int W,
                                  int levels, int radius, int iters, int max_w, int max_h, unsigned flags, int* ticket);
 int ofps_hip_lk_frame_wait(ofps_hip_ctx* ctx, int ticket, float* out_entries, size_t* n_out, int* out_w, int* out_h,
                            int* have_vectors);
-int ofps_hip_lk_reset(ofps_hip_ctx* ctx);                  /* waits for tickets in flight; the next frame starts a new stream */
+int ofps_hip_lk_reset(ofps_hip_ctx* ctx);                  /* waits for tickets in flight; the next frame starts a new stream (zero initial flow) */
+/* The same, but the stream's last flow stays the next pair's initial flow (OFPS_HIP_FLOW_USE_PREVIOUS): what a decoder calls when it skipped
+ * frames and pushes the pair's first frame again -- cv-decoder's `self.flow` persists across skipped reads (cv-decoder/src/lib.rs:92-142,161-165). */
+int ofps_hip_lk_rewind(ofps_hip_ctx* ctx);
 int ofps_hip_lk_flow_dev(ofps_hip_ctx* ctx, const void* d_prev, const void* d_cur, int W, int H, int stride,
                          int levels, int radius, int iters, void* d_out_flow, void* d_out_entries);
 /* The same with a starting flow for the COARSEST pyramid level (d_init_flow: 2 f32 per pixel of that level, whose size is

@@ -50,6 +50,12 @@ PROTOTYPES = {
     "ofps_hip_lk_wait_timeouts": (C.c_int, [_ctx, C.POINTER(C.c_uint64)]),
     "ofps_hip_lk_recoveries": (C.c_int, [_ctx, C.POINTER(C.c_uint64)]),
     "ofps_hip_flow_cache_hits": (C.c_int, [_ctx, C.POINTER(C.c_uint64)]),
+    "ofps_hip_frame_channels": (C.c_int, [C.c_int]),
+    "ofps_hip_cv_grid": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "ofps_hip_resize_linear": (C.c_int, [_ctx, _u8p, C.c_int, C.c_int, C.c_int, C.c_int, _u8p, C.c_int, C.c_int]),
+    "ofps_hip_resize_linear_dev": (C.c_int, [_ctx, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_int, C.c_int]),
+    "ofps_hip_cv_frontend": (C.c_int, [_ctx, _u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _u8p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "ofps_hip_cv_frontend_dev": (C.c_int, [_ctx, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "ofps_hip_contrast_mask": (C.c_int, [_ctx, _u8p, C.c_int, C.c_int, C.c_int, _u8p]),
     "ofps_hip_contrast_mask_dev": (C.c_int, [_ctx, _vp, C.c_int, C.c_int, C.c_int, _vp]),
     "ofps_hip_lk_decode": (C.c_int, [_ctx, _u8p, _u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
@@ -60,6 +66,7 @@ PROTOTYPES = {
                                                C.c_uint, C.POINTER(C.c_int)]),
     "ofps_hip_lk_frame_wait": (C.c_int, [_ctx, C.c_int, _f32p, _szp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "ofps_hip_lk_reset": (C.c_int, [_ctx]),
+    "ofps_hip_lk_rewind": (C.c_int, [_ctx]),
     "ofps_hip_lk_flow_dev": (C.c_int, [_ctx, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp]),
     "ofps_hip_lk_flow_init_dev": (C.c_int, [_ctx, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp]),
     "ofps_hip_densify": (C.c_int, [_ctx, _f32p, C.c_size_t, C.c_int, C.c_int, _f32p, _u32p]),

@@ -41,7 +41,8 @@ struct ofps_hip_ctx {
     } opt;
 
     // hip_lk stream state (lk.hip: ofps_hip_lk_push_frame): frame k of the stream lives in slot k % 2 of S_FRAMES
-    int lk_w = 0, lk_h = 0;
+    int lk_w = 0, lk_h = 0;              // the arriving frames' size
+    int lk_fw = 0, lk_fh = 0, lk_fmt = 0; // the size of the frames in the ring (reduced with OFPS_HIP_LK_REDUCED) and the arriving frames' format
     long lk_frames = 0;
     uint64_t lk_frames_gen = 0;          // generation of the S_LK_FRAMES allocation the count refers to
     uint32_t lk_epoch = 0;               // lk_levels_kernel: tag of the last launch in the tile flags (S_LK_FLAGS)
@@ -65,7 +66,7 @@ struct ofps_hip_ctx {
         // what the ticket computed, for the repeat after an expired parent-tile wait (lk.hip: ofps_hip_lk_frame_wait)
         uint32_t epoch = 0;              // the flow launch's epoch (0: nothing to compare the block's second word with)
         const uint8_t* d_prev = nullptr; const uint8_t* d_cur = nullptr;
-        int W = 0, H = 0, levels = 0, radius = 0, iters = 0, max_w = 0, max_h = 0;
+        int W = 0, H = 0, stride = 0, levels = 0, radius = 0, iters = 0, max_w = 0, max_h = 0;
         unsigned flags = 0;
     } lk_ticket[kLkTickets];
     long lk_next_ticket = 0;
@@ -149,9 +150,10 @@ enum ScratchSlot {
     S_FB_WORK,              // farneback.hip: blur / image / expansion / flow planes of one pair
     S_FB_FLOW,              // hip_flow streams with OFPS_HIP_FLOW_USE_PREVIOUS: the last pair's flow (the next pair's initial flow)
     S_XMAJOR,               // densify.hip, raster producers: the field + visited flag in (x, y)-sorted cell order (the record order)
-    S_LK_MASKS              // dense decoders, stream forms: one contrast mask per ticket in flight (made on the upload's stream, beside the previous pair's flow)
+    S_LK_MASKS,             // dense decoders, stream forms: one contrast mask per ticket in flight (made on the upload's stream, beside the previous pair's flow)
+    S_FE_RAW                // frontend.hip: the frames as they arrive (colour and / or full size) when the decoder resizes / converts them: one per ticket in flight
 };
-static_assert(S_LK_MASKS < ofps_hip_ctx::kNumScratch, "scratch table too small");
+static_assert(S_FE_RAW < ofps_hip_ctx::kNumScratch, "scratch table too small");
 
 // Page-locked blocks that kernels write directly and the host reads after an event (ticket result blocks, ofps_hip_host_alloc):
 // fine-grained host memory, asked for explicitly.  A/B builds (tools/read_ahead_bisect.sh) override the two constants with -D.
@@ -185,6 +187,11 @@ int densify_raster_device(ofps_hip_ctx* ctx, const float4* d_entries, const uint
                           float2* d_field, uint32_t** out_begin, uint32_t** out_end, float4* d_xmajor = nullptr);
 int densify_raster_entries_device(ofps_hip_ctx* ctx, const float4* d_entries, const uint8_t* d_mask, int W, int H, int w, int h,
                                   float2* d_field, float4* d_out_entries, uint32_t* d_count, const uint32_t* d_aux = nullptr);
+// frontend.hip: cv-decoder's capped grid (cv-decoder/src/lib.rs:98-121) and its per-frame [resize ->] gray step (:124-135)
+int frame_format_channels(int fmt);
+void cv_grid(int W, int H, int max_w, int max_h, int* gw, int* gh);
+int frontend_device(ofps_hip_ctx* ctx, const uint8_t* d_src, int W, int H, int stride, int fmt, bool to_gray, uint8_t* d_dst, int dw, int dh,
+                    hipStream_t st = nullptr);
 int contrast_mask_device(ofps_hip_ctx* ctx, const uint8_t* d_gray, int W, int H, int stride, uint8_t* d_mask, hipStream_t st = nullptr);   // st: nullptr = ctx->stream
 int compact_entries_device(ofps_hip_ctx* ctx, const float4* d_in, const uint8_t* d_mask, size_t n, float4* d_out,
                            uint32_t* d_count);
@@ -193,6 +200,7 @@ int detect_device(ofps_hip_ctx* ctx, const float4* d_entries, size_t n, int batc
 int farneback_flow_device(ofps_hip_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_cur, int W, int H, int stride, int levels, int winsize,
                           int iters, int poly_n, double poly_sigma, const float2* d_init, float2* d_flow, float4* d_entries,
                           uint64_t prev_id = 0, uint64_t cur_id = 0);     // ids != 0: frames of a stream (ofps_hip_ctx::fb_cache)
+int farneback_check_params(ofps_hip_ctx* ctx, int W, int H, int levels, int winsize, int poly_n);       // what farneback_flow_device would refuse, without running it
 int lk_check_dev_calls(ofps_hip_ctx* ctx);          // lk.hip: did a device-pointer LK launch since the last look have an expired wait?
 int almeida_device(ofps_hip_ctx* ctx, const float4* d_entries, size_t n, int batch, float aspect, float fov_y_deg,
                    int use_ransac, size_t num_iters, float inlier_deg, size_t num_samples, uint64_t seed, float4* d_quat);

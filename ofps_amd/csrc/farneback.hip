@@ -27,7 +27,7 @@
 
 namespace {
 
-constexpr int kMaxBlurTaps = 128;       // 2 r + 1 <= 79 for six layers; up to nine layers (r = 639) would not fit: refused
+constexpr int kMaxBlurTaps = 160;       // 2 r + 1 <= 159 for the six layers above the frame (k = 6: sigma 31.5); deeper pyramids are refused
 constexpr int kMaxPolyN = 15;
 
 struct FbBlur {                         // Gaussian taps of one layer (getGaussianKernel(ksize, sigma, CV_32F))
@@ -723,19 +723,42 @@ int farneback_layers(int W, int H, int levels) {
 
 // d_prev / d_cur: u8 luma on the device (row pitch `stride`).  d_init: nullptr or W x H float2 (OPTFLOW_USE_INITIAL_FLOW).  d_flow (W x H
 // float2) and / or d_entries (W x H float4 records) receive the result.  Everything is enqueued on ctx->stream.
+// Everything farneback_flow_device refuses for a geometry / parameter set, without touching the device: the stream forms call it when a
+// stream's FIRST frame arrives (no flow runs yet), so that a stream never accepts a frame and fails the next.
+int farneback_check_params(ofps_hip_ctx* ctx, int W, int H, int levels, int winsize, int poly_n) {
+    OFPS_REQUIRE(ctx, W >= 1 && H >= 1, "farneback: bad geometry W=%d H=%d", W, H);
+    OFPS_REQUIRE(ctx, levels >= 0 && levels <= 16 && winsize >= 1 && (winsize & 1) && poly_n >= 1,
+                 "farneback: levels=%d winsize=%d poly_n=%d out of range", levels, winsize, poly_n);
+    if (winsize / 2 > kMaxM || poly_n > kMaxPolyN)
+        return set_error(ctx, OFPS_HIP_EUNSUPPORTED, "farneback: winsize %d > %d or poly_n %d > %d has no kernel", winsize, 2 * kMaxM + 1, poly_n, kMaxPolyN);
+    const int K = farneback_layers(W, H, levels);
+    if (K >= kMaxLayers || W > 16384)
+        return set_error(ctx, OFPS_HIP_EUNSUPPORTED, "farneback: %d pyramid layers above the frame (max %d) or width %d > 16384 has no kernel", K, kMaxLayers - 1, W);
+    int ntaps = 0;
+    for (int k = 0; k <= K; ++k) {
+        double scale = 1.0;
+        for (int i = 0; i < k; ++i) scale *= 0.5;
+        FbBlur blur;
+        if (!make_blur(k, &blur) || ntaps + 2 * blur.r + 1 > kMaxTaps) return set_error(ctx, OFPS_HIP_EUNSUPPORTED, "farneback: layer %d needs too many blur taps", k);
+        ntaps += 2 * blur.r + 1;
+        if (k >= 1 && round_half_even(W * scale) == W && round_half_even(H * scale) == H)
+            return set_error(ctx, OFPS_HIP_EUNSUPPORTED, "farneback: degenerate layer %d", k);
+    }
+    return OFPS_HIP_OK;
+}
+
 int farneback_flow_device(ofps_hip_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_cur, int W, int H, int stride, int levels, int winsize,
                           int iters, int poly_n, double poly_sigma, const float2* d_init, float2* d_flow, float4* d_entries,
                           uint64_t prev_id, uint64_t cur_id) {
     OFPS_REQUIRE(ctx, W >= 1 && H >= 1 && stride >= W, "farneback: bad geometry W=%d H=%d stride=%d", W, H, stride);
-    OFPS_REQUIRE(ctx, levels >= 0 && levels <= 16 && iters >= 1 && iters <= 64 && winsize >= 1 && (winsize & 1) && poly_n >= 1,
-                 "farneback: levels=%d winsize=%d iters=%d poly_n=%d out of range", levels, winsize, iters, poly_n);
-    if (winsize / 2 > kMaxM || poly_n > kMaxPolyN)
-        return set_error(ctx, OFPS_HIP_EUNSUPPORTED, "farneback: winsize %d > %d or poly_n %d > %d has no kernel", winsize, 2 * kMaxM + 1, poly_n, kMaxPolyN);
+    OFPS_REQUIRE(ctx, iters >= 1 && iters <= 64, "farneback: iters=%d out of range", iters);
+    {
+        const int rc_params = farneback_check_params(ctx, W, H, levels, winsize, poly_n);
+        if (rc_params != OFPS_HIP_OK) return rc_params;
+    }
     OFPS_REQUIRE(ctx, d_flow || d_entries, "farneback: no output");
     hipStream_t s = ctx->stream;
     const int K = farneback_layers(W, H, levels);
-    if (K >= kMaxLayers || W > 16384)
-        return set_error(ctx, OFPS_HIP_EUNSUPPORTED, "farneback: %d pyramid layers above the frame (max %d) or width %d > 16384 has no kernel", K, kMaxLayers - 1, W);
     FbPoly P;
     make_poly(poly_n, poly_sigma, &P);
     // ---- geometry of the layers and the workspace

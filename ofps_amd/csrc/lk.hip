@@ -1827,26 +1827,65 @@ namespace {
 
 struct LkGrid {                 // what a process_frame returns for this geometry / these flags
     int gw = 0, gh = 0;         // the record grid
-    bool per_pixel = false, use_mask = false;
+    int fw = 0, fh = 0;         // the frames the mask and the flow run on: W x H, or the record grid itself with OFPS_HIP_LK_REDUCED
+    bool per_pixel = false;     // one record per (unmasked) pixel of the fw x fh frames (OFPS_HIP_LK_FULLRES_RECORDS, OFPS_HIP_LK_REDUCED)
+    bool use_mask = false;
     bool farneback = false;     // OFPS_HIP_FLOW_FARNEBACK: the flow is farneback.hip's (the "hip_flow" decoder), not the iterative LK
     bool use_previous = false;  // OFPS_HIP_FLOW_USE_PREVIOUS: the stream's previous flow is the initial flow (cv-decoder/src/lib.rs:161-165)
+    bool reduced = false;       // OFPS_HIP_LK_REDUCED: cv-decoder's "Process Fullres" = false (:124-133,274-276)
+    int fmt = OFPS_HIP_FMT_LUMA, cn = 1;      // the arriving frames' pixel format (bits 8-9 of the flags)
+    bool frontend = false;      // the arriving frames are resized and / or converted behind their upload (frontend.hip)
+    size_t raw_row = 0;         // bytes per row of the staged arriving frame (W * cn rounded up to 4)
     size_t max_records = 0;     // capacity the records need
 };
 
-int lk_grid_of(ofps_hip_ctx* ctx, int W, int H, int max_w, int max_h, unsigned flags, LkGrid* g) {
-    g->use_mask = flags & OFPS_HIP_LK_CONTRAST_MASK; g->per_pixel = flags & OFPS_HIP_LK_PER_PIXEL;
+constexpr unsigned kLkFlagBits = OFPS_HIP_LK_CONTRAST_MASK | OFPS_HIP_LK_FULLRES_RECORDS | OFPS_HIP_FLOW_FARNEBACK | OFPS_HIP_FLOW_USE_PREVIOUS |
+                                 OFPS_HIP_LK_REDUCED | OFPS_HIP_FRAME_FORMAT_MASK;
+
+int lk_grid_of(ofps_hip_ctx* ctx, int W, int H, int stride, int max_w, int max_h, unsigned flags, LkGrid* g) {
+    g->use_mask = flags & OFPS_HIP_LK_CONTRAST_MASK;
     g->farneback = flags & OFPS_HIP_FLOW_FARNEBACK;
     g->use_previous = flags & OFPS_HIP_FLOW_USE_PREVIOUS;
+    g->reduced = flags & OFPS_HIP_LK_REDUCED;
+    const bool fullres_records = flags & OFPS_HIP_LK_FULLRES_RECORDS;
+    g->fmt = (int)((flags & OFPS_HIP_FRAME_FORMAT_MASK) >> 8);
+    g->cn = ofps::frame_format_channels(g->fmt);
     OFPS_REQUIRE(ctx, !g->use_previous || g->farneback, "OFPS_HIP_FLOW_USE_PREVIOUS without OFPS_HIP_FLOW_FARNEBACK (the iterative LK has no initial flow across pairs)");
-    // cv-decoder/src/lib.rs:98-121 with aspect_ratio_scale = (1, 1): usize arithmetic
-    const size_t cw = (size_t)(max_w < W ? max_w : W), ch = (size_t)(max_h < H ? max_h : H);
-    const size_t wb0 = cw, wb1 = cw * (size_t)H / (size_t)W, hb0 = ch * (size_t)W / (size_t)H, hb1 = ch;
-    const int gw = (int)(wb0 < hb0 ? wb0 : hb0), gh = (int)(wb0 < hb0 ? wb1 : hb1);
-    if (!g->per_pixel)
-        OFPS_REQUIRE(ctx, gw >= 1 && gh >= 1 && (size_t)gw * gh <= 65536, "lk_decode: field %dx%d unsupported", gw, gh);
-    g->gw = g->per_pixel ? W : gw; g->gh = g->per_pixel ? H : gh;
-    g->max_records = g->per_pixel ? (size_t)W * H : (size_t)gw * gh;
+    OFPS_REQUIRE(ctx, !(g->reduced && fullres_records), "OFPS_HIP_LK_REDUCED with OFPS_HIP_LK_FULLRES_RECORDS: the reduced mode has no full-resolution flow");
+    OFPS_REQUIRE(ctx, stride >= W * g->cn, "dense decoder: stride %d < %d bytes per row (%d x %d channels)", stride, W * g->cn, W, g->cn);
+    int gw = 0, gh = 0;
+    ofps::cv_grid(W, H, max_w, max_h, &gw, &gh);            // cv-decoder/src/lib.rs:98-121 with aspect_ratio_scale = (1, 1)
+    g->per_pixel = fullres_records || g->reduced;
+    if (g->reduced) OFPS_REQUIRE(ctx, gw >= 1 && gh >= 1, "dense decoder: the capped grid of %dx%d under (%d, %d) is empty", W, H, max_w, max_h);
+    else if (!fullres_records) OFPS_REQUIRE(ctx, gw >= 1 && gh >= 1 && (size_t)gw * gh <= 65536, "lk_decode: field %dx%d unsupported", gw, gh);
+    g->fw = g->reduced ? gw : W; g->fh = g->reduced ? gh : H;
+    g->gw = fullres_records ? W : gw; g->gh = fullres_records ? H : gh;
+    g->max_records = (size_t)g->gw * g->gh;
+    g->frontend = g->reduced || g->fmt != OFPS_HIP_FMT_LUMA;
+    g->raw_row = ((size_t)W * g->cn + 3) & ~(size_t)3;
     return OFPS_HIP_OK;
+}
+
+// The flow's own parameter limits, checked where a stream's FIRST frame is pushed (it runs no flow) and before any upload: a stream must not
+// accept a frame and then fail every later one.  Farneback: winsize = 2 radius + 1 <= 15, and the layers of the fw x fh frames.
+int lk_check_flow_params(ofps_hip_ctx* ctx, const LkGrid& g, int levels, int radius, int iters, const char* who) {
+    OFPS_REQUIRE(ctx, levels >= 1 && levels <= 8 && radius >= 1 && radius <= 15 && iters >= 1 && iters <= 64,
+                 "%s: levels=%d radius=%d iters=%d out of range", who, levels, radius, iters);
+    if (g.farneback) {
+        const int rc = ofps::farneback_check_params(ctx, g.fw, g.fh, levels, 2 * radius + 1, 7);
+        if (rc != OFPS_HIP_OK) return rc;
+    }
+    return OFPS_HIP_OK;
+}
+
+// the arriving frame (host memory) -> the fw x fh luma frame the flow reads, on stream `up`: a plain upload, or upload into `d_raw` + front-end
+int lk_upload_frame(ofps_hip_ctx* ctx, const LkGrid& g, const uint8_t* frame, int W, int H, int stride, uint8_t* d_raw, uint8_t* d_dst, hipStream_t up) {
+    if (!g.frontend) {
+        OFPS_HIP_TRY(ctx, ofps::upload_rows(d_dst, W, frame, stride, W, H, up));
+        return OFPS_HIP_OK;
+    }
+    OFPS_HIP_TRY(ctx, ofps::upload_rows(d_raw, g.raw_row, frame, stride, (size_t)W * g.cn, H, up));
+    return ofps::frontend_device(ctx, d_raw, W, H, (int)g.raw_row, g.fmt, true, d_dst, g.fw, g.fh, up);
 }
 
 // records 0 .. *d_count - 1 (or n_max when d_count is null) to a device-addressable destination, the count to cnt_dst
@@ -1904,7 +1943,9 @@ int lk_enqueue_frame(ofps_hip_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_
         if (g.use_previous && cur_id != 0) {
             d_keep = static_cast<float2*>(ofps::scratch(ctx, ofps::S_FB_FLOW, px * sizeof(float2)));
             if (!d_keep) return OFPS_HIP_ENOMEM;
-            if (pf.valid && pf.id == prev_id && pf.W == W && pf.H == H && pf.gen == ctx->scratch[ofps::S_FB_FLOW].gen) d_init = d_keep;
+            // (the stream's LAST flow, whichever frames it related: cv-decoder's self.flow persists across skipped reads, cv-decoder/src/lib.rs:161-165;
+            // ofps_hip_lk_reset and a geometry change forget it, ofps_hip_lk_rewind does not)
+            if (pf.valid && pf.W == W && pf.H == H && pf.gen == ctx->scratch[ofps::S_FB_FLOW].gen) d_init = d_keep;
         }
         if (d_keep) pf.valid = false;               // (until this call has enqueued everything; a call that keeps nothing leaves the buffer alone)
         rc = ofps::farneback_flow_device(ctx, d_prev, d_cur, W, H, W, levels, 2 * radius + 1, iters, 7, 1.5, d_init, d_keep, d_ent, prev_id, cur_id);
@@ -1993,17 +2034,22 @@ int ofps_hip_lk_decode(ofps_hip_ctx* ctx, const uint8_t* prev, const uint8_t* cu
                        int* out_w, int* out_h) {
     if (!ctx) return OFPS_HIP_EINVAL;
     OFPS_REQUIRE(ctx, prev && cur && out_entries && n_out, "lk_decode: null host pointer");
-    OFPS_REQUIRE(ctx, W >= 1 && H >= 1 && stride >= W && max_w >= 1 && max_h >= 1, "lk_decode: bad geometry");
-    OFPS_REQUIRE(ctx, (flags & ~(unsigned)(OFPS_HIP_LK_CONTRAST_MASK | OFPS_HIP_LK_PER_PIXEL | OFPS_HIP_FLOW_FARNEBACK | OFPS_HIP_FLOW_USE_PREVIOUS)) == 0, "lk_decode: unknown flags 0x%x", flags);
+    OFPS_REQUIRE(ctx, W >= 1 && H >= 1 && max_w >= 1 && max_h >= 1, "lk_decode: bad geometry");
+    OFPS_REQUIRE(ctx, (flags & ~kLkFlagBits) == 0, "lk_decode: unknown flags 0x%x", flags);
     OFPS_HIP_TRY(ctx, hipSetDevice(ctx->device));
     LkGrid g;
-    int rc = lk_grid_of(ctx, W, H, max_w, max_h, flags, &g);
+    int rc = lk_grid_of(ctx, W, H, stride, max_w, max_h, flags, &g);
     if (rc != OFPS_HIP_OK) return rc;
-    const size_t px = (size_t)W * H;
+    rc = lk_check_flow_params(ctx, g, levels, radius, iters, "lk_decode");
+    if (rc != OFPS_HIP_OK) return rc;
+    const size_t px = (size_t)g.fw * g.fh, raw_bytes = g.raw_row * (size_t)H;
     auto* d_frames = static_cast<uint8_t*>(ofps::scratch(ctx, ofps::S_FRAMES, 2 * px));
-    if (!d_frames) return OFPS_HIP_ENOMEM;
-    OFPS_HIP_TRY(ctx, ofps::upload_rows(d_frames, W, prev, stride, W, H, ctx->stream));
-    OFPS_HIP_TRY(ctx, ofps::upload_rows(d_frames + px, W, cur, stride, W, H, ctx->stream));
+    auto* d_raw = g.frontend ? static_cast<uint8_t*>(ofps::scratch(ctx, ofps::S_FE_RAW, 2 * raw_bytes)) : nullptr;
+    if (!d_frames || (g.frontend && !d_raw)) return OFPS_HIP_ENOMEM;
+    rc = lk_upload_frame(ctx, g, prev, W, H, stride, d_raw, d_frames, ctx->stream);
+    if (rc != OFPS_HIP_OK) return rc;
+    rc = lk_upload_frame(ctx, g, cur, W, H, stride, d_raw ? d_raw + raw_bytes : nullptr, d_frames + px, ctx->stream);
+    if (rc != OFPS_HIP_OK) return rc;
     // the count and the records come back in ONE page-locked block and one wait; only the visited cells' records reach the
     // caller's buffer
     rc = lk_pinned_block(ctx, &ctx->lk_pinned, &ctx->lk_pinned_cap, g.max_records);
@@ -2011,12 +2057,12 @@ int ofps_hip_lk_decode(ofps_hip_ctx* ctx, const uint8_t* prev, const uint8_t* cu
     void* mapped = nullptr;
     OFPS_REQUIRE(ctx, ofps::device_address_of(ctx->lk_pinned, &mapped), "lk_decode: page-locked block is not device-addressable");
     uint32_t epoch = 0;
-    rc = lk_enqueue_frame(ctx, d_frames, d_frames + px, W, H, levels, radius, iters, g, reinterpret_cast<float4*>(static_cast<char*>(mapped) + 16),
+    rc = lk_enqueue_frame(ctx, d_frames, d_frames + px, g.fw, g.fh, levels, radius, iters, g, reinterpret_cast<float4*>(static_cast<char*>(mapped) + 16),
                           static_cast<uint32_t*>(mapped), false, &epoch);
     if (rc != OFPS_HIP_OK) return rc;
     OFPS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (lk_waits_expired(lk_block_waits(ctx->lk_pinned), epoch)) {        // a tile may have started from unfinished parent flows: level by level
-        rc = lk_enqueue_frame(ctx, d_frames, d_frames + px, W, H, levels, radius, iters, g, reinterpret_cast<float4*>(static_cast<char*>(mapped) + 16),
+        rc = lk_enqueue_frame(ctx, d_frames, d_frames + px, g.fw, g.fh, levels, radius, iters, g, reinterpret_cast<float4*>(static_cast<char*>(mapped) + 16),
                               static_cast<uint32_t*>(mapped), true, &epoch);
         if (rc != OFPS_HIP_OK) return rc;
         OFPS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -2032,40 +2078,48 @@ int ofps_hip_lk_push_frame_async(ofps_hip_ctx* ctx, const uint8_t* frame, int W,
                                  int max_w, int max_h, unsigned flags, int* ticket) {
     if (!ctx) return OFPS_HIP_EINVAL;
     OFPS_REQUIRE(ctx, frame && ticket, "lk_push_frame_async: null pointer");
-    OFPS_REQUIRE(ctx, W >= 1 && H >= 1 && stride >= W && max_w >= 1 && max_h >= 1, "lk_push_frame_async: bad geometry");
-    OFPS_REQUIRE(ctx, (flags & ~(unsigned)(OFPS_HIP_LK_CONTRAST_MASK | OFPS_HIP_LK_PER_PIXEL | OFPS_HIP_FLOW_FARNEBACK | OFPS_HIP_FLOW_USE_PREVIOUS)) == 0, "lk_push_frame_async: unknown flags 0x%x", flags);
-    // (a stream's first frame runs no flow: the flow's parameters are refused here, not one frame later)
-    OFPS_REQUIRE(ctx, levels >= 1 && levels <= 8 && radius >= 1 && radius <= 15 && iters >= 1 && iters <= 64,
-                 "lk_push_frame_async: levels=%d radius=%d iters=%d out of range", levels, radius, iters);
+    OFPS_REQUIRE(ctx, W >= 1 && H >= 1 && max_w >= 1 && max_h >= 1, "lk_push_frame_async: bad geometry");
+    OFPS_REQUIRE(ctx, (flags & ~kLkFlagBits) == 0, "lk_push_frame_async: unknown flags 0x%x", flags);
     OFPS_HIP_TRY(ctx, hipSetDevice(ctx->device));
     int rc = lk_stream_setup(ctx);
     if (rc != OFPS_HIP_OK) return rc;
     LkGrid g;
-    rc = lk_grid_of(ctx, W, H, max_w, max_h, flags, &g);
+    rc = lk_grid_of(ctx, W, H, stride, max_w, max_h, flags, &g);
+    if (rc != OFPS_HIP_OK) return rc;
+    // (a stream's first frame runs no flow: the flow's parameters -- Farneback's own limits included -- are refused here, not one frame later)
+    rc = lk_check_flow_params(ctx, g, levels, radius, iters, "lk_push_frame_async");
     if (rc != OFPS_HIP_OK) return rc;
     const long tno = ctx->lk_next_ticket;
     auto& t = ctx->lk_ticket[tno % ofps_hip_ctx::kLkTickets];
     OFPS_REQUIRE(ctx, !t.pending, "lk_push_frame_async: ticket %ld has not been collected (at most %d frames in flight)",
                  tno - ofps_hip_ctx::kLkTickets, ofps_hip_ctx::kLkTickets);
-    const size_t px = (size_t)W * H;
+    const size_t px = (size_t)g.fw * g.fh, raw_bytes = g.raw_row * (size_t)H;      // the ring holds the frames the flow reads (reduced / converted)
     // A new geometry restarts the stream and may reallocate the ring.  With a ticket in flight that would throw its records away
     // (draining marks it collected: the caller's later lk_frame_wait would fail with "already collected"): refused, like the
     // multi-device form does -- collect first, or ofps_hip_lk_reset.
     const bool other_pending = ctx->lk_ticket[(tno + 1) % ofps_hip_ctx::kLkTickets].pending;
-    const bool restart = ctx->lk_w != W || ctx->lk_h != H || ctx->scratch[ofps::S_LK_FRAMES].cap < ofps_hip_ctx::kLkSlots * px;
+    // (so does a change of the front-end -- "Process Fullres" flipped, another pixel format: the ring's frames are the other mode's; cv-decoder
+    // returns Ok(false) for that frame because gray and old_gray differ in size, cv-decoder/src/lib.rs:156-158)
+    const bool restart = ctx->lk_w != W || ctx->lk_h != H || ctx->lk_fw != g.fw || ctx->lk_fh != g.fh || ctx->lk_fmt != g.fmt ||
+                         ctx->scratch[ofps::S_LK_FRAMES].cap < ofps_hip_ctx::kLkSlots * px ||
+                         (g.frontend && ctx->scratch[ofps::S_FE_RAW].cap < ofps_hip_ctx::kLkTickets * raw_bytes);
     OFPS_REQUIRE(ctx, !(restart && other_pending), "lk_push_frame_async: geometry change %dx%d -> %dx%d with a ticket in flight "
                  "(collect it with ofps_hip_lk_frame_wait first)", ctx->lk_w, ctx->lk_h, W, H);
     if (restart) {
         rc = lk_stream_drain(ctx);
         if (rc != OFPS_HIP_OK) return rc;
-        ctx->lk_w = W; ctx->lk_h = H;
+        ctx->lk_w = W; ctx->lk_h = H; ctx->lk_fw = g.fw; ctx->lk_fh = g.fh; ctx->lk_fmt = g.fmt;
+        ctx->fb_prev_flow.valid = false;
     }
     // the stream's frames have slots of their own: no other entry point (lk_decode, lk_flow, sad_flow, contrast_mask stage
     // their frames in S_FRAMES) can overwrite or reallocate a previous frame behind the stream's back.  Three slots: frame
     // k + 1 is uploaded (copy stream) into the slot of frame k - 2, whose last reader -- ticket k - 1 -- has been collected
     // by the time a third push is accepted.
     auto* d_frames = static_cast<uint8_t*>(ofps::scratch(ctx, ofps::S_LK_FRAMES, ofps_hip_ctx::kLkSlots * px));
-    if (!d_frames) return OFPS_HIP_ENOMEM;
+    // the arriving frame of a stream with a front-end is staged per ticket in flight (the ticket's upload + front-end run on one stream; the
+    // buffer's previous user, ticket tno - 2, has been collected)
+    auto* d_raw_all = g.frontend ? static_cast<uint8_t*>(ofps::scratch(ctx, ofps::S_FE_RAW, ofps_hip_ctx::kLkTickets * raw_bytes)) : nullptr;
+    if (!d_frames || (g.frontend && !d_raw_all)) return OFPS_HIP_ENOMEM;
     if (ctx->lk_frames_gen != ctx->scratch[ofps::S_LK_FRAMES].gen) {         // (re)allocated: whatever was there is gone
         ctx->lk_frames_gen = ctx->scratch[ofps::S_LK_FRAMES].gen;
         ctx->lk_frames = 0;
@@ -2076,8 +2130,10 @@ int ofps_hip_lk_push_frame_async(ofps_hip_ctx* ctx, const uint8_t* frame, int W,
     const bool overlap = other_pending;
     const int slot = (int)(ctx->lk_frames % ofps_hip_ctx::kLkSlots);
     hipStream_t up = overlap ? ctx->lk_copy_stream : s;
-    OFPS_HIP_TRY(ctx, ofps::upload_rows(d_frames + (size_t)slot * px, W, frame, stride, W, H, up));
     ctx->lk_slot_id[slot] = ++ctx->lk_frame_serial;               // (a new id for whatever is in the slot now, also if the push fails below)
+    rc = lk_upload_frame(ctx, g, frame, W, H, stride, d_raw_all ? d_raw_all + (size_t)(tno % ofps_hip_ctx::kLkTickets) * raw_bytes : nullptr,
+                         d_frames + (size_t)slot * px, up);
+    if (rc != OFPS_HIP_OK) return rc;
     // cv-decoder's contrast mask depends on the new frame only: it is made right behind the upload, on the upload's stream -- with
     // another ticket in flight that is beside that ticket's flow instead of after this one's (one mask buffer per ticket in flight)
     const uint8_t* d_mask_ready = nullptr;
@@ -2085,7 +2141,7 @@ int ofps_hip_lk_push_frame_async(ofps_hip_ctx* ctx, const uint8_t* frame, int W,
         auto* masks = static_cast<uint8_t*>(ofps::scratch(ctx, ofps::S_LK_MASKS, (size_t)ofps_hip_ctx::kLkTickets * px));
         if (!masks) return OFPS_HIP_ENOMEM;
         uint8_t* m = masks + (size_t)(tno % ofps_hip_ctx::kLkTickets) * px;
-        rc = ofps::contrast_mask_device(ctx, d_frames + (size_t)slot * px, W, H, W, m, up);
+        rc = ofps::contrast_mask_device(ctx, d_frames + (size_t)slot * px, g.fw, g.fh, g.fw, m, up);
         if (rc != OFPS_HIP_OK) return rc;
         d_mask_ready = m;
     }
@@ -2106,7 +2162,7 @@ int ofps_hip_lk_push_frame_async(ofps_hip_ctx* ctx, const uint8_t* frame, int W,
         OFPS_REQUIRE(ctx, ofps::device_address_of(t.pinned, &mapped), "lk_push_frame_async: page-locked block is not device-addressable");
         const int prev_slot = (int)((frames_after - 2) % ofps_hip_ctx::kLkSlots);
         tp = d_frames + (size_t)prev_slot * px; tc = d_frames + (size_t)slot * px;
-        rc = lk_enqueue_frame(ctx, tp, tc, W, H, levels, radius, iters, g,
+        rc = lk_enqueue_frame(ctx, tp, tc, g.fw, g.fh, levels, radius, iters, g,
                               reinterpret_cast<float4*>(static_cast<char*>(mapped) + 16), static_cast<uint32_t*>(mapped), false, &epoch,
                               ctx->lk_slot_id[prev_slot], ctx->lk_slot_id[slot], d_mask_ready);
         if (rc != OFPS_HIP_OK) return rc;
@@ -2118,7 +2174,7 @@ int ofps_hip_lk_push_frame_async(ofps_hip_ctx* ctx, const uint8_t* frame, int W,
     // what a repeat of this ticket needs (ofps_hip_lk_frame_wait, after an expired wait): its two frames stay in the ring
     // until the ticket after the next one is pushed, which cannot happen before this one is collected
     t.epoch = epoch; t.d_prev = tp; t.d_cur = tc;
-    t.W = W; t.H = H; t.levels = levels; t.radius = radius; t.iters = iters; t.max_w = max_w; t.max_h = max_h; t.flags = flags;
+    t.W = W; t.H = H; t.stride = stride; t.levels = levels; t.radius = radius; t.iters = iters; t.max_w = max_w; t.max_h = max_h; t.flags = flags;
     t.pending = true;
     *ticket = (int)(tno & 0x7FFFFFFF);
     ctx->lk_next_ticket = tno + 1;
@@ -2146,12 +2202,12 @@ int ofps_hip_lk_frame_wait(ofps_hip_ctx* ctx, int ticket, float* out_entries, si
         // (the word looked at is the one this ticket's last kernel saw, compared with this ticket's own launch; the repeat below
         // rewrites the block; a later ticket compares what ITS last kernel saw with ITS epoch)
         LkGrid g;
-        int rc = lk_grid_of(ctx, t.W, t.H, t.max_w, t.max_h, t.flags, &g);
+        int rc = lk_grid_of(ctx, t.W, t.H, t.stride, t.max_w, t.max_h, t.flags, &g);
         if (rc != OFPS_HIP_OK) return rc;
         void* mapped = nullptr;
         OFPS_REQUIRE(ctx, ofps::device_address_of(t.pinned, &mapped), "lk_frame_wait: page-locked block is not device-addressable");
         uint32_t epoch = 0;
-        rc = lk_enqueue_frame(ctx, t.d_prev, t.d_cur, t.W, t.H, t.levels, t.radius, t.iters, g,
+        rc = lk_enqueue_frame(ctx, t.d_prev, t.d_cur, g.fw, g.fh, t.levels, t.radius, t.iters, g,
                               reinterpret_cast<float4*>(static_cast<char*>(mapped) + 16), static_cast<uint32_t*>(mapped), true, &epoch);
         if (rc != OFPS_HIP_OK) return rc;
         OFPS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -2177,7 +2233,14 @@ int ofps_hip_lk_push_frame(ofps_hip_ctx* ctx, const uint8_t* frame, int W, int H
 int ofps_hip_lk_reset(ofps_hip_ctx* ctx) {
     if (!ctx) return OFPS_HIP_EINVAL;
     OFPS_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ctx->fb_prev_flow.valid = false;                       // a new stream starts from zero flow, like a new CvDecoder
     return lk_stream_drain(ctx);
+}
+
+int ofps_hip_lk_rewind(ofps_hip_ctx* ctx) {
+    if (!ctx) return OFPS_HIP_EINVAL;
+    OFPS_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return lk_stream_drain(ctx);                           // the frames are forgotten, the kept flow (OFPS_HIP_FLOW_USE_PREVIOUS) is not
 }
 
 int ofps_hip_lk_flow(ofps_hip_ctx* ctx, const uint8_t* prev, const uint8_t* cur, int W, int H, int stride, int levels,

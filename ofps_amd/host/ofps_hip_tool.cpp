@@ -1,5 +1,5 @@
 // ofps_hip_tool -- small CLI over the C++ host layer; the counterparts of the reference's non-GUI callers:
-//   extract <decoder> <arg> <out.mvec> [max_frames]     motion-extract/src/main.rs:7-38 (decode -> .mvec)
+//   extract <decoder> <arg> <out.mvec> [max_frames [Name=value[@frame] ...]]     motion-extract/src/main.rs:7-38 (decode -> .mvec); properties set by name
 //   detect  <decoder> <arg> [max_frames]                detection loop, ofps-suite/src/app/detection.rs:92-168
 //   detect  --config <saved.json> [--perf-csv <dir>] [max_frames]
 //                                                       the same loop from a saved MotionDetectionConfig (detection.rs:45-50):
@@ -58,10 +58,40 @@ int main(int argc, char** argv) {
             auto dec = create_decoder(argv[2], argv[3]);
             std::ofstream out(argv[4], std::ios::binary);
             const size_t max_frames = argc > 5 ? std::strtoull(argv[5], nullptr, 10) : SIZE_MAX;
+            // "Name=value[@k]": the property is set (Properties::set_prop, plugins/properties.rs:6-18) before frame k is read (default 0) --
+            // what the GUI's property panel does to a running decoder (ofps-suite/src/app/widgets.rs)
+            struct PropArg { std::string name, value; size_t at; };
+            std::vector<PropArg> prop_args;
+            for (int i = 6; i < argc; ++i) {
+                std::string a = argv[i];
+                const auto eq = a.find('=');
+                if (eq == std::string::npos) throw Error("extract: expected Name=value[@frame], got " + a);
+                PropArg pa{a.substr(0, eq), a.substr(eq + 1), 0};
+                if (const auto at = pa.value.rfind('@'); at != std::string::npos) { pa.at = std::stoul(pa.value.substr(at + 1)); pa.value = pa.value.substr(0, at); }
+                prop_args.push_back(pa);
+            }
+            auto apply_props = [&](size_t frame) {
+                for (const auto& pa : prop_args) {
+                    if (pa.at != frame) continue;
+                    bool found = false;
+                    for (const auto& [n, cur] : dec->props()) {
+                        if (n != pa.name) continue;
+                        found = true;
+                        Property v = cur;
+                        if (std::holds_alternative<bool>(cur)) v = (pa.value == "true" || pa.value == "1");
+                        else if (auto* f = std::get_if<BoundedProp<float>>(&v)) f->val = std::stof(pa.value);
+                        else if (auto* u = std::get_if<BoundedProp<size_t>>(&v)) u->val = std::stoul(pa.value);
+                        else v = pa.value;
+                        dec->set_prop(n, v);
+                    }
+                    if (!found) throw Error("extract: the decoder has no property \"" + pa.name + "\"");
+                }
+            };
             MotionVectors mv;
             size_t frames = 0, total = 0;
             while (frames < max_frames) {                              // while c.process_frame(..).is_ok()
                 mv.clear();
+                apply_props(frames);
                 try { dec->process_frame(mv, nullptr, nullptr, 0); } catch (const Error&) { break; }
                 write_mvec_frame(out, mv);                             // a frame without vectors is written with count 0
                 ++frames; total += mv.size();

@@ -9,6 +9,7 @@
 #include <sys/socket.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstring>
@@ -154,12 +155,15 @@ std::vector<std::pair<std::string, PropertyMut>> HipSadDecoder::props_mut() {
 
 // ------------------------------------------------------------------ hip_lk
 HipLkDecoder::HipLkDecoder(std::unique_ptr<std::istream> input, size_t width, size_t height, std::optional<double> fps, int device,
-                           bool farneback)
-    : ctx_(device), in_(std::move(input)), w_(width), h_(height), fps_(fps), prev_(width * height), cur_(width * height),
-      farneback_(farneback) {
+                           bool farneback, int frame_format)
+    : ctx_(device), in_(std::move(input)), w_(width), h_(height), fps_(fps), fmt_(frame_format), farneback_(farneback) {
     if (farneback_) { levels_ = 5; radius_ = 6; iters_ = 3; }
     if (!in_ || !*in_) throw Error("hip_lk: cannot open input");
     if (w_ == 0 || h_ == 0) throw Error("hip_lk: frame size required (arg \"path?w=..&h=..\")");
+    cn_ = (size_t)ofps_hip_frame_channels(fmt_);
+    if (cn_ == 0) throw Error("hip_lk: unknown frame format");
+    prev_.resize(w_ * h_ * cn_);
+    cur_.resize(w_ * h_ * cn_);
 }
 
 bool HipLkDecoder::process_frame(MotionVectors& field, std::vector<RGBA>* out_frame, size_t* out_height, size_t skip) {
@@ -168,30 +172,44 @@ bool HipLkDecoder::process_frame(MotionVectors& field, std::vector<RGBA>* out_fr
         in_->read(reinterpret_cast<char*>(cur_.data()), (std::streamsize)cur_.size());
         if ((size_t)in_->gcount() != cur_.size()) throw Error("hip_lk: failed to grab frame");
     }
-    if (out_frame && out_height) {
+    if (out_frame && out_height) {                                    // :144-154 (the full-size frame as it arrived)
         *out_height = h_;
         out_frame->clear();
-        for (uint8_t y : cur_) out_frame->push_back(RGBA{y, y, y, 255});
+        out_frame->reserve(w_ * h_);
+        const uint8_t* p = cur_.data();
+        for (size_t i = 0; i < w_ * h_; ++i, p += cn_) {
+            if (fmt_ == OFPS_HIP_FMT_LUMA) out_frame->push_back(RGBA{p[0], p[0], p[0], 255});
+            else if (fmt_ == OFPS_HIP_FMT_RGBA) out_frame->push_back(RGBA{p[0], p[1], p[2], 255});
+            else out_frame->push_back(RGBA{p[2], p[1], p[0], 255});   // BGR / BGRA
+        }
     }
     // :156-158 compares the sizes of gray and old_gray: flow is computed as soon as TWO frames have been read, also when
     // both were read by this very call (skip >= 1 on the first call)
     frames_read_ += skip + 1;
     if (frames_read_ < 2) return false;
-    out_.resize(process_fullres_ ? 4 * std::min(max_w_, w_) * std::min(max_h_, h_) : 4 * w_ * h_);
+    const bool records_fullres = process_fullres_ && fullres_records_;
+    out_.resize(records_fullres ? 4 * w_ * h_ : 4 * std::min(max_w_, w_) * std::min(max_h_, h_));
     size_t n_out = 0;
-    const unsigned flags = (contrast_mask_ ? OFPS_HIP_LK_CONTRAST_MASK : 0u) | (process_fullres_ ? 0u : OFPS_HIP_LK_PER_PIXEL) |
+    const unsigned flags = (contrast_mask_ ? OFPS_HIP_LK_CONTRAST_MASK : 0u) | (process_fullres_ ? 0u : OFPS_HIP_LK_REDUCED) |
+                           (records_fullres ? OFPS_HIP_LK_FULLRES_RECORDS : 0u) | OFPS_HIP_FRAME_FORMAT(fmt_) |
                            (farneback_ ? OFPS_HIP_FLOW_FARNEBACK | OFPS_HIP_FLOW_USE_PREVIOUS : 0u);   // cv-decoder/src/lib.rs:161-165: its previous flow is the initial flow
-    // the frame uploaded by the previous call is this call's previous frame unless frames were skipped in between:
-    // then (and for the first pair) the previous frame goes up first
+    const size_t params[5] = {levels_, radius_, iters_, max_w_, max_h_};
+    const bool same_mode = on_device_ && flags == on_device_flags_ && std::equal(params, params + 5, on_device_params_);
+    const int pitch = (int)(w_ * cn_);
+    // the frame uploaded by the previous call is this call's previous frame unless frames were skipped in between or a property
+    // changed: then (and for the first pair) the previous frame goes up first.  After a skip the stream's last flow stays the initial
+    // flow (cv-decoder's self.flow persists across skipped reads): rewind, not reset.
     int have = 0;
-    if (!(skip == 0 && on_device_)) {
-        ctx_.check(ofps_hip_lk_reset(ctx_.get()));
-        ctx_.check(ofps_hip_lk_push_frame(ctx_.get(), prev_.data(), (int)w_, (int)h_, (int)w_, (int)levels_, (int)radius_, (int)iters_,
+    if (!(skip == 0 && same_mode)) {
+        ctx_.check(same_mode ? ofps_hip_lk_rewind(ctx_.get()) : ofps_hip_lk_reset(ctx_.get()));
+        ctx_.check(ofps_hip_lk_push_frame(ctx_.get(), prev_.data(), (int)w_, (int)h_, pitch, (int)levels_, (int)radius_, (int)iters_,
                                           (int)max_w_, (int)max_h_, flags, out_.data(), &n_out, nullptr, nullptr, &have));
     }
-    ctx_.check(ofps_hip_lk_push_frame(ctx_.get(), cur_.data(), (int)w_, (int)h_, (int)w_, (int)levels_, (int)radius_, (int)iters_,
+    ctx_.check(ofps_hip_lk_push_frame(ctx_.get(), cur_.data(), (int)w_, (int)h_, pitch, (int)levels_, (int)radius_, (int)iters_,
                                       (int)max_w_, (int)max_h_, flags, out_.data(), &n_out, nullptr, nullptr, &have));
     on_device_ = true;
+    on_device_flags_ = flags;
+    std::copy(params, params + 5, on_device_params_);
     if (!have) throw Error("hip_lk: no vectors for the second frame of a pair");
     const size_t base = field.size();
     field.resize(base + n_out);
@@ -199,11 +217,11 @@ bool HipLkDecoder::process_frame(MotionVectors& field, std::vector<RGBA>* out_fr
     return true;
 }
 
-std::vector<std::pair<std::string, PropertyMut>> HipLkDecoder::props_mut() {   // cv-decoder/src/lib.rs:35-52 + the LK knobs
+std::vector<std::pair<std::string, PropertyMut>> HipLkDecoder::props_mut() {   // cv-decoder/src/lib.rs:35-52 + the flow's knobs
     return {{"Width", PropertyMut::usize(&max_w_, 1, 2000)}, {"Height", PropertyMut::usize(&max_h_, 1, 2000)},
-            {"Pyramid levels", PropertyMut::usize(&levels_, 1, 8)}, {"Window radius", PropertyMut::usize(&radius_, 1, 15)},
+            {"Pyramid levels", PropertyMut::usize(&levels_, 1, 8)}, {"Window radius", PropertyMut::usize(&radius_, 1, farneback_ ? 7 : 15)},
             {"Iterations", PropertyMut::usize(&iters_, 1, 64)}, {"Contrast mask", PropertyMut::boolean(&contrast_mask_)},
-            {"Process Fullres", PropertyMut::boolean(&process_fullres_)}};
+            {"Process Fullres", PropertyMut::boolean(&process_fullres_)}, {"Fullres records", PropertyMut::boolean(&fullres_records_)}};
 }
 
 // ------------------------------------------------------------------ .mvec
@@ -514,6 +532,7 @@ std::unique_ptr<Decoder> create_decoder(const std::string& name, const std::stri
     if (name == "hip_sad" || name == "hip_lk" || name == "hip_flow") {                      // "<path>?w=1920&h=1080&fps=60"
         std::string path = arg;
         size_t w = 0, h = 0;
+        int fmt = OFPS_HIP_FMT_LUMA;
         std::optional<double> fps;
         if (auto q = arg.find('?'); q != std::string::npos) {
             path = arg.substr(0, q);
@@ -524,10 +543,16 @@ std::unique_ptr<Decoder> create_decoder(const std::string& name, const std::stri
                 if (eq == std::string::npos) continue;
                 const std::string k = kv.substr(0, eq), v = kv.substr(eq + 1);
                 if (k == "w") w = std::stoul(v); else if (k == "h") h = std::stoul(v); else if (k == "fps") fps = std::stod(v);
+                else if (k == "fmt") {                                  // hip_lk / hip_flow: the stream's pixel format (default luma)
+                    if (v == "luma") fmt = OFPS_HIP_FMT_LUMA; else if (v == "bgr") fmt = OFPS_HIP_FMT_BGR;
+                    else if (v == "rgba") fmt = OFPS_HIP_FMT_RGBA; else if (v == "bgra") fmt = OFPS_HIP_FMT_BGRA;
+                    else throw Error("unknown frame format: " + v);
+                }
             }
         }
-        if (name == "hip_lk") return std::make_unique<HipLkDecoder>(open_input(path), w, h, fps);
-        if (name == "hip_flow") return std::make_unique<HipLkDecoder>(open_input(path), w, h, fps, 0, /*farneback=*/true);
+        if (name == "hip_lk") return std::make_unique<HipLkDecoder>(open_input(path), w, h, fps, 0, false, fmt);
+        if (name == "hip_flow") return std::make_unique<HipLkDecoder>(open_input(path), w, h, fps, 0, /*farneback=*/true, fmt);
+        if (fmt != OFPS_HIP_FMT_LUMA) throw Error("hip_sad reads luma frames only");
         return std::make_unique<HipSadDecoder>(open_input(path), w, h, fps);
     }
     throw Error("unknown decoder plugin: " + name);

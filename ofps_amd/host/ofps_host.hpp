@@ -162,8 +162,10 @@ public:
     // farneback = true is the "hip_flow" plugin: Farneback's polynomial-expansion flow with cv-decoder's arguments
     // (cv-decoder/src/lib.rs:188-199: levels 5, winsize 13 = 2 * 6 + 1, 3 iterations, poly_n 7, poly_sigma 1.5) through the same
     // entry points (OFPS_HIP_FLOW_FARNEBACK); the properties keep their names, "Window radius" r means winsize 2 r + 1
+    // frame_format: OFPS_HIP_FMT_LUMA (raw luma streams, the default) or a colour format (OFPS_HIP_FMT_BGR = what cv-decoder's VideoCapture
+    // hands it): colour frames are converted on the device with cvt_color(BGR2GRAY)'s formula (cv-decoder/src/lib.rs:135)
     HipLkDecoder(std::unique_ptr<std::istream> input, size_t width, size_t height, std::optional<double> fps, int device = 0,
-                 bool farneback = false);
+                 bool farneback = false, int frame_format = OFPS_HIP_FMT_LUMA);
     bool process_frame(MotionVectors& field, std::vector<RGBA>* out_frame, size_t* out_height, size_t skip_frames) override;
     std::optional<double> get_framerate() const override { return fps_; }
     std::optional<std::pair<size_t, size_t>> get_aspect() const override { return std::make_pair(w_, h_); }
@@ -172,12 +174,18 @@ private:
     HipContext ctx_;
     std::unique_ptr<std::istream> in_;
     size_t w_, h_, max_w_ = 150, max_h_ = 150, levels_ = 3, radius_ = 4, iters_ = 3;
-    bool contrast_mask_ = true, process_fullres_ = true;            // cv-decoder: the Farneback path always masks (:203-237)
+    // "Process Fullres" has cv-decoder's meaning (cv-decoder/src/lib.rs:124-133,274-276): false = frames resized to the capped grid before
+    // the flow, one record per unmasked pixel of the reduced frame.  "Fullres records" is this build's own output form.
+    bool contrast_mask_ = true, process_fullres_ = true, fullres_records_ = false;      // cv-decoder: the Farneback path always masks (:203-237)
     std::optional<double> fps_;
+    int fmt_ = OFPS_HIP_FMT_LUMA;
+    size_t cn_ = 1;
     std::vector<uint8_t> prev_, cur_;
     std::vector<float> out_;
     size_t frames_read_ = 0;
     bool on_device_ = false;           // the last frame of the previous call is on the device (ofps_hip_lk_push_frame's state)
+    unsigned on_device_flags_ = 0;     // ... pushed with these flags / parameters (a property change restarts the library's stream)
+    size_t on_device_params_[5] = {0, 0, 0, 0, 0};
     bool farneback_ = false;
 };
 

@@ -126,17 +126,41 @@ class HipSadDecoder(Properties):
 
 
 class HipLkDecoder(HipSadDecoder):
-    """Decoder producing dense per-pixel flow the way cv-decoder does in full-resolution mode
-    (cv-decoder/src/lib.rs:82-294): records down-sampled through the densifier to the (Width, Height)-capped grid."""
+    """Decoder producing dense per-pixel flow the way cv-decoder does (cv-decoder/src/lib.rs:82-294).  "Process Fullres" = true (the
+    default, as in the reference): flow on the full frames, records down-sampled through the densifier to the (Width, Height)-capped grid;
+    false: every frame is resized (INTER_LINEAR) to that grid first and every unmasked pixel of the REDUCED frame is one record
+    (:124-133,274-276).  Frames: [H, W] luma (this build's raw streams) or [H, W, 3 | 4] colour with `frame_format` = FMT_BGR / FMT_RGBA /
+    FMT_BGRA -- converted with cvt_color(BGR2GRAY)'s formula on the device (:135).  "Fullres records" is this build's own output form (one
+    record per full-resolution pixel, no down-sampling), not a cv-decoder mode."""
     _PROPS = (("Width", "usize", "max_w", 1, 2000), ("Height", "usize", "max_h", 1, 2000),
               ("Pyramid levels", "usize", "levels", 1, 8), ("Window radius", "usize", "radius", 1, 15),
               ("Iterations", "usize", "iters", 1, 64), ("Contrast mask", "bool", "contrast_mask", None, None),
-              ("Process Fullres", "bool", "process_fullres", None, None))
+              ("Process Fullres", "bool", "process_fullres", None, None), ("Fullres records", "bool", "fullres_records", None, None))
 
-    def __init__(self, frames, framerate=None, device: int = 0):
+    def __init__(self, frames, framerate=None, device: int = 0, frame_format: int = HipContext.FMT_LUMA):
         super().__init__(frames, framerate, device)
         self.max_w, self.max_h, self.levels, self.radius, self.iters = 150, 150, 3, 4, 3
         self.contrast_mask, self.process_fullres = True, True          # cv-decoder's Farneback path always masks
+        self.fullres_records = False
+        self.frame_format = frame_format
+        self._mode = None
+
+    def _flow_kw(self) -> dict:
+        return dict(contrast_mask=self.contrast_mask, reduced=not self.process_fullres, fmt=self.frame_format,
+                    fullres_records=self.fullres_records and self.process_fullres)
+
+    def _decode(self, field: list, kw: dict) -> bool:
+        """the pair (self._prev, self._cur) through the library's stream form; the frame on the device from the last call is this call's
+        previous frame unless frames were skipped or the mode changed: then (and on the first pair) the previous frame goes up first"""
+        mode = tuple(sorted(kw.items())) + (self.levels, self.radius, self.iters, self.max_w, self.max_h)
+        if getattr(self, "_on_device", None) is not self._prev or mode != self._mode:
+            # (frames were skipped: the stream's last flow stays the initial flow, cv-decoder's self.flow persists, cv-decoder/src/lib.rs:161-165)
+            self.ctx.lk_reset() if (mode != self._mode or getattr(self, "_on_device", None) is None) else self.ctx.lk_rewind()
+            self.ctx.lk_push_frame(self._prev, self.levels, self.radius, self.iters, self.max_w, self.max_h, **kw)
+        ent, _ = self.ctx.lk_push_frame(self._cur, self.levels, self.radius, self.iters, self.max_w, self.max_h, **kw)
+        self._on_device, self._mode = self._cur, mode
+        field.extend(ent)
+        return True
 
     def process_frame(self, field: list, out_frame=None, skip_frames: int = 0) -> bool:
         for _ in range(skip_frames + 1):
@@ -150,16 +174,7 @@ class HipLkDecoder(HipSadDecoder):
         if self._prev is None or self._prev.shape != self._cur.shape:
             self._on_device = None
             return False
-        kw = dict(contrast_mask=self.contrast_mask, per_pixel=not self.process_fullres)
-        # the frame that is on the device from the last call is this call's previous frame unless frames were skipped:
-        # then (and on the first pair) the previous frame goes up first
-        if getattr(self, "_on_device", None) is not self._prev:
-            self.ctx.lk_reset()
-            self.ctx.lk_push_frame(self._prev, self.levels, self.radius, self.iters, self.max_w, self.max_h, **kw)
-        ent, _ = self.ctx.lk_push_frame(self._cur, self.levels, self.radius, self.iters, self.max_w, self.max_h, **kw)
-        self._on_device = self._cur
-        field.extend(ent)
-        return True
+        return self._decode(field, self._flow_kw())
 
 
 class HipFlowDecoder(HipLkDecoder):
@@ -167,8 +182,10 @@ class HipFlowDecoder(HipLkDecoder):
     (cv-decoder/src/lib.rs:188-199: levels 5, winsize 13, iterations 3, poly_n 7, poly_sigma 1.5), then cv-decoder's contrast mask and
     down-sampling exactly as HipLkDecoder (ofps_amd/csrc/farneback.hip; "Window radius" r means winsize 2 r + 1)."""
 
-    def __init__(self, frames, framerate=None, device: int = 0):
-        super().__init__(frames, framerate, device)
+    _PROPS = tuple(p if p[0] != "Window radius" else ("Window radius", "usize", "radius", 1, 7) for p in HipLkDecoder._PROPS)   # winsize <= 15
+
+    def __init__(self, frames, framerate=None, device: int = 0, frame_format: int = HipContext.FMT_LUMA):
+        super().__init__(frames, framerate, device, frame_format)
         self.levels, self.radius, self.iters = 5, 6, 3
         self.use_previous_flow = True      # OPTFLOW_USE_INITIAL_FLOW as cv-decoder sets it (the library keeps the flow; a stream restart forgets it)
 
@@ -185,14 +202,7 @@ class HipFlowDecoder(HipLkDecoder):
             self._on_device = None
             return False
         # cv-decoder/src/lib.rs:161-165: from its second pair on the decoder passes its previous flow as the initial flow
-        kw = dict(contrast_mask=self.contrast_mask, per_pixel=not self.process_fullres, farneback=True, use_previous=self.use_previous_flow)
-        if getattr(self, "_on_device", None) is not self._prev:
-            self.ctx.lk_reset()
-            self.ctx.lk_push_frame(self._prev, self.levels, self.radius, self.iters, self.max_w, self.max_h, **kw)
-        ent, _ = self.ctx.lk_push_frame(self._cur, self.levels, self.radius, self.iters, self.max_w, self.max_h, **kw)
-        self._on_device = self._cur
-        field.extend(ent)
-        return True
+        return self._decode(field, dict(self._flow_kw(), farneback=True, use_previous=self.use_previous_flow))
 
 
 class HipBlockMotionDetection(Properties):

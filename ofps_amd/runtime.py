@@ -204,32 +204,87 @@ class HipContext:
                 self.free(b)
         return flow
 
-    LK_CONTRAST_MASK, LK_PER_PIXEL, FLOW_FARNEBACK, FLOW_USE_PREVIOUS = 1, 2, 4, 8
+    LK_CONTRAST_MASK, LK_FULLRES_RECORDS, FLOW_FARNEBACK, FLOW_USE_PREVIOUS, LK_REDUCED = 1, 2, 4, 8, 16
+    FMT_LUMA, FMT_BGR, FMT_RGBA, FMT_BGRA = 0, 1, 2, 3
+
+    def _lk_flags(self, contrast_mask, fullres_records, farneback, use_previous, reduced, fmt) -> int:
+        return ((self.LK_CONTRAST_MASK if contrast_mask else 0) | (self.LK_FULLRES_RECORDS if fullres_records else 0) |
+                (self.FLOW_FARNEBACK if farneback else 0) | (self.FLOW_USE_PREVIOUS if use_previous else 0) |
+                (self.LK_REDUCED if reduced else 0) | (int(fmt) << 8))
+
+    def _frame_geometry(self, frame: np.ndarray, fmt: int):
+        """-> (W, H, row pitch in bytes) of a C-contiguous u8 frame [H, W] (luma) or [H, W, channels]"""
+        cn = int(self._lib.ofps_hip_frame_channels(int(fmt)))
+        if cn == 0:
+            raise ValueError(f"unknown frame format {fmt}")
+        if (frame.ndim == 2 and cn != 1) or (frame.ndim == 3 and frame.shape[2] != cn) or frame.ndim not in (2, 3):
+            raise ValueError(f"frame of shape {frame.shape} is not a format-{fmt} frame ({cn} bytes per pixel)")
+        H, W = frame.shape[:2]
+        return W, H, W * cn
+
+    @staticmethod
+    def _lk_capacity(W, H, max_w, max_h, fullres_records) -> int:
+        return W * H if fullres_records else min(max_w, W) * min(max_h, H)
+
+    def cv_grid(self, W: int, H: int, max_w: int = 150, max_h: int = 150):
+        """cv-decoder/src/lib.rs:98-121: the capped record grid (and the size "Process Fullres" = false resizes the frames to)."""
+        gw = C.c_int(0); gh = C.c_int(0)
+        rc = self._lib.ofps_hip_cv_grid(W, H, max_w, max_h, C.byref(gw), C.byref(gh))
+        if rc != 0:
+            raise ValueError("ofps_hip_cv_grid: bad arguments")
+        return gw.value, gh.value
+
+    def resize_linear(self, img: np.ndarray, dw: int, dh: int, fmt: int = 0) -> np.ndarray:
+        """imgproc::resize(.., INTER_LINEAR) of an 8-bit frame, channels kept (cv-decoder/src/lib.rs:124-133)."""
+        img = np.ascontiguousarray(img, np.uint8)
+        W, H, pitch = self._frame_geometry(img, fmt)
+        out = np.zeros((dh, dw) + img.shape[2:], np.uint8)
+        u8 = C.POINTER(C.c_uint8)
+        self._check(self._lib.ofps_hip_resize_linear(self._h, img.ctypes.data_as(u8), W, H, pitch, int(fmt), out.ctypes.data_as(u8), dw, dh))
+        return out
+
+    def cv_frontend(self, frame: np.ndarray, fmt: int = 0, reduced: bool = False, max_w: int = 150, max_h: int = 150) -> np.ndarray:
+        """[resize to the capped grid ->] gray: what cv-decoder leaves in `self.gray` for one frame (cv-decoder/src/lib.rs:98-135)."""
+        frame = np.ascontiguousarray(frame, np.uint8)
+        W, H, pitch = self._frame_geometry(frame, fmt)
+        out = np.zeros(W * H, np.uint8)
+        ow = C.c_int(0); oh = C.c_int(0)
+        u8 = C.POINTER(C.c_uint8)
+        self._check(self._lib.ofps_hip_cv_frontend(self._h, frame.ctypes.data_as(u8), W, H, pitch, int(fmt), int(bool(reduced)), max_w, max_h,
+                                                   out.ctypes.data_as(u8), C.byref(ow), C.byref(oh)))
+        return out[:ow.value * oh.value].reshape(oh.value, ow.value).copy()
+
+    def cv_frontend_dev(self, d_frame: int, W: int, H: int, stride: int, fmt: int, reduced: bool, max_w: int, max_h: int, d_out_gray: int):
+        ow = C.c_int(0); oh = C.c_int(0)
+        self._check(self._lib.ofps_hip_cv_frontend_dev(self._h, C.c_void_p(d_frame), W, H, stride, int(fmt), int(bool(reduced)), max_w, max_h,
+                                                       C.c_void_p(d_out_gray), C.byref(ow), C.byref(oh)))
+        return ow.value, oh.value
 
     def lk_decode(self, prev: np.ndarray, cur: np.ndarray, levels=3, radius=4, iters=3, max_w=150, max_h=150, farneback=False, use_previous=False,
-                  contrast_mask=False, per_pixel=False):
-        """-> (entries[n,4], (grid_w, grid_h)): what a hip_lk Decoder appends per frame (cv-decoder/src/lib.rs:82-294)."""
+                  contrast_mask=False, fullres_records=False, reduced=False, fmt=0):
+        """-> (entries[n,4], (grid_w, grid_h)): what a hip_lk Decoder appends per frame (cv-decoder/src/lib.rs:82-294).
+        reduced: cv-decoder's "Process Fullres" = false; fmt: the frames' pixel format (FMT_*; colour frames are [H, W, channels])."""
         prev = np.ascontiguousarray(prev, np.uint8); cur = np.ascontiguousarray(cur, np.uint8)
-        H, W = prev.shape
-        out = np.zeros((W * H if per_pixel else min(max_w, W) * min(max_h, H), 4), np.float32)
+        assert prev.shape == cur.shape
+        W, H, pitch = self._frame_geometry(prev, fmt)
+        out = np.zeros((self._lk_capacity(W, H, max_w, max_h, fullres_records), 4), np.float32)
         n = C.c_size_t(0); gw = C.c_int(0); gh = C.c_int(0)
         u8 = C.POINTER(C.c_uint8)
-        flags = (self.LK_CONTRAST_MASK if contrast_mask else 0) | (self.LK_PER_PIXEL if per_pixel else 0) | (self.FLOW_FARNEBACK if farneback else 0) | (self.FLOW_USE_PREVIOUS if use_previous else 0)
-        self._check(self._lib.ofps_hip_lk_decode(self._h, prev.ctypes.data_as(u8), cur.ctypes.data_as(u8), W, H, W, levels, radius,
+        flags = self._lk_flags(contrast_mask, fullres_records, farneback, use_previous, reduced, fmt)
+        self._check(self._lib.ofps_hip_lk_decode(self._h, prev.ctypes.data_as(u8), cur.ctypes.data_as(u8), W, H, pitch, levels, radius,
                                                  iters, max_w, max_h, flags, _fp(out), C.byref(n), C.byref(gw), C.byref(gh)))
         return out[:n.value].copy(), (gw.value, gh.value)
 
-
     def lk_push_frame(self, frame: np.ndarray, levels=3, radius=4, iters=3, max_w=150, max_h=150, contrast_mask=False,
-                      per_pixel=False, farneback=False, use_previous=False):
+                      fullres_records=False, farneback=False, use_previous=False, reduced=False, fmt=0):
         """Stream form of lk_decode: the frame is uploaded once and is the next call's previous frame.
         -> None for the first frame of a stream, else (entries[n,4], (grid_w, grid_h))."""
         frame = np.ascontiguousarray(frame, np.uint8)
-        H, W = frame.shape
-        out = np.zeros((W * H if per_pixel else min(max_w, W) * min(max_h, H), 4), np.float32)
+        W, H, pitch = self._frame_geometry(frame, fmt)
+        out = np.zeros((self._lk_capacity(W, H, max_w, max_h, fullres_records), 4), np.float32)
         n = C.c_size_t(0); gw = C.c_int(0); gh = C.c_int(0); have = C.c_int(0)
-        flags = (self.LK_CONTRAST_MASK if contrast_mask else 0) | (self.LK_PER_PIXEL if per_pixel else 0) | (self.FLOW_FARNEBACK if farneback else 0) | (self.FLOW_USE_PREVIOUS if use_previous else 0)
-        self._check(self._lib.ofps_hip_lk_push_frame(self._h, frame.ctypes.data_as(C.POINTER(C.c_uint8)), W, H, W, levels, radius,
+        flags = self._lk_flags(contrast_mask, fullres_records, farneback, use_previous, reduced, fmt)
+        self._check(self._lib.ofps_hip_lk_push_frame(self._h, frame.ctypes.data_as(C.POINTER(C.c_uint8)), W, H, pitch, levels, radius,
                                                      iters, max_w, max_h, flags, _fp(out), C.byref(n), C.byref(gw), C.byref(gh),
                                                      C.byref(have)))
         if not have.value:
@@ -237,17 +292,17 @@ class HipContext:
         return out[:n.value].copy(), (gw.value, gh.value)
 
     def lk_push_frame_async(self, frame: np.ndarray, levels=3, radius=4, iters=3, max_w=150, max_h=150, contrast_mask=False,
-                            per_pixel=False, farneback=False, use_previous=False) -> int:
+                            fullres_records=False, farneback=False, use_previous=False, reduced=False, fmt=0) -> int:
         """Read-ahead form: returns a ticket once the upload, the flow and the output stage are enqueued.  `frame` must be
         C-contiguous u8 and stay alive (ideally page-locked: pinned_frame) until lk_frame_wait(ticket)."""
-        assert frame.dtype == np.uint8 and frame.flags["C_CONTIGUOUS"] and frame.ndim == 2
-        H, W = frame.shape
-        flags = (self.LK_CONTRAST_MASK if contrast_mask else 0) | (self.LK_PER_PIXEL if per_pixel else 0) | (self.FLOW_FARNEBACK if farneback else 0) | (self.FLOW_USE_PREVIOUS if use_previous else 0)
+        assert frame.dtype == np.uint8 and frame.flags["C_CONTIGUOUS"]
+        W, H, pitch = self._frame_geometry(frame, fmt)
+        flags = self._lk_flags(contrast_mask, fullres_records, farneback, use_previous, reduced, fmt)
         t = C.c_int(0)
-        self._check(self._lib.ofps_hip_lk_push_frame_async(self._h, frame.ctypes.data_as(C.POINTER(C.c_uint8)), W, H, W, levels, radius,
+        self._check(self._lib.ofps_hip_lk_push_frame_async(self._h, frame.ctypes.data_as(C.POINTER(C.c_uint8)), W, H, pitch, levels, radius,
                                                            iters, max_w, max_h, flags, C.byref(t)))
         self._lk_cap = getattr(self, "_lk_cap", {})
-        self._lk_cap[t.value] = W * H if per_pixel else min(max_w, W) * min(max_h, H)
+        self._lk_cap[t.value] = self._lk_capacity(W, H, max_w, max_h, fullres_records)
         return t.value
 
     def lk_frame_wait(self, ticket: int, out: np.ndarray | None = None):
@@ -265,6 +320,10 @@ class HipContext:
 
     def lk_reset(self):
         self._check(self._lib.ofps_hip_lk_reset(self._h))
+
+    def lk_rewind(self):
+        """forget the stream's frames, keep its last flow as the next pair's initial flow (a decoder that skipped frames)"""
+        self._check(self._lib.ofps_hip_lk_rewind(self._h))
 
     def contrast_mask(self, gray: np.ndarray) -> np.ndarray:
         """cv-decoder's Sobel/threshold/dilate mask (cv-decoder/src/lib.rs:203-237) -> u8[H, W], 1 = keep."""

@@ -18,7 +18,7 @@ _LIB_PATH = os.path.join(_HERE, "libofps_oracle.so")
 
 def build(force: bool = False) -> str:
     """Compile the oracle with gcc (see oracle/Makefile)."""
-    srcs = [os.path.join(_HERE, f) for f in ("ofps_oracle.c", "farneback_oracle.c", "ofps_oracle.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("ofps_oracle.c", "farneback_oracle.c", "frontend_oracle.c", "ofps_oracle.h")]
     stale = not os.path.exists(_LIB_PATH) or any(os.path.getmtime(_LIB_PATH) < os.path.getmtime(f) for f in srcs)
     if force or stale:
         subprocess.check_call(["make", "-s", "-C", _HERE, "-B", "libofps_oracle.so"])
@@ -441,3 +441,81 @@ def num_threads() -> int:
 def set_num_threads(n: int) -> int:
     """Threads of the OpenMP loops that take no thread argument (lk_flow); returns the previous setting."""
     return int(lib().orc_set_num_threads(int(n)))
+
+
+# ---- cv-decoder's frame front-end (oracle/frontend_oracle.c) ----
+FMT_LUMA, FMT_BGR, FMT_RGBA, FMT_BGRA = 0, 1, 2, 3
+_FMT_CN = {FMT_LUMA: 1, FMT_BGR: 3, FMT_RGBA: 4, FMT_BGRA: 4}
+
+
+def cv_grid(W: int, H: int, max_w: int = 150, max_h: int = 150):
+    """cv-decoder/src/lib.rs:98-121 -> (gw, gh): the record grid (and, with "Process Fullres" = false, the size the frame is resized to)."""
+    gw, gh = C.c_int(0), C.c_int(0)
+    lib().orc_cv_grid(int(W), int(H), int(max_w), int(max_h), C.byref(gw), C.byref(gh))
+    return gw.value, gh.value
+
+
+def resize_linear(img, dw: int, dh: int, variant: int = 0) -> np.ndarray:
+    """imgproc::resize(.., INTER_LINEAR) of an 8-bit image [H, W] or [H, W, cn] (cv-decoder/src/lib.rs:124-133) -> [dh, dw(, cn)]."""
+    a = np.ascontiguousarray(img, np.uint8)
+    H, W = a.shape[:2]
+    cn = 1 if a.ndim == 2 else a.shape[2]
+    out = np.zeros((dh, dw) if a.ndim == 2 else (dh, dw, cn), np.uint8)
+    u8 = C.POINTER(C.c_uint8)
+    f = lib().orc_resize_linear_u8_ex
+    f.argtypes = [u8, C.c_int, C.c_int, C.c_int, C.c_int, u8, C.c_int, C.c_int, C.c_int]
+    if f(a.ctypes.data_as(u8), W, H, W * cn, cn, out.ctypes.data_as(u8), int(dw), int(dh), int(variant)) != 0:
+        raise ValueError("orc_resize_linear_u8: bad arguments")
+    return out
+
+
+def resize_linear_axis(src: int, dst: int, edge_rule: bool):
+    ofs = np.zeros(dst, np.int32); coef = np.zeros((dst, 2), np.int16)
+    f = lib().orc_resize_linear_axis
+    f.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_short)]
+    assert f(src, dst, int(edge_rule), ofs.ctypes.data_as(C.POINTER(C.c_int)), coef.ctypes.data_as(C.POINTER(C.c_short))) == 0
+    return ofs, coef
+
+
+def to_gray(img, fmt: int = FMT_BGR) -> np.ndarray:
+    """imgproc::cvt_color(.., COLOR_BGR2GRAY) (cv-decoder/src/lib.rs:135) of [H, W, 3 | 4] u8 -> [H, W] u8; fmt names the byte order."""
+    a = np.ascontiguousarray(img, np.uint8)
+    H, W, cn = a.shape
+    assert cn == _FMT_CN[fmt], (cn, fmt)
+    out = np.zeros((H, W), np.uint8)
+    u8 = C.POINTER(C.c_uint8)
+    f = lib().orc_to_gray_u8
+    f.argtypes = [u8, C.c_int, C.c_int, C.c_int, C.c_int, u8]
+    if f(a.ctypes.data_as(u8), W, H, W * cn, int(fmt), out.ctypes.data_as(u8)) != 0:
+        raise ValueError("orc_to_gray_u8: bad arguments")
+    return out
+
+
+def cv_frontend(frame, fmt: int = FMT_LUMA, process_fullres: bool = True, max_w: int = 150, max_h: int = 150) -> np.ndarray:
+    """What cv-decoder's read loop leaves in `self.gray` for one frame (cv-decoder/src/lib.rs:98-135): [resize to the capped grid] -> gray.
+    A luma frame (this build's raw-stream input) has no colour conversion: it is resized as one channel."""
+    a = np.ascontiguousarray(frame, np.uint8)
+    H, W = a.shape[:2]
+    if not process_fullres:
+        gw, gh = cv_grid(W, H, max_w, max_h)
+        a = resize_linear(a, gw, gh)
+    return a if fmt == FMT_LUMA else to_gray(a, fmt)
+
+
+def cv_decode(prev, cur, fmt: int = FMT_LUMA, process_fullres: bool = True, max_w: int = 150, max_h: int = 150, flow: str = "farneback",
+              contrast_mask_on: bool = True, levels=None, radius=None, iters: int = 3, init=None):
+    """One cv-decoder process_frame on a pair (cv-decoder/src/lib.rs:82-294) with the stages of this oracle chained:
+    front-end -> flow -> contrast mask -> records.  -> (records [n, 4], (grid_w, grid_h), flow [h, w, 2] of the processed frames).
+    process_fullres = False: one record per unmasked pixel of the REDUCED frame (:274-276)."""
+    H, W = np.asarray(prev).shape[:2]
+    g0 = cv_frontend(prev, fmt, process_fullres, max_w, max_h)
+    g1 = cv_frontend(cur, fmt, process_fullres, max_w, max_h)
+    if flow == "farneback":
+        f = farneback_flow(g0, g1, 5 if levels is None else levels, 2 * (6 if radius is None else radius) + 1, iters, init=init)
+    else:
+        f = lk_flow(g0, g1, 3 if levels is None else levels, 4 if radius is None else radius, iters)
+    rec = masked_flow_to_entries(f, contrast_mask(g1) if contrast_mask_on else None)
+    gw, gh = cv_grid(W, H, max_w, max_h)
+    if process_fullres:
+        rec = densify_to_entries(rec, gw, gh)
+    return rec, (gw, gh), f

@@ -294,7 +294,7 @@ static void make_layer(const uint8_t* img, int W, int H, int stride, int k, int 
                        float* I) {
     for (int y = 0; y < H; ++y)
         for (int x = 0; x < W; ++x) scratch_a[(size_t)y * W + x] = (float)img[(size_t)y * stride + x];
-    float taps[128];
+    float taps[256];                                   /* k <= 6: 159 taps (orc_farneback_blur_kernel writes 2 r + 1) */
     const int r = orc_farneback_blur_kernel(k, taps);
     gaussian_blur(scratch_a, W, H, taps, r, scratch_b, scratch_c);
     if (w == W && h == H) memcpy(I, scratch_c, sizeof(float) * (size_t)W * H);
@@ -329,6 +329,7 @@ int orc_farneback_flow(const uint8_t* prev, const uint8_t* cur, int W, int H, in
         poly_n < 1 || poly_n > 15)
         return -1;
     const int L = orc_farneback_layers(W, H, levels);
+    if (L > 6) return -1;                              /* layer 7 would need 317 blur taps (make_layer holds 256): frames beyond 4096 px with levels >= 7 */
     const size_t px = (size_t)W * H;
     float* a = malloc(sizeof(float) * px); float* b = malloc(sizeof(float) * px); float* c = malloc(sizeof(float) * px);
     float* I = malloc(sizeof(float) * px);

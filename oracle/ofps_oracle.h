@@ -169,6 +169,14 @@ int orc_farneback_layer_debug(const uint8_t* img, int W, int H, int stride, int 
 int orc_farneback_flow(const uint8_t* prev, const uint8_t* cur, int W, int H, int stride, int levels, int winsize, int iters, int poly_n,
                        double poly_sigma, const float* init, float* out_flow);
 
+/* ---- cv-decoder's frame front-end (cv-decoder/src/lib.rs:98-135; OpenCV's 8-bit resize(INTER_LINEAR) and cvtColor(BGR2GRAY) restated from
+ * the published code: frontend_oracle.c).  PARITY UNPINNED: OpenCV is neither under /root/reference nor installed. ---- */
+void orc_cv_grid(int W, int H, int max_w, int max_h, int* gw, int* gh);     /* the capped record grid of :98-121 */
+int orc_resize_linear_u8(const uint8_t* src, int W, int H, int stride, int cn, uint8_t* dst, int dw, int dh);
+int orc_resize_linear_u8_ex(const uint8_t* src, int W, int H, int stride, int cn, uint8_t* dst, int dw, int dh, int variant);
+int orc_resize_linear_axis(int src, int dst, int edge_rule, int* ofs, short* coef);
+int orc_to_gray_u8(const uint8_t* src, int W, int H, int stride, int fmt /* 1 BGR, 2 RGBA, 3 BGRA */, uint8_t* dst);
+
 #ifdef __cplusplus
 }
 #endif

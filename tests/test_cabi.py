@@ -33,7 +33,7 @@ def test_every_declared_symbol_is_exported_and_bound():
 
 def test_api_version_and_pure_helpers():
     lib = _lib.load()
-    assert lib.ofps_hip_api_version() == 1
+    assert lib.ofps_hip_api_version() == 2
     assert lib.ofps_hip_sad_block_count(1920, 1080, 16) == 120 * 67          # full blocks only
     assert lib.ofps_hip_sad_block_count(640, 360, 16) == 40 * 22
     assert lib.ofps_hip_sad_block_count(3840, 2160, 8) == 480 * 270

@@ -98,16 +98,16 @@ def test_hip_flow_decoder_is_the_lk_decoders_output_stage_on_farnebacks_flow(ctx
     from ofps_amd.plugins import HipFlowDecoder
     fr = synth.luma_sequence(4, 480, 270, max_step=3, seed=21)
 
-    def chain(a, b, mask=True, per_pixel=False):
+    def chain(a, b, mask=True, fullres_records=False):
         flow = oracle.farneback_flow(a, b)
         ent = oracle.masked_flow_to_entries(flow, oracle.contrast_mask(b) if mask else None)
-        return ent if per_pixel else oracle.densify_to_entries(ent, 150, 84)
+        return ent if fullres_records else oracle.densify_to_entries(ent, 150, 84)
     want = [chain(fr[k], fr[k + 1]) for k in range(3)]
     ent, grid = ctx.lk_decode(fr[0], fr[1], 5, 6, 3, contrast_mask=True, farneback=True)
     assert grid == (150, 84)
     np.testing.assert_array_equal(ent.view(np.uint32), want[0].view(np.uint32))
-    ent, _ = ctx.lk_decode(fr[0], fr[1], 5, 6, 3, contrast_mask=False, per_pixel=True, farneback=True)
-    np.testing.assert_array_equal(ent.view(np.uint32), chain(fr[0], fr[1], mask=False, per_pixel=True).view(np.uint32))
+    ent, _ = ctx.lk_decode(fr[0], fr[1], 5, 6, 3, contrast_mask=False, fullres_records=True, farneback=True)
+    np.testing.assert_array_equal(ent.view(np.uint32), chain(fr[0], fr[1], mask=False, fullres_records=True).view(np.uint32))
     ctx.lk_reset()
     assert ctx.lk_push_frame(fr[0], 5, 6, 3, contrast_mask=True, farneback=True) is None
     for k in range(1, 4):

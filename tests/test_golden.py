@@ -151,7 +151,7 @@ def test_hip_flow_decoder_matches_golden(ctx):
     fr = g["frames"]
     np.testing.assert_array_equal(ctx.lk_flow(fr[0], fr[1], 3, 4, 3).view(np.uint32), g["flow"].view(np.uint32))
     np.testing.assert_array_equal(ctx.contrast_mask(fr[1]), g["mask"])
-    rec, _ = ctx.lk_decode(fr[0], fr[1], contrast_mask=True, per_pixel=True)
+    rec, _ = ctx.lk_decode(fr[0], fr[1], contrast_mask=True, fullres_records=True)
     np.testing.assert_array_equal(rec.view(np.uint32), g["records"].view(np.uint32))
     ent, (gw, gh) = ctx.lk_decode(fr[0], fr[1], max_w=60, max_h=60, contrast_mask=True)
     assert (gw, gh) == (60, 36)

@@ -947,7 +947,7 @@ def test_lk_decode_with_contrast_mask(ctx):
     mask = oracle.contrast_mask(fr[1])
     assert 0.1 < mask.mean() < 0.95
     rec_o = oracle.masked_flow_to_entries(flow, mask)
-    ent, (gw, gh) = ctx.lk_decode(fr[0], fr[1], contrast_mask=True, per_pixel=True)
+    ent, (gw, gh) = ctx.lk_decode(fr[0], fr[1], contrast_mask=True, fullres_records=True)
     assert (gw, gh) == (480, 270)
     np.testing.assert_array_equal(ent.view(np.uint32), rec_o.view(np.uint32))
     ent, (gw, gh) = ctx.lk_decode(fr[0], fr[1], contrast_mask=True)
@@ -956,7 +956,7 @@ def test_lk_decode_with_contrast_mask(ctx):
     assert len(e_o) < 150 * 84                         # some cells are never visited
     np.testing.assert_array_equal(ent.view(np.uint32), e_o.view(np.uint32))
     # per-pixel without the mask = every pixel
-    ent, _ = ctx.lk_decode(fr[0], fr[1], per_pixel=True)
+    ent, _ = ctx.lk_decode(fr[0], fr[1], fullres_records=True)
     np.testing.assert_array_equal(ent.view(np.uint32), oracle.flow_to_entries(flow).view(np.uint32))
     # nothing survives a flat frame: zero records, not an error
     flat = np.full((2, 64, 96), 90, np.uint8)
@@ -969,7 +969,7 @@ def test_lk_push_frame_stream_matches_pairwise_decode(ctx):
     ofps_hip_lk_decode returns for each consecutive pair (masked and unmasked, down-sampled and per pixel), nothing for
     the first frame, and start over after a reset or a geometry change."""
     fr = synth.flatten_regions(synth.luma_sequence(5, 320, 180, max_step=2, seed=21), region=40, seed=3)
-    for kw in (dict(), dict(contrast_mask=True), dict(per_pixel=True), dict(contrast_mask=True, per_pixel=True)):
+    for kw in (dict(), dict(contrast_mask=True), dict(fullres_records=True), dict(contrast_mask=True, fullres_records=True)):
         ctx.lk_reset()
         assert ctx.lk_push_frame(fr[0], **kw) is None
         for k in range(1, 5):
@@ -985,7 +985,7 @@ def test_lk_push_frame_stream_matches_pairwise_decode(ctx):
     assert ctx.lk_push_frame(fr[2]) is None
 
 
-@pytest.mark.parametrize("kw", [dict(), dict(contrast_mask=True), dict(per_pixel=True), dict(per_pixel=True, contrast_mask=True)])
+@pytest.mark.parametrize("kw", [dict(), dict(contrast_mask=True), dict(fullres_records=True), dict(fullres_records=True, contrast_mask=True)])
 def test_lk_push_frame_async_equals_the_synchronous_decoder(ctx, kw):
     """The ticketed read-ahead form (ofps_hip_lk_push_frame_async / _frame_wait, two tickets in flight: the upload of frame k+1
     on the copy stream beside the flow of pair (k-1, k), the records written by the ticket's last kernel straight into its
@@ -1063,7 +1063,7 @@ def test_lk_push_frame_stream_survives_every_other_entry_point(ctx):
     ent, grid = ctx.lk_push_frame(fr[1])
     assert grid == want[1][1]
     np.testing.assert_array_equal(ent.view(np.uint32), want[1][0].view(np.uint32))
-    ctx.lk_decode(big[1], big[0], per_pixel=True)
+    ctx.lk_decode(big[1], big[0], fullres_records=True)
     ent, grid = ctx.lk_push_frame(fr[2])
     assert grid == want[2][1]
     np.testing.assert_array_equal(ent.view(np.uint32), want[2][0].view(np.uint32))

@@ -38,7 +38,7 @@ def op_lk_flow():
     return same(ctx.lk_flow(frames[g][a], frames[g][b], L, Rr, it), clean.lk_flow(frames[g][a], frames[g][b], L, Rr, it))
 def op_lk_decode():
     g = GEOMS[rng.integers(len(GEOMS))]; a, b = rng.integers(6, size=2)
-    kw = dict(contrast_mask=bool(rng.integers(2)), per_pixel=bool(rng.integers(2)), max_w=int([40, 150][rng.integers(2)]), farneback=bool(rng.integers(2)))
+    kw = dict(contrast_mask=bool(rng.integers(2)), fullres_records=bool(rng.integers(2)), max_w=int([40, 150][rng.integers(2)]), farneback=bool(rng.integers(2)))
     r, e = ctx.lk_decode(frames[g][a], frames[g][b], 2, 4, 2, **kw), clean.lk_decode(frames[g][a], frames[g][b], 2, 4, 2, **kw)
     return r[1] == e[1] and same(r[0], e[0])
 def op_lk_stream():
