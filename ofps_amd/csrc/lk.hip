@@ -1884,6 +1884,13 @@ int lk_upload_frame(ofps_hip_ctx* ctx, const LkGrid& g, const uint8_t* frame, in
         OFPS_HIP_TRY(ctx, ofps::upload_rows(d_dst, W, frame, stride, W, H, up));
         return OFPS_HIP_OK;
     }
+    // A strongly reduced frame needs two of every H / fh source rows (168 of 1080 at the default cap): when the caller's frame is page-locked
+    // -- device-addressable -- the front-end gathers them straight from host memory (~1 MB over PCIe instead of the 6.2 MB of a 1080p BGR
+    // frame; the pixels of a row are 38 bytes apart, so the touched rows cross whole) and nothing is staged.  The frame must stay valid until
+    // the ticket is collected, which the read-ahead form asks for anyway (include/ofps_hip.h).
+    void* mapped = nullptr;
+    if (g.reduced && g.fh * 3 <= H && ofps::device_address_of(frame, &mapped))
+        return ofps::frontend_device(ctx, static_cast<const uint8_t*>(mapped), W, H, stride, g.fmt, true, d_dst, g.fw, g.fh, up);
     OFPS_HIP_TRY(ctx, ofps::upload_rows(d_raw, g.raw_row, frame, stride, (size_t)W * g.cn, H, up));
     return ofps::frontend_device(ctx, d_raw, W, H, (int)g.raw_row, g.fmt, true, d_dst, g.fw, g.fh, up);
 }
