@@ -46,8 +46,7 @@ enum {
     OFPS_HIP_EINVAL = -1,      /* bad argument (message says which) */
     OFPS_HIP_EDEVICE = -2,     /* HIP runtime error / no device */
     OFPS_HIP_EUNSUPPORTED = -3, /* parameter combination has no kernel */
-    OFPS_HIP_ENOMEM = -4,
-    OFPS_HIP_ESTALE = -5       /* ofps_hip_sync only: a device-pointer LK call since the last sync must be repeated (see ofps_hip_lk_flow_dev) */
+    OFPS_HIP_ENOMEM = -4
 };
 
 typedef struct ofps_hip_ctx ofps_hip_ctx;
@@ -67,7 +66,7 @@ int   ofps_hip_sync(ofps_hip_ctx* ctx);
 /* Diagnostic / A-B switches (table in INTEGRATION.md).  `name` is the switch's environment-variable name, e.g.
  * "OFPS_HIP_ALMEIDA_HIER"; value NULL or "" restores the default.  ofps_hip_init reads the same variables from the
  * environment ONCE; no other entry point looks at the environment.  The fault injectors
- * (OFPS_HIP_ALMEIDA_TEST_FAULT, OFPS_HIP_LK_TEST_FALL, OFPS_HIP_LK_TEST_WAIT_BUDGET) exist only in libofps_hip_testhooks.so (built with
+ * (OFPS_HIP_ALMEIDA_TEST_FAULT, OFPS_HIP_LK_TEST_FALL, OFPS_HIP_LK_TEST_WAIT_BUDGET, OFPS_HIP_LK_TEST_ORDER) exist only in libofps_hip_testhooks.so (built with
  * -DOFPS_HIP_TEST_HOOKS, used by the parity tests), can only be armed through this call, and are refused with
  * OFPS_HIP_EUNSUPPORTED by the product library. */
 int   ofps_hip_set_option(ofps_hip_ctx* ctx, const char* name, const char* value);
@@ -128,19 +127,14 @@ int ofps_hip_lk_flow(ofps_hip_ctx* ctx, const uint8_t* prev, const uint8_t* cur,
  * sample, the residual sums and the structure tensor (the default), 1 = separate multiply and add (-DOFPS_LK_SPEC_FMA=0,
  * A/B builds).  The oracle exports the same number (orc_lk_spec_revision); the parity tests assert they agree. */
 int ofps_hip_lk_spec_revision(void);
-/* Diagnostics (synchronises): the flow runs its whole pyramid as ONE launch in which a tile waits -- bounded, ~0.3 s -- for its parent
- * tile of the coarser level to publish its flows; a wait that expired (it cannot while workgroups are dispatched in block order: an
- * assumption about the dispatcher, INTEGRATION.md "Forward progress") is counted here since the flag buffer was last allocated.
- * The entry points that hand results to the HOST (ofps_hip_lk_flow, ofps_hip_lk_decode, ofps_hip_lk_push_frame,
- * ofps_hip_lk_frame_wait) see, with their results, whether THEIR launch had an expired wait (each call compares with its own
- * launch's epoch) and, if so, repeat the call with one launch per pyramid level (nothing waits there) before they return: their
- * results always had all their dependencies, and ofps_hip_lk_recoveries counts the repeats.  The device-pointer entry points
- * (ofps_hip_lk_flow_dev, ofps_hip_lk_flow_init_dev) return before anything ran: the next ofps_hip_sync() returns OFPS_HIP_ESTALE
- * -- once -- when one of their launches since the previous ofps_hip_sync had an expired wait; the caller repeats those calls
- * (or sets OFPS_HIP_LK_SERIAL=1).  A caller that synchronises its own stream instead checks this count (unchanged = every flow
- * since had its dependencies).  The counterpart of ofps_hip_almeida_recoveries for the other spin-waiting kernel. */
-int ofps_hip_lk_wait_timeouts(ofps_hip_ctx* ctx, uint64_t* count);
-int ofps_hip_lk_recoveries(ofps_hip_ctx* ctx, uint64_t* count);
+/* The flow runs its whole pyramid as ONE launch in which a tile waits for its parent tile of the coarser level to publish its flows.
+ * Forward progress does not depend on how the device schedules the launch: a tile whose parent has not published within 0.3 ms computes the
+ * missing ancestors itself (a tile's flows are a pure function of the frames: computed twice they are written twice with the same bits), so
+ * every workgroup finishes in bounded time in any dispatch order, with any number of resident workgroups, on a CU-masked stream -- and no
+ * flow is ever made from an unfinished parent.  Diagnostics (synchronises): how many tiles a waiting child computed since the flag buffer
+ * was last allocated -- 0 on a whole device with an in-order dispatcher; a non-zero count costs time, never bits.  OFPS_HIP_LK_SERIAL=1 runs
+ * one launch per pyramid level instead (A/B runs). */
+int ofps_hip_lk_helped_tiles(ofps_hip_ctx* ctx, uint64_t* count);
 /* ---- cv-decoder's frame front-end (cv-decoder/src/lib.rs:98-135): capped grid, resize(INTER_LINEAR), cvt_color(BGR2GRAY) ----
  * OpenCV's 8-bit arithmetic restated integer for integer (oracle/frontend_oracle.c names the sources; "parity unpinned": OpenCV is not vendored
  * by the reference): 11-bit bilinear coefficients with half-pixel centres, the horizontal edge rule, the uchar vertical pass

@@ -47,8 +47,7 @@ PROTOTYPES = {
     "ofps_hip_farneback_flow": (C.c_int, [_ctx, _u8p, _u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _f32p, _f32p, _f32p]),
     "ofps_hip_farneback_flow_dev": (C.c_int, [_ctx, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _vp, _vp, _vp]),
     "ofps_hip_lk_spec_revision": (C.c_int, []),
-    "ofps_hip_lk_wait_timeouts": (C.c_int, [_ctx, C.POINTER(C.c_uint64)]),
-    "ofps_hip_lk_recoveries": (C.c_int, [_ctx, C.POINTER(C.c_uint64)]),
+    "ofps_hip_lk_helped_tiles": (C.c_int, [_ctx, C.POINTER(C.c_uint64)]),
     "ofps_hip_flow_cache_hits": (C.c_int, [_ctx, C.POINTER(C.c_uint64)]),
     "ofps_hip_frame_channels": (C.c_int, [C.c_int]),
     "ofps_hip_cv_grid": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),

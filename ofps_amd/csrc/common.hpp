@@ -37,7 +37,8 @@ struct ofps_hip_ctx {
         // through ofps_hip_set_option -- never from the environment
         int test_almeida_fault = 0;      // OFPS_HIP_ALMEIDA_TEST_FAULT: workgroup (value - 1) withholds its step-3 granule
         int test_lk_fall = -1;           // OFPS_HIP_LK_TEST_FALL: every other tile hands over at this step
-        int test_lk_wait_budget = 0;     // OFPS_HIP_LK_TEST_WAIT_BUDGET: polls a tile spends on its parent's flag (0 = the product's 2^18)
+        int test_lk_wait_budget = 0;     // OFPS_HIP_LK_TEST_WAIT_BUDGET: 100 MHz ticks a tile waits for its parent's flag before it computes its ancestors itself (0 = the product's budget)
+        int test_lk_order = 0;           // OFPS_HIP_LK_TEST_ORDER: the one-launch pyramid's blocks take their positions 1: in reverse, 2: permuted, after random delays
     } opt;
 
     // hip_lk stream state (lk.hip: ofps_hip_lk_push_frame): frame k of the stream lives in slot k % 2 of S_FRAMES
@@ -47,8 +48,6 @@ struct ofps_hip_ctx {
     uint64_t lk_frames_gen = 0;          // generation of the S_LK_FRAMES allocation the count refers to
     uint32_t lk_epoch = 0;               // lk_levels_kernel: tag of the last launch in the tile flags (S_LK_FLAGS)
     uint64_t lk_flags_gen = 0;           // generation of the flag buffer the tags refer to
-    uint32_t lk_dev_unchecked_epoch = 0; // epoch of the first device-pointer LK launch since ofps_hip_sync last looked (0 = none)
-    uint64_t lk_recoveries = 0;          // calls repeated level by level because a wait had expired (ofps_hip_lk_recoveries)
     void* lk_pinned = nullptr;           // page-locked staging for a frame's records + their count (one D2H, one wait)
     size_t lk_pinned_cap = 0;
     // read-ahead form (ofps_hip_lk_push_frame_async / ofps_hip_lk_frame_wait): a ring of three device frame slots, the new frame
@@ -63,11 +62,6 @@ struct ofps_hip_ctx {
         int have_vectors = 0, gw = 0, gh = 0;
         size_t max_records = 0;
         long fixed_count = -1;           // >= 0: the record count is known on the host (per-pixel output without a mask)
-        // what the ticket computed, for the repeat after an expired parent-tile wait (lk.hip: ofps_hip_lk_frame_wait)
-        uint32_t epoch = 0;              // the flow launch's epoch (0: nothing to compare the block's second word with)
-        const uint8_t* d_prev = nullptr; const uint8_t* d_cur = nullptr;
-        int W = 0, H = 0, stride = 0, levels = 0, radius = 0, iters = 0, max_w = 0, max_h = 0;
-        unsigned flags = 0;
     } lk_ticket[kLkTickets];
     long lk_next_ticket = 0;
     // hip_flow in the stream forms (farneback.hip): the pyramid + polynomial expansion of a pair's second frame is the next pair's
@@ -143,7 +137,7 @@ enum ScratchSlot {
     // the estimator's own workspaces: it may run beside the detector (pipeline.hip), so the two share no slot
     S_ALM_PART, S_ALM_STATE, S_ALM_HYP, S_ALM_COUNTS, S_ALM_SEL, S_ALM_SELN, S_ALM_PROF, S_ALM_RECOVER,
     S_LK_FRAMES, S_BATCH_FRAMES, S_BATCH_ENTRIES, S_BATCH_OUT, S_BATCH_FIELD,
-    // the one-launch LK pyramid's tile flags + expired-wait counter: they carry state ACROSS calls (epoch tags, never cleared), so the slot
+    // the one-launch LK pyramid's tile flags + helped-tile counter: they carry state ACROSS calls (epoch tags, never cleared), so the slot
     // is nobody else's (round 4: they sat in S_WORK3, which the densifier's per-cell tables also use -- a decode call wiped the counter,
     // and a begin[] value equal to a later launch's epoch would have read as "parent tile done")
     S_LK_FLAGS,
@@ -186,7 +180,7 @@ int densify_entries_device(ofps_hip_ctx* ctx, const float4* d_entries, size_t n,
 int densify_raster_device(ofps_hip_ctx* ctx, const float4* d_entries, const uint8_t* d_mask, int W, int H, int w, int h,
                           float2* d_field, uint32_t** out_begin, uint32_t** out_end, float4* d_xmajor = nullptr);
 int densify_raster_entries_device(ofps_hip_ctx* ctx, const float4* d_entries, const uint8_t* d_mask, int W, int H, int w, int h,
-                                  float2* d_field, float4* d_out_entries, uint32_t* d_count, const uint32_t* d_aux = nullptr);
+                                  float2* d_field, float4* d_out_entries, uint32_t* d_count);
 // frontend.hip: cv-decoder's capped grid (cv-decoder/src/lib.rs:98-121) and its per-frame [resize ->] gray step (:124-135)
 int frame_format_channels(int fmt);
 void cv_grid(int W, int H, int max_w, int max_h, int* gw, int* gh);
@@ -201,7 +195,6 @@ int farneback_flow_device(ofps_hip_ctx* ctx, const uint8_t* d_prev, const uint8_
                           int iters, int poly_n, double poly_sigma, const float2* d_init, float2* d_flow, float4* d_entries,
                           uint64_t prev_id = 0, uint64_t cur_id = 0);     // ids != 0: frames of a stream (ofps_hip_ctx::fb_cache)
 int farneback_check_params(ofps_hip_ctx* ctx, int W, int H, int levels, int winsize, int poly_n);       // what farneback_flow_device would refuse, without running it
-int lk_check_dev_calls(ofps_hip_ctx* ctx);          // lk.hip: did a device-pointer LK launch since the last look have an expired wait?
 int almeida_device(ofps_hip_ctx* ctx, const float4* d_entries, size_t n, int batch, float aspect, float fov_y_deg,
                    int use_ransac, size_t num_iters, float inlier_deg, size_t num_samples, uint64_t seed, float4* d_quat);
 

@@ -82,11 +82,12 @@ int apply_option(ofps_hip_ctx* ctx, const char* name, const char* value, bool fr
     } else if (!strcmp(name, "OFPS_HIP_LK_SERIAL")) {
         o.lk_serial = unset ? 0 : (iv != 0);
     } else if (!strcmp(name, "OFPS_HIP_ALMEIDA_TEST_FAULT") || !strcmp(name, "OFPS_HIP_LK_TEST_FALL") ||
-               !strcmp(name, "OFPS_HIP_LK_TEST_WAIT_BUDGET")) {
+               !strcmp(name, "OFPS_HIP_LK_TEST_WAIT_BUDGET") || !strcmp(name, "OFPS_HIP_LK_TEST_ORDER")) {
 #ifdef OFPS_HIP_TEST_HOOKS
         if (from_env) return OFPS_HIP_OK;                    // fault injectors are never armed from the environment
         if (!strcmp(name, "OFPS_HIP_ALMEIDA_TEST_FAULT")) o.test_almeida_fault = unset ? 0 : iv;
         else if (!strcmp(name, "OFPS_HIP_LK_TEST_WAIT_BUDGET")) o.test_lk_wait_budget = unset || iv < 0 ? 0 : iv;
+        else if (!strcmp(name, "OFPS_HIP_LK_TEST_ORDER")) o.test_lk_order = unset || iv < 0 || iv > 2 ? 0 : iv;
         else o.test_lk_fall = unset ? -1 : iv;
 #else
         if (from_env) return OFPS_HIP_OK;
@@ -253,8 +254,7 @@ int ofps_hip_sync(ofps_hip_ctx* ctx) {
     if (!ctx) return OFPS_HIP_EINVAL;
     OFPS_HIP_TRY(ctx, hipSetDevice(ctx->device));
     OFPS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    // device-pointer LK calls cannot repair an expired parent-tile wait themselves: reported here, once (OFPS_HIP_ESTALE)
-    return ofps::lk_check_dev_calls(ctx);
+    return OFPS_HIP_OK;
 }
 
 int ofps_hip_malloc(ofps_hip_ctx* ctx, size_t bytes, void** dptr) {

@@ -453,7 +453,7 @@ __global__ __launch_bounds__(256) void raster_cell_sum_kernel(const float4* __re
 // workgroup per 1,024 cells: it counts the visited cells before its chunk itself (flags of at most 64 K cells: a few loads per thread),
 // so the chunks' records -- usually headed for a page-locked host block -- leave from several CUs at once instead of one.
 __global__ __launch_bounds__(1024) void cells_to_entries_x_kernel(const float4* __restrict__ xmajor, int w, int h, float4* __restrict__ out_entries,
-                                                                  uint32_t* __restrict__ out_count, const uint32_t* __restrict__ aux_src) {
+                                                                  uint32_t* __restrict__ out_count) {
     __shared__ uint32_t wave_cnt[2][16];
     const size_t cells = (size_t)w * h;
     const float nx = 1.0f / (float)w, ny = 1.0f / (float)h;
@@ -477,7 +477,7 @@ __global__ __launch_bounds__(1024) void cells_to_entries_x_kernel(const float4* 
         const uint32_t pos = base + before + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
         out_entries[pos] = make_float4(((float)x + 0.5f) * nx, ((float)y + 0.5f) * ny, v.x, v.y);
     }
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) { out_count[0] = base + total; if (aux_src) out_count[1] = *aux_src; }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) out_count[0] = base + total;
 }
 
 // test aid: does every record sit where the rectangle walk assumes?  flag[0] counts records whose stored position maps
@@ -501,9 +501,7 @@ __global__ __launch_bounds__(1024) void cells_to_entries_kernel(const float2* __
                                                                 const uint32_t* __restrict__ cell_begin,
                                                                 const uint32_t* __restrict__ cell_end, int w, int h,
                                                                 float4* __restrict__ out_entries,
-                                                                uint32_t* __restrict__ out_count,
-                                                                const uint32_t* __restrict__ aux_src = nullptr) {
-    // (aux_src: one more word copied to out_count[1] -- the hip_lk decoder's expired-wait counter travels with the count)
+                                                                uint32_t* __restrict__ out_count) {
     // ordered compaction, 1024 cells per round: rank inside the wave from a ballot, the 16 wave totals through LDS
     // (two barriers per round; a 10-step scan over the workgroup with its 20 barriers took 37 us at 150 x 84)
     __shared__ uint32_t wave_cnt[2][16];
@@ -532,7 +530,7 @@ __global__ __launch_bounds__(1024) void cells_to_entries_kernel(const float2* __
         }
         base += total;
     }
-    if (threadIdx.x == 0) { out_count[item] = base; if (aux_src) out_count[1] = *aux_src; }
+    if (threadIdx.x == 0) out_count[item] = base;
 }
 
 // MotionFieldDensifier::interpolate_empty_cells (motion_field.rs:193-294) + MotionField::from.
@@ -745,14 +743,14 @@ int densify_raster_device(ofps_hip_ctx* ctx, const float4* d_entries, const uint
 }
 
 int densify_raster_entries_device(ofps_hip_ctx* ctx, const float4* d_entries, const uint8_t* d_mask, int W, int H, int w, int h,
-                                  float2* d_field, float4* d_out_entries, uint32_t* d_count, const uint32_t* d_aux) {
+                                  float2* d_field, float4* d_out_entries, uint32_t* d_count) {
     uint32_t *begin = nullptr, *end = nullptr;
     auto* xmajor = static_cast<float4*>(scratch(ctx, S_XMAJOR, (size_t)w * h * sizeof(float4)));
     if (!xmajor) return OFPS_HIP_ENOMEM;
     int rc = densify_raster_device(ctx, d_entries, d_mask, W, H, w, h, d_field, &begin, &end, xmajor);
     if (rc != OFPS_HIP_OK) return rc;
     hipLaunchKernelGGL(cells_to_entries_x_kernel, dim3((unsigned)(((size_t)w * h + 1023) / 1024)), dim3(1024), 0, ctx->stream, (const float4*)xmajor, w, h,
-                       d_out_entries, d_count, d_aux);
+                       d_out_entries, d_count);
     OFPS_HIP_TRY(ctx, hipGetLastError());
     return OFPS_HIP_OK;
 }

@@ -936,11 +936,12 @@ __device__ __forceinline__ void lk_store(const float2 out, int x, int y, int w, 
 // U8 = true (level 0): I_ / J_ are the u8 frames themselves, rows src_stride bytes apart; no f32 level-0 planes and no
 // level-0 gradient planes exist (lk_stage3_u8; the rectangle is converted while it is staged).
 constexpr int kLkMaxRounds = 8;
-template <int RADIUS, bool U8>
+constexpr long long kLkHelpAfterTicks = 15000;      // wall_clock64 ticks (100 MHz) per ancestor level a tile waits for its parent before it computes it itself
+template <int RADIUS, bool U8, typename HelpFn>
 __device__ __forceinline__ void lk_level_body(LkStepShared<RADIUS>& sh, const void* __restrict__ I_, const void* __restrict__ J_, int src_stride,
                                               int w, int h, int iters, const LkFlowIO io, unsigned long long* __restrict__ prof,
                                               int force_fall_arg, int tile_x, int tile_y, const uint32_t* parent_flag, uint32_t* done_flag,
-                                              uint32_t epoch, uint32_t* timeouts, int wait_budget_arg) {
+                                              uint32_t epoch, int wait_budget_arg, int depth, HelpFn help_ancestors) {
     // force_fall (libofps_hip_testhooks.so only; compiled out of the product library): low 4 bits = a step at which every
     // other tile is treated as not fitting, so that the grouped path in the middle of a level is exercised on inputs that
     // would never trigger it; bits 4.. = how many grouping rounds those tiles get (0 = the default kLkMaxRounds; 1 + n = n
@@ -974,30 +975,35 @@ __device__ __forceinline__ void lk_level_body(LkStepShared<RADIUS>& sh, const vo
     LkU8Regs<RADIUS, TIn> u8g;
     lk_stage3_u8_issue<RADIUS, TIn>(static_cast<const TIn*>(I_), U8 ? src_stride : w, w, h, x0, y0, u8g);
     // One launch runs the whole pyramid (lk_levels_kernel): this tile's starting flows are the results of ONE tile of the next
-    // coarser level (its parent), a workgroup of the same launch with a lower block index.  Thread 0 polls the parent's flag
-    // past the caches until it carries this launch's epoch.  The wait is bounded (~0.3 s): workgroups are dispatched in block
-    // order, so a parent is always resident or done before its children get a slot; should that ever not hold, the tile goes
-    // on with whatever the plane holds instead of hanging the device (a wrong answer a parity check sees, not a hang).
+    // coarser level (its parent), normally a workgroup of the same launch with a lower block index that is running or done.  Thread 0
+    // polls the parent's flag past the caches until it carries this launch's epoch.  FORWARD PROGRESS (round 6) does not depend on that
+    // "normally": a tile whose parent has not published within kLkHelpAfterTicks per ancestor level (0.15 ms each; an in-order launch makes
+    // a tile wait at most about half of that per level) stops waiting and COMPUTES the missing ancestors itself, coarsest first (lk_help_ancestors) -- a tile's flows are a pure
+    // function of the frames, so a tile computed twice is written twice with the same bits and its flag set twice with the same epoch.
+    // Every workgroup therefore finishes in bounded time whatever the dispatcher does (any order, any number of resident workgroups, a
+    // CU-masked stream), and no flow is ever made from an unfinished parent.  Rounds 4-5 went on "with whatever the plane holds" and
+    // left the repeat to the host.
     if (parent_flag) {                                                   // uniform
+        __shared__ int s_help;
         if (threadIdx.x == 0) {
             uint32_t v;
-#ifdef OFPS_HIP_TEST_HOOKS                       // OFPS_HIP_LK_TEST_WAIT_BUDGET: a budget of one poll makes most waits expire (the recovery's test)
-            int budget = wait_budget_arg > 0 ? wait_budget_arg : 1 << 18;
+#ifdef OFPS_HIP_TEST_HOOKS                       // OFPS_HIP_LK_TEST_WAIT_BUDGET: a budget of one tick makes most tiles compute their ancestors themselves
+            const long long budget = wait_budget_arg > 0 ? wait_budget_arg : kLkHelpAfterTicks * depth;
 #else
-            int budget = 1 << 18;
+            const long long budget = kLkHelpAfterTicks * depth;
 #endif
-            do {
+            const long long t_start = wall_clock64();                    // 100 MHz
+            int help = 0;
+            for (;;) {
                 asm volatile("global_load_dword %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(parent_flag) : "memory");
                 if (v == epoch) break;
+                if (wall_clock64() - t_start >= budget) { help = 1; break; }
                 __builtin_amdgcn_s_sleep(16);
-            } while (--budget);
-            // never silent: counted (ofps_hip_lk_wait_timeouts); the host-output entry points see the count with their results and
-            // repeat the call level by level (lk_flow_device: serial), the device-pointer ones document the check
-            // word 0: running count (diagnostics); word 1: the epoch of the newest launch in which a wait expired -- what a call
-            // compares with ITS launch's epoch, so concurrent tickets and calls never share a watermark
-            if (!budget && timeouts) { atomicAdd(timeouts, 1u); atomicMax(timeouts + 1, epoch); }
+            }
+            s_help = help;
         }
         __syncthreads();
+        if (s_help) help_ancestors();                                    // uniform; rare
     }
     float2 f[PP];
 #pragma unroll
@@ -1520,13 +1526,59 @@ struct LkLevelsArgs {
     int levels, iters, force_fall, wait_budget;
     uint32_t epoch;
     uint32_t* flags;
+    int test_order;               // libofps_hip_testhooks.so only: 1 = blocks take the positions in reverse, 2 = permuted (test_mul, test_add)
+    unsigned test_mul, test_add;
     unsigned long long* prof;
     LkLevelArgs lv[8];            // lv[0] = the coarsest level ... lv[levels - 1] = level 0
 };
+// The missing ancestors of tile (tx, ty) of level index k (lv[0] = the coarsest), computed by the waiting workgroup itself: thread 0 climbs
+// from the grandparent up while the flags are not this launch's (one look each), then the tiles are made coarsest first -- each one's
+// parent is done by then -- and published like any other.  Not inlined: the cold path must not cost the level kernel registers.  A: the
+// kernel's own argument segment (the level table is read from there).
+template <int RADIUS>
+__device__ __noinline__ void lk_help_ancestors(LkStepShared<RADIUS>* sh, const LkLevelsArgs* A, int k, int tx, int ty) {
+    uint32_t* const flags = A->flags;
+    const uint32_t epoch = A->epoch;
+    __shared__ int s_from;
+    if (threadIdx.x == 0) {
+        int from = k - 1;                                                // (the parent: the caller's wait has just expired)
+        for (int j = k - 2; j >= 0; --j) {
+            const uint32_t* fl = flags + A->lv[j].flag_off + (size_t)(ty >> (k - j)) * A->lv[j].tiles_x + (tx >> (k - j));
+            uint32_t v;
+            asm volatile("global_load_dword %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(fl) : "memory");
+            if (v == epoch) break;
+            from = j;
+        }
+        s_from = from;
+        atomicAdd(flags, (uint32_t)(k - from));                          // diagnostics (ofps_hip_lk_helped_tiles): tiles computed by a waiting child
+    }
+    __syncthreads();
+    const int from = s_from;
+    for (int j = from; j < k; ++j) {
+        const int ax = tx >> (k - j), ay = ty >> (k - j);
+        uint32_t* done = flags + A->lv[j].flag_off + (size_t)ay * A->lv[j].tiles_x + ax;
+        LkFlowIO io = A->lv[j].io;
+        lk_level_body<RADIUS, false>(*sh, A->lv[j].I, A->lv[j].J, A->lv[j].stride, A->lv[j].w, A->lv[j].h, A->iters, io, nullptr, A->force_fall, ax, ay,
+                                     nullptr, done, epoch, 0, 0, [] {});
+        __syncthreads();                                                 // (everybody is done with `sh`)
+    }
+}
+
 template <int RADIUS>
 __global__ __launch_bounds__(256, LkStepShared<RADIUS>::WAVES_PER_SIMD) void lk_levels_kernel(const LkLevelsArgs A) {
     __shared__ LkStepShared<RADIUS> sh;
-    const unsigned b = blockIdx.x;
+    unsigned b = blockIdx.x;
+#ifdef OFPS_HIP_TEST_HOOKS
+    // OFPS_HIP_LK_TEST_ORDER: the launch as another dispatcher would run it -- 1: the blocks take the positions in REVERSE (level 0's tiles
+    // first, the coarsest level last), 2: a pseudo-random permutation of the positions, and every workgroup starts after a pseudo-random delay
+    if (A.test_order == 1) b = gridDim.x - 1 - b;
+    else if (A.test_order == 2) b = (unsigned)(((unsigned long long)b * A.test_mul + A.test_add) % gridDim.x);
+    if (A.test_order) {
+        unsigned hsh = blockIdx.x * 2654435761u;
+        hsh ^= hsh >> 15;
+        for (unsigned i = 0; i < (hsh & 63u); ++i) __builtin_amdgcn_s_sleep(64);
+    }
+#endif
     int k = 0;
 #pragma unroll
     for (int i = 1; i < 8; ++i) k += (i < A.levels && b >= A.lv[i].start) ? 1 : 0;
@@ -1538,12 +1590,11 @@ __global__ __launch_bounds__(256, LkStepShared<RADIUS>::WAVES_PER_SIMD) void lk_
     // the parent: the tile of the next coarser level (lv[k - 1]) that holds this tile's half-resolution pixels
     const uint32_t* parent = k > 0 ? A.flags + A.lv[k - 1].flag_off + (size_t)(ty / 2) * A.lv[k - 1].tiles_x + tx / 2 : nullptr;
     uint32_t* done = k < A.levels - 1 ? A.flags + L.flag_off + (size_t)ty * L.tiles_x + tx : nullptr;
+    auto help = [&] { lk_help_ancestors<RADIUS>(&sh, (const LkLevelsArgs*)__builtin_amdgcn_kernarg_segment_ptr(), k, tx, ty); };   // (the kernel's only argument: offset 0)
     if (L.u8)
-        lk_level_body<RADIUS, true>(sh, L.I, L.J, L.stride, L.w, L.h, A.iters, L.io, A.prof, A.force_fall, tx, ty, parent, done, A.epoch, A.flags,
-                                    A.wait_budget);
+        lk_level_body<RADIUS, true>(sh, L.I, L.J, L.stride, L.w, L.h, A.iters, L.io, A.prof, A.force_fall, tx, ty, parent, done, A.epoch, A.wait_budget, k, help);
     else
-        lk_level_body<RADIUS, false>(sh, L.I, L.J, L.stride, L.w, L.h, A.iters, L.io, nullptr, A.force_fall, tx, ty, parent, done, A.epoch, A.flags,
-                                     A.wait_budget);
+        lk_level_body<RADIUS, false>(sh, L.I, L.J, L.stride, L.w, L.h, A.iters, L.io, nullptr, A.force_fall, tx, ty, parent, done, A.epoch, A.wait_budget, k, help);
 }
 
 // cv-decoder/src/lib.rs:239-243,262-269: per-pixel records, raster order
@@ -1565,7 +1616,7 @@ static dim3 lk_grid_xcd(int w, int h, int tx = 64, int ty = 4) {
 // d_prev/d_cur: u8 luma on the device.  d_flow: W*H float2.  Workspace comes from the context.
 // d_flow (W*H float2) and/or d_entries (W*H float4 records) receive the result; at least one of them.
 int lk_flow_device(ofps_hip_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_cur, int W, int H, int stride, int levels,
-                   int radius, int iters, float2* d_flow, float4* d_entries, const float2* d_init = nullptr, bool force_serial = false) {
+                   int radius, int iters, float2* d_flow, float4* d_entries, const float2* d_init = nullptr) {
     OFPS_REQUIRE(ctx, W >= 1 && H >= 1 && stride >= W, "lk_flow: bad geometry W=%d H=%d stride=%d", W, H, stride);
     OFPS_REQUIRE(ctx, levels >= 1 && levels <= 8 && radius >= 1 && radius <= 15 && iters >= 1 && iters <= 64,
                  "lk_flow: levels=%d radius=%d iters=%d out of range", levels, radius, iters);
@@ -1645,7 +1696,7 @@ int lk_flow_device(ofps_hip_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_cu
         LkLevelsArgs A{};
         A.levels = levels; A.iters = iters; A.force_fall = force_fall; A.prof = prof;
         A.wait_budget = ctx->opt.test_lk_wait_budget;          // 0 in the product library (a test hook of libofps_hip_testhooks.so)
-        unsigned nb = 0, nflags = 2;                                  // word 0 of the flag buffer counts expired waits (ofps_hip_lk_wait_timeouts)
+        unsigned nb = 0, nflags = 2;                                  // word 0 of the flag buffer counts the tiles a waiting child computed itself (ofps_hip_lk_helped_tiles); word 1 spare
         for (int k = 0; k < levels; ++k) {                            // k = 0: the coarsest level
             const int l = levels - 1 - k;
             LkLevelArgs& L = A.lv[k];
@@ -1674,10 +1725,16 @@ int lk_flow_device(ofps_hip_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_cu
             OFPS_HIP_TRY(ctx, hipMemsetAsync(flags, 0, ctx->scratch[S_LK_FLAGS].cap, s));
             ctx->lk_flags_gen = ctx->scratch[S_LK_FLAGS].gen;
             ctx->lk_epoch = 0;
-            ctx->lk_dev_unchecked_epoch = 0;                     // (what the old buffer said about earlier device-pointer calls is gone with it)
         }
         A.epoch = ++ctx->lk_epoch;
         A.flags = flags;
+        A.test_order = ctx->opt.test_lk_order;                   // 0 in the product library
+        if (A.test_order == 2) {                                 // b -> (b * mul + add) mod nb with gcd(mul, nb) = 1: a permutation of the positions
+            unsigned mul = 40503u % nb;
+            auto gcd = [](unsigned a, unsigned b) { while (b) { const unsigned t = a % b; a = b; b = t; } return a; };
+            while (mul < 2 || gcd(mul, nb) != 1) ++mul;
+            A.test_mul = mul; A.test_add = A.epoch * 7919u % nb;
+        }
         auto launch = [&](const LkLevelsArgs& B, unsigned blocks) {
             switch (radius) {
                 case 2: hipLaunchKernelGGL(lk_levels_kernel<2>, dim3(blocks), dim3(256), 0, s, B); break;
@@ -1685,14 +1742,15 @@ int lk_flow_device(ofps_hip_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_cu
                 default: hipLaunchKernelGGL(lk_levels_kernel<6>, dim3(blocks), dim3(256), 0, s, B); break;
             }
         };
-        if (force_serial || ctx->opt.lk_serial) {
+        if (ctx->opt.lk_serial) {
             // one launch per level, coarsest first: a level's parents are complete before its launch starts, nothing waits on a
-            // flag.  OFPS_HIP_LK_SERIAL for A/B runs, and what a host-output call is repeated with after an expired wait.
+            // flag.  OFPS_HIP_LK_SERIAL, for A/B runs.
             for (int k = 0; k < levels; ++k) {
                 LkLevelsArgs B = A;
                 B.levels = 1;
                 B.lv[0] = A.lv[k];
                 B.lv[0].start = 0;
+                B.test_order = 0;
                 launch(B, A.lv[k].count);
             }
         } else {
@@ -1745,7 +1803,7 @@ extern "C" {
 
 int ofps_hip_lk_spec_revision(void) { return OFPS_LK_SPEC_FMA ? 2 : 1; }
 
-int ofps_hip_lk_wait_timeouts(ofps_hip_ctx* ctx, uint64_t* count) {
+int ofps_hip_lk_helped_tiles(ofps_hip_ctx* ctx, uint64_t* count) {
     if (!ctx || !count) return OFPS_HIP_EINVAL;
     *count = 0;
     const void* d = ctx->scratch[ofps::S_LK_FLAGS].p;
@@ -1758,45 +1816,10 @@ int ofps_hip_lk_wait_timeouts(ofps_hip_ctx* ctx, uint64_t* count) {
     return OFPS_HIP_OK;
 }
 
-}  // extern "C"
-
-namespace ofps {
-// ofps_hip_sync's look at the device-pointer LK calls since the last look (the stream has just been synchronised)
-int lk_check_dev_calls(ofps_hip_ctx* ctx) {
-    const uint32_t first = ctx->lk_dev_unchecked_epoch;
-    if (!first) return OFPS_HIP_OK;
-    ctx->lk_dev_unchecked_epoch = 0;
-    const void* d = ctx->scratch[S_LK_FLAGS].p;
-    if (!d) return OFPS_HIP_OK;
-    uint32_t newest = 0;
-    OFPS_HIP_TRY(ctx, hipMemcpy(&newest, static_cast<const uint32_t*>(d) + 1, sizeof(newest), hipMemcpyDeviceToHost));
-    if (newest >= first)
-        return set_error(ctx, OFPS_HIP_ESTALE, "lk_flow_dev: a parent-tile wait of the one-launch pyramid expired in a launch since the last "
-                         "ofps_hip_sync (launch %u; first unchecked %u): the flow / records of the device-pointer LK calls since then may "
-                         "come from unfinished coarse levels -- repeat them (OFPS_HIP_LK_SERIAL=1 runs one launch per level)", newest, first);
-    return OFPS_HIP_OK;
-}
-}  // namespace ofps
-
-extern "C" {
-
-int ofps_hip_lk_recoveries(ofps_hip_ctx* ctx, uint64_t* count) {
-    if (!ctx || !count) return OFPS_HIP_EINVAL;
-    *count = ctx->lk_recoveries;
-    return OFPS_HIP_OK;
-}
-
-// The device-pointer forms return before anything ran, so an expired parent-tile wait cannot be repaired inside the call the way
-// the host-output forms do it: the first such call since the last check is remembered, and the next ofps_hip_sync() looks at the
-// flag buffer's "newest epoch with an expired wait" and answers OFPS_HIP_ESTALE once if it is one of theirs.
 static int lk_flow_dev_call(ofps_hip_ctx* ctx, const void* d_prev, const void* d_cur, int W, int H, int stride, int levels, int radius,
-                            int iters, const void* d_init, void* d_out_flow, void* d_out_entries) {
-    const int rc = ofps::lk_flow_device(ctx, static_cast<const uint8_t*>(d_prev), static_cast<const uint8_t*>(d_cur), W, H, stride, levels,
-                                        radius, iters, static_cast<float2*>(d_out_flow), static_cast<float4*>(d_out_entries),
-                                        static_cast<const float2*>(d_init));
-    if (rc == OFPS_HIP_OK && (radius == 2 || radius == 4 || radius == 6) && !ctx->opt.lk_serial && !ctx->lk_dev_unchecked_epoch)
-        ctx->lk_dev_unchecked_epoch = ctx->lk_epoch;             // the epoch lk_flow_device just launched with
-    return rc;
+                            int iters, const void* d_init_flow, void* d_out_flow, void* d_out_entries) {
+    return ofps::lk_flow_device(ctx, static_cast<const uint8_t*>(d_prev), static_cast<const uint8_t*>(d_cur), W, H, stride, levels, radius, iters,
+                                static_cast<float2*>(d_out_flow), static_cast<float4*>(d_out_entries), static_cast<const float2*>(d_init_flow));
 }
 
 int ofps_hip_lk_flow_dev(ofps_hip_ctx* ctx, const void* d_prev, const void* d_cur, int W, int H, int stride, int levels,
@@ -1818,9 +1841,9 @@ int ofps_hip_lk_flow_init_dev(ofps_hip_ctx* ctx, const void* d_prev, const void*
 // The body of a "hip_lk" Decoder::process_frame (cv-decoder/src/lib.rs:82-294): dense flow, per-pixel records,
 // optionally filtered by the contrast mask of :203-237 (OFPS_HIP_LK_CONTRAST_MASK, computed on `cur` like the
 // reference's `self.gray`), then either down-sampled through the densifier to the (max_w, max_h)-capped grid of
-// :98-121 with one record per visited cell in BTreeSet<(x,y)> order ("Process Fullres" = true, the default), or
-// returned per pixel in raster order (OFPS_HIP_LK_PER_PIXEL: the `mf.push` branch; the reference resizes its
-// frames to the capped grid first, which is the caller's job here).  Only the final records leave the device.
+// :98-121 with one record per visited cell in BTreeSet<(x,y)> order ("Process Fullres" = true, the default), or -- with
+// OFPS_HIP_LK_REDUCED, "Process Fullres" = false -- computed on frames resized to that grid first (frontend.hip) and returned per pixel
+// of the reduced frame in raster order (the `mf.push` branch, :274-276).  Only the final records leave the device.
 }  // extern "C"
 
 namespace {
@@ -1897,39 +1920,18 @@ int lk_upload_frame(ofps_hip_ctx* ctx, const LkGrid& g, const uint8_t* frame, in
 
 // records 0 .. *d_count - 1 (or n_max when d_count is null) to a device-addressable destination, the count to cnt_dst
 __global__ __launch_bounds__(256) void lk_copy_records_kernel(const float4* __restrict__ src, float4* __restrict__ dst,
-                                                              const uint32_t* __restrict__ d_count, size_t n_max, uint32_t* __restrict__ cnt_dst,
-                                                              const uint32_t* __restrict__ aux_src) {
+                                                              const uint32_t* __restrict__ d_count, size_t n_max, uint32_t* __restrict__ cnt_dst) {
     size_t n = d_count ? (size_t)*d_count : n_max;
     if (n > n_max) n = n_max;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = src[i];
-    if (cnt_dst && blockIdx.x == 0 && threadIdx.x == 0) { *cnt_dst = (uint32_t)n; if (aux_src) cnt_dst[1] = *aux_src; }
-}
-
-// Expired parent-tile waits of the one-launch pyramid (lk_level_body): word 0 of the flag buffer counts them, word 1 holds the epoch
-// of the newest launch in which one expired.  The decoder's last kernel copies word 1 into the second word of the frame's
-// page-locked block; launches of one context run in stream order, so what that kernel reads is >= the epoch of the frame's own
-// launch exactly when that launch had an expired wait.  The host then sees with the records whether the flow that made them may
-// have started a tile from unfinished parent flows -- and repeats the frame level by level if so.  Every call / ticket compares
-// with its own launch's epoch: no watermark shared between calls.
-bool lk_is_tiled(int radius) { return radius == 2 || radius == 4 || radius == 6; }
-const uint32_t* lk_stale_word(ofps_hip_ctx* ctx, int radius) {
-    return lk_is_tiled(radius) ? static_cast<const uint32_t*>(ctx->scratch[ofps::S_LK_FLAGS].p) + 1 : nullptr;
-}
-// `seen`: flag word 1 as the call's results saw it; `epoch`: the call's own launch
-bool lk_waits_expired(uint32_t seen, uint32_t epoch) { return epoch != 0 && seen >= epoch; }
-uint32_t lk_block_waits(const void* pinned) {
-    uint32_t c = 0;
-    memcpy(&c, static_cast<const char*>(pinned) + 4, sizeof(c));
-    return c;
+    if (cnt_dst && blockIdx.x == 0 && threadIdx.x == 0) *cnt_dst = (uint32_t)n;
 }
 
 // Enqueues everything of a process_frame that follows the uploads on ctx->stream: flow [-> contrast mask] -> output stage.
 // The record count lands at cnt_dst and the records at rec_dst -- device scratch, or the device address of a page-locked
 // block (the kernels store there directly: no read-back launch of their own).
-// serial: the pyramid level by level (the repeat after an expired wait).  *epoch: the flow launch's epoch when the block's second
-// word carries flag word 1 (0 otherwise: nothing to compare).
 int lk_enqueue_frame(ofps_hip_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_cur, int W, int H, int levels, int radius, int iters,
-                     const LkGrid& g, float4* rec_dst, uint32_t* cnt_dst, bool serial, uint32_t* epoch, uint64_t prev_id = 0,
+                     const LkGrid& g, float4* rec_dst, uint32_t* cnt_dst, uint64_t prev_id = 0,
                      uint64_t cur_id = 0, const uint8_t* d_mask_ready = nullptr) {
     const size_t px = (size_t)W * H, cells = g.per_pixel ? 1 : (size_t)g.gw * g.gh;
     auto* d_ent = static_cast<float4*>(ofps::scratch(ctx, ofps::S_ENTRIES, px * sizeof(float4)));
@@ -1937,10 +1939,9 @@ int lk_enqueue_frame(ofps_hip_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_
     auto* d_cnt = static_cast<uint32_t*>(ofps::scratch(ctx, ofps::S_RESULT, 16));
     if (!d_ent || !d_field || !d_cnt) return OFPS_HIP_ENOMEM;
     int rc;
-    const uint32_t* d_waits = nullptr;
     if (g.farneback) {
         // cv-decoder's call (cv-decoder/src/lib.rs:188-199): levels = pyramid levels, winsize = 2 * radius + 1, iters = iterations,
-        // poly_n 7, poly_sigma 1.5.  No tile waits on another in this flow: nothing to repair, *epoch = 0.  prev_id / cur_id: the
+        // poly_n 7, poly_sigma 1.5.  prev_id / cur_id: the
         // stream's frame ids -- the first frame's pyramid + expansion are the previous call's (farneback.hip)
         // OFPS_HIP_FLOW_USE_PREVIOUS: the flow of the pair that ended with this pair's first frame is the initial flow, and this pair's flow is
         // kept for the next one (read by the coarsest layer's first kernel, written by the last kernel of the call: one buffer)
@@ -1958,12 +1959,9 @@ int lk_enqueue_frame(ofps_hip_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_
         rc = ofps::farneback_flow_device(ctx, d_prev, d_cur, W, H, W, levels, 2 * radius + 1, iters, 7, 1.5, d_init, d_keep, d_ent, prev_id, cur_id);
         if (rc != OFPS_HIP_OK) return rc;
         if (d_keep) { pf.valid = true; pf.id = cur_id; pf.W = W; pf.H = H; pf.gen = ctx->scratch[ofps::S_FB_FLOW].gen; }
-        *epoch = 0;
     } else {
-        rc = ofps::lk_flow_device(ctx, d_prev, d_cur, W, H, W, levels, radius, iters, nullptr, d_ent, nullptr, serial);
+        rc = ofps::lk_flow_device(ctx, d_prev, d_cur, W, H, W, levels, radius, iters, nullptr, d_ent, nullptr);
         if (rc != OFPS_HIP_OK) return rc;
-        d_waits = lk_stale_word(ctx, radius);
-        *epoch = d_waits && !serial && !ctx->opt.lk_serial ? ctx->lk_epoch : 0;
     }
     const uint8_t* d_mask = d_mask_ready;          // (stream forms: made on the upload's stream already, beside the previous pair's flow)
     if (g.use_mask && !d_mask) {
@@ -1983,13 +1981,13 @@ int lk_enqueue_frame(ofps_hip_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_
             if (rc != OFPS_HIP_OK) return rc;
             d_rec = d_ent2; d_n = d_cnt + 1;
         }
-        hipLaunchKernelGGL(lk_copy_records_kernel, dim3(1024), dim3(256), 0, ctx->stream, d_rec, rec_dst, d_n, px, cnt_dst, d_waits);
+        hipLaunchKernelGGL(lk_copy_records_kernel, dim3(1024), dim3(256), 0, ctx->stream, d_rec, rec_dst, d_n, px, cnt_dst);
         OFPS_HIP_TRY(ctx, hipGetLastError());
         return OFPS_HIP_OK;
     }
     // down-sampled output (cv-decoder/src/lib.rs:244-291): the records are this call's own per-pixel lattice, so the
     // densifier walks each cell's rectangle of pixels (masked ones skipped in place) instead of sorting 2 M records
-    return ofps::densify_raster_entries_device(ctx, d_ent, d_mask, W, H, g.gw, g.gh, d_field, rec_dst, cnt_dst, d_waits);
+    return ofps::densify_raster_entries_device(ctx, d_ent, d_mask, W, H, g.gw, g.gh, d_field, rec_dst, cnt_dst);
 }
 
 // a page-locked block [count, pad x 3][records]; grows, never shrinks
@@ -2063,18 +2061,10 @@ int ofps_hip_lk_decode(ofps_hip_ctx* ctx, const uint8_t* prev, const uint8_t* cu
     if (rc != OFPS_HIP_OK) return rc;
     void* mapped = nullptr;
     OFPS_REQUIRE(ctx, ofps::device_address_of(ctx->lk_pinned, &mapped), "lk_decode: page-locked block is not device-addressable");
-    uint32_t epoch = 0;
     rc = lk_enqueue_frame(ctx, d_frames, d_frames + px, g.fw, g.fh, levels, radius, iters, g, reinterpret_cast<float4*>(static_cast<char*>(mapped) + 16),
-                          static_cast<uint32_t*>(mapped), false, &epoch);
+                          static_cast<uint32_t*>(mapped));
     if (rc != OFPS_HIP_OK) return rc;
     OFPS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    if (lk_waits_expired(lk_block_waits(ctx->lk_pinned), epoch)) {        // a tile may have started from unfinished parent flows: level by level
-        rc = lk_enqueue_frame(ctx, d_frames, d_frames + px, g.fw, g.fh, levels, radius, iters, g, reinterpret_cast<float4*>(static_cast<char*>(mapped) + 16),
-                              static_cast<uint32_t*>(mapped), true, &epoch);
-        if (rc != OFPS_HIP_OK) return rc;
-        OFPS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        ctx->lk_recoveries += 1;
-    }
     lk_collect(ctx->lk_pinned, g.max_records, out_entries, n_out);
     if (out_w) *out_w = g.gw;
     if (out_h) *out_h = g.gh;
@@ -2160,17 +2150,14 @@ int ofps_hip_lk_push_frame_async(ofps_hip_ctx* ctx, const uint8_t* frame, int W,
     // frame's slot is simply uploaded again by the next push) -- ADVICE r4
     const long frames_after = ctx->lk_frames + 1;
     int have_vectors = 0;
-    uint32_t epoch = 0;
-    const uint8_t *tp = nullptr, *tc = nullptr;
     if (frames_after >= 2) {                                        // cv-decoder/src/lib.rs:156-158: flow needs two frames
         rc = lk_pinned_block(ctx, &t.pinned, &t.pinned_cap, g.max_records);
         if (rc != OFPS_HIP_OK) return rc;
         void* mapped = nullptr;
         OFPS_REQUIRE(ctx, ofps::device_address_of(t.pinned, &mapped), "lk_push_frame_async: page-locked block is not device-addressable");
         const int prev_slot = (int)((frames_after - 2) % ofps_hip_ctx::kLkSlots);
-        tp = d_frames + (size_t)prev_slot * px; tc = d_frames + (size_t)slot * px;
-        rc = lk_enqueue_frame(ctx, tp, tc, g.fw, g.fh, levels, radius, iters, g,
-                              reinterpret_cast<float4*>(static_cast<char*>(mapped) + 16), static_cast<uint32_t*>(mapped), false, &epoch,
+        rc = lk_enqueue_frame(ctx, d_frames + (size_t)prev_slot * px, d_frames + (size_t)slot * px, g.fw, g.fh, levels, radius, iters, g,
+                              reinterpret_cast<float4*>(static_cast<char*>(mapped) + 16), static_cast<uint32_t*>(mapped),
                               ctx->lk_slot_id[prev_slot], ctx->lk_slot_id[slot], d_mask_ready);
         if (rc != OFPS_HIP_OK) return rc;
         have_vectors = 1;
@@ -2178,10 +2165,6 @@ int ofps_hip_lk_push_frame_async(ofps_hip_ctx* ctx, const uint8_t* frame, int W,
     OFPS_HIP_TRY(ctx, hipEventRecord(t.done, s));
     ctx->lk_frames = frames_after;
     t.have_vectors = have_vectors; t.gw = g.gw; t.gh = g.gh; t.max_records = g.max_records; t.fixed_count = -1;
-    // what a repeat of this ticket needs (ofps_hip_lk_frame_wait, after an expired wait): its two frames stay in the ring
-    // until the ticket after the next one is pushed, which cannot happen before this one is collected
-    t.epoch = epoch; t.d_prev = tp; t.d_cur = tc;
-    t.W = W; t.H = H; t.stride = stride; t.levels = levels; t.radius = radius; t.iters = iters; t.max_w = max_w; t.max_h = max_h; t.flags = flags;
     t.pending = true;
     *ticket = (int)(tno & 0x7FFFFFFF);
     ctx->lk_next_ticket = tno + 1;
@@ -2205,21 +2188,6 @@ int ofps_hip_lk_frame_wait(ofps_hip_ctx* ctx, int ticket, float* out_entries, si
     *have_vectors = t.have_vectors;
     if (out_w) *out_w = t.gw;
     if (out_h) *out_h = t.gh;
-    if (t.have_vectors && lk_waits_expired(lk_block_waits(t.pinned), t.epoch)) {
-        // (the word looked at is the one this ticket's last kernel saw, compared with this ticket's own launch; the repeat below
-        // rewrites the block; a later ticket compares what ITS last kernel saw with ITS epoch)
-        LkGrid g;
-        int rc = lk_grid_of(ctx, t.W, t.H, t.stride, t.max_w, t.max_h, t.flags, &g);
-        if (rc != OFPS_HIP_OK) return rc;
-        void* mapped = nullptr;
-        OFPS_REQUIRE(ctx, ofps::device_address_of(t.pinned, &mapped), "lk_frame_wait: page-locked block is not device-addressable");
-        uint32_t epoch = 0;
-        rc = lk_enqueue_frame(ctx, t.d_prev, t.d_cur, g.fw, g.fh, t.levels, t.radius, t.iters, g,
-                              reinterpret_cast<float4*>(static_cast<char*>(mapped) + 16), static_cast<uint32_t*>(mapped), true, &epoch);
-        if (rc != OFPS_HIP_OK) return rc;
-        OFPS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        ctx->lk_recoveries += 1;
-    }
     if (t.have_vectors) lk_collect(t.pinned, t.max_records, out_entries, n_out);
     return OFPS_HIP_OK;
 }
@@ -2265,24 +2233,9 @@ int ofps_hip_lk_flow(ofps_hip_ctx* ctx, const uint8_t* prev, const uint8_t* cur,
     OFPS_HIP_TRY(ctx, ofps::upload_rows(d_frames + px, W, cur, stride, W, H, ctx->stream));
     int rc = ofps::lk_flow_device(ctx, d_frames, d_frames + px, W, H, W, levels, radius, iters, d_flow, d_ent);
     if (rc != OFPS_HIP_OK) return rc;
-    const uint32_t epoch = lk_is_tiled(radius) && !ctx->opt.lk_serial ? ctx->lk_epoch : 0;     // this call's launch
-    auto read_back = [&](uint32_t* waits) -> int {
-        if (out_flow) OFPS_HIP_TRY(ctx, hipMemcpyAsync(out_flow, d_flow, px * sizeof(float2), hipMemcpyDeviceToHost, ctx->stream));
-        if (out_entries) OFPS_HIP_TRY(ctx, hipMemcpyAsync(out_entries, d_ent, px * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
-        if (waits) OFPS_HIP_TRY(ctx, hipMemcpyAsync(waits, lk_stale_word(ctx, radius), sizeof(*waits), hipMemcpyDeviceToHost, ctx->stream));
-        OFPS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        return OFPS_HIP_OK;
-    };
-    uint32_t waits = 0;
-    rc = read_back(epoch ? &waits : nullptr);
-    if (rc != OFPS_HIP_OK) return rc;
-    if (lk_waits_expired(waits, epoch)) {                     // a tile may have started from unfinished parent flows: level by level
-        rc = ofps::lk_flow_device(ctx, d_frames, d_frames + px, W, H, W, levels, radius, iters, d_flow, d_ent, nullptr, true);
-        if (rc != OFPS_HIP_OK) return rc;
-        rc = read_back(nullptr);
-        if (rc != OFPS_HIP_OK) return rc;
-        ctx->lk_recoveries += 1;
-    }
+    if (out_flow) OFPS_HIP_TRY(ctx, hipMemcpyAsync(out_flow, d_flow, px * sizeof(float2), hipMemcpyDeviceToHost, ctx->stream));
+    if (out_entries) OFPS_HIP_TRY(ctx, hipMemcpyAsync(out_entries, d_ent, px * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
+    OFPS_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return OFPS_HIP_OK;
 }
 

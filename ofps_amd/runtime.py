@@ -168,16 +168,11 @@ class HipContext:
     def lk_spec_revision(self) -> int:
         return int(self._lib.ofps_hip_lk_spec_revision())
 
-    def lk_wait_timeouts(self) -> int:
-        """Expired parent-tile waits of the one-launch pyramid flow on this context (0 = none; diagnostics, synchronises)."""
+    def lk_helped_tiles(self) -> int:
+        """Tiles of the one-launch pyramid flow that a waiting child computed itself on this context (0 on an in-order dispatcher; costs
+        time, never bits; diagnostics, synchronises)."""
         n = C.c_uint64(0)
-        self._check(self._lib.ofps_hip_lk_wait_timeouts(self._h, C.byref(n)))
-        return int(n.value)
-
-    def lk_recoveries(self) -> int:
-        """Host-output LK calls of this context that were repeated level by level because a parent-tile wait had expired."""
-        n = C.c_uint64(0)
-        self._check(self._lib.ofps_hip_lk_recoveries(self._h, C.byref(n)))
+        self._check(self._lib.ofps_hip_lk_helped_tiles(self._h, C.byref(n)))
         return int(n.value)
 
     def flow_cache_hits(self) -> int:

@@ -551,7 +551,7 @@ def test_lk_flow_degenerate_geometries(ctx, W, H, levels, radius):
     f_g, e_g = ctx.lk_flow(fr[0], fr[1], levels, radius, 2, want_entries=True)
     np.testing.assert_array_equal(f_g.view(np.uint32), f_o.view(np.uint32))
     np.testing.assert_array_equal(e_g.view(np.uint32), oracle.flow_to_entries(f_o).view(np.uint32))
-    assert ctx.lk_wait_timeouts() == 0
+    assert ctx.lk_helped_tiles() == 0
 
 
 @pytest.mark.parametrize("fall_step", [0, 1, 2, 16 + 0, 16 + 1, 16 + 2, 32 + 0, 32 + 2, 48 + 1])
@@ -587,38 +587,65 @@ def test_lk_flow_hand_over_in_the_middle_of_a_level(hooks_ctx, fall_step, radius
     np.testing.assert_array_equal(d_ent.cpu().numpy().view(np.uint32), oracle.flow_to_entries(f_o).view(np.uint32))
 
 
-def test_lk_expired_parent_waits_are_repaired_before_results_reach_the_host(hooks_ctx):
-    """The pyramid is one launch in which a tile waits for its parent tile's flows (bounded).  With the hook a tile polls its
-    parent's flag ONCE, so most waits expire and the one-launch flows are wrong; the entry points that hand results to the
-    host see the expired-wait count arrive with the results and repeat the call level by level: same bits as the oracle, the
-    repeat counted -- on the pair call, the decoder call, the synchronous stream and the read-ahead stream."""
+def _cu_masked_stream(n_cus: int):
+    """a HIP stream whose kernels may only use the first n_cus compute units (hipExtStreamCreateWithCUMask)"""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    words = (C.c_uint32 * 8)(*([0] * 8))
+    for cu in range(n_cus):
+        words[cu // 32] |= 1 << (cu % 32)
+    stream = C.c_void_p(0)
+    rc = hip.hipExtStreamCreateWithCUMask(C.byref(stream), 8, words)
+    assert rc == 0, rc
+    return hip, stream
+
+
+@pytest.mark.parametrize("mode", ["budget", "reversed", "permuted", "cu_mask", "cu_mask_permuted"])
+def test_lk_forward_progress_does_not_depend_on_the_dispatcher(hooks_ctx, mode):
+    """The pyramid is ONE launch in which a tile waits for its parent tile's flows; a tile whose parent has not published in time computes
+    the missing ancestors ITSELF (lk_help_ancestors), so every workgroup finishes whatever the dispatcher does and no flow is made from
+    an unfinished parent.  Hooks: a wait budget of one tick (nearly every tile computes its own ancestors), the blocks taking the
+    positions in REVERSE (level 0 first, the coarsest level last) or in a pseudo-random permutation with random start delays; and a
+    stream masked to 32 of the 256 CUs.  Every entry-point form returns the oracle's bits; the helped-tile count says the path ran."""
     ctx = hooks_ctx
     W, H, levels, radius, iters = 640, 360, 3, 4, 3
     fr = synth.luma_sequence(4, W, H, max_step=3, seed=311)
     f_o = oracle.lk_flow(fr[0], fr[1], levels, radius, iters)
+    ctx.lk_reset()
     ref_dec = [ctx.lk_decode(fr[k], fr[k + 1], levels, radius, iters) for k in range(3)]     # undisturbed
-    assert ctx.lk_wait_timeouts() == 0 and ctx.lk_recoveries() == 0
-    ctx.set_option("OFPS_HIP_LK_TEST_WAIT_BUDGET", "1")
+    helped0 = ctx.lk_helped_tiles()
+    hip = stream = None
     try:
-        r0 = ctx.lk_recoveries()
+        if mode == "budget":
+            ctx.set_option("OFPS_HIP_LK_TEST_WAIT_BUDGET", "1")
+        if mode in ("reversed",):
+            ctx.set_option("OFPS_HIP_LK_TEST_ORDER", "1")
+        if mode in ("permuted", "cu_mask_permuted"):
+            ctx.set_option("OFPS_HIP_LK_TEST_ORDER", "2")
+        if mode.startswith("cu_mask"):
+            hip, stream = _cu_masked_stream(32)
+            ctx.set_stream(stream.value)
         f_g, e_g = ctx.lk_flow(fr[0], fr[1], levels, radius, iters, want_entries=True)
         np.testing.assert_array_equal(f_g.view(np.uint32), f_o.view(np.uint32))
         np.testing.assert_array_equal(e_g.view(np.uint32), oracle.flow_to_entries(f_o).view(np.uint32))
-        t1 = ctx.lk_wait_timeouts()
-        assert t1 > 0 and ctx.lk_recoveries() == r0 + 1              # waits did expire, and the call was repeated once
+        if mode == "budget":
+            assert ctx.lk_helped_tiles() > helped0                      # the path under test did run (the other modes need it only when the launch
+                                                                        # exceeds the resident workgroups: the 1080p test below)
+        for rad in (2, 6):                                               # the other tiled kernels
+            np.testing.assert_array_equal(ctx.lk_flow(fr[0], fr[1], levels, rad, 2).view(np.uint32), oracle.lk_flow(fr[0], fr[1], levels, rad, 2).view(np.uint32))
+        # a deeper pyramid: ancestors of ancestors
+        np.testing.assert_array_equal(ctx.lk_flow(fr[1], fr[2], 5, radius, 2).view(np.uint32), oracle.lk_flow(fr[1], fr[2], 5, radius, 2).view(np.uint32))
         ent, grid = ctx.lk_decode(fr[0], fr[1], levels, radius, iters)
         assert grid == ref_dec[0][1]
         np.testing.assert_array_equal(ent.view(np.uint32), ref_dec[0][0].view(np.uint32))
-        assert ctx.lk_recoveries() == r0 + 2
         # synchronous stream form
         ctx.lk_reset()
         assert ctx.lk_push_frame(fr[0], levels, radius, iters) is None
         for k in range(1, 4):
             ent, grid = ctx.lk_push_frame(fr[k], levels, radius, iters)
             np.testing.assert_array_equal(ent.view(np.uint32), ref_dec[k - 1][0].view(np.uint32))
-        # read-ahead form, two tickets in flight: every ticket notices its own launch's expired waits
+        # read-ahead form, two tickets in flight
         ctx.lk_reset()
-        r1 = ctx.lk_recoveries()
         pins = [ctx.pinned_frame(H, W) for _ in range(4)]
         for k in range(4): np.copyto(pins[k], fr[k])
         tickets = [ctx.lk_push_frame_async(pins[0], levels, radius, iters), ctx.lk_push_frame_async(pins[1], levels, radius, iters)]
@@ -631,63 +658,50 @@ def test_lk_expired_parent_waits_are_repaired_before_results_reach_the_host(hook
         assert got[0] is None
         for k in range(1, 4):
             np.testing.assert_array_equal(got[k][0].view(np.uint32), ref_dec[k - 1][0].view(np.uint32))
-        assert ctx.lk_recoveries() == r1 + 3
-        # the ADVICE r4 interleaving: ticket A's launch has expired waits; a decode call queued behind it notices ITS OWN launch's
-        # (and only those), and A still notices A's when it is collected -- no watermark shared between calls
         ctx.lk_reset()
-        r2 = ctx.lk_recoveries()
-        ta0 = ctx.lk_push_frame_async(pins[0], levels, radius, iters)
-        ta = ctx.lk_push_frame_async(pins[1], levels, radius, iters)
-        ent, grid = ctx.lk_decode(fr[1], fr[2], levels, radius, iters)
-        np.testing.assert_array_equal(ent.view(np.uint32), ref_dec[1][0].view(np.uint32))
-        assert ctx.lk_recoveries() == r2 + 1
-        assert ctx.lk_frame_wait(ta0) is None
-        got_a = ctx.lk_frame_wait(ta)
-        np.testing.assert_array_equal(got_a[0].view(np.uint32), ref_dec[0][0].view(np.uint32))
-        assert ctx.lk_recoveries() == r2 + 2
-        # the device-pointer entry point returns before anything ran: the next ofps_hip_sync answers OFPS_HIP_ESTALE, once
-        import torch
-        from ofps_amd.runtime import OfpsHipError
-        dfr = torch.from_numpy(fr[:2]).cuda()
-        d_ent = torch.zeros((W * H, 4), dtype=torch.float32, device="cuda")
-        ctx.use_torch_stream()
-        try:
-            ctx.lk_flow_dev(dfr[0].data_ptr(), dfr[1].data_ptr(), W, H, W, levels, radius, iters, None, d_ent.data_ptr())
-            with pytest.raises(OfpsHipError) as ei:
+        # the device-pointer entry point: nothing to repair afterwards, the sync is clean and the records are the oracle's
+        if not mode.startswith("cu_mask"):
+            import torch
+            dfr = torch.from_numpy(fr[:2]).cuda()
+            d_ent = torch.zeros((W * H, 4), dtype=torch.float32, device="cuda")
+            ctx.use_torch_stream()
+            try:
+                ctx.lk_flow_dev(dfr[0].data_ptr(), dfr[1].data_ptr(), W, H, W, levels, radius, iters, None, d_ent.data_ptr())
                 ctx.sync()
-            assert ei.value.code == -5 and "expired" in str(ei.value)            # OFPS_HIP_ESTALE
-            ctx.sync()                                                           # reported once
-            assert ctx.lk_wait_timeouts() > t1
-            # the repeat the message asks for, level by level: the oracle's bits, and the sync after it is clean
-            ctx.set_option("OFPS_HIP_LK_SERIAL", "1")
-            ctx.lk_flow_dev(dfr[0].data_ptr(), dfr[1].data_ptr(), W, H, W, levels, radius, iters, None, d_ent.data_ptr())
-            ctx.set_option("OFPS_HIP_LK_SERIAL", None)
-            ctx.sync()
+            finally:
+                ctx.use_own_stream()
             np.testing.assert_array_equal(d_ent.cpu().numpy().view(np.uint32), oracle.flow_to_entries(f_o).view(np.uint32))
-        finally:
-            ctx.set_option("OFPS_HIP_LK_SERIAL", None)
-            ctx.use_own_stream()
     finally:
         ctx.set_option("OFPS_HIP_LK_TEST_WAIT_BUDGET", None)
+        ctx.set_option("OFPS_HIP_LK_TEST_ORDER", None)
+        ctx.use_own_stream()
         ctx.lk_reset()
-    # the hook is off: every call compares with its own launch's epoch, so the expired waits of earlier launches (the device-pointer
-    # call's included) cost nothing now -- one launch per call, nothing to repair, the count stands still
-    before, waits = ctx.lk_recoveries(), ctx.lk_wait_timeouts()
+        if stream is not None:
+            hip.hipStreamDestroy(stream)
+    # hooks off, whole device: an in-order launch needs no help
+    before = ctx.lk_helped_tiles()
     f_g = ctx.lk_flow(fr[0], fr[1], levels, radius, iters)
     np.testing.assert_array_equal(f_g.view(np.uint32), f_o.view(np.uint32))
-    ent, grid = ctx.lk_decode(fr[0], fr[1], levels, radius, iters)
-    np.testing.assert_array_equal(ent.view(np.uint32), ref_dec[0][0].view(np.uint32))
-    assert ctx.lk_recoveries() == before and ctx.lk_wait_timeouts() == waits
-    import torch
-    dfr = torch.from_numpy(fr[:2]).cuda()
-    d_ent = torch.zeros((W * H, 4), dtype=torch.float32, device="cuda")
-    ctx.use_torch_stream()
+    assert ctx.lk_helped_tiles() == before
+
+
+def test_lk_forward_progress_1080p_reversed_positions(hooks_ctx):
+    """BASELINE's size with the worst start order (level 0's 4,050 tiles before their parents): every level-0 tile computes its two
+    ancestors itself -- three times the work, the same bits."""
+    ctx = hooks_ctx
+    fr = synth.luma_sequence(2, 1920, 1080, max_step=3, seed=11)
+    f_o = oracle.lk_flow(fr[0], fr[1], 3, 4, 3)
+    np.testing.assert_array_equal(ctx.lk_flow(fr[0], fr[1], 3, 4, 3).view(np.uint32), f_o.view(np.uint32))     # (allocates the flag buffer: the count restarts)
+    assert ctx.lk_helped_tiles() == 0                                   # in order: nobody needs help
+    ctx.set_option("OFPS_HIP_LK_TEST_ORDER", "1")
     try:
-        ctx.lk_flow_dev(dfr[0].data_ptr(), dfr[1].data_ptr(), W, H, W, levels, radius, iters, None, d_ent.data_ptr())
-        ctx.sync()                                                               # clean: OFPS_HIP_OK
+        f_g = ctx.lk_flow(fr[0], fr[1], 3, 4, 3)
+        helped = ctx.lk_helped_tiles()
+        print(f"1080p, positions reversed: {helped} ancestor tiles computed by waiting children (the pyramid has {272 + 1020} of them)")
+        assert helped > 1000
     finally:
-        ctx.use_own_stream()
-    np.testing.assert_array_equal(d_ent.cpu().numpy().view(np.uint32), oracle.flow_to_entries(f_o).view(np.uint32))
+        ctx.set_option("OFPS_HIP_LK_TEST_ORDER", None)
+    np.testing.assert_array_equal(f_g.view(np.uint32), f_o.view(np.uint32))
 
 
 def test_lk_read_ahead_refuses_a_geometry_change_with_a_ticket_in_flight(ctx):
@@ -728,7 +742,7 @@ def test_lk_tile_flags_are_nobodys_scratch(ctx):
         ctx.densify(e, 16, 9)
         f_g = ctx.lk_flow(fr[0], fr[1], 3, 4, 2)
         np.testing.assert_array_equal(f_g.view(np.uint32), f_o.view(np.uint32))
-    assert ctx.lk_wait_timeouts() == 0
+    assert ctx.lk_helped_tiles() == 0
 
 
 @pytest.mark.parametrize("radius", [2, 4, 6])
@@ -745,7 +759,7 @@ def test_lk_one_launch_per_level_gives_the_same_bits(ctx, radius):
     np.testing.assert_array_equal(f_ser.view(np.uint32), f_one.view(np.uint32))
     np.testing.assert_array_equal(e_ser.view(np.uint32), e_one.view(np.uint32))
     np.testing.assert_array_equal(f_ser.view(np.uint32), oracle.lk_flow(fr[0], fr[1], levels, radius, iters).view(np.uint32))
-    assert ctx.lk_wait_timeouts() == 0 and ctx.lk_recoveries() == 0
+    assert ctx.lk_helped_tiles() == 0
 
 
 def test_lk_flow_on_a_smooth_subpixel_camera_warp(ctx):

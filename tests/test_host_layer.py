@@ -380,16 +380,16 @@ bad = 0
 for k in range(int(sys.argv[4])):
     f = ctx.lk_flow(fr[0], fr[1], 3, 4, 3)
     bad += int((f.view(np.uint32) != want.view(np.uint32)).any())
-print(json.dumps({"runs": int(sys.argv[4]), "mismatching_runs": bad, "wait_timeouts": ctx.lk_wait_timeouts()}))
+print(json.dumps({"runs": int(sys.argv[4]), "mismatching_runs": bad, "helped_tiles": ctx.lk_helped_tiles()}))
 """
 
 
 @pytest.mark.gpu
 def test_two_processes_running_the_one_launch_pyramid_flow_get_the_oracles_bits(tmp_path):
-    """lk_levels_kernel runs the whole pyramid in one launch: a tile spins (bounded) until its parent tile of the coarser level --
-    a workgroup of the same launch -- has published its flows.  Two PROCESSES running 1080p flows back to back on one GPU share its
-    CUs, so each launch's workgroups become resident in whatever order the two launches interleave; whatever happens, every run of
-    either process returns the oracle's flow bit for bit (a spin that expired would show as a mismatch, not as a hang)."""
+    """lk_levels_kernel runs the whole pyramid in one launch: a tile waits until its parent tile of the coarser level -- a workgroup
+    of the same launch -- has published its flows, and computes it itself when that takes too long.  Two PROCESSES running 1080p flows
+    back to back on one GPU share its CUs, so each launch's workgroups become resident in whatever order the two launches interleave;
+    whatever happens, every run of either process returns the oracle's flow bit for bit (helped tiles cost time, never bits)."""
     import sys
     import oracle
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -403,7 +403,7 @@ def test_two_processes_running_the_one_launch_pyramid_flow_get_the_oracles_bits(
     for p, (so, se) in zip(procs, outs):
         assert p.returncode == 0, se[-1500:]
         r = json.loads(so.strip().splitlines()[-1])
-        assert r["runs"] == 40 and r["mismatching_runs"] == 0 and r["wait_timeouts"] == 0, r
+        assert r["runs"] == 40 and r["mismatching_runs"] == 0, r
 
 
 @pytest.mark.gpu

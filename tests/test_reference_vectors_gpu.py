@@ -112,7 +112,7 @@ def test_hip_lk_flow_1080p_large_motion_and_flat_areas(ctx):
     f_o = oracle.lk_flow(fr[0], fr[1], 3, 4, 3)
     f_g = ctx.lk_flow(fr[0], fr[1], 3, 4, 3)
     np.testing.assert_array_equal(f_g.view(np.uint32), f_o.view(np.uint32))
-    assert ctx.lk_wait_timeouts() == 0          # every tile of every flow on this context found its parent tile's flows in time
+    assert ctx.lk_helped_tiles() == 0          # every tile of every flow on this context found its parent tile's flows in time
 
 
 # ---- BASELINE configs[4] at full size: the fused per-frame path on 1080p frames ---------------------------------------

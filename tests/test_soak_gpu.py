@@ -18,7 +18,7 @@ def _run(tool, *args, env=None):
 
 def test_lk_read_ahead_stream_soak_with_other_stages_in_between():
     r = _run("lk_soak.py", "400")
-    assert r.returncode == 0 and "mismatching frames 0, expired waits 0, repeats 0" in r.stdout, r.stdout + r.stderr
+    assert r.returncode == 0 and "mismatching frames 0, tiles computed by a waiting child 0" in r.stdout, r.stdout + r.stderr
 
 
 def test_fused_per_frame_stream_soak_with_other_entry_points_in_between():

@@ -110,5 +110,5 @@ for i in range(OPS):
     hist[f.__name__] = hist.get(f.__name__, 0) + 1
     if not f(): bad.append((i, f.__name__))
 print(f"api fuzz: {OPS} calls (seed {SEED}) in {time.perf_counter() - t0:.1f} s, {hist}, mismatches {len(bad)} {bad[:8]}, "
-      f"lk expired waits {ctx.lk_wait_timeouts()}, repeats {ctx.lk_recoveries()}, hip_flow frames that reused the previous expansion {ctx.flow_cache_hits()}")
+      f"lk tiles computed by a waiting child {ctx.lk_helped_tiles()}, hip_flow frames that reused the previous expansion {ctx.flow_cache_hits()}")
 sys.exit(1 if bad else 0)

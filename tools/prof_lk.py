@@ -27,12 +27,11 @@ def main():
         ctx.densify_raster_dev(d_ent.data_ptr(), None, 1920, 1080, 150, 84, f84.data_ptr())
         ctx.almeida_dev(d_ent.data_ptr(), 1920 * 1080, 1, 16 / 9, 22.275, False, 0, 0.05, 0, 0, q1.data_ptr())
     torch.cuda.synchronize()
-    # lk_flow_dev cannot repair an expired parent-tile wait itself: a profile of flows with broken dependencies is refused
-    waits = ctx.lk_wait_timeouts()
+    helped = ctx.lk_helped_tiles()                     # tiles a waiting child computed itself: extra work in the profile (0 on a whole device)
     ctx.use_own_stream()
     ctx.close()
-    if waits:
-        raise SystemExit(f"prof_lk: {waits} parent-tile waits of the LK pyramid expired -- this profile is not of the product's flows")
+    if helped:
+        print(f"prof_lk: {helped} tiles of the LK pyramid were computed by a waiting child -- the profile contains duplicate work", file=sys.stderr)
 
 
 if __name__ == "__main__":
