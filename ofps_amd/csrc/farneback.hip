@@ -869,8 +869,8 @@ int farneback_flow_device(ofps_hip_ctx* ctx, const uint8_t* d_prev, const uint8_
             st.mode = 2; st.flow_in = coarse; st.pw = pw; st.ph = ph;
             st.inv_x = 1.0 / ((double)w / pw); st.inv_y = 1.0 / ((double)h / ph);
         }
-        hipLaunchKernelGGL(fb_start_kernel, dim3((((w + 63) / 64) * ((h + 3) / 4) + 7) / 8 * 8), dim3(256), 0, s, st);
         float2* layer_flow = coarse == Fp[0] ? Fp[1] : Fp[0];
+        hipLaunchKernelGGL(fb_start_kernel, dim3((((w + 63) / 64) * ((h + 3) / 4) + 7) / 8 * 8), dim3(256), 0, s, st);
         for (int it = 0; it < iters; ++it) {
             const bool last_it = it == iters - 1, last = k == 0 && last_it;
             FbIter a{};
