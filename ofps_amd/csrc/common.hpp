@@ -65,16 +65,21 @@ struct ofps_hip_ctx {
     } lk_ticket[kLkTickets];
     long lk_next_ticket = 0;
     // hip_flow in the stream forms (farneback.hip): the pyramid + polynomial expansion of a pair's second frame is the next pair's
-    // first.  Frames of the stream carry ids (never reused); the expansion planes of the frame with id `fb_cache.id` are in R slot
-    // `fb_cache.slot` of the S_FB_WORK allocation of generation `gen`, made with these parameters.
+    // first, and the NEW frame's is made on the upload's stream beside the previous pair's flow.  Frames of the stream carry ids (never
+    // reused); `fb_cache.id[i]` is the frame whose expansion planes are in R slot i of the S_FB_WORK allocation of generation `gen`, made
+    // with these parameters.
     uint64_t lk_frame_serial = 0;
     uint64_t lk_slot_id[kLkSlots] = {0, 0, 0};
+    static constexpr int kFbSlots = 3;   // expansion-plane slots per layer: the frames of two pairs in flight (k - 1, k, k + 1)
     struct FbCache {
-        bool valid = false;
-        int slot = 0, W = 0, H = 0, K = 0, poly_n = 0;
+        uint64_t id[kFbSlots] = {0, 0, 0};   // the stream frame whose planes a slot holds (0 = none)
+        int W = 0, H = 0, K = 0, poly_n = 0;
         double poly_sigma = 0;
-        uint64_t id = 0, gen = 0;
+        uint64_t gen = 0;
     } fb_cache;
+    hipEvent_t fb_prep_done = nullptr;   // the last pyramid + expansion of this context (its T / I temporaries are shared; prepares may run on two streams)
+    bool fb_prep_recorded = false;
+    hipStream_t fb_prep_stream = nullptr;
     uint64_t fb_cache_hits = 0;          // (tests: how many calls skipped the first frame's pyramid + expansion)
     struct FbPrevFlow { bool valid = false; int W = 0, H = 0; uint64_t id = 0, gen = 0; } fb_prev_flow;     // S_FB_FLOW holds the flow of the pair whose second frame has this id
 
@@ -194,6 +199,8 @@ int detect_device(ofps_hip_ctx* ctx, const float4* d_entries, size_t n, int batc
 int farneback_flow_device(ofps_hip_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_cur, int W, int H, int stride, int levels, int winsize,
                           int iters, int poly_n, double poly_sigma, const float2* d_init, float2* d_flow, float4* d_entries,
                           uint64_t prev_id = 0, uint64_t cur_id = 0);     // ids != 0: frames of a stream (ofps_hip_ctx::fb_cache)
+int farneback_prepare_device(ofps_hip_ctx* ctx, const uint8_t* d_img, int W, int H, int stride, int levels, int winsize, int poly_n, double poly_sigma,
+                             uint64_t id, hipStream_t st);          // a stream frame's pyramid + expansion ahead of its pair's flow, on stream st
 int farneback_check_params(ofps_hip_ctx* ctx, int W, int H, int levels, int winsize, int poly_n);       // what farneback_flow_device would refuse, without running it
 int almeida_device(ofps_hip_ctx* ctx, const float4* d_entries, size_t n, int batch, float aspect, float fov_y_deg,
                    int use_ransac, size_t num_iters, float inlier_deg, size_t num_samples, uint64_t seed, float4* d_quat);

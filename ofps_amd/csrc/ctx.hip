@@ -214,6 +214,7 @@ void ofps_hip_destroy(ofps_hip_ctx* ctx) {
     if (ctx->lk_copy_stream) (void)hipStreamDestroy(ctx->lk_copy_stream);
     if (ctx->pipe_copy_stream) (void)hipStreamDestroy(ctx->pipe_copy_stream);
     if (ctx->pipe_aux_stream) (void)hipStreamDestroy(ctx->pipe_aux_stream);
+    if (ctx->fb_prep_done) (void)hipEventDestroy(ctx->fb_prep_done);
     if (ctx->pipe_fork) (void)hipEventDestroy(ctx->pipe_fork);
     if (ctx->pipe_join) (void)hipEventDestroy(ctx->pipe_join);
     if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);

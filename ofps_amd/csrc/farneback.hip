@@ -747,26 +747,35 @@ int farneback_check_params(ofps_hip_ctx* ctx, int W, int H, int levels, int wins
     return OFPS_HIP_OK;
 }
 
-int farneback_flow_device(ofps_hip_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_cur, int W, int H, int stride, int levels, int winsize,
-                          int iters, int poly_n, double poly_sigma, const float2* d_init, float2* d_flow, float4* d_entries,
-                          uint64_t prev_id, uint64_t cur_id) {
-    OFPS_REQUIRE(ctx, W >= 1 && H >= 1 && stride >= W, "farneback: bad geometry W=%d H=%d stride=%d", W, H, stride);
-    OFPS_REQUIRE(ctx, iters >= 1 && iters <= 64, "farneback: iters=%d out of range", iters);
-    {
-        const int rc_params = farneback_check_params(ctx, W, H, levels, winsize, poly_n);
-        if (rc_params != OFPS_HIP_OK) return rc_params;
-    }
-    OFPS_REQUIRE(ctx, d_flow || d_entries, "farneback: no output");
-    hipStream_t s = ctx->stream;
-    const int K = farneback_layers(W, H, levels);
+// ---- the call's geometry, taps and workspace
+struct FbPlan {
+    int W, H, K, poly_n;
+    double poly_sigma;
+    FbPyr Y;
     FbPoly P;
-    make_poly(poly_n, poly_sigma, &P);
-    // ---- geometry of the layers and the workspace
-    FbPyr Y{};
+    size_t r_off[kMaxLayers], r_px, px;
+    int vblocks;
+    float *T, *I, *R, *Mb[2];
+    float2* Fp[2];
+    uint64_t gen;
+    // expansion planes of layer k in R slot `slot` (three slots per layer: the frames of a stream's two pairs in flight)
+    float* Rk(int k, int slot) const { return R + (size_t)ofps_hip_ctx::kFbSlots * 5 * r_off[k] + (size_t)slot * 5 * Y.w[k] * Y.h[k]; }
+};
+
+int fb_plan(ofps_hip_ctx* ctx, int W, int H, int levels, int winsize, int poly_n, double poly_sigma, FbPlan* pl) {
+    const int rc_params = farneback_check_params(ctx, W, H, levels, winsize, poly_n);
+    if (rc_params != OFPS_HIP_OK) return rc_params;
+    FbPlan& q = *pl;
+    q.W = W; q.H = H; q.poly_n = poly_n; q.poly_sigma = poly_sigma;
+    const int K = q.K = farneback_layers(W, H, levels);
+    make_poly(poly_n, poly_sigma, &q.P);
+    FbPyr& Y = q.Y;
+    Y = FbPyr{};
     Y.K = K;
-    size_t t_floats = 0, i_floats = 0, r_px = 0;
-    size_t r_off[kMaxLayers];
-    int ntaps = 0, vblocks = 0;
+    size_t t_floats = 0, i_floats = 0;
+    q.r_px = 0;
+    int ntaps = 0;
+    q.vblocks = 0;
     for (int k = 0; k <= K; ++k) {
         double scale = 1.0;
         for (int i = 0; i < k; ++i) scale *= 0.5;
@@ -777,37 +786,43 @@ int farneback_flow_device(ofps_hip_ctx* ctx, const uint8_t* d_prev, const uint8_
         memcpy(Y.taps + ntaps, blur.taps, sizeof(float) * (size_t)(2 * blur.r + 1));
         ntaps += 2 * blur.r + 1;
         Y.inv_x[k] = 1.0 / ((double)Y.w[k] / W); Y.inv_y[k] = 1.0 / ((double)Y.h[k] / H);
-        r_off[k] = r_px; r_px += (size_t)Y.w[k] * Y.h[k];
-        Y.blk0[k] = vblocks;
+        q.r_off[k] = q.r_px; q.r_px += (size_t)Y.w[k] * Y.h[k];
+        Y.blk0[k] = q.vblocks;
         if (k >= 1) {
             if (Y.w[k] == W && Y.h[k] == H) return set_error(ctx, OFPS_HIP_EUNSUPPORTED, "farneback: degenerate layer %d", k);
             Y.t_off[k] = t_floats; t_floats += (size_t)2 * H * 2 * Y.w[k];
             Y.i_off[k] = i_floats; i_floats += (size_t)2 * Y.w[k] * Y.h[k];
-            vblocks += (blur.r <= kShortR ? (Y.w[k] + 63) / 64 : (Y.w[k] + 15) / 16) * ((Y.h[k] + 3) / 4);
+            q.vblocks += (blur.r <= kShortR ? (Y.w[k] + 63) / 64 : (Y.w[k] + 15) / 16) * ((Y.h[k] + 3) / 4);
         }
     }
-    Y.blk0[K + 1] = vblocks;
-    const size_t px = (size_t)W * H;
-    // T | I (layers >= 1) | R [layer][2][5][h][w] | M x 2 [5][H][W] | two flow planes [H][W] float2
-    const size_t floats = t_floats + i_floats + 10 * r_px + 2 * 5 * px + 2 * 2 * px;
+    Y.blk0[K + 1] = q.vblocks;
+    q.px = (size_t)W * H;
+    // T | I (layers >= 1) | R [layer][3 slots][5][h][w] | M x 2 [5][H][W] | two flow planes [H][W] float2
+    const size_t floats = t_floats + i_floats + (size_t)ofps_hip_ctx::kFbSlots * 5 * q.r_px + 2 * 5 * q.px + 2 * 2 * q.px;
     auto* base = static_cast<float*>(scratch(ctx, S_FB_WORK, floats * sizeof(float)));
     if (!base) return OFPS_HIP_ENOMEM;
-    float* T = base; float* I = T + t_floats; float* R = I + i_floats;
-    float* Mb[2] = {R + 10 * r_px, R + 10 * r_px + 5 * px};
-    float2* Fp[2] = {reinterpret_cast<float2*>(Mb[1] + 5 * px), reinterpret_cast<float2*>(Mb[1] + 5 * px) + px};
-    // Stream forms (prev_id / cur_id != 0: frames of ofps_hip_lk_push_frame[_async]): the first frame's expansion planes are the ones
-    // the previous call made for ITS second frame, if that call was about the same frame (id), geometry and parameters and the
-    // workspace has not moved since -- then only the second frame goes through the pyramid and the expansion.  The two R slots of a
-    // layer swap roles from call to call.  Everything is on ctx->stream: the planes are complete before this call's kernels read them.
+    q.T = base; q.I = q.T + t_floats; q.R = q.I + i_floats;
+    q.Mb[0] = q.R + (size_t)ofps_hip_ctx::kFbSlots * 5 * q.r_px; q.Mb[1] = q.Mb[0] + 5 * q.px;
+    q.Fp[0] = reinterpret_cast<float2*>(q.Mb[1] + 5 * q.px); q.Fp[1] = q.Fp[0] + q.px;
+    q.gen = ctx->scratch[S_FB_WORK].gen;
+    // the cache of expanded frames belongs to one workspace, geometry and parameter set
     ofps_hip_ctx::FbCache& fc = ctx->fb_cache;
-    const uint64_t gen = ctx->scratch[S_FB_WORK].gen;
-    const bool reuse = prev_id != 0 && fc.valid && fc.id == prev_id && fc.gen == gen && fc.W == W && fc.H == H && fc.K == K &&
-                       fc.poly_n == poly_n && fc.poly_sigma == poly_sigma;
-    const int slot_prev = reuse ? fc.slot : 0, slot_cur = 1 - slot_prev;
-    fc.valid = false;                              // (until this call has enqueued everything)
-    auto Rk = [&](int k, int img) { return R + 10 * r_off[k] + (size_t)(img ? slot_cur : slot_prev) * 5 * Y.w[k] * Y.h[k]; };
-    const int n_img = reuse ? 1 : 2;               // images that go through the pyramid + expansion: (prev, cur) or (cur)
-    if (reuse) ctx->fb_cache_hits += 1;
+    if (fc.gen != q.gen || fc.W != W || fc.H != H || fc.K != K || fc.poly_n != poly_n || fc.poly_sigma != poly_sigma) {
+        for (auto& id : fc.id) id = 0;
+        fc.gen = q.gen; fc.W = W; fc.H = H; fc.K = K; fc.poly_n = poly_n; fc.poly_sigma = poly_sigma;
+    }
+    return OFPS_HIP_OK;
+}
+
+// pyramid + polynomial expansion of one or two frames into R slots, on stream st.  The T / I planes are the pyramid's temporaries and
+// shared by every prepare of the context: a prepare waits for the previous one (which may have run on another stream) and leaves its event.
+int fb_prepare(ofps_hip_ctx* ctx, const FbPlan& pl, const uint8_t* const* imgs, const int* slots, int n_img, int stride, hipStream_t st) {
+    const FbPyr& Y = pl.Y;
+    const int K = pl.K, W = pl.W, H = pl.H;
+    if (!ctx->fb_prep_done) OFPS_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->fb_prep_done, hipEventDisableTiming));
+    if (ctx->fb_prep_recorded && ctx->fb_prep_stream != st) OFPS_HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->fb_prep_done, 0));
+    const uint8_t* i0 = imgs[0];
+    const uint8_t* i1 = imgs[n_img - 1];
     // ---- pyramid above layer 0: two launches
     if (K >= 1) {
         // LDS rows: margins of the longest filter (a multiple of 4 bytes, so that the dword copies stay aligned), starts 1 dword (mod 64) apart
@@ -816,9 +831,8 @@ int farneback_flow_device(ofps_hip_ctx* ctx, const uint8_t* d_prev, const uint8_
         const int PAD = (Y.r[K] + 3) & ~3;
         const int need = W + 2 * PAD;
         const dim3 grid((H + kPR - 1) / kPR, n_img, K);
-        const uint8_t* i0 = reuse ? d_cur : d_prev;
-#define OFPS_FB_PYR_H(RS_) hipLaunchKernelGGL((fb_pyr_h_kernel<RS_>), grid, dim3(256), (size_t)kPR * RS_ + (size_t)(2 * Y.r[K] + 1) * sizeof(float), s, \
-                                              i0, d_cur, W, H, stride, Y, PAD, T)
+#define OFPS_FB_PYR_H(RS_) hipLaunchKernelGGL((fb_pyr_h_kernel<RS_>), grid, dim3(256), (size_t)kPR * RS_ + (size_t)(2 * Y.r[K] + 1) * sizeof(float), st, \
+                                              i0, i1, W, H, stride, Y, PAD, pl.T)
         if (need <= kPyrRS0) OFPS_FB_PYR_H(kPyrRS0);
         else if (need <= kPyrRS1) OFPS_FB_PYR_H(kPyrRS1);
         else {                                                                        // 135 KB of dynamic LDS: above the 64 KB a launch gets unasked
@@ -827,33 +841,113 @@ int farneback_flow_device(ofps_hip_ctx* ctx, const uint8_t* d_prev, const uint8_
             OFPS_FB_PYR_H(kPyrRS2);
         }
 #undef OFPS_FB_PYR_H
-        hipLaunchKernelGGL(fb_pyr_v_kernel, dim3(vblocks * n_img), dim3(256), 0, s, (const float*)T, W, H, Y, n_img, I);
+        hipLaunchKernelGGL(fb_pyr_v_kernel, dim3(pl.vblocks * n_img), dim3(256), 0, st, (const float*)pl.T, W, H, Y, n_img, pl.I);
     }
-    // ---- polynomial expansion of every layer and both images: one launch (layer 0 blurs the u8 frame while it fills its tiles)
+    // ---- polynomial expansion of every layer and the frames: one launch (layer 0 blurs the u8 frame while it fills its tiles)
     {
         FbExp E{};
         int blk = 0;
         for (int k = 0; k <= K; ++k)
             for (int z = 0; z < n_img; ++z) {
-                const int img = reuse ? 1 : z;
                 FbExpJob& J = E.job[E.njobs++];
-                J.w = Y.w[k]; J.h = Y.h[k]; J.R = Rk(k, img); J.blk0 = blk; J.tiles_x = (J.w + kPX - 1) / kPX;
-                if (k == 0) { J.u8 = img ? d_cur : d_prev; J.stride = stride; J.I = nullptr; }
-                else { J.u8 = nullptr; J.stride = 0; J.I = I + Y.i_off[k] + (size_t)z * J.w * J.h; }
+                J.w = Y.w[k]; J.h = Y.h[k]; J.R = pl.Rk(k, slots[z]); J.blk0 = blk; J.tiles_x = (J.w + kPX - 1) / kPX;
+                if (k == 0) { J.u8 = imgs[z]; J.stride = stride; J.I = nullptr; }
+                else { J.u8 = nullptr; J.stride = 0; J.I = pl.I + Y.i_off[k] + (size_t)z * J.w * J.h; }
                 blk += J.tiles_x * ((J.h + kPY - 1) / kPY);
             }
+        const int poly_n = pl.poly_n;
         const size_t lds = (size_t)((kPY + 2 * poly_n) * (kPX + 2 * poly_n) + 3 * kPY * (kPX + 2 * poly_n)) * sizeof(float);
         const float t_c = Y.taps[Y.toff[0] + 1], t_s = Y.taps[Y.toff[0] + 2];
-        if (poly_n == 7) hipLaunchKernelGGL((fb_polyexp_kernel<7>), dim3(blk), dim3(256), lds, s, E, P, t_c, t_s);
-        else if (poly_n == 5) hipLaunchKernelGGL((fb_polyexp_kernel<5>), dim3(blk), dim3(256), lds, s, E, P, t_c, t_s);
-        else hipLaunchKernelGGL((fb_polyexp_kernel<0>), dim3(blk), dim3(256), lds, s, E, P, t_c, t_s);
+        if (poly_n == 7) hipLaunchKernelGGL((fb_polyexp_kernel<7>), dim3(blk), dim3(256), lds, st, E, pl.P, t_c, t_s);
+        else if (poly_n == 5) hipLaunchKernelGGL((fb_polyexp_kernel<5>), dim3(blk), dim3(256), lds, st, E, pl.P, t_c, t_s);
+        else hipLaunchKernelGGL((fb_polyexp_kernel<0>), dim3(blk), dim3(256), lds, st, E, pl.P, t_c, t_s);
+    }
+    OFPS_HIP_TRY(ctx, hipGetLastError());
+    OFPS_HIP_TRY(ctx, hipEventRecord(ctx->fb_prep_done, st));
+    ctx->fb_prep_recorded = true; ctx->fb_prep_stream = st;
+    return OFPS_HIP_OK;
+}
+
+// which R slot holds the expansion of the stream frame `id` (0 = none does)
+int fb_find_slot(const ofps_hip_ctx::FbCache& fc, uint64_t id) {
+    if (id == 0) return -1;
+    for (int i = 0; i < ofps_hip_ctx::kFbSlots; ++i)
+        if (fc.id[i] == id) return i;
+    return -1;
+}
+// a slot to overwrite: an empty one, else the one with the oldest frame -- never `keep` (the other frame of the pair being computed)
+int fb_victim_slot(const ofps_hip_ctx::FbCache& fc, int keep) {
+    int best = -1;
+    for (int i = 0; i < ofps_hip_ctx::kFbSlots; ++i) {
+        if (i == keep) continue;
+        if (best < 0 || fc.id[i] < fc.id[best]) best = i;
+    }
+    return best;
+}
+
+// Stream forms (ofps_hip_lk_push_frame[_async]): the NEW frame's pyramid + expansion, enqueued on the upload's stream right behind the
+// upload -- with another ticket in flight that is beside the previous pair's flow, whose coarse layers are a chain of dependent round trips
+// that leaves most of the device idle (round 6).  The flow call for the pair then finds both frames' planes by their ids.
+// A frame's planes are written into the slot of the oldest frame: its last reader is the flow of a ticket that has been collected.
+int farneback_prepare_device(ofps_hip_ctx* ctx, const uint8_t* d_img, int W, int H, int stride, int levels, int winsize, int poly_n, double poly_sigma,
+                             uint64_t id, hipStream_t st) {
+    OFPS_REQUIRE(ctx, W >= 1 && H >= 1 && stride >= W && id != 0, "farneback_prepare: bad arguments");
+    FbPlan pl;
+    int rc = fb_plan(ctx, W, H, levels, winsize, poly_n, poly_sigma, &pl);
+    if (rc != OFPS_HIP_OK) return rc;
+    ofps_hip_ctx::FbCache& fc = ctx->fb_cache;
+    if (fb_find_slot(fc, id) >= 0) return OFPS_HIP_OK;
+    const int slot = fb_victim_slot(fc, -1);
+    fc.id[slot] = 0;
+    rc = fb_prepare(ctx, pl, &d_img, &slot, 1, stride, st);
+    if (rc != OFPS_HIP_OK) return rc;
+    fc.id[slot] = id;
+    return OFPS_HIP_OK;
+}
+
+int farneback_flow_device(ofps_hip_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_cur, int W, int H, int stride, int levels, int winsize,
+                          int iters, int poly_n, double poly_sigma, const float2* d_init, float2* d_flow, float4* d_entries,
+                          uint64_t prev_id, uint64_t cur_id) {
+    OFPS_REQUIRE(ctx, W >= 1 && H >= 1 && stride >= W, "farneback: bad geometry W=%d H=%d stride=%d", W, H, stride);
+    OFPS_REQUIRE(ctx, iters >= 1 && iters <= 64, "farneback: iters=%d out of range", iters);
+    OFPS_REQUIRE(ctx, d_flow || d_entries, "farneback: no output");
+    hipStream_t s = ctx->stream;
+    FbPlan pl;
+    int rc = fb_plan(ctx, W, H, levels, winsize, poly_n, poly_sigma, &pl);
+    if (rc != OFPS_HIP_OK) return rc;
+    const FbPyr& Y = pl.Y;
+    const int K = pl.K;
+    float* const* Mb = pl.Mb;
+    float2* const* Fp = pl.Fp;
+    // Stream forms (prev_id / cur_id != 0: frames of ofps_hip_lk_push_frame[_async]): a frame's expansion planes may be there already --
+    // the first frame's from the previous pair (its second frame), the second frame's from farneback_prepare_device on the upload's
+    // stream -- if they were made for the same frame id, geometry and parameters and the workspace has not moved since (fb_plan).
+    // Whatever is missing goes through the pyramid and the expansion here, on ctx->stream.
+    ofps_hip_ctx::FbCache& fc = ctx->fb_cache;
+    int slot_prev = fb_find_slot(fc, prev_id), slot_cur = fb_find_slot(fc, cur_id);
+    if (slot_prev >= 0) ctx->fb_cache_hits += 1;
+    {
+        const uint8_t* imgs[2]; int slots[2]; int n = 0;
+        if (slot_prev < 0) { slot_prev = fb_victim_slot(fc, slot_cur); fc.id[slot_prev] = 0; imgs[n] = d_prev; slots[n++] = slot_prev; }
+        if (slot_cur < 0) {
+            int v = -1;                                            // not the first frame's slot
+            for (int i = 0; i < ofps_hip_ctx::kFbSlots; ++i)
+                if (i != slot_prev && (v < 0 || fc.id[i] < fc.id[v])) v = i;
+            slot_cur = v; fc.id[slot_cur] = 0; imgs[n] = d_cur; slots[n++] = slot_cur;
+        }
+        if (n) {
+            rc = fb_prepare(ctx, pl, imgs, slots, n, stride, s);
+            if (rc != OFPS_HIP_OK) return rc;
+        } else if (ctx->fb_prep_recorded && ctx->fb_prep_stream != s) {
+            OFPS_HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->fb_prep_done, 0));      // (the stream forms order the flow behind the upload's stream themselves; cheap and safe here)
+        }
     }
     // ---- layers, coarsest first
     int pw = 0, ph = 0;
     const float2* coarse = nullptr;
     for (int k = K; k >= 0; --k) {
         const int w = Y.w[k], h = Y.h[k];
-        FbLayer L{Rk(k, 0), Rk(k, 1), w, h};
+        FbLayer L{pl.Rk(k, slot_prev), pl.Rk(k, slot_cur), w, h};
         FbStart st{};
         st.L = L; st.M = Mb[0];
         if (k == K) {
@@ -893,9 +987,7 @@ int farneback_flow_device(ofps_hip_ctx* ctx, const uint8_t* d_prev, const uint8_
         coarse = layer_flow; pw = w; ph = h;
     }
     OFPS_HIP_TRY(ctx, hipGetLastError());
-    if (cur_id != 0) {
-        fc.valid = true; fc.slot = slot_cur; fc.id = cur_id; fc.gen = gen; fc.W = W; fc.H = H; fc.K = K; fc.poly_n = poly_n; fc.poly_sigma = poly_sigma;
-    }
+    fc.id[slot_prev] = prev_id; fc.id[slot_cur] = cur_id;          // (0: a pair on its own -- its planes are nobody's)
     return OFPS_HIP_OK;
 }
 

@@ -164,17 +164,17 @@ def test_hip_flow_stream_reuses_the_previous_frames_expansion(ctx):
     h0 = ctx.flow_cache_hits()
     assert ctx.lk_push_frame(fr[0], 5, 6, 3, contrast_mask=True, farneback=True) is None
     got = [ctx.lk_push_frame(fr[k], 5, 6, 3, contrast_mask=True, farneback=True)[0] for k in (1, 2, 3)]
-    assert ctx.flow_cache_hits() - h0 == 2                            # pairs (1,2) and (2,3); pair (0,1) made both expansions
+    assert ctx.flow_cache_hits() - h0 == 3                            # every pair found its first frame's planes (round 6: a frame is expanded when it is pushed)
     for k in range(3):
         np.testing.assert_array_equal(got[k].view(np.uint32), want[k].view(np.uint32))
-    # a pair call in between uses the same planes: the stream's next pair must not trust them
+    # a pair call in between uses two of the three plane slots (the oldest frames'): the stream's last frame keeps its own
     ctx.farneback_flow(fr[5], fr[6])
     e = ctx.lk_push_frame(fr[4], 5, 6, 3, contrast_mask=True, farneback=True)[0]
-    assert ctx.flow_cache_hits() - h0 == 2
+    assert ctx.flow_cache_hits() - h0 == 4
     np.testing.assert_array_equal(e.view(np.uint32), want[3].view(np.uint32))
     # other parameters (fewer layers: 352 x 200 has three at levels >= 2, two at levels = 1): recomputed
     e = ctx.lk_push_frame(fr[5], 1, 6, 3, contrast_mask=True, farneback=True)[0]
-    assert ctx.flow_cache_hits() - h0 == 2
+    assert ctx.flow_cache_hits() - h0 == 4
     np.testing.assert_array_equal(e.view(np.uint32), pair(fr[4], fr[5], levels=1).view(np.uint32))
     ctx.lk_reset()
     assert ctx.lk_push_frame(fr[2], 5, 6, 3, contrast_mask=True, farneback=True) is None
