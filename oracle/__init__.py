@@ -355,6 +355,23 @@ def farneback_flow(prev, cur, levels: int = 5, winsize: int = 13, iters: int = 3
     return out
 
 
+class farneback_blur_variant:
+    """with oracle.farneback_blur_variant(v): ... -- the published form of OpenCV's separable Gaussian the layers are blurred with (0 = the
+    SPEC, what every parity test uses; 1 = ascending row taps beyond 5 taps; 2 = 1 with fused multiply-adds).  External kit only."""
+
+    def __init__(self, v: int):
+        self.v = int(v)
+
+    def __enter__(self):
+        f = lib().orc_farneback_set_blur_variant
+        f.argtypes = [C.c_int]; f.restype = C.c_int
+        self.prev = f(self.v)
+        return self
+
+    def __exit__(self, *a):
+        lib().orc_farneback_set_blur_variant(self.prev)
+
+
 def farneback_layer(img, k: int, poly_n: int = 7, poly_sigma: float = 1.5):
     """Stage-wise view of layer k of one frame: -> (I [h, w] the blurred + resized image, R [h, w, 5] its polynomial expansion)."""
     img = np.ascontiguousarray(img, np.uint8)

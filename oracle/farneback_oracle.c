@@ -80,22 +80,52 @@ static int reflect101(int i, int n) {
     return i;
 }
 
-/* row filter then column filter, symmetric pairing: s = c[r] * S[0] + sum_j c[r + j] * (S[-j] + S[+j]), f32 */
+/* Which published form of OpenCV's separable Gaussian the layers are blurred with (the part of the restatement where OpenCV builds differ
+ * among themselves; everything else is scalar code with one form).  Test infrastructure for tools/external_parity/opencv_compare.py:
+ *   0  (the SPEC the HIP kernels are built to: every committed vector, every parity test): symmetric pairing in both passes,
+ *      s = c[r] * S[0] + sum_j c[r + j] * (S[-j] + S[+j]), separate multiply and add;
+ *   1  the row pass as filter.simd.hpp's RowFilter has it for kernels of more than 5 taps (SymmRowSmallFilter serves 3 and 5 only: layers
+ *      k >= 2 have 9 .. 159 taps): taps in ascending order, s = sum_k c[k] * S[k - r]; the column pass is SymmColumnFilter's pairing;
+ *   2  variant 1 with the multiply-adds fused (v_muladd on builds whose dispatch has FMA3 / NEON: RowVec_32f, SymmColumnVec_32f).
+ * Set by orc_farneback_set_blur_variant; read by every orc_farneback_* call of the process. */
+static int g_blur_variant = 0;
+int orc_farneback_set_blur_variant(int v) {
+    const int prev = g_blur_variant;
+    if (v >= 0 && v <= 2) g_blur_variant = v;
+    return prev;
+}
+
 static void gaussian_blur(const float* src, int W, int H, const float* taps, int r, float* tmp, float* dst) {
+    const int variant = g_blur_variant;
+    const int ascending_rows = variant >= 1 && 2 * r + 1 > 5;
+    const int fused = variant == 2;
 #pragma omp parallel for schedule(static)
     for (int y = 0; y < H; ++y)
         for (int x = 0; x < W; ++x) {
-            float s = taps[r] * src[(size_t)y * W + x];
-            for (int j = 1; j <= r; ++j)
-                s += taps[r + j] * (src[(size_t)y * W + reflect101(x - j, W)] + src[(size_t)y * W + reflect101(x + j, W)]);
+            float s;
+            if (ascending_rows) {
+                s = 0.0f;
+                for (int k = 0; k <= 2 * r; ++k) {
+                    const float v = src[(size_t)y * W + reflect101(x + k - r, W)];
+                    s = fused ? fmaf(v, taps[k], s) : s + taps[k] * v;
+                }
+            } else {
+                s = taps[r] * src[(size_t)y * W + x];
+                for (int j = 1; j <= r; ++j) {
+                    const float p = src[(size_t)y * W + reflect101(x - j, W)] + src[(size_t)y * W + reflect101(x + j, W)];
+                    s = fused ? fmaf(p, taps[r + j], s) : s + taps[r + j] * p;
+                }
+            }
             tmp[(size_t)y * W + x] = s;
         }
 #pragma omp parallel for schedule(static)
     for (int y = 0; y < H; ++y)
         for (int x = 0; x < W; ++x) {
             float s = taps[r] * tmp[(size_t)y * W + x];
-            for (int j = 1; j <= r; ++j)
-                s += taps[r + j] * (tmp[(size_t)reflect101(y - j, H) * W + x] + tmp[(size_t)reflect101(y + j, H) * W + x]);
+            for (int j = 1; j <= r; ++j) {
+                const float p = tmp[(size_t)reflect101(y - j, H) * W + x] + tmp[(size_t)reflect101(y + j, H) * W + x];
+                s = fused ? fmaf(p, taps[r + j], s) : s + taps[r + j] * p;
+            }
             dst[(size_t)y * W + x] = s;
         }
 }

@@ -161,6 +161,9 @@ int orc_set_num_threads(int n);   /* for the OpenMP loops without a thread argum
 
 /* ---- Farneback dense flow as cv-decoder calls it (cv-decoder/src/lib.rs:188-199; OpenCV's calcOpticalFlowFarneback restated from the
  * published algorithm: farneback_oracle.c).  PARITY UNPINNED: OpenCV is neither under /root/reference nor installed. ---- */
+/* 0 (default, the SPEC: symmetric pairing) / 1 (ascending row taps beyond 5 taps) / 2 (1 + fused multiply-adds): which published form of
+ * OpenCV's separable Gaussian blurs the layers -- for the external kit only; returns the previous setting */
+int orc_farneback_set_blur_variant(int v);
 int orc_farneback_layers(int W, int H, int levels);                       /* highest layer index k kept (layers k = 0 .. result) */
 void orc_farneback_layer_size(int W, int H, int k, int* w, int* h);
 int orc_farneback_blur_kernel(int k, float* taps);                        /* -> radius; taps[2 r + 1] */

@@ -70,12 +70,25 @@ def test_planted_homography_is_recovered():
 
 
 def test_committed_vectors_of_the_external_kit_are_this_oracles_output():
-    d = np.load(os.path.join(ROOT, "tools", "external_parity", "data", "farneback_pairs.npz"))
+    """every expected array of tools/external_parity/data/farneback_pairs.npz -- cv-decoder's call cold and warm, the two other published forms
+    of the separable Gaussian, the stage ablations, the layer images, the front-end -- is what the oracle computes today"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_farneback_pairs", os.path.join(ROOT, "tools", "external_parity", "make_farneback_pairs.py"))
+    gen = importlib.util.module_from_spec(spec); spec.loader.exec_module(gen)
+    d = np.load(gen.PATH)
+    seen = set()
     for name in ("camera", "regions"):
-        f = oracle.farneback_flow(d[name + "_prev"], d[name + "_cur"])
-        np.testing.assert_array_equal(f.view(np.uint32), d[name + "_flow"].view(np.uint32))
-        w = oracle.farneback_flow(d[name + "_prev"], d[name + "_cur"], init=f)          # OPTFLOW_USE_INITIAL_FLOW (cv-decoder/src/lib.rs:161-165)
-        np.testing.assert_array_equal(w.view(np.uint32), d[name + "_flow_warm"].view(np.uint32))
+        exp = gen.expected(d[name + "_prev"], d[name + "_cur"], name)
+        for k, v in exp.items():
+            np.testing.assert_array_equal(v.view(np.uint8), d[k].view(np.uint8), err_msg=k)
+            seen.add(k)
+        # the other forms of the Gaussian move the flow by a few 1e-7 px: far inside north_star's 1e-4, and not the same bits
+        for v in (1, 2):
+            dd = np.abs(exp[f"{name}_flow_v{v}"] - exp[name + "_flow"])
+            assert 0 < dd.max() < 2e-5, (name, v, float(dd.max()))
+        np.testing.assert_array_equal(exp[name + "_layer1"], exp[name + "_layer1_v1"])            # 3 taps: SymmRowSmallFilter in every form
+        assert (exp[name + "_layer2"] != exp[name + "_layer2_v1"]).any()                         # 9 taps: the row pass differs
+    assert seen | {n + s for n in ("camera", "regions") for s in ("_prev", "_cur")} == set(d.files)
 
 
 def test_initial_flow_and_bad_arguments():

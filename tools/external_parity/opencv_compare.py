@@ -2,21 +2,35 @@
 """External check of the hip_flow decoder's algorithm against the REAL thing the reference calls (anyone with OpenCV can run it; this
 build's image has no cv2, so the result is not part of the build's own evidence):
 
+    cv-decoder/src/lib.rs:124-135   imgproc::resize(.., INTER_LINEAR), cvt_color(.., COLOR_BGR2GRAY)
     cv-decoder/src/lib.rs:188-199   calc_optical_flow_farneback(old_gray, gray, flow, 0.5, 5, 13, 3, 7, 1.5, flags)
 
 data/farneback_pairs.npz holds two seeded 256 x 144 luma pairs (a smooth camera rotation; region-wise integer motion with flow
-discontinuities) and the flow this build's CPU restatement (oracle/farneback_oracle.c, bit-identical to the HIP kernels:
-tests/test_farneback_gpu.py) computes for them, cold and started from that flow (make_farneback_pairs.py made the second set).  The script runs cv2.calcOpticalFlowFarneback with the reference's arguments on the
-same frames and prints how far apart the two flows are.
+discontinuities) and what this build's CPU restatement (oracle/farneback_oracle.c + frontend_oracle.c, bit-identical to the HIP kernels:
+tests/test_farneback_gpu.py, tests/test_frontend_gpu.py) computes for them; make_farneback_pairs.py lists the arrays.  The script runs
+cv2 on the same frames and prints, stage by stage, how far apart the two are -- so that a difference can be LOCALISED:
+
+    front-end    resize of a luma / BGR frame to 150 x 84 and BGR -> gray: integer arithmetic, expected IDENTICAL (any difference: which
+                 vertical pass the build's resize runs -- the script tries the generic form too -- or an IPP / OpenCL resize)
+    layers       GaussianBlur(float frame, ksize_k, sigma_k) + resize(INTER_LINEAR) for k = 1, 2, 3: against the build's layer images in
+                 both published row-filter orders (symmetric pairing = the build's spec; ascending taps = RowFilter for kernels > 5 taps)
+    ablations    the flow with one layer and one update (expansion + one solve), one layer, two and three layers
+    the call     cv-decoder's arguments, cold and with OPTFLOW_USE_INITIAL_FLOW, against the spec and the two other forms of the Gaussian
+                 (v1 ascending rows, v2 = v1 + fused multiply-adds): the form with the smallest max |d| is the one this OpenCV build runs
 
     python opencv_compare.py [data/farneback_pairs.npz]            # needs numpy + opencv-python, nothing from this repository
 
-What to expect: every stage is restated with the precision OpenCV's CPU path uses, but OpenCV's SIMD builds fuse and reorder
-float operations, its resize / Gaussian kernels differ in the last bit, and Farneback's 2 x 2 solve amplifies that where the window has
-no texture -- so not bit-equal; a median difference around 1e-4 px and a 99th percentile under 1e-2 px say "same algorithm"."""
+Pass bar (round 6): median |cv2 - build| <= 1e-4 px (north_star's float tolerance) and p99 <= 1e-2 px for the best-matching form; the
+three forms themselves are within 2e-6 px of each other on these pairs, so a larger gap is NOT the Gaussian's summation order."""
 import sys
 
 import numpy as np
+
+
+def stats(a, b):
+    d = np.linalg.norm(a.astype(np.float64) - b.astype(np.float64), axis=2) if a.ndim == 3 else np.abs(a.astype(np.float64) - b.astype(np.float64))
+    q = np.percentile(d, [50, 99, 100])
+    return q, f"median {q[0]:.2e}  p99 {q[1]:.2e}  max {q[2]:.2e}"
 
 
 def main():
@@ -24,24 +38,55 @@ def main():
     path = sys.argv[1] if len(sys.argv) > 1 else __file__.rsplit("/", 1)[0] + "/data/farneback_pairs.npz"
     d = np.load(path)
     ok = True
-    print("OpenCV", cv2.__version__)
+    print("OpenCV", cv2.__version__, "| IPP", cv2.getBuildInformation().count("Intel IPP:                   YES") > 0 if hasattr(cv2, "getBuildInformation") else "?")
     for name in ("camera", "regions"):
-        prev, cur, ours = d[name + "_prev"], d[name + "_cur"], d[name + "_flow"]
+        prev, cur = d[name + "_prev"], d[name + "_cur"]
+        H, W = cur.shape
+        print(f"== {name} ({W} x {H})")
+        # ---- front-end: integers
+        gs = cv2.resize(cur, (150, 84), interpolation=cv2.INTER_LINEAR)
+        n_bad = int((gs != d[name + "_gray_small"]).sum())
+        print(f"  resize luma -> 150 x 84:        {n_bad} of {gs.size} pixels differ (max |d| {int(np.abs(gs.astype(int) - d[name + '_gray_small'].astype(int)).max())})")
+        bs = cv2.cvtColor(cv2.resize(d[name + "_bgr"], (150, 84), interpolation=cv2.INTER_LINEAR), cv2.COLOR_BGR2GRAY)
+        n_bad2 = int((bs != d[name + "_bgr_small_gray"]).sum())
+        print(f"  resize BGR -> gray 150 x 84:    {n_bad2} of {bs.size} pixels differ")
+        full = cv2.cvtColor(d[name + "_bgr"], cv2.COLOR_BGR2GRAY)
+        b, g, r = [d[name + "_bgr"][..., i].astype(np.int64) for i in range(3)]
+        print(f"  BGR -> gray, full size:         {int((full != ((b * 1868 + g * 9617 + r * 4899 + 8192) >> 14)).sum())} pixels differ from (B 1868 + G 9617 + R 4899 + 8192) >> 14")
+        ok = ok and n_bad == 0 and n_bad2 == 0
+        # ---- layer images
+        fimg = cur.astype(np.float32)
+        for k in (1, 2, 3):
+            if f"{name}_layer{k}" not in d.files:
+                continue
+            sigma = (2 ** k - 1) * 0.5
+            ks = max(int(round(sigma * 5)) | 1, 3)
+            want = d[f"{name}_layer{k}"]
+            I = cv2.resize(cv2.GaussianBlur(fimg, (ks, ks), sigma, sigma), (want.shape[1], want.shape[0]), interpolation=cv2.INTER_LINEAR)
+            _, s0 = stats(I, want)
+            _, s1 = stats(I, d[f"{name}_layer{k}_v1"])
+            print(f"  layer {k} ({ks:2d} taps) vs spec:        {s0}\n  {'':26s}vs ascending: {s1}   (grey levels)")
+        # ---- ablations
+        for key, kw in (("_stage_levels0_iters1", dict(levels=0, iterations=1)), ("_stage_levels0", dict(levels=0, iterations=3)),
+                        ("_stage_levels1", dict(levels=1, iterations=3)), ("_stage_levels2", dict(levels=2, iterations=3))):
+            cv = cv2.calcOpticalFlowFarneback(prev, cur, None, 0.5, kw["levels"], 13, kw["iterations"], 7, 1.5, 0)
+            print(f"  flow, levels {kw['levels']}, iterations {kw['iterations']}:   |cv2 - build| {stats(cv, d[name + key])[1]} px")
+        # ---- the call
         cv = cv2.calcOpticalFlowFarneback(prev, cur, None, 0.5, 5, 13, 3, 7, 1.5, 0)
-        diff = np.linalg.norm(cv - ours, axis=2)
-        mag = np.linalg.norm(cv, axis=2)
-        q = np.percentile(diff, [50, 90, 99, 100])
-        print(f"{name:8s} {prev.shape[1]}x{prev.shape[0]}  |flow| mean {mag.mean():.3f} px   |cv2 - build| median {q[0]:.2e}  p90 {q[1]:.2e}  p99 {q[2]:.2e}  "
-              f"max {q[3]:.2e} px")
-        ok = ok and q[0] < 2e-3 and q[2] < 5e-2
-        # the same pair started from that flow (OPTFLOW_USE_INITIAL_FLOW, what cv-decoder passes from its second frame on: cv-decoder/src/
-        # lib.rs:161-165): OpenCV area-resizes the flow to the coarsest layer and scales it; both sides start from the BUILD's cold flow
-        if name + "_flow_warm" in d:
-            cvw = cv2.calcOpticalFlowFarneback(prev, cur, ours.copy(), 0.5, 5, 13, 3, 7, 1.5, cv2.OPTFLOW_USE_INITIAL_FLOW)
-            qw = np.percentile(np.linalg.norm(cvw - d[name + "_flow_warm"], axis=2), [50, 90, 99, 100])
-            print(f"{'':8s} with OPTFLOW_USE_INITIAL_FLOW               |cv2 - build| median {qw[0]:.2e}  p90 {qw[1]:.2e}  p99 {qw[2]:.2e}  max {qw[3]:.2e} px")
-            ok = ok and qw[0] < 2e-3 and qw[2] < 5e-2
-    print("verdict:", "same algorithm (within the stated bounds)" if ok else "DIFFERENT -- please report the numbers above")
+        best = None
+        for tag, key in (("spec (symmetric pairing)", "_flow"), ("v1 (ascending rows)", "_flow_v1"), ("v2 (v1 + fused)", "_flow_v2")):
+            q, txt = stats(cv, d[name + key])
+            print(f"  cv-decoder's call vs {tag:26s} {txt} px")
+            if best is None or q[2] < best[0][2]:
+                best = (q, tag)
+        print(f"  -> this OpenCV build is closest to: {best[1]}")
+        ok = ok and best[0][0] <= 1e-4 and best[0][1] <= 1e-2
+        # started from the BUILD's cold flow (OPTFLOW_USE_INITIAL_FLOW, what cv-decoder passes from its second frame on, :161-165)
+        cvw = cv2.calcOpticalFlowFarneback(prev, cur, d[name + "_flow"].copy(), 0.5, 5, 13, 3, 7, 1.5, cv2.OPTFLOW_USE_INITIAL_FLOW)
+        qw, txt = stats(cvw, d[name + "_flow_warm"])
+        print(f"  with OPTFLOW_USE_INITIAL_FLOW vs spec:            {txt} px")
+        ok = ok and qw[0] <= 1e-4 and qw[1] <= 1e-2
+    print("verdict:", "same algorithm (within the stated bounds)" if ok else "DIFFERENT -- please report the lines above; the first stage that differs says where")
     return 0 if ok else 1
 
 
