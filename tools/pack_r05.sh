@@ -15,4 +15,4 @@ rm -f $D/hbm_traffic.json
 python tools/make_hbm_traffic.py
 cmp -s profiles/hbm_traffic.json $S/hbm_traffic.json || echo "note: hbm_traffic.json differs from the one the bench line of this collection read"
 { for f in lk farneback almeida sad densify detect mask pipeline multi; do python tools/kernel_resources.py ofps_amd/csrc/$f.hip 2>/dev/null | sed "s/^/$f.hip  /"; done; } > $D/kernel_resources.txt
-cp $D/bench_n1.json profiles/perf_baseline.json
+# (round 6: the gate reads profiles/r05/bench_n1.json itself; no refreshed copy)
