@@ -202,7 +202,9 @@ PARITY_PIN = {"A6-A12 (camera + Almeida)": "reference-held mfield tables (docs/r
               "N2 (dense LK flow)": "build-defined spec: bit-exact vs the build's own CPU restatement only (reference calls OpenCV Farneback)",
               "N2b (Farneback flow, hip_flow)": "the published algorithm in the form of OpenCV's calcOpticalFlowFarneback with cv-decoder's arguments: "
                                                 "bit-identical to the build's own CPU restatement; OpenCV itself is not part of the reference tree "
-                                                "(unpinned here; tools/external_parity/opencv_compare.py is the check for anyone who has cv2)"}
+                                                "(unpinned here; tools/external_parity/opencv_compare.py is the check for anyone who has cv2)",
+              "cv-decoder front-end (resize INTER_LINEAR, BGR->gray; 'Process Fullres' = false)": "OpenCV's published 8-bit code paths restated "
+                                                "integer for integer: bit-exact vs the build's C restatement and an independent NumPy one; unpinned (no OpenCV here)"}
 
 
 def build_line(args, world: int, el: float, launch_ms: float, launch_pairs: int, counts: list, nblk: int, ranks_seen: int,

@@ -362,6 +362,11 @@ int  ofps_hip_multi_init(const int* devices, int n, ofps_hip_multi** out);
 void ofps_hip_multi_destroy(ofps_hip_multi* m);
 const char* ofps_hip_multi_last_error(const ofps_hip_multi* m);       /* m may be NULL: last init error */
 int  ofps_hip_multi_worker_count(const ofps_hip_multi* m);
+/* How the shared key frame of ref_mode 1 reaches the workers' devices: 0 = hipMemcpyPeerAsync from the first worker's copy (the default),
+ * 1 = ONE ncclBroadcast over an RCCL communicator of the workers' devices (xGMI) -- chosen at ofps_hip_multi_init when the environment
+ * has OFPS_HIP_MULTI_RCCL=1, the devices are distinct and librccl.so can be dlopen'ed (the library does not link it).  *broadcasts (may
+ * be NULL): key frames that went through ncclBroadcast so far. */
+int  ofps_hip_multi_fanout(const ofps_hip_multi* m, uint64_t* broadcasts);
 /* The partition, as pure functions (no device needed): worker k of n gets pairs [first, first + count) -- the first
  * n_pairs % n workers one more -- and keeps frames [first_frame, first_frame + n_frames) resident: count + 1 frames in
  * pair mode (one halo frame shared with the next worker), count frames in key mode (frame 0 arrives by the fan-out). */

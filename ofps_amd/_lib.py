@@ -118,6 +118,7 @@ PROTOTYPES["ofps_hip_multi_init"] = (C.c_int, [C.POINTER(C.c_int), C.c_int, C.PO
 PROTOTYPES["ofps_hip_multi_destroy"] = (None, [_multi])
 PROTOTYPES["ofps_hip_multi_last_error"] = (C.c_char_p, [_multi])
 PROTOTYPES["ofps_hip_multi_worker_count"] = (C.c_int, [_multi])
+PROTOTYPES["ofps_hip_multi_fanout"] = (C.c_int, [_multi, C.POINTER(C.c_uint64)])
 PROTOTYPES["ofps_hip_multi_pair_range"] = (None, [C.c_size_t, C.c_int, C.c_int, _szp, _szp])
 PROTOTYPES["ofps_hip_multi_frame_range"] = (None, [C.c_size_t, C.c_int, C.c_int, C.c_int, _szp, _szp])
 PROTOTYPES["ofps_hip_multi_sad_flow"] = (C.c_int, [_multi, _u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_int, _f32p])

@@ -14,6 +14,8 @@
 // Frame pairs are independent units, so the workers never talk to each other except for that one fan-out.
 #include "common.hpp"
 
+#include <dlfcn.h>
+
 #include <condition_variable>
 #include <deque>
 #include <functional>
@@ -62,6 +64,20 @@ struct ofps_hip_multi {
     size_t halo_bytes = 0;
     int sW = 0, sH = 0;
     long stream_frames = 0;
+    // ---- optional RCCL fan-out of the key frame (OFPS_HIP_MULTI_RCCL=1 at ofps_hip_multi_init; north_star: "RCCL broadcast of shared
+    // reference frames over xGMI").  librccl.so is dlopen'ed: the library itself keeps linking libamdhip64 only.
+    struct Rccl {
+        void* lib = nullptr;
+        std::vector<void*> comm;               // ncclComm_t per worker (rank = worker index)
+        int (*CommInitAll)(void**, int, const int*) = nullptr;
+        int (*CommDestroy)(void*) = nullptr;
+        int (*GroupStart)() = nullptr;
+        int (*GroupEnd)() = nullptr;
+        int (*Broadcast)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+        const char* (*GetErrorString)(int) = nullptr;
+        bool active = false;
+        unsigned long broadcasts = 0;          // key frames fanned out through ncclBroadcast (diagnostics: ofps_hip_multi_fanout)
+    } rccl;
 };
 
 static thread_local char g_multi_init_err[512] = {0};
@@ -220,10 +236,50 @@ int ofps_hip_multi_init(const int* devices, int n, ofps_hip_multi** out) {
             if (e != hipSuccess) (void)hipGetLastError();          // already enabled / unsupported: ignore
         }
     }
+    // OFPS_HIP_MULTI_RCCL=1: one RCCL communicator over the workers' devices (ncclCommInitAll: one process, one rank per device) for the
+    // key-frame fan-out.  Needs distinct devices (RCCL refuses a device twice in a communicator: workers sharing a GPU keep the copy path)
+    // and librccl.so at run time; anything missing is not an error -- the peer-copy path is the default and always there.
+    const char* want = getenv("OFPS_HIP_MULTI_RCCL");
+    if (want && want[0] && strcmp(want, "0") != 0) {
+        bool distinct = true;
+        for (size_t a = 0; a < m->w.size(); ++a)
+            for (size_t b = a + 1; b < m->w.size(); ++b) distinct = distinct && m->w[a]->device != m->w[b]->device;
+        auto& R = m->rccl;
+        if (distinct) R.lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+        if (!R.lib && distinct) R.lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+        if (R.lib) {
+            R.CommInitAll = reinterpret_cast<decltype(R.CommInitAll)>(dlsym(R.lib, "ncclCommInitAll"));
+            R.CommDestroy = reinterpret_cast<decltype(R.CommDestroy)>(dlsym(R.lib, "ncclCommDestroy"));
+            R.GroupStart = reinterpret_cast<decltype(R.GroupStart)>(dlsym(R.lib, "ncclGroupStart"));
+            R.GroupEnd = reinterpret_cast<decltype(R.GroupEnd)>(dlsym(R.lib, "ncclGroupEnd"));
+            R.Broadcast = reinterpret_cast<decltype(R.Broadcast)>(dlsym(R.lib, "ncclBroadcast"));
+            R.GetErrorString = reinterpret_cast<decltype(R.GetErrorString)>(dlsym(R.lib, "ncclGetErrorString"));
+            if (R.CommInitAll && R.CommDestroy && R.GroupStart && R.GroupEnd && R.Broadcast) {
+                std::vector<int> devs;
+                for (auto* w : m->w) devs.push_back(w->device);
+                R.comm.assign(m->w.size(), nullptr);
+                const int e = R.CommInitAll(R.comm.data(), (int)devs.size(), devs.data());
+                if (e == 0) R.active = true;
+                else {
+                    snprintf(m->err, sizeof(m->err), "multi_init: ncclCommInitAll failed (%s): key frames go by peer copies",
+                             R.GetErrorString ? R.GetErrorString(e) : "?");
+                    R.comm.clear();
+                }
+            }
+        }
+    }
     if (caller_device >= 0) (void)hipSetDevice(caller_device);
     for (auto* w : m->w) w->th = std::thread(worker_main, w);
     *out = m;
     return OFPS_HIP_OK;
+}
+
+// 0 = key frames travel by hipMemcpyPeerAsync (the default), 1 = by ncclBroadcast over the communicator made at init; *broadcasts (may be
+// NULL): how many key frames went that way
+int ofps_hip_multi_fanout(const ofps_hip_multi* m, uint64_t* broadcasts) {
+    if (!m) return OFPS_HIP_EINVAL;
+    if (broadcasts) *broadcasts = m->rccl.broadcasts;
+    return m->rccl.active ? 1 : 0;
 }
 
 void ofps_hip_multi_destroy(ofps_hip_multi* m) {
@@ -245,6 +301,8 @@ void ofps_hip_multi_destroy(ofps_hip_multi* m) {
         delete w;
     }
     for (auto* h : m->halo) if (h) (void)hipHostFree(h);
+    if (m->rccl.active) for (void* c : m->rccl.comm) if (c) (void)m->rccl.CommDestroy(c);
+    if (m->rccl.lib) (void)dlclose(m->rccl.lib);
     delete m;
 }
 
@@ -289,6 +347,28 @@ int ofps_hip_multi_stage_frames(ofps_hip_multi* m, const uint8_t* frames, int n_
         return OFPS_HIP_OK;
     });
     if (rc != OFPS_HIP_OK) return rc;
+    // phase 2 (key mode), RCCL form: ONE ncclBroadcast of the key frame from worker 0's device inside a group call, each rank on its worker's
+    // stream (the single-process multi-device idiom; the workers are idle: phase 1 has been synchronised).  Also with one worker (a
+    // communicator of one rank: the broadcast is a self-copy in place) so that the path can be exercised on a one-GPU box.
+    if (ref_mode == 1 && m->rccl.active) {
+        auto& R = m->rccl;
+        int e = R.GroupStart();
+        for (int k = 0; k < n && e == 0; ++k) {
+            Worker& w = *m->w[(size_t)k];
+            if (k != 0 && !w.n_pairs) continue;
+            e = R.Broadcast(w.d_frames, w.d_frames, m->pitch, /*ncclUint8*/ 1, /*root*/ 0, R.comm[(size_t)k], w.ctx->stream);
+        }
+        const int e2 = R.GroupEnd();
+        if (e != 0 || e2 != 0)
+            return multi_error(m, OFPS_HIP_EDEVICE, "multi_stage_frames: ncclBroadcast of the key frame failed (%s)",
+                               R.GetErrorString ? R.GetErrorString(e ? e : e2) : "?");
+        for (int k = 0; k < n; ++k) {
+            Worker& w = *m->w[(size_t)k];
+            if (hipSetDevice(w.device) != hipSuccess || hipStreamSynchronize(w.ctx->stream) != hipSuccess)
+                return multi_error(m, OFPS_HIP_EDEVICE, "multi_stage_frames: synchronising worker %d after the broadcast failed", k);
+        }
+        R.broadcasts += 1;
+    } else
     // phase 2 (key mode): the key frame travels device to device from worker 0's copy -- one xGMI hop per receiver
     if (ref_mode == 1 && n > 1) {
         Worker* w0 = m->w[0];
