@@ -937,11 +937,11 @@ __device__ __forceinline__ void lk_store(const float2 out, int x, int y, int w, 
 // level-0 gradient planes exist (lk_stage3_u8; the rectangle is converted while it is staged).
 constexpr int kLkMaxRounds = 8;
 constexpr long long kLkHelpAfterTicks = 15000;      // wall_clock64 ticks (100 MHz) per ancestor level a tile waits for its parent before it computes it itself
-template <int RADIUS, bool U8, typename HelpFn>
-__device__ __forceinline__ void lk_level_body(LkStepShared<RADIUS>& sh, const void* __restrict__ I_, const void* __restrict__ J_, int src_stride,
+template <int RADIUS, bool U8>
+__device__ __forceinline__ bool lk_level_body(LkStepShared<RADIUS>& sh, const void* __restrict__ I_, const void* __restrict__ J_, int src_stride,
                                               int w, int h, int iters, const LkFlowIO io, unsigned long long* __restrict__ prof,
                                               int force_fall_arg, int tile_x, int tile_y, const uint32_t* parent_flag, uint32_t* done_flag,
-                                              uint32_t epoch, int wait_budget_arg, int depth, HelpFn help_ancestors) {
+                                              uint32_t epoch, int wait_budget_arg, int depth) {
     // force_fall (libofps_hip_testhooks.so only; compiled out of the product library): low 4 bits = a step at which every
     // other tile is treated as not fitting, so that the grouped path in the middle of a level is exercised on inputs that
     // would never trigger it; bits 4.. = how many grouping rounds those tiles get (0 = the default kLkMaxRounds; 1 + n = n
@@ -978,7 +978,7 @@ __device__ __forceinline__ void lk_level_body(LkStepShared<RADIUS>& sh, const vo
     // coarser level (its parent), normally a workgroup of the same launch with a lower block index that is running or done.  Thread 0
     // polls the parent's flag past the caches until it carries this launch's epoch.  FORWARD PROGRESS (round 6) does not depend on that
     // "normally": a tile whose parent has not published within kLkHelpAfterTicks per ancestor level (0.15 ms each; an in-order launch makes
-    // a tile wait at most about half of that per level) stops waiting and COMPUTES the missing ancestors itself, coarsest first (lk_help_ancestors) -- a tile's flows are a pure
+    // a tile wait at most about half of that per level) stops waiting and COMPUTES the missing ancestors itself, coarsest first, then itself (lk_help_tile) -- a tile's flows are a pure
     // function of the frames, so a tile computed twice is written twice with the same bits and its flag set twice with the same epoch.
     // Every workgroup therefore finishes in bounded time whatever the dispatcher does (any order, any number of resident workgroups, a
     // CU-masked stream), and no flow is ever made from an unfinished parent.  Rounds 4-5 went on "with whatever the plane holds" and
@@ -1003,7 +1003,7 @@ __device__ __forceinline__ void lk_level_body(LkStepShared<RADIUS>& sh, const vo
             s_help = help;
         }
         __syncthreads();
-        if (s_help) help_ancestors();                                    // uniform; rare
+        if (s_help) return false;                                        // uniform; rare: the caller hands the tile to lk_help_tile (nothing has been written yet)
     }
     float2 f[PP];
 #pragma unroll
@@ -1505,6 +1505,7 @@ __device__ __forceinline__ void lk_level_body(LkStepShared<RADIUS>& sh, const vo
     }
     OFPS_LK_STAMP(5);
 #undef OFPS_LK_STAMP
+    return true;
 }
 
 // The whole pyramid in ONE launch.  Blocks are ordered coarsest level first (each level's range padded to a multiple of 8 so
@@ -1531,12 +1532,14 @@ struct LkLevelsArgs {
     unsigned long long* prof;
     LkLevelArgs lv[8];            // lv[0] = the coarsest level ... lv[levels - 1] = level 0
 };
-// The missing ancestors of tile (tx, ty) of level index k (lv[0] = the coarsest), computed by the waiting workgroup itself: thread 0 climbs
-// from the grandparent up while the flags are not this launch's (one look each), then the tiles are made coarsest first -- each one's
-// parent is done by then -- and published like any other.  Not inlined: the cold path must not cost the level kernel registers.  A: the
-// kernel's own argument segment (the level table is read from there).
+// A tile whose parent did not publish in time: the missing ancestors of tile (tx, ty) of level index k (lv[0] = the coarsest), then the tile
+// itself, computed by this workgroup.  Thread 0 climbs from the grandparent up while the flags are not this launch's (one look each), then
+// the tiles are made coarsest first -- each one's parent is done by then -- and published like any other.  Not inlined, and called in
+// TAIL position (lk_levels_kernel has nothing to do afterwards): the cold path costs the level kernel neither registers nor spills around a
+// call -- a first form that called a helper from inside lk_level_body and went on cost 2.8 % (SGPR spills 8 -> 72: profiles/r06/
+// lk_forward_progress.txt).  A: the kernel's own argument segment (the level table is read from there).
 template <int RADIUS>
-__device__ __noinline__ void lk_help_ancestors(LkStepShared<RADIUS>* sh, const LkLevelsArgs* A, int k, int tx, int ty) {
+__device__ __noinline__ void lk_help_tile(LkStepShared<RADIUS>* sh, const LkLevelsArgs* A, int k, int tx, int ty) {
     uint32_t* const flags = A->flags;
     const uint32_t epoch = A->epoch;
     __shared__ int s_from;
@@ -1554,26 +1557,29 @@ __device__ __noinline__ void lk_help_ancestors(LkStepShared<RADIUS>* sh, const L
     }
     __syncthreads();
     const int from = s_from;
-    for (int j = from; j < k; ++j) {
+    for (int j = from; j <= k; ++j) {
         const int ax = tx >> (k - j), ay = ty >> (k - j);
-        uint32_t* done = flags + A->lv[j].flag_off + (size_t)ay * A->lv[j].tiles_x + ax;
+        uint32_t* done = j < A->levels - 1 ? flags + A->lv[j].flag_off + (size_t)ay * A->lv[j].tiles_x + ax : nullptr;
         LkFlowIO io = A->lv[j].io;
-        lk_level_body<RADIUS, false>(*sh, A->lv[j].I, A->lv[j].J, A->lv[j].stride, A->lv[j].w, A->lv[j].h, A->iters, io, nullptr, A->force_fall, ax, ay,
-                                     nullptr, done, epoch, 0, 0, [] {});
+        if (A->lv[j].u8)
+            lk_level_body<RADIUS, true>(*sh, A->lv[j].I, A->lv[j].J, A->lv[j].stride, A->lv[j].w, A->lv[j].h, A->iters, io, nullptr, A->force_fall, ax, ay,
+                                        nullptr, done, epoch, 0, 0);
+        else
+            lk_level_body<RADIUS, false>(*sh, A->lv[j].I, A->lv[j].J, A->lv[j].stride, A->lv[j].w, A->lv[j].h, A->iters, io, nullptr, A->force_fall, ax, ay,
+                                         nullptr, done, epoch, 0, 0);
         __syncthreads();                                                 // (everybody is done with `sh`)
     }
 }
 
-template <int RADIUS>
-__global__ __launch_bounds__(256, LkStepShared<RADIUS>::WAVES_PER_SIMD) void lk_levels_kernel(const LkLevelsArgs A) {
-    __shared__ LkStepShared<RADIUS> sh;
+// block -> (level index, tile); false: a padding block of a level's range.  delay: the test hook's start delay (first call only)
+__device__ __forceinline__ bool lk_position(const LkLevelsArgs& A, bool delay, int* k_out, int* tx_out, int* ty_out) {
     unsigned b = blockIdx.x;
 #ifdef OFPS_HIP_TEST_HOOKS
     // OFPS_HIP_LK_TEST_ORDER: the launch as another dispatcher would run it -- 1: the blocks take the positions in REVERSE (level 0's tiles
     // first, the coarsest level last), 2: a pseudo-random permutation of the positions, and every workgroup starts after a pseudo-random delay
     if (A.test_order == 1) b = gridDim.x - 1 - b;
     else if (A.test_order == 2) b = (unsigned)(((unsigned long long)b * A.test_mul + A.test_add) % gridDim.x);
-    if (A.test_order) {
+    if (A.test_order && delay) {
         unsigned hsh = blockIdx.x * 2654435761u;
         hsh ^= hsh >> 15;
         for (unsigned i = 0; i < (hsh & 63u); ++i) __builtin_amdgcn_s_sleep(64);
@@ -1585,16 +1591,32 @@ __global__ __launch_bounds__(256, LkStepShared<RADIUS>::WAVES_PER_SIMD) void lk_
     const LkLevelArgs& L = A.lv[k];
     const unsigned local = b - L.start;
     const int t = (int)((local % 8u) * (L.count / 8u) + local / 8u);
-    if (t >= L.ntiles) return;
-    const int ty = t / L.tiles_x, tx = t - ty * L.tiles_x;
+    if (t >= L.ntiles) return false;
+    const int ty = t / L.tiles_x;
+    *k_out = k; *ty_out = ty; *tx_out = t - ty * L.tiles_x;
+    return true;
+}
+
+template <int RADIUS>
+__global__ __launch_bounds__(256, LkStepShared<RADIUS>::WAVES_PER_SIMD) void lk_levels_kernel(const LkLevelsArgs A) {
+    __shared__ LkStepShared<RADIUS> sh;
+    int k, tx, ty;
+    if (!lk_position(A, true, &k, &tx, &ty)) return;
+    const LkLevelArgs& L = A.lv[k];
     // the parent: the tile of the next coarser level (lv[k - 1]) that holds this tile's half-resolution pixels
     const uint32_t* parent = k > 0 ? A.flags + A.lv[k - 1].flag_off + (size_t)(ty / 2) * A.lv[k - 1].tiles_x + tx / 2 : nullptr;
     uint32_t* done = k < A.levels - 1 ? A.flags + L.flag_off + (size_t)ty * L.tiles_x + tx : nullptr;
-    auto help = [&] { lk_help_ancestors<RADIUS>(&sh, (const LkLevelsArgs*)__builtin_amdgcn_kernarg_segment_ptr(), k, tx, ty); };   // (the kernel's only argument: offset 0)
+    bool ok;
     if (L.u8)
-        lk_level_body<RADIUS, true>(sh, L.I, L.J, L.stride, L.w, L.h, A.iters, L.io, A.prof, A.force_fall, tx, ty, parent, done, A.epoch, A.wait_budget, k, help);
+        ok = lk_level_body<RADIUS, true>(sh, L.I, L.J, L.stride, L.w, L.h, A.iters, L.io, A.prof, A.force_fall, tx, ty, parent, done, A.epoch, A.wait_budget, k);
     else
-        lk_level_body<RADIUS, false>(sh, L.I, L.J, L.stride, L.w, L.h, A.iters, L.io, nullptr, A.force_fall, tx, ty, parent, done, A.epoch, A.wait_budget, k, help);
+        ok = lk_level_body<RADIUS, false>(sh, L.I, L.J, L.stride, L.w, L.h, A.iters, L.io, nullptr, A.force_fall, tx, ty, parent, done, A.epoch, A.wait_budget, k);
+    if (!ok) {                                                           // uniform; rare
+        // (the position is made AGAIN here instead of being kept alive across the tile: the cold path must not cost the hot one registers)
+        int k2, tx2, ty2;
+        lk_position(A, false, &k2, &tx2, &ty2);
+        lk_help_tile<RADIUS>(&sh, (const LkLevelsArgs*)__builtin_amdgcn_kernarg_segment_ptr(), k2, tx2, ty2);     // the kernel's only argument is at offset 0
+    }
 }
 
 // cv-decoder/src/lib.rs:239-243,262-269: per-pixel records, raster order
