@@ -31,7 +31,30 @@ def entries(n, seed, lo=0.0, hi=1.0, scale=0.01):
     return e
 
 
+def frontend():
+    """frontend.npz (round 6): cv-decoder's frame front-end and its "Process Fullres" = false mode on one small BGR pair -- the resized colour
+    frame, the gray frames both modes leave, the reduced decoder's records with Farneback's flow (cv-decoder's own) cold and with the
+    previous flow carried over, and with the build's LK flow.  python tests/golden/generate.py frontend"""
+    rng = np.random.default_rng(61)
+    y = synth.flatten_regions(synth.luma_sequence(3, 320, 180, max_step=3, seed=61), region=36, seed=62)
+    # (channel offsets + a little noise: the flattened regions stay flat enough for the contrast mask to drop them)
+    bgr = np.clip(y[..., None].astype(int) + np.array([12, -7, 20]) + rng.integers(-2, 3, (1, 180, 320, 3)), 0, 255).astype(np.uint8)
+    gw, gh = oracle.cv_grid(320, 180, 120, 120)
+    d = {"bgr": bgr, "grid_120": np.array([gw, gh]), "bgr_small": oracle.resize_linear(bgr[1], gw, gh),
+         "gray_full": oracle.cv_frontend(bgr[1], oracle.FMT_BGR), "gray_small": oracle.cv_frontend(bgr[1], oracle.FMT_BGR, False, 120, 120),
+         "luma_small": oracle.resize_linear(y[1], gw, gh)}
+    r1, _, f1 = oracle.cv_decode(bgr[0], bgr[1], oracle.FMT_BGR, process_fullres=False, max_w=120, max_h=120)
+    r2, _, _ = oracle.cv_decode(bgr[1], bgr[2], oracle.FMT_BGR, process_fullres=False, max_w=120, max_h=120, init=f1)
+    r_lk, _, _ = oracle.cv_decode(bgr[0], bgr[1], oracle.FMT_BGR, process_fullres=False, max_w=120, max_h=120, flow="lk")
+    assert 0.2 * gw * gh < len(r1) < 0.98 * gw * gh, len(r1)              # partly masked
+    d.update(records_pair01=r1, flow_pair01=f1, records_pair12_warm=r2, records_pair01_lk=r_lk)
+    np.savez_compressed(os.path.join(HERE, "frontend.npz"), **d)
+    print({k: v.shape for k, v in d.items()})
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "frontend":
+        return frontend()
     # ---- Almeida: 8 of the reference's 32 cases with full fields (inputs are 2.5k x 4 floats each), all 32 answers
     cam = oracle.camera(1.0, 90.0)
     cases = ac.cases()

@@ -88,6 +88,27 @@ def test_flow_revision_1_golden_guards_the_spec_against_drift():
     assert differing > 0.05, differing                     # the revisions are far enough apart for a drift to show
 
 
+def test_oracle_reproduces_frontend_golden():
+    """cv-decoder's front-end + reduced mode (round 6): the C oracle and the independent NumPy restatement against the committed bytes"""
+    from tests import indep_frontend as indep
+    g = _load("frontend.npz")
+    bgr = g["bgr"]
+    gw, gh = (int(v) for v in g["grid_120"])
+    assert (gw, gh) == oracle.cv_grid(320, 180, 120, 120) == (120, 67)
+    np.testing.assert_array_equal(oracle.resize_linear(bgr[1], gw, gh), g["bgr_small"])
+    np.testing.assert_array_equal(indep.resize_linear(bgr[1], gw, gh), g["bgr_small"])
+    np.testing.assert_array_equal(oracle.to_gray(bgr[1]), g["gray_full"])
+    np.testing.assert_array_equal(indep.to_gray(indep.resize_linear(bgr[1], gw, gh)), g["gray_small"])
+    r1, grid, f1 = oracle.cv_decode(bgr[0], bgr[1], oracle.FMT_BGR, process_fullres=False, max_w=120, max_h=120)
+    assert grid == (gw, gh) and 0 < len(r1) <= gw * gh
+    np.testing.assert_array_equal(r1.view(np.uint32), g["records_pair01"].view(np.uint32))
+    np.testing.assert_array_equal(f1.view(np.uint32), g["flow_pair01"].view(np.uint32))
+    r2, _, _ = oracle.cv_decode(bgr[1], bgr[2], oracle.FMT_BGR, process_fullres=False, max_w=120, max_h=120, init=f1)
+    np.testing.assert_array_equal(r2.view(np.uint32), g["records_pair12_warm"].view(np.uint32))
+    r_lk, _, _ = oracle.cv_decode(bgr[0], bgr[1], oracle.FMT_BGR, process_fullres=False, max_w=120, max_h=120, flow="lk")
+    np.testing.assert_array_equal(r_lk.view(np.uint32), g["records_pair01_lk"].view(np.uint32))
+
+
 # ---------------------------------------------------------------- HIP path vs golden (GPU)
 @pytest.fixture(scope="module")
 def ctx():
@@ -156,6 +177,27 @@ def test_hip_flow_decoder_matches_golden(ctx):
     ent, (gw, gh) = ctx.lk_decode(fr[0], fr[1], max_w=60, max_h=60, contrast_mask=True)
     assert (gw, gh) == (60, 36)
     np.testing.assert_array_equal(ent.view(np.uint32), g["cells_60x36"].view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_hip_frontend_and_reduced_decoder_match_golden(ctx):
+    g = _load("frontend.npz")
+    bgr = g["bgr"]
+    gw, gh = (int(v) for v in g["grid_120"])
+    np.testing.assert_array_equal(ctx.resize_linear(bgr[1], gw, gh, ctx.FMT_BGR), g["bgr_small"])
+    np.testing.assert_array_equal(ctx.cv_frontend(bgr[1], ctx.FMT_BGR, False), g["gray_full"])
+    np.testing.assert_array_equal(ctx.cv_frontend(bgr[1], ctx.FMT_BGR, True, 120, 120), g["gray_small"])
+    kw = dict(max_w=120, max_h=120, contrast_mask=True, reduced=True, fmt=ctx.FMT_BGR)
+    ctx.lk_reset()
+    assert ctx.lk_push_frame(bgr[0], 5, 6, 3, farneback=True, use_previous=True, **kw) is None
+    r1, grid = ctx.lk_push_frame(bgr[1], 5, 6, 3, farneback=True, use_previous=True, **kw)
+    r2, _ = ctx.lk_push_frame(bgr[2], 5, 6, 3, farneback=True, use_previous=True, **kw)
+    ctx.lk_reset()
+    assert grid == (gw, gh)
+    np.testing.assert_array_equal(r1.view(np.uint32), g["records_pair01"].view(np.uint32))
+    np.testing.assert_array_equal(r2.view(np.uint32), g["records_pair12_warm"].view(np.uint32))
+    r_lk, _ = ctx.lk_decode(bgr[0], bgr[1], 3, 4, 3, **kw)
+    np.testing.assert_array_equal(r_lk.view(np.uint32), g["records_pair01_lk"].view(np.uint32))
 
 
 @pytest.mark.gpu
