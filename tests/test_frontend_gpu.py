@@ -233,3 +233,46 @@ def test_farneback_limits_are_refused_with_the_first_frame(ctx):
     f_o = oracle.farneback_flow(big[0], big[1], levels=6)
     assert len(oracle.farneback_layers(3840, 2160, 6)) == 7
     np.testing.assert_array_equal(f_g.view(np.uint32), f_o.view(np.uint32))
+
+
+def test_decoders_take_padded_strides_and_every_format(ctx):
+    """rows `stride` bytes apart with stride > W * channels and not a multiple of 4 (the dword fast paths must not be taken), RGBA / BGRA
+    frames, a frame smaller than the cap in the reduced mode (the "resize" is a copy, the records are still per pixel, cv-decoder/src/lib.rs:
+    98-121,274-276) -- through the C ABI directly"""
+    import ctypes as C
+    from ofps_amd import _lib
+    lib = _lib.load()
+    W, H = 333, 177
+    clip = colour_clip(2, W, H, seed=31)
+    rec_o, grid_o, _ = oracle.cv_decode(clip[0], clip[1], oracle.FMT_BGR, process_fullres=False)
+    stride = 3 * W + 13
+    buf = np.zeros((2, H, stride), np.uint8)
+    buf[:, :, :3 * W] = clip.reshape(2, H, 3 * W)
+    out = np.zeros((150 * 150, 4), np.float32)
+    n = C.c_size_t(0); gw = C.c_int(0); gh = C.c_int(0)
+    u8 = C.POINTER(C.c_uint8)
+    flags = ctx.LK_CONTRAST_MASK | ctx.FLOW_FARNEBACK | ctx.LK_REDUCED | (ctx.FMT_BGR << 8)
+    rc = lib.ofps_hip_lk_decode(ctx._h, buf[0].ctypes.data_as(u8), buf[1].ctypes.data_as(u8), W, H, stride, 5, 6, 3, 150, 150, flags,
+                                out.ctypes.data_as(C.POINTER(C.c_float)), C.byref(n), C.byref(gw), C.byref(gh))
+    assert rc == 0 and (gw.value, gh.value) == grid_o
+    np.testing.assert_array_equal(out[:n.value].view(np.uint32), rec_o.view(np.uint32))
+    # a stride that cannot hold a row is refused
+    rc = lib.ofps_hip_lk_decode(ctx._h, buf[0].ctypes.data_as(u8), buf[1].ctypes.data_as(u8), W, H, 3 * W - 1, 5, 6, 3, 150, 150, flags,
+                                out.ctypes.data_as(C.POINTER(C.c_float)), C.byref(n), C.byref(gw), C.byref(gh))
+    assert rc == -1
+    # RGBA / BGRA: the same gray frames as the BGR clip, hence the same records
+    rgba = np.concatenate([clip[..., ::-1], np.full(clip.shape[:3] + (1,), 255, np.uint8)], 3)
+    bgra = np.concatenate([clip, np.full(clip.shape[:3] + (1,), 3, np.uint8)], 3)
+    for fr, fmt in ((rgba, ctx.FMT_RGBA), (bgra, ctx.FMT_BGRA)):
+        rec, grid = ctx.lk_decode(fr[0], fr[1], 5, 6, 3, contrast_mask=True, farneback=True, reduced=True, fmt=fmt)
+        assert grid == grid_o
+        np.testing.assert_array_equal(rec.view(np.uint32), rec_o.view(np.uint32))
+        rec_f, _ = ctx.lk_decode(fr[0], fr[1], 5, 6, 3, contrast_mask=True, farneback=True, fmt=fmt)
+        rec_fo, _, _ = oracle.cv_decode(clip[0], clip[1], oracle.FMT_BGR, process_fullres=True)
+        np.testing.assert_array_equal(rec_f.view(np.uint32), rec_fo.view(np.uint32))
+    # a frame under the cap: grid = frame, one record per unmasked pixel, no densifier
+    small = colour_clip(2, 96, 64, seed=5)
+    rec, grid = ctx.lk_decode(small[0], small[1], 5, 6, 3, contrast_mask=False, farneback=True, reduced=True, fmt=ctx.FMT_BGR)
+    rec_so, grid_so, _ = oracle.cv_decode(small[0], small[1], oracle.FMT_BGR, process_fullres=False, contrast_mask_on=False)
+    assert grid == grid_so == (96, 64) and len(rec) == 96 * 64
+    np.testing.assert_array_equal(rec.view(np.uint32), rec_so.view(np.uint32))

@@ -19,6 +19,11 @@ clean = HipContext(0)                     # stateless calls: the same call here 
 #                                           itself a weaker version of the test, so a third context replays a sample)
 GEOMS = [(64, 48), (160, 96), (320, 176), (97, 61), (384, 216)]
 frames = {g: synth.luma_sequence(6, g[0], g[1], max_step=3, seed=40 + g[0]) for g in GEOMS}
+bgr_frames = {g: np.clip(frames[g][..., None].astype(int) + np.array([9, -6, 15]) + np.random.default_rng(7).integers(-3, 4, frames[g].shape + (3,)), 0, 255).astype(np.uint8) for g in GEOMS}
+def front_end():
+    """round 6: a random frame format / "Process Fullres" setting for the dense decoders -> (kwargs, which frame set)"""
+    fmt = int(rng.integers(2)); red = bool(rng.integers(2))
+    return dict(fmt=fmt, reduced=red), (bgr_frames if fmt else frames)
 fields = {n: synth.rotation_field(*n) for n in [(16, 9), (40, 30), (64, 36)]}
 bad = []
 def same(a, b): return a.shape == b.shape and np.array_equal(a.view(np.uint32) if a.dtype == np.float32 else a, b.view(np.uint32) if b.dtype == np.float32 else b)
@@ -38,26 +43,31 @@ def op_lk_flow():
     return same(ctx.lk_flow(frames[g][a], frames[g][b], L, Rr, it), clean.lk_flow(frames[g][a], frames[g][b], L, Rr, it))
 def op_lk_decode():
     g = GEOMS[rng.integers(len(GEOMS))]; a, b = rng.integers(6, size=2)
-    kw = dict(contrast_mask=bool(rng.integers(2)), fullres_records=bool(rng.integers(2)), max_w=int([40, 150][rng.integers(2)]), farneback=bool(rng.integers(2)))
-    r, e = ctx.lk_decode(frames[g][a], frames[g][b], 2, 4, 2, **kw), clean.lk_decode(frames[g][a], frames[g][b], 2, 4, 2, **kw)
+    fe, fs = front_end()
+    kw = dict(contrast_mask=bool(rng.integers(2)), fullres_records=bool(rng.integers(2)) and not fe["reduced"], max_w=int([40, 150][rng.integers(2)]), farneback=bool(rng.integers(2)), **fe)
+    r, e = ctx.lk_decode(fs[g][a], fs[g][b], 2, 4, 2, **kw), clean.lk_decode(fs[g][a], fs[g][b], 2, 4, 2, **kw)
     return r[1] == e[1] and same(r[0], e[0])
 def op_lk_stream():
     s = lk_stream
     if s["geom"] is None or rng.random() < 0.08:                         # (re)start, maybe with a new geometry, tickets in flight collected first
         for t, *_ in s["pending"]: ctx.lk_frame_wait(t)
-        s["pending"] = []; ctx.lk_reset(); s["geom"] = GEOMS[rng.integers(len(GEOMS))]; s["k"] = 0; s["pins"] = [ctx.pinned_frame(s["geom"][1], s["geom"][0]) for _ in range(3)]
+        s["pending"] = []; ctx.lk_reset(); s["geom"] = GEOMS[rng.integers(len(GEOMS))]; s["k"] = 0
+        s["fe"], s["frames"] = front_end()
+        gw_, gh_ = s["geom"]
+        s["pins"] = [ctx.pinned_frame(gh_, gw_ * 3).reshape(gh_, gw_, 3) if s["fe"]["fmt"] else ctx.pinned_frame(gh_, gw_) for _ in range(3)]
         # half of the streams are hip_flow streams (round 5): their frames reuse the previous frame's pyramid + expansion, which every
         # other Farneback call through this context (op_fb_flow, op_lk_decode) must invalidate
-        s["kw"] = dict(farneback=True) if rng.random() < 0.5 else {}
-        s["par"] = (int(rng.integers(1, 4)), int([2, 4, 6][rng.integers(3)]), 2) if s["kw"] else (2, 4, 2)
+        s["kw"] = dict(farneback=True, **s["fe"]) if rng.random() < 0.5 else dict(s["fe"])
+        s["par"] = (int(rng.integers(1, 4)), int([2, 4, 6][rng.integers(3)]), 2) if s["kw"].get("farneback") else (2, 4, 2)
         # half of those chain their flows (OFPS_HIP_FLOW_USE_PREVIOUS = cv-decoder's OPTFLOW_USE_INITIAL_FLOW): the expected records then come
         # from the same stream run synchronously on the replay context, which does nothing else
-        s["chained"] = bool(s["kw"]) and rng.random() < 0.5
+        s["chained"] = bool(s["kw"].get("farneback")) and rng.random() < 0.5
         if s["chained"]: s["kw"]["use_previous"] = True; s["ctx"].lk_reset()
     g, k = s["geom"], s["k"]
-    np.copyto(s["pins"][k % 3], frames[g][k % 6])
+    fset = s["frames"]
+    np.copyto(s["pins"][k % 3], fset[g][k % 6])
     t = ctx.lk_push_frame_async(s["pins"][k % 3], *s["par"], **s["kw"])
-    exp = s["ctx"].lk_push_frame(frames[g][k % 6], *s["par"], **s["kw"]) if s["chained"] else None
+    exp = s["ctx"].lk_push_frame(fset[g][k % 6], *s["par"], **s["kw"]) if s["chained"] else None
     s["pending"].append((t, k, exp)); s["k"] += 1
     ok = True
     while len(s["pending"]) > int(rng.integers(1, 3)) - 1 and s["pending"]:      # keep 0 or 1 tickets in flight
@@ -65,7 +75,7 @@ def op_lk_stream():
         r = ctx.lk_frame_wait(t0)
         if k0 == 0: ok &= r is None
         else:
-            e = e0 if s["chained"] else clean.lk_decode(frames[g][(k0 - 1) % 6], frames[g][k0 % 6], *s["par"], **s["kw"])
+            e = e0 if s["chained"] else clean.lk_decode(s["frames"][g][(k0 - 1) % 6], s["frames"][g][k0 % 6], *s["par"], **s["kw"])
             ok &= r is not None and e is not None and same(r[0], e[0])
     return ok
 def op_fb_flow():
