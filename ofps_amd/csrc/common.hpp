@@ -33,6 +33,7 @@ struct ofps_hip_ctx {
         int almeida_prof = 0;            // OFPS_HIP_ALMEIDA_PROF
         int lk_prof = 0;                 // OFPS_HIP_LK_PROF
         int lk_serial = 0;               // OFPS_HIP_LK_SERIAL: one launch per pyramid level instead of one for the pyramid
+        int multi_rccl = 0;              // OFPS_HIP_MULTI_RCCL: ofps_hip_multi_init fans the shared key frame out by ncclBroadcast (multi.hip)
         // fault injectors: only builds with -DOFPS_HIP_TEST_HOOKS (libofps_hip_testhooks.so) can set them, and only
         // through ofps_hip_set_option -- never from the environment
         int test_almeida_fault = 0;      // OFPS_HIP_ALMEIDA_TEST_FAULT: workgroup (value - 1) withholds its step-3 granule

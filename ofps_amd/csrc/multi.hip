@@ -239,8 +239,7 @@ int ofps_hip_multi_init(const int* devices, int n, ofps_hip_multi** out) {
     // OFPS_HIP_MULTI_RCCL=1: one RCCL communicator over the workers' devices (ncclCommInitAll: one process, one rank per device) for the
     // key-frame fan-out.  Needs distinct devices (RCCL refuses a device twice in a communicator: workers sharing a GPU keep the copy path)
     // and librccl.so at run time; anything missing is not an error -- the peer-copy path is the default and always there.
-    const char* want = getenv("OFPS_HIP_MULTI_RCCL");
-    if (want && want[0] && strcmp(want, "0") != 0) {
+    if (m->w[0]->ctx->opt.multi_rccl) {                       // (read from the environment by ofps_hip_init, like every switch)
         bool distinct = true;
         for (size_t a = 0; a < m->w.size(); ++a)
             for (size_t b = a + 1; b < m->w.size(); ++b) distinct = distinct && m->w[a]->device != m->w[b]->device;
