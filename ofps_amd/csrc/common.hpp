@@ -46,6 +46,7 @@ struct ofps_hip_ctx {
     int lk_w = 0, lk_h = 0;              // the arriving frames' size
     int lk_fw = 0, lk_fh = 0, lk_fmt = 0; // the size of the frames in the ring (reduced with OFPS_HIP_LK_REDUCED) and the arriving frames' format
     long lk_frames = 0;
+    bool lk_fb_params_valid = false; int lk_fb_levels = 0, lk_fb_radius = 0;     // the hip_flow stream's last Farneback parameters (a change with a ticket in flight is refused)
     uint64_t lk_frames_gen = 0;          // generation of the S_LK_FRAMES allocation the count refers to
     uint32_t lk_epoch = 0;               // lk_levels_kernel: tag of the last launch in the tile flags (S_LK_FLAGS)
     uint64_t lk_flags_gen = 0;           // generation of the flag buffer the tags refer to

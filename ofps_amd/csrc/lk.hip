@@ -2124,6 +2124,12 @@ int ofps_hip_lk_push_frame_async(ofps_hip_ctx* ctx, const uint8_t* frame, int W,
                          (g.frontend && ctx->scratch[ofps::S_FE_RAW].cap < ofps_hip_ctx::kLkTickets * raw_bytes);
     OFPS_REQUIRE(ctx, !(restart && other_pending), "lk_push_frame_async: geometry change %dx%d -> %dx%d with a ticket in flight "
                  "(collect it with ofps_hip_lk_frame_wait first)", ctx->lk_w, ctx->lk_h, W, H);
+    // hip_flow expands a new frame ahead of its pair, into the plane slot of the oldest frame of THIS parameter set: other Farneback parameters
+    // re-plan the workspace (other layers), which a flow still in flight would be reading -- refused like a geometry change
+    const bool fb_params_changed = g.farneback && ctx->lk_fb_params_valid && (ctx->lk_fb_levels != levels || ctx->lk_fb_radius != radius);
+    OFPS_REQUIRE(ctx, !(fb_params_changed && other_pending), "lk_push_frame_async: Farneback parameters changed (levels %d -> %d, radius %d -> %d) with a "
+                 "ticket in flight (collect it with ofps_hip_lk_frame_wait first)", ctx->lk_fb_levels, levels, ctx->lk_fb_radius, radius);
+    if (g.farneback) { ctx->lk_fb_params_valid = true; ctx->lk_fb_levels = levels; ctx->lk_fb_radius = radius; }
     if (restart) {
         rc = lk_stream_drain(ctx);
         if (rc != OFPS_HIP_OK) return rc;

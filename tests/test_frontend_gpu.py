@@ -276,3 +276,28 @@ def test_decoders_take_padded_strides_and_every_format(ctx):
     rec_so, grid_so, _ = oracle.cv_decode(small[0], small[1], oracle.FMT_BGR, process_fullres=False, contrast_mask_on=False)
     assert grid == grid_so == (96, 64) and len(rec) == 96 * 64
     np.testing.assert_array_equal(rec.view(np.uint32), rec_so.view(np.uint32))
+
+
+def test_hip_flow_parameter_change_with_a_ticket_in_flight_is_refused(ctx):
+    """a new frame is expanded ahead of its pair into the plane slot of the oldest frame; other Farneback parameters re-plan that workspace,
+    which a flow still in flight would be reading: refused like a geometry change, accepted once the ticket is collected"""
+    fr = synth.luma_sequence(4, 320, 180, max_step=2, seed=3)
+    pins = [ctx.pinned_frame(180, 320) for _ in range(4)]
+    for k in range(4):
+        np.copyto(pins[k], fr[k])
+    kw = dict(contrast_mask=True, farneback=True)
+    ctx.lk_reset()
+    t0 = ctx.lk_push_frame_async(pins[0], 5, 6, 3, **kw)
+    t1 = ctx.lk_push_frame_async(pins[1], 5, 6, 3, **kw)
+    assert ctx.lk_frame_wait(t0) is None
+    with pytest.raises(OfpsHipError) as ei:
+        ctx.lk_push_frame_async(pins[2], 2, 4, 3, **kw)                       # t1 is in flight
+    assert "in flight" in str(ei.value)
+    got = ctx.lk_frame_wait(t1)
+    want, _ = ctx.lk_decode(fr[0], fr[1], 5, 6, 3, **kw)
+    np.testing.assert_array_equal(got[0].view(np.uint32), want.view(np.uint32))
+    t2 = ctx.lk_push_frame_async(pins[2], 2, 4, 3, **kw)                      # nothing in flight: accepted, the pair (1, 2) with the new parameters
+    got = ctx.lk_frame_wait(t2)
+    want, _ = ctx.lk_decode(fr[1], fr[2], 2, 4, 3, **kw)
+    np.testing.assert_array_equal(got[0].view(np.uint32), want.view(np.uint32))
+    ctx.lk_reset()
