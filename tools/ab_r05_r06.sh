@@ -1,5 +1,7 @@
 #!/bin/bash
-# Same-box A/B of the cfg3 leg: the round-5 tree (build/r05tree: git archive of 2bdfaf5, built here) against this tree, alternating processes.
+# Same-box A/B of the cfg3 leg: the round-5 tree against this tree, alternating processes.  The round-5 tree is made in the build container first:
+#   mkdir -p build/r05tree && git archive 2bdfaf5 | tar -x -C build/r05tree && (cd build/r05tree && python -c "from ofps_amd import build; build.build(); import oracle; oracle.build()")
+# (build/ is git-ignored but travels to the GPU box with the snapshot).
 # usage (on the GPU box): tools/ab_r05_r06.sh [repeats]   -> gpurun_out/r06/ab_r05_r06.txt
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r06; mkdir -p $O
 N=${1:-3}
