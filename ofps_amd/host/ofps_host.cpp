@@ -172,12 +172,20 @@ bool HipLkDecoder::process_frame(MotionVectors& field, std::vector<RGBA>* out_fr
         in_->read(reinterpret_cast<char*>(cur_.data()), (std::streamsize)cur_.size());
         if ((size_t)in_->gcount() != cur_.size()) throw Error("hip_lk: failed to grab frame");
     }
-    if (out_frame && out_height) {                                    // :144-154 (the full-size frame as it arrived)
-        *out_height = h_;
-        out_frame->clear();
-        out_frame->reserve(w_ * h_);
+    if (out_frame && out_height) {                                    // :144-154: `self.frame` -- the arriving frame, or the REDUCED one ("Process Fullres" = false)
+        size_t ow = w_, oh = h_;
         const uint8_t* p = cur_.data();
-        for (size_t i = 0; i < w_ * h_; ++i, p += cn_) {
+        if (!process_fullres_) {
+            int gw = 0, gh = 0;
+            ctx_.check(ofps_hip_cv_grid((int)w_, (int)h_, (int)max_w_, (int)max_h_, &gw, &gh));
+            shown_.resize((size_t)gw * gh * cn_);
+            ctx_.check(ofps_hip_resize_linear(ctx_.get(), cur_.data(), (int)w_, (int)h_, (int)(w_ * cn_), fmt_, shown_.data(), gw, gh));
+            ow = (size_t)gw; oh = (size_t)gh; p = shown_.data();
+        }
+        *out_height = oh;
+        out_frame->clear();
+        out_frame->reserve(ow * oh);
+        for (size_t i = 0; i < ow * oh; ++i, p += cn_) {
             if (fmt_ == OFPS_HIP_FMT_LUMA) out_frame->push_back(RGBA{p[0], p[0], p[0], 255});
             else if (fmt_ == OFPS_HIP_FMT_RGBA) out_frame->push_back(RGBA{p[0], p[1], p[2], 255});
             else out_frame->push_back(RGBA{p[2], p[1], p[0], 255});   // BGR / BGRA

@@ -168,7 +168,13 @@ public:
                  bool farneback = false, int frame_format = OFPS_HIP_FMT_LUMA);
     bool process_frame(MotionVectors& field, std::vector<RGBA>* out_frame, size_t* out_height, size_t skip_frames) override;
     std::optional<double> get_framerate() const override { return fps_; }
-    std::optional<std::pair<size_t, size_t>> get_aspect() const override { return std::make_pair(w_, h_); }
+    // cv-decoder/src/lib.rs:296-298: the size of `self.gray` -- the reduced frame's with "Process Fullres" = false
+    std::optional<std::pair<size_t, size_t>> get_aspect() const override {
+        if (process_fullres_) return std::make_pair(w_, h_);
+        int gw = 0, gh = 0;
+        ofps_hip_cv_grid((int)w_, (int)h_, (int)max_w_, (int)max_h_, &gw, &gh);
+        return std::make_pair((size_t)gw, (size_t)gh);
+    }
     std::vector<std::pair<std::string, PropertyMut>> props_mut() override;
 private:
     HipContext ctx_;
@@ -180,7 +186,7 @@ private:
     std::optional<double> fps_;
     int fmt_ = OFPS_HIP_FMT_LUMA;
     size_t cn_ = 1;
-    std::vector<uint8_t> prev_, cur_;
+    std::vector<uint8_t> prev_, cur_, shown_;
     std::vector<float> out_;
     size_t frames_read_ = 0;
     bool on_device_ = false;           // the last frame of the previous call is on the device (ofps_hip_lk_push_frame's state)

@@ -145,6 +145,22 @@ class HipLkDecoder(HipSadDecoder):
         self.frame_format = frame_format
         self._mode = None
 
+    def get_aspect(self):
+        """cv-decoder/src/lib.rs:296-298: the size of `self.gray` -- the REDUCED frame's with "Process Fullres" = false"""
+        if self._cur is None:
+            return None
+        H, W = self._cur.shape[:2]
+        return (W, H) if self.process_fullres else self.ctx.cv_grid(W, H, self.max_w, self.max_h)
+
+    def _shown_frame(self) -> np.ndarray:
+        """what cv-decoder hands out as the frame (cv-decoder/src/lib.rs:144-154: `self.frame`): the arriving frame, or -- "Process Fullres" =
+        false -- the frame resized to the capped grid (channels kept)"""
+        if self.process_fullres:
+            return self._cur
+        H, W = self._cur.shape[:2]
+        gw, gh = self.ctx.cv_grid(W, H, self.max_w, self.max_h)
+        return self.ctx.resize_linear(self._cur, gw, gh, self.frame_format)
+
     def _flow_kw(self) -> dict:
         return dict(contrast_mask=self.contrast_mask, reduced=not self.process_fullres, fmt=self.frame_format,
                     fullres_records=self.fullres_records and self.process_fullres)
@@ -170,7 +186,7 @@ class HipLkDecoder(HipSadDecoder):
             except StopIteration:
                 raise EOFError("failed to grab frame") from None
         if out_frame is not None:
-            out_frame[:] = [self._cur]
+            out_frame[:] = [self._shown_frame()]
         if self._prev is None or self._prev.shape != self._cur.shape:
             self._on_device = None
             return False
@@ -197,7 +213,7 @@ class HipFlowDecoder(HipLkDecoder):
             except StopIteration:
                 raise EOFError("failed to grab frame") from None
         if out_frame is not None:
-            out_frame[:] = [self._cur]
+            out_frame[:] = [self._shown_frame()]
         if self._prev is None or self._prev.shape != self._cur.shape:
             self._on_device = None
             return False

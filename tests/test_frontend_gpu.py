@@ -180,11 +180,18 @@ def test_plugin_mirror_flips_process_fullres(ctx):
         rec_o, _, flow = oracle.cv_decode(fr[k - 1], fr[k], oracle.FMT_BGR, process_fullres=False, init=flow)
         assert 0 < len(rec_o) <= 12600
         np.testing.assert_array_equal(np.asarray(field, np.float32).view(np.uint32), rec_o.view(np.uint32))
+    assert dec.get_aspect() == (150, 84)                        # the reduced gray frame's size (cv-decoder/src/lib.rs:296-298)
+    shown = []
+    field = []
+    dec2 = HipFlowDecoder(iter(fr[:2]), frame_format=ctx.FMT_BGR); dec2.set_prop("Process Fullres", False)
+    dec2.process_frame(field, shown)                            # the frame handed out is cv-decoder's `self.frame`: the RESIZED colour frame (:144-154)
+    np.testing.assert_array_equal(shown[0], oracle.resize_linear(fr[0], 150, 84))
     dec.set_prop("Process Fullres", True)                       # frames 2, 3 are the pair now, at full resolution, from zero flow (a new stream)
     field = []
     assert dec.process_frame(field) is True
     rec_o, _, flow = oracle.cv_decode(fr[2], fr[3], oracle.FMT_BGR, process_fullres=True)
     np.testing.assert_array_equal(np.asarray(field, np.float32).view(np.uint32), rec_o.view(np.uint32))
+    assert dec.get_aspect() == (640, 360)
     field = []
     assert dec.process_frame(field, skip_frames=1) is True      # frames 4 read and dropped, pair (4, 5): the flow of (2, 3) is still the initial flow
     rec_o, _, flow = oracle.cv_decode(fr[4], fr[5], oracle.FMT_BGR, process_fullres=True, init=flow)
