@@ -152,9 +152,11 @@ enum ScratchSlot {
     S_FB_FLOW,              // hip_flow streams with OFPS_HIP_FLOW_USE_PREVIOUS: the last pair's flow (the next pair's initial flow)
     S_XMAJOR,               // densify.hip, raster producers: the field + visited flag in (x, y)-sorted cell order (the record order)
     S_LK_MASKS,             // dense decoders, stream forms: one contrast mask per ticket in flight (made on the upload's stream, beside the previous pair's flow)
-    S_FE_RAW                // frontend.hip: the frames as they arrive (colour and / or full size) when the decoder resizes / converts them: one per ticket in flight
+    S_FE_RAW,               // frontend.hip: the frames as they arrive (colour and / or full size) when the decoder resizes / converts them: one per ticket in flight
+    S_FE_RAW_PAIR           // ... of the stateless calls (ofps_hip_lk_decode, ofps_hip_cv_frontend, ofps_hip_resize_linear): never the stream's staging, whose
+                            // upload + front-end may still be running on the upload stream when such a call comes in
 };
-static_assert(S_FE_RAW < ofps_hip_ctx::kNumScratch, "scratch table too small");
+static_assert(S_FE_RAW_PAIR < ofps_hip_ctx::kNumScratch, "scratch table too small");
 
 // Page-locked blocks that kernels write directly and the host reads after an event (ticket result blocks, ofps_hip_host_alloc):
 // fine-grained host memory, asked for explicitly.  A/B builds (tools/read_ahead_bisect.sh) override the two constants with -D.

@@ -197,7 +197,7 @@ static int fe_host_call(ofps_hip_ctx* ctx, const uint8_t* src, int W, int H, int
     OFPS_REQUIRE(ctx, cn != 0, "frontend: unknown frame format %d", fmt);
     OFPS_REQUIRE(ctx, W >= 1 && H >= 1 && dw >= 1 && dh >= 1 && stride >= W * cn, "frontend: bad geometry");
     const size_t row = (size_t)W * cn, row_al = (row + 3) & ~(size_t)3, out_bytes = (size_t)dw * dh * (to_gray ? 1 : cn);
-    auto* d_src = static_cast<uint8_t*>(ofps::scratch(ctx, ofps::S_FE_RAW, row_al * H));
+    auto* d_src = static_cast<uint8_t*>(ofps::scratch(ctx, ofps::S_FE_RAW_PAIR, row_al * H));
     auto* d_dst = static_cast<uint8_t*>(ofps::scratch(ctx, ofps::S_FRAMES, out_bytes));
     if (!d_src || !d_dst) return OFPS_HIP_ENOMEM;
     OFPS_HIP_TRY(ctx, ofps::upload_rows(d_src, row_al, src, stride, row, H, ctx->stream));

@@ -2071,7 +2071,7 @@ int ofps_hip_lk_decode(ofps_hip_ctx* ctx, const uint8_t* prev, const uint8_t* cu
     if (rc != OFPS_HIP_OK) return rc;
     const size_t px = (size_t)g.fw * g.fh, raw_bytes = g.raw_row * (size_t)H;
     auto* d_frames = static_cast<uint8_t*>(ofps::scratch(ctx, ofps::S_FRAMES, 2 * px));
-    auto* d_raw = g.frontend ? static_cast<uint8_t*>(ofps::scratch(ctx, ofps::S_FE_RAW, 2 * raw_bytes)) : nullptr;
+    auto* d_raw = g.frontend ? static_cast<uint8_t*>(ofps::scratch(ctx, ofps::S_FE_RAW_PAIR, 2 * raw_bytes)) : nullptr;
     if (!d_frames || (g.frontend && !d_raw)) return OFPS_HIP_ENOMEM;
     rc = lk_upload_frame(ctx, g, prev, W, H, stride, d_raw, d_frames, ctx->stream);
     if (rc != OFPS_HIP_OK) return rc;
