@@ -283,6 +283,13 @@ int ofps_hip_multi_fanout(const ofps_hip_multi* m, uint64_t* broadcasts) {
 
 void ofps_hip_multi_destroy(ofps_hip_multi* m) {
     if (!m) return;
+    // the communicator first: its ranks were given the workers' streams for the broadcasts (workers are idle or about to be joined; every
+    // broadcast was synchronised where it was issued)
+    if (m->rccl.active) {
+        for (size_t k = 0; k < m->rccl.comm.size(); ++k)
+            if (m->rccl.comm[k]) { (void)hipSetDevice(m->w[k]->device); (void)m->rccl.CommDestroy(m->rccl.comm[k]); }
+        m->rccl.active = false;
+    }
     for (auto* w : m->w) {
         if (w->th.joinable()) {
             { std::lock_guard<std::mutex> lk(w->m); w->quit = true; w->cv.notify_all(); }
@@ -300,7 +307,6 @@ void ofps_hip_multi_destroy(ofps_hip_multi* m) {
         delete w;
     }
     for (auto* h : m->halo) if (h) (void)hipHostFree(h);
-    if (m->rccl.active) for (void* c : m->rccl.comm) if (c) (void)m->rccl.CommDestroy(c);
     if (m->rccl.lib) (void)dlclose(m->rccl.lib);
     delete m;
 }
