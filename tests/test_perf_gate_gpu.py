@@ -1,6 +1,6 @@
 """The performance gate on the GPU box: one full `python bench.py` (N = 1, every leg), checked against the committed line of the
 PREVIOUS round (profiles/r05/bench_n1.json: never a line of the round being gated; slower-only, 5 % on the device-timed medians, 15 % on
-the median of three processes' cfg5 p50) and against the relations that must hold inside one run (tools/perf_gate.py; VERDICT r4
+the best of three processes' cfg5 p50) and against the relations that must hold inside one run (tools/perf_gate.py; VERDICT r4
 item 2, r5 item 6).  The line that was gated is kept under gpurun_out/."""
 import os
 import subprocess
