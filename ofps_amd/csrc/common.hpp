@@ -198,6 +198,8 @@ int frontend_device(ofps_hip_ctx* ctx, const uint8_t* d_src, int W, int H, int s
 int contrast_mask_device(ofps_hip_ctx* ctx, const uint8_t* d_gray, int W, int H, int stride, uint8_t* d_mask, hipStream_t st = nullptr);   // st: nullptr = ctx->stream
 int compact_entries_device(ofps_hip_ctx* ctx, const float4* d_in, const uint8_t* d_mask, size_t n, float4* d_out,
                            uint32_t* d_count);
+constexpr size_t kCompactSmallMax = 32768;          // record sets up to this size are compacted by one workgroup, straight to their destination (mask.hip)
+int compact_small_device(ofps_hip_ctx* ctx, const float4* d_in, const uint8_t* d_mask, size_t n, float4* d_out, uint32_t* d_count);
 int detect_device(ofps_hip_ctx* ctx, const float4* d_entries, size_t n, int batch, float min_size, size_t subdivide,
                   float target_motion, int* d_result, float2* d_out_field, int* out_dim);
 int farneback_flow_device(ofps_hip_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_cur, int W, int H, int stride, int levels, int winsize,

@@ -1996,6 +1996,8 @@ int lk_enqueue_frame(ofps_hip_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_
     if (g.per_pixel) {
         const float4* d_rec = d_ent;
         const uint32_t* d_n = nullptr;
+        if (g.use_mask && px <= ofps::kCompactSmallMax)      // a reduced frame's records: one single-workgroup launch, straight into the block
+            return ofps::compact_small_device(ctx, d_ent, d_mask, px, rec_dst, cnt_dst);
         if (g.use_mask) {                                  // the masked records themselves: order-preserving compaction
             auto* d_ent2 = static_cast<float4*>(ofps::scratch(ctx, ofps::S_ENTRIES2, px * sizeof(float4)));
             if (!d_ent2) return OFPS_HIP_ENOMEM;

@@ -170,6 +170,44 @@ __global__ __launch_bounds__(256) void compact_scatter_kernel(const float4* __re
         if (keep[k]) out[pos++] = in[base + k];
 }
 
+// Order-preserving compaction of a SMALL record set (a reduced frame: 150 x 84 = 12,600 records) in ONE launch of one workgroup: 1,024
+// records per round -- rank inside the wave from a ballot, the 16 wave totals through LDS, a running base --, the surviving records and
+// their count written straight to the destination (the ticket's page-locked block).  The general path is three launches (count, scan,
+// scatter) plus the copy to the block: four dependent launches of ~4 us each for work that fits one CU.
+__global__ __launch_bounds__(1024) void compact_small_kernel(const float4* __restrict__ in, const uint8_t* __restrict__ mask, uint32_t n,
+                                                             float4* __restrict__ out, uint32_t* __restrict__ out_count) {
+    __shared__ uint32_t wtot[16];
+    __shared__ uint32_t base_sh;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) base_sh = 0;
+    __syncthreads();
+    for (uint32_t i0 = 0; i0 < n; i0 += 1024) {
+        const uint32_t i = i0 + tid;
+        const bool keep = i < n && mask[i];
+        float4 v;
+        if (keep) v = in[i];
+        const unsigned long long bal = __ballot(keep);
+        const uint32_t rank = (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) wtot[wave] = (uint32_t)__popcll(bal);
+        __syncthreads();
+        uint32_t off = base_sh;
+        for (int k = 0; k < wave; ++k) off += wtot[k];
+        if (keep) out[off + rank] = v;
+        __syncthreads();
+        if (tid == 0) { uint32_t t = 0; for (int k = 0; k < 16; ++k) t += wtot[k]; base_sh += t; }
+        __syncthreads();
+    }
+    if (tid == 0) *out_count = base_sh;
+}
+
+// records of the unmasked pixels, in order, and their count straight to (d_out, d_count) -- device memory or the device address of a page-locked block
+int compact_small_device(ofps_hip_ctx* ctx, const float4* d_in, const uint8_t* d_mask, size_t n, float4* d_out, uint32_t* d_count) {
+    OFPS_REQUIRE(ctx, n >= 1 && n <= kCompactSmallMax, "compact_small: %zu records", n);
+    hipLaunchKernelGGL(compact_small_kernel, dim3(1), dim3(1024), 0, ctx->stream, d_in, d_mask, (uint32_t)n, d_out, d_count);
+    OFPS_HIP_TRY(ctx, hipGetLastError());
+    return OFPS_HIP_OK;
+}
+
 int contrast_mask_device(ofps_hip_ctx* ctx, const uint8_t* d_gray, int W, int H, int stride, uint8_t* d_mask, hipStream_t st) {
     OFPS_REQUIRE(ctx, W >= 1 && H >= 1 && stride >= W, "contrast_mask: bad geometry W=%d H=%d stride=%d", W, H, stride);
     hipLaunchKernelGGL(contrast_mask_kernel, dim3((W + MT_W - 1) / MT_W, (H + MT_H - 1) / MT_H), dim3(256), 0, st ? st : ctx->stream,
