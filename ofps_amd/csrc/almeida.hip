@@ -182,6 +182,12 @@ __device__ __forceinline__ DeltaAffine delta_affine_uniform(const DeltaAffine& a
     return r;
 }
 
+// Two records per instruction: gfx950's packed-f32 VALU forms (v_pk_fma_f32 / v_pk_add_f32) retire two IEEE fused
+// multiply-adds per lane per issue slot -- each half rounds exactly like the scalar v_fma_f32 it replaces.
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ v2f pk_splat(float x) { return v2f{x, x}; }
+
 // camera.rs:150-161
 __device__ __forceinline__ float2 cam_point_angle(float fx, float fy, float px, float py) {
     return make_float2(atanf((px - 0.5f) / fx), atanf((py - 0.5f) / fy));
@@ -516,6 +522,22 @@ __device__ __forceinline__ void block_sum(float v[9], float (*red)[9]) {
     }
 }
 __device__ __forceinline__ void block_sum9(float v[9], float (*red)[9]) { block_sum<0, 9>(v, red); }
+
+// The step loop's form for three values: every wave stops at its four 16-lane row sums (12 DPP adds instead of 18 + the
+// two broadcasts and three v_readlane), the 4 * waves row sums go through LDS, and wave W alone runs the full wave tree
+// over them.  -> a, b, c uniform in wave W (undefined elsewhere).  One barrier, like block_sum.
+template <int W>
+__device__ __forceinline__ void block_sum3_rows(float& a, float& b, float& c, float (*red4)[64]) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    row_sum16x3(a, b, c);
+    if ((lane & 15) == 0) { const int slot = wave * 4 + (lane >> 4); red4[0][slot] = a; red4[1][slot] = b; red4[2][slot] = c; }
+    __syncthreads();
+    if (wave == W) {
+        const int nrow = (int)(blockDim.x >> 4);
+        a = lane < nrow ? red4[0][lane] : 0.0f; b = lane < nrow ? red4[1][lane] : 0.0f; c = lane < nrow ? red4[2][lane] : 0.0f;
+        wave_sum3(a, b, c);
+    }
+}
 
 // ---- small problems: one workgroup per item, EPT entries per thread, all 30 steps in-kernel.
 // n_dev (optional): per-item entry count on the device (RANSAC refit); stride = entries per item.
@@ -996,10 +1018,15 @@ __global__ __launch_bounds__(BLOCK) void almeida_lsq_cluster_kernel(const float4
 #define OFPS_STAMP(slot) do { if (prof && threadIdx.x == kSerialWave * 64) prof[(((size_t)blockIdx.y * gridDim.x + blockIdx.x) * kIters + it) * kProfSlots + (slot)] = __builtin_readcyclecounter(); } while (0)
 #define OFPS_STAMP_W2(slot) do { if (prof && threadIdx.x == kSerialWave * 64) prof[(((size_t)blockIdx.y * gridDim.x + blockIdx.x) * kIters + it) * kProfSlots + (slot)] = __builtin_readcyclecounter(); } while (0)
     constexpr bool P_LDS = EPT >= 8;
+    // dense regime, an even number of records per thread: the step loop works on PAIRS of records with packed-f32 fused
+    // multiply-adds (14 v_pk_fma_f32 + 2 v_rcp_f32 per pair instead of 28 v_fma_f32 + 2 v_rcp_f32); the two halves keep
+    // partial sums of their own (even / odd records), joined once per step
+    constexpr bool PK = FAST && (EPT % 2 == 0);
     // the wave that carries a step's serial chain: finishes the block sum, publishes the granule, gathers, updates
     constexpr int kSerialWave = 2;                       // (waves 0 and 1 gather the A triples in step 0)
     static_assert(kSerialWave == 2 && BLOCK >= 256, "the step-0 gather of A uses waves 0 and 1, the two-level gather wave 3");
     __shared__ float red[BLOCK / 64][9];
+    __shared__ float red4[3][64];                       // the step's row sums (block_sum3_rows)
     __shared__ float apart_sh[6];                       // this workgroup's partial of A = J^T J, published in step 0
     __shared__ float a_sh[6];                           // A folded over all workgroups (rotation-independent)
     __shared__ Quat rot_sh[2];
@@ -1061,7 +1088,14 @@ __global__ __launch_bounds__(BLOCK) void almeida_lsq_cluster_kernel(const float4
         const float2 r = ok[t] ? cam_delta_w<FAST>(cam, e[t].x, e[t].y, un, mroll) : zero2;
         const float2 p = ok[t] ? cam_delta_w<FAST>(cam, e[t].x, e[t].y, un, mpitch) : zero2;
         py[t] = ok[t] ? cam_delta_w<FAST>(cam, e[t].x, e[t].y, un, myaw) : zero2;
-        if constexpr (P_LDS) plds[t * BLOCK + threadIdx.x] = make_float4(r.x, r.y, p.x, p.y);
+        if constexpr (P_LDS && PK) {
+            // pair u = t / 2 keeps (roll.x of both records, roll.y of both) in slot 2u and the pitch prototypes in slot 2u + 1:
+            // one ds_read_b128 per slot hands the step loop its packed operands
+            float* lf = reinterpret_cast<float*>(plds);
+            const int h = t & 1;
+            const size_t a0 = ((size_t)(t & ~1) * BLOCK + threadIdx.x) * 4, a1 = ((size_t)(t | 1) * BLOCK + threadIdx.x) * 4;
+            lf[a0 + h] = r.x; lf[a0 + 2 + h] = r.y; lf[a1 + h] = p.x; lf[a1 + 2 + h] = p.y;
+        } else if constexpr (P_LDS) plds[t * BLOCK + threadIdx.x] = make_float4(r.x, r.y, p.x, p.y);
         else { pr[t] = r; pp[t] = p; }
         s[0] += r.x * r.x + r.y * r.y;
         s[1] += r.x * p.x + r.y * p.y;
@@ -1074,6 +1108,17 @@ __global__ __launch_bounds__(BLOCK) void almeida_lsq_cluster_kernel(const float4
     if constexpr (FAST) {
 #pragma unroll
         for (int t = 0; t < EPT; ++t) { e[t].z += e[t].x - 0.5f; e[t].w += e[t].y - 0.5f; }    // see the step loop
+    }
+    // PK: the per-record state of the step loop, two records side by side
+    constexpr int NP = PK ? EPT / 2 : 1;
+    v2f ex2[NP], ey2[NP], ez2[NP], ew2[NP], yx2[NP], yy2[NP];
+    if constexpr (PK) {
+#pragma unroll
+        for (int u = 0; u < NP; ++u) {
+            ex2[u] = v2f{e[2 * u].x, e[2 * u + 1].x}; ey2[u] = v2f{e[2 * u].y, e[2 * u + 1].y};
+            ez2[u] = v2f{e[2 * u].z, e[2 * u + 1].z}; ew2[u] = v2f{e[2 * u].w, e[2 * u + 1].w};
+            yx2[u] = v2f{py[2 * u].x, py[2 * u + 1].x}; yy2[u] = v2f{py[2 * u].y, py[2 * u + 1].y};
+        }
     }
     // the six A partials leave the registers before the step loop (they would stay live through all 30 steps otherwise)
     block_sum<0, 6>(s, red);
@@ -1093,6 +1138,33 @@ __global__ __launch_bounds__(BLOCK) void almeida_lsq_cluster_kernel(const float4
         if constexpr (FAST) aff = delta_affine_uniform(aff_sh[(it + 1) & 1]);                                   // lib.rs:140, folded by the updating wave
         else rotm = mat3_uniform(quat_to_mat3(rot_sh[(it + 1) & 1]));                                          // lib.rs:140
         s[6] = 0.0f; s[7] = 0.0f; s[8] = 0.0f;
+        if constexpr (PK) {
+            const v2f xa = pk_splat(aff.xa), xb = pk_splat(aff.xb), xc = pk_splat(aff.xc);
+            const v2f ya = pk_splat(aff.ya), yb = pk_splat(aff.yb), yc = pk_splat(aff.yc);
+            const v2f da = pk_splat(aff.da), db = pk_splat(aff.db), dc = pk_splat(aff.dc);
+            v2f s6 = pk_splat(0.0f), s7 = pk_splat(0.0f), s8 = pk_splat(0.0f);
+#pragma unroll
+            for (int u = 0; u < NP; ++u) {
+                const v2f X = pk_fma(xa, ex2[u], pk_fma(xb, ey2[u], xc));
+                const v2f Y = pk_fma(ya, ex2[u], pk_fma(yb, ey2[u], yc));
+                const v2f D = pk_fma(da, ex2[u], pk_fma(db, ey2[u], dc));
+                const v2f ninv = v2f{-__builtin_amdgcn_rcpf(D.x), -__builtin_amdgcn_rcpf(D.y)};
+                const v2f rx = pk_fma(X, ninv, ez2[u]), ry = pk_fma(Y, ninv, ew2[u]);      // motion - delta, as below
+                v2f rrx, rry, ppx, ppy;
+                if constexpr (P_LDS) {
+                    const float4 v0 = plds[(2 * u) * BLOCK + threadIdx.x], v1 = plds[(2 * u + 1) * BLOCK + threadIdx.x];
+                    rrx = v2f{v0.x, v0.y}; rry = v2f{v0.z, v0.w}; ppx = v2f{v1.x, v1.y}; ppy = v2f{v1.z, v1.w};
+                } else {
+                    rrx = v2f{pr[2 * u].x, pr[2 * u + 1].x}; rry = v2f{pr[2 * u].y, pr[2 * u + 1].y};
+                    ppx = v2f{pp[2 * u].x, pp[2 * u + 1].x}; ppy = v2f{pp[2 * u].y, pp[2 * u + 1].y};
+                }
+                s6 = pk_fma(rry, ry, pk_fma(rrx, rx, s6));
+                s7 = pk_fma(ppy, ry, pk_fma(ppx, rx, s7));
+                s8 = pk_fma(yy2[u], ry, pk_fma(yx2[u], rx, s8));
+                if constexpr (EPT >= 8) __builtin_amdgcn_sched_barrier(0);  // one pair at a time (registers: see below)
+            }
+            s[6] = s6.x + s6.y; s[7] = s7.x + s7.y; s[8] = s8.x + s8.y;
+        } else {
 #pragma unroll
         for (int t = 0; t < EPT; ++t) {
             float rx, ry;                                          // motion - delta
@@ -1125,8 +1197,9 @@ __global__ __launch_bounds__(BLOCK) void almeida_lsq_cluster_kernel(const float4
             // from overlapping more than two records (4 waves per SIMD hide the latency instead)
             if constexpr (EPT >= 8) { if ((t & (OFPS_ALMEIDA_REC_GROUP - 1)) == OFPS_ALMEIDA_REC_GROUP - 1) __builtin_amdgcn_sched_barrier(0); }
         }
+        }
         OFPS_STAMP(1);
-        block_sum<6, 9, kSerialWave>(s, red);
+        block_sum3_rows<kSerialWave>(s[6], s[7], s[8], red4);
         OFPS_STAMP(2);
         const uint32_t tag = (tag_base + (uint32_t)it + 1u) & 0xFFFFu;
         gran_u4* gp = g + (size_t)(it & 1) * 3 * nblk * gs;
