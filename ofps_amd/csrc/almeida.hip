@@ -845,9 +845,9 @@ __device__ __forceinline__ bool spin_expired(unsigned spins, const FailFlag& f) 
 }
 
 // same-XCD form of gran_sweep_sum3 for at most 64 granules
-__device__ __forceinline__ bool gran_sweep_sum3_local(const gran_u4* g, int count, uint32_t tag16, const FailFlag& ff, float& ta, float& tb, float& tc) {
+__device__ __forceinline__ bool gran_sweep_sum3_local(const gran_u4* g, int count, uint32_t tag16, const FailFlag& ff, float& ta, float& tb, float& tc, int gs = 1) {
     const int lane = threadIdx.x & 63;
-    const gran_u4* p = g + (lane < count ? lane : count - 1);
+    const gran_u4* p = g + (size_t)(lane < count ? lane : count - 1) * gs;
     gran_u4 x;
     for (unsigned spins = 0;; ++spins) {
         gran_load3_local(p, x);
@@ -864,9 +864,10 @@ __device__ __forceinline__ bool gran_sweep_sum3_local(const gran_u4* g, int coun
 }
 // every workgroup's XCC_ID, published once per launch: all workgroups read all of them and reach the same verdict on
 // whether workgroup b runs on XCD b % 8 (round-robin dispatch), the premise of the two-level gather.  false = timed out.
-__device__ __forceinline__ bool xcc_sweep_check(const uint32_t* xccs, int nblk, uint32_t tag16, const FailFlag& ff, bool& round_robin) {
+__device__ __forceinline__ bool xcc_sweep_check(const uint32_t* xccs, int nblk, uint32_t tag16, const FailFlag& ff, bool& round_robin, bool& one_xcd) {
     const int lane = threadIdx.x & 63;
-    bool rr = true;
+    bool rr = true, same = true;
+    uint32_t first = 0;
     for (int j0 = 0; j0 < nblk; j0 += 64) {
         const int idx = j0 + lane < nblk ? j0 + lane : nblk - 1;
         uint32_t v;
@@ -877,8 +878,11 @@ __device__ __forceinline__ bool xcc_sweep_check(const uint32_t* xccs, int nblk, 
             __builtin_amdgcn_s_sleep(1);
         }
         rr = rr && ((int)(v & 0xFFu) == (idx & 7));
+        if (j0 == 0) first = (uint32_t)__builtin_amdgcn_readfirstlane((int)(v & 0xFFu));
+        same = same && (v & 0xFFu) == first;
     }
     round_robin = __all(rr);
+    one_xcd = __all(same);
     return true;
 }
 
@@ -902,7 +906,7 @@ __device__ __forceinline__ bool gran_sweep_sum3_j(const gran_u4* g, int gs, int 
             if (64 * j < nblk) ok = ok && (x[j].y >> 16) == tag16 && (x[j].w >> 16) == tag16;
         if (__all(ok)) break;
         if (spin_expired(spins, ff)) return false;
-        if (gridDim.x > 64) __builtin_amdgcn_s_sleep(1);        // hundreds of pollers on the same lines: leave the channel some air (measured)
+        if (nblk > 64) __builtin_amdgcn_s_sleep(1);             // hundreds of pollers on the same lines: leave the channel some air (measured)
     }
     // lane-strided partial sums in the order ((x0 + x1) + x2) + x3; absent terms are exact zeros
     ta = 0.0f; tb = 0.0f; tc = 0.0f;
@@ -986,6 +990,13 @@ constexpr int kHierMinBlocks = 65;            // up to 64 workgroups (one granul
 // packed / 2.45k a line each; 32 workgroups 3.3k packed -- 32 publishers and 32 x 64 polling lanes meet in four lines of
 // one memory channel -- / 2.55k a line each.
 constexpr int kGranLine = 8;
+// One-XCD launches (block-vector sized fields): the launch is `spread` = 8 times as wide as the cluster, only every
+// eighth workgroup works (round-robin dispatch puts those on ONE XCD; the others return at once), and from step 1 on
+// the partial sums are exchanged through that XCD's L2 alone -- plain stores, `sc1` loads, no write-through to memory:
+// 540 instead of 950 cycles per hand-off and a single level (tools/ubench_exchange).  Step 0 verifies the premise from the
+// workgroups' XCC_IDs (hier_sh = 2); a launch that is not on one XCD keeps the flat write-through exchange.  Both forms
+// add the same numbers in the same order (one granule per lane, then the wave tree): same bits.
+constexpr int kOneXcdMax = 64;                // workgroups of such a cluster at most (one granule per polling lane)
 #ifndef OFPS_ALMEIDA_REC_GROUP
 #define OFPS_ALMEIDA_REC_GROUP 1
 #endif
@@ -995,7 +1006,7 @@ constexpr int kGranLine = 8;
 constexpr int kXgStride = OFPS_ALMEIDA_XG_STRIDE;   // the 8 XCD sums, polled by every workgroup of a two-level launch
 __host__ __device__ inline int cluster_gran_stride(int nblk) { return nblk <= 8 ? 1 : kGranLine; }
 __host__ __device__ inline size_t cluster_gran_per_item(int nblk) {     // a multiple of 8 granules: every item starts on a cache line
-    return 6 * (size_t)nblk * cluster_gran_stride(nblk) + 2 * 8 * kXgStride + 2 * 8 * kXcdSlots + 64 + 8;
+    return 6 * (size_t)nblk * cluster_gran_stride(nblk) + 2 * 8 * kXgStride + 2 * 8 * kXcdSlots + 64 + 8 + 2 * kOneXcdMax * kGranLine;
 }
 
 #ifdef OFPS_HIP_TEST_HOOKS
@@ -1009,14 +1020,15 @@ __global__ __launch_bounds__(BLOCK) void almeida_lsq_cluster_kernel(const float4
                                                                    const DeltaConsts dk, gran_u4* gran, uint32_t tag_base,
                                                                    float4* __restrict__ out_quat,
                                                                    unsigned long long* __restrict__ prof, uint32_t fault_arg, int hier_mode,
-                                                                   unsigned long long* __restrict__ recoveries) {
+                                                                   unsigned long long* __restrict__ recoveries, int spread) {
+    if (spread > 1 && (blockIdx.x % (unsigned)spread) != 0) return;     // one-XCD launch: the workgroups dealt to the other XCDs
     // fault (libofps_hip_testhooks.so only; compiled out of the product library): workgroup fault-1 withholds its step-3
     // granule, which is what a workgroup that never became resident looks like to the others -- exercises the timeout
     // and the in-kernel recovery (almeida_solo_solve)
     const uint32_t fault = OFPS_TEST_FAULT(fault_arg);
     // prof (diagnostics, normally null): the serial wave of every workgroup stamps s_memtime at the phase boundaries of each step
-#define OFPS_STAMP(slot) do { if (prof && threadIdx.x == kSerialWave * 64) prof[(((size_t)blockIdx.y * gridDim.x + blockIdx.x) * kIters + it) * kProfSlots + (slot)] = __builtin_readcyclecounter(); } while (0)
-#define OFPS_STAMP_W2(slot) do { if (prof && threadIdx.x == kSerialWave * 64) prof[(((size_t)blockIdx.y * gridDim.x + blockIdx.x) * kIters + it) * kProfSlots + (slot)] = __builtin_readcyclecounter(); } while (0)
+#define OFPS_STAMP(slot) do { if (prof && threadIdx.x == kSerialWave * 64) prof[(((size_t)blockIdx.y * (gridDim.x / spread) + blockIdx.x / spread) * kIters + it) * kProfSlots + (slot)] = __builtin_readcyclecounter(); } while (0)
+#define OFPS_STAMP_W2(slot) do { if (prof && threadIdx.x == kSerialWave * 64) prof[(((size_t)blockIdx.y * (gridDim.x / spread) + blockIdx.x / spread) * kIters + it) * kProfSlots + (slot)] = __builtin_readcyclecounter(); } while (0)
     constexpr bool P_LDS = EPT >= 8;
     // dense regime, an even number of records per thread: the step loop works on PAIRS of records with packed-f32 fused
     // multiply-adds (14 v_pk_fma_f32 + 2 v_rcp_f32 per pair instead of 28 v_fma_f32 + 2 v_rcp_f32); the two halves keep
@@ -1036,7 +1048,7 @@ __global__ __launch_bounds__(BLOCK) void almeida_lsq_cluster_kernel(const float4
     __shared__ int hier_sh;                             // steps >= 1 gather in two levels (per XCD through its L2, then across)
     __shared__ Lu3 lu_sh;                               // factorisation of the folded A, made in step 0 by the updating wave
     __shared__ float4 plds[P_LDS ? EPT * BLOCK : 1];     // (roll.x, roll.y, pitch.x, pitch.y) per record
-    const int nblk = gridDim.x, blk = blockIdx.x;
+    const int nblk = (int)(gridDim.x / (unsigned)spread), blk = (int)(blockIdx.x / (unsigned)spread);
     const size_t item = blockIdx.y;
     gran_u4* g = gran + item * cluster_gran_per_item(nblk);            // [parity][triple: A0-2, A3-5, b][workgroup], then:
     const int gs = cluster_gran_stride(nblk);
@@ -1046,6 +1058,7 @@ __global__ __launch_bounds__(BLOCK) void almeida_lsq_cluster_kernel(const float4
     // the item's fail word (a granule of its own) and this launch's value for it: unique per launch until the tags wrap
     // (the buffer is re-zeroed then)
     const FailFlag ff = {reinterpret_cast<uint32_t*>(xg + 2 * 8 * kXgStride + 64), (tag_base + 1u) | 0x80000000u};
+    gran_u4* x1 = xg + 2 * 8 * kXgStride + 64 + 8;                     // [parity][workgroup], a line each: the one-XCD exchange
     const int xcd = blk & 7, xrank = blk >> 3;                         // where round-robin dispatch puts this workgroup
     const int xmembers = (nblk - xcd + 7) / 8, nxcd = nblk < 8 ? nblk : 8;
     const float eps = almeida_eps();
@@ -1205,7 +1218,8 @@ __global__ __launch_bounds__(BLOCK) void almeida_lsq_cluster_kernel(const float4
         gran_u4* gp = g + (size_t)(it & 1) * 3 * nblk * gs;
         // (uniform: hier_sh was written before the barrier that ended step 0; launches without the two-level gather do not
         // even read it -- an LDS round trip less on the serial wave's chain)
-        const bool hier = hier_mode != 0 && it > 0 && hier_sh != 0;
+        const int hsel = (hier_mode != 0 && it > 0) ? hier_sh : 0;       // 0 flat, 1 two levels, 2 everybody on one XCD
+        const bool hier = hsel == 1, onex = hsel == 2;
         if (threadIdx.x == kSerialWave * 64) {
             if (it == 0) {
                 gran_store3(gp + (size_t)blk * gs, tag, apart_sh[0], apart_sh[1], apart_sh[2]);
@@ -1213,6 +1227,7 @@ __global__ __launch_bounds__(BLOCK) void almeida_lsq_cluster_kernel(const float4
             }
             if (!(fault && it == 3 && (uint32_t)blk == fault - 1u)) {
                 if (hier) gran_store3_local(xl + ((size_t)(it & 1) * 8 + xcd) * kXcdSlots + xrank, tag, s[6], s[7], s[8]);
+                else if (onex) gran_store3_local(x1 + ((size_t)(it & 1) * kOneXcdMax + blk) * kGranLine, tag, s[6], s[7], s[8]);
                 else gran_store3(gp + (2 * (size_t)nblk + blk) * gs, tag, s[6], s[7], s[8]);
             }
         }
@@ -1235,6 +1250,8 @@ __global__ __launch_bounds__(BLOCK) void almeida_lsq_cluster_kernel(const float4
                 }
             }
             if (wave == kSerialWave) got = gran_sweep_sum3(xg + (size_t)(it & 1) * 8 * kXgStride, kXgStride, nxcd, tag, ff, ta, tb, tc);
+        } else if (onex) {
+            if (wave == kSerialWave) got = gran_sweep_sum3_local(x1 + (size_t)(it & 1) * kOneXcdMax * kGranLine, nblk, tag, ff, ta, tb, tc, kGranLine);
         } else if (wave < 3 && (wave == kSerialWave || it == 0)) {
             got = gran_sweep_sum3(gp + (size_t)wave * nblk * gs, gs, nblk, tag, ff, ta, tb, tc);
         }
@@ -1244,10 +1261,11 @@ __global__ __launch_bounds__(BLOCK) void almeida_lsq_cluster_kernel(const float4
                 else fail_sh = 1;
             }
             if (wave == 3 && hier_mode) {               // does workgroup b sit on XCD b % 8?  every workgroup reaches the same verdict
-                bool rr = false;
-                const bool xgot = xcc_sweep_check(xccs, nblk, tag, ff, rr);
+                bool rr = false, same = false;
+                const bool xgot = xcc_sweep_check(xccs, nblk, tag, ff, rr, same);
                 if (lane == 0) {
                     if (!xgot) fail_sh = 1;
+                    else if (hier_mode == 3) hier_sh = (same && nblk <= kOneXcdMax) ? 2 : 0;
                     else hier_sh = rr ? 1 : 0;
                 }
             }
@@ -1528,9 +1546,16 @@ static void launch_cluster(ofps_hip_ctx* ctx, hipStream_t s, int nblk, int items
     const uint32_t fault = (uint32_t)ctx->opt.test_almeida_fault;   // always 0 in the product library (ofps_hip_set_option refuses it)
     int hier_mode = ctx->opt.almeida_hier;                    // 0 never, 1 when it pays (>= kHierMinBlocks workgroups), 2 always (A/B, tests)
     if (hier_mode == 1 && nblk < kHierMinBlocks) hier_mode = 0;     // few workgroups: the flat gather is as fast and needs no XCC_ID round
-    hipLaunchKernelGGL((almeida_lsq_cluster_kernel<FAST, EPT, BLOCK>), dim3(nblk, items), dim3(BLOCK), 0, s, d_entries, n, cam,
+    // small clusters of 256-thread workgroups: a launch eight times as wide whose every eighth workgroup works -- all on one
+    // XCD under round-robin dispatch, exchanging through its L2 (kOneXcdMax; verified in step 0, flat otherwise)
+    int spread = 1;
+    // (a CU-masked stream may leave that XCD a handful of CUs -- too few for the working workgroups to be co-resident: measured
+    // 57 ms of timeouts + solo solves per call on a 32-CU mask dealt four CUs to each XCD -- so masked streams keep the flat form)
+    if (BLOCK == 256 && ctx->opt.almeida_one_xcd && ctx->opt.almeida_hier != 2 && nblk * items <= kOneXcdMax && nblk >= 2 &&
+        ctx->stream_cus >= ctx->num_cus) { spread = 8; hier_mode = 3; }
+    hipLaunchKernelGGL((almeida_lsq_cluster_kernel<FAST, EPT, BLOCK>), dim3(nblk * spread, items), dim3(BLOCK), 0, s, d_entries, n, cam,
                        delta_consts(cam), gran,
-                       tag_base, d_quat, prof, fault, hier_mode, recoveries);
+                       tag_base, d_quat, prof, fault, hier_mode, recoveries, spread);
 }
 
 // -> 1 launched, 0 not applicable (caller falls back to the launch-per-step kernel), < 0 error

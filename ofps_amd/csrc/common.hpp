@@ -17,6 +17,7 @@ struct ofps_hip_ctx {
     hipStream_t stream = nullptr;        // the stream work is enqueued on (own or caller's)
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     int num_cus = 0;
+    int stream_cus = 0;                  // compute units `stream` may use (hipExtStreamGetCUMask; a caller's stream may carry a CU mask)
     int sad_mode = OFPS_HIP_SAD_EXHAUSTIVE;
     char err[512] = {0};
 
@@ -30,6 +31,7 @@ struct ofps_hip_ctx {
         int almeida_block = 0;           // OFPS_HIP_ALMEIDA_BLOCK: 0 = 1024, else 256/1024
         int almeida_hier = 1;            // OFPS_HIP_ALMEIDA_HIER: 0 never, 1 when it pays, 2 always
         int almeida_fast = -1;           // OFPS_HIP_ALMEIDA_FAST: -1 by size, 0 exact, 1 folded
+        int almeida_one_xcd = 1;         // OFPS_HIP_ALMEIDA_ONE_XCD: 0 never, 1 small clusters run on one XCD and exchange through its L2 (almeida.hip)
         int almeida_prof = 0;            // OFPS_HIP_ALMEIDA_PROF
         int lk_prof = 0;                 // OFPS_HIP_LK_PROF
         int lk_serial = 0;               // OFPS_HIP_LK_SERIAL: one launch per pyramid level instead of one for the pyramid

@@ -75,6 +75,8 @@ int apply_option(ofps_hip_ctx* ctx, const char* name, const char* value, bool fr
         o.almeida_hier = unset ? dflt.almeida_hier : iv;
     } else if (!strcmp(name, "OFPS_HIP_ALMEIDA_FAST")) {
         o.almeida_fast = unset ? -1 : (iv != 0);
+    } else if (!strcmp(name, "OFPS_HIP_ALMEIDA_ONE_XCD")) {
+        o.almeida_one_xcd = unset ? dflt.almeida_one_xcd : (iv != 0);
     } else if (!strcmp(name, "OFPS_HIP_ALMEIDA_PROF")) {
         o.almeida_prof = unset ? 0 : (iv != 0);
     } else if (!strcmp(name, "OFPS_HIP_LK_PROF")) {
@@ -103,7 +105,7 @@ int apply_option(ofps_hip_ctx* ctx, const char* name, const char* value, bool fr
 
 static const char* const kOptionNames[] = {
     "OFPS_HIP_SAD_KERNEL", "OFPS_HIP_DENSIFY_NO_SMALL", "OFPS_HIP_ALMEIDA_PATH", "OFPS_HIP_ALMEIDA_EPT", "OFPS_HIP_ALMEIDA_BLOCK",
-    "OFPS_HIP_ALMEIDA_HIER", "OFPS_HIP_ALMEIDA_FAST", "OFPS_HIP_ALMEIDA_PROF", "OFPS_HIP_LK_PROF", "OFPS_HIP_LK_SERIAL", "OFPS_HIP_MULTI_RCCL"};
+    "OFPS_HIP_ALMEIDA_HIER", "OFPS_HIP_ALMEIDA_FAST", "OFPS_HIP_ALMEIDA_ONE_XCD", "OFPS_HIP_ALMEIDA_PROF", "OFPS_HIP_LK_PROF", "OFPS_HIP_LK_SERIAL", "OFPS_HIP_MULTI_RCCL"};
 
 }  // namespace ofps
 
@@ -116,6 +118,8 @@ int ofps_hip_device_count(void) {
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
 }
+
+static int stream_cu_count(ofps_hip_ctx* ctx, hipStream_t s);
 
 int ofps_hip_init(int device, ofps_hip_ctx** out) {
     if (!out) return ofps::set_error(nullptr, OFPS_HIP_EINVAL, "ofps_hip_init: out is NULL");
@@ -146,6 +150,7 @@ int ofps_hip_init(int device, ofps_hip_ctx** out) {
         return rc;
     }
     ctx->stream = ctx->own_stream;
+    ctx->stream_cus = stream_cu_count(ctx, ctx->stream);     // (HSA_CU_MASK / ROC_GLOBAL_CU_MASK narrow every stream)
     // the only place the library looks at the environment (OFPS_HIP_SAD_PRUNED is the host layers' business)
     for (const char* name : ofps::kOptionNames)
         if (const char* v = getenv(name)) {
@@ -230,6 +235,15 @@ const char* ofps_hip_last_error(const ofps_hip_ctx* ctx) { return ctx ? ctx->err
 // Work enqueued on the old stream (and the frame uploads of the per-frame pipeline that are ordered by it) is finished
 // before the context moves to another stream: nothing in the library then depends on cross-stream ordering it did not
 // set up itself.
+// compute units the stream's kernels may be dealt to; the whole device when the runtime cannot say
+static int stream_cu_count(ofps_hip_ctx* ctx, hipStream_t s) {
+    uint32_t words[16] = {0};
+    if (hipExtStreamGetCUMask(s, 16, words) != hipSuccess) { (void)hipGetLastError(); return ctx->num_cus; }
+    int n = 0;
+    for (uint32_t w : words) n += __builtin_popcount(w);
+    return n > 0 && n < ctx->num_cus ? n : ctx->num_cus;
+}
+
 static int switch_stream(ofps_hip_ctx* ctx, hipStream_t next) {
     if (next == ctx->stream) return OFPS_HIP_OK;
     OFPS_HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -238,6 +252,7 @@ static int switch_stream(ofps_hip_ctx* ctx, hipStream_t next) {
     if (ctx->pipe_aux_stream) OFPS_HIP_TRY(ctx, hipStreamSynchronize(ctx->pipe_aux_stream));
     if (ctx->lk_copy_stream) OFPS_HIP_TRY(ctx, hipStreamSynchronize(ctx->lk_copy_stream));
     ctx->stream = next;
+    ctx->stream_cus = stream_cu_count(ctx, next);
     return OFPS_HIP_OK;
 }
 

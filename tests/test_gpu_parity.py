@@ -600,6 +600,36 @@ def _cu_masked_stream(n_cus: int):
     return hip, stream
 
 
+@pytest.mark.parametrize("mask", ["first32", "every_other", "every_eighth"])
+def test_almeida_one_xcd_cluster_on_cu_masked_streams(ctx, mask):
+    """The one-XCD form of the small cluster solve rests on round-robin dispatch; on a stream whose kernels may only use some of the
+    CUs the working workgroups may or may not share an XCD -- step 0 finds out from their XCC_IDs and the launch keeps the flat
+    exchange if they do not.  Either way: the unmasked launch's bits, nobody finishes alone."""
+    import ctypes as C
+    e = synth.rotation_field(120, 67)
+    q_ref, _ = ctx.almeida(e, 16 / 9, 22.275, use_ransac=False)
+    np.testing.assert_allclose(q_ref, oracle.solve_ypr_given(e, oracle.camera(16 / 9, 22.275)), atol=2e-6, rtol=0)
+    hip = C.CDLL("libamdhip64.so")
+    words = (C.c_uint32 * 8)(*([0] * 8))
+    cus = {"first32": range(32), "every_other": range(0, 256, 2), "every_eighth": range(0, 256, 8)}[mask]
+    for cu in cus:
+        words[cu // 32] |= 1 << (cu % 32)
+    stream = C.c_void_p(0)
+    assert hip.hipExtStreamCreateWithCUMask(C.byref(stream), 8, words) == 0
+    rec0 = ctx.almeida_recoveries()
+    try:
+        ctx.set_stream(stream.value)
+        ctx.set_option("OFPS_HIP_ALMEIDA_PATH", "cluster")
+        for _ in range(3):
+            q, _ = ctx.almeida(e, 16 / 9, 22.275, use_ransac=False)
+            np.testing.assert_array_equal(q.view(np.uint32), q_ref.view(np.uint32))
+    finally:
+        ctx.set_option("OFPS_HIP_ALMEIDA_PATH", None)
+        ctx.use_own_stream()
+        hip.hipStreamDestroy(stream)
+    assert ctx.almeida_recoveries() == rec0
+
+
 @pytest.mark.parametrize("mode", ["budget", "reversed", "permuted", "cu_mask", "cu_mask_permuted"])
 def test_lk_forward_progress_does_not_depend_on_the_dispatcher(hooks_ctx, mode):
     """The pyramid is ONE launch in which a tile waits for its parent tile's flows; a tile whose parent has not published in time computes

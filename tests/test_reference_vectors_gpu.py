@@ -274,6 +274,44 @@ def test_hip_almeida_cluster_two_level_gather_matches_the_flat_gather(hooks, sha
     np.testing.assert_allclose(q_fb, q_o, atol=2e-6, rtol=0)
 
 
+@pytest.mark.parametrize("shape,batch", [((120, 67), 1), ((150, 84), 1), ((60, 40), 1), ((240, 135), 1), ((80, 50), 2), ((64, 60), 3)])
+def test_hip_almeida_one_xcd_cluster_has_the_flat_exchange_s_bits(hooks, shape, batch):
+    """Round 6: clusters of at most 64 256-thread workgroups are launched eight times as wide, every eighth workgroup works (one
+    XCD under round-robin dispatch, verified in step 0 from the workgroups' XCC_IDs) and the steps' partial sums go through
+    that XCD's L2.  OFPS_HIP_ALMEIDA_ONE_XCD=0 keeps the flat write-through exchange: the same numbers added in the same
+    order -> the same bits, per item of a batch too; a withheld granule is recovered inside the launch in this form as well."""
+    import torch
+    n = shape[0] * shape[1]
+    fields = [synth.rotation_field(*shape, euler_deg=(0.5 + 0.2 * k, 0.3 - 0.1 * k, -0.2 + 0.15 * k), seed=synth.SEED0 + 60 + k) for k in range(batch)]
+    cam = oracle.camera(16 / 9, 22.275)
+    d_ent = torch.from_numpy(np.stack(fields)).cuda()
+    out = {}
+    hooks.use_torch_stream()
+    try:
+        hooks.set_option("OFPS_HIP_ALMEIDA_PATH", "cluster")
+        for mode in ("0", "1"):
+            hooks.set_option("OFPS_HIP_ALMEIDA_ONE_XCD", mode)
+            d_q = torch.full((batch, 4), float("nan"), dtype=torch.float32, device="cuda")
+            hooks.almeida_dev(d_ent.data_ptr(), n, batch, 16 / 9, 22.275, False, 0, 0.05, 0, 0, d_q.data_ptr())
+            torch.cuda.synchronize()
+            out[mode] = d_q.cpu().numpy()
+        r0 = hooks.almeida_recoveries()
+        hooks.set_option("OFPS_HIP_ALMEIDA_TEST_FAULT", "2")
+        d_q = torch.full((batch, 4), float("nan"), dtype=torch.float32, device="cuda")
+        hooks.almeida_dev(d_ent.data_ptr(), n, batch, 16 / 9, 22.275, False, 0, 0.05, 0, 0, d_q.data_ptr())
+        torch.cuda.synchronize()
+        q_fb = d_q.cpu().numpy()
+        assert hooks.almeida_recoveries() == r0 + batch
+    finally:
+        hooks.use_own_stream()
+        for k in ("OFPS_HIP_ALMEIDA_TEST_FAULT", "OFPS_HIP_ALMEIDA_ONE_XCD", "OFPS_HIP_ALMEIDA_PATH"): hooks.set_option(k, None)
+    np.testing.assert_array_equal(out["0"].view(np.uint32), out["1"].view(np.uint32))
+    for k in range(batch):
+        q_o = oracle.solve_ypr_given(fields[k], cam)
+        np.testing.assert_allclose(out["1"][k], q_o, atol=2e-6, rtol=0)
+        np.testing.assert_allclose(q_fb[k], q_o, atol=2e-6, rtol=0)
+
+
 @pytest.mark.parametrize("shape,block,ept", [((120, 67), 256, 1), ((120, 67), 256, 2), ((120, 67), 256, 4), ((120, 67), 1024, 1), ((120, 67), 1024, 4),
                                              ((60, 40), 256, 1), ((240, 135), 256, 2), ((240, 135), 256, 4), ((240, 135), 1024, 1),
                                              ((320, 180), 256, 4), ((320, 180), 1024, 2)])
