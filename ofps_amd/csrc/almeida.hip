@@ -182,6 +182,18 @@ __device__ __forceinline__ DeltaAffine delta_affine_uniform(const DeltaAffine& a
     return r;
 }
 
+// the nine coefficients in LDS as three float4: written by one lane, read by every wave with all three reads in flight
+__device__ __forceinline__ void aff_store(float4 (&d)[3], const DeltaAffine& a) {
+    d[0] = make_float4(a.xa, a.xb, a.xc, a.ya); d[1] = make_float4(a.yb, a.yc, a.da, a.db); d[2] = make_float4(a.dc, 0.0f, 0.0f, 0.0f);
+}
+__device__ __forceinline__ DeltaAffine aff_load_uniform(const float4 (&d)[3]) {
+    float4 v0 = d[0], v1 = d[1];
+    float v2 = d[2].x;
+    asm volatile("" : "+v"(v0.x), "+v"(v0.y), "+v"(v0.z), "+v"(v0.w), "+v"(v1.x), "+v"(v1.y), "+v"(v1.z), "+v"(v1.w), "+v"(v2));   // all nine loaded before the first is used
+    const DeltaAffine a = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2};
+    return delta_affine_uniform(a);
+}
+
 // Two records per instruction: gfx950's packed-f32 VALU forms (v_pk_fma_f32 / v_pk_add_f32) retire two IEEE fused
 // multiply-adds per lane per issue slot -- each half rounds exactly like the scalar v_fma_f32 it replaces.
 typedef float v2f __attribute__((ext_vector_type(2)));
@@ -193,7 +205,7 @@ __device__ __forceinline__ float2 cam_point_angle(float fx, float fy, float px, 
     return make_float2(atanf((px - 0.5f) / fx), atanf((py - 0.5f) / fy));
 }
 
-struct Quat { float w, i, j, k; };
+struct alignas(16) Quat { float w, i, j, k; };      // (16-byte aligned: one ds_read_b128 / global dwordx4 per quaternion)
 
 __device__ __forceinline__ Quat quat_mul(const Quat& a, const Quat& b) {         // nalgebra Hamilton product
     Quat r;
@@ -1042,7 +1054,8 @@ __global__ __launch_bounds__(BLOCK) void almeida_lsq_cluster_kernel(const float4
     __shared__ float apart_sh[6];                       // this workgroup's partial of A = J^T J, published in step 0
     __shared__ float a_sh[6];                           // A folded over all workgroups (rotation-independent)
     __shared__ Quat rot_sh[2];
-    __shared__ DeltaAffine aff_sh[2];                   // dense regime: the folded camera + rotation of rot_sh[], same slots
+    __shared__ float4 aff_sh[2][3];                     // dense regime: the folded camera + rotation of rot_sh[] (DeltaAffine's nine coefficients), same slots;
+                                                        // three 16-byte reads in flight per wave and step (as a plain struct: five dependent LDS round trips)
     __shared__ int fail_sh;
     __shared__ struct { const float4* entries; size_t n; float4* out; unsigned long long* recoveries; uint32_t* flag; uint32_t tag; Camera cam; } cold_sh;   // what the recovery path needs, parked
     __shared__ int hier_sh;                             // steps >= 1 gather in two levels (per XCD through its L2, then across)
@@ -1082,7 +1095,7 @@ __global__ __launch_bounds__(BLOCK) void almeida_lsq_cluster_kernel(const float4
             const uint32_t me = (((tag_base + 1u) & 0xFFFFu) << 16) | ((uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xFFu);   // HW_REG_XCC_ID
             asm volatile("global_store_dword %0, %1, off sc0 sc1" :: "v"(xccs + blk), "v"(me) : "memory");
         }
-        if constexpr (FAST) aff_sh[1] = delta_affine(dk, quat_to_mat3(rot_sh[1]));
+        if constexpr (FAST) aff_store(aff_sh[1], delta_affine(dk, quat_to_mat3(rot_sh[1])));
     }
 #pragma unroll
     for (int t = 0; t < EPT; ++t) {
@@ -1148,7 +1161,7 @@ __global__ __launch_bounds__(BLOCK) void almeida_lsq_cluster_kernel(const float4
         OFPS_STAMP(0);
         Mat3 rotm;
         DeltaAffine aff;
-        if constexpr (FAST) aff = delta_affine_uniform(aff_sh[(it + 1) & 1]);                                   // lib.rs:140, folded by the updating wave
+        if constexpr (FAST) aff = aff_load_uniform(aff_sh[(it + 1) & 1]);                                   // lib.rs:140, folded by the updating wave
         else rotm = mat3_uniform(quat_to_mat3(rot_sh[(it + 1) & 1]));                                          // lib.rs:140
         s[6] = 0.0f; s[7] = 0.0f; s[8] = 0.0f;
         if constexpr (PK) {
@@ -1286,7 +1299,7 @@ __global__ __launch_bounds__(BLOCK) void almeida_lsq_cluster_kernel(const float4
                 const Quat q = almeida_update_wave_lu<FAST>(rot_sh[(it + 1) & 1], lu, ta, tb, tc, eps, alpha);
                 if constexpr (FAST) {                   // fold camera and new rotation once, here, for every wave's next step
                     const DeltaAffine A = delta_affine(dk, quat_to_mat3(q));
-                    if (lane == 0) aff_sh[it & 1] = A;
+                    if (lane == 0) aff_store(aff_sh[it & 1], A);
                 }
                 if (lane == 0) rot_sh[it & 1] = q;
                 OFPS_STAMP_W2(6);
@@ -1722,7 +1735,8 @@ static int lsq_device(ofps_hip_ctx* ctx, const float4* d_entries, size_t stride,
     // (N > 256 x 8192) or a forced A/B run takes one launch per step.
     bool wg_path = n_max <= 8192;
     bool cluster = d_n == nullptr && stride == n_max;
-    size_t cluster_min = batch == 1 ? 2048 : 8192;                       // lone problems above this size use the cluster (3,600 vectors: 0.074 vs 0.093 ms)
+    size_t cluster_min = batch == 1 ? 1536 : 8192;                       // lone problems above this size use the cluster (one XCD: 0.061 ms at any size up to 8,040; the
+                                                                         // one-workgroup solver: 1,280 vectors 0.055, 1,600 0.062, 2,048 0.066 -- tools/almeida_threshold_ab.py)
     if (ctx->opt.almeida_path == 1 && d_n == nullptr) { wg_path = false; cluster = false; }   // A/B experiments only (OFPS_HIP_ALMEIDA_PATH)
     if (ctx->opt.almeida_path == 2) cluster = false;
     if (ctx->opt.almeida_path == 3) cluster_min = 0;
