@@ -322,7 +322,10 @@ __device__ __forceinline__ bool lu3_solve(const float a_in[9], const float b_in[
 
 // The normal matrix A does not change from step to step, so neither does its factorisation: lu3_factor is lu3_solve's
 // elimination (the same operations on the same numbers), lu3_apply its row exchanges of b, forward and back substitution.
-struct Lu3 { float r0[3], r1[3], r2[3]; int piv0, p2; };            // L multipliers below the diagonal, U on and above it
+struct Lu3 { float r0[3], r1[3], r2[3]; int piv0, p2; float inv[3]; };   // L multipliers below the diagonal, U on and above it; inv[k] = 1 / U[k][k]
+// (IEEE quotients, formed once per solve: the back substitution of each of the 30 steps multiplies by them -- one rounding more than the
+// division it replaces, 1e-7 of a step that is itself 1e-5 rad: six orders inside the parity bound, and ~27 dependent instructions less
+// on every step's serial chain)
 __device__ __forceinline__ Lu3 lu3_factor(const float a_in[9]) {
     Lu3 f;
     float r0[3] = {a_in[0], a_in[1], a_in[2]}, r1[3] = {a_in[3], a_in[4], a_in[5]}, r2[3] = {a_in[6], a_in[7], a_in[8]};
@@ -362,6 +365,7 @@ __device__ __forceinline__ Lu3 lu3_factor(const float a_in[9]) {
     }
 #pragma unroll
     for (int c = 0; c < 3; ++c) { f.r0[c] = r0[c]; f.r1[c] = r1[c]; f.r2[c] = r2[c]; }
+    f.inv[0] = r0[0] != 0.0f ? 1.0f / r0[0] : 0.0f; f.inv[1] = r1[1] != 0.0f ? 1.0f / r1[1] : 0.0f; f.inv[2] = r2[2] != 0.0f ? 1.0f / r2[2] : 0.0f;
     return f;
 }
 template <bool FAST = false>
@@ -375,15 +379,13 @@ __device__ __forceinline__ bool lu3_apply(const Lu3& f, const float b_in[3], flo
         const float c1 = b1 / 1.0f;
         b2 = (-c1) * f.r2[1] + b2;
     }
-    if (f.r2[2] == 0.0f) return false;
-    const float x2 = fdiv<FAST>(b2, f.r2[2]);
+    if (f.r2[2] == 0.0f || f.r1[1] == 0.0f || f.r0[0] == 0.0f) return false;      // a zero on U's diagonal: lib.rs:181-183
+    const float x2 = b2 * f.inv[2];
     b0 = (-x2) * f.r0[2] + b0;
     b1 = (-x2) * f.r1[2] + b1;
-    if (f.r1[1] == 0.0f) return false;
-    const float x1 = fdiv<FAST>(b1, f.r1[1]);
+    const float x1 = b1 * f.inv[1];
     b0 = (-x1) * f.r0[1] + b0;
-    if (f.r0[0] == 0.0f) return false;
-    const float x0 = fdiv<FAST>(b0, f.r0[0]);
+    const float x0 = b0 * f.inv[0];
     x[0] = x0; x[1] = x1; x[2] = x2;
     return true;
 }
@@ -445,11 +447,11 @@ __device__ __forceinline__ Quat almeida_update_wave_lu(const Quat& rotation, con
     const float b[3] = {b0, b1, b2};
     float model[3];
     if (!lu3_apply<FAST>(f, b, model)) { model[0] = model[1] = model[2] = 0.0f; }       // :181-183
-    model[0] = model[0] * eps * alpha;                                            // :185
-    model[1] = model[1] * eps * alpha;
-    model[2] = model[2] * eps * alpha;
+    // :185 and the half angles of :189-191 in one product per lane: alpha (0.5 or 1) and the 0.5 are powers of two, so
+    // x * (eps * alpha * 0.5) carries the bits of ((x * eps) * alpha) * 0.5
     const int lane = threadIdx.x & 63;
-    const float half = lane == 0 ? model[0] * 0.5f : (lane == 1 ? model[1] * 0.5f : -model[2] * 0.5f);
+    const float xsel = lane == 0 ? model[0] : (lane == 1 ? model[1] : -model[2]);
+    const float half = xsel * (eps * alpha * 0.5f);
     float sn, cs;
     sincos_small(half, sn, cs);
     const float s0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sn), 0)), c0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cs), 0));
@@ -458,9 +460,18 @@ __device__ __forceinline__ Quat almeida_update_wave_lu(const Quat& rotation, con
     // :193, (pitch * roll) * yaw with pitch = (c1, s1, 0, 0), roll = (c0, 0, s0, 0), yaw = (c2, 0, 0, s2): the Hamilton products
     // with the terms that are exact zeros left out -- x * 0 is an exact zero and adding it changes nothing, so these are
     // quat_mul's values (16 operations instead of 56 on the step's serial chain; a lone wave issues one every ~5 cycles)
+    // Sums of products are fused here (28 dependent instructions instead of 44): each sum is rounded once instead of after every
+    // term -- closer to the exact product, 1e-8 from the unfused one.
     const Quat pr = {c1 * c0, s1 * c0, c1 * s0, s1 * s0};
-    const Quat rot = {pr.w * c2 - pr.k * s2, pr.i * c2 + pr.j * s2, pr.j * c2 - pr.i * s2, pr.w * s2 + pr.k * c2};
-    return quat_mul(rotation, rot);                                               // :195
+    const Quat rot = {__builtin_fmaf(pr.w, c2, -(pr.k * s2)), __builtin_fmaf(pr.i, c2, pr.j * s2), __builtin_fmaf(pr.j, c2, -(pr.i * s2)),
+                      __builtin_fmaf(pr.w, s2, pr.k * c2)};
+    const Quat& a = rotation;
+    Quat r;                                                                       // :195, quat_mul(rotation, rot)
+    r.w = __builtin_fmaf(-a.k, rot.k, __builtin_fmaf(-a.j, rot.j, __builtin_fmaf(-a.i, rot.i, a.w * rot.w)));
+    r.i = __builtin_fmaf(-a.k, rot.j, __builtin_fmaf(a.j, rot.k, __builtin_fmaf(a.i, rot.w, a.w * rot.i)));
+    r.j = __builtin_fmaf(a.k, rot.i, __builtin_fmaf(a.j, rot.w, __builtin_fmaf(-a.i, rot.k, a.w * rot.j)));
+    r.k = __builtin_fmaf(a.k, rot.w, __builtin_fmaf(-a.j, rot.i, __builtin_fmaf(a.i, rot.j, a.w * rot.k)));
+    return r;
 }
 
 constexpr int kIters = 30;                      // ceil(15 / ALPHA), lib.rs:132
