@@ -1397,22 +1397,28 @@ __device__ __forceinline__ float quad_sum3(float init, float t, uint32_t n3) {  
     if (n3 > 2) s += t2;
     return s;
 }
-__device__ __forceinline__ Quat almeida_update_quad(const Quat& rotation, const float s[9], float eps, float alpha, int q) {
-    const float a[9] = {s[0], s[1], s[2], s[1], s[3], s[4], s[2], s[4], s[5]};
-    const float b[3] = {s[6], s[7], s[8]};
+// One Gauss-Newton update of a quad's hypothesis (lib.rs:181-195) on a factorisation made once per hypothesis (A = J^T J of the three
+// samples does not change over the 30 steps), with almeida_update_wave_lu's shortened chain: reciprocal-multiply back substitution, one product for scale and half angle, the
+// polynomial sincos of a step-sized angle, fused quaternion products (~250 instead of ~400 dependent instructions per step).
+__device__ __forceinline__ Quat almeida_update_quad_lu(const Quat& rotation, const Lu3& f, float b0, float b1, float b2, float eps, float alpha, int q) {
+    const float b[3] = {b0, b1, b2};
     float model[3];
-    if (!lu3_solve(a, b, model)) { model[0] = model[1] = model[2] = 0.0f; }       // :181-183
-    model[0] = model[0] * eps * alpha;                                            // :185
-    model[1] = model[1] * eps * alpha;
-    model[2] = model[2] * eps * alpha;
-    const float half = q == 0 ? model[0] * 0.5f : (q == 1 ? model[1] * 0.5f : -model[2] * 0.5f);
+    if (!lu3_apply(f, b, model)) { model[0] = model[1] = model[2] = 0.0f; }       // :181-183
+    const float xsel = q == 0 ? model[0] : (q == 1 ? model[1] : -model[2]);
+    const float half = xsel * (eps * alpha * 0.5f);                               // :185, :189-191 (see almeida_update_wave_lu)
     float sn, cs;
-    sincosf(half, &sn, &cs);
-    const Quat roll = {quad_bcast<0>(cs), 0.0f, quad_bcast<0>(sn), 0.0f};
-    const Quat pitch = {quad_bcast<1>(cs), quad_bcast<1>(sn), 0.0f, 0.0f};
-    const Quat yaw = {quad_bcast<2>(cs), 0.0f, 0.0f, quad_bcast<2>(sn)};
-    const Quat rot = quat_mul(quat_mul(pitch, roll), yaw);                        // :193
-    return quat_mul(rotation, rot);                                               // :195
+    sincos_small(half, sn, cs);
+    const float c0 = quad_bcast<0>(cs), s0 = quad_bcast<0>(sn), c1 = quad_bcast<1>(cs), s1 = quad_bcast<1>(sn), c2 = quad_bcast<2>(cs), s2 = quad_bcast<2>(sn);
+    const Quat pr = {c1 * c0, s1 * c0, c1 * s0, s1 * s0};                         // :193, (pitch * roll) * yaw without the exact-zero terms
+    const Quat rot = {__builtin_fmaf(pr.w, c2, -(pr.k * s2)), __builtin_fmaf(pr.i, c2, pr.j * s2), __builtin_fmaf(pr.j, c2, -(pr.i * s2)),
+                      __builtin_fmaf(pr.w, s2, pr.k * c2)};
+    const Quat& a = rotation;
+    Quat r;                                                                       // :195
+    r.w = __builtin_fmaf(-a.k, rot.k, __builtin_fmaf(-a.j, rot.j, __builtin_fmaf(-a.i, rot.i, a.w * rot.w)));
+    r.i = __builtin_fmaf(-a.k, rot.j, __builtin_fmaf(a.j, rot.k, __builtin_fmaf(a.i, rot.w, a.w * rot.i)));
+    r.j = __builtin_fmaf(a.k, rot.i, __builtin_fmaf(a.j, rot.w, __builtin_fmaf(-a.i, rot.k, a.w * rot.j)));
+    r.k = __builtin_fmaf(a.k, rot.w, __builtin_fmaf(-a.j, rot.i, __builtin_fmaf(a.i, rot.j, a.w * rot.k)));
+    return r;
 }
 
 constexpr int kHypPerWave = 16;
@@ -1444,17 +1450,18 @@ __global__ __launch_bounds__(64) void ransac_hyp_kernel(const float4* __restrict
     a[3] = quad_sum3(0.0f, pp.x * pp.x + pp.y * pp.y, n3);
     a[4] = quad_sum3(0.0f, pp.x * py.x + pp.y * py.y, n3);
     a[5] = quad_sum3(0.0f, py.x * py.x + py.y * py.y, n3);
+    const float am[9] = {a[0], a[1], a[2], a[1], a[3], a[4], a[2], a[4], a[5]};
+    const Lu3 lu = lu3_factor(am);
     Quat rotation = {1.0f, 0.0f, 0.0f, 0.0f};
     for (int s_it = 0; s_it < kIters; ++s_it) {
         const float alpha = (s_it == kIters - 1) ? 1.0f : 0.5f;
         const Mat3 rotm = quat_to_mat3(rotation);
         const float2 d = cam_delta(cam, e.x, e.y, rotm);
         const float rx = e.z - d.x, ry = e.w - d.y;
-        float s[9] = {a[0], a[1], a[2], a[3], a[4], a[5], 0, 0, 0};
-        s[6] = quad_sum3(0.0f, pr.x * rx + pr.y * ry, n3);
-        s[7] = quad_sum3(0.0f, pp.x * rx + pp.y * ry, n3);
-        s[8] = quad_sum3(0.0f, py.x * rx + py.y * ry, n3);
-        rotation = almeida_update_quad(rotation, s, eps, alpha, q);
+        const float b0 = quad_sum3(0.0f, pr.x * rx + pr.y * ry, n3);
+        const float b1 = quad_sum3(0.0f, pp.x * rx + pp.y * ry, n3);
+        const float b2 = quad_sum3(0.0f, py.x * rx + py.y * ry, n3);
+        rotation = almeida_update_quad_lu(rotation, lu, b0, b1, b2, eps, alpha, q);
     }
     // fit = rotation.inverse(); mat = fit.inverse().to_homogeneous() = to_homogeneous(rotation)
     if (live && q == 0) hyp[item * iters + it] = quat_to_mat3(rotation);
