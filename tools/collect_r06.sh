@@ -22,6 +22,12 @@ python tools/lk_decode_time.py > $O/lk_decode_time.txt 2>&1
 python tools/reduced_decoder_time.py > $O/reduced_decoder.txt 2>&1
 python tools/measure_misc.py > $O/misc.json 2>/dev/null
 python tools/almeida_prof.py 2>&1 | grep "n=2073600" > $O/almeida_prof_2m.txt
+# the Almeida solver after the round's last changes: packed record pairs, one-XCD small clusters, short update chain, RANSAC hypotheses
+python tools/almeida_dense_time.py > $O/almeida_dense_time.txt 2>&1
+python tools/almeida_one_xcd_ab.py 2>&1 | grep -v "per workgroup" > $O/almeida_one_xcd_ab.txt
+python tools/almeida_threshold_ab.py > $O/almeida_threshold_ab.txt 2>&1
+python tools/almeida_cu_mask_probe.py > $O/almeida_cu_mask_probe.txt 2>&1
+python tools/ransac_time.py > $O/ransac_time.txt 2>&1
 # hip_flow: time, per-dispatch sequence, kernel stats
 python tools/farneback_time.py 30 > $O/farneback_time.json 2>/dev/null
 (cd /tmp && export TMPDIR=/tmp && rm -rf $O/fb_trace && rocprofv3 --kernel-trace --stats --output-format csv -d $O/fb_trace -o k -- python $R/tools/farneback_time.py 6 > /dev/null 2>&1)
