@@ -574,6 +574,7 @@ __global__ __launch_bounds__(1024) void almeida_lsq_wg_kernel(const float4* __re
                                                               uint32_t min_n, Camera cam, float4* __restrict__ out_quat) {
     constexpr bool P_LDS = EPT >= 8;
     __shared__ float red[16][9];
+    __shared__ float red4[3][64];                       // the steps' row sums (block_sum3_rows)
     __shared__ Quat rot_sh[2];
     __shared__ float4 plds[P_LDS ? EPT * 1024 : 1];     // (roll.x, roll.y, pitch.x, pitch.y) per entry
     const size_t item = blockIdx.x;
@@ -644,13 +645,10 @@ __global__ __launch_bounds__(1024) void almeida_lsq_wg_kernel(const float4* __re
             s[7] += p.x * rx + p.y * ry;
             s[8] += py[t].x * rx + py[t].y * ry;
         }
-        block_sum<6, 9>(s, red);
+        block_sum3_rows<0>(s[6], s[7], s[8], red4);               // (uniform in wave 0 afterwards)
         if (threadIdx.x < 64) {                                    // wave 0, all lanes: see almeida_update_wave_lu
             const Lu3 lu = lu_sh;                                  // (written by this very wave before the loop)
-            const Quat q = almeida_update_wave_lu(rotation, lu,
-                                                  __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(s[6]))),
-                                                  __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(s[7]))),
-                                                  __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(s[8]))), eps, alpha);
+            const Quat q = almeida_update_wave_lu(rotation, lu, s[6], s[7], s[8], eps, alpha);
             if (threadIdx.x == 0) rot_sh[it & 1] = q;
         }
         __syncthreads();
