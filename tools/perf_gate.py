@@ -12,7 +12,8 @@ Checks (each prints PASS / FAIL with both numbers; exit code 1 on any FAIL):
   against the baseline, slower-only, 5 %:  headline Mvectors/s, cfg4 Mvectors/s, LK ms (+-16 px content), Farneback ms, the
       cfg3 chain, Almeida cluster-solver ms (medians of five event-timed groups since round 6), the dense decoders' read-ahead ms per
       frame and the native read-ahead (medians of 5 x 100 frames / 5 processes);
-      8 %: LK ms on +-3 px content -- the one row whose process-to-process and box-to-box spread is as wide as a 5 % window: the round-5
+      8 %: the native read-ahead (two modes 4 % apart, by the DMA engine the runtime picks; the baseline is the fast one) and
+      LK ms on +-3 px content -- the one row whose process-to-process and box-to-box spread is as wide as a 5 % window: the round-5
       build itself read 0.2072-0.2214 ms over twelve processes on four boxes (6.9 %), the unchanged kernel 0.2172 / 0.2212 / 0.2287 / 0.2301 on the
       fifth box of round 6 (profiles/r06/perf_gate_test_run.txt: the median of three failed 5 % by 1.7 %); 8 % above the round-5 median is 4.5 %
       above the slowest round-5 sample;
@@ -66,7 +67,10 @@ BASELINE_CHECKS = [
     # touched by the neighbours, is what is gated; the median is in the line beside it)
     ("cfg5 p50 ms (LSQ), best of 3 processes", ("cfg5_stream.process_level.lsq.p50_min", "cfg5_stream.latency_ms.p50"), False, 0.15),
     ("cfg5 p50 ms (RANSAC), best of 3 processes", ("cfg5_stream.process_level.ransac.p50_min", "cfg5_stream.ransac.latency_ms.p50"), False, 0.15),
-    ("native read-ahead ms/frame", "end_to_end.read_ahead_native_host.ms_per_frame", False, None),
+    # (the lone frame's upload takes whichever DMA engine the runtime binds the stream to at its first copy -- profiles/r05/batched_bimodal.txt --:
+    # the medians of five processes read 0.0525 / 0.0525 / 0.0544 / 0.0544 / 0.0547 ms in five collections of rounds 5-6 at one PCIe ceiling
+    # (217-219 Mvectors/s); the baseline is the fast mode, the slow mode sits 4 % above it, so this row's window is 8 %)
+    ("native read-ahead ms/frame", "end_to_end.read_ahead_native_host.ms_per_frame", False, 0.08),
 ]
 
 
