@@ -34,6 +34,7 @@ struct ofps_hip_ctx {
         int almeida_one_xcd = 1;         // OFPS_HIP_ALMEIDA_ONE_XCD: 0 never, 1 small clusters run on one XCD and exchange through its L2 (almeida.hip)
         int almeida_prof = 0;            // OFPS_HIP_ALMEIDA_PROF
         int lk_prof = 0;                 // OFPS_HIP_LK_PROF
+        int fb_prepare_ahead = 1;        // OFPS_HIP_FB_PREPARE_AHEAD: a hip_flow stream's new frame is expanded on the upload's stream when it is pushed (0: inside the pair's flow, round 5's order)
         int lk_serial = 0;               // OFPS_HIP_LK_SERIAL: one launch per pyramid level instead of one for the pyramid
         int multi_rccl = 0;              // OFPS_HIP_MULTI_RCCL: ofps_hip_multi_init fans the shared key frame out by ncclBroadcast (multi.hip)
         // fault injectors: only builds with -DOFPS_HIP_TEST_HOOKS (libofps_hip_testhooks.so) can set them, and only

@@ -81,6 +81,8 @@ int apply_option(ofps_hip_ctx* ctx, const char* name, const char* value, bool fr
         o.almeida_prof = unset ? 0 : (iv != 0);
     } else if (!strcmp(name, "OFPS_HIP_LK_PROF")) {
         o.lk_prof = unset ? 0 : (iv != 0);
+    } else if (!strcmp(name, "OFPS_HIP_FB_PREPARE_AHEAD")) {
+        o.fb_prepare_ahead = unset ? dflt.fb_prepare_ahead : (iv != 0);
     } else if (!strcmp(name, "OFPS_HIP_LK_SERIAL")) {
         o.lk_serial = unset ? 0 : (iv != 0);
     } else if (!strcmp(name, "OFPS_HIP_MULTI_RCCL")) {
@@ -105,7 +107,7 @@ int apply_option(ofps_hip_ctx* ctx, const char* name, const char* value, bool fr
 
 static const char* const kOptionNames[] = {
     "OFPS_HIP_SAD_KERNEL", "OFPS_HIP_DENSIFY_NO_SMALL", "OFPS_HIP_ALMEIDA_PATH", "OFPS_HIP_ALMEIDA_EPT", "OFPS_HIP_ALMEIDA_BLOCK",
-    "OFPS_HIP_ALMEIDA_HIER", "OFPS_HIP_ALMEIDA_FAST", "OFPS_HIP_ALMEIDA_ONE_XCD", "OFPS_HIP_ALMEIDA_PROF", "OFPS_HIP_LK_PROF", "OFPS_HIP_LK_SERIAL", "OFPS_HIP_MULTI_RCCL"};
+    "OFPS_HIP_ALMEIDA_HIER", "OFPS_HIP_ALMEIDA_FAST", "OFPS_HIP_ALMEIDA_ONE_XCD", "OFPS_HIP_ALMEIDA_PROF", "OFPS_HIP_LK_PROF", "OFPS_HIP_LK_SERIAL", "OFPS_HIP_FB_PREPARE_AHEAD", "OFPS_HIP_MULTI_RCCL"};
 
 }  // namespace ofps
 

@@ -2175,7 +2175,7 @@ int ofps_hip_lk_push_frame_async(ofps_hip_ctx* ctx, const uint8_t* frame, int W,
     // hip_flow: the new frame's pyramid + polynomial expansion depend on that frame only, like the mask: made here, behind the upload on the
     // upload's stream -- with another ticket in flight beside that ticket's flow, whose coarse layers (a chain of dependent round trips) leave
     // most of the device idle (farneback.hip: farneback_prepare_device; the pair's flow below finds the planes by the frame's id)
-    if (g.farneback) {
+    if (g.farneback && ctx->opt.fb_prepare_ahead) {
         rc = ofps::farneback_prepare_device(ctx, d_frames + (size_t)slot * px, g.fw, g.fh, g.fw, levels, 2 * radius + 1, 7, 1.5, ctx->lk_slot_id[slot], up);
         if (rc != OFPS_HIP_OK) return rc;
     }
