@@ -1473,8 +1473,10 @@ __device__ __forceinline__ bool ransac_is_inlier(const Camera& cam, float fx, fl
     return vx * vx + vy * vy <= thr2;                                         // :236
 }
 
-// one workgroup per (hypothesis, item): inlier count over the drawn samples
-__global__ __launch_bounds__(256) void ransac_count_kernel(const float4* __restrict__ entries, uint32_t n, uint32_t ns,
+// one workgroup per (hypothesis, item): inlier count over the drawn samples.  kCountThreads threads: with the reference's 1,000 samples one
+// inlier test per thread (a chain of ~300 dependent instructions: sampler, gather, delta, two atan, two cos) instead of four in a row
+constexpr int kCountThreads = 1024;
+__global__ __launch_bounds__(kCountThreads) void ransac_count_kernel(const float4* __restrict__ entries, uint32_t n, uint32_t ns,
                                                            uint32_t iters, uint64_t seed, Camera cam, float fx, float fy,
                                                            float thr2, const Mat3* __restrict__ hyp,
                                                            uint32_t* __restrict__ counts) {
@@ -1486,7 +1488,7 @@ __global__ __launch_bounds__(256) void ransac_count_kernel(const float4* __restr
     const Mat3 mat = hyp[item * iters + it];
     const SampleKey sk = sample_key(seed + item, it, 1, n);
     uint32_t c = 0;
-    for (uint32_t j = threadIdx.x; j < ns; j += 256) {
+    for (uint32_t j = threadIdx.x; j < ns; j += kCountThreads) {
         const float4 e = entries[item * n + sample_index(sk, j, n)];
         c += ransac_is_inlier(cam, fx, fy, mat, e, thr2) ? 1u : 0u;
     }
@@ -1802,7 +1804,7 @@ int almeida_device(ofps_hip_ctx* ctx, const float4* d_entries, size_t n, int bat
     } else {
         hipLaunchKernelGGL(ransac_hyp_kernel, dim3((iters + kHypPerWave - 1) / kHypPerWave, batch), dim3(64), 0, s, d_entries, (uint32_t)n, iters,
                            seed, cam, hyp);
-        hipLaunchKernelGGL(ransac_count_kernel, dim3(iters, batch), dim3(256), 0, s, d_entries, (uint32_t)n, ns, iters, seed,
+        hipLaunchKernelGGL(ransac_count_kernel, dim3(iters, batch), dim3(kCountThreads), 0, s, d_entries, (uint32_t)n, ns, iters, seed,
                            cam, fx, fy, thr2, hyp, counts);
         hipLaunchKernelGGL(ransac_select_kernel, dim3(batch), dim3(1024), 0, s, d_entries, (uint32_t)n, ns, iters, seed, cam,
                            fx, fy, thr2, hyp, counts, sel, (uint32_t*)nullptr, sel_n);
