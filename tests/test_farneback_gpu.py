@@ -256,3 +256,36 @@ def test_hip_flow_stream_with_the_previous_flow_as_initial_flow(ctx):
     with pytest.raises(Exception):
         ctx.lk_push_frame(fr[0], 3, 4, 3, contrast_mask=True, use_previous=True)
     ctx.lk_reset()
+
+
+@pytest.mark.parametrize("ahead", ["0", "1"])
+def test_hip_flow_read_ahead_records_do_not_depend_on_where_the_new_frame_is_expanded(ctx, ahead):
+    """OFPS_HIP_FB_PREPARE_AHEAD: a stream's new frame goes through the pyramid + expansion on the upload's stream when it is pushed (1, the
+    default) or inside the pair's flow on the compute stream (0, round 5's order) -- an A/B switch, not a result switch: the oracle's chained
+    records either way, and every frame after the first pair reuses the previous frame's expansion."""
+    fr = synth.luma_sequence(6, 416, 240, max_step=3, seed=9)
+    kw = dict(contrast_mask=True, farneback=True, use_previous=True)
+    flow, want = None, []
+    for a, b in zip(fr[:-1], fr[1:]):
+        flow = oracle.farneback_flow(a, b, init=flow)
+        want.append(oracle.densify_to_entries(oracle.masked_flow_to_entries(flow, oracle.contrast_mask(b)), 150, 86))
+    ctx.set_option("OFPS_HIP_FB_PREPARE_AHEAD", ahead)
+    try:
+        ctx.lk_reset()
+        pins = [ctx.pinned_frame(240, 416) for _ in range(6)]
+        for k in range(6):
+            np.copyto(pins[k], fr[k])
+        h0 = ctx.flow_cache_hits()
+        t = [ctx.lk_push_frame_async(pins[0], 5, 6, 3, **kw), ctx.lk_push_frame_async(pins[1], 5, 6, 3, **kw)]
+        got = []
+        for k in range(2, 6):
+            got.append(ctx.lk_frame_wait(t[k - 2]))
+            t.append(ctx.lk_push_frame_async(pins[k], 5, 6, 3, **kw))
+        got += [ctx.lk_frame_wait(t[4]), ctx.lk_frame_wait(t[5])]
+        assert got[0] is None
+        for k in range(1, 6):
+            np.testing.assert_array_equal(got[k][0].view(np.uint32), want[k - 1].view(np.uint32))
+        assert ctx.flow_cache_hits() - h0 >= 4
+    finally:
+        ctx.set_option("OFPS_HIP_FB_PREPARE_AHEAD", None)
+        ctx.lk_reset()
