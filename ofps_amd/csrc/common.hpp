@@ -83,8 +83,9 @@ struct ofps_hip_ctx {
         uint64_t gen = 0;
     } fb_cache;
     hipEvent_t fb_prep_done = nullptr;   // the last pyramid + expansion of this context (its T / I temporaries are shared; prepares may run on two streams)
-    bool fb_prep_recorded = false;
+    bool fb_prep_recorded = false;       // a prepare has been enqueued (on fb_prep_stream) since the context was made
     hipStream_t fb_prep_stream = nullptr;
+    hipStream_t fb_prep_synced = nullptr; // a stream that has been ordered behind the latest prepare by its caller (the stream forms' `uploaded` event)
     uint64_t fb_cache_hits = 0;          // (tests: how many calls skipped the first frame's pyramid + expansion)
     struct FbPrevFlow { bool valid = false; int W = 0, H = 0; uint64_t id = 0, gen = 0; } fb_prev_flow;     // S_FB_FLOW holds the flow of the pair whose second frame has this id
 
@@ -208,6 +209,7 @@ int detect_device(ofps_hip_ctx* ctx, const float4* d_entries, size_t n, int batc
 int farneback_flow_device(ofps_hip_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_cur, int W, int H, int stride, int levels, int winsize,
                           int iters, int poly_n, double poly_sigma, const float2* d_init, float2* d_flow, float4* d_entries,
                           uint64_t prev_id = 0, uint64_t cur_id = 0);     // ids != 0: frames of a stream (ofps_hip_ctx::fb_cache)
+void farneback_mark_ordered(ofps_hip_ctx* ctx, hipStream_t s);
 int farneback_prepare_device(ofps_hip_ctx* ctx, const uint8_t* d_img, int W, int H, int stride, int levels, int winsize, int poly_n, double poly_sigma,
                              uint64_t id, hipStream_t st);          // a stream frame's pyramid + expansion ahead of its pair's flow, on stream st
 int farneback_check_params(ofps_hip_ctx* ctx, int W, int H, int levels, int winsize, int poly_n);       // what farneback_flow_device would refuse, without running it

@@ -815,12 +815,24 @@ int fb_plan(ofps_hip_ctx* ctx, int W, int H, int levels, int winsize, int poly_n
 }
 
 // pyramid + polynomial expansion of one or two frames into R slots, on stream st.  The T / I planes are the pyramid's temporaries and
-// shared by every prepare of the context: a prepare waits for the previous one (which may have run on another stream) and leaves its event.
+// shared by every prepare of the context: a prepare on ANOTHER stream than the previous one waits for it -- through an event recorded then,
+// on the previous prepare's stream (a record covers everything enqueued before it); prepares that follow each other on one stream, the
+// steady state of both the read-ahead and the synchronous forms, cost no event at all.
+static int fb_order_behind_last_prepare(ofps_hip_ctx* ctx, hipStream_t st) {
+    if (!ctx->fb_prep_recorded || ctx->fb_prep_stream == st || ctx->fb_prep_synced == st) return OFPS_HIP_OK;
+    if (!ctx->fb_prep_done) OFPS_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->fb_prep_done, hipEventDisableTiming));
+    OFPS_HIP_TRY(ctx, hipEventRecord(ctx->fb_prep_done, ctx->fb_prep_stream));
+    OFPS_HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->fb_prep_done, 0));
+    ctx->fb_prep_synced = st;
+    return OFPS_HIP_OK;
+}
 int fb_prepare(ofps_hip_ctx* ctx, const FbPlan& pl, const uint8_t* const* imgs, const int* slots, int n_img, int stride, hipStream_t st) {
     const FbPyr& Y = pl.Y;
     const int K = pl.K, W = pl.W, H = pl.H;
-    if (!ctx->fb_prep_done) OFPS_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->fb_prep_done, hipEventDisableTiming));
-    if (ctx->fb_prep_recorded && ctx->fb_prep_stream != st) OFPS_HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->fb_prep_done, 0));
+    {
+        const int rc_order = fb_order_behind_last_prepare(ctx, st);
+        if (rc_order != OFPS_HIP_OK) return rc_order;
+    }
     const uint8_t* i0 = imgs[0];
     const uint8_t* i1 = imgs[n_img - 1];
     // ---- pyramid above layer 0: two launches
@@ -863,8 +875,7 @@ int fb_prepare(ofps_hip_ctx* ctx, const FbPlan& pl, const uint8_t* const* imgs, 
         else hipLaunchKernelGGL((fb_polyexp_kernel<0>), dim3(blk), dim3(256), lds, st, E, pl.P, t_c, t_s);
     }
     OFPS_HIP_TRY(ctx, hipGetLastError());
-    OFPS_HIP_TRY(ctx, hipEventRecord(ctx->fb_prep_done, st));
-    ctx->fb_prep_recorded = true; ctx->fb_prep_stream = st;
+    ctx->fb_prep_recorded = true; ctx->fb_prep_stream = st; ctx->fb_prep_synced = nullptr;
     return OFPS_HIP_OK;
 }
 
@@ -905,6 +916,10 @@ int farneback_prepare_device(ofps_hip_ctx* ctx, const uint8_t* d_img, int W, int
     return OFPS_HIP_OK;
 }
 
+// the caller has made `s` wait for everything enqueued so far on the stream of the latest prepare (the stream forms' `uploaded` event):
+// the flow on `s` needs no event of its own
+void farneback_mark_ordered(ofps_hip_ctx* ctx, hipStream_t s) { ctx->fb_prep_synced = s; }
+
 int farneback_flow_device(ofps_hip_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_cur, int W, int H, int stride, int levels, int winsize,
                           int iters, int poly_n, double poly_sigma, const float2* d_init, float2* d_flow, float4* d_entries,
                           uint64_t prev_id, uint64_t cur_id) {
@@ -938,8 +953,11 @@ int farneback_flow_device(ofps_hip_ctx* ctx, const uint8_t* d_prev, const uint8_
         if (n) {
             rc = fb_prepare(ctx, pl, imgs, slots, n, stride, s);
             if (rc != OFPS_HIP_OK) return rc;
-        } else if (ctx->fb_prep_recorded && ctx->fb_prep_stream != s) {
-            OFPS_HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->fb_prep_done, 0));      // (the stream forms order the flow behind the upload's stream themselves; cheap and safe here)
+        } else {
+            // both frames' planes are there: the flow must come after the prepare that made the newer ones.  The stream forms have ordered
+            // ctx->stream behind the upload's stream already (ofps::farneback_mark_ordered); anybody else gets the event
+            rc = fb_order_behind_last_prepare(ctx, s);
+            if (rc != OFPS_HIP_OK) return rc;
         }
     }
     // ---- layers, coarsest first

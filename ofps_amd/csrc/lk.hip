@@ -2182,6 +2182,7 @@ int ofps_hip_lk_push_frame_async(ofps_hip_ctx* ctx, const uint8_t* frame, int W,
     if (overlap) {
         OFPS_HIP_TRY(ctx, hipEventRecord(t.uploaded, up));
         OFPS_HIP_TRY(ctx, hipStreamWaitEvent(s, t.uploaded, 0));       // everything of this ticket on the compute stream comes after the upload
+        if (g.farneback) ofps::farneback_mark_ordered(ctx, s);         // ... the new frame's pyramid + expansion included
     }
     // the stream position and the ticket change only once everything is enqueued: a failure below leaves both as they were (the
     // frame's slot is simply uploaded again by the next push) -- ADVICE r4
