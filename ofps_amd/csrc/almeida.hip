@@ -1564,12 +1564,29 @@ __global__ __launch_bounds__(1024) void ransac_select_kernel(const float4* __res
 // Persistent (spin-waiting) launches of different contexts must not interleave on one device: two clusters that each
 // hold part of the CUs would wait for each other's missing workgroups.  Within a process they are chained on the GPU
 // through one event per device (no host blocking); across processes the in-kernel timeout is the safety net.
+// A device with ONE live context needs none of this -- its launches follow each other on its stream, and a stream change drains the old
+// stream first (switch_stream) -- and pays nothing: no event is recorded behind its launches (the record is a barrier packet between the
+// estimator's kernel and whatever follows it on the stream: ~4 us of every estimate).  A second context on the device switches the gate on:
+// its ofps_hip_init drains the device under the gate's lock, so a launch made while the count read one is over before the count reads two.
 struct ClusterGate {
     std::mutex m;
     hipEvent_t ev[64] = {};
     hipStream_t last[64] = {};      // the stream of the device's latest cluster launch: stream order already chains launches on it
+    int live[64] = {};              // contexts alive on the device
 };
 static ClusterGate g_cluster_gate;
+
+void cluster_gate_context_created(int device) {
+    std::lock_guard<std::mutex> lk(g_cluster_gate.m);
+    if (++g_cluster_gate.live[device & 63] == 2) {
+        (void)hipDeviceSynchronize();                       // (the caller has made `device` current) whatever the lone context launched ungated is over
+        g_cluster_gate.last[device & 63] = nullptr;
+    }
+}
+void cluster_gate_context_destroyed(int device) {
+    std::lock_guard<std::mutex> lk(g_cluster_gate.m);
+    if (g_cluster_gate.live[device & 63] > 0) --g_cluster_gate.live[device & 63];
+}
 
 template <bool FAST, int EPT, int BLOCK = 1024>
 static void launch_cluster(ofps_hip_ctx* ctx, hipStream_t s, int nblk, int items, const float4* d_entries, size_t n, const Camera& cam,
@@ -1663,11 +1680,14 @@ static int lsq_cluster(ofps_hip_ctx* ctx, const float4* d_entries, size_t n, int
         const float4* ent = d_entries + (size_t)b0 * n;
         float4* q = d_quat + b0;
         std::lock_guard<std::mutex> lk(g_cluster_gate.m);
+        const bool gated = g_cluster_gate.live[ctx->device & 63] > 1;            // several contexts on this device: chain their launches
         hipEvent_t& ev = g_cluster_gate.ev[ctx->device & 63];
         hipStream_t& last = g_cluster_gate.last[ctx->device & 63];
-        if (!ev) OFPS_HIP_TRY(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-        else if (last != s) OFPS_HIP_TRY(ctx, hipStreamWaitEvent(s, ev, 0));      // (a barrier packet costs ~4 us in front of the kernel)
-        last = s;
+        if (gated) {
+            if (!ev) OFPS_HIP_TRY(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            else if (last != s) OFPS_HIP_TRY(ctx, hipStreamWaitEvent(s, ev, 0));  // (a barrier packet costs ~4 us in front of the kernel)
+            last = s;
+        }
         if (block == 256 && ept >= 4) launch_cluster<false, 4, 256>(ctx, s, nblk, items, ent, n, cam, gran, tag_base, q, prof, recoveries);
         else if (block == 256 && ept == 2) launch_cluster<false, 2, 256>(ctx, s, nblk, items, ent, n, cam, gran, tag_base, q, prof, recoveries);
         else if (block == 256) launch_cluster<false, 1, 256>(ctx, s, nblk, items, ent, n, cam, gran, tag_base, q, prof, recoveries);
@@ -1679,7 +1699,7 @@ static int lsq_cluster(ofps_hip_ctx* ctx, const float4* d_entries, size_t n, int
         else if (ept == 2) launch_cluster<false, 2>(ctx, s, nblk, items, ent, n, cam, gran, tag_base, q, prof, recoveries);
         else launch_cluster<false, 1>(ctx, s, nblk, items, ent, n, cam, gran, tag_base, q, prof, recoveries);
         OFPS_HIP_TRY(ctx, hipGetLastError());
-        OFPS_HIP_TRY(ctx, hipEventRecord(ev, s));
+        if (gated) OFPS_HIP_TRY(ctx, hipEventRecord(ev, s));
     }
     if (prof) {                                              // diagnostics: phase table of the last launch to stderr
         const size_t cnt = (size_t)nblk * kIters * kProfSlots;

@@ -213,6 +213,8 @@ void farneback_mark_ordered(ofps_hip_ctx* ctx, hipStream_t s);
 int farneback_prepare_device(ofps_hip_ctx* ctx, const uint8_t* d_img, int W, int H, int stride, int levels, int winsize, int poly_n, double poly_sigma,
                              uint64_t id, hipStream_t st);          // a stream frame's pyramid + expansion ahead of its pair's flow, on stream st
 int farneback_check_params(ofps_hip_ctx* ctx, int W, int H, int levels, int winsize, int poly_n);       // what farneback_flow_device would refuse, without running it
+void cluster_gate_context_created(int device);      // almeida.hip: the cluster launches' per-device gate counts the contexts alive on a device
+void cluster_gate_context_destroyed(int device);
 int almeida_device(ofps_hip_ctx* ctx, const float4* d_entries, size_t n, int batch, float aspect, float fov_y_deg,
                    int use_ransac, size_t num_iters, float inlier_deg, size_t num_samples, uint64_t seed, float4* d_quat);
 

@@ -163,6 +163,7 @@ int ofps_hip_init(int device, ofps_hip_ctx** out) {
                 ctx->err[0] = '\0';
             }
         }
+    ofps::cluster_gate_context_created(device);
     *out = ctx;
     return OFPS_HIP_OK;
 }
@@ -229,6 +230,7 @@ void ofps_hip_destroy(ofps_hip_ctx* ctx) {
     if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
     if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    ofps::cluster_gate_context_destroyed(ctx->device);
     delete ctx;
 }
 

@@ -560,3 +560,42 @@ def test_hip_ransac_at_the_image_centre_is_the_identity(ctx):
     for sub in (slice(None), [2, 5, 6, 0]):
         q, _ = ctx.almeida(e[sub], 16 / 9, 22.275, use_ransac=True, num_iters=5, inlier_deg=0.05, num_samples=1000, seed=3)
         np.testing.assert_array_equal(q, np.array([1, 0, 0, 0], np.float32))
+
+
+def test_hip_almeida_cluster_launches_of_two_contexts_are_chained_on_the_device(ctx):
+    """A device with one live context launches its clusters ungated (no event behind the estimator's kernel); a second context switches the
+    per-device gate on -- its ofps_hip_init drains the device, from then on every cluster launch waits for the other context's last one.
+    Device-pointer calls of two contexts on two streams, never synchronised in between: every estimate is the oracle's, nobody had to finish
+    alone (two clusters that each held part of the CUs would time out waiting for each other's workgroups), and the first context goes on
+    when the second is gone."""
+    import torch
+    from ofps_amd.runtime import HipContext
+    shapes = [(120, 67), (480, 270), (960, 540)]
+    cam = oracle.camera(16 / 9, 22.275)
+    fields = [synth.rotation_field(w, h, euler_deg=(0.4 + 0.1 * k, 0.2, -0.1 * k), seed=synth.SEED0 + 90 + k) for k, (w, h) in enumerate(shapes)]
+    want = [oracle.solve_ypr_given(f, cam) for f in fields]
+    d_fields = [torch.from_numpy(f).cuda() for f in fields]
+    s_a, s_b = torch.cuda.Stream(), torch.cuda.Stream()
+    rec0 = ctx.almeida_recoveries()
+    ctx.set_stream(s_a.cuda_stream)
+    other = HipContext(0)
+    try:
+        other.set_stream(s_b.cuda_stream)
+        outs = []
+        for rep in range(6):
+            for k, (w, h) in enumerate(shapes):
+                qa = torch.empty((1, 4), dtype=torch.float32, device="cuda"); qb = torch.empty((1, 4), dtype=torch.float32, device="cuda")
+                ctx.almeida_dev(d_fields[k].data_ptr(), w * h, 1, 16 / 9, 22.275, False, 0, 0.05, 0, 0, qa.data_ptr())
+                other.almeida_dev(d_fields[(k + 1) % 3].data_ptr(), shapes[(k + 1) % 3][0] * shapes[(k + 1) % 3][1], 1, 16 / 9, 22.275, False, 0, 0.05, 0, 0, qb.data_ptr())
+                outs.append((k, qa, (k + 1) % 3, qb))
+        torch.cuda.synchronize()
+        for k, qa, kb, qb in outs:
+            np.testing.assert_allclose(qa.cpu().numpy().ravel(), want[k], atol=2e-6, rtol=0)
+            np.testing.assert_allclose(qb.cpu().numpy().ravel(), want[kb], atol=2e-6, rtol=0)
+        assert other.almeida_recoveries() == 0
+    finally:
+        other.close()
+        ctx.use_own_stream()
+    assert ctx.almeida_recoveries() == rec0
+    q, _ = ctx.almeida(fields[0], 16 / 9, 22.275, use_ransac=False)
+    np.testing.assert_allclose(q, want[0], atol=2e-6, rtol=0)
