@@ -142,7 +142,7 @@ def test_perf_gate_is_one_sided_and_tolerant():
     line["value"] = base["value"] * 0.96                       # 4 % slower: inside the tolerance
     line["cfg3_chain"]["almeida_ms"] = base["cfg3_chain"]["almeida_ms"] * 1.06      # 6 % slower at 5 %: fails
     line["cfg4"]["Mvectors_per_s"] = base["cfg4"]["Mvectors_per_s"] * 1.30    # faster never fails
-    line["cfg3_chain"]["per_content"]["pm3"]["lk_ms"] = base["cfg3_chain"]["per_content"]["pm3"]["lk_ms"] * 1.09   # 9 % slower: fails (this row: 8 %, its own spread over processes and boxes is 7 %)
+    line["cfg3_chain"]["per_content"]["pm3"]["lk_ms"] = base["cfg3_chain"]["per_content"]["pm3"]["lk_ms"] * 1.12   # 12 % slower: fails (this row: 10 %, its own spread over processes and boxes is 7-9 %)
     line["cfg3_chain"]["per_content"]["pm16"]["lk_ms"] = base["cfg3_chain"]["per_content"]["pm16"]["lk_ms"] * 1.04  # 4 %: passes
     # cfg5: the new line carries three processes' p50s (the best one is gated), the round-5 baseline only its single p50; 15 %
     line["cfg5_stream"]["process_level"] = {"lsq": {"p50_min": base["cfg5_stream"]["latency_ms"]["p50"] * 1.14, "p50_median_of_processes": 9.9},
@@ -157,7 +157,7 @@ def test_perf_gate_is_one_sided_and_tolerant():
 
 
 def test_perf_gate_uses_the_baseline_builds_sample_median_for_noisy_rows():
-    """round 6: the round-5 BUILD re-measured twelve times with the gate's protocol; a cfg3 row is gated (5 %; the +-3 px LK row 8 %) against the median of those
+    """round 6: the round-5 BUILD re-measured twelve times with the gate's protocol; a cfg3 row is gated (5 %; the +-3 px LK row 10 %) against the median of those
     samples, not against the single (low) draw the committed line holds -- and nothing of round 6 is in the sample file"""
     import copy
     import json
@@ -167,11 +167,11 @@ def test_perf_gate_uses_the_baseline_builds_sample_median_for_noisy_rows():
     row = samples["rows"]["cfg3_chain.per_content.pm3.lk_ms"]
     assert len(row["samples"]) == 12 and row["min"] <= row["committed_r05_line"] <= row["max"] and row["committed_r05_line"] < row["median"]
     line = copy.deepcopy(base)
-    line["cfg3_chain"]["per_content"]["pm3"]["lk_ms"] = round(row["median"] * 1.07, 4)       # 7 % over the build's median (9 % over the committed draw); the row's window is 8 %
+    line["cfg3_chain"]["per_content"]["pm3"]["lk_ms"] = round(row["median"] * 1.09, 4)       # 9 % over the build's median (11 % over the committed draw); the row's window is 10 %
     rows = {name: ok for name, ok, _ in g.gate(line, base, 0.05, samples)}
     assert rows["LK flow ms, +-3 px content"] is True
     assert {name: ok for name, ok, _ in g.gate(line, base, 0.05)}["LK flow ms, +-3 px content"] is False       # without the samples: the single draw
-    line["cfg3_chain"]["per_content"]["pm3"]["lk_ms"] = round(row["median"] * 1.09, 4)
+    line["cfg3_chain"]["per_content"]["pm3"]["lk_ms"] = round(row["median"] * 1.12, 4)
     assert {name: ok for name, ok, _ in g.gate(line, base, 0.05, samples)}["LK flow ms, +-3 px content"] is False
 
 

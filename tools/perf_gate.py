@@ -12,11 +12,11 @@ Checks (each prints PASS / FAIL with both numbers; exit code 1 on any FAIL):
   against the baseline, slower-only, 5 %:  headline Mvectors/s, cfg4 Mvectors/s, LK ms (+-16 px content), Farneback ms, the
       cfg3 chain, Almeida cluster-solver ms (medians of five event-timed groups since round 6), the dense decoders' read-ahead ms per
       frame and the native read-ahead (medians of 5 x 100 frames / 5 processes);
-      8 %: the native read-ahead (two modes 4 % apart, by the DMA engine the runtime picks; the baseline is the fast one) and
-      LK ms on +-3 px content -- the one row whose process-to-process and box-to-box spread is as wide as a 5 % window: the round-5
-      build itself read 0.2072-0.2214 ms over twelve processes on four boxes (6.9 %), the unchanged kernel 0.2172 / 0.2212 / 0.2287 / 0.2301 on the
-      fifth box of round 6 (profiles/r06/perf_gate_test_run.txt: the median of three failed 5 % by 1.7 %); 8 % above the round-5 median is 4.5 %
-      above the slowest round-5 sample;
+      8 %: the native read-ahead (two modes 4 % apart, by the DMA engine the runtime picks; the baseline is the fast one);
+      10 %: LK ms on +-3 px content -- the one row whose process-to-process and box-to-box spread is wider than a 5 % window: the round-5
+      build itself read 0.2072-0.2214 ms over twelve processes on four boxes (6.9 %), the unchanged kernel 0.2129-0.2321 in nine bench lines on
+      nine boxes of round 6 (profiles/r06/r06_final_tree_gate_rows.json, perf_gate_test_run.txt: one median of three failed 5 % by 1.7 %, one
+      line read 8.4 % above the round-5 median); every other device-timed row spreads 0.7-1.8 % over the same lines;
       15 %: cfg5 p50, LSQ and RANSAC -- the BEST OF THREE fresh processes' p50s (host + loop-back TCP + PCIe latency on a shared host: the
       median of three moved 0.206-0.252 ms from box to box for one build; the minimum is the estimate the neighbours touch least; a baseline
       line that predates the process-level numbers is compared through its single p50);
@@ -55,7 +55,7 @@ def get(d, path, default=None):
 BASELINE_CHECKS = [
     ("headline Mvectors/s (cfg2)", "value", True, None),
     ("cfg4 Mvectors/s", "cfg4.Mvectors_per_s", True, None),
-    ("LK flow ms, +-3 px content", "cfg3_chain.per_content.pm3.lk_ms", False, 0.08),      # (see the docstring: this row's own spread is 7 %)
+    ("LK flow ms, +-3 px content", "cfg3_chain.per_content.pm3.lk_ms", False, 0.10),      # (see the docstring: this row's own spread is 7-9 %)
     ("LK flow ms, +-16 px content", "cfg3_chain.per_content.pm16.lk_ms", False, None),
     ("Almeida cluster solve ms (2.07 M records)", "cfg3_chain.almeida_ms", False, None),
     ("cfg3 chain ms", "cfg3_chain.chain_ms", False, None),
