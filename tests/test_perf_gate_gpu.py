@@ -1,5 +1,5 @@
 """The performance gate on the GPU box: one full `python bench.py` (N = 1, every leg), checked against the committed line of the
-PREVIOUS round (profiles/r05/bench_n1.json: never a line of the round being gated; slower-only, 5 % on the device-timed medians -- 10 % on the +-3 px LK row, whose own spread over processes and boxes is 7-9 %, 8 % on the native read-ahead, whose two DMA-engine modes are 4 % apart --, 15 % on
+PREVIOUS round (profiles/r05/bench_n1.json: never a line of the round being gated; slower-only, 5 % on the device-timed medians -- 10 % / 8 % on the two LK rows (the LK kernel's time moves from box to box: 9 % / 3.4 % over ten boxes, +-1 % within one), 8 % on the native read-ahead, whose two DMA-engine modes are 4 % apart --, 15 % on
 the best of three processes' cfg5 p50) and against the relations that must hold inside one run (tools/perf_gate.py; VERDICT r4
 item 2, r5 item 6).  The line that was gated is kept under gpurun_out/."""
 import os

@@ -9,10 +9,13 @@ inside one run.
   python tools/perf_gate.py --run                      runs `python bench.py` itself (N = 1, a few minutes)
 
 Checks (each prints PASS / FAIL with both numbers; exit code 1 on any FAIL):
-  against the baseline, slower-only, 5 %:  headline Mvectors/s, cfg4 Mvectors/s, LK ms (+-16 px content), Farneback ms, the
+  against the baseline, slower-only, 5 %:  headline Mvectors/s, cfg4 Mvectors/s, Farneback ms, the
       cfg3 chain, Almeida cluster-solver ms (medians of five event-timed groups since round 6), the dense decoders' read-ahead ms per
       frame and the native read-ahead (medians of 5 x 100 frames / 5 processes);
-      8 %: the native read-ahead (two modes 4 % apart, by the DMA engine the runtime picks; the baseline is the fast one);
+      8 %: the native read-ahead (two modes 4 % apart, by the DMA engine the runtime picks; the baseline is the fast one), and LK ms on +-16 px
+      content: the LDS-bound LK kernel is the one kernel whose time moves from BOX to box (six fresh processes on one box: +-1 %; ten boxes:
+      0.2794-0.2890 ms, and the +-3 px content 0.2129-0.2321 -- tools/lk_variance_probe.py, profiles/r06/lk_variance_probe.txt; the SAD
+      kernel: 0.9 % over the same boxes), and a 5 % window above the round-5 median (0.2923) is 1 % above what a slow box reads;
       10 %: LK ms on +-3 px content -- the one row whose process-to-process and box-to-box spread is wider than a 5 % window: the round-5
       build itself read 0.2072-0.2214 ms over twelve processes on four boxes (6.9 %), the unchanged kernel 0.2129-0.2321 in nine bench lines on
       nine boxes of round 6 (profiles/r06/r06_final_tree_gate_rows.json, perf_gate_test_run.txt: one median of three failed 5 % by 1.7 %, one
@@ -56,7 +59,7 @@ BASELINE_CHECKS = [
     ("headline Mvectors/s (cfg2)", "value", True, None),
     ("cfg4 Mvectors/s", "cfg4.Mvectors_per_s", True, None),
     ("LK flow ms, +-3 px content", "cfg3_chain.per_content.pm3.lk_ms", False, 0.10),      # (see the docstring: this row's own spread is 7-9 %)
-    ("LK flow ms, +-16 px content", "cfg3_chain.per_content.pm16.lk_ms", False, None),
+    ("LK flow ms, +-16 px content", "cfg3_chain.per_content.pm16.lk_ms", False, 0.08),    # (box to box: 0.2794-0.2890 with the kernel unchanged; see the docstring)
     ("Almeida cluster solve ms (2.07 M records)", "cfg3_chain.almeida_ms", False, None),
     ("cfg3 chain ms", "cfg3_chain.chain_ms", False, None),
     ("Farneback (hip_flow) ms per 1080p pair", "cfg3_chain.farneback_ms", False, None),
